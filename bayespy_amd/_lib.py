@@ -1,0 +1,117 @@
+"""
+ctypes binding of ``libvmp_hip.so`` (the C ABI declared in include/vmp_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or does not export
+a declared symbol, importing this module's :func:`load` raises.  ``import torch``
+must precede the ``CDLL`` call so that the HIP runtime already mapped by torch
+(``libamdhip64.so.7``) is the one the library binds to.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libvmp_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'vmp_hip.h')
+
+VMP_OK = 0
+VMP_ERR_INVALID = -1
+VMP_ERR_NOT_POSDEF = -2
+VMP_ERR_HIP = -3
+VMP_ERR_UNSUPPORTED = -4
+VMP_ERR_FLOATING = -5
+VMP_ERR_NOT_POSITIVE = -6
+
+
+class NotPositiveDefiniteError(Exception):
+    """The reference raises a bare ``Exception("Matrix not positive definite")``
+    (bayespy/utils/linalg.py:58-59)."""
+
+
+def raise_for_status(rc, msg=''):
+    """Map a C-ABI status to the exception type the reference raises."""
+    if rc == VMP_OK:
+        return
+    if rc == VMP_ERR_INVALID:
+        raise ValueError(msg or 'invalid argument')
+    if rc == VMP_ERR_NOT_POSDEF:
+        raise NotPositiveDefiniteError(msg or 'Matrix not positive definite')
+    if rc == VMP_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg or 'unsupported by the built HIP kernels')
+    if rc == VMP_ERR_FLOATING:
+        raise FloatingPointError(msg or 'invalid value encountered')
+    if rc == VMP_ERR_NOT_POSITIVE:
+        raise ValueError(msg or 'Natural parameters should be positive')
+    raise RuntimeError(msg or 'HIP runtime error (status %d)' % rc)
+
+
+class PCALayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        'DP', 'KP', 'off_S', 'len_S', 'off_Syy', 'off_tau', 'off_alpha', 'off_W',
+        'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_scal', 'off_L', 'total')]
+
+
+c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
+P = ctypes.POINTER
+
+# name -> (restype, argtypes); must list every symbol of include/vmp_hip.h
+SIGNATURES = {
+    'vmp_ctx_create': (c_i32, [c_i32, c_vp, P(c_vp)]),
+    'vmp_ctx_destroy': (c_i32, [c_vp]),
+    'vmp_ctx_set_stream': (c_i32, [c_vp, c_vp]),
+    'vmp_ctx_sync': (c_i32, [c_vp]),
+    'vmp_ctx_num_cu': (c_i32, [c_vp]),
+    'vmp_last_error': (ctypes.c_char_p, [c_vp]),
+    'vmp_version': (ctypes.c_char_p, []),
+    'vmp_malloc': (c_i32, [c_vp, c_sz, P(c_vp)]),
+    'vmp_free': (c_i32, [c_vp, c_vp]),
+    'vmp_memcpy_h2d': (c_i32, [c_vp, c_vp, c_vp, c_sz]),
+    'vmp_memcpy_d2h': (c_i32, [c_vp, c_vp, c_vp, c_sz]),
+    'vmp_memset_zero': (c_i32, [c_vp, c_vp, c_sz]),
+    'vmp_pca_get_layout': (c_i32, [c_i32, c_i32, P(PCALayout)]),
+    'vmp_pca_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, P(c_sz)]),
+    'vmp_pca_init_state': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_vp]),
+    'vmp_pca_syy': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    'vmp_pca_stats_from_x': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64,
+                                     c_vp, c_vp]),
+    'vmp_pca_update_w': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp]),
+    'vmp_pca_prepare_x': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_vp]),
+    'vmp_pca_pass': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'vmp_pca_update_tau': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_vp]),
+    'vmp_pca_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_vp]),
+    'vmp_pca_lower_bound': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
+                                    c_f64, c_vp]),
+    'vmp_ctx_set_timing': (c_i32, [c_vp, c_i32]),
+    'vmp_pca_last_pass_ms': (c_i32, [c_vp, P(c_f64), P(c_f64)]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """All function names declared in include/vmp_hip.h."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vmp_[a-z0-9_]+)\s*\(', src)))
+
+
+def load():
+    """Load libvmp_hip.so (once) and attach the signatures.  Raises if the
+    library has not been built -- the product path has no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libvmp_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
+            'g.build()"` or `make -C bayespy_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    import torch  # noqa: F401  -- maps libamdhip64.so.7 first (see module docstring)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

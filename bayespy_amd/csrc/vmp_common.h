@@ -1,0 +1,120 @@
+// vmp_common.h -- shared host/device helpers of libvmp_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/vmp_hip.h"
+
+struct vmp_ctx {
+    int device;
+    hipStream_t stream;
+    int num_cu;
+    int timing;
+    hipEvent_t ev[3];
+    char err[512];
+};
+
+#define VMP_SET_ERR(ctx, ...)                                         \
+    do {                                                              \
+        if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+    } while (0)
+
+#define VMP_HIP_CHECK(ctx, expr)                                                   \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            VMP_SET_ERR(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                       \
+            return VMP_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define VMP_REQUIRE(ctx, cond, code, ...)   \
+    do {                                    \
+        if (!(cond)) {                      \
+            VMP_SET_ERR(ctx, __VA_ARGS__);  \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------
+// Special functions (E17-E19 of SURVEY.md 2.2: scipy.special.digamma / gammaln
+// call sites gamma.py:145-147, dirichlet.py:150-158, utils/misc.py:1146-1151).
+// Host+device so the CPU test-suite can check them against SciPy.
+// ---------------------------------------------------------------------------
+
+// psi(x) for x > 0: upward recurrence to x >= 10, then the asymptotic series
+// ln x - 1/(2x) - sum_n B_2n / (2n x^2n)  (truncation error < 1e-17 at x >= 10).
+__host__ __device__ inline double vmp_digamma(double x)
+{
+    if (!(x > 0.0)) {
+        if (x == 0.0) return -INFINITY;
+        // reflection psi(1-x) - psi(x) = pi cot(pi x); not on the hot path
+        double r = 1.0 - x;
+        double s = 0.0;
+        while (r < 10.0) { s -= 1.0 / r; r += 1.0; }
+        double inv = 1.0 / r, inv2 = inv * inv;
+        double ser = inv2 * (1.0 / 12 - inv2 * (1.0 / 120 - inv2 * (1.0 / 252 - inv2 * (1.0 / 240 - inv2 * (1.0 / 132 - inv2 * (691.0 / 32760 - inv2 * (1.0 / 12)))))));
+        double psi1mx = s + log(r) - 0.5 * inv - ser;
+        return psi1mx - M_PI / tan(M_PI * x);
+    }
+    double s = 0.0;
+    while (x < 10.0) { s -= 1.0 / x; x += 1.0; }
+    double inv = 1.0 / x, inv2 = inv * inv;
+    double ser = inv2 * (1.0 / 12 - inv2 * (1.0 / 120 - inv2 * (1.0 / 252 - inv2 * (1.0 / 240 - inv2 * (1.0 / 132 - inv2 * (691.0 / 32760 - inv2 * (1.0 / 12)))))));
+    return s + log(x) - 0.5 * inv - ser;
+}
+
+// ln Gamma(x) for x > 0: downward-recurrence-free Stirling series at x >= 10,
+// product shift below (keeps ~1e-15 relative accuracy; matches scipy.special.gammaln).
+__host__ __device__ inline double vmp_lgamma(double x)
+{
+    if (!(x > 0.0)) return INFINITY;
+    double shift = 0.0;
+    // accumulate log of the product in pieces to avoid overflow
+    double prod = 1.0;
+    while (x < 10.0) {
+        prod *= x;
+        x += 1.0;
+        if (prod > 1e150) { shift += log(prod); prod = 1.0; }
+    }
+    shift += log(prod);
+    double inv = 1.0 / x, inv2 = inv * inv;
+    // sum_n B_2n / (2n (2n-1) x^(2n-1))
+    double ser = inv * (1.0 / 12 - inv2 * (1.0 / 360 - inv2 * (1.0 / 1260 - inv2 * (1.0 / 1680 - inv2 * (1.0 / 1188 - inv2 * (691.0 / 360360 - inv2 * (1.0 / 156)))))));
+    return (x - 0.5) * log(x) - x + 0.91893853320467274178 + ser - shift;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------
+// Wavefront (64 lanes) and workgroup reductions, fixed order => deterministic.
+// ---------------------------------------------------------------------------
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // valid in lane 0
+}
+
+// Sum over a workgroup of NT threads (NT multiple of 64, <= 1024); the result
+// is returned to ALL threads.  `red` is LDS scratch of >= NT/64 doubles.
+template <int NT>
+__device__ inline double block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+#endif

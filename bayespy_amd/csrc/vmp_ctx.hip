@@ -1,0 +1,117 @@
+// vmp_ctx.hip -- context, stream and raw-memory entry points of libvmp_hip.
+#include "vmp_common.h"
+
+#include <new>
+
+static char g_err[512] = "no context";
+
+extern "C" {
+
+const char *vmp_version(void) { return "libvmp_hip 0.1 (gfx950)"; }
+
+int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
+{
+    if (!out) return VMP_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device visible (%s)", hipGetErrorString(e));
+        return VMP_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        snprintf(g_err, sizeof(g_err), "device %d out of range [0,%d)", device, ndev);
+        return VMP_ERR_INVALID;
+    }
+    vmp_ctx *ctx = new (std::nothrow) vmp_ctx();
+    if (!ctx) return VMP_ERR_HIP;
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    ctx->timing = 0;
+    ctx->err[0] = 0;
+    for (int i = 0; i < 3; ++i) ctx->ev[i] = nullptr;
+    VMP_HIP_CHECK(ctx, hipSetDevice(device));
+    int cu = 0;
+    VMP_HIP_CHECK(ctx, hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device));
+    ctx->num_cu = cu > 0 ? cu : 256;
+    *out = ctx;
+    return VMP_OK;
+}
+
+int32_t vmp_ctx_destroy(vmp_ctx *ctx)
+{
+    if (!ctx) return VMP_OK;
+    for (int i = 0; i < 3; ++i)
+        if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+    return VMP_OK;
+}
+
+int32_t vmp_ctx_set_stream(vmp_ctx *ctx, void *stream)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    ctx->stream = (hipStream_t)stream;
+    return VMP_OK;
+}
+
+int32_t vmp_ctx_sync(vmp_ctx *ctx)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VMP_OK;
+}
+
+int32_t vmp_ctx_num_cu(vmp_ctx *ctx) { return ctx ? ctx->num_cu : 0; }
+
+const char *vmp_last_error(vmp_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int32_t vmp_ctx_set_timing(vmp_ctx *ctx, int32_t enabled)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    if (enabled && !ctx->ev[0]) {
+        VMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        for (int i = 0; i < 3; ++i) VMP_HIP_CHECK(ctx, hipEventCreate(&ctx->ev[i]));
+    }
+    ctx->timing = enabled ? 1 : 0;
+    return VMP_OK;
+}
+
+int32_t vmp_malloc(vmp_ctx *ctx, size_t bytes, void **ptr)
+{
+    if (!ctx || !ptr) return VMP_ERR_INVALID;
+    VMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    VMP_HIP_CHECK(ctx, hipMalloc(ptr, bytes ? bytes : 8));
+    return VMP_OK;
+}
+
+int32_t vmp_free(vmp_ctx *ctx, void *ptr)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    if (ptr) VMP_HIP_CHECK(ctx, hipFree(ptr));
+    return VMP_OK;
+}
+
+int32_t vmp_memcpy_h2d(vmp_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VMP_OK;
+}
+
+int32_t vmp_memcpy_d2h(vmp_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VMP_OK;
+}
+
+int32_t vmp_memset_zero(vmp_ctx *ctx, void *dst, size_t bytes)
+{
+    if (!ctx) return VMP_ERR_INVALID;
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    return VMP_OK;
+}
+
+}  // extern "C"

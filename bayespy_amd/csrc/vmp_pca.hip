@@ -1,0 +1,774 @@
+// vmp_pca.hip -- fused probabilistic-PCA / factor-analysis VB block for gfx950.
+//
+// Replaces, for the model block of bayespy/demos/pca.py:22-61 with a scalar
+// observation mask, the NumPy call sites E1-E11, E14, E16, E17 of SURVEY.md 2.2:
+//   dot.py:355,403,581 (SumMultiply moments + messages),
+//   gaussian.py:628-635,649-706,2344-2369 (GaussianARD / WrapToGaussianGamma),
+//   gamma.py:116-148, expfamily.py:400-480 (lower bound), utils/linalg.py:31-223.
+//
+// Data layout in HBM (all fp64):
+//   Y  (D, N) row-major, leading dimension ldy  -- N (the sharded observation
+//       plate) is the contiguous axis, exactly the reference's plates (D, N);
+//   X  (K, N) row-major, leading dimension ldx  -- <x_n>, structure-of-arrays
+//       along the plate so stores are coalesced (host view transposes to the
+//       reference's (1, N, K));
+//   state: one block of doubles, layout = vmp_pca_layout (include/vmp_hip.h).
+//
+// The streaming pass keeps a (DP+KP) x 32-column tile Z = [Y_tile ; X_tile] in
+// LDS (row stride 34 doubles => both MFMA operand access patterns below are
+// bank-conflict free for ds_read_b64) and issues v_mfma_f64_16x16x4_f64 for
+//   role 1:  X_tile = A * Y_tile            (contraction over d)
+//   role 2:  S     += Z_tile * X_tile^T     (contraction over n)
+// with the S accumulators resident in registers for the whole kernel.
+#include "vmp_common.h"
+
+namespace {
+
+constexpr int TN = 32;        // columns (plate elements) per tile
+constexpr int SZ = TN + 2;    // LDS row stride in doubles (== 2 mod 32)
+constexpr int NT = 256;       // threads per workgroup (4 wavefronts)
+constexpr int MAX_KP = 64;
+constexpr int MAX_DP = 256;
+
+inline int pow2_blocks(int x, int unit)
+{
+    int b = (x + unit - 1) / unit;
+    int p = 1;
+    while (p < b) p <<= 1;
+    return p;
+}
+
+inline void fill_layout(int D, int K, vmp_pca_layout *L)
+{
+    const int64_t DP = 32 * pow2_blocks(D, 32);
+    const int64_t KP = 16 * pow2_blocks(K, 16);
+    int64_t o = 0;
+    L->DP = DP;
+    L->KP = KP;
+    L->off_S = o;      L->len_S = (DP + KP) * KP; o += L->len_S;
+    L->off_Syy = o;    o += 8;
+    L->off_tau = o;    o += 8;
+    L->off_alpha = o;  o += 4 * KP;
+    L->off_W = o;      o += (int64_t)D * KP;
+    L->off_CW = o;     o += KP * KP;
+    L->off_Sww = o;    o += KP * KP;
+    L->off_CX = o;     o += KP * KP;
+    L->off_A = o;      o += KP * DP;
+    L->off_scal = o;   o += 8;
+    L->off_L = o;      o += 8;
+    L->total = (o + 7) / 8 * 8;
+}
+
+__device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// The streaming pass.
+//   DB = DP/32 in {1,2,4,8}, KT = KP/16 in {1,2,4}.
+//   COMPUTE_X: true  -> X.update() (x = A y, write X, accumulate S)
+//              false -> statistics of a given X (initialize_from_value)
+// ---------------------------------------------------------------------------
+template <int DB, int KT, bool COMPUTE_X>
+__global__ void __launch_bounds__(NT, (DB >= 8 || DB * KT > 8) ? 1 : 2)
+pca_pass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
+                const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
+                double *__restrict__ P, int64_t ntiles)
+{
+    constexpr int DP = 32 * DB, KP = 16 * KT, ZR = DP + KP;
+    constexpr int YP = DP / 16;          // Y load passes of 16 rows
+    constexpr int XP = KP / 16;          // X load passes (COMPUTE_X == false)
+    constexpr int KS1 = DP / 4;          // role-1 MFMA k-steps
+    constexpr int T1 = KT * (TN / 16);   // role-1 output tiles
+    constexpr int R1 = (T1 + 3) / 4;
+    constexpr int T2 = (2 * DB + KT) * KT;  // role-2 output tiles
+    constexpr int R2 = (T2 + 3) / 4;
+
+    __shared__ double Z[ZR * SZ];
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int l15 = l & 15, l4 = l >> 4;
+    const int lrow = tid >> 4;         // row inside a 16-row load pass
+    const int lcol = (tid & 15) * 2;   // first of this thread's two columns
+    const int it1 = w % KT;            // role-1 row tile (k) of this wave
+    const int jt2 = w % KT;            // role-2 column tile (k) of this wave
+
+    // A operand fragments of role 1: lane holds A[it1*16 + l15][d(q, l4)],
+    // d(q, kk) = 32*(q/8) + (q%8) + 8*kk  (the four d-slices of one MFMA are 8
+    // rows apart so the matching Y reads from LDS hit disjoint banks).
+    double afrag[COMPUTE_X ? KS1 : 1];
+    if (COMPUTE_X) {
+        const double *arow = Apad + (int64_t)(it1 * 16 + l15) * DP;
+#pragma unroll
+        for (int q = 0; q < KS1; ++q) afrag[q] = arow[32 * (q >> 3) + (q & 7) + 8 * l4];
+    }
+
+    v4f64 acc2[R2];
+#pragma unroll
+    for (int m = 0; m < R2; ++m) acc2[m] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    v2f64 yreg[YP];
+
+    auto load_tile = [&](int64_t tile) {
+        const int64_t n = tile * TN + lcol;
+#pragma unroll
+        for (int p = 0; p < YP; ++p) {
+            const int row = p * 16 + lrow;
+            v2f64 v = v2f64{0.0, 0.0};
+            if (row < D) {
+                const double *src = Y + (int64_t)row * ldy + n;
+                if (n + 1 < N) v = *reinterpret_cast<const v2f64 *>(src);
+                else if (n < N) v.x = src[0];
+            }
+            yreg[p] = v;
+        }
+    };
+
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = tile * TN;
+        // ---- stage the Y tile (and, for given-X statistics, the X tile) ----
+#pragma unroll
+        for (int p = 0; p < YP; ++p)
+            *reinterpret_cast<v2f64 *>(&Z[(p * 16 + lrow) * SZ + lcol]) = yreg[p];
+        if (!COMPUTE_X) {
+#pragma unroll
+            for (int p = 0; p < XP; ++p) {
+                const int row = p * 16 + lrow;
+                const int64_t n = n0 + lcol;
+                v2f64 v = v2f64{0.0, 0.0};
+                if (row < K) {
+                    const double *src = X + (int64_t)row * ldx + n;
+                    if (n + 1 < N) { v.x = src[0]; v.y = src[1]; }
+                    else if (n < N) v.x = src[0];
+                }
+                *reinterpret_cast<v2f64 *>(&Z[(DP + row) * SZ + lcol]) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- prefetch the next Y tile into registers (in flight during MFMAs)
+        const int64_t next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+
+        // ---- role 1: X_tile = A * Y_tile --------------------------------------
+        if (COMPUTE_X) {
+#pragma unroll
+            for (int m = 0; m < R1; ++m) {
+                const int t1 = w + 4 * m;
+                if (t1 < T1) {
+                    const int jt = t1 / KT;
+                    const double *zb = Z + jt * 16 + l15 + 8 * l4 * SZ;
+                    v4f64 c0 = v4f64{0.0, 0.0, 0.0, 0.0};
+                    v4f64 c1 = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < KS1; q += 2) {
+                        const double b0 = zb[(32 * (q >> 3) + (q & 7)) * SZ];
+                        const double b1 = zb[(32 * ((q + 1) >> 3) + ((q + 1) & 7)) * SZ];
+                        c0 = mfma_f64(afrag[q], b0, c0);
+                        c1 = mfma_f64(afrag[q + 1], b1, c1);
+                    }
+                    c0 += c1;
+                    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15,
+                    // row = (lane>>4) + 4*reg.
+                    const int n = jt * 16 + l15;
+                    const bool nok = (n0 + n) < N;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = it1 * 16 + l4 + 4 * r;
+                        Z[(DP + k) * SZ + n] = c0[r];
+                        if (nok && k < K) X[(int64_t)k * ldx + n0 + n] = c0[r];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- role 2: S += Z_tile * X_tile^T  (n-slices of one MFMA adjacent) ---
+        {
+            const double *zbB = Z + (DP + jt2 * 16 + l15) * SZ + l4;
+            const double *zbA = Z + l15 * SZ + l4;
+#pragma unroll
+            for (int q = 0; q < TN / 4; ++q) {
+                const double b = zbB[4 * q];
+#pragma unroll
+                for (int m = 0; m < R2; ++m) {
+                    const int t2 = w + 4 * m;
+                    if (t2 < T2) {
+                        const int it2 = t2 / KT;
+                        const double a = zbA[it2 * 16 * SZ + 4 * q];
+                        acc2[m] = mfma_f64(a, b, acc2[m]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- per-workgroup partial statistics (reduced in fixed order later) -----
+    double *Pb = P + (int64_t)blockIdx.x * (ZR * KP);
+#pragma unroll
+    for (int m = 0; m < R2; ++m) {
+        const int t2 = w + 4 * m;
+        if (t2 < T2) {
+            const int it2 = t2 / KT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = it2 * 16 + l4 + 4 * r;
+                Pb[row * KP + jt2 * 16 + l15] = acc2[m][r];
+            }
+        }
+    }
+}
+
+// S[e] = sum_b P[b][e] in fixed order b = 0..nb-1 (deterministic).
+__global__ void __launch_bounds__(NT)
+reduce_partials_kernel(const double *__restrict__ P, int nb, int len, double *__restrict__ S)
+{
+    const int e = blockIdx.x * NT + threadIdx.x;
+    if (e >= len) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < nb; b += 4) {
+        s0 += P[(int64_t)b * len + e];
+        s1 += P[(int64_t)(b + 1) * len + e];
+        s2 += P[(int64_t)(b + 2) * len + e];
+        s3 += P[(int64_t)(b + 3) * len + e];
+    }
+    for (; b < nb; ++b) s0 += P[(int64_t)b * len + e];
+    S[e] = (s0 + s1) + (s2 + s3);
+}
+
+// partial[b] = sum over this workgroup's grid-stride share of y^2.
+__global__ void __launch_bounds__(NT)
+sumsq_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D,
+             double *__restrict__ partial)
+{
+    __shared__ double red[NT / 64];
+    double s = 0.0;
+    const int64_t npairs = (N + 1) / 2;
+    const int64_t total = npairs * D;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * NT) {
+        const int64_t d = i / npairs;
+        const int64_t n = (i - d * npairs) * 2;
+        const double *src = Y + d * ldy + n;
+        if (n + 1 < N) {
+            const v2f64 v = *reinterpret_cast<const v2f64 *>(src);
+            s += v.x * v.x + v.y * v.y;
+        } else {
+            s += src[0] * src[0];
+        }
+    }
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(NT)
+sum_partials_kernel(const double *__restrict__ partial, int n, double *__restrict__ out)
+{
+    __shared__ double red[NT / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += NT) s += partial[i];
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// ---------------------------------------------------------------------------
+// Small replicated-node kernels: ONE workgroup each, everything in LDS.
+// ---------------------------------------------------------------------------
+constexpr int LD = MAX_KP + 1;
+
+// In-place inverse of the SPD n x n matrix M (LDS, row-major ld LD) through a
+// Cholesky factor (utils/linalg.py:31-63 chol, :174-207 chol_inv, :209-223
+// chol_logdet).  Li is LDS scratch of the same size.  On exit M = inverse,
+// *logdet = log|M_in|; *bad is set when M_in is not positive definite.
+__device__ void spd_inverse_lds(double *M, double *Li, int n, double *logdet, int *bad)
+{
+    const int tid = threadIdx.x;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        if (tid == 0) {
+            double s = M[j * LD + j];
+            for (int k = 0; k < j; ++k) s -= M[j * LD + k] * M[j * LD + k];
+            if (!(s > 0.0)) { *bad = 1; s = 1.0; }
+            M[j * LD + j] = sqrt(s);
+        }
+        __syncthreads();
+        const double djj = M[j * LD + j];
+        for (int i = j + 1 + tid; i < n; i += NT) {
+            double s = M[i * LD + j];
+            for (int k = 0; k < j; ++k) s -= M[i * LD + k] * M[j * LD + k];
+            M[i * LD + j] = s / djj;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += log(M[j * LD + j]);
+        *logdet = 2.0 * s;
+    }
+    // Li = L^-1 (lower triangular), one column per thread by forward substitution
+    if (tid < n) {
+        const int c = tid;
+        for (int i = 0; i < c; ++i) Li[i * LD + c] = 0.0;
+        Li[c * LD + c] = 1.0 / M[c * LD + c];
+        for (int i = c + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = c; k < i; ++k) s += M[i * LD + k] * Li[k * LD + c];
+            Li[i * LD + c] = -s / M[i * LD + i];
+        }
+    }
+    __syncthreads();
+    // M = Li^T Li
+    for (int e = tid; e < n * n; e += NT) {
+        const int i = e / n, j = e - i * n;
+        const int k0 = i > j ? i : j;
+        double s = 0.0;
+        for (int k = k0; k < n; ++k) s += Li[k * LD + i] * Li[k * LD + j];
+        M[i * LD + j] = s;
+    }
+    __syncthreads();
+}
+
+// <x x^T> total statistic: n_total * Cov_X + sum_n <x><x>^T, symmetrised.
+__device__ inline double sxx_total(const double *st, const vmp_pca_layout &L, double n_total,
+                                   int i, int j)
+{
+    const double *S = st + L.off_S;
+    const double m = 0.5 * (S[(L.DP + i) * L.KP + j] + S[(L.DP + j) * L.KP + i]);
+    return n_total * st[L.off_CX + i * L.KP + j] + m;
+}
+
+__global__ void __launch_bounds__(NT)
+pca_init_state_kernel(vmp_pca_layout L, int K, double a0t, double b0t, double a0a, double b0a,
+                      double *st)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        st[L.off_tau + 0] = a0t;
+        st[L.off_tau + 1] = b0t;
+        st[L.off_tau + 2] = a0t / b0t;
+        st[L.off_tau + 3] = vmp_digamma(a0t) - log(b0t);
+    }
+    for (int k = tid; k < K; k += NT) {
+        st[L.off_alpha + 0 * L.KP + k] = a0a;
+        st[L.off_alpha + 1 * L.KP + k] = b0a;
+        st[L.off_alpha + 2 * L.KP + k] = a0a / b0a;
+        st[L.off_alpha + 3 * L.KP + k] = vmp_digamma(a0a) - log(b0a);
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+pca_update_w_kernel(vmp_pca_layout L, int D, int K, double n_total, double *st)
+{
+    __shared__ double M[MAX_KP * LD];
+    __shared__ double Li[MAX_KP * LD];
+    __shared__ double logdet;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const int KP = (int)L.KP;
+    if (tid == 0) bad = 0;
+    const double tau = st[L.off_tau + 2];
+    // Lambda_W = diag<alpha> + <tau> sum_n <x x^T>      (gaussian.py:656-670 + dot.py:581)
+    for (int e = tid; e < K * K; e += NT) {
+        const int i = e / K, j = e - i * K;
+        double v = tau * sxx_total(st, L, n_total, i, j);
+        if (i == j) v += st[L.off_alpha + 2 * KP + i];
+        M[i * LD + j] = v;
+    }
+    spd_inverse_lds(M, Li, K, &logdet, &bad);
+    for (int e = tid; e < K * K; e += NT) {
+        const int i = e / K, j = e - i * K;
+        st[L.off_CW + i * KP + j] = M[i * LD + j];
+    }
+    // <W> = <tau> Syx Cov_W                              (gaussian.py:694)
+    const double *Syx = st + L.off_S;
+    double *W = st + L.off_W;
+    for (int e = tid; e < D * K; e += NT) {
+        const int d = e / K, k = e - d * K;
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += Syx[d * KP + j] * M[j * LD + k];
+        W[d * KP + k] = tau * s;
+    }
+    __syncthreads();
+    // Sww = sum_d <w_d w_d^T> = D Cov_W + W^T W          (gaussian.py:695)
+    for (int e = tid; e < K * K; e += NT) {
+        const int i = e / K, j = e - i * K;
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += W[d * KP + i] * W[d * KP + j];
+        st[L.off_Sww + i * KP + j] = (double)D * M[i * LD + j] + s;
+    }
+    if (tid == 0) {
+        st[L.off_scal + 0] = logdet;
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+pca_prepare_x_kernel(vmp_pca_layout L, int D, int K, double x_prec, double *st)
+{
+    __shared__ double M[MAX_KP * LD];
+    __shared__ double Li[MAX_KP * LD];
+    __shared__ double logdet;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const int KP = (int)L.KP, DP = (int)L.DP;
+    if (tid == 0) bad = 0;
+    const double tau = st[L.off_tau + 2];
+    // Lambda_X = x_prec I + <tau> sum_d <w_d w_d^T>
+    for (int e = tid; e < K * K; e += NT) {
+        const int i = e / K, j = e - i * K;
+        double v = tau * 0.5 * (st[L.off_Sww + i * KP + j] + st[L.off_Sww + j * KP + i]);
+        if (i == j) v += x_prec;
+        M[i * LD + j] = v;
+    }
+    spd_inverse_lds(M, Li, K, &logdet, &bad);
+    for (int e = tid; e < K * K; e += NT) {
+        const int i = e / K, j = e - i * K;
+        st[L.off_CX + i * KP + j] = M[i * LD + j];
+    }
+    // A = <tau> Cov_X <W>^T   (K x D, zero padded to KP x DP)
+    const double *W = st + L.off_W;
+    for (int e = tid; e < K * D; e += NT) {
+        const int k = e / D, d = e - k * D;
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += M[k * LD + j] * W[d * KP + j];
+        st[L.off_A + (int64_t)k * DP + d] = tau * s;
+    }
+    if (tid == 0) {
+        st[L.off_scal + 1] = logdet;
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
+}
+
+// sum_dn <(y_dn - f_dn)^2> = Syy - 2 sum(W o Syx) + sum(Sww o Sxx)
+// (dot.py:355 E1 and dot.py:403 E2 collapsed to traces).
+__device__ double pca_residual(const double *st, const vmp_pca_layout &L, int D, int K,
+                               double n_total, double *red)
+{
+    const int tid = threadIdx.x;
+    const int KP = (int)L.KP;
+    double t1 = 0.0, t2 = 0.0;
+    for (int e = tid; e < D * K; e += NT) {
+        const int d = e / K, k = e - d * K;
+        t1 += st[L.off_W + d * KP + k] * st[L.off_S + d * KP + k];
+    }
+    for (int e = tid; e < K * K; e += NT) {
+        const int i = e / K, j = e - i * K;
+        t2 += st[L.off_Sww + i * KP + j] * sxx_total(st, L, n_total, i, j);
+    }
+    t1 = block_sum<NT>(t1, red);
+    t2 = block_sum<NT>(t2, red);
+    return st[L.off_Syy] - 2.0 * t1 + t2;
+}
+
+__global__ void __launch_bounds__(NT)
+pca_update_tau_kernel(vmp_pca_layout L, int D, int K, double n_total, double a0, double b0,
+                      double *st)
+{
+    __shared__ double red[NT / 64];
+    const double resid = pca_residual(st, L, D, K, n_total, red);
+    if (threadIdx.x == 0) {
+        // gamma.py:116-122 phi = [-b, a] with the message gaussian.py:2363-2369
+        const double a = a0 + 0.5 * (double)D * n_total;
+        const double b = b0 + 0.5 * resid;
+        st[L.off_tau + 0] = a;
+        st[L.off_tau + 1] = b;
+        st[L.off_tau + 2] = a / b;                       // gamma.py:144
+        st[L.off_tau + 3] = vmp_digamma(a) - log(b);     // gamma.py:145
+        st[L.off_scal + 2] = resid;
+        if (!(b > 0.0)) st[L.off_scal + 3] = (double)VMP_ERR_FLOATING;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+pca_update_alpha_kernel(vmp_pca_layout L, int D, int K, double a0, double b0, double *st)
+{
+    const int KP = (int)L.KP;
+    for (int k = threadIdx.x; k < K; k += NT) {
+        const double a = a0 + 0.5 * (double)D;
+        const double b = b0 + 0.5 * st[L.off_Sww + k * KP + k];
+        st[L.off_alpha + 0 * KP + k] = a;
+        st[L.off_alpha + 1 * KP + k] = b;
+        st[L.off_alpha + 2 * KP + k] = a / b;
+        st[L.off_alpha + 3 * KP + k] = vmp_digamma(a) - log(b);
+    }
+}
+
+// E[log p - log q] of a Gamma(a,b) node with prior Gamma(a0,b0)
+// (expfamily.py:400-480 with gamma.py:147,160).
+__device__ inline double gamma_elbo(double a0, double b0, double a, double b, double x,
+                                    double logx)
+{
+    const double g_p = a0 * log(b0) - vmp_lgamma(a0);
+    const double g_q = a * log(b) - vmp_lgamma(a);
+    return g_p - g_q + (b - b0) * x + (a0 - a) * logx;
+}
+
+__global__ void __launch_bounds__(NT)
+pca_lower_bound_kernel(vmp_pca_layout L, int D, int K, double n_total, double x_prec,
+                       double a0t, double b0t, double a0a, double b0a, double *st)
+{
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x;
+    const int KP = (int)L.KP;
+    const double resid = pca_residual(st, L, D, K, n_total, red);
+    double trx = 0.0, sla = 0.0, saw = 0.0, lal = 0.0;
+    for (int k = tid; k < K; k += NT) {
+        const double a = st[L.off_alpha + 0 * KP + k], b = st[L.off_alpha + 1 * KP + k];
+        const double al = st[L.off_alpha + 2 * KP + k], la = st[L.off_alpha + 3 * KP + k];
+        trx += sxx_total(st, L, n_total, k, k);
+        sla += la;
+        saw += al * st[L.off_Sww + k * KP + k];
+        lal += gamma_elbo(a0a, b0a, a, b, al, la);
+    }
+    trx = block_sum<NT>(trx, red);
+    sla = block_sum<NT>(sla, red);
+    saw = block_sum<NT>(saw, red);
+    lal = block_sum<NT>(lal, red);
+    if (tid == 0) {
+        const double tau = st[L.off_tau + 2], logtau = st[L.off_tau + 3];
+        const double Dd = (double)D, Kd = (double)K;
+        const double LY = Dd * n_total * (-0.5 * log(2.0 * M_PI) + 0.5 * logtau) - 0.5 * tau * resid;
+        const double LX = -0.5 * x_prec * trx
+                          + n_total * (0.5 * Kd * log(x_prec) - 0.5 * st[L.off_scal + 1] + 0.5 * Kd);
+        const double LW = 0.5 * Dd * sla - 0.5 * saw + Dd * (-0.5 * st[L.off_scal + 0] + 0.5 * Kd);
+        const double Lt = gamma_elbo(a0t, b0t, st[L.off_tau + 0], st[L.off_tau + 1], tau, logtau);
+        st[L.off_L + 0] = LY;
+        st[L.off_L + 1] = LX;
+        st[L.off_L + 2] = LW;
+        st[L.off_L + 3] = Lt;
+        st[L.off_L + 4] = lal;
+        st[L.off_L + 5] = LY + LX + LW + Lt + lal;
+        st[L.off_scal + 2] = resid;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+int wgs_per_cu()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("VMP_PCA_WGS_PER_CU");
+        v = e ? atoi(e) : 2;
+        if (v < 1) v = 1;
+        if (v > 8) v = 8;
+    }
+    return v;
+}
+
+int64_t max_grid(vmp_ctx *ctx) { return (int64_t)ctx->num_cu * wgs_per_cu(); }
+
+template <int DB, int KT>
+void launch_pass(bool compute_x, dim3 grid, hipStream_t s, const double *Y, int64_t ldy,
+                 int64_t N, int D, int K, const double *A, double *X, int64_t ldx, double *P,
+                 int64_t ntiles)
+{
+    if (compute_x)
+        hipLaunchKernelGGL((pca_pass_kernel<DB, KT, true>), grid, dim3(NT), 0, s, Y, ldy, N, D, K,
+                           A, X, ldx, P, ntiles);
+    else
+        hipLaunchKernelGGL((pca_pass_kernel<DB, KT, false>), grid, dim3(NT), 0, s, Y, ldy, N, D,
+                           K, A, X, ldx, P, ntiles);
+}
+
+int32_t run_pass(vmp_ctx *ctx, bool compute_x, const double *Y, int64_t ldy, int64_t N, int D,
+                 int K, double *X, int64_t ldx, double *state, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx != nullptr, VMP_ERR_INVALID, "null context");
+    VMP_REQUIRE(ctx, Y && X && state && workspace, VMP_ERR_INVALID, "null pointer argument");
+    VMP_REQUIRE(ctx, D >= 1 && K >= 1 && N >= 0, VMP_ERR_INVALID, "bad dims D=%d K=%d N=%lld", D,
+                K, (long long)N);
+    VMP_REQUIRE(ctx, D <= MAX_DP && K <= MAX_KP, VMP_ERR_UNSUPPORTED,
+                "fused PCA pass supports D <= %d, K <= %d (got D=%d, K=%d)", MAX_DP, MAX_KP, D, K);
+    VMP_REQUIRE(ctx, ldy >= N && ldx >= N, VMP_ERR_INVALID, "leading dimension smaller than N");
+    VMP_REQUIRE(ctx, (ldy % 2) == 0 && ((uintptr_t)Y % 16) == 0, VMP_ERR_INVALID,
+                "Y must be 16-byte aligned with an even leading dimension (ldy=%lld)",
+                (long long)ldy);
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    const int DB = (int)(L.DP / 32), KT = (int)(L.KP / 16);
+    const int64_t ntiles = (N + TN - 1) / TN;
+    int64_t g = ntiles < max_grid(ctx) ? ntiles : max_grid(ctx);
+    if (g < 1) g = 1;
+    double *P = reinterpret_cast<double *>(workspace);
+    const double *A = state + L.off_A;
+    hipStream_t s = ctx->stream;
+    dim3 grid((unsigned)g);
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
+#define VMP_CASE(db, kt)                                                                 \
+    if (DB == db && KT == kt) {                                                          \
+        launch_pass<db, kt>(compute_x, grid, s, Y, ldy, N, D, K, A, X, ldx, P, ntiles);  \
+    } else
+    VMP_CASE(1, 1) VMP_CASE(2, 1) VMP_CASE(4, 1) VMP_CASE(8, 1)
+    VMP_CASE(1, 2) VMP_CASE(2, 2) VMP_CASE(4, 2) VMP_CASE(8, 2)
+    VMP_CASE(1, 4) VMP_CASE(2, 4) VMP_CASE(4, 4) VMP_CASE(8, 4)
+    {
+        VMP_SET_ERR(ctx, "no kernel instance for DB=%d KT=%d", DB, KT);
+        return VMP_ERR_UNSUPPORTED;
+    }
+#undef VMP_CASE
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
+    const int len = (int)L.len_S;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + NT - 1) / NT), dim3(NT), 0, s, P,
+                       (int)g, len, state + L.off_S);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
+    return VMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_pca_get_layout(int32_t D, int32_t K, vmp_pca_layout *out)
+{
+    if (!out || D < 1 || K < 1) return VMP_ERR_INVALID;
+    if (D > MAX_DP || K > MAX_KP) return VMP_ERR_UNSUPPORTED;
+    fill_layout(D, K, out);
+    return VMP_OK;
+}
+
+int32_t vmp_pca_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *bytes)
+{
+    VMP_REQUIRE(ctx, ctx && bytes, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, D >= 1 && K >= 1, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, D <= MAX_DP && K <= MAX_KP, VMP_ERR_UNSUPPORTED,
+                "fused PCA pass supports D <= %d, K <= %d", MAX_DP, MAX_KP);
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    *bytes = (size_t)(max_grid(ctx) * L.len_S + 4096) * sizeof(double);
+    return VMP_OK;
+}
+
+int32_t vmp_pca_init_state(vmp_ctx *ctx, int32_t D, int32_t K, double a0_tau, double b0_tau,
+                           double a0_alpha, double b0_alpha, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");
+    vmp_pca_layout L;
+    int32_t rc = vmp_pca_get_layout(D, K, &L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "unsupported dims D=%d K=%d", D, K);
+    VMP_REQUIRE(ctx, a0_tau > 0 && b0_tau > 0 && a0_alpha > 0 && b0_alpha > 0, VMP_ERR_INVALID,
+                "Gamma prior parameters must be positive");
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, (size_t)L.total * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(pca_init_state_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, K, a0_tau,
+                       b0_tau, a0_alpha, b0_alpha, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_syy(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
+                    double *state, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Y && state && workspace, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, (ldy % 2) == 0 && ((uintptr_t)Y % 16) == 0 && ldy >= N, VMP_ERR_INVALID,
+                "Y must be 16-byte aligned with an even leading dimension >= N");
+    vmp_pca_layout L;
+    int32_t rc = vmp_pca_get_layout(D, K, &L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "unsupported dims D=%d K=%d", D, K);
+    double *partial = reinterpret_cast<double *>(workspace);
+    int64_t work = ((N + 1) / 2) * D;
+    int64_t g = (work + NT - 1) / NT;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, Y, ldy, N, D,
+                       partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(NT), 0, ctx->stream, partial, (int)g,
+                       state + L.off_Syy);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_stats_from_x(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D,
+                             int32_t K, const double *X, int64_t ldx, double *state,
+                             void *workspace)
+{
+    return run_pass(ctx, false, Y, ldy, N, D, K, const_cast<double *>(X), ldx, state, workspace);
+}
+
+int32_t vmp_pca_pass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
+                     double *X, int64_t ldx, double *state, void *workspace)
+{
+    return run_pass(ctx, true, Y, ldy, N, D, K, X, ldx, state, workspace);
+}
+
+#define VMP_SMALL_PROLOGUE()                                               \
+    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");      \
+    vmp_pca_layout L;                                                      \
+    {                                                                      \
+        int32_t rc__ = vmp_pca_get_layout(D, K, &L);                       \
+        VMP_REQUIRE(ctx, rc__ == VMP_OK, rc__, "unsupported dims D=%d K=%d", D, K); \
+    }
+
+int32_t vmp_pca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double *state)
+{
+    VMP_SMALL_PROLOGUE();
+    hipLaunchKernelGGL(pca_update_w_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K,
+                       (double)n_total, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_prepare_x(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, double *state)
+{
+    VMP_SMALL_PROLOGUE();
+    VMP_REQUIRE(ctx, x_prec > 0, VMP_ERR_INVALID, "x_prec must be positive");
+    hipLaunchKernelGGL(pca_prepare_x_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, x_prec,
+                       state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_update_tau(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double a0,
+                           double b0, double *state)
+{
+    VMP_SMALL_PROLOGUE();
+    hipLaunchKernelGGL(pca_update_tau_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K,
+                       (double)n_total, a0, b0, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_update_alpha(vmp_ctx *ctx, int32_t D, int32_t K, double a0, double b0,
+                             double *state)
+{
+    VMP_SMALL_PROLOGUE();
+    hipLaunchKernelGGL(pca_update_alpha_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, a0, b0,
+                       state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
+                            double a0_tau, double b0_tau, double a0_alpha, double b0_alpha,
+                            double *state)
+{
+    VMP_SMALL_PROLOGUE();
+    hipLaunchKernelGGL(pca_lower_bound_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K,
+                       (double)n_total, x_prec, a0_tau, b0_tau, a0_alpha, b0_alpha, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_last_pass_ms(vmp_ctx *ctx, double *ms_pass, double *ms_reduce)
+{
+    VMP_REQUIRE(ctx, ctx && ctx->timing && ctx->ev[0], VMP_ERR_INVALID,
+                "timing not enabled (vmp_ctx_set_timing)");
+    VMP_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[2]));
+    float a = 0.f, b = 0.f;
+    VMP_HIP_CHECK(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+    VMP_HIP_CHECK(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+    if (ms_pass) *ms_pass = a;
+    if (ms_reduce) *ms_reduce = b;
+    return VMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""
+Device runtime: one process per GPU, one HIP stream, one ``vmp_ctx``.
+
+PyTorch is used here as plumbing only -- device memory (caching allocator),
+the current HIP stream and ``torch.distributed`` (backend "nccl" == RCCL over
+xGMI).  All arithmetic on plate-sized arrays goes through libvmp_hip.so.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+class Runtime:
+    """Process-wide device runtime (lazy singleton, see :func:`get_runtime`)."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError(
+                    'bayespy_amd needs an AMD GPU (HIP device); none is visible and there is '
+                    'no CPU fallback.')
+            ndev = torch.cuda.device_count()
+            idx = int(os.environ.get('LOCAL_RANK', '0')) % max(ndev, 1)
+            torch.cuda.set_device(idx)
+            self.device = torch.device('cuda', idx)
+        else:
+            self.device = torch.device(device)
+        self.lib = None
+        self.ctx = None
+        if self.device.type == 'cuda':
+            self.lib = _lib.load()
+            ctx = ctypes.c_void_p()
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.vmp_ctx_create(self.device.index, ctypes.c_void_p(stream),
+                                         ctypes.byref(ctx))
+            if rc != _lib.VMP_OK:
+                _lib.raise_for_status(rc, self.lib.vmp_last_error(None).decode())
+            self.ctx = ctx
+        self._refresh_dist()
+
+    # -- distributed ---------------------------------------------------------
+    def _refresh_dist(self):
+        dist = self.torch.distributed
+        if dist.is_available() and dist.is_initialized():
+            self.rank = dist.get_rank()
+            self.world = dist.get_world_size()
+        else:
+            self.rank, self.world = 0, 1
+
+    def all_reduce_sum_(self, tensor):
+        """In-place sum over ranks (RCCL all-reduce over xGMI on GPUs).  This is
+        the ONLY data-path collective: it stands where the reference sums a
+        message over a plate the parent lacks (node.py:650, dot.py:581) and
+        where it sums the per-node lower bound (expfamily.py:470-480)."""
+        self._refresh_dist()
+        if self.world > 1:
+            self.torch.distributed.all_reduce(tensor)
+        return tensor
+
+    def all_reduce_int(self, value):
+        self._refresh_dist()
+        if self.world == 1:
+            return int(value)
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.device)
+        self.torch.distributed.all_reduce(t)
+        return int(t.item())
+
+    # -- memory ----------------------------------------------------------------
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float64, device=self.device)
+
+    def to_device(self, array):
+        """Host ndarray (any float dtype) or torch tensor -> fp64 device tensor."""
+        torch = self.torch
+        if isinstance(array, torch.Tensor):
+            return array.to(device=self.device, dtype=torch.float64)
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        return torch.from_numpy(a).to(self.device)
+
+    # -- C ABI helpers -----------------------------------------------------------
+    def check(self, rc):
+        if rc != _lib.VMP_OK:
+            msg = self.lib.vmp_last_error(self.ctx).decode(errors='replace')
+            _lib.raise_for_status(rc, msg)
+
+    def sync_stream(self):
+        """Point the context at torch's current stream (cheap; call before launches)."""
+        if self.ctx is not None:
+            s = self.torch.cuda.current_stream(self.device).cuda_stream
+            self.lib.vmp_ctx_set_stream(self.ctx, ctypes.c_void_p(s))
+
+    def synchronize(self):
+        if self.device.type == 'cuda':
+            self.torch.cuda.synchronize(self.device)
+
+
+_runtime = None
+
+
+def get_runtime():
+    global _runtime
+    if _runtime is None:
+        _runtime = Runtime()
+    return _runtime
+
+
+def set_runtime(rt):
+    """Install a runtime explicitly (tests inject a CPU runtime together with a
+    kernel test double; the product path never does this)."""
+    global _runtime
+    _runtime = rt
+
+
+def ptr(tensor):
+    return ctypes.c_void_p(tensor.data_ptr())

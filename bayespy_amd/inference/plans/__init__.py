@@ -1,0 +1,35 @@
+"""
+Compiled execution plans: each plan owns the HBM-resident state of one model
+block and maps the reference's per-node operations (``update``,
+``lower_bound_contribution``, ``get_moments``) onto HIP kernel launches.
+"""
+from .pca import PCAPlan
+
+PLAN_TYPES = [PCAPlan]
+
+
+def compile_model(nodes, **options):
+    """Cover the stochastic nodes of ``nodes`` with plans.  Raises
+    NotImplementedError (loudly -- there is no CPU fallback) when a node is not
+    covered by any built plan."""
+    from ...nodes.node import Stochastic
+    remaining = [n for n in nodes]
+    plans = []
+    progress = True
+    while progress:
+        progress = False
+        for P in PLAN_TYPES:
+            roles = P.match(remaining)
+            if roles is not None:
+                plan = P(roles, **options)
+                plans.append(plan)
+                used = set(id(n) for n in roles.values())
+                remaining = [n for n in remaining if id(n) not in used]
+                progress = True
+                break
+    left = [n for n in remaining if isinstance(n, Stochastic)]
+    if left:
+        raise NotImplementedError(
+            'No HIP execution plan is built for nodes %s. Supported model blocks: %s'
+            % ([n.name for n in left], [P.describe() for P in PLAN_TYPES]))
+    return plans

@@ -1,0 +1,397 @@
+"""
+Execution plan of the probabilistic-PCA / factor-analysis block
+
+    Y = GaussianARD(SumMultiply('i,i', W, X), tau);  W = GaussianARD(0, alpha);
+    X = GaussianARD(0, c);  tau, alpha = Gamma(a0, b0)        (demos/pca.py:22-61)
+
+with a fully observed Y (scalar mask).  The plan owns, in HBM:
+
+* ``Y``  (D, ldy)  fp64, the observation plate N contiguous (the local shard
+  when the plate is sharded over ranks);
+* ``X``  (K, ldx)  fp64, posterior means, plate contiguous;
+* ``state``        one block of doubles (``vmp_pca_layout``): the statistics S
+  that ranks all-reduce, and every replicated quantity (tau, alpha, <W>, Cov_W,
+  Sww, Cov_X, A, lower-bound terms).
+
+Reference semantics preserved: each ``node.update()`` sees the latest moments
+of its Markov blanket, in whatever order the user calls them
+(vmp.py:154-172); the only plate-sized work per VB iteration is ONE streaming
+pass over Y (``vmp_pca_pass``) issued by ``X.update()``.
+"""
+import ctypes
+
+import numpy as np
+
+from ... import _lib
+from ...device import get_runtime, ptr
+from ...nodes.node import Constant
+from ...nodes.gamma import Gamma
+from ...nodes.gaussian import GaussianARD
+from ...nodes.dot import SumMultiply
+
+
+class HIPKernels:
+    """The C-ABI entry points used by this plan, bound to a runtime."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.lib = rt.lib
+        self.ctx = rt.ctx
+
+    def layout(self, D, K):
+        L = _lib.PCALayout()
+        rc = self.lib.vmp_pca_get_layout(D, K, ctypes.byref(L))
+        if rc != _lib.VMP_OK:
+            _lib.raise_for_status(rc, 'fused PCA block supports D <= 256 and K <= 64 '
+                                      '(got D=%d, K=%d)' % (D, K))
+        return L
+
+    def workspace_doubles(self, D, K):
+        n = ctypes.c_size_t()
+        self.rt.check(self.lib.vmp_pca_workspace_bytes(self.ctx, D, K, ctypes.byref(n)))
+        return (n.value + 7) // 8
+
+    def init_state(self, D, K, a0t, b0t, a0a, b0a, state):
+        self.rt.check(self.lib.vmp_pca_init_state(self.ctx, D, K, a0t, b0t, a0a, b0a, ptr(state)))
+
+    def syy(self, Y, ldy, N, D, K, state, ws):
+        self.rt.check(self.lib.vmp_pca_syy(self.ctx, ptr(Y), ldy, N, D, K, ptr(state), ptr(ws)))
+
+    def stats_from_x(self, Y, ldy, N, D, K, X, ldx, state, ws):
+        self.rt.check(self.lib.vmp_pca_stats_from_x(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
+                                                    ptr(state), ptr(ws)))
+
+    def update_w(self, D, K, n_total, state):
+        self.rt.check(self.lib.vmp_pca_update_w(self.ctx, D, K, n_total, ptr(state)))
+
+    def prepare_x(self, D, K, x_prec, state):
+        self.rt.check(self.lib.vmp_pca_prepare_x(self.ctx, D, K, x_prec, ptr(state)))
+
+    def pass_(self, Y, ldy, N, D, K, X, ldx, state, ws):
+        self.rt.check(self.lib.vmp_pca_pass(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
+                                            ptr(state), ptr(ws)))
+
+    def update_tau(self, D, K, n_total, a0, b0, state):
+        self.rt.check(self.lib.vmp_pca_update_tau(self.ctx, D, K, n_total, a0, b0, ptr(state)))
+
+    def update_alpha(self, D, K, a0, b0, state):
+        self.rt.check(self.lib.vmp_pca_update_alpha(self.ctx, D, K, a0, b0, ptr(state)))
+
+    def lower_bound(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, state):
+        self.rt.check(self.lib.vmp_pca_lower_bound(self.ctx, D, K, n_total, x_prec, a0t, b0t,
+                                                   a0a, b0a, ptr(state)))
+
+    def set_timing(self, on):
+        self.rt.check(self.lib.vmp_ctx_set_timing(self.ctx, 1 if on else 0))
+
+    def last_pass_ms(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self.rt.check(self.lib.vmp_pca_last_pass_ms(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+
+def _const_scalar(node):
+    return isinstance(node, Constant) and node.is_scalar()
+
+
+def _const_zero(node):
+    return isinstance(node, Constant) and not np.any(node.value)
+
+
+def _gamma_with_const_parents(node):
+    return (isinstance(node, Gamma) and _const_scalar(node.parents[0])
+            and _const_scalar(node.parents[1]))
+
+
+def _lead(plates, n):
+    """plates right-aligned into n axes (missing axes = 1)."""
+    return (1,) * (n - len(plates)) + tuple(plates)
+
+
+class PCAPlan:
+
+    @staticmethod
+    def describe():
+        return ("GaussianARD(SumMultiply('i,i', W, X), Gamma) with W=GaussianARD(0, Gamma, "
+                "shape=(K,), plates=(D,1)), X=GaussianARD(0, const, shape=(K,), plates=(1,N)), "
+                "fully observed")
+
+    # -- pattern matching -----------------------------------------------------------
+    @staticmethod
+    def match(nodes):
+        for Y in nodes:
+            if not isinstance(Y, GaussianARD) or Y.ndim != 0:
+                continue
+            F, tau = Y.parents
+            if not isinstance(F, SumMultiply) or not _gamma_with_const_parents(tau):
+                continue
+            if len(F.parents) != 2 or F.out_keys != [] or F.in_keys[0] != F.in_keys[1] \
+                    or len(F.in_keys[0]) != 1:
+                continue
+            if any(p != 1 for p in tau.plates) or len(Y.plates) != 2:
+                continue
+            D, N = Y.plates
+            A, B = F.parents
+            if not (isinstance(A, GaussianARD) and isinstance(B, GaussianARD)):
+                continue
+            if A.ndim != 1 or B.ndim != 1 or A.shape != B.shape:
+                continue
+            pa, pb = _lead(A.plates, 2), _lead(B.plates, 2)
+            if pa == (D, 1) and pb == (1, N):
+                W, X = A, B
+            elif pb == (D, 1) and pa == (1, N):
+                W, X = B, A
+            else:
+                continue
+            K = W.shape[0]
+            alpha = W.parents[1]
+            if not (_const_zero(W.parents[0]) and _gamma_with_const_parents(alpha)):
+                continue
+            if _lead(alpha.plates, 1) != (K,):
+                continue
+            if not (_const_zero(X.parents[0]) and _const_scalar(X.parents[1])):
+                continue
+            # every role must be private to this block
+            if len(W.children) != 1 or len(X.children) != 1 or len(F.children) != 1 \
+                    or len(tau.children) != 1 or len(alpha.children) != 1:
+                continue
+            return dict(Y=Y, F=F, W=W, X=X, tau=tau, alpha=alpha)
+        return None
+
+    # -- construction ------------------------------------------------------------------
+    def __init__(self, roles, runtime=None, kernels=None):
+        self.roles = roles
+        self.Y, self.F, self.W, self.X = roles['Y'], roles['F'], roles['W'], roles['X']
+        self.tau, self.alpha = roles['tau'], roles['alpha']
+        self.D, self.N = self.Y.plates
+        self.K = self.W.shape[0]
+        self.a0t = self.tau.parents[0].scalar()
+        self.b0t = self.tau.parents[1].scalar()
+        self.a0a = self.alpha.parents[0].scalar()
+        self.b0a = self.alpha.parents[1].scalar()
+        self.x_prec = self.X.parents[1].scalar()
+        self._rt = runtime
+        self._kernels = kernels
+        self._ready = False
+        self._version = 0
+        self._L_version = -1
+        self._L = None
+        self.timing = False
+        for n in roles.values():
+            n._plan = self
+
+    @property
+    def rt(self):
+        if self._rt is None:
+            self._rt = get_runtime()
+        return self._rt
+
+    @property
+    def kernels(self):
+        if self._kernels is None:
+            self._kernels = HIPKernels(self.rt)
+        return self._kernels
+
+    def nodes(self):
+        return list(self.roles.values())
+
+    def invalidate(self, node):
+        """Data or initial value of ``node`` changed: rebuild device state lazily."""
+        self._ready = False
+        self._version += 1
+
+    # -- device state --------------------------------------------------------------------
+    def _materialize(self):
+        if self._ready:
+            return
+        rt, k = self.rt, self.kernels
+        torch = rt.torch
+        D, N, K = self.D, self.N, self.K
+        if self.Y._data is None:
+            raise ValueError('Node %s has not been observed; the fused PCA block needs '
+                             'Y.observe(y)' % self.Y.name)
+        rt.sync_stream()
+        self.layout = L = k.layout(D, K)
+        self.n_total = rt.all_reduce_int(N)
+        # ---- Y: (D, ldy), plate contiguous, 16-byte aligned rows -----------------------
+        y = self.Y._data
+        if isinstance(y, torch.Tensor) and y.device == rt.device and y.dtype == torch.float64 \
+                and tuple(y.shape) == (D, N) and y.stride(1) == 1 and y.stride(0) % 2 == 0 \
+                and y.data_ptr() % 16 == 0:
+            self.Yd, self.ldy = y, y.stride(0)
+        else:
+            ldy = (N + 1) // 2 * 2
+            self.Yd = rt.zeros(D, ldy)
+            if isinstance(y, torch.Tensor):
+                src = y
+            else:
+                ya = np.asarray(y, dtype=np.float64)
+                if ya.shape != (D, N) or not ya.flags.c_contiguous or not ya.flags.writeable:
+                    ya = np.array(np.broadcast_to(ya, (D, N)), dtype=np.float64, order='C')
+                src = torch.from_numpy(ya)
+            self.Yd[:, :N].copy_(src)
+            self.ldy = ldy
+        self.ldx = (N + 1) // 2 * 2
+        self.state = rt.zeros(int(L.total))
+        self.ws = rt.empty(int(k.workspace_doubles(D, K)))
+        k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)
+        k.syy(self.Yd, self.ldy, N, D, K, self.state, self.ws)
+        rt.all_reduce_sum_(self.state[L.off_Syy:L.off_Syy + 1])
+        # ---- X: delta moments (initialize_from_value/random) or the prior --------------
+        init = self.X._init
+        if init is None:
+            self.Xd = rt.zeros(K, self.ldx)
+            self._set_block(L.off_CX, np.eye(K) / self.x_prec)
+        else:
+            if init[0] == 'value':
+                x0 = init[1]
+                if isinstance(x0, torch.Tensor):
+                    x0 = x0.detach().cpu().numpy()
+                x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
+                                     self.X.plates + (K,)).reshape(N, K)
+                self.Xd = rt.zeros(K, self.ldx)
+                self.Xd[:, :N].copy_(torch.from_numpy(np.ascontiguousarray(x0.T)))
+            else:
+                # a draw from the current q = prior N(0, I/x_prec) (expfamily.py:206-212);
+                # RNG streams are not part of the parity contract
+                self.Xd = torch.randn(K, self.ldx, dtype=torch.float64, device=rt.device)
+                if self.x_prec != 1.0:
+                    self.Xd.mul_(self.x_prec ** -0.5)
+            k.stats_from_x(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+            rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
+        # ---- W: prior (mean 0, Cov diag(1/<alpha>)) or a given value ---------------------
+        KP = int(L.KP)
+        init = self.W._init
+        if init is None:
+            cw = np.eye(K) * (self.b0a / self.a0a)
+            self._set_block(L.off_CW, cw)
+            self._set_block(L.off_Sww, D * cw)
+        else:
+            if init[0] == 'value':
+                w0 = init[1]
+                if isinstance(w0, torch.Tensor):
+                    w0 = w0.detach().cpu().numpy()
+                w0 = np.broadcast_to(np.asarray(w0, dtype=np.float64),
+                                     self.W.plates + (K,)).reshape(D, K)
+            else:
+                w0 = np.random.normal(size=(D, K)) * np.sqrt(self.b0a / self.a0a)
+            wp = np.zeros((D, KP))
+            wp[:, :K] = w0
+            self.state[L.off_W:L.off_W + D * KP].copy_(torch.from_numpy(wp.reshape(-1)))
+            self._set_block(L.off_Sww, w0.T @ w0)
+        self._ready = True
+        self._version += 1
+
+    def _set_block(self, off, mat):
+        """Upload a small K x K host matrix into a KP x KP state block (set-up only)."""
+        KP = int(self.layout.KP)
+        K = mat.shape[0]
+        buf = np.zeros((KP, KP))
+        buf[:K, :K] = mat
+        self.state[off:off + KP * KP].copy_(self.rt.torch.from_numpy(buf.reshape(-1)))
+
+    # -- node operations ---------------------------------------------------------------------
+    def update(self, node):
+        self._materialize()
+        rt, k, L = self.rt, self.kernels, self.layout
+        rt.sync_stream()
+        D, N, K = self.D, self.N, self.K
+        if node is self.W:
+            k.update_w(D, K, self.n_total, self.state)
+        elif node is self.X:
+            k.prepare_x(D, K, self.x_prec, self.state)
+            k.pass_(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+            # child -> parent message sum over the sharded plate (node.py:650, dot.py:581)
+            rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
+        elif node is self.tau:
+            k.update_tau(D, K, self.n_total, self.a0t, self.b0t, self.state)
+        elif node is self.alpha:
+            k.update_alpha(D, K, self.a0a, self.b0a, self.state)
+        else:
+            return
+        self._version += 1
+
+    def _lower_bound_terms(self):
+        self._materialize()
+        if self._L_version != self._version:
+            rt, k, L = self.rt, self.kernels, self.layout
+            rt.sync_stream()
+            k.lower_bound(self.D, self.K, self.n_total, self.x_prec, self.a0t, self.b0t,
+                          self.a0a, self.b0a, self.state)
+            host = self.state[L.off_scal:L.off_L + 8].cpu().numpy()
+            status = int(host[3])
+            if status != 0:
+                _lib.raise_for_status(status)
+            t = host[8:]
+            self._L = dict(Y=float(t[0]), X=float(t[1]), W=float(t[2]), tau=float(t[3]),
+                           alpha=float(t[4]), total=float(t[5]))
+            self._L_version = self._version
+        return self._L
+
+    def lower_bound_contribution(self, node):
+        terms = self._lower_bound_terms()
+        for key in ('Y', 'X', 'W', 'tau', 'alpha'):
+            if node is self.roles[key]:
+                return terms[key]
+        return 0.0
+
+    def lower_bound(self):
+        return self._lower_bound_terms()['total']
+
+    # -- host views (reference shapes) ---------------------------------------------------------
+    def _block(self, off, rows, cols, ld):
+        a = self.state[off:off + rows * ld].cpu().numpy().reshape(rows, ld)
+        return a[:, :cols].copy()
+
+    def get_moments(self, node):
+        self._materialize()
+        L = self.layout
+        D, N, K, KP = self.D, self.N, self.K, int(self.layout.KP)
+        if node is self.W:
+            w = self._block(L.off_W, D, K, KP)
+            cw = self._block(L.off_CW, K, K, KP)
+            u1 = w[:, :, None] * w[:, None, :] + cw
+            return [w.reshape(self.W.plates + (K,)), u1.reshape(self.W.plates + (K, K))]
+        if node is self.X:
+            x = self.Xd[:, :N].cpu().numpy().T.copy()
+            cx = self._block(L.off_CX, K, K, KP)
+            u1 = x[:, :, None] * x[:, None, :] + cx
+            return [x.reshape(self.X.plates + (K,)), u1.reshape(self.X.plates + (K, K))]
+        if node is self.tau:
+            t = self.state[L.off_tau:L.off_tau + 4].cpu().numpy()
+            return [np.reshape(t[2], self.tau.plates), np.reshape(t[3], self.tau.plates)]
+        if node is self.alpha:
+            a = self.state[L.off_alpha:L.off_alpha + 4 * KP].cpu().numpy().reshape(4, KP)
+            return [a[2, :K].reshape(self.alpha.plates), a[3, :K].reshape(self.alpha.plates)]
+        if node is self.Y:
+            y = self.Yd[:, :N].cpu().numpy()
+            return [y, y * y]
+        raise NotImplementedError('moments of %s are never materialised by the fused PCA block'
+                                  % node.name)
+
+    def get_parameters(self, node):
+        """(a, b) of the Gamma nodes; (mean, covariance) of the Gaussian nodes."""
+        self._materialize()
+        L = self.layout
+        K, KP = self.K, int(self.layout.KP)
+        if node is self.tau:
+            t = self.state[L.off_tau:L.off_tau + 2].cpu().numpy()
+            return float(t[0]), float(t[1])
+        if node is self.alpha:
+            a = self.state[L.off_alpha:L.off_alpha + 2 * KP].cpu().numpy().reshape(2, KP)
+            return a[0, :K].copy(), a[1, :K].copy()
+        if node is self.W:
+            return self._block(L.off_W, self.D, K, KP), self._block(L.off_CW, K, K, KP)
+        if node is self.X:
+            return (self.Xd[:, :self.N].cpu().numpy().T.copy(),
+                    self._block(L.off_CX, K, K, KP))
+        raise NotImplementedError
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._materialize()
+        self.kernels.set_timing(on)
+        self.timing = on
+
+    def last_pass_ms(self):
+        return self.kernels.last_pass_ms()

@@ -1,0 +1,170 @@
+"""
+The VB engine: iteration driver, lower-bound bookkeeping, convergence test.
+
+Host-side mirror of ``bayespy.inference.vmp.vmp.VB`` (vmp.py:52-172,
+:180-199, :693-764): same constructor/``update`` signature, same iteration
+semantics (update the given nodes in order, then evaluate the full lower
+bound, warn if it decreased by more than 1e-6, stop when the relative change
+drops below ``tol``), same log line.  The numbers come from the compiled
+plans, i.e. from HIP kernels.
+"""
+import time
+import warnings
+
+import numpy as np
+
+from ..nodes.node import Node
+from .plans import compile_model
+
+
+def _unique(nodes):
+    seen, out = set(), []
+    for n in nodes:
+        if id(n) not in seen:
+            seen.add(id(n))
+            out.append(n)
+    return out
+
+
+def _closure(node):
+    """The connected model block around ``node`` (for stand-alone node calls)."""
+    seen, stack, out = set(), [node], []
+    while stack:
+        n = stack.pop()
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        out.append(n)
+        stack.extend(n.parents)
+        stack.extend(c for (c, _) in n.children)
+    return out
+
+
+def compile_for_node(node):
+    compile_model(_closure(node))
+
+
+class VB:
+
+    def __init__(self, *nodes, tol=1e-5, autosave_filename=None, autosave_iterations=0,
+                 use_logging=False, user_data=None, callback=None):
+        for i, n in enumerate(nodes):
+            if not isinstance(n, Node):
+                raise ValueError("Argument number %d is not a node" % (i + 1))
+        if autosave_filename or autosave_iterations:
+            raise NotImplementedError('HDF5 autosave (vmp.py:237-356) is outside the hot path')
+        if use_logging:
+            import logging
+            self.print = logging.getLogger(__name__).info
+        else:
+            self.print = print
+        self.user_data = user_data
+        self.model = _unique(nodes)
+        names = [n.name for n in self.model]
+        if len(set(names)) != len(names):
+            raise Exception("Use unique names for nodes.")
+        self.plans = compile_model(self.model)
+        self.ignore_bound_checks = False
+        self.iter = 0
+        self.converged = False
+        self.L = np.array(())
+        self.cputime = np.array(())
+        self.l = {n: np.array(()) for n in self.model}
+        self.callback = callback
+        self.callback_output = None
+        self.tol = tol
+
+    # -- containers ---------------------------------------------------------------
+    def __getitem__(self, name):
+        if isinstance(name, Node):
+            return name
+        for n in self.model:
+            if n.name == name:
+                return n
+        raise KeyError(name)
+
+    def set_callback(self, callback):
+        self.callback = callback
+
+    def _append_iterations(self, k):
+        self.L = np.append(self.L, np.full(k, np.nan))
+        self.cputime = np.append(self.cputime, np.full(k, np.nan))
+        for n in self.model:
+            self.l[n] = np.append(self.l[n], np.full(k, np.nan))
+
+    # -- the loop (vmp.py:132-172) ---------------------------------------------------
+    def update(self, *nodes, repeat=1, plot=False, tol=None, verbose=True, tqdm=None):
+        if len(nodes) == 0:
+            nodes = self.model
+        if tqdm is not None:
+            tqdm = tqdm(total=repeat)
+        i = 0
+        while repeat is None or i < repeat:
+            t = time.time()
+            for node in nodes:
+                X = self[node]
+                if hasattr(X, 'update') and callable(X.update):
+                    X.update()
+            cputime = time.time() - t
+            i += 1
+            if tqdm is not None:
+                tqdm.update()
+            if self._end_iteration_step(None, cputime, tol=tol, verbose=verbose):
+                return
+
+    def has_converged(self, tol=None):
+        return self.converged
+
+    # -- lower bound (vmp.py:180-199) ----------------------------------------------------
+    def compute_lowerbound(self, ignore_masked=True):
+        return sum(n.lower_bound_contribution() for n in self.model)
+
+    def compute_lowerbound_terms(self, *nodes):
+        if len(nodes) == 0:
+            nodes = self.model
+        return {n: n.lower_bound_contribution() for n in nodes}
+
+    def loglikelihood_lowerbound(self):
+        L = 0.0
+        for n in self.model:
+            lp = n.lower_bound_contribution()
+            L += lp
+            self.l[n][self.iter] = lp
+        return L
+
+    def _end_iteration_step(self, method, cputime, tol=None, verbose=True):
+        if self.iter >= len(self.L):
+            self._append_iterations(100)
+        if callable(self.callback):
+            z = self.callback()
+            if z is not None:
+                z = np.array(z)[..., np.newaxis]
+                self.callback_output = z if self.callback_output is None else \
+                    np.concatenate((self.callback_output, z), axis=-1)
+        t = time.time()
+        L = self.loglikelihood_lowerbound()      # device -> host sync point
+        cputime += time.time() - t
+        self.cputime[self.iter] = cputime
+        self.L[self.iter] = L
+        if verbose:
+            if method:
+                self.print("Iteration %d (%s): loglike=%e (%.3f seconds)"
+                           % (self.iter + 1, method, L, cputime))
+            else:
+                self.print("Iteration %d: loglike=%e (%.3f seconds)"
+                           % (self.iter + 1, L, cputime))
+        self.converged = False
+        if not self.ignore_bound_checks and self.iter > 0:
+            L0 = self.L[self.iter - 1]
+            if L0 - L > 1e-6:
+                warnings.warn("Lower bound decreased %e! Bug somewhere or "
+                              "numerical inaccuracy?" % (L0 - L))
+            if tol is None:
+                tol = self.tol
+            div = 0.5 * (abs(L0) + abs(L))
+            if (L - L0) / div < tol:
+                if verbose:
+                    self.print("Converged at iteration %d." % (self.iter + 1))
+                self.converged = True
+        self.iter += 1
+        return self.converged

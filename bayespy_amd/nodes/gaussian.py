@@ -1,0 +1,50 @@
+"""
+GaussianARD node (reference: bayespy/inference/vmp/nodes/gaussian.py:1559-1774).
+
+``GaussianARD(mu, alpha, shape=(K,), plates=...)``: Gaussian with mean ``mu``
+and diagonal (ARD) prior precision ``alpha``; the posterior has a full
+``shape x shape`` covariance per plate.  Moments u = [<x>, <x x^T>]
+(gaussian.py:42-84); the joint (mu, alpha) parent of the reference
+(``WrapToGaussianGamma``, gaussian.py:2299-2371) is folded into the plan's
+kernels instead of being a separate deterministic node.
+"""
+from .node import Node, Stochastic
+from ..utils.shapes import broadcasted_shape
+
+
+class GaussianARD(Stochastic):
+
+    def __init__(self, mu, alpha, ndim=None, shape=None, plates=None, name=None):
+        super().__init__(mu, alpha, plates=(), dims=((), ()), name=name)
+        mu_node, alpha_node = self.parents
+        mu_shape = mu_node.plates + (mu_node.dims[0] if _is_gaussian(mu_node) else ())
+        if shape is None:
+            if ndim is None:
+                shape = mu_node.dims[0] if _is_gaussian(mu_node) else ()
+            else:
+                full = broadcasted_shape(mu_shape, alpha_node.plates)
+                shape = full[len(full) - ndim:] if ndim > 0 else ()
+        shape = tuple(int(s) for s in shape)
+        nd = len(shape)
+        self.shape = shape
+        self.ndim = nd
+        self.dims = (shape, shape + shape)
+        # plates the parents impose: their shapes minus the trailing `ndim` axes
+        # (gaussian.py:756-769)
+        def strip(s):
+            return tuple(s[:len(s) - nd]) if nd > 0 else tuple(s)
+        if _is_gaussian(mu_node):
+            mu_plates = mu_node.plates if len(mu_node.dims[0]) == nd else strip(mu_shape)
+        else:
+            mu_plates = strip(mu_shape)
+        alpha_plates = strip(alpha_node.plates)
+        given = tuple(plates) if plates is not None else ()
+        self.plates = broadcasted_shape(given, mu_plates, alpha_plates)
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates %s of the parents do not broadcast to plates %s'
+                             % ((mu_plates, alpha_plates), given))
+
+
+def _is_gaussian(node):
+    from .dot import SumMultiply
+    return isinstance(node, (GaussianARD, SumMultiply))

@@ -1,0 +1,153 @@
+"""
+Node-graph core: graph edges, plates, names, the hand-off to compiled plans.
+
+Host-side mirror of the reference's node protocol (``Node`` node.py:223,
+``Stochastic`` stochastic.py:83, ``Constant`` constant.py:13): the same
+constructor arguments (``plates=``, ``name=``), the same user-visible methods
+(``observe``, ``update``, ``get_moments``, ``lower_bound_contribution``,
+``initialize_from_value/random/prior``) and attributes (``plates``, ``dims``,
+``u``, ``observed``).  Unlike the reference, a node holds NO arrays on the
+host: all moments live in HBM inside the *plan* that ``VB`` compiled for the
+model block the node belongs to (``bayespy_amd/inference/plans``), and every
+method that touches numbers forwards to that plan, which launches HIP kernels
+through the C ABI.
+"""
+import numpy as np
+
+from ..utils.shapes import broadcasted_shape
+
+
+class Node:
+    """Base class of all nodes (reference: node.py:223-301)."""
+
+    _counter = 0
+
+    def __init__(self, *parents, plates=(), dims=(), name=None):
+        Node._counter += 1
+        self._uid = Node._counter
+        self.parents = [ensure_node(p) for p in parents]
+        self.children = []
+        self.plates = tuple(int(p) for p in plates)
+        self.dims = tuple(tuple(d) for d in dims)
+        self.name = name if name else '%s_%d' % (type(self).__name__, self._uid)
+        self._plan = None
+        for i, p in enumerate(self.parents):
+            p.children.append((self, i))
+
+    # -- plan hand-off ----------------------------------------------------------
+    def _require_plan(self):
+        if self._plan is None:
+            # A model becomes executable when VB(...) compiles it.  Build a
+            # throw-away engine so that stand-alone node calls work like in the
+            # reference (e.g. ``X.update()`` in a script without VB).
+            from ..inference.vb import compile_for_node
+            compile_for_node(self)
+        return self._plan
+
+    def get_moments(self):
+        """Host copies of the node's moments in the reference's shapes
+        (stochastic.py:172-175, deterministic.py:62-64)."""
+        return self._require_plan().get_moments(self)
+
+    @property
+    def u(self):
+        return self.get_moments()
+
+    def lower_bound_contribution(self, **kwargs):
+        return 0.0
+
+    def get_shape(self, i):
+        return self.plates + self.dims[i]
+
+    def __repr__(self):
+        return '<%s %r plates=%s>' % (type(self).__name__, self.name, self.plates)
+
+
+class Constant(Node):
+    """Fixed numeric parent (reference: constant.py:13-86)."""
+
+    def __init__(self, value, name=None):
+        self.value = np.asarray(value, dtype=np.float64)
+        super().__init__(plates=self.value.shape, dims=((),), name=name)
+
+    def is_scalar(self):
+        return self.value.size == 1
+
+    def scalar(self):
+        return float(self.value.reshape(-1)[0])
+
+    def get_moments(self):
+        return [self.value]
+
+
+def ensure_node(x):
+    """Numeric arguments become Constant nodes (node.py:360-376)."""
+    if isinstance(x, Node):
+        return x
+    return Constant(x)
+
+
+class Stochastic(Node):
+    """Base of the exponential-family nodes (stochastic.py:83-376,
+    expfamily.py:94-542)."""
+
+    def __init__(self, *parents, plates=(), dims=(), name=None):
+        super().__init__(*parents, plates=plates, dims=dims, name=name)
+        self.observed = False
+        self._data = None          # pending observation (host ndarray / device tensor)
+        self._mask = True
+        self._init = None          # pending initialisation: ('value', x) | ('random',) | None
+
+    # -- data / initialisation (expfamily.py:168-212, :369-398) ------------------
+    def observe(self, x, mask=True):
+        """Fix the node to data.  ``x`` may be a host ndarray or a fp64 tensor
+        already resident in HBM (then it is used in place)."""
+        if not (mask is True or (np.ndim(mask) == 0 and bool(mask))):
+            raise NotImplementedError(
+                'array observation masks (missing data) are not built yet; only the scalar '
+                'mask=True path of expfamily.py:369-398 is supported')
+        self._check_value_shape(x)
+        self._data = x
+        self._mask = True
+        self.observed = True
+        if self._plan is not None:
+            self._plan.invalidate(self)
+
+    def initialize_from_value(self, x):
+        self._check_value_shape(x)
+        self._init = ('value', x)
+        if self._plan is not None:
+            self._plan.invalidate(self)
+
+    def initialize_from_random(self):
+        self._init = ('random',)
+        if self._plan is not None:
+            self._plan.invalidate(self)
+
+    def initialize_from_prior(self):
+        self._init = None
+        if self._plan is not None:
+            self._plan.invalidate(self)
+
+    def _check_value_shape(self, x):
+        shape = tuple(x.shape) if hasattr(x, 'shape') else np.shape(x)
+        full = self.plates + self.dims[0]
+        try:
+            out = broadcasted_shape(shape, full)
+        except ValueError:
+            out = None
+        if out != full:
+            raise ValueError('Value of shape %s does not match node %s with plates+dims %s'
+                             % (shape, self.name, full))
+
+    # -- inference ------------------------------------------------------------------
+    def update(self):
+        """Recompute q(node) from the current moments of its Markov blanket
+        (stochastic.py:276-282).  Observed nodes are skipped like in the reference."""
+        if self.observed:
+            return
+        self._require_plan().update(self)
+
+    def lower_bound_contribution(self, **kwargs):
+        """E_q[log p(node | parents) - log q(node)] (expfamily.py:400-480)."""
+        return self._require_plan().lower_bound_contribution(self)

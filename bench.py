@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""
+bench.py -- VB iterations/sec of probabilistic PCA (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full VB iteration exactly as ``VB.update`` does it
+(vmp.py:154-172, :693-764): W, X, tau, alpha updated once in constructor order
+plus the full lower bound (one device->host read of the ELBO per iteration).
+Workload: BASELINE.json's metric config, PCA N=1e7, D=128, K=32, fully observed,
+fp64, synthetic data of demos/pca.py:70-74 generated on the device.  With N
+GPUs the observation plate N is sharded (strong scaling: the metric is quoted
+on N=1e7 at 1/2/4/8 GPUs) and the child->parent message sums are one RCCL
+all-reduce per iteration.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD
+                               # x 1024 SIMDs x 2.4 GHz); not tabulated in the microarch guide
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--n', type=int, default=10_000_000, help='total observation plate size')
+    p.add_argument('--d', type=int, default=128)
+    p.add_argument('--k', type=int, default=32)
+    p.add_argument('--scaling', choices=['strong', 'weak'], default='strong')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-sample-n', type=int, default=200_000)
+    return p.parse_args()
+
+
+def make_shard(torch, dev, n_local, D, K, seed, rank):
+    """Synthetic PCA data of BASELINE.md section 3 for this rank's shard, generated
+    on the device in chunks: y = w x + 0.1 eps, (D, n_local) with the plate contiguous."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)   # same w on all ranks
+    g.manual_seed(seed + 1000 * (rank + 1))
+    ld = (n_local + 1) // 2 * 2
+    y = torch.empty(D, ld, device=dev, dtype=torch.float64)
+    if ld != n_local:
+        y[:, n_local:].zero_()
+    step = 1 << 20
+    for s in range(0, n_local, step):
+        e = min(n_local, s + step)
+        x = torch.randn(K, e - s, generator=g, device=dev, dtype=torch.float64)
+        y[:, s:e] = w @ x
+        y[:, s:e] += 0.1 * torch.randn(D, e - s, generator=g, device=dev, dtype=torch.float64)
+    return y[:, :n_local]
+
+
+def cpu_baseline(D, K, n_sample, n_full):
+    """The NumPy oracle (kind 'port') timed on this box's host cores on a bounded
+    sample of the same workload; linear in N (measured linear)."""
+    import numpy as np
+    from oracle.pca import PCAOracle, make_pca_data
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    y, x0 = make_pca_data(n_sample, D, K, seed=42)
+    o = PCAOracle(y, x0, keep_x=True)
+    o.iterate(1)
+    iters = 3
+    t = time.time()
+    o.iterate(iters)
+    dt = (time.time() - t) / iters
+    it_s = 1.0 / (dt * (n_full / float(n_sample)))
+    return {
+        'value': it_s, 'unit': 'VB iterations/s', 'cores': int(cores), 'kind': 'port',
+        'sample': 'oracle/pca.py (NumPy fp64, BLAS GEMMs) on N=%d columns of the same D=%d,K=%d '
+                  'workload, %d timed iterations at %.3f s/iter, extrapolated linearly to N=%d; '
+                  'the unmodified reference measured 35.4 s/iter at N=1e5 on 8 vCPU '
+                  '(BASELINE.md section 2) = 2.8e-4 it/s at N=1e7' % (n_sample, D, K, iters, dt, n_full),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+
+    from bayespy_amd import nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.device import get_runtime
+
+    rt = get_runtime()
+    dev = rt.device
+    D, K = args.d, args.k
+    if args.scaling == 'strong':
+        n_total = args.n
+        lo = n_total * rank // world
+        hi = n_total * (rank + 1) // world
+        n_local = hi - lo
+    else:
+        n_local = args.n
+        n_total = args.n * world
+
+    y = make_shard(torch, dev, n_local, D, K, seed=42, rank=rank)
+
+    # ---- the model, written exactly like a BayesPy script (demos/pca.py:22-61) ----
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, n_local), name='X')
+    F = nodes.SumMultiply('i,i', W, X, name='F')
+    tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    X.initialize_from_random()
+    Y.observe(y)
+    Q = VB(Y, F, W, X, tau, alpha)
+    Q.ignore_bound_checks = True          # never stop early: time exactly K iterations
+    plan = Q.plans[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    Q.update(repeat=args.warmup, verbose=False)
+    plan.enable_timing(True)              # HIP events around the pass kernel, on its stream
+    pass_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        Q.update(repeat=1, verbose=False)
+        pass_ms.append(plan.last_pass_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    L = Q.L[:Q.iter]
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        it_s = args.steps / dt
+        avg_pass = sum(p[0] for p in pass_ms) / len(pass_ms)
+        avg_red = sum(p[1] for p in pass_ms) / len(pass_ms)
+        # algorithmic work of ONE launch of the dominant kernel (pca_pass_kernel) on this
+        # rank: SURVEY.md 8(d): bytes = 8 N (D+K), flops = 4 N D K + 2 N K^2
+        alg_bytes = 8.0 * n_local * (D + K)
+        alg_flops = 4.0 * n_local * D * K + 2.0 * n_local * K * K
+        tflops = alg_flops / (avg_pass * 1e-3) / 1e12
+        gbs = alg_bytes / (avg_pass * 1e-3) / 1e9
+        out = {
+            'metric': 'VB iterations/sec, PCA N=%d D=%d K=%d' % (n_total, D, K),
+            'value': it_s, 'unit': 'VB iterations/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': 'probabilistic PCA (GaussianARD+SumMultiply+Gamma), N=%d D=%d K=%d, '
+                            'fully observed, one VB iteration = W,X,tau,alpha updates + full ELBO'
+                            % (n_total, D, K),
+                'n_local': n_local, 'parallelism': 'plate-shard x%d' % world,
+            },
+            'elbo_first': float(L[0]), 'elbo_last': float(L[-1]),
+            'roofline': {
+                'kernel': 'pca_pass_kernel<4,2,true>' if (D, K) == (128, 32) else 'pca_pass_kernel',
+                'bound': 'mfma', 'achieved': tflops, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': tflops / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'avg_launch_ms': avg_pass, 'reduce_ms': avg_red,
+                'hbm_achieved_GBs': gbs, 'hbm_frac_of_8TBs': gbs / HBM_PEAK_GBS,
+                'alg_bytes_per_launch': alg_bytes, 'alg_flops_per_launch': alg_flops,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(D, K, min(args.cpu_sample_n, n_total), n_total)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""
+Generate the golden fixtures under tests/golden/ from the LIVE reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the authoring container, where the
+reference is mounted read-only at /root/reference; the GPU box never runs this.
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+The reference is imported unmodified, with two empty stub modules for its
+absent optional dependencies ``h5py`` (save/load only) and ``truncnorm``
+(observe_limits only) -- SURVEY.md section 8(c).
+
+Every fixture stores the exact inputs (data + injected initial moments) and the
+reference's outputs after each VB iteration, so both the numpy oracle
+(oracle/*.py) and the HIP path can be replayed on identical inputs.  RNG
+streams are not part of the contract: all random draws are made HERE with a
+seeded RandomState and stored.
+"""
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+REF = os.environ.get('BAYESPY_REFERENCE', '/root/reference')
+
+
+def _import_reference():
+    stubs = tempfile.mkdtemp(prefix='bpstubs_')
+    for name in ('h5py', 'truncnorm'):
+        os.makedirs(os.path.join(stubs, name))
+        open(os.path.join(stubs, name, '__init__.py'), 'w').close()
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, stubs)
+    os.environ.setdefault('MPLBACKEND', 'Agg')
+    warnings.simplefilter('ignore')
+    import bayespy  # noqa: F401
+    return bayespy
+
+
+def pca_case(name, N, D, K, n_iter, seed):
+    """bayespy/demos/pca.py:22-61, fully observed, X initialised from value."""
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy.inference import VB
+    rs = np.random.RandomState(seed)
+    w = rs.normal(0, 1, (D, K))
+    x = rs.normal(0, 1, (N, K))
+    y = w @ x.T + 0.1 * rs.normal(size=(D, N))
+    x0 = rs.normal(0, 1, (N, K))
+
+    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    F = SumMultiply('i,i', W, X, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None, :, :])
+    Y.observe(y)
+    Q = VB(Y, F, W, X, tau, alpha)
+    Q.ignore_bound_checks = True
+    Ls = []
+    terms = {k: [] for k in ('Y', 'X', 'W', 'tau', 'alpha')}
+    for _ in range(n_iter):
+        Q.update(repeat=1, verbose=False)
+        Ls.append(Q.L[Q.iter - 1])
+        for k in terms:
+            terms[k].append(Q.l[Q[k]][Q.iter - 1])
+    out = dict(
+        y=y, x0=x0, n_iter=n_iter, a0=1e-2, b0=1e-2,
+        L=np.array(Ls),
+        **{'L_' + k: np.array(v) for k, v in terms.items()},
+        W_u0=W.u[0], W_u1=W.u[1], W_phi0=W.phi[0], W_phi1=W.phi[1], W_g=W.g,
+        X_u0=X.u[0], X_u1_first=X.u[1][0, :3], X_phi1=X.phi[1], X_g=X.g,
+        tau_u0=tau.u[0], tau_u1=tau.u[1], tau_phi0=tau.phi[0], tau_phi1=tau.phi[1],
+        alpha_u0=alpha.u[0], alpha_u1=alpha.u[1],
+        alpha_phi0=alpha.phi[0], alpha_phi1=alpha.phi[1],
+        F_u0=F.get_moments()[0][:, :5], F_u1=F.get_moments()[1][:, :5],
+    )
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'L =', Ls)
+
+
+def quickstart_case(name, N, n_iter, seed):
+    """
+    Config 1 / doc/source/user_guide/quickstart.rst:8-13,41,111-118: unknown
+    mean and precision of a 1-D Gaussian.  With seed(1), N=10 the doc's known
+    answer is -6.020956e+01, -5.820527e+01, -5.820290e+01, -5.820288e+01.
+    """
+    from bayespy.nodes import GaussianARD, Gamma
+    from bayespy.inference import VB
+    np.random.seed(seed)
+    data = np.random.normal(5, 10, size=(N,))
+    mu = GaussianARD(0, 1e-6, name='mu')
+    tau = Gamma(1e-6, 1e-6, name='tau')
+    y = GaussianARD(mu, tau, plates=(N,), name='y')
+    y.observe(data)
+    Q = VB(y, mu, tau)
+    Q.ignore_bound_checks = True
+    Ls = []
+    mu_u, tau_u = [], []
+    for _ in range(n_iter):
+        Q.update(repeat=1, verbose=False)
+        Ls.append(Q.L[Q.iter - 1])
+        mu_u.append([float(mu.u[0]), float(mu.u[1])])
+        tau_u.append([float(tau.u[0]), float(tau.u[1])])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'),
+                        data=data, L=np.array(Ls), mu_u=np.array(mu_u),
+                        tau_u=np.array(tau_u), n_iter=n_iter)
+    print(name, 'L =', Ls)
+
+
+def gmm_case(name, N, D, K, n_iter, seed):
+    """bayespy/demos/mog.py:17-64 (full covariance), z initialised from value."""
+    from bayespy.nodes import (GaussianARD, Gaussian, Wishart, Dirichlet,
+                               Categorical, Mixture)
+    from bayespy.inference import VB
+    rs = np.random.RandomState(seed)
+    centers = 3 * rs.normal(size=(K, D))
+    lab = rs.randint(K, size=N)
+    y = centers[lab] + 0.5 * rs.normal(size=(N, D))
+    lab0 = rs.randint(K, size=N)
+
+    alpha = Dirichlet(1e-3 * np.ones(K), name='alpha')
+    z = Categorical(alpha, plates=(N,), name='z')
+    mu = GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
+    Lam = Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
+    Y = Mixture(z, Gaussian, mu, Lam, plates=(N,), name='Y')
+    z.initialize_from_value(lab0)
+    Y.observe(y)
+    Q = VB(Y, mu, Lam, z, alpha)
+    Q.ignore_bound_checks = True
+    Ls = []
+    terms = {k: [] for k in ('Y', 'mu', 'Lambda', 'z', 'alpha')}
+    for _ in range(n_iter):
+        Q.update(repeat=1, verbose=False)
+        Ls.append(Q.L[Q.iter - 1])
+        for k in terms:
+            terms[k].append(Q.l[Q[k]][Q.iter - 1])
+    out = dict(
+        y=y, lab0=lab0, n_iter=n_iter,
+        L=np.array(Ls),
+        **{'L_' + k: np.array(v) for k, v in terms.items()},
+        z_u0=z.u[0], z_phi0=z.phi[0], z_g=z.g,
+        mu_u0=mu.u[0], mu_u1=mu.u[1],
+        Lambda_u0=Lam.u[0], Lambda_u1=Lam.u[1],
+        Lambda_phi0=Lam.phi[0], Lambda_phi1=Lam.phi[1],
+        alpha_u0=alpha.u[0], alpha_phi0=alpha.phi[0],
+    )
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'L =', Ls)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    _import_reference()
+    quickstart_case('quickstart_n10', N=10, n_iter=4, seed=1)
+    quickstart_case('quickstart_n1000', N=1000, n_iter=6, seed=1)
+    pca_case('pca_n500_d6_k3', N=500, D=6, K=3, n_iter=5, seed=7)
+    pca_case('pca_n777_d20_k5', N=777, D=20, K=5, n_iter=5, seed=8)
+    pca_case('pca_n2048_d128_k32', N=2048, D=128, K=32, n_iter=4, seed=9)
+    pca_case('pca_n4000_d64_k16', N=4000, D=64, K=16, n_iter=4, seed=10)
+    gmm_case('gmm_n400_d3_k4', N=400, D=3, K=4, n_iter=5, seed=11)
+    gmm_case('gmm_n3000_d8_k16', N=3000, D=8, K=16, n_iter=4, seed=12)
+
+
+if __name__ == '__main__':
+    main()

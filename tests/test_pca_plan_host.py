@@ -1,0 +1,105 @@
+"""CPU: host logic of the PCA plan (pattern match, update order, lazy state,
+lower-bound cache) with the kernel test double, against the live-reference
+golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bayespy_amd.nodes as nodes
+from bayespy_amd.device import Runtime
+from bayespy_amd.inference import VB
+from bayespy_amd.inference.plans.pca import PCAPlan
+
+from fake_kernels import CPURuntimeKernels
+from models import build_pca
+
+
+def _attach_cpu(Q):
+    rt = Runtime(device='cpu')
+    for p in Q.plans:
+        p._rt = rt
+        p._kernels = CPURuntimeKernels(rt)
+    return Q
+
+
+@pytest.mark.parametrize('name', ['pca_n500_d6_k3', 'pca_n777_d20_k5'])
+def test_plan_reproduces_reference_trace(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    K = g['x0'].shape[1]
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], K))
+    Q.update(repeat=int(g['n_iter']), verbose=False)
+    np.testing.assert_allclose(Q.L[:Q.iter], g['L'], rtol=1e-10)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[k]][:Q.iter], g['L_' + k], rtol=1e-8, atol=1e-7)
+    assert np.all(Q.l[Q['F']][:Q.iter] == 0)
+    W, X, tau, alpha = Q['W'], Q['X'], Q['tau'], Q['alpha']
+    np.testing.assert_allclose(W.u[0], g['W_u0'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(W.u[1], g['W_u1'], rtol=1e-8, atol=1e-10)
+    assert W.u[0].shape == g['W_u0'].shape and X.u[0].shape == g['X_u0'].shape
+    np.testing.assert_allclose(X.u[0], g['X_u0'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(X.u[1][0, :3], g['X_u1_first'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(tau.u[0], g['tau_u0'], rtol=1e-10)
+    np.testing.assert_allclose(alpha.u[1], g['alpha_u1'], rtol=1e-9)
+
+
+def test_update_order_and_one_pass_per_iteration(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.update(repeat=2, verbose=False)
+    calls = Q.plans[0].kernels.calls
+    assert calls[0] == 'stats_from_x'
+    per_iter = ['update_w', 'prepare_x', 'pass', 'update_tau', 'update_alpha']
+    assert calls[1:] == per_iter * 2
+    # explicit node order, as VB.update(*nodes) allows (vmp.py:139-141)
+    Q.update(Q['X'], Q['W'], repeat=1, verbose=False)
+    assert Q.plans[0].kernels.calls[-3:] == ['prepare_x', 'pass', 'update_w']
+
+
+def test_lower_bound_cache_and_observed_skip(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q['Y'].update()           # observed -> no-op (stochastic.py:277)
+    assert Q.plans[0].kernels.calls == []
+    Q.update(repeat=1, verbose=False)
+    a = Q.compute_lowerbound()
+    b = Q.compute_lowerbound()
+    assert a == b == Q.L[0]
+
+
+def test_unsupported_models_fail_loudly():
+    K, D, N = 3, 4, 10
+    mu = nodes.GaussianARD(0, 1e-6, name='mu')
+    tau = nodes.Gamma(1e-6, 1e-6, name='tau')
+    y = nodes.GaussianARD(mu, tau, plates=(N,), name='y')
+    with pytest.raises(NotImplementedError, match='No HIP execution plan'):
+        VB(y, mu, tau)
+    # array masks are a later row of the scope table
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,))
+    W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, N))
+    Y = nodes.GaussianARD(nodes.Dot(W, X), nodes.Gamma(1e-2, 1e-2))
+    with pytest.raises(NotImplementedError):
+        Y.observe(np.zeros((D, N)), mask=np.ones((D, N), dtype=bool))
+    with pytest.raises(ValueError):
+        Y.observe(np.zeros((D + 1, N)))
+
+
+def test_plates_and_shapes_follow_reference_rules():
+    K, D, N = 5, 7, 11
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,))
+    W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, N))
+    F = nodes.SumMultiply('i,i', W, X)
+    Y = nodes.GaussianARD(F, nodes.Gamma(1e-2, 1e-2))
+    assert W.plates == (D, 1) and W.dims == ((K,), (K, K))
+    assert F.plates == (D, N) and F.dims == ((), ())
+    assert Y.plates == (D, N) and Y.dims == ((), ())
+    assert PCAPlan.match([Y, F, W, X]) is not None
+    F2 = nodes.SumMultiply(W, [0], X, [0])
+    assert F2.plates == (D, N) and F2.out_keys == []
+    # W and X now feed two blocks: no longer a private PCA block
+    assert PCAPlan.match([Y, F, W, X]) is None
+    with pytest.raises(ValueError):
+        nodes.SumMultiply('i,i', W, nodes.GaussianARD(0, 1, shape=(K + 1,), plates=(1, N)))

@@ -1,0 +1,109 @@
+// microbench.hip -- the two roofline denominators measured on the box itself:
+//   (1) fp64 MFMA issue loop (v_mfma_f64_16x16x4_f64)  -> TFLOP/s
+//   (2) HBM stream read / copy                          -> GB/s
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int NACC>
+__global__ void __launch_bounds__(256) mfma_loop(double *out, int iters)
+{
+    v4f64 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = v4f64{0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) fma_loop(double *out, int iters)
+{
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-9;
+    double x0 = 1, x1 = 2, x2 = 3, x3 = 4, x4 = 5, x5 = 6, x6 = 7, x7 = 8;
+    for (int it = 0; it < iters; ++it) {
+        x0 = fma(x0, b, a); x1 = fma(x1, b, a); x2 = fma(x2, b, a); x3 = fma(x3, b, a);
+        x4 = fma(x4, b, a); x5 = fma(x5, b, a); x6 = fma(x6, b, a); x7 = fma(x7, b, a);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
+__global__ void __launch_bounds__(256) stream_read(const v2f64 *in, double *out, size_t n)
+{
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        v2f64 v = in[i];
+        s += v.x + v.y;
+    }
+    if (s == 12345.678) out[0] = s;
+}
+
+__global__ void __launch_bounds__(256) stream_copy(const v2f64 *in, v2f64 *out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = in[i];
+}
+
+template <typename F>
+float time_ms(F f, int reps)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    printf("device: %s, CUs %d, clock %d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
+    double *out;
+    CK(hipMalloc(&out, 256 * 4096 * sizeof(double)));
+    const int iters = 20000;
+    for (int wgs = 1; wgs <= 2; ++wgs) {
+        int grid = p.multiProcessorCount * wgs;
+        float ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<4>, dim3(grid), dim3(256), 0, 0, out, iters); }, 3);
+        double flops = (double)grid * 4 /*waves*/ * iters * 4 /*acc*/ * 2.0 * 16 * 16 * 4;
+        printf("mfma_f64_16x16x4 4 acc, %d WG/CU: %.2f TFLOP/s (%.1f cycles/mfma/SIMD at 2.4GHz)\n", wgs,
+               flops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)iters * 4 * wgs));
+        ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<1>, dim3(grid), dim3(256), 0, 0, out, iters); }, 3);
+        flops = (double)grid * 4 * iters * 1 * 2.0 * 16 * 16 * 4;
+        printf("mfma_f64_16x16x4 1 acc (dependent), %d WG/CU: %.2f TFLOP/s (%.1f cycles/mfma)\n", wgs,
+               flops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)iters * wgs));
+    }
+    {
+        int grid = p.multiProcessorCount * 8;
+        float ms = time_ms([&] { hipLaunchKernelGGL(fma_loop, dim3(grid), dim3(256), 0, 0, out, iters); }, 3);
+        double flops = (double)grid * 256 * iters * 8 * 2.0;
+        printf("v_fma_f64 VALU: %.2f TFLOP/s\n", flops / ms / 1e9);
+    }
+    size_t bytes = (size_t)4 << 30;
+    v2f64 *a, *b;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
+    size_t n = bytes / sizeof(v2f64);
+    for (int g = 1024; g <= 8192; g *= 2) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(stream_read, dim3(g), dim3(256), 0, 0, a, out, n); }, 5);
+        float mc = time_ms([&] { hipLaunchKernelGGL(stream_copy, dim3(g), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("grid %5d: stream read %.0f GB/s, copy (r+w) %.0f GB/s\n", g, bytes / ms / 1e6, 2.0 * bytes / mc / 1e6);
+    }
+    return 0;
+}
