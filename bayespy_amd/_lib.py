@@ -48,7 +48,7 @@ def raise_for_status(rc, msg=''):
 class PCALayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in (
         'DP', 'KP', 'off_S', 'len_S', 'off_Syy', 'off_tau', 'off_alpha', 'off_W',
-        'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_scal', 'off_L', 'total')]
+        'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_G', 'off_scal', 'off_L', 'total')]
 
 
 c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -78,6 +78,8 @@ SIGNATURES = {
     'vmp_pca_update_w': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp]),
     'vmp_pca_prepare_x': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_vp]),
     'vmp_pca_pass': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'vmp_pca_xpass': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'vmp_pca_gram': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'vmp_pca_update_tau': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_vp]),
     'vmp_pca_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_vp]),
     'vmp_pca_lower_bound': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,

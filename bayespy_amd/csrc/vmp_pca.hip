@@ -1,5 +1,12 @@
 // vmp_pca.hip -- fused probabilistic-PCA / factor-analysis VB block for gfx950.
 //
+// Two forms of X.update()'s plate work are built:
+//   * vmp_pca_xpass  (default): X = A Y only; the messages to W come from the
+//     constant Gram matrix G = Y Y^T (HBM-bound: read Y once, write <x>);
+//   * vmp_pca_pass   (streaming statistics): additionally accumulates
+//     sum y<x>^T and sum <x><x>^T on the fly (fp64-MFMA-bound) -- also the kernel
+//     that builds G and the statistics of a given X.
+//
 // Replaces, for the model block of bayespy/demos/pca.py:22-61 with a scalar
 // observation mask, the NumPy call sites E1-E11, E14, E16, E17 of SURVEY.md 2.2:
 //   dot.py:355,403,581 (SumMultiply moments + messages),
@@ -54,6 +61,7 @@ inline void fill_layout(int D, int K, vmp_pca_layout *L)
     L->off_Sww = o;    o += KP * KP;
     L->off_CX = o;     o += KP * KP;
     L->off_A = o;      o += KP * DP;
+    L->off_G = o;      o += DP * DP;
     L->off_scal = o;   o += 8;
     L->off_L = o;      o += 8;
     L->total = (o + 7) / 8 * 8;
@@ -279,59 +287,195 @@ sum_partials_kernel(const double *__restrict__ partial, int n, double *__restric
 }
 
 // ---------------------------------------------------------------------------
-// Small replicated-node kernels: ONE workgroup each, everything in LDS.
+// X.update(), plate half, Gram form: X = A Y, nothing else.  HBM-bound.
+//
+// With a scalar mask the posterior mean of every x_n is the SAME linear map of
+// y_n, so the messages to W collapse onto the constant Gram matrix G = Y Y^T:
+//     sum_n y_n <x_n>^T   = G A^T,      sum_n <x_n><x_n>^T = A G A^T
+// (SURVEY.md 2.2 notes the same collapse for E2).  The per-iteration plate work
+// is then exactly SURVEY.md 8(d)'s algorithmic traffic: read Y once, write <x>.
+//
+// Each wavefront owns 32-column tiles and never touches LDS for Y: lane
+// (l15, l4) loads the 16 bytes Y[4q + l4][n0 + 2 l15 .. +1], whose two halves are
+// the B operands of two MFMAs (even / odd columns), and stores 16 bytes of X per
+// accumulator register.  A (K x D, L2 resident) sits in LDS in fragment order.
 // ---------------------------------------------------------------------------
-constexpr int LD = MAX_KP + 1;
+//
+// GUARD = false: only full 32-column tiles, D == DP and K == KP -- no predication
+// anywhere in the loop; GUARD = true handles ragged D, K and the last partial tile.
+template <int DB, int KT, bool GUARD, int OCC>
+__global__ void __launch_bounds__(NT, OCC)
+pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
+                 const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
+                 int64_t tile0, int64_t tile1)
+{
+    constexpr int DP = 32 * DB, KP = 16 * KT;
+    constexpr int KS = DP / 4;                 // MFMA k-steps per tile
+    constexpr int NCH = (DB < 2) ? 2 : DB;     // chunks per tile (even)
+    constexpr int CH = KS / NCH;               // k-steps per chunk
 
-// In-place inverse of the SPD n x n matrix M (LDS, row-major ld LD) through a
-// Cholesky factor (utils/linalg.py:31-63 chol, :174-207 chol_inv, :209-223
-// chol_logdet).  Li is LDS scratch of the same size.  On exit M = inverse,
-// *logdet = log|M_in|; *bad is set when M_in is not positive definite.
-__device__ void spd_inverse_lds(double *M, double *Li, int n, double *logdet, int *bad)
+    __shared__ double Af[KT * KS * 64];        // A fragments: [(it*KS + q)*64 + lane]
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int l15 = l & 15, l4 = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, scalar
+
+    for (int e = tid; e < KT * KS * 64; e += NT) {
+        const int lane = e & 63, fq = e >> 6;
+        const int it = fq / KS, q = fq - it * KS;
+        Af[e] = Apad[(int64_t)(it * 16 + (lane & 15)) * DP + 4 * q + (lane >> 4)];
+    }
+    __syncthreads();
+
+    const double *Afl = Af + l;
+    // per-lane byte offsets (32-bit; the host checks 3*ld*8 + 256 < 2^32): the
+    // wave-uniform part of every address stays in SGPRs
+    const uint32_t yoff = (uint32_t)(((int64_t)l4 * ldy + 2 * l15) * 8);
+    const uint32_t xoff = (uint32_t)(((int64_t)l4 * ldx + 2 * l15) * 8);
+
+    v2f64 buf[2][CH];
+    const int64_t stride = (int64_t)gridDim.x * 4;
+
+    auto issue = [&](int64_t tile, int c, v2f64 *dst) {
+        const char *base = reinterpret_cast<const char *>(Y)
+                           + ((tile * TN + (int64_t)(4 * c * CH) * ldy) << 3);
+        if (!GUARD) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                dst[i] = *reinterpret_cast<const v2f64 *>(base + ((int64_t)(4 * i) * ldy << 3)
+                                                          + yoff);
+        } else {
+            const int64_t n = tile * TN + 2 * l15;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int row = 4 * (c * CH + i) + l4;
+                v2f64 v = v2f64{0.0, 0.0};
+                if (row < D) {
+                    const double *src = reinterpret_cast<const double *>(
+                        base + ((int64_t)(4 * i) * ldy << 3) + yoff);
+                    if (n + 1 < N) v = *reinterpret_cast<const v2f64 *>(src);
+                    else if (n < N) v.x = src[0];
+                }
+                dst[i] = v;
+            }
+        }
+    };
+
+    int64_t tile = tile0 + (int64_t)blockIdx.x * 4 + w;
+    if (tile < tile1) issue(tile, 0, buf[0]);
+
+    for (; tile < tile1; tile += stride) {
+        v4f64 acc[KT][2];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            acc[it][0] = v4f64{0.0, 0.0, 0.0, 0.0};
+            acc[it][1] = v4f64{0.0, 0.0, 0.0, 0.0};
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // prefetch the next chunk (the next tile's first chunk at the end) so
+            // that its loads are in flight while this chunk's MFMAs run
+            if (c + 1 < NCH) issue(tile, c + 1, buf[(c + 1) & 1]);
+            else if (tile + stride < tile1) issue(tile + stride, 0, buf[(c + 1) & 1]);
+            // compiler-only barrier: keeps the fragment reads of A inside the loop
+            // (otherwise all KT*KS of them are hoisted into spilled registers)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int q = c * CH + i;
+                const v2f64 b = buf[c & 1][i];
+#pragma unroll
+                for (int it = 0; it < KT; ++it) {
+                    const double a = Afl[(it * KS + q) * 64];
+                    acc[it][0] = mfma_f64(a, b.x, acc[it][0]);
+                    acc[it][1] = mfma_f64(a, b.y, acc[it][1]);
+                }
+            }
+        }
+        // C/D layout: col = lane&15 -> column pair, row = (lane>>4) + 4*reg -> k
+        char *xbase = reinterpret_cast<char *>(X) + ((tile * TN) << 3);
+        if (!GUARD) {
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<v2f64 *>(xbase + ((int64_t)(it * 16 + 4 * r) * ldx << 3)
+                                               + xoff) = v2f64{acc[it][0][r], acc[it][1][r]};
+        } else {
+            const int64_t n = tile * TN + 2 * l15;
+#pragma unroll
+            for (int it = 0; it < KT; ++it) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = it * 16 + l4 + 4 * r;
+                    if (k < K) {
+                        double *dst = reinterpret_cast<double *>(
+                            xbase + ((int64_t)(it * 16 + 4 * r) * ldx << 3) + xoff);
+                        if (n + 1 < N)
+                            *reinterpret_cast<v2f64 *>(dst) = v2f64{acc[it][0][r], acc[it][1][r]};
+                        else if (n < N)
+                            dst[0] = acc[it][0][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Small replicated-node kernels.  Single-workgroup kernels use 1024 threads and
+// keep every K x K object in LDS.
+// ---------------------------------------------------------------------------
+constexpr int NTS = 1024;
+constexpr int LD = MAX_KP + 1;
+constexpr int EPT = MAX_KP * MAX_KP / NTS;   // K*K elements per thread (4)
+constexpr int RB = 64;                       // row block of the D x K products
+
+// In-place inverse of the SPD n x n matrix M (LDS, row-major, ld LD) by
+// pivot-free Gauss-Jordan sweeps (all n^2 elements updated in parallel per
+// pivot; stable for SPD input).  Replaces the per-matrix SciPy calls
+// chol / chol_inv / chol_logdet (utils/linalg.py:31-63, :174-223).
+// *logdet = log|M_in| ; *bad set when a pivot is not positive.
+__device__ void spd_inverse_gj(double *M, int n, double *logdet, int *bad)
 {
     const int tid = threadIdx.x;
-    for (int j = 0; j < n; ++j) {
+    double ld = 0.0;
+    for (int p = 0; p < n; ++p) {
         __syncthreads();
+        const double piv = M[p * LD + p];
+        double ci[EPT], rj[EPT], me[EPT];
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int e = tid + m * NTS;
+            if (e < n * n) {
+                const int i = e / n, j = e - i * n;
+                ci[m] = M[i * LD + p];
+                rj[m] = M[p * LD + j];
+                me[m] = M[i * LD + j];
+            }
+        }
         if (tid == 0) {
-            double s = M[j * LD + j];
-            for (int k = 0; k < j; ++k) s -= M[j * LD + k] * M[j * LD + k];
-            if (!(s > 0.0)) { *bad = 1; s = 1.0; }
-            M[j * LD + j] = sqrt(s);
+            if (!(piv > 0.0)) *bad = 1;
+            ld += log(piv);
         }
+        const double d = 1.0 / piv;
         __syncthreads();
-        const double djj = M[j * LD + j];
-        for (int i = j + 1 + tid; i < n; i += NT) {
-            double s = M[i * LD + j];
-            for (int k = 0; k < j; ++k) s -= M[i * LD + k] * M[j * LD + k];
-            M[i * LD + j] = s / djj;
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int e = tid + m * NTS;
+            if (e < n * n) {
+                const int i = e / n, j = e - i * n;
+                double v;
+                if (i == p) v = (j == p) ? d : rj[m] * d;
+                else if (j == p) v = -ci[m] * d;
+                else v = me[m] - ci[m] * rj[m] * d;
+                M[i * LD + j] = v;
+            }
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += log(M[j * LD + j]);
-        *logdet = 2.0 * s;
-    }
-    // Li = L^-1 (lower triangular), one column per thread by forward substitution
-    if (tid < n) {
-        const int c = tid;
-        for (int i = 0; i < c; ++i) Li[i * LD + c] = 0.0;
-        Li[c * LD + c] = 1.0 / M[c * LD + c];
-        for (int i = c + 1; i < n; ++i) {
-            double s = 0.0;
-            for (int k = c; k < i; ++k) s += M[i * LD + k] * Li[k * LD + c];
-            Li[i * LD + c] = -s / M[i * LD + i];
-        }
-    }
-    __syncthreads();
-    // M = Li^T Li
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e - i * n;
-        const int k0 = i > j ? i : j;
-        double s = 0.0;
-        for (int k = k0; k < n; ++k) s += Li[k * LD + i] * Li[k * LD + j];
-        M[i * LD + j] = s;
-    }
+    if (tid == 0) *logdet = ld;
     __syncthreads();
 }
 
@@ -363,45 +507,74 @@ pca_init_state_kernel(vmp_pca_layout L, int K, double a0t, double b0t, double a0
     }
 }
 
-__global__ void __launch_bounds__(NT)
+// W.update(): Lambda_W = diag<alpha> + <tau> Sxx ; Cov_W ; <W> = <tau> Syx Cov_W ;
+// Sww = D Cov_W + W^T W.
+__global__ void __launch_bounds__(NTS)
 pca_update_w_kernel(vmp_pca_layout L, int D, int K, double n_total, double *st)
 {
     __shared__ double M[MAX_KP * LD];
-    __shared__ double Li[MAX_KP * LD];
+    __shared__ double Sb[RB * LD];     // block of Syx rows
+    __shared__ double Wb[RB * LD];     // block of W rows
     __shared__ double logdet;
     __shared__ int bad;
     const int tid = threadIdx.x;
     const int KP = (int)L.KP;
     if (tid == 0) bad = 0;
     const double tau = st[L.off_tau + 2];
-    // Lambda_W = diag<alpha> + <tau> sum_n <x x^T>      (gaussian.py:656-670 + dot.py:581)
-    for (int e = tid; e < K * K; e += NT) {
+    // gaussian.py:656-670 (prior phi) + dot.py:581 (message E4)
+    for (int e = tid; e < K * K; e += NTS) {
         const int i = e / K, j = e - i * K;
         double v = tau * sxx_total(st, L, n_total, i, j);
         if (i == j) v += st[L.off_alpha + 2 * KP + i];
         M[i * LD + j] = v;
     }
-    spd_inverse_lds(M, Li, K, &logdet, &bad);
-    for (int e = tid; e < K * K; e += NT) {
+    spd_inverse_gj(M, K, &logdet, &bad);
+    for (int e = tid; e < K * K; e += NTS) {
         const int i = e / K, j = e - i * K;
         st[L.off_CW + i * KP + j] = M[i * LD + j];
     }
-    // <W> = <tau> Syx Cov_W                              (gaussian.py:694)
     const double *Syx = st + L.off_S;
     double *W = st + L.off_W;
-    for (int e = tid; e < D * K; e += NT) {
-        const int d = e / K, k = e - d * K;
-        double s = 0.0;
-        for (int j = 0; j < K; ++j) s += Syx[d * KP + j] * M[j * LD + k];
-        W[d * KP + k] = tau * s;
+    double sw[EPT];
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) sw[m] = 0.0;
+    for (int r0 = 0; r0 < D; r0 += RB) {
+        const int nr = (D - r0) < RB ? (D - r0) : RB;
+        __syncthreads();
+        for (int e = tid; e < nr * K; e += NTS) {
+            const int r = e / K, k = e - r * K;
+            Sb[r * LD + k] = Syx[(r0 + r) * KP + k];
+        }
+        __syncthreads();
+        // <w_d> = Cov_W phi0_d,  phi0_d = <tau> Syx[d]        (gaussian.py:694)
+        for (int e = tid; e < nr * K; e += NTS) {
+            const int r = e / K, k = e - r * K;
+            double s = 0.0;
+            for (int j = 0; j < K; ++j) s += Sb[r * LD + j] * M[j * LD + k];
+            s *= tau;
+            Wb[r * LD + k] = s;
+            W[(r0 + r) * KP + k] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int e = tid + m * NTS;
+            if (e < K * K) {
+                const int i = e / K, j = e - i * K;
+                double s = 0.0;
+                for (int r = 0; r < nr; ++r) s += Wb[r * LD + i] * Wb[r * LD + j];
+                sw[m] += s;
+            }
+        }
     }
-    __syncthreads();
-    // Sww = sum_d <w_d w_d^T> = D Cov_W + W^T W          (gaussian.py:695)
-    for (int e = tid; e < K * K; e += NT) {
-        const int i = e / K, j = e - i * K;
-        double s = 0.0;
-        for (int d = 0; d < D; ++d) s += W[d * KP + i] * W[d * KP + j];
-        st[L.off_Sww + i * KP + j] = (double)D * M[i * LD + j] + s;
+    // Sww = sum_d <w_d w_d^T> = D Cov_W + W^T W                (gaussian.py:695)
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) {
+        const int e = tid + m * NTS;
+        if (e < K * K) {
+            const int i = e / K, j = e - i * K;
+            st[L.off_Sww + i * KP + j] = (double)D * M[i * LD + j] + sw[m];
+        }
     }
     if (tid == 0) {
         st[L.off_scal + 0] = logdet;
@@ -409,36 +582,45 @@ pca_update_w_kernel(vmp_pca_layout L, int D, int K, double n_total, double *st)
     }
 }
 
-__global__ void __launch_bounds__(NT)
+// X.update(), replicated half: Lambda_X = x_prec I + <tau> Sww ; Cov_X ; A = <tau> Cov_X W^T.
+__global__ void __launch_bounds__(NTS)
 pca_prepare_x_kernel(vmp_pca_layout L, int D, int K, double x_prec, double *st)
 {
     __shared__ double M[MAX_KP * LD];
-    __shared__ double Li[MAX_KP * LD];
+    __shared__ double Wb[RB * LD];
     __shared__ double logdet;
     __shared__ int bad;
     const int tid = threadIdx.x;
     const int KP = (int)L.KP, DP = (int)L.DP;
     if (tid == 0) bad = 0;
     const double tau = st[L.off_tau + 2];
-    // Lambda_X = x_prec I + <tau> sum_d <w_d w_d^T>
-    for (int e = tid; e < K * K; e += NT) {
+    for (int e = tid; e < K * K; e += NTS) {
         const int i = e / K, j = e - i * K;
         double v = tau * 0.5 * (st[L.off_Sww + i * KP + j] + st[L.off_Sww + j * KP + i]);
         if (i == j) v += x_prec;
         M[i * LD + j] = v;
     }
-    spd_inverse_lds(M, Li, K, &logdet, &bad);
-    for (int e = tid; e < K * K; e += NT) {
+    spd_inverse_gj(M, K, &logdet, &bad);
+    for (int e = tid; e < K * K; e += NTS) {
         const int i = e / K, j = e - i * K;
         st[L.off_CX + i * KP + j] = M[i * LD + j];
     }
-    // A = <tau> Cov_X <W>^T   (K x D, zero padded to KP x DP)
     const double *W = st + L.off_W;
-    for (int e = tid; e < K * D; e += NT) {
-        const int k = e / D, d = e - k * D;
-        double s = 0.0;
-        for (int j = 0; j < K; ++j) s += M[k * LD + j] * W[d * KP + j];
-        st[L.off_A + (int64_t)k * DP + d] = tau * s;
+    for (int r0 = 0; r0 < D; r0 += RB) {
+        const int nr = (D - r0) < RB ? (D - r0) : RB;
+        __syncthreads();
+        for (int e = tid; e < nr * K; e += NTS) {
+            const int r = e / K, k = e - r * K;
+            Wb[r * LD + k] = W[(r0 + r) * KP + k];
+        }
+        __syncthreads();
+        // A[k][d] = <tau> sum_j Cov_X[k][j] W[d][j]
+        for (int e = tid; e < nr * K; e += NTS) {
+            const int k = e / nr, r = e - k * nr;
+            double s = 0.0;
+            for (int j = 0; j < K; ++j) s += M[k * LD + j] * Wb[r * LD + j];
+            st[L.off_A + (int64_t)k * DP + r0 + r] = tau * s;
+        }
     }
     if (tid == 0) {
         st[L.off_scal + 1] = logdet;
@@ -446,33 +628,87 @@ pca_prepare_x_kernel(vmp_pca_layout L, int D, int K, double x_prec, double *st)
     }
 }
 
+// Messages to W from the Gram matrix: workgroup b owns GR rows of G.
+//   Syx[r][k]      = sum_d G[r][d] A[k][d]
+//   Pxx_b[k][k']   = sum_{r in b} A[k][r] Syx[r][k']     (reduced in fixed order later)
+constexpr int GR = 8;
+__global__ void __launch_bounds__(NT)
+pca_gram_stats_kernel(vmp_pca_layout L, int D, int K, const double *__restrict__ st_in,
+                      double *__restrict__ st, double *__restrict__ P)
+{
+    extern __shared__ double lds[];
+    const int DP = (int)L.DP, KP = (int)L.KP;
+    const int LA = DP + 1;
+    double *As = lds;                    // KP x LA
+    double *Gs = As + KP * LA;           // GR x DP
+    double *Ss = Gs + GR * DP;           // GR x LD
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * GR;
+    const double *A = st_in + L.off_A;
+    const double *G = st_in + L.off_G;
+    for (int e = tid; e < K * DP; e += NT) {
+        const int k = e / DP, d = e - k * DP;
+        As[k * LA + d] = A[(int64_t)k * DP + d];
+    }
+    for (int e = tid; e < GR * DP; e += NT) Gs[e] = G[(int64_t)r0 * DP + e];
+    __syncthreads();
+    for (int e = tid; e < GR * K; e += NT) {
+        const int r = e / K, k = e - r * K;
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += Gs[r * DP + d] * As[k * LA + d];
+        Ss[r * LD + k] = s;
+        if (r0 + r < D) st[L.off_S + (int64_t)(r0 + r) * KP + k] = s;
+    }
+    __syncthreads();
+    double *Pb = P + (int64_t)blockIdx.x * KP * KP;
+    for (int e = tid; e < KP * KP; e += NT) {
+        const int k = e / KP, k2 = e - k * KP;
+        double s = 0.0;
+        if (k < K && k2 < K) {
+#pragma unroll
+            for (int r = 0; r < GR; ++r) s += As[k * LA + r0 + r] * Ss[r * LD + k2];
+        }
+        Pb[e] = s;
+    }
+}
+
+// G[:, j0:j0+Kx] <- block of the statistics kernel's output (set-up only).
+__global__ void __launch_bounds__(NT)
+pca_gram_copy_kernel(const double *__restrict__ Stmp, int KPx, int D, int Kx, int j0, int DP,
+                     double *__restrict__ G)
+{
+    const int e = blockIdx.x * NT + threadIdx.x;
+    if (e >= D * Kx) return;
+    const int i = e / Kx, j = e - i * Kx;
+    G[(int64_t)i * DP + j0 + j] = Stmp[(int64_t)i * KPx + j];
+}
+
 // sum_dn <(y_dn - f_dn)^2> = Syy - 2 sum(W o Syx) + sum(Sww o Sxx)
 // (dot.py:355 E1 and dot.py:403 E2 collapsed to traces).
+template <int NTH>
 __device__ double pca_residual(const double *st, const vmp_pca_layout &L, int D, int K,
                                double n_total, double *red)
 {
     const int tid = threadIdx.x;
     const int KP = (int)L.KP;
     double t1 = 0.0, t2 = 0.0;
-    for (int e = tid; e < D * K; e += NT) {
-        const int d = e / K, k = e - d * K;
-        t1 += st[L.off_W + d * KP + k] * st[L.off_S + d * KP + k];
-    }
-    for (int e = tid; e < K * K; e += NT) {
+    // padded entries of W are zero, so the D x KP blocks can be walked linearly
+    for (int e = tid; e < D * KP; e += NTH) t1 += st[L.off_W + e] * st[L.off_S + e];
+    for (int e = tid; e < K * K; e += NTH) {
         const int i = e / K, j = e - i * K;
         t2 += st[L.off_Sww + i * KP + j] * sxx_total(st, L, n_total, i, j);
     }
-    t1 = block_sum<NT>(t1, red);
-    t2 = block_sum<NT>(t2, red);
+    t1 = block_sum<NTH>(t1, red);
+    t2 = block_sum<NTH>(t2, red);
     return st[L.off_Syy] - 2.0 * t1 + t2;
 }
 
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NTS)
 pca_update_tau_kernel(vmp_pca_layout L, int D, int K, double n_total, double a0, double b0,
                       double *st)
 {
-    __shared__ double red[NT / 64];
-    const double resid = pca_residual(st, L, D, K, n_total, red);
+    __shared__ double red[NTS / 64];
+    const double resid = pca_residual<NTS>(st, L, D, K, n_total, red);
     if (threadIdx.x == 0) {
         // gamma.py:116-122 phi = [-b, a] with the message gaussian.py:2363-2369
         const double a = a0 + 0.5 * (double)D * n_total;
@@ -510,16 +746,17 @@ __device__ inline double gamma_elbo(double a0, double b0, double a, double b, do
     return g_p - g_q + (b - b0) * x + (a0 - a) * logx;
 }
 
-__global__ void __launch_bounds__(NT)
+constexpr int NTL = 512;
+__global__ void __launch_bounds__(NTL)
 pca_lower_bound_kernel(vmp_pca_layout L, int D, int K, double n_total, double x_prec,
                        double a0t, double b0t, double a0a, double b0a, double *st)
 {
-    __shared__ double red[NT / 64];
+    __shared__ double red[NTL / 64];
     const int tid = threadIdx.x;
     const int KP = (int)L.KP;
-    const double resid = pca_residual(st, L, D, K, n_total, red);
+    const double resid = pca_residual<NTL>(st, L, D, K, n_total, red);
     double trx = 0.0, sla = 0.0, saw = 0.0, lal = 0.0;
-    for (int k = tid; k < K; k += NT) {
+    for (int k = tid; k < K; k += NTL) {
         const double a = st[L.off_alpha + 0 * KP + k], b = st[L.off_alpha + 1 * KP + k];
         const double al = st[L.off_alpha + 2 * KP + k], la = st[L.off_alpha + 3 * KP + k];
         trx += sxx_total(st, L, n_total, k, k);
@@ -527,10 +764,10 @@ pca_lower_bound_kernel(vmp_pca_layout L, int D, int K, double n_total, double x_
         saw += al * st[L.off_Sww + k * KP + k];
         lal += gamma_elbo(a0a, b0a, a, b, al, la);
     }
-    trx = block_sum<NT>(trx, red);
-    sla = block_sum<NT>(sla, red);
-    saw = block_sum<NT>(saw, red);
-    lal = block_sum<NT>(lal, red);
+    trx = block_sum<NTL>(trx, red);
+    sla = block_sum<NTL>(sla, red);
+    saw = block_sum<NTL>(saw, red);
+    lal = block_sum<NTL>(lal, red);
     if (tid == 0) {
         const double tau = st[L.off_tau + 2], logtau = st[L.off_tau + 3];
         const double Dd = (double)D, Kd = (double)K;
@@ -552,24 +789,44 @@ pca_lower_bound_kernel(vmp_pca_layout L, int D, int K, double n_total, double x_
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
+int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    int v = e ? atoi(e) : dflt;
+    if (v < lo) v = lo;
+    if (v > hi) v = hi;
+    return v;
+}
+
 int wgs_per_cu()
 {
     static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("VMP_PCA_WGS_PER_CU");
-        v = e ? atoi(e) : 2;
-        if (v < 1) v = 1;
-        if (v > 8) v = 8;
-    }
+    if (v < 0) v = env_int("VMP_PCA_WGS_PER_CU", 2, 1, 8);
+    return v;
+}
+
+int xpass_wgs_per_cu()
+{
+    static int v = -1;
+    if (v < 0) v = env_int("VMP_PCA_XPASS_WGS_PER_CU", 3, 1, 8);
+    return v;
+}
+
+int xpass_occupancy()
+{
+    static int v = -1;
+    if (v < 0) v = env_int("VMP_PCA_XPASS_OCC", 3, 2, 3);
     return v;
 }
 
 int64_t max_grid(vmp_ctx *ctx) { return (int64_t)ctx->num_cu * wgs_per_cu(); }
 
+int64_t partial_len(const vmp_pca_layout &L) { return (L.DP + MAX_KP) * MAX_KP; }
+
 template <int DB, int KT>
-void launch_pass(bool compute_x, dim3 grid, hipStream_t s, const double *Y, int64_t ldy,
-                 int64_t N, int D, int K, const double *A, double *X, int64_t ldx, double *P,
-                 int64_t ntiles)
+void launch_fused(bool compute_x, dim3 grid, hipStream_t s, const double *Y, int64_t ldy,
+                  int64_t N, int D, int K, const double *A, double *X, int64_t ldx, double *P,
+                  int64_t ntiles)
 {
     if (compute_x)
         hipLaunchKernelGGL((pca_pass_kernel<DB, KT, true>), grid, dim3(NT), 0, s, Y, ldy, N, D, K,
@@ -579,49 +836,88 @@ void launch_pass(bool compute_x, dim3 grid, hipStream_t s, const double *Y, int6
                            K, A, X, ldx, P, ntiles);
 }
 
-int32_t run_pass(vmp_ctx *ctx, bool compute_x, const double *Y, int64_t ldy, int64_t N, int D,
-                 int K, double *X, int64_t ldx, double *state, void *workspace)
+#define VMP_FOR_EACH_INSTANCE(M)                                       \
+    M(1, 1) M(2, 1) M(4, 1) M(8, 1) M(1, 2) M(2, 2) M(4, 2) M(8, 2)    \
+    M(1, 4) M(2, 4) M(4, 4) M(8, 4)
+
+int32_t check_pass_args(vmp_ctx *ctx, const void *Y, const void *X, const void *state,
+                        const void *workspace, int64_t ldy, int64_t ldx, int64_t N, int D, int K)
 {
     VMP_REQUIRE(ctx, ctx != nullptr, VMP_ERR_INVALID, "null context");
     VMP_REQUIRE(ctx, Y && X && state && workspace, VMP_ERR_INVALID, "null pointer argument");
     VMP_REQUIRE(ctx, D >= 1 && K >= 1 && N >= 0, VMP_ERR_INVALID, "bad dims D=%d K=%d N=%lld", D,
                 K, (long long)N);
     VMP_REQUIRE(ctx, D <= MAX_DP && K <= MAX_KP, VMP_ERR_UNSUPPORTED,
-                "fused PCA pass supports D <= %d, K <= %d (got D=%d, K=%d)", MAX_DP, MAX_KP, D, K);
+                "fused PCA block supports D <= %d, K <= %d (got D=%d, K=%d)", MAX_DP, MAX_KP, D, K);
     VMP_REQUIRE(ctx, ldy >= N && ldx >= N, VMP_ERR_INVALID, "leading dimension smaller than N");
     VMP_REQUIRE(ctx, (ldy % 2) == 0 && ((uintptr_t)Y % 16) == 0, VMP_ERR_INVALID,
                 "Y must be 16-byte aligned with an even leading dimension (ldy=%lld)",
                 (long long)ldy);
-    vmp_pca_layout L;
-    fill_layout(D, K, &L);
-    const int DB = (int)(L.DP / 32), KT = (int)(L.KP / 16);
+    VMP_REQUIRE(ctx, (ldx % 2) == 0 && ((uintptr_t)X % 16) == 0, VMP_ERR_INVALID,
+                "X must be 16-byte aligned with an even leading dimension (ldx=%lld)",
+                (long long)ldx);
+    VMP_REQUIRE(ctx, ldy < (int64_t)170000000 && ldx < (int64_t)170000000, VMP_ERR_UNSUPPORTED,
+                "leading dimension >= 1.7e8 elements per shard is not supported "
+                "(32-bit lane offsets); shard the plate over more ranks");
+    return VMP_OK;
+}
+
+// The statistics kernel: out_S ((DPy+KPx) x KPx) <- [Y Xs^T ; Xs Xs^T] (or the
+// fused compute_x form).  Xs has Kx rows.
+int32_t run_stats(vmp_ctx *ctx, bool compute_x, const double *Y, int64_t ldy, int64_t N, int D,
+                  int Kx, double *Xs, int64_t ldx, const double *A, double *out_S, double *P,
+                  bool timed)
+{
+    vmp_pca_layout Lx;
+    fill_layout(D, Kx, &Lx);
+    const int DB = (int)(Lx.DP / 32), KT = (int)(Lx.KP / 16);
     const int64_t ntiles = (N + TN - 1) / TN;
     int64_t g = ntiles < max_grid(ctx) ? ntiles : max_grid(ctx);
     if (g < 1) g = 1;
-    double *P = reinterpret_cast<double *>(workspace);
-    const double *A = state + L.off_A;
     hipStream_t s = ctx->stream;
     dim3 grid((unsigned)g);
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
-#define VMP_CASE(db, kt)                                                                 \
-    if (DB == db && KT == kt) {                                                          \
-        launch_pass<db, kt>(compute_x, grid, s, Y, ldy, N, D, K, A, X, ldx, P, ntiles);  \
-    } else
-    VMP_CASE(1, 1) VMP_CASE(2, 1) VMP_CASE(4, 1) VMP_CASE(8, 1)
-    VMP_CASE(1, 2) VMP_CASE(2, 2) VMP_CASE(4, 2) VMP_CASE(8, 2)
-    VMP_CASE(1, 4) VMP_CASE(2, 4) VMP_CASE(4, 4) VMP_CASE(8, 4)
+    if (timed && ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
+#define VMP_CASE(db, kt)                                                                     \
+    if (DB == db && KT == kt)                                                                \
+        launch_fused<db, kt>(compute_x, grid, s, Y, ldy, N, D, Kx, A, Xs, ldx, P, ntiles);   \
+    else
+    VMP_FOR_EACH_INSTANCE(VMP_CASE)
     {
         VMP_SET_ERR(ctx, "no kernel instance for DB=%d KT=%d", DB, KT);
         return VMP_ERR_UNSUPPORTED;
     }
 #undef VMP_CASE
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
-    const int len = (int)L.len_S;
+    if (timed && ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
+    const int len = (int)Lx.len_S;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + NT - 1) / NT), dim3(NT), 0, s, P,
-                       (int)g, len, state + L.off_S);
+                       (int)g, len, out_S);
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
+    if (timed && ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
+    return VMP_OK;
+}
+
+int32_t run_gram_stats(vmp_ctx *ctx, const vmp_pca_layout &L, int D, int K, double *state,
+                       double *P)
+{
+    const int nb = (int)(L.DP / GR);
+    const size_t lds = ((size_t)L.KP * (L.DP + 1) + (size_t)GR * L.DP + (size_t)GR * LD)
+                       * sizeof(double);
+    hipStream_t s = ctx->stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)pca_gram_stats_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pca_gram_stats_kernel, dim3(nb), dim3(NT), lds, s, L, D, K, state, state,
+                       P);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    const int len = (int)(L.KP * L.KP);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + NT - 1) / NT), dim3(NT), 0, s, P, nb,
+                       len, state + L.off_S + L.DP * L.KP);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
 
@@ -642,10 +938,11 @@ int32_t vmp_pca_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *byte
     VMP_REQUIRE(ctx, ctx && bytes, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, D >= 1 && K >= 1, VMP_ERR_INVALID, "bad dims");
     VMP_REQUIRE(ctx, D <= MAX_DP && K <= MAX_KP, VMP_ERR_UNSUPPORTED,
-                "fused PCA pass supports D <= %d, K <= %d", MAX_DP, MAX_KP);
+                "fused PCA block supports D <= %d, K <= %d", MAX_DP, MAX_KP);
     vmp_pca_layout L;
     fill_layout(D, K, &L);
-    *bytes = (size_t)(max_grid(ctx) * L.len_S + 4096) * sizeof(double);
+    // per-workgroup partial statistics + one scratch statistics block (Gram set-up)
+    *bytes = (size_t)((max_grid(ctx) + 1) * partial_len(L) + 4096) * sizeof(double);
     return VMP_OK;
 }
 
@@ -687,17 +984,102 @@ int32_t vmp_pca_syy(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32
     return VMP_OK;
 }
 
+int32_t vmp_pca_gram(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
+                     double *state, void *workspace)
+{
+    int32_t rc = check_pass_args(ctx, Y, Y, state, workspace, ldy, ldy, N, D, K);
+    if (rc != VMP_OK) return rc;
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    double *P = reinterpret_cast<double *>(workspace);
+    double *tmpS = P + max_grid(ctx) * partial_len(L);
+    for (int j0 = 0; j0 < D; j0 += MAX_KP) {
+        const int Kx = (D - j0) < MAX_KP ? (D - j0) : MAX_KP;
+        vmp_pca_layout Lx;
+        fill_layout(D, Kx, &Lx);
+        double *Xs = const_cast<double *>(Y) + (int64_t)j0 * ldy;
+        rc = run_stats(ctx, false, Y, ldy, N, D, Kx, Xs, ldy, state + L.off_A, tmpS, P, false);
+        if (rc != VMP_OK) return rc;
+        const int n = D * Kx;
+        hipLaunchKernelGGL(pca_gram_copy_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream,
+                           tmpS, (int)Lx.KP, D, Kx, j0, (int)L.DP, state + L.off_G);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return VMP_OK;
+}
+
 int32_t vmp_pca_stats_from_x(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D,
                              int32_t K, const double *X, int64_t ldx, double *state,
                              void *workspace)
 {
-    return run_pass(ctx, false, Y, ldy, N, D, K, const_cast<double *>(X), ldx, state, workspace);
+    int32_t rc = check_pass_args(ctx, Y, X, state, workspace, ldy, ldx, N, D, K);
+    if (rc != VMP_OK) return rc;
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    return run_stats(ctx, false, Y, ldy, N, D, K, const_cast<double *>(X), ldx, state + L.off_A,
+                     state + L.off_S, reinterpret_cast<double *>(workspace), false);
 }
 
 int32_t vmp_pca_pass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
                      double *X, int64_t ldx, double *state, void *workspace)
 {
-    return run_pass(ctx, true, Y, ldy, N, D, K, X, ldx, state, workspace);
+    int32_t rc = check_pass_args(ctx, Y, X, state, workspace, ldy, ldx, N, D, K);
+    if (rc != VMP_OK) return rc;
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    return run_stats(ctx, true, Y, ldy, N, D, K, X, ldx, state + L.off_A, state + L.off_S,
+                     reinterpret_cast<double *>(workspace), true);
+}
+
+int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
+                      double *X, int64_t ldx, double *state, void *workspace)
+{
+    int32_t rc = check_pass_args(ctx, Y, X, state, workspace, ldy, ldx, N, D, K);
+    if (rc != VMP_OK) return rc;
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    const int DB = (int)(L.DP / 32), KT = (int)(L.KP / 16);
+    const int64_t ntiles = (N + TN - 1) / TN;
+    // full tiles with unpadded D, K run the predication-free instance
+    const bool exact = (D == L.DP && K == L.KP);
+    const int64_t nfast = exact ? N / TN : 0;
+    const int occ = xpass_occupancy();
+    const int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
+    hipStream_t s = ctx->stream;
+    const double *A = state + L.off_A;
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool guard = (pass == 1);
+        const int64_t t0 = guard ? nfast : 0, t1 = guard ? ntiles : nfast;
+        if (t1 <= t0) continue;
+        int64_t g = (t1 - t0 + 3) / 4;
+        if (g > gmax) g = gmax;
+        const dim3 grid((unsigned)g);
+#define VMP_CASE(db, kt)                                                                        \
+    if (DB == db && KT == kt) {                                                                 \
+        if (guard)                                                                              \
+            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, true, 2>), grid, dim3(NT), 0, s, Y,    \
+                               ldy, N, D, K, A, X, ldx, t0, t1);                                \
+        else if (occ >= 3 && kt < 4)                                                            \
+            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3>), grid, dim3(NT), 0, s, Y,   \
+                               ldy, N, D, K, A, X, ldx, t0, t1);                                \
+        else                                                                                    \
+            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 2>), grid, dim3(NT), 0, s, Y,   \
+                               ldy, N, D, K, A, X, ldx, t0, t1);                                \
+    } else
+        VMP_FOR_EACH_INSTANCE(VMP_CASE)
+        {
+            VMP_SET_ERR(ctx, "no kernel instance for DB=%d KT=%d", DB, KT);
+            return VMP_ERR_UNSUPPORTED;
+        }
+#undef VMP_CASE
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
+    rc = run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace));
+    if (rc != VMP_OK) return rc;
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
+    return VMP_OK;
 }
 
 #define VMP_SMALL_PROLOGUE()                                               \
@@ -711,7 +1093,7 @@ int32_t vmp_pca_pass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int3
 int32_t vmp_pca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double *state)
 {
     VMP_SMALL_PROLOGUE();
-    hipLaunchKernelGGL(pca_update_w_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K,
+    hipLaunchKernelGGL(pca_update_w_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K,
                        (double)n_total, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -721,7 +1103,7 @@ int32_t vmp_pca_prepare_x(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, dou
 {
     VMP_SMALL_PROLOGUE();
     VMP_REQUIRE(ctx, x_prec > 0, VMP_ERR_INVALID, "x_prec must be positive");
-    hipLaunchKernelGGL(pca_prepare_x_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, x_prec,
+    hipLaunchKernelGGL(pca_prepare_x_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K, x_prec,
                        state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -731,7 +1113,7 @@ int32_t vmp_pca_update_tau(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, 
                            double b0, double *state)
 {
     VMP_SMALL_PROLOGUE();
-    hipLaunchKernelGGL(pca_update_tau_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K,
+    hipLaunchKernelGGL(pca_update_tau_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K,
                        (double)n_total, a0, b0, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -752,7 +1134,7 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
                             double *state)
 {
     VMP_SMALL_PROLOGUE();
-    hipLaunchKernelGGL(pca_lower_bound_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K,
+    hipLaunchKernelGGL(pca_lower_bound_kernel, dim3(1), dim3(NTL), 0, ctx->stream, L, D, K,
                        (double)n_total, x_prec, a0_tau, b0_tau, a0_alpha, b0_alpha, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;

@@ -16,9 +16,21 @@ with a fully observed Y (scalar mask).  The plan owns, in HBM:
 Reference semantics preserved: each ``node.update()`` sees the latest moments
 of its Markov blanket, in whatever order the user calls them
 (vmp.py:154-172); the only plate-sized work per VB iteration is ONE streaming
-pass over Y (``vmp_pca_pass``) issued by ``X.update()``.
+pass over Y issued by ``X.update()``.
+
+Two forms of that pass (``stats=``):
+
+* ``'gram'`` (default): ``vmp_pca_xpass`` writes <x_n> = A y_n (read Y once,
+  write <x> once -- HBM-bound) and the messages to W come from the constant
+  Gram matrix G = Y Y^T, computed and summed over ranks ONCE at set-up; no
+  per-iteration collective is left.
+* ``'stream'``: ``vmp_pca_pass`` additionally accumulates sum y<x>^T and
+  sum <x><x>^T while streaming (fp64-MFMA-bound); the partial sums are
+  all-reduced over ranks every iteration (the reference's plate sums,
+  node.py:650 / dot.py:581).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -70,6 +82,13 @@ class HIPKernels:
     def pass_(self, Y, ldy, N, D, K, X, ldx, state, ws):
         self.rt.check(self.lib.vmp_pca_pass(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
                                             ptr(state), ptr(ws)))
+
+    def gram(self, Y, ldy, N, D, K, state, ws):
+        self.rt.check(self.lib.vmp_pca_gram(self.ctx, ptr(Y), ldy, N, D, K, ptr(state), ptr(ws)))
+
+    def xpass(self, Y, ldy, N, D, K, X, ldx, state, ws):
+        self.rt.check(self.lib.vmp_pca_xpass(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
+                                             ptr(state), ptr(ws)))
 
     def update_tau(self, D, K, n_total, a0, b0, state):
         self.rt.check(self.lib.vmp_pca_update_tau(self.ctx, D, K, n_total, a0, b0, ptr(state)))
@@ -159,7 +178,12 @@ class PCAPlan:
         return None
 
     # -- construction ------------------------------------------------------------------
-    def __init__(self, roles, runtime=None, kernels=None):
+    def __init__(self, roles, runtime=None, kernels=None, stats=None):
+        if stats is None:
+            stats = os.environ.get('BAYESPY_AMD_PCA_STATS', 'gram')
+        if stats not in ('gram', 'stream'):
+            raise ValueError("stats must be 'gram' or 'stream'")
+        self.stats = stats
         self.roles = roles
         self.Y, self.F, self.W, self.X = roles['Y'], roles['F'], roles['W'], roles['X']
         self.tau, self.alpha = roles['tau'], roles['alpha']
@@ -237,6 +261,10 @@ class PCAPlan:
         k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)
         k.syy(self.Yd, self.ldy, N, D, K, self.state, self.ws)
         rt.all_reduce_sum_(self.state[L.off_Syy:L.off_Syy + 1])
+        if self.stats == 'gram':
+            k.gram(self.Yd, self.ldy, N, D, K, self.state, self.ws)
+            DP = int(L.DP)
+            rt.all_reduce_sum_(self.state[L.off_G:L.off_G + DP * DP])
         # ---- X: delta moments (initialize_from_value/random) or the prior --------------
         init = self.X._init
         if init is None:
@@ -300,9 +328,13 @@ class PCAPlan:
             k.update_w(D, K, self.n_total, self.state)
         elif node is self.X:
             k.prepare_x(D, K, self.x_prec, self.state)
-            k.pass_(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
-            # child -> parent message sum over the sharded plate (node.py:650, dot.py:581)
-            rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
+            if self.stats == 'gram':
+                # messages to W from the global Gram matrix: nothing to exchange
+                k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+            else:
+                k.pass_(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+                # child -> parent message sum over the sharded plate (node.py:650, dot.py:581)
+                rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
         elif node is self.tau:
             k.update_tau(D, K, self.n_total, self.a0t, self.b0t, self.state)
         elif node is self.alpha:

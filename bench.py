@@ -41,6 +41,8 @@ def parse():
     p.add_argument('--d', type=int, default=128)
     p.add_argument('--k', type=int, default=32)
     p.add_argument('--scaling', choices=['strong', 'weak'], default='strong')
+    p.add_argument('--stats', choices=['gram', 'stream'], default='gram',
+                   help="form of X.update()'s plate pass (see bayespy_amd/inference/plans/pca.py)")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-sample-n', type=int, default=200_000)
     return p.parse_args()
@@ -138,6 +140,7 @@ def main():
     Q = VB(Y, F, W, X, tau, alpha)
     Q.ignore_bound_checks = True          # never stop early: time exactly K iterations
     plan = Q.plans[0]
+    plan.stats = args.stats
 
     def barrier():
         if world > 1:
@@ -169,8 +172,24 @@ def main():
         # rank: SURVEY.md 8(d): bytes = 8 N (D+K), flops = 4 N D K + 2 N K^2
         alg_bytes = 8.0 * n_local * (D + K)
         alg_flops = 4.0 * n_local * D * K + 2.0 * n_local * K * K
+        if args.stats == 'gram':
+            # Gram form: the plate kernel only computes X = A Y (2 N D K flops)
+            alg_flops = 2.0 * n_local * D * K
         tflops = alg_flops / (avg_pass * 1e-3) / 1e12
         gbs = alg_bytes / (avg_pass * 1e-3) / 1e9
+        if args.stats == 'gram':
+            roof = {'kernel': 'pca_xpass_kernel', 'bound': 'hbm', 'achieved': gbs,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                    'traffic': None, 'avg_launch_ms': avg_pass, 'gram_stats_ms': avg_red,
+                    'mfma_TFLOPs': tflops, 'mfma_frac_of_78.6': tflops / FP64_MFMA_PEAK_TFLOPS,
+                    'alg_bytes_per_launch': alg_bytes, 'alg_flops_per_launch': alg_flops}
+        else:
+            roof = {'kernel': 'pca_pass_kernel', 'bound': 'mfma', 'achieved': tflops,
+                    'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': tflops / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'avg_launch_ms': avg_pass, 'reduce_ms': avg_red, 'hbm_achieved_GBs': gbs,
+                    'hbm_frac_of_8TBs': gbs / HBM_PEAK_GBS,
+                    'alg_bytes_per_launch': alg_bytes, 'alg_flops_per_launch': alg_flops}
         out = {
             'metric': 'VB iterations/sec, PCA N=%d D=%d K=%d' % (n_total, D, K),
             'value': it_s, 'unit': 'VB iterations/s', 'n_gpus': world, 'steps': args.steps,
@@ -183,15 +202,9 @@ def main():
                 'n_local': n_local, 'parallelism': 'plate-shard x%d' % world,
             },
             'elbo_first': float(L[0]), 'elbo_last': float(L[-1]),
-            'roofline': {
-                'kernel': 'pca_pass_kernel<4,2,true>' if (D, K) == (128, 32) else 'pca_pass_kernel',
-                'bound': 'mfma', 'achieved': tflops, 'peak': FP64_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': tflops / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
-                'avg_launch_ms': avg_pass, 'reduce_ms': avg_red,
-                'hbm_achieved_GBs': gbs, 'hbm_frac_of_8TBs': gbs / HBM_PEAK_GBS,
-                'alg_bytes_per_launch': alg_bytes, 'alg_flops_per_launch': alg_flops,
-            },
+            'roofline': roof,
         }
+        out['config']['stats'] = args.stats
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(D, K, min(args.cpu_sample_n, n_total), n_total)
         print(json.dumps(out))

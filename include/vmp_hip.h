@@ -81,6 +81,7 @@ typedef struct vmp_pca_layout {
     int64_t off_Sww;    /* KP x KP  sum_d <w_d w_d^T>                                          */
     int64_t off_CX;     /* KP x KP  Cov_X (shared by all n; zero for delta-initialised X)      */
     int64_t off_A;      /* KP x DP  A = <tau> Cov_X <W>^T, zero padded                         */
+    int64_t off_G;      /* DP x DP  Gram matrix G = Y Y^T (constant; summed over ranks once)   */
     int64_t off_scal;   /* 8 : [0] log|Lambda_W|  [1] log|Lambda_X|  [2] residual  [3] status  */
     int64_t off_L;      /* 8 : L_Y, L_X, L_W, L_tau, L_alpha, L_total                          */
     int64_t total;      /* doubles in the state block                                          */
@@ -119,10 +120,26 @@ int32_t vmp_pca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
 int32_t vmp_pca_prepare_x(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec,
                           double *state);
 
-/* X.update(), plate half -- THE streaming pass: for every local n
+/* G <- Y Y^T over the local shard (set-up; the caller all-reduces G once when the
+ * plate is sharded).  With a scalar mask every <x_n> is the same linear map of y_n,
+ * so the messages to W (dot.py:581) collapse onto G:  sum y<x>^T = G A^T and
+ * sum <x><x>^T = A G A^T. */
+int32_t vmp_pca_gram(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
+                     int32_t D, int32_t K, double *state, void *workspace);
+
+/* X.update(), plate half, Gram form (default): for every local n  <x_n> = A y_n
+ * is written to X ((K,N) row-major) -- read Y once, write <x> once, HBM-bound --
+ * then S <- [G A^T ; A G A^T] from the (already global) Gram matrix: no
+ * per-iteration collective.  fp64 MFMA (v_mfma_f64_16x16x4_f64). */
+int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
+                      int32_t D, int32_t K, double *X, int64_t ldx,
+                      double *state, void *workspace);
+
+/* X.update(), plate half, streaming-statistics form: for every local n
  *   <x_n> = A y_n  (written to X, (K,N) row-major),
- *   S <- [sum y_n <x_n>^T ; sum <x_n><x_n>^T]  (local partial; caller all-reduces).
- * fp64 MFMA (v_mfma_f64_16x16x4_f64). */
+ *   S <- [sum y_n <x_n>^T ; sum <x_n><x_n>^T]  (local partial; caller all-reduces:
+ *   the child->parent message sum over the sharded plate, node.py:650, dot.py:581).
+ * fp64 MFMA (v_mfma_f64_16x16x4_f64), MFMA-bound. */
 int32_t vmp_pca_pass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
                      int32_t D, int32_t K, double *X, int64_t ldx,
                      double *state, void *workspace);
@@ -142,7 +159,7 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
                             double a0_tau, double b0_tau,
                             double a0_alpha, double b0_alpha, double *state);
 
-/* Elapsed milliseconds of the most recent vmp_pca_pass on this context,
+/* Elapsed milliseconds of the most recent vmp_pca_xpass / vmp_pca_pass on this context,
  * measured with HIP events on the context's stream (blocks until done);
  * enabled by vmp_ctx_set_timing(ctx, 1). */
 int32_t vmp_ctx_set_timing(vmp_ctx *ctx, int32_t enabled);

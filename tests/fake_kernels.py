@@ -49,6 +49,7 @@ class CPURuntimeKernels:
             Sww=s[L.off_Sww:L.off_Sww + KP * KP].reshape(KP, KP),
             CX=s[L.off_CX:L.off_CX + KP * KP].reshape(KP, KP),
             A=s[L.off_A:L.off_A + KP * DP].reshape(KP, DP),
+            G=s[L.off_G:L.off_G + DP * DP].reshape(DP, DP),
             scal=s[L.off_scal:L.off_scal + 8],
             Lt=s[L.off_L:L.off_L + 8],
         )
@@ -109,6 +110,22 @@ class CPURuntimeKernels:
         v['S'][:] = 0
         v['S'][:D, :K] = y @ x.T
         v['S'][v['DP']:v['DP'] + K, :K] = x @ x.T
+
+    def gram(self, Y, ldy, N, D, K, state, ws):
+        self.calls.append('gram')
+        v = self._v(state, D, K)
+        y = Y.numpy()[:, :N]
+        v['G'][:D, :D] = y @ y.T
+
+    def xpass(self, Y, ldy, N, D, K, X, ldx, state, ws):
+        self.calls.append('xpass')
+        v = self._v(state, D, K)
+        A = v['A'][:K, :D]
+        X.numpy()[:, :N] = A @ Y.numpy()[:, :N]
+        syx = v['G'][:D, :D] @ A.T
+        v['S'][:] = 0
+        v['S'][:D, :K] = syx
+        v['S'][v['DP']:v['DP'] + K, :K] = A @ syx
 
     def _resid(self, v, D, K, n_total):
         return (v['Syy'][0] - 2 * np.sum(v['W'][:, :K] * v['S'][:D, :K])

@@ -19,11 +19,12 @@ ELBO_RTOL = 1e-9
 MOM_RTOL = 1e-8
 
 
-def _run(y, x0, K, iters, **kw):
+def _run(y, x0, K, iters, stats='gram', **kw):
     import bayespy_amd.nodes as nodes
     from bayespy_amd.inference import VB
     from models import build_pca
     Q = build_pca(nodes, VB, y, x0, K, **kw)
+    Q.plans[0].stats = stats          # 'gram' (default) or 'stream' form of X.update()
     Q.update(repeat=iters, verbose=False)
     return Q
 
@@ -37,13 +38,14 @@ def test_native_library_is_loaded():
     assert 'libvmp_hip.so' in maps
 
 
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
 @pytest.mark.parametrize('name', ['pca_n500_d6_k3', 'pca_n777_d20_k5', 'pca_n2048_d128_k32',
                                   'pca_n4000_d64_k16'])
-def test_gpu_matches_reference_golden(golden_dir, name):
+def test_gpu_matches_reference_golden(golden_dir, name, stats):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     K = g['x0'].shape[1]
     n = int(g['n_iter'])
-    Q = _run(g['y'], g['x0'], K, n)
+    Q = _run(g['y'], g['x0'], K, n, stats=stats)
     np.testing.assert_allclose(Q.L[:n], g['L'], rtol=ELBO_RTOL)
     for k in ('Y', 'X', 'W', 'tau', 'alpha'):
         np.testing.assert_allclose(Q.l[Q[k]][:n], g['L_' + k], rtol=1e-8, atol=1e-6)
@@ -62,11 +64,12 @@ def test_gpu_matches_reference_golden(golden_dir, name):
     (1000, 64, 16), (4097, 100, 10), (5000, 128, 32), (3001, 129, 33), (2000, 256, 64),
     (70001, 128, 32),
 ])
-def test_gpu_vs_oracle_ragged_sizes(N, D, K):
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+def test_gpu_vs_oracle_ragged_sizes(N, D, K, stats):
     from oracle.pca import PCAOracle, make_pca_data
     y, x0 = make_pca_data(N, D, K, seed=N + D + K)
     iters = 3
-    Q = _run(y, x0, K, iters)
+    Q = _run(y, x0, K, iters, stats=stats)
     o = PCAOracle(y, x0)
     o.iterate(iters)
     np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=ELBO_RTOL)
@@ -120,6 +123,21 @@ def test_pass_kernel_direct_cabi():
                                           ptr(ws)))
         S2 = state[L.off_S:L.off_S + L.len_S].cpu().numpy().reshape(DP + KP, KP)
         np.testing.assert_allclose(S2, S, rtol=1e-12, atol=1e-10)
+        # Gram form: G = Y Y^T once, then X = A Y and S = [G A^T ; A G A^T]
+        rt.check(lib.vmp_pca_gram(rt.ctx, ptr(Yd), ld, N, D, K, ptr(state), ptr(ws)))
+        G = state[L.off_G:L.off_G + DP * DP].cpu().numpy().reshape(DP, DP)
+        np.testing.assert_allclose(G[:D, :D], y @ y.T, rtol=1e-12, atol=1e-10)
+        assert not np.any(G[D:]) and not np.any(G[:, D:])
+        Xd.zero_()
+        state[L.off_S:L.off_S + L.len_S].zero_()
+        rt.check(lib.vmp_pca_xpass(rt.ctx, ptr(Yd), ld, N, D, K, ptr(Xd), ld, ptr(state),
+                                   ptr(ws)))
+        x3 = Xd[:, :N].cpu().numpy()
+        assert not Xd[:, N:].any()
+        S3 = state[L.off_S:L.off_S + L.len_S].cpu().numpy().reshape(DP + KP, KP)
+        np.testing.assert_allclose(x3, xr, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(S3[:D, :K], y @ xr.T, rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(S3[DP:DP + K, :K], xr @ xr.T, rtol=1e-10, atol=1e-9)
 
 
 def test_cabi_rejects_bad_arguments():
@@ -136,11 +154,12 @@ def test_cabi_rejects_bad_arguments():
         rt.check(rc)
 
 
-def test_determinism_bitwise():
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+def test_determinism_bitwise(stats):
     from oracle.pca import make_pca_data
     y, x0 = make_pca_data(50000, 128, 32, seed=11)
-    Q1 = _run(y, x0, 32, 3)
-    Q2 = _run(y, x0, 32, 3)
+    Q1 = _run(y, x0, 32, 3, stats=stats)
+    Q2 = _run(y, x0, 32, 3, stats=stats)
     assert np.array_equal(Q1.L[:3], Q2.L[:3])
     assert np.array_equal(Q1['X'].u[0], Q2['X'].u[0])
 
@@ -153,7 +172,8 @@ def test_not_positive_definite_is_reported():
         _run(y, x0, 2, 1)
 
 
-def test_headline_size_properties():
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+def test_headline_size_properties(stats):
     """N=1e7, D=128, K=32 (BASELINE.json metric config): the reference cannot hold
     this size, so parity is checked through size-independent properties."""
     import torch
@@ -175,6 +195,7 @@ def test_headline_size_properties():
     from models import build_pca
     Q = build_pca(nodes, VB, y, None, K)
     plan = Q.plans[0]
+    plan.stats = stats
     # inject the initial X in device layout (K, N)
     Q['X'].initialize_from_random()
     plan._materialize()

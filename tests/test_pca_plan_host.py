@@ -16,19 +16,21 @@ from fake_kernels import CPURuntimeKernels
 from models import build_pca
 
 
-def _attach_cpu(Q):
+def _attach_cpu(Q, stats='gram'):
     rt = Runtime(device='cpu')
     for p in Q.plans:
         p._rt = rt
         p._kernels = CPURuntimeKernels(rt)
+        p.stats = stats
     return Q
 
 
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
 @pytest.mark.parametrize('name', ['pca_n500_d6_k3', 'pca_n777_d20_k5'])
-def test_plan_reproduces_reference_trace(golden_dir, name):
+def test_plan_reproduces_reference_trace(golden_dir, name, stats):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     K = g['x0'].shape[1]
-    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], K))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], K), stats)
     Q.update(repeat=int(g['n_iter']), verbose=False)
     np.testing.assert_allclose(Q.L[:Q.iter], g['L'], rtol=1e-10)
     for k in ('Y', 'X', 'W', 'tau', 'alpha'):
@@ -49,12 +51,17 @@ def test_update_order_and_one_pass_per_iteration(golden_dir):
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
     Q.update(repeat=2, verbose=False)
     calls = Q.plans[0].kernels.calls
-    assert calls[0] == 'stats_from_x'
-    per_iter = ['update_w', 'prepare_x', 'pass', 'update_tau', 'update_alpha']
-    assert calls[1:] == per_iter * 2
+    assert calls[:2] == ['gram', 'stats_from_x']
+    per_iter = ['update_w', 'prepare_x', 'xpass', 'update_tau', 'update_alpha']
+    assert calls[2:] == per_iter * 2
     # explicit node order, as VB.update(*nodes) allows (vmp.py:139-141)
     Q.update(Q['X'], Q['W'], repeat=1, verbose=False)
-    assert Q.plans[0].kernels.calls[-3:] == ['prepare_x', 'pass', 'update_w']
+    assert Q.plans[0].kernels.calls[-3:] == ['prepare_x', 'xpass', 'update_w']
+    # streaming-statistics form: one fused pass per iteration instead
+    Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3), 'stream')
+    Q2.update(repeat=1, verbose=False)
+    assert Q2.plans[0].kernels.calls == ['stats_from_x', 'update_w', 'prepare_x', 'pass',
+                                         'update_tau', 'update_alpha']
 
 
 def test_lower_bound_cache_and_observed_skip(golden_dir):

@@ -11,17 +11,22 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
+__device__ long long g_cycles[8];
+
 template <int NACC>
-__global__ void __launch_bounds__(256) mfma_loop(double *out, int iters)
+__global__ void __launch_bounds__(256) mfma_loop(double *out, int iters, double scale = 1.0)
 {
     v4f64 acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = v4f64{0, 0, 0, 0};
-    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    double a = scale * threadIdx.x * 1e-3, b = scale * (1.0 + threadIdx.x * 1e-4);
+    long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
             acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
+    long long t1 = clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_cycles[0] = t1 - t0;
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -78,16 +83,25 @@ int main()
     double *out;
     CK(hipMalloc(&out, 256 * 4096 * sizeof(double)));
     const int iters = 20000;
-    for (int wgs = 1; wgs <= 2; ++wgs) {
+    auto report = [&](const char *name, int nacc, int wgs, float ms, double scale) {
         int grid = p.multiProcessorCount * wgs;
-        float ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<4>, dim3(grid), dim3(256), 0, 0, out, iters); }, 3);
-        double flops = (double)grid * 4 /*waves*/ * iters * 4 /*acc*/ * 2.0 * 16 * 16 * 4;
-        printf("mfma_f64_16x16x4 4 acc, %d WG/CU: %.2f TFLOP/s (%.1f cycles/mfma/SIMD at 2.4GHz)\n", wgs,
-               flops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)iters * 4 * wgs));
-        ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<1>, dim3(grid), dim3(256), 0, 0, out, iters); }, 3);
-        flops = (double)grid * 4 * iters * 1 * 2.0 * 16 * 16 * 4;
-        printf("mfma_f64_16x16x4 1 acc (dependent), %d WG/CU: %.2f TFLOP/s (%.1f cycles/mfma)\n", wgs,
-               flops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)iters * wgs));
+        long long cyc = 0;
+        CK(hipMemcpyFromSymbol(&cyc, HIP_SYMBOL(g_cycles), sizeof(cyc)));
+        double flops = (double)grid * 4 /*waves*/ * iters * nacc * 2.0 * 16 * 16 * 4;
+        printf("%s acc=%d WG/CU=%d data=%s: %.2f TFLOP/s, %.1f shader-cycles per mfma per SIMD, eff clock %.0f MHz\n",
+               name, nacc, wgs, scale == 0.0 ? "zero" : "nonzero", flops / ms / 1e9,
+               (double)cyc / ((double)iters * nacc * wgs), (double)cyc / (ms * 1e3));
+    };
+    for (double scale : {1.0, 0.0}) {
+        for (int wgs = 1; wgs <= 4; wgs *= 2) {
+            int grid = p.multiProcessorCount * wgs;
+            float ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<1>, dim3(grid), dim3(256), 0, 0, out, iters, scale); }, 3);
+            report("mfma_f64_16x16x4", 1, wgs, ms, scale);
+            ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<4>, dim3(grid), dim3(256), 0, 0, out, iters, scale); }, 3);
+            report("mfma_f64_16x16x4", 4, wgs, ms, scale);
+            ms = time_ms([&] { hipLaunchKernelGGL(mfma_loop<8>, dim3(grid), dim3(256), 0, 0, out, iters, scale); }, 3);
+            report("mfma_f64_16x16x4", 8, wgs, ms, scale);
+        }
     }
     {
         int grid = p.multiProcessorCount * 8;

@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""
+Summarise rocprofv3 (rocpd sqlite) outputs into short text tables.
+
+    python tools/rocpd_summary.py gpurun_out/prof_stats/r1_results.db            # kernel stats
+    python tools/rocpd_summary.py --pmc gpurun_out/pmc_sq/r1_results.db [...]   # counters
+
+Kernel names are shortened; torch's data-generation kernels are folded into one line.
+"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([A-Za-z0-9_:]+(<[0-9a-z, ]+>)?)', name)
+    s = m.group(1) if m else name
+    if s.startswith('at::native') or s.startswith('Cijk_'):
+        return '[torch: synthetic-data generation] ' + s[:40]
+    return s[:70]
+
+
+def stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute('select name, duration from kernels').fetchall()
+    agg = defaultdict(list)
+    for n, d in rows:
+        agg[short(n)].append(d)
+    tot = sum(sum(v) for v in agg.values())
+    print('%-72s %6s %12s %12s %12s %12s %6s' % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us',
+                                                'max_us', '%'))
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print('%-72s %6d %12.1f %12.1f %12.1f %12.1f %6.2f' % (
+            k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3,
+            100.0 * sum(v) / tot))
+
+
+def pmc(dbs, only='pca_pass_kernel'):
+    for db in dbs:
+        con = sqlite3.connect(db)
+        rows = con.execute('select kernel_name, counter_name, value, duration, dispatch_id '
+                           'from counters_collection').fetchall()
+        per = defaultdict(lambda: defaultdict(float))
+        dur = {}
+        for n, c, v, d, disp in rows:
+            if only and only not in n:
+                continue
+            per[(short(n), disp)][c] += v
+            dur[(short(n), disp)] = d
+        agg = defaultdict(lambda: defaultdict(list))
+        for (k, disp), cs in per.items():
+            for c, v in cs.items():
+                agg[k][c].append(v)
+            agg[k]['duration_ns'].append(dur[(k, disp)])
+        print('== %s' % db)
+        for k, cs in agg.items():
+            print(k)
+            for c, v in sorted(cs.items()):
+                print('    %-34s avg %18.1f   (n=%d, min %.1f, max %.1f)' % (
+                    c, sum(v) / len(v), len(v), min(v), max(v)))
+
+
+if __name__ == '__main__':
+    args = sys.argv[1:]
+    if args and args[0] == '--pmc':
+        pmc(args[1:])
+    else:
+        for a in args:
+            stats(a)
