@@ -84,6 +84,14 @@ SIGNATURES = {
     'vmp_pca_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_vp]),
     'vmp_pca_lower_bound': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
                                     c_f64, c_vp]),
+    'vmp_sum_multiply': (c_i32, [c_vp, c_i32, P(c_i64), c_i32, P(c_vp), P(c_i64), P(c_i64),
+                                 ctypes.c_uint32, c_f64, c_vp, c_vp, c_sz]),
+    'vmp_sum_multiply_workspace_bytes': (c_sz, []),
+    'vmp_ewise': (c_i32, [c_vp, c_i32, P(c_i64), c_i32, P(c_vp), P(c_i64), c_i32, P(c_i32),
+                          c_i32, P(c_f64), c_vp]),
+    'vmp_spd_batched': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_softmax_moments': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    'vmp_onehot_i64': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_ctx_set_timing': (c_i32, [c_vp, c_i32]),
     'vmp_pca_last_pass_ms': (c_i32, [c_vp, P(c_f64), P(c_f64)]),
 }

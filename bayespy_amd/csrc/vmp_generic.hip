@@ -1,0 +1,493 @@
+// vmp_generic.hip -- generic plate-broadcast kernels behind bayespy_amd.utils:
+//
+//   vmp_sum_multiply    misc.sum_multiply / sum_multiply_to_plates (utils/misc.py:805-933,
+//                       np.einsum(optimize=False) call site :906) -- E14/E15
+//   vmp_ewise           fused broadcast elementwise formulas (the ufunc chains inside the
+//                       five VMP formulas of every Distribution), one pass over HBM
+//   vmp_spd_batched     linalg.chol / chol_inv / chol_logdet (utils/linalg.py:31-223),
+//                       one workgroup (or wavefront) per matrix instead of a Python loop -- E13
+//   vmp_softmax_moments misc.normalized_exp / logsumexp (utils/misc.py:1366-1401) -- E20
+//   vmp_onehot_i64      CategoricalMoments.compute_fixed_moments (categorical.py:30-46),
+//                       integer scatter, bit-exact -- E26
+//
+// All arrays are fp64 with explicit element strides (stride 0 = broadcast axis), i.e.
+// the reference's broadcast-compressed plate semantics are preserved on the device.
+#include "vmp_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXD = VMP_MAX_DIMS;
+constexpr int MAXIN = VMP_MAX_OPERANDS;
+
+struct Iter {
+    int nk, nr, nin;                 // kept dims, reduced dims, operands
+    int64_t ksize[MAXD], rsize[MAXD];
+    int64_t kstride[MAXIN][MAXD], rstride[MAXIN][MAXD];
+    int64_t okstride[MAXD];
+    const double *in[MAXIN];
+    int64_t nkeep, nred;
+};
+
+__device__ inline void decode_keep(const Iter &it, int64_t o, int64_t *off, int64_t &ooff)
+{
+    for (int i = 0; i < it.nin; ++i) off[i] = 0;
+    ooff = 0;
+    for (int d = it.nk - 1; d >= 0; --d) {
+        const int64_t q = o / it.ksize[d];
+        const int64_t c = o - q * it.ksize[d];
+        o = q;
+        for (int i = 0; i < it.nin; ++i) off[i] += c * it.kstride[i][d];
+        ooff += c * it.okstride[d];
+    }
+}
+
+__device__ inline double product_at(const Iter &it, const int64_t *base, int64_t r)
+{
+    int64_t off[MAXIN];
+    for (int i = 0; i < it.nin; ++i) off[i] = base[i];
+    for (int d = it.nr - 1; d >= 0; --d) {
+        const int64_t q = r / it.rsize[d];
+        const int64_t c = r - q * it.rsize[d];
+        r = q;
+        for (int i = 0; i < it.nin; ++i) off[i] += c * it.rstride[i][d];
+    }
+    double p = it.in[0][off[0]];
+    for (int i = 1; i < it.nin; ++i) p *= it.in[i][off[i]];
+    return p;
+}
+
+// One thread per output element, sequential reduction (many outputs / short sums).
+__global__ void __launch_bounds__(NT)
+sum_multiply_thread_kernel(Iter it, double scale, double *__restrict__ out)
+{
+    for (int64_t o = (int64_t)blockIdx.x * NT + threadIdx.x; o < it.nkeep;
+         o += (int64_t)gridDim.x * NT) {
+        int64_t base[MAXIN], ooff;
+        decode_keep(it, o, base, ooff);
+        double acc = 0.0;
+        for (int64_t r = 0; r < it.nred; ++r) acc += product_at(it, base, r);
+        out[ooff] = scale * acc;
+    }
+}
+
+// One workgroup per (output element, slice of the reduction domain): wavefront
+// reductions, fixed-order combination of the slices => deterministic.
+__global__ void __launch_bounds__(NT)
+sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial)
+{
+    __shared__ double red[NT / 64];
+    const int64_t o = blockIdx.x;
+    const int sp = blockIdx.y;
+    int64_t base[MAXIN], ooff;
+    decode_keep(it, o, base, ooff);
+    const int64_t chunk = (it.nred + nsplit - 1) / nsplit;
+    const int64_t r0 = sp * chunk;
+    const int64_t r1 = (r0 + chunk < it.nred) ? r0 + chunk : it.nred;
+    double acc = 0.0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += NT) acc += product_at(it, base, r);
+    acc = block_sum<NT>(acc, red);
+    if (threadIdx.x == 0) partial[o * nsplit + sp] = acc;
+}
+
+__global__ void __launch_bounds__(NT)
+sum_multiply_finish_kernel(Iter it, int nsplit, double scale, const double *__restrict__ partial,
+                           double *__restrict__ out)
+{
+    for (int64_t o = (int64_t)blockIdx.x * NT + threadIdx.x; o < it.nkeep;
+         o += (int64_t)gridDim.x * NT) {
+        int64_t base[MAXIN], ooff;
+        decode_keep(it, o, base, ooff);
+        double acc = 0.0;
+        for (int s = 0; s < nsplit; ++s) acc += partial[o * nsplit + s];
+        out[ooff] = scale * acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise expression VM: a postfix program over <= 6 broadcast operands,
+// evaluated with a 4-deep register stack, one HBM pass.
+// ---------------------------------------------------------------------------
+struct EwiseArgs {
+    int ndim, nin, nops;
+    int64_t shape[MAXD];
+    int64_t stride[MAXIN][MAXD];
+    const double *in[MAXIN];
+    int32_t ops[VMP_EWISE_MAX_OPS];
+    double consts[VMP_EWISE_MAX_CONSTS];
+    int64_t total;
+};
+
+__global__ void __launch_bounds__(NT)
+ewise_kernel(EwiseArgs a, double *__restrict__ out)
+{
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < a.total;
+         e += (int64_t)gridDim.x * NT) {
+        int64_t off[MAXIN];
+        for (int i = 0; i < a.nin; ++i) off[i] = 0;
+        int64_t t = e;
+        for (int d = a.ndim - 1; d >= 0; --d) {
+            const int64_t q = t / a.shape[d];
+            const int64_t c = t - q * a.shape[d];
+            t = q;
+            for (int i = 0; i < a.nin; ++i) off[i] += c * a.stride[i][d];
+        }
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
+#define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
+        for (int p = 0; p < a.nops; ++p) {
+            const int op = a.ops[p] & 0xff, arg = a.ops[p] >> 8;
+            switch (op) {
+            case VMP_OP_IN:      PUSH(a.in[arg][off[arg]]); break;
+            case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
+            case VMP_OP_ADD:     BIN(x + y); break;
+            case VMP_OP_SUB:     BIN(x - y); break;
+            case VMP_OP_MUL:     BIN(x * y); break;
+            case VMP_OP_DIV:     BIN(x / y); break;
+            case VMP_OP_NEG:     s0 = -s0; break;
+            case VMP_OP_LOG:     s0 = log(s0); break;
+            case VMP_OP_EXP:     s0 = exp(s0); break;
+            case VMP_OP_SQR:     s0 = s0 * s0; break;
+            case VMP_OP_SQRT:    s0 = sqrt(s0); break;
+            case VMP_OP_RECIP:   s0 = 1.0 / s0; break;
+            case VMP_OP_DIGAMMA: s0 = vmp_digamma(s0); break;
+            case VMP_OP_LGAMMA:  s0 = vmp_lgamma(s0); break;
+            case VMP_OP_MAX:     BIN(fmax(x, y)); break;
+            case VMP_OP_MIN:     BIN(fmin(x, y)); break;
+            case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;   // 0 * -inf guard
+            case VMP_OP_DUP:     PUSH(s0); break;
+            case VMP_OP_SWAP:    { const double tmp = s0; s0 = s1; s1 = tmp; } break;
+            default: break;
+            }
+        }
+#undef PUSH
+#undef BIN
+        out[e] = s0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batched SPD inverse / log-determinant by Gauss-Jordan sweeps in LDS.
+// ---------------------------------------------------------------------------
+constexpr int SPD_MAXN = 64;
+constexpr int SPD_LD = SPD_MAXN + 1;
+
+// one workgroup per matrix (n <= 64)
+__global__ void __launch_bounds__(NT)
+spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
+                         double *__restrict__ Ainv, double *__restrict__ logdet,
+                         int32_t *__restrict__ info)
+{
+    __shared__ double M[SPD_MAXN * SPD_LD];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const double *a = A + b * n * n;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < n * n; e += NT) {
+        const int i = e / n, j = e - i * n;
+        M[i * SPD_LD + j] = 0.5 * (a[i * n + j] + a[j * n + i]);
+    }
+    double ld = 0.0;
+    constexpr int EPT = SPD_MAXN * SPD_MAXN / NT;
+    for (int p = 0; p < n; ++p) {
+        __syncthreads();
+        const double piv = M[p * SPD_LD + p];
+        double ci[EPT], rj[EPT], me[EPT];
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int e = tid + m * NT;
+            if (e < n * n) {
+                const int i = e / n, j = e - i * n;
+                ci[m] = M[i * SPD_LD + p];
+                rj[m] = M[p * SPD_LD + j];
+                me[m] = M[i * SPD_LD + j];
+            }
+        }
+        if (tid == 0) {
+            if (!(piv > 0.0)) bad = 1;
+            ld += log(piv);
+        }
+        const double d = 1.0 / piv;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int e = tid + m * NT;
+            if (e < n * n) {
+                const int i = e / n, j = e - i * n;
+                double v;
+                if (i == p) v = (j == p) ? d : rj[m] * d;
+                else if (j == p) v = -ci[m] * d;
+                else v = me[m] - ci[m] * rj[m] * d;
+                M[i * SPD_LD + j] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (Ainv)
+        for (int e = tid; e < n * n; e += NT) {
+            const int i = e / n, j = e - i * n;
+            Ainv[b * n * n + e] = M[i * SPD_LD + j];
+        }
+    if (tid == 0) {
+        if (logdet) logdet[b] = ld;
+        if (info) info[b] = bad;
+    }
+}
+
+// one wavefront per matrix (n <= 8): n*n <= 64 elements, one per lane
+__global__ void __launch_bounds__(NT)
+spd_batched_wave_kernel(int n, int64_t batch, const double *__restrict__ A,
+                        double *__restrict__ Ainv, double *__restrict__ logdet,
+                        int32_t *__restrict__ info)
+{
+    __shared__ double Ms[4][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + w;
+    const bool act = (b < batch) && (l < n * n);
+    const int i = act ? l / n : 0, j = act ? l - i * n : 0;
+    double *M = Ms[w];
+    double v = 0.0;
+    if (act) v = 0.5 * (A[b * n * n + i * n + j] + A[b * n * n + j * n + i]);
+    double ld = 0.0;
+    int bad = 0;
+    for (int p = 0; p < n; ++p) {
+        M[l] = v;
+        __syncthreads();
+        const double piv = M[p * n + p];
+        const double ci = M[i * n + p], rj = M[p * n + j];
+        if (!(piv > 0.0)) bad = 1;
+        ld += log(piv);
+        const double d = 1.0 / piv;
+        if (i == p) v = (j == p) ? d : rj * d;
+        else if (j == p) v = -ci * d;
+        else v = v - ci * rj * d;
+        __syncthreads();
+    }
+    if (act && Ainv) Ainv[b * n * n + l] = v;
+    if (b < batch && l == 0) {
+        if (logdet) logdet[b] = ld;
+        if (info) info[b] = bad;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row softmax with the reference's exact recipe: stable log-sum-exp, exp, then a
+// second renormalisation (utils/misc.py:1388-1401).  One wavefront per row.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+softmax_kernel(int64_t rows, int K, const double *__restrict__ phi, double *__restrict__ p,
+               double *__restrict__ lse)
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < rows; r += (int64_t)gridDim.x * 4) {
+        const double *x = phi + r * K;
+        double mx = -INFINITY;
+        for (int k = l; k < K; k += 64) mx = fmax(mx, x[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        if (!isfinite(mx)) mx = 0.0;                       // misc.py:1375-1378
+        double s = 0.0;
+        for (int k = l; k < K; k += 64) s += exp(x[k] - mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const double ls = log(s) + mx;
+        double s2 = 0.0;
+        for (int k = l; k < K; k += 64) s2 += exp(x[k] - ls);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+        for (int k = l; k < K; k += 64) p[r * K + k] = exp(x[k] - ls) / s2;
+        if (l == 0 && lse) lse[r] = ls;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+onehot_kernel(int64_t n, int K, const int64_t *__restrict__ labels, double *__restrict__ out,
+              int32_t *__restrict__ info)
+{
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n * K;
+         e += (int64_t)gridDim.x * NT) {
+        const int64_t r = e / K;
+        const int k = (int)(e - r * K);
+        const int64_t lab = labels[r];
+        if (k == 0 && (lab < 0 || lab >= K)) atomicOr(info, 1);
+        out[e] = (lab == k) ? 1.0 : 0.0;
+    }
+}
+
+int64_t grid_for(vmp_ctx *ctx, int64_t work_items, int per_block)
+{
+    int64_t g = (work_items + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
+                         const double *const *in, const int64_t *in_strides,
+                         const int64_t *out_strides, uint32_t reduce_mask, double scale,
+                         double *out, void *workspace, size_t workspace_bytes)
+{
+    VMP_REQUIRE(ctx, ctx && shape && in && in_strides && out_strides && out, VMP_ERR_INVALID,
+                "null argument");
+    VMP_REQUIRE(ctx, ndim >= 0 && ndim <= MAXD && nin >= 1 && nin <= MAXIN, VMP_ERR_UNSUPPORTED,
+                "sum_multiply supports <= %d dims and <= %d operands", MAXD, MAXIN);
+    Iter it;
+    memset(&it, 0, sizeof(it));
+    it.nin = nin;
+    it.nkeep = 1;
+    it.nred = 1;
+    for (int i = 0; i < nin; ++i) {
+        VMP_REQUIRE(ctx, in[i] != nullptr, VMP_ERR_INVALID, "null operand %d", i);
+        it.in[i] = in[i];
+    }
+    for (int d = 0; d < ndim; ++d) {
+        VMP_REQUIRE(ctx, shape[d] >= 0, VMP_ERR_INVALID, "negative extent");
+        if (shape[d] == 1) continue;
+        if (reduce_mask & (1u << d)) {
+            const int k = it.nr++;
+            it.rsize[k] = shape[d];
+            for (int i = 0; i < nin; ++i) it.rstride[i][k] = in_strides[i * ndim + d];
+            it.nred *= shape[d];
+        } else {
+            const int k = it.nk++;
+            it.ksize[k] = shape[d];
+            for (int i = 0; i < nin; ++i) it.kstride[i][k] = in_strides[i * ndim + d];
+            it.okstride[k] = out_strides[d];
+            it.nkeep *= shape[d];
+        }
+    }
+    if (it.nkeep == 0) return VMP_OK;
+    hipStream_t s = ctx->stream;
+    if (it.nred == 0) {
+        // empty sum -> zeros
+        it.nred = 0;
+    }
+    const bool use_block = (it.nred >= 2048) && (it.nkeep <= 16384);
+    if (!use_block) {
+        hipLaunchKernelGGL(sum_multiply_thread_kernel, dim3((unsigned)grid_for(ctx, it.nkeep, NT)),
+                           dim3(NT), 0, s, it, scale, out);
+    } else {
+        int64_t want = ((int64_t)ctx->num_cu * 8 + it.nkeep - 1) / it.nkeep;
+        int64_t maxsplit = (it.nred + 4 * NT - 1) / (4 * NT);
+        int64_t nsplit = want < maxsplit ? want : maxsplit;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 4096) nsplit = 4096;
+        VMP_REQUIRE(ctx, workspace && workspace_bytes >= (size_t)(it.nkeep * nsplit) * sizeof(double),
+                    VMP_ERR_INVALID, "sum_multiply workspace too small (%lld doubles needed)",
+                    (long long)(it.nkeep * nsplit));
+        double *partial = reinterpret_cast<double *>(workspace);
+        hipLaunchKernelGGL(sum_multiply_block_kernel, dim3((unsigned)it.nkeep, (unsigned)nsplit),
+                           dim3(NT), 0, s, it, (int)nsplit, partial);
+        hipLaunchKernelGGL(sum_multiply_finish_kernel,
+                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
+                           (int)nsplit, scale, partial, out);
+    }
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+size_t vmp_sum_multiply_workspace_bytes(void) { return (size_t)1 << 20; }
+
+int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
+                  const double *const *in, const int64_t *in_strides, int32_t nops,
+                  const int32_t *ops, int32_t nconsts, const double *consts, double *out)
+{
+    VMP_REQUIRE(ctx, ctx && out && (ndim == 0 || shape), VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, ndim >= 0 && ndim <= MAXD && nin >= 0 && nin <= MAXIN
+                         && nops >= 1 && nops <= VMP_EWISE_MAX_OPS
+                         && nconsts >= 0 && nconsts <= VMP_EWISE_MAX_CONSTS,
+                VMP_ERR_UNSUPPORTED, "ewise program/operand count out of range");
+    EwiseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nin = nin;
+    a.nops = nops;
+    a.total = 1;
+    for (int i = 0; i < nin; ++i) a.in[i] = in[i];
+    // drop unit dims and merge adjacent dims that are jointly contiguous in every operand
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] == 1) continue;
+        a.total *= shape[d];
+        bool merged = false;
+        if (a.ndim > 0) {
+            const int k = a.ndim - 1;
+            bool ok = true;
+            for (int i = 0; i < nin; ++i)
+                if (a.stride[i][k] != in_strides[i * ndim + d] * shape[d]) ok = false;
+            if (ok) {
+                a.shape[k] *= shape[d];
+                for (int i = 0; i < nin; ++i) a.stride[i][k] = in_strides[i * ndim + d];
+                merged = true;
+            }
+        }
+        if (!merged) {
+            const int k = a.ndim++;
+            a.shape[k] = shape[d];
+            for (int i = 0; i < nin; ++i) a.stride[i][k] = in_strides[i * ndim + d];
+        }
+    }
+    for (int p = 0; p < nops; ++p) {
+        const int op = ops[p] & 0xff, arg = ops[p] >> 8;
+        VMP_REQUIRE(ctx, op >= 0 && op < VMP_OP__COUNT, VMP_ERR_INVALID, "bad opcode %d", op);
+        if (op == VMP_OP_IN) VMP_REQUIRE(ctx, arg >= 0 && arg < nin, VMP_ERR_INVALID, "bad operand");
+        if (op == VMP_OP_CONST)
+            VMP_REQUIRE(ctx, arg >= 0 && arg < nconsts, VMP_ERR_INVALID, "bad constant index");
+        a.ops[p] = ops[p];
+    }
+    for (int c = 0; c < nconsts; ++c) a.consts[c] = consts[c];
+    if (a.total == 0) return VMP_OK;
+    hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)grid_for(ctx, a.total, NT * 4)), dim3(NT), 0,
+                       ctx->stream, a, out);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A, double *Ainv,
+                        double *logdet, int32_t *info)
+{
+    VMP_REQUIRE(ctx, ctx && A, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, n >= 1 && batch >= 0, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, n <= SPD_MAXN, VMP_ERR_UNSUPPORTED, "batched SPD kernels support n <= %d",
+                SPD_MAXN);
+    if (batch == 0) return VMP_OK;
+    if (n <= 8)
+        hipLaunchKernelGGL(spd_batched_wave_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(NT), 0,
+                           ctx->stream, n, batch, A, Ainv, logdet, info);
+    else
+        hipLaunchKernelGGL(spd_batched_block_kernel, dim3((unsigned)batch), dim3(NT), 0,
+                           ctx->stream, n, batch, A, Ainv, logdet, info);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double *phi, double *p,
+                            double *lse)
+{
+    VMP_REQUIRE(ctx, ctx && phi && p, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, rows >= 0 && K >= 1, VMP_ERR_INVALID, "bad dims");
+    if (rows == 0) return VMP_OK;
+    hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)grid_for(ctx, rows, 4)), dim3(NT), 0,
+                       ctx->stream, rows, K, phi, p, lse);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_onehot_i64(vmp_ctx *ctx, int64_t n, int32_t K, const int64_t *labels, double *out,
+                       int32_t *info)
+{
+    VMP_REQUIRE(ctx, ctx && labels && out && info, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, n >= 0 && K >= 1, VMP_ERR_INVALID, "bad dims");
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
+    if (n == 0) return VMP_OK;
+    hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)grid_for(ctx, n * K, NT * 4)), dim3(NT), 0,
+                       ctx->stream, n, K, labels, out, info);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+}  // extern "C"

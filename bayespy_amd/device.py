@@ -82,7 +82,7 @@ class Runtime:
         torch = self.torch
         if isinstance(array, torch.Tensor):
             return array.to(device=self.device, dtype=torch.float64)
-        a = np.ascontiguousarray(array, dtype=np.float64)
+        a = np.array(array, dtype=np.float64, order='C', copy=True)   # keeps 0-d arrays 0-d
         return torch.from_numpy(a).to(self.device)
 
     # -- C ABI helpers -----------------------------------------------------------

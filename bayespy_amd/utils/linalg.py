@@ -1,0 +1,123 @@
+"""
+Batched linear algebra on device arrays.
+
+Device counterparts of ``bayespy.utils.linalg``: ``chol`` (:31), ``chol_solve``
+(:66), ``chol_inv`` (:174), ``chol_logdet`` (:209), ``inner`` (:299), ``outer``
+(:309), ``mvdot`` (:407), ``mmdot`` (:430), ``transpose`` (:444).  The reference
+loops in Python over the plates and calls SciPy once per matrix; here one
+``vmp_spd_batched`` launch handles every plate (one workgroup or wavefront per
+matrix).  ``chol`` returns an opaque factor handle, like the reference's ``U``.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from ..darray import DArray, asdarray, contiguous, fuse
+from ..device import get_runtime
+from .misc import sum_multiply
+
+
+class CholFactor:
+    """Handle returned by :func:`chol`; inverse and log-determinant are computed
+    together by one batched kernel on first use."""
+
+    def __init__(self, C):
+        self.C = contiguous(asdarray(C))
+        if self.C.ndim < 2 or self.C.shape[-1] != self.C.shape[-2]:
+            raise ValueError('chol needs (..., n, n) arrays')
+        self._inv = None
+        self._logdet = None
+        self._factor()
+
+    def _factor(self):
+        rt = get_runtime()
+        C = self.C
+        n = C.shape[-1]
+        batch = C.size // (n * n) if n else 0
+        inv = DArray.empty(C.shape)
+        logdet = DArray.empty(C.shape[:-2])
+        info = rt.torch.zeros(max(batch, 1), dtype=rt.torch.int32, device=rt.device)
+        rt.sync_stream()
+        rt.check(rt.lib.vmp_spd_batched(rt.ctx, n, batch, ctypes.c_void_p(C.t.data_ptr()),
+                                        ctypes.c_void_p(inv.t.data_ptr()),
+                                        ctypes.c_void_p(logdet.t.data_ptr()),
+                                        ctypes.c_void_p(info.data_ptr())))
+        if bool(info.any().item()):
+            # same failure the reference reports (utils/linalg.py:58-59)
+            raise _lib.NotPositiveDefiniteError("Matrix not positive definite")
+        self._inv, self._logdet = inv, logdet
+
+
+def chol(C, ndim=1):
+    if ndim != 1:
+        raise NotImplementedError('chol with ndim != 1')
+    return CholFactor(C)
+
+
+def chol_inv(U, ndim=1):
+    return U._inv
+
+
+def chol_logdet(U, ndim=1):
+    return U._logdet
+
+
+def chol_solve(U, b, ndim=1, out=None, matrix=False):
+    """Solve C x = b for every plate (broadcasting like the reference)."""
+    b = asdarray(b)
+    if matrix:
+        return mmdot(U._inv, b)
+    return mvdot(U._inv, b)
+
+
+def inner(*args, ndim=1):
+    """Sum of the elementwise product over the trailing ``ndim`` axes (linalg.py:299-306)."""
+    if ndim == 0:
+        return sum_multiply(*args, axis=None, sumaxis=False) if len(args) > 1 else asdarray(args[0])
+    return sum_multiply(*args, axis=tuple(range(-ndim, 0)))
+
+
+def outer(A, B, ndim=1):
+    """Outer product over the trailing ``ndim`` axes (linalg.py:309-334)."""
+    A, B = asdarray(A), asdarray(B)
+    a = A.reshape(A.shape + (1,) * ndim)
+    sb = B.shape
+    b = B.reshape(sb[:len(sb) - ndim] + (1,) * ndim + sb[len(sb) - ndim:])
+    return fuse(lambda x, y: x * y, a, b)
+
+
+def mvdot(A, b, ndim=1):
+    """(..., M, N) x (..., N) -> (..., M)  (linalg.py:407-427)."""
+    if ndim != 1:
+        raise NotImplementedError
+    A, b = asdarray(A), asdarray(b)
+    bb = b.reshape(b.shape[:-1] + (1, b.shape[-1]))
+    return sum_multiply(A, bb, axis=-1)
+
+
+def mmdot(A, B, ndim=1):
+    """(..., M, K) x (..., K, N) -> (..., M, N)  (linalg.py:430-441)."""
+    if ndim != 1:
+        raise NotImplementedError
+    A, B = asdarray(A), asdarray(B)
+    a = A.reshape(A.shape + (1,))                         # (..., M, K, 1)
+    b = B.reshape(B.shape[:-2] + (1,) + B.shape[-2:])     # (..., 1, K, N)
+    return sum_multiply(a, b, axis=-2)
+
+
+def dot(*arrays):
+    out = asdarray(arrays[0])
+    for a in arrays[1:]:
+        out = mmdot(out, a)
+    return out
+
+
+def transpose(X, ndim=1):
+    if ndim != 1:
+        raise NotImplementedError
+    return asdarray(X).swapaxes(-1, -2)
+
+
+def logdet_cov(C):
+    return chol_logdet(chol(C))

@@ -1,0 +1,232 @@
+"""
+Contraction / broadcast utilities on device arrays.
+
+Device counterparts of ``bayespy.utils.misc``: ``sum_multiply`` (:851-933),
+``sum_product`` (:935-945), ``sum_multiply_to_plates`` (:805-844),
+``broadcasting_multiplier`` (:761-802), ``logsumexp`` / ``normalized_exp``
+(:1366-1401), ``multidigamma`` (:1146-1151), ``diag`` / ``get_diag``
+(:1253, :1207), ``add_trailing_axes`` (:1052).  Same names, argument meaning
+and error behaviour; every reduction is the ``vmp_sum_multiply`` HIP kernel.
+"""
+import ctypes
+
+import numpy as np
+
+from ..darray import DArray, asdarray, fuse, contiguous, is_scalar, _strides
+from ..darray import exp as _exp, digamma as _digamma
+from ..device import get_runtime
+from .shapes import broadcasted_shape, broadcasting_multiplier, is_shape_subset  # noqa: F401
+
+_ws = {}
+
+
+def _workspace(rt):
+    key = id(rt)
+    if key not in _ws:
+        nbytes = rt.lib.vmp_sum_multiply_workspace_bytes()
+        _ws[key] = rt.empty(nbytes // 8)
+    return _ws[key]
+
+
+def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
+    """out (shape with size-1 on reduced axes) = scale * sum_{reduce_axes} prod arrays."""
+    rt = get_runtime()
+    nd = len(shape)
+    if nd > 8 or len(arrays) > 6:
+        raise NotImplementedError('sum_multiply supports <= 8 axes and <= 6 operands')
+    out = DArray.empty(out_shape_keep)
+    mask = 0
+    for ax in reduce_axes:
+        mask |= 1 << ax
+    c_shape = (ctypes.c_int64 * max(nd, 1))(*shape)
+    c_in = (ctypes.c_void_p * len(arrays))(*[a.t.data_ptr() for a in arrays])
+    flat = []
+    for a in arrays:
+        flat += _strides(a.t, shape)
+    c_str = (ctypes.c_int64 * max(len(flat), 1))(*flat)
+    ostr = _strides(out.t, shape)
+    c_ostr = (ctypes.c_int64 * max(nd, 1))(*ostr)
+    ws = _workspace(rt)
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_sum_multiply(
+        rt.ctx, nd, c_shape, len(arrays), c_in, c_str, c_ostr, ctypes.c_uint32(mask),
+        float(scale), ctypes.c_void_p(out.t.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+        ws.numel() * 8))
+    return out
+
+
+def sum_multiply(*args, axis=None, sumaxis=True, keepdims=False):
+    """
+    ``sum(arg[0]*arg[1]*..., axis=...)`` without forming the product
+    (reference: utils/misc.py:851-933).  ``axis`` lists the axes to sum
+    (``sumaxis=True``; None = all) or to keep (``sumaxis=False``; None = all).
+    """
+    if len(args) == 0:
+        raise ValueError("You must give at least one input array")
+    scale = 1.0
+    arrays = []
+    for a in args:
+        if is_scalar(a):
+            scale *= float(a)
+        else:
+            arrays.append(asdarray(a))
+    if not arrays:
+        return DArray.from_host(np.float64(scale))
+    max_dim = max(a.ndim for a in arrays)
+    if sumaxis:
+        if axis is None:
+            keep = []
+        else:
+            if np.isscalar(axis):
+                axis = [axis]
+            keep = [i for i in range(max_dim) if i not in axis and (i - max_dim) not in axis]
+    else:
+        if axis is None:
+            keep = list(range(max_dim))
+        else:
+            if np.isscalar(axis):
+                axis = [axis]
+            keep = sorted(i if i >= 0 else i + max_dim for i in axis)
+    if len(keep) > 0 and (min(keep) < 0 or max(keep) >= max_dim):
+        raise ValueError("Axis index out of bounds")
+    shape = broadcasted_shape(*[a.shape for a in arrays])
+    red = [i for i in range(max_dim) if i not in keep]
+    keep_shape = tuple(shape[i] if i in keep else 1 for i in range(max_dim))
+    out = _launch_sum_multiply(arrays, shape, red, keep_shape, scale)
+    if not keepdims:
+        out = out.reshape(tuple(shape[i] for i in keep))
+    return out
+
+
+def sum_product(*args, axes_to_keep=None, axes_to_sum=None, keepdims=False):
+    if axes_to_keep is not None:
+        return sum_multiply(*args, axis=axes_to_keep, sumaxis=False, keepdims=keepdims)
+    return sum_multiply(*args, axis=axes_to_sum, sumaxis=True, keepdims=keepdims)
+
+
+def sum_multiply_to_plates(*arrays, to_plates=(), from_plates=None, ndim=0):
+    """
+    Product of the arguments summed to the plates ``to_plates`` (their trailing
+    ``ndim`` axes are variable axes and are kept), times the integer plate
+    multiplier for axes that are broadcast in every operand
+    (reference: utils/misc.py:805-844 -- the plate sum of ``node.py:650``).
+    """
+    arrays = [asdarray(a) for a in arrays]
+
+    def plates_of(s):
+        return tuple(s) if ndim == 0 else tuple(s[:len(s) - ndim])
+
+    plate_shapes = [plates_of(a.shape) for a in arrays]
+    product_plates = broadcasted_shape(*plate_shapes)
+    if from_plates is None:
+        r = 1
+    else:
+        r = broadcasting_multiplier(tuple(from_plates), product_plates, tuple(to_plates))
+    full = broadcasted_shape(*[a.shape for a in arrays])
+    npl = len(full) - ndim
+    to = (1,) * (npl - len(to_plates)) + tuple(to_plates) if npl >= len(to_plates) else None
+    if to is None:
+        # the target has more plate axes than the product: nothing to sum on those
+        to = tuple(to_plates)[len(to_plates) - npl:]
+    red = [i for i in range(npl) if full[i] != 1 and to[i] == 1]
+    keep_shape = tuple(1 if i in red else full[i] for i in range(len(full)))
+    out = _launch_sum_multiply(arrays, full, red, keep_shape, float(r))
+    want = len(to_plates) + ndim
+    s = out.shape
+    while len(s) > want and s[0] == 1:
+        s = s[1:]
+    if len(s) > want:
+        raise ValueError('cannot squeeze %s to %d axes' % (out.shape, want))
+    return out.reshape(s)
+
+
+def add_trailing_axes(x, n):
+    if is_scalar(x):
+        return x
+    x = asdarray(x)
+    return x.reshape(x.shape + (1,) * n)
+
+
+def add_leading_axes(x, n):
+    if is_scalar(x):
+        return x
+    x = asdarray(x)
+    return x.reshape((1,) * n + x.shape)
+
+
+def logsumexp(X, axis=-1, keepdims=False):
+    """Stable log-sum-exp over the LAST axis (utils/misc.py:1366-1385)."""
+    if axis not in (-1, asdarray(X).ndim - 1):
+        raise NotImplementedError('device logsumexp reduces the last axis')
+    _, lse = normalized_exp(X)
+    return lse if keepdims else lse.reshape(lse.shape[:-1])
+
+
+def normalized_exp(phi):
+    """(p, logsum_p): exp(phi) normalised over the last axis with the reference's
+    second renormalisation (utils/misc.py:1388-1401) -- ``vmp_softmax_moments``."""
+    rt = get_runtime()
+    phi = contiguous(asdarray(phi))
+    K = phi.shape[-1]
+    rows = phi.size // K if K else 0
+    p = DArray.empty(phi.shape)
+    lse = DArray.empty(phi.shape[:-1] + (1,))
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_softmax_moments(rt.ctx, rows, K, ctypes.c_void_p(phi.t.data_ptr()),
+                                        ctypes.c_void_p(p.t.data_ptr()),
+                                        ctypes.c_void_p(lse.t.data_ptr())))
+    return p, lse
+
+
+def multidigamma(a, d):
+    """sum_{i<d} digamma(a - i/2)  (utils/misc.py:1146-1151)."""
+    a = asdarray(a)
+    half = DArray.from_host(0.5 * np.arange(d))
+    terms = fuse(lambda x, h: _digamma(x - h), a.reshape(a.shape + (1,)), half)
+    return sum_multiply(terms, axis=-1)
+
+
+def diag(X, ndim=1):
+    """Embed the trailing ``ndim`` axes as the diagonal of ``2*ndim`` axes
+    (utils/misc.py:1253-1262)."""
+    X = asdarray(X)
+    if ndim == 0:
+        return X
+    sh = X.shape[len(X.shape) - ndim:]
+    n = int(np.prod(sh)) if sh else 1
+    eye = DArray.from_host(np.eye(n).reshape(sh + sh))
+    return fuse(lambda x, e: x * e, X.reshape(X.shape + (1,) * ndim), eye)
+
+
+def get_diag(X, ndim=1):
+    """Diagonal of the trailing ``2*ndim`` axes (utils/misc.py:1207-1250)."""
+    X = asdarray(X)
+    if ndim == 0:
+        return X
+    sh = X.shape[len(X.shape) - ndim:]
+    n = int(np.prod(sh)) if sh else 1
+    lead = X.shape[:len(X.shape) - 2 * ndim]
+    eye = DArray.from_host(np.eye(n).reshape(sh + sh))
+    out = sum_multiply(X, eye, axis=tuple(range(-ndim, 0)))
+    return out.reshape(lead + sh)
+
+
+def onehot(labels, K):
+    """One-hot fixed moments of a categorical variable: integer indexing, bit-exact
+    (categorical.py:30-46).  ``labels``: host integer array (any shape) -> (..., K)."""
+    rt = get_runtime()
+    lab = np.ascontiguousarray(np.asarray(labels))
+    if not np.issubdtype(lab.dtype, np.integer):
+        raise ValueError("Class indices must be integers")
+    lab = lab.astype(np.int64)
+    n = int(lab.size)
+    dl = rt.torch.from_numpy(lab.reshape(-1)).to(rt.device)
+    out = DArray.empty(lab.shape + (K,))
+    info = rt.torch.zeros(1, dtype=rt.torch.int32, device=rt.device)
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_onehot_i64(rt.ctx, n, K, ctypes.c_void_p(dl.data_ptr()),
+                                   ctypes.c_void_p(out.t.data_ptr()),
+                                   ctypes.c_void_p(info.data_ptr())))
+    if int(info.item()) != 0:
+        raise ValueError("Class indices out of range [0, %d)" % K)
+    return out

@@ -159,6 +159,62 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
                             double a0_tau, double b0_tau,
                             double a0_alpha, double b0_alpha, double *state);
 
+
+/* ---- generic plate-broadcast kernels -------------------------------------- *
+ *
+ * Arrays are fp64 with explicit ELEMENT strides per axis; stride 0 marks a
+ * broadcast axis (the reference's unit / missing plate axes).
+ */
+#define VMP_MAX_DIMS          8
+#define VMP_MAX_OPERANDS      6
+#define VMP_EWISE_MAX_OPS     48
+#define VMP_EWISE_MAX_CONSTS  8
+
+/* out[kept axes] = scale * sum_{axes in reduce_mask} prod_i in_i[...]
+ * -- misc.sum_multiply (utils/misc.py:851-933, np.einsum call site :906) and the
+ * plate sum of Node._message_to_parent via misc.sum_multiply_to_plates
+ * (node.py:650, utils/misc.py:805-844); `scale` carries broadcasting_multiplier
+ * (utils/misc.py:761-802).  in_strides is [nin][ndim] row-major; out_strides[ndim]
+ * (ignored on reduced axes).  Deterministic (fixed-order) reduction. */
+int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
+                         const double *const *in, const int64_t *in_strides,
+                         const int64_t *out_strides, uint32_t reduce_mask, double scale,
+                         double *out, void *workspace, size_t workspace_bytes);
+size_t vmp_sum_multiply_workspace_bytes(void);
+
+/* Fused broadcast elementwise formula: a postfix program (opcode | operand<<8)
+ * over <= VMP_MAX_OPERANDS inputs evaluated per output element with a 4-deep
+ * stack; `out` is contiguous with the given shape.  Replaces the NumPy ufunc
+ * chains inside the Distribution formulas (e.g. gaussian.py:675-678, :2344-2369,
+ * gamma.py:142-148, dirichlet.py:150-158, expfamily.py:449-468). */
+enum {
+    VMP_OP_IN = 0, VMP_OP_CONST, VMP_OP_ADD, VMP_OP_SUB, VMP_OP_MUL, VMP_OP_DIV, VMP_OP_NEG,
+    VMP_OP_LOG, VMP_OP_EXP, VMP_OP_SQR, VMP_OP_SQRT, VMP_OP_RECIP, VMP_OP_DIGAMMA,
+    VMP_OP_LGAMMA, VMP_OP_MAX, VMP_OP_MIN, VMP_OP_WHERE_NZ, VMP_OP_DUP, VMP_OP_SWAP,
+    VMP_OP__COUNT
+};
+int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
+                  const double *const *in, const int64_t *in_strides, int32_t nops,
+                  const int32_t *ops, int32_t nconsts, const double *consts, double *out);
+
+/* Batched SPD inverse and log-determinant of `batch` contiguous n x n matrices
+ * (n <= 64): linalg.chol + chol_inv + chol_logdet (utils/linalg.py:31-223), one
+ * workgroup / wavefront per matrix instead of a Python loop over plates.
+ * Ainv / logdet may be NULL; info[b] = 1 where a matrix is not positive definite
+ * ("Matrix not positive definite", utils/linalg.py:58-59). */
+int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A, double *Ainv,
+                        double *logdet, int32_t *info);
+
+/* Row softmax moments of Multinomial/Categorical: p = normalized_exp(phi),
+ * lse = logsumexp(phi) (multinomial.py:114-120, utils/misc.py:1366-1401). */
+int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double *phi, double *p,
+                            double *lse);
+
+/* One-hot fixed moments of Categorical (categorical.py:30-46, :93-114); integer
+ * indexing, bit-exact.  *info != 0 when a label is outside [0, K). */
+int32_t vmp_onehot_i64(vmp_ctx *ctx, int64_t n, int32_t K, const int64_t *labels, double *out,
+                       int32_t *info);
+
 /* Elapsed milliseconds of the most recent vmp_pca_xpass / vmp_pca_pass on this context,
  * measured with HIP events on the context's stream (blocks until done);
  * enabled by vmp_ctx_set_timing(ctx, 1). */

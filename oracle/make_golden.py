@@ -155,6 +155,67 @@ def gmm_case(name, N, D, K, n_iter, seed):
     print(name, 'L =', Ls)
 
 
+def utils_cases(name):
+    """Known answers of the reference's own utility functions on seeded inputs:
+    misc.sum_multiply_to_plates / sum_multiply / logsumexp / normalized_exp /
+    multidigamma, linalg.chol_inv / chol_logdet / chol_solve."""
+    from bayespy.utils import misc, linalg
+    rs = np.random.RandomState(123)
+    out = {}
+    # (shapes of the arrays, to_plates, from_plates, ndim)
+    cases = [
+        (((5, 4),), (4,), (5, 4), 0),
+        (((5, 4),), (1,), (5, 4), 0),
+        (((5, 4),), (), (5, 4), 0),
+        (((), ), (), (5, 4), 0),
+        (((1, 4),), (), (5, 4), 0),
+        (((5, 1),), (4,), (5, 4), 0),
+        (((5, 4, 3),), (4,), (5, 4), 1),
+        (((5, 1, 3),), (5, 1), (5, 4), 1),
+        (((3, 3),), (), (6, 5), 2),
+        (((6, 5, 3, 3),), (5,), (6, 5), 2),
+        (((6, 1, 3, 3), (6, 5, 1, 1)), (5,), (6, 5), 2),
+        (((6, 5, 1), (6, 5, 3)), (6, 1), (6, 5), 1),
+        (((7, 1, 2), (1, 4, 2), (4, 1)), (4,), (7, 4), 1),
+        (((2, 3, 4, 5),), (3, 1, 5), (2, 3, 4, 5), 0),
+        (((2, 3, 4, 5), (4, 1)), (2, 1, 1, 1), (2, 3, 4, 5), 0),
+    ]
+    for i, (shapes, to_plates, from_plates, ndim) in enumerate(cases):
+        arrs = [rs.normal(size=s) for s in shapes]
+        y = misc.sum_multiply_to_plates(*arrs, to_plates=to_plates, from_plates=from_plates,
+                                        ndim=ndim)
+        for j, a in enumerate(arrs):
+            out['smtp%d_in%d' % (i, j)] = a
+        out['smtp%d_out' % i] = np.asarray(y)
+        out['smtp%d_meta' % i] = np.array([len(arrs), ndim])
+        out['smtp%d_to' % i] = np.array(to_plates, dtype=np.int64)
+        out['smtp%d_from' % i] = np.array(from_plates, dtype=np.int64)
+    out['smtp_n'] = len(cases)
+    x = rs.normal(size=(7, 5)) * 10
+    x[2, :] = -np.inf
+    x[3, 1] = -np.inf
+    with np.errstate(all='ignore'):
+        out['lse_in'] = x
+        out['lse_out'] = misc.logsumexp(x, axis=-1)
+        p, ls = misc.normalized_exp(x)
+        out['nexp_p'], out['nexp_lse'] = p, ls
+    a = 3.0 + rs.gamma(2.0, size=(4, 3))
+    out['mdg_in'] = a
+    out['mdg_out5'] = misc.multidigamma(a, 5)
+    for n in (1, 3, 8, 20):
+        A = rs.normal(size=(4, 2, n, n))
+        C = A @ np.swapaxes(A, -1, -2) + n * np.eye(n)
+        b = rs.normal(size=(4, 2, n))
+        U = linalg.chol(C)
+        out['chol%d_C' % n] = C
+        out['chol%d_b' % n] = b
+        out['chol%d_inv' % n] = linalg.chol_inv(U)
+        out['chol%d_logdet' % n] = linalg.chol_logdet(U)
+        out['chol%d_solve' % n] = linalg.chol_solve(U, b)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'cases', len(cases))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -166,6 +227,7 @@ def main():
     pca_case('pca_n4000_d64_k16', N=4000, D=64, K=16, n_iter=4, seed=10)
     gmm_case('gmm_n400_d3_k4', N=400, D=3, K=4, n_iter=5, seed=11)
     gmm_case('gmm_n3000_d8_k16', N=3000, D=8, K=16, n_iter=4, seed=12)
+    utils_cases('utils_known_answers')
 
 
 if __name__ == '__main__':

@@ -1,0 +1,229 @@
+"""
+GPU parity of the generic plate-broadcast kernels (bayespy_amd.utils.misc /
+linalg / darray.fuse) against NumPy brute force on seeded inputs and against
+known answers produced by the reference's own utility functions
+(tests/golden/utils_known_answers.npz, made by oracle/make_golden.py).
+
+Tolerance: fp64, rtol 1e-12 for sums/products, 1e-10 for inverses; one-hot is
+bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy import special
+
+pytestmark = pytest.mark.gpu
+
+
+def _brute(arrs, axis, sumaxis, keepdims):
+    y = 1
+    for a in arrs:
+        y = y * a
+    nd = np.ndim(y)
+    if sumaxis:
+        if axis is None:
+            return np.sum(y, keepdims=keepdims)
+        return np.sum(y, axis=tuple(axis) if not np.isscalar(axis) else axis, keepdims=keepdims)
+    if axis is None:
+        return y
+    keep = sorted(a if a >= 0 else a + nd for a in ([axis] if np.isscalar(axis) else axis))
+    red = tuple(i for i in range(nd) if i not in keep)
+    return np.sum(y, axis=red, keepdims=keepdims) if red else y
+
+
+SM_CASES = [
+    (((),), dict()),
+    (((), (), ()), dict()),
+    (((3,),), dict(axis=())),
+    (((3, 1, 5), (4, 1), (5,), ()), dict(axis=(), keepdims=True)),
+    (((3, 1), (1, 4), (3, 4)), dict(axis=(1,))),
+    (((3, 1), (1, 4), (3, 4)), dict(axis=(-2,))),
+    (((3, 1), (1, 4), (3, 4)), dict(axis=(1, -2))),
+    (((3, 1), (1, 4), (3, 4)), dict(axis=(1,), keepdims=True)),
+    (((3, 1, 5, 6), (4, 1, 6), (4, 1, 1), ()), dict(axis=(1, -2), keepdims=True)),
+    (((3, 1), (1, 4), (3, 4)), dict(axis=(0,), sumaxis=False)),
+    (((3, 1), (1, 4), (3, 4)), dict(axis=(-1,), sumaxis=False, keepdims=True)),
+    (((3, 1, 5, 6), (4, 1, 6), (4, 1, 1), ()), dict(axis=(1, -1), sumaxis=False)),
+    (((2, 3, 4, 5, 2, 3),), dict(axis=(0, 2, 4))),
+    (((7, 1, 1), (1, 5000, 1), (7, 5000, 3)), dict(axis=(1,))),           # long reduction
+    (((100000, 3), (100000, 1)), dict(axis=(0,))),                          # plate sum
+    (((3, 40000, 2, 2), (1, 40000, 1, 1)), dict(axis=(1,), keepdims=True)),
+    (((64, 1, 32), (1, 1000, 32)), dict(axis=(-1,))),                       # many outputs
+]
+
+
+@pytest.mark.parametrize('shapes,kw', SM_CASES)
+def test_sum_multiply_matches_bruteforce(shapes, kw):
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(len(shapes) * 7 + sum(len(s) for s in shapes))
+    arrs = [rs.normal(size=s) if s else float(rs.normal()) for s in shapes]
+    got = misc.sum_multiply(*arrs, **kw).numpy()
+    ref = _brute(arrs, kw.get('axis'), kw.get('sumaxis', True), kw.get('keepdims', False))
+    assert got.shape == np.shape(ref)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.max(np.abs(ref))))
+
+
+def test_sum_multiply_errors():
+    from bayespy_amd.utils import misc
+    with pytest.raises(ValueError):
+        misc.sum_multiply()
+    with pytest.raises(ValueError):
+        misc.sum_multiply(np.ones((3, 4)), axis=(5,), sumaxis=False)
+    with pytest.raises(ValueError):
+        misc.sum_multiply(np.ones((3, 4)), np.ones((5, 4)))
+
+
+def test_sum_multiply_to_plates_known_answers(golden_dir):
+    from bayespy_amd.utils import misc
+    g = np.load(os.path.join(golden_dir, 'utils_known_answers.npz'))
+    for i in range(int(g['smtp_n'])):
+        nin, ndim = [int(v) for v in g['smtp%d_meta' % i]]
+        arrs = [g['smtp%d_in%d' % (i, j)] for j in range(nin)]
+        to = tuple(int(v) for v in g['smtp%d_to' % i])
+        frm = tuple(int(v) for v in g['smtp%d_from' % i])
+        got = misc.sum_multiply_to_plates(*arrs, to_plates=to, from_plates=frm, ndim=ndim).numpy()
+        ref = g['smtp%d_out' % i]
+        assert got.shape == ref.shape, (i, got.shape, ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_softmax_and_special_known_answers(golden_dir):
+    from bayespy_amd.utils import misc
+    g = np.load(os.path.join(golden_dir, 'utils_known_answers.npz'))
+    p, lse = misc.normalized_exp(g['lse_in'])
+    np.testing.assert_allclose(lse.numpy(), g['nexp_lse'], rtol=1e-13)
+    ref_p = g['nexp_p']
+    ok = np.isfinite(ref_p)
+    np.testing.assert_allclose(p.numpy()[ok], ref_p[ok], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(misc.logsumexp(g['lse_in']).numpy(), g['lse_out'], rtol=1e-13)
+    np.testing.assert_allclose(misc.multidigamma(g['mdg_in'], 5).numpy(), g['mdg_out5'],
+                               rtol=1e-13)
+
+
+def test_large_softmax_rows():
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(3)
+    x = rs.normal(size=(20011, 64)) * 30
+    p, lse = misc.normalized_exp(x)
+    m = x.max(axis=1, keepdims=True)
+    ref_l = np.log(np.exp(x - m).sum(axis=1, keepdims=True)) + m
+    ref_p = np.exp(x - ref_l)
+    ref_p /= ref_p.sum(axis=1, keepdims=True)
+    np.testing.assert_allclose(lse.numpy(), ref_l, rtol=1e-13)
+    np.testing.assert_allclose(p.numpy(), ref_p, rtol=1e-12, atol=1e-300)
+
+
+def test_batched_spd_known_answers_and_random(golden_dir):
+    from bayespy_amd.utils import linalg
+    from bayespy_amd import _lib
+    g = np.load(os.path.join(golden_dir, 'utils_known_answers.npz'))
+    for n in (1, 3, 8, 20):
+        U = linalg.chol(g['chol%d_C' % n])
+        np.testing.assert_allclose(linalg.chol_inv(U).numpy(), g['chol%d_inv' % n], rtol=1e-9,
+                                   atol=1e-12)
+        np.testing.assert_allclose(linalg.chol_logdet(U).numpy(), g['chol%d_logdet' % n],
+                                   rtol=1e-12)
+        np.testing.assert_allclose(linalg.chol_solve(U, g['chol%d_b' % n]).numpy(),
+                                   g['chol%d_solve' % n], rtol=1e-9, atol=1e-12)
+    rs = np.random.RandomState(5)
+    for n, batch in ((2, 1000), (5, 333), (9, 64), (16, 100), (32, 50), (64, 7)):
+        A = rs.normal(size=(batch, n, n))
+        C = A @ A.transpose(0, 2, 1) + n * np.eye(n)
+        U = linalg.chol(C)
+        np.testing.assert_allclose(linalg.chol_inv(U).numpy(), np.linalg.inv(C), rtol=1e-8,
+                                   atol=1e-11)
+        np.testing.assert_allclose(linalg.chol_logdet(U).numpy(), np.linalg.slogdet(C)[1],
+                                   rtol=1e-11)
+    bad = np.array([[1.0, 2.0], [2.0, 1.0]])
+    with pytest.raises(_lib.NotPositiveDefiniteError):
+        linalg.chol(bad)
+    with pytest.raises(NotImplementedError):
+        linalg.chol(np.eye(65))
+
+
+def test_linalg_products():
+    from bayespy_amd.utils import linalg
+    rs = np.random.RandomState(9)
+    A, B = rs.normal(size=(4, 1, 3, 5)), rs.normal(size=(6, 5, 2))
+    np.testing.assert_allclose(linalg.mmdot(A, B).numpy(), A @ B, rtol=1e-12)
+    b = rs.normal(size=(6, 5))
+    np.testing.assert_allclose(linalg.mvdot(A, b).numpy(), np.einsum('...ij,...j->...i', A, b),
+                               rtol=1e-12)
+    x, y = rs.normal(size=(7, 3)), rs.normal(size=(1, 3))
+    np.testing.assert_allclose(linalg.outer(x, y).numpy(), x[..., :, None] * y[..., None, :],
+                               rtol=1e-15)
+    np.testing.assert_allclose(linalg.inner(x, y).numpy(), np.sum(x * y, axis=-1), rtol=1e-13)
+    X = rs.normal(size=(2, 3, 4))
+    np.testing.assert_array_equal(linalg.transpose(X).numpy(), np.swapaxes(X, -1, -2))
+
+
+def test_fused_elementwise_formulas():
+    from bayespy_amd import darray as da
+    rs = np.random.RandomState(11)
+    a = rs.gamma(2.0, size=(50, 1, 7)) + 0.1
+    b = rs.normal(size=(3, 7))
+    A, B = da.DArray.from_host(a), da.DArray.from_host(b)
+    # GaussianARD scalar moments (gaussian.py:675-678): u0, u1, g
+    phi0, phi1 = b, -a
+    P0, P1 = da.DArray.from_host(phi0), da.DArray.from_host(phi1)
+    u0 = da.fuse(lambda p0, p1: -p0 / (2 * p1), P0, P1)
+    np.testing.assert_allclose(u0.numpy(), -phi0 / (2 * phi1), rtol=1e-15)
+    g = da.fuse(lambda u, p0, p1: -0.5 * u * p0 + 0.5 * da.log(-2 * p1), u0, P0, P1)
+    np.testing.assert_allclose(g.numpy(), -0.5 * (-phi0 / (2 * phi1)) * phi0
+                               + 0.5 * np.log(-2 * phi1), rtol=1e-14)
+    # Gamma moments (gamma.py:142-148)
+    r = da.fuse(lambda x, y: da.digamma(x) - da.log(y * y + 1.0), A, B)
+    np.testing.assert_allclose(r.numpy(), special.digamma(a) - np.log(b * b + 1), rtol=1e-13,
+                               atol=1e-14)
+    r = da.fuse(lambda x: x * da.log(x) - da.gammaln(x), A)
+    np.testing.assert_allclose(r.numpy(), a * np.log(a) - special.gammaln(a), rtol=1e-12,
+                               atol=1e-13)
+    # 0 * -inf guard (expfamily.py:463-464)
+    u = np.array([0.0, 1.0, 0.0, 2.0])
+    v = np.array([-np.inf, 3.0, np.inf, -1.0])
+    r = da.fuse(lambda x, y: da.where_nonzero(x, y) * x, u, v)
+    np.testing.assert_array_equal(r.numpy(), np.array([0.0, 3.0, 0.0, -2.0]))
+    # operators, scalars, 0-d, broadcasting
+    np.testing.assert_allclose((A * B + 2.0 - B / A).numpy(), a * b + 2 - b / a, rtol=1e-14)
+    np.testing.assert_allclose((-(3.0 - A)).numpy(), -(3 - a), rtol=1e-15)
+    s = da.DArray.from_host(np.float64(2.5))
+    np.testing.assert_allclose((s * s).numpy(), 6.25)
+    np.testing.assert_allclose(da.fuse(lambda x: da.maximum(x, 0.5) + da.minimum(x, 0.5) +
+                                       da.sqrt(x) + da.exp(-x) + da.recip(x) + x ** 2, A).numpy(),
+                               np.maximum(a, 0.5) + np.minimum(a, 0.5) + np.sqrt(a) + np.exp(-a)
+                               + 1 / a + a * a, rtol=1e-14)
+    # a view is an operand like any other
+    V = A[:, 0, ::2]
+    np.testing.assert_allclose((V + 1.0).numpy(), a[:, 0, ::2] + 1, rtol=1e-15)
+    with pytest.raises(ValueError):
+        da.fuse(lambda x, y: x + y, np.ones((3, 4)), np.ones((5, 4)))
+
+
+def test_onehot_is_bit_exact_and_validates():
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(2)
+    lab = rs.randint(0, 64, size=(1234, 3))
+    got = misc.onehot(lab, 64).numpy()
+    ref = np.zeros((1234, 3, 64))
+    ref[np.arange(1234)[:, None], np.arange(3)[None, :], lab] = 1
+    assert np.array_equal(got, ref)
+    with pytest.raises(ValueError):
+        misc.onehot(np.array([0, 64]), 64)
+    with pytest.raises(ValueError):
+        misc.onehot(np.array([-1, 3]), 64)
+    with pytest.raises(ValueError):
+        misc.onehot(np.array([0.5]), 4)
+
+
+def test_diag_helpers():
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(4)
+    x = rs.normal(size=(5, 3))
+    d = misc.diag(x).numpy()
+    ref = np.zeros((5, 3, 3))
+    for i in range(5):
+        ref[i] = np.diag(x[i])
+    np.testing.assert_array_equal(d, ref)
+    M = rs.normal(size=(5, 3, 3))
+    np.testing.assert_allclose(misc.get_diag(M).numpy(), np.einsum('...ii->...i', M), rtol=1e-15)
