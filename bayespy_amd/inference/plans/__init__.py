@@ -8,11 +8,17 @@ from .pca import PCAPlan
 PLAN_TYPES = [PCAPlan]
 
 
-def compile_model(nodes, **options):
+def compile_model(nodes, engine=None, **options):
     """Cover the stochastic nodes of ``nodes`` with plans.  Raises
     NotImplementedError (loudly -- there is no CPU fallback) when a node is not
     covered by any built plan."""
     from ...nodes.node import Stochastic
+    import os
+    if engine is None:
+        engine = os.environ.get('BAYESPY_AMD_ENGINE', 'auto')
+    if engine == 'generic':
+        from .generic import GenericPlan
+        return [GenericPlan(nodes)]
     remaining = [n for n in nodes]
     plans = []
     progress = True
@@ -29,7 +35,8 @@ def compile_model(nodes, **options):
                 break
     left = [n for n in remaining if isinstance(n, Stochastic)]
     if left:
-        raise NotImplementedError(
-            'No HIP execution plan is built for nodes %s. Supported model blocks: %s'
-            % ([n.name for n in left], [P.describe() for P in PLAN_TYPES]))
+        # nodes outside the fused blocks: the whole model runs on the generic device
+        # message-passing engine (raises NotImplementedError for unknown node types)
+        from .generic import GenericPlan
+        return [GenericPlan(nodes)]
     return plans

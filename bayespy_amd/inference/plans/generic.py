@@ -1,0 +1,874 @@
+"""
+Generic variational message passing on device arrays.
+
+Any graph of the built node types that no fused plan covers runs here: the
+reference's per-node protocol (the five VMP formulas of ``Distribution``,
+stochastic.py:16-80 / expfamily.py:17-70; ``_compute_moments`` /
+``_compute_message_to_parent`` of ``Deterministic``, deterministic.py:16-96) and
+its message routing (``Node._message_to_parent`` node.py:570-655,
+``_message_from_children`` :657-688, mask propagation :457-526, the lower bound
+expfamily.py:400-480) restated over ``DArray``s, so that every array operation
+is a HIP kernel (``vmp_ewise``, ``vmp_sum_multiply``, ``vmp_spd_batched``,
+``vmp_softmax_moments``, ``vmp_onehot_i64``).
+
+Differences from the reference's design (not its results):
+
+* the joint-parent wrappers ``WrapToGaussianGamma`` / ``WrapToGaussianWishart``
+  (gaussian.py:2299-2527) are folded into the Gaussian families;
+* messages may be *products of factors* that are multiplied and plate-summed by
+  ONE fused kernel launch, so e.g. the (N, K, D, D) weighted messages of a
+  mixture (mixture.py:126-158) are never materialised;
+* plate sums, masks and the integer plate multiplier (utils/misc.py:761-844)
+  are a single ``sum_multiply_to_plates`` launch per message.
+"""
+import numpy as np
+
+from ... import darray as da
+from ...darray import DArray, fuse
+from ...nodes.node import Constant, Stochastic
+from ...nodes.gamma import Gamma
+from ...nodes.gaussian import GaussianARD, Gaussian
+from ...nodes.dot import SumMultiply
+from ...nodes.wishart import Wishart
+from ...nodes.dirichlet import Dirichlet
+from ...nodes.categorical import Categorical
+from ...nodes.mixture import Mixture
+from ...utils import misc, linalg
+from ...utils.shapes import broadcasted_shape, broadcasting_multiplier, is_shape_subset
+
+LOG2PI = float(np.log(2 * np.pi))
+
+
+def _shape(x):
+    return x.shape if isinstance(x, DArray) else np.shape(x)
+
+
+def _arr(x):
+    return x if isinstance(x, DArray) else DArray.from_host(np.asarray(x, dtype=np.float64))
+
+
+def _trail(x, n):
+    """Append n unit axes."""
+    if n == 0 or not isinstance(x, DArray):
+        return x
+    return x.reshape(x.shape + (1,) * n)
+
+
+def _ones(shape):
+    return DArray.from_host(np.ones(shape))
+
+
+def _eye(shape):
+    n = int(np.prod(shape)) if len(shape) else 1
+    return DArray.from_host(np.eye(n).reshape(tuple(shape) + tuple(shape)))
+
+
+def _sum_last(x, n):
+    return x if n == 0 else misc.sum_multiply(x, axis=tuple(range(-n, 0)))
+
+
+def _multigammaln(a, d):
+    """log Gamma_d(a) (scipy.special.multigammaln call site wishart.py:187)."""
+    half = DArray.from_host(0.5 * np.arange(d))
+    t = fuse(lambda x, h: da.gammaln(x - h), _trail(_arr(a), 1), half)
+    return fuse(lambda s: s + d * (d - 1) / 4.0 * np.log(np.pi), misc.sum_multiply(t, axis=-1))
+
+
+# ---------------------------------------------------------------------------
+# families: the five VMP formulas per node type
+# ---------------------------------------------------------------------------
+class Family:
+
+    def __init__(self, node):
+        self.node = node
+
+    def plates_to_parent(self, index):
+        return self.node.plates
+
+    def mask_to_parent(self, index, mask):
+        return mask
+
+    def constant_moments(self, index, value):
+        raise NotImplementedError
+
+
+class GammaFamily(Family):
+    """gamma.py:90-211."""
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        if index == 0:
+            return [v, fuse(lambda a: da.gammaln(a), v)]          # GammaPriorMoments, gamma.py:33-58
+        return [v, fuse(lambda b: da.log(b), v)]
+
+    def phi_from_parents(self, up):
+        return [fuse(lambda b: -b, up[1][0]), fuse(lambda a: 1.0 * a, up[0][0])]
+
+    def moments_and_cgf(self, phi):
+        u0 = fuse(lambda p0, p1: p1 / (-p0), phi[0], phi[1])
+        u1 = fuse(lambda p0, p1: da.digamma(p1) - da.log(-p0), phi[0], phi[1])
+        g = fuse(lambda p0, p1: p1 * da.log(-p0) - da.gammaln(p1), phi[0], phi[1])
+        return [u0, u1], g
+
+    def cgf_from_parents(self, up):
+        return fuse(lambda a, lga, logb: a * logb - lga, up[0][0], up[0][1], up[1][1])
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(x)
+        if np.any(np.asarray(x.numpy()) < 0):
+            raise ValueError("Values must be positive")
+        logx = fuse(lambda v: da.log(v), x)
+        return [x, logx], fuse(lambda l: -l, logx)
+
+    def message_to_parent(self, index, u, up):
+        if index == 1:
+            return [fuse(lambda x: -x, u[0]), up[0][0]]
+        raise NotImplementedError('message from Gamma to its shape parameter')
+
+
+class GaussianARDFamily(Family):
+    """gaussian.py:576-889 with the wrapper gaussian.py:2299-2371 folded in."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.shape = node.shape
+        self.ndim = node.ndim
+        mu = node.parents[0]
+        self.mu_ndim = 0 if isinstance(mu, Constant) else len(mu.dims[0])
+        if self.mu_ndim not in (0, self.ndim):
+            raise NotImplementedError('mean parent with %d variable axes for a node with %d'
+                                      % (self.mu_ndim, self.ndim))
+
+    def plates_to_parent(self, index):
+        if index == 0 and self.mu_ndim == self.ndim:
+            return self.node.plates
+        return self.node.plates + self.shape
+
+    def mask_to_parent(self, index, mask):
+        if index == 0 and self.mu_ndim == self.ndim:
+            return mask
+        return mask.reshape(mask.shape + (1,) * self.ndim) if self.ndim else mask
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        if index == 0:
+            return [v, fuse(lambda m: m * m, v)]
+        return [v, fuse(lambda a: da.log(a), v)]
+
+    def _mu(self, up):
+        """(m, m2) elementwise over plates + shape."""
+        m, mm = up[0]
+        if self.mu_ndim == self.ndim and self.ndim > 0 and not isinstance(self.node.parents[0],
+                                                                           Constant):
+            return m, misc.get_diag(mm, ndim=self.ndim)
+        return m, mm
+
+    def phi_from_parents(self, up):
+        m, _ = self._mu(up)
+        a = up[1][0]
+        if self.ndim == 0:
+            return [fuse(lambda a_, m_: a_ * m_, a, m), fuse(lambda a_: -0.5 * a_, a)]
+        ones = _ones(self.shape)
+        phi0 = fuse(lambda a_, m_, o: a_ * m_ * o, a, m, ones)
+        d = fuse(lambda a_, o: -0.5 * a_ * o, a, ones)
+        return [phi0, misc.diag(d, ndim=self.ndim)]
+
+    def moments_and_cgf(self, phi):
+        if self.ndim == 0:
+            u0 = fuse(lambda p0, p1: -p0 / (2 * p1), phi[0], phi[1])
+            u1 = fuse(lambda u, p1: u * u - 1.0 / (2 * p1), u0, phi[1])
+            g = fuse(lambda u, p0, p1: -0.5 * u * p0 + 0.5 * da.log(-2 * p1), u0, phi[0], phi[1])
+            return [u0, u1], g
+        D = int(np.prod(self.shape))
+        p0 = _arr(phi[0])
+        p1 = _arr(phi[1])
+        p0f = p0.reshape(p0.shape[:p0.ndim - self.ndim] + (D,))
+        p1f = p1.reshape(p1.shape[:p1.ndim - 2 * self.ndim] + (D, D))
+        U = linalg.chol(fuse(lambda p: -2 * p, p1f))
+        cov = linalg.chol_inv(U)
+        u0 = linalg.chol_solve(U, p0f)
+        u1 = fuse(lambda a, b, c: a * b + c, _trail(u0, 1), u0.reshape(u0.shape[:-1] + (1, D)), cov)
+        g = fuse(lambda s, ld: -0.5 * s + 0.5 * ld, misc.sum_multiply(u0, p0f, axis=-1),
+                 linalg.chol_logdet(U))
+        u0 = u0.reshape(u0.shape[:-1] + self.shape)
+        u1 = u1.reshape(u1.shape[:-2] + self.shape + self.shape)
+        return [u0, u1], g
+
+    def cgf_from_parents(self, up):
+        m, m2 = self._mu(up)
+        a, loga = up[1]
+        if self.ndim == 0:
+            return fuse(lambda a_, q, la: -0.5 * a_ * q + 0.5 * la, a, m2, loga)
+        t = fuse(lambda a_, q, la, o: (-0.5 * a_ * q + 0.5 * la) * o, a, m2, loga,
+                 _ones(self.shape))
+        return _sum_last(t, self.ndim)
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(x)
+        if self.ndim > 0 and x.shape[x.ndim - self.ndim:] != self.shape:
+            raise ValueError("Invalid shape")
+        k = int(np.prod(self.shape)) if self.ndim else 1
+        xx = linalg.outer(x, x, ndim=self.ndim) if self.ndim else fuse(lambda v: v * v, x)
+        return [x, xx], -0.5 * k * LOG2PI
+
+    def message_to_parent(self, index, u, up):
+        x = u[0]
+        a = up[1][0]
+        if index == 0:
+            m0 = fuse(lambda a_, x_: a_ * x_, a, x)
+            if self.mu_ndim == self.ndim and self.ndim > 0:
+                d = fuse(lambda a_, o: -0.5 * a_ * o, a, _ones(self.shape))
+                return [m0, misc.diag(d, ndim=self.ndim)]
+            return [m0, fuse(lambda a_: -0.5 * a_, a)]
+        m, m2 = self._mu(up)
+        x2 = misc.get_diag(u[1], ndim=self.ndim) if self.ndim else u[1]
+        m0 = fuse(lambda x_, m_, q, x2_: x_ * m_ - 0.5 * q - 0.5 * x2_, x, m, m2, x2)
+        return [m0, 0.5]
+
+
+class GaussianFamily(Family):
+    """gaussian.py:293-573 with the wrapper gaussian.py:2374-2527 folded in."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.D = node.dims[0][0]
+        self.shape = (self.D,)
+        self.ndim = 1
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        if index == 0:
+            return [v, linalg.outer(v, v)]
+        return [v, linalg.chol_logdet(linalg.chol(v))]
+
+    def phi_from_parents(self, up):
+        m, L = up[0][0], up[1][0]
+        return [linalg.mvdot(L, m), fuse(lambda l: -0.5 * l, L)]
+
+    moments_and_cgf = GaussianARDFamily.moments_and_cgf
+
+    def cgf_from_parents(self, up):
+        mm = up[0][1]
+        L, logdet = up[1]
+        return fuse(lambda t, ld: -0.5 * t + 0.5 * ld, misc.sum_multiply(L, mm, axis=(-1, -2)),
+                    logdet)
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(x)
+        if x.shape[-1:] != (self.D,):
+            raise ValueError("Invalid shape")
+        return [x, linalg.outer(x, x)], -0.5 * self.D * LOG2PI
+
+    def message_to_parent(self, index, u, up):
+        x, xx = u
+        m, mm = up[0]
+        L = up[1][0]
+        if index == 0:
+            return [linalg.mvdot(L, x), fuse(lambda l: -0.5 * l, L)]
+        xm = linalg.outer(x, m)
+        mx = linalg.outer(m, x)
+        return [fuse(lambda a, b, c, d: -0.5 * (a - b - c + d), xx, xm, mx, mm), 0.5]
+
+
+class WishartFamily(Family):
+    """wishart.py:118-225."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.D = node.dims[0][0]
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        if index == 0:
+            return [v, _multigammaln(fuse(lambda n: 0.5 * n, v), self.D)]   # wishart.py:96-115
+        return [v, linalg.chol_logdet(linalg.chol(v))]
+
+    def phi_from_parents(self, up):
+        return [fuse(lambda V: -0.5 * V, up[1][0]), fuse(lambda n: 0.5 * n, up[0][0])]
+
+    def moments_and_cgf(self, phi):
+        U = linalg.chol(fuse(lambda p: -p, phi[0]))
+        ld = linalg.chol_logdet(U)
+        p1 = _arr(phi[1])
+        u0 = fuse(lambda n, c: n * c, _trail(p1, 2), linalg.chol_inv(U))
+        u1 = fuse(lambda l, md: -l + md, ld, misc.multidigamma(p1, self.D))
+        g = fuse(lambda n, l, mg: n * l - mg, p1, ld, _multigammaln(p1, self.D))
+        return [u0, u1], g
+
+    def cgf_from_parents(self, up):
+        n, gln = up[0]
+        ldV = up[1][1]
+        k = self.D
+        return fuse(lambda n_, l, g_: 0.5 * n_ * l - 0.5 * k * np.log(2.0) * n_ - g_, n, ldV, gln)
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(x)
+        ld = linalg.chol_logdet(linalg.chol(x))
+        return [x, ld], fuse(lambda l: -(self.D + 1) / 2.0 * l, ld)
+
+    def message_to_parent(self, index, u, up):
+        raise NotImplementedError('Wishart parents are constants in the built path')
+
+
+class DirichletFamily(Family):
+    """dirichlet.py:107-231."""
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        return [v]
+
+    def phi_from_parents(self, up):
+        return [up[0][0]]
+
+    def moments_and_cgf(self, phi):
+        p = _arr(phi[0])
+        if np.any(p.numpy() <= 0):
+            raise ValueError("Natural parameters should be positive")
+        s = misc.sum_multiply(p, axis=-1, keepdims=True)
+        u0 = fuse(lambda a, t: da.digamma(a) - da.digamma(t), p, s)
+        lg = misc.sum_multiply(fuse(lambda a: da.gammaln(a), p), axis=-1)
+        g = fuse(lambda t, l: da.gammaln(t) - l, s.reshape(s.shape[:-1]), lg)
+        return [u0], g
+
+    def cgf_from_parents(self, up):
+        a = _arr(up[0][0])
+        s = misc.sum_multiply(a, axis=-1)
+        lg = misc.sum_multiply(fuse(lambda v: da.gammaln(v), a), axis=-1)
+        return fuse(lambda t, l: da.gammaln(t) - l, s, lg)
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(x)
+        logp = fuse(lambda v: da.log(v), x)
+        return [logp], fuse(lambda s: -s, misc.sum_multiply(logp, axis=-1))
+
+    def message_to_parent(self, index, u, up):
+        raise NotImplementedError('Dirichlet concentration is a constant in the built path')
+
+
+class CategoricalFamily(Family):
+    """categorical.py:25-126, multinomial.py:62-231 (one trial)."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.K = node.dims[0][0]
+
+    def constant_moments(self, index, value):
+        return [fuse(lambda p: da.log(p), _arr(value))]
+
+    def phi_from_parents(self, up):
+        return [up[0][0]]
+
+    def moments_and_cgf(self, phi):
+        p, lse = misc.normalized_exp(_arr(phi[0]))
+        return [p], fuse(lambda l: -l, lse.reshape(lse.shape[:-1]))
+
+    def cgf_from_parents(self, up):
+        return 0.0
+
+    def fixed_moments_and_f(self, x):
+        return [misc.onehot(np.asarray(x), self.K)], 0.0
+
+    def message_to_parent(self, index, u, up):
+        return [u[0]]
+
+
+class MixtureFamily(Family):
+    """mixture.py:26-356 over the last parameter plate."""
+
+    def __init__(self, node, base):
+        super().__init__(node)
+        self.base = base                 # family of the mixed distribution (on node._proto)
+        self.K = node.clusters
+        self.ndims = [len(d) for d in node.dims]
+
+    def plates_to_parent(self, index):
+        if index == 0:
+            return self.node.plates
+        saved = self.base.node.plates
+        self.base.node.plates = self.node.plates + (self.K,)
+        try:
+            return self.base.plates_to_parent(index - 1)
+        finally:
+            self.base.node.plates = saved
+
+    def mask_to_parent(self, index, mask):
+        if index == 0:
+            return mask
+        return self.base.mask_to_parent(index - 1, mask.reshape(mask.shape + (1,)))
+
+    def constant_moments(self, index, value):
+        if index == 0:
+            raise NotImplementedError('Mixture needs a Categorical node as its first parent')
+        return self.base.constant_moments(index - 1, value)
+
+    def _with_cluster_axis(self, u):
+        """u_i (plates + dims_i) -> (plates, 1, dims_i)."""
+        out = []
+        for ui, nd in zip(u, self.ndims):
+            ui = _arr(ui)
+            out.append(ui.reshape(ui.shape[:ui.ndim - nd] + (1,) + ui.shape[ui.ndim - nd:]))
+        return out
+
+    def phi_from_parents(self, up):
+        p = up[0][0]
+        phik = self.base.phi_from_parents(up[1:])
+        out = []
+        for ph, nd in zip(phik, self.ndims):
+            ph = _arr(ph)
+            out.append(misc.sum_multiply(_trail(p, nd), ph, axis=-(nd + 1)))
+        return out
+
+    def moments_and_cgf(self, phi):
+        return self.base.moments_and_cgf(phi)
+
+    def cgf_from_parents(self, up):
+        p = up[0][0]
+        gk = self.base.cgf_from_parents(up[1:])
+        return misc.sum_multiply(p, _arr(gk), axis=-1)
+
+    def fixed_moments_and_f(self, x):
+        return self.base.fixed_moments_and_f(x)
+
+    def message_to_parent(self, index, u, up):
+        uk = self._with_cluster_axis(u)
+        if index == 0:
+            # E[log p(y | cluster k)] for every cluster (mixture.py:67-104, expfamily.py:45-61)
+            phik = self.base.phi_from_parents(up[1:])
+            L = _arr(self.base.cgf_from_parents(up[1:]))
+            f = self._f
+            if f is not None:
+                L = fuse(lambda a, b: a + b, L, f if not isinstance(f, DArray) else _trail(f, 1))
+            for ph, ui, nd in zip(phik, uk, self.ndims):
+                t = fuse(lambda a, b: da.where_nonzero(b, a) * b, _arr(ph), ui)
+                L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
+            return [L]
+        p = up[0][0]
+        msgs = self.base.message_to_parent(index - 1, uk, up[1:])
+        out = []
+        parent = self.node.parents[index]
+        for i, m in enumerate(msgs):
+            if m is None:
+                out.append(None)
+                continue
+            nd = len(parent.dims[i])
+            # weight by the responsibilities: a lazy product, fused with the plate sum
+            out.append((_arr(m), _trail(p, nd)))
+        return out
+
+
+class SumMultiplyFamily:
+    """dot.py:19-633: einsum over Gaussian moments and its messages to the parents."""
+
+    def __init__(self, node):
+        self.node = node
+        for p in node.parents:
+            if isinstance(p, Constant):
+                raise NotImplementedError('constant parents of SumMultiply')
+
+    def _labels(self, plan_plates):
+        n = self.node
+        npl = len(n.plates)
+        plate_labels = ['p%d' % i for i in range(npl)]
+        sizes = {lab: s for lab, s in zip(plate_labels, n.plates)}
+        for k, s in n.key_sizes.items():
+            sizes['k%d' % k] = s
+            sizes['K%d' % k] = s
+        return plate_labels, sizes
+
+    def _parent_labels(self, i, second):
+        n = self.node
+        par = n.parents[i]
+        pl, _ = self._labels(None)
+        lead = pl[len(pl) - len(par.plates):] if len(par.plates) else []
+        ks = ['k%d' % k for k in n.in_keys[i]]
+        if second:
+            ks = ks + ['K%d' % k for k in n.in_keys[i]]
+        return list(lead) + ks
+
+    def moments(self, ups):
+        n = self.node
+        pl, sizes = self._labels(None)
+        ops0, labs0, ops1, labs1 = [], [], [], []
+        for i, u in enumerate(ups):
+            x, xx = _arr(u[0]), _arr(u[1])
+            l0 = self._parent_labels(i, False)
+            l1 = self._parent_labels(i, True)
+            ops0.append(x)
+            labs0.append(l0[len(l0) - x.ndim:])
+            ops1.append(xx)
+            labs1.append(l1[len(l1) - xx.ndim:])
+        out0 = pl + ['k%d' % k for k in n.out_keys]
+        out1 = out0 + ['K%d' % k for k in n.out_keys]
+        return [misc.contract(ops0, labs0, out0, sizes), misc.contract(ops1, labs1, out1, sizes)]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        """Messages to parent ``index`` already summed to its plates (dot.py:425-633)."""
+        n = self.node
+        pl, sizes = self._labels(None)
+        par = n.parents[index]
+        npl, nparpl = len(pl), len(par.plates)
+        out = []
+        for second in (False, True):
+            m = m_child[1 if second else 0]
+            if m is None:
+                out.append(None)
+                continue
+            m = _arr(m)
+            lm = pl + ['k%d' % k for k in n.out_keys]
+            if second:
+                lm = lm + ['K%d' % k for k in n.out_keys]
+            ops, labs = [m], [lm[len(lm) - m.ndim:]]
+            for j, u in enumerate(ups):
+                if j == index:
+                    continue
+                a = _arr(u[1 if second else 0])
+                lj = self._parent_labels(j, second)
+                ops.append(a)
+                labs.append(lj[len(lj) - a.ndim:])
+            if mask is not None:
+                ops.append(mask)
+                labs.append(pl[npl - mask.ndim:])
+            present = set()
+            for a, ls in zip(ops, labs):
+                for ax, lab in enumerate(ls):
+                    if a.shape[ax] != 1:
+                        present.add(lab)
+            # plate axes: kept (parent has them and some operand varies along them),
+            # broadcast-compressed (parent has them, no operand varies), summed (parent
+            # lacks them, some operand varies) or an integer factor (parent lacks them and
+            # every operand is unit there -- utils/misc.py:761-802)
+            mult = 1
+            lout, final = [], []
+            for ax, lab in enumerate(pl):
+                pax = ax - (npl - nparpl)
+                in_parent = pax >= 0 and par.plates[pax] != 1
+                if in_parent:
+                    if lab in present:
+                        lout.append(lab)
+                        final.append(sizes[lab])
+                    else:
+                        final.append(1)
+                elif pax >= 0:
+                    final.append(1)
+                    if lab not in present:
+                        mult *= sizes[lab]
+                elif lab not in present:
+                    mult *= sizes[lab]
+            keys = ['k%d' % k for k in n.in_keys[index]]
+            if second:
+                keys = keys + ['K%d' % k for k in n.in_keys[index]]
+            res = misc.contract(ops, labs, lout + keys, sizes, scale=float(mult))
+            final = tuple(final) + tuple(sizes[k] for k in keys)
+            out.append(res.reshape(final))
+        return out
+
+
+def make_family(node):
+    if isinstance(node, Mixture):
+        return MixtureFamily(node, make_family(node._proto))
+    if isinstance(node, Gamma):
+        return GammaFamily(node)
+    if isinstance(node, GaussianARD):
+        return GaussianARDFamily(node)
+    if isinstance(node, Gaussian):
+        return GaussianFamily(node)
+    if isinstance(node, Wishart):
+        return WishartFamily(node)
+    if isinstance(node, Dirichlet):
+        return DirichletFamily(node)
+    if isinstance(node, Categorical):
+        return CategoricalFamily(node)
+    if isinstance(node, SumMultiply):
+        return SumMultiplyFamily(node)
+    raise NotImplementedError('no device family for node type %s' % type(node).__name__)
+
+
+# ---------------------------------------------------------------------------
+# the plan: state + routing
+# ---------------------------------------------------------------------------
+class _State:
+    __slots__ = ('u', 'phi', 'g', 'f', 'observed', 'mask', 'ready')
+
+    def __init__(self):
+        self.u = self.phi = None
+        self.g = self.f = None
+        self.observed = False
+        self.mask = None
+        self.ready = False
+
+
+class GenericPlan:
+
+    @staticmethod
+    def describe():
+        return 'any graph of Gamma, GaussianARD, Gaussian, Wishart, Dirichlet, Categorical, ' \
+               'Mixture, SumMultiply/Dot nodes (generic device message passing)'
+
+    def __init__(self, nodes):
+        self.all = []
+        seen = set()
+
+        def visit(n):
+            if id(n) in seen:
+                return
+            seen.add(id(n))
+            for p in n.parents:
+                visit(p)
+            self.all.append(n)
+            for c, _ in n.children:
+                visit(c)
+        for n in nodes:
+            visit(n)
+        self.family = {}
+        self.state = {}
+        for n in self.all:
+            if isinstance(n, Constant):
+                continue
+            self.family[id(n)] = make_family(n)
+            if isinstance(n, Stochastic):
+                self.state[id(n)] = _State()
+            n._plan = self
+        self._const_cache = {}
+        self._masks_ready = False
+
+    def nodes(self):
+        return [n for n in self.all if not isinstance(n, Constant)]
+
+    def invalidate(self, node):
+        st = self.state.get(id(node))
+        if st is not None:
+            st.ready = False
+        self._masks_ready = False
+
+    # -- moments -----------------------------------------------------------------------
+    def _ensure(self, node):
+        """Materialise the device state of a stochastic node (prior / value / data)."""
+        st = self.state[id(node)]
+        if st.ready:
+            return st
+        fam = self.family[id(node)]
+        st.ready = True          # guards recursion through parents
+        if node.observed:
+            u, f = fam.fixed_moments_and_f(node._data)
+            st.u, st.f, st.g = u, f, None
+            st.observed = True
+            st.phi = None
+        else:
+            st.observed = False
+            up = self._parent_moments(node)
+            st.phi = fam.phi_from_parents(up)
+            init = node._init
+            if init is None:
+                st.u, st.g = fam.moments_and_cgf(st.phi)      # initialize_from_prior
+            elif init[0] == 'value':
+                st.u, _ = fam.fixed_moments_and_f(init[1])
+                st.g = np.inf
+            else:
+                u, _ = fam.moments_and_cgf(st.phi)
+                st.u, _ = fam.fixed_moments_and_f(self._sample(node, fam, u))
+                st.g = np.inf
+            st.f = None
+        return st
+
+    def _sample(self, node, fam, u):
+        """A draw from the current q (initialize_from_random, expfamily.py:206-212); set-up
+        only, on the host -- RNG streams are not part of the parity contract."""
+        if isinstance(node, Categorical):
+            p = np.broadcast_to(u[0].numpy(), node.plates + (fam.K,)).reshape(-1, fam.K)
+            c = np.cumsum(p, axis=1)
+            r = np.random.rand(p.shape[0], 1) * c[:, -1:]
+            return (r > c).sum(axis=1).clip(0, fam.K - 1).reshape(node.plates)
+        if isinstance(node, (GaussianARD, Gaussian)):
+            shape = node.plates + node.dims[0]
+            m = np.broadcast_to(u[0].numpy(), shape)
+            if node.ndim == 0:
+                v = np.broadcast_to(u[1].numpy(), shape) - m * m
+                return m + np.sqrt(np.maximum(v, 0)) * np.random.randn(*shape)
+            D = int(np.prod(node.dims[0]))
+            mm = np.broadcast_to(u[1].numpy(), node.plates + node.dims[1]).reshape(-1, D, D)
+            mf = m.reshape(-1, D)
+            cov = mm - mf[:, :, None] * mf[:, None, :]
+            Lc = np.linalg.cholesky(cov + 1e-12 * np.eye(D))
+            z = np.random.randn(mf.shape[0], D)
+            return (mf + np.einsum('nij,nj->ni', Lc, z)).reshape(shape)
+        raise NotImplementedError('initialize_from_random for %s' % type(node).__name__)
+
+    def _moments(self, node):
+        if isinstance(node, Stochastic):
+            return self._ensure(node).u
+        fam = self.family[id(node)]
+        return fam.moments(self._parent_moments(node))
+
+    def _parent_moments(self, node):
+        fam = self.family[id(node)]
+        out = []
+        for i, p in enumerate(node.parents):
+            if isinstance(p, Constant):
+                key = (id(node), i)
+                if key not in self._const_cache:
+                    self._const_cache[key] = fam.constant_moments(i, p.value)
+                out.append(self._const_cache[key])
+            else:
+                out.append(self._moments(p))
+        return out
+
+    # -- masks (node.py:457-526) -----------------------------------------------------------
+    def _update_masks(self):
+        if self._masks_ready:
+            return
+        memo = {}
+
+        def mask_of(n):
+            if id(n) in memo:
+                return memo[id(n)]
+            m = np.array(False)
+            for c, idx in n.children:
+                if isinstance(c, Constant) or id(c) not in self.family:
+                    continue
+                cm = mask_of(c)
+                fam = self.family[id(c)]
+                if isinstance(fam, SumMultiplyFamily):
+                    pm = cm
+                else:
+                    pm = fam.mask_to_parent(idx, cm)
+                # "sum" (logical or) over the plates that are unit in this node
+                nd = len(n.plates)
+                pm = np.asarray(pm)
+                while pm.ndim > nd:
+                    pm = np.any(pm, axis=0)
+                tgt = (1,) * (nd - pm.ndim) + pm.shape
+                pm = pm.reshape(tgt)
+                axes = tuple(i for i in range(nd) if n.plates[i] == 1 and pm.shape[i] != 1)
+                if axes:
+                    pm = np.any(pm, axis=axes, keepdims=True)
+                m = np.logical_or(m, pm)
+            if isinstance(n, Stochastic) and n.observed:
+                om = np.asarray(n._mask, dtype=bool)
+                m = np.logical_or(m, om)
+            memo[id(n)] = m
+            return m
+        for n in self.nodes():
+            m = mask_of(n)
+            if isinstance(n, Stochastic):
+                self.state[id(n)].mask = m
+            else:
+                n._gmask = m
+        self._dev_masks = {}
+        self._masks_ready = True
+
+    def _mask_array(self, node):
+        self._update_masks()
+        if isinstance(node, Stochastic):
+            return self.state[id(node)].mask
+        return node._gmask
+
+    def _mask_factor(self, host_mask):
+        """None when everything is active, else a 0/1 device array."""
+        if np.all(host_mask):
+            return None
+        key = (host_mask.shape, host_mask.tobytes())
+        if key not in self._dev_masks:
+            self._dev_masks[key] = DArray.from_host(host_mask.astype(np.float64))
+        return self._dev_masks[key]
+
+    # -- message routing (node.py:570-688) ------------------------------------------------------
+    def _message_to_parent(self, child, index):
+        fam = self.family[id(child)]
+        parent = child.parents[index]
+        if isinstance(fam, SumMultiplyFamily):
+            m_child = self._messages_from_children(child)
+            ups = self._parent_moments(child)
+            mask = self._mask_factor(np.asarray(self._mask_array(child)))
+            return fam.message_to_parent(index, m_child, ups, mask)
+        u = self._moments(child)
+        up = self._parent_moments(child)
+        if isinstance(fam, MixtureFamily):
+            fam._f = self._ensure(child).f if isinstance(child, Stochastic) else None
+        msgs = fam.message_to_parent(index, u, up)
+        plates_self = tuple(fam.plates_to_parent(index))
+        hmask = fam.mask_to_parent(index, np.asarray(self._mask_array(child)))
+        mask = self._mask_factor(np.asarray(hmask))
+        out = []
+        for i, m in enumerate(msgs):
+            if m is None:
+                out.append(None)
+                continue
+            factors = list(m) if isinstance(m, tuple) else [_arr(m)]
+            nd = len(parent.dims[i])
+            mshape = broadcasted_shape(*[f.shape for f in factors])
+            dims = broadcasted_shape(mshape[len(mshape) - nd:], parent.dims[i]) if nd else ()
+            from_shape = plates_self + dims
+            to_shape = parent.plates + parent.dims[i]
+            if mask is not None:
+                factors.append(_trail(mask, nd))
+            out.append(misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
+                                                   from_plates=from_shape, ndim=0))
+        return out
+
+    def _messages_from_children(self, node):
+        total = [None] * len(node.dims)
+        for c, idx in node.children:
+            if id(c) not in self.family:
+                continue
+            m = self._message_to_parent(c, idx)
+            for i in range(len(total)):
+                if m[i] is None:
+                    continue
+                total[i] = m[i] if total[i] is None else fuse(lambda a, b: a + b, total[i], m[i])
+        return total
+
+    # -- node operations -------------------------------------------------------------------------
+    def update(self, node):
+        if not isinstance(node, Stochastic):
+            return
+        st = self._ensure(node)
+        if st.observed:
+            return
+        fam = self.family[id(node)]
+        up = self._parent_moments(node)
+        phi = fam.phi_from_parents(up)
+        msgs = self._messages_from_children(node)
+        for i in range(len(phi)):
+            if msgs[i] is not None:
+                phi[i] = fuse(lambda a, b: a + b, _arr(phi[i]), msgs[i])
+        st.phi = phi
+        st.u, st.g = fam.moments_and_cgf(phi)
+
+    def lower_bound_contribution(self, node):
+        """expfamily.py:400-480."""
+        if not isinstance(node, Stochastic):
+            return 0.0
+        st = self._ensure(node)
+        fam = self.family[id(node)]
+        up = self._parent_moments(node)
+        phi_p = fam.phi_from_parents(up)
+        L = _arr(fam.cgf_from_parents(up))
+        if st.observed:
+            L = fuse(lambda a, b: a + b, L, st.f if isinstance(st.f, DArray) else float(st.f))
+        else:
+            if not isinstance(st.g, DArray):
+                return float(-np.inf) if np.isinf(st.g) else float('nan')
+            L = fuse(lambda a, g: a - g, L, st.g)
+        for i, nd in enumerate(len(d) for d in node.dims):
+            if st.observed:
+                t = fuse(lambda pp, u: da.where_nonzero(u, pp) * u, _arr(phi_p[i]), _arr(st.u[i]))
+            else:
+                t = fuse(lambda pp, pq, u: da.where_nonzero(u, pp - pq) * u, _arr(phi_p[i]),
+                         _arr(st.phi[i]), _arr(st.u[i]))
+            L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
+        hmask = np.asarray(self._mask_array(node))
+        factors = [L]
+        mask = self._mask_factor(hmask)
+        if mask is not None:
+            factors.append(mask)
+        tot = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
+        if not np.any(hmask):
+            return 0.0
+        return tot.item()
+
+    def get_moments(self, node):
+        return [np.asarray(_arr(m).numpy()) for m in self._moments(node)]
+
+    def get_parameters(self, node):
+        st = self._ensure(node)
+        return [np.asarray(_arr(p).numpy()) for p in st.phi]

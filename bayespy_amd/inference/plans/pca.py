@@ -223,6 +223,11 @@ class PCAPlan:
         """Data or initial value of ``node`` changed: rebuild device state lazily."""
         self._ready = False
         self._version += 1
+        if node is self.Y and node._mask is not True:
+            # missing data: per-plate posteriors, outside this fused block -> the model
+            # moves to the generic device message-passing engine
+            from .generic import GenericPlan
+            GenericPlan(self.nodes())
 
     # -- device state --------------------------------------------------------------------
     def _materialize(self):
@@ -234,6 +239,10 @@ class PCAPlan:
         if self.Y._data is None:
             raise ValueError('Node %s has not been observed; the fused PCA block needs '
                              'Y.observe(y)' % self.Y.name)
+        if self.Y._mask is not True:
+            from .generic import GenericPlan
+            GenericPlan(self.nodes())
+            raise RuntimeError('model moved to the generic engine; call again')
         rt.sync_stream()
         self.layout = L = k.layout(D, K)
         self.n_total = rt.all_reduce_int(N)

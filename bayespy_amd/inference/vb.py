@@ -47,7 +47,7 @@ def compile_for_node(node):
 class VB:
 
     def __init__(self, *nodes, tol=1e-5, autosave_filename=None, autosave_iterations=0,
-                 use_logging=False, user_data=None, callback=None):
+                 use_logging=False, user_data=None, callback=None, engine=None):
         for i, n in enumerate(nodes):
             if not isinstance(n, Node):
                 raise ValueError("Argument number %d is not a node" % (i + 1))
@@ -63,7 +63,7 @@ class VB:
         names = [n.name for n in self.model]
         if len(set(names)) != len(names):
             raise Exception("Use unique names for nodes.")
-        self.plans = compile_model(self.model)
+        compile_model(self.model, engine=engine)
         self.ignore_bound_checks = False
         self.iter = 0
         self.converged = False
@@ -73,6 +73,17 @@ class VB:
         self.callback = callback
         self.callback_output = None
         self.tol = tol
+
+    @property
+    def plans(self):
+        """The execution plans that currently own the model's nodes."""
+        out, seen = [], set()
+        for n in self.model:
+            p = n._plan
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
 
     # -- containers ---------------------------------------------------------------
     def __getitem__(self, name):

@@ -4,7 +4,12 @@ Node classes with the reference's construction API
 """
 from .node import Node, Constant, Stochastic
 from .gamma import Gamma
-from .gaussian import GaussianARD
+from .gaussian import GaussianARD, Gaussian
 from .dot import SumMultiply, Dot
+from .wishart import Wishart
+from .dirichlet import Dirichlet
+from .categorical import Categorical
+from .mixture import Mixture
 
-__all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'SumMultiply', 'Dot']
+__all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
+           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Mixture']

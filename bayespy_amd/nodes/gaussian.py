@@ -47,4 +47,39 @@ class GaussianARD(Stochastic):
 
 def _is_gaussian(node):
     from .dot import SumMultiply
-    return isinstance(node, (GaussianARD, SumMultiply))
+    return isinstance(node, (GaussianARD, SumMultiply)) or type(node).__name__ == 'Gaussian'
+
+
+class Gaussian(Stochastic):
+    """``Gaussian(mu, Lambda)``: mean ``mu`` (Gaussian moments or array) and precision
+    matrix ``Lambda`` (Wishart node or SPD array) -- reference gaussian.py:1346-1556,
+    formulas gaussian.py:293-573; the joint (mu, Lambda) wrapper of the reference
+    (``WrapToGaussianWishart``, gaussian.py:2374-2527) is folded into the formulas."""
+
+    def __init__(self, mu, Lambda, plates=None, name=None):
+        super().__init__(mu, Lambda, plates=(), dims=((), ()), name=name)
+        from .node import Constant
+        mu_node, L_node = self.parents
+        if isinstance(L_node, Constant):
+            Ls = L_node.value.shape
+            if len(Ls) < 2 or Ls[-1] != Ls[-2]:
+                raise ValueError('Lambda must be a (..., D, D) array')
+            D, Lplates = Ls[-1], Ls[:-2]
+        else:
+            D, Lplates = L_node.dims[0][0], L_node.plates
+        if isinstance(mu_node, Constant):
+            ms = mu_node.value.shape
+            mu_plates = ms[:-1] if len(ms) >= 1 else ()
+            if len(ms) >= 1 and ms[-1] not in (1, D):
+                raise ValueError('mu has %d components, Lambda is %dx%d' % (ms[-1], D, D))
+        else:
+            if len(mu_node.dims[0]) != 1 or mu_node.dims[0][0] != D:
+                raise ValueError('mu must be a vector variable of length %d' % D)
+            mu_plates = mu_node.plates
+        self.shape = (D,)
+        self.ndim = 1
+        self.dims = ((D,), (D, D))
+        given = tuple(plates) if plates is not None else ()
+        self.plates = broadcasted_shape(given, mu_plates, Lplates)
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))

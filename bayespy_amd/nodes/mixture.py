@@ -1,0 +1,39 @@
+"""
+Mixture node (reference: bayespy/inference/vmp/nodes/mixture.py:359-545).
+
+``Mixture(z, Dist, *params, cluster_plate=-1, plates=...)``: the variable follows
+``Dist(*params[k])`` where ``k`` is the class of the categorical node ``z`` and the
+parameters carry the cluster axis among their plates.
+"""
+from .node import Stochastic
+from ..utils.shapes import broadcasted_shape
+
+
+class Mixture(Stochastic):
+
+    def __init__(self, z, node_class, *params, cluster_plate=-1, plates=None, name=None):
+        if cluster_plate != -1:
+            raise NotImplementedError('only cluster_plate=-1 is built')
+        super().__init__(z, *params, plates=(), dims=((), ()), name=name)
+        self.node_class = node_class
+        self.cluster_plate = cluster_plate
+        # a throw-away instance of the mixed node class gives dims and plates
+        # (with the cluster axis still among the plates)
+        proto = node_class(*self.parents[1:])
+        for p in self.parents[1:]:
+            p.children = [(c, i) for (c, i) in p.children if c is not proto]
+        self._proto = proto
+        self.dims = proto.dims
+        if hasattr(proto, 'shape'):
+            self.shape = proto.shape
+            self.ndim = proto.ndim
+        K = self.parents[0].dims[0][0]
+        pp = proto.plates
+        if len(pp) < 1 or pp[-1] not in (1, K):
+            raise ValueError('The cluster plate (%s) of the parameters does not match the '
+                             'number of categories %d' % (pp[-1:] or None, K))
+        self.clusters = K
+        given = tuple(plates) if plates is not None else ()
+        self.plates = broadcasted_shape(given, self.parents[0].plates, pp[:-1])
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))

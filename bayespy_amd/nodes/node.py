@@ -102,13 +102,20 @@ class Stochastic(Node):
     def observe(self, x, mask=True):
         """Fix the node to data.  ``x`` may be a host ndarray or a fp64 tensor
         already resident in HBM (then it is used in place)."""
-        if not (mask is True or (np.ndim(mask) == 0 and bool(mask))):
-            raise NotImplementedError(
-                'array observation masks (missing data) are not built yet; only the scalar '
-                'mask=True path of expfamily.py:369-398 is supported')
         self._check_value_shape(x)
+        if mask is True or (np.ndim(mask) == 0 and bool(mask)):
+            mask = True
+        else:
+            mask = np.asarray(mask, dtype=bool)
+            try:
+                ok = broadcasted_shape(mask.shape, self.plates) == self.plates
+            except ValueError:
+                ok = False
+            if not ok:
+                raise ValueError('Mask of shape %s does not broadcast to plates %s'
+                                 % (mask.shape, self.plates))
         self._data = x
-        self._mask = True
+        self._mask = mask
         self.observed = True
         if self._plan is not None:
             self._plan.invalidate(self)

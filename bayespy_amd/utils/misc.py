@@ -230,3 +230,57 @@ def onehot(labels, K):
     if int(info.item()) != 0:
         raise ValueError("Class indices out of range [0, %d)" % K)
     return out
+
+
+def contract(operands, labels, out_labels, sizes, scale=1.0):
+    """
+    Labeled broadcast contraction (one ``vmp_sum_multiply`` launch):
+
+        out[out_labels] = scale * sum_{labels not in out_labels} prod_i operands[i][labels[i]]
+
+    ``labels[i]`` names every axis of ``operands[i]`` (an axis of extent 1 is a
+    broadcast axis whatever its label); ``sizes`` maps label -> extent.  This is
+    the einsum of ``SumMultiply`` (dot.py:355, :403, :581) on device arrays.
+    """
+    ops = [asdarray(a) for a in operands]
+    all_labels = list(out_labels)
+    for ls in labels:
+        for lab in ls:
+            if lab not in all_labels:
+                all_labels.append(lab)
+    nd = len(all_labels)
+    # a summed label along which EVERY operand is unit contributes no implicit factor
+    # (plate multipliers are explicit, via `scale`)
+    varying = set()
+    for a, ls in zip(ops, labels):
+        for ax, lab in enumerate(ls):
+            if a.shape[ax] != 1:
+                varying.add(lab)
+    shape = tuple(int(sizes[lab]) if (lab in out_labels or lab in varying) else 1
+                  for lab in all_labels)
+    views = []
+    for a, ls in zip(ops, labels):
+        if a.ndim != len(ls):
+            raise ValueError('operand with %d axes given %d labels' % (a.ndim, len(ls)))
+        # a strided view of `a` laid out along all_labels (extent 1 / stride 0 where absent)
+        st, sh = [], []
+        for lab in all_labels:
+            if lab in ls:
+                ax = list(ls).index(lab)
+                if a.shape[ax] == 1:
+                    st.append(0)
+                    sh.append(1)
+                else:
+                    if a.shape[ax] != sizes[lab]:
+                        raise ValueError('axis %r has extent %d, expected %d'
+                                         % (lab, a.shape[ax], sizes[lab]))
+                    st.append(a.t.stride(ax))
+                    sh.append(a.shape[ax])
+            else:
+                st.append(0)
+                sh.append(1)
+        views.append(DArray(a.t.as_strided(sh, st, a.t.storage_offset())))
+    red = [i for i, lab in enumerate(all_labels) if lab not in out_labels]
+    keep_shape = tuple(1 if i in red else shape[i] for i in range(nd))
+    out = _launch_sum_multiply(views, shape, red, keep_shape, scale)
+    return out.reshape(tuple(shape[i] for i in range(len(out_labels))))

@@ -216,6 +216,76 @@ def utils_cases(name):
     print(name, 'cases', len(cases))
 
 
+def small_model_cases(name):
+    """Small graphs that exercise every built node family and the message routing
+    (plates, masks, plate multipliers); used to pin the generic device engine."""
+    from bayespy.nodes import (GaussianARD, Gaussian, Gamma, Wishart, Dirichlet, Categorical,
+                               SumMultiply)
+    from bayespy.inference import VB
+    rs = np.random.RandomState(77)
+    out = {}
+
+    def run(tag, Q, nodes, n_iter=4):
+        Q.ignore_bound_checks = True
+        Ls = []
+        for _ in range(n_iter):
+            Q.update(repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+        out[tag + '_L'] = np.array(Ls)
+        for nm, nd in nodes.items():
+            for i, ui in enumerate(nd.u):
+                out['%s_%s_u%d' % (tag, nm, i)] = np.asarray(ui)
+            out['%s_%s_L' % (tag, nm)] = np.array(Q.l[nd][:Q.iter])
+
+    # (a) masked PCA (demos/pca.py:80-82 default usage: randomly missing values)
+    D, N, K = 5, 60, 2
+    w, x = rs.normal(size=(D, K)), rs.normal(size=(N, K))
+    y = w @ x.T + 0.1 * rs.normal(size=(D, N))
+    mask = rs.rand(D, N) < 0.8
+    x0 = rs.normal(size=(N, K))
+    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    F = SumMultiply('i,i', W, X, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None])
+    Y.observe(y, mask=mask)
+    out['mpca_y'], out['mpca_mask'], out['mpca_x0'] = y, mask, x0
+    run('mpca', VB(Y, F, W, X, tau, alpha), dict(W=W, X=X, tau=tau, alpha=alpha))
+
+    # (b) vector GaussianARD with a Gaussian mean parent and per-component precision
+    N = 50
+    data = rs.normal(size=(N, 3)) * np.array([1.0, 2.0, 0.5]) + np.array([1.0, -2.0, 0.0])
+    mu = GaussianARD(0, 1e-3, shape=(3,), name='mu')
+    al = Gamma(1e-3, 1e-3, plates=(3,), name='al')
+    yy = GaussianARD(mu, al, shape=(3,), plates=(N,), name='yy')
+    yy.observe(data)
+    out['vard_data'] = data
+    run('vard', VB(yy, mu, al), dict(mu=mu, al=al))
+
+    # (c) Gaussian with Wishart precision
+    N = 40
+    data = rs.multivariate_normal([1.0, 0.0, -1.0], [[1.0, 0.5, 0.0], [0.5, 2.0, 0.3],
+                                                      [0.0, 0.3, 0.5]], size=N)
+    mu = GaussianARD(0, 1e-3, shape=(3,), name='mu')
+    Lam = Wishart(3, np.identity(3), name='Lam')
+    yg = Gaussian(mu, Lam, plates=(N,), name='yg')
+    yg.observe(data)
+    out['gw_data'] = data
+    run('gw', VB(yg, mu, Lam), dict(mu=mu, Lam=Lam))
+
+    # (d) Dirichlet + Categorical with observed labels
+    lab = rs.randint(4, size=30)
+    p = Dirichlet(np.array([1.0, 0.5, 2.0, 1.5]), name='p')
+    z = Categorical(p, plates=(30,), name='z')
+    z.observe(lab)
+    out['dc_lab'] = lab
+    run('dc', VB(z, p), dict(p=p), n_iter=2)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, {k: v for k, v in out.items() if k.endswith('_L') and k.count('_') == 1})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -228,6 +298,7 @@ def main():
     gmm_case('gmm_n400_d3_k4', N=400, D=3, K=4, n_iter=5, seed=11)
     gmm_case('gmm_n3000_d8_k16', N=3000, D=8, K=16, n_iter=4, seed=12)
     utils_cases('utils_known_answers')
+    small_model_cases('small_models')
 
 
 if __name__ == '__main__':

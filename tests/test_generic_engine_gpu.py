@@ -1,0 +1,185 @@
+"""
+GPU parity of the generic device message-passing engine
+(bayespy_amd/inference/plans/generic.py) against golden traces of the LIVE
+reference on identical inputs (tests/golden/*.npz from oracle/make_golden.py):
+config 1 (quickstart, incl. the reference's doctest known answer), masked PCA,
+vector GaussianARD, Gaussian+Wishart, Dirichlet+Categorical, the Gaussian
+mixture of demos/mog.py, and the PCA block forced through the generic engine.
+
+Tolerances: ELBO rtol 1e-9; moments rtol 1e-7; one-hot / counts exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ELBO_RTOL = 1e-9
+MOM_RTOL = 1e-7
+
+
+def _trace(Q, n):
+    Q.ignore_bound_checks = True
+    Q.update(repeat=n, verbose=False)
+    return Q.L[:n]
+
+
+def test_quickstart_known_answer_on_device(golden_dir):
+    """doc/source/user_guide/quickstart.rst:111-118 reproduced by HIP kernels."""
+    from bayespy_amd.nodes import GaussianARD, Gamma
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.generic import GenericPlan
+    for name in ('quickstart_n10', 'quickstart_n1000'):
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        data = g['data']
+        mu = GaussianARD(0, 1e-6, name='mu')
+        tau = Gamma(1e-6, 1e-6, name='tau')
+        y = GaussianARD(mu, tau, plates=(len(data),), name='y')
+        y.observe(data)
+        Q = VB(y, mu, tau)
+        assert isinstance(Q.plans[0], GenericPlan)
+        n = int(g['n_iter'])
+        Q.ignore_bound_checks = True
+        for i in range(n):
+            Q.update(repeat=1, verbose=False)
+            np.testing.assert_allclose([float(v) for v in mu.u], g['mu_u'][i], rtol=MOM_RTOL)
+            np.testing.assert_allclose([float(v) for v in tau.u], g['tau_u'][i], rtol=MOM_RTOL)
+        np.testing.assert_allclose(Q.L[:n], g['L'], rtol=ELBO_RTOL)
+        if name == 'quickstart_n10':
+            assert ['%e' % v for v in Q.L[:n]] == ['-6.020956e+01', '-5.820527e+01',
+                                                   '-5.820290e+01', '-5.820288e+01']
+
+
+def _check_nodes(g, tag, nodes):
+    for nm, nd in nodes.items():
+        u = nd.u
+        for i, ui in enumerate(u):
+            ref = g['%s_%s_u%d' % (tag, nm, i)]
+            got = np.broadcast_to(ui, ref.shape) if np.shape(ui) != ref.shape else ui
+            np.testing.assert_allclose(got, ref, rtol=MOM_RTOL, atol=1e-9,
+                                       err_msg='%s.%s u[%d]' % (tag, nm, i))
+
+
+def test_masked_pca_matches_reference(golden_dir):
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.generic import GenericPlan
+    g = np.load(os.path.join(golden_dir, 'small_models.npz'))
+    y, mask, x0 = g['mpca_y'], g['mpca_mask'], g['mpca_x0']
+    D, N = y.shape
+    K = x0.shape[1]
+    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    F = SumMultiply('i,i', W, X, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None])
+    Q = VB(Y, F, W, X, tau, alpha)
+    Y.observe(y, mask=mask)          # after VB: the fused block hands over to the generic engine
+    assert isinstance(Q.plans[0], GenericPlan)
+    L = _trace(Q, 4)
+    np.testing.assert_allclose(L, g['mpca_L'], rtol=ELBO_RTOL)
+    _check_nodes(g, 'mpca', dict(W=W, X=X, tau=tau, alpha=alpha))
+    for nm, nd in dict(W=W, X=X, tau=tau, alpha=alpha).items():
+        np.testing.assert_allclose(Q.l[nd][:4], g['mpca_%s_L' % nm], rtol=1e-8, atol=1e-8)
+
+
+def test_vector_gaussian_ard_matches_reference(golden_dir):
+    from bayespy_amd.nodes import GaussianARD, Gamma
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'small_models.npz'))
+    data = g['vard_data']
+    mu = GaussianARD(0, 1e-3, shape=(3,), name='mu')
+    al = Gamma(1e-3, 1e-3, plates=(3,), name='al')
+    yy = GaussianARD(mu, al, shape=(3,), plates=(len(data),), name='yy')
+    yy.observe(data)
+    Q = VB(yy, mu, al)
+    np.testing.assert_allclose(_trace(Q, 4), g['vard_L'], rtol=ELBO_RTOL)
+    _check_nodes(g, 'vard', dict(mu=mu, al=al))
+
+
+def test_gaussian_wishart_matches_reference(golden_dir):
+    from bayespy_amd.nodes import GaussianARD, Gaussian, Wishart
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'small_models.npz'))
+    data = g['gw_data']
+    mu = GaussianARD(0, 1e-3, shape=(3,), name='mu')
+    Lam = Wishart(3, np.identity(3), name='Lam')
+    yg = Gaussian(mu, Lam, plates=(len(data),), name='yg')
+    yg.observe(data)
+    Q = VB(yg, mu, Lam)
+    np.testing.assert_allclose(_trace(Q, 4), g['gw_L'], rtol=ELBO_RTOL)
+    _check_nodes(g, 'gw', dict(mu=mu, Lam=Lam))
+
+
+def test_dirichlet_categorical_matches_reference(golden_dir):
+    from bayespy_amd.nodes import Dirichlet, Categorical
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'small_models.npz'))
+    p = Dirichlet(np.array([1.0, 0.5, 2.0, 1.5]), name='p')
+    z = Categorical(p, plates=(30,), name='z')
+    z.observe(g['dc_lab'])
+    Q = VB(z, p)
+    np.testing.assert_allclose(_trace(Q, 2), g['dc_L'], rtol=ELBO_RTOL)
+    _check_nodes(g, 'dc', dict(p=p))
+    # one-hot moments of the observed labels: integer indexing, bit-exact
+    ref = np.zeros((30, 4))
+    ref[np.arange(30), g['dc_lab']] = 1
+    assert np.array_equal(z.u[0], ref)
+    with pytest.raises(ValueError):
+        z.observe(np.full(30, 7))
+        z.u
+
+
+@pytest.mark.parametrize('name', ['gmm_n400_d3_k4', 'gmm_n3000_d8_k16'])
+def test_gaussian_mixture_matches_reference(golden_dir, name):
+    """demos/mog.py:17-64 (Mixture + Categorical + Gaussian + Wishart + Dirichlet)."""
+    from bayespy_amd.nodes import (GaussianARD, Gaussian, Wishart, Dirichlet, Categorical,
+                                   Mixture)
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    y, lab0 = g['y'], g['lab0']
+    N, D = y.shape
+    K = g['alpha_u0'].shape[-1]
+    alpha = Dirichlet(1e-3 * np.ones(K), name='alpha')
+    z = Categorical(alpha, plates=(N,), name='z')
+    mu = GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
+    Lam = Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
+    Y = Mixture(z, Gaussian, mu, Lam, plates=(N,), name='Y')
+    z.initialize_from_value(lab0)
+    Y.observe(y)
+    Q = VB(Y, mu, Lam, z, alpha)
+    n = int(g['n_iter'])
+    L = _trace(Q, n)
+    np.testing.assert_allclose(L, g['L'], rtol=ELBO_RTOL)
+    for k in ('Y', 'mu', 'Lambda', 'z', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[k]][:n], g['L_' + k], rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(z.u[0], g['z_u0'], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(mu.u[0], g['mu_u0'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(mu.u[1], g['mu_u1'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Lam.u[0], g['Lambda_u0'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Lam.u[1], g['Lambda_u1'], rtol=MOM_RTOL)
+    np.testing.assert_allclose(alpha.u[0], g['alpha_u0'], rtol=MOM_RTOL)
+
+
+def test_pca_block_through_generic_engine(golden_dir):
+    """The same PCA golden trace, with the fused block switched off: exercises
+    SumMultiply moments/messages (dot.py:316-633) and the plate multipliers."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.generic import GenericPlan
+    from models import build_pca
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = build_pca(nodes, VB, g['y'], g['x0'], 3, engine='generic')
+    assert isinstance(Q.plans[0], GenericPlan)
+    n = int(g['n_iter'])
+    np.testing.assert_allclose(_trace(Q, n), g['L'], rtol=ELBO_RTOL)
+    np.testing.assert_allclose(Q['W'].u[0], g['W_u0'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(np.broadcast_to(Q['W'].u[1], g['W_u1'].shape), g['W_u1'],
+                               rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Q['X'].u[0], g['X_u0'], rtol=MOM_RTOL, atol=1e-10)
+    F = Q['F'].get_moments()
+    np.testing.assert_allclose(F[0][:, :5], g['F_u0'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(F[1][:, :5], g['F_u1'], rtol=MOM_RTOL, atol=1e-10)

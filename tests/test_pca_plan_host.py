@@ -75,22 +75,37 @@ def test_lower_bound_cache_and_observed_skip(golden_dir):
     assert a == b == Q.L[0]
 
 
-def test_unsupported_models_fail_loudly():
+def test_plan_selection_and_loud_failures():
+    from bayespy_amd.inference.plans.generic import GenericPlan
+    from bayespy_amd.nodes.node import Stochastic
     K, D, N = 3, 4, 10
+    # config 1 (quickstart model): no fused block -> generic device message passing
     mu = nodes.GaussianARD(0, 1e-6, name='mu')
     tau = nodes.Gamma(1e-6, 1e-6, name='tau')
     y = nodes.GaussianARD(mu, tau, plates=(N,), name='y')
-    with pytest.raises(NotImplementedError, match='No HIP execution plan'):
-        VB(y, mu, tau)
-    # array masks are a later row of the scope table
+    Q = VB(y, mu, tau)
+    assert isinstance(Q.plans[0], GenericPlan) and len(Q.plans) == 1
+    # a fully observed PCA block is fused ...
     alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,))
     W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
     X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, N))
     Y = nodes.GaussianARD(nodes.Dot(W, X), nodes.Gamma(1e-2, 1e-2))
-    with pytest.raises(NotImplementedError):
-        Y.observe(np.zeros((D, N)), mask=np.ones((D, N), dtype=bool))
+    Q2 = VB(Y, W, X)
+    assert isinstance(Q2.plans[0], PCAPlan)
+    # ... and moves to the generic engine as soon as data are missing (array mask)
+    Y.observe(np.zeros((D, N)), mask=np.ones((D, N), dtype=bool))
+    assert isinstance(Q2.plans[0], GenericPlan)
+    assert VB(Y, W, X, engine='generic') is not None
     with pytest.raises(ValueError):
         Y.observe(np.zeros((D + 1, N)))
+    with pytest.raises(ValueError):
+        Y.observe(np.zeros((D, N)), mask=np.ones((D, N + 1), dtype=bool))
+
+    # node types without device formulas fail loudly -- there is no CPU fallback
+    class Exotic(Stochastic):
+        pass
+    with pytest.raises(NotImplementedError, match='no device family'):
+        VB(Exotic(plates=(3,), dims=((),)))
 
 
 def test_plates_and_shapes_follow_reference_rules():
