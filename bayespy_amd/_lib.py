@@ -51,6 +51,13 @@ class PCALayout(ctypes.Structure):
         'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_G', 'off_scal', 'off_L', 'total')]
 
 
+class GMMLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        'DP', 'KP', 'FS', 'FP', 'F2P', 'off_T', 'len_T', 'off_zs', 'off_alpha', 'off_mu',
+        'off_Cmu', 'off_logdetLmu', 'off_nk', 'off_Vk', 'off_Lam', 'off_logdetLam',
+        'off_logdetV', 'off_C', 'off_prior', 'off_scal', 'off_L', 'total')]
+
+
 c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 P = ctypes.POINTER
@@ -84,6 +91,17 @@ SIGNATURES = {
     'vmp_pca_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_vp]),
     'vmp_pca_lower_bound': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
                                     c_f64, c_vp]),
+    'vmp_gmm_get_layout': (c_i32, [c_i32, c_i32, P(GMMLayout)]),
+    'vmp_gmm_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, P(c_sz)]),
+    'vmp_gmm_init_state': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_f64, c_f64, c_vp, c_vp]),
+    'vmp_gmm_stats_from_labels': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                          c_vp]),
+    'vmp_gmm_update_mu': (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    'vmp_gmm_update_lambda': (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    'vmp_gmm_prepare_z': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
+    'vmp_gmm_pass': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'vmp_gmm_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    'vmp_gmm_lower_bound': (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     'vmp_sum_multiply': (c_i32, [c_vp, c_i32, P(c_i64), c_i32, P(c_vp), P(c_i64), P(c_i64),
                                  ctypes.c_uint32, c_f64, c_vp, c_vp, c_sz]),
     'vmp_sum_multiply_workspace_bytes': (c_sz, []),

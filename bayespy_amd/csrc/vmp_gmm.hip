@@ -1,0 +1,806 @@
+// vmp_gmm.hip -- fused full-covariance Gaussian-mixture VB block for gfx950.
+//
+// Model block of bayespy/demos/mog.py:17-64:
+//   Y = Mixture(z, Gaussian, mu, Lambda), z = Categorical(alpha), alpha = Dirichlet(a0),
+//   mu = GaussianARD(0, beta0, shape=(D,), plates=(K,)), Lambda = Wishart(n0, V0, plates=(K,)),
+// Y fully observed.  Replaces the NumPy call sites E12, E18-E24 of SURVEY.md 2.2:
+//   mixture.py:53-293 (+ expfamily.py:45-61 compute_logpdf), multinomial.py:83-128,
+//   utils/misc.py:1366-1401 (normalized_exp), gaussian.py:293-573, :2374-2527,
+//   wishart.py:118-225, dirichlet.py:107-231, expfamily.py:400-480.
+//
+// One pass over Y per VB iteration (issued by z.update()):
+//   phase 1  Phi(K x 16) = C (K x F) * feat(y)     feat = [y_a y_b, y_d, 1]   (fp64 MFMA)
+//   softmax  r = normalized_exp(Phi) per column (reference recipe), r written (N, K)
+//   phase 2  T (K x F2) += r * feat2(y)^T          feat2 = [y_a y_b (a<=b), y_d, 1]
+// T = [R_k, sum r y, sum r y y^T] are the messages to mu / Lambda / alpha, i.e. the
+// plate sums of mixture.py:126-158 + node.py:650 that the reference materialises
+// as (N, K, D, D) arrays.  D <= 8, K <= 64 built.
+//
+// Layout: Y (N, D) row-major as in the reference (plates (N,), dims (D,)); a wave reads
+// 16 consecutive rows = one contiguous block.  r (N, K) row-major, written as whole rows.
+#include "vmp_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int TNC = 16;          // columns (plate elements) per wave tile
+constexpr int MAXK = 64, MAXD = 8;
+
+inline int round_pow2(int x, int unit)
+{
+    int b = (x + unit - 1) / unit, p = 1;
+    while (p < b) p <<= 1;
+    return p * unit;
+}
+
+inline int n_feat2(int D) { return D * (D + 1) / 2 + D + 1; }
+
+inline void fill_layout(int D, int K, vmp_gmm_layout *L)
+{
+    const int64_t DP = round_pow2(D, 4), KP = round_pow2(K, 16);
+    const int64_t FS = 1 + D + (int64_t)D * D;
+    const int64_t FP = DP * DP + DP + 4;
+    int64_t o = 0;
+    L->DP = DP; L->KP = KP; L->FS = FS; L->FP = FP;
+    L->F2P = (n_feat2(D) + 15) / 16 * 16;
+    L->off_T = o;         L->len_T = KP * FS; o += L->len_T;
+    L->off_zs = o;        o += 8;
+    L->off_alpha = o;     o += 2 * KP;
+    L->off_mu = o;        o += KP * D;
+    L->off_Cmu = o;       o += KP * D * D;
+    L->off_logdetLmu = o; o += KP;
+    L->off_nk = o;        o += KP;
+    L->off_Vk = o;        o += KP * D * D;
+    L->off_Lam = o;       o += KP * D * D;
+    L->off_logdetLam = o; o += KP;
+    L->off_logdetV = o;   o += KP;
+    L->off_C = o;         o += KP * FP;
+    L->off_prior = o;     o += KP + 8 + (int64_t)D * D;   // alpha0[KP], beta0, n0, logdetV0, -, V0
+    L->off_scal = o;      o += 8;
+    L->off_L = o;         o += 8;
+    L->total = (o + 7) / 8 * 8;
+}
+
+__device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ inline void lds_fence()
+{
+    // LDS operations of one wavefront complete in issue order: waiting for the
+    // outstanding ones makes this wave's writes visible to all of its lanes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
+// The pass.  DPT = DP/4 in {1,2}, KT = KP/16 in {1,2,4}, FT2 = F2P/16 in {1,2,3}.
+// FROM_LABELS: responsibilities are the one-hot of given labels
+// (z.initialize_from_value, categorical.py:30-46) instead of the softmax.
+// ---------------------------------------------------------------------------
+template <int DPT, int KT, int FT2, bool FROM_LABELS>
+__global__ void __launch_bounds__(NT, 2)
+gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
+                const double *__restrict__ Cmat, const int64_t *__restrict__ labels,
+                double *__restrict__ Rout, double *__restrict__ P, int64_t ntiles)
+{
+    constexpr int DP = 4 * DPT, KP = 16 * KT;
+    constexpr int KSQ = DP * DPT;                 // quadratic k-steps
+    constexpr int KS1 = KSQ + DPT + 1;            // + linear + constant
+    constexpr int FP = DP * DP + DP + 4;
+    constexpr int YS = DP + 3;                    // y tile row stride (ONE at DP, ZERO at DP+1)
+    constexpr int RS = KP + 1;                    // r tile row stride
+    constexpr int F2P = 16 * FT2;
+
+    extern __shared__ double lds[];
+    double *Cf = lds;                                            // KT*KS1*64
+    double *wbase = lds + (FROM_LABELS ? 0 : KT * KS1 * 64);
+    const int tid = threadIdx.x;
+    const int l = tid & 63, l15 = l & 15, g = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *ytile = wbase + w * (TNC * YS + TNC * RS);           // [16][YS]
+    double *rtile = ytile + TNC * YS;                            // [16][RS]
+
+    if (!FROM_LABELS) {
+        // A fragments of phase 1: lane holds C[it*16 + l15][4q + g]
+        for (int e = tid; e < KT * KS1 * 64; e += NT) {
+            const int lane = e & 63, fq = e >> 6;
+            const int it = fq / KS1, q = fq - it * KS1;
+            Cf[e] = Cmat[(int64_t)(it * 16 + (lane & 15)) * FP + 4 * q + (lane >> 4)];
+        }
+    }
+    // constant slots of the y tile
+    ytile[l15 * YS + DP] = 1.0;
+    ytile[l15 * YS + DP + 1] = 0.0;
+    __syncthreads();
+
+    // phase-2 features of this lane: feat2[ft*16 + l15] = ytile[n][ia] * ytile[n][ib]
+    int ia[FT2], ib[FT2];
+    {
+        const int npair = D * (D + 1) / 2;
+#pragma unroll
+        for (int ft = 0; ft < FT2; ++ft) {
+            const int f = ft * 16 + l15;
+            int a = DP + 1, b = DP + 1;              // zero feature
+            if (f < npair) {
+                int rem = f, aa = 0;
+                while (rem >= D - aa) { rem -= D - aa; ++aa; }
+                a = aa; b = aa + rem;
+            } else if (f < npair + D) {
+                a = f - npair; b = DP;               // linear: y_d * 1
+            } else if (f == npair + D) {
+                a = DP; b = DP;                      // constant
+            }
+            ia[ft] = a; ib[ft] = b;
+        }
+    }
+
+    v4f64 acc2[KT][FT2];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int ft = 0; ft < FT2; ++ft) acc2[it][ft] = v4f64{0.0, 0.0, 0.0, 0.0};
+    double s_lse = 0.0, s_rphi = 0.0;
+
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += stride) {
+        const int64_t n0 = tile * TNC;
+        const int64_t n = n0 + l15;
+        const bool nok = n < N;
+        // ---- y: lane (g, l15) owns y[n][4j + g] ------------------------------------
+        double yb[DPT];
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            const int d = 4 * j + g;
+            yb[j] = (nok && d < D) ? Y[n * D + d] : 0.0;
+            ytile[l15 * YS + d] = yb[j];
+        }
+        lds_fence();
+
+        if (!FROM_LABELS) {
+            double ya[DP];
+#pragma unroll
+            for (int a = 0; a < DP; ++a) ya[a] = ytile[l15 * YS + a];
+            // ---- phase 1: Phi = C * feat(y) -------------------------------------------
+            v4f64 acc1[KT];
+#pragma unroll
+            for (int it = 0; it < KT; ++it) acc1[it] = v4f64{0.0, 0.0, 0.0, 0.0};
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < KS1; ++q) {
+                double b;
+                if (q < KSQ) b = ya[q / DPT] * yb[q % DPT];
+                else if (q < KSQ + DPT) b = yb[q - KSQ];
+                else b = (g == 0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int it = 0; it < KT; ++it)
+                    acc1[it] = mfma_f64(Cf[(it * KS1 + q) * 64 + l], b, acc1[it]);
+            }
+            // ---- softmax over k for column n (utils/misc.py:1388-1401) ------------------
+            // lane holds Phi[k = it*16 + g + 4r][n]
+            double mx = -INFINITY;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmax(mx, acc1[it][r]);
+            mx = fmax(mx, __shfl_xor(mx, 16, 64));
+            mx = fmax(mx, __shfl_xor(mx, 32, 64));
+            if (!isfinite(mx)) mx = 0.0;
+            double e[KT][4], s = 0.0;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[it][r] = exp(acc1[it][r] - mx);
+                    s += e[it][r];
+                }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const double lse = log(s) + mx;
+            double s2 = 0.0;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[it][r] = exp(acc1[it][r] - lse);
+                    s2 += e[it][r];
+                }
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const double inv = nok ? 1.0 / s2 : 0.0;
+            if (nok && g == 0) s_lse += lse;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double p = e[it][r] * inv;
+                    if (p != 0.0) s_rphi += p * acc1[it][r];
+                    rtile[l15 * RS + it * 16 + g + 4 * r] = p;
+                }
+        } else {
+            const int64_t lab = nok ? labels[n] : -1;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = it * 16 + g + 4 * r;
+                    rtile[l15 * RS + k] = (lab == k) ? 1.0 : 0.0;
+                }
+        }
+        lds_fence();
+
+        // ---- r -> HBM, whole rows (N, K) ------------------------------------------------
+#pragma unroll 4
+        for (int rr = 0; rr < TNC; ++rr) {
+            if (n0 + rr < N) {
+                for (int k = l; k < K; k += 64) Rout[(n0 + rr) * K + k] = rtile[rr * RS + k];
+            }
+        }
+
+        // ---- phase 2: T += r * feat2(y)^T  (contraction over the 16 columns) ---------------
+#pragma unroll
+        for (int q = 0; q < TNC / 4; ++q) {
+            const int nn = 4 * q + g;
+            double bf[FT2];
+#pragma unroll
+            for (int ft = 0; ft < FT2; ++ft)
+                bf[ft] = ytile[nn * YS + ia[ft]] * ytile[nn * YS + ib[ft]];
+#pragma unroll
+            for (int it = 0; it < KT; ++it) {
+                const double a = rtile[nn * RS + it * 16 + l15];
+#pragma unroll
+                for (int ft = 0; ft < FT2; ++ft) acc2[it][ft] = mfma_f64(a, bf[ft], acc2[it][ft]);
+            }
+        }
+        lds_fence();
+    }
+
+    // ---- per-wave partials: [KP][F2P] + 2 scalars -------------------------------------------
+    const int64_t plen = (int64_t)KP * F2P + 8;
+    double *Pw = P + ((int64_t)blockIdx.x * 4 + w) * plen;
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int ft = 0; ft < FT2; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Pw[(it * 16 + g + 4 * r) * F2P + ft * 16 + l15] = acc2[it][ft][r];
+    s_lse = wave_sum(s_lse);
+    s_rphi = wave_sum(s_rphi);
+    if (l == 0) {
+        Pw[(int64_t)KP * F2P + 0] = s_lse;
+        Pw[(int64_t)KP * F2P + 1] = s_rphi;
+    }
+}
+
+// T (natural layout) <- sum over wave partials (fixed order), compact -> natural.
+__global__ void __launch_bounds__(NT)
+gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, int nb,
+                  int update_zs, double *__restrict__ st)
+{
+    const int KP = (int)L.KP, F2P = (int)L.F2P;
+    const int64_t plen = (int64_t)KP * F2P + 8;
+    const int e = blockIdx.x * NT + threadIdx.x;
+    const int total = KP * F2P + 2;
+    if (e >= total) return;
+    double s0 = 0.0, s1 = 0.0;
+    int b = 0;
+    for (; b + 1 < nb; b += 2) {
+        s0 += P[(int64_t)b * plen + e];
+        s1 += P[(int64_t)(b + 1) * plen + e];
+    }
+    if (b < nb) s0 += P[(int64_t)b * plen + e];
+    const double v = s0 + s1;
+    if (e >= KP * F2P) {
+        if (update_zs) st[L.off_zs + (e - KP * F2P)] = v;
+        return;
+    }
+    const int k = e / F2P, f = e - k * F2P;
+    if (k >= K) return;
+    double *T = st + L.off_T + (int64_t)k * L.FS;
+    const int npair = D * (D + 1) / 2;
+    if (f < npair) {
+        int rem = f, a = 0;
+        while (rem >= D - a) { rem -= D - a; ++a; }
+        const int bb = a + rem;
+        T[1 + D + a * D + bb] = v;
+        T[1 + D + bb * D + a] = v;
+    } else if (f < npair + D) {
+        T[1 + (f - npair)] = v;
+    } else if (f == npair + D) {
+        T[0] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-cluster small kernels: one wavefront per cluster, D*D <= 64 elements,
+// one matrix element per lane; SPD inverse by Gauss-Jordan sweeps.
+// ---------------------------------------------------------------------------
+// in: v = element (i,j) of an SPD matrix (lanes >= D*D idle); out: element of the inverse
+__device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool act, double *M,
+                                          double *logdet, int *bad)
+{
+    double ld = 0.0;
+    const int l = threadIdx.x & 63;
+    for (int p = 0; p < D; ++p) {
+        M[l] = v;
+        lds_fence();
+        const double piv = M[p * D + p];
+        const double ci = act ? M[i * D + p] : 0.0, rj = act ? M[p * D + j] : 0.0;
+        if (!(piv > 0.0)) *bad = 1;
+        ld += log(piv);
+        const double d = 1.0 / piv;
+        if (i == p) v = (j == p) ? d : rj * d;
+        else if (j == p) v = -ci * d;
+        else v = v - ci * rj * d;
+        lds_fence();
+    }
+    *logdet = ld;
+    return v;
+}
+
+__global__ void __launch_bounds__(NT)
+gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, double *st)
+{
+    // priors are already stored in st[off_prior..]; initialise every node from its prior
+    // (ExponentialFamily.initialize_from_prior, expfamily.py:168-184)
+    __shared__ double Ms[4][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + w;
+    const bool act = (k < K) && (l < D * D);
+    const int i = act ? l / D : 0, j = act ? l - i * D : 0;
+    const double *pr = st + L.off_prior;
+    const double *V0 = pr + L.KP + 8;
+    // alpha: Dirichlet prior moments
+    if (k < K && l == 0) {
+        double sa = 0.0;
+        for (int c = 0; c < K; ++c) sa += pr[c];
+        st[L.off_alpha + k] = pr[k];
+        st[L.off_alpha + L.KP + k] = vmp_digamma(pr[k]) - vmp_digamma(sa);
+        st[L.off_nk + k] = n0;
+        st[L.off_logdetLmu + k] = (double)D * log(beta0);
+    }
+    if (act) {
+        st[L.off_Cmu + (int64_t)k * D * D + l] = (i == j) ? 1.0 / beta0 : 0.0;
+        st[L.off_Vk + (int64_t)k * D * D + l] = V0[l];
+    }
+    if (act && j == 0) st[L.off_mu + (int64_t)k * D + i] = 0.0;
+    double ld;
+    int bad = 0;
+    const double vinv = wave_spd_inverse(act ? V0[l] : 0.0, D, i, j, act, Ms[w], &ld, &bad);
+    if (act) st[L.off_Lam + (int64_t)k * D * D + l] = n0 * vinv;
+    if (k < K && l == 0) {
+        double md = 0.0;
+        for (int c = 0; c < D; ++c) md += vmp_digamma(0.5 * n0 - 0.5 * c);
+        st[L.off_logdetV + k] = ld;
+        st[L.off_logdetLam + k] = md + (double)D * log(2.0) - ld;
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
+    if (k == 0 && l == 0) st[L.off_prior + L.KP + 2] = ld;   // log|V0|
+}
+
+// mu.update(): Lambda_mu = beta0 I + R_k <Lambda_k>, Cov, mean = Cov <Lambda_k> S1_k
+// (gaussian.py:649-706 with the messages gaussian.py:2451-2454 weighted by r, mixture.py:126-158)
+__global__ void __launch_bounds__(NT)
+gmm_update_mu_kernel(vmp_gmm_layout L, int D, int K, double *st)
+{
+    __shared__ double Ms[4][64];
+    __shared__ double Cs[4][64];
+    __shared__ double bs[4][8];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + w;
+    const bool act = (k < K) && (l < D * D);
+    const int i = act ? l / D : 0, j = act ? l - i * D : 0;
+    const double beta0 = st[L.off_prior + L.KP + 0];
+    const int kk = k < K ? k : 0;
+    const double *T = st + L.off_T + (int64_t)kk * L.FS;
+    const double *Lam = st + L.off_Lam + (int64_t)kk * D * D;
+    const double R = T[0];
+    double v = act ? R * Lam[l] + ((i == j) ? beta0 : 0.0) : 0.0;
+    double ld;
+    int bad = 0;
+    v = wave_spd_inverse(v, D, i, j, act, Ms[w], &ld, &bad);
+    Cs[w][l] = v;
+    if (l < D) {
+        double s = 0.0;
+        for (int c = 0; c < D; ++c) s += Lam[l * D + c] * T[1 + c];     // <Lambda> S1
+        bs[w][l] = s;
+    }
+    lds_fence();
+    if (act) st[L.off_Cmu + (int64_t)k * D * D + l] = v;
+    if (k < K && l < D) {
+        double s = 0.0;
+        for (int c = 0; c < D; ++c) s += Cs[w][l * D + c] * bs[w][c];
+        st[L.off_mu + (int64_t)k * D + l] = s;
+    }
+    if (k < K && l == 0) {
+        st[L.off_logdetLmu + k] = ld;
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
+}
+
+// Lambda.update(): n_k = n0 + R_k, V_k = V0 + S2 - S1 mu^T - mu S1^T + R <mu mu^T>
+// (wishart.py:153-188 with the message gaussian.py:2516-2520 weighted by r)
+__global__ void __launch_bounds__(NT)
+gmm_update_lambda_kernel(vmp_gmm_layout L, int D, int K, double *st)
+{
+    __shared__ double Ms[4][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + w;
+    const bool act = (k < K) && (l < D * D);
+    const int i = act ? l / D : 0, j = act ? l - i * D : 0;
+    const int kk = k < K ? k : 0;
+    const double n0 = st[L.off_prior + L.KP + 1];
+    const double *V0 = st + L.off_prior + L.KP + 8;
+    const double *T = st + L.off_T + (int64_t)kk * L.FS;
+    const double *mu = st + L.off_mu + (int64_t)kk * D;
+    const double *Cmu = st + L.off_Cmu + (int64_t)kk * D * D;
+    const double R = T[0];
+    const double nk = n0 + R;
+    double v = 0.0;
+    if (act) {
+        const double mm = Cmu[l] + mu[i] * mu[j];
+        v = V0[l] + T[1 + D + l] - T[1 + i] * mu[j] - mu[i] * T[1 + j] + R * mm;
+        st[L.off_Vk + (int64_t)k * D * D + l] = v;
+    }
+    // symmetrise before factorising
+    Ms[w][l] = v;
+    lds_fence();
+    if (act) v = 0.5 * (Ms[w][i * D + j] + Ms[w][j * D + i]);
+    lds_fence();
+    double ld;
+    int bad = 0;
+    v = wave_spd_inverse(v, D, i, j, act, Ms[w], &ld, &bad);
+    if (act) st[L.off_Lam + (int64_t)k * D * D + l] = nk * v;               // wishart.py:184
+    if (k < K && l == 0) {
+        double md = 0.0;
+        for (int c = 0; c < D; ++c) md += vmp_digamma(0.5 * nk - 0.5 * c);  // utils/misc.py:1146
+        st[L.off_nk + k] = nk;
+        st[L.off_logdetV + k] = ld;
+        st[L.off_logdetLam + k] = md + (double)D * log(2.0) - ld;           // wishart.py:185
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
+}
+
+// c_k of E[log N(y | mu_k, Lambda_k)] without the data terms
+__device__ inline double gmm_ck(const double *st, const vmp_gmm_layout &L, int D, int k)
+{
+    const double *Lam = st + L.off_Lam + (int64_t)k * D * D;
+    const double *mu = st + L.off_mu + (int64_t)k * D;
+    const double *Cmu = st + L.off_Cmu + (int64_t)k * D * D;
+    double tr = 0.0;
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) tr += Lam[i * D + j] * (Cmu[i * D + j] + mu[i] * mu[j]);
+    return 0.5 * st[L.off_logdetLam + k] - 0.5 * (double)D * log(2.0 * M_PI) - 0.5 * tr;
+}
+
+// z.update(), replicated half: the coefficient matrix C of the pass
+// (phi of the Categorical = <log pi> + E[log p(y | k)], mixture.py:67-104)
+__global__ void __launch_bounds__(NT)
+gmm_prepare_z_kernel(vmp_gmm_layout L, int D, int K, int prior_only, double *st)
+{
+    const int DP = (int)L.DP, FP = (int)L.FP, KP = (int)L.KP;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < KP * FP; e += gridDim.x * NT) {
+        const int k = e / FP, f = e - k * FP;
+        double v = 0.0;
+        if (k < K && prior_only) {
+            // q(z) from its prior: phi = <log pi> only (initialize_from_prior)
+            if (f == DP * DP + DP) v = st[L.off_alpha + KP + k];
+        } else if (k < K) {
+            const double *Lam = st + L.off_Lam + (int64_t)k * D * D;
+            if (f < DP * DP) {
+                const int a = f / DP, b = f - a * DP;
+                if (a < D && b < D) v = -0.5 * Lam[a * D + b];
+            } else if (f < DP * DP + DP) {
+                const int d = f - DP * DP;
+                if (d < D) {
+                    const double *mu = st + L.off_mu + (int64_t)k * D;
+                    double s = 0.0;
+                    for (int c = 0; c < D; ++c) s += Lam[d * D + c] * mu[c];
+                    v = s;
+                }
+            } else if (f == DP * DP + DP) {
+                v = st[L.off_alpha + KP + k] + gmm_ck(st, L, D, k);
+            }
+        } else if (f == DP * DP + DP) {
+            v = -INFINITY;                    // padded clusters get zero responsibility
+        }
+        st[L.off_C + e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+gmm_update_alpha_kernel(vmp_gmm_layout L, int D, int K, double *st)
+{
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int k = tid; k < K; k += NT) {
+        const double a = st[L.off_prior + k] + st[L.off_T + (int64_t)k * L.FS];   // alpha0 + R_k
+        st[L.off_alpha + k] = a;
+        s += a;
+    }
+    s = block_sum<NT>(s, red);
+    const double ps = vmp_digamma(s);
+    for (int k = tid; k < K; k += NT)
+        st[L.off_alpha + L.KP + k] = vmp_digamma(st[L.off_alpha + k]) - ps;      // dirichlet.py:150-152
+}
+
+__device__ inline double multigammaln_dev(double a, int d)
+{
+    double s = (double)d * (d - 1) / 4.0 * log(M_PI);
+    for (int i = 0; i < d; ++i) s += vmp_lgamma(a - 0.5 * i);
+    return s;
+}
+
+// expfamily.py:400-480 for Y, z, alpha, mu, Lambda
+__global__ void __launch_bounds__(NT)
+gmm_lower_bound_kernel(vmp_gmm_layout L, int D, int K, double *st)
+{
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x;
+    const int KP = (int)L.KP;
+    const double beta0 = st[L.off_prior + KP + 0], n0 = st[L.off_prior + KP + 1];
+    const double ldV0 = st[L.off_prior + KP + 2];
+    const double *V0 = st + L.off_prior + KP + 8;
+    double LY = 0.0, Lz = 0.0, La = 0.0, Lmu = 0.0, LL = 0.0, sa0 = 0.0, sa = 0.0;
+    for (int k = tid; k < K; k += NT) {
+        const double *T = st + L.off_T + (int64_t)k * L.FS;
+        const double *Lam = st + L.off_Lam + (int64_t)k * D * D;
+        const double *mu = st + L.off_mu + (int64_t)k * D;
+        const double *Cmu = st + L.off_Cmu + (int64_t)k * D * D;
+        const double *Vk = st + L.off_Vk + (int64_t)k * D * D;
+        const double R = T[0];
+        double bs = 0.0, ls2 = 0.0, trmm = 0.0, trV0 = 0.0, trVk = 0.0;
+        for (int i = 0; i < D; ++i) {
+            double bi = 0.0;
+            for (int j = 0; j < D; ++j) {
+                bi += Lam[i * D + j] * mu[j];
+                ls2 += Lam[i * D + j] * T[1 + D + i * D + j];
+                trV0 += V0[i * D + j] * Lam[i * D + j];
+                trVk += 0.5 * (Vk[i * D + j] + Vk[j * D + i]) * Lam[i * D + j];
+            }
+            bs += bi * T[1 + i];
+            trmm += Cmu[i * D + i] + mu[i] * mu[i];
+        }
+        LY += R * gmm_ck(st, L, D, k) + bs - 0.5 * ls2;
+        const double a0 = st[L.off_prior + k], a = st[L.off_alpha + k];
+        const double lp = st[L.off_alpha + KP + k];
+        Lz += R * lp;
+        La += -vmp_lgamma(a0) + vmp_lgamma(a) + (a0 - a) * lp;
+        sa0 += a0;
+        sa += a;
+        Lmu += -0.5 * beta0 * trmm + 0.5 * (double)D * log(beta0) - 0.5 * st[L.off_logdetLmu + k]
+               + 0.5 * (double)D;
+        const double nk = st[L.off_nk + k], ldL = st[L.off_logdetLam + k];
+        const double gp = 0.5 * n0 * ldV0 - 0.5 * D * n0 * log(2.0) - multigammaln_dev(0.5 * n0, D);
+        const double gq = 0.5 * nk * st[L.off_logdetV + k] - 0.5 * D * nk * log(2.0)
+                          - multigammaln_dev(0.5 * nk, D);
+        LL += gp - gq - 0.5 * trV0 + 0.5 * n0 * ldL + 0.5 * trVk - 0.5 * nk * ldL;
+    }
+    LY = block_sum<NT>(LY, red);
+    Lz = block_sum<NT>(Lz, red);
+    La = block_sum<NT>(La, red);
+    Lmu = block_sum<NT>(Lmu, red);
+    LL = block_sum<NT>(LL, red);
+    sa0 = block_sum<NT>(sa0, red);
+    sa = block_sum<NT>(sa, red);
+    if (tid == 0) {
+        Lz += st[L.off_zs + 0] - st[L.off_zs + 1];
+        La += vmp_lgamma(sa0) - vmp_lgamma(sa);
+        st[L.off_L + 0] = LY;
+        st[L.off_L + 1] = Lz;
+        st[L.off_L + 2] = La;
+        st[L.off_L + 3] = Lmu;
+        st[L.off_L + 4] = LL;
+        st[L.off_L + 5] = LY + Lz + La + Lmu + LL;
+    }
+}
+
+int gmm_wgs_per_cu()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("VMP_GMM_WGS_PER_CU");
+        v = e ? atoi(e) : 2;
+        if (v < 1) v = 1;
+        if (v > 4) v = 4;
+    }
+    return v;
+}
+
+int64_t gmm_max_grid(vmp_ctx *ctx) { return (int64_t)ctx->num_cu * gmm_wgs_per_cu(); }
+
+template <int DPT, int KT, int FT2>
+int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, dim3 grid, const double *Y, int64_t N,
+                        int D, int K, const double *C, const int64_t *labels, double *R,
+                        double *P, int64_t ntiles)
+{
+    constexpr int DP = 4 * DPT, KP = 16 * KT;
+    constexpr int KS1 = DP * DPT + DPT + 1;
+    const size_t per_wave = (size_t)(TNC * (DP + 3) + TNC * (KP + 1));
+    const size_t lds = ((from_labels ? 0 : (size_t)KT * KS1 * 64) + 4 * per_wave) * sizeof(double);
+    hipStream_t s = ctx->stream;
+    if (from_labels) {
+        auto kern = gmm_pass_kernel<DPT, KT, FT2, true>;
+        static bool attr = false;
+        if (!attr) {
+            VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
+    } else {
+        auto kern = gmm_pass_kernel<DPT, KT, FT2, false>;
+        static bool attr = false;
+        if (!attr) {
+            VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
+    }
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N, int D, int K,
+                     const int64_t *labels, double *R, double *state, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Y && R && state && workspace, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, !from_labels || labels, VMP_ERR_INVALID, "null labels");
+    VMP_REQUIRE(ctx, D >= 1 && K >= 1 && N >= 0, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, D <= MAXD && K <= MAXK, VMP_ERR_UNSUPPORTED,
+                "fused GMM block supports D <= %d, K <= %d (got D=%d, K=%d)", MAXD, MAXK, D, K);
+    vmp_gmm_layout L;
+    fill_layout(D, K, &L);
+    const int DPT = (int)(L.DP / 4), KT = (int)(L.KP / 16), FT2 = (int)(L.F2P / 16);
+    const int64_t ntiles = (N + TNC - 1) / TNC;
+    int64_t g = (ntiles + 3) / 4;
+    if (g > gmm_max_grid(ctx)) g = gmm_max_grid(ctx);
+    if (g < 1) g = 1;
+    double *P = reinterpret_cast<double *>(workspace);
+    const double *C = state + L.off_C;
+    dim3 grid((unsigned)g);
+    int32_t rc = VMP_ERR_UNSUPPORTED;
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+#define VMP_GCASE(dpt, kt, ft2)                                                                 \
+    if (DPT == dpt && KT == kt && FT2 == ft2)                                                   \
+        rc = launch_gmm_pass<dpt, kt, ft2>(ctx, from_labels, grid, Y, N, D, K, C, labels, R, P, \
+                                           ntiles);
+    VMP_GCASE(1, 1, 1) VMP_GCASE(1, 2, 1) VMP_GCASE(1, 4, 1)
+    VMP_GCASE(2, 1, 1) VMP_GCASE(2, 2, 1) VMP_GCASE(2, 4, 1)
+    VMP_GCASE(2, 1, 2) VMP_GCASE(2, 2, 2) VMP_GCASE(2, 4, 2)
+    VMP_GCASE(2, 1, 3) VMP_GCASE(2, 2, 3) VMP_GCASE(2, 4, 3)
+#undef VMP_GCASE
+    if (rc != VMP_OK) {
+        if (rc == VMP_ERR_UNSUPPORTED)
+            VMP_SET_ERR(ctx, "no GMM kernel instance for DPT=%d KT=%d FT2=%d", DPT, KT, FT2);
+        return rc;
+    }
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    const int total = (int)(L.KP * L.F2P + 2);
+    hipLaunchKernelGGL(gmm_reduce_kernel, dim3((total + NT - 1) / NT), dim3(NT), 0, ctx->stream,
+                       L, D, K, P, (int)(g * 4), from_labels ? 0 : 1, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    return VMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_gmm_get_layout(int32_t D, int32_t K, vmp_gmm_layout *out)
+{
+    if (!out || D < 1 || K < 1) return VMP_ERR_INVALID;
+    if (D > MAXD || K > MAXK) return VMP_ERR_UNSUPPORTED;
+    fill_layout(D, K, out);
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *bytes)
+{
+    VMP_REQUIRE(ctx, ctx && bytes, VMP_ERR_INVALID, "null argument");
+    vmp_gmm_layout L;
+    int32_t rc = vmp_gmm_get_layout(D, K, &L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "fused GMM block supports D <= %d, K <= %d", MAXD, MAXK);
+    *bytes = (size_t)(gmm_max_grid(ctx) * 4 * (L.KP * L.F2P + 8) + 64) * sizeof(double);
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_init_state(vmp_ctx *ctx, int32_t D, int32_t K, const double *alpha0_host,
+                           double beta0, double n0, const double *V0_host, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && alpha0_host && V0_host && state, VMP_ERR_INVALID, "null argument");
+    vmp_gmm_layout L;
+    int32_t rc = vmp_gmm_get_layout(D, K, &L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "fused GMM block supports D <= %d, K <= %d", MAXD, MAXK);
+    VMP_REQUIRE(ctx, beta0 > 0 && n0 > D - 1, VMP_ERR_INVALID, "bad prior parameters");
+    for (int k = 0; k < K; ++k)
+        VMP_REQUIRE(ctx, alpha0_host[k] > 0, VMP_ERR_NOT_POSITIVE,
+                    "Natural parameters should be positive");
+    hipStream_t s = ctx->stream;
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, (size_t)L.total * sizeof(double), s));
+    double hdr[8] = {beta0, n0, 0, 0, 0, 0, 0, 0};
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(state + L.off_prior, alpha0_host, K * sizeof(double),
+                                      hipMemcpyHostToDevice, s));
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(state + L.off_prior + L.KP, hdr, sizeof(hdr),
+                                      hipMemcpyHostToDevice, s));
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(state + L.off_prior + L.KP + 8, V0_host,
+                                      (size_t)D * D * sizeof(double), hipMemcpyHostToDevice, s));
+    VMP_HIP_CHECK(ctx, hipStreamSynchronize(s));   // host buffers may be temporaries
+    hipLaunchKernelGGL(gmm_init_state_kernel, dim3((K + 3) / 4), dim3(NT), 0, s, L, D, K, beta0,
+                       n0, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_stats_from_labels(vmp_ctx *ctx, const double *Y, int64_t N, int32_t D, int32_t K,
+                                  const int64_t *labels, double *R, double *state,
+                                  void *workspace)
+{
+    return run_gmm_pass(ctx, true, Y, N, D, K, labels, R, state, workspace);
+}
+
+int32_t vmp_gmm_pass(vmp_ctx *ctx, const double *Y, int64_t N, int32_t D, int32_t K, double *R,
+                     double *state, void *workspace)
+{
+    return run_gmm_pass(ctx, false, Y, N, D, K, nullptr, R, state, workspace);
+}
+
+#define VMP_GMM_PROLOGUE()                                                           \
+    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");                \
+    vmp_gmm_layout L;                                                                \
+    {                                                                                \
+        int32_t rc__ = vmp_gmm_get_layout(D, K, &L);                                 \
+        VMP_REQUIRE(ctx, rc__ == VMP_OK, rc__, "unsupported dims D=%d K=%d", D, K);  \
+    }
+
+int32_t vmp_gmm_update_mu(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
+{
+    VMP_GMM_PROLOGUE();
+    hipLaunchKernelGGL(gmm_update_mu_kernel, dim3((K + 3) / 4), dim3(NT), 0, ctx->stream, L, D, K,
+                       state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_update_lambda(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
+{
+    VMP_GMM_PROLOGUE();
+    hipLaunchKernelGGL(gmm_update_lambda_kernel, dim3((K + 3) / 4), dim3(NT), 0, ctx->stream, L, D,
+                       K, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_prepare_z(vmp_ctx *ctx, int32_t D, int32_t K, int32_t prior_only, double *state)
+{
+    VMP_GMM_PROLOGUE();
+    const int n = (int)(L.KP * L.FP);
+    hipLaunchKernelGGL(gmm_prepare_z_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, L,
+                       D, K, (int)prior_only, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_update_alpha(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
+{
+    VMP_GMM_PROLOGUE();
+    hipLaunchKernelGGL(gmm_update_alpha_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_gmm_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
+{
+    VMP_GMM_PROLOGUE();
+    hipLaunchKernelGGL(gmm_lower_bound_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+}  // extern "C"

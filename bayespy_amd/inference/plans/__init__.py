@@ -4,8 +4,9 @@ block and maps the reference's per-node operations (``update``,
 ``lower_bound_contribution``, ``get_moments``) onto HIP kernel launches.
 """
 from .pca import PCAPlan
+from .gmm import GMMPlan
 
-PLAN_TYPES = [PCAPlan]
+PLAN_TYPES = [PCAPlan, GMMPlan]
 
 
 def compile_model(nodes, engine=None, **options):

@@ -160,6 +160,68 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
                             double a0_alpha, double b0_alpha, double *state);
 
 
+/* ---- fused full-covariance Gaussian-mixture block -------------------------- *
+ *
+ * Model block  Y = Mixture(z, Gaussian, mu, Lambda), z = Categorical(alpha),
+ * alpha = Dirichlet(a0), mu = GaussianARD(0, beta0, shape=(D,), plates=(K,)),
+ * Lambda = Wishart(n0, V0, plates=(K,))   (bayespy/demos/mog.py:17-64), Y fully
+ * observed, D <= 8, K <= 64.  One VB iteration reads Y exactly once and writes the
+ * responsibilities once.  Y is (N, D) row-major (the reference's layout), the
+ * responsibilities R are (N, K) row-major.
+ */
+typedef struct vmp_gmm_layout {
+    int64_t DP, KP;        /* padded D (4 or 8) and K (16, 32, 64)                          */
+    int64_t FS;            /* 1 + D + D*D : row length of the statistics                      */
+    int64_t FP, F2P;       /* feature counts of the two MFMA phases (padded)                  */
+    int64_t off_T, len_T;  /* KP x FS : per cluster [R_k, sum_n r y (D), sum_n r y y^T (D*D)] */
+                           /*   -- the plate sums of mixture.py:126-158 + node.py:650          */
+    int64_t off_zs;        /* sum_n logsumexp(phi_n), sum_nk r phi   (for L_z)                */
+    int64_t off_alpha;     /* alpha[KP], <log pi>[KP]                  (dirichlet.py:150-158) */
+    int64_t off_mu;        /* KP x D   <mu_k>                                                 */
+    int64_t off_Cmu;       /* KP x D x D  Cov(mu_k)                                           */
+    int64_t off_logdetLmu; /* KP  log|Lambda_mu_k|                                            */
+    int64_t off_nk;        /* KP  Wishart degrees of freedom                                  */
+    int64_t off_Vk;        /* KP x D x D  Wishart inverse scale                               */
+    int64_t off_Lam;       /* KP x D x D  <Lambda_k> = n_k V_k^-1        (wishart.py:184)     */
+    int64_t off_logdetLam; /* KP  <log|Lambda_k|>                          (wishart.py:185)   */
+    int64_t off_logdetV;   /* KP  log|V_k|                                                    */
+    int64_t off_C;         /* KP x FP coefficient matrix of the pass                          */
+    int64_t off_prior;     /* alpha0[KP], beta0, n0, log|V0|, 5 pad, V0[D*D]                  */
+    int64_t off_scal;      /* 8 : [3] status                                                  */
+    int64_t off_L;         /* 8 : L_Y, L_z, L_alpha, L_mu, L_Lambda, L_total                  */
+    int64_t total;
+} vmp_gmm_layout;
+
+int32_t vmp_gmm_get_layout(int32_t D, int32_t K, vmp_gmm_layout *out);
+int32_t vmp_gmm_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *bytes);
+/* Store the priors (host arrays alpha0[K], V0[D*D]) and initialise every node from its
+ * prior (expfamily.py:168-184). */
+int32_t vmp_gmm_init_state(vmp_ctx *ctx, int32_t D, int32_t K, const double *alpha0_host,
+                           double beta0, double n0, const double *V0_host, double *state);
+/* z.initialize_from_value(labels): one-hot responsibilities (categorical.py:30-46,
+ * bit-exact) written to R and their statistics to T. */
+int32_t vmp_gmm_stats_from_labels(vmp_ctx *ctx, const double *Y, int64_t N, int32_t D, int32_t K,
+                                  const int64_t *labels, double *R, double *state,
+                                  void *workspace);
+/* mu.update(): gaussian.py:649-706 with the mixture-weighted messages of
+ * gaussian.py:2451-2454 / mixture.py:126-158. */
+int32_t vmp_gmm_update_mu(vmp_ctx *ctx, int32_t D, int32_t K, double *state);
+/* Lambda.update(): wishart.py:153-188 with the messages gaussian.py:2516-2520. */
+int32_t vmp_gmm_update_lambda(vmp_ctx *ctx, int32_t D, int32_t K, double *state);
+/* z.update(), replicated half: coefficients of E[log p(y_n | k)] + <log pi_k>
+ * (mixture.py:67-104, expfamily.py:45-61).  prior_only != 0 keeps only <log pi_k>
+ * (q(z) initialised from its prior). */
+int32_t vmp_gmm_prepare_z(vmp_ctx *ctx, int32_t D, int32_t K, int32_t prior_only, double *state);
+/* z.update(), plate half -- THE pass: phi = C feat(y), r = normalized_exp(phi)
+ * (multinomial.py:114-120, utils/misc.py:1388-1401) written to R, and the statistics
+ * T = r^T [1, y, y y^T] (local partial; the caller all-reduces T and zs). fp64 MFMA. */
+int32_t vmp_gmm_pass(vmp_ctx *ctx, const double *Y, int64_t N, int32_t D, int32_t K, double *R,
+                     double *state, void *workspace);
+/* alpha.update(): dirichlet.py:113-160 with the message categorical -> [r]. */
+int32_t vmp_gmm_update_alpha(vmp_ctx *ctx, int32_t D, int32_t K, double *state);
+/* Lower bound of Y, z, alpha, mu, Lambda (expfamily.py:400-480). */
+int32_t vmp_gmm_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, double *state);
+
 /* ---- generic plate-broadcast kernels -------------------------------------- *
  *
  * Arrays are fp64 with explicit ELEMENT strides per axis; stride 0 marks a

@@ -133,9 +133,11 @@ def test_dirichlet_categorical_matches_reference(golden_dir):
         z.u
 
 
+@pytest.mark.parametrize('engine', ['generic', 'fused'])
 @pytest.mark.parametrize('name', ['gmm_n400_d3_k4', 'gmm_n3000_d8_k16'])
-def test_gaussian_mixture_matches_reference(golden_dir, name):
-    """demos/mog.py:17-64 (Mixture + Categorical + Gaussian + Wishart + Dirichlet)."""
+def test_gaussian_mixture_matches_reference(golden_dir, name, engine):
+    """demos/mog.py:17-64 (Mixture + Categorical + Gaussian + Wishart + Dirichlet), through
+    the generic message-passing engine and through the fused GMM block."""
     from bayespy_amd.nodes import (GaussianARD, Gaussian, Wishart, Dirichlet, Categorical,
                                    Mixture)
     from bayespy_amd.inference import VB
@@ -150,7 +152,8 @@ def test_gaussian_mixture_matches_reference(golden_dir, name):
     Y = Mixture(z, Gaussian, mu, Lam, plates=(N,), name='Y')
     z.initialize_from_value(lab0)
     Y.observe(y)
-    Q = VB(Y, mu, Lam, z, alpha)
+    Q = VB(Y, mu, Lam, z, alpha, engine=None if engine == 'fused' else 'generic')
+    assert type(Q.plans[0]).__name__ == ('GMMPlan' if engine == 'fused' else 'GenericPlan')
     n = int(g['n_iter'])
     L = _trace(Q, n)
     np.testing.assert_allclose(L, g['L'], rtol=ELBO_RTOL)
