@@ -197,12 +197,15 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             const double lse = log(s) + mx;
+            // exp(phi - lse) = exp(phi - mx) / s; then the reference's second
+            // renormalisation p / sum(p) (utils/misc.py:1399)
+            const double is = 1.0 / s;
             double s2 = 0.0;
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    e[it][r] = exp(acc1[it][r] - lse);
+                    e[it][r] *= is;
                     s2 += e[it][r];
                 }
             s2 += __shfl_xor(s2, 16, 64);
@@ -255,22 +258,32 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
         lds_fence();
     }
 
-    // ---- per-wave partials: [KP][F2P] + 2 scalars -------------------------------------------
-    const int64_t plen = (int64_t)KP * F2P + 8;
-    double *Pw = P + ((int64_t)blockIdx.x * 4 + w) * plen;
-#pragma unroll
-    for (int it = 0; it < KT; ++it)
-#pragma unroll
-        for (int ft = 0; ft < FT2; ++ft)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Pw[(it * 16 + g + 4 * r) * F2P + ft * 16 + l15] = acc2[it][ft][r];
+    // ---- per-WORKGROUP partials: [KP][F2P] + 2 scalars (waves combined in fixed order) ----
+    __syncthreads();                       // every wave is done with the LDS tiles / fragments
+    double *scr = lds;                     // KP*F2P + 2 doubles
     s_lse = wave_sum(s_lse);
     s_rphi = wave_sum(s_rphi);
-    if (l == 0) {
-        Pw[(int64_t)KP * F2P + 0] = s_lse;
-        Pw[(int64_t)KP * F2P + 1] = s_rphi;
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int ft = 0; ft < FT2; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = (it * 16 + g + 4 * r) * F2P + ft * 16 + l15;
+                        scr[idx] = (ww == 0 ? 0.0 : scr[idx]) + acc2[it][ft][r];
+                    }
+            if (l == 0) {
+                scr[KP * F2P + 0] = (ww == 0 ? 0.0 : scr[KP * F2P + 0]) + s_lse;
+                scr[KP * F2P + 1] = (ww == 0 ? 0.0 : scr[KP * F2P + 1]) + s_rphi;
+            }
+        }
+        __syncthreads();
     }
+    const int64_t plen = (int64_t)KP * F2P + 8;
+    double *Pb = P + (int64_t)blockIdx.x * plen;
+    for (int e2 = tid; e2 < KP * F2P + 2; e2 += NT) Pb[e2] = scr[e2];
 }
 
 // T (natural layout) <- sum over wave partials (fixed order), compact -> natural.
@@ -278,19 +291,28 @@ __global__ void __launch_bounds__(NT)
 gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, int nb,
                   int update_zs, double *__restrict__ st)
 {
+    __shared__ double part[4][64];
     const int KP = (int)L.KP, F2P = (int)L.F2P;
     const int64_t plen = (int64_t)KP * F2P + 8;
-    const int e = blockIdx.x * NT + threadIdx.x;
     const int total = KP * F2P + 2;
-    if (e >= total) return;
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + o;
+    // slice sl sums partials [b0, b1) in order; slices combined in order 0..3
+    const int per = (nb + 3) / 4;
+    const int b0 = sl * per, b1 = (b0 + per < nb) ? b0 + per : nb;
     double s0 = 0.0, s1 = 0.0;
-    int b = 0;
-    for (; b + 1 < nb; b += 2) {
-        s0 += P[(int64_t)b * plen + e];
-        s1 += P[(int64_t)(b + 1) * plen + e];
+    if (e < total) {
+        int b = b0;
+        for (; b + 1 < b1; b += 2) {
+            s0 += P[(int64_t)b * plen + e];
+            s1 += P[(int64_t)(b + 1) * plen + e];
+        }
+        if (b < b1) s0 += P[(int64_t)b * plen + e];
     }
-    if (b < nb) s0 += P[(int64_t)b * plen + e];
-    const double v = s0 + s1;
+    part[sl][o] = s0 + s1;
+    __syncthreads();
+    if (sl != 0 || e >= total) return;
+    const double v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
     if (e >= KP * F2P) {
         if (update_zs) st[L.off_zs + (e - KP * F2P)] = v;
         return;
@@ -526,68 +548,95 @@ gmm_update_alpha_kernel(vmp_gmm_layout L, int D, int K, double *st)
         st[L.off_alpha + L.KP + k] = vmp_digamma(st[L.off_alpha + k]) - ps;      // dirichlet.py:150-152
 }
 
-__device__ inline double multigammaln_dev(double a, int d)
+// out-of-line copies keep the register footprint of the bookkeeping kernels small
+__device__ __noinline__ double lgamma_ni(double x) { return vmp_lgamma(x); }
+
+__device__ __noinline__ double multigammaln_dev(double a, int d)
 {
     double s = (double)d * (d - 1) / 4.0 * log(M_PI);
-    for (int i = 0; i < d; ++i) s += vmp_lgamma(a - 0.5 * i);
+    for (int i = 0; i < d; ++i) s += lgamma_ni(a - 0.5 * i);
     return s;
 }
 
-// expfamily.py:400-480 for Y, z, alpha, mu, Lambda
-__global__ void __launch_bounds__(NT)
+// expfamily.py:400-480 for Y, z, alpha, mu, Lambda.  One workgroup of 16
+// wavefronts; a wavefront owns clusters k = w, w+16, ... with one (i,j) matrix element per lane.
+constexpr int NTLB = 512;
+__global__ void __launch_bounds__(NTLB)
 gmm_lower_bound_kernel(vmp_gmm_layout L, int D, int K, double *st)
 {
-    __shared__ double red[NT / 64];
-    const int tid = threadIdx.x;
+    __shared__ double red[NTLB / 64];
+    __shared__ double lgs[MAXK][2 + 2 * MAXD];     // all log-Gamma values, ONE call site
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int KP = (int)L.KP;
     const double beta0 = st[L.off_prior + KP + 0], n0 = st[L.off_prior + KP + 1];
     const double ldV0 = st[L.off_prior + KP + 2];
     const double *V0 = st + L.off_prior + KP + 8;
+    const int per = 2 + 2 * D;
+    for (int e = tid; e < K * per; e += NTLB) {
+        const int k = e / per, c = e - k * per;
+        double x;
+        if (c == 0) x = st[L.off_prior + k];                          // alpha0_k
+        else if (c == 1) x = st[L.off_alpha + k];                     // alpha_k
+        else if (c < 2 + D) x = 0.5 * n0 - 0.5 * (c - 2);             // Gamma_D(n0/2) terms
+        else x = 0.5 * st[L.off_nk + k] - 0.5 * (c - 2 - D);          // Gamma_D(n_k/2) terms
+        lgs[k][c] = vmp_lgamma(x);
+    }
+    __syncthreads();
+    const bool act = l < D * D;
+    const int i = act ? l / D : 0, j = act ? l - i * D : 0;
+    const double mgc = (double)D * (D - 1) / 4.0 * log(M_PI);
     double LY = 0.0, Lz = 0.0, La = 0.0, Lmu = 0.0, LL = 0.0, sa0 = 0.0, sa = 0.0;
-    for (int k = tid; k < K; k += NT) {
+    for (int k = w; k < K; k += NTLB / 64) {
         const double *T = st + L.off_T + (int64_t)k * L.FS;
         const double *Lam = st + L.off_Lam + (int64_t)k * D * D;
         const double *mu = st + L.off_mu + (int64_t)k * D;
         const double *Cmu = st + L.off_Cmu + (int64_t)k * D * D;
         const double *Vk = st + L.off_Vk + (int64_t)k * D * D;
-        const double R = T[0];
-        double bs = 0.0, ls2 = 0.0, trmm = 0.0, trV0 = 0.0, trVk = 0.0;
-        for (int i = 0; i < D; ++i) {
-            double bi = 0.0;
-            for (int j = 0; j < D; ++j) {
-                bi += Lam[i * D + j] * mu[j];
-                ls2 += Lam[i * D + j] * T[1 + D + i * D + j];
-                trV0 += V0[i * D + j] * Lam[i * D + j];
-                trVk += 0.5 * (Vk[i * D + j] + Vk[j * D + i]) * Lam[i * D + j];
-            }
-            bs += bi * T[1 + i];
-            trmm += Cmu[i * D + i] + mu[i] * mu[i];
+        double bs = 0.0, ls2 = 0.0, trLmm = 0.0, trmm = 0.0, trV0 = 0.0, trVk = 0.0;
+        if (act) {
+            const double lam = Lam[l];
+            bs = lam * mu[j] * T[1 + i];                       // (Lambda mu) . S1
+            ls2 = lam * T[1 + D + l];                          // tr(Lambda S2)
+            trLmm = lam * (Cmu[l] + mu[i] * mu[j]);            // tr(Lambda <mu mu^T>)
+            trV0 = V0[l] * lam;
+            trVk = 0.5 * (Vk[l] + Vk[j * D + i]) * lam;
+            if (i == j) trmm = Cmu[l] + mu[i] * mu[i];
         }
-        LY += R * gmm_ck(st, L, D, k) + bs - 0.5 * ls2;
-        const double a0 = st[L.off_prior + k], a = st[L.off_alpha + k];
-        const double lp = st[L.off_alpha + KP + k];
-        Lz += R * lp;
-        La += -vmp_lgamma(a0) + vmp_lgamma(a) + (a0 - a) * lp;
-        sa0 += a0;
-        sa += a;
-        Lmu += -0.5 * beta0 * trmm + 0.5 * (double)D * log(beta0) - 0.5 * st[L.off_logdetLmu + k]
-               + 0.5 * (double)D;
-        const double nk = st[L.off_nk + k], ldL = st[L.off_logdetLam + k];
-        const double gp = 0.5 * n0 * ldV0 - 0.5 * D * n0 * log(2.0) - multigammaln_dev(0.5 * n0, D);
-        const double gq = 0.5 * nk * st[L.off_logdetV + k] - 0.5 * D * nk * log(2.0)
-                          - multigammaln_dev(0.5 * nk, D);
-        LL += gp - gq - 0.5 * trV0 + 0.5 * n0 * ldL + 0.5 * trVk - 0.5 * nk * ldL;
+        bs = wave_sum(bs); ls2 = wave_sum(ls2); trLmm = wave_sum(trLmm);
+        trmm = wave_sum(trmm); trV0 = wave_sum(trV0); trVk = wave_sum(trVk);
+        if (l == 0) {
+            const double R = T[0];
+            const double ldL = st[L.off_logdetLam + k];
+            const double ck = 0.5 * ldL - 0.5 * (double)D * log(2.0 * M_PI) - 0.5 * trLmm;
+            LY += R * ck + bs - 0.5 * ls2;
+            const double a0 = st[L.off_prior + k], a = st[L.off_alpha + k];
+            const double lp = st[L.off_alpha + KP + k];
+            Lz += R * lp;
+            La += -lgs[k][0] + lgs[k][1] + (a0 - a) * lp;
+            sa0 += a0;
+            sa += a;
+            Lmu += -0.5 * beta0 * trmm + 0.5 * (double)D * log(beta0)
+                   - 0.5 * st[L.off_logdetLmu + k] + 0.5 * (double)D;
+            const double nk = st[L.off_nk + k];
+            double mg0 = mgc, mgk = mgc;
+            for (int c = 0; c < D; ++c) { mg0 += lgs[k][2 + c]; mgk += lgs[k][2 + D + c]; }
+            const double gp = 0.5 * n0 * ldV0 - 0.5 * D * n0 * log(2.0) - mg0;
+            const double gq = 0.5 * nk * st[L.off_logdetV + k] - 0.5 * D * nk * log(2.0) - mgk;
+            LL += gp - gq - 0.5 * trV0 + 0.5 * n0 * ldL + 0.5 * trVk - 0.5 * nk * ldL;
+        }
     }
-    LY = block_sum<NT>(LY, red);
-    Lz = block_sum<NT>(Lz, red);
-    La = block_sum<NT>(La, red);
-    Lmu = block_sum<NT>(Lmu, red);
-    LL = block_sum<NT>(LL, red);
-    sa0 = block_sum<NT>(sa0, red);
-    sa = block_sum<NT>(sa, red);
+    LY = block_sum<NTLB>(LY, red);
+    Lz = block_sum<NTLB>(Lz, red);
+    La = block_sum<NTLB>(La, red);
+    Lmu = block_sum<NTLB>(Lmu, red);
+    LL = block_sum<NTLB>(LL, red);
+    sa0 = block_sum<NTLB>(sa0, red);
+    sa = block_sum<NTLB>(sa, red);
+    if (tid < 2) lgs[0][tid] = vmp_lgamma(tid == 0 ? sa0 : sa);
+    __syncthreads();
     if (tid == 0) {
         Lz += st[L.off_zs + 0] - st[L.off_zs + 1];
-        La += vmp_lgamma(sa0) - vmp_lgamma(sa);
+        La += lgs[0][0] - lgs[0][1];
         st[L.off_L + 0] = LY;
         st[L.off_L + 1] = Lz;
         st[L.off_L + 2] = La;
@@ -682,8 +731,8 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
     }
     if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const int total = (int)(L.KP * L.F2P + 2);
-    hipLaunchKernelGGL(gmm_reduce_kernel, dim3((total + NT - 1) / NT), dim3(NT), 0, ctx->stream,
-                       L, D, K, P, (int)(g * 4), from_labels ? 0 : 1, state);
+    hipLaunchKernelGGL(gmm_reduce_kernel, dim3((total + 63) / 64), dim3(NT), 0, ctx->stream,
+                       L, D, K, P, (int)g, from_labels ? 0 : 1, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     return VMP_OK;
@@ -707,7 +756,7 @@ int32_t vmp_gmm_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *byte
     vmp_gmm_layout L;
     int32_t rc = vmp_gmm_get_layout(D, K, &L);
     VMP_REQUIRE(ctx, rc == VMP_OK, rc, "fused GMM block supports D <= %d, K <= %d", MAXD, MAXK);
-    *bytes = (size_t)(gmm_max_grid(ctx) * 4 * (L.KP * L.F2P + 8) + 64) * sizeof(double);
+    *bytes = (size_t)(gmm_max_grid(ctx) * (L.KP * L.F2P + 8) + 64) * sizeof(double);
     return VMP_OK;
 }
 
@@ -798,7 +847,8 @@ int32_t vmp_gmm_update_alpha(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
 int32_t vmp_gmm_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
 {
     VMP_GMM_PROLOGUE();
-    hipLaunchKernelGGL(gmm_lower_bound_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, state);
+    hipLaunchKernelGGL(gmm_lower_bound_kernel, dim3(1), dim3(NTLB), 0, ctx->stream, L, D, K,
+                       state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

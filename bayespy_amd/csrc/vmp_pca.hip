@@ -303,7 +303,7 @@ sum_partials_kernel(const double *__restrict__ partial, int n, double *__restric
 //
 // GUARD = false: only full 32-column tiles, D == DP and K == KP -- no predication
 // anywhere in the loop; GUARD = true handles ragged D, K and the last partial tile.
-template <int DB, int KT, bool GUARD, int OCC>
+template <int DB, int KT, bool GUARD, int OCC, int NTM = 0>
 __global__ void __launch_bounds__(NT, OCC)
 pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
                  const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
@@ -342,9 +342,11 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
                            + ((tile * TN + (int64_t)(4 * c * CH) * ldy) << 3);
         if (!GUARD) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-                dst[i] = *reinterpret_cast<const v2f64 *>(base + ((int64_t)(4 * i) * ldy << 3)
-                                                          + yoff);
+            for (int i = 0; i < CH; ++i) {
+                const v2f64 *src = reinterpret_cast<const v2f64 *>(
+                    base + ((int64_t)(4 * i) * ldy << 3) + yoff);
+                dst[i] = (NTM & 1) ? __builtin_nontemporal_load(src) : *src;
+            }
         } else {
             const int64_t n = tile * TN + 2 * l15;
 #pragma unroll
@@ -399,9 +401,13 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    *reinterpret_cast<v2f64 *>(xbase + ((int64_t)(it * 16 + 4 * r) * ldx << 3)
-                                               + xoff) = v2f64{acc[it][0][r], acc[it][1][r]};
+                for (int r = 0; r < 4; ++r) {
+                    v2f64 *dstp = reinterpret_cast<v2f64 *>(
+                        xbase + ((int64_t)(it * 16 + 4 * r) * ldx << 3) + xoff);
+                    const v2f64 val = v2f64{acc[it][0][r], acc[it][1][r]};
+                    if (NTM & 2) __builtin_nontemporal_store(val, dstp);
+                    else *dstp = val;
+                }
         } else {
             const int64_t n = tile * TN + 2 * l15;
 #pragma unroll
@@ -1044,6 +1050,7 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
     const bool exact = (D == L.DP && K == L.KP);
     const int64_t nfast = exact ? N / TN : 0;
     const int occ = xpass_occupancy();
+    static const int ntm = env_int("VMP_PCA_XPASS_NT", 3, 0, 3);   // nontemporal Y loads + X stores: +3%
     const int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
     hipStream_t s = ctx->stream;
     const double *A = state + L.off_A;
@@ -1060,6 +1067,15 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
         if (guard)                                                                              \
             hipLaunchKernelGGL((pca_xpass_kernel<db, kt, true, 2>), grid, dim3(NT), 0, s, Y,    \
                                ldy, N, D, K, A, X, ldx, t0, t1);                                \
+        else if (ntm == 1 && kt < 4)                                                            \
+            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 1>), grid, dim3(NT), 0, s,   \
+                               Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
+        else if (ntm == 2 && kt < 4)                                                            \
+            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 2>), grid, dim3(NT), 0, s,   \
+                               Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
+        else if (ntm == 3 && kt < 4)                                                            \
+            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 3>), grid, dim3(NT), 0, s,   \
+                               Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
         else if (occ >= 3 && kt < 4)                                                            \
             hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3>), grid, dim3(NT), 0, s, Y,   \
                                ldy, N, D, K, A, X, ldx, t0, t1);                                \

@@ -68,6 +68,32 @@ def make_shard(torch, dev, n_local, D, K, seed, rank):
     return y[:, :n_local]
 
 
+def pmc_traffic(stats, D, K, n_local):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of
+    this same command (profiles/r*/pmc_pca_<stats>.txt; separate FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the profile is not
+    for this workload or is absent."""
+    import glob
+    import re
+    if (D, K, n_local) != (128, 32, 10_000_000):
+        return None, None
+    kern = 'pca_xpass_kernel' if stats == 'gram' else 'pca_pass_kernel<4, 2, true>'
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_pca_%s.txt' % stats)),
+                       reverse=True):
+        vals, cur = {}, None
+        for line in open(path):
+            if not line.startswith(' '):
+                cur = line.strip()
+                continue
+            m = re.match(r'\s+(FETCH_SIZE|WRITE_SIZE)\s+avg\s+([0-9.]+)', line)
+            if m and cur and cur.startswith(kern):
+                vals[m.group(1)] = float(m.group(2))
+        if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+            return 2.0 * vals['FETCH_SIZE'] * 1024 + vals['WRITE_SIZE'] * 1024, \
+                os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(D, K, n_sample, n_full):
     """The NumPy oracle (kind 'port') timed on this box's host cores on a bounded
     sample of the same workload; linear in N (measured linear)."""
@@ -204,6 +230,7 @@ def main():
             'elbo_first': float(L[0]), 'elbo_last': float(L[-1]),
             'roofline': roof,
         }
+        roof['traffic'], roof['traffic_source'] = pmc_traffic(args.stats, D, K, n_local)
         out['config']['stats'] = args.stats
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(D, K, min(args.cpu_sample_n, n_total), n_total)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for profiles/ on the GPU box (summaries only; the
+# rocpd databases are too large to travel back).  Usage: tools/collect_profiles.sh <outdir>
+O=${1:-gpurun_out/prof}
+mkdir -p $O
+R=$PWD
+export TMPDIR=/tmp
+for st in gram stream; do
+  B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --stats $st"
+  (cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats_$st -o r -- $B > $R/$O/bench_under_rocprof_$st.log 2>&1)
+  python tools/rocpd_summary.py /tmp/p_stats_$st/r_results.db > $O/kernel_stats_pca_$st.txt 2>&1
+  (cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch_$st -o r -- $B > /dev/null 2>&1)
+  (cd /tmp; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write_$st -o r -- $B > /dev/null 2>&1)
+  (cd /tmp; timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/p_sq_$st -o r -- $B > /dev/null 2>&1)
+  (cd /tmp; timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace -d /tmp/p_sq2_$st -o r -- $B > /dev/null 2>&1)
+  python tools/rocpd_summary.py --pmc /tmp/p_fetch_$st/r_results.db /tmp/p_write_$st/r_results.db /tmp/p_sq_$st/r_results.db /tmp/p_sq2_$st/r_results.db > $O/pmc_pca_$st.txt 2>&1
+done
+G="python $R/tools/bench_gmm.py --steps 5"
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats_gmm -o r -- $G > $R/$O/bench_under_rocprof_gmm.log 2>&1)
+python tools/rocpd_summary.py /tmp/p_stats_gmm/r_results.db > $O/kernel_stats_gmm.txt 2>&1
+(cd /tmp; timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace -d /tmp/p_sq_gmm -o r -- $G > /dev/null 2>&1)
+(cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f_gmm -o r -- $G > /dev/null 2>&1)
+(cd /tmp; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w_gmm -o r -- $G > /dev/null 2>&1)
+python tools/rocpd_summary.py --pmc /tmp/p_sq_gmm/r_results.db /tmp/p_f_gmm/r_results.db /tmp/p_w_gmm/r_results.db > $O/pmc_gmm.txt 2>&1
+python bench.py --steps 20 --warmup 3 > $O/bench_n1_gram.json 2>/dev/null
+python bench.py --steps 20 --warmup 3 --stats stream --no-cpu-baseline > $O/bench_n1_stream.json 2>/dev/null
+python tools/bench_gmm.py > $O/bench_gmm_n1.json 2>/dev/null
+tools/microbench.bin > $O/microbench.txt 2>&1
+ls -la $O

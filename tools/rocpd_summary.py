@@ -38,7 +38,7 @@ def stats(db):
             100.0 * sum(v) / tot))
 
 
-def pmc(dbs, only='pass_kernel'):
+def pmc(dbs, only='pass_kernel'):  # pca_xpass / pca_pass / gmm_pass
     for db in dbs:
         con = sqlite3.connect(db)
         rows = con.execute('select kernel_name, counter_name, value, duration, dispatch_id '
