@@ -46,6 +46,13 @@ __device__ inline double product_at(const Iter &it, const int64_t *base, int64_t
 {
     int64_t off[MAXIN];
     for (int i = 0; i < it.nin; ++i) off[i] = base[i];
+    if (it.nr == 1) {
+        for (int i = 0; i < it.nin; ++i) off[i] += r * it.rstride[i][0];
+    } else if (it.nr == 2) {
+        const int64_t q = r / it.rsize[1];
+        const int64_t c = r - q * it.rsize[1];
+        for (int i = 0; i < it.nin; ++i) off[i] += q * it.rstride[i][0] + c * it.rstride[i][1];
+    } else
     for (int d = it.nr - 1; d >= 0; --d) {
         const int64_t q = r / it.rsize[d];
         const int64_t c = r - q * it.rsize[d];
@@ -88,6 +95,39 @@ sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial)
     for (int64_t r = r0 + threadIdx.x; r < r1; r += NT) acc += product_at(it, base, r);
     acc = block_sum<NT>(acc, red);
     if (threadIdx.x == 0) partial[o * nsplit + sp] = acc;
+}
+
+// Column reduce: the innermost kept axis is dense in the operands that carry it, so
+// lanes run along it (coalesced) and the workgroup's row-lanes split the reduction.
+//   grid = (kept-inner blocks, kept-outer, nsplit); block = KX x (NT/KX) threads.
+template <int KX>
+__global__ void __launch_bounds__(NT)
+sum_multiply_column_kernel(Iter it, int nsplit, double *__restrict__ partial)
+{
+    constexpr int RY = NT / KX;
+    __shared__ double tile[RY][KX + 1];
+    const int kx = threadIdx.x % KX, ry = threadIdx.x / KX;
+    const int64_t kin = it.ksize[it.nk - 1];
+    const int64_t ki = (int64_t)blockIdx.x * KX + kx;        // index along the inner kept axis
+    const int64_t ko = blockIdx.y;                           // flattened outer kept index
+    const int sp = blockIdx.z;
+    const int64_t o = ko * kin + (ki < kin ? ki : 0);
+    int64_t base[MAXIN], ooff;
+    decode_keep(it, o, base, ooff);
+    const int64_t chunk = (it.nred + nsplit - 1) / nsplit;
+    const int64_t r0 = sp * chunk;
+    const int64_t r1 = (r0 + chunk < it.nred) ? r0 + chunk : it.nred;
+    double acc = 0.0;
+    if (ki < kin)
+        for (int64_t r = r0 + ry; r < r1; r += RY) acc += product_at(it, base, r);
+    tile[ry][kx] = acc;
+    __syncthreads();
+    if (ry == 0 && ki < kin) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < RY; ++j) s += tile[j][kx];
+        partial[o * nsplit + sp] = s;
+    }
 }
 
 __global__ void __launch_bounds__(NT)
@@ -155,6 +195,57 @@ ewise_kernel(EwiseArgs a, double *__restrict__ out)
             case VMP_OP_MAX:     BIN(fmax(x, y)); break;
             case VMP_OP_MIN:     BIN(fmin(x, y)); break;
             case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;   // 0 * -inf guard
+            case VMP_OP_DUP:     PUSH(s0); break;
+            case VMP_OP_SWAP:    { const double tmp = s0; s0 = s1; s1 = tmp; } break;
+            default: break;
+            }
+        }
+#undef PUSH
+#undef BIN
+        out[e] = s0;
+    }
+}
+
+// Fast path: after dimension merging every operand is either dense (stride 1) or a
+// broadcast scalar (stride 0): no index decode, 64-bit only for the base offset.
+template <int NDIM>
+__global__ void __launch_bounds__(NT)
+ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
+{
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < a.total;
+         e += (int64_t)gridDim.x * NT) {
+        int64_t off[MAXIN];
+        if (NDIM == 1) {
+            for (int i = 0; i < a.nin; ++i) off[i] = e * a.stride[i][0];
+        } else {
+            // NDIM == 2: one division
+            const int64_t q = e / a.shape[1];
+            const int64_t c = e - q * a.shape[1];
+            for (int i = 0; i < a.nin; ++i) off[i] = q * a.stride[i][0] + c * a.stride[i][1];
+        }
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
+#define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
+        for (int p = 0; p < a.nops; ++p) {
+            const int op = a.ops[p] & 0xff, arg = a.ops[p] >> 8;
+            switch (op) {
+            case VMP_OP_IN:      PUSH(a.in[arg][off[arg]]); break;
+            case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
+            case VMP_OP_ADD:     BIN(x + y); break;
+            case VMP_OP_SUB:     BIN(x - y); break;
+            case VMP_OP_MUL:     BIN(x * y); break;
+            case VMP_OP_DIV:     BIN(x / y); break;
+            case VMP_OP_NEG:     s0 = -s0; break;
+            case VMP_OP_LOG:     s0 = log(s0); break;
+            case VMP_OP_EXP:     s0 = exp(s0); break;
+            case VMP_OP_SQR:     s0 = s0 * s0; break;
+            case VMP_OP_SQRT:    s0 = sqrt(s0); break;
+            case VMP_OP_RECIP:   s0 = 1.0 / s0; break;
+            case VMP_OP_DIGAMMA: s0 = vmp_digamma(s0); break;
+            case VMP_OP_LGAMMA:  s0 = vmp_lgamma(s0); break;
+            case VMP_OP_MAX:     BIN(fmax(x, y)); break;
+            case VMP_OP_MIN:     BIN(fmin(x, y)); break;
+            case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;
             case VMP_OP_DUP:     PUSH(s0); break;
             case VMP_OP_SWAP:    { const double tmp = s0; s0 = s1; s1 = tmp; } break;
             default: break;
@@ -369,7 +460,44 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         it.nred = 0;
     }
     const bool use_block = (it.nred >= 2048) && (it.nkeep <= 16384);
-    if (!use_block) {
+    // column pattern: several kept elements along a dense innermost kept axis
+    bool use_column = false;
+    if (it.nred >= 512 && it.nk >= 1 && it.ksize[it.nk - 1] >= 4 && it.nkeep <= 65536) {
+        use_column = true;
+        for (int i = 0; i < nin; ++i) {
+            const int64_t st = it.kstride[i][it.nk - 1];
+            if (st != 0 && st != 1) use_column = false;
+        }
+    }
+    if (use_column) {
+        const int64_t kin = it.ksize[it.nk - 1];
+        const int64_t kouter = it.nkeep / kin;
+        const int KX = kin >= 64 ? 64 : (kin >= 16 ? 16 : 4);
+        const int64_t kblocks = (kin + KX - 1) / KX;
+        int64_t want = ((int64_t)ctx->num_cu * 8 + kblocks * kouter - 1) / (kblocks * kouter);
+        int64_t maxsplit = (it.nred + 8 * (NT / KX) - 1) / (8 * (NT / KX));
+        int64_t nsplit = want < maxsplit ? want : maxsplit;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 1024) nsplit = 1024;
+        VMP_REQUIRE(ctx, kouter <= 65535 && workspace
+                             && workspace_bytes >= (size_t)(it.nkeep * nsplit) * sizeof(double),
+                    VMP_ERR_INVALID, "sum_multiply workspace too small (%lld doubles needed)",
+                    (long long)(it.nkeep * nsplit));
+        double *partial = reinterpret_cast<double *>(workspace);
+        const dim3 grid((unsigned)kblocks, (unsigned)kouter, (unsigned)nsplit);
+        if (KX == 64)
+            hipLaunchKernelGGL(sum_multiply_column_kernel<64>, grid, dim3(NT), 0, s, it,
+                               (int)nsplit, partial);
+        else if (KX == 16)
+            hipLaunchKernelGGL(sum_multiply_column_kernel<16>, grid, dim3(NT), 0, s, it,
+                               (int)nsplit, partial);
+        else
+            hipLaunchKernelGGL(sum_multiply_column_kernel<4>, grid, dim3(NT), 0, s, it,
+                               (int)nsplit, partial);
+        hipLaunchKernelGGL(sum_multiply_finish_kernel,
+                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
+                           (int)nsplit, scale, partial, out);
+    } else if (!use_block) {
         hipLaunchKernelGGL(sum_multiply_thread_kernel, dim3((unsigned)grid_for(ctx, it.nkeep, NT)),
                            dim3(NT), 0, s, it, scale, out);
     } else {
@@ -392,7 +520,7 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
     return VMP_OK;
 }
 
-size_t vmp_sum_multiply_workspace_bytes(void) { return (size_t)1 << 20; }
+size_t vmp_sum_multiply_workspace_bytes(void) { return (size_t)64 << 20; }
 
 int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
                   const double *const *in, const int64_t *in_strides, int32_t nops,
@@ -441,8 +569,13 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
     }
     for (int c = 0; c < nconsts; ++c) a.consts[c] = consts[c];
     if (a.total == 0) return VMP_OK;
-    hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)grid_for(ctx, a.total, NT * 4)), dim3(NT), 0,
-                       ctx->stream, a, out);
+    const dim3 grid((unsigned)grid_for(ctx, a.total, NT * 4));
+    if (a.ndim <= 1)
+        hipLaunchKernelGGL(ewise_small_kernel<1>, grid, dim3(NT), 0, ctx->stream, a, out);
+    else if (a.ndim == 2)
+        hipLaunchKernelGGL(ewise_small_kernel<2>, grid, dim3(NT), 0, ctx->stream, a, out);
+    else
+        hipLaunchKernelGGL(ewise_kernel, grid, dim3(NT), 0, ctx->stream, a, out);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
