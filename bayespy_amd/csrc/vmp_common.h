@@ -15,6 +15,8 @@ struct vmp_ctx {
     int num_cu;
     int timing;
     hipEvent_t ev[3];
+    hipStream_t side;          // side stream: small dependent-free kernels overlap the plate pass
+    hipEvent_t ev_fork, ev_join;
     char err[512];
 };
 
@@ -93,6 +95,30 @@ __host__ __device__ inline double vmp_lgamma(double x)
 }
 
 #ifdef __HIPCC__
+// Running log-determinant without a log per pivot: the product of the pivots is kept in
+// `prod` and folded into `ld` only when it leaves a safe range (fp64 log is ~1000 cycles on
+// the serial critical path of a Gauss-Jordan sweep).
+__device__ inline void logdet_accumulate(double piv, double &prod, double &ld)
+{
+    prod *= piv;
+    if (!(prod < 1e120 && prod > 1e-120)) {
+        ld += log(prod);
+        prod = 1.0;
+    }
+}
+
+__device__ inline double logdet_finish(double prod, double ld) { return ld + log(prod); }
+
+// 1/x to fp64 round-off: hardware estimate + two Newton steps (avoids the ~40-instruction
+// IEEE division sequence on the serial critical path).
+__device__ inline double fast_recip(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // Wavefront (64 lanes) and workgroup reductions, fixed order => deterministic.
 // ---------------------------------------------------------------------------

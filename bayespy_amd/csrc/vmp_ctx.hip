@@ -30,6 +30,8 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     ctx->timing = 0;
     ctx->err[0] = 0;
     for (int i = 0; i < 3; ++i) ctx->ev[i] = nullptr;
+    ctx->side = nullptr;
+    ctx->ev_fork = ctx->ev_join = nullptr;
     VMP_HIP_CHECK(ctx, hipSetDevice(device));
     int cu = 0;
     VMP_HIP_CHECK(ctx, hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device));
@@ -42,7 +44,10 @@ int32_t vmp_ctx_destroy(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_OK;
     for (int i = 0; i < 3; ++i)
-        if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
     return VMP_OK;
 }

@@ -279,7 +279,7 @@ spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
         const int i = e / n, j = e - i * n;
         M[i * SPD_LD + j] = 0.5 * (a[i * n + j] + a[j * n + i]);
     }
-    double ld = 0.0;
+    double ld = 0.0, prod = 1.0;
     constexpr int EPT = SPD_MAXN * SPD_MAXN / NT;
     for (int p = 0; p < n; ++p) {
         __syncthreads();
@@ -297,9 +297,9 @@ spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
         }
         if (tid == 0) {
             if (!(piv > 0.0)) bad = 1;
-            ld += log(piv);
+            logdet_accumulate(piv, prod, ld);
         }
-        const double d = 1.0 / piv;
+        const double d = fast_recip(piv);
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
@@ -321,7 +321,7 @@ spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
             Ainv[b * n * n + e] = M[i * SPD_LD + j];
         }
     if (tid == 0) {
-        if (logdet) logdet[b] = ld;
+        if (logdet) logdet[b] = logdet_finish(prod, ld);
         if (info) info[b] = bad;
     }
 }
@@ -340,7 +340,7 @@ spd_batched_wave_kernel(int n, int64_t batch, const double *__restrict__ A,
     double *M = Ms[w];
     double v = 0.0;
     if (act) v = 0.5 * (A[b * n * n + i * n + j] + A[b * n * n + j * n + i]);
-    double ld = 0.0;
+    double ld = 0.0, prod = 1.0;
     int bad = 0;
     for (int p = 0; p < n; ++p) {
         M[l] = v;
@@ -348,8 +348,8 @@ spd_batched_wave_kernel(int n, int64_t batch, const double *__restrict__ A,
         const double piv = M[p * n + p];
         const double ci = M[i * n + p], rj = M[p * n + j];
         if (!(piv > 0.0)) bad = 1;
-        ld += log(piv);
-        const double d = 1.0 / piv;
+        logdet_accumulate(piv, prod, ld);
+        const double d = fast_recip(piv);
         if (i == p) v = (j == p) ? d : rj * d;
         else if (j == p) v = -ci * d;
         else v = v - ci * rj * d;
@@ -357,7 +357,7 @@ spd_batched_wave_kernel(int n, int64_t batch, const double *__restrict__ A,
     }
     if (act && Ainv) Ainv[b * n * n + l] = v;
     if (b < batch && l == 0) {
-        if (logdet) logdet[b] = ld;
+        if (logdet) logdet[b] = logdet_finish(prod, ld);
         if (info) info[b] = bad;
     }
 }

@@ -342,7 +342,7 @@ gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, 
 __device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool act, double *M,
                                           double *logdet, int *bad)
 {
-    double ld = 0.0;
+    double ld = 0.0, prod = 1.0;
     const int l = threadIdx.x & 63;
     for (int p = 0; p < D; ++p) {
         M[l] = v;
@@ -350,14 +350,14 @@ __device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool ac
         const double piv = M[p * D + p];
         const double ci = act ? M[i * D + p] : 0.0, rj = act ? M[p * D + j] : 0.0;
         if (!(piv > 0.0)) *bad = 1;
-        ld += log(piv);
-        const double d = 1.0 / piv;
+        logdet_accumulate(piv, prod, ld);
+        const double d = fast_recip(piv);
         if (i == p) v = (j == p) ? d : rj * d;
         else if (j == p) v = -ci * d;
         else v = v - ci * rj * d;
         lds_fence();
     }
-    *logdet = ld;
+    *logdet = logdet_finish(prod, ld);
     return v;
 }
 

@@ -438,15 +438,70 @@ constexpr int LD = MAX_KP + 1;
 constexpr int EPT = MAX_KP * MAX_KP / NTS;   // K*K elements per thread (4)
 constexpr int RB = 64;                       // row block of the D x K products
 
-// In-place inverse of the SPD n x n matrix M (LDS, row-major, ld LD) by
-// pivot-free Gauss-Jordan sweeps (all n^2 elements updated in parallel per
-// pivot; stable for SPD input).  Replaces the per-matrix SciPy calls
+// Register-resident Gauss-Jordan inverse by ONE wavefront (KP = 16 or 32): lane l owns
+// CPL consecutive columns of row l / LPR; the pivot row travels through a KP-double LDS
+// buffer, the pivot-column element through one cross-lane shuffle; no workgroup barrier.
+// Rows / columns >= n are treated as identity (SPD-preserving padding).
+template <int KP>
+__device__ __forceinline__ void wave_gj_inverse(double *M, int n, double *rowbuf, double *logdet, int *bad)
+{
+    constexpr int LPR = 64 / KP;
+    constexpr int CPL = KP / LPR;
+    const int l = threadIdx.x & 63;
+    const int i = l / LPR, h = l % LPR;
+    double m[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = h * CPL + c;
+        m[c] = (i < n && j < n) ? M[i * LD + j] : ((i == j) ? 1.0 : 0.0);
+    }
+    double ld = 0.0, prod = 1.0;
+    int isbad = 0;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        if (i == p) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) rowbuf[h * CPL + c] = m[c];
+        }
+        const double ci = __shfl(m[p % CPL], (l & ~(LPR - 1)) | (p / CPL), 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double piv = rowbuf[p];
+        if (!(piv > 0.0)) isbad = 1;
+        logdet_accumulate(piv, prod, ld);
+        const double d = fast_recip(piv);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const double rj = rowbuf[h * CPL + c];
+            const bool jp = (h == p / CPL) && (c == p % CPL);
+            double v;
+            if (i == p) v = jp ? d : rj * d;
+            else if (jp) v = -ci * d;
+            else v = m[c] - ci * rj * d;
+            m[c] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = h * CPL + c;
+        if (i < n && j < n) M[i * LD + j] = m[c];
+    }
+    if (l == 0) {
+        *logdet = logdet_finish(prod, ld);
+        if (isbad) *bad = 1;
+    }
+}
+
+// In-place inverse of the SPD n x n matrix M (LDS, row-major, ld LD) by pivot-free
+// Gauss-Jordan sweeps (stable for SPD input).  Replaces the per-matrix SciPy calls
 // chol / chol_inv / chol_logdet (utils/linalg.py:31-63, :174-223).
-// *logdet = log|M_in| ; *bad set when a pivot is not positive.
-__device__ void spd_inverse_gj(double *M, int n, double *logdet, int *bad)
+// *logdet = log|M_in| ; *bad set when a pivot is not positive.  KP <= 32: one wavefront,
+// registers (pca_spd_kernel below); KP = 64: all n^2 elements updated in parallel per
+// pivot through LDS by the whole workgroup.
+__device__ __forceinline__ void spd_inverse_gj(double *M, int n, double *logdet, int *bad)
 {
     const int tid = threadIdx.x;
-    double ld = 0.0;
+    double ld = 0.0, prod = 1.0;
     for (int p = 0; p < n; ++p) {
         __syncthreads();
         const double piv = M[p * LD + p];
@@ -463,9 +518,9 @@ __device__ void spd_inverse_gj(double *M, int n, double *logdet, int *bad)
         }
         if (tid == 0) {
             if (!(piv > 0.0)) *bad = 1;
-            ld += log(piv);
+            logdet_accumulate(piv, prod, ld);
         }
-        const double d = 1.0 / piv;
+        const double d = fast_recip(piv);
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
@@ -481,7 +536,7 @@ __device__ void spd_inverse_gj(double *M, int n, double *logdet, int *bad)
         }
     }
     __syncthreads();
-    if (tid == 0) *logdet = ld;
+    if (tid == 0) *logdet = logdet_finish(prod, ld);
     __syncthreads();
 }
 
@@ -492,6 +547,47 @@ __device__ inline double sxx_total(const double *st, const vmp_pca_layout &L, do
     const double *S = st + L.off_S;
     const double m = 0.5 * (S[(L.DP + i) * L.KP + j] + S[(L.DP + j) * L.KP + i]);
     return n_total * st[L.off_CX + i * L.KP + j] + m;
+}
+
+// Lambda_W (which = 0) or Lambda_X (which = 1) -> inverse + log-determinant, by one
+// wavefront with the matrix in registers.  K <= 32.
+template <int KP>
+__global__ void __launch_bounds__(64)
+pca_spd_kernel(vmp_pca_layout L, int K, int which, double n_total, double x_prec, double *st)
+{
+    __shared__ double M[32 * LD];
+    __shared__ double rowbuf[32];
+    __shared__ double logdet;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const int KPs = (int)L.KP;
+    if (tid == 0) bad = 0;
+    const double tau = st[L.off_tau + 2];
+    for (int e = tid; e < K * K; e += 64) {
+        const int i = e / K, j = e - i * K;
+        double v;
+        if (which == 0) {
+            // gaussian.py:656-670 (prior phi) + dot.py:581 (message E4)
+            v = tau * sxx_total(st, L, n_total, i, j);
+            if (i == j) v += st[L.off_alpha + 2 * KPs + i];
+        } else {
+            v = tau * 0.5 * (st[L.off_Sww + i * KPs + j] + st[L.off_Sww + j * KPs + i]);
+            if (i == j) v += x_prec;
+        }
+        M[i * LD + j] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_gj_inverse<KP>(M, K, rowbuf, &logdet, &bad);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int64_t off = which == 0 ? L.off_CW : L.off_CX;
+    for (int e = tid; e < K * K; e += 64) {
+        const int i = e / K, j = e - i * K;
+        st[off + i * KPs + j] = M[i * LD + j];
+    }
+    if (tid == 0) {
+        st[L.off_scal + which] = logdet;
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
 }
 
 __global__ void __launch_bounds__(NT)
@@ -527,17 +623,27 @@ pca_update_w_kernel(vmp_pca_layout L, int D, int K, double n_total, double *st)
     const int KP = (int)L.KP;
     if (tid == 0) bad = 0;
     const double tau = st[L.off_tau + 2];
-    // gaussian.py:656-670 (prior phi) + dot.py:581 (message E4)
-    for (int e = tid; e < K * K; e += NTS) {
-        const int i = e / K, j = e - i * K;
-        double v = tau * sxx_total(st, L, n_total, i, j);
-        if (i == j) v += st[L.off_alpha + 2 * KP + i];
-        M[i * LD + j] = v;
-    }
-    spd_inverse_gj(M, K, &logdet, &bad);
-    for (int e = tid; e < K * K; e += NTS) {
-        const int i = e / K, j = e - i * K;
-        st[L.off_CW + i * KP + j] = M[i * LD + j];
+    if (KP <= 32) {
+        // Cov_W and log|Lambda_W| were produced by pca_spd_kernel (one wavefront, registers)
+        for (int e = tid; e < K * K; e += NTS) {
+            const int i = e / K, j = e - i * K;
+            M[i * LD + j] = st[L.off_CW + i * KP + j];
+        }
+        if (tid == 0) logdet = st[L.off_scal + 0];
+        __syncthreads();
+    } else {
+        // gaussian.py:656-670 (prior phi) + dot.py:581 (message E4)
+        for (int e = tid; e < K * K; e += NTS) {
+            const int i = e / K, j = e - i * K;
+            double v = tau * sxx_total(st, L, n_total, i, j);
+            if (i == j) v += st[L.off_alpha + 2 * KP + i];
+            M[i * LD + j] = v;
+        }
+        spd_inverse_gj(M, K, &logdet, &bad);
+        for (int e = tid; e < K * K; e += NTS) {
+            const int i = e / K, j = e - i * K;
+            st[L.off_CW + i * KP + j] = M[i * LD + j];
+        }
     }
     const double *Syx = st + L.off_S;
     double *W = st + L.off_W;
@@ -600,16 +706,25 @@ pca_prepare_x_kernel(vmp_pca_layout L, int D, int K, double x_prec, double *st)
     const int KP = (int)L.KP, DP = (int)L.DP;
     if (tid == 0) bad = 0;
     const double tau = st[L.off_tau + 2];
-    for (int e = tid; e < K * K; e += NTS) {
-        const int i = e / K, j = e - i * K;
-        double v = tau * 0.5 * (st[L.off_Sww + i * KP + j] + st[L.off_Sww + j * KP + i]);
-        if (i == j) v += x_prec;
-        M[i * LD + j] = v;
-    }
-    spd_inverse_gj(M, K, &logdet, &bad);
-    for (int e = tid; e < K * K; e += NTS) {
-        const int i = e / K, j = e - i * K;
-        st[L.off_CX + i * KP + j] = M[i * LD + j];
+    if (KP <= 32) {
+        for (int e = tid; e < K * K; e += NTS) {
+            const int i = e / K, j = e - i * K;
+            M[i * LD + j] = st[L.off_CX + i * KP + j];
+        }
+        if (tid == 0) logdet = st[L.off_scal + 1];
+        __syncthreads();
+    } else {
+        for (int e = tid; e < K * K; e += NTS) {
+            const int i = e / K, j = e - i * K;
+            double v = tau * 0.5 * (st[L.off_Sww + i * KP + j] + st[L.off_Sww + j * KP + i]);
+            if (i == j) v += x_prec;
+            M[i * LD + j] = v;
+        }
+        spd_inverse_gj(M, K, &logdet, &bad);
+        for (int e = tid; e < K * K; e += NTS) {
+            const int i = e / K, j = e - i * K;
+            st[L.off_CX + i * KP + j] = M[i * LD + j];
+        }
     }
     const double *W = st + L.off_W;
     for (int r0 = 0; r0 < D; r0 += RB) {
@@ -904,12 +1019,11 @@ int32_t run_stats(vmp_ctx *ctx, bool compute_x, const double *Y, int64_t ldy, in
 }
 
 int32_t run_gram_stats(vmp_ctx *ctx, const vmp_pca_layout &L, int D, int K, double *state,
-                       double *P)
+                       double *P, hipStream_t s)
 {
     const int nb = (int)(L.DP / GR);
     const size_t lds = ((size_t)L.KP * (L.DP + 1) + (size_t)GR * L.DP + (size_t)GR * LD)
                        * sizeof(double);
-    hipStream_t s = ctx->stream;
     static bool attr_set = false;
     if (!attr_set) {
         VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)pca_gram_stats_kernel,
@@ -1054,6 +1168,18 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
     const int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
     hipStream_t s = ctx->stream;
     const double *A = state + L.off_A;
+    // The messages to W depend only on (G, A), not on the pass: compute them on a side
+    // stream so that their latency hides under the streaming kernel.
+    if (!ctx->side) {
+        VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    rc = run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), ctx->side);
+    if (rc != VMP_OK) return rc;
+    VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
     if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
     for (int pass = 0; pass < 2; ++pass) {
         const bool guard = (pass == 1);
@@ -1067,12 +1193,6 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
         if (guard)                                                                              \
             hipLaunchKernelGGL((pca_xpass_kernel<db, kt, true, 2>), grid, dim3(NT), 0, s, Y,    \
                                ldy, N, D, K, A, X, ldx, t0, t1);                                \
-        else if (ntm == 1 && kt < 4)                                                            \
-            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 1>), grid, dim3(NT), 0, s,   \
-                               Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
-        else if (ntm == 2 && kt < 4)                                                            \
-            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 2>), grid, dim3(NT), 0, s,   \
-                               Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
         else if (ntm == 3 && kt < 4)                                                            \
             hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 3>), grid, dim3(NT), 0, s,   \
                                Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
@@ -1092,8 +1212,7 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
         VMP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
-    rc = run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace));
-    if (rc != VMP_OK) return rc;
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
     return VMP_OK;
 }
@@ -1109,6 +1228,12 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
 int32_t vmp_pca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double *state)
 {
     VMP_SMALL_PROLOGUE();
+    if (L.KP == 16)
+        hipLaunchKernelGGL(pca_spd_kernel<16>, dim3(1), dim3(64), 0, ctx->stream, L, K, 0,
+                           (double)n_total, 1.0, state);
+    else if (L.KP == 32)
+        hipLaunchKernelGGL(pca_spd_kernel<32>, dim3(1), dim3(64), 0, ctx->stream, L, K, 0,
+                           (double)n_total, 1.0, state);
     hipLaunchKernelGGL(pca_update_w_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K,
                        (double)n_total, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
@@ -1119,6 +1244,12 @@ int32_t vmp_pca_prepare_x(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, dou
 {
     VMP_SMALL_PROLOGUE();
     VMP_REQUIRE(ctx, x_prec > 0, VMP_ERR_INVALID, "x_prec must be positive");
+    if (L.KP == 16)
+        hipLaunchKernelGGL(pca_spd_kernel<16>, dim3(1), dim3(64), 0, ctx->stream, L, K, 1, 0.0,
+                           x_prec, state);
+    else if (L.KP == 32)
+        hipLaunchKernelGGL(pca_spd_kernel<32>, dim3(1), dim3(64), 0, ctx->stream, L, K, 1, 0.0,
+                           x_prec, state);
     hipLaunchKernelGGL(pca_prepare_x_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K, x_prec,
                        state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
