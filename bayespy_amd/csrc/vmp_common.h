@@ -119,6 +119,37 @@ __device__ inline double fast_recip(double x)
     return r;
 }
 
+__device__ inline void lds_fence()
+{
+    // LDS operations of one wavefront complete in issue order: waiting for the
+    // outstanding ones makes this wave's writes visible to all of its lanes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+
+// in: v = element (i,j) of an SPD matrix (lanes >= D*D idle); out: element of the inverse
+__device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool act, double *M,
+                                          double *logdet, int *bad)
+{
+    double ld = 0.0, prod = 1.0;
+    const int l = threadIdx.x & 63;
+    for (int p = 0; p < D; ++p) {
+        M[l] = v;
+        lds_fence();
+        const double piv = M[p * D + p];
+        const double ci = act ? M[i * D + p] : 0.0, rj = act ? M[p * D + j] : 0.0;
+        if (!(piv > 0.0)) *bad = 1;
+        logdet_accumulate(piv, prod, ld);
+        const double d = fast_recip(piv);
+        if (i == p) v = (j == p) ? d : rj * d;
+        else if (j == p) v = -ci * d;
+        else v = v - ci * rj * d;
+        lds_fence();
+    }
+    *logdet = logdet_finish(prod, ld);
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // Wavefront (64 lanes) and workgroup reductions, fixed order => deterministic.
 // ---------------------------------------------------------------------------

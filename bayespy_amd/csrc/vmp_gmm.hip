@@ -66,13 +66,6 @@ __device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-__device__ inline void lds_fence()
-{
-    // LDS operations of one wavefront complete in issue order: waiting for the
-    // outstanding ones makes this wave's writes visible to all of its lanes
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 // ---------------------------------------------------------------------------
 // The pass.  DPT = DP/4 in {1,2}, KT = KP/16 in {1,2,4}, FT2 = F2P/16 in {1,2,3}.
 // FROM_LABELS: responsibilities are the one-hot of given labels
@@ -338,29 +331,6 @@ gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, 
 // Per-cluster small kernels: one wavefront per cluster, D*D <= 64 elements,
 // one matrix element per lane; SPD inverse by Gauss-Jordan sweeps.
 // ---------------------------------------------------------------------------
-// in: v = element (i,j) of an SPD matrix (lanes >= D*D idle); out: element of the inverse
-__device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool act, double *M,
-                                          double *logdet, int *bad)
-{
-    double ld = 0.0, prod = 1.0;
-    const int l = threadIdx.x & 63;
-    for (int p = 0; p < D; ++p) {
-        M[l] = v;
-        lds_fence();
-        const double piv = M[p * D + p];
-        const double ci = act ? M[i * D + p] : 0.0, rj = act ? M[p * D + j] : 0.0;
-        if (!(piv > 0.0)) *bad = 1;
-        logdet_accumulate(piv, prod, ld);
-        const double d = fast_recip(piv);
-        if (i == p) v = (j == p) ? d : rj * d;
-        else if (j == p) v = -ci * d;
-        else v = v - ci * rj * d;
-        lds_fence();
-    }
-    *logdet = logdet_finish(prod, ld);
-    return v;
-}
-
 __global__ void __launch_bounds__(NT)
 gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, double *st)
 {

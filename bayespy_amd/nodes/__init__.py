@@ -10,6 +10,7 @@ from .wishart import Wishart
 from .dirichlet import Dirichlet
 from .categorical import Categorical
 from .mixture import Mixture
+from .gaussian_markov_chain import GaussianMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
-           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Mixture']
+           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Mixture', 'GaussianMarkovChain']

@@ -50,6 +50,10 @@ class SumMultiply(Node):
         nodes, in_keys, out_keys = _parse(args)
         if len(nodes) < 1:
             raise ValueError('SumMultiply needs at least one parent')
+        # a Gaussian Markov chain parent is seen through its Gaussian view (moment
+        # converter search of the reference, node.py:110-179)
+        from .gaussian_markov_chain import GaussianMarkovChain
+        nodes = [n.as_gaussian() if isinstance(n, GaussianMarkovChain) else n for n in nodes]
         super().__init__(*nodes, plates=(), dims=((), ()), name=name)
         self.in_keys = in_keys
         self.out_keys = out_keys

@@ -47,7 +47,8 @@ class GaussianARD(Stochastic):
 
 def _is_gaussian(node):
     from .dot import SumMultiply
-    return isinstance(node, (GaussianARD, SumMultiply)) or type(node).__name__ == 'Gaussian'
+    return isinstance(node, (GaussianARD, SumMultiply)) or type(node).__name__ in (
+        'Gaussian', 'MarkovChainToGaussian')
 
 
 class Gaussian(Stochastic):

@@ -1,0 +1,91 @@
+"""
+Gaussian Markov chain node (reference:
+bayespy/inference/vmp/nodes/gaussian_markov_chain.py:709-1190, formulas :270-707).
+
+``GaussianMarkovChain(mu, Lambda, A, nu, n=N, plates=...)``: x_0 ~ N(mu, Lambda^-1),
+x_n ~ N(A x_{n-1}, diag(nu)^-1).  Moments u = [<x_n> (N,D), <x_n x_n^T> (N,D,D),
+<x_{n-1} x_n^T> (N-1,D,D)].  The dynamics matrix ``A`` is a Gaussian variable with
+shape (D,) whose LAST plate (D) indexes the rows of A; ``nu`` has last plate D.  Only
+time-constant dynamics are built (A, nu without the N-1 plate).  A chain used as a
+Gaussian parent (e.g. of SumMultiply) is seen through :class:`MarkovChainToGaussian`,
+which turns the time axis into the last plate (reference :1988-2098).
+"""
+import numpy as np
+
+from .node import Node, Stochastic, Constant
+from ..utils.shapes import broadcasted_shape
+
+
+class GaussianMarkovChain(Stochastic):
+
+    def __init__(self, mu, Lambda, A, nu, n=None, inputs=None, plates=None, name=None):
+        if inputs is not None:
+            raise NotImplementedError('input signals of GaussianMarkovChain are not built')
+        super().__init__(mu, Lambda, A, nu, plates=(), dims=((), (), ()), name=name)
+        mu_n, L_n, A_n, nu_n = self.parents
+        if isinstance(L_n, Constant):
+            if L_n.value.ndim < 2 or L_n.value.shape[-1] != L_n.value.shape[-2]:
+                raise Exception("Initial state parameters have wrong dimensionality")
+            D, Lpl = L_n.value.shape[-1], L_n.value.shape[:-2]
+        else:
+            D, Lpl = L_n.dims[0][0], L_n.plates
+        if isinstance(mu_n, Constant):
+            if mu_n.value.ndim < 1 or mu_n.value.shape[-1] != D:
+                raise Exception("Initial state parameters have wrong dimensionality")
+            mupl = mu_n.value.shape[:-1]
+        else:
+            if mu_n.dims[0] != (D,):
+                raise Exception("Initial state parameters have wrong dimensionality")
+            mupl = mu_n.plates
+        if isinstance(A_n, Constant):
+            if A_n.value.shape[-2:] != (D, D):
+                raise Exception("Dynamics matrix has wrong dimensionality")
+            Apl = A_n.value.shape[:-1]
+        else:
+            if A_n.dims[0] != (D,):
+                raise Exception("Dynamics matrix has wrong dimensionality")
+            Apl = A_n.plates
+        nupl = nu_n.value.shape if isinstance(nu_n, Constant) else nu_n.plates
+        for pl in (Apl, nupl):
+            if len(pl) == 0 or pl[-1] != D:
+                raise Exception("Dynamics matrix should have a last plate equal to the "
+                                "dimensionality of the system.")
+            if len(pl) >= 2 and pl[-2] != 1:
+                raise NotImplementedError('time-varying dynamics (an N-1 plate on A / nu) '
+                                          'are not built')
+        if n is None:
+            raise Exception("The number of time instances could not be determined "
+                            "automatically. Give the number of time instances.")
+        self.N, self.D = int(n), int(D)
+        self.dims = ((self.N, D), (self.N, D, D), (self.N - 1, D, D))
+        given = tuple(plates) if plates is not None else ()
+        self.plates = broadcasted_shape(given, mupl, Lpl, Apl[:-2], nupl[:-2])
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
+
+    def _check_value_shape(self, x):
+        shape = tuple(x.shape) if hasattr(x, 'shape') else np.shape(x)
+        full = self.plates + self.dims[0]
+        try:
+            ok = broadcasted_shape(shape, full) == full
+        except ValueError:
+            ok = False
+        if not ok:
+            raise ValueError('Value of shape %s does not match node %s with plates+dims %s'
+                             % (shape, self.name, full))
+
+    def as_gaussian(self):
+        if not hasattr(self, '_as_gaussian'):
+            self._as_gaussian = MarkovChainToGaussian(self)
+        return self._as_gaussian
+
+
+class MarkovChainToGaussian(Node):
+    """Deterministic view of a chain as Gaussian moments with the time axis as the last
+    plate (reference ``_MarkovChainToGaussian``, gaussian_markov_chain.py:1988-2098)."""
+
+    def __init__(self, X, name=None):
+        super().__init__(X, plates=X.plates + (X.N,), dims=((X.D,), (X.D, X.D)),
+                         name=name or (X.name + '_as_gaussian'))
+        self.shape = (X.D,)
+        self.ndim = 1

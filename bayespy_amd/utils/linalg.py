@@ -121,3 +121,50 @@ def transpose(X, ndim=1):
 
 def logdet_cov(C):
     return chol_logdet(chol(C))
+
+
+def block_banded_solve(A, B, y):
+    """
+    Solve a symmetric positive-definite block-tridiagonal system for every plate and
+    return the diagonal / super-diagonal blocks of its inverse, the solution and the
+    log-determinant -- the Kalman filter + RTS smoother of the Gaussian Markov chain
+    (reference: utils/linalg.py:468-575).
+
+    A (..., N, D, D) diagonal blocks, B (..., N-1, D, D) super-diagonal blocks,
+    y (..., N, D).  One ``vmp_block_banded_solve`` launch sequence; the matrix
+    recursions run once when A and B carry no plates (shared dynamics).
+    """
+    from .shapes import broadcasted_shape
+    rt = get_runtime()
+    A, B, y = asdarray(A), asdarray(B), asdarray(y)
+    N, D = y.shape[-2], y.shape[-1]
+    # a unit time axis means "the same block at every time instance"
+    if A.ndim < 3 or A.shape[-3] not in (1, N):
+        raise ValueError("The number of diagonal blocks is incorrect")
+    if A.shape[-2:] != (D, D):
+        raise ValueError("The diagonal blocks have wrong shape")
+    if N > 1 and (B.ndim < 3 or B.shape[-3] not in (1, N - 1) or B.shape[-2:] != (D, D)):
+        raise ValueError("The super-diagonal blocks have wrong shape")
+    plates_m = broadcasted_shape(A.shape[:-3], B.shape[:-3])
+    plates_y = broadcasted_shape(plates_m, y.shape[:-2])
+    shared = all(p == 1 for p in plates_m)
+    pm = plates_m if shared else plates_y
+    Ac = contiguous(A.broadcast_to(pm + (N, D, D)))
+    Bc = contiguous(B.broadcast_to(pm + (max(N - 1, 1), D, D))) if N > 1 else Ac
+    yc = contiguous(y.broadcast_to(plates_y + (N, D)))
+    nm = int(np.prod(pm)) if pm else 1
+    ny = int(np.prod(plates_y)) if plates_y else 1
+    V = DArray.empty(pm + (N, D, D))
+    C = DArray.empty(pm + (max(N - 1, 0), D, D))
+    x = DArray.empty(plates_y + (N, D))
+    ldet = DArray.empty(pm)
+    info = rt.torch.zeros(max(nm, 1), dtype=rt.torch.int32, device=rt.device)
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_block_banded_solve(
+        rt.ctx, N, D, nm, ny, ctypes.c_void_p(Ac.t.data_ptr()), ctypes.c_void_p(Bc.t.data_ptr()),
+        ctypes.c_void_p(yc.t.data_ptr()), ctypes.c_void_p(V.t.data_ptr()),
+        ctypes.c_void_p(C.t.data_ptr()), ctypes.c_void_p(x.t.data_ptr()),
+        ctypes.c_void_p(ldet.t.data_ptr()), ctypes.c_void_p(info.data_ptr())))
+    if bool(info.any().item()):
+        raise _lib.NotPositiveDefiniteError("Matrix not positive definite")
+    return V, C, x, ldet

@@ -277,6 +277,17 @@ int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double 
 int32_t vmp_onehot_i64(vmp_ctx *ctx, int64_t n, int32_t K, const int64_t *labels, double *out,
                        int32_t *info);
 
+/* Block-tridiagonal SPD solve = Kalman filter + RTS smoother of the Gaussian Markov chain
+ * (linalg.block_banded_solve, utils/linalg.py:468-575, called by
+ * gaussian_markov_chain.py:89-123).  A: nm x T x K x K diagonal blocks, B: nm x (T-1) x K x K
+ * super-diagonal blocks, y: ny x T x K right-hand sides; nm == 1 (shared dynamics) or
+ * nm == ny.  Out: V (diagonal blocks of the inverse), C (super-diagonal blocks), x
+ * (solutions), ldet[nm] (log-determinant); info[b] = 1 where a block is not positive
+ * definite.  K <= 8. */
+int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, int64_t ny,
+                               const double *A, const double *B, const double *y, double *V,
+                               double *C, double *x, double *ldet, int32_t *info);
+
 /* Elapsed milliseconds of the most recent vmp_pca_xpass / vmp_pca_pass on this context,
  * measured with HIP events on the context's stream (blocks until done);
  * enabled by vmp_ctx_set_timing(ctx, 1). */

@@ -286,6 +286,89 @@ def small_model_cases(name):
     print(name, {k: v for k, v in out.items() if k.endswith('_L') and k.count('_') == 1})
 
 
+def lssm_cases(name):
+    """Linear state-space models (bayespy/demos/lssm.py:33-103): a single chain with fixed
+    innovation precision, and a batch of sequences with a Gamma innovation precision;
+    plus known answers of linalg.block_banded_solve (utils/linalg.py:468-575)."""
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+    from bayespy.inference import VB
+    from bayespy.utils import linalg
+    rs = np.random.RandomState(2024)
+    out = {}
+
+    def build(tag, M, T, D, B, gamma_nu):
+        plates_x = () if B is None else (B,)
+        a_true = 0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]
+        nseq = 1 if B is None else B
+        x = np.zeros((nseq, T, D))
+        x[:, 0] = rs.normal(size=(nseq, D))
+        for t in range(1, T):
+            x[:, t] = x[:, t - 1] @ a_true.T + rs.normal(size=(nseq, D))
+        c_true = rs.normal(size=(M, D))
+        f = np.einsum('md,btd->mbt', c_true, x)
+        y = f + 0.3 * rs.normal(size=f.shape)
+        if B is None:
+            y = y[:, 0]
+        alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+        A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+        A.initialize_from_value(np.identity(D))
+        nu = Gamma(1e-3, 1e-3, plates=(D,), name='nu') if gamma_nu else np.ones(D)
+        X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, nu, n=T,
+                                plates=plates_x, name='X')
+        x0 = rs.normal(size=plates_x + (T, D))
+        X.initialize_from_value(x0)
+        gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+        gamma.initialize_from_value(1e-2 * np.ones(D))
+        cplates = (M, 1) if B is None else (M, 1, 1)
+        C = GaussianARD(0, gamma, shape=(D,), plates=cplates, name='C')
+        c0 = rs.normal(size=cplates + (D,))
+        C.initialize_from_value(c0)
+        tau = Gamma(1e-5, 1e-5, name='tau')
+        tau.initialize_from_value(1e2)
+        F = SumMultiply('i,i', C, X, name='F')
+        Y = GaussianARD(F, tau, name='Y')
+        Y.observe(y)
+        nodes = [Y, F, C, gamma, X, A, alpha, tau]
+        if gamma_nu:
+            nodes.append(nu)
+        Q = VB(*nodes)
+        Q.ignore_bound_checks = True
+        Ls = []
+        n_iter = 4
+        for _ in range(n_iter):
+            Q.update(repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+        out[tag + '_y'], out[tag + '_x0'], out[tag + '_c0'] = y, x0, c0
+        out[tag + '_L'] = np.array(Ls)
+        track = dict(X=X, A=A, C=C, tau=tau, alpha=alpha, gamma=gamma)
+        if gamma_nu:
+            track['nu'] = nu
+        for nm, nd in track.items():
+            for i, ui in enumerate(nd.u):
+                out['%s_%s_u%d' % (tag, nm, i)] = np.asarray(ui)
+            out['%s_%s_L' % (tag, nm)] = np.array(Q.l[nd][:Q.iter])
+        print(tag, Ls)
+
+    build('lssm1', M=5, T=30, D=3, B=None, gamma_nu=False)
+    build('lssmB', M=4, T=25, D=2, B=6, gamma_nu=True)
+    build('lssmBc', M=4, T=25, D=2, B=6, gamma_nu=False)
+    build('lssm1g', M=5, T=30, D=3, B=None, gamma_nu=True)
+
+    # block_banded_solve known answers: shared and per-sequence matrices
+    for tag, pl in (('bbs_shared', ()), ('bbs_batch', (5,))):
+        T, D = 12, 3
+        Z = rs.normal(size=pl + (T * D, T * D + 3))
+        full = Z @ np.swapaxes(Z, -1, -2) + T * D * np.eye(T * D)
+        Ab = np.stack([full[..., t * D:(t + 1) * D, t * D:(t + 1) * D] for t in range(T)], axis=-3)
+        Bb = np.stack([full[..., t * D:(t + 1) * D, (t + 1) * D:(t + 2) * D]
+                       for t in range(T - 1)], axis=-3)
+        yv = rs.normal(size=(5, T, D))
+        V, Cc, xx, ld = linalg.block_banded_solve(Ab, Bb, yv)
+        out[tag + '_A'], out[tag + '_B'], out[tag + '_y'] = Ab, Bb, yv
+        out[tag + '_V'], out[tag + '_C'], out[tag + '_x'], out[tag + '_ld'] = V, Cc, xx, ld
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -299,6 +382,7 @@ def main():
     gmm_case('gmm_n3000_d8_k16', N=3000, D=8, K=16, n_iter=4, seed=12)
     utils_cases('utils_known_answers')
     small_model_cases('small_models')
+    lssm_cases('lssm')
 
 
 if __name__ == '__main__':

@@ -1,0 +1,129 @@
+"""
+GPU parity of the Gaussian Markov chain path (BASELINE.json config 5 family):
+``vmp_block_banded_solve`` against known answers of the reference's own
+``linalg.block_banded_solve`` and against a dense solve, and linear state-space models
+(bayespy/demos/lssm.py) against golden traces of the live reference
+(tests/golden/lssm.npz).  Tolerances: ELBO rtol 1e-9, moments rtol 1e-7.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_block_banded_solve_known_answers(golden_dir):
+    from bayespy_amd.utils import linalg
+    g = np.load(os.path.join(golden_dir, 'lssm.npz'))
+    for tag in ('bbs_shared', 'bbs_batch'):
+        V, C, x, ld = linalg.block_banded_solve(g[tag + '_A'], g[tag + '_B'], g[tag + '_y'])
+        np.testing.assert_allclose(np.broadcast_to(V.numpy(), g[tag + '_V'].shape), g[tag + '_V'],
+                                   rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.broadcast_to(C.numpy(), g[tag + '_C'].shape), g[tag + '_C'],
+                                   rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(x.numpy(), g[tag + '_x'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.broadcast_to(ld.numpy(), g[tag + '_ld'].shape),
+                                   g[tag + '_ld'], rtol=1e-11)
+
+
+@pytest.mark.parametrize('T,D,nseq', [(1, 1, 1), (2, 1, 3), (7, 2, 1), (50, 4, 10), (33, 8, 5),
+                                      (1000, 4, 200)])
+def test_block_banded_solve_vs_dense(T, D, nseq):
+    from bayespy_amd.utils import linalg
+    rs = np.random.RandomState(T * 10 + D)
+    A = rs.normal(size=(T, D, 2 * D))
+    A = A @ A.transpose(0, 2, 1) + 4 * D * np.eye(D)
+    B = 0.5 * rs.normal(size=(max(T - 1, 1), D, D))[:max(T - 1, 0)]
+    y = rs.normal(size=(nseq, T, D))
+    V, C, x, ld = linalg.block_banded_solve(A, B if T > 1 else np.zeros((0, D, D)), y)
+    if T <= 64:
+        full = np.zeros((T * D, T * D))
+        for t in range(T):
+            full[t * D:(t + 1) * D, t * D:(t + 1) * D] = A[t]
+            if t < T - 1:
+                full[t * D:(t + 1) * D, (t + 1) * D:(t + 2) * D] = B[t]
+                full[(t + 1) * D:(t + 2) * D, t * D:(t + 1) * D] = B[t].T
+        inv = np.linalg.inv(full)
+        xs = np.linalg.solve(full, y.reshape(nseq, T * D).T).T.reshape(nseq, T, D)
+        np.testing.assert_allclose(x.numpy(), xs, rtol=1e-9, atol=1e-12)
+        Vn, Cn = V.numpy(), C.numpy()
+        for t in range(T):
+            np.testing.assert_allclose(Vn[t], inv[t * D:(t + 1) * D, t * D:(t + 1) * D],
+                                       rtol=1e-8, atol=1e-12)
+            if t < T - 1:
+                np.testing.assert_allclose(Cn[t], inv[t * D:(t + 1) * D, (t + 1) * D:(t + 2) * D],
+                                           rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(ld.numpy(), np.linalg.slogdet(full)[1], rtol=1e-11)
+    else:
+        # residual check of the solution for long chains
+        xn = x.numpy()
+        r = np.einsum('tij,stj->sti', A, xn)
+        r[:, :-1] += np.einsum('tij,stj->sti', B, xn[:, 1:])
+        r[:, 1:] += np.einsum('tji,stj->sti', B, xn[:, :-1])
+        np.testing.assert_allclose(r, y, rtol=1e-8, atol=1e-9)
+
+
+def test_block_banded_solve_errors():
+    from bayespy_amd.utils import linalg
+    from bayespy_amd import _lib
+    with pytest.raises(ValueError):
+        linalg.block_banded_solve(np.ones((3, 2, 2)), np.ones((2, 2, 2)), np.ones((4, 2)))
+    with pytest.raises(NotImplementedError):
+        linalg.block_banded_solve(np.tile(np.eye(9), (3, 1, 1)), np.zeros((2, 9, 9)),
+                                  np.ones((3, 9)))
+    bad = np.tile(-np.eye(2), (3, 1, 1))
+    with pytest.raises(_lib.NotPositiveDefiniteError):
+        linalg.block_banded_solve(bad, np.zeros((2, 2, 2)), np.ones((3, 2)))
+
+
+def _build_lssm(g, tag, B, gamma_nu):
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+    from bayespy_amd.inference import VB
+    y, x0, c0 = g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0']
+    M = y.shape[0]
+    T, D = x0.shape[-2], x0.shape[-1]
+    plates_x = () if B is None else (B,)
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    A.initialize_from_value(np.identity(D))
+    nu = Gamma(1e-3, 1e-3, plates=(D,), name='nu') if gamma_nu else np.ones(D)
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, nu, n=T, plates=plates_x,
+                            name='X')
+    X.initialize_from_value(x0)
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(D))
+    cplates = (M, 1) if B is None else (M, 1, 1)
+    C = GaussianARD(0, gamma, shape=(D,), plates=cplates, name='C')
+    C.initialize_from_value(c0)
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = SumMultiply('i,i', C, X, name='F')
+    Y = GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    nodes = [Y, F, C, gamma, X, A, alpha, tau]
+    if gamma_nu:
+        nodes.append(nu)
+    Q = VB(*nodes)
+    Q.ignore_bound_checks = True
+    track = dict(X=X, A=A, C=C, tau=tau, alpha=alpha, gamma=gamma)
+    if gamma_nu:
+        track['nu'] = nu
+    return Q, track
+
+
+@pytest.mark.parametrize('tag,B,gamma_nu', [('lssm1', None, False), ('lssm1g', None, True),
+                                             ('lssmBc', 6, False), ('lssmB', 6, True)])
+def test_lssm_matches_reference(golden_dir, tag, B, gamma_nu):
+    g = np.load(os.path.join(golden_dir, 'lssm.npz'))
+    Q, track = _build_lssm(g, tag, B, gamma_nu)
+    n = len(g[tag + '_L'])
+    Q.update(repeat=n, verbose=False)
+    np.testing.assert_allclose(Q.L[:n], g[tag + '_L'], rtol=1e-9)
+    for nm, nd in track.items():
+        np.testing.assert_allclose(Q.l[nd][:n], g['%s_%s_L' % (tag, nm)], rtol=1e-8, atol=1e-7,
+                                   err_msg=nm)
+        for i, ui in enumerate(nd.u):
+            ref = g['%s_%s_u%d' % (tag, nm, i)]
+            np.testing.assert_allclose(np.broadcast_to(ui, ref.shape), ref, rtol=1e-7, atol=1e-9,
+                                       err_msg='%s u[%d]' % (nm, i))
