@@ -95,7 +95,7 @@ class GMMPlan:
         for Y in nodes:
             if not isinstance(Y, Mixture) or Y.node_class is not Gaussian:
                 continue
-            if len(Y.parents) != 3 or len(Y.plates) != 1:
+            if len(Y.parents) != 3 or len(Y.plates) != 1 or Y._mask is not True:
                 continue
             z, mu, Lam = Y.parents
             if not (isinstance(z, Categorical) and isinstance(mu, GaussianARD)

@@ -149,6 +149,8 @@ class PCAPlan:
                 continue
             if any(p != 1 for p in tau.plates) or len(Y.plates) != 2:
                 continue
+            if Y._mask is not True:
+                continue          # missing data: per-plate posteriors -> generic engine
             D, N = Y.plates
             A, B = F.parents
             if not (isinstance(A, GaussianARD) and isinstance(B, GaussianARD)):
@@ -239,10 +241,7 @@ class PCAPlan:
         if self.Y._data is None:
             raise ValueError('Node %s has not been observed; the fused PCA block needs '
                              'Y.observe(y)' % self.Y.name)
-        if self.Y._mask is not True:
-            from .generic import GenericPlan
-            GenericPlan(self.nodes())
-            raise RuntimeError('model moved to the generic engine; call again')
+        assert self.Y._mask is True, 'masked models never reach the fused PCA block'
         rt.sync_stream()
         self.layout = L = k.layout(D, K)
         self.n_total = rt.all_reduce_int(N)

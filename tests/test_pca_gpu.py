@@ -258,3 +258,21 @@ def test_headline_size_properties(stats):
     L_host, _ = o.lower_bound()
     L_dev = Q.compute_lowerbound()
     assert abs(L_dev - L_host) / abs(L_host) < 1e-10
+
+
+def test_config2_size_vs_oracle():
+    """BASELINE.json config 2 (PCA N=1e6, D=64, K=16): direct ELBO / moment parity against the
+    pinned oracle at the size where the reference itself is still feasible."""
+    from oracle.pca import PCAOracle, make_pca_data
+    N, D, K = 1_000_000, 64, 16
+    y, x0 = make_pca_data(N, D, K, seed=42)
+    iters = 3
+    for stats in ('gram', 'stream'):
+        Q = _run(y, x0, K, iters, stats=stats)
+        if stats == 'gram':
+            o = PCAOracle(y, x0, keep_x=True)
+            o.iterate(iters)
+        np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=1e-10)
+        xs, cx = Q.plans[0].get_parameters(Q['X'])
+        np.testing.assert_allclose(xs, o.X, rtol=MOM_RTOL, atol=1e-9)
+        np.testing.assert_allclose(Q['tau'].u[0], o.moments()['tau'][0], rtol=1e-9)
