@@ -110,6 +110,9 @@ SIGNATURES = {
     'vmp_spd_batched': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'vmp_softmax_moments': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_onehot_i64': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    'vmp_gemm_strided': (c_i32, [c_vp, c_i32, P(c_i64), c_i64, c_i64, c_i64, c_vp, P(c_i64), c_i64,
+                                 c_i64, c_vp, P(c_i64), c_i64, c_i64, c_vp, P(c_i64), c_i64, c_i64,
+                                 c_f64, c_vp, c_sz]),
     'vmp_block_banded_solve': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_vp]),
     'vmp_ctx_set_timing': (c_i32, [c_vp, c_i32]),

@@ -1,0 +1,229 @@
+// vmp_gemm.hip -- strided, batched fp64 contraction on the matrix cores.
+//
+// Where a SumMultiply / sum_multiply call collapses to a dense M x N x K contraction
+//     C[b, m, n] = scale * sum_k A[b, m, k] * B[b, k, n]
+// (the messages and moments of dot.py:355, :403, :581 with array masks, the weighted
+// mixture statistics of mixture.py:126-158, the chain statistics of
+// gaussian_markov_chain.py:462-475, ...), the generic engine routes it here instead of the
+// scalar einsum loop the reference uses (np.einsum(optimize=False), utils/misc.py:906).
+//
+// Arbitrary element strides on every axis (stride 0 = broadcast batch axis), up to three
+// batch axes, split-K with fixed-order combination (deterministic).  64 x 64 x 16 tiles
+// staged through LDS with conflict-free strides (18 / 80 doubles), each of the four
+// wavefronts owns a 32 x 32 block = 2 x 2 v_mfma_f64_16x16x4_f64 accumulators.
+#include "vmp_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDA_S = BK + 2;     // 18: A tile [BM][18]
+constexpr int LDB_S = BN + 16;    // 80: B tile [BK][80]
+
+struct GemmArgs {
+    int64_t M, N, K;
+    int nb;                          // batch axes (<= 3)
+    int64_t bshape[3];
+    int64_t a_bs[3], b_bs[3], c_bs[3];
+    int64_t a_ms, a_ks, b_ks, b_ns, c_ms, c_ns;
+    const double *A, *B;
+    double *C;                       // final output, or the partial buffer when nsplit > 1
+    int nsplit;
+    int64_t kchunk;                  // K elements per split (multiple of BK)
+    double scale;
+};
+
+__device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(NT, 2)
+gemm_kernel(GemmArgs g)
+{
+    __shared__ double As[BM * LDA_S];
+    __shared__ double Bs[BK * LDB_S];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, l15 = l & 15, l4 = l >> 4;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    const int64_t tiles_n = (g.N + BN - 1) / BN;
+    const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int sp = blockIdx.y;
+    // batch offsets
+    int64_t bz = blockIdx.z, aoff = 0, boff = 0, coff = 0;
+    for (int d = g.nb - 1; d >= 0; --d) {
+        const int64_t q = bz / g.bshape[d], c = bz - q * g.bshape[d];
+        bz = q;
+        aoff += c * g.a_bs[d];
+        boff += c * g.b_bs[d];
+        coff += c * g.c_bs[d];
+    }
+    const double *A = g.A + aoff;
+    const double *B = g.B + boff;
+    const int64_t k_begin = (int64_t)sp * g.kchunk;
+    const int64_t k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
+
+    // thread -> element maps for the tile loads; lanes run along the dense axis
+    const bool a_kfast = (g.a_ks == 1) || (g.a_ms != 1);     // else M is the dense axis of A
+    const bool b_nfast = (g.b_ns == 1) || (g.b_ks != 1);
+
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+        // A tile: BM x BK = 1024 elements, 4 per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * NT;
+            const int mi = a_kfast ? idx / BK : idx % BM;
+            const int ki = a_kfast ? idx % BK : idx / BM;
+            const int64_t m = m0 + mi, k = k0 + ki;
+            double v = 0.0;
+            if (m < g.M && k < k_end) v = A[m * g.a_ms + k * g.a_ks];
+            As[mi * LDA_S + ki] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * NT;
+            const int ki = b_nfast ? idx / BN : idx % BK;
+            const int ni = b_nfast ? idx % BN : idx / BK;
+            const int64_t k = k0 + ki, n = n0 + ni;
+            double v = 0.0;
+            if (k < k_end && n < g.N) v = B[k * g.b_ks + n * g.b_ns];
+            Bs[ki * LDB_S + ni] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BK / 4; ++q) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[(wm + i * 16 + l15) * LDA_S + 4 * q + l4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[(4 * q + l4) * LDB_S + wn + j * 16 + l15];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // C/D layout: col = lane&15, row = (lane>>4) + 4*reg
+    if (g.nsplit == 1) {
+        double *C = g.C + coff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm + i * 16 + l4 + 4 * r, n = n0 + wn + j * 16 + l15;
+                    if (m < g.M && n < g.N) C[m * g.c_ms + n * g.c_ns] = g.scale * acc[i][j][r];
+                }
+    } else {
+        // partial buffer: [split][batch][M][N] dense
+        double *P = g.C + (((int64_t)sp * gridDim.z + blockIdx.z) * g.M) * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm + i * 16 + l4 + 4 * r, n = n0 + wn + j * 16 + l15;
+                    if (m < g.M && n < g.N) P[m * g.N + n] = acc[i][j][r];
+                }
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+gemm_finish_kernel(GemmArgs g, const double *__restrict__ P, double *__restrict__ C,
+                   int64_t nbatch)
+{
+    const int64_t total = nbatch * g.M * g.N;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * NT) {
+        double s = 0.0;
+        for (int sp = 0; sp < g.nsplit; ++sp) s += P[(int64_t)sp * total + e];
+        const int64_t bz = e / (g.M * g.N);
+        const int64_t r = e - bz * g.M * g.N;
+        const int64_t m = r / g.N, n = r - m * g.N;
+        int64_t b = bz, coff = 0;
+        for (int d = g.nb - 1; d >= 0; --d) {
+            const int64_t q = b / g.bshape[d], c = b - q * g.bshape[d];
+            b = q;
+            coff += c * g.c_bs[d];
+        }
+        C[coff + m * g.c_ms + n * g.c_ns] = g.scale * s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshape, int64_t M,
+                         int64_t N, int64_t K, const double *A, const int64_t *a_bstride,
+                         int64_t a_ms, int64_t a_ks, const double *B, const int64_t *b_bstride,
+                         int64_t b_ks, int64_t b_ns, double *C, const int64_t *c_bstride,
+                         int64_t c_ms, int64_t c_ns, double scale, void *workspace,
+                         size_t workspace_bytes)
+{
+    VMP_REQUIRE(ctx, ctx && A && B && C, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, nbatch_dims >= 0 && nbatch_dims <= 3, VMP_ERR_UNSUPPORTED,
+                "at most 3 batch axes");
+    VMP_REQUIRE(ctx, M >= 0 && N >= 0 && K >= 0, VMP_ERR_INVALID, "bad dims");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K;
+    g.nb = nbatch_dims;
+    int64_t nbatch = 1;
+    for (int d = 0; d < nbatch_dims; ++d) {
+        g.bshape[d] = bshape[d];
+        g.a_bs[d] = a_bstride[d];
+        g.b_bs[d] = b_bstride[d];
+        g.c_bs[d] = c_bstride[d];
+        nbatch *= bshape[d];
+    }
+    if (M == 0 || N == 0 || nbatch == 0) return VMP_OK;
+    g.a_ms = a_ms; g.a_ks = a_ks; g.b_ks = b_ks; g.b_ns = b_ns; g.c_ms = c_ms; g.c_ns = c_ns;
+    g.A = A; g.B = B; g.scale = scale;
+    const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    VMP_REQUIRE(ctx, nbatch <= 65535, VMP_ERR_UNSUPPORTED, "too many batch elements (%lld)",
+                (long long)nbatch);
+    // split K when the output alone cannot fill the chip
+    int64_t nsplit = 1;
+    const int64_t ksteps = (K + BK - 1) / BK;
+    const int64_t want = ((int64_t)ctx->num_cu * 4 + tiles * nbatch - 1) / (tiles * nbatch);
+    if (want > 1 && ksteps >= 8) {
+        nsplit = want < ksteps / 4 ? want : ksteps / 4;
+        if (nsplit > 1024) nsplit = 1024;
+        if (nsplit < 1) nsplit = 1;
+        const size_t need = (size_t)nsplit * nbatch * M * N * sizeof(double);
+        if (!workspace || need > workspace_bytes) {
+            nsplit = workspace ? (int64_t)(workspace_bytes / ((size_t)nbatch * M * N * sizeof(double)))
+                               : 1;
+            if (nsplit < 1) nsplit = 1;
+        }
+    }
+    g.nsplit = (int)nsplit;
+    g.kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
+    if (g.kchunk < BK) g.kchunk = BK;
+    g.C = nsplit > 1 ? reinterpret_cast<double *>(workspace) : C;
+    hipStream_t s = ctx->stream;
+    const dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)nbatch);
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(NT), 0, s, g);
+    if (nsplit > 1) {
+        const int64_t total = nbatch * M * N;
+        int64_t gb = (total + NT - 1) / NT;
+        if (gb > (int64_t)ctx->num_cu * 8) gb = (int64_t)ctx->num_cu * 8;
+        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)gb), dim3(NT), 0, s, g,
+                           reinterpret_cast<const double *>(workspace), C, nbatch);
+    }
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+}  // extern "C"

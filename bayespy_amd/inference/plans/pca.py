@@ -286,7 +286,7 @@ class PCAPlan:
                 x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
                                      self.X.plates + (K,)).reshape(N, K)
                 self.Xd = rt.zeros(K, self.ldx)
-                self.Xd[:, :N].copy_(torch.from_numpy(np.ascontiguousarray(x0.T)))
+                self.Xd[:, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
             else:
                 # a draw from the current q = prior N(0, I/x_prec) (expfamily.py:206-212);
                 # RNG streams are not part of the parity contract

@@ -28,6 +28,101 @@ def _workspace(rt):
     return _ws[key]
 
 
+def _merge_axes(dims, shape, *stride_lists):
+    """Merge the axes `dims` (outer -> inner) into one strided axis for every stride list;
+    returns (extent, [stride per list]) or None when some operand is not laid out densely
+    across them."""
+    if not dims:
+        return 1, [0] * len(stride_lists)
+    ext = 1
+    for d in dims:
+        ext *= shape[d]
+    out = []
+    for st in stride_lists:
+        for a, b in zip(dims[:-1], dims[1:]):
+            if st[a] != st[b] * shape[b]:
+                return None
+        out.append(st[dims[-1]])
+    return ext, out
+
+
+def _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
+    """Route a dense two-operand contraction to the fp64 MFMA kernel (``vmp_gemm_strided``).
+    Returns True when launched."""
+    ops = list(arrays)
+    # fold operands of "subset" shape into a partner (e.g. a plate mask into its message)
+    while len(ops) > 2:
+        done = False
+        for i in range(len(ops)):
+            for j in range(len(ops)):
+                if i == j:
+                    continue
+                try:
+                    bs = broadcasted_shape(ops[i].shape, ops[j].shape)
+                except ValueError:
+                    continue
+                full_j = (1,) * (len(bs) - ops[j].ndim) + ops[j].shape
+                if bs == full_j:
+                    prod = fuse(lambda a, b: a * b, ops[i], ops[j])
+                    ops = [o for k, o in enumerate(ops) if k not in (i, j)] + [prod]
+                    done = True
+                    break
+            if done:
+                break
+        if not done:
+            return False
+    if len(ops) != 2:
+        return False
+    A, B = ops
+    nd = len(shape)
+    sa, sb, so = _strides(A.t, shape), _strides(B.t, shape), _strides(out.t, shape)
+    Md, Nd, Kd, Bd = [], [], [], []
+    for d in range(nd):
+        if shape[d] == 1:
+            continue
+        va, vb = sa[d] != 0, sb[d] != 0
+        if d in reduce_axes:
+            if va and vb:
+                Kd.append(d)
+            elif not va and not vb:
+                scale *= shape[d]
+            else:
+                return False
+        elif va and vb:
+            Bd.append(d)
+        elif va:
+            Md.append(d)
+        elif vb:
+            Nd.append(d)
+        else:
+            return False
+    if len(Bd) > 3:
+        return False
+    mm = _merge_axes(Md, shape, sa, so)
+    nn = _merge_axes(Nd, shape, sb, so)
+    kk = _merge_axes(Kd, shape, sa, sb)
+    if mm is None or nn is None or kk is None:
+        return False
+    (M, (a_ms, c_ms)), (N, (b_ns, c_ns)), (K, (a_ks, b_ks)) = mm, nn, kk
+    nbatch = 1
+    for d in Bd:
+        nbatch *= shape[d]
+    if M < 8 or N < 8 or K < 16 or M * N * K * nbatch < (1 << 20) or nbatch > 65535:
+        return False
+    c3 = ctypes.c_int64 * 3
+    bshape = c3(*([shape[d] for d in Bd] + [1] * (3 - len(Bd))))
+    a_bs = c3(*([sa[d] for d in Bd] + [0] * (3 - len(Bd))))
+    b_bs = c3(*([sb[d] for d in Bd] + [0] * (3 - len(Bd))))
+    c_bs = c3(*([so[d] for d in Bd] + [0] * (3 - len(Bd))))
+    ws = _workspace(rt)
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_gemm_strided(
+        rt.ctx, len(Bd), bshape, M, N, K, ctypes.c_void_p(A.t.data_ptr()), a_bs, a_ms, a_ks,
+        ctypes.c_void_p(B.t.data_ptr()), b_bs, b_ks, b_ns, ctypes.c_void_p(out.t.data_ptr()),
+        c_bs, c_ms, c_ns, float(scale), ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8))
+    return True
+
+
 def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
     """out (shape with size-1 on reduced axes) = scale * sum_{reduce_axes} prod arrays."""
     rt = get_runtime()
@@ -35,6 +130,9 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
     if nd > 8 or len(arrays) > 6:
         raise NotImplementedError('sum_multiply supports <= 8 axes and <= 6 operands')
     out = DArray.empty(out_shape_keep)
+    if len(arrays) >= 2 and len(reduce_axes) > 0 and _try_gemm(rt, arrays, shape, reduce_axes,
+                                                                 out, scale):
+        return out
     mask = 0
     for ax in reduce_axes:
         mask |= 1 << ax

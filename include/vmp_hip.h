@@ -277,6 +277,20 @@ int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double 
 int32_t vmp_onehot_i64(vmp_ctx *ctx, int64_t n, int32_t K, const int64_t *labels, double *out,
                        int32_t *info);
 
+/* Strided batched fp64 contraction on the matrix cores (v_mfma_f64_16x16x4_f64):
+ *     C[b, m, n] = scale * sum_k A[b, m, k] * B[b, k, n]
+ * with arbitrary ELEMENT strides on every axis (0 = broadcast batch axis), up to three
+ * batch axes, split-K with fixed-order combination.  The dense N x K x D contractions
+ * that SumMultiply / sum_multiply collapse to (dot.py:355, :403, :581 with array masks;
+ * mixture.py:126-158; gaussian_markov_chain.py:462-475) instead of
+ * np.einsum(optimize=False) (utils/misc.py:906).  `workspace` holds split-K partials. */
+int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshape, int64_t M,
+                         int64_t N, int64_t K, const double *A, const int64_t *a_bstride,
+                         int64_t a_ms, int64_t a_ks, const double *B, const int64_t *b_bstride,
+                         int64_t b_ks, int64_t b_ns, double *C, const int64_t *c_bstride,
+                         int64_t c_ms, int64_t c_ns, double scale, void *workspace,
+                         size_t workspace_bytes);
+
 /* Block-tridiagonal SPD solve = Kalman filter + RTS smoother of the Gaussian Markov chain
  * (linalg.block_banded_solve, utils/linalg.py:468-575, called by
  * gaussian_markov_chain.py:89-123).  A: nm x T x K x K diagonal blocks, B: nm x (T-1) x K x K

@@ -227,3 +227,52 @@ def test_diag_helpers():
     np.testing.assert_array_equal(d, ref)
     M = rs.normal(size=(5, 3, 3))
     np.testing.assert_allclose(misc.get_diag(M).numpy(), np.einsum('...ii->...i', M), rtol=1e-15)
+
+
+GEMM_CASES = [
+    # (shapes, reduce axes) -- all large enough to take the MFMA contraction path
+    (((64, 5000, 1, 1), (1, 5000, 16, 16)), (1,)),            # masked-PCA message to W
+    (((64, 5000, 1, 1), (64, 1, 16, 16)), (0,)),              # ... to X
+    (((70, 1, 9, 9), (1, 3000, 9, 9)), (2, 3)),               # SumMultiply second moment (E2)
+    (((3000, 17, 1, 1), (3000, 1, 6, 6)), (0,)),              # mixture weighted statistics
+    (((4, 300, 20, 8, 1), (4, 1, 1, 8, 33)), (3,)),           # batched matmul, broadcast batch
+    (((129, 1, 257), (1, 65, 257)), (2,)),                    # ragged M, N, K
+    (((64, 5000, 1, 1), (1, 5000, 16, 16), (64, 5000, 1, 1)), (1,)),   # mask folded in
+    (((2, 3, 40, 50, 1), (2, 1, 1, 50, 60)), (3,)),           # two batch axes
+]
+
+
+@pytest.mark.parametrize('shapes,red', GEMM_CASES)
+def test_dense_contractions_on_matrix_cores(shapes, red):
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(17)
+    arrs = [rs.normal(size=s) for s in shapes]
+    nd = max(len(s) for s in shapes)
+    axis = tuple(a - nd for a in red) if red else None
+    got = misc.sum_multiply(*arrs, axis=tuple(red), keepdims=True).numpy()
+    y = 1
+    for a in arrs:
+        y = y * a
+    ref = np.sum(y, axis=tuple(red), keepdims=True)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-10 * np.abs(ref).max())
+
+
+def test_gemm_path_is_taken_and_deterministic(monkeypatch):
+    from bayespy_amd.utils import misc
+    calls = []
+    orig = misc._try_gemm
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        calls.append(r)
+        return r
+    monkeypatch.setattr(misc, '_try_gemm', spy)
+    rs = np.random.RandomState(3)
+    a, b = rs.normal(size=(64, 20000, 1, 1)), rs.normal(size=(1, 20000, 16, 16))
+    r1 = misc.sum_multiply(a, b, axis=(1,)).numpy()
+    r2 = misc.sum_multiply(a, b, axis=(1,)).numpy()
+    assert calls == [True, True] and np.array_equal(r1, r2)
+    # small or one-sided contractions stay on the generic kernels
+    misc.sum_multiply(rs.normal(size=(3, 4)), rs.normal(size=(4,)), axis=(1,))
+    assert calls[-1] is False

@@ -52,6 +52,14 @@ def main():
         t = timeit(lambda: linalg.chol(C), reps=3)
         out['spd_batched n=%d batch=%d' % (n, batch)] = {
             'Mmatrices/s': batch / t / 1e6, 'GB/s': 2 * 8 * batch * n * n / t / 1e9, 'ms': t * 1e3}
+    # dense contraction on the matrix cores (masked-PCA message shape)
+    Dd, Nn, Kk = 128, 1_000_000, 32
+    m = da.DArray(torch.randn(Dd, Nn, 1, 1, device=dev, dtype=torch.float64))
+    xx = da.DArray(torch.randn(1, Nn, Kk, Kk, device=dev, dtype=torch.float64))
+    t = timeit(lambda: misc.sum_multiply(m, xx, axis=(1,)), reps=3)
+    out['gemm (128,N)x(N,32,32) N=1e6'] = {'TFLOP/s': 2.0 * Dd * Nn * Kk * Kk / t / 1e12,
+                                            'GB/s': 8.0 * Nn * (Dd + Kk * Kk) / t / 1e9,
+                                            'ms': t * 1e3}
     print(json.dumps(out, indent=1))
 
 
