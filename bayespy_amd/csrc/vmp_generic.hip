@@ -362,6 +362,103 @@ spd_batched_wave_kernel(int n, int64_t batch, const double *__restrict__ A,
     }
 }
 
+// Throughput form for 8 < n <= 32 and large batches: one matrix per group of NP lanes, lane i
+// holds row i in registers (NP doubles), so a wavefront inverts 64/NP matrices with no
+// workgroup barrier.  Each Gauss-Jordan step needs the pivot row in every lane of the group:
+// NP = 16 is exactly one DPP row, so the broadcast is v_mov_b64_dpp row_newbcast (pure VALU);
+// NP = 32 goes through a per-group LDS row.  Matrices are staged through LDS both ways so the
+// global accesses stay fully coalesced.
+template <int NP, int P>
+__device__ __forceinline__ double group_bcast(double x, double *rowbuf, int j, int gl)
+{
+    if constexpr (NP == 16) {
+        return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + P, 0xf, 0xf, false);
+    } else {
+        if (gl == P) rowbuf[j] = x;
+        lds_fence();
+        return rowbuf[j];
+    }
+}
+
+template <int NP, int P>
+__device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double *rowbuf, double &prod,
+                                              double &ld, int &bad)
+{
+    if constexpr (P < NP) {
+        double row[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) row[j] = group_bcast<NP, P>(m[j], rowbuf, j, gl);
+        const double piv = row[P];
+        if (!(piv > 0.0)) bad = 1;
+        logdet_accumulate(piv, prod, ld);
+        const double d = fast_recip(piv);
+        const double ci = m[P];
+        const double f = (gl == P) ? 0.0 : -ci * d;      // row i: m_i -= (m_ip / piv) row_p
+        const double sc = (gl == P) ? d : 0.0;           // pivot row: row_p / piv
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const double base = (gl == P) ? 0.0 : m[j];
+            m[j] = (j == P) ? ((gl == P) ? d : f) : base + (f + sc) * row[j];
+        }
+        if constexpr (NP != 16) lds_fence();
+        gj_rows_steps<NP, P + 1>(m, gl, rowbuf, prod, ld, bad);
+    }
+}
+
+template <int NP, int NTB>
+__global__ void __launch_bounds__(NTB)
+spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
+                        double *__restrict__ Ainv, double *__restrict__ logdet,
+                        int32_t *__restrict__ info)
+{
+    constexpr int MPW = 64 / NP;             // matrices per wavefront
+    constexpr int MPB = MPW * (NTB / 64);     // matrices per workgroup
+    constexpr int LDP = NP + 1;
+    __shared__ double Ms[MPB * NP * LDP];
+    __shared__ double rows[(NTB / 64) * MPW * NP];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int g = l / NP, gl = l % NP;
+    const int nn = n * n;
+    for (int64_t b0 = (int64_t)blockIdx.x * MPB; b0 < batch; b0 += (int64_t)gridDim.x * MPB) {
+        const int nb = (int)((batch - b0) < MPB ? (batch - b0) : MPB);
+        __syncthreads();
+        for (int e = tid; e < nb * nn; e += NTB) {
+            const int mb = e / nn, r = e - mb * nn;
+            const int i = r / n, j = r - i * n;
+            Ms[(mb * NP + i) * LDP + j] = __builtin_nontemporal_load(A + b0 * nn + e);
+        }
+        __syncthreads();
+        const int mb = w * MPW + g;
+        const bool act = mb < nb;
+        double *M = Ms + mb * NP * LDP;
+        double m[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            m[j] = (act && gl < n && j < n) ? 0.5 * (M[gl * LDP + j] + M[j * LDP + gl])
+                                            : ((gl == j) ? 1.0 : 0.0);
+        double ld = 0.0, prod = 1.0;
+        int bad = 0;
+        gj_rows_steps<NP, 0>(m, gl, rows + (w * MPW + g) * NP, prod, ld, bad);
+        __syncthreads();
+        if (act && gl < n) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                if (j < n) M[gl * LDP + j] = m[j];
+        }
+        if (act && gl == 0) {
+            if (logdet) logdet[b0 + mb] = logdet_finish(prod, ld);
+            if (info) info[b0 + mb] = bad;
+        }
+        __syncthreads();
+        if (Ainv)
+            for (int e = tid; e < nb * nn; e += NTB) {
+                const int mb2 = e / nn, r = e - mb2 * nn;
+                const int i = r / n, j = r - i * n;
+                Ainv[b0 * nn + e] = Ms[(mb2 * NP + i) * LDP + j];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Row softmax with the reference's exact recipe: stable log-sum-exp, exp, then a
 // second renormalisation (utils/misc.py:1388-1401).  One wavefront per row.
@@ -588,7 +685,14 @@ int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A,
     VMP_REQUIRE(ctx, n <= SPD_MAXN, VMP_ERR_UNSUPPORTED, "batched SPD kernels support n <= %d",
                 SPD_MAXN);
     if (batch == 0) return VMP_OK;
-    if (n <= 8)
+    const int64_t big = 4 * (int64_t)ctx->num_cu;      // enough matrices to fill the chip row-wise
+    if (n > 8 && n <= 16 && batch >= big)
+        hipLaunchKernelGGL((spd_batched_rows_kernel<16, 256>),
+                           dim3((unsigned)grid_for(ctx, batch, 16)), dim3(256), 0, ctx->stream, n, batch, A, Ainv, logdet, info);
+    else if (n > 16 && n <= 32 && batch >= big)
+        hipLaunchKernelGGL((spd_batched_rows_kernel<32, 128>),
+                           dim3((unsigned)grid_for(ctx, batch, 4)), dim3(128), 0, ctx->stream, n, batch, A, Ainv, logdet, info);
+    else if (n <= 8)
         hipLaunchKernelGGL(spd_batched_wave_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(NT), 0,
                            ctx->stream, n, batch, A, Ainv, logdet, info);
     else

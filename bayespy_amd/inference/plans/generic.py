@@ -928,13 +928,17 @@ class GenericPlan:
             return self.state[id(node)].mask
         return node._gmask
 
-    def _mask_factor(self, host_mask):
-        """None when everything is active, else a 0/1 device array."""
-        if np.all(host_mask):
-            return None
-        key = (host_mask.shape, host_mask.tobytes())
+    def _mask_factor(self, key, make_host_mask):
+        """None when everything is active, else a 0/1 device array.  Cached per `key` until the
+        masks change (host masks are N-sized: scanning them every message would dominate)."""
+        self._update_masks()
         if key not in self._dev_masks:
-            self._dev_masks[key] = DArray.from_host(host_mask.astype(np.float64))
+            host_mask = np.asarray(make_host_mask())
+            if np.all(host_mask):
+                ent = (None, True)
+            else:
+                ent = (DArray.from_host(host_mask.astype(np.float64)), bool(np.any(host_mask)))
+            self._dev_masks[key] = ent
         return self._dev_masks[key]
 
     # -- message routing (node.py:570-688) ------------------------------------------------------
@@ -944,7 +948,7 @@ class GenericPlan:
         if getattr(fam, 'deterministic', False):
             m_child = self._messages_from_children(child)
             ups = self._parent_moments(child)
-            mask = self._mask_factor(np.asarray(self._mask_array(child)))
+            mask, _ = self._mask_factor((id(child), 'self'), lambda: self._mask_array(child))
             return fam.message_to_parent(index, m_child, ups, mask)
         u = self._moments(child)
         up = self._parent_moments(child)
@@ -952,8 +956,9 @@ class GenericPlan:
             fam._f = self._ensure(child).f if isinstance(child, Stochastic) else None
         msgs = fam.message_to_parent(index, u, up)
         plates_self = tuple(fam.plates_to_parent(index))
-        hmask = fam.mask_to_parent(index, np.asarray(self._mask_array(child)))
-        mask = self._mask_factor(np.asarray(hmask))
+        mask, _ = self._mask_factor(
+            (id(child), index),
+            lambda: fam.mask_to_parent(index, np.asarray(self._mask_array(child))))
         out = []
         for i, m in enumerate(msgs):
             if m is None:
@@ -1022,14 +1027,13 @@ class GenericPlan:
                 t = fuse(lambda pp, pq, u: da.where_nonzero(u, pp - pq) * u, _arr(phi_p[i]),
                          _arr(st.phi[i]), _arr(st.u[i]))
             L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
-        hmask = np.asarray(self._mask_array(node))
         factors = [L]
-        mask = self._mask_factor(hmask)
+        mask, any_active = self._mask_factor((id(node), 'self'), lambda: self._mask_array(node))
         if mask is not None:
             factors.append(mask)
-        tot = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
-        if not np.any(hmask):
+        if not any_active:
             return 0.0
+        tot = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
         return tot.item()
 
     def get_moments(self, node):

@@ -133,6 +133,9 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
     if len(arrays) >= 2 and len(reduce_axes) > 0 and _try_gemm(rt, arrays, shape, reduce_axes,
                                                                  out, scale):
         return out
+    import os as _os
+    if _os.environ.get('VMP_DEBUG_SM') and int(np.prod(shape)) > 5e7:
+        print('generic sum_multiply', shape, [a.shape for a in arrays], 'reduce', reduce_axes)
     mask = 0
     for ax in reduce_axes:
         mask |= 1 << ax
@@ -297,16 +300,19 @@ def diag(X, ndim=1):
 
 
 def get_diag(X, ndim=1):
-    """Diagonal of the trailing ``2*ndim`` axes (utils/misc.py:1207-1250)."""
+    """Diagonal of the trailing ``2*ndim`` axes (utils/misc.py:1207-1250) -- a strided VIEW of
+    the array (stride sum of the paired axes), no kernel launch."""
     X = asdarray(X)
     if ndim == 0:
         return X
     sh = X.shape[len(X.shape) - ndim:]
-    n = int(np.prod(sh)) if sh else 1
     lead = X.shape[:len(X.shape) - 2 * ndim]
-    eye = DArray.from_host(np.eye(n).reshape(sh + sh))
-    out = sum_multiply(X, eye, axis=tuple(range(-ndim, 0)))
-    return out.reshape(lead + sh)
+    t = X.t
+    nl = len(lead)
+    strides = list(t.stride())
+    dstr = [strides[nl + i] + strides[nl + ndim + i] for i in range(ndim)]
+    view = t.as_strided(tuple(lead) + tuple(sh), strides[:nl] + dstr, t.storage_offset())
+    return DArray(view)
 
 
 def onehot(labels, K):

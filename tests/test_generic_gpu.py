@@ -127,7 +127,8 @@ def test_batched_spd_known_answers_and_random(golden_dir):
         np.testing.assert_allclose(linalg.chol_solve(U, g['chol%d_b' % n]).numpy(),
                                    g['chol%d_solve' % n], rtol=1e-9, atol=1e-12)
     rs = np.random.RandomState(5)
-    for n, batch in ((2, 1000), (5, 333), (9, 64), (16, 100), (32, 50), (64, 7)):
+    for n, batch in ((2, 1000), (5, 333), (9, 64), (16, 100), (32, 50), (64, 7),
+                     (9, 5003), (13, 2049), (16, 4099), (17, 1500), (24, 1031), (32, 1027)):
         A = rs.normal(size=(batch, n, n))
         C = A @ A.transpose(0, 2, 1) + n * np.eye(n)
         U = linalg.chol(C)
@@ -138,6 +139,12 @@ def test_batched_spd_known_answers_and_random(golden_dir):
     bad = np.array([[1.0, 2.0], [2.0, 1.0]])
     with pytest.raises(_lib.NotPositiveDefiniteError):
         linalg.chol(bad)
+    # one indefinite matrix inside a large batch (row-per-lane kernels)
+    for n in (12, 20):
+        C = np.tile(np.eye(n) * 2.0, (3000, 1, 1))
+        C[1234, 3, 3] = -1.0
+        with pytest.raises(_lib.NotPositiveDefiniteError):
+            linalg.chol(C)
     with pytest.raises(NotImplementedError):
         linalg.chol(np.eye(65))
 
