@@ -664,7 +664,8 @@ class SumMultiplyFamily:
             labs1.append(l1[len(l1) - xx.ndim:])
         out0 = pl + ['k%d' % k for k in n.out_keys]
         out1 = out0 + ['K%d' % k for k in n.out_keys]
-        return [misc.contract(ops0, labs0, out0, sizes), misc.contract(ops1, labs1, out1, sizes)]
+        return [misc.contract(ops0, labs0, out0, sizes, compress=pl),
+                misc.contract(ops1, labs1, out1, sizes, compress=pl)]
 
     def message_to_parent(self, index, m_child, ups, mask=None):
         """Messages to parent ``index`` already summed to its plates (dot.py:425-633)."""

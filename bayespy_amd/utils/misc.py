@@ -133,9 +133,6 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
     if len(arrays) >= 2 and len(reduce_axes) > 0 and _try_gemm(rt, arrays, shape, reduce_axes,
                                                                  out, scale):
         return out
-    import os as _os
-    if _os.environ.get('VMP_DEBUG_SM') and int(np.prod(shape)) > 5e7:
-        print('generic sum_multiply', shape, [a.shape for a in arrays], 'reduce', reduce_axes)
     mask = 0
     for ax in reduce_axes:
         mask |= 1 << ax
@@ -336,7 +333,7 @@ def onehot(labels, K):
     return out
 
 
-def contract(operands, labels, out_labels, sizes, scale=1.0):
+def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     """
     Labeled broadcast contraction (one ``vmp_sum_multiply`` launch):
 
@@ -344,7 +341,9 @@ def contract(operands, labels, out_labels, sizes, scale=1.0):
 
     ``labels[i]`` names every axis of ``operands[i]`` (an axis of extent 1 is a
     broadcast axis whatever its label); ``sizes`` maps label -> extent.  This is
-    the einsum of ``SumMultiply`` (dot.py:355, :403, :581) on device arrays.
+    the einsum of ``SumMultiply`` (dot.py:355, :403, :581) on device arrays.  Output labels
+    listed in ``compress`` keep extent 1 when no operand varies along them (plate axes of
+    broadcast-compressed moments, node.py:311-345).
     """
     ops = [asdarray(a) for a in operands]
     all_labels = list(out_labels)
@@ -360,7 +359,8 @@ def contract(operands, labels, out_labels, sizes, scale=1.0):
         for ax, lab in enumerate(ls):
             if a.shape[ax] != 1:
                 varying.add(lab)
-    shape = tuple(int(sizes[lab]) if (lab in out_labels or lab in varying) else 1
+    shape = tuple(int(sizes[lab]) if ((lab in out_labels and lab not in compress)
+                                      or lab in varying) else 1
                   for lab in all_labels)
     views = []
     for a, ls in zip(ops, labels):
