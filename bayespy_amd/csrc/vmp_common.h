@@ -9,16 +9,33 @@
 
 #include "../../include/vmp_hip.h"
 
+#define VMP_EV_RING 64
+
 struct vmp_ctx {
     int device;
     hipStream_t stream;
     int num_cu;
     int timing;
-    hipEvent_t ev[3];
-    hipStream_t side;          // side stream: small dependent-free kernels overlap the plate pass
-    hipEvent_t ev_fork, ev_join;
+    // ring of (start, pass end, reduce end) event triples, one per timed plate pass, so that
+    // the host never has to block inside an iteration to read a duration
+    hipEvent_t ev[3 * VMP_EV_RING];
+    int64_t ev_n;
+    // plate stream: the PCA latent pass runs here (on all but a few reserved CUs) while the
+    // replicated-node kernels of the next iteration proceed on `stream`
+    hipStream_t xs;
+    hipEvent_t ev_xfork, ev_xdone;
+    int x_pending;
+    int xs_cus;                // compute units the plate stream may use
     char err[512];
 };
+
+// event triple of the plate pass being issued (timing enabled); advances the ring
+static inline hipEvent_t *vmp_next_events(vmp_ctx *ctx)
+{
+    hipEvent_t *e = ctx->ev + 3 * (ctx->ev_n % VMP_EV_RING);
+    ctx->ev_n += 1;
+    return e;
+}
 
 #define VMP_SET_ERR(ctx, ...)                                         \
     do {                                                              \

@@ -29,9 +29,12 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     ctx->stream = (hipStream_t)stream;
     ctx->timing = 0;
     ctx->err[0] = 0;
-    for (int i = 0; i < 3; ++i) ctx->ev[i] = nullptr;
-    ctx->side = nullptr;
-    ctx->ev_fork = ctx->ev_join = nullptr;
+    for (int i = 0; i < 3 * VMP_EV_RING; ++i) ctx->ev[i] = nullptr;
+    ctx->ev_n = 0;
+    ctx->xs = nullptr;
+    ctx->ev_xfork = ctx->ev_xdone = nullptr;
+    ctx->x_pending = 0;
+    ctx->xs_cus = 0;
     VMP_HIP_CHECK(ctx, hipSetDevice(device));
     int cu = 0;
     VMP_HIP_CHECK(ctx, hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device));
@@ -43,11 +46,14 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
 int32_t vmp_ctx_destroy(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_OK;
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3 * VMP_EV_RING; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->xs) {
+        (void)hipStreamSynchronize(ctx->xs);
+        (void)hipStreamDestroy(ctx->xs);
+    }
+    if (ctx->ev_xfork) (void)hipEventDestroy(ctx->ev_xfork);
+    if (ctx->ev_xdone) (void)hipEventDestroy(ctx->ev_xdone);
     delete ctx;
     return VMP_OK;
 }
@@ -63,6 +69,7 @@ int32_t vmp_ctx_sync(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_ERR_INVALID;
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->xs) VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->xs));
     return VMP_OK;
 }
 
@@ -75,9 +82,32 @@ int32_t vmp_ctx_set_timing(vmp_ctx *ctx, int32_t enabled)
     if (!ctx) return VMP_ERR_INVALID;
     if (enabled && !ctx->ev[0]) {
         VMP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        for (int i = 0; i < 3; ++i) VMP_HIP_CHECK(ctx, hipEventCreate(&ctx->ev[i]));
+        for (int i = 0; i < 3 * VMP_EV_RING; ++i) VMP_HIP_CHECK(ctx, hipEventCreate(&ctx->ev[i]));
     }
     ctx->timing = enabled ? 1 : 0;
+    ctx->ev_n = 0;
+    return VMP_OK;
+}
+
+int32_t vmp_pass_times_ms(vmp_ctx *ctx, double *ms_pass, double *ms_reduce, int32_t cap,
+                          int32_t *count)
+{
+    VMP_REQUIRE(ctx, ctx && count && cap >= 0, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, ctx->timing && ctx->ev[0], VMP_ERR_INVALID,
+                "timing not enabled (vmp_ctx_set_timing)");
+    int64_t n = ctx->ev_n < VMP_EV_RING ? ctx->ev_n : VMP_EV_RING;
+    if (n > cap) n = cap;
+    for (int64_t i = 0; i < n; ++i) {
+        hipEvent_t *e = ctx->ev + 3 * ((ctx->ev_n - n + i) % VMP_EV_RING);
+        VMP_HIP_CHECK(ctx, hipEventSynchronize(e[2]));
+        float a = 0.f, b = 0.f;
+        VMP_HIP_CHECK(ctx, hipEventElapsedTime(&a, e[0], e[1]));
+        VMP_HIP_CHECK(ctx, hipEventElapsedTime(&b, e[1], e[2]));
+        if (ms_pass) ms_pass[i] = a;
+        if (ms_reduce) ms_reduce[i] = b;
+    }
+    *count = (int32_t)n;
+    ctx->ev_n = 0;
     return VMP_OK;
 }
 

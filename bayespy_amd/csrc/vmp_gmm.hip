@@ -684,7 +684,8 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
     const double *C = state + L.off_C;
     dim3 grid((unsigned)g);
     int32_t rc = VMP_ERR_UNSUPPORTED;
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
 #define VMP_GCASE(dpt, kt, ft2)                                                                 \
     if (DPT == dpt && KT == kt && FT2 == ft2)                                                   \
         rc = launch_gmm_pass<dpt, kt, ft2>(ctx, from_labels, grid, Y, N, D, K, C, labels, R, P, \
@@ -699,12 +700,12 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
             VMP_SET_ERR(ctx, "no GMM kernel instance for DPT=%d KT=%d FT2=%d", DPT, KT, FT2);
         return rc;
     }
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
     const int total = (int)(L.KP * L.F2P + 2);
     hipLaunchKernelGGL(gmm_reduce_kernel, dim3((total + 63) / 64), dim3(NT), 0, ctx->stream,
                        L, D, K, P, (int)g, from_labels ? 0 : 1, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
     return VMP_OK;
 }
 

@@ -997,7 +997,8 @@ int32_t run_stats(vmp_ctx *ctx, bool compute_x, const double *Y, int64_t ldy, in
     if (g < 1) g = 1;
     hipStream_t s = ctx->stream;
     dim3 grid((unsigned)g);
-    if (timed && ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
+    hipEvent_t *ev = (timed && ctx->timing) ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
 #define VMP_CASE(db, kt)                                                                     \
     if (DB == db && KT == kt)                                                                \
         launch_fused<db, kt>(compute_x, grid, s, Y, ldy, N, D, Kx, A, Xs, ldx, P, ntiles);   \
@@ -1009,12 +1010,70 @@ int32_t run_stats(vmp_ctx *ctx, bool compute_x, const double *Y, int64_t ldy, in
     }
 #undef VMP_CASE
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    if (timed && ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
     const int len = (int)Lx.len_S;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + NT - 1) / NT), dim3(NT), 0, s, P,
                        (int)g, len, out_S);
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    if (timed && ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    return VMP_OK;
+}
+
+// Plate stream of the context, created on first use.  VMP_PCA_RESERVE_CUS=n (default 0)
+// creates it with a CU mask that keeps n compute units free for the one-workgroup
+// replicated-node kernels of the main stream.  Measured on MI355X (profiles/r01/README):
+// the mask unbalances the persistent streaming grid across XCDs (pass +9..14 % for n = 8)
+// while the step at shard size gains only 3-5 %, so the default is an unmasked non-blocking
+// stream: the small kernels that fit beside the streaming workgroups overlap, the others
+// run between two passes.
+int32_t ensure_plate_stream(vmp_ctx *ctx)
+{
+    if (ctx->xs) return VMP_OK;
+    static const int reserve = env_int("VMP_PCA_RESERVE_CUS", 0, 0, 64);
+    hipStream_t xs = nullptr;
+    const int ncu = ctx->num_cu;
+    ctx->xs_cus = ncu;
+    if (reserve > 0 && ncu > 2 * reserve) {
+        const int words = (ncu + 31) / 32;
+        uint32_t mask[64];
+        for (int w = 0; w < words && w < 64; ++w) mask[w] = 0;
+        for (int c = 0; c < ncu; ++c) mask[c >> 5] |= (1u << (c & 31));
+        const int step = ncu / reserve;
+        for (int r = 0; r < reserve; ++r) {
+            const int c = r * step + step / 2;
+            mask[c >> 5] &= ~(1u << (c & 31));
+        }
+        if (hipExtStreamCreateWithCUMask(&xs, (uint32_t)words, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            xs = nullptr;
+        } else {
+            ctx->xs_cus = ncu - reserve;
+        }
+    }
+    if (!xs) VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&xs, hipStreamNonBlocking));
+    ctx->xs = xs;
+    VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_xfork, hipEventDisableTiming));
+    VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_xdone, hipEventDisableTiming));
+    return VMP_OK;
+}
+
+int64_t plate_stream_A_offset(vmp_ctx *ctx, const vmp_pca_layout &L)
+{
+    return (max_grid(ctx) + 1) * partial_len(L) + 4096;
+}
+
+double *plate_stream_A(vmp_ctx *ctx, const vmp_pca_layout &L, void *workspace)
+{
+    return reinterpret_cast<double *>(workspace) + plate_stream_A_offset(ctx, L);
+}
+
+// anything on the main stream that touches X must follow the outstanding latent pass
+int32_t join_plate_stream(vmp_ctx *ctx)
+{
+    if (ctx->x_pending) {
+        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_xdone, 0));
+        ctx->x_pending = 0;
+    }
     return VMP_OK;
 }
 
@@ -1062,7 +1121,8 @@ int32_t vmp_pca_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *byte
     vmp_pca_layout L;
     fill_layout(D, K, &L);
     // per-workgroup partial statistics + one scratch statistics block (Gram set-up)
-    *bytes = (size_t)((max_grid(ctx) + 1) * partial_len(L) + 4096) * sizeof(double);
+    // (+ the plate stream's private copy of A)
+    *bytes = (size_t)(plate_stream_A_offset(ctx, L) + L.KP * L.DP) * sizeof(double);
     return VMP_OK;
 }
 
@@ -1136,6 +1196,8 @@ int32_t vmp_pca_stats_from_x(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t
     if (rc != VMP_OK) return rc;
     vmp_pca_layout L;
     fill_layout(D, K, &L);
+    rc = join_plate_stream(ctx);
+    if (rc != VMP_OK) return rc;
     return run_stats(ctx, false, Y, ldy, N, D, K, const_cast<double *>(X), ldx, state + L.off_A,
                      state + L.off_S, reinterpret_cast<double *>(workspace), false);
 }
@@ -1147,6 +1209,8 @@ int32_t vmp_pca_pass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int3
     if (rc != VMP_OK) return rc;
     vmp_pca_layout L;
     fill_layout(D, K, &L);
+    rc = join_plate_stream(ctx);
+    if (rc != VMP_OK) return rc;
     return run_stats(ctx, true, Y, ldy, N, D, K, X, ldx, state + L.off_A, state + L.off_S,
                      reinterpret_cast<double *>(workspace), true);
 }
@@ -1165,22 +1229,33 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
     const int64_t nfast = exact ? N / TN : 0;
     const int occ = xpass_occupancy();
     static const int ntm = env_int("VMP_PCA_XPASS_NT", 3, 0, 3);   // nontemporal Y loads + X stores: +3%
-    const int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
-    hipStream_t s = ctx->stream;
+    hipStream_t m = ctx->stream;
+    // VMP_PCA_PLATE_STREAM=0: everything in order on the caller's stream (A/B measurements)
+    static const int overlap = env_int("VMP_PCA_PLATE_STREAM", 1, 0, 1);
+    hipStream_t s = m;
     const double *A = state + L.off_A;
-    // The messages to W depend only on (G, A), not on the pass: compute them on a side
-    // stream so that their latency hides under the streaming kernel.
-    if (!ctx->side) {
-        VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-        VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
+    if (overlap) {
+        rc = ensure_plate_stream(ctx);
+        if (rc != VMP_OK) return rc;
+        gmax = (int64_t)ctx->xs_cus * xpass_wgs_per_cu();
+        // Nothing in a Gram-form iteration reads X: the latent pass is a pure by-product of
+        // (A, Y).  It runs on the plate stream from a private copy of A, so the
+        // replicated-node kernels of the NEXT iteration (main stream, reserved CUs) overlap
+        // it; the only ordering kept is pass(i) before pass(i+1) and before anything that
+        // touches X.
+        double *Ax = plate_stream_A(ctx, L, workspace);
+        if (ctx->x_pending) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(m, ctx->ev_xdone, 0));
+        VMP_HIP_CHECK(ctx, hipMemcpyAsync(Ax, state + L.off_A,
+                                          (size_t)(L.KP * L.DP) * sizeof(double),
+                                          hipMemcpyDeviceToDevice, m));
+        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xfork, m));
+        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->xs, ctx->ev_xfork, 0));
+        s = ctx->xs;
+        A = Ax;
     }
-    VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
-    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    rc = run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), ctx->side);
-    if (rc != VMP_OK) return rc;
-    VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], s));
+    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
     for (int pass = 0; pass < 2; ++pass) {
         const bool guard = (pass == 1);
         const int64_t t0 = guard ? nfast : 0, t1 = guard ? ntiles : nfast;
@@ -1211,9 +1286,25 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
 #undef VMP_CASE
         VMP_HIP_CHECK(ctx, hipGetLastError());
     }
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], s));
-    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-    if (ctx->timing) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], s));
+    if (ev) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
+        VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    }
+    if (overlap) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xdone, s));
+        ctx->x_pending = 1;
+    }
+    // messages to W from (G, A): main stream, concurrent with the pass
+    return run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), m);
+}
+
+int32_t vmp_pca_xjoin(vmp_ctx *ctx)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null argument");
+    if (ctx->x_pending) {
+        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_xdone, 0));
+        ctx->x_pending = 0;
+    }
     return VMP_OK;
 }
 
@@ -1289,12 +1380,13 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
 
 int32_t vmp_pca_last_pass_ms(vmp_ctx *ctx, double *ms_pass, double *ms_reduce)
 {
-    VMP_REQUIRE(ctx, ctx && ctx->timing && ctx->ev[0], VMP_ERR_INVALID,
-                "timing not enabled (vmp_ctx_set_timing)");
-    VMP_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[2]));
+    VMP_REQUIRE(ctx, ctx && ctx->timing && ctx->ev[0] && ctx->ev_n > 0, VMP_ERR_INVALID,
+                "no timed pass (vmp_ctx_set_timing)");
+    hipEvent_t *e = ctx->ev + 3 * ((ctx->ev_n - 1) % VMP_EV_RING);
+    VMP_HIP_CHECK(ctx, hipEventSynchronize(e[2]));
     float a = 0.f, b = 0.f;
-    VMP_HIP_CHECK(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-    VMP_HIP_CHECK(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+    VMP_HIP_CHECK(ctx, hipEventElapsedTime(&a, e[0], e[1]));
+    VMP_HIP_CHECK(ctx, hipEventElapsedTime(&b, e[1], e[2]));
     if (ms_pass) *ms_pass = a;
     if (ms_reduce) *ms_reduce = b;
     return VMP_OK;

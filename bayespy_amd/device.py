@@ -1,5 +1,5 @@
 """
-Device runtime: one process per GPU, one HIP stream, one ``vmp_ctx``.
+Device runtime: one process per GPU, one caller-visible HIP stream, one ``vmp_ctx``.
 
 PyTorch is used here as plumbing only -- device memory (caching allocator),
 the current HIP stream and ``torch.distributed`` (backend "nccl" == RCCL over
@@ -35,6 +35,12 @@ class Runtime:
         if self.device.type == 'cuda':
             self.lib = _lib.load()
             ctx = ctypes.c_void_p()
+            # A dedicated non-blocking stream becomes torch's current stream: work issued on
+            # the legacy null stream would implicitly serialise with the library's internal
+            # plate stream (CU-masked streams are "blocking" streams in HIP).
+            self.stream = torch.cuda.Stream(self.device)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            torch.cuda.set_stream(self.stream)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = self.lib.vmp_ctx_create(self.device.index, ctypes.c_void_p(stream),
                                          ctypes.byref(ctx))

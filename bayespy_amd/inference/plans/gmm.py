@@ -81,6 +81,14 @@ class GMMKernels:
         self.rt.check(self.lib.vmp_pca_last_pass_ms(self.ctx, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def pass_times_ms(self, cap=64):
+        """(pass_ms, reduce_ms) of the most recent timed plate passes, oldest first."""
+        a = (ctypes.c_double * cap)()
+        b = (ctypes.c_double * cap)()
+        n = ctypes.c_int32()
+        self.rt.check(self.lib.vmp_pass_times_ms(self.ctx, a, b, cap, ctypes.byref(n)))
+        return [(a[i], b[i]) for i in range(n.value)]
+
 
 class GMMPlan:
 
@@ -290,3 +298,6 @@ class GMMPlan:
 
     def last_pass_ms(self):
         return self.kernels.last_pass_ms()
+
+    def pass_times_ms(self, cap=64):
+        return self.kernels.pass_times_ms(cap)

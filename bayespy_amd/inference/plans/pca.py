@@ -90,6 +90,9 @@ class HIPKernels:
         self.rt.check(self.lib.vmp_pca_xpass(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
                                              ptr(state), ptr(ws)))
 
+    def xjoin(self):
+        self.rt.check(self.lib.vmp_pca_xjoin(self.ctx))
+
     def update_tau(self, D, K, n_total, a0, b0, state):
         self.rt.check(self.lib.vmp_pca_update_tau(self.ctx, D, K, n_total, a0, b0, ptr(state)))
 
@@ -107,6 +110,14 @@ class HIPKernels:
         a, b = ctypes.c_double(), ctypes.c_double()
         self.rt.check(self.lib.vmp_pca_last_pass_ms(self.ctx, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def pass_times_ms(self, cap=64):
+        """(pass_ms, reduce_ms) of the most recent timed plate passes, oldest first."""
+        a = (ctypes.c_double * cap)()
+        b = (ctypes.c_double * cap)()
+        n = ctypes.c_int32()
+        self.rt.check(self.lib.vmp_pass_times_ms(self.ctx, a, b, cap, ctypes.byref(n)))
+        return [(a[i], b[i]) for i in range(n.value)]
 
 
 def _const_scalar(node):
@@ -223,6 +234,7 @@ class PCAPlan:
 
     def invalidate(self, node):
         """Data or initial value of ``node`` changed: rebuild device state lazily."""
+        self.finish()
         self._ready = False
         self._version += 1
         if node is self.Y and node._mask is not True:
@@ -351,6 +363,12 @@ class PCAPlan:
             return
         self._version += 1
 
+    def finish(self):
+        """Order the caller's stream after the outstanding latent pass (Gram form runs it on the
+        library's plate stream so that it overlaps the next iteration's replicated updates)."""
+        if getattr(self, 'Xd', None) is not None and self.stats == 'gram':
+            self.kernels.xjoin()
+
     def _lower_bound_terms(self):
         self._materialize()
         if self._L_version != self._version:
@@ -393,6 +411,7 @@ class PCAPlan:
             u1 = w[:, :, None] * w[:, None, :] + cw
             return [w.reshape(self.W.plates + (K,)), u1.reshape(self.W.plates + (K, K))]
         if node is self.X:
+            self.finish()
             x = self.Xd[:, :N].cpu().numpy().T.copy()
             cx = self._block(L.off_CX, K, K, KP)
             u1 = x[:, :, None] * x[:, None, :] + cx
@@ -423,6 +442,7 @@ class PCAPlan:
         if node is self.W:
             return self._block(L.off_W, self.D, K, KP), self._block(L.off_CW, K, K, KP)
         if node is self.X:
+            self.finish()
             return (self.Xd[:, :self.N].cpu().numpy().T.copy(),
                     self._block(L.off_CX, K, K, KP))
         raise NotImplementedError
@@ -435,3 +455,6 @@ class PCAPlan:
 
     def last_pass_ms(self):
         return self.kernels.last_pass_ms()
+
+    def pass_times_ms(self, cap=64):
+        return self.kernels.pass_times_ms(cap)

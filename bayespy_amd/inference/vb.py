@@ -110,18 +110,26 @@ class VB:
         if tqdm is not None:
             tqdm = tqdm(total=repeat)
         i = 0
-        while repeat is None or i < repeat:
-            t = time.time()
-            for node in nodes:
-                X = self[node]
-                if hasattr(X, 'update') and callable(X.update):
-                    X.update()
-            cputime = time.time() - t
-            i += 1
-            if tqdm is not None:
-                tqdm.update()
-            if self._end_iteration_step(None, cputime, tol=tol, verbose=verbose):
-                return
+        try:
+            while repeat is None or i < repeat:
+                t = time.time()
+                for node in nodes:
+                    X = self[node]
+                    if hasattr(X, 'update') and callable(X.update):
+                        X.update()
+                cputime = time.time() - t
+                i += 1
+                if tqdm is not None:
+                    tqdm.update()
+                if self._end_iteration_step(None, cputime, tol=tol, verbose=verbose):
+                    return
+        finally:
+            # plans may keep plate-sized work in flight on their own streams across
+            # iterations; order the caller's stream after it before handing back control
+            for p in self.plans:
+                fin = getattr(p, 'finish', None)
+                if fin is not None:
+                    fin()
 
     def has_converged(self, tol=None):
         return self.converged

@@ -130,10 +130,20 @@ int32_t vmp_pca_gram(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
 /* X.update(), plate half, Gram form (default): for every local n  <x_n> = A y_n
  * is written to X ((K,N) row-major) -- read Y once, write <x> once, HBM-bound --
  * then S <- [G A^T ; A G A^T] from the (already global) Gram matrix: no
- * per-iteration collective.  fp64 MFMA (v_mfma_f64_16x16x4_f64). */
+ * per-iteration collective.  fp64 MFMA (v_mfma_f64_16x16x4_f64).
+ *
+ * Ordering: in this form no other update of the iteration reads X, so the plate pass is
+ * issued on the context's internal plate stream (from a private copy of A) and the call
+ * returns with S queued on the main stream; the replicated-node updates of the next
+ * iteration overlap the pass.  Passes are ordered among themselves.  Anything that reads
+ * X outside this library on the context's stream must call vmp_pca_xjoin first
+ * (vmp_ctx_sync, vmp_pca_pass and vmp_pca_stats_from_x join implicitly). */
 int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
                       int32_t D, int32_t K, double *X, int64_t ldx,
                       double *state, void *workspace);
+
+/* Make the context's stream wait for the outstanding vmp_pca_xpass (no host block). */
+int32_t vmp_pca_xjoin(vmp_ctx *ctx);
 
 /* X.update(), plate half, streaming-statistics form: for every local n
  *   <x_n> = A y_n  (written to X, (K,N) row-major),
@@ -303,10 +313,16 @@ int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, i
                                double *C, double *x, double *ldet, int32_t *info);
 
 /* Elapsed milliseconds of the most recent vmp_pca_xpass / vmp_pca_pass on this context,
- * measured with HIP events on the context's stream (blocks until done);
+ * measured with HIP events on the stream the pass kernel was launched on (blocks until done);
  * enabled by vmp_ctx_set_timing(ctx, 1). */
 int32_t vmp_ctx_set_timing(vmp_ctx *ctx, int32_t enabled);
 int32_t vmp_pca_last_pass_ms(vmp_ctx *ctx, double *ms_pass, double *ms_reduce);
+
+/* Durations of the (up to 64, up to `cap`) most recent timed plate passes (PCA or GMM) in issue
+ * order, then forget them: one HIP event triple per pass, so a measurement loop reads them
+ * after its timed region instead of blocking inside every iteration. */
+int32_t vmp_pass_times_ms(vmp_ctx *ctx, double *ms_pass, double *ms_reduce, int32_t cap,
+                          int32_t *count);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,9 @@ class CPURuntimeKernels:
         v['S'][:D, :K] = syx
         v['S'][v['DP']:v['DP'] + K, :K] = A @ syx
 
+    def xjoin(self):
+        self.calls.append('xjoin')
+
     def _resid(self, v, D, K, n_total):
         return (v['Syy'][0] - 2 * np.sum(v['W'][:, :K] * v['S'][:D, :K])
                 + np.sum(v['Sww'][:K, :K] * self._sxx(v, K, n_total)))

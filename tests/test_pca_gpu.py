@@ -132,6 +132,8 @@ def test_pass_kernel_direct_cabi():
         state[L.off_S:L.off_S + L.len_S].zero_()
         rt.check(lib.vmp_pca_xpass(rt.ctx, ptr(Yd), ld, N, D, K, ptr(Xd), ld, ptr(state),
                                    ptr(ws)))
+        # the pass is in flight on the library's plate stream: order this stream after it
+        rt.check(lib.vmp_pca_xjoin(rt.ctx))
         x3 = Xd[:, :N].cpu().numpy()
         assert not Xd[:, N:].any()
         S3 = state[L.off_S:L.off_S + L.len_S].cpu().numpy().reshape(DP + KP, KP)

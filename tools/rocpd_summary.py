@@ -63,10 +63,30 @@ def pmc(dbs, only='pass_kernel'):  # pca_xpass / pca_pass / gmm_pass
                     c, sum(v) / len(v), len(v), min(v), max(v)))
 
 
+def timeline(db, count):
+    """Last `count` kernel dispatches: start offset, duration, gap to the previous end (us)."""
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info('kernels')").fetchall()]
+    extra = [c for c in ('stream_id', 'queue_id') if c in cols]
+    q = 'select name, start, end%s from kernels order by start' % ''.join(', ' + c for c in extra)
+    rows = con.execute(q).fetchall()[-count:]
+    t0 = rows[0][1]
+    prev_end = None
+    print('%-44s %12s %10s %10s  %s' % ('kernel', 'start_us', 'dur_us', 'gap_us', ' '.join(extra)))
+    for r in rows:
+        gap = (r[1] - prev_end) / 1e3 if prev_end is not None else 0.0
+        print('%-44s %12.1f %10.1f %10.1f  %s' % (short(r[0])[:44], (r[1] - t0) / 1e3,
+                                                 (r[2] - r[1]) / 1e3, gap,
+                                                 ' '.join(str(x) for x in r[3:])))
+        prev_end = r[2] if prev_end is None else max(prev_end, r[2])
+
+
 if __name__ == '__main__':
     args = sys.argv[1:]
     if args and args[0] == '--pmc':
         pmc(args[1:])
+    elif args and args[0] == '--timeline':
+        timeline(args[2], int(args[1]))
     else:
         for a in args:
             stats(a)
