@@ -117,6 +117,8 @@ SIGNATURES = {
                                        c_vp, c_vp, c_vp, c_vp]),
     'vmp_ctx_set_timing': (c_i32, [c_vp, c_i32]),
     'vmp_pca_xjoin': (c_i32, [c_vp]),
+    'vmp_pca_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
+                                  c_i32, P(c_i32), c_vp]),
     'vmp_pass_times_ms': (c_i32, [c_vp, P(c_f64), P(c_f64), c_i32, P(c_i32)]),
     'vmp_pca_last_pass_ms': (c_i32, [c_vp, P(c_f64), P(c_f64)]),
 }

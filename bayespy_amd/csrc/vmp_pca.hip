@@ -430,165 +430,10 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
 }
 
 // ---------------------------------------------------------------------------
-// Small replicated-node kernels.  Single-workgroup kernels use 1024 threads and
-// keep every K x K object in LDS.
+// Set-up and Gram-form statistics kernels (the replicated-node updates live in
+// vmp_pca_small.hip).
 // ---------------------------------------------------------------------------
-constexpr int NTS = 1024;
 constexpr int LD = MAX_KP + 1;
-constexpr int EPT = MAX_KP * MAX_KP / NTS;   // K*K elements per thread (4)
-constexpr int RB = 64;                       // row block of the D x K products
-
-// Register-resident Gauss-Jordan inverse by ONE wavefront (KP = 16 or 32): lane l owns
-// CPL consecutive columns of row l / LPR; the pivot row travels through a KP-double LDS
-// buffer, the pivot-column element through one cross-lane shuffle; no workgroup barrier.
-// Rows / columns >= n are treated as identity (SPD-preserving padding).
-template <int KP>
-__device__ __forceinline__ void wave_gj_inverse(double *M, int n, double *rowbuf, double *logdet, int *bad)
-{
-    constexpr int LPR = 64 / KP;
-    constexpr int CPL = KP / LPR;
-    const int l = threadIdx.x & 63;
-    const int i = l / LPR, h = l % LPR;
-    double m[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int j = h * CPL + c;
-        m[c] = (i < n && j < n) ? M[i * LD + j] : ((i == j) ? 1.0 : 0.0);
-    }
-    double ld = 0.0, prod = 1.0;
-    int isbad = 0;
-#pragma unroll
-    for (int p = 0; p < KP; ++p) {
-        if (i == p) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) rowbuf[h * CPL + c] = m[c];
-        }
-        const double ci = __shfl(m[p % CPL], (l & ~(LPR - 1)) | (p / CPL), 64);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const double piv = rowbuf[p];
-        if (!(piv > 0.0)) isbad = 1;
-        logdet_accumulate(piv, prod, ld);
-        const double d = fast_recip(piv);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const double rj = rowbuf[h * CPL + c];
-            const bool jp = (h == p / CPL) && (c == p % CPL);
-            double v;
-            if (i == p) v = jp ? d : rj * d;
-            else if (jp) v = -ci * d;
-            else v = m[c] - ci * rj * d;
-            m[c] = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int j = h * CPL + c;
-        if (i < n && j < n) M[i * LD + j] = m[c];
-    }
-    if (l == 0) {
-        *logdet = logdet_finish(prod, ld);
-        if (isbad) *bad = 1;
-    }
-}
-
-// In-place inverse of the SPD n x n matrix M (LDS, row-major, ld LD) by pivot-free
-// Gauss-Jordan sweeps (stable for SPD input).  Replaces the per-matrix SciPy calls
-// chol / chol_inv / chol_logdet (utils/linalg.py:31-63, :174-223).
-// *logdet = log|M_in| ; *bad set when a pivot is not positive.  KP <= 32: one wavefront,
-// registers (pca_spd_kernel below); KP = 64: all n^2 elements updated in parallel per
-// pivot through LDS by the whole workgroup.
-__device__ __forceinline__ void spd_inverse_gj(double *M, int n, double *logdet, int *bad)
-{
-    const int tid = threadIdx.x;
-    double ld = 0.0, prod = 1.0;
-    for (int p = 0; p < n; ++p) {
-        __syncthreads();
-        const double piv = M[p * LD + p];
-        double ci[EPT], rj[EPT], me[EPT];
-#pragma unroll
-        for (int m = 0; m < EPT; ++m) {
-            const int e = tid + m * NTS;
-            if (e < n * n) {
-                const int i = e / n, j = e - i * n;
-                ci[m] = M[i * LD + p];
-                rj[m] = M[p * LD + j];
-                me[m] = M[i * LD + j];
-            }
-        }
-        if (tid == 0) {
-            if (!(piv > 0.0)) *bad = 1;
-            logdet_accumulate(piv, prod, ld);
-        }
-        const double d = fast_recip(piv);
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < EPT; ++m) {
-            const int e = tid + m * NTS;
-            if (e < n * n) {
-                const int i = e / n, j = e - i * n;
-                double v;
-                if (i == p) v = (j == p) ? d : rj[m] * d;
-                else if (j == p) v = -ci[m] * d;
-                else v = me[m] - ci[m] * rj[m] * d;
-                M[i * LD + j] = v;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) *logdet = logdet_finish(prod, ld);
-    __syncthreads();
-}
-
-// <x x^T> total statistic: n_total * Cov_X + sum_n <x><x>^T, symmetrised.
-__device__ inline double sxx_total(const double *st, const vmp_pca_layout &L, double n_total,
-                                   int i, int j)
-{
-    const double *S = st + L.off_S;
-    const double m = 0.5 * (S[(L.DP + i) * L.KP + j] + S[(L.DP + j) * L.KP + i]);
-    return n_total * st[L.off_CX + i * L.KP + j] + m;
-}
-
-// Lambda_W (which = 0) or Lambda_X (which = 1) -> inverse + log-determinant, by one
-// wavefront with the matrix in registers.  K <= 32.
-template <int KP>
-__global__ void __launch_bounds__(64)
-pca_spd_kernel(vmp_pca_layout L, int K, int which, double n_total, double x_prec, double *st)
-{
-    __shared__ double M[32 * LD];
-    __shared__ double rowbuf[32];
-    __shared__ double logdet;
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    const int KPs = (int)L.KP;
-    if (tid == 0) bad = 0;
-    const double tau = st[L.off_tau + 2];
-    for (int e = tid; e < K * K; e += 64) {
-        const int i = e / K, j = e - i * K;
-        double v;
-        if (which == 0) {
-            // gaussian.py:656-670 (prior phi) + dot.py:581 (message E4)
-            v = tau * sxx_total(st, L, n_total, i, j);
-            if (i == j) v += st[L.off_alpha + 2 * KPs + i];
-        } else {
-            v = tau * 0.5 * (st[L.off_Sww + i * KPs + j] + st[L.off_Sww + j * KPs + i]);
-            if (i == j) v += x_prec;
-        }
-        M[i * LD + j] = v;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_gj_inverse<KP>(M, K, rowbuf, &logdet, &bad);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int64_t off = which == 0 ? L.off_CW : L.off_CX;
-    for (int e = tid; e < K * K; e += 64) {
-        const int i = e / K, j = e - i * K;
-        st[off + i * KPs + j] = M[i * LD + j];
-    }
-    if (tid == 0) {
-        st[L.off_scal + which] = logdet;
-        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
-    }
-}
 
 __global__ void __launch_bounds__(NT)
 pca_init_state_kernel(vmp_pca_layout L, int K, double a0t, double b0t, double a0a, double b0a,
@@ -606,146 +451,6 @@ pca_init_state_kernel(vmp_pca_layout L, int K, double a0t, double b0t, double a0
         st[L.off_alpha + 1 * L.KP + k] = b0a;
         st[L.off_alpha + 2 * L.KP + k] = a0a / b0a;
         st[L.off_alpha + 3 * L.KP + k] = vmp_digamma(a0a) - log(b0a);
-    }
-}
-
-// W.update(): Lambda_W = diag<alpha> + <tau> Sxx ; Cov_W ; <W> = <tau> Syx Cov_W ;
-// Sww = D Cov_W + W^T W.
-__global__ void __launch_bounds__(NTS)
-pca_update_w_kernel(vmp_pca_layout L, int D, int K, double n_total, double *st)
-{
-    __shared__ double M[MAX_KP * LD];
-    __shared__ double Sb[RB * LD];     // block of Syx rows
-    __shared__ double Wb[RB * LD];     // block of W rows
-    __shared__ double logdet;
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    const int KP = (int)L.KP;
-    if (tid == 0) bad = 0;
-    const double tau = st[L.off_tau + 2];
-    if (KP <= 32) {
-        // Cov_W and log|Lambda_W| were produced by pca_spd_kernel (one wavefront, registers)
-        for (int e = tid; e < K * K; e += NTS) {
-            const int i = e / K, j = e - i * K;
-            M[i * LD + j] = st[L.off_CW + i * KP + j];
-        }
-        if (tid == 0) logdet = st[L.off_scal + 0];
-        __syncthreads();
-    } else {
-        // gaussian.py:656-670 (prior phi) + dot.py:581 (message E4)
-        for (int e = tid; e < K * K; e += NTS) {
-            const int i = e / K, j = e - i * K;
-            double v = tau * sxx_total(st, L, n_total, i, j);
-            if (i == j) v += st[L.off_alpha + 2 * KP + i];
-            M[i * LD + j] = v;
-        }
-        spd_inverse_gj(M, K, &logdet, &bad);
-        for (int e = tid; e < K * K; e += NTS) {
-            const int i = e / K, j = e - i * K;
-            st[L.off_CW + i * KP + j] = M[i * LD + j];
-        }
-    }
-    const double *Syx = st + L.off_S;
-    double *W = st + L.off_W;
-    double sw[EPT];
-#pragma unroll
-    for (int m = 0; m < EPT; ++m) sw[m] = 0.0;
-    for (int r0 = 0; r0 < D; r0 += RB) {
-        const int nr = (D - r0) < RB ? (D - r0) : RB;
-        __syncthreads();
-        for (int e = tid; e < nr * K; e += NTS) {
-            const int r = e / K, k = e - r * K;
-            Sb[r * LD + k] = Syx[(r0 + r) * KP + k];
-        }
-        __syncthreads();
-        // <w_d> = Cov_W phi0_d,  phi0_d = <tau> Syx[d]        (gaussian.py:694)
-        for (int e = tid; e < nr * K; e += NTS) {
-            const int r = e / K, k = e - r * K;
-            double s = 0.0;
-            for (int j = 0; j < K; ++j) s += Sb[r * LD + j] * M[j * LD + k];
-            s *= tau;
-            Wb[r * LD + k] = s;
-            W[(r0 + r) * KP + k] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < EPT; ++m) {
-            const int e = tid + m * NTS;
-            if (e < K * K) {
-                const int i = e / K, j = e - i * K;
-                double s = 0.0;
-                for (int r = 0; r < nr; ++r) s += Wb[r * LD + i] * Wb[r * LD + j];
-                sw[m] += s;
-            }
-        }
-    }
-    // Sww = sum_d <w_d w_d^T> = D Cov_W + W^T W                (gaussian.py:695)
-#pragma unroll
-    for (int m = 0; m < EPT; ++m) {
-        const int e = tid + m * NTS;
-        if (e < K * K) {
-            const int i = e / K, j = e - i * K;
-            st[L.off_Sww + i * KP + j] = (double)D * M[i * LD + j] + sw[m];
-        }
-    }
-    if (tid == 0) {
-        st[L.off_scal + 0] = logdet;
-        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
-    }
-}
-
-// X.update(), replicated half: Lambda_X = x_prec I + <tau> Sww ; Cov_X ; A = <tau> Cov_X W^T.
-__global__ void __launch_bounds__(NTS)
-pca_prepare_x_kernel(vmp_pca_layout L, int D, int K, double x_prec, double *st)
-{
-    __shared__ double M[MAX_KP * LD];
-    __shared__ double Wb[RB * LD];
-    __shared__ double logdet;
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    const int KP = (int)L.KP, DP = (int)L.DP;
-    if (tid == 0) bad = 0;
-    const double tau = st[L.off_tau + 2];
-    if (KP <= 32) {
-        for (int e = tid; e < K * K; e += NTS) {
-            const int i = e / K, j = e - i * K;
-            M[i * LD + j] = st[L.off_CX + i * KP + j];
-        }
-        if (tid == 0) logdet = st[L.off_scal + 1];
-        __syncthreads();
-    } else {
-        for (int e = tid; e < K * K; e += NTS) {
-            const int i = e / K, j = e - i * K;
-            double v = tau * 0.5 * (st[L.off_Sww + i * KP + j] + st[L.off_Sww + j * KP + i]);
-            if (i == j) v += x_prec;
-            M[i * LD + j] = v;
-        }
-        spd_inverse_gj(M, K, &logdet, &bad);
-        for (int e = tid; e < K * K; e += NTS) {
-            const int i = e / K, j = e - i * K;
-            st[L.off_CX + i * KP + j] = M[i * LD + j];
-        }
-    }
-    const double *W = st + L.off_W;
-    for (int r0 = 0; r0 < D; r0 += RB) {
-        const int nr = (D - r0) < RB ? (D - r0) : RB;
-        __syncthreads();
-        for (int e = tid; e < nr * K; e += NTS) {
-            const int r = e / K, k = e - r * K;
-            Wb[r * LD + k] = W[(r0 + r) * KP + k];
-        }
-        __syncthreads();
-        // A[k][d] = <tau> sum_j Cov_X[k][j] W[d][j]
-        for (int e = tid; e < nr * K; e += NTS) {
-            const int k = e / nr, r = e - k * nr;
-            double s = 0.0;
-            for (int j = 0; j < K; ++j) s += M[k * LD + j] * Wb[r * LD + j];
-            st[L.off_A + (int64_t)k * DP + r0 + r] = tau * s;
-        }
-    }
-    if (tid == 0) {
-        st[L.off_scal + 1] = logdet;
-        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
     }
 }
 
@@ -802,109 +507,6 @@ pca_gram_copy_kernel(const double *__restrict__ Stmp, int KPx, int D, int Kx, in
     if (e >= D * Kx) return;
     const int i = e / Kx, j = e - i * Kx;
     G[(int64_t)i * DP + j0 + j] = Stmp[(int64_t)i * KPx + j];
-}
-
-// sum_dn <(y_dn - f_dn)^2> = Syy - 2 sum(W o Syx) + sum(Sww o Sxx)
-// (dot.py:355 E1 and dot.py:403 E2 collapsed to traces).
-template <int NTH>
-__device__ double pca_residual(const double *st, const vmp_pca_layout &L, int D, int K,
-                               double n_total, double *red)
-{
-    const int tid = threadIdx.x;
-    const int KP = (int)L.KP;
-    double t1 = 0.0, t2 = 0.0;
-    // padded entries of W are zero, so the D x KP blocks can be walked linearly
-    for (int e = tid; e < D * KP; e += NTH) t1 += st[L.off_W + e] * st[L.off_S + e];
-    for (int e = tid; e < K * K; e += NTH) {
-        const int i = e / K, j = e - i * K;
-        t2 += st[L.off_Sww + i * KP + j] * sxx_total(st, L, n_total, i, j);
-    }
-    t1 = block_sum<NTH>(t1, red);
-    t2 = block_sum<NTH>(t2, red);
-    return st[L.off_Syy] - 2.0 * t1 + t2;
-}
-
-__global__ void __launch_bounds__(NTS)
-pca_update_tau_kernel(vmp_pca_layout L, int D, int K, double n_total, double a0, double b0,
-                      double *st)
-{
-    __shared__ double red[NTS / 64];
-    const double resid = pca_residual<NTS>(st, L, D, K, n_total, red);
-    if (threadIdx.x == 0) {
-        // gamma.py:116-122 phi = [-b, a] with the message gaussian.py:2363-2369
-        const double a = a0 + 0.5 * (double)D * n_total;
-        const double b = b0 + 0.5 * resid;
-        st[L.off_tau + 0] = a;
-        st[L.off_tau + 1] = b;
-        st[L.off_tau + 2] = a / b;                       // gamma.py:144
-        st[L.off_tau + 3] = vmp_digamma(a) - log(b);     // gamma.py:145
-        st[L.off_scal + 2] = resid;
-        if (!(b > 0.0)) st[L.off_scal + 3] = (double)VMP_ERR_FLOATING;
-    }
-}
-
-__global__ void __launch_bounds__(NT)
-pca_update_alpha_kernel(vmp_pca_layout L, int D, int K, double a0, double b0, double *st)
-{
-    const int KP = (int)L.KP;
-    for (int k = threadIdx.x; k < K; k += NT) {
-        const double a = a0 + 0.5 * (double)D;
-        const double b = b0 + 0.5 * st[L.off_Sww + k * KP + k];
-        st[L.off_alpha + 0 * KP + k] = a;
-        st[L.off_alpha + 1 * KP + k] = b;
-        st[L.off_alpha + 2 * KP + k] = a / b;
-        st[L.off_alpha + 3 * KP + k] = vmp_digamma(a) - log(b);
-    }
-}
-
-// E[log p - log q] of a Gamma(a,b) node with prior Gamma(a0,b0)
-// (expfamily.py:400-480 with gamma.py:147,160).
-__device__ inline double gamma_elbo(double a0, double b0, double a, double b, double x,
-                                    double logx)
-{
-    const double g_p = a0 * log(b0) - vmp_lgamma(a0);
-    const double g_q = a * log(b) - vmp_lgamma(a);
-    return g_p - g_q + (b - b0) * x + (a0 - a) * logx;
-}
-
-constexpr int NTL = 512;
-__global__ void __launch_bounds__(NTL)
-pca_lower_bound_kernel(vmp_pca_layout L, int D, int K, double n_total, double x_prec,
-                       double a0t, double b0t, double a0a, double b0a, double *st)
-{
-    __shared__ double red[NTL / 64];
-    const int tid = threadIdx.x;
-    const int KP = (int)L.KP;
-    const double resid = pca_residual<NTL>(st, L, D, K, n_total, red);
-    double trx = 0.0, sla = 0.0, saw = 0.0, lal = 0.0;
-    for (int k = tid; k < K; k += NTL) {
-        const double a = st[L.off_alpha + 0 * KP + k], b = st[L.off_alpha + 1 * KP + k];
-        const double al = st[L.off_alpha + 2 * KP + k], la = st[L.off_alpha + 3 * KP + k];
-        trx += sxx_total(st, L, n_total, k, k);
-        sla += la;
-        saw += al * st[L.off_Sww + k * KP + k];
-        lal += gamma_elbo(a0a, b0a, a, b, al, la);
-    }
-    trx = block_sum<NTL>(trx, red);
-    sla = block_sum<NTL>(sla, red);
-    saw = block_sum<NTL>(saw, red);
-    lal = block_sum<NTL>(lal, red);
-    if (tid == 0) {
-        const double tau = st[L.off_tau + 2], logtau = st[L.off_tau + 3];
-        const double Dd = (double)D, Kd = (double)K;
-        const double LY = Dd * n_total * (-0.5 * log(2.0 * M_PI) + 0.5 * logtau) - 0.5 * tau * resid;
-        const double LX = -0.5 * x_prec * trx
-                          + n_total * (0.5 * Kd * log(x_prec) - 0.5 * st[L.off_scal + 1] + 0.5 * Kd);
-        const double LW = 0.5 * Dd * sla - 0.5 * saw + Dd * (-0.5 * st[L.off_scal + 0] + 0.5 * Kd);
-        const double Lt = gamma_elbo(a0t, b0t, st[L.off_tau + 0], st[L.off_tau + 1], tau, logtau);
-        st[L.off_L + 0] = LY;
-        st[L.off_L + 1] = LX;
-        st[L.off_L + 2] = LW;
-        st[L.off_L + 3] = Lt;
-        st[L.off_L + 4] = lal;
-        st[L.off_L + 5] = LY + LX + LW + Lt + lal;
-        st[L.off_scal + 2] = resid;
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1305,76 +907,6 @@ int32_t vmp_pca_xjoin(vmp_ctx *ctx)
         VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_xdone, 0));
         ctx->x_pending = 0;
     }
-    return VMP_OK;
-}
-
-#define VMP_SMALL_PROLOGUE()                                               \
-    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");      \
-    vmp_pca_layout L;                                                      \
-    {                                                                      \
-        int32_t rc__ = vmp_pca_get_layout(D, K, &L);                       \
-        VMP_REQUIRE(ctx, rc__ == VMP_OK, rc__, "unsupported dims D=%d K=%d", D, K); \
-    }
-
-int32_t vmp_pca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double *state)
-{
-    VMP_SMALL_PROLOGUE();
-    if (L.KP == 16)
-        hipLaunchKernelGGL(pca_spd_kernel<16>, dim3(1), dim3(64), 0, ctx->stream, L, K, 0,
-                           (double)n_total, 1.0, state);
-    else if (L.KP == 32)
-        hipLaunchKernelGGL(pca_spd_kernel<32>, dim3(1), dim3(64), 0, ctx->stream, L, K, 0,
-                           (double)n_total, 1.0, state);
-    hipLaunchKernelGGL(pca_update_w_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K,
-                       (double)n_total, state);
-    VMP_HIP_CHECK(ctx, hipGetLastError());
-    return VMP_OK;
-}
-
-int32_t vmp_pca_prepare_x(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, double *state)
-{
-    VMP_SMALL_PROLOGUE();
-    VMP_REQUIRE(ctx, x_prec > 0, VMP_ERR_INVALID, "x_prec must be positive");
-    if (L.KP == 16)
-        hipLaunchKernelGGL(pca_spd_kernel<16>, dim3(1), dim3(64), 0, ctx->stream, L, K, 1, 0.0,
-                           x_prec, state);
-    else if (L.KP == 32)
-        hipLaunchKernelGGL(pca_spd_kernel<32>, dim3(1), dim3(64), 0, ctx->stream, L, K, 1, 0.0,
-                           x_prec, state);
-    hipLaunchKernelGGL(pca_prepare_x_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K, x_prec,
-                       state);
-    VMP_HIP_CHECK(ctx, hipGetLastError());
-    return VMP_OK;
-}
-
-int32_t vmp_pca_update_tau(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double a0,
-                           double b0, double *state)
-{
-    VMP_SMALL_PROLOGUE();
-    hipLaunchKernelGGL(pca_update_tau_kernel, dim3(1), dim3(NTS), 0, ctx->stream, L, D, K,
-                       (double)n_total, a0, b0, state);
-    VMP_HIP_CHECK(ctx, hipGetLastError());
-    return VMP_OK;
-}
-
-int32_t vmp_pca_update_alpha(vmp_ctx *ctx, int32_t D, int32_t K, double a0, double b0,
-                             double *state)
-{
-    VMP_SMALL_PROLOGUE();
-    hipLaunchKernelGGL(pca_update_alpha_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, D, K, a0, b0,
-                       state);
-    VMP_HIP_CHECK(ctx, hipGetLastError());
-    return VMP_OK;
-}
-
-int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
-                            double a0_tau, double b0_tau, double a0_alpha, double b0_alpha,
-                            double *state)
-{
-    VMP_SMALL_PROLOGUE();
-    hipLaunchKernelGGL(pca_lower_bound_kernel, dim3(1), dim3(NTL), 0, ctx->stream, L, D, K,
-                       (double)n_total, x_prec, a0_tau, b0_tau, a0_alpha, b0_alpha, state);
-    VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
 

@@ -42,6 +42,10 @@ from ...nodes.gaussian import GaussianARD
 from ...nodes.dot import SumMultiply
 
 
+# operation codes of vmp_pca_small_ops (include/vmp_hip.h, enum vmp_pca_op)
+OP_W, OP_XPREP, OP_TAU, OP_ALPHA, OP_ELBO = 1, 2, 3, 4, 5
+
+
 class HIPKernels:
     """The C-ABI entry points used by this plan, bound to a runtime."""
 
@@ -73,11 +77,12 @@ class HIPKernels:
         self.rt.check(self.lib.vmp_pca_stats_from_x(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
                                                     ptr(state), ptr(ws)))
 
-    def update_w(self, D, K, n_total, state):
-        self.rt.check(self.lib.vmp_pca_update_w(self.ctx, D, K, n_total, ptr(state)))
-
-    def prepare_x(self, D, K, x_prec, state):
-        self.rt.check(self.lib.vmp_pca_prepare_x(self.ctx, D, K, x_prec, ptr(state)))
+    def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state):
+        """Replicated-node operations (OP_* codes) in order, fused into as few
+        single-workgroup launches as the library knows sequences for."""
+        arr = (ctypes.c_int32 * len(ops))(*ops)
+        self.rt.check(self.lib.vmp_pca_small_ops(self.ctx, D, K, n_total, x_prec, a0t, b0t, a0a,
+                                                 b0a, len(ops), arr, ptr(state)))
 
     def pass_(self, Y, ldy, N, D, K, X, ldx, state, ws):
         self.rt.check(self.lib.vmp_pca_pass(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
@@ -92,16 +97,6 @@ class HIPKernels:
 
     def xjoin(self):
         self.rt.check(self.lib.vmp_pca_xjoin(self.ctx))
-
-    def update_tau(self, D, K, n_total, a0, b0, state):
-        self.rt.check(self.lib.vmp_pca_update_tau(self.ctx, D, K, n_total, a0, b0, ptr(state)))
-
-    def update_alpha(self, D, K, a0, b0, state):
-        self.rt.check(self.lib.vmp_pca_update_alpha(self.ctx, D, K, a0, b0, ptr(state)))
-
-    def lower_bound(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, state):
-        self.rt.check(self.lib.vmp_pca_lower_bound(self.ctx, D, K, n_total, x_prec, a0t, b0t,
-                                                   a0a, b0a, ptr(state)))
 
     def set_timing(self, on):
         self.rt.check(self.lib.vmp_ctx_set_timing(self.ctx, 1 if on else 0))
@@ -213,6 +208,7 @@ class PCAPlan:
         self._version = 0
         self._L_version = -1
         self._L = None
+        self._pending = []          # queued replicated-node operations (see _flush)
         self.timing = False
         for n in roles.values():
             n._plan = self
@@ -345,9 +341,10 @@ class PCAPlan:
         rt.sync_stream()
         D, N, K = self.D, self.N, self.K
         if node is self.W:
-            k.update_w(D, K, self.n_total, self.state)
+            self._pending.append(OP_W)
         elif node is self.X:
-            k.prepare_x(D, K, self.x_prec, self.state)
+            self._pending.append(OP_XPREP)
+            self._flush()
             if self.stats == 'gram':
                 # messages to W from the global Gram matrix: nothing to exchange
                 k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
@@ -356,26 +353,40 @@ class PCAPlan:
                 # child -> parent message sum over the sharded plate (node.py:650, dot.py:581)
                 rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
         elif node is self.tau:
-            k.update_tau(D, K, self.n_total, self.a0t, self.b0t, self.state)
+            self._pending.append(OP_TAU)
         elif node is self.alpha:
-            k.update_alpha(D, K, self.a0a, self.b0a, self.state)
+            self._pending.append(OP_ALPHA)
         else:
             return
         self._version += 1
 
+    def _flush(self):
+        """Issue the queued replicated-node updates.  They are queued rather than launched
+        one by one so that the sequences of a VB iteration -- (W, X) and (tau, alpha, lower
+        bound) -- become single launches; results are identical, only launch count differs."""
+        if not self._pending:
+            return
+        ops, self._pending = self._pending, []
+        self.rt.sync_stream()
+        for i in range(0, len(ops), 8):
+            self.kernels.small_ops(self.D, self.K, self.n_total, self.x_prec, self.a0t, self.b0t,
+                                   self.a0a, self.b0a, ops[i:i + 8], self.state)
+
     def finish(self):
         """Order the caller's stream after the outstanding latent pass (Gram form runs it on the
         library's plate stream so that it overlaps the next iteration's replicated updates)."""
+        if self._ready:
+            self._flush()
+        self._pending = []
         if getattr(self, 'Xd', None) is not None and self.stats == 'gram':
             self.kernels.xjoin()
 
     def _lower_bound_terms(self):
         self._materialize()
         if self._L_version != self._version:
-            rt, k, L = self.rt, self.kernels, self.layout
-            rt.sync_stream()
-            k.lower_bound(self.D, self.K, self.n_total, self.x_prec, self.a0t, self.b0t,
-                          self.a0a, self.b0a, self.state)
+            L = self.layout
+            self._pending.append(OP_ELBO)
+            self._flush()
             host = self.state[L.off_scal:L.off_L + 8].cpu().numpy()
             status = int(host[3])
             if status != 0:
@@ -403,6 +414,7 @@ class PCAPlan:
 
     def get_moments(self, node):
         self._materialize()
+        self._flush()
         L = self.layout
         D, N, K, KP = self.D, self.N, self.K, int(self.layout.KP)
         if node is self.W:
@@ -431,6 +443,7 @@ class PCAPlan:
     def get_parameters(self, node):
         """(a, b) of the Gamma nodes; (mean, covariance) of the Gaussian nodes."""
         self._materialize()
+        self._flush()
         L = self.layout
         K, KP = self.K, int(self.layout.KP)
         if node is self.tau:

@@ -109,6 +109,23 @@ int32_t vmp_pca_stats_from_x(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t
                              int32_t D, int32_t K, const double *X, int64_t ldx,
                              double *state, void *workspace);
 
+/* The replicated-node updates below (W, the replicated half of X, tau, alpha, the lower
+ * bound) are latency-bound K x K work.  vmp_pca_small_ops runs a list of them, in the
+ * order given (the order VB.update visits the nodes, vmp.py:154-160), inside ONE
+ * single-workgroup launch; the five named entry points that follow are the one-operation
+ * forms of the same kernel. */
+enum vmp_pca_op {
+    VMP_PCA_OP_W = 1,      /* vmp_pca_update_w     */
+    VMP_PCA_OP_XPREP = 2,  /* vmp_pca_prepare_x    */
+    VMP_PCA_OP_TAU = 3,    /* vmp_pca_update_tau   */
+    VMP_PCA_OP_ALPHA = 4,  /* vmp_pca_update_alpha */
+    VMP_PCA_OP_ELBO = 5    /* vmp_pca_lower_bound  */
+};
+#define VMP_PCA_MAX_OPS 8
+int32_t vmp_pca_small_ops(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
+                          double a0_tau, double b0_tau, double a0_alpha, double b0_alpha,
+                          int32_t nops, const int32_t *ops, double *state);
+
 /* W.update(): GaussianARDDistribution.compute_phi_from_parents + messages E3/E4
  * + compute_moments_and_cgf (gaussian.py:649-706, dot.py:581).  Uses S (already
  * summed over ranks), <tau>, <alpha>; writes W, CW, Sww, log|Lambda_W|. */

@@ -130,6 +130,22 @@ class CPURuntimeKernels:
     def xjoin(self):
         self.calls.append('xjoin')
 
+    def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state):
+        """vmp_pca_small_ops: the operations in order (launch fusion is not modelled)."""
+        for op in ops:
+            if op == 1:
+                self.update_w(D, K, n_total, state)
+            elif op == 2:
+                self.prepare_x(D, K, x_prec, state)
+            elif op == 3:
+                self.update_tau(D, K, n_total, a0t, b0t, state)
+            elif op == 4:
+                self.update_alpha(D, K, a0a, b0a, state)
+            elif op == 5:
+                self.lower_bound(D, K, n_total, x_prec, a0t, b0t, a0a, b0a, state)
+            else:
+                raise ValueError(op)
+
     def _resid(self, v, D, K, n_total):
         return (v['Syy'][0] - 2 * np.sum(v['W'][:, :K] * v['S'][:D, :K])
                 + np.sum(v['Sww'][:K, :K] * self._sxx(v, K, n_total)))
