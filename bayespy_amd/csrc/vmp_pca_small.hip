@@ -14,6 +14,8 @@
 // expfamily.py:400-480 (lower bound), utils/linalg.py:31-223 (chol, chol_inv, chol_logdet).
 #include "vmp_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 
@@ -50,6 +52,7 @@ __device__ void gj_inverse(double *M, int n, double *logdet, int *bad)
     const int tid = threadIdx.x;
     double ld = 0.0, prod = 1.0;
     int isbad = 0;
+#pragma unroll 1
     for (int p = 0; p < n; ++p) {
         __syncthreads();
         const double piv = M[p * LDM + p];
@@ -63,7 +66,12 @@ __device__ void gj_inverse(double *M, int n, double *logdet, int *bad)
             me[m] = M[i * LDM + j];
         }
         if (!(piv > 0.0)) isbad = 1;
-        logdet_accumulate(piv, prod, ld);
+        // running log-determinant: fold the pivot product only when it leaves a safe range
+        prod *= piv;
+        if (!(prod < 1e120 && prod > 1e-120)) {
+            ld += sf_log(prod);
+            prod = 1.0;
+        }
         const double d = fast_recip(piv);
         __syncthreads();
 #pragma unroll
@@ -79,7 +87,7 @@ __device__ void gj_inverse(double *M, int n, double *logdet, int *bad)
     }
     __syncthreads();
     if (tid == 0) {
-        *logdet = logdet_finish(prod, ld);
+        *logdet = ld + sf_log(prod);
         if (isbad) *bad = 1;
     }
     __syncthreads();
@@ -361,12 +369,351 @@ __global__ void __launch_bounds__(NTQ)
 pca_small_kernel(small_args a, double *st)
 {
     __shared__ small_lds<KP, NTQ> s;
+    __builtin_amdgcn_s_setprio(3);   // latency-critical: win issue arbitration on a shared CU
     if (threadIdx.x == 0) s.bad = 0;
     run_op<KP, NTQ, O0>(a, st, s);
     run_op<KP, NTQ, O1>(a, st, s);
     run_op<KP, NTQ, O2>(a, st, s);
     __syncthreads();
     if (threadIdx.x == 0 && s.bad) st[a.L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+}
+
+// ---------------------------------------------------------------------------
+// LDS-resident forms of the two sequences of a VB iteration, for K <= 32 and D <= 128.
+//
+// Beside the streaming grid every dependent global access of this workgroup queues behind
+// the pass kernel's outstanding loads on the same CU (~10 us per round trip, measured), so
+// the generic operations above -- a dozen round trips each -- take 100-200 us there.  These
+// kernels fetch their whole working set in one batch, compute from LDS, and store at the end.
+// ---------------------------------------------------------------------------
+constexpr int FAST_D = 128;
+constexpr int NTF = 256;
+
+// the state block is a few hundred KB: 32-bit element offsets keep the index arithmetic
+// of these kernels off the 64-bit VALU paths (registers)
+struct lay32 {
+    int DP, KP, off_S, off_Syy, off_tau, off_alpha, off_W, off_CW, off_Sww, off_CX, off_A,
+        off_scal, off_L;
+    __device__ explicit lay32(const vmp_pca_layout &l)
+        : DP((int)l.DP), KP((int)l.KP), off_S((int)l.off_S), off_Syy((int)l.off_Syy),
+          off_tau((int)l.off_tau), off_alpha((int)l.off_alpha), off_W((int)l.off_W),
+          off_CW((int)l.off_CW), off_Sww((int)l.off_Sww), off_CX((int)l.off_CX),
+          off_A((int)l.off_A), off_scal((int)l.off_scal), off_L((int)l.off_L) {}
+};
+
+// One wavefront, one 16 x 16 tile of C = A B from LDS operands with arbitrary strides
+// (v_mfma_f64_16x16x4_f64; A(m,k) = As[m*am + k*ak], B(k,n) = Bs[k*bk + n*bn], kc % 4 == 0).
+// Result layout: element (row = (lane>>4) + 4*reg, col = lane&15).
+__device__ __forceinline__ v4f64 wave_tile_mma(const double *As, int am, int ak, const double *Bs,
+                                               int bk, int bn, int kc)
+{
+    const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int q = 0; q < kc; q += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[l15 * am + (q + l4) * ak],
+                                                   Bs[(q + l4) * bk + l15 * bn], acc, 0, 0, 0);
+    return acc;
+}
+
+// (W.update(), X.update() replicated half)
+template <int KP>
+__global__ void __launch_bounds__(NTF)
+pca_head_fast_kernel(small_args a, double *st)
+{
+    constexpr int LDM = KP + 1, E = KP * KP / NTF, RB = 32;
+    __shared__ double M[KP * LDM];          // Lambda_W -> Cov_W -> Lambda_X -> Cov_X
+    __shared__ double T[KP * LDM];          // sum <x x^T> (shard sum) -> Sww
+    __shared__ double SW[FAST_D * LDM];     // Syx rows -> <W> rows, in place
+    __shared__ double alm[KP];
+    __shared__ double logdet;
+    __shared__ int bad;
+    const lay32 L(a.L);
+    const int tid = threadIdx.x, D = a.D, K = a.K;
+    const int DP = (int)L.DP;
+    const int Dc = (D + RB - 1) / RB * RB;
+    __builtin_amdgcn_s_setprio(3);   // latency-critical: win issue arbitration on a shared CU
+    if (tid == 0) bad = 0;
+    // ---- one batch of loads ------------------------------------------------------------
+    const double tau = st[L.off_tau + 2];
+    {
+        constexpr int NL = FAST_D * KP / NTF;
+        double cx[E], sx[E], v[NL];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            const int i = e / KP, j = e % KP;
+            const bool in = (i < K && j < K);
+            cx[m] = in ? st[L.off_CX + i * KP + j] : 0.0;
+            sx[m] = in ? st[L.off_S + (L.DP + i) * KP + j] : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < NL; ++m) {
+            const int e = tid + m * NTF;
+            const int r = e / KP, k = e % KP;
+            v[m] = (r < D && k < K) ? st[L.off_S + r * KP + k] : 0.0;
+        }
+        if (tid < KP) alm[tid] = tid < K ? st[L.off_alpha + 2 * KP + tid] : 0.0;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            M[(e / KP) * LDM + (e % KP)] = cx[m];
+            T[(e / KP) * LDM + (e % KP)] = sx[m];
+        }
+#pragma unroll
+        for (int m = 0; m < NL; ++m) {
+            const int e = tid + m * NTF;
+            SW[(e / KP) * LDM + (e % KP)] = v[m];
+        }
+    }
+    __syncthreads();
+    // ---- W: Lambda_W = diag<alpha> + <tau> Sxx  (gaussian.py:656-670, dot.py:581) -------
+    {
+        double lam[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            const int i = e / KP, j = e % KP;
+            double v = (i == j) ? 1.0 : 0.0;
+            if (i < K && j < K) {
+                v = tau * (a.n_total * M[i * LDM + j] + 0.5 * (T[i * LDM + j] + T[j * LDM + i]));
+                if (i == j) v += alm[i];
+            }
+            lam[m] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            M[(e / KP) * LDM + (e % KP)] = lam[m];
+        }
+    }
+    gj_inverse<KP, NTF>(M, K, &logdet, &bad);
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int e = tid + m * NTF;
+        const int i = e / KP, j = e % KP;
+        if (i < K && j < K) st[L.off_CW + i * KP + j] = M[i * LDM + j];
+    }
+    if (tid == 0) st[L.off_scal + 0] = logdet;
+    const int w = tid >> 6, l15 = tid & 15, l4 = (tid & 63) >> 4;
+    constexpr int KT = KP / 16;
+    // <w_d> = <tau> Cov_W Syx[d]  (gaussian.py:694): (Dc x KP) = (Dc x KP)(KP x KP) on the
+    // matrix cores, written back over the Syx rows once every tile has been computed
+    // (64 rows per round: rows are only rewritten after every tile that reads them is done)
+    for (int r0 = 0; r0 < Dc; r0 += 64) {
+        constexpr int MAXT = 4 * KT / 4;
+        const int nrt = (Dc - r0) < 64 ? (Dc - r0) / 16 : 4;
+        const int ntile = nrt * KT;
+        v4f64 acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int tile = w + 4 * t;
+            if (tile < ntile)
+                acc[t] = wave_tile_mma(SW + (r0 + (tile / KT) * 16) * LDM, LDM, 1,
+                                       M + (tile % KT) * 16, LDM, 1, KP);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int tile = w + 4 * t;
+            if (tile < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + (tile / KT) * 16 + l4 + 4 * r, k = (tile % KT) * 16 + l15;
+                    const double v = tau * acc[t][r];
+                    SW[row * LDM + k] = v;
+                    if (row < D && k < K) st[L.off_W + row * KP + k] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // Sww = D Cov_W + W^T W  (gaussian.py:695)
+    for (int tile = w; tile < KT * KT; tile += 4) {
+        const int ti = tile / KT, tj = tile % KT;
+        const v4f64 acc = wave_tile_mma(SW + ti * 16, 1, LDM, SW + tj * 16, LDM, 1, Dc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + l4 + 4 * r, j = tj * 16 + l15;
+            const double sww = (double)D * M[i * LDM + j] + acc[r];
+            T[i * LDM + j] = sww;
+            if (i < K && j < K) st[L.off_Sww + i * KP + j] = sww;
+        }
+    }
+    __syncthreads();
+    // ---- X, replicated half: Lambda_X = x_prec I + <tau> Sww ; A = <tau> Cov_X W^T --------
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int e = tid + m * NTF;
+        const int i = e / KP, j = e % KP;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < K && j < K) {
+            v = tau * 0.5 * (T[i * LDM + j] + T[j * LDM + i]);
+            if (i == j) v += a.x_prec;
+        }
+        M[i * LDM + j] = v;
+    }
+    gj_inverse<KP, NTF>(M, K, &logdet, &bad);
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int e = tid + m * NTF;
+        const int i = e / KP, j = e % KP;
+        if (i < K && j < K) st[L.off_CX + i * KP + j] = M[i * LDM + j];
+    }
+    // A = <tau> Cov_X W^T : (KP x Dc) = (KP x KP)(KP x Dc)
+    for (int tile = w; tile < KT * (Dc / 16); tile += 4) {
+        const int tk = tile % KT, td = tile / KT;
+        const v4f64 acc = wave_tile_mma(M + tk * 16 * LDM, LDM, 1, SW + td * 16 * LDM, 1, LDM, KP);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = tk * 16 + l4 + 4 * r, d = td * 16 + l15;
+            if (k < K && d < D) st[L.off_A + k * DP + d] = tau * acc[r];
+        }
+    }
+    if (tid == 0) {
+        st[L.off_scal + 1] = logdet;
+        if (bad) st[L.off_scal + 3] = (double)VMP_ERR_NOT_POSDEF;
+    }
+}
+
+// (tau.update(), alpha.update(), lower bound)
+template <int KP>
+__global__ void __launch_bounds__(NTF)
+pca_tail_fast_kernel(small_args a, double *st)
+{
+    constexpr int LDM = KP + 1, E = KP * KP / NTF;
+    __shared__ double Sw[KP * LDM];         // Sww
+    __shared__ double Cx[KP * LDM];         // Cov_X
+    __shared__ double Sx[KP * LDM];         // sum <x><x>^T (shard sum)
+    __shared__ double al[4 * KP];           // alpha: a, b, <alpha>, <log alpha>
+    __shared__ double sc[8];                // tau a, b, mean, logmean ; Syy ; log|LW| ; log|LX|
+    __shared__ double red[NTF / 64 + 1];
+    const lay32 L(a.L);
+    const int tid = threadIdx.x, D = a.D, K = a.K;
+    __builtin_amdgcn_s_setprio(3);   // latency-critical: win issue arbitration on a shared CU
+    // ---- one batch of loads ------------------------------------------------------------
+    {
+        double v0[E], v1[E], v2[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            const int i = e / KP, j = e % KP;
+            const bool in = (i < K && j < K);
+            v0[m] = in ? st[L.off_Sww + i * KP + j] : 0.0;
+            v1[m] = in ? st[L.off_CX + i * KP + j] : 0.0;
+            v2[m] = in ? st[L.off_S + (L.DP + i) * KP + j] : 0.0;
+        }
+        if (tid == 0) {
+            sc[4] = st[L.off_Syy];
+            sc[5] = st[L.off_scal + 0];
+            sc[6] = st[L.off_scal + 1];
+        }
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            const int i = e / KP, j = e % KP;
+            Sw[i * LDM + j] = v0[m];
+            Cx[i * LDM + j] = v1[m];
+            Sx[i * LDM + j] = v2[m];
+        }
+    }
+    // sum(W o Syx): padded entries of W are zero, so the D x KP blocks are walked linearly
+    double t1 = 0.0;
+    {
+        const int n = D * KP;
+#pragma unroll 1
+        for (int e0 = 0; e0 < n; e0 += 8 * NTF) {
+            double w[8], y[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int e = e0 + tid + m * NTF;
+                w[m] = e < n ? st[L.off_W + e] : 0.0;
+                y[m] = e < n ? st[L.off_S + e] : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) t1 += w[m] * y[m];
+        }
+    }
+    __syncthreads();
+    double t2 = 0.0, trx = 0.0;
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int e = tid + m * NTF;
+        const int i = e / KP, j = e % KP;
+        const double sxx = a.n_total * Cx[i * LDM + j] + 0.5 * (Sx[i * LDM + j] + Sx[j * LDM + i]);
+        t2 += Sw[i * LDM + j] * sxx;
+        if (i == j) trx += sxx;
+    }
+    t1 = block_sum<NTF>(t1, red);
+    t2 = block_sum<NTF>(t2, red);
+    trx = block_sum<NTF>(trx, red);
+    // (dot.py:355 E1 and dot.py:403 E2 collapsed to traces)
+    const double resid = sc[4] - 2.0 * t1 + t2;
+    // ---- tau (gamma.py:116-148 with the message gaussian.py:2363-2369), alpha -------------
+    if (tid == 64) {
+        const double ta = a.a0t + 0.5 * (double)D * a.n_total;
+        const double tb = a.b0t + 0.5 * resid;
+        sc[0] = ta;
+        sc[1] = tb;
+        sc[2] = ta / tb;
+        sc[3] = sf_digamma(ta) - sf_log(tb);
+        st[L.off_tau + 0] = ta;
+        st[L.off_tau + 1] = tb;
+        st[L.off_tau + 2] = sc[2];
+        st[L.off_tau + 3] = sc[3];
+        st[L.off_scal + 2] = resid;
+        if (!(tb > 0.0)) st[L.off_scal + 3] = (double)VMP_ERR_FLOATING;
+    }
+    if (tid < K) {
+        const double aa = a.a0a + 0.5 * (double)D;
+        const double ab = a.b0a + 0.5 * Sw[tid * LDM + tid];
+        const double am = aa / ab, alg = sf_digamma(aa) - sf_log(ab);
+        al[0 * KP + tid] = aa;
+        al[1 * KP + tid] = ab;
+        al[2 * KP + tid] = am;
+        al[3 * KP + tid] = alg;
+        st[L.off_alpha + 0 * KP + tid] = aa;
+        st[L.off_alpha + 1 * KP + tid] = ab;
+        st[L.off_alpha + 2 * KP + tid] = am;
+        st[L.off_alpha + 3 * KP + tid] = alg;
+    }
+    __syncthreads();
+    // ---- lower bound (expfamily.py:400-480) ----------------------------------------------
+    double sla = 0.0, saw = 0.0, lal = 0.0;
+    if (tid <= K) {
+        const bool is_tau = (tid == K);
+        const double *p = is_tau ? sc : al + tid;
+        const int sp = is_tau ? 1 : KP;
+        const double g = gamma_elbo(is_tau ? a.a0t : a.a0a, is_tau ? a.b0t : a.b0a, p[0], p[sp],
+                                    p[2 * sp], p[3 * sp]);
+        if (is_tau) {
+            red[NTF / 64] = g;
+        } else {
+            sla = p[3 * sp];
+            saw = p[2 * sp] * Sw[tid * LDM + tid];
+            lal = g;
+        }
+    }
+    sla = block_sum<NTF>(sla, red);
+    saw = block_sum<NTF>(saw, red);
+    lal = block_sum<NTF>(lal, red);
+    if (tid == 0) {
+        const double tau = sc[2], logtau = sc[3];
+        const double Dd = (double)D, Kd = (double)K;
+        const double LY = Dd * a.n_total * (-0.5 * sf_log(2.0 * M_PI) + 0.5 * logtau)
+                          - 0.5 * tau * resid;
+        const double LX = -0.5 * a.x_prec * trx
+                          + a.n_total * (0.5 * Kd * sf_log(a.x_prec) - 0.5 * sc[6] + 0.5 * Kd);
+        const double LW = 0.5 * Dd * sla - 0.5 * saw + Dd * (-0.5 * sc[5] + 0.5 * Kd);
+        const double Lt = red[NTF / 64];
+        st[L.off_L + 0] = LY;
+        st[L.off_L + 1] = LX;
+        st[L.off_L + 2] = LW;
+        st[L.off_L + 3] = Lt;
+        st[L.off_L + 4] = lal;
+        st[L.off_L + 5] = LY + LX + LW + Lt + lal;
+    }
 }
 
 template <int O0, int O1, int O2>
@@ -415,16 +762,33 @@ int32_t launch_small(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double
             VMP_REQUIRE(ctx, a0a > 0 && b0a > 0, VMP_ERR_INVALID,
                         "Gamma prior parameters must be positive");
     }
-    // greedy: the two sequences a VB iteration produces are single launches, anything else
+    // greedy: the two sequences a VB iteration produces are single launches (LDS-resident
+    // forms when K <= 32 and D <= 128; VMP_PCA_FAST_SMALL=0 disables them), anything else
     // falls back to one launch per operation
+    static const int fast_enabled = getenv("VMP_PCA_FAST_SMALL") ? atoi(getenv("VMP_PCA_FAST_SMALL")) : 1;
+    const bool fast = fast_enabled && a.L.KP <= 32 && D <= FAST_D;
     int i = 0;
     while (i < nops) {
         const int o0 = ops[i], o1 = i + 1 < nops ? ops[i + 1] : 0, o2 = i + 2 < nops ? ops[i + 2] : 0;
         if (o0 == VMP_PCA_OP_W && o1 == VMP_PCA_OP_XPREP) {
-            launch_sequence<VMP_PCA_OP_W, VMP_PCA_OP_XPREP, 0>(ctx, a, state);
+            if (fast && a.L.KP == 16)
+                hipLaunchKernelGGL(pca_head_fast_kernel<16>, dim3(1), dim3(NTF), 0, ctx->stream, a,
+                                   state);
+            else if (fast)
+                hipLaunchKernelGGL(pca_head_fast_kernel<32>, dim3(1), dim3(NTF), 0, ctx->stream, a,
+                                   state);
+            else
+                launch_sequence<VMP_PCA_OP_W, VMP_PCA_OP_XPREP, 0>(ctx, a, state);
             i += 2;
         } else if (o0 == VMP_PCA_OP_TAU && o1 == VMP_PCA_OP_ALPHA && o2 == VMP_PCA_OP_ELBO) {
-            launch_sequence<VMP_PCA_OP_TAU, VMP_PCA_OP_ALPHA, VMP_PCA_OP_ELBO>(ctx, a, state);
+            if (fast && a.L.KP == 16)
+                hipLaunchKernelGGL(pca_tail_fast_kernel<16>, dim3(1), dim3(NTF), 0, ctx->stream, a,
+                                   state);
+            else if (fast)
+                hipLaunchKernelGGL(pca_tail_fast_kernel<32>, dim3(1), dim3(NTF), 0, ctx->stream, a,
+                                   state);
+            else
+                launch_sequence<VMP_PCA_OP_TAU, VMP_PCA_OP_ALPHA, VMP_PCA_OP_ELBO>(ctx, a, state);
             i += 3;
         } else {
             switch (o0) {

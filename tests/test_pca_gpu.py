@@ -142,6 +142,44 @@ def test_pass_kernel_direct_cabi():
         np.testing.assert_allclose(S3[DP:DP + K, :K], xr @ xr.T, rtol=1e-10, atol=1e-9)
 
 
+@pytest.mark.parametrize('N,D,K', [(3000, 128, 32), (1500, 50, 9), (900, 64, 16), (700, 130, 20)])
+def test_small_ops_fused_sequences_match_single_operations(N, D, K):
+    """vmp_pca_small_ops: the fused sequences (W, X-replicated) and (tau, alpha, lower bound)
+    -- LDS-resident kernels when K <= 32 and D <= 128 -- against the same operations
+    launched one by one (the generic kernel), from the same state."""
+    from oracle.pca import make_pca_data
+    from bayespy_amd.device import ptr
+    y, x0 = make_pca_data(N, D, K, seed=7)
+    Q = _run(y, x0, K, 2)
+    plan = Q.plans[0]
+    rt, lib = plan.rt, plan.rt.lib
+    plan.finish()
+    base = plan.state.clone()
+
+    def run(seqs):
+        st = base.clone()
+        rt.sync_stream()
+        for ops in seqs:
+            arr = (ctypes.c_int32 * len(ops))(*ops)
+            rt.check(lib.vmp_pca_small_ops(rt.ctx, D, K, plan.n_total, plan.x_prec, plan.a0t,
+                                           plan.b0t, plan.a0a, plan.b0a, len(ops), arr, ptr(st)))
+        return st.cpu().numpy()
+
+    fused = run([[1, 2], [3, 4, 5]])
+    single = run([[1], [2], [3], [4], [5]])
+    mixed = run([[2, 1][::-1], [4, 3][::-1], [5]])          # (W, X) fused, tau/alpha generic pair
+    assert np.all(np.isfinite(fused))
+    np.testing.assert_allclose(fused, single, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(mixed, single, rtol=1e-11, atol=1e-11)
+    assert not np.array_equal(fused, base.cpu().numpy())
+    # unknown operation codes and empty lists are rejected
+    bad = (ctypes.c_int32 * 1)(9)
+    assert lib.vmp_pca_small_ops(rt.ctx, D, K, plan.n_total, plan.x_prec, plan.a0t, plan.b0t,
+                                 plan.a0a, plan.b0a, 1, bad, ptr(base)) == -1
+    assert lib.vmp_pca_small_ops(rt.ctx, D, K, plan.n_total, plan.x_prec, plan.a0t, plan.b0t,
+                                 plan.a0a, plan.b0a, 0, bad, ptr(base)) == -1
+
+
 def test_cabi_rejects_bad_arguments():
     from bayespy_amd import _lib
     from bayespy_amd.device import get_runtime, ptr
