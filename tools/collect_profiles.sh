@@ -22,6 +22,20 @@ python tools/rocpd_summary.py /tmp/p_stats_gmm/r_results.db > $O/kernel_stats_gm
 (cd /tmp; timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f_gmm -o r -- $G > /dev/null 2>&1)
 (cd /tmp; timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w_gmm -o r -- $G > /dev/null 2>&1)
 python tools/rocpd_summary.py --pmc /tmp/p_sq_gmm/r_results.db /tmp/p_f_gmm/r_results.db /tmp/p_w_gmm/r_results.db > $O/pmc_gmm.txt 2>&1
+# masked PCA (generic engine) and the shard-size step (what one of 8 ranks runs at N=1e7)
+M="python $R/tools/bench_masked_pca.py --n 200000 --steps 9"
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats_mpca -o r -- $M > $R/$O/bench_under_rocprof_masked_pca.log 2>&1)
+python tools/rocpd_summary.py /tmp/p_stats_mpca/r_results.db > $O/kernel_stats_masked_pca.txt 2>&1
+python tools/bench_masked_pca.py --n 20000 --steps 10 > $O/bench_masked_pca_n2e4.json 2>/dev/null
+python tools/bench_masked_pca.py --n 200000 --steps 10 > $O/bench_masked_pca_n2e5.json 2>/dev/null
+S="python $R/bench.py --n 1250000 --steps 10 --warmup 2 --no-cpu-baseline"
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace -d /tmp/p_tl -o r -- $S > /dev/null 2>&1)
+python tools/rocpd_summary.py --timeline 30 /tmp/p_tl/r_results.db > $O/timeline_shard_n1250000.txt 2>&1
+python bench.py --n 1250000 --no-cpu-baseline > $O/bench_shard_n1250000_overlap.json 2>/dev/null
+VMP_PCA_PLATE_STREAM=0 python bench.py --n 1250000 --no-cpu-baseline > $O/bench_shard_n1250000_inorder.json 2>/dev/null
+VMP_PCA_PLATE_STREAM=0 python bench.py --no-cpu-baseline > $O/bench_n1_gram_inorder.json 2>/dev/null
+python bench.py --n 1000000 --d 64 --k 16 --no-cpu-baseline > $O/bench_config2.json 2>/dev/null
+python tools/bench_lssm.py > $O/bench_lssm.json 2>/dev/null
 python bench.py --steps 20 --warmup 3 > $O/bench_n1_gram.json 2>/dev/null
 python bench.py --steps 20 --warmup 3 --stats stream --no-cpu-baseline > $O/bench_n1_stream.json 2>/dev/null
 python tools/bench_gmm.py > $O/bench_gmm_n1.json 2>/dev/null
