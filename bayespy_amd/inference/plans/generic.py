@@ -1040,6 +1040,40 @@ class GenericPlan:
     def get_moments(self, node):
         return [np.asarray(_arr(m).numpy()) for m in self._moments(node)]
 
+    # -- rotations (inference/transformations.py) ------------------------------------------------
+    def gamma_posterior_shape(self, node):
+        st = self._ensure(node)
+        return np.asarray(_arr(st.phi[1]).numpy())
+
+    def rotation_statistics(self, node):
+        """sum over the plates of <x x^T> (K x K) and the plate count of a vector GaussianARD."""
+        if not isinstance(node, GaussianARD) or node.ndim != 1:
+            raise NotImplementedError('rotation of %s' % node.name)
+        st = self._ensure(node)
+        K = node.dims[0][-1]
+        xx = misc.sum_multiply_to_plates(_arr(st.u[1]), to_plates=(K, K),
+                                         from_plates=node.plates + (K, K), ndim=0)
+        return dict(XX=np.asarray(xx.numpy()), nplates=float(np.prod(node.plates)))
+
+    def rotate_node(self, node, R, invR, logdetR):
+        """q(node) <- distribution of R x: phi0 <- R^-T phi0, phi1 <- R^-T phi1 R^-1,
+        u0 <- R u0, u1 <- R u1 R^T, g <- g - log|det R|  (gaussian.py:1693-1741)."""
+        if not isinstance(node, GaussianARD) or node.ndim != 1:
+            raise NotImplementedError('rotation of %s' % node.name)
+        st = self._ensure(node)
+        if st.observed:
+            raise ValueError('cannot rotate the observed node %s' % node.name)
+        Rd = DArray.from_host(np.ascontiguousarray(R))
+        Rt = DArray.from_host(np.ascontiguousarray(R.T))
+        Ri = DArray.from_host(np.ascontiguousarray(invR))
+        Rit = DArray.from_host(np.ascontiguousarray(invR.T))
+        phi0, phi1 = _arr(st.phi[0]), _arr(st.phi[1])
+        u0, u1 = _arr(st.u[0]), _arr(st.u[1])
+        st.phi = [linalg.mvdot(Rit, phi0), linalg.mmdot(linalg.mmdot(Rit, phi1), Ri)]
+        st.u = [linalg.mvdot(Rd, u0), linalg.mmdot(linalg.mmdot(Rd, u1), Rt)]
+        if isinstance(st.g, DArray):
+            st.g = fuse(lambda g: g - float(logdetR), st.g)
+
     def get_parameters(self, node):
         st = self._ensure(node)
         return [np.asarray(_arr(p).numpy()) for p in st.phi]

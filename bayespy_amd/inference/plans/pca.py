@@ -98,6 +98,13 @@ class HIPKernels:
     def xjoin(self):
         self.rt.check(self.lib.vmp_pca_xjoin(self.ctx))
 
+    def rotate_rows(self, R, X, N):
+        """X[:, :N] <- R X[:, :N] on the device (vmp_gemm_strided via utils.linalg)."""
+        from ...darray import DArray
+        from ...utils import linalg
+        xn = linalg.mmdot(DArray.from_host(np.ascontiguousarray(R)), DArray(X[:, :N]))
+        X[:, :N].copy_(xn.t)
+
     def set_timing(self, on):
         self.rt.check(self.lib.vmp_ctx_set_timing(self.ctx, 1 if on else 0))
 
@@ -429,10 +436,10 @@ class PCAPlan:
             u1 = x[:, :, None] * x[:, None, :] + cx
             return [x.reshape(self.X.plates + (K,)), u1.reshape(self.X.plates + (K, K))]
         if node is self.tau:
-            t = self.state[L.off_tau:L.off_tau + 4].cpu().numpy()
+            t = np.array(self.state[L.off_tau:L.off_tau + 4].cpu().numpy())
             return [np.reshape(t[2], self.tau.plates), np.reshape(t[3], self.tau.plates)]
         if node is self.alpha:
-            a = self.state[L.off_alpha:L.off_alpha + 4 * KP].cpu().numpy().reshape(4, KP)
+            a = np.array(self.state[L.off_alpha:L.off_alpha + 4 * KP].cpu().numpy()).reshape(4, KP)
             return [a[2, :K].reshape(self.alpha.plates), a[3, :K].reshape(self.alpha.plates)]
         if node is self.Y:
             y = self.Yd[:, :N].cpu().numpy()
@@ -459,6 +466,63 @@ class PCAPlan:
             return (self.Xd[:, :self.N].cpu().numpy().T.copy(),
                     self._block(L.off_CX, K, K, KP))
         raise NotImplementedError
+
+    # -- rotations (inference/transformations.py) ----------------------------------------------------
+    def gamma_posterior_shape(self, node):
+        return self.get_parameters(node)[0]
+
+    def rotation_statistics(self, node):
+        """sum over the plates of <x x^T> (K x K, global over ranks) and the plate count."""
+        self._materialize()
+        self._flush()
+        L = self.layout
+        K, KP, DP = self.K, int(L.KP), int(L.DP)
+        if node is self.W:
+            return dict(XX=self._block(L.off_Sww, K, K, KP), nplates=self.D)
+        if node is self.X:
+            sxx = self._block(L.off_S + DP * KP, K, K, KP)
+            cx = self._block(L.off_CX, K, K, KP)
+            return dict(XX=self.n_total * cx + 0.5 * (sxx + sxx.T), nplates=self.n_total)
+        raise NotImplementedError('rotation of %s' % node.name)
+
+    def _put_block(self, off, mat, ld):
+        """Upload a small host matrix into a row-major state block of leading dimension ld."""
+        rows, cols = mat.shape
+        buf = np.zeros((rows, ld))
+        buf[:, :cols] = mat
+        self.state[off:off + rows * ld].copy_(self.rt.torch.from_numpy(buf.reshape(-1)))
+
+    def rotate_node(self, node, R, invR, logdetR):
+        """q(node) <- the distribution of R x (gaussian.py:1693-1741): means and covariances of
+        the K x K / D x K state on the host (O(K^3)), the (K, N) array of <x_n> on the device
+        through the fp64 MFMA contraction kernel."""
+        self._materialize()
+        self.finish()
+        rt, L = self.rt, self.layout
+        torch = rt.torch
+        D, K, KP, DP = self.D, self.K, int(L.KP), int(L.DP)
+        sc = self.state[L.off_scal:L.off_scal + 2].cpu().numpy()
+        if node is self.W:
+            w = self._block(L.off_W, D, K, KP)
+            cw = self._block(L.off_CW, K, K, KP)
+            sww = self._block(L.off_Sww, K, K, KP)
+            self._put_block(L.off_W, w @ R.T, KP)
+            self._put_block(L.off_CW, R @ cw @ R.T, KP)
+            self._put_block(L.off_Sww, R @ sww @ R.T, KP)
+            sc[0] -= 2.0 * logdetR             # log|Lambda_W| of the rotated covariance
+        elif node is self.X:
+            syx = self._block(L.off_S, D, K, KP)
+            sxx = self._block(L.off_S + DP * KP, K, K, KP)
+            cx = self._block(L.off_CX, K, K, KP)
+            self._put_block(L.off_S, syx @ R.T, KP)
+            self._put_block(L.off_S + DP * KP, R @ sxx @ R.T, KP)
+            self._put_block(L.off_CX, R @ cx @ R.T, KP)
+            sc[1] -= 2.0 * logdetR
+            self.kernels.rotate_rows(R, self.Xd, self.N)
+        else:
+            raise NotImplementedError('rotation of %s' % node.name)
+        self.state[L.off_scal:L.off_scal + 2].copy_(torch.from_numpy(sc))
+        self._version += 1
 
     # -- measurement ---------------------------------------------------------------------------------
     def enable_timing(self, on=True):

@@ -1,0 +1,244 @@
+"""
+Rotation parameter expansion for pairs of Gaussian blocks whose product is observed
+(reference: bayespy/inference/vmp/transformations.py:23-224 ``RotationOptimizer``,
+:376-1110 ``RotateGaussianARD``; used by demos/pca.py:85-94 as the VB callback).
+
+Rotating q(W) by R and q(X) by R^-T leaves <w^T x> unchanged but can raise the lower bound
+by orders of magnitude per iteration.  The split of work follows SURVEY.md 8(f).3:
+
+* the K x K optimisation runs on the host (SciPy nonlinear CG, like the reference's
+  utils/optimize.py:15-25) on the sufficient statistics  sum_plates <x x^T>  which the
+  execution plan hands over -- a K x K read-back, never plate-sized data;
+* the rotation itself is applied to the device state by the plan that owns the node
+  (``plan.rotate_node``): means and covariances on the device, the plate-sized array of the
+  fused PCA block through the fp64 MFMA contraction kernel.
+
+Supported: ``RotateGaussianARD(X)`` / ``RotateGaussianARD(X, alpha)`` for a zero-mean
+GaussianARD rotated along its last axis with the precision shared over the plates
+(``alpha`` with plates ``(K,)`` or a constant) -- the PCA / factor-analysis use.  Plate
+rotations (``Q``), subsets and non-zero prior means raise ``NotImplementedError``.
+"""
+import warnings
+
+import numpy as np
+from scipy import optimize as _sp_optimize
+
+from ..nodes.node import Constant
+from ..nodes.gamma import Gamma
+from ..nodes.gaussian import GaussianARD
+
+
+def _minimize(f, x0, maxiter=None, verbose=False):
+    """SciPy nonlinear conjugate gradients on (value, gradient) functions
+    (utils/optimize.py:15-25)."""
+    options = {'disp': verbose}
+    if maxiter is not None:
+        options['maxiter'] = maxiter
+    return _sp_optimize.minimize(f, x0, jac=True, method='CG', options=options).x
+
+
+class RotateGaussianARD:
+    """Rotation of q(X) (and the coupled update of q(alpha)) along the last axis of a
+    GaussianARD node with prior  N(0, diag(alpha)^-1)  (transformations.py:376-1110)."""
+
+    def __init__(self, X, *alpha, axis=-1, precompute=False, subset=None):
+        if not isinstance(X, GaussianARD) or X.ndim != 1:
+            raise NotImplementedError('RotateGaussianARD supports vector-valued GaussianARD nodes')
+        if not isinstance(axis, int):
+            raise ValueError("Axis must be integer")
+        if axis >= 0:
+            axis -= X.ndim
+        if axis < -X.ndim or axis >= 0:
+            raise ValueError("Axis out of bounds")
+        if subset is not None:
+            raise NotImplementedError('subset rotations are not supported')
+        if len(alpha) > 1:
+            raise ValueError('Too many arguments')
+        self.node_X = X
+        self.D = X.dims[0][-1]
+        self.update_alpha = len(alpha) == 1
+        mu, prec = X.parents
+        if not (isinstance(mu, Constant) and np.all(np.asarray(mu.value) == 0)):
+            raise NotImplementedError('RotateGaussianARD needs a constant zero prior mean')
+        if self.update_alpha:
+            self.node_alpha = alpha[0]
+            if self.node_alpha is not prec:
+                raise ValueError('alpha must be the precision parent of X')
+            if not isinstance(prec, Gamma) or prec.plates not in ((self.D,), (1,), ()):
+                raise NotImplementedError('alpha must be a Gamma node with plates (K,) or scalar')
+        else:
+            if not isinstance(prec, Constant):
+                raise NotImplementedError('without alpha the precision must be a constant')
+            a = np.asarray(prec.value, dtype=np.float64)
+            if a.ndim > 1 or a.size not in (1, self.D):
+                raise NotImplementedError('constant precision must be a scalar or a (K,) vector')
+            self.alpha = np.broadcast_to(a, (self.D,)).astype(np.float64)
+
+    def nodes(self):
+        return [self.node_X, self.node_alpha] if self.update_alpha else [self.node_X]
+
+    # -- statistics ---------------------------------------------------------------------------
+    def setup(self, plate_axis=None):
+        """Fetch  XX = sum_plates <x x^T>  (K x K) and the number of plates from the plan that
+        owns X (transformations.py:476-640 for mu = 0, axis = -1, no plate rotation)."""
+        if plate_axis is not None:
+            raise NotImplementedError('plate rotations are not supported')
+        plan = self.node_X._plan
+        if plan is None:
+            raise RuntimeError('node %s is not part of a VB engine' % self.node_X.name)
+        st = plan.rotation_statistics(self.node_X)
+        self.XX = np.asarray(st['XX'], dtype=np.float64)
+        self.nplates = float(st['nplates'])
+        if self.update_alpha:
+            a = self.node_alpha._plan.gamma_posterior_shape(self.node_alpha)
+            self.a = np.broadcast_to(np.asarray(a, dtype=np.float64).reshape(-1), (self.D,))
+            a0 = np.asarray(self.node_alpha.parents[0].value, dtype=np.float64).reshape(-1)
+            b0 = np.asarray(self.node_alpha.parents[1].value, dtype=np.float64).reshape(-1)
+            self.a0 = np.broadcast_to(a0, (self.D,))
+            self.b0 = np.broadcast_to(b0, (self.D,))
+            if self.node_alpha.plates != (self.D,):
+                raise NotImplementedError('a precision shared over the rotated axis is not '
+                                          'supported')
+
+    # -- bound and gradient (transformations.py:693-960) ------------------------------------------
+    def _terms(self, R, logdet, inv):
+        RXX = R @ self.XX
+        v = np.einsum('ik,ik->i', RXX, R)           # <(R x)_k^2> summed over the plates
+        N = self.nplates
+        if self.update_alpha:
+            b = self.b0 + 0.5 * v
+            alpha = self.a / b
+            logalpha = -np.log(b)
+        else:
+            alpha = self.alpha
+            logalpha = np.zeros(self.D)
+        logH_X = N * logdet                          # entropy of q(X)
+        logp_X = -0.5 * np.sum(alpha * v) + 0.5 * N * np.sum(logalpha)
+        logp_alpha = 0.0
+        if self.update_alpha:
+            # the entropy of q(alpha) cancels against the log(alpha) term of <log p(alpha)>
+            logp_alpha = np.sum(self.a0 * logalpha) - np.sum(self.b0 * alpha)
+        # gradient with respect to R, row k multiplies RXX[k]
+        if self.update_alpha:
+            coef = (-alpha + (0.5 * v + self.b0) * alpha / b - (0.5 * N + self.a0) / b)
+        else:
+            coef = -alpha
+        grad = N * inv.T + coef[:, None] * RXX
+        return logp_X + logH_X, logp_alpha, grad
+
+    def bound(self, R, logdet=None, inv=None, Q=None):
+        if Q is not None:
+            raise NotImplementedError('plate rotations are not supported')
+        if logdet is None:
+            logdet = np.linalg.slogdet(R)[1]
+        if inv is None:
+            inv = np.linalg.inv(R)
+        bx, ba, grad = self._terms(R, logdet, inv)
+        return bx + ba, grad
+
+    def get_bound_terms(self, R, logdet=None, inv=None, Q=None):
+        if logdet is None:
+            logdet = np.linalg.slogdet(R)[1]
+        if inv is None:
+            inv = np.linalg.inv(R)
+        bx, ba, _ = self._terms(R, logdet, inv)
+        terms = {self.node_X: bx}
+        if self.update_alpha:
+            terms[self.node_alpha] = ba
+        return terms
+
+    # -- apply -------------------------------------------------------------------------------------
+    def rotate(self, R, inv=None, logdet=None, Q=None):
+        if Q is not None:
+            raise NotImplementedError('plate rotations are not supported')
+        R = np.asarray(R, dtype=np.float64)
+        if inv is None:
+            inv = np.linalg.inv(R)
+        if logdet is None:
+            logdet = np.linalg.slogdet(R)[1]
+        self.node_X._plan.rotate_node(self.node_X, R, inv, float(logdet))
+        if self.update_alpha:
+            self.node_alpha.update()
+
+
+class RotationOptimizer:
+    """Jointly optimal rotation of two blocks: block1 by R, block2 by R^-T
+    (transformations.py:23-224)."""
+
+    def __init__(self, block1, block2, D):
+        self.block1 = block1
+        self.block2 = block2
+        self.D = D
+
+    def rotate(self, maxiter=10, check_gradient=False, verbose=False, check_bound=False):
+        D = self.D
+
+        def cost(r):
+            R = np.reshape(r, (D, D))
+            invR = np.linalg.inv(R)
+            logdetR = np.linalg.slogdet(R)[1]
+            b1, db1 = self.block1.bound(R, logdet=logdetR, inv=invR)
+            b2, db2 = self.block2.bound(invR.T, logdet=-logdetR, inv=R.T)
+            # chain rule for the block rotated by R^-T (transformations.py:90-96)
+            db2 = -invR.T @ db2.T @ invR.T
+            return -(b1 + b2), -np.ravel(db1 + db2)
+
+        def bound_terms(r):
+            R = np.reshape(r, (D, D))
+            invR = np.linalg.inv(R)
+            logdetR = np.linalg.slogdet(R)[1]
+            t = self.block1.get_bound_terms(R, logdet=logdetR, inv=invR)
+            t.update(self.block2.get_bound_terms(invR.T, logdet=-logdetR, inv=R.T))
+            return t
+
+        def true_bound_terms():
+            nodes = set(self.block1.nodes()) | set(self.block2.nodes())
+            return {n: n.lower_bound_contribution() for n in nodes}
+
+        self.block1.setup()
+        self.block2.setup()
+
+        if check_gradient:
+            R0 = np.random.randn(D, D)
+            g = cost(np.ravel(R0))[1]
+            gn = _sp_optimize.approx_fprime(np.ravel(R0), lambda x: cost(x)[0],
+                                            np.sqrt(np.finfo(float).eps))
+            err = np.linalg.norm(g - gn) / max(np.linalg.norm(gn), 1e-300)
+            if err > 1e-5:
+                warnings.warn("Rotation gradient has relative error %g" % err)
+
+        r0 = np.ravel(np.identity(D))
+        cost_begin = cost(r0)[0]
+        if check_bound:
+            terms_begin = bound_terms(r0)
+            true_begin = true_bound_terms()
+
+        r = _minimize(cost, r0, maxiter=maxiter, verbose=verbose)
+        cost_end = cost(r)[0]
+
+        R = np.reshape(r, (D, D))
+        invR = np.linalg.inv(R)
+        logdetR = np.linalg.slogdet(R)[1]
+        self.block1.rotate(R, inv=invR, logdet=logdetR)
+        self.block2.rotate(invR.T, inv=R.T, logdet=-logdetR)
+
+        if cost_end - cost_begin > 0:
+            warnings.warn("Rotation optimization made the cost function worse by %g. Probably a "
+                          "bug in the gradient of the rotation functions."
+                          % (cost_end - cost_begin,))
+        if check_bound:
+            terms_end = bound_terms(r)
+            true_end = true_bound_terms()
+            change = 0.0
+            for node in terms_begin:
+                d = terms_end[node] - terms_begin[node]
+                dt = true_end[node] - true_begin[node]
+                change += d
+                if not np.allclose(d, dt):
+                    warnings.warn("Rotation cost function is not consistent with the true lower "
+                                  "bound for node %s. Bound changed %g but optimized function "
+                                  "changed %g." % (node.name, dt, d))
+            if change < 0:
+                warnings.warn("Rotation made the true lower bound worse by %g. Probably a bug "
+                              "in the rotation functions." % (change,))
+        return R

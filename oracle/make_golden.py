@@ -369,6 +369,62 @@ def lssm_cases(name):
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
 
 
+def rotation_cases(name):
+    """PCA with the rotation parameter expansion run as the VB callback, exactly as
+    demos/pca.py:85-94 does (RotateGaussianARD(W, alpha), RotateGaussianARD(X),
+    RotationOptimizer): (a) fully observed, (b) 20 % missing; plus one stand-alone rotation
+    from a fixed state with the optimal R recorded."""
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy.inference import VB
+    from bayespy.inference.vmp import transformations
+    import warnings
+    rs = np.random.RandomState(123)
+    out = {}
+    for tag, D, N, K, masked in (('rot', 8, 300, 4, False), ('rotm', 6, 80, 3, True)):
+        w, x = rs.normal(size=(D, K - 1)), rs.normal(size=(N, K - 1))
+        y = w @ x.T + 0.1 * rs.normal(size=(D, N))
+        mask = rs.rand(D, N) < 0.8
+        x0 = rs.normal(size=(N, K))
+        alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+        W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+        X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+        F = SumMultiply('i,i', W, X, name='F')
+        tau = Gamma(1e-2, 1e-2, name='tau')
+        Y = GaussianARD(F, tau, name='Y')
+        X.initialize_from_value(x0[None])
+        if masked:
+            Y.observe(y, mask=mask)
+        else:
+            Y.observe(y)
+        Q = VB(Y, F, W, X, tau, alpha)
+        Q.ignore_bound_checks = True
+        rotW = transformations.RotateGaussianARD(W, alpha)
+        rotX = transformations.RotateGaussianARD(X)
+        R = transformations.RotationOptimizer(rotW, rotX, K)
+        # stand-alone rotation after two plain iterations
+        Q.update(repeat=2, verbose=False)
+        L_before = Q.compute_lowerbound()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            R.rotate()
+        L_after = Q.compute_lowerbound()
+        out[tag + '_L_before'], out[tag + '_L_after'] = np.array(L_before), np.array(L_after)
+        # copies: the reference updates moments in place (stochastic.py:248-250)
+        out[tag + '_W_u0_rot'], out[tag + '_X_u0_rot'] = np.array(W.u[0]), np.array(X.u[0])
+        out[tag + '_alpha_u0_rot'] = np.array(alpha.u[0])
+        # then the demo's usage: rotate in the callback of every iteration
+        Q.callback = R.rotate
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Q.update(repeat=6, verbose=False)
+        out[tag + '_y'], out[tag + '_mask'], out[tag + '_x0'] = y, mask, x0
+        out[tag + '_L'] = np.array(Q.L[:Q.iter])
+        out[tag + '_W_u0'], out[tag + '_X_u0'] = np.asarray(W.u[0]), np.asarray(X.u[0])
+        out[tag + '_tau_u0'], out[tag + '_alpha_u0'] = np.asarray(tau.u[0]), np.asarray(alpha.u[0])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, {k: v for k, v in out.items() if '_L' in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -383,6 +439,7 @@ def main():
     utils_cases('utils_known_answers')
     small_model_cases('small_models')
     lssm_cases('lssm')
+    rotation_cases('rotations')
 
 
 if __name__ == '__main__':

@@ -182,6 +182,9 @@ class CPURuntimeKernels:
         La = gamma_elbo(a0a, b0a, v['alpha'][0, :K], v['alpha'][1, :K])
         v['Lt'][:6] = [LY, LX, LW, Lt, La, LY + LX + LW + Lt + La]
 
+    def rotate_rows(self, R, X, N):
+        X.numpy()[:, :N] = R @ X.numpy()[:, :N]
+
     def set_timing(self, on):
         pass
 

@@ -65,6 +65,22 @@ def test_update_order_and_one_pass_per_iteration(golden_dir):
                                          'update_tau', 'update_alpha']
 
 
+def test_rotation_matches_reference(golden_dir):
+    """RotationOptimizer + RotateGaussianARD on the fused block (K x K optimisation on the
+    host, state rotated through the plan) against the live-reference trace."""
+    from bayespy_amd.inference import transformations
+    from models import run_rotation_sequence, check_rotation_results
+    g = np.load(os.path.join(golden_dir, 'rotations.npz'))
+    K = g['rot_x0'].shape[1]
+    Q = _attach_cpu(build_pca(nodes, VB, g['rot_y'], g['rot_x0'], K))
+    res = run_rotation_sequence(Q, K, transformations)
+    check_rotation_results(res, g, 'rot')
+    with pytest.raises(NotImplementedError):
+        transformations.RotateGaussianARD(Q['X'], subset=[0, 1])
+    with pytest.raises(ValueError):
+        transformations.RotateGaussianARD(Q['W'], Q['alpha'], axis=1)
+
+
 def test_lower_bound_cache_and_observed_skip(golden_dir):
     g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
