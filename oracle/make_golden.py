@@ -425,6 +425,49 @@ def rotation_cases(name):
     print(name, {k: v for k, v in out.items() if '_L' in k})
 
 
+def pca_doctest_case(name):
+    """doc/source/examples/pca.rst:8-118 verbatim (numpy.random.seed(1) from its testsetup):
+    PCA with ARD and the rotation callback run to convergence.  The doctest pins
+    "Iteration 1: loglike=-2.33...e+03" and a final "loglike=6.500...e+02"; the drawn initial
+    value of C is recorded so that the run can be repeated without sharing the RNG stream."""
+    import io
+    import contextlib
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy.inference import VB
+    from bayespy.inference.vmp.transformations import RotateGaussianARD, RotationOptimizer
+    np.random.seed(1)
+    M, N = 20, 100
+    x = np.random.randn(N, 2)
+    w = np.random.randn(M, 2)
+    f = np.einsum('ik,jk->ij', w, x)
+    y = f + 0.1 * np.random.randn(M, N)
+    D = 10
+    X = GaussianARD(0, 1, plates=(1, N), shape=(D,))
+    alpha = Gamma(1e-5, 1e-5, plates=(D,))
+    C = GaussianARD(0, alpha, plates=(M, 1), shape=(D,))
+    F = SumMultiply('d,d->', X, C)
+    tau = Gamma(1e-5, 1e-5)
+    Y = GaussianARD(F, tau)
+    Y.observe(y)
+    Q = VB(Y, X, C, alpha, tau)
+    C.initialize_from_random()
+    C_init = np.array(C.u[0])
+    R = RotationOptimizer(RotateGaussianARD(X), RotateGaussianARD(C, alpha), D)
+    Q.set_callback(R.rotate)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Q.update(repeat=1000)
+    lines = buf.getvalue().strip().splitlines()
+    assert lines[0].startswith('Iteration 1: loglike=-2.33'), lines[0]
+    assert 'loglike=6.500' in lines[-2] and lines[-1].startswith('Converged'), lines[-2:]
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), y=y, C_init=C_init,
+                        L=np.array(Q.L[:Q.iter]), n_iter=Q.iter,
+                        alpha_u0=np.array(alpha.u[0]), tau_u0=np.array(tau.u[0]),
+                        F_u0=np.array(F.get_moments()[0]))
+    print(name, lines[0], '|', lines[-2], '|', lines[-1])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -440,6 +483,7 @@ def main():
     small_model_cases('small_models')
     lssm_cases('lssm')
     rotation_cases('rotations')
+    pca_doctest_case('pca_doctest')
 
 
 if __name__ == '__main__':

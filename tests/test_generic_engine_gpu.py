@@ -207,3 +207,16 @@ def test_rotation_parameter_expansion_matches_reference(golden_dir, case):
     assert isinstance(Q.plans[0], PCAPlan if case == 'fused' else GenericPlan)
     res = run_rotation_sequence(Q, K, transformations)
     check_rotation_results(res, g, tag)
+
+
+@pytest.mark.parametrize('engine', ['fused', 'generic'])
+def test_reference_pca_doctest_known_answer(golden_dir, engine):
+    """doc/source/examples/pca.rst:26-118 (ARD + rotation callback, run to convergence) on
+    the device: first bound -2.33...e+03, converged bound ~6.50e+02."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB, transformations
+    from models import run_pca_doctest, check_pca_doctest
+    g = np.load(os.path.join(golden_dir, 'pca_doctest.npz'))
+    Q, nd = run_pca_doctest(nodes, VB, transformations, g,
+                            engine=None if engine == 'fused' else 'generic')
+    check_pca_doctest(Q, nd, g)

@@ -81,6 +81,17 @@ def test_rotation_matches_reference(golden_dir):
         transformations.RotateGaussianARD(Q['W'], Q['alpha'], axis=1)
 
 
+def test_reference_pca_doctest_known_answer(golden_dir):
+    """doc/source/examples/pca.rst:114-118: first and converged lower bound of the
+    reference's PCA example (ARD + rotation callback, run to convergence)."""
+    from bayespy_amd.inference import transformations
+    from models import run_pca_doctest, check_pca_doctest
+    g = np.load(os.path.join(golden_dir, 'pca_doctest.npz'))
+    Q, nd = run_pca_doctest(nodes, VB, transformations, g, attach=_attach_cpu)
+    assert isinstance(Q.plans[0], PCAPlan)
+    check_pca_doctest(Q, nd, g)
+
+
 def test_lower_bound_cache_and_observed_skip(golden_dir):
     g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
