@@ -131,8 +131,15 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        # "nccl" is RCCL on ROCm.  VMP_BENCH_BACKEND=gloo exists only to smoke-test this launch
+        # path with several ranks on a one-GPU box (RCCL refuses two ranks on one device).
+        backend = os.environ.get('VMP_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ndev))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
