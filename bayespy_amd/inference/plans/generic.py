@@ -977,16 +977,48 @@ class GenericPlan:
                                                    from_plates=from_shape, ndim=0))
         return out
 
+    @property
+    def rt(self):
+        from ...device import get_runtime
+        return get_runtime()
+
+    def _is_sharded(self, node):
+        """The node carries a plate axis partitioned over the ranks: it was declared with
+        Node.shard(), or it descends from such a node (a child's plates contain its parents'
+        plates, node.py:303-345, so the partition is inherited)."""
+        memo = self.__dict__.setdefault('_shard_memo', {})
+        key = id(node)
+        if key not in memo:
+            memo[key] = False          # guards cycles; graphs are DAGs
+            memo[key] = (getattr(node, '_shard_axis', None) is not None
+                         or any(self._is_sharded(p) for p in node.parents))
+        if not memo[key]:
+            return False
+        rt = self.rt
+        rt._refresh_dist()
+        return rt.world > 1
+
     def _messages_from_children(self, node):
         total = [None] * len(node.dims)
+        partial = [None] * len(node.dims)     # sums over a sharded plate: local parts only
+        replicated = not self._is_sharded(node)
         for c, idx in node.children:
             if id(c) not in self.family:
                 continue
             m = self._message_to_parent(c, idx)
+            acc = partial if (replicated and self._is_sharded(c)) else total
             for i in range(len(total)):
                 if m[i] is None:
                     continue
-                total[i] = m[i] if total[i] is None else fuse(lambda a, b: a + b, total[i], m[i])
+                acc[i] = m[i] if acc[i] is None else fuse(lambda a, b: a + b, acc[i], m[i])
+        for i, p in enumerate(partial):
+            if p is None:
+                continue
+            # child -> parent message sum over the sharded plate (node.py:650, dot.py:581):
+            # complete it over the ranks (RCCL all-reduce on GPUs)
+            p = fuse(lambda x: x + 0.0, p)          # private dense copy: reduced in place
+            self.rt.all_reduce_sum_(p.t)
+            total[i] = p if total[i] is None else fuse(lambda a, b: a + b, total[i], p)
         return total
 
     # -- node operations -------------------------------------------------------------------------
@@ -1032,9 +1064,14 @@ class GenericPlan:
         mask, any_active = self._mask_factor((id(node), 'self'), lambda: self._mask_array(node))
         if mask is not None:
             factors.append(mask)
-        if not any_active:
+        sharded = self._is_sharded(node)
+        if not any_active and not sharded:
             return 0.0
         tot = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
+        if sharded:
+            # the node's term is a sum over its plates (expfamily.py:470-480): complete it
+            tot = fuse(lambda x: x + 0.0, tot) if any_active else DArray.zeros(())
+            self.rt.all_reduce_sum_(tot.t)
         return tot.item()
 
     def get_moments(self, node):
@@ -1053,7 +1090,12 @@ class GenericPlan:
         K = node.dims[0][-1]
         xx = misc.sum_multiply_to_plates(_arr(st.u[1]), to_plates=(K, K),
                                          from_plates=node.plates + (K, K), ndim=0)
-        return dict(XX=np.asarray(xx.numpy()), nplates=float(np.prod(node.plates)))
+        nplates = float(np.prod(node.plates))
+        if self._is_sharded(node):
+            xx = fuse(lambda x: x + 0.0, xx)
+            self.rt.all_reduce_sum_(xx.t)
+            nplates = float(self.rt.all_reduce_int(int(nplates)))
+        return dict(XX=np.asarray(xx.numpy()), nplates=nplates)
 
     def rotate_node(self, node, R, invR, logdetR):
         """q(node) <- distribution of R x: phi0 <- R^-T phi0, phi1 <- R^-T phi1 R^-1,

@@ -31,8 +31,28 @@ class Node:
         self.dims = tuple(tuple(d) for d in dims)
         self.name = name if name else '%s_%d' % (type(self).__name__, self._uid)
         self._plan = None
+        self._shard_axis = None
         for i, p in enumerate(self.parents):
             p.children.append((self, i))
+
+    # -- multi-GPU: sharded plates ---------------------------------------
+    def shard(self, axis=-1):
+        """Declare that plate axis ``axis`` of this node is partitioned over the ranks of
+        ``torch.distributed`` -- this process holds only its contiguous part, ``plates`` are the
+        LOCAL sizes.  Every sum over that axis in a message to a replicated (non-sharded)
+        parent, and the node's lower-bound term, is then completed with an all-reduce
+        (the reference's plate sums node.py:650 / dot.py:581 /
+        expfamily.py:470-480 become local partial sum + RCCL all-reduce).  Mark the top-most
+        nodes that carry the sharded plate (e.g. X of a PCA model); descendants (F, Y) inherit
+        the partition.  Returns ``self``."""
+        if not isinstance(axis, int):
+            raise ValueError('Plate axis must be integer')
+        if axis >= 0:
+            axis -= len(self.plates)
+        if axis < -len(self.plates) or axis >= 0:
+            raise ValueError('Plate axis out of bounds')
+        self._shard_axis = axis
+        return self
 
     # -- plan hand-off ----------------------------------------------------------
     def _require_plan(self):

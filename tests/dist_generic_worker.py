@@ -1,0 +1,113 @@
+"""Worker of tests/test_sharded_generic_gpu.py: one rank of a sharded run of the generic
+engine.  Launched by ``python -m torch.distributed.run``; all ranks may share one GPU
+(backend from VMP_TEST_BACKEND, gloo on a one-GPU box; nccl = RCCL on a multi-GPU node)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    case, golden, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % ndev)
+    dist.init_process_group(os.environ.get('VMP_TEST_BACKEND', 'gloo'))
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB, transformations
+    res = {}
+    if case == 'masked_pca':
+        g = np.load(os.path.join(golden, 'small_models.npz'))
+        y, mask, x0 = g['mpca_y'], g['mpca_mask'], g['mpca_x0']
+        D, N = y.shape
+        K = x0.shape[1]
+        lo, hi = N * rank // world, N * (rank + 1) // world
+        alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+        W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+        X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, hi - lo), name='X').shard(-1)
+        F = nodes.SumMultiply('i,i', W, X, name='F').shard(-1)
+        tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+        Y = nodes.GaussianARD(F, tau, name='Y').shard(-1)
+        X.initialize_from_value(x0[None, lo:hi])
+        Y.observe(y[:, lo:hi], mask=mask[:, lo:hi])
+        Q = VB(Y, F, W, X, tau, alpha, engine='generic')
+        Q.ignore_bound_checks = True
+        Q.update(repeat=4, verbose=False)
+        res['L'] = np.array(Q.L[:Q.iter])
+        res['W_u0'], res['tau_u0'] = np.asarray(W.u[0]), np.asarray(tau.u[0])
+        res['alpha_u0'] = np.asarray(alpha.u[0])
+        res['X_u0'] = np.asarray(X.u[0])
+        res['lo'], res['hi'] = lo, hi
+    elif case == 'rotation':
+        g = np.load(os.path.join(golden, 'rotations.npz'))
+        y, mask, x0 = g['rotm_y'], g['rotm_mask'], g['rotm_x0']
+        D, N = y.shape
+        K = x0.shape[1]
+        lo, hi = N * rank // world, N * (rank + 1) // world
+        alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+        W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+        X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, hi - lo), name='X').shard(-1)
+        F = nodes.SumMultiply('i,i', W, X, name='F')      # inherits the partition
+        tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+        Y = nodes.GaussianARD(F, tau, name='Y')
+        X.initialize_from_value(x0[None, lo:hi])
+        Y.observe(y[:, lo:hi], mask=mask[:, lo:hi])
+        Q = VB(Y, F, W, X, tau, alpha)
+        Q.ignore_bound_checks = True
+        Q.update(repeat=2, verbose=False)
+        res['L_before'] = Q.compute_lowerbound()
+        R = transformations.RotationOptimizer(transformations.RotateGaussianARD(W, alpha),
+                                              transformations.RotateGaussianARD(X), K)
+        R.rotate()
+        res['L_after'] = Q.compute_lowerbound()
+        res['W_u0_rot'] = np.asarray(W.u[0])
+        res['X_u0_rot'] = np.asarray(X.u[0])
+        res['lo'], res['hi'] = lo, hi
+    elif case == 'lssm':
+        # batched linear state-space model (BASELINE config 5 shape): sequences sharded
+        from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+        g = np.load(os.path.join(golden, 'lssm.npz'))
+        tag = 'lssmB'
+        y, x0, c0 = g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0']
+        M, B = y.shape[0], y.shape[1]
+        T, D = x0.shape[-2], x0.shape[-1]
+        lo, hi = B * rank // world, B * (rank + 1) // world
+        alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+        A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+        A.initialize_from_value(np.identity(D))
+        nu = Gamma(1e-3, 1e-3, plates=(D,), name='nu')
+        X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, nu, n=T,
+                                plates=(hi - lo,), name='X').shard(-1)
+        X.initialize_from_value(x0[lo:hi])
+        gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+        gamma.initialize_from_value(1e-2 * np.ones(D))
+        C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
+        C.initialize_from_value(c0)
+        tau = Gamma(1e-5, 1e-5, name='tau')
+        tau.initialize_from_value(1e2)
+        F = SumMultiply('i,i', C, X, name='F')          # inherits the partition from X
+        Y = GaussianARD(F, tau, name='Y')
+        Y.observe(y[:, lo:hi])
+        Q = VB(Y, F, C, gamma, X, A, alpha, tau, nu)
+        Q.ignore_bound_checks = True
+        n = len(g[tag + '_L'])
+        Q.update(repeat=n, verbose=False)
+        res['L'] = np.array(Q.L[:n])
+        for nm, nd in dict(A=A, C=C, tau=tau, alpha=alpha, gamma=gamma, nu=nu).items():
+            res['L_' + nm] = np.array(Q.l[nd][:n])
+        res['A_u0'] = np.asarray(A.u[0])
+    else:
+        raise SystemExit('unknown case ' + case)
+    np.savez(os.path.join(out, 'rank%d.npz' % rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
