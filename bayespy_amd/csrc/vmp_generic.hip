@@ -97,6 +97,60 @@ sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial)
     if (threadIdx.x == 0) partial[o * nsplit + sp] = acc;
 }
 
+// Few outputs, long reduction, kept axes NOT dense (e.g. sum over sequences and time of
+// (B, T, D, D) blocks against a broadcast factor): every thread walks reduce positions and
+// accumulates ALL kept elements of its position in registers, so each 128-byte line of the
+// big operand is consumed by one lane instead of being re-read once per kept element.
+template <int NK>
+__global__ void __launch_bounds__(NT)
+sum_multiply_fat_kernel(Iter it, int nsplit, double *__restrict__ partial)
+{
+    __shared__ int64_t koff[MAXIN][NK];
+    __shared__ double wsum[NT / 64][NK];
+    const int tid = threadIdx.x;
+    const int nkeep = (int)it.nkeep;
+    if (tid < NK) {
+        int64_t off[MAXIN], ooff;
+        decode_keep(it, tid < nkeep ? tid : 0, off, ooff);
+        for (int i = 0; i < it.nin; ++i) koff[i][tid] = off[i];
+    }
+    __syncthreads();
+    double acc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[k] = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * NT + tid; r < it.nred; r += (int64_t)gridDim.x * NT) {
+        int64_t roff[MAXIN];
+        for (int i = 0; i < it.nin; ++i) roff[i] = 0;
+        int64_t q = r;
+        for (int d = it.nr - 1; d >= 0; --d) {
+            const int64_t q2 = q / it.rsize[d];
+            const int64_t c = q - q2 * it.rsize[d];
+            q = q2;
+            for (int i = 0; i < it.nin; ++i) roff[i] += c * it.rstride[i][d];
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (k < nkeep) {
+                double p = it.in[0][roff[0] + koff[0][k]];
+                for (int i = 1; i < it.nin; ++i) p *= it.in[i][roff[i] + koff[i][k]];
+                acc[k] += p;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((tid & 63) == 0) wsum[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < nkeep) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) v += wsum[w][tid];
+        partial[(int64_t)tid * nsplit + blockIdx.x] = v;
+    }
+}
+
 // Column reduce: the innermost kept axis is dense in the operands that carry it, so
 // lanes run along it (coalesced) and the workgroup's row-lanes split the reduction.
 //   grid = (kept-inner blocks, kept-outer, nsplit); block = KX x (NT/KX) threads.
@@ -556,7 +610,12 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         // empty sum -> zeros
         it.nred = 0;
     }
-    const bool use_block = (it.nred >= 2048) && (it.nkeep <= 16384);
+    // long reductions: one workgroup per kept element (and slice), lanes along the reduced
+    // axes -- also when there are many kept elements (e.g. per-sequence sums over T x D x D),
+    // where a thread per output would read with a stride of the whole reduced extent
+    const int64_t ws_doubles = workspace ? (int64_t)(workspace_bytes / sizeof(double)) : 0;
+    const bool use_block = (it.nred >= 1024) && (it.nkeep <= ws_doubles) &&
+                           (it.nkeep <= 0x7fffffff);
     // column pattern: several kept elements along a dense innermost kept axis
     bool use_column = false;
     if (it.nred >= 512 && it.nk >= 1 && it.ksize[it.nk - 1] >= 4 && it.nkeep <= 65536) {
@@ -566,7 +625,27 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
             if (st != 0 && st != 1) use_column = false;
         }
     }
-    if (use_column) {
+    // the column form needs >= 16 dense lanes to coalesce; below that the fat-thread form wins
+    const bool use_fat = it.nkeep <= 64 && it.nkeep >= 2 && it.nred >= 65536 &&
+                         !(use_column && it.ksize[it.nk - 1] >= 16) && workspace;
+    if (use_fat) {
+        int64_t nsplit = (int64_t)ctx->num_cu * 4;
+        const int64_t maxsplit = (it.nred + NT - 1) / NT;
+        if (nsplit > maxsplit) nsplit = maxsplit;
+        VMP_REQUIRE(ctx, workspace_bytes >= (size_t)(it.nkeep * nsplit) * sizeof(double),
+                    VMP_ERR_INVALID, "sum_multiply workspace too small (%lld doubles needed)",
+                    (long long)(it.nkeep * nsplit));
+        double *partial = reinterpret_cast<double *>(workspace);
+        if (it.nkeep <= 16)
+            hipLaunchKernelGGL(sum_multiply_fat_kernel<16>, dim3((unsigned)nsplit), dim3(NT), 0, s,
+                               it, (int)nsplit, partial);
+        else
+            hipLaunchKernelGGL(sum_multiply_fat_kernel<64>, dim3((unsigned)nsplit), dim3(NT), 0, s,
+                               it, (int)nsplit, partial);
+        hipLaunchKernelGGL(sum_multiply_finish_kernel,
+                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
+                           (int)nsplit, scale, partial, out);
+    } else if (use_column) {
         const int64_t kin = it.ksize[it.nk - 1];
         const int64_t kouter = it.nkeep / kin;
         const int KX = kin >= 64 ? 64 : (kin >= 16 ? 16 : 4);

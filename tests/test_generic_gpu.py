@@ -50,6 +50,15 @@ SM_CASES = [
     (((100000, 3), (100000, 1)), dict(axis=(0,))),                          # plate sum
     (((3, 40000, 2, 2), (1, 40000, 1, 1)), dict(axis=(1,), keepdims=True)),
     (((64, 1, 32), (1, 1000, 32)), dict(axis=(-1,))),                       # many outputs
+    # few outputs, long reduction over the leading plates, kept axes not dense in every
+    # operand (messages of the chain to its dynamics): fat-thread kernel, 16 / 64 accumulators
+    (((300, 250, 4, 4), (1, 4, 1)), dict(axis=(0, 1))),
+    (((300, 250, 1, 4, 4), (1, 4, 1, 1)), dict(axis=(0, 1))),
+    (((90000, 3, 5),), dict(axis=(0,))),
+    (((70000, 2, 3), (70000, 1, 1), (1, 2, 1)), dict(axis=(0,), keepdims=True)),
+    # many outputs each with a long contiguous reduction (per-sequence sums)
+    (((3000, 700, 2, 2),), dict(axis=(1, 2, 3))),
+    (((3000, 1100), (1, 1100)), dict(axis=(1,))),
 ]
 
 
@@ -62,6 +71,13 @@ def test_sum_multiply_matches_bruteforce(shapes, kw):
     ref = _brute(arrs, kw.get('axis'), kw.get('sumaxis', True), kw.get('keepdims', False))
     assert got.shape == np.shape(ref)
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * max(1.0, np.max(np.abs(ref))))
+    # transposed (non-dense) trailing axes of the first operand take the strided paths
+    if np.ndim(arrs[0]) >= 2 and np.shape(arrs[0])[-1] == np.shape(arrs[0])[-2]:
+        from bayespy_amd.darray import DArray
+        a0 = DArray.from_host(np.ascontiguousarray(np.swapaxes(arrs[0], -1, -2))).swapaxes(-1, -2)
+        got = misc.sum_multiply(a0, *arrs[1:], **kw).numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-12,
+                                   atol=1e-12 * max(1.0, np.max(np.abs(ref))))
 
 
 def test_sum_multiply_errors():
