@@ -35,7 +35,8 @@ from ...nodes.categorical import Categorical
 from ...nodes.mixture import Mixture
 from ...nodes.gaussian_markov_chain import GaussianMarkovChain, MarkovChainToGaussian
 from ...utils import misc, linalg
-from ...utils.shapes import broadcasted_shape, broadcasting_multiplier, is_shape_subset
+from ...utils.shapes import (broadcasted_shape, broadcasting_multiplier, is_shape_subset,
+                             multiplier_factor)
 
 LOG2PI = float(np.log(2 * np.pi))
 
@@ -946,7 +947,13 @@ class GenericPlan:
     def _message_to_parent(self, child, index):
         fam = self.family[id(child)]
         parent = child.parents[index]
+        # plate multiplier: the part of this node's multiplier the parent does not carry
+        # (node.py:589-632)
+        r = multiplier_factor(child.plates_multiplier, parent.plates_multiplier)
         if getattr(fam, 'deterministic', False):
+            if r != 1.0:
+                raise NotImplementedError('plate multipliers through %s are not built'
+                                          % type(child).__name__)
             m_child = self._messages_from_children(child)
             ups = self._parent_moments(child)
             mask, _ = self._mask_factor((id(child), 'self'), lambda: self._mask_array(child))
@@ -973,8 +980,11 @@ class GenericPlan:
             to_shape = parent.plates + parent.dims[i]
             if mask is not None:
                 factors.append(_trail(mask, nd))
-            out.append(misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
-                                                   from_plates=from_shape, ndim=0))
+            msg = misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
+                                              from_plates=from_shape, ndim=0)
+            if r != 1.0:
+                msg = fuse(lambda m_, r_=r: m_ * r_, msg)
+            out.append(msg)
         return out
 
     @property
@@ -1022,12 +1032,9 @@ class GenericPlan:
         return total
 
     # -- node operations -------------------------------------------------------------------------
-    def update(self, node):
-        if not isinstance(node, Stochastic):
-            return
-        st = self._ensure(node)
-        if st.observed:
-            return
+    def _optimal_phi(self, node):
+        """Natural parameters of the VB-optimal factor: prior from the parents plus the
+        messages of the children (expfamily.py:215-257)."""
         fam = self.family[id(node)]
         up = self._parent_moments(node)
         phi = fam.phi_from_parents(up)
@@ -1035,8 +1042,36 @@ class GenericPlan:
         for i in range(len(phi)):
             if msgs[i] is not None:
                 phi[i] = fuse(lambda a, b: a + b, _arr(phi[i]), msgs[i])
+        return phi
+
+    def update(self, node):
+        if not isinstance(node, Stochastic):
+            return
+        st = self._ensure(node)
+        if st.observed:
+            return
+        phi = self._optimal_phi(node)
         st.phi = phi
-        st.u, st.g = fam.moments_and_cgf(phi)
+        st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
+
+    def gradient_step(self, nodes, scale=1.0):
+        """phi <- phi + scale * (phi_optimal - phi) for all ``nodes`` at once: a step along
+        the Riemannian (natural) gradient of the lower bound (vmp.py:432-440 with
+        expfamily.py:296-340), the global update of stochastic variational inference."""
+        todo = []
+        for node in nodes:
+            if not isinstance(node, Stochastic):
+                continue
+            st = self._ensure(node)
+            if st.observed:
+                continue
+            todo.append((node, st, self._optimal_phi(node)))      # all gradients first
+        s = float(scale)
+        for node, st, opt in todo:
+            phi = [fuse(lambda p, q, s_=s: p + s_ * (q - p), _arr(p0), _arr(q0))
+                   for p0, q0 in zip(st.phi, opt)]
+            st.phi = phi
+            st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
 
     def lower_bound_contribution(self, node):
         """expfamily.py:400-480."""
@@ -1072,7 +1107,8 @@ class GenericPlan:
             # the node's term is a sum over its plates (expfamily.py:470-480): complete it
             tot = fuse(lambda x: x + 0.0, tot) if any_active else DArray.zeros(())
             self.rt.all_reduce_sum_(tot.t)
-        return tot.item()
+        # ... times the plate multiplier (expfamily.py:475,480)
+        return tot.item() * float(np.prod(node.plates_multiplier))
 
     def get_moments(self, node):
         return [np.asarray(_arr(m).numpy()) for m in self._moments(node)]

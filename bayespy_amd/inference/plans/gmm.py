@@ -100,6 +100,9 @@ class GMMPlan:
 
     @staticmethod
     def match(nodes):
+        # mini-batch multipliers (stochastic VI) go through the generic engine
+        if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
+            return None
         for Y in nodes:
             if not isinstance(Y, Mixture) or Y.node_class is not Gaussian:
                 continue

@@ -151,6 +151,9 @@ class PCAPlan:
     # -- pattern matching -----------------------------------------------------------
     @staticmethod
     def match(nodes):
+        # mini-batch multipliers (stochastic VI) go through the generic engine
+        if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
+            return None
         for Y in nodes:
             if not isinstance(Y, GaussianARD) or Y.ndim != 0:
                 continue

@@ -131,6 +131,25 @@ class VB:
                 if fin is not None:
                     fin()
 
+    def gradient_step(self, *nodes, scale=1.0):
+        """Update ``nodes`` by a step of length ``scale`` along the Riemannian gradient of the
+        lower bound (vmp.py:432-440): with mini-batch children carrying ``plates_multiplier``
+        this is the global step of stochastic variational inference
+        (demos/stochastic_inference.py:99-133); ``scale=1`` equals a simultaneous VB update."""
+        if len(nodes) == 0:
+            nodes = self.model
+        nodes = [self[n] for n in nodes]
+        by_plan = {}
+        for n in nodes:
+            p = n._plan
+            if p is None or not hasattr(p, 'gradient_step'):
+                raise NotImplementedError('gradient steps are built for the generic engine; '
+                                          'node %s is owned by %s'
+                                          % (n.name, type(p).__name__))
+            by_plan.setdefault(id(p), (p, []))[1].append(n)
+        for p, ns in by_plan.values():
+            p.gradient_step(ns, scale=scale)
+
     def has_converged(self, tol=None):
         return self.converged
 

@@ -14,8 +14,9 @@ from ..utils.shapes import broadcasted_shape
 
 class Categorical(Stochastic):
 
-    def __init__(self, p, plates=None, name=None):
+    def __init__(self, p, plates=None, name=None, plates_multiplier=None):
         super().__init__(p, plates=(), dims=((),), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         par = self.parents[0]
         if isinstance(par, Constant):
             if par.value.ndim < 1:

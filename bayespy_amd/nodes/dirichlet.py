@@ -10,8 +10,9 @@ from ..utils.shapes import broadcasted_shape
 
 class Dirichlet(Stochastic):
 
-    def __init__(self, alpha, plates=None, name=None):
+    def __init__(self, alpha, plates=None, name=None, plates_multiplier=None):
         super().__init__(alpha, plates=(), dims=((),), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         a = self.parents[0]
         if not isinstance(a, Constant):
             raise NotImplementedError('Dirichlet concentration must be a numeric constant')

@@ -12,8 +12,9 @@ from ..utils.shapes import broadcasted_shape
 class Gamma(Stochastic):
     """``Gamma(a, b, plates=(), name=...)`` -- shape a, rate b."""
 
-    def __init__(self, a, b, plates=None, name=None):
+    def __init__(self, a, b, plates=None, name=None, plates_multiplier=None):
         super().__init__(a, b, plates=(), dims=((), ()), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         pa, pb = self.parents[0].plates, self.parents[1].plates
         given = tuple(plates) if plates is not None else ()
         self.plates = broadcasted_shape(given, pa, pb)

@@ -14,8 +14,10 @@ from ..utils.shapes import broadcasted_shape
 
 class GaussianARD(Stochastic):
 
-    def __init__(self, mu, alpha, ndim=None, shape=None, plates=None, name=None):
+    def __init__(self, mu, alpha, ndim=None, shape=None, plates=None, name=None,
+                 plates_multiplier=None):
         super().__init__(mu, alpha, plates=(), dims=((), ()), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         mu_node, alpha_node = self.parents
         mu_shape = mu_node.plates + (mu_node.dims[0] if _is_gaussian(mu_node) else ())
         if shape is None:
@@ -57,8 +59,9 @@ class Gaussian(Stochastic):
     formulas gaussian.py:293-573; the joint (mu, Lambda) wrapper of the reference
     (``WrapToGaussianWishart``, gaussian.py:2374-2527) is folded into the formulas."""
 
-    def __init__(self, mu, Lambda, plates=None, name=None):
+    def __init__(self, mu, Lambda, plates=None, name=None, plates_multiplier=None):
         super().__init__(mu, Lambda, plates=(), dims=((), ()), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         from .node import Constant
         mu_node, L_node = self.parents
         if isinstance(L_node, Constant):

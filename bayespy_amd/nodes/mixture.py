@@ -11,10 +11,12 @@ from ..utils.shapes import broadcasted_shape
 
 class Mixture(Stochastic):
 
-    def __init__(self, z, node_class, *params, cluster_plate=-1, plates=None, name=None):
+    def __init__(self, z, node_class, *params, cluster_plate=-1, plates=None, name=None,
+                 plates_multiplier=None):
         if cluster_plate != -1:
             raise NotImplementedError('only cluster_plate=-1 is built')
         super().__init__(z, *params, plates=(), dims=((), ()), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         self.node_class = node_class
         self.cluster_plate = cluster_plate
         # a throw-away instance of the mixed node class gives dims and plates

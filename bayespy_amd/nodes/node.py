@@ -32,8 +32,27 @@ class Node:
         self.name = name if name else '%s_%d' % (type(self).__name__, self._uid)
         self._plan = None
         self._shard_axis = None
+        self._plates_multiplier_arg = None
         for i, p in enumerate(self.parents):
             p.children.append((self, i))
+
+    # -- plate multipliers (node.py:294-301, :403-420) -----------------------------------------
+    @property
+    def plates_multiplier(self):
+        """Per-plate-axis factors by which this node's plates stand for more replications than
+        they hold (mini-batches of stochastic variational inference): messages to parents
+        that lack the multiplier and the lower-bound term are scaled by it (node.py:589-632,
+        expfamily.py:470-480).  Default: inherited from the parents."""
+        from ..utils.shapes import multiplier_shape
+        parents = [p.plates_multiplier for p in self.parents]
+        own = self._plates_multiplier_arg
+        return multiplier_shape(own, *parents)
+
+    @plates_multiplier.setter
+    def plates_multiplier(self, value):
+        self._plates_multiplier_arg = None if value is None else tuple(value)
+        if self._plan is not None and hasattr(self._plan, 'invalidate'):
+            self._plan.invalidate(self)
 
     # -- multi-GPU: sharded plates (DESIGN.md section 6) ---------------------------------------
     def shard(self, axis=-1):

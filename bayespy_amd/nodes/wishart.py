@@ -13,8 +13,9 @@ from ..utils.shapes import broadcasted_shape
 
 class Wishart(Stochastic):
 
-    def __init__(self, n, V, plates=None, name=None):
+    def __init__(self, n, V, plates=None, name=None, plates_multiplier=None):
         super().__init__(n, V, plates=(), dims=((), ()), name=name)
+        self._plates_multiplier_arg = plates_multiplier
         n_node, V_node = self.parents
         if not isinstance(n_node, Constant) or not isinstance(V_node, Constant):
             raise NotImplementedError('Wishart parents must be numeric constants')

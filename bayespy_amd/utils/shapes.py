@@ -41,6 +41,30 @@ def prod(shape):
     return reduce(lambda a, b: a * int(b), shape, 1)
 
 
+def multiplier_shape(own, *parents):
+    """Plate multiplier of a node: its own tuple (may hold non-integers, e.g. N / N_batch)
+    broadcast against those of its parents (node.py:294-301 with _total_plates :336-360)."""
+    out = []
+    seqs = [tuple(q) for q in ((own,) if own is not None else ()) + tuple(parents)]
+    n = max([len(q) for q in seqs] or [0])
+    for j in range(1, n + 1):
+        vals = {q[-j] for q in seqs if len(q) >= j and q[-j] != 1}
+        if len(vals) > 1:
+            raise ValueError('The plate multipliers do not broadcast: %s' % (seqs,))
+        out.append(vals.pop() if vals else 1)
+    return tuple(reversed(out))
+
+
+def multiplier_factor(mult, *args):
+    """Product of the entries of ``mult`` along axes where every multiplier in ``args`` is
+    unit or missing (broadcasting_multiplier of node.py:604,625 on multiplier tuples)."""
+    r = 1.0
+    for j in range(1, len(mult) + 1):
+        if all(len(a) < j or a[-j] == 1 for a in args):
+            r *= float(mult[-j])
+    return r
+
+
 def broadcasting_multiplier(plates, *args):
     """
     Integer factor by which a sum over broadcast-compressed arrays of shapes

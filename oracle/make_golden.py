@@ -468,6 +468,45 @@ def pca_doctest_case(name):
     print(name, lines[0], '|', lines[-2], '|', lines[-1])
 
 
+def svi_case(name):
+    """Stochastic variational inference on a Gaussian mixture, the loop of
+    demos/stochastic_inference.py:85-133 with a recorded mini-batch sequence: the class node
+    carries plates_multiplier=(N/N_batch,), each step observes a mini-batch, updates the local
+    node and takes a Riemannian gradient step on the global nodes."""
+    from bayespy.nodes import GaussianARD, Gaussian, Dirichlet, Categorical, Mixture
+    from bayespy.inference import VB
+    rs = np.random.RandomState(5)
+    N, D, K, NB, steps = 600, 2, 3, 50, 8
+    centers = 4 * rs.normal(size=(K, D))
+    data = centers[rs.randint(K, size=N)] + rs.normal(size=(N, D))
+    mu0 = rs.normal(size=(K, D))
+    batches = np.array([rs.choice(N, NB) for _ in range(steps)])
+    mu = GaussianARD(0, 0.001, shape=(D,), plates=(K,), name='means')
+    alpha = Dirichlet(np.ones(K), name='class probabilities')
+    Z = Categorical(alpha, plates=(NB,), plates_multiplier=(N / NB,), name='classes')
+    Y = Mixture(Z, Gaussian, mu, np.identity(D), name='observations')
+    mu.initialize_from_value(mu0)
+    Q = VB(Y, Z, mu, alpha)
+    Q.ignore_bound_checks = True
+    out = dict(data=data, mu0=mu0, batches=batches, N=N, NB=NB)
+    Ls, mus, als = [], [], []
+    for n in range(steps):
+        Y.observe(data[batches[n], :])
+        Q.update(Z, verbose=False)
+        step = (n + 1) ** (-0.7)
+        Q.gradient_step(mu, alpha, scale=step)
+        Ls.append(Q.compute_lowerbound())
+        mus.append(np.array(mu.u[0]))
+        als.append(np.array(alpha.u[0]))
+    out['L'], out['mu_u0'], out['alpha_u0'] = np.array(Ls), np.array(mus), np.array(als)
+    out['Z_u0_last'] = np.array(Z.u[0])
+    out['L_terms_last'] = np.array([Y.lower_bound_contribution(), Z.lower_bound_contribution(),
+                                    mu.lower_bound_contribution(),
+                                    alpha.lower_bound_contribution()])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, out['L'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -484,6 +523,7 @@ def main():
     lssm_cases('lssm')
     rotation_cases('rotations')
     pca_doctest_case('pca_doctest')
+    svi_case('svi_gmm')
 
 
 if __name__ == '__main__':

@@ -220,3 +220,36 @@ def test_reference_pca_doctest_known_answer(golden_dir, engine):
     Q, nd = run_pca_doctest(nodes, VB, transformations, g,
                             engine=None if engine == 'fused' else 'generic')
     check_pca_doctest(Q, nd, g)
+
+
+def test_stochastic_variational_inference_matches_reference(golden_dir):
+    """plates_multiplier + VB.gradient_step: the mini-batch loop of
+    demos/stochastic_inference.py:99-133 against the live-reference trace (bound, global
+    moments after every step, local responsibilities of the last mini-batch)."""
+    from bayespy_amd.nodes import GaussianARD, Gaussian, Dirichlet, Categorical, Mixture
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.generic import GenericPlan
+    g = np.load(os.path.join(golden_dir, 'svi_gmm.npz'))
+    data, batches = g['data'], g['batches']
+    N, NB = int(g['N']), int(g['NB'])
+    K, D = g['mu0'].shape
+    mu = GaussianARD(0, 0.001, shape=(D,), plates=(K,), name='means')
+    alpha = Dirichlet(np.ones(K), name='class probabilities')
+    Z = Categorical(alpha, plates=(NB,), plates_multiplier=(N / NB,), name='classes')
+    Y = Mixture(Z, Gaussian, mu, np.identity(D), name='observations')
+    assert Y.plates_multiplier == (N / NB,) and mu.plates_multiplier == ()
+    mu.initialize_from_value(g['mu0'])
+    Q = VB(Y, Z, mu, alpha)
+    Q.ignore_bound_checks = True
+    assert isinstance(Q.plans[0], GenericPlan)
+    for n in range(len(batches)):
+        Y.observe(data[batches[n], :])
+        Q.update(Z, verbose=False)
+        Q.gradient_step(mu, alpha, scale=(n + 1) ** (-0.7))
+        np.testing.assert_allclose(Q.compute_lowerbound(), g['L'][n], rtol=ELBO_RTOL)
+        np.testing.assert_allclose(mu.u[0], g['mu_u0'][n], rtol=MOM_RTOL, atol=1e-10)
+        np.testing.assert_allclose(alpha.u[0], g['alpha_u0'][n], rtol=MOM_RTOL)
+    np.testing.assert_allclose(Z.u[0], g['Z_u0_last'], rtol=MOM_RTOL, atol=1e-12)
+    terms = [Y.lower_bound_contribution(), Z.lower_bound_contribution(),
+             mu.lower_bound_contribution(), alpha.lower_bound_contribution()]
+    np.testing.assert_allclose(terms, g['L_terms_last'], rtol=1e-9, atol=1e-9)
