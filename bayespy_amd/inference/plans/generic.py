@@ -1113,6 +1113,44 @@ class GenericPlan:
     def get_moments(self, node):
         return [np.asarray(_arr(m).numpy()) for m in self._moments(node)]
 
+    # -- persistence (stochastic.py:305-355, expfamily.py:507-535) ------------------------------
+    def save_state(self, put, nodes, index):
+        for node in nodes:
+            if not isinstance(node, Stochastic):
+                continue
+            st = self._ensure(node)
+            base = 'nodes/%s/' % node.name
+            for i, ui in enumerate(st.u):
+                put(base + 'u%d' % i, _arr(ui).numpy())
+            if st.phi is not None:
+                for i, pi in enumerate(st.phi):
+                    put(base + 'phi%d' % i, _arr(pi).numpy())
+            put(base + 'f', 0.0 if st.f is None else (_arr(st.f).numpy() if isinstance(st.f, DArray)
+                                                     else np.asarray(st.f, dtype=np.float64)))
+            put(base + 'g', np.inf if st.g is None else (
+                _arr(st.g).numpy() if isinstance(st.g, DArray) else np.asarray(st.g, dtype=np.float64)))
+            put(base + 'observed', bool(st.observed))
+
+    def load_state(self, reader, nodes, index):
+        for node in nodes:
+            if not isinstance(node, Stochastic):
+                continue
+            base = 'nodes/%s/' % node.name
+            if not reader.has(base + 'u0'):
+                raise Exception("File does not contain variable %s" % node.name)
+            st = self._ensure(node)
+            if bool(reader.get(base + 'observed')) != bool(st.observed):
+                raise ValueError('node %s: the file and the model disagree on whether it is '
+                                 'observed' % node.name)
+            st.u = [DArray.from_host(np.array(reader.get(base + 'u%d' % i), dtype=np.float64))
+                    for i in range(len(st.u))]
+            if not st.observed:
+                st.phi = [DArray.from_host(np.array(reader.get(base + 'phi%d' % i),
+                                                    dtype=np.float64))
+                          for i in range(len(node.dims))]
+                g = np.array(reader.get(base + 'g'), dtype=np.float64)
+                st.g = float(g) if (g.ndim == 0 and not np.isfinite(g)) else DArray.from_host(g)
+
     # -- rotations (inference/transformations.py) ------------------------------------------------
     def gamma_posterior_shape(self, node):
         st = self._ensure(node)

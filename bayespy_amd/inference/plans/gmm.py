@@ -270,6 +270,29 @@ class GMMPlan:
         n = int(np.prod(shape))
         return self.state[off:off + n].cpu().numpy().reshape(shape).copy()
 
+    # -- persistence: the packed device state + responsibilities ------------------------------------
+    def save_state(self, put, nodes, index):
+        self._materialize()
+        base = 'plans/%d/' % index
+        put(base + 'kind', np.array([ord(c) for c in 'gmm'], dtype=np.uint8))
+        put(base + 'dims', np.array([self.N, self.D, self.K], dtype=np.int64))
+        put(base + 'state', self.state.cpu().numpy())
+        put(base + 'R', self.Rd.cpu().numpy())
+
+    def load_state(self, reader, nodes, index):
+        self._materialize()
+        base = 'plans/%d/' % index
+        if not reader.has(base + 'state'):
+            raise Exception("File does not contain the state of the fused mixture block")
+        dims = tuple(int(v) for v in reader.get(base + 'dims'))
+        if dims != (self.N, self.D, self.K):
+            raise ValueError('checkpoint is for (N, D, K) = %s, the model has %s'
+                             % (dims, (self.N, self.D, self.K)))
+        torch = self.rt.torch
+        self.state.copy_(torch.from_numpy(np.array(reader.get(base + 'state'), dtype=np.float64)))
+        self.Rd.copy_(torch.from_numpy(np.array(reader.get(base + 'R'), dtype=np.float64)))
+        self._version += 1
+
     def get_moments(self, node):
         self._materialize()
         L, D, K = self.layout, self.D, self.K

@@ -470,6 +470,38 @@ class PCAPlan:
                     self._block(L.off_CX, K, K, KP))
         raise NotImplementedError
 
+    # -- persistence: the packed device state + <x_n>; node moments for inspection -----------------
+    def save_state(self, put, nodes, index):
+        self._materialize()
+        self.finish()
+        base = 'plans/%d/' % index
+        put(base + 'kind', np.array([ord(c) for c in 'pca'], dtype=np.uint8))
+        put(base + 'dims', np.array([self.D, self.N, self.K], dtype=np.int64))
+        put(base + 'state', self.state.cpu().numpy())
+        put(base + 'X', self.Xd[:, :self.N].cpu().numpy())
+        for node in nodes:
+            if node in (self.W, self.tau, self.alpha):
+                for i, ui in enumerate(self.get_moments(node)):
+                    put('nodes/%s/u%d' % (node.name, i), ui)
+                put('nodes/%s/observed' % node.name, False)
+
+    def load_state(self, reader, nodes, index):
+        self._materialize()
+        self.finish()
+        base = 'plans/%d/' % index
+        if not reader.has(base + 'state'):
+            raise Exception("File does not contain the state of the fused PCA block")
+        dims = tuple(int(v) for v in reader.get(base + 'dims'))
+        if dims != (self.D, self.N, self.K):
+            raise ValueError('checkpoint is for (D, N, K) = %s, the model has %s'
+                             % (dims, (self.D, self.N, self.K)))
+        torch = self.rt.torch
+        st = np.array(reader.get(base + 'state'), dtype=np.float64)
+        self.state.copy_(torch.from_numpy(st))
+        self.Xd[:, :self.N].copy_(torch.from_numpy(np.array(reader.get(base + 'X'),
+                                                           dtype=np.float64)))
+        self._version += 1
+
     # -- rotations (inference/transformations.py) ----------------------------------------------------
     def gamma_posterior_shape(self, node):
         return self.get_parameters(node)[0]

@@ -51,8 +51,10 @@ class VB:
         for i, n in enumerate(nodes):
             if not isinstance(n, Node):
                 raise ValueError("Argument number %d is not a node" % (i + 1))
-        if autosave_filename or autosave_iterations:
-            raise NotImplementedError('HDF5 autosave (vmp.py:237-356) is outside the hot path')
+        self.autosave_filename = autosave_filename
+        self.autosave_iterations = int(autosave_iterations or 0)
+        if self.autosave_iterations and not autosave_filename:
+            raise ValueError('autosave_iterations needs autosave_filename')
         if use_logging:
             import logging
             self.print = logging.getLogger(__name__).info
@@ -123,6 +125,8 @@ class VB:
                     tqdm.update()
                 if self._end_iteration_step(None, cputime, tol=tol, verbose=verbose):
                     return
+                if self.autosave_iterations and self.iter % self.autosave_iterations == 0:
+                    self.save()
         finally:
             # plans may keep plate-sized work in flight on their own streams across
             # iterations; order the caller's stream after it before handing back control
@@ -130,6 +134,64 @@ class VB:
                 fin = getattr(p, 'finish', None)
                 if fin is not None:
                     fin()
+
+    # -- persistence (vmp.py:237-356) ------------------------------------------------------
+    def save(self, *nodes, filename=None):
+        """Write the state of ``nodes`` (default: all) and the iteration statistics; device
+        state is read back once.  Layout: inference/checkpoint.py."""
+        from .checkpoint import Writer
+        nodes = [self[n] for n in nodes if n is not None] if nodes else list(self.model)
+        filename = filename or self.autosave_filename
+        if not filename:
+            raise Exception("Filename must be given.")
+        names = [n.name for n in nodes]
+        if len(set(names)) != len(names) or any(nm == '' for nm in names):
+            raise Exception("In order to save nodes, they must have (unique) names.")
+        w = Writer(filename)
+        seen = []
+        for n in nodes:
+            p = n._plan
+            if p is None or any(p is q for q in seen):
+                continue
+            seen.append(p)
+            p.save_state(lambda path, v: w.put(path, v), [m for m in nodes if m._plan is p],
+                         len(seen) - 1)
+        w.put('L', self.L)
+        w.put('cputime', self.cputime)
+        w.put('iter', self.iter)
+        w.put('converged', bool(self.converged))
+        if self.callback_output is not None:
+            w.put('callback_output', self.callback_output)
+        for n in nodes:
+            w.put('boundterms/' + n.name, self.l[n])
+        w.close()
+
+    def load(self, *nodes, filename=None, nodes_only=False):
+        from .checkpoint import Reader
+        nodes = [self[n] for n in nodes if n is not None] if nodes else list(self.model)
+        filename = filename or self.autosave_filename
+        if not filename:
+            raise Exception("Filename must be given.")
+        r = Reader(filename)
+        try:
+            seen = []
+            for n in nodes:
+                p = n._plan
+                if p is None or any(p is q for q in seen):
+                    continue
+                seen.append(p)
+                p.load_state(r, [m for m in nodes if m._plan is p], len(seen) - 1)
+            if not nodes_only:
+                self.L = np.array(r.get('L'))
+                self.cputime = np.array(r.get('cputime'))
+                self.iter = int(r.get('iter'))
+                self.converged = bool(r.get('converged'))
+                for n in nodes:
+                    self.l[n] = np.array(r.get('boundterms/' + n.name))
+                if r.has('callback_output'):
+                    self.callback_output = np.array(r.get('callback_output'))
+        finally:
+            r.close()
 
     def gradient_step(self, *nodes, scale=1.0):
         """Update ``nodes`` by a step of length ``scale`` along the Riemannian gradient of the

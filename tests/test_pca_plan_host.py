@@ -92,6 +92,31 @@ def test_reference_pca_doctest_known_answer(golden_dir):
     check_pca_doctest(Q, nd, g)
 
 
+def test_checkpoint_round_trip(golden_dir, tmp_path):
+    """VB.save / VB.load (vmp.py:237-356): a restored model continues bit-for-bit."""
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.update(repeat=2, verbose=False)
+    fn = str(tmp_path / 'ckpt.bin')
+    Q.save(filename=fn)
+    Q.update(repeat=3, verbose=False)
+    Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q2.load(filename=fn)
+    assert Q2.iter == 2 and np.array_equal(Q2.L[:2], Q.L[:2])
+    Q2.update(repeat=3, verbose=False)
+    assert np.array_equal(Q2.L[:5], Q.L[:5])
+    np.testing.assert_array_equal(Q2['W'].u[0], Q['W'].u[0])
+    np.testing.assert_array_equal(Q2['X'].u[0], Q['X'].u[0])
+    with pytest.raises(Exception, match='Filename'):
+        Q.save()
+    # autosave every second iteration writes the same container
+    fn2 = str(tmp_path / 'auto.bin')
+    Q3 = build_pca(nodes, VB, g['y'], g['x0'], 3, autosave_filename=fn2, autosave_iterations=2)
+    _attach_cpu(Q3)
+    Q3.update(repeat=2, verbose=False)
+    assert os.path.exists(fn2)
+
+
 def test_lower_bound_cache_and_observed_skip(golden_dir):
     g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
