@@ -309,7 +309,7 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
                  const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
                  int64_t tile0, int64_t tile1)
 {
-    constexpr int DP = 32 * DB, KP = 16 * KT;
+    constexpr int DP = 32 * DB;
     constexpr int KS = DP / 4;                 // MFMA k-steps per tile
     constexpr int NCH = (DB < 2) ? 2 : DB;     // chunks per tile (even)
     constexpr int CH = KS / NCH;               // k-steps per chunk

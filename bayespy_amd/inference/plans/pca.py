@@ -391,6 +391,14 @@ class PCAPlan:
         if getattr(self, 'Xd', None) is not None and self.stats == 'gram':
             self.kernels.xjoin()
 
+    def __del__(self):
+        # the plate array must not return to the allocator while a pass still writes it
+        try:
+            if getattr(self, 'Xd', None) is not None and self.stats == 'gram':
+                self.kernels.xjoin()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
     def _lower_bound_terms(self):
         self._materialize()
         if self._L_version != self._version:
