@@ -283,6 +283,7 @@ class PCAPlan:
             self.ldy = ldy
         self.ldx = (N + 1) // 2 * 2
         self.state = rt.zeros(int(L.total))
+        self._scal_host = None
         self.ws = rt.empty(int(k.workspace_doubles(D, K)))
         k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)
         k.syy(self.Yd, self.ldy, N, D, K, self.state, self.ws)
@@ -348,13 +349,13 @@ class PCAPlan:
     def update(self, node):
         self._materialize()
         rt, k, L = self.rt, self.kernels, self.layout
-        rt.sync_stream()
         D, N, K = self.D, self.N, self.K
         if node is self.W:
             self._pending.append(OP_W)
         elif node is self.X:
             self._pending.append(OP_XPREP)
             self._flush()
+            rt.sync_stream()
             if self.stats == 'gram':
                 # messages to W from the global Gram matrix: nothing to exchange
                 k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
@@ -399,13 +400,27 @@ class PCAPlan:
         except Exception:       # noqa: BLE001 - interpreter shutdown
             pass
 
+    def _read_scalars(self):
+        """state[off_scal : off_L + 8] -> host through a pinned staging buffer (this read-back
+        sits on the critical path of every iteration)."""
+        L = self.layout
+        if self.rt.device.type != 'cuda':
+            return self.state[L.off_scal:L.off_L + 8].numpy().copy()
+        if getattr(self, '_scal_host', None) is None:
+            self._scal_view = self.state[L.off_scal:L.off_L + 8]
+            self._scal_host = self.rt.torch.empty(self._scal_view.numel(),
+                                                  dtype=self.rt.torch.float64, pin_memory=True)
+        self._scal_host.copy_(self._scal_view, non_blocking=True)
+        self.rt.torch.cuda.current_stream(self.rt.device).synchronize()
+        return self._scal_host.numpy()
+
     def _lower_bound_terms(self):
         self._materialize()
         if self._L_version != self._version:
             L = self.layout
             self._pending.append(OP_ELBO)
             self._flush()
-            host = self.state[L.off_scal:L.off_L + 8].cpu().numpy()
+            host = self._read_scalars()
             status = int(host[3])
             if status != 0:
                 _lib.raise_for_status(status)
