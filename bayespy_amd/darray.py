@@ -217,6 +217,33 @@ def _strides(t, shape):
     return st
 
 
+_PROGRAMS = {}
+
+
+def _program_key(fn, kinds):
+    """Cache key of a traced formula: its code, default arguments, the numbers it closes over
+    and which operands are arrays / which constant values were passed; None = do not cache."""
+    try:
+        cells = tuple(c.cell_contents for c in (fn.__closure__ or ()))
+        if not all(isinstance(v, numbers.Number) for v in cells):
+            return None
+        key = (fn.__code__, fn.__defaults__, cells, kinds)
+        hash(key)
+        return key
+    except (AttributeError, TypeError, ValueError):
+        return None
+
+
+def _compile(fn, leaves):
+    expr = Expr.wrap(fn(*leaves))
+    if _depth(expr) > 4:
+        raise ValueError('fused expression needs a stack deeper than 4; split it')
+    ops, consts = [], []
+    _emit(expr, ops, consts)
+    return ((ctypes.c_int32 * len(ops))(*ops), len(ops),
+            (ctypes.c_double * max(len(consts), 1))(*consts), len(consts))
+
+
 def fuse(fn, *operands):
     """
     Evaluate the elementwise formula ``fn(*operands)`` in ONE kernel launch.
@@ -225,22 +252,27 @@ def fuse(fn, *operands):
     """
     from .utils.shapes import broadcasted_shape
     rt = get_runtime()
-    arrays, leaves = [], []
+    arrays, leaves, kinds = [], [], []
     for x in operands:
         if isinstance(x, DArray):
             leaves.append(Expr('in', val=len(arrays)))
             arrays.append(x)
+            kinds.append(None)
         elif is_scalar(x):
             leaves.append(Expr('const', val=float(x)))
+            kinds.append(float(x))
         else:
             leaves.append(Expr('in', val=len(arrays)))
             arrays.append(DArray.from_host(x))
-    expr = Expr.wrap(fn(*leaves))
-    if _depth(expr) > 4:
-        raise ValueError('fused expression needs a stack deeper than 4; split it')
-    ops, consts = [], []
-    _emit(expr, ops, consts)
-    if len(ops) > MAX_OPS or len(consts) > MAX_CONSTS or len(arrays) > MAX_IN:
+            kinds.append(None)
+    key = _program_key(fn, tuple(kinds))
+    prog = _PROGRAMS.get(key) if key is not None else None
+    if prog is None:
+        prog = _compile(fn, leaves)
+        if key is not None and len(_PROGRAMS) < 4096:
+            _PROGRAMS[key] = prog
+    c_ops, nops, c_consts, nconsts = prog
+    if nops > MAX_OPS or nconsts > MAX_CONSTS or len(arrays) > MAX_IN:
         raise ValueError('fused expression too large for one launch')
     shape = broadcasted_shape(*[a.shape for a in arrays]) if arrays else ()
     if len(shape) > MAX_DIMS:
@@ -253,11 +285,9 @@ def fuse(fn, *operands):
     for a in arrays:
         flat += _strides(a.t, shape)
     c_str = (ctypes.c_int64 * max(len(flat), 1))(*flat)
-    c_ops = (ctypes.c_int32 * len(ops))(*ops)
-    c_consts = (ctypes.c_double * max(len(consts), 1))(*consts)
     rt.sync_stream()
-    rt.check(rt.lib.vmp_ewise(rt.ctx, nd, c_shape, nin, c_in, c_str, len(ops), c_ops,
-                              len(consts), c_consts, ctypes.c_void_p(out.t.data_ptr())))
+    rt.check(rt.lib.vmp_ewise(rt.ctx, nd, c_shape, nin, c_in, c_str, nops, c_ops,
+                              nconsts, c_consts, ctypes.c_void_p(out.t.data_ptr())))
     return out
 
 

@@ -32,6 +32,8 @@ class Runtime:
             self.device = torch.device(device)
         self.lib = None
         self.ctx = None
+        self._op_depth = 0
+        self._deferred = []
         if self.device.type == 'cuda':
             self.lib = _lib.load()
             ctx = ctypes.c_void_p()
@@ -98,14 +100,61 @@ class Runtime:
             _lib.raise_for_status(rc, msg)
 
     def sync_stream(self):
-        """Point the context at torch's current stream (cheap; call before launches)."""
-        if self.ctx is not None:
+        """Point the context at torch's current stream before launches.  Inside a plan
+        operation (``with rt.operation():``) the lookup is done once at entry, not per launch."""
+        if self.ctx is not None and self._op_depth == 0:
             s = self.torch.cuda.current_stream(self.device).cuda_stream
             self.lib.vmp_ctx_set_stream(self.ctx, ctypes.c_void_p(s))
+
+    def operation(self):
+        """Context of one plan-level operation (a node update, a lower-bound term): the stream
+        is resolved once, and validity checks that would need a device->host read each
+        (positive definiteness, positivity of natural parameters) are queued on the device and
+        read together by :meth:`check_deferred` -- at the latest when the operation ends."""
+        return _Operation(self)
+
+    def defer_check(self, flag_tensor, exc_type, message):
+        """``flag_tensor``: device tensor, any non-zero element means failure."""
+        if self._op_depth == 0:
+            if bool(flag_tensor.any().item()):
+                raise exc_type(message)
+            return
+        self._deferred.append((flag_tensor.any().reshape(1), exc_type, message))
+
+    def check_deferred(self):
+        if not self._deferred:
+            return
+        items, self._deferred = self._deferred, []
+        flags = self.torch.cat([f for f, _, _ in items]).cpu().numpy()
+        for bad, (_, exc_type, message) in zip(flags, items):
+            if bad:
+                raise exc_type(message)
 
     def synchronize(self):
         if self.device.type == 'cuda':
             self.torch.cuda.synchronize(self.device)
+
+
+class _Operation:
+    def __init__(self, rt):
+        self.rt = rt
+
+    def __enter__(self):
+        rt = self.rt
+        if rt._op_depth == 0:
+            rt.sync_stream()
+        rt._op_depth += 1
+        return rt
+
+    def __exit__(self, exc_type, exc, tb):
+        rt = self.rt
+        rt._op_depth -= 1
+        if rt._op_depth == 0:
+            if exc_type is None:
+                rt.check_deferred()
+            else:
+                rt._deferred = []
+        return False
 
 
 _runtime = None

@@ -56,13 +56,34 @@ def _trail(x, n):
     return x.reshape(x.shape + (1,) * n)
 
 
+_CONSTS = {}
+
+
+def _const(key, make):
+    """Small read-only device constants (ones, identities, ...) are uploaded once."""
+    from ...device import get_runtime
+    k = (id(get_runtime()),) + key
+    if k not in _CONSTS:
+        _CONSTS[k] = DArray.from_host(make())
+    return _CONSTS[k]
+
+
 def _ones(shape):
-    return DArray.from_host(np.ones(shape))
+    shape = tuple(shape)
+    return _const(('ones', shape), lambda: np.ones(shape))
 
 
 def _eye(shape):
+    shape = tuple(shape)
     n = int(np.prod(shape)) if len(shape) else 1
-    return DArray.from_host(np.eye(n).reshape(tuple(shape) + tuple(shape)))
+    return _const(('eye', shape), lambda: np.eye(n).reshape(shape + shape))
+
+
+def _check_device(x, bad, exc_type, message):
+    """Raise ``exc_type(message)`` if ``bad(x)`` holds anywhere -- evaluated on the device and
+    read with the other checks of the running plan operation (device.Runtime.defer_check)."""
+    from ...device import get_runtime
+    get_runtime().defer_check(bad(_arr(x).t), exc_type, message)
 
 
 def _sum_last(x, n):
@@ -71,7 +92,7 @@ def _sum_last(x, n):
 
 def _multigammaln(a, d):
     """log Gamma_d(a) (scipy.special.multigammaln call site wishart.py:187)."""
-    half = DArray.from_host(0.5 * np.arange(d))
+    half = _const(('half_arange', int(d)), lambda: 0.5 * np.arange(d))
     t = fuse(lambda x, h: da.gammaln(x - h), _trail(_arr(a), 1), half)
     return fuse(lambda s: s + d * (d - 1) / 4.0 * np.log(np.pi), misc.sum_multiply(t, axis=-1))
 
@@ -117,8 +138,7 @@ class GammaFamily(Family):
 
     def fixed_moments_and_f(self, x):
         x = _arr(x)
-        if np.any(np.asarray(x.numpy()) < 0):
-            raise ValueError("Values must be positive")
+        _check_device(x, lambda t: t < 0, ValueError, "Values must be positive")
         logx = fuse(lambda v: da.log(v), x)
         return [x, logx], fuse(lambda l: -l, logx)
 
@@ -324,8 +344,7 @@ class DirichletFamily(Family):
 
     def moments_and_cgf(self, phi):
         p = _arr(phi[0])
-        if np.any(p.numpy() <= 0):
-            raise ValueError("Natural parameters should be positive")
+        _check_device(p, lambda t: t <= 0, ValueError, "Natural parameters should be positive")
         s = misc.sum_multiply(p, axis=-1, keepdims=True)
         u0 = fuse(lambda a, t: da.digamma(a) - da.digamma(t), p, s)
         lg = misc.sum_multiply(fuse(lambda a: da.gammaln(a), p), axis=-1)
@@ -768,6 +787,18 @@ class _State:
         self.ready = False
 
 
+def _operation(method):
+    """Run a plan-level operation inside Runtime.operation() (one stream lookup, validity
+    checks read back together at the end)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with self.rt.operation():
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 class GenericPlan:
 
     @staticmethod
@@ -1044,6 +1075,7 @@ class GenericPlan:
                 phi[i] = fuse(lambda a, b: a + b, _arr(phi[i]), msgs[i])
         return phi
 
+    @_operation
     def update(self, node):
         if not isinstance(node, Stochastic):
             return
@@ -1054,6 +1086,7 @@ class GenericPlan:
         st.phi = phi
         st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
 
+    @_operation
     def gradient_step(self, nodes, scale=1.0):
         """phi <- phi + scale * (phi_optimal - phi) for all ``nodes`` at once: a step along
         the Riemannian (natural) gradient of the lower bound (vmp.py:432-440 with
@@ -1073,6 +1106,7 @@ class GenericPlan:
             st.phi = phi
             st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
 
+    @_operation
     def lower_bound_contribution(self, node):
         """expfamily.py:400-480."""
         if not isinstance(node, Stochastic):
@@ -1156,6 +1190,7 @@ class GenericPlan:
         st = self._ensure(node)
         return np.asarray(_arr(st.phi[1]).numpy())
 
+    @_operation
     def rotation_statistics(self, node):
         """sum over the plates of <x x^T> (K x K) and the plate count of a vector GaussianARD."""
         if not isinstance(node, GaussianARD) or node.ndim != 1:
@@ -1171,6 +1206,7 @@ class GenericPlan:
             nplates = float(self.rt.all_reduce_int(int(nplates)))
         return dict(XX=np.asarray(xx.numpy()), nplates=nplates)
 
+    @_operation
     def rotate_node(self, node, R, invR, logdetR):
         """q(node) <- distribution of R x: phi0 <- R^-T phi0, phi1 <- R^-T phi1 R^-1,
         u0 <- R u0, u1 <- R u1 R^T, g <- g - log|det R|  (gaussian.py:1693-1741)."""

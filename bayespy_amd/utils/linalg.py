@@ -43,9 +43,9 @@ class CholFactor:
                                         ctypes.c_void_p(inv.t.data_ptr()),
                                         ctypes.c_void_p(logdet.t.data_ptr()),
                                         ctypes.c_void_p(info.data_ptr())))
-        if bool(info.any().item()):
-            # same failure the reference reports (utils/linalg.py:58-59)
-            raise _lib.NotPositiveDefiniteError("Matrix not positive definite")
+        # same failure the reference reports (utils/linalg.py:58-59); inside a plan
+        # operation the flag is read together with the operation's other checks
+        rt.defer_check(info, _lib.NotPositiveDefiniteError, "Matrix not positive definite")
         self._inv, self._logdet = inv, logdet
 
 

@@ -276,10 +276,21 @@ def normalized_exp(phi):
     return p, lse
 
 
+_HALF_ARANGE = {}
+
+
+def _half_arange(d):
+    """0.5 * arange(d) on the device, uploaded once per runtime."""
+    key = (id(get_runtime()), d)
+    if key not in _HALF_ARANGE:
+        _HALF_ARANGE[key] = DArray.from_host(0.5 * np.arange(d))
+    return _HALF_ARANGE[key]
+
+
 def multidigamma(a, d):
     """sum_{i<d} digamma(a - i/2)  (utils/misc.py:1146-1151)."""
     a = asdarray(a)
-    half = DArray.from_host(0.5 * np.arange(d))
+    half = _half_arange(int(d))
     terms = fuse(lambda x, h: _digamma(x - h), a.reshape(a.shape + (1,)), half)
     return sum_multiply(terms, axis=-1)
 
