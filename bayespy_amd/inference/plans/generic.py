@@ -1106,11 +1106,11 @@ class GenericPlan:
             st.phi = phi
             st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
 
-    @_operation
-    def lower_bound_contribution(self, node):
-        """expfamily.py:400-480."""
+    def _lower_bound_device(self, node):
+        """The node's lower-bound term (expfamily.py:400-480) as (device scalar | None,
+        host factor): no device->host read here."""
         if not isinstance(node, Stochastic):
-            return 0.0
+            return None, 0.0
         st = self._ensure(node)
         fam = self.family[id(node)]
         up = self._parent_moments(node)
@@ -1120,7 +1120,7 @@ class GenericPlan:
             L = fuse(lambda a, b: a + b, L, st.f if isinstance(st.f, DArray) else float(st.f))
         else:
             if not isinstance(st.g, DArray):
-                return float(-np.inf) if np.isinf(st.g) else float('nan')
+                return None, (float(-np.inf) if np.isinf(st.g) else float('nan'))
             L = fuse(lambda a, g: a - g, L, st.g)
         for i, nd in enumerate(len(d) for d in node.dims):
             if st.observed:
@@ -1135,14 +1135,27 @@ class GenericPlan:
             factors.append(mask)
         sharded = self._is_sharded(node)
         if not any_active and not sharded:
-            return 0.0
+            return None, 0.0
         tot = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
         if sharded:
             # the node's term is a sum over its plates (expfamily.py:470-480): complete it
             tot = fuse(lambda x: x + 0.0, tot) if any_active else DArray.zeros(())
             self.rt.all_reduce_sum_(tot.t)
         # ... times the plate multiplier (expfamily.py:475,480)
-        return tot.item() * float(np.prod(node.plates_multiplier))
+        return tot, float(np.prod(node.plates_multiplier))
+
+    @_operation
+    def lower_bound_contribution(self, node):
+        tot, factor = self._lower_bound_device(node)
+        return factor if tot is None else tot.item() * factor
+
+    @_operation
+    def lower_bound_contributions(self, nodes):
+        """Terms of several nodes with ONE device->host read (VB.loglikelihood_lowerbound)."""
+        parts = [self._lower_bound_device(n) for n in nodes]
+        dev = [t.t.reshape(1) for t, _ in parts if t is not None]
+        vals = iter(self.rt.torch.cat(dev).cpu().numpy() if dev else ())
+        return [f if t is None else float(next(vals)) * f for t, f in parts]
 
     def get_moments(self, node):
         return [np.asarray(_arr(m).numpy()) for m in self._moments(node)]

@@ -225,9 +225,20 @@ class VB:
         return {n: n.lower_bound_contribution() for n in nodes}
 
     def loglikelihood_lowerbound(self):
+        # nodes of one plan are asked together so that a plan can answer with a single
+        # device -> host read; the sum runs in model order like vmp.py:192-199
+        terms = {}
+        groups = {}
+        for n in self.model:
+            p = n._plan
+            if p is not None and hasattr(p, 'lower_bound_contributions'):
+                groups.setdefault(id(p), (p, []))[1].append(n)
+        for p, ns in groups.values():
+            for n, v in zip(ns, p.lower_bound_contributions(ns)):
+                terms[n] = v
         L = 0.0
         for n in self.model:
-            lp = n.lower_bound_contribution()
+            lp = terms[n] if n in terms else n.lower_bound_contribution()
             L += lp
             self.l[n][self.iter] = lp
         return L
