@@ -108,6 +108,7 @@ SIGNATURES = {
     'vmp_ewise': (c_i32, [c_vp, c_i32, P(c_i64), c_i32, P(c_vp), P(c_i64), c_i32, P(c_i32),
                           c_i32, P(c_f64), c_vp]),
     'vmp_spd_batched': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_gaussian_moments': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_softmax_moments': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_onehot_i64': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_gemm_strided': (c_i32, [c_vp, c_i32, P(c_i64), c_i64, c_i64, c_i64, c_vp, P(c_i64), c_i64,

@@ -459,10 +459,50 @@ __device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double *r
     }
 }
 
-template <int NP, int NTB>
+// x_i = sum_P m[P] * v_P and friends: every lane of the group needs the value held by
+// lane P, for all P (static unrolling: the DPP control is an immediate)
+template <int NP, int P>
+__device__ __forceinline__ void rows_matvec(const double (&m)[NP], double v, double *rowbuf, int gl,
+                                            double &acc)
+{
+    if constexpr (P < NP) {
+        acc += m[P] * group_bcast<NP, P>(v, rowbuf, 0, gl);
+        if constexpr (NP != 16) lds_fence();
+        rows_matvec<NP, P + 1>(m, v, rowbuf, gl, acc);
+    }
+}
+
+template <int NP, int P>
+__device__ __forceinline__ void rows_rank1(double (&m)[NP], double xi, double *rowbuf, int gl)
+{
+    if constexpr (P < NP) {
+        m[P] += xi * group_bcast<NP, P>(xi, rowbuf, 0, gl);
+        if constexpr (NP != 16) lds_fence();
+        rows_rank1<NP, P + 1>(m, xi, rowbuf, gl);
+    }
+}
+
+template <int NP, int P>
+__device__ __forceinline__ void rows_sum(double v, double *rowbuf, int gl, double &acc)
+{
+    if constexpr (P < NP) {
+        acc += group_bcast<NP, P>(v, rowbuf, 0, gl);
+        if constexpr (NP != 16) lds_fence();
+        rows_sum<NP, P + 1>(v, rowbuf, gl, acc);
+    }
+}
+
+// MOMENTS = false: A -> A^-1, log|A| (vmp_spd_batched).
+// MOMENTS = true : natural parameters (phi0 = `rhs`, phi1 = `A`) of a Gaussian with full
+// covariance per plate -> moments and log-normaliser in the same pass
+// (GaussianARDDistribution.compute_moments_and_cgf, gaussian.py:680-706):
+//   Cov = (-2 phi1)^-1 ; u0 = Cov phi0 ; u1 = u0 u0^T + Cov ; g = -1/2 u0.phi0 + 1/2 log|-2 phi1|
+// with u0 -> `vec_out`, u1 -> `Ainv`, g -> `logdet`.
+template <int NP, int NTB, bool MOMENTS>
 __global__ void __launch_bounds__(NTB)
 spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
-                        double *__restrict__ Ainv, double *__restrict__ logdet,
+                        const double *__restrict__ rhs, double *__restrict__ Ainv,
+                        double *__restrict__ vec_out, double *__restrict__ logdet,
                         int32_t *__restrict__ info)
 {
     constexpr int MPW = 64 / NP;             // matrices per wavefront
@@ -485,14 +525,27 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
         const int mb = w * MPW + g;
         const bool act = mb < nb;
         double *M = Ms + mb * NP * LDP;
+        double *rowbuf = rows + (w * MPW + g) * NP;
+        constexpr double SC = MOMENTS ? -1.0 : 0.5;      // -2 phi1, symmetrised / symmetrise
         double m[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            m[j] = (act && gl < n && j < n) ? 0.5 * (M[gl * LDP + j] + M[j * LDP + gl])
+            m[j] = (act && gl < n && j < n) ? SC * (M[gl * LDP + j] + M[j * LDP + gl])
                                             : ((gl == j) ? 1.0 : 0.0);
         double ld = 0.0, prod = 1.0;
         int bad = 0;
-        gj_rows_steps<NP, 0>(m, gl, rows + (w * MPW + g) * NP, prod, ld, bad);
+        gj_rows_steps<NP, 0>(m, gl, rowbuf, prod, ld, bad);
+        double lg = logdet_finish(prod, ld);
+        if constexpr (MOMENTS) {
+            const double p0 = (act && gl < n) ? rhs[(b0 + mb) * n + gl] : 0.0;
+            double x = 0.0;
+            rows_matvec<NP, 0>(m, p0, rowbuf, gl, x);
+            double s = 0.0;
+            rows_sum<NP, 0>(x * p0, rowbuf, gl, s);
+            rows_rank1<NP, 0>(m, x, rowbuf, gl);
+            if (act && gl < n) vec_out[(b0 + mb) * n + gl] = x;
+            lg = -0.5 * s + 0.5 * lg;
+        }
         __syncthreads();
         if (act && gl < n) {
 #pragma unroll
@@ -500,7 +553,7 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
                 if (j < n) M[gl * LDP + j] = m[j];
         }
         if (act && gl == 0) {
-            if (logdet) logdet[b0 + mb] = logdet_finish(prod, ld);
+            if (logdet) logdet[b0 + mb] = lg;
             if (info) info[b0 + mb] = bad;
         }
         __syncthreads();
@@ -766,17 +819,39 @@ int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A,
     if (batch == 0) return VMP_OK;
     const int64_t big = 4 * (int64_t)ctx->num_cu;      // enough matrices to fill the chip row-wise
     if (n > 8 && n <= 16 && batch >= big)
-        hipLaunchKernelGGL((spd_batched_rows_kernel<16, 256>),
-                           dim3((unsigned)grid_for(ctx, batch, 16)), dim3(256), 0, ctx->stream, n, batch, A, Ainv, logdet, info);
+        hipLaunchKernelGGL((spd_batched_rows_kernel<16, 256, false>),
+                           dim3((unsigned)grid_for(ctx, batch, 16)), dim3(256), 0, ctx->stream, n,
+                           batch, A, nullptr, Ainv, nullptr, logdet, info);
     else if (n > 16 && n <= 32 && batch >= big)
-        hipLaunchKernelGGL((spd_batched_rows_kernel<32, 128>),
-                           dim3((unsigned)grid_for(ctx, batch, 4)), dim3(128), 0, ctx->stream, n, batch, A, Ainv, logdet, info);
+        hipLaunchKernelGGL((spd_batched_rows_kernel<32, 128, false>),
+                           dim3((unsigned)grid_for(ctx, batch, 4)), dim3(128), 0, ctx->stream, n,
+                           batch, A, nullptr, Ainv, nullptr, logdet, info);
     else if (n <= 8)
         hipLaunchKernelGGL(spd_batched_wave_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(NT), 0,
                            ctx->stream, n, batch, A, Ainv, logdet, info);
     else
         hipLaunchKernelGGL(spd_batched_block_kernel, dim3((unsigned)batch), dim3(NT), 0,
                            ctx->stream, n, batch, A, Ainv, logdet, info);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_gaussian_moments(vmp_ctx *ctx, int32_t n, int64_t batch, const double *phi0,
+                             const double *phi1, double *u0, double *u1, double *g, int32_t *info)
+{
+    VMP_REQUIRE(ctx, ctx && phi0 && phi1 && u0 && u1 && g, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, batch >= 0, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, n > 8 && n <= 32, VMP_ERR_UNSUPPORTED,
+                "fused Gaussian moments are built for 8 < n <= 32 (got %d)", n);
+    if (batch == 0) return VMP_OK;
+    if (n <= 16)
+        hipLaunchKernelGGL((spd_batched_rows_kernel<16, 256, true>),
+                           dim3((unsigned)grid_for(ctx, batch, 16)), dim3(256), 0, ctx->stream, n,
+                           batch, phi1, phi0, u1, u0, g, info);
+    else
+        hipLaunchKernelGGL((spd_batched_rows_kernel<32, 128, true>),
+                           dim3((unsigned)grid_for(ctx, batch, 4)), dim3(128), 0, ctx->stream, n,
+                           batch, phi1, phi0, u1, u0, g, info);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

@@ -206,6 +206,11 @@ class GaussianARDFamily(Family):
         p1 = _arr(phi[1])
         p0f = p0.reshape(p0.shape[:p0.ndim - self.ndim] + (D,))
         p1f = p1.reshape(p1.shape[:p1.ndim - 2 * self.ndim] + (D, D))
+        fused = linalg.gaussian_moments(p0f, p1f)     # one launch for per-plate posteriors
+        if fused is not None:
+            u0, u1, g = fused
+            return [u0.reshape(u0.shape[:-1] + self.shape),
+                    u1.reshape(u1.shape[:-2] + self.shape + self.shape)], g
         U = linalg.chol(fuse(lambda p: -2 * p, p1f))
         cov = linalg.chol_inv(U)
         u0 = linalg.chol_solve(U, p0f)

@@ -49,6 +49,37 @@ class CholFactor:
         self._inv, self._logdet = inv, logdet
 
 
+def gaussian_moments(phi0, phi1):
+    """Moments and log-normaliser of Gaussians with a full covariance per plate from their
+    natural parameters, in ONE launch when the fused kernel applies (dense (..., n) / (..., n, n)
+    arrays of the same plates, 8 < n <= 32, a chip-filling number of plates); returns
+    ``(u0, u1, g)`` or ``None`` when the caller should use chol / chol_solve / outer
+    (GaussianARDDistribution.compute_moments_and_cgf, gaussian.py:680-706)."""
+    phi0, phi1 = asdarray(phi0), asdarray(phi1)
+    n = phi1.shape[-1]
+    if not (8 < n <= 32) or phi1.shape[-2] != n or phi0.shape[-1] != n:
+        return None
+    plates = phi1.shape[:-2]
+    if phi0.shape[:-1] != plates:
+        return None
+    rt = get_runtime()
+    batch = int(np.prod(plates)) if plates else 1
+    if batch < 4 * 256 or rt.lib is None:
+        return None
+    p0, p1 = contiguous(phi0), contiguous(phi1)
+    u0, u1, g = DArray.empty(p0.shape), DArray.empty(p1.shape), DArray.empty(plates)
+    info = rt.torch.zeros(batch, dtype=rt.torch.int32, device=rt.device)
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_gaussian_moments(rt.ctx, n, batch, ctypes.c_void_p(p0.t.data_ptr()),
+                                         ctypes.c_void_p(p1.t.data_ptr()),
+                                         ctypes.c_void_p(u0.t.data_ptr()),
+                                         ctypes.c_void_p(u1.t.data_ptr()),
+                                         ctypes.c_void_p(g.t.data_ptr()),
+                                         ctypes.c_void_p(info.data_ptr())))
+    rt.defer_check(info, _lib.NotPositiveDefiniteError, "Matrix not positive definite")
+    return u0, u1, g
+
+
 def chol(C, ndim=1):
     if ndim != 1:
         raise NotImplementedError('chol with ndim != 1')

@@ -294,6 +294,18 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
 int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A, double *Ainv,
                         double *logdet, int32_t *info);
 
+/* Moments and log-normaliser of a Gaussian with a full covariance per plate from its natural
+ * parameters, one pass (GaussianARDDistribution.compute_moments_and_cgf, gaussian.py:680-706,
+ * i.e. linalg.chol + chol_inv + chol_solve + outer + chol_logdet fused):
+ *   Cov = (-2 phi1)^-1,  u0 = Cov phi0,  u1 = u0 u0^T + Cov,
+ *   g = -1/2 u0 . phi0 + 1/2 log|-2 phi1|.
+ * phi0, u0: batch x n; phi1, u1: batch x n x n; g: batch; info[b] = 1 where -2 phi1 is not
+ * positive definite.  Built for 8 < n <= 32 (row-per-lane kernel); other sizes go through
+ * vmp_spd_batched + vmp_sum_multiply. */
+int32_t vmp_gaussian_moments(vmp_ctx *ctx, int32_t n, int64_t batch, const double *phi0,
+                             const double *phi1, double *u0, double *u1, double *g,
+                             int32_t *info);
+
 /* Row softmax moments of Multinomial/Categorical: p = normalized_exp(phi),
  * lse = logsumexp(phi) (multinomial.py:114-120, utils/misc.py:1366-1401). */
 int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double *phi, double *p,

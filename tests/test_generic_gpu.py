@@ -299,3 +299,34 @@ def test_gemm_path_is_taken_and_deterministic(monkeypatch):
     # small or one-sided contractions stay on the generic kernels
     misc.sum_multiply(rs.normal(size=(3, 4)), rs.normal(size=(4,)), axis=(1,))
     assert calls[-1] is False
+
+
+@pytest.mark.parametrize('n,batch', [(9, 3000), (16, 4099), (12, 1025), (17, 1100), (32, 1029),
+                                     (24, 2000)])
+def test_fused_gaussian_moments(n, batch):
+    """vmp_gaussian_moments (compute_moments_and_cgf of a Gaussian with a covariance per
+    plate, gaussian.py:680-706) against NumPy: u0 = Cov phi0, u1 = u0 u0^T + Cov,
+    g = -1/2 u0.phi0 + 1/2 log|-2 phi1|."""
+    from bayespy_amd.utils import linalg
+    from bayespy_amd import _lib
+    rs = np.random.RandomState(n * 7 + batch)
+    A = rs.normal(size=(batch, n, n))
+    Lam = A @ A.transpose(0, 2, 1) + n * np.eye(n)
+    phi1 = -0.5 * Lam
+    phi0 = rs.normal(size=(batch, n))
+    out = linalg.gaussian_moments(phi0, phi1)
+    assert out is not None
+    u0, u1, g = [o.numpy() for o in out]
+    cov = np.linalg.inv(Lam)
+    r0 = np.einsum('bij,bj->bi', cov, phi0)
+    np.testing.assert_allclose(u0, r0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(u1, cov + r0[:, :, None] * r0[:, None, :], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g, -0.5 * np.sum(r0 * phi0, axis=1) + 0.5 * np.linalg.slogdet(Lam)[1],
+                               rtol=1e-10)
+    # sizes / layouts outside the fused kernel are declined, indefinite input is reported
+    assert linalg.gaussian_moments(phi0[:10], phi1[:10]) is None
+    assert linalg.gaussian_moments(np.zeros((2000, 4)), np.tile(-np.eye(4), (2000, 1, 1))) is None
+    bad = phi1.copy()
+    bad[batch // 2] = np.eye(n)
+    with pytest.raises(_lib.NotPositiveDefiniteError):
+        linalg.gaussian_moments(phi0, bad)
