@@ -903,8 +903,20 @@ class GenericPlan:
     def _moments(self, node):
         if isinstance(node, Stochastic):
             return self._ensure(node).u
+        # Deterministic nodes hold no state (deterministic.py:62-64), and the reference
+        # recomputes their moments on every request -- e.g. the D x N x K^2 contraction of a
+        # PCA model twice per iteration.  Moment arrays are never modified in
+        # place here, so "same parent arrays" means "same result": keep the last one.
         fam = self.family[id(node)]
-        return fam.moments(self._parent_moments(node))
+        ups = self._parent_moments(node)
+        key = tuple(id(a) for u in ups for a in u)
+        cache = self.__dict__.setdefault('_det_cache', {})
+        hit = cache.get(id(node))
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        out = fam.moments(ups)
+        cache[id(node)] = (key, ups, out)          # `ups` keeps the keyed arrays alive
+        return out
 
     def _parent_moments(self, node):
         fam = self.family[id(node)]
