@@ -32,6 +32,7 @@ from ...nodes.dot import SumMultiply
 from ...nodes.wishart import Wishart
 from ...nodes.dirichlet import Dirichlet
 from ...nodes.categorical import Categorical
+from ...nodes.multinomial import Multinomial
 from ...nodes.mixture import Mixture
 from ...nodes.gaussian_markov_chain import GaussianMarkovChain, MarkovChainToGaussian
 from ...utils import misc, linalg
@@ -396,6 +397,26 @@ class CategoricalFamily(Family):
 
     def message_to_parent(self, index, u, up):
         return [u[0]]
+
+
+class MultinomialFamily(CategoricalFamily):
+    """multinomial.py:62-231 with N trials (an integer or an integer array over the plates)."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.trials = np.asarray(node.trials, dtype=np.float64)
+        self.Nd = DArray.from_host(self.trials)
+
+    def moments_and_cgf(self, phi):
+        p, lse = misc.normalized_exp(_arr(phi[0]))
+        u0 = fuse(lambda n, q: n * q, _trail(self.Nd, 1), p)
+        return [u0], fuse(lambda n, l: -(n * l), self.Nd, lse.reshape(lse.shape[:-1]))
+
+    def fixed_moments_and_f(self, x):
+        # f = log N! - sum_k log x_k!   (multinomial.py:153-155)
+        x = _arr(np.asarray(x, dtype=np.float64))
+        lg = misc.sum_multiply(fuse(lambda c: da.gammaln(c + 1.0), x), axis=-1)
+        return [x], fuse(lambda n, s_: da.gammaln(n + 1.0) - s_, self.Nd, lg)
 
 
 class MixtureFamily(Family):
@@ -767,6 +788,8 @@ def make_family(node):
         return WishartFamily(node)
     if isinstance(node, Dirichlet):
         return DirichletFamily(node)
+    if isinstance(node, Multinomial):
+        return MultinomialFamily(node)
     if isinstance(node, Categorical):
         return CategoricalFamily(node)
     if isinstance(node, SumMultiply):

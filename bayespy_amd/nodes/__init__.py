@@ -9,8 +9,10 @@ from .dot import SumMultiply, Dot
 from .wishart import Wishart
 from .dirichlet import Dirichlet
 from .categorical import Categorical
+from .multinomial import Multinomial
 from .mixture import Mixture
 from .gaussian_markov_chain import GaussianMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
-           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Mixture', 'GaussianMarkovChain']
+           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
+           'GaussianMarkovChain']

@@ -507,6 +507,34 @@ def svi_case(name):
     print(name, out['L'])
 
 
+def multinomial_case(name):
+    """Dirichlet + Multinomial with observed count vectors (different numbers of trials per
+    plate), and a latent Multinomial feeding a Mixture-free check of its moments."""
+    from bayespy.nodes import Dirichlet, Multinomial
+    from bayespy.inference import VB
+    rs = np.random.RandomState(21)
+    K, N = 5, 40
+    trials = rs.randint(1, 30, size=N)
+    ptrue = rs.dirichlet(np.ones(K))
+    counts = np.array([rs.multinomial(t, ptrue) for t in trials])
+    p = Dirichlet(np.array([1.0, 0.5, 2.0, 1.5, 1.0]), name='p')
+    x = Multinomial(trials, p, name='x')
+    x.observe(counts)
+    Q = VB(x, p)
+    Q.update(repeat=2, verbose=False)
+    out = dict(trials=trials, counts=counts, L=np.array(Q.L[:Q.iter]),
+               p_u0=np.array(p.u[0]), L_x=np.array(Q.l[x][:Q.iter]), L_p=np.array(Q.l[p][:Q.iter]))
+    # latent multinomial: moments from the prior
+    p2 = Dirichlet(np.array([2.0, 1.0, 3.0]), name='p2')
+    z = Multinomial(7, p2, plates=(4,), name='z')
+    Q2 = VB(z, p2)
+    Q2.update(repeat=2, verbose=False)
+    out['z_u0'] = np.array(z.u[0])
+    out['L2'] = np.array(Q2.L[:Q2.iter])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, out['L'], out['L2'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -524,6 +552,7 @@ def main():
     rotation_cases('rotations')
     pca_doctest_case('pca_doctest')
     svi_case('svi_gmm')
+    multinomial_case('multinomial')
 
 
 if __name__ == '__main__':

@@ -299,3 +299,36 @@ def test_checkpoint_round_trip_on_device(golden_dir, tmp_path, model):
     for nm in track:
         for a, b in zip(Q2[nm].u, Q[nm].u):
             np.testing.assert_array_equal(a, b)
+
+
+def test_dirichlet_multinomial_matches_reference(golden_dir):
+    """Multinomial (multinomial.py:62-319): observed count vectors with a different number of
+    trials per plate, and the prior moments of a latent node."""
+    from bayespy_amd.nodes import Dirichlet, Multinomial
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'multinomial.npz'))
+    p = Dirichlet(np.array([1.0, 0.5, 2.0, 1.5, 1.0]), name='p')
+    x = Multinomial(g['trials'], p, name='x')
+    assert x.plates == (len(g['trials']),) and x.dims == ((5,),)
+    x.observe(g['counts'])
+    Q = VB(x, p)
+    Q.update(repeat=2, verbose=False)
+    np.testing.assert_allclose(Q.L[:2], g['L'], rtol=ELBO_RTOL)
+    np.testing.assert_allclose(p.u[0], g['p_u0'], rtol=MOM_RTOL)
+    np.testing.assert_allclose(Q.l[x][:2], g['L_x'], rtol=1e-9)
+    np.testing.assert_allclose(Q.l[p][:2], g['L_p'], rtol=1e-9)
+    p2 = Dirichlet(np.array([2.0, 1.0, 3.0]), name='p2')
+    z = Multinomial(7, p2, plates=(4,), name='z')
+    Q2 = VB(z, p2)
+    Q2.ignore_bound_checks = True        # L = 0: the relative change is 0/0 like in the reference
+    Q2.update(repeat=2, verbose=False)
+    # moments may be broadcast-compressed over the plates on either side
+    np.testing.assert_allclose(np.broadcast_to(z.u[0], (4, 3)), np.broadcast_to(g['z_u0'], (4, 3)),
+                               rtol=MOM_RTOL)
+    np.testing.assert_allclose(Q2.L[:2], g['L2'], atol=1e-9)
+    bad = g['counts'].copy()
+    bad[0, 0] += 1
+    with pytest.raises(ValueError, match='sum to the number of trials'):
+        x.observe(bad)
+    with pytest.raises(ValueError, match='integer'):
+        Multinomial(2.5, p2)
