@@ -9,7 +9,8 @@
 //   wishart.py:118-225, dirichlet.py:107-231, expfamily.py:400-480.
 //
 // One pass over Y per VB iteration (issued by z.update()):
-//   phase 1  Phi(K x 16) = C (K x F) * feat(y)     feat = [y_a y_b, y_d, 1]   (fp64 MFMA)
+//   phase 1  Phi(K x 16) = C (K x F2) * feat2(y)   (fp64 MFMA; symmetric pairs once, their
+//                                                   coefficients folded: 12 k-steps, not 19)
 //   softmax  r = normalized_exp(Phi) per column (reference recipe), r written (N, K)
 //   phase 2  T (K x F2) += r * feat2(y)^T          feat2 = [y_a y_b (a<=b), y_d, 1]
 // T = [R_k, sum r y, sum r y y^T] are the messages to mu / Lambda / alpha, i.e. the
@@ -39,10 +40,11 @@ inline void fill_layout(int D, int K, vmp_gmm_layout *L)
 {
     const int64_t DP = round_pow2(D, 4), KP = round_pow2(K, 16);
     const int64_t FS = 1 + D + (int64_t)D * D;
-    const int64_t FP = DP * DP + DP + 4;
+    const int64_t F2P = (n_feat2(D) + 15) / 16 * 16;
+    const int64_t FP = F2P;        // coefficient rows of C use the compact feature order
     int64_t o = 0;
     L->DP = DP; L->KP = KP; L->FS = FS; L->FP = FP;
-    L->F2P = (n_feat2(D) + 15) / 16 * 16;
+    L->F2P = F2P;
     L->off_T = o;         L->len_T = KP * FS; o += L->len_T;
     L->off_zs = o;        o += 8;
     L->off_alpha = o;     o += 2 * KP;
@@ -78,12 +80,10 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
                 double *__restrict__ Rout, double *__restrict__ P, int64_t ntiles)
 {
     constexpr int DP = 4 * DPT, KP = 16 * KT;
-    constexpr int KSQ = DP * DPT;                 // quadratic k-steps
-    constexpr int KS1 = KSQ + DPT + 1;            // + linear + constant
-    constexpr int FP = DP * DP + DP + 4;
     constexpr int YS = DP + 3;                    // y tile row stride (ONE at DP, ZERO at DP+1)
     constexpr int RS = KP + 1;                    // r tile row stride
-    constexpr int F2P = 16 * FT2;
+    constexpr int F2P = 16 * FT2;                 // compact features: y_a y_b (a<=b), y_d, 1
+    constexpr int KS1 = F2P / 4;                  // phase-1 k-steps over the same features
 
     extern __shared__ double lds[];
     double *Cf = lds;                                            // KT*KS1*64
@@ -99,7 +99,7 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
         for (int e = tid; e < KT * KS1 * 64; e += NT) {
             const int lane = e & 63, fq = e >> 6;
             const int it = fq / KS1, q = fq - it * KS1;
-            Cf[e] = Cmat[(int64_t)(it * 16 + (lane & 15)) * FP + 4 * q + (lane >> 4)];
+            Cf[e] = Cmat[(int64_t)(it * 16 + (lane & 15)) * F2P + 4 * q + (lane >> 4)];
         }
     }
     // constant slots of the y tile
@@ -107,25 +107,37 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     ytile[l15 * YS + DP + 1] = 0.0;
     __syncthreads();
 
-    // phase-2 features of this lane: feat2[ft*16 + l15] = ytile[n][ia] * ytile[n][ib]
-    int ia[FT2], ib[FT2];
-    {
+    // feature f of a column n is ytile[n][fa(f)] * ytile[n][fb(f)] (slot DP holds 1, DP+1 holds 0)
+    auto feature = [&](int f, int &a, int &b) {
         const int npair = D * (D + 1) / 2;
-#pragma unroll
-        for (int ft = 0; ft < FT2; ++ft) {
-            const int f = ft * 16 + l15;
-            int a = DP + 1, b = DP + 1;              // zero feature
-            if (f < npair) {
-                int rem = f, aa = 0;
-                while (rem >= D - aa) { rem -= D - aa; ++aa; }
-                a = aa; b = aa + rem;
-            } else if (f < npair + D) {
-                a = f - npair; b = DP;               // linear: y_d * 1
-            } else if (f == npair + D) {
-                a = DP; b = DP;                      // constant
-            }
-            ia[ft] = a; ib[ft] = b;
+        a = DP + 1; b = DP + 1;                      // zero feature
+        if (f < npair) {
+            int rem = f, aa = 0;
+            while (rem >= D - aa) { rem -= D - aa; ++aa; }
+            a = aa; b = aa + rem;
+        } else if (f < npair + D) {
+            a = f - npair; b = DP;                   // linear: y_d * 1
+        } else if (f == npair + D) {
+            a = DP; b = DP;                          // constant
         }
+    };
+    // phase 2: this lane generates feat2[ft*16 + l15]; phase 1: feature 4q + g of its column,
+    // packed two 4-bit slots per byte to keep the tables in a few registers
+    uint32_t f2 = 0;
+#pragma unroll
+    for (int ft = 0; ft < FT2; ++ft) {
+        int a, b;
+        feature(ft * 16 + l15, a, b);
+        f2 |= (uint32_t)((a << 4) | b) << (8 * ft);
+    }
+    uint32_t f1[(KS1 + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (KS1 + 3) / 4; ++i) f1[i] = 0;
+#pragma unroll
+    for (int q = 0; q < KS1; ++q) {
+        int a, b;
+        feature(4 * q + g, a, b);
+        f1[q >> 2] |= (uint32_t)((a << 4) | b) << (8 * (q & 3));
     }
 
     v4f64 acc2[KT][FT2];
@@ -151,20 +163,18 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
         lds_fence();
 
         if (!FROM_LABELS) {
-            double ya[DP];
-#pragma unroll
-            for (int a = 0; a < DP; ++a) ya[a] = ytile[l15 * YS + a];
-            // ---- phase 1: Phi = C * feat(y) -------------------------------------------
+            // ---- phase 1: Phi = C * feat(y) over the compact features ------------------
             v4f64 acc1[KT];
 #pragma unroll
             for (int it = 0; it < KT; ++it) acc1[it] = v4f64{0.0, 0.0, 0.0, 0.0};
             asm volatile("" ::: "memory");
+            const double *yrow = ytile + l15 * YS;
 #pragma unroll
             for (int q = 0; q < KS1; ++q) {
-                double b;
-                if (q < KSQ) b = ya[q / DPT] * yb[q % DPT];
-                else if (q < KSQ + DPT) b = yb[q - KSQ];
-                else b = (g == 0) ? 1.0 : 0.0;
+                // keep the feature reads next to their use (hoisted together they spill)
+                if ((q & 3) == 0) asm volatile("" ::: "memory");
+                const uint32_t ab = (f1[q >> 2] >> (8 * (q & 3))) & 0xffu;
+                const double b = yrow[ab >> 4] * yrow[ab & 15];
 #pragma unroll
                 for (int it = 0; it < KT; ++it)
                     acc1[it] = mfma_f64(Cf[(it * KS1 + q) * 64 + l], b, acc1[it]);
@@ -240,7 +250,8 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             double bf[FT2];
 #pragma unroll
             for (int ft = 0; ft < FT2; ++ft)
-                bf[ft] = ytile[nn * YS + ia[ft]] * ytile[nn * YS + ib[ft]];
+                bf[ft] = ytile[nn * YS + ((f2 >> (8 * ft + 4)) & 15u)]
+                         * ytile[nn * YS + ((f2 >> (8 * ft)) & 15u)];
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
                 const double a = rtile[nn * RS + it * 16 + l15];
@@ -471,30 +482,33 @@ __device__ inline double gmm_ck(const double *st, const vmp_gmm_layout &L, int D
 __global__ void __launch_bounds__(NT)
 gmm_prepare_z_kernel(vmp_gmm_layout L, int D, int K, int prior_only, double *st)
 {
-    const int DP = (int)L.DP, FP = (int)L.FP, KP = (int)L.KP;
-    for (int e = blockIdx.x * NT + threadIdx.x; e < KP * FP; e += gridDim.x * NT) {
-        const int k = e / FP, f = e - k * FP;
+    // Row k of C holds the coefficients of  ell_nk = c_k + b_k . y - 1/2 y^T Lam_k y  in the
+    // compact feature order of the pass kernel: pairs y_a y_b (a <= b), then y_d, then 1.
+    const int F2P = (int)L.F2P, KP = (int)L.KP;
+    const int npair = D * (D + 1) / 2;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < KP * F2P; e += gridDim.x * NT) {
+        const int k = e / F2P, f = e - k * F2P;
         double v = 0.0;
         if (k < K && prior_only) {
             // q(z) from its prior: phi = <log pi> only (initialize_from_prior)
-            if (f == DP * DP + DP) v = st[L.off_alpha + KP + k];
+            if (f == npair + D) v = st[L.off_alpha + KP + k];
         } else if (k < K) {
             const double *Lam = st + L.off_Lam + (int64_t)k * D * D;
-            if (f < DP * DP) {
-                const int a = f / DP, b = f - a * DP;
-                if (a < D && b < D) v = -0.5 * Lam[a * D + b];
-            } else if (f < DP * DP + DP) {
-                const int d = f - DP * DP;
-                if (d < D) {
-                    const double *mu = st + L.off_mu + (int64_t)k * D;
-                    double s = 0.0;
-                    for (int c = 0; c < D; ++c) s += Lam[d * D + c] * mu[c];
-                    v = s;
-                }
-            } else if (f == DP * DP + DP) {
+            if (f < npair) {
+                int rem = f, a = 0;
+                while (rem >= D - a) { rem -= D - a; ++a; }
+                const int b = a + rem;
+                v = (a == b) ? -0.5 * Lam[a * D + a] : -0.5 * (Lam[a * D + b] + Lam[b * D + a]);
+            } else if (f < npair + D) {
+                const int d = f - npair;
+                const double *mu = st + L.off_mu + (int64_t)k * D;
+                double s = 0.0;
+                for (int c = 0; c < D; ++c) s += Lam[d * D + c] * mu[c];
+                v = s;
+            } else if (f == npair + D) {
                 v = st[L.off_alpha + KP + k] + gmm_ck(st, L, D, k);
             }
-        } else if (f == DP * DP + DP) {
+        } else if (f == npair + D) {
             v = -INFINITY;                    // padded clusters get zero responsibility
         }
         st[L.off_C + e] = v;
@@ -636,7 +650,7 @@ int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, dim3 grid, const double 
                         double *P, int64_t ntiles)
 {
     constexpr int DP = 4 * DPT, KP = 16 * KT;
-    constexpr int KS1 = DP * DPT + DPT + 1;
+    constexpr int KS1 = 4 * FT2;                  // k-steps of phase 1 (compact features)
     const size_t per_wave = (size_t)(TNC * (DP + 3) + TNC * (KP + 1));
     const size_t lds = ((from_labels ? 0 : (size_t)KT * KS1 * 64) + 4 * per_wave) * sizeof(double);
     hipStream_t s = ctx->stream;
@@ -800,7 +814,7 @@ int32_t vmp_gmm_update_lambda(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
 int32_t vmp_gmm_prepare_z(vmp_ctx *ctx, int32_t D, int32_t K, int32_t prior_only, double *state)
 {
     VMP_GMM_PROLOGUE();
-    const int n = (int)(L.KP * L.FP);
+    const int n = (int)(L.KP * L.F2P);
     hipLaunchKernelGGL(gmm_prepare_z_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, L,
                        D, K, (int)prior_only, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());

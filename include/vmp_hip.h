@@ -199,7 +199,7 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
 typedef struct vmp_gmm_layout {
     int64_t DP, KP;        /* padded D (4 or 8) and K (16, 32, 64)                          */
     int64_t FS;            /* 1 + D + D*D : row length of the statistics                      */
-    int64_t FP, F2P;       /* feature counts of the two MFMA phases (padded)                  */
+    int64_t FP, F2P;       /* padded feature count [y_a y_b (a<=b), y_d, 1] of both MFMA phases */
     int64_t off_T, len_T;  /* KP x FS : per cluster [R_k, sum_n r y (D), sum_n r y y^T (D*D)] */
                            /*   -- the plate sums of mixture.py:126-158 + node.py:650          */
     int64_t off_zs;        /* sum_n logsumexp(phi_n), sum_nk r phi   (for L_z)                */
@@ -212,7 +212,7 @@ typedef struct vmp_gmm_layout {
     int64_t off_Lam;       /* KP x D x D  <Lambda_k> = n_k V_k^-1        (wishart.py:184)     */
     int64_t off_logdetLam; /* KP  <log|Lambda_k|>                          (wishart.py:185)   */
     int64_t off_logdetV;   /* KP  log|V_k|                                                    */
-    int64_t off_C;         /* KP x FP coefficient matrix of the pass                          */
+    int64_t off_C;         /* KP x F2P coefficients of ell_nk in the compact feature order     */
     int64_t off_prior;     /* alpha0[KP], beta0, n0, log|V0|, 5 pad, V0[D*D]                  */
     int64_t off_scal;      /* 8 : [3] status                                                  */
     int64_t off_L;         /* 8 : L_Y, L_z, L_alpha, L_mu, L_Lambda, L_total                  */
