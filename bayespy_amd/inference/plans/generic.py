@@ -21,6 +21,8 @@ Differences from the reference's design (not its results):
 * plate sums, masks and the integer plate multiplier (utils/misc.py:761-844)
   are a single ``sum_multiply_to_plates`` launch per message.
 """
+import os
+
 import numpy as np
 
 from ... import darray as da
@@ -938,7 +940,8 @@ class GenericPlan:
         if hit is not None and hit[0] == key:
             return hit[2]
         out = fam.moments(ups)
-        cache[id(node)] = (key, ups, out)          # `ups` keeps the keyed arrays alive
+        if os.environ.get('BAYESPY_AMD_DET_CACHE', '1') != '0':
+            cache[id(node)] = (key, ups, out)          # `ups` keeps the keyed arrays alive
         return out
 
     def _parent_moments(self, node):
