@@ -78,6 +78,32 @@ sum_multiply_thread_kernel(Iter it, double scale, double *__restrict__ out)
     }
 }
 
+// Many outputs, each a short reduction along a dense axis (row dot products, traces, ...):
+// a group of G lanes owns one output and walks the reduced index together, so consecutive
+// lanes read consecutive addresses; the group's partial sums meet by xor-shuffles.
+template <int G>
+__global__ void __launch_bounds__(NT)
+sum_multiply_rowgroup_kernel(Iter it, double scale, double *__restrict__ out)
+{
+    const int gl = threadIdx.x % G;
+    const int64_t ngroups = (int64_t)gridDim.x * (NT / G);
+    const int64_t first = (int64_t)blockIdx.x * (NT / G) + threadIdx.x / G;
+    // the same trip count for every lane: all lanes of a wavefront take part in the shuffles
+    const int64_t trips = (it.nkeep + ngroups - 1) / ngroups;
+    for (int64_t t = 0; t < trips; ++t) {
+        const int64_t o = first + t * ngroups;
+        const bool act = o < it.nkeep;
+        int64_t base[MAXIN], ooff;
+        decode_keep(it, act ? o : 0, base, ooff);
+        double acc = 0.0;
+        if (act)
+            for (int64_t r = gl; r < it.nred; r += G) acc += product_at(it, base, r);
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (act && gl == 0) out[ooff] = scale * acc;
+    }
+}
+
 // One workgroup per (output element, slice of the reduction domain): wavefront
 // reductions, fixed-order combination of the slices => deterministic.
 __global__ void __launch_bounds__(NT)
@@ -260,54 +286,84 @@ ewise_kernel(EwiseArgs a, double *__restrict__ out)
     }
 }
 
-// Fast path: after dimension merging every operand is either dense (stride 1) or a
-// broadcast scalar (stride 0): no index decode, 64-bit only for the base offset.
+// Fast path: after dimension merging the iteration space has one or two axes.  A thread
+// evaluates NE elements at once: all operand loads of the NE elements are issued before the
+// program is interpreted (they overlap instead of serialising inside the dispatch loop), and
+// the per-operation dispatch is paid once per NE elements.
+constexpr int EW_NE = 4;
+
 template <int NDIM>
 __global__ void __launch_bounds__(NT)
 ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
 {
-    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < a.total;
-         e += (int64_t)gridDim.x * NT) {
-        int64_t off[MAXIN];
-        if (NDIM == 1) {
-            for (int i = 0; i < a.nin; ++i) off[i] = e * a.stride[i][0];
-        } else {
-            // NDIM == 2: one division
-            const int64_t q = e / a.shape[1];
-            const int64_t c = e - q * a.shape[1];
-            for (int i = 0; i < a.nin; ++i) off[i] = q * a.stride[i][0] + c * a.stride[i][1];
+    const int64_t span = (int64_t)gridDim.x * NT;
+    for (int64_t e0 = (int64_t)blockIdx.x * NT + threadIdx.x; e0 < a.total; e0 += span * EW_NE) {
+        double v[MAXIN][EW_NE];
+        bool ok[EW_NE];
+#pragma unroll
+        for (int j = 0; j < EW_NE; ++j) {
+            const int64_t e = e0 + j * span;
+            ok[j] = e < a.total;
+            const int64_t ee = ok[j] ? e : 0;
+            if (NDIM == 1) {
+#pragma unroll
+                for (int i = 0; i < MAXIN; ++i)
+                    v[i][j] = (i < a.nin) ? a.in[i][ee * a.stride[i][0]] : 0.0;
+            } else {
+                // NDIM == 2: one division
+                const int64_t q = ee / a.shape[1];
+                const int64_t c = ee - q * a.shape[1];
+#pragma unroll
+                for (int i = 0; i < MAXIN; ++i)
+                    v[i][j] = (i < a.nin) ? a.in[i][q * a.stride[i][0] + c * a.stride[i][1]] : 0.0;
+            }
         }
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
-#define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
+        double s0[EW_NE], s1[EW_NE], s2[EW_NE], s3[EW_NE];
+#pragma unroll
+        for (int j = 0; j < EW_NE; ++j) s0[j] = s1[j] = s2[j] = s3[j] = 0.0;
+#define EACH for (int j = 0; j < EW_NE; ++j)
+#define PUSH(val) _Pragma("unroll") EACH { s3[j] = s2[j]; s2[j] = s1[j]; s1[j] = s0[j]; s0[j] = (val); }
+#define BIN(expr) _Pragma("unroll") EACH { const double y = s0[j], x = s1[j]; s0[j] = (expr); \
+                                           s1[j] = s2[j]; s2[j] = s3[j]; }
+#define UNA(expr) _Pragma("unroll") EACH { const double x = s0[j]; s0[j] = (expr); }
         for (int p = 0; p < a.nops; ++p) {
             const int op = a.ops[p] & 0xff, arg = a.ops[p] >> 8;
             switch (op) {
-            case VMP_OP_IN:      PUSH(a.in[arg][off[arg]]); break;
+            case VMP_OP_IN:
+                // operand index is wave-uniform: a short chain of selects keeps v[] in registers
+                PUSH(arg == 0 ? v[0][j] : arg == 1 ? v[1][j] : arg == 2 ? v[2][j]
+                     : arg == 3 ? v[3][j] : arg == 4 ? v[4][j] : v[5][j]);
+                break;
             case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
             case VMP_OP_ADD:     BIN(x + y); break;
             case VMP_OP_SUB:     BIN(x - y); break;
             case VMP_OP_MUL:     BIN(x * y); break;
             case VMP_OP_DIV:     BIN(x / y); break;
-            case VMP_OP_NEG:     s0 = -s0; break;
-            case VMP_OP_LOG:     s0 = log(s0); break;
-            case VMP_OP_EXP:     s0 = exp(s0); break;
-            case VMP_OP_SQR:     s0 = s0 * s0; break;
-            case VMP_OP_SQRT:    s0 = sqrt(s0); break;
-            case VMP_OP_RECIP:   s0 = 1.0 / s0; break;
-            case VMP_OP_DIGAMMA: s0 = vmp_digamma(s0); break;
-            case VMP_OP_LGAMMA:  s0 = vmp_lgamma(s0); break;
+            case VMP_OP_NEG:     UNA(-x); break;
+            case VMP_OP_LOG:     UNA(log(x)); break;
+            case VMP_OP_EXP:     UNA(exp(x)); break;
+            case VMP_OP_SQR:     UNA(x * x); break;
+            case VMP_OP_SQRT:    UNA(sqrt(x)); break;
+            case VMP_OP_RECIP:   UNA(1.0 / x); break;
+            case VMP_OP_DIGAMMA: UNA(vmp_digamma(x)); break;
+            case VMP_OP_LGAMMA:  UNA(vmp_lgamma(x)); break;
             case VMP_OP_MAX:     BIN(fmax(x, y)); break;
             case VMP_OP_MIN:     BIN(fmin(x, y)); break;
             case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;
-            case VMP_OP_DUP:     PUSH(s0); break;
-            case VMP_OP_SWAP:    { const double tmp = s0; s0 = s1; s1 = tmp; } break;
+            case VMP_OP_DUP:     PUSH(s0[j]); break;
+            case VMP_OP_SWAP:
+                _Pragma("unroll") EACH { const double tmp = s0[j]; s0[j] = s1[j]; s1[j] = tmp; }
+                break;
             default: break;
             }
         }
+#undef EACH
 #undef PUSH
 #undef BIN
-        out[e] = s0;
+#undef UNA
+#pragma unroll
+        for (int j = 0; j < EW_NE; ++j)
+            if (ok[j]) out[e0 + j * span] = s0[j];
     }
 }
 
@@ -678,6 +734,10 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
             if (st != 0 && st != 1) use_column = false;
         }
     }
+    // innermost reduced axis dense in some operand (then lanes along it coalesce)
+    bool dense_reduce = false;
+    if (it.nr >= 1)
+        for (int i = 0; i < nin; ++i) dense_reduce = dense_reduce || it.rstride[i][it.nr - 1] == 1;
     // the column form needs >= 16 dense lanes to coalesce; below that the fat-thread form wins
     const bool use_fat = it.nkeep <= 64 && it.nkeep >= 2 && it.nred >= 65536 &&
                          !(use_column && it.ksize[it.nk - 1] >= 16) && workspace;
@@ -726,6 +786,18 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         hipLaunchKernelGGL(sum_multiply_finish_kernel,
                            dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
                            (int)nsplit, scale, partial, out);
+    } else if (!use_block && it.nred >= 8 && it.nkeep >= 4096 && dense_reduce) {
+        // short dense reductions: a lane group per output (coalesced), else a thread per output
+        const int G = it.nred >= 64 ? 64 : (it.nred >= 32 ? 32 : (it.nred >= 16 ? 16 : 8));
+        const dim3 grid((unsigned)grid_for(ctx, it.nkeep, NT / G));
+        if (G == 64)
+            hipLaunchKernelGGL(sum_multiply_rowgroup_kernel<64>, grid, dim3(NT), 0, s, it, scale, out);
+        else if (G == 32)
+            hipLaunchKernelGGL(sum_multiply_rowgroup_kernel<32>, grid, dim3(NT), 0, s, it, scale, out);
+        else if (G == 16)
+            hipLaunchKernelGGL(sum_multiply_rowgroup_kernel<16>, grid, dim3(NT), 0, s, it, scale, out);
+        else
+            hipLaunchKernelGGL(sum_multiply_rowgroup_kernel<8>, grid, dim3(NT), 0, s, it, scale, out);
     } else if (!use_block) {
         hipLaunchKernelGGL(sum_multiply_thread_kernel, dim3((unsigned)grid_for(ctx, it.nkeep, NT)),
                            dim3(NT), 0, s, it, scale, out);

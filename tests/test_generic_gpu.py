@@ -59,6 +59,12 @@ SM_CASES = [
     # many outputs each with a long contiguous reduction (per-sequence sums)
     (((3000, 700, 2, 2),), dict(axis=(1, 2, 3))),
     (((3000, 1100), (1, 1100)), dict(axis=(1,))),
+    # many outputs, short dense reductions: lane-group kernel (8 / 16 / 32 / 64 lanes)
+    (((5000, 16), (5000, 16)), dict(axis=(1,))),
+    (((5000, 9),), dict(axis=(1,))),
+    (((4100, 3, 40), (1, 3, 40)), dict(axis=(2,))),
+    (((4500, 70), (4500, 1), (1, 70)), dict(axis=(1,), keepdims=True)),
+    (((300, 20, 6, 6), (300, 20, 6, 6)), dict(axis=(2, 3))),
 ]
 
 
