@@ -107,7 +107,8 @@ sum_multiply_rowgroup_kernel(Iter it, double scale, double *__restrict__ out)
 // One workgroup per (output element, slice of the reduction domain): wavefront
 // reductions, fixed-order combination of the slices => deterministic.
 __global__ void __launch_bounds__(NT)
-sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial)
+sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial, double scale,
+                          double *__restrict__ out)
 {
     __shared__ double red[NT / 64];
     const int64_t o = blockIdx.x;
@@ -120,7 +121,10 @@ sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial)
     double acc = 0.0;
     for (int64_t r = r0 + threadIdx.x; r < r1; r += NT) acc += product_at(it, base, r);
     acc = block_sum<NT>(acc, red);
-    if (threadIdx.x == 0) partial[o * nsplit + sp] = acc;
+    if (threadIdx.x == 0) {
+        if (nsplit == 1) out[ooff] = scale * acc;          // single slice: no combine pass
+        else partial[(int64_t)sp * it.nkeep + o] = acc;
+    }
 }
 
 // Few outputs, long reduction, kept axes NOT dense (e.g. sum over sequences and time of
@@ -173,7 +177,7 @@ sum_multiply_fat_kernel(Iter it, int nsplit, double *__restrict__ partial)
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) v += wsum[w][tid];
-        partial[(int64_t)tid * nsplit + blockIdx.x] = v;
+        partial[(int64_t)blockIdx.x * it.nkeep + tid] = v;
     }
 }
 
@@ -206,7 +210,7 @@ sum_multiply_column_kernel(Iter it, int nsplit, double *__restrict__ partial)
         double s = 0.0;
 #pragma unroll
         for (int j = 0; j < RY; ++j) s += tile[j][kx];
-        partial[o * nsplit + sp] = s;
+        partial[(int64_t)sp * it.nkeep + o] = s;
     }
 }
 
@@ -219,7 +223,8 @@ sum_multiply_finish_kernel(Iter it, int nsplit, double scale, const double *__re
         int64_t base[MAXIN], ooff;
         decode_keep(it, o, base, ooff);
         double acc = 0.0;
-        for (int s = 0; s < nsplit; ++s) acc += partial[o * nsplit + s];
+        // slice-major partials: consecutive outputs are consecutive addresses
+        for (int s = 0; s < nsplit; ++s) acc += partial[(int64_t)s * it.nkeep + o];
         out[ooff] = scale * acc;
     }
 }
@@ -812,10 +817,11 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
                     (long long)(it.nkeep * nsplit));
         double *partial = reinterpret_cast<double *>(workspace);
         hipLaunchKernelGGL(sum_multiply_block_kernel, dim3((unsigned)it.nkeep, (unsigned)nsplit),
-                           dim3(NT), 0, s, it, (int)nsplit, partial);
-        hipLaunchKernelGGL(sum_multiply_finish_kernel,
-                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
-                           (int)nsplit, scale, partial, out);
+                           dim3(NT), 0, s, it, (int)nsplit, partial, scale, out);
+        if (nsplit > 1)
+            hipLaunchKernelGGL(sum_multiply_finish_kernel,
+                               dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
+                               (int)nsplit, scale, partial, out);
     }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
