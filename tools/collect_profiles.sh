@@ -15,7 +15,7 @@ for st in gram stream; do
   (cd /tmp; timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace -d /tmp/p_sq2_$st -o r -- $B > /dev/null 2>&1)
   python tools/rocpd_summary.py --pmc /tmp/p_fetch_$st/r_results.db /tmp/p_write_$st/r_results.db /tmp/p_sq_$st/r_results.db /tmp/p_sq2_$st/r_results.db > $O/pmc_pca_$st.txt 2>&1
 done
-G="python $R/tools/bench_gmm.py --steps 5"
+G="python $R/tools/bench_gmm.py --steps 5 --no-cpu-baseline"
 (cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats_gmm -o r -- $G > $R/$O/bench_under_rocprof_gmm.log 2>&1)
 python tools/rocpd_summary.py /tmp/p_stats_gmm/r_results.db > $O/kernel_stats_gmm.txt 2>&1
 (cd /tmp; timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace -d /tmp/p_sq_gmm -o r -- $G > /dev/null 2>&1)
