@@ -100,6 +100,17 @@ def _multigammaln(a, d):
     return fuse(lambda s: s + d * (d - 1) / 4.0 * np.log(np.pi), misc.sum_multiply(t, axis=-1))
 
 
+def _gaussian_q_term(family_ndim, shape, phi, u, g):
+    """-(g_q + phi_q . u_q) of a Gaussian factor without touching its second-order arrays:
+    with Lambda = -2 phi1 and mean x,  phi0.x = x^T Lambda x,  phi1:<xx^T> = -K/2 - x^T Lambda x / 2
+    and  g = -x^T Lambda x / 2 + log|Lambda| / 2,  so the sum is  K/2 - g - phi0.x / 2
+    (expfamily.py:449-468 evaluates the same quantity as two contractions over plates x K x K)."""
+    k = float(np.prod(shape)) if family_ndim else 1.0
+    d = _sum_last(fuse(lambda p, x: p * x, _arr(phi[0]), _arr(u[0])), family_ndim)
+    return fuse(lambda g_, d_: 0.5 * k - g_ - 0.5 * d_, _arr(g), d)
+
+
+
 # ---------------------------------------------------------------------------
 # families: the five VMP formulas per node type
 # ---------------------------------------------------------------------------
@@ -224,6 +235,9 @@ class GaussianARDFamily(Family):
         u1 = u1.reshape(u1.shape[:-2] + self.shape + self.shape)
         return [u0, u1], g
 
+    def q_term(self, phi, u, g):
+        return _gaussian_q_term(self.ndim, self.shape, phi, u, g)
+
     def cgf_from_parents(self, up):
         m, m2 = self._mu(up)
         a, loga = up[1]
@@ -276,6 +290,7 @@ class GaussianFamily(Family):
         return [linalg.mvdot(L, m), fuse(lambda l: -0.5 * l, L)]
 
     moments_and_cgf = GaussianARDFamily.moments_and_cgf
+    q_term = GaussianARDFamily.q_term
 
     def cgf_from_parents(self, up):
         mm = up[0][1]
@@ -1159,14 +1174,26 @@ class GenericPlan:
         up = self._parent_moments(node)
         phi_p = fam.phi_from_parents(up)
         L = _arr(fam.cgf_from_parents(up))
+        closed = None
         if st.observed:
             L = fuse(lambda a, b: a + b, L, st.f if isinstance(st.f, DArray) else float(st.f))
         else:
             if not isinstance(st.g, DArray):
                 return None, (float(-np.inf) if np.isinf(st.g) else float('nan'))
-            L = fuse(lambda a, g: a - g, L, st.g)
+            closed = getattr(fam, 'q_term', None)
+            if closed is not None:
+                # Gaussian factors: -(g_q + phi_q . u_q) in closed form, no K x K contraction
+                L = fuse(lambda a, q: a + q, L, closed(st.phi, st.u, st.g))
+            else:
+                L = fuse(lambda a, g: a - g, L, st.g)
         for i, nd in enumerate(len(d) for d in node.dims):
-            if st.observed:
+            if closed is not None and nd > 0:
+                # finite Gaussian prior parameters: phi_p . u as one contraction, no temporary
+                L = fuse(lambda a, b: a + b, L,
+                         misc.sum_multiply(_arr(phi_p[i]), _arr(st.u[i]),
+                                           axis=tuple(range(-nd, 0))))
+                continue
+            if st.observed or closed is not None:
                 t = fuse(lambda pp, u: da.where_nonzero(u, pp) * u, _arr(phi_p[i]), _arr(st.u[i]))
             else:
                 t = fuse(lambda pp, pq, u: da.where_nonzero(u, pp - pq) * u, _arr(phi_p[i]),
