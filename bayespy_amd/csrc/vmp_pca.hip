@@ -828,7 +828,10 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
     const int64_t ntiles = (N + TN - 1) / TN;
     // full tiles with unpadded D, K run the predication-free instance
     const bool exact = (D == L.DP && K == L.KP);
-    const int64_t nfast = exact ? N / TN : 0;
+    // a ragged last tile also runs predication-free when both arrays are padded to whole
+    // tiles (its pad columns of X are then written too: <x> of whatever Y holds there)
+    const bool padded = (ldy >= ntiles * TN && ldx >= ntiles * TN);
+    const int64_t nfast = exact ? (padded ? ntiles : N / TN) : 0;
     const int occ = xpass_occupancy();
     static const int ntm = env_int("VMP_PCA_XPASS_NT", 3, 0, 3);   // nontemporal Y loads + X stores: +3%
     hipStream_t m = ctx->stream;

@@ -270,7 +270,7 @@ class PCAPlan:
                 and y.data_ptr() % 16 == 0:
             self.Yd, self.ldy = y, y.stride(0)
         else:
-            ldy = (N + 1) // 2 * 2
+            ldy = (N + 31) // 32 * 32        # whole 32-column tiles: no ragged-tail launch
             self.Yd = rt.zeros(D, ldy)
             if isinstance(y, torch.Tensor):
                 src = y
@@ -281,7 +281,7 @@ class PCAPlan:
                 src = torch.from_numpy(ya)
             self.Yd[:, :N].copy_(src)
             self.ldy = ldy
-        self.ldx = (N + 1) // 2 * 2
+        self.ldx = (N + 31) // 32 * 32
         self.state = rt.zeros(int(L.total))
         self._scal_host = None
         self.ws = rt.empty(int(k.workspace_doubles(D, K)))

@@ -55,7 +55,7 @@ def make_shard(torch, dev, n_local, D, K, seed, rank):
     g.manual_seed(seed)
     w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)   # same w on all ranks
     g.manual_seed(seed + 1000 * (rank + 1))
-    ld = (n_local + 1) // 2 * 2
+    ld = (n_local + 31) // 32 * 32       # whole 32-column tiles (pad columns are zero)
     y = torch.empty(D, ld, device=dev, dtype=torch.float64)
     if ld != n_local:
         y[:, n_local:].zero_()

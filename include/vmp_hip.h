@@ -149,6 +149,11 @@ int32_t vmp_pca_gram(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
  * then S <- [G A^T ; A G A^T] from the (already global) Gram matrix: no
  * per-iteration collective.  fp64 MFMA (v_mfma_f64_16x16x4_f64).
  *
+ * Padding: with D, K at their padded sizes and ldy, ldx >= 32 * ceil(N / 32) the ragged last
+ * tile runs through the predication-free kernel as well, which also writes the pad columns
+ * X[:, N .. 32*ceil(N/32)) (= A times the pad columns of Y); with smaller leading dimensions
+ * only columns < N are touched.
+ *
  * Ordering: in this form no other update of the iteration reads X, so the plate pass is
  * issued on the context's internal plate stream (from a private copy of A) and the call
  * returns with S queued on the main stream; the replicated-node updates of the next
