@@ -9,6 +9,8 @@ Device counterparts of ``bayespy.utils.misc``: ``sum_multiply`` (:851-933),
 and error behaviour; every reduction is the ``vmp_sum_multiply`` HIP kernel.
 """
 import ctypes
+import functools
+import operator
 
 import numpy as np
 
@@ -123,27 +125,92 @@ def _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
     return True
 
 
+def _hoist_invariant(arrays, shape, reduce_axes, out_shape_keep, scale):
+    """sum_r a(r, k) b(k) = b(k) sum_r a(r, k): operands that do not vary along any reduced
+    axis leave the (long) reduction and multiply its (small) result instead.  None if nothing
+    can be hoisted or the reduction is too short to matter."""
+    nd = len(shape)
+    nred = 1
+    for ax in reduce_axes:
+        nred *= int(shape[ax])
+    if nred < 1024:
+        return None
+
+    def varies(a):
+        off = nd - a.ndim
+        return any(ax - off >= 0 and a.shape[ax - off] != 1 for ax in reduce_axes)
+
+    var = [a for a in arrays if varies(a)]
+    inv = [a for a in arrays if not varies(a)]
+    if not inv or not var:
+        return None
+    shape_var = [1] * nd
+    for a in var:
+        off = nd - a.ndim
+        for d in range(a.ndim):
+            if a.shape[d] != 1:
+                shape_var[off + d] = a.shape[d]
+    keep_var = tuple(1 if ax in reduce_axes else shape_var[ax] for ax in range(nd))
+    partial = _launch_sum_multiply(var, tuple(shape_var), reduce_axes, keep_var, scale)
+    out = fuse(lambda *xs: functools.reduce(operator.mul, xs), partial, *inv)
+    if out.shape != tuple(out_shape_keep):
+        return out.reshape(tuple(out_shape_keep)) if out.size == int(np.prod(out_shape_keep)) \
+            else None
+    return out
+
+
 def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
     """out (shape with size-1 on reduced axes) = scale * sum_{reduce_axes} prod arrays."""
     rt = get_runtime()
     nd = len(shape)
     if nd > 8 or len(arrays) > 6:
         raise NotImplementedError('sum_multiply supports <= 8 axes and <= 6 operands')
+    if len(arrays) >= 2 and len(reduce_axes) > 0:
+        hoisted = _hoist_invariant(arrays, shape, reduce_axes, out_shape_keep, scale)
+        if hoisted is not None:
+            return hoisted
     out = DArray.empty(out_shape_keep)
     if len(arrays) >= 2 and len(reduce_axes) > 0 and _try_gemm(rt, arrays, shape, reduce_axes,
                                                                  out, scale):
         return out
+    # coalesce neighbouring axes of the same role (both kept or both reduced) that every
+    # operand and the output walk densely: the kernels decode a flat index into axes with
+    # 64-bit divisions, so fewer axes is directly fewer instructions per element
+    in_str = [_strides(a.t, shape) for a in arrays]
+    ostr = _strides(out.t, shape)
+    red = set(reduce_axes)
+    m_shape, m_red, m_in, m_out = [], [], [[] for _ in arrays], []
+    for ax in range(nd):
+        if shape[ax] == 1:
+            continue
+        if m_shape and (m_red[-1] == (ax in red)):
+            ext = shape[ax]
+            lists = m_in + ([m_out] if ax not in red else [])
+            cur = in_str + ([ostr] if ax not in red else [])
+            if all(l[-1] == c[ax] * ext for l, c in zip(lists, cur)):
+                m_shape[-1] *= ext
+                for l, c in zip(lists, cur):
+                    l[-1] = c[ax]
+                if ax in red:
+                    m_out[-1] = 0
+                continue
+        m_shape.append(shape[ax])
+        m_red.append(ax in red)
+        for l, c in zip(m_in, in_str):
+            l.append(c[ax])
+        m_out.append(0 if ax in red else ostr[ax])
+    nd = len(m_shape)
     mask = 0
-    for ax in reduce_axes:
-        mask |= 1 << ax
-    c_shape = (ctypes.c_int64 * max(nd, 1))(*shape)
+    for i, r in enumerate(m_red):
+        if r:
+            mask |= 1 << i
+    c_shape = (ctypes.c_int64 * max(nd, 1))(*m_shape)
     c_in = (ctypes.c_void_p * len(arrays))(*[a.t.data_ptr() for a in arrays])
     flat = []
-    for a in arrays:
-        flat += _strides(a.t, shape)
+    for l in m_in:
+        flat += l
     c_str = (ctypes.c_int64 * max(len(flat), 1))(*flat)
-    ostr = _strides(out.t, shape)
-    c_ostr = (ctypes.c_int64 * max(nd, 1))(*ostr)
+    c_ostr = (ctypes.c_int64 * max(nd, 1))(*m_out)
     ws = _workspace(rt)
     rt.sync_stream()
     rt.check(rt.lib.vmp_sum_multiply(
