@@ -297,7 +297,7 @@ ewise_kernel(EwiseArgs a, double *__restrict__ out)
 // the per-operation dispatch is paid once per NE elements.
 constexpr int EW_NE = 4;
 
-template <int NDIM>
+template <int NDIM, bool I32>
 __global__ void __launch_bounds__(NT)
 ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
 {
@@ -310,18 +310,36 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
             const int64_t e = e0 + j * span;
             ok[j] = e < a.total;
             const int64_t ee = ok[j] ? e : 0;
-            if (NDIM == 1) {
+            // flat index -> one coordinate per (merged) axis; 32-bit divisions when they fit
+            int64_t off[MAXIN];
 #pragma unroll
-                for (int i = 0; i < MAXIN; ++i)
-                    v[i][j] = (i < a.nin) ? a.in[i][ee * a.stride[i][0]] : 0.0;
+            for (int i = 0; i < MAXIN; ++i) off[i] = 0;
+            if (I32) {
+                uint32_t t = (uint32_t)ee;
+#pragma unroll
+                for (int d = NDIM - 1; d >= 1; --d) {
+                    const uint32_t sz = (uint32_t)a.shape[d];
+                    const uint32_t q = t / sz, c = t - q * sz;
+                    t = q;
+#pragma unroll
+                    for (int i = 0; i < MAXIN; ++i) off[i] += (int64_t)c * a.stride[i][d];
+                }
+#pragma unroll
+                for (int i = 0; i < MAXIN; ++i) off[i] += (int64_t)t * a.stride[i][0];
             } else {
-                // NDIM == 2: one division
-                const int64_t q = ee / a.shape[1];
-                const int64_t c = ee - q * a.shape[1];
+                int64_t t = ee;
 #pragma unroll
-                for (int i = 0; i < MAXIN; ++i)
-                    v[i][j] = (i < a.nin) ? a.in[i][q * a.stride[i][0] + c * a.stride[i][1]] : 0.0;
+                for (int d = NDIM - 1; d >= 1; --d) {
+                    const int64_t q = t / a.shape[d], c = t - q * a.shape[d];
+                    t = q;
+#pragma unroll
+                    for (int i = 0; i < MAXIN; ++i) off[i] += c * a.stride[i][d];
+                }
+#pragma unroll
+                for (int i = 0; i < MAXIN; ++i) off[i] += t * a.stride[i][0];
             }
+#pragma unroll
+            for (int i = 0; i < MAXIN; ++i) v[i][j] = (i < a.nin) ? a.in[i][off[i]] : 0.0;
         }
         double s0[EW_NE], s1[EW_NE], s2[EW_NE], s3[EW_NE];
 #pragma unroll
@@ -877,12 +895,22 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
     for (int c = 0; c < nconsts; ++c) a.consts[c] = consts[c];
     if (a.total == 0) return VMP_OK;
     const dim3 grid((unsigned)grid_for(ctx, a.total, NT * 4));
-    if (a.ndim <= 1)
-        hipLaunchKernelGGL(ewise_small_kernel<1>, grid, dim3(NT), 0, ctx->stream, a, out);
-    else if (a.ndim == 2)
-        hipLaunchKernelGGL(ewise_small_kernel<2>, grid, dim3(NT), 0, ctx->stream, a, out);
-    else
-        hipLaunchKernelGGL(ewise_kernel, grid, dim3(NT), 0, ctx->stream, a, out);
+    const bool i32 = a.total < ((int64_t)1 << 31);
+#define VMP_EW(nd)                                                                             \
+    do {                                                                                       \
+        if (i32)                                                                               \
+            hipLaunchKernelGGL((ewise_small_kernel<nd, true>), grid, dim3(NT), 0, ctx->stream, \
+                               a, out);                                                        \
+        else                                                                                   \
+            hipLaunchKernelGGL((ewise_small_kernel<nd, false>), grid, dim3(NT), 0,             \
+                               ctx->stream, a, out);                                           \
+    } while (0)
+    if (a.ndim <= 1) VMP_EW(1);
+    else if (a.ndim == 2) VMP_EW(2);
+    else if (a.ndim == 3) VMP_EW(3);
+    else if (a.ndim == 4) VMP_EW(4);
+    else hipLaunchKernelGGL(ewise_kernel, grid, dim3(NT), 0, ctx->stream, a, out);
+#undef VMP_EW
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
