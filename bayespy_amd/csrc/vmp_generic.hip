@@ -27,12 +27,24 @@ struct Iter {
     int64_t okstride[MAXD];
     const double *in[MAXIN];
     int64_t nkeep, nred;
+    int i32;                         // every flat index fits 32 bits: cheaper divisions
 };
 
 __device__ inline void decode_keep(const Iter &it, int64_t o, int64_t *off, int64_t &ooff)
 {
     for (int i = 0; i < it.nin; ++i) off[i] = 0;
     ooff = 0;
+    if (it.i32) {
+        uint32_t t = (uint32_t)o;
+        for (int d = it.nk - 1; d >= 0; --d) {
+            const uint32_t sz = (uint32_t)it.ksize[d];
+            const uint32_t q = t / sz, c = t - q * sz;
+            t = q;
+            for (int i = 0; i < it.nin; ++i) off[i] += (int64_t)c * it.kstride[i][d];
+            ooff += (int64_t)c * it.okstride[d];
+        }
+        return;
+    }
     for (int d = it.nk - 1; d >= 0; --d) {
         const int64_t q = o / it.ksize[d];
         const int64_t c = o - q * it.ksize[d];
@@ -48,6 +60,14 @@ __device__ inline double product_at(const Iter &it, const int64_t *base, int64_t
     for (int i = 0; i < it.nin; ++i) off[i] = base[i];
     if (it.nr == 1) {
         for (int i = 0; i < it.nin; ++i) off[i] += r * it.rstride[i][0];
+    } else if (it.i32) {
+        uint32_t t = (uint32_t)r;
+        for (int d = it.nr - 1; d >= 0; --d) {
+            const uint32_t sz = (uint32_t)it.rsize[d];
+            const uint32_t q = t / sz, c = t - q * sz;
+            t = q;
+            for (int i = 0; i < it.nin; ++i) off[i] += (int64_t)c * it.rstride[i][d];
+        }
     } else if (it.nr == 2) {
         const int64_t q = r / it.rsize[1];
         const int64_t c = r - q * it.rsize[1];
@@ -151,12 +171,22 @@ sum_multiply_fat_kernel(Iter it, int nsplit, double *__restrict__ partial)
     for (int64_t r = (int64_t)blockIdx.x * NT + tid; r < it.nred; r += (int64_t)gridDim.x * NT) {
         int64_t roff[MAXIN];
         for (int i = 0; i < it.nin; ++i) roff[i] = 0;
-        int64_t q = r;
-        for (int d = it.nr - 1; d >= 0; --d) {
-            const int64_t q2 = q / it.rsize[d];
-            const int64_t c = q - q2 * it.rsize[d];
-            q = q2;
-            for (int i = 0; i < it.nin; ++i) roff[i] += c * it.rstride[i][d];
+        if (it.i32) {
+            uint32_t q = (uint32_t)r;
+            for (int d = it.nr - 1; d >= 0; --d) {
+                const uint32_t sz = (uint32_t)it.rsize[d];
+                const uint32_t q2 = q / sz, c = q - q2 * sz;
+                q = q2;
+                for (int i = 0; i < it.nin; ++i) roff[i] += (int64_t)c * it.rstride[i][d];
+            }
+        } else {
+            int64_t q = r;
+            for (int d = it.nr - 1; d >= 0; --d) {
+                const int64_t q2 = q / it.rsize[d];
+                const int64_t c = q - q2 * it.rsize[d];
+                q = q2;
+                for (int i = 0; i < it.nin; ++i) roff[i] += c * it.rstride[i][d];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -737,6 +767,7 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         }
     }
     if (it.nkeep == 0) return VMP_OK;
+    it.i32 = (it.nkeep < ((int64_t)1 << 31) && it.nred < ((int64_t)1 << 31)) ? 1 : 0;
     hipStream_t s = ctx->stream;
     if (it.nred == 0) {
         // empty sum -> zeros
