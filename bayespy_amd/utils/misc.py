@@ -109,7 +109,9 @@ def _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
     nbatch = 1
     for d in Bd:
         nbatch *= shape[d]
-    if M < 8 or N < 8 or K < 16 or M * N * K * nbatch < (1 << 20) or nbatch > 65535:
+    # (short contractions with a large output are worth it too: the generic kernels pay a
+    # full index decode per output element)
+    if M < 8 or N < 8 or K < 4 or M * N * K * nbatch < (1 << 20) or nbatch > 65535:
         return False
     c3 = ctypes.c_int64 * 3
     bshape = c3(*([shape[d] for d in Bd] + [1] * (3 - len(Bd))))
