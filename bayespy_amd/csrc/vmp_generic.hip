@@ -549,8 +549,20 @@ __device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double *r
 {
     if constexpr (P < NP) {
         double row[NP];
+        if constexpr (NP == 16) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) row[j] = group_bcast<NP, P>(m[j], rowbuf, j, gl);
+            for (int j = 0; j < NP; ++j) row[j] = group_bcast<NP, P>(m[j], rowbuf, j, gl);
+        } else {
+            // the pivot lane publishes its whole row once, everybody reads it back
+            if (gl == P) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) rowbuf[j] = m[j];
+            }
+            lds_fence();
+#pragma unroll
+            for (int j = 0; j < NP; ++j) row[j] = rowbuf[j];
+            lds_fence();
+        }
         const double piv = row[P];
         if (!(piv > 0.0)) bad = 1;
         logdet_accumulate(piv, prod, ld);
@@ -563,41 +575,87 @@ __device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double *r
             const double base = (gl == P) ? 0.0 : m[j];
             m[j] = (j == P) ? ((gl == P) ? d : f) : base + (f + sc) * row[j];
         }
-        if constexpr (NP != 16) lds_fence();
         gj_rows_steps<NP, P + 1>(m, gl, rowbuf, prod, ld, bad);
     }
 }
 
 // x_i = sum_P m[P] * v_P and friends: every lane of the group needs the value held by
-// lane P, for all P (static unrolling: the DPP control is an immediate)
+// lane P, for all P.  NP = 16: DPP broadcasts (static unrolling: the control is an
+// immediate); otherwise the group exchanges the vector through its LDS row.
 template <int NP, int P>
+__device__ __forceinline__ void rows_dpp_matvec(const double (&m)[NP], double v, double &acc)
+{
+    if constexpr (P < NP) {
+        acc += m[P] * group_bcast<NP, P>(v, nullptr, 0, 0);
+        rows_dpp_matvec<NP, P + 1>(m, v, acc);
+    }
+}
+
+template <int NP, int P>
+__device__ __forceinline__ void rows_dpp_rank1(double (&m)[NP], double xi)
+{
+    if constexpr (P < NP) {
+        m[P] += xi * group_bcast<NP, P>(xi, nullptr, 0, 0);
+        rows_dpp_rank1<NP, P + 1>(m, xi);
+    }
+}
+
+template <int NP, int P>
+__device__ __forceinline__ void rows_dpp_sum(double v, double &acc)
+{
+    if constexpr (P < NP) {
+        acc += group_bcast<NP, P>(v, nullptr, 0, 0);
+        rows_dpp_sum<NP, P + 1>(v, acc);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void rows_exchange(double v, double *rowbuf, int gl, double (&all)[NP])
+{
+    rowbuf[gl] = v;
+    lds_fence();
+#pragma unroll
+    for (int j = 0; j < NP; ++j) all[j] = rowbuf[j];
+    lds_fence();
+}
+
+template <int NP>
 __device__ __forceinline__ void rows_matvec(const double (&m)[NP], double v, double *rowbuf, int gl,
                                             double &acc)
 {
-    if constexpr (P < NP) {
-        acc += m[P] * group_bcast<NP, P>(v, rowbuf, 0, gl);
-        if constexpr (NP != 16) lds_fence();
-        rows_matvec<NP, P + 1>(m, v, rowbuf, gl, acc);
+    if constexpr (NP == 16) {
+        rows_dpp_matvec<NP, 0>(m, v, acc);
+    } else {
+        double all[NP];
+        rows_exchange<NP>(v, rowbuf, gl, all);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc += m[j] * all[j];
     }
 }
 
-template <int NP, int P>
+template <int NP>
 __device__ __forceinline__ void rows_rank1(double (&m)[NP], double xi, double *rowbuf, int gl)
 {
-    if constexpr (P < NP) {
-        m[P] += xi * group_bcast<NP, P>(xi, rowbuf, 0, gl);
-        if constexpr (NP != 16) lds_fence();
-        rows_rank1<NP, P + 1>(m, xi, rowbuf, gl);
+    if constexpr (NP == 16) {
+        rows_dpp_rank1<NP, 0>(m, xi);
+    } else {
+        double all[NP];
+        rows_exchange<NP>(xi, rowbuf, gl, all);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) m[j] += xi * all[j];
     }
 }
 
-template <int NP, int P>
+template <int NP>
 __device__ __forceinline__ void rows_sum(double v, double *rowbuf, int gl, double &acc)
 {
-    if constexpr (P < NP) {
-        acc += group_bcast<NP, P>(v, rowbuf, 0, gl);
-        if constexpr (NP != 16) lds_fence();
-        rows_sum<NP, P + 1>(v, rowbuf, gl, acc);
+    if constexpr (NP == 16) {
+        rows_dpp_sum<NP, 0>(v, acc);
+    } else {
+        double all[NP];
+        rows_exchange<NP>(v, rowbuf, gl, all);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc += all[j];
     }
 }
 
@@ -648,10 +706,10 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
         if constexpr (MOMENTS) {
             const double p0 = (act && gl < n) ? rhs[(b0 + mb) * n + gl] : 0.0;
             double x = 0.0;
-            rows_matvec<NP, 0>(m, p0, rowbuf, gl, x);
+            rows_matvec<NP>(m, p0, rowbuf, gl, x);
             double s = 0.0;
-            rows_sum<NP, 0>(x * p0, rowbuf, gl, s);
-            rows_rank1<NP, 0>(m, x, rowbuf, gl);
+            rows_sum<NP>(x * p0, rowbuf, gl, s);
+            rows_rank1<NP>(m, x, rowbuf, gl);
             if (act && gl < n) vec_out[(b0 + mb) * n + gl] = x;
             lg = -0.5 * s + 0.5 * lg;
         }
