@@ -74,17 +74,17 @@ gemm_kernel(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
 
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
-        // A tile: BM x BK = 1024 elements, 4 per thread
+    // Tile loads go global -> registers -> LDS; the registers of tile k0+BK are filled while the
+    // MFMAs of tile k0 run (the loads' latency hides behind the matrix pipe).
+    double ra[4], rb[4];
+    auto fetch = [&](int64_t k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + e * NT;
             const int mi = a_kfast ? idx / BK : idx % BM;
             const int ki = a_kfast ? idx % BK : idx / BM;
             const int64_t m = m0 + mi, k = k0 + ki;
-            double v = 0.0;
-            if (m < g.M && k < k_end) v = A[m * g.a_ms + k * g.a_ks];
-            As[mi * LDA_S + ki] = v;
+            ra[e] = (m < g.M && k < k_end) ? A[m * g.a_ms + k * g.a_ks] : 0.0;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -92,11 +92,30 @@ gemm_kernel(GemmArgs g)
             const int ki = b_nfast ? idx / BN : idx % BK;
             const int ni = b_nfast ? idx % BN : idx / BK;
             const int64_t k = k0 + ki, n = n0 + ni;
-            double v = 0.0;
-            if (k < k_end && n < g.N) v = B[k * g.b_ks + n * g.b_ns];
-            Bs[ki * LDB_S + ni] = v;
+            rb[e] = (k < k_end && n < g.N) ? B[k * g.b_ks + n * g.b_ns] : 0.0;
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * NT;
+            const int mi = a_kfast ? idx / BK : idx % BM;
+            const int ki = a_kfast ? idx % BK : idx / BM;
+            As[mi * LDA_S + ki] = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * NT;
+            const int ki = b_nfast ? idx / BN : idx % BK;
+            const int ni = b_nfast ? idx % BN : idx / BK;
+            Bs[ki * LDB_S + ni] = rb[e];
+        }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage();
         __syncthreads();
+        if (k0 + BK < k_end) fetch(k0 + BK);
 #pragma unroll
         for (int q = 0; q < BK / 4; ++q) {
             double af[2], bf[2];
