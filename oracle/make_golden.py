@@ -535,6 +535,60 @@ def multinomial_case(name):
     print(name, out['L'], out['L2'])
 
 
+def summultiply_cases(name):
+    """SumMultiply beyond the PCA pattern (dot.py:19-633, the shapes of test_dot.py): a
+    matrix-vector product with a matrix-shaped Gaussian parent, and a three-factor product
+    with plates broadcast three ways (PARAFAC-like)."""
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy.inference import VB
+    rs = np.random.RandomState(31)
+    out = {}
+
+    def run(tag, Q, track, n_iter=4):
+        Q.ignore_bound_checks = True
+        Q.update(repeat=n_iter, verbose=False)
+        out[tag + '_L'] = np.array(Q.L[:Q.iter])
+        for nm, nd in track.items():
+            for i, ui in enumerate(nd.u):
+                out['%s_%s_u%d' % (tag, nm, i)] = np.array(ui)
+            out['%s_%s_L' % (tag, nm)] = np.array(Q.l[nd][:Q.iter])
+
+    # (a) y_n = A x_n + noise, A a (2,3) matrix-valued GaussianARD, x_n vectors
+    N = 30
+    A0 = rs.normal(size=(2, 3))
+    x_true = rs.normal(size=(N, 3))
+    y = x_true @ A0.T + 0.1 * rs.normal(size=(N, 2))
+    x0 = rs.normal(size=(N, 3))
+    A = GaussianARD(0, 1e-2, shape=(2, 3), name='A')
+    x = GaussianARD(0, 1, shape=(3,), plates=(N,), name='x')
+    F = SumMultiply('ij,j->i', A, x, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    x.initialize_from_value(x0)
+    Y.observe(y)
+    out['mv_y'], out['mv_x0'] = y, x0
+    run('mv', VB(Y, F, A, x, tau), dict(A=A, x=x, tau=tau))
+
+    # (b) three factors with plates (4,1,1), (1,5,1), (1,1,6), contracted over the component
+    I, J, Kp, C = 4, 5, 6, 2
+    a_t, b_t, c_t = rs.normal(size=(I, C)), rs.normal(size=(J, C)), rs.normal(size=(Kp, C))
+    y3 = np.einsum('ic,jc,kc->ijk', a_t, b_t, c_t) + 0.1 * rs.normal(size=(I, J, Kp))
+    b0, c0 = rs.normal(size=(1, J, 1, C)), rs.normal(size=(1, 1, Kp, C))
+    a = GaussianARD(0, 1e-1, shape=(C,), plates=(I, 1, 1), name='a')
+    b = GaussianARD(0, 1e-1, shape=(C,), plates=(1, J, 1), name='b')
+    c = GaussianARD(0, 1e-1, shape=(C,), plates=(1, 1, Kp), name='c')
+    F3 = SumMultiply('i,i,i', a, b, c, name='F3')
+    tau3 = Gamma(1e-2, 1e-2, name='tau3')
+    Y3 = GaussianARD(F3, tau3, name='Y3')
+    b.initialize_from_value(b0)
+    c.initialize_from_value(c0)
+    Y3.observe(y3)
+    out['pf_y'], out['pf_b0'], out['pf_c0'] = y3, b0, c0
+    run('pf', VB(Y3, F3, a, b, c, tau3), dict(a=a, b=b, c=c, tau3=tau3))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, out['mv_L'], out['pf_L'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -553,6 +607,7 @@ def main():
     pca_doctest_case('pca_doctest')
     svi_case('svi_gmm')
     multinomial_case('multinomial')
+    summultiply_cases('summultiply')
 
 
 if __name__ == '__main__':

@@ -332,3 +332,50 @@ def test_dirichlet_multinomial_matches_reference(golden_dir):
         x.observe(bad)
     with pytest.raises(ValueError, match='integer'):
         Multinomial(2.5, p2)
+
+
+def test_summultiply_general_patterns_match_reference(golden_dir):
+    """SumMultiply beyond the PCA pattern (dot.py:19-633): 'ij,j->i' with a matrix-valued
+    GaussianARD parent, and a three-factor product with plates broadcast three ways."""
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'summultiply.npz'))
+
+    def check(tag, Q, track):
+        n = len(g[tag + '_L'])
+        L = _trace(Q, n)
+        np.testing.assert_allclose(L, g[tag + '_L'], rtol=ELBO_RTOL)
+        for nm, nd in track.items():
+            np.testing.assert_allclose(Q.l[nd][:n], g['%s_%s_L' % (tag, nm)], rtol=1e-8, atol=1e-7,
+                                       err_msg=nm)
+            for i, ui in enumerate(nd.u):
+                ref = g['%s_%s_u%d' % (tag, nm, i)]
+                np.testing.assert_allclose(np.broadcast_to(ui, ref.shape), ref, rtol=MOM_RTOL,
+                                           atol=1e-10, err_msg='%s u%d' % (nm, i))
+
+    y, x0 = g['mv_y'], g['mv_x0']
+    N = y.shape[0]
+    A = GaussianARD(0, 1e-2, shape=(2, 3), name='A')
+    x = GaussianARD(0, 1, shape=(3,), plates=(N,), name='x')
+    F = SumMultiply('ij,j->i', A, x, name='F')
+    assert F.plates == (N,) and F.dims == ((2,), (2, 2))
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    x.initialize_from_value(x0)
+    Y.observe(y)
+    check('mv', VB(Y, F, A, x, tau), dict(A=A, x=x, tau=tau))
+
+    y3, b0, c0 = g['pf_y'], g['pf_b0'], g['pf_c0']
+    I, J, Kp = y3.shape
+    C = b0.shape[-1]
+    a = GaussianARD(0, 1e-1, shape=(C,), plates=(I, 1, 1), name='a')
+    b = GaussianARD(0, 1e-1, shape=(C,), plates=(1, J, 1), name='b')
+    c = GaussianARD(0, 1e-1, shape=(C,), plates=(1, 1, Kp), name='c')
+    F3 = SumMultiply('i,i,i', a, b, c, name='F3')
+    assert F3.plates == (I, J, Kp)
+    tau3 = Gamma(1e-2, 1e-2, name='tau3')
+    Y3 = GaussianARD(F3, tau3, name='Y3')
+    b.initialize_from_value(b0)
+    c.initialize_from_value(c0)
+    Y3.observe(y3)
+    check('pf', VB(Y3, F3, a, b, c, tau3), dict(a=a, b=b, c=c, tau3=tau3))
