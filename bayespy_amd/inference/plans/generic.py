@@ -510,13 +510,16 @@ class MixtureFamily(Family):
         msgs = self.base.message_to_parent(index - 1, uk, up[1:])
         out = []
         parent = self.node.parents[index]
+        # variable axes the mixed family maps onto plates of this parent (the precision of a
+        # GaussianARD has the variable's shape among its plates) trail the cluster axis too
+        extra = len(self.plates_to_parent(index)) - len(self.node.plates) - 1
         for i, m in enumerate(msgs):
             if m is None:
                 out.append(None)
                 continue
             nd = len(parent.dims[i])
             # weight by the responsibilities: a lazy product, fused with the plate sum
-            out.append((_arr(m), _trail(p, nd)))
+            out.append((_arr(m), _trail(p, nd + extra)))
         return out
 
 

@@ -13,6 +13,7 @@ from ..utils.shapes import broadcasted_shape
 
 
 class Categorical(Stochastic):
+    _parent_count = 1
 
     def __init__(self, p, plates=None, name=None, plates_multiplier=None):
         super().__init__(p, plates=(), dims=((),), name=name)

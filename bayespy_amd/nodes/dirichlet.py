@@ -9,6 +9,7 @@ from ..utils.shapes import broadcasted_shape
 
 
 class Dirichlet(Stochastic):
+    _parent_count = 1
 
     def __init__(self, alpha, plates=None, name=None, plates_multiplier=None):
         super().__init__(alpha, plates=(), dims=((),), name=name)

@@ -11,6 +11,7 @@ from ..utils.shapes import broadcasted_shape
 
 class Gamma(Stochastic):
     """``Gamma(a, b, plates=(), name=...)`` -- shape a, rate b."""
+    _parent_count = 2
 
     def __init__(self, a, b, plates=None, name=None, plates_multiplier=None):
         super().__init__(a, b, plates=(), dims=((), ()), name=name)

@@ -13,6 +13,7 @@ from ..utils.shapes import broadcasted_shape
 
 
 class GaussianARD(Stochastic):
+    _parent_count = 2
 
     def __init__(self, mu, alpha, ndim=None, shape=None, plates=None, name=None,
                  plates_multiplier=None):
@@ -58,6 +59,7 @@ class Gaussian(Stochastic):
     matrix ``Lambda`` (Wishart node or SPD array) -- reference gaussian.py:1346-1556,
     formulas gaussian.py:293-573; the joint (mu, Lambda) wrapper of the reference
     (``WrapToGaussianWishart``, gaussian.py:2374-2527) is folded into the formulas."""
+    _parent_count = 2
 
     def __init__(self, mu, Lambda, plates=None, name=None, plates_multiplier=None):
         super().__init__(mu, Lambda, plates=(), dims=((), ()), name=name)

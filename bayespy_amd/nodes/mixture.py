@@ -12,16 +12,23 @@ from ..utils.shapes import broadcasted_shape
 class Mixture(Stochastic):
 
     def __init__(self, z, node_class, *params, cluster_plate=-1, plates=None, name=None,
-                 plates_multiplier=None):
+                 plates_multiplier=None, **node_kwargs):
         if cluster_plate != -1:
             raise NotImplementedError('only cluster_plate=-1 is built')
+        # positional arguments beyond the parents of the mixed class are constructor
+        # arguments of that class (the reference forwards them to ``_constructor``, e.g. the
+        # ``ndim`` of ``Mixture(z, GaussianARD, mu, alpha, 1)``; mixture.py:398-420)
+        npar = getattr(node_class, '_parent_count', None)
+        extra = ()
+        if npar is not None and len(params) > npar:
+            params, extra = params[:npar], params[npar:]
         super().__init__(z, *params, plates=(), dims=((), ()), name=name)
         self._plates_multiplier_arg = plates_multiplier
         self.node_class = node_class
         self.cluster_plate = cluster_plate
         # a throw-away instance of the mixed node class gives dims and plates
         # (with the cluster axis still among the plates)
-        proto = node_class(*self.parents[1:])
+        proto = node_class(*self.parents[1:], *extra, **node_kwargs)
         for p in self.parents[1:]:
             p.children = [(c, i) for (c, i) in p.children if c is not proto]
         self._proto = proto

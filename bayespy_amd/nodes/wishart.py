@@ -12,6 +12,7 @@ from ..utils.shapes import broadcasted_shape
 
 
 class Wishart(Stochastic):
+    _parent_count = 2
 
     def __init__(self, n, V, plates=None, name=None, plates_multiplier=None):
         super().__init__(n, V, plates=(), dims=((), ()), name=name)

@@ -589,6 +589,37 @@ def summultiply_cases(name):
     print(name, out['mv_L'], out['pf_L'])
 
 
+def mixture_ard_case(name):
+    """Mixture over GaussianARD components (diagonal covariances: latent means AND Gamma
+    precisions per cluster and dimension, mixture.py:359-545 with gaussian.py:1559-1774)."""
+    from bayespy.nodes import GaussianARD, Gamma, Dirichlet, Categorical, Mixture
+    from bayespy.inference import VB
+    rs = np.random.RandomState(41)
+    N, D, K = 120, 3, 4
+    centers = 3 * rs.normal(size=(K, D))
+    lab = rs.randint(K, size=N)
+    y = centers[lab] + rs.normal(size=(N, D)) * np.array([0.3, 0.6, 1.0])
+    lab0 = rs.randint(K, size=N)
+    alpha = Dirichlet(np.ones(K), name='alpha')
+    z = Categorical(alpha, plates=(N,), name='z')
+    mu = GaussianARD(0, 1e-2, shape=(D,), plates=(K,), name='mu')
+    lam = Gamma(1e-1, 1e-1, plates=(K, D), name='lam')
+    Y = Mixture(z, GaussianARD, mu, lam, 1, name='Y')      # positional ndim=1 of GaussianARD
+    z.initialize_from_value(lab0)
+    Y.observe(y)
+    Q = VB(Y, mu, lam, z, alpha)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=4, verbose=False)
+    out = dict(y=y, lab0=lab0, L=np.array(Q.L[:Q.iter]))
+    for nm, nd in dict(alpha=alpha, z=z, mu=mu, lam=lam).items():
+        for i, ui in enumerate(nd.u):
+            out['%s_u%d' % (nm, i)] = np.array(ui)
+        out['%s_L' % nm] = np.array(Q.l[nd][:Q.iter])
+    out['Y_L'] = np.array(Q.l[Y][:Q.iter])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, out['L'], Y.plates, mu.plates, lam.plates)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -608,6 +639,7 @@ def main():
     svi_case('svi_gmm')
     multinomial_case('multinomial')
     summultiply_cases('summultiply')
+    mixture_ard_case('mixture_ard')
 
 
 if __name__ == '__main__':

@@ -379,3 +379,37 @@ def test_summultiply_general_patterns_match_reference(golden_dir):
     c.initialize_from_value(c0)
     Y3.observe(y3)
     check('pf', VB(Y3, F3, a, b, c, tau3), dict(a=a, b=b, c=c, tau3=tau3))
+
+
+def test_mixture_of_gaussian_ard_matches_reference(golden_dir):
+    """Mixture over GaussianARD components with a latent mean and a latent Gamma precision per
+    cluster and dimension (mixture.py:359-545 over gaussian.py:1559-1774); the trailing
+    positional ``1`` is the ``ndim`` the reference forwards to the mixed class."""
+    from bayespy_amd.nodes import GaussianARD, Gamma, Dirichlet, Categorical, Mixture
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'mixture_ard.npz'))
+    y, lab0 = g['y'], g['lab0']
+    N, D = y.shape
+    K = g['mu_u0'].shape[0]
+    alpha = Dirichlet(np.ones(K), name='alpha')
+    z = Categorical(alpha, plates=(N,), name='z')
+    mu = GaussianARD(0, 1e-2, shape=(D,), plates=(K,), name='mu')
+    lam = Gamma(1e-1, 1e-1, plates=(K, D), name='lam')
+    Y = Mixture(z, GaussianARD, mu, lam, 1, name='Y')
+    assert Y.plates == (N,) and Y.dims == ((D,), (D, D))
+    z.initialize_from_value(lab0)
+    Y.observe(y)
+    Q = VB(Y, mu, lam, z, alpha)
+    n = len(g['L'])
+    L = _trace(Q, n)
+    np.testing.assert_allclose(L, g['L'], rtol=ELBO_RTOL)
+    for nm, nd in dict(alpha=alpha, z=z, mu=mu, lam=lam).items():
+        np.testing.assert_allclose(Q.l[nd][:n], g['%s_L' % nm], rtol=1e-8, atol=1e-7, err_msg=nm)
+        for i, ui in enumerate(nd.u):
+            ref = g['%s_u%d' % (nm, i)]
+            np.testing.assert_allclose(np.broadcast_to(ui, ref.shape), ref, rtol=MOM_RTOL,
+                                       atol=1e-10, err_msg='%s u%d' % (nm, i))
+    np.testing.assert_allclose(Q.l[Y][:n], g['Y_L'], rtol=1e-8)
+    # the keyword form builds the same node
+    Y2 = Mixture(z, GaussianARD, mu, lam, ndim=1)
+    assert Y2.plates == Y.plates and Y2.dims == Y.dims
