@@ -111,6 +111,19 @@ __host__ __device__ inline double vmp_lgamma(double x)
     return (x - 0.5) * log(x) - x + 0.91893853320467274178 + ser - shift;
 }
 
+// psi'(x) (trigamma; scipy.special.polygamma(1, .) call sites gamma.py:210,
+// dirichlet.py:230) for x > 0: upward recurrence to x >= 10, then the asymptotic series
+// 1/x + 1/(2x^2) + sum_n B_2n / x^(2n+1).
+__host__ __device__ inline double vmp_trigamma(double x)
+{
+    if (!(x > 0.0)) return (x == 0.0) ? INFINITY : NAN;
+    double s = 0.0;
+    while (x < 10.0) { s += 1.0 / (x * x); x += 1.0; }
+    double inv = 1.0 / x, inv2 = inv * inv;
+    double ser = inv * inv2 * (1.0 / 6 - inv2 * (1.0 / 30 - inv2 * (1.0 / 42 - inv2 * (1.0 / 30 - inv2 * (5.0 / 66 - inv2 * (691.0 / 2730 - inv2 * (7.0 / 6)))))));
+    return s + inv + 0.5 * inv2 + ser;
+}
+
 #ifdef __HIPCC__
 // Running log-determinant without a log per pivot: the product of the pivots is kept in
 // `prod` and folded into `ld` only when it leaves a safe range (fp64 log is ~1000 cycles on

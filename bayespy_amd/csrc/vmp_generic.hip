@@ -307,6 +307,7 @@ ewise_kernel(EwiseArgs a, double *__restrict__ out)
             case VMP_OP_RECIP:   s0 = 1.0 / s0; break;
             case VMP_OP_DIGAMMA: s0 = vmp_digamma(s0); break;
             case VMP_OP_LGAMMA:  s0 = vmp_lgamma(s0); break;
+            case VMP_OP_TRIGAMMA: s0 = vmp_trigamma(s0); break;
             case VMP_OP_MAX:     BIN(fmax(x, y)); break;
             case VMP_OP_MIN:     BIN(fmin(x, y)); break;
             case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;   // 0 * -inf guard
@@ -400,6 +401,7 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
             case VMP_OP_RECIP:   UNA(1.0 / x); break;
             case VMP_OP_DIGAMMA: UNA(vmp_digamma(x)); break;
             case VMP_OP_LGAMMA:  UNA(vmp_lgamma(x)); break;
+            case VMP_OP_TRIGAMMA: UNA(vmp_trigamma(x)); break;
             case VMP_OP_MAX:     BIN(fmax(x, y)); break;
             case VMP_OP_MIN:     BIN(fmin(x, y)); break;
             case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;

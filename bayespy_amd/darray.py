@@ -23,7 +23,8 @@ from .device import get_runtime
 
 # opcodes of include/vmp_hip.h
 (OP_IN, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_LOG, OP_EXP, OP_SQR, OP_SQRT,
- OP_RECIP, OP_DIGAMMA, OP_LGAMMA, OP_MAX, OP_MIN, OP_WHERE_NZ, OP_DUP, OP_SWAP) = range(19)
+ OP_RECIP, OP_DIGAMMA, OP_LGAMMA, OP_MAX, OP_MIN, OP_WHERE_NZ, OP_DUP, OP_SWAP,
+ OP_TRIGAMMA) = range(20)
 MAX_OPS, MAX_CONSTS, MAX_IN, MAX_DIMS = 48, 8, 6, 8
 
 
@@ -161,6 +162,7 @@ def _un(op):
 
 log, exp, sqrt, square = _un(OP_LOG), _un(OP_EXP), _un(OP_SQRT), _un(OP_SQR)
 digamma, gammaln, recip = _un(OP_DIGAMMA), _un(OP_LGAMMA), _un(OP_RECIP)
+trigamma = _un(OP_TRIGAMMA)
 
 
 def maximum(a, b): return Expr(OP_MAX, (Expr.wrap(a), Expr.wrap(b)))

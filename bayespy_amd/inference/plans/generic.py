@@ -111,6 +111,33 @@ def _gaussian_q_term(family_ndim, shape, phi, u, g):
 
 
 
+def _gaussian_gradient(rg, u, ndim, shape):
+    """Euclidean gradient of a Gaussian factor given the Riemannian one (the chain rule of
+    gaussian.py:489-556 / :824-892) -- with Cov = <xx> - <x><x>^T:
+    d0 = Cov g0 + 2 Cov g1 x,   d1 = Cov g0 x^T + x (Cov g0)^T + 2 <xx> g1 <xx> - 2 (x^T g1 x) x x^T."""
+    x, xx, g0, g1 = _arr(u[0]), _arr(u[1]), _arr(rg[0]), _arr(rg[1])
+    if ndim == 0:
+        d0 = fuse(lambda x_, q, a, b: (q - x_ * x_) * (a + 2 * b * x_), x, xx, g0, g1)
+        d1 = fuse(lambda x_, q, a, b: 2 * (q - x_ * x_) * a * x_ + 2 * q * b * q
+                  - 2 * x_ * x_ * b * x_ * x_, x, xx, g0, g1)
+        return [d0, d1]
+    D = int(np.prod(shape))
+
+    def flat(a, k):
+        return a.reshape(a.shape[:a.ndim - k * ndim] + (D,) * k)
+    x, xx, g0, g1 = flat(x, 1), flat(xx, 2), flat(g0, 1), flat(g1, 2)
+    cov = fuse(lambda q, a, b: q - a * b, xx, _trail(x, 1), x.reshape(x.shape[:-1] + (1, D)))
+    cov_g0 = linalg.mvdot(cov, g0)
+    g1_x = linalg.mvdot(g1, x)
+    d0 = fuse(lambda a, b: a + 2 * b, cov_g0, linalg.mvdot(cov, g1_x))
+    c = linalg.outer(cov_g0, x)
+    d1 = fuse(lambda c_, ct, m, xa, xb, s_: c_ + ct + 2 * m - 2 * xa * xb * s_,
+              c, linalg.transpose(c), linalg.mmdot(xx, linalg.mmdot(g1, xx)),
+              _trail(x, 1), x.reshape(x.shape[:-1] + (1, D)), _trail(linalg.inner(g1_x, x), 2))
+    return [d0.reshape(d0.shape[:-1] + tuple(shape)),
+            d1.reshape(d1.shape[:-2] + tuple(shape) + tuple(shape))]
+
+
 # ---------------------------------------------------------------------------
 # families: the five VMP formulas per node type
 # ---------------------------------------------------------------------------
@@ -127,6 +154,11 @@ class Family:
 
     def constant_moments(self, index, value):
         raise NotImplementedError
+
+    def gradient(self, rg, u, phi):
+        """Euclidean gradient from the Riemannian one (expfamily.py:64-70)."""
+        raise NotImplementedError("Standard gradient not yet implemented for %s"
+                                  % type(self.node).__name__)
 
 
 class GammaFamily(Family):
@@ -160,6 +192,12 @@ class GammaFamily(Family):
         if index == 1:
             return [fuse(lambda x: -x, u[0]), up[0][0]]
         raise NotImplementedError('message from Gamma to its shape parameter')
+
+    def gradient(self, rg, u, phi):
+        # gamma.py:183-211
+        d0 = fuse(lambda a, b, p0, p1: a * p1 / (p0 * p0) - b / p0, rg[0], rg[1], phi[0], phi[1])
+        d1 = fuse(lambda a, b, p0, p1: b * da.trigamma(p1) - a / p0, rg[0], rg[1], phi[0], phi[1])
+        return [d0, d1]
 
 
 class GaussianARDFamily(Family):
@@ -238,6 +276,9 @@ class GaussianARDFamily(Family):
     def q_term(self, phi, u, g):
         return _gaussian_q_term(self.ndim, self.shape, phi, u, g)
 
+    def gradient(self, rg, u, phi):
+        return _gaussian_gradient(rg, u, self.ndim, self.shape)
+
     def cgf_from_parents(self, up):
         m, m2 = self._mu(up)
         a, loga = up[1]
@@ -291,6 +332,7 @@ class GaussianFamily(Family):
 
     moments_and_cgf = GaussianARDFamily.moments_and_cgf
     q_term = GaussianARDFamily.q_term
+    gradient = GaussianARDFamily.gradient
 
     def cgf_from_parents(self, up):
         mm = up[0][1]
@@ -388,6 +430,12 @@ class DirichletFamily(Family):
     def message_to_parent(self, index, u, up):
         raise NotImplementedError('Dirichlet concentration is a constant in the built path')
 
+    def gradient(self, rg, u, phi):
+        # dirichlet.py:213-231
+        p = _arr(phi[0])
+        s = misc.sum_multiply(p, axis=-1, keepdims=True)
+        return [fuse(lambda g, a, t: g * (da.trigamma(a) - da.trigamma(t)), rg[0], p, s)]
+
 
 class CategoricalFamily(Family):
     """categorical.py:25-126, multinomial.py:62-231 (one trial)."""
@@ -415,6 +463,14 @@ class CategoricalFamily(Family):
     def message_to_parent(self, index, u, up):
         return [u[0]]
 
+    _trials = 1.0
+
+    def gradient(self, rg, u, phi):
+        # multinomial.py:161-212:  u_i (g_i - sum_j g_j u_j / N)
+        t = misc.sum_multiply(_arr(rg[0]), _arr(u[0]), axis=-1, keepdims=True)
+        n = self._trials if not isinstance(self._trials, DArray) else _trail(self._trials, 1)
+        return [fuse(lambda u_, g, t_, n_: u_ * (g - t_ / n_), u[0], rg[0], t, n)]
+
 
 class MultinomialFamily(CategoricalFamily):
     """multinomial.py:62-231 with N trials (an integer or an integer array over the plates)."""
@@ -423,6 +479,7 @@ class MultinomialFamily(CategoricalFamily):
         super().__init__(node)
         self.trials = np.asarray(node.trials, dtype=np.float64)
         self.Nd = DArray.from_host(self.trials)
+        self._trials = self.Nd
 
     def moments_and_cgf(self, phi):
         p, lse = misc.normalized_exp(_arr(phi[0]))
@@ -493,15 +550,17 @@ class MixtureFamily(Family):
     def fixed_moments_and_f(self, x):
         return self.base.fixed_moments_and_f(x)
 
+    def gradient(self, rg, u, phi):
+        return self.base.gradient(rg, u, phi)          # mixture.py:352-356
+
     def message_to_parent(self, index, u, up):
         uk = self._with_cluster_axis(u)
         if index == 0:
             # E[log p(y | cluster k)] for every cluster (mixture.py:67-104, expfamily.py:45-61)
             phik = self.base.phi_from_parents(up[1:])
+            # f(y) is left out like in the reference (it passes f = 0, mixture.py:92-98): it
+            # is the same for every cluster and cancels in the normalisation of q(z)
             L = _arr(self.base.cgf_from_parents(up[1:]))
-            f = self._f
-            if f is not None:
-                L = fuse(lambda a, b: a + b, L, f if not isinstance(f, DArray) else _trail(f, 1))
             for ph, ui, nd in zip(phik, uk, self.ndims):
                 t = fuse(lambda a, b: da.where_nonzero(b, a) * b, _arr(ph), ui)
                 L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
@@ -910,6 +969,19 @@ class GenericPlan:
             init = node._init
             if init is None:
                 st.u, st.g = fam.moments_and_cgf(st.phi)      # initialize_from_prior
+            elif init[0] == 'parameters':
+                # initialize_from_parameters (expfamily.py:187-190): the given values stand
+                # in for the parents
+                if len(init[1]) != len(node.parents):
+                    raise ValueError('%s has %d parents, %d parameters were given'
+                                     % (node.name, len(node.parents), len(init[1])))
+                ups = [fam.constant_moments(i, a) for i, a in enumerate(init[1])]
+                st.phi = fam.phi_from_parents(ups)
+                st.u, st.g = fam.moments_and_cgf(st.phi)
+            elif init[0] == 'phi':
+                st.phi = [_arr(np.array(x, dtype=np.float64)) if not isinstance(x, DArray) else x
+                          for x in init[1]]
+                st.u, st.g = fam.moments_and_cgf(st.phi)
             elif init[0] == 'value':
                 st.u, _ = fam.fixed_moments_and_f(init[1])
                 st.g = np.inf
@@ -941,7 +1013,17 @@ class GenericPlan:
             Lc = np.linalg.cholesky(cov + 1e-12 * np.eye(D))
             z = np.random.randn(mf.shape[0], D)
             return (mf + np.einsum('nij,nj->ni', Lc, z)).reshape(shape)
-        raise NotImplementedError('initialize_from_random for %s' % type(node).__name__)
+        if isinstance(node, Gamma):
+            st = self.state[id(node)]
+            a = np.broadcast_to(_arr(st.phi[1]).numpy(), node.plates)
+            b = np.broadcast_to(-_arr(st.phi[0]).numpy(), node.plates)
+            return np.random.gamma(a, 1.0 / b)
+        if isinstance(node, Dirichlet):
+            st = self.state[id(node)]
+            a = np.broadcast_to(_arr(st.phi[0]).numpy(), node.plates + node.dims[0])
+            x = np.random.gamma(a)
+            return x / x.sum(axis=-1, keepdims=True)
+        raise NotImplementedError('random draws for %s' % type(node).__name__)
 
     def _moments(self, node):
         if isinstance(node, Stochastic):
@@ -1022,6 +1104,9 @@ class GenericPlan:
             return self.state[id(node)].mask
         return node._gmask
 
+    def get_mask(self, node):
+        return np.array(self._mask_array(node))
+
     def _mask_factor(self, key, make_host_mask):
         """None when everything is active, else a 0/1 device array.  Cached per `key` until the
         masks change (host masks are N-sized: scanning them every message would dominate)."""
@@ -1052,8 +1137,6 @@ class GenericPlan:
             return fam.message_to_parent(index, m_child, ups, mask)
         u = self._moments(child)
         up = self._parent_moments(child)
-        if isinstance(fam, MixtureFamily):
-            fam._f = self._ensure(child).f if isinstance(child, Stochastic) else None
         msgs = fam.message_to_parent(index, u, up)
         plates_self = tuple(fam.plates_to_parent(index))
         mask, _ = self._mask_factor(
@@ -1131,9 +1214,13 @@ class GenericPlan:
         up = self._parent_moments(node)
         phi = fam.phi_from_parents(up)
         msgs = self._messages_from_children(node)
+        a = float(getattr(node, 'annealing', 1.0))
         for i in range(len(phi)):
             if msgs[i] is not None:
-                phi[i] = fuse(lambda a, b: a + b, _arr(phi[i]), msgs[i])
+                phi[i] = fuse(lambda p, m: p + m, _arr(phi[i]), msgs[i])
+            if a != 1.0:
+                # deterministic annealing (expfamily.py:343-350)
+                phi[i] = fuse(lambda p, a_=a: a_ * p, _arr(phi[i]))
         return phi
 
     @_operation
@@ -1167,7 +1254,7 @@ class GenericPlan:
             st.phi = phi
             st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
 
-    def _lower_bound_device(self, node):
+    def _lower_bound_device(self, node, ignore_masked=True):
         """The node's lower-bound term (expfamily.py:400-480) as (device scalar | None,
         host factor): no device->host read here."""
         if not isinstance(node, Stochastic):
@@ -1178,17 +1265,20 @@ class GenericPlan:
         phi_p = fam.phi_from_parents(up)
         L = _arr(fam.cgf_from_parents(up))
         closed = None
+        # annealing temperature: the entropy part of the term, i.e. phi and g of q, is
+        # multiplied by T (expfamily.py:403-411)
+        T = 1.0 / float(getattr(node, 'annealing', 1.0))
         if st.observed:
             L = fuse(lambda a, b: a + b, L, st.f if isinstance(st.f, DArray) else float(st.f))
         else:
             if not isinstance(st.g, DArray):
                 return None, (float(-np.inf) if np.isinf(st.g) else float('nan'))
-            closed = getattr(fam, 'q_term', None)
+            closed = getattr(fam, 'q_term', None) if T == 1.0 else None
             if closed is not None:
                 # Gaussian factors: -(g_q + phi_q . u_q) in closed form, no K x K contraction
                 L = fuse(lambda a, q: a + q, L, closed(st.phi, st.u, st.g))
             else:
-                L = fuse(lambda a, g: a - g, L, st.g)
+                L = fuse(lambda a, g, T_=T: a - T_ * g, L, st.g)
         for i, nd in enumerate(len(d) for d in node.dims):
             if closed is not None and nd > 0:
                 # finite Gaussian prior parameters: phi_p . u as one contraction, no temporary
@@ -1199,11 +1289,13 @@ class GenericPlan:
             if st.observed or closed is not None:
                 t = fuse(lambda pp, u: da.where_nonzero(u, pp) * u, _arr(phi_p[i]), _arr(st.u[i]))
             else:
-                t = fuse(lambda pp, pq, u: da.where_nonzero(u, pp - pq) * u, _arr(phi_p[i]),
-                         _arr(st.phi[i]), _arr(st.u[i]))
+                t = fuse(lambda pp, pq, u, T_=T: da.where_nonzero(u, pp - T_ * pq) * u,
+                         _arr(phi_p[i]), _arr(st.phi[i]), _arr(st.u[i]))
             L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
         factors = [L]
         mask, any_active = self._mask_factor((id(node), 'self'), lambda: self._mask_array(node))
+        if not ignore_masked:
+            mask, any_active = None, True
         if mask is not None:
             factors.append(mask)
         sharded = self._is_sharded(node)
@@ -1218,8 +1310,8 @@ class GenericPlan:
         return tot, float(np.prod(node.plates_multiplier))
 
     @_operation
-    def lower_bound_contribution(self, node):
-        tot, factor = self._lower_bound_device(node)
+    def lower_bound_contribution(self, node, ignore_masked=True):
+        tot, factor = self._lower_bound_device(node, ignore_masked)
         return factor if tot is None else tot.item() * factor
 
     @_operation
@@ -1312,6 +1404,87 @@ class GenericPlan:
         if isinstance(st.g, DArray):
             st.g = fuse(lambda g: g - float(logdetR), st.g)
 
-    def get_parameters(self, node):
+    # -- natural parameters, gradients, densities (expfamily.py:258-340, :483-542) --------------
+    def _latent_state(self, node):
         st = self._ensure(node)
-        return [np.asarray(_arr(p).numpy()) for p in st.phi]
+        if st.observed or st.phi is None:
+            raise ValueError('node %s is observed: it has no variational parameters' % node.name)
+        return st
+
+    def natural_parameters(self, node):
+        """phi of q(node) as device arrays (shared with the plan: do not modify)."""
+        return [_arr(p) for p in self._latent_state(node).phi]
+
+    def get_parameters(self, node):
+        return [np.array(p.numpy()) for p in self.natural_parameters(node)]
+
+    @_operation
+    def set_parameters(self, node, x):
+        st = self._latent_state(node)
+        if len(x) != len(st.phi):
+            raise ValueError('%s has %d natural parameters, %d were given'
+                             % (node.name, len(st.phi), len(x)))
+        phi = []
+        for i, xi in enumerate(x):
+            xi = xi if isinstance(xi, DArray) else _arr(np.array(xi, dtype=np.float64))
+            if not is_shape_subset(xi.shape, node.plates + node.dims[i]):
+                raise ValueError('parameter %d of shape %s does not broadcast to %s'
+                                 % (i, xi.shape, node.plates + node.dims[i]))
+            phi.append(xi)
+        u, g = self.family[id(node)].moments_and_cgf(phi)
+        self.rt.check_deferred()         # an invalid phi leaves the node as it was
+        st.phi, st.u, st.g = phi, u, g
+
+    def log_normalizer(self, node):
+        """(g, f) of the node as host values (nan where not defined, expfamily.py:125-126)."""
+        st = self._ensure(node)
+
+        def host(v):
+            if v is None:
+                return np.array(np.nan)
+            return np.array(v.numpy()) if isinstance(v, DArray) else np.array(float(v))
+        return host(st.g), host(st.f)
+
+    @_operation
+    def riemannian_gradient(self, node):
+        """annealing * (phi_prior + sum of messages) - phi, with the full shape of the
+        parameters (expfamily.py:258-278)."""
+        st = self._latent_state(node)
+        opt = self._optimal_phi(node)
+        out = []
+        for i, (q, p) in enumerate(zip(opt, st.phi)):
+            d = fuse(lambda a, b: a - b, _arr(q), _arr(p))
+            full = node.plates + node.dims[i]
+            if d.shape != full:
+                d = fuse(lambda a, o: a * o, d, _ones(full))
+            out.append(d)
+        return out
+
+    @_operation
+    def gradient(self, node, rg):
+        """Euclidean gradient with respect to phi from the Riemannian one
+        (expfamily.py:281-294)."""
+        st = self._latent_state(node)
+        rg = [r if isinstance(r, DArray) else _arr(np.asarray(r, dtype=np.float64)) for r in rg]
+        g = self.family[id(node)].gradient(rg, st.u, st.phi)
+        a = float(getattr(node, 'annealing', 1.0))
+        if a != 1.0:
+            g = [fuse(lambda v, a_=a: v / a_, gi) for gi in g]
+        return g
+
+    @_operation
+    def logpdf(self, node, X):
+        """log q(X) = g + f(X) + sum_i phi_i . u_i(X)   (expfamily.py:483-498)."""
+        st = self._latent_state(node)
+        u, f = self.family[id(node)].fixed_moments_and_f(X)
+        z = fuse(lambda g, f_: g + f_, _arr(st.g), f if isinstance(f, DArray) else float(f))
+        for i, nd in enumerate(len(d) for d in node.dims):
+            t = fuse(lambda p, v: p * v, _arr(st.phi[i]), _arr(u[i]))
+            z = fuse(lambda a, b: a + b, z, _sum_last(t, nd))
+        return np.array(z.numpy())
+
+    def random(self, node):
+        """A draw from q(node) on the host (set-up / inspection; RNG streams are not part of
+        the parity contract)."""
+        st = self._latent_state(node)
+        return self._sample(node, self.family[id(node)], st.u)

@@ -473,7 +473,7 @@ class PCAPlan:
         raise NotImplementedError('moments of %s are never materialised by the fused PCA block'
                                   % node.name)
 
-    def get_parameters(self, node):
+    def posterior_parameters(self, node):
         """(a, b) of the Gamma nodes; (mean, covariance) of the Gaussian nodes."""
         self._materialize()
         self._flush()
@@ -492,6 +492,26 @@ class PCAPlan:
             return (self.Xd[:, :self.N].cpu().numpy().T.copy(),
                     self._block(L.off_CX, K, K, KP))
         raise NotImplementedError
+
+    def get_parameters(self, node):
+        """Natural parameters phi of q(node) in the reference's layout (``node.phi``,
+        expfamily.py:314-321), derived on the host from the packed state: [-b, a] for the
+        Gamma nodes (gamma.py:116-148); [Lambda m, -Lambda / 2] with the shared K x K precision
+        Lambda for the Gaussian nodes (gaussian.py:649-706).  Inspection only."""
+        if node in (self.tau, self.alpha):
+            a, b = self.posterior_parameters(node)
+            return [np.reshape(-np.asarray(b), node.plates), np.reshape(a, node.plates)]
+        if node in (self.W, self.X):
+            m, cov = self.posterior_parameters(node)
+            lam = np.linalg.inv(cov)
+            lam = 0.5 * (lam + lam.T)
+            K = self.K
+            return [(m @ lam).reshape(node.plates + (K,)),
+                    (-0.5 * lam).reshape((1,) * len(node.plates) + (K, K))]
+        raise ValueError('node %s is observed: it has no variational parameters' % node.name)
+
+    def get_mask(self, node):
+        return np.array(True)
 
     # -- persistence: the packed device state + <x_n>; node moments for inspection -----------------
     def save_state(self, put, nodes, index):
@@ -527,7 +547,7 @@ class PCAPlan:
 
     # -- rotations (inference/transformations.py) ----------------------------------------------------
     def gamma_posterior_shape(self, node):
-        return self.get_parameters(node)[0]
+        return self.posterior_parameters(node)[0]
 
     def rotation_statistics(self, node):
         """sum over the plates of <x x^T> (K x K, global over ranks) and the plate count."""

@@ -67,6 +67,7 @@ class VB:
             raise Exception("Use unique names for nodes.")
         compile_model(self.model, engine=engine)
         self.ignore_bound_checks = False
+        self.annealing_changed = False
         self.iter = 0
         self.converged = False
         self.L = np.array(())
@@ -215,9 +216,205 @@ class VB:
     def has_converged(self, tol=None):
         return self.converged
 
+    # -- deterministic annealing (vmp.py:665-677) ------------------------------------------
+    def set_annealing(self, annealing):
+        """Annealing coefficient from (0, 1]; 1 = standard updates.  The next iteration's
+        bound is not compared with the previous one (the objective changed)."""
+        if not (0.0 < annealing <= 1.0):
+            raise ValueError('annealing must be in (0, 1]')
+        for node in self.model:
+            if hasattr(node, 'annealing'):
+                if annealing != 1.0 and node._plan is not None and \
+                        not hasattr(node._plan, 'riemannian_gradient'):
+                    raise NotImplementedError(
+                        "annealing is not built into the fused %s plan; build the engine with "
+                        "VB(..., engine='generic')" % type(node._plan).__name__)
+                node.annealing = float(annealing)
+        self.annealing_changed = True
+
+    # -- parameter vectors and gradients (vmp.py:401-466) ------------------------------------
+    # Vectors are lists (nodes) of lists (parameters) of DEVICE arrays: the conjugate-gradient
+    # and pattern-search loops below never move plate-sized data to the host.
+    def _param_plan(self, node, method):
+        node = self[node]
+        plan = node._require_plan()
+        fn = getattr(plan, method, None)
+        if fn is None:
+            raise NotImplementedError(
+                "%s: the fused %s plan does not expose variational parameters; build the "
+                "engine with VB(..., engine='generic')" % (method, type(plan).__name__))
+        return node, fn
+
+    def get_parameters(self, *nodes):
+        out = []
+        for n in nodes:
+            node, fn = self._param_plan(n, 'natural_parameters')
+            out.append(list(fn(node)))
+        return out
+
+    def set_parameters(self, x, *nodes):
+        for n, xi in zip(nodes, x):
+            node, fn = self._param_plan(n, 'set_parameters')
+            fn(node, xi)
+
+    def get_gradients(self, *nodes, euclidian=False):
+        rg = []
+        for n in nodes:
+            node, fn = self._param_plan(n, 'riemannian_gradient')
+            rg.append(fn(node))
+        if not euclidian:
+            return rg
+        g = []
+        for n, r in zip(nodes, rg):
+            node, fn = self._param_plan(n, 'gradient')
+            g.append(fn(node, r))
+        return rg, g
+
+    @staticmethod
+    def dot(x1, x2):
+        """Inner product of two parameter vectors: every pair is one device contraction, the
+        partial results are added on the device and read once."""
+        from ..utils import misc
+        from ..darray import asdarray, fuse
+        tot = None
+        for y1, y2 in zip(x1, x2):
+            for z1, z2 in zip(y1, y2):
+                z1, z2 = asdarray(z1), asdarray(z2)
+                nd = max(z1.ndim, z2.ndim)
+                v = misc.sum_multiply(z1, z2, axis=tuple(range(nd))) if nd else \
+                    fuse(lambda a, b: a * b, z1, z2)
+                tot = v if tot is None else fuse(lambda a, b: a + b, tot, v)
+        return 0.0 if tot is None else float(tot.item())
+
+    @staticmethod
+    def add(x1, x2, scale=1):
+        from ..darray import asdarray, fuse
+        s = float(scale)
+        return [[fuse(lambda a, b, s_=s: a + s_ * b, asdarray(z1), asdarray(z2))
+                 for z1, z2 in zip(y1, y2)] for y1, y2 in zip(x1, x2)]
+
+    # -- gradient-based optimisation (vmp.py:469-660) ------------------------------------------
+    def _try_step(self, p, direction, scale, nodes, collapsed):
+        """Move ``nodes`` to p + scale * direction and update the collapsed nodes.  Returns
+        ('ok', p_new), or ('invalid', None) when a distribution left its domain, or
+        ('lowered', None) when the bound dropped; the collapsed nodes are restored then."""
+        p_new = self.add(p, direction, scale=scale)
+        try:
+            self.set_parameters(p_new, *nodes)
+        except Exception:
+            return 'invalid', None
+        saved = self.get_parameters(*collapsed)
+        try:
+            for node in collapsed:
+                self[node].update()
+        except Exception:
+            self.set_parameters(saved, *collapsed)
+            return 'invalid', None
+        L = self.compute_lowerbound()
+        if self.iter > 0:
+            L0 = self.L[self.iter - 1]
+            lowered = L < L0 and not np.allclose(L, L0, rtol=1e-8)
+        else:
+            lowered = False
+        if np.isnan(L) or lowered:
+            self.set_parameters(saved, *collapsed)
+            return 'lowered', None
+        return 'ok', p_new
+
+    def optimize(self, *nodes, maxiter=10, verbose=True, method='fletcher-reeves',
+                 riemannian=True, collapsed=None, tol=None):
+        """Riemannian conjugate-gradient ascent on the variational parameters of ``nodes``
+        with the ``collapsed`` nodes kept at their optimum (vmp.py:469-601).  The step length
+        grows by sqrt(2) after an accepted step and halves after a rejected gradient step; a
+        conjugate direction is dropped for the plain gradient when a step along it leaves the
+        domain, or lowers the bound with the step length already below 2^-10."""
+        method = method.lower()
+        if method not in ('gradient', 'fletcher-reeves'):
+            raise Exception("Unknown optimization method: %s" % (method))
+        collapsed = list(collapsed) if collapsed is not None else []
+        scale = 1.0
+        p = self.get_parameters(*nodes)
+        norm_prev = 0
+        s = None
+        for _ in range(maxiter):
+            t = time.time()
+            if riemannian and method == 'gradient':
+                steepest = weight = self.get_gradients(*nodes)
+            else:
+                rg, g = self.get_gradients(*nodes, euclidian=True)
+                weight = g
+                steepest = rg if riemannian else g
+            beta = 0
+            if method == 'fletcher-reeves':
+                norm = self.dot(weight, steepest)
+                if norm_prev != 0:
+                    beta = norm / norm_prev
+                norm_prev = norm
+            s = self.add(steepest, s, scale=beta) if beta else steepest
+            while True:
+                status, p_new = self._try_step(p, s, scale, nodes, collapsed)
+                if status == 'ok':
+                    break
+                plain = s is steepest
+                if status == 'invalid':
+                    if verbose:
+                        self.print("CG update was unsuccessful, using gradient and resetting CG")
+                    if plain:
+                        scale = scale / 2
+                    norm_prev = 0
+                    s = steepest
+                elif plain or scale >= 2 ** (-10):
+                    if verbose:
+                        self.print("Step decreased the lower bound, halfing step length")
+                    scale = scale / 2
+                else:
+                    if verbose:
+                        self.print("CG decreased the lower bound, reset CG.")
+                    norm_prev = 0
+                    s = steepest
+            scale = scale * np.sqrt(2)
+            p = p_new
+            cputime = time.time() - t
+            if self._end_iteration_step('OPT', cputime, tol=tol, verbose=verbose):
+                break
+
+    def pattern_search(self, *nodes, collapsed=None, maxiter=3):
+        """Pattern search (Honkela et al. 2003; vmp.py:603-662): extrapolate along the change
+        of the parameters made by one VB update, with the step length chosen by a scalar
+        minimisation of the negative lower bound."""
+        from scipy import optimize as sp_optimize
+        collapsed = list(collapsed) if collapsed is not None else []
+        t = time.time()
+        for x in nodes:
+            self[x].update()
+        for x in collapsed:
+            self[x].update()
+        p0 = self.get_parameters(*nodes)
+        for x in nodes:
+            self[x].update()
+        p1 = self.get_parameters(*nodes)
+        dp = self.add(p1, p0, scale=-1)
+
+        def cost(alpha):
+            try:
+                self.set_parameters(self.add(p1, dp, scale=alpha), *nodes)
+            except Exception:
+                return np.inf
+            for x in collapsed:
+                self[x].update()
+            return -self.compute_lowerbound()
+
+        res = sp_optimize.minimize_scalar(cost, bracket=[0, 3], options={'maxiter': maxiter})
+        self.set_parameters(self.add(p1, dp, scale=res.x), *nodes)
+        for x in collapsed:
+            self[x].update()
+        self._end_iteration_step('PS', time.time() - t)
+
     # -- lower bound (vmp.py:180-199) ----------------------------------------------------
     def compute_lowerbound(self, ignore_masked=True):
-        return sum(n.lower_bound_contribution() for n in self.model)
+        if ignore_masked:
+            return sum(n.lower_bound_contribution() for n in self.model)
+        return sum(n.lower_bound_contribution(ignore_masked=False) for n in self.model)
 
     def compute_lowerbound_terms(self, *nodes):
         if len(nodes) == 0:
@@ -265,7 +462,7 @@ class VB:
                 self.print("Iteration %d: loglike=%e (%.3f seconds)"
                            % (self.iter + 1, L, cputime))
         self.converged = False
-        if not self.ignore_bound_checks and self.iter > 0:
+        if not self.ignore_bound_checks and not self.annealing_changed and self.iter > 0:
             L0 = self.L[self.iter - 1]
             if L0 - L > 1e-6:
                 warnings.warn("Lower bound decreased %e! Bug somewhere or "
@@ -278,4 +475,5 @@ class VB:
                     self.print("Converged at iteration %d." % (self.iter + 1))
                 self.converged = True
         self.iter += 1
+        self.annealing_changed = False
         return self.converged

@@ -136,6 +136,7 @@ class Stochastic(Node):
         self._data = None          # pending observation (host ndarray / device tensor)
         self._mask = True
         self._init = None          # pending initialisation: ('value', x) | ('random',) | None
+        self.annealing = 1.0       # deterministic annealing coefficient (expfamily.py:123)
 
     # -- data / initialisation (expfamily.py:168-212, :369-398) ------------------
     def observe(self, x, mask=True):
@@ -175,6 +176,77 @@ class Stochastic(Node):
         if self._plan is not None:
             self._plan.invalidate(self)
 
+    def initialize_from_parameters(self, *args):
+        """q := the node's own distribution with the given values in place of the parents
+        (expfamily.py:187-190), e.g. ``GaussianARD.initialize_from_parameters(mu, alpha)``."""
+        self._init = ('parameters', args)
+        if self._plan is not None:
+            self._plan.invalidate(self)
+
+    def unobserve(self):
+        """stochastic.py:284-287."""
+        self.observed = False
+        self._data = None
+        self._mask = True
+        if self._plan is not None:
+            self._plan.invalidate(self)
+
+    # -- state of q read by users and tests (SURVEY.md 8b) -- host copies ------------------------
+    def _plan_call(self, method, *args, **kwargs):
+        fn = getattr(self._require_plan(), method, None)
+        if fn is None:
+            raise NotImplementedError(
+                "%s of node %s: the fused %s plan does not expose it; build the engine with "
+                "VB(..., engine='generic')" % (method, self.name,
+                                               type(self._plan).__name__))
+        return fn(self, *args, **kwargs)
+
+    @property
+    def phi(self):
+        """Natural parameters of q (expfamily.py:215-257)."""
+        return self._plan_call('get_parameters')
+
+    @property
+    def g(self):
+        """Log-normaliser term of q; ``inf`` after initialize_from_value (expfamily.py:125)."""
+        return self._plan_call('log_normalizer')[0]
+
+    @property
+    def f(self):
+        """Fixed term f(x) of an observed node (expfamily.py:126)."""
+        return self._plan_call('log_normalizer')[1]
+
+    @property
+    def mask(self):
+        """Observation mask after propagation from the children (node.py:457-526)."""
+        return self._plan_call('get_mask')
+
+    def get_parameters(self):
+        return self._plan_call('get_parameters')
+
+    def set_parameters(self, x):
+        self._plan_call('set_parameters', x)
+
+    def get_riemannian_gradient(self):
+        """annealing * (phi_prior + messages) - phi  (expfamily.py:258-278)."""
+        return [np.array(d.numpy()) for d in self._plan_call('riemannian_gradient')]
+
+    def get_gradient(self, rg):
+        """Euclidean gradient with respect to phi given the Riemannian gradient
+        (expfamily.py:281-294)."""
+        return [np.array(d.numpy()) for d in self._plan_call('gradient', rg)]
+
+    def logpdf(self, X, mask=True):
+        if mask is not True:
+            raise NotImplementedError('Mask not yet implemented')
+        return self._plan_call('logpdf', X)
+
+    def pdf(self, X, mask=True):
+        return np.exp(self.logpdf(X, mask=mask))
+
+    def random(self):
+        return self._plan_call('random')
+
     def _check_value_shape(self, x):
         shape = tuple(x.shape) if hasattr(x, 'shape') else np.shape(x)
         full = self.plates + self.dims[0]
@@ -194,6 +266,10 @@ class Stochastic(Node):
             return
         self._require_plan().update(self)
 
-    def lower_bound_contribution(self, **kwargs):
+    def lower_bound_contribution(self, gradient=False, ignore_masked=True):
         """E_q[log p(node | parents) - log q(node)] (expfamily.py:400-480)."""
-        return self._require_plan().lower_bound_contribution(self)
+        if gradient:
+            raise NotImplementedError('gradient of the lower bound term')
+        if ignore_masked:
+            return self._require_plan().lower_bound_contribution(self)
+        return self._plan_call('lower_bound_contribution', ignore_masked=False)

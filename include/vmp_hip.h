@@ -285,6 +285,7 @@ enum {
     VMP_OP_IN = 0, VMP_OP_CONST, VMP_OP_ADD, VMP_OP_SUB, VMP_OP_MUL, VMP_OP_DIV, VMP_OP_NEG,
     VMP_OP_LOG, VMP_OP_EXP, VMP_OP_SQR, VMP_OP_SQRT, VMP_OP_RECIP, VMP_OP_DIGAMMA,
     VMP_OP_LGAMMA, VMP_OP_MAX, VMP_OP_MIN, VMP_OP_WHERE_NZ, VMP_OP_DUP, VMP_OP_SWAP,
+    VMP_OP_TRIGAMMA,
     VMP_OP__COUNT
 };
 int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,

@@ -620,6 +620,26 @@ def mixture_ard_case(name):
     print(name, out['L'], Y.plates, mu.plates, lam.plates)
 
 
+def parameter_api_case(name):
+    """Variational-parameter access, gradients, annealing, collapsed CG and pattern search:
+    tests/models.py run_parameter_api_cases executed on the reference."""
+    import bayespy.nodes
+    from bayespy.inference import VB
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tests'))
+    import models
+    g = models.make_parameter_api_inputs(np.random.RandomState(77))
+    res = models.run_parameter_api_cases(bayespy.nodes, VB, g)
+    out = {'in_' + k: v for k, v in g.items()}
+    for k, v in res.items():
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                out['%s_%d' % (k, i)] = np.array(vi)
+        else:
+            out[k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, out['cg_L'], out['mix_L'][-3:], out['an0_g_0'], out['an0_g_1'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -640,6 +660,7 @@ def main():
     multinomial_case('multinomial')
     summultiply_cases('summultiply')
     mixture_ard_case('mixture_ard')
+    parameter_api_case('parameter_api')
 
 
 if __name__ == '__main__':

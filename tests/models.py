@@ -116,3 +116,143 @@ def check_pca_doctest(Q, nd, g):
     # two components survive ARD, as in the data (latent dimensionality two)
     a = np.sort(np.ravel(nd['alpha'].u[0]))
     assert a[1] < 10 and a[2] > 100
+
+
+def make_parameter_api_inputs(rs):
+    """Seeded inputs of run_parameter_api_cases (stored in tests/golden/parameter_api.npz)."""
+    def spd(d):
+        a = rs.normal(size=(d, d))
+        return a @ a.T + d * np.eye(d)
+    D = 3
+    g = dict(
+        gam_a=rs.rand(D) + 0.5, gam_b=rs.rand(D) + 0.5, gam_mu=rs.normal(size=D),
+        gam_y=rs.normal(size=D), gam_pa=rs.rand(D) + 0.5, gam_pb=rs.rand(D) + 0.5,
+        gam_x=rs.rand(D) + 0.2,
+        gs_mu=rs.normal(size=D), gs_L=spd(D), gs_mu0=rs.normal(size=D), gs_L0=spd(D),
+        gs_V=spd(D), gs_y=rs.normal(size=(5, D)), gs_x=rs.normal(size=D),
+        ard_mu=rs.normal(size=(2, D)), ard_al=rs.rand(2, D) + 0.5, ard_m0=rs.normal(size=(2, D)),
+        ard_a0=rs.rand(2, D) + 0.5, ard_y=rs.normal(size=(4, 2, D)),
+        dir_a=rs.rand(4) + 0.5, dir_a0=rs.rand(4) + 0.5, dir_z=rs.randint(4, size=25),
+    )
+    # small PCA for the collapsed optimisation (demos/collapsed_cg.py:28-66)
+    M, N, K = 6, 30, 3
+    g['cg_y'] = (rs.normal(size=(M, 1, K - 1)) * rs.normal(size=(1, N, K - 1))).sum(-1) \
+        + 0.1 * rs.normal(size=(M, N))
+    g['cg_w0'] = rs.normal(size=(M, 1, K))
+    # two-cluster 1-D mixture for the annealing run (demos/annealing.py:33-90)
+    z = rs.rand(60) < 0.3
+    g['an_y'] = np.where(z, 4.0, -4.0) + rs.normal(size=60)
+    return g
+
+
+def run_parameter_api_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Natural-parameter access, Riemannian / Euclidean gradients, densities, deterministic
+    annealing, collapsed conjugate gradients and pattern search, statement for statement the
+    same on the reference and on this framework (the reference's own checks of these:
+    tests/test_annealing.py:34-110, nodes/tests/test_gamma.py:160-260,
+    test_gaussian.py:1255-1420, test_categorical.py:227-250; demos/collapsed_cg.py,
+    demos/pattern_search.py, demos/annealing.py)."""
+    import warnings
+    N_ = nodes_mod
+    out = {}
+
+    def record(tag, node, Q, x=None):
+        out[tag + '_phi'] = [np.array(p) for p in node.phi]
+        rg = node.get_riemannian_gradient()
+        out[tag + '_rg'] = [np.array(r) for r in rg]
+        out[tag + '_g'] = [np.array(v) for v in node.get_gradient(rg)]
+        out[tag + '_L'] = Q.compute_lowerbound(ignore_masked=False)
+        out[tag + '_u'] = [np.array(v) for v in node.u]
+        if x is not None:
+            out[tag + '_logpdf'] = np.array(node.logpdf(x))
+
+    # 1. annealed scalar Gaussian (test_annealing.py:34-110)
+    X = N_.GaussianARD(3, 4, name='X')
+    X.initialize_from_parameters(-1, 6)
+    Q = vb_cls(X, **vb_kwargs)
+    Q.set_annealing(0.1)
+    record('an0', X, Q, x=0.3)
+    p = X.get_parameters()
+    X.set_parameters([p[0] + 0.25, p[1] - 0.5])
+    record('an1', X, Q)
+    X.update()
+    record('an2', X, Q)
+
+    # 2. Gamma with an observed Gaussian child (test_gamma.py:200-260)
+    tau = N_.Gamma(g['gam_a'], g['gam_b'], name='tau')
+    Y = N_.GaussianARD(g['gam_mu'], tau, name='Y')
+    Y.observe(g['gam_y'])
+    Q = vb_cls(Y, tau, **vb_kwargs)
+    tau.initialize_from_parameters(g['gam_pa'], g['gam_pb'])
+    record('gam', tau, Q, x=g['gam_x'])
+
+    # 3. Gaussian with a full precision and Gaussian observations (test_gaussian.py:1303-1350)
+    X = N_.Gaussian(g['gs_mu'], g['gs_L'], name='X')
+    Y = N_.Gaussian(X, g['gs_V'], plates=(5,), name='Y')
+    Y.observe(g['gs_y'])
+    X.initialize_from_parameters(g['gs_mu0'], g['gs_L0'])
+    Q = vb_cls(Y, X, **vb_kwargs)
+    record('gs', X, Q, x=g['gs_x'])
+
+    # 4. vector GaussianARD with plates and observations (test_gaussian.py:1355-1420)
+    X = N_.GaussianARD(g['ard_mu'], g['ard_al'], shape=(3,), name='X')
+    Y = N_.GaussianARD(X, 2.0, shape=(3,), plates=(4, 2), name='Y')
+    Y.observe(g['ard_y'])
+    X.initialize_from_parameters(g['ard_m0'], g['ard_a0'])
+    Q = vb_cls(Y, X, **vb_kwargs)
+    record('ard', X, Q)
+
+    # 5. Dirichlet with categorical observations; categorical under a Gamma mixture
+    #    (test_categorical.py:227-250)
+    pi = N_.Dirichlet(g['dir_a'], name='pi')
+    Z = N_.Categorical(pi, plates=(25,), name='Z')
+    Z.observe(g['dir_z'])
+    pi.initialize_from_parameters(g['dir_a0'])
+    Q = vb_cls(Z, pi, **vb_kwargs)
+    record('dir', pi, Q)
+    Z = N_.Categorical([[0.3, 0.5, 0.2], [0.1, 0.6, 0.3]], name='Z')
+    Y = N_.Mixture(Z, N_.Gamma, [2, 3, 4], [5, 6, 7], name='Y')
+    Y.observe([4.2, 0.2])
+    Q = vb_cls(Y, Z, **vb_kwargs)
+    Z.set_parameters([np.log([[2, 3, 7], [0.1, 3, 1]])])
+    record('cat', Z, Q)
+
+    # 6. deterministic annealing of a two-cluster mixture (demos/annealing.py:33-90)
+    mu = N_.GaussianARD(0, 1, plates=(2,), name='means')
+    Z = N_.Categorical([0.3, 0.7], plates=(60,), name='classes')
+    Y = N_.Mixture(Z, N_.GaussianARD, mu, 1, name='observations')
+    Y.observe(g['an_y'])
+    mu.initialize_from_value([0, 6])
+    Q = vb_cls(Y, Z, mu, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    for beta in (0.05, 0.2, 0.5, 1.0):
+        Q.set_annealing(beta)
+        Q.update(repeat=3, verbose=False)
+    out['mix_L'] = np.array(Q.L[:Q.iter])
+    out['mix_mu'] = np.array(mu.u[0])
+
+    # 7. collapsed Riemannian conjugate gradients, plain gradient ascent and pattern search
+    #    on a small PCA model (demos/collapsed_cg.py:28-66, demos/pattern_search.py:40-80)
+    y = g['cg_y']
+    M, N = y.shape
+    K = g['cg_w0'].shape[-1]
+    alpha = N_.Gamma(1e-3, 1e-3, plates=(K,), name='alpha')
+    W = N_.GaussianARD(0, alpha, plates=(M, 1), shape=(K,), name='W')
+    X = N_.GaussianARD(0, 1, plates=(1, N), shape=(K,), name='X')
+    tau = N_.Gamma(1e-3, 1e-3, name='tau')
+    W.initialize_from_value(g['cg_w0'])
+    F = N_.SumMultiply('d,d->', W, X)
+    Y = N_.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = vb_cls(Y, X, W, alpha, tau, **vb_kwargs)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Q.update(repeat=1, verbose=False)
+        Q.optimize(W, tau, maxiter=5, collapsed=[X, alpha], verbose=False)
+        out['cg_W'] = np.array(W.u[0])
+        Q.optimize(W, X, riemannian=False, method='gradient', maxiter=3, verbose=False)
+        Q.pattern_search(W, tau, maxiter=3, collapsed=[X, alpha])
+        Q.update(repeat=2, verbose=False)
+    out['cg_L'] = np.array(Q.L[:Q.iter])
+    out['cg_tau'] = np.array(tau.u[0])
+    return out

@@ -63,7 +63,7 @@ def test_no_gpu_means_loud_failure():
 
 
 def test_device_special_functions_match_scipy():
-    """vmp_digamma / vmp_lgamma (csrc/vmp_common.h) compiled for the host."""
+    """vmp_digamma / vmp_lgamma / vmp_trigamma (csrc/vmp_common.h) compiled for the host."""
     src = os.path.join(ROOT, 'bayespy_amd', 'csrc', 'vmp_common.h')
     text = open(src).read()
     s = text.index('__host__ __device__ inline double vmp_digamma')
@@ -76,14 +76,17 @@ def test_device_special_functions_match_scipy():
             f.write('extern "C" void dg(const double*x,double*y,int n)'
                     '{for(int i=0;i<n;i++)y[i]=vmp_digamma(x[i]);}\n'
                     'extern "C" void lg(const double*x,double*y,int n)'
-                    '{for(int i=0;i<n;i++)y[i]=vmp_lgamma(x[i]);}\n')
+                    '{for(int i=0;i<n;i++)y[i]=vmp_lgamma(x[i]);}\n'
+                    'extern "C" void tg(const double*x,double*y,int n)'
+                    '{for(int i=0;i<n;i++)y[i]=vmp_trigamma(x[i]);}\n')
         so = os.path.join(d, 'sf.so')
         subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', cpp, '-o', so])
         lib = ctypes.CDLL(so)
         x = np.concatenate([np.logspace(-6, 8, 4001), np.linspace(0.01, 40, 4001),
                             0.01 + 0.5 * np.arange(1, 200)])
         y = np.empty_like(x)
-        for fn, ref in ((lib.dg, special.digamma), (lib.lg, special.gammaln)):
+        for fn, ref in ((lib.dg, special.digamma), (lib.lg, special.gammaln),
+                        (lib.tg, lambda v: special.polygamma(1, v))):
             fn(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), len(x))
             r = ref(x)
             err = np.minimum(np.abs(y - r), np.abs(y - r) / np.maximum(np.abs(r), 1e-300))

@@ -74,8 +74,8 @@ def test_gpu_vs_oracle_ragged_sizes(N, D, K, stats):
     o.iterate(iters)
     np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=ELBO_RTOL)
     m = o.moments()
-    xs, cx = Q.plans[0].get_parameters(Q['X'])
-    ws, cw = Q.plans[0].get_parameters(Q['W'])
+    xs, cx = Q.plans[0].posterior_parameters(Q['X'])
+    ws, cw = Q.plans[0].posterior_parameters(Q['W'])
     np.testing.assert_allclose(xs, m['X'], rtol=MOM_RTOL, atol=1e-9)
     np.testing.assert_allclose(cx, m['CX'], rtol=MOM_RTOL, atol=1e-12)
     np.testing.assert_allclose(ws, m['W'], rtol=MOM_RTOL, atol=1e-9)
@@ -313,6 +313,6 @@ def test_config2_size_vs_oracle():
             o = PCAOracle(y, x0, keep_x=True)
             o.iterate(iters)
         np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=1e-10)
-        xs, cx = Q.plans[0].get_parameters(Q['X'])
+        xs, cx = Q.plans[0].posterior_parameters(Q['X'])
         np.testing.assert_allclose(xs, o.X, rtol=MOM_RTOL, atol=1e-9)
         np.testing.assert_allclose(Q['tau'].u[0], o.moments()['tau'][0], rtol=1e-9)

@@ -178,3 +178,30 @@ def test_plates_and_shapes_follow_reference_rules():
     assert PCAPlan.match([Y, F, W, X]) is None
     with pytest.raises(ValueError):
         nodes.SumMultiply('i,i', W, nodes.GaussianARD(0, 1, shape=(K + 1,), plates=(1, N)))
+
+
+def test_node_state_access_on_the_fused_block(golden_dir):
+    """node.phi / node.mask of the fused PCA block (SURVEY.md 8b "node state read by users");
+    what the block does not carry fails loudly and names the generic engine."""
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.update(repeat=2, verbose=False)
+    W, X, tau, alpha = Q['W'], Q['X'], Q['tau'], Q['alpha']
+    for nd in (W, X):
+        phi = nd.phi
+        assert phi[0].shape == nd.plates + (3,)
+        cov = np.linalg.inv(-2 * phi[1][0, 0])
+        np.testing.assert_allclose(phi[0] @ cov, nd.u[0], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(nd.u[1][0, 0] - np.outer(nd.u[0][0, 0], nd.u[0][0, 0]),
+                                   cov, rtol=1e-8, atol=1e-12)
+    for nd in (tau, alpha):
+        phi = nd.phi                     # [-b, a]: <x> = a / b  (gamma.py:116-148)
+        np.testing.assert_allclose(phi[1] / -phi[0], nd.u[0], rtol=1e-12)
+    assert bool(W.mask) is True
+    with pytest.raises(NotImplementedError, match="engine='generic'"):
+        Q.set_annealing(0.5)
+    with pytest.raises(NotImplementedError, match="engine='generic'"):
+        Q.optimize(W, tau, collapsed=[X, alpha], maxiter=1, verbose=False)
+    with pytest.raises(NotImplementedError, match="engine='generic'"):
+        W.get_riemannian_gradient()
+    Q.set_annealing(1.0)                 # the standard updates are always allowed
