@@ -1,0 +1,201 @@
+"""
+Device families of the count / probability nodes and of the small deterministic nodes
+(Beta, Complement, Binomial / Bernoulli, Poisson, Add).  Same protocol as the families in
+``generic.py`` (the five VMP formulas of stochastic.py:16-80 / the two of
+deterministic.py:16-96), every array operation a HIP kernel launch.
+"""
+import numpy as np
+
+from ... import darray as da
+from ...darray import DArray, fuse
+from ...nodes.node import Constant
+from ...nodes.beta import Beta, Complement
+from ...nodes.binomial import Binomial
+from ...nodes.poisson import Poisson
+from ...nodes.add import Add
+from ...utils import misc, linalg
+from .generic import Family, DirichletFamily, _arr, _trail, _const, _check_device
+
+
+def _flip2(x):
+    """Swap the two entries of the last axis (a strided device view cannot be reversed: one
+    tiny contraction with the exchange matrix)."""
+    x = _arr(x)
+    ex = _const(('exchange2',), lambda: np.array([[0.0, 1.0], [1.0, 0.0]]))
+    return misc.sum_multiply(_trail(x, 1), ex, axis=-2)
+
+
+def _pair(p):
+    """Probabilities -> [p, 1 - p] on a new last axis (beta.py:33-37)."""
+    p = _arr(np.asarray(p, dtype=np.float64)) if not isinstance(p, DArray) else p
+    s = _const(('pair_s',), lambda: np.array([1.0, -1.0]))
+    o = _const(('pair_o',), lambda: np.array([0.0, 1.0]))
+    return fuse(lambda v, s_, o_: v * s_ + o_, _trail(p, 1), s, o)
+
+
+class BetaFamily(DirichletFamily):
+    """beta.py:46-110: Dirichlet formulas, scalar realisations."""
+
+    def fixed_moments_and_f(self, p):
+        return super().fixed_moments_and_f(_pair(p))
+
+
+class ComplementFamily:
+    """beta.py:194-214."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+
+    def mask_to_parent(self, index, mask):
+        return mask
+
+    def moments(self, ups):
+        return [_flip2(ups[0][0])]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        m = m_child[0]
+        if m is None:
+            return [None]
+        m = _flip2(m)
+        if mask is not None:
+            m = fuse(lambda a, w: a * w, m, _trail(mask, 1))
+        return [m]
+
+
+class BinomialFamily(Family):
+    """binomial.py:54-165 (Bernoulli: one trial, bernoulli.py:33-41)."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.trials = np.asarray(node.trials, dtype=np.float64)
+        self.Nd = DArray.from_host(self.trials)
+
+    def constant_moments(self, index, value):
+        return [fuse(lambda q: da.log(q), _pair(value))]          # BetaMoments, beta.py:33-37
+
+    def phi_from_parents(self, up):
+        lp = _arr(up[0][0])
+        return [fuse(lambda a, b: a - b, lp[..., 0], lp[..., 1])]
+
+    def moments_and_cgf(self, phi):
+        p = _arr(phi[0])
+        u0 = fuse(lambda n, x: n / (1.0 + da.exp(-x)), self.Nd, p)
+        # log(1 + e^x) without overflow: max(x, 0) + log(1 + e^-|x|)
+        g = fuse(lambda n, x: -n * (da.maximum(x, 0.0)
+                                    + da.log(1.0 + da.exp(-da.maximum(x, -x)))), self.Nd, p)
+        return [u0], g
+
+    def cgf_from_parents(self, up):
+        lp = _arr(up[0][0])
+        return fuse(lambda n, b: n * b, self.Nd, lp[..., 1])
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(np.asarray(x, dtype=np.float64))
+        f = fuse(lambda n, c: da.gammaln(n + 1.0) - da.gammaln(c + 1.0) - da.gammaln(n - c + 1.0),
+                 self.Nd, x)
+        return [x], f
+
+    def message_to_parent(self, index, u, up):
+        # [x, n - x] on a new last axis (binomial.py:80-84)
+        s = _const(('pair_s',), lambda: np.array([1.0, -1.0]))
+        o = _const(('pair_o',), lambda: np.array([0.0, 1.0]))
+        return [fuse(lambda x, n, s_, o_: x * s_ + n * o_, _trail(_arr(u[0]), 1),
+                     _trail(self.Nd, 1), s, o)]
+
+    def plates_to_parent(self, index):
+        return self.node.plates
+
+    def sample(self, st):
+        p = 1.0 / (1.0 + np.exp(-np.broadcast_to(_arr(st.phi[0]).numpy(), self.node.plates)))
+        return np.random.binomial(np.broadcast_to(self.trials, self.node.plates).astype(np.int64),
+                                  p)
+
+
+class PoissonFamily(Family):
+    """poisson.py:52-120."""
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        return [v, fuse(lambda l: da.log(l), v)]                  # GammaMoments, gamma.py:60-75
+
+    def phi_from_parents(self, up):
+        return [fuse(lambda l: 1.0 * l, up[0][1])]
+
+    def moments_and_cgf(self, phi):
+        u0 = fuse(lambda p: da.exp(p), phi[0])
+        return [u0], fuse(lambda v: -v, u0)
+
+    def cgf_from_parents(self, up):
+        return fuse(lambda l: -l, up[0][0])
+
+    def fixed_moments_and_f(self, x):
+        x = _arr(np.asarray(x, dtype=np.float64))
+        return [x], fuse(lambda c: -da.gammaln(c + 1.0), x)
+
+    def message_to_parent(self, index, u, up):
+        return [-1.0, u[0]]
+
+    def sample(self, st):
+        return np.random.poisson(np.exp(np.broadcast_to(_arr(st.phi[0]).numpy(),
+                                                        self.node.plates)))
+
+
+class AddFamily:
+    """add.py:95-154."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.ndim = node.ndim
+
+    def mask_to_parent(self, index, mask):
+        return mask
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        return [v, linalg.outer(v, v, ndim=self.ndim)]
+
+    def moments(self, ups):
+        u0, u1 = _arr(ups[0][0]), _arr(ups[0][1])
+        for up in ups[1:]:
+            x = _arr(up[0])
+            xy = linalg.outer(u0, x, ndim=self.ndim)     # cross terms with the running sum
+            yx = linalg.transpose(xy, ndim=self.ndim)
+            u1 = fuse(lambda a, b, c, d: a + b + c + d, u1, _arr(up[1]), xy, yx)
+            u0 = fuse(lambda a, b: a + b, u0, x)
+        return [u0, u1]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        m0, m1 = m_child
+        if m1 is None:
+            out = [m0, None]
+        else:
+            others = [_arr(up[0]) for i, up in enumerate(ups) if i != index]
+            s = others[0]
+            for x in others[1:]:
+                s = fuse(lambda a, b: a + b, s, x)
+            m1 = _arr(m1)
+            t = linalg.mvdot(fuse(lambda q: 2.0 * q, m1), s, ndim=self.ndim)
+            out = [t if m0 is None else fuse(lambda a, b: a + b, _arr(m0), t), m1]
+        if mask is not None:
+            out = [None if m is None else
+                   fuse(lambda a, w: a * w, _arr(m), _trail(mask, (1 + i) * self.ndim))
+                   for i, m in enumerate(out)]
+        return out
+
+
+def make_extra_family(node):
+    if isinstance(node, Beta):
+        return BetaFamily(node)
+    if isinstance(node, Complement):
+        return ComplementFamily(node)
+    if isinstance(node, Binomial):
+        return BinomialFamily(node)
+    if isinstance(node, Poisson):
+        return PoissonFamily(node)
+    if isinstance(node, Add):
+        return AddFamily(node)
+    return None

@@ -855,6 +855,10 @@ class SumMultiplyFamily:
 
 
 def make_family(node):
+    from .families_extra import make_extra_family
+    fam = make_extra_family(node)
+    if fam is not None:
+        return fam
     if isinstance(node, Mixture):
         return MixtureFamily(node, make_family(node._proto))
     if isinstance(node, Gamma):
@@ -1013,6 +1017,8 @@ class GenericPlan:
             Lc = np.linalg.cholesky(cov + 1e-12 * np.eye(D))
             z = np.random.randn(mf.shape[0], D)
             return (mf + np.einsum('nij,nj->ni', Lc, z)).reshape(shape)
+        if hasattr(fam, 'sample'):
+            return fam.sample(self.state[id(node)])
         if isinstance(node, Gamma):
             st = self.state[id(node)]
             a = np.broadcast_to(_arr(st.phi[1]).numpy(), node.plates)
@@ -1022,7 +1028,8 @@ class GenericPlan:
             st = self.state[id(node)]
             a = np.broadcast_to(_arr(st.phi[0]).numpy(), node.plates + node.dims[0])
             x = np.random.gamma(a)
-            return x / x.sum(axis=-1, keepdims=True)
+            x = x / x.sum(axis=-1, keepdims=True)
+            return x[..., 0] if type(node).__name__ == 'Beta' else x     # beta.py:100-105
         raise NotImplementedError('random draws for %s' % type(node).__name__)
 
     def _moments(self, node):
@@ -1134,7 +1141,18 @@ class GenericPlan:
             m_child = self._messages_from_children(child)
             ups = self._parent_moments(child)
             mask, _ = self._mask_factor((id(child), 'self'), lambda: self._mask_array(child))
-            return fam.message_to_parent(index, m_child, ups, mask)
+            msgs = fam.message_to_parent(index, m_child, ups, mask)
+            if getattr(fam, 'plate_sum', False) and not isinstance(parent, Constant):
+                # families that answer with the node's own plates: sum over the plates the
+                # parent does not have (node.py:633-655)
+                for i, m in enumerate(msgs):
+                    if m is None or not isinstance(m, DArray):
+                        continue
+                    dims = tuple(parent.dims[i])
+                    msgs[i] = misc.sum_multiply_to_plates(
+                        m, to_plates=parent.plates + dims, from_plates=child.plates + dims,
+                        ndim=0)
+            return msgs
         u = self._moments(child)
         up = self._parent_moments(child)
         msgs = fam.message_to_parent(index, u, up)

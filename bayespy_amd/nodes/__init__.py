@@ -3,16 +3,20 @@ Node classes with the reference's construction API
 (``bayespy.nodes``, bayespy/nodes/__init__.py:105).
 """
 from .node import Node, Constant, Stochastic
-from .gamma import Gamma
+from .gamma import Gamma, Exponential
 from .gaussian import GaussianARD, Gaussian
 from .dot import SumMultiply, Dot
 from .wishart import Wishart
 from .dirichlet import Dirichlet
 from .categorical import Categorical
 from .multinomial import Multinomial
+from .beta import Beta
+from .binomial import Binomial, Bernoulli
+from .poisson import Poisson
+from .add import Add
 from .mixture import Mixture
 from .gaussian_markov_chain import GaussianMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
-           'GaussianMarkovChain']
+           'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add']

@@ -22,3 +22,10 @@ class Gamma(Stochastic):
         if plates is not None and self.plates != given:
             raise ValueError('Plates %s of the parents do not broadcast to plates %s'
                              % ((pa, pb), given))
+
+
+class Exponential(Gamma):
+    """The reference declines this node and points to ``Gamma(1, l)`` (exponential.py:60-67)."""
+
+    def __init__(self, l, **kwargs):
+        raise NotImplementedError("Not yet implemented. Use Gamma(1, lambda)")

@@ -51,7 +51,7 @@ class GaussianARD(Stochastic):
 def _is_gaussian(node):
     from .dot import SumMultiply
     return isinstance(node, (GaussianARD, SumMultiply)) or type(node).__name__ in (
-        'Gaussian', 'MarkovChainToGaussian')
+        'Gaussian', 'MarkovChainToGaussian', 'Add')
 
 
 class Gaussian(Stochastic):

@@ -120,9 +120,19 @@ def outer(A, B, ndim=1):
 
 def mvdot(A, b, ndim=1):
     """(..., M, N) x (..., N) -> (..., M)  (linalg.py:407-427)."""
-    if ndim != 1:
-        raise NotImplementedError
     A, b = asdarray(A), asdarray(b)
+    if ndim == 0:
+        return fuse(lambda x, y: x * y, A, b)
+    if ndim != 1:
+        # several variable axes: the same product on the flattened axes
+        shape = b.shape[b.ndim - ndim:]
+        D = 1
+        for d in shape:
+            D *= d
+        Af = A.reshape(A.shape[:A.ndim - 2 * ndim] + (D, D))
+        bf = b.reshape(b.shape[:b.ndim - ndim] + (D,))
+        r = mvdot(Af, bf)
+        return r.reshape(r.shape[:-1] + tuple(shape))
     bb = b.reshape(b.shape[:-1] + (1, b.shape[-1]))
     return sum_multiply(A, bb, axis=-1)
 
@@ -145,9 +155,17 @@ def dot(*arrays):
 
 
 def transpose(X, ndim=1):
+    X = asdarray(X)
+    if ndim == 0:
+        return X
     if ndim != 1:
-        raise NotImplementedError
-    return asdarray(X).swapaxes(-1, -2)
+        shape = X.shape[X.ndim - ndim:]
+        D = 1
+        for d in shape:
+            D *= d
+        lead = X.shape[:X.ndim - 2 * ndim]
+        return X.reshape(lead + (D, D)).swapaxes(-1, -2).reshape(lead + tuple(shape) * 2)
+    return X.swapaxes(-1, -2)
 
 
 def logdet_cov(C):

@@ -640,6 +640,34 @@ def parameter_api_case(name):
     print(name, out['cg_L'], out['mix_L'][-3:], out['an0_g_0'], out['an0_g_1'])
 
 
+def _shared_case(name, make_inputs, run, seed, show):
+    """Run a statement-for-statement shared script of tests/models.py on the reference and
+    store its inputs (in_*) and results."""
+    import bayespy.nodes
+    from bayespy.inference import VB
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tests'))
+    import models
+    g = getattr(models, make_inputs)(np.random.RandomState(seed))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = getattr(models, run)(bayespy.nodes, VB, g)
+    out = {'in_' + k: v for k, v in g.items()}
+    for k, v in res.items():
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                out['%s_%d' % (k, i)] = np.array(vi)
+        else:
+            out[k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, *[out[k] for k in show])
+
+
+def count_nodes_case(name):
+    """Beta / Bernoulli / Binomial / Poisson / Complement / Add and count mixtures."""
+    _shared_case(name, 'make_count_node_inputs', 'run_count_node_cases', 99,
+                 ('bern_L', 'bmm_L', 'pmm_L', 'add_L'))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -661,6 +689,7 @@ def main():
     summultiply_cases('summultiply')
     mixture_ard_case('mixture_ard')
     parameter_api_case('parameter_api')
+    count_nodes_case('count_nodes')
 
 
 if __name__ == '__main__':

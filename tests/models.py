@@ -256,3 +256,113 @@ def run_parameter_api_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     out['cg_L'] = np.array(Q.L[:Q.iter])
     out['cg_tau'] = np.array(tau.u[0])
     return out
+
+
+def make_count_node_inputs(rs):
+    """Seeded inputs of run_count_node_cases (tests/golden/count_nodes.npz)."""
+    g = {}
+    g['bin_alpha'] = np.array([[1.0, 2.0], [0.5, 0.5], [3.0, 1.0]])
+    g['bin_n'] = np.array([10, 7, 12])
+    g['bin_x'] = rs.binomial(g['bin_n'], [0.3, 0.6, 0.8], size=(4, 3))
+    g['cmp_z'] = rs.randint(2, size=(6, 1))
+    g['poi_a'] = rs.rand(3) + 0.5
+    g['poi_b'] = rs.rand(3) + 0.5
+    g['poi_x'] = rs.poisson([2.0, 7.0, 0.5], size=(20, 3))
+    # Bernoulli mixture of doc/source/examples/bmm.rst:40-75
+    p = np.array([[0.1, 0.9] * 5, [0.1] * 5 + [0.9] * 5, [0.9] * 5 + [0.1] * 5])
+    z = rs.randint(3, size=100)
+    g['bmm_x'] = (rs.rand(100, 10) < p[z]).astype(np.int64)
+    g['bmm_p0'] = rs.beta(0.5, 0.5, size=(10, 10)).clip(1e-3, 1 - 1e-3)
+    # Poisson mixture
+    lab = rs.randint(3, size=80)
+    g['pmm_x'] = rs.poisson(np.array([1.0, 6.0, 15.0])[lab])
+    g['pmm_lab0'] = rs.randint(3, size=80)
+    # sums of Gaussians (add.py:19-33 and test_add.py)
+    g['add_y'] = rs.normal(size=(5, 3, 2))
+    g['add_b0'] = rs.normal(size=(3, 2))
+    g['adds_y'] = rs.normal(size=(7,))
+    return g
+
+
+def run_count_node_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Beta / Bernoulli / Binomial / Poisson / Complement / Add and mixtures of count
+    distributions, the same statements on the reference and on this framework
+    (binomial.py:166-195, bernoulli.py:44-62, poisson.py:122-150, beta.py:112-214,
+    add.py:15-154, doc/source/examples/bmm.rst:40-95)."""
+    N_ = nodes_mod
+    out = {}
+
+    def trace(tag, Q, n, track):
+        Q.ignore_bound_checks = True
+        Q.update(repeat=n, verbose=False)
+        out[tag + '_L'] = np.array(Q.L[:n])
+        for nm, nd in track.items():
+            out['%s_%s_u' % (tag, nm)] = [np.array(v) for v in nd.u]
+            out['%s_%s_Lterm' % (tag, nm)] = np.array(Q.l[nd][:n])
+
+    # 1. the doctest of bernoulli.py:55-60
+    p = N_.Beta([1e-3, 1e-3], name='p')
+    z = N_.Bernoulli(p, plates=(10,), name='z')
+    z.observe([0, 1, 1, 1, 0, 1, 1, 1, 0, 1])
+    trace('bern', vb_cls(z, p, **vb_kwargs), 2, dict(p=p))
+    out['bern_phi'] = [np.array(v) for v in p.phi]
+    out['bern_logpdf'] = np.array(p.logpdf(np.array([0.2, 0.7, 0.9])[:, None]))
+
+    # 2. binomial observations with a different number of trials per plate, a latent
+    #    binomial under the same probabilities, and the complement of the probability
+    p = N_.Beta(g['bin_alpha'], name='p')
+    x = N_.Binomial(g['bin_n'], p, plates=(4, 3), name='x')
+    x.observe(g['bin_x'])
+    h = N_.Binomial(5, p, name='h')
+    c = p.complement()
+    zc = N_.Bernoulli(c, plates=(6, 3), name='zc')
+    zc.observe(np.broadcast_to(g['cmp_z'], (6, 3)))
+    trace('bin', vb_cls(x, zc, h, p, **vb_kwargs), 2, dict(p=p, h=h, x=x, zc=zc))
+    out['bin_c_u'] = [np.array(v) for v in c.get_moments()]
+
+    # 3. Poisson counts with Gamma rates
+    lam = N_.Gamma(g['poi_a'], g['poi_b'], name='lam')
+    x = N_.Poisson(lam, plates=(20, 3), name='x')
+    x.observe(g['poi_x'])
+    xl = N_.Poisson(lam, name='xl')
+    trace('poi', vb_cls(x, xl, lam, **vb_kwargs), 2, dict(lam=lam, xl=xl, x=x))
+
+    # 4. Bernoulli mixture (bmm.rst)
+    N, D = g['bmm_x'].shape
+    K = g['bmm_p0'].shape[1]
+    R = N_.Dirichlet(K * [1e-5], name='R')
+    Z = N_.Categorical(R, plates=(N, 1), name='Z')
+    P = N_.Beta([0.5, 0.5], plates=(D, K), name='P')
+    X = N_.Mixture(Z, N_.Bernoulli, P, name='X')
+    Q = vb_cls(Z, R, X, P, **vb_kwargs)
+    P.initialize_from_value(g['bmm_p0'])
+    X.observe(g['bmm_x'])
+    trace('bmm', Q, 6, dict(R=R, P=P, Z=Z))
+
+    # 5. Poisson mixture
+    N = len(g['pmm_x'])
+    al = N_.Dirichlet(np.ones(3), name='al')
+    Z = N_.Categorical(al, plates=(N,), name='Z')
+    lam = N_.Gamma(1.0, 0.2, plates=(3,), name='lam')
+    X = N_.Mixture(Z, N_.Poisson, lam, name='X')
+    Z.initialize_from_value(g['pmm_lab0'])
+    X.observe(g['pmm_x'])
+    trace('pmm', vb_cls(X, lam, Z, al, **vb_kwargs), 5, dict(lam=lam, Z=Z, al=al))
+
+    # 6. sums of independent Gaussian factors as the mean of observations
+    a = N_.GaussianARD(0, 1e-1, shape=(2,), plates=(5, 1), name='a')
+    b = N_.GaussianARD(0, 1e-1, shape=(2,), plates=(1, 3), name='b')
+    c = N_.Gaussian(np.array([0.5, -0.5]), np.array([[2.0, 0.3], [0.3, 1.0]]), name='c')
+    s = N_.Add(a, b, c, name='s')
+    tau = N_.Gamma(1e-2, 1e-2, name='tau')
+    Y = N_.GaussianARD(s, tau, name='Y')
+    b.initialize_from_value(g['add_b0'][None])
+    Y.observe(g['add_y'])
+    trace('add', vb_cls(Y, a, b, c, tau, **vb_kwargs), 4, dict(a=a, b=b, c=c, tau=tau))
+    out['add_s_u'] = [np.array(v) for v in s.get_moments()]
+    m1 = N_.GaussianARD(0, 1, name='m1')
+    m2 = N_.GaussianARD(1, 2, plates=(7,), name='m2')
+    Ys = N_.GaussianARD(N_.Add(m1, m2, 0.25), 3.0, name='Ys')
+    Ys.observe(g['adds_y'])
+    trace('adds', vb_cls(Ys, m1, m2, **vb_kwargs), 3, dict(m1=m1, m2=m2))
+    return out

@@ -443,3 +443,48 @@ def test_parameter_api_gradients_annealing_and_optimizers_match_reference(golden
     np.testing.assert_allclose(res['cg_L'], f['cg_L'], rtol=1e-6)
     np.testing.assert_allclose(res['cg_W'], f['cg_W'], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(res['cg_tau'], f['cg_tau'], rtol=1e-5)
+
+
+def _compare_shared(res, f, skip=(), rtol=MOM_RTOL):
+    for k, v in res.items():
+        if k in skip:
+            continue
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                ref = f['%s_%d' % (k, i)]
+                np.testing.assert_allclose(np.broadcast_to(vi, ref.shape), ref, rtol=rtol,
+                                           atol=1e-9, err_msg='%s[%d]' % (k, i))
+        else:
+            np.testing.assert_allclose(v, f[k], rtol=1e-8, atol=1e-8, err_msg=k)
+
+
+def test_count_probability_and_add_nodes_match_reference(golden_dir):
+    """Beta, Bernoulli, Binomial, Poisson, Complement, Add, and Bernoulli / Poisson mixtures
+    (tests/models.py run_count_node_cases on both sides; the Bernoulli mixture is the model
+    of doc/source/examples/bmm.rst)."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_count_node_cases
+    f = np.load(os.path.join(golden_dir, 'count_nodes.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_count_node_cases(N_, VB, g)
+    _compare_shared(res, f)
+    # argument checks of the reference
+    p = N_.Beta([1.0, 1.0])
+    with pytest.raises(ValueError, match='integer'):
+        N_.Binomial(2.5, p)
+    with pytest.raises(ValueError, match='non-negative'):
+        N_.Binomial(-1, p)
+    with pytest.raises(ValueError, match='two-dimensional'):
+        N_.Beta([1.0, 1.0, 1.0])
+    x = N_.Binomial(3, p)
+    with pytest.raises(ValueError, match='Invalid count'):
+        x.observe(4)
+    with pytest.raises(ValueError):
+        N_.Poisson(2.0).observe(1.5)
+    with pytest.raises(NotImplementedError, match='Gamma'):
+        N_.Exponential(1.0)
+    with pytest.raises(ValueError, match='at least two'):
+        N_.Add(N_.GaussianARD(0, 1))
+    with pytest.raises(ValueError, match='identical shapes'):
+        N_.Add(N_.GaussianARD(0, 1, shape=(2,)), N_.GaussianARD(0, 1, shape=(3,)))
