@@ -13,6 +13,7 @@ from ...nodes.beta import Beta, Complement
 from ...nodes.binomial import Binomial
 from ...nodes.poisson import Poisson
 from ...nodes.add import Add
+from ...nodes.take import Take, Concatenate, Gate
 from ...utils import misc, linalg
 from .generic import Family, DirichletFamily, _arr, _trail, _const, _check_device
 
@@ -187,7 +188,217 @@ class AddFamily:
         return out
 
 
+def _masked(m, mask, nd):
+    if mask is None or m is None:
+        return m
+    return fuse(lambda a, w: a * w, _arr(m), _trail(mask, nd))
+
+
+class TakeFamily:
+    """take.py:72-140: moments are gathered along the plate axis, messages are accumulated
+    back (several picks of the same element add up)."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.axis = node.plate_axis
+        self.imap = misc.IndexMap(node.indices, node.original_length)
+        self.ndims = [len(d) for d in node.dims]
+
+    def plates_to_parent(self, index):
+        p = self.node.plates
+        end_before = self.axis - self.node.indices.ndim + 1
+        start_after = self.axis + 1
+        head = p[:len(p) + end_before] if end_before != 0 else p
+        tail = p[len(p) + start_after:] if start_after != 0 else ()
+        return tuple(head) + (self.node.original_length,) + tuple(tail)
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask, dtype=bool)
+        nax = self.node.indices.ndim
+        first = self.axis - nax + 1
+        if mask.ndim < -first:
+            mask = mask.reshape((1,) * (-first - mask.ndim) + mask.shape)
+        a = mask.ndim + first
+        full = mask.shape[:a] + self.node.indices.shape + mask.shape[a + nax:]
+        m = np.broadcast_to(mask, full).reshape(full[:a] + (-1,) + full[a + nax:])
+        out = np.zeros(full[:a] + (self.node.original_length,) + full[a + nax:], dtype=np.int64)
+        flat = np.where(self.node.indices < 0, self.node.indices + self.node.original_length,
+                        self.node.indices).reshape(-1)
+        np.add.at(np.moveaxis(out, a, 0), flat, np.moveaxis(m, a, 0).astype(np.int64))
+        return out > 0
+
+    def moments(self, ups):
+        out = []
+        L = self.node.original_length
+        for ui, nd in zip(ups[0], self.ndims):
+            ui = _arr(ui)
+            ax = self.axis - nd
+            if ui.ndim < -ax:
+                ui = ui.reshape((1,) * (-ax - ui.ndim) + ui.shape)
+            if ui.shape[ax] != L:             # broadcast along the taken axis
+                sh = list(ui.shape)
+                sh[ax] = L
+                ui = ui.broadcast_to(tuple(sh))
+            out.append(misc.take(ui, self.imap, axis=ax))
+        return out
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        out = []
+        for m, nd in zip(m_child, self.ndims):
+            if m is None:
+                out.append(None)
+                continue
+            m = _masked(m, mask, nd)
+            out.append(misc.put_simple(_arr(m), self.imap, axis=self.axis - nd))
+        return out
+
+
+class ConcatenateFamily:
+    """concatenate.py:96-167."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.axis = node.axis
+        self.ndims = [len(d) for d in node.dims]
+
+    def plates_to_parent(self, index):
+        p = list(self.node.plates)
+        p[self.axis] = self.node.lengths[index]
+        return tuple(p)
+
+    def _slice(self, x, index, ax):
+        """The part of ``x`` that belongs to parent ``index`` along array axis ``ax`` (all of
+        it when that axis is missing or broadcast)."""
+        nd = np.ndim(x) if not isinstance(x, DArray) else x.ndim
+        shape = x.shape
+        if nd >= -ax and shape[ax] > 1:
+            a, b = int(self.node.offsets[index]), int(self.node.offsets[index + 1])
+            sl = [slice(None)] * nd
+            sl[ax] = slice(a, b)
+            return x[tuple(sl)]
+        return x
+
+    def mask_to_parent(self, index, mask):
+        return self._slice(np.asarray(mask), index, self.axis)
+
+    def moments(self, ups):
+        out = []
+        for i, nd in enumerate(self.ndims):
+            ax = self.axis - nd
+            parts = []
+            for up, n in zip(ups, self.node.lengths):
+                x = _arr(up[i])
+                if x.ndim < -ax:
+                    x = x.reshape((1,) * (-ax - x.ndim) + x.shape)
+                if x.shape[ax] != n:
+                    sh = list(x.shape)
+                    sh[ax] = n
+                    x = x.broadcast_to(tuple(sh))
+                parts.append(x)
+            out.append(misc.concatenate(parts, axis=ax))
+        return out
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        out = []
+        for m, nd in zip(m_child, self.ndims):
+            if m is None:
+                out.append(None)
+                continue
+            m = _arr(_masked(m, mask, nd))
+            out.append(self._slice(m, index, self.axis - nd))
+        return out
+
+
+class GateFamily:
+    """gate.py:71-205: moments  sum_k <z_k> u_X[k]  over the gated plate axis."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.gp = node.gated_plate
+        self.K = node.K
+        self.ndims = [len(d) for d in node.dims]
+
+    def constant_moments(self, index, value):
+        if index != 0:
+            raise NotImplementedError('the gated parent must be a node')
+        return [misc.onehot(np.asarray(value).astype(np.int64), self.K)]
+
+    def plates_to_parent(self, index):
+        if index == 0:
+            return self.node.plates
+        p = list(self.node.plates)
+        p.insert(len(p) + self.gp + 1, self.K)
+        return tuple(p)
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask)
+        if index == 0 or mask.ndim < abs(self.gp):
+            return mask
+        return np.expand_dims(mask, self.gp)
+
+    def _gated_last_plate(self, x, nd):
+        """x (plates of X + dims_i) -> the gated axis moved to just before the dims."""
+        x = _arr(x)
+        ax = self.gp - nd
+        if x.ndim < -ax:
+            return x.reshape(x.shape[:x.ndim - nd] + (1,) + x.shape[x.ndim - nd:])
+        return misc.moveaxis(x, ax, -nd - 1)
+
+    def moments(self, ups):
+        z = _arr(ups[0][0])
+        out = []
+        for x, nd in zip(ups[1], self.ndims):
+            out.append(misc.sum_multiply(_trail(z, nd), self._gated_last_plate(x, nd),
+                                         axis=-nd - 1))
+        return out
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        z = _arr(ups[0][0])
+        if index == 0:
+            tot = None
+            for m, x, nd in zip(m_child, ups[1], self.ndims):
+                if m is None:
+                    continue
+                c = _arr(_masked(m, mask, nd))
+                c = c.reshape(c.shape[:c.ndim - nd] + (1,) + c.shape[c.ndim - nd:])
+                t = misc.sum_multiply(c, self._gated_last_plate(x, nd),
+                                      axis=tuple(range(-nd, 0))) if nd else \
+                    fuse(lambda a, b: a * b, c, self._gated_last_plate(x, nd))
+                tot = t if tot is None else fuse(lambda a, b: a + b, tot, t)
+            if tot is None:
+                return [None]
+            if tot.shape[-1] != self.K:           # the class axis must not be broadcast
+                tot = fuse(lambda a, o: a * o, tot, _const(('ones', (self.K,)),
+                                                           lambda: np.ones(self.K)))
+            return [tot]
+        out = []
+        for m, nd in zip(m_child, self.ndims):
+            if m is None:
+                out.append(None)
+                continue
+            c = _arr(_masked(m, mask, nd))
+            c = c.reshape(c.shape[:c.ndim - nd] + (1,) + c.shape[c.ndim - nd:])
+            mi = fuse(lambda a, b: a * b, _trail(z, nd), c)     # plates + (K,) + dims
+            ax = self.gp - nd
+            if mi.ndim < -ax:
+                mi = mi.reshape((1,) * (-ax - mi.ndim) + mi.shape)
+            out.append(misc.moveaxis(mi, -nd - 1, ax))
+        return out
+
+
 def make_extra_family(node):
+    if isinstance(node, Take):
+        return TakeFamily(node)
+    if isinstance(node, Concatenate):
+        return ConcatenateFamily(node)
+    if isinstance(node, Gate):
+        return GateFamily(node)
     if isinstance(node, Beta):
         return BetaFamily(node)
     if isinstance(node, Complement):

@@ -1149,9 +1149,10 @@ class GenericPlan:
                     if m is None or not isinstance(m, DArray):
                         continue
                     dims = tuple(parent.dims[i])
+                    own = tuple(fam.plates_to_parent(index)) \
+                        if hasattr(fam, 'plates_to_parent') else tuple(child.plates)
                     msgs[i] = misc.sum_multiply_to_plates(
-                        m, to_plates=parent.plates + dims, from_plates=child.plates + dims,
-                        ndim=0)
+                        m, to_plates=parent.plates + dims, from_plates=own + dims, ndim=0)
             return msgs
         u = self._moments(child)
         up = self._parent_moments(child)

@@ -14,9 +14,11 @@ from .beta import Beta
 from .binomial import Binomial, Bernoulli
 from .poisson import Poisson
 from .add import Add
+from .take import Take, Concatenate, Gate
 from .mixture import Mixture
 from .gaussian_markov_chain import GaussianMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
-           'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add']
+           'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add',
+           'Take', 'Concatenate', 'Gate']

@@ -468,3 +468,122 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     keep_shape = tuple(1 if i in red else shape[i] for i in range(nd))
     out = _launch_sum_multiply(views, shape, red, keep_shape, scale)
     return out.reshape(tuple(shape[i] for i in range(len(out_labels))))
+
+
+# ---------------------------------------------------------------------------
+# plate re-indexing (take / put_simple / concatenate, utils/misc.py:549-585 and the
+# np.take / np.concatenate call sites take.py:72-94, concatenate.py:130-167)
+# ---------------------------------------------------------------------------
+class IndexMap:
+    """A constant integer index array along one axis of length ``length``, resident on the
+    device together with its inverse (CSR: for every target row the source positions, in
+    increasing order) so that the accumulation of ``put_simple`` has a fixed order."""
+
+    def __init__(self, indices, length):
+        idx = np.asarray(indices)
+        if not np.issubdtype(idx.dtype, np.integer):
+            raise ValueError("Indices must be integers")
+        idx = idx.astype(np.int64)
+        if np.any(idx < -length) or np.any(idx >= length):
+            raise ValueError("Index out of bounds")
+        flat = np.where(idx < 0, idx + length, idx).reshape(-1)
+        self.shape = tuple(idx.shape)
+        self.length = int(length)
+        self.n = int(flat.size)
+        ptr = np.zeros(length + 1, dtype=np.int64)
+        np.add.at(ptr, flat + 1, 1)
+        rt = get_runtime()
+        up = lambda a: rt.torch.from_numpy(np.ascontiguousarray(a)).to(rt.device)
+        self.idx = up(flat)
+        self.ptr = up(np.cumsum(ptr))
+        self.perm = up(np.argsort(flat, kind='stable').astype(np.int64))
+
+
+def _split3(shape, axis, nax=1):
+    """(outer, inner) sizes around the ``nax`` axes starting at negative ``axis``."""
+    nd = len(shape)
+    a = nd + axis
+    outer = int(np.prod(shape[:a], dtype=np.int64))
+    inner = int(np.prod(shape[a + nax:], dtype=np.int64))
+    return a, outer, inner
+
+
+def take(x, imap, axis=-1):
+    """``np.take(x, indices, axis)`` for a negative ``axis``; an index array with several
+    axes creates as many axes in the result."""
+    x = contiguous(asdarray(x))
+    if axis >= 0 or -axis > x.ndim:
+        raise ValueError("axis must be a negative index into the array")
+    if x.shape[axis] != imap.length:
+        raise ValueError("axis has length %d, the index map expects %d"
+                         % (x.shape[axis], imap.length))
+    a, outer, inner = _split3(x.shape, axis)
+    out = DArray.empty(x.shape[:a] + imap.shape + x.shape[a + 1:])
+    rt = get_runtime()
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_take_axis(rt.ctx, outer, imap.length, inner,
+                                  ctypes.c_void_p(x.t.data_ptr()), imap.n,
+                                  ctypes.c_void_p(imap.idx.data_ptr()),
+                                  ctypes.c_void_p(out.t.data_ptr()), imap.n, 0))
+    return out
+
+
+def put_simple(y, imap, axis=-1):
+    """Accumulating inverse of :func:`take`: the ``len(imap.shape)`` axes of ``y`` that end at
+    negative ``axis`` collapse into one axis of length ``imap.length``; entries with the same
+    index are added (utils/misc.py:549-585)."""
+    y = asdarray(y)
+    nax = len(imap.shape)
+    if axis >= 0:
+        raise ValueError("Axis index must be negative")
+    first = axis - nax + 1                  # negative position of the first index axis
+    need = -first
+    if y.ndim < need:
+        y = y.reshape((1,) * (need - y.ndim) + y.shape)
+    a = y.ndim + first
+    want = y.shape[:a] + imap.shape + y.shape[a + nax:]
+    if y.shape != want:
+        y = y.broadcast_to(want)            # broadcast index axes are real terms of the sum
+    y = contiguous(y)
+    _, outer, inner = _split3(y.shape, first, nax)
+    out = DArray.empty(y.shape[:a] + (imap.length,) + y.shape[a + nax:])
+    rt = get_runtime()
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_segment_sum_axis(rt.ctx, outer, imap.n, inner,
+                                         ctypes.c_void_p(y.t.data_ptr()), imap.length,
+                                         ctypes.c_void_p(imap.ptr.data_ptr()),
+                                         ctypes.c_void_p(imap.perm.data_ptr()),
+                                         ctypes.c_void_p(out.t.data_ptr())))
+    return out
+
+
+def concatenate(arrays, axis=-1):
+    """``np.concatenate`` along a negative ``axis`` with broadcasting of all other axes (the
+    explicit broadcast of concatenate.py:140-163)."""
+    arrays = [asdarray(a) for a in arrays]
+    if axis >= 0:
+        raise ValueError("Currently, only negative axis indeces are allowed.")
+    nd = max(max(a.ndim for a in arrays), -axis)
+    arrays = [a.reshape((1,) * (nd - a.ndim) + a.shape) for a in arrays]
+    ax = nd + axis
+    others = [tuple(1 if i == ax else s for i, s in enumerate(a.shape)) for a in arrays]
+    common = broadcasted_shape(*others)
+    lengths = [a.shape[ax] for a in arrays]
+    total = int(sum(lengths))
+    out = DArray.empty(common[:ax] + (total,) + common[ax + 1:])
+    _, outer, inner = _split3(out.shape, axis)
+    rt = get_runtime()
+    rt.sync_stream()
+    off = 0
+    for a, n in zip(arrays, lengths):
+        src = contiguous(a.broadcast_to(common[:ax] + (n,) + common[ax + 1:]))
+        rt.check(rt.lib.vmp_take_axis(rt.ctx, outer, n, inner, ctypes.c_void_p(src.t.data_ptr()),
+                                      n, None, ctypes.c_void_p(out.t.data_ptr()), total, off))
+        off += n
+    return out
+
+
+def moveaxis(x, src, dst):
+    """Stride-only view with one axis moved (utils/misc.py:947-960)."""
+    x = asdarray(x)
+    return DArray(x.t.movedim(src, dst))

@@ -322,6 +322,25 @@ int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double 
 int32_t vmp_onehot_i64(vmp_ctx *ctx, int64_t n, int32_t K, const int64_t *labels, double *out,
                        int32_t *info);
 
+/* Plate re-indexing of the deterministic nodes that move plates.  Arrays are contiguous and
+ * seen as (outer, axis, inner).
+ *   vmp_take_axis:  dst[o, dst_off + j, i] = src[o, idx ? idx[j] : j, i]  for j < n; dst has
+ *     dst_len rows on the axis.  np.take on a plate axis (Take._compute_moments, take.py:72-81);
+ *     with idx = NULL the block copy of Concatenate._compute_moments (concatenate.py:130-167).
+ *     idx is a device array of n valid row numbers in [0, src_len).
+ *   vmp_segment_sum_axis:  dst[o, l, i] = sum over t in [ptr[l], ptr[l+1]) of
+ *     src[o, perm[t], i]  for l < out_len -- misc.put_simple (utils/misc.py:549-585), the
+ *     accumulating inverse of take used by Take._compute_message_to_parent (take.py:83-94).
+ *     ptr (out_len + 1) and perm (src_len) are device arrays: the CSR map from target row to
+ *     its source rows, built once on the host; the order of the additions is fixed, so the
+ *     result is bit-reproducible. */
+int32_t vmp_take_axis(vmp_ctx *ctx, int64_t outer, int64_t src_len, int64_t inner,
+                      const double *src, int64_t n, const int64_t *idx, double *dst,
+                      int64_t dst_len, int64_t dst_off);
+int32_t vmp_segment_sum_axis(vmp_ctx *ctx, int64_t outer, int64_t src_len, int64_t inner,
+                             const double *src, int64_t out_len, const int64_t *ptr,
+                             const int64_t *perm, double *dst);
+
 /* Strided batched fp64 contraction on the matrix cores (v_mfma_f64_16x16x4_f64):
  *     C[b, m, n] = scale * sum_k A[b, m, k] * B[b, k, n]
  * with arbitrary ELEMENT strides on every axis (0 = broadcast batch axis), up to three

@@ -668,6 +668,12 @@ def count_nodes_case(name):
                  ('bern_L', 'bmm_L', 'pmm_L', 'add_L'))
 
 
+def plate_nodes_case(name):
+    """Take / Concatenate / Gate inside small models."""
+    _shared_case(name, 'make_plate_node_inputs', 'run_plate_node_cases', 314,
+                 ('tk_doc', 'tk_L', 'tk2_L', 'cc_L', 'cc2_L', 'gt_L', 'gt2_L'))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -690,6 +696,7 @@ def main():
     mixture_ard_case('mixture_ard')
     parameter_api_case('parameter_api')
     count_nodes_case('count_nodes')
+    plate_nodes_case('plate_nodes')
 
 
 if __name__ == '__main__':

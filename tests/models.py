@@ -366,3 +366,88 @@ def run_count_node_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     Ys.observe(g['adds_y'])
     trace('adds', vb_cls(Ys, m1, m2, **vb_kwargs), 3, dict(m1=m1, m2=m2))
     return out
+
+
+def make_plate_node_inputs(rs):
+    """Seeded inputs of run_plate_node_cases (tests/golden/plate_nodes.npz)."""
+    g = {}
+    g['tk_y'] = rs.normal(size=(6,)) * np.array([1.0, 1.0, 0.5, 0.5, 1.0, 2.0])
+    g['tk2_y'] = rs.normal(size=(5, 2, 2, 4, 2))
+    g['tk2_mask'] = rs.rand(5, 2, 2, 4) < 0.8
+    g['cc_y'] = rs.normal(size=(4, 5)) + np.array([0.0, 0.0, 0.0, 3.0, 3.0])
+    g['cc_mask'] = rs.rand(4, 5) < 0.85
+    g['cc2_y'] = rs.normal(size=(7, 3, 2))
+    lab = rs.randint(3, size=40)
+    g['gt_y'] = np.array([[-3.0, 0.0], [0.0, 3.0], [3.0, -1.0]])[lab] + 0.5 * rs.normal(size=(40, 2))
+    g['gt_lab0'] = rs.randint(3, size=40)
+    g['gt2_y'] = rs.normal(size=(6, 4)) + np.array([0.0, 1.0, -2.0, 4.0])
+    return g
+
+
+def run_plate_node_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Take, Concatenate and Gate inside small models, the same statements on the reference
+    and on this framework (take.py:34-39 doctest, nodes/tests/test_take.py,
+    test_concatenate.py, test_gate.py)."""
+    N_ = nodes_mod
+    out = {}
+
+    def trace(tag, Q, n, track):
+        Q.ignore_bound_checks = True
+        Q.update(repeat=n, verbose=False)
+        out[tag + '_L'] = np.array(Q.L[:n])
+        for nm, nd in track.items():
+            out['%s_%s_u' % (tag, nm)] = [np.array(v) for v in nd.get_moments()]
+
+    # 1. the doctest of take.py:34-39, then the taken precisions in a model
+    alpha = N_.Gamma([1, 2, 3], [1, 1, 1], name='alpha')
+    x = N_.Take(alpha, [1, 1, 2, 2, 1, 0], name='x')
+    out['tk_doc'] = np.array(x.get_moments()[0])
+    Y = N_.GaussianARD(0, x, name='Y')
+    Y.observe(g['tk_y'])
+    trace('tk', vb_cls(Y, alpha, **vb_kwargs), 2, dict(alpha=alpha, x=x))
+
+    # 2. an index array with two axes on a non-last plate axis of a vector Gaussian, masked data
+    mu = N_.GaussianARD(0, 1e-1, shape=(2,), plates=(3, 4), name='mu')
+    t = N_.Take(mu, [[0, 2], [1, 1]], plate_axis=-2, name='t')
+    out['tk2_plates'] = np.array(t.plates)
+    Y = N_.GaussianARD(t, 2.0, shape=(2,), plates=(5, 2, 2, 4), name='Y')
+    Y.observe(g['tk2_y'], mask=g['tk2_mask'])
+    trace('tk2', vb_cls(Y, mu, **vb_kwargs), 2, dict(mu=mu, t=t))
+
+    # 3. concatenation of scalar Gaussians along the last plate axis; the mask is constant
+    #    along that axis (the reference's Concatenate cannot split a mask, concatenate.py:118-126)
+    a = N_.GaussianARD(0, 1, plates=(3,), name='a')
+    b = N_.GaussianARD(1, 2, plates=(2,), name='b')
+    c = N_.Concatenate(a, b, name='c')
+    tau = N_.Gamma(1e-2, 1e-2, name='tau')
+    Y = N_.GaussianARD(c, tau, plates=(4, 5), name='Y')
+    Y.observe(g['cc_y'], mask=g['cc_mask'][:, :1])
+    trace('cc', vb_cls(Y, a, b, tau, **vb_kwargs), 3, dict(a=a, b=b, c=c, tau=tau))
+    #    ... and of vector Gaussians along the second-last plate axis
+    a = N_.GaussianARD(0, 1, shape=(2,), plates=(2, 1), name='a2')
+    b = N_.GaussianARD(0.5, 1, shape=(2,), plates=(1, 1), name='b2')
+    c = N_.Concatenate(a, b, axis=-2, name='c2')
+    out['cc2_plates'] = np.array(c.plates)
+    Y = N_.GaussianARD(c, 1.5, shape=(2,), plates=(7, 3, 1), name='Y')
+    Y.observe(g['cc2_y'][:, :, None, :])
+    trace('cc2', vb_cls(Y, a, b, **vb_kwargs), 2, dict(a=a, b=b, c=c))
+
+    # 4. gated cluster means: a mixture written with Gate instead of Mixture
+    N, K = g['gt_y'].shape[0], 3
+    al = N_.Dirichlet(np.ones(K), name='al')
+    Z = N_.Categorical(al, plates=(N,), name='Z')
+    X = N_.GaussianARD(0, 1e-2, shape=(2,), plates=(K,), name='X')
+    G = N_.Gate(Z, X, name='G')
+    lam = N_.Gamma(1e-1, 1e-1, name='lam')
+    Y = N_.GaussianARD(G, lam, name='Y')
+    Z.initialize_from_value(g['gt_lab0'])
+    Y.observe(g['gt_y'])
+    trace('gt', vb_cls(Y, X, lam, Z, al, **vb_kwargs), 5, dict(X=X, lam=lam, Z=Z, G=G))
+    #    ... gating a non-default plate axis with fixed class labels
+    X = N_.GaussianARD(0, 1, plates=(3, 4), name='X2')
+    G = N_.Gate([[1], [0], [2], [1], [1], [0]], X, gated_plate=-2, name='G2')
+    out['gt2_plates'] = np.array(G.plates)
+    Y = N_.GaussianARD(G, 2.0, plates=(6, 4), name='Y')
+    Y.observe(g['gt2_y'])
+    trace('gt2', vb_cls(Y, X, **vb_kwargs), 2, dict(X=X, G=G))
+    return out

@@ -488,3 +488,65 @@ def test_count_probability_and_add_nodes_match_reference(golden_dir):
         N_.Add(N_.GaussianARD(0, 1))
     with pytest.raises(ValueError, match='identical shapes'):
         N_.Add(N_.GaussianARD(0, 1, shape=(2,)), N_.GaussianARD(0, 1, shape=(3,)))
+
+
+def test_take_concatenate_gate_match_reference(golden_dir):
+    """Take (incl. the doctest of take.py:34-39, a two-axis index array on a non-last plate
+    axis, masked data), Concatenate (last and second-last plate axis) and Gate (latent gate,
+    fixed labels on a non-default plate axis) -- tests/models.py run_plate_node_cases."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_plate_node_cases
+    f = np.load(os.path.join(golden_dir, 'plate_nodes.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_plate_node_cases(N_, VB, g)
+    np.testing.assert_array_equal(res['tk_doc'], [2., 2., 3., 3., 2., 1.])
+    _compare_shared(res, f)
+    # argument checks of take.py:47-62, concatenate.py:27-31, gate.py:45-78
+    a = N_.Gamma([1, 2, 3], [1, 1, 1])
+    with pytest.raises(ValueError, match='negative'):
+        N_.Take(a, [0], plate_axis=0)
+    with pytest.raises(ValueError, match='out of bounds'):
+        N_.Take(a, [0], plate_axis=-2)
+    with pytest.raises(ValueError, match='Index out of bounds'):
+        N_.Take(a, [3])
+    with pytest.raises(ValueError, match='integers'):
+        N_.Take(a, [0.5])
+    with pytest.raises(ValueError, match='negative'):
+        N_.Concatenate(a, a, axis=0)
+    with pytest.raises(ValueError, match='dimensionalities'):
+        N_.Concatenate(N_.GaussianARD(0, 1, plates=(2,)), N_.GaussianARD(0, 1, shape=(2,), plates=(2,)))
+    with pytest.raises(ValueError, match='Inconsistent number of clusters'):
+        N_.Gate(N_.Categorical([0.5, 0.5]), N_.GaussianARD(0, 1, plates=(3,)))
+
+
+def test_take_and_put_kernels_are_exact_and_reproducible():
+    """vmp_take_axis is a copy (bit-exact against np.take); vmp_segment_sum_axis adds the
+    sources of a row in a fixed order: equal to a sequential NumPy accumulation bit for bit,
+    and identical from run to run."""
+    from bayespy_amd.darray import DArray
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(5)
+    for shape, axis, ishape in (((7, 5), -1, (11,)), ((4, 6, 3), -2, (2, 5)), ((9,), -1, (3, 2, 2)),
+                                ((3, 1000, 2), -2, (4000,))):
+        x = rs.normal(size=shape)
+        L = shape[axis]
+        idx = rs.randint(-L, L, size=ishape)
+        im = misc.IndexMap(idx, L)
+        got = misc.take(DArray.from_host(x), im, axis=axis).numpy()
+        np.testing.assert_array_equal(got, np.take(x, idx, axis=axis))
+        y = rs.normal(size=got.shape)
+        back = misc.put_simple(DArray.from_host(y), im, axis=axis).numpy()
+        a = len(shape) + axis
+        ref = np.zeros(shape)
+        ym = np.moveaxis(y.reshape(shape[:a] + (-1,) + shape[a + 1:]), a, 0)
+        rm = np.moveaxis(ref, a, 0)
+        for j, l in enumerate(np.where(idx < 0, idx + L, idx).reshape(-1)):
+            rm[l] += ym[j]
+        np.testing.assert_array_equal(back, ref)
+        np.testing.assert_array_equal(
+            back, misc.put_simple(DArray.from_host(y), im, axis=axis).numpy())
+    parts = [rs.normal(size=(2, 3, 4)), rs.normal(size=(1, 5, 4)), rs.normal(size=(2, 1, 1))]
+    got = misc.concatenate([DArray.from_host(p) for p in parts], axis=-2).numpy()
+    ref = np.concatenate([np.broadcast_to(p, (2, p.shape[1], 4)) for p in parts], axis=-2)
+    np.testing.assert_array_equal(got, ref)
