@@ -111,6 +111,8 @@ SIGNATURES = {
     'vmp_gaussian_moments': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_softmax_moments': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_onehot_i64': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    'vmp_alpha_beta_recursion': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64,
+                                         c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t]),
     'vmp_take_axis': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64]),
     'vmp_segment_sum_axis': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'vmp_gemm_strided': (c_i32, [c_vp, c_i32, P(c_i64), c_i64, c_i64, c_i64, c_vp, P(c_i64), c_i64,

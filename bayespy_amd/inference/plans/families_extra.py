@@ -14,7 +14,10 @@ from ...nodes.binomial import Binomial
 from ...nodes.poisson import Poisson
 from ...nodes.add import Add
 from ...nodes.take import Take, Concatenate, Gate
+from ...nodes.categorical_markov_chain import (CategoricalMarkovChain,
+                                                CategoricalMarkovChainToCategorical)
 from ...utils import misc, linalg
+from ...utils import random as drandom
 from .generic import Family, DirichletFamily, _arr, _trail, _const, _check_device
 
 
@@ -392,7 +395,122 @@ class GateFamily:
         return out
 
 
+class CategoricalMarkovChainFamily(Family):
+    """categorical_markov_chain.py:71-205; the moments are one launch of the forward-backward
+    kernel for all chains and time instances (utils/random.py:357-422)."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.K = node.categories
+        self.N = node.states
+
+    def constant_moments(self, index, value):
+        return [fuse(lambda p: da.log(p), _arr(value))]          # DirichletMoments of a value
+
+    def plates_to_parent(self, index):
+        if index == 0:
+            return self.node.plates
+        return self.node.plates + (self.N - 1, self.K)
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask)
+        return mask if index == 0 else mask[..., None, None]
+
+    def phi_from_parents(self, up):
+        logP = _arr(up[1][0])
+        want = (self.N - 1, self.K, self.K)
+        if logP.ndim < 3:
+            logP = logP.reshape((1,) * (3 - logP.ndim) + logP.shape)
+        if logP.shape[-3:] != want:
+            logP = logP.broadcast_to(logP.shape[:-3] + want)     # time-invariant transitions
+        return [_arr(up[0][0]), logP]
+
+    def moments_and_cgf(self, phi):
+        z0, zz, g = drandom.alpha_beta_recursion(phi[0], phi[1])
+        return [z0, zz], g
+
+    def cgf_from_parents(self, up):
+        return 0.0
+
+    def fixed_moments_and_f(self, x):
+        # one-hot first state and one-hot transitions (categorical_markov_chain.py:38-58)
+        x = np.asarray(x).astype(np.int64)
+        K = self.K
+        u0 = misc.onehot(x[..., 0], K)
+        pair = x[..., :-1] * K + x[..., 1:]
+        us = misc.onehot(pair, K * K)
+        return [u0, us.reshape(us.shape[:-1] + (K, K))], 0.0
+
+    def message_to_parent(self, index, u, up):
+        return [u[index]]
+
+    def sample(self, st):
+        plates = self.node.plates
+        p0 = np.broadcast_to(_arr(st.u[0]).numpy(), plates + (self.K,)).reshape(-1, self.K)
+        zz = np.broadcast_to(_arr(st.u[1]).numpy(),
+                             plates + (self.N - 1, self.K, self.K)).reshape(-1, self.N - 1,
+                                                                             self.K, self.K)
+        B = p0.shape[0]
+        Z = np.zeros((B, self.N), dtype=np.int64)
+
+        def draw(p):
+            c = np.cumsum(p, axis=-1)
+            r = np.random.rand(p.shape[0], 1) * c[:, -1:]
+            return (r > c).sum(axis=1).clip(0, self.K - 1)
+        Z[:, 0] = draw(p0)
+        rows = np.arange(B)
+        for n in range(self.N - 1):
+            Z[:, n + 1] = draw(zz[rows, n, Z[:, n]] + 1e-300)     # q(z_{n+1} | z_n)
+        return Z.reshape(plates + (self.N,))
+
+
+class ChainToCategoricalFamily:
+    """CategoricalMarkovChainToCategorical (categorical_markov_chain.py:363-438): marginals of
+    all time instances with time as the last plate."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+
+    def plates_to_parent(self, index):
+        return self.node.plates[:-1]
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask)
+        return np.any(mask, axis=-1) if mask.ndim >= 1 else mask
+
+    def moments(self, ups):
+        z0, zz = _arr(ups[0][0]), _arr(ups[0][1])
+        p = misc.sum_multiply(zz, axis=-2)                      # q(z_{n+1}), (..., N-1, K)
+        first = z0.reshape(z0.shape[:-1] + (1, z0.shape[-1]))
+        return [misc.concatenate([first, p], axis=-2)]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        m = m_child[0]
+        if m is None:
+            return [None, None]
+        m = _arr(m)
+        if mask is not None:
+            m = fuse(lambda a, w: a * w, m, _trail(mask, 1))
+        N = self.node.plates[-1]
+        if m.ndim < 2 or m.shape[-2] != N:
+            # constant over time: give it the time axis
+            lead = m.shape[:-1] if m.ndim >= 1 else ()
+            lead = lead[:-1] if (m.ndim >= 2 and m.shape[-2] == 1) else lead
+            m = m.broadcast_to(lead + (N, self.node.categories)) if m.ndim >= 2 else \
+                m.reshape((1, -1)).broadcast_to((N, self.node.categories))
+        m0 = m[..., 0, :]
+        m1 = m[..., 1:, :]
+        m1 = m1.reshape(m1.shape[:-1] + (1, m1.shape[-1]))       # (..., N-1, 1, K)
+        return [m0, m1]
+
+
 def make_extra_family(node):
+    if isinstance(node, CategoricalMarkovChain):
+        return CategoricalMarkovChainFamily(node)
+    if isinstance(node, CategoricalMarkovChainToCategorical):
+        return ChainToCategoricalFamily(node)
     if isinstance(node, Take):
         return TakeFamily(node)
     if isinstance(node, Concatenate):

@@ -17,8 +17,9 @@ from .add import Add
 from .take import Take, Concatenate, Gate
 from .mixture import Mixture
 from .gaussian_markov_chain import GaussianMarkovChain
+from .categorical_markov_chain import CategoricalMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
            'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add',
-           'Take', 'Concatenate', 'Gate']
+           'Take', 'Concatenate', 'Gate', 'CategoricalMarkovChain']

@@ -18,6 +18,10 @@ class Mixture(Stochastic):
         # positional arguments beyond the parents of the mixed class are constructor
         # arguments of that class (the reference forwards them to ``_constructor``, e.g. the
         # ``ndim`` of ``Mixture(z, GaussianARD, mu, alpha, 1)``; mixture.py:398-420)
+        # a categorical Markov chain is seen through its categorical view: the time axis
+        # becomes the last plate (moment converter of categorical_markov_chain.py:435-438)
+        if hasattr(z, 'as_categorical'):
+            z = z.as_categorical()
         npar = getattr(node_class, '_parent_count', None)
         extra = ()
         if npar is not None and len(params) > npar:
@@ -46,3 +50,13 @@ class Mixture(Stochastic):
         self.plates = broadcasted_shape(given, self.parents[0].plates, pp[:-1])
         if plates is not None and self.plates != given:
             raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
+
+    def _check_value_shape(self, x):
+        # values have the form of the mixed class (labels for Categorical, counts for
+        # Poisson, ...) on this node's plates
+        saved = self._proto.plates
+        self._proto.plates = self.plates
+        try:
+            self._proto._check_value_shape(x)
+        finally:
+            self._proto.plates = saved

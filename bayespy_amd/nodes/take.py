@@ -96,6 +96,8 @@ class Gate(Node):
         if len(X.plates) < abs(gated_plate):
             raise ValueError("The gated node does not have a plate axis is gated")
         K = X.plates[gated_plate]
+        if hasattr(Z, 'as_categorical'):
+            Z = Z.as_categorical()
         super().__init__(Z, X, plates=(), dims=X.dims, name=name)
         z = self.parents[0]
         if isinstance(z, Constant):

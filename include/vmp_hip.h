@@ -355,6 +355,21 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
                          int64_t c_ms, int64_t c_ns, double scale, void *workspace,
                          size_t workspace_bytes);
 
+/* Forward-backward recursion of `nchains` categorical Markov chains with K states and N
+ * transitions (N + 1 time instances): random.alpha_beta_recursion (utils/random.py:357-422),
+ * the moments of CategoricalMarkovChain (categorical_markov_chain.py:107-117).
+ *   logp0: K unnormalised log-probabilities of the first state per chain (chain stride
+ *          p0_bstride elements, 0 = shared);
+ *   logP:  N x K x K slices per chain, logP[n, i, j] = log p(z_{n+1} = j | z_n = i) + evidence
+ *          of instance n + 1, each slice contiguous (chain stride P_bstride, time stride
+ *          P_tstride elements; 0 = shared / time-invariant).
+ * Out: z0 (nchains x K) = q(z_0), zz (nchains x N x K x K) = q(z_n, z_{n+1}), g (nchains) = minus
+ * the log-normaliser.  workspace: nchains * N * K doubles.  K <= 64. */
+int32_t vmp_alpha_beta_recursion(vmp_ctx *ctx, int32_t N, int32_t K, int64_t nchains,
+                                 const double *logp0, int64_t p0_bstride, const double *logP,
+                                 int64_t P_bstride, int64_t P_tstride, double *z0, double *zz,
+                                 double *g, void *workspace, size_t workspace_bytes);
+
 /* Block-tridiagonal SPD solve = Kalman filter + RTS smoother of the Gaussian Markov chain
  * (linalg.block_banded_solve, utils/linalg.py:468-575, called by
  * gaussian_markov_chain.py:89-123).  A: nm x T x K x K diagonal blocks, B: nm x (T-1) x K x K

@@ -674,6 +674,70 @@ def plate_nodes_case(name):
                  ('tk_doc', 'tk_L', 'tk2_L', 'cc_L', 'cc2_L', 'gt_L', 'gt2_L'))
 
 
+def markov_chain_case(name):
+    """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
+    models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
+    doc/source/examples/hmm.rst are drawn here exactly as the document does (numpy seed 1)."""
+    import bayespy.nodes
+    from bayespy.nodes import CategoricalMarkovChain, Categorical, Mixture
+    from bayespy.inference import VB
+    from bayespy.utils import random as brandom
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tests'))
+    import models
+    out = {}
+    rs = np.random.RandomState(2024)
+    for tag, plates_p0, plates_P, N, K in (('ab_a', (), (), 7, 3), ('ab_b', (5,), (5,), 12, 8),
+                                          ('ab_c', (4, 1), (3,), 6, 20), ('ab_d', (2,), (), 5, 40),
+                                          ('ab_e', (3,), (3,), 1, 2), ('ab_f', (300,), (), 9, 5)):
+        logp0 = np.log(rs.dirichlet(np.ones(K), size=plates_p0)) + rs.normal(size=plates_p0 + (K,))
+        logP = np.log(rs.dirichlet(np.ones(K), size=plates_P + (N, K))) \
+            + 3 * rs.normal(size=plates_P + (N, 1, K))
+        if tag == 'ab_c':
+            logP[..., 2, :, 1] = -np.inf            # an impossible state at one instance
+        z0, zz, gg = brandom.alpha_beta_recursion(logp0, logP)
+        out.update({tag + '_logp0': logp0, tag + '_logP': logP, tag + '_z0': z0, tag + '_zz': zz,
+                    tag + '_g': gg})
+    # hmm.rst testsetup: numpy.random.seed(1)
+    np.random.seed(1)
+    Z = CategoricalMarkovChain([0.6, 0.4], [[0.7, 0.3], [0.4, 0.6]], states=100)
+    P = [[0.1, 0.4, 0.5], [0.6, 0.3, 0.1]]
+    Y = Mixture(Z, Categorical, P)
+    weather = Z.random()
+    activity = Mixture(weather, Categorical, P).random()
+    g = {'hmm1_activity': np.array(activity)}
+    mu = np.array([[0, 0], [3, 4], [6, 0]])
+    K, N, std = 3, 200, 2.0
+    p0 = np.ones(K) / K
+    q = 0.9
+    r = (1 - q) / (K - 1)
+    Pm = q * np.identity(K) + r * (np.ones((3, 3)) - np.identity(3))
+    y = np.zeros((N, 2))
+    state = np.random.choice(K, p=p0)
+    for n in range(N):
+        y[n, :] = std * np.random.randn(2) + mu[state]
+        state = np.random.choice(K, p=Pm[state])
+    g['hmm2_y'] = y
+    rs = np.random.RandomState(7)
+    B, T, K = 6, 15, 4
+    zt = rs.randint(K, size=(B, T))
+    g['hmm3_y'] = np.array([-6.0, -2.0, 2.0, 6.0])[zt] + rs.normal(size=(B, T))
+    g['hmm3_prior'] = 0.5 + rs.rand(T - 1, K, K)
+    g['hmm3_z0'] = rs.randint(K, size=(B, T))
+    g['hmm4_y'] = np.where(np.arange(30) // 10 % 2 == 0, -2.0, 2.0) + rs.normal(size=30)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = models.run_markov_chain_cases(bayespy.nodes, VB, g)
+    out.update({'in_' + k: v for k, v in g.items()})
+    for k, v in res.items():
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                out['%s_%d' % (k, i)] = np.array(vi)
+        else:
+            out[k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, out['hmm1_L'], out['hmm2_L'], out['hmm3_L'], out['hmm4_L'])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
@@ -697,6 +761,7 @@ def main():
     parameter_api_case('parameter_api')
     count_nodes_case('count_nodes')
     plate_nodes_case('plate_nodes')
+    markov_chain_case('markov_chains')
 
 
 if __name__ == '__main__':

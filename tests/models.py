@@ -451,3 +451,72 @@ def run_plate_node_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     Y.observe(g['gt2_y'])
     trace('gt2', vb_cls(Y, X, **vb_kwargs), 2, dict(X=X, G=G))
     return out
+
+
+def run_markov_chain_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Categorical Markov chains / hidden Markov models, the same statements on the reference
+    and on this framework: the two models of doc/source/examples/hmm.rst (known answers
+    "Iteration 1: loglike=-1.095883e+02" and "-9.963054e+02 ... Iteration 8: -9.235053e+02"),
+    a batch of chains with time-varying transition priors, and a chain used through Gate."""
+    N_ = nodes_mod
+    out = {}
+
+    def trace(tag, Q, n, track, tol=None):
+        Q.update(repeat=n, verbose=False, **({} if tol is None else dict(tol=tol)))
+        out[tag + '_L'] = np.array(Q.L[:Q.iter])
+        for nm, nd in track.items():
+            out['%s_%s_u' % (tag, nm)] = [np.array(v) for v in nd.get_moments()]
+
+    # 1. discrete HMM with known parameters (hmm.rst:35-94)
+    N = len(g['hmm1_activity'])
+    Z = N_.CategoricalMarkovChain([0.6, 0.4], [[0.7, 0.3], [0.4, 0.6]], states=N, name='Z')
+    P = [[0.1, 0.4, 0.5], [0.6, 0.3, 0.1]]
+    Y = N_.Mixture(Z, N_.Categorical, P, name='Y')
+    Y.observe(g['hmm1_activity'])
+    Q = vb_cls(Y, Z, **vb_kwargs)
+    trace('hmm1', Q, 1, dict(Z=Z))
+    out['hmm1_g'] = np.array(Z.g)
+
+    # 2. Gaussian HMM with unknown initial state and transition probabilities (hmm.rst:157-295)
+    y = g['hmm2_y']
+    K = 3
+    a0 = N_.Dirichlet(1e-3 * np.ones(K), name='a0')
+    A = N_.Dirichlet(1e-3 * np.ones((K, K)), name='A')
+    Z = N_.CategoricalMarkovChain(a0, A, states=len(y), name='Z')
+    mu = np.array([[0, 0], [3, 4], [6, 0]])
+    Lambda = 2.0 ** (-2) * np.identity(2)
+    Y = N_.Mixture(Z, N_.Gaussian, mu, Lambda, name='Y')
+    Y.observe(y)
+    Q = vb_cls(Y, Z, A, a0, **vb_kwargs)
+    trace('hmm2', Q, 1000, dict(Z=Z, A=A, a0=a0))
+
+    # 3. a batch of chains, transition prior varying in time, latent emission parameters
+    yb = g['hmm3_y']                                  # (B, T)
+    B, T = yb.shape
+    K = 4
+    a0 = N_.Dirichlet(np.ones(K), plates=(B,), name='a0')
+    A = N_.Dirichlet(g['hmm3_prior'], name='A')      # plates (T-1, K)
+    Z = N_.CategoricalMarkovChain(a0, A, name='Z')
+    out['hmm3_plates'] = np.array(Z.plates + (Z.dims[1][0],))
+    m = N_.GaussianARD(0, 1e-2, plates=(K,), name='m')
+    t = N_.Gamma(1e-1, 1e-1, plates=(K,), name='t')
+    Y = N_.Mixture(Z, N_.GaussianARD, m, t, name='Y')
+    Z.initialize_from_value(g['hmm3_z0'])
+    Y.observe(yb)
+    Q = vb_cls(Y, m, t, Z, A, a0, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    trace('hmm3', Q, 4, dict(Z=Z, A=A, a0=a0, m=m, t=t))
+
+    # 4. a chain that gates Gaussian means
+    yg = g['hmm4_y']
+    T = len(yg)
+    Z = N_.CategoricalMarkovChain([0.5, 0.5], [[0.9, 0.1], [0.2, 0.8]], states=T, name='Z')
+    X = N_.GaussianARD(0, 1e-1, plates=(2,), name='X')
+    Gt = N_.Gate(Z, X, name='G')
+    Y = N_.GaussianARD(Gt, 1.0, name='Y')
+    X.initialize_from_value(np.array([-1.0, 1.0]))
+    Y.observe(yg)
+    Q = vb_cls(Y, Z, X, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    trace('hmm4', Q, 3, dict(Z=Z, X=X))
+    return out

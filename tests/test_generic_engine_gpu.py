@@ -550,3 +550,42 @@ def test_take_and_put_kernels_are_exact_and_reproducible():
     got = misc.concatenate([DArray.from_host(p) for p in parts], axis=-2).numpy()
     ref = np.concatenate([np.broadcast_to(p, (2, p.shape[1], 4)) for p in parts], axis=-2)
     np.testing.assert_array_equal(got, ref)
+
+
+def test_alpha_beta_recursion_matches_reference(golden_dir):
+    """vmp_alpha_beta_recursion against random.alpha_beta_recursion of the reference
+    (utils/random.py:357-422): K = 3 ... 40 (all lane-group widths), broadcast plates, shared
+    transition slices, an impossible state (-inf), a single transition, 300 chains."""
+    from bayespy_amd.darray import DArray
+    from bayespy_amd.utils import random as drandom
+    f = np.load(os.path.join(golden_dir, 'markov_chains.npz'))
+    for tag in ('ab_a', 'ab_b', 'ab_c', 'ab_d', 'ab_e', 'ab_f'):
+        z0, zz, g = drandom.alpha_beta_recursion(DArray.from_host(f[tag + '_logp0']),
+                                                 DArray.from_host(f[tag + '_logP']))
+        np.testing.assert_allclose(g.numpy(), f[tag + '_g'], rtol=1e-11, atol=1e-11, err_msg=tag)
+        np.testing.assert_allclose(z0.numpy(), f[tag + '_z0'], rtol=1e-9, atol=1e-14, err_msg=tag)
+        np.testing.assert_allclose(zz.numpy(), f[tag + '_zz'], rtol=1e-9, atol=1e-14, err_msg=tag)
+        np.testing.assert_allclose(zz.numpy().sum(axis=(-1, -2)), 1.0, rtol=1e-13)
+
+
+def test_hidden_markov_models_match_reference(golden_dir):
+    """CategoricalMarkovChain: the two models of doc/source/examples/hmm.rst with their
+    doctest known answers, a batch of chains with time-varying transition priors and latent
+    emission parameters, and a chain that gates Gaussian means."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_markov_chain_cases
+    f = np.load(os.path.join(golden_dir, 'markov_chains.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_markov_chain_cases(N_, VB, g)
+    assert '%e' % res['hmm1_L'][0] == '-1.095883e+02'              # hmm.rst:94
+    assert '%e' % res['hmm2_L'][0] == '-9.963054e+02'              # hmm.rst:293
+    assert len(res['hmm2_L']) == 8 and '%e' % res['hmm2_L'][7] == '-9.235053e+02'   # hmm.rst:295
+    _compare_shared(res, f)
+    Z = N_.CategoricalMarkovChain([0.5, 0.5], [[0.9, 0.1], [0.2, 0.8]], states=4)
+    with pytest.raises(NotImplementedError):
+        Z.observe([0, 1, 1, 0])
+    with pytest.raises(ValueError, match='infer the length'):
+        N_.CategoricalMarkovChain([0.5, 0.5], [[0.9, 0.1], [0.2, 0.8]])
+    with pytest.raises(ValueError, match='different size'):
+        N_.CategoricalMarkovChain([0.5, 0.3, 0.2], [[0.9, 0.1], [0.2, 0.8]], states=3)
