@@ -73,6 +73,13 @@ __global__ __launch_bounds__(64) void alpha_beta_kernel(
         // ---- forward -------------------------------------------------------------------------
         double la = act ? logp0[cc * p0_bs + j] : -INFINITY;     // logalpha_n[j]
         double gsum = 0.0;
+        // the slices do not depend on the recursion: the column of the next instance is
+        // fetched while the current one is reduced (a step is otherwise one HBM latency long)
+        double pre[REG ? KP : 1];
+        if constexpr (REG) {
+#pragma unroll
+            for (int i = 0; i < KP; ++i) pre[i] = (act && i < K) ? P[i * K + j] : -INFINITY;
+        }
         for (int n = 0; n < N; ++n) {
             if (act && live) aw[(int64_t)n * K + j] = la;
             vec[j] = la;
@@ -81,9 +88,18 @@ __global__ __launch_bounds__(64) void alpha_beta_kernel(
             double col[REG ? KP : 1];
             double m = -INFINITY;
             if constexpr (REG) {
+                double cur[KP];
+#pragma unroll
+                for (int i = 0; i < KP; ++i) cur[i] = pre[i];
+                if (n + 1 < N) {
+                    const double *Pq = Pn + P_ts;
+#pragma unroll
+                    for (int i = 0; i < KP; ++i)
+                        pre[i] = (act && i < K) ? Pq[i * K + j] : -INFINITY;
+                }
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
-                    col[i] = (act && i < K) ? vec[i] + Pn[i * K + j] : -INFINITY;
+                    col[i] = (act && i < K) ? vec[i] + cur[i] : -INFINITY;
                     m = fmax(m, col[i]);
                 }
             } else {
@@ -106,19 +122,46 @@ __global__ __launch_bounds__(64) void alpha_beta_kernel(
             lds_fence();
         }
         if (live && j == 0) g[c] = gsum;
+        // the backward sweep reads logalpha values stored by OTHER lanes of this wavefront
+        __threadfence_block();
         // ---- backward: zz_n and logbeta_{n-1} from the same slice ----------------------------
         double lb = 0.0;                          // logbeta_n[j]
+        double prea[REG ? KP : 1];
+        if constexpr (REG) {
+            const double *Pl = P + (int64_t)(N - 1) * P_ts;
+            const double *al = aw + (int64_t)(N - 1) * K;
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                pre[i] = (act && i < K) ? Pl[i * K + j] : -INFINITY;
+                prea[i] = (act && i < K) ? al[i] : 0.0;
+            }
+        }
         for (int n = N - 1; n >= 0; --n) {
             const double *Pn = P + (int64_t)n * P_ts;
             const double *an = aw + (int64_t)n * K;
             double col[REG ? KP : 1], w[REG ? KP : 1];
             double mz = -INFINITY, mb = -INFINITY;
             if constexpr (REG) {
+                double cur[KP], cura[KP];
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    cur[i] = pre[i];
+                    cura[i] = prea[i];
+                }
+                if (n > 0) {
+                    const double *Pq = Pn - P_ts;
+                    const double *aq = an - K;
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) {
+                        pre[i] = (act && i < K) ? Pq[i * K + j] : -INFINITY;
+                        prea[i] = (act && i < K) ? aq[i] : 0.0;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     const bool ok = act && i < K;
-                    col[i] = ok ? lb + Pn[i * K + j] : -INFINITY;
-                    w[i] = ok ? an[i] + col[i] : -INFINITY;
+                    col[i] = ok ? lb + cur[i] : -INFINITY;
+                    w[i] = ok ? cura[i] + col[i] : -INFINITY;
                     mz = fmax(mz, w[i]);
                     mb = fmax(mb, col[i]);
                 }
