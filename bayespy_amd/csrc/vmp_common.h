@@ -63,6 +63,11 @@ static inline hipEvent_t *vmp_next_events(vmp_ctx *ctx)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
+// vmp_spd_mfma.hip: batched SPD inverse / Gaussian moments for 16 < n <= 32 on the matrix cores
+int32_t vmp_launch_spd_mfma(vmp_ctx *ctx, bool moments, int32_t n, int64_t batch, const double *A,
+                            const double *rhs, double *Ainv, double *vec_out, double *logdet,
+                            int32_t *info);
+
 // ---------------------------------------------------------------------------
 // Special functions (E17-E19 of SURVEY.md 2.2: scipy.special.digamma / gammaln
 // call sites gamma.py:145-147, dirichlet.py:150-158, utils/misc.py:1146-1151).

@@ -527,44 +527,27 @@ spd_batched_wave_kernel(int n, int64_t batch, const double *__restrict__ A,
     }
 }
 
-// Throughput form for 8 < n <= 32 and large batches: one matrix per group of NP lanes, lane i
-// holds row i in registers (NP doubles), so a wavefront inverts 64/NP matrices with no
-// workgroup barrier.  Each Gauss-Jordan step needs the pivot row in every lane of the group:
-// NP = 16 is exactly one DPP row, so the broadcast is v_mov_b64_dpp row_newbcast (pure VALU);
-// NP = 32 goes through a per-group LDS row.  Matrices are staged through LDS both ways so the
-// global accesses stay fully coalesced.
-template <int NP, int P>
-__device__ __forceinline__ double group_bcast(double x, double *rowbuf, int j, int gl)
+// Throughput form for 8 < n <= 16 and large batches: one matrix per group of NP = 16 lanes
+// (exactly one DPP row), lane i holds row i in registers, so a wavefront inverts four matrices
+// with no workgroup barrier.  Each Gauss-Jordan step needs the pivot row in every lane of the
+// group: v_mov_b64_dpp row_newbcast (pure VALU, the control is an immediate -> static
+// unrolling).  Matrices are staged through LDS both ways so the global accesses stay fully
+// coalesced.  (16 < n <= 32 runs on the matrix cores: vmp_spd_mfma.hip.)
+template <int P>
+__device__ __forceinline__ double group_bcast(double x)
 {
-    if constexpr (NP == 16) {
-        return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + P, 0xf, 0xf, false);
-    } else {
-        if (gl == P) rowbuf[j] = x;
-        lds_fence();
-        return rowbuf[j];
-    }
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + P, 0xf, 0xf, false);
 }
 
 template <int NP, int P>
-__device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double *rowbuf, double &prod,
-                                              double &ld, int &bad)
+__device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double &prod, double &ld,
+                                              int &bad)
 {
+    static_assert(NP == 16, "one DPP row per matrix");
     if constexpr (P < NP) {
         double row[NP];
-        if constexpr (NP == 16) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) row[j] = group_bcast<NP, P>(m[j], rowbuf, j, gl);
-        } else {
-            // the pivot lane publishes its whole row once, everybody reads it back
-            if (gl == P) {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) rowbuf[j] = m[j];
-            }
-            lds_fence();
-#pragma unroll
-            for (int j = 0; j < NP; ++j) row[j] = rowbuf[j];
-            lds_fence();
-        }
+        for (int j = 0; j < NP; ++j) row[j] = group_bcast<P>(m[j]);
         const double piv = row[P];
         if (!(piv > 0.0)) bad = 1;
         logdet_accumulate(piv, prod, ld);
@@ -577,87 +560,36 @@ __device__ __forceinline__ void gj_rows_steps(double (&m)[NP], int gl, double *r
             const double base = (gl == P) ? 0.0 : m[j];
             m[j] = (j == P) ? ((gl == P) ? d : f) : base + (f + sc) * row[j];
         }
-        gj_rows_steps<NP, P + 1>(m, gl, rowbuf, prod, ld, bad);
+        gj_rows_steps<NP, P + 1>(m, gl, prod, ld, bad);
     }
 }
 
-// x_i = sum_P m[P] * v_P and friends: every lane of the group needs the value held by
-// lane P, for all P.  NP = 16: DPP broadcasts (static unrolling: the control is an
-// immediate); otherwise the group exchanges the vector through its LDS row.
+// x_i = sum_P m[P] * v_P and friends: every lane of the group needs the value held by lane P,
+// for all P.
 template <int NP, int P>
-__device__ __forceinline__ void rows_dpp_matvec(const double (&m)[NP], double v, double &acc)
+__device__ __forceinline__ void rows_matvec(const double (&m)[NP], double v, double &acc)
 {
     if constexpr (P < NP) {
-        acc += m[P] * group_bcast<NP, P>(v, nullptr, 0, 0);
-        rows_dpp_matvec<NP, P + 1>(m, v, acc);
-    }
-}
-
-template <int NP, int P>
-__device__ __forceinline__ void rows_dpp_rank1(double (&m)[NP], double xi)
-{
-    if constexpr (P < NP) {
-        m[P] += xi * group_bcast<NP, P>(xi, nullptr, 0, 0);
-        rows_dpp_rank1<NP, P + 1>(m, xi);
+        acc += m[P] * group_bcast<P>(v);
+        rows_matvec<NP, P + 1>(m, v, acc);
     }
 }
 
 template <int NP, int P>
-__device__ __forceinline__ void rows_dpp_sum(double v, double &acc)
+__device__ __forceinline__ void rows_rank1(double (&m)[NP], double xi)
 {
     if constexpr (P < NP) {
-        acc += group_bcast<NP, P>(v, nullptr, 0, 0);
-        rows_dpp_sum<NP, P + 1>(v, acc);
+        m[P] += xi * group_bcast<P>(xi);
+        rows_rank1<NP, P + 1>(m, xi);
     }
 }
 
-template <int NP>
-__device__ __forceinline__ void rows_exchange(double v, double *rowbuf, int gl, double (&all)[NP])
+template <int NP, int P>
+__device__ __forceinline__ void rows_sum(double v, double &acc)
 {
-    rowbuf[gl] = v;
-    lds_fence();
-#pragma unroll
-    for (int j = 0; j < NP; ++j) all[j] = rowbuf[j];
-    lds_fence();
-}
-
-template <int NP>
-__device__ __forceinline__ void rows_matvec(const double (&m)[NP], double v, double *rowbuf, int gl,
-                                            double &acc)
-{
-    if constexpr (NP == 16) {
-        rows_dpp_matvec<NP, 0>(m, v, acc);
-    } else {
-        double all[NP];
-        rows_exchange<NP>(v, rowbuf, gl, all);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) acc += m[j] * all[j];
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void rows_rank1(double (&m)[NP], double xi, double *rowbuf, int gl)
-{
-    if constexpr (NP == 16) {
-        rows_dpp_rank1<NP, 0>(m, xi);
-    } else {
-        double all[NP];
-        rows_exchange<NP>(xi, rowbuf, gl, all);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) m[j] += xi * all[j];
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void rows_sum(double v, double *rowbuf, int gl, double &acc)
-{
-    if constexpr (NP == 16) {
-        rows_dpp_sum<NP, 0>(v, acc);
-    } else {
-        double all[NP];
-        rows_exchange<NP>(v, rowbuf, gl, all);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) acc += all[j];
+    if constexpr (P < NP) {
+        acc += group_bcast<P>(v);
+        rows_sum<NP, P + 1>(v, acc);
     }
 }
 
@@ -678,7 +610,6 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
     constexpr int MPB = MPW * (NTB / 64);     // matrices per workgroup
     constexpr int LDP = NP + 1;
     __shared__ double Ms[MPB * NP * LDP];
-    __shared__ double rows[(NTB / 64) * MPW * NP];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int g = l / NP, gl = l % NP;
     const int nn = n * n;
@@ -694,7 +625,6 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
         const int mb = w * MPW + g;
         const bool act = mb < nb;
         double *M = Ms + mb * NP * LDP;
-        double *rowbuf = rows + (w * MPW + g) * NP;
         constexpr double SC = MOMENTS ? -1.0 : 0.5;      // -2 phi1, symmetrised / symmetrise
         double m[NP];
 #pragma unroll
@@ -703,15 +633,15 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
                                             : ((gl == j) ? 1.0 : 0.0);
         double ld = 0.0, prod = 1.0;
         int bad = 0;
-        gj_rows_steps<NP, 0>(m, gl, rowbuf, prod, ld, bad);
+        gj_rows_steps<NP, 0>(m, gl, prod, ld, bad);
         double lg = logdet_finish(prod, ld);
         if constexpr (MOMENTS) {
             const double p0 = (act && gl < n) ? rhs[(b0 + mb) * n + gl] : 0.0;
             double x = 0.0;
-            rows_matvec<NP>(m, p0, rowbuf, gl, x);
+            rows_matvec<NP, 0>(m, p0, x);
             double s = 0.0;
-            rows_sum<NP>(x * p0, rowbuf, gl, s);
-            rows_rank1<NP>(m, x, rowbuf, gl);
+            rows_sum<NP, 0>(x * p0, s);
+            rows_rank1<NP, 0>(m, x);
             if (act && gl < n) vec_out[(b0 + mb) * n + gl] = x;
             lg = -0.5 * s + 0.5 * lg;
         }
@@ -1020,9 +950,7 @@ int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A,
                            dim3((unsigned)grid_for(ctx, batch, 16)), dim3(256), 0, ctx->stream, n,
                            batch, A, nullptr, Ainv, nullptr, logdet, info);
     else if (n > 16 && n <= 32 && batch >= big)
-        hipLaunchKernelGGL((spd_batched_rows_kernel<32, 128, false>),
-                           dim3((unsigned)grid_for(ctx, batch, 4)), dim3(128), 0, ctx->stream, n,
-                           batch, A, nullptr, Ainv, nullptr, logdet, info);
+        return vmp_launch_spd_mfma(ctx, false, n, batch, A, nullptr, Ainv, nullptr, logdet, info);
     else if (n <= 8)
         hipLaunchKernelGGL(spd_batched_wave_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(NT), 0,
                            ctx->stream, n, batch, A, Ainv, logdet, info);
@@ -1046,9 +974,7 @@ int32_t vmp_gaussian_moments(vmp_ctx *ctx, int32_t n, int64_t batch, const doubl
                            dim3((unsigned)grid_for(ctx, batch, 16)), dim3(256), 0, ctx->stream, n,
                            batch, phi1, phi0, u1, u0, g, info);
     else
-        hipLaunchKernelGGL((spd_batched_rows_kernel<32, 128, true>),
-                           dim3((unsigned)grid_for(ctx, batch, 4)), dim3(128), 0, ctx->stream, n,
-                           batch, phi1, phi0, u1, u0, g, info);
+        return vmp_launch_spd_mfma(ctx, true, n, batch, phi1, phi0, u1, u0, g, info);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
