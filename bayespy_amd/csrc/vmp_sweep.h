@@ -1,0 +1,123 @@
+// vmp_sweep.h -- a 32 x 32 symmetric positive definite matrix held by ONE wavefront as 2 x 2
+// accumulator tiles of v_mfma_f64_16x16x4_f64 and inverted in registers by the symmetric sweep
+// operator with 4 x 4 pivot blocks (see vmp_spd_mfma.hip for the derivation).  Element
+// (16 tr + (l>>4) + 4 r, 16 tc + (l&15)) of the matrix is register r of tile (tr, tc) in lane l.
+#pragma once
+#include "vmp_common.h"
+
+namespace vmp_sweep {
+
+__device__ inline v4f64 mfma(double a, double b, v4f64 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ inline double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) to fp64 round-off: hardware estimate + two Newton steps
+__device__ inline double fast_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    return r;
+}
+
+// log-determinant from the running (mantissa, exponent) pair of sweep_block
+__device__ inline double sweep_logdet(double prod, double ld)
+{
+    return log(prod) + ld * 0.69314718055994530942;
+}
+
+// One sweep over pivot block P (rows / columns 4P .. 4P+3).
+template <int P>
+__device__ __forceinline__ void sweep_block(v4f64 (&T)[2][2], int l15, int l4, double &prod,
+                                            double &ld, int &bad)
+{
+    constexpr int TP = P / 4, RR = P % 4, C0 = 4 * (P % 4);
+    // ---- the 4 x 4 pivot block, uniform in all lanes ----------------------------------------
+    const double pan = T[TP][TP][RR];
+    double d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) d[a][b] = readlane_f64(pan, a * 16 + C0 + b);
+    // Cholesky D = L L^T (lower), reciprocal pivots
+    const double p0 = d[0][0];
+    const double i0 = fast_rsqrt(p0);
+    const double l10 = d[0][1] * i0, l20 = d[0][2] * i0, l30 = d[0][3] * i0;
+    const double p1 = d[1][1] - l10 * l10;
+    const double i1 = fast_rsqrt(p1);
+    const double l21 = (d[1][2] - l20 * l10) * i1, l31 = (d[1][3] - l30 * l10) * i1;
+    const double p2 = d[2][2] - l20 * l20 - l21 * l21;
+    const double i2 = fast_rsqrt(p2);
+    const double l32 = (d[2][3] - l30 * l20 - l31 * l21) * i2;
+    const double p3 = d[3][3] - l30 * l30 - l31 * l31 - l32 * l32;
+    const double i3 = fast_rsqrt(p3);
+    if (!(p0 > 0.0 && p1 > 0.0 && p2 > 0.0 && p3 > 0.0)) bad = 1;
+    // running determinant as mantissa x 2^exponent (`ld` counts the exponent): no logarithm on
+    // the serial path, one at the very end (sweep_logdet)
+    const double q0 = prod * (p0 * p1);
+    ld += (double)__builtin_amdgcn_frexp_exp(q0);
+    const double q1 = __builtin_amdgcn_frexp_mant(q0) * (p2 * p3);
+    ld += (double)__builtin_amdgcn_frexp_exp(q1);
+    prod = __builtin_amdgcn_frexp_mant(q1);
+    // column c = l15 & 3 of D^-1: L y = e_c, L^T x = y
+    const int c = l15 & 3;
+    const double e0 = (c == 0) ? 1.0 : 0.0, e1 = (c == 1) ? 1.0 : 0.0;
+    const double e2 = (c == 2) ? 1.0 : 0.0, e3 = (c == 3) ? 1.0 : 0.0;
+    const double y0 = e0 * i0;
+    const double y1 = (e1 - l10 * y0) * i1;
+    const double y2 = (e2 - l20 * y0 - l21 * y1) * i2;
+    const double y3 = (e3 - l30 * y0 - l31 * y1 - l32 * y2) * i3;
+    const double x3 = y3 * i3;
+    const double x2 = (y2 - l32 * x3) * i2;
+    const double x1 = (y1 - l21 * x2 - l31 * x3) * i1;
+    const double x0 = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * i0;
+    // this lane's entry D^-1[l4][c]
+    const double val = (l4 == 0) ? x0 : (l4 == 1) ? x1 : (l4 == 2) ? x2 : x3;
+    const bool incol = (l15 >= C0) && (l15 < C0 + 4);
+    const double aop = (l15 < 4) ? val : 0.0;           // A[i][k] = D^-1[i][k], rows i < 4
+    const double bop = incol ? val : 0.0;               // B[k][j] = D^-1[k][j - C0] on the block columns
+    // ---- panels --------------------------------------------------------------------------------
+    const double R0 = T[TP][0][RR], R1 = T[TP][1][RR];  // row panel = column panel transposed
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    const double Pv0 = mfma(aop, R0, zero)[0];          // P = D^-1 R, rows k = l4 in register 0
+    const double Pv1 = mfma(aop, R1, zero)[0];
+    // ---- rank-4 update of all four tiles; in tile column TP the block columns receive
+    //      P^T = R^T D^-1 instead (old values dropped, operand D^-1 in place of -P) --------------
+    const double B0 = (TP == 0 && incol) ? bop : -Pv0;
+    const double B1 = (TP == 1 && incol) ? bop : -Pv1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T[0][TP][r] = incol ? 0.0 : T[0][TP][r];
+        T[1][TP][r] = incol ? 0.0 : T[1][TP][r];
+    }
+    T[0][0] = mfma(R0, B0, T[0][0]);
+    T[0][1] = mfma(R0, B1, T[0][1]);
+    T[1][0] = mfma(R1, B0, T[1][0]);
+    T[1][1] = mfma(R1, B1, T[1][1]);
+    // ---- the swept rows and the pivot block ------------------------------------------------------
+    T[TP][0][RR] = (TP == 0 && incol) ? -val : Pv0;
+    T[TP][1][RR] = (TP == 1 && incol) ? -val : Pv1;
+}
+
+// Sweep the first `nblocks` pivot blocks (rows / columns beyond 4 nblocks hold the identity and
+// are left alone: sweeping them is a no-op).  Afterwards T = -A^-1 on the swept part.
+template <int P>
+__device__ __forceinline__ void sweep_upto(v4f64 (&T)[2][2], int nblocks, int l15, int l4,
+                                           double &prod, double &ld, int &bad)
+{
+    if constexpr (P < 8) {
+        if (P < nblocks) sweep_block<P>(T, l15, l4, prod, ld, bad);
+        sweep_upto<P + 1>(T, nblocks, l15, l4, prod, ld, bad);
+    }
+}
+
+}  // namespace vmp_sweep
