@@ -13,7 +13,7 @@ from ...nodes.beta import Beta, Complement
 from ...nodes.binomial import Binomial
 from ...nodes.poisson import Poisson
 from ...nodes.add import Add
-from ...nodes.take import Take, Concatenate, Gate
+from ...nodes.take import Take, Concatenate, Gate, Slice
 from ...nodes.categorical_markov_chain import (CategoricalMarkovChain,
                                                 CategoricalMarkovChainToCategorical)
 from ...utils import misc, linalg
@@ -506,7 +506,121 @@ class ChainToCategoricalFamily:
         return [m0, m1]
 
 
+class SliceFamily:
+    """Slice (node.py:868-1130): moments are strided views of the parent's moments; a message
+    goes back into a zero array of the parent's plates, one accumulating put per indexed axis
+    (no duplicates: every target element has at most one source)."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.parent = node.parents[0]
+        self.ndims = [len(d) for d in node.dims]
+        self.P = len(self.parent.plates)
+        # per parent plate axis: ('int', s) | ('slice', slice, IndexMap or None)
+        self.axes = []
+        j = 0
+        for sl in node.slices:
+            if sl is None:
+                continue
+            L = self.parent.plates[j]
+            if isinstance(sl, int):
+                self.axes.append(('int', sl, misc.IndexMap([sl], L)))
+            else:
+                rng = range(sl.start, sl.stop, sl.step)
+                full = (len(rng) == L and sl.step == 1)
+                self.axes.append(('slice', sl, None if full else misc.IndexMap(list(rng), L)))
+            j += 1
+
+    def plates_to_parent(self, index):
+        return self.parent.plates
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask, dtype=bool)
+        full = np.broadcast_to(mask, self.node.plates)
+        out = np.zeros(self.parent.plates, dtype=bool)
+        child_idx, parent_idx = [], []
+        for sl in self.node.slices:
+            if sl is None:
+                child_idx.append(0)
+            elif isinstance(sl, int):
+                parent_idx.append(sl)
+            else:
+                child_idx.append(slice(None))
+                parent_idx.append(sl)
+        out[tuple(parent_idx)] = full[tuple(child_idx)]
+        return out
+
+    def moments(self, ups):
+        out = []
+        for x, nd in zip(ups[0], self.ndims):
+            x = _arr(x)
+            npl = x.ndim - nd
+            if npl < self.P:
+                x = x.reshape((1,) * (self.P - npl) + x.shape)
+            idx = []
+            j = 0
+            for sl in self.node.slices:
+                if sl is None:
+                    idx.append(None)
+                    continue
+                kind, s_, imap = self.axes[j]
+                bc = x.shape[j] == 1 and self.parent.plates[j] != 1      # broadcast axis
+                if kind == 'int':
+                    idx.append(0 if bc else s_)
+                elif bc or imap is None:
+                    idx.append(slice(None))
+                elif s_.step > 0:
+                    idx.append(s_)
+                else:
+                    # a reversed slice is not a strided view of a device tensor: gather it
+                    x = misc.take(x, imap, axis=j - x.ndim)
+                    idx.append(slice(None))
+                j += 1
+            out.append(x[tuple(idx) + (Ellipsis,)])
+        return out
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        out = []
+        C = len(self.node.plates)
+        for m, nd in zip(m_child, self.ndims):
+            if m is None:
+                out.append(None)
+                continue
+            m = _arr(_masked(m, mask, nd))
+            npl = m.ndim - nd
+            if npl < C:
+                m = m.reshape((1,) * (C - npl) + m.shape)
+            # rearrange the plate axes of the node into the parent's: drop new axes, give
+            # integer-indexed parent axes a unit axis
+            shape, ci = [], 0
+            for sl in self.node.slices:
+                if sl is None:
+                    ci += 1
+                elif isinstance(sl, int):
+                    shape.append(1)
+                else:
+                    shape.append(m.shape[ci])
+                    ci += 1
+            m = m.reshape(tuple(shape) + m.shape[C:])
+            for j in range(self.P - 1, -1, -1):
+                kind, s_, imap = self.axes[j]
+                if imap is None:
+                    continue
+                ax = j - self.P - nd
+                if kind == 'slice' and m.shape[j] == 1 and imap.n > 1:
+                    sh = list(m.shape)
+                    sh[j] = imap.n
+                    m = m.broadcast_to(tuple(sh))
+                m = misc.put_simple(m, imap, axis=ax)
+            out.append(m)
+        return out
+
+
 def make_extra_family(node):
+    if isinstance(node, Slice):
+        return SliceFamily(node)
     if isinstance(node, CategoricalMarkovChain):
         return CategoricalMarkovChainFamily(node)
     if isinstance(node, CategoricalMarkovChainToCategorical):

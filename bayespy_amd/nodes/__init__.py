@@ -14,7 +14,7 @@ from .beta import Beta
 from .binomial import Binomial, Bernoulli
 from .poisson import Poisson
 from .add import Add
-from .take import Take, Concatenate, Gate
+from .take import Take, Concatenate, Gate, Choose
 from .mixture import Mixture
 from .gaussian_markov_chain import GaussianMarkovChain
 from .categorical_markov_chain import CategoricalMarkovChain
@@ -22,4 +22,4 @@ from .categorical_markov_chain import CategoricalMarkovChain
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
            'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add',
-           'Take', 'Concatenate', 'Gate', 'CategoricalMarkovChain']
+           'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain']

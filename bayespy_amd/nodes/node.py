@@ -98,6 +98,11 @@ class Node:
     def get_shape(self, i):
         return self.plates + self.dims[i]
 
+    def __getitem__(self, index):
+        """Basic indexing of the plates (node.py:761-763)."""
+        from .take import Slice
+        return Slice(self, index, name=self.name + '.__getitem__')
+
     def __repr__(self):
         return '<%s %r plates=%s>' % (type(self).__name__, self.name, self.plates)
 

@@ -9,7 +9,10 @@ only the plates differ:
   several axes creates several plate axes);
 * ``Concatenate(*nodes, axis=-1)`` -- ``np.concatenate`` along a plate axis;
 * ``Gate(Z, X, gated_plate=-1)`` -- the plate axis ``gated_plate`` of ``X`` is averaged with the
-  class probabilities of the categorical ``Z``.
+  class probabilities of the categorical ``Z``;
+* ``Slice(X, index)`` = ``X[index]`` -- basic indexing of the plates with integers, slices,
+  ``None`` and ``...`` (node.py:761-763, :868-1130);
+* ``Choose(z, *nodes)`` -- ``Gate`` over the concatenation of the nodes (gate.py:207-250).
 """
 import numpy as np
 
@@ -120,3 +123,70 @@ class Gate(Node):
         for attr in ('shape', 'ndim'):
             if hasattr(X, attr):
                 setattr(self, attr, getattr(X, attr))
+
+
+def _slicelen(s):
+    return len(range(s.start, s.stop, s.step))
+
+
+class Slice(Node):
+    """Basic slicing of the plates: ``X[2:5]``, ``X[..., 0]``, ``X[:, None]`` ..."""
+
+    def __init__(self, X, slices, name=None):
+        if not isinstance(X, Node) or isinstance(X, Constant):
+            raise ValueError("Slice needs a node")
+        slices = list(slices) if isinstance(slices, tuple) else [slices]
+        num_axis, ellipsis_index = 0, None
+        for k, sl in enumerate(slices):
+            if isinstance(sl, (int, np.integer)) or isinstance(sl, slice):
+                num_axis += 1
+            elif sl is None:
+                pass
+            elif sl is Ellipsis:
+                if ellipsis_index is None:
+                    ellipsis_index = k
+                else:                                  # later ellipses stand for ":"
+                    num_axis += 1
+                    slices[k] = slice(None)
+            else:
+                raise TypeError("Invalid argument type: {0}".format(sl.__class__))
+        if num_axis > len(X.plates):
+            raise IndexError("Too many indices")
+        expand = [slice(None)] * (len(X.plates) - num_axis)
+        if ellipsis_index is not None:
+            slices = slices[:ellipsis_index] + expand + slices[ellipsis_index + 1:]
+        else:
+            slices = slices + expand
+        j = 0
+        plates = []
+        for k, sl in enumerate(slices):
+            if isinstance(sl, (int, np.integer)):
+                sl = int(sl)
+                if sl < 0:
+                    sl += X.plates[j]
+                if sl < 0 or sl >= X.plates[j]:
+                    raise IndexError("Index out of range")
+                slices[k] = sl
+                j += 1
+            elif isinstance(sl, slice):
+                sl = slice(*sl.indices(X.plates[j]))
+                if _slicelen(sl) <= 0:
+                    raise IndexError("Slicing leads to empty plates")
+                slices[k] = sl
+                plates.append(_slicelen(sl))
+                j += 1
+            else:
+                plates.append(1)
+        super().__init__(X, plates=tuple(plates), dims=X.dims, name=name)
+        self.slices = slices
+        self._gaussian_like = _kind_of(X)
+        for attr in ('shape', 'ndim'):
+            if hasattr(X, attr):
+                setattr(self, attr, getattr(X, attr))
+
+
+def Choose(z, *nodes):
+    """Choose plate elements from ``nodes`` by the categorical variable ``z``: a gate over the
+    concatenation of the nodes along a new last plate axis (gate.py:207-250)."""
+    combined = Concatenate(*[n[..., None] for n in nodes])
+    return Gate(z, combined)

@@ -674,6 +674,11 @@ def plate_nodes_case(name):
                  ('tk_doc', 'tk_L', 'tk2_L', 'cc_L', 'cc2_L', 'gt_L', 'gt2_L'))
 
 
+def slice_nodes_case(name):
+    """Plate indexing X[...] and Choose."""
+    _shared_case(name, 'make_slice_inputs', 'run_slice_cases', 2718, ('sl_plates', 'sl_L', 'ch_doc', 'ch_L'))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -762,6 +767,7 @@ def main():
     count_nodes_case('count_nodes')
     plate_nodes_case('plate_nodes')
     markov_chain_case('markov_chains')
+    slice_nodes_case('slice_nodes')
 
 
 if __name__ == '__main__':

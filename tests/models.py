@@ -520,3 +520,54 @@ def run_markov_chain_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     Q.ignore_bound_checks = True
     trace('hmm4', Q, 3, dict(Z=Z, X=X))
     return out
+
+
+def make_slice_inputs(rs):
+    """Seeded inputs of run_slice_cases (tests/golden/slice_nodes.npz)."""
+    return dict(sl_y1=rs.normal(size=(2, 3, 2)), sl_y2=rs.normal(size=(4, 2)),
+                sl_y3=rs.normal(size=(4, 3, 3, 2)), sl_mask3=rs.rand(4, 3, 3) < 0.8,
+                sl_y4=rs.normal(size=(5,)),
+                ch_y=np.array([0.5, 9.0, 21.0, 19.0, -1.0, 11.0]) + 0.3 * rs.normal(size=6))
+
+
+def run_slice_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Plate indexing ``X[...]`` (node.py:761-763, :868-1130) and ``Choose`` (gate.py:207-250;
+    its doctest gives [0, 0, 20, 10]), the same statements on both sides."""
+    N_ = nodes_mod
+    out = {}
+    X = N_.GaussianARD(0, 1e-1, shape=(2,), plates=(4, 5), name='X')
+    a, b, c = X[1:3, ::2], X[..., 0], X[:, None, 1:4]
+    out['sl_plates'] = np.array(a.plates + b.plates + c.plates)
+    tau = N_.Gamma(1e-1, 1e-1, name='tau')
+    Y1 = N_.GaussianARD(a, tau, name='Y1')
+    Y2 = N_.GaussianARD(b, 1.0, shape=(2,), name='Y2')
+    Y3 = N_.GaussianARD(c, 2.0, shape=(2,), plates=(4, 3, 3), name='Y3')
+    Y1.observe(g['sl_y1'])
+    Y2.observe(g['sl_y2'])
+    Y3.observe(g['sl_y3'], mask=g['sl_mask3'])
+    t = N_.Gamma([1.0, 2.0, 3.0, 4.0, 5.0], 1.0, name='t')
+    Y4 = N_.GaussianARD(0, t[-2], plates=(5,), name='Y4')          # an integer index
+    Y4.observe(g['sl_y4'])
+    Q = vb_cls(Y1, Y2, Y3, Y4, X, tau, t, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=3, verbose=False)
+    out['sl_L'] = np.array(Q.L[:3])
+    for nm, nd in dict(X=X, tau=tau, t=t, a=a, c=c).items():
+        out['sl_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
+
+    x0 = N_.GaussianARD(0, 1, name='x0')
+    x1 = N_.GaussianARD(10, 1, name='x1')
+    x2 = N_.GaussianARD(20, 1, name='x2')
+    x = N_.Choose([0, 0, 2, 1], x0, x1, x2)
+    out['ch_doc'] = np.array(x.get_moments()[0])
+    Z = N_.Categorical([0.3, 0.3, 0.4], plates=(6,), name='Z')
+    xz = N_.Choose(Z, x0, x1, x2)
+    Y = N_.GaussianARD(xz, 1.0, name='Y')
+    Y.observe(g['ch_y'])
+    Q = vb_cls(Y, Z, x0, x1, x2, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=3, verbose=False)
+    out['ch_L'] = np.array(Q.L[:3])
+    for nm, nd in dict(Z=Z, x0=x0, x1=x1, x2=x2).items():
+        out['ch_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
+    return out

@@ -589,3 +589,32 @@ def test_hidden_markov_models_match_reference(golden_dir):
         N_.CategoricalMarkovChain([0.5, 0.5], [[0.9, 0.1], [0.2, 0.8]])
     with pytest.raises(ValueError, match='different size'):
         N_.CategoricalMarkovChain([0.5, 0.3, 0.2], [[0.9, 0.1], [0.2, 0.8]], states=3)
+
+
+def test_plate_indexing_and_choose_match_reference(golden_dir):
+    """``X[1:3, ::2]``, ``X[..., 0]``, ``X[:, None, 1:4]``, ``t[-2]`` as parents of observed
+    nodes (node.py:868-1130) and ``Choose`` with fixed labels (doctest of gate.py:215-225) and
+    with a latent categorical (tests/models.py run_slice_cases on both sides)."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_slice_cases
+    f = np.load(os.path.join(golden_dir, 'slice_nodes.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_slice_cases(N_, VB, g)
+    np.testing.assert_array_equal(res['ch_doc'], [0., 0., 20., 10.])
+    _compare_shared(res, f)
+    X = N_.GaussianARD(0, 1, plates=(4, 5))
+    with pytest.raises(IndexError, match='Too many indices'):
+        X[0, 0, 0]
+    with pytest.raises(IndexError, match='out of range'):
+        X[4]
+    with pytest.raises(IndexError, match='empty'):
+        X[2:2]
+    with pytest.raises(TypeError):
+        X[[0, 1]]
+    # a reversed slice (gathered on the device) against NumPy indexing of the moments
+    r = X[::-1, 1::2]
+    Q = VB(r, X)
+    u = np.asarray(X.get_moments()[0])
+    np.testing.assert_array_equal(np.broadcast_to(r.get_moments()[0], (4, 2)),
+                                  np.broadcast_to(u, (4, 5))[::-1, 1::2])
