@@ -18,7 +18,9 @@ from ...nodes.categorical_markov_chain import (CategoricalMarkovChain,
                                                 CategoricalMarkovChainToCategorical)
 from ...utils import misc, linalg
 from ...utils import random as drandom
-from .generic import Family, DirichletFamily, _arr, _trail, _const, _check_device
+from .generic import (Family, DirichletFamily, GaussianMarkovChainFamily, _arr, _trail, _const,
+                      _check_device)
+from ...nodes.gaussian_markov_chain import SwitchingGaussianMarkovChain
 
 
 def _flip2(x):
@@ -618,7 +620,126 @@ class SliceFamily:
         return out
 
 
+class SwitchingGaussianMarkovChainFamily(GaussianMarkovChainFamily):
+    """gaussian_markov_chain.py:1454-1741: the dynamics of transition n are
+    sum_k <z_nk> B_k.  The smoother, the fixed moments and the messages to mu / Lambda are those
+    of the plain chain; every einsum of the reference is one ``sum_multiply`` launch here."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.K = node.K
+
+    def plates_to_parent(self, index):
+        p = self.node.plates
+        if index < 2:
+            return p
+        if index == 2:
+            return p + (self.K, self.D)
+        if index == 3:
+            return p + (self.N - 1,)
+        return p + (self.N - 1, self.D)
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask)
+        if index < 2:
+            return mask
+        return mask[..., None] if index == 3 else mask[..., None, None]
+
+    def constant_moments(self, index, value):
+        if index == 3:
+            return [misc.onehot(np.asarray(value).astype(np.int64), self.K)]
+        if index == 4:
+            return super().constant_moments(3, value)
+        return super().constant_moments(index, value)
+
+    def _v(self, up, i):
+        """Innovation precision moment i as (..., D): a unit time axis is dropped."""
+        v = _arr(up[4][i])
+        par = self.node.parents[4]
+        npl = par.value.ndim if isinstance(par, Constant) else len(par.plates)
+        if npl >= 2 and v.ndim >= 2:
+            v = v[..., 0, :]
+        return v
+
+    def _vBB(self, up):
+        """sum_d v_d <b_kd b_kd^T>  (..., K, D, D)."""
+        D = self.D
+        v = self._v(up, 0)
+        return misc.sum_multiply(v.reshape(v.shape[:-1] + (1, D, 1, 1)), _arr(up[2][1]), axis=-3)
+
+    def phi_from_parents(self, up):
+        D, N = self.D, self.N
+        m, Lam = up[0][0], up[1][0]
+        Bm, Z = _arr(up[2][0]), _arr(up[3][0])
+        v = self._v(up, 0)
+        Lm = linalg.mvdot(Lam, m)
+        phi0 = fuse(lambda e, q: e * q, self._e0v, _arr(Lm).reshape(_arr(Lm).shape[:-1] + (1, D)))
+        # sum_k z_nk sum_d v_d <b_kd b_kd^T> for the N-1 transitions, zero for the last instance
+        vBB = self._vBB(up)
+        dyn = misc.sum_multiply(Z.reshape(Z.shape + (1, 1)),
+                                vBB.reshape(vBB.shape[:-3] + (1,) + vBB.shape[-3:]), axis=-3)
+        dyn = misc.concatenate([dyn, DArray.zeros((1, D, D))], axis=-3)
+        dv = misc.diag(v.reshape(v.shape[:-1] + (1, D)), ndim=1)            # (..., 1, D, D)
+        L = _arr(Lam)
+        L = L.reshape(L.shape[:-2] + (1,) + L.shape[-2:])
+        phi1 = fuse(lambda a, b, l, d, q: -0.5 * (a * l + b * d + q), self._e0, self._en0, L, dv,
+                    dyn)
+        # phi2[n, i, j] = sum_k z_nk B_k[j, i] v_j
+        Bt = Bm.swapaxes(-1, -2)
+        phi2 = misc.sum_multiply(Z.reshape(Z.shape + (1, 1)),
+                                 Bt.reshape(Bt.shape[:-3] + (1,) + Bt.shape[-3:]),
+                                 v.reshape(v.shape[:-1] + (1, 1, 1, D)), axis=-3)
+        return [phi0, phi1, phi2]
+
+    def cgf_from_parents(self, up):
+        mm = up[0][1]
+        Lam, logdet = up[1]
+        s = misc.sum_multiply(self._v(up, 1), axis=-1)
+        return fuse(lambda t, ld, ln: -0.5 * t + 0.5 * ld + 0.5 * (self.N - 1) * ln,
+                    misc.sum_multiply(Lam, mm, axis=(-1, -2)), logdet, s)
+
+    def message_to_parent(self, index, u, up):
+        if index < 2:
+            return super().message_to_parent(index, u, up)
+        if index == 4:
+            raise NotImplementedError('message to the innovation precision of a switching chain')
+        D = self.D
+        XX, XpXn = _arr(u[1]), _arr(u[2])
+        XXp = XX[..., :-1, :, :]                         # <x_{n-1} x_{n-1}^T>, n = 1 .. N-1
+        Z = _arr(up[3][0])
+        v = self._v(up, 0)
+        if index == 2:
+            XnXp = XpXn.swapaxes(-1, -2)                 # [i][j] = <x_n[i] x_{n-1}[j]>
+            m0 = misc.sum_multiply(XnXp.reshape(XnXp.shape[:-2] + (1, D, D)),
+                                   Z.reshape(Z.shape + (1, 1)),
+                                   v.reshape(v.shape[:-1] + (1, 1, D, 1)), axis=-4)
+            m1 = misc.sum_multiply(XXp.reshape(XXp.shape[:-2] + (1, 1, D, D)),
+                                   Z.reshape(Z.shape + (1, 1, 1)),
+                                   v.reshape(v.shape[:-1] + (1, 1, D, 1, 1)), axis=-5)
+            return [m0, fuse(lambda q: -0.5 * q, m1)]
+        # index == 3: expected log-density of every transition under every dynamics matrix
+        Bm = _arr(up[2][0])
+        t_nn = misc.sum_multiply(misc.get_diag(XX[..., 1:, :, :], ndim=1),
+                                 v.reshape(v.shape[:-1] + (1, D)), axis=-1)       # (..., N-1)
+        Bt = Bm.swapaxes(-1, -2)                                                   # [k][i][l]
+        t_pn = misc.sum_multiply(XpXn.reshape(XpXn.shape[:-2] + (1, D, D)),
+                                 v.reshape(v.shape[:-1] + (1, 1, 1, D)),
+                                 Bt.reshape(Bt.shape[:-3] + (1,) + Bt.shape[-3:]),
+                                 axis=(-1, -2))                                    # (..., N-1, K)
+        vBB = self._vBB(up)
+        t_pp = misc.sum_multiply(XXp.reshape(XXp.shape[:-2] + (1, D, D)),
+                                 vBB.reshape(vBB.shape[:-3] + (1,) + vBB.shape[-3:]),
+                                 axis=(-1, -2))                                    # (..., N-1, K)
+        slv = misc.sum_multiply(self._v(up, 1), axis=-1)
+        c = -0.5 * D * float(np.log(2 * np.pi))
+        m0 = fuse(lambda a, b, c_, s: -0.5 * a + b - 0.5 * c_ + 0.5 * s + c,
+                  _trail(t_nn, 1), t_pn, t_pp, _trail(_arr(slv), 2))
+        return [m0]
+
+
 def make_extra_family(node):
+    if isinstance(node, SwitchingGaussianMarkovChain):
+        return SwitchingGaussianMarkovChainFamily(node)
     if isinstance(node, Slice):
         return SliceFamily(node)
     if isinstance(node, CategoricalMarkovChain):

@@ -16,10 +16,11 @@ from .poisson import Poisson
 from .add import Add
 from .take import Take, Concatenate, Gate, Choose
 from .mixture import Mixture
-from .gaussian_markov_chain import GaussianMarkovChain
+from .gaussian_markov_chain import GaussianMarkovChain, SwitchingGaussianMarkovChain
 from .categorical_markov_chain import CategoricalMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
            'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add',
-           'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain']
+           'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain',
+           'SwitchingGaussianMarkovChain']

@@ -89,3 +89,79 @@ class MarkovChainToGaussian(Node):
                          name=name or (X.name + '_as_gaussian'))
         self.shape = (X.D,)
         self.ndim = 1
+
+
+class SwitchingGaussianMarkovChain(GaussianMarkovChain):
+    """``SwitchingGaussianMarkovChain(mu, Lambda, B, Z, nu, n=N)``: a Gaussian Markov chain whose
+    dynamics matrix at every transition is picked from K matrices by a categorical variable,
+    x_n ~ N(B[z_{n-1}] x_{n-1}, diag(nu)^-1)  (reference gaussian_markov_chain.py:1454-1985).
+    ``B``: Gaussian with shape (D,) and plates (..., K, D) -- the last plate indexes the rows of
+    the K matrices; ``Z``: categorical-like with plates (..., N-1) (a CategoricalMarkovChain of
+    N-1 states is seen through its categorical view); ``nu``: gamma-like with last plate D,
+    constant in time.  Messages go to ``B`` and ``Z`` (and to mu / Lambda); the innovation
+    precision is not updated, like in the reference (:1555-1558)."""
+
+    def __init__(self, mu, Lambda, B, Z, nu, n=None, plates=None, name=None):
+        if hasattr(Z, 'as_categorical'):
+            Z = Z.as_categorical()
+        Stochastic.__init__(self, mu, Lambda, B, Z, nu, plates=(), dims=((), (), ()), name=name)
+        mu_n, L_n, B_n, Z_n, nu_n = self.parents
+        if isinstance(L_n, Constant):
+            if L_n.value.ndim < 2 or L_n.value.shape[-1] != L_n.value.shape[-2]:
+                raise ValueError("Second parent has wrong dimensionality")
+            D, Lpl = L_n.value.shape[-1], L_n.value.shape[:-2]
+        else:
+            D, Lpl = L_n.dims[0][0], L_n.plates
+        if isinstance(mu_n, Constant):
+            if mu_n.value.ndim < 1 or mu_n.value.shape[-1] != D:
+                raise ValueError("First parent has wrong dimensionality")
+            mupl = mu_n.value.shape[:-1]
+        else:
+            if mu_n.dims[0] != (D,):
+                raise ValueError("First parent has wrong dimensionality")
+            mupl = mu_n.plates
+        if isinstance(B_n, Constant):
+            if B_n.value.ndim < 3 or B_n.value.shape[-1] != D:
+                raise ValueError("Third parent has wrong dimensionality")
+            Bpl = B_n.value.shape[:-1]
+        else:
+            if tuple(B_n.dims[0]) != (D,):
+                raise ValueError("Third parent has wrong dimensionality")
+            Bpl = B_n.plates
+        if len(Bpl) < 2 or Bpl[-1] != D:
+            raise ValueError("Third parent should have a last plate equal to the "
+                             "dimensionality of the system.")
+        K = Bpl[-2]
+        if isinstance(Z_n, Constant):
+            if np.any(Z_n.value != np.round(Z_n.value)) or np.any(Z_n.value < 0) \
+                    or np.any(Z_n.value >= K):
+                raise ValueError("Invalid category index")
+            Zpl = Z_n.value.shape
+        else:
+            if tuple(Z_n.dims) != ((K,),):
+                raise ValueError("Fourth parent has wrong dimensionality %s, should be %s"
+                                 % (Z_n.dims, ((K,),)))
+            Zpl = Z_n.plates
+        if len(Zpl) == 0:
+            raise ValueError("Z must have temporal axis on plates")
+        nupl = nu_n.value.shape if isinstance(nu_n, Constant) else nu_n.plates
+        if len(nupl) == 0 or nupl[-1] != D:
+            raise Exception("Fifth parent should have a last plate equal to the "
+                            "dimensionality of the system.")
+        if len(nupl) >= 2 and nupl[-2] != 1:
+            raise NotImplementedError('a time-dependent innovation precision is not built')
+        n_Z = Zpl[-1]
+        if n is None:
+            if n_Z == 1:
+                raise Exception("The number of time instances could not be determined "
+                                "automatically. Give the number of time instances.")
+            n = n_Z + 1
+        if n_Z != n - 1:
+            raise ValueError("The last plate of the fourth parent should have length equal to "
+                             "N-1, where N is the number of time instances.")
+        self.N, self.D, self.K = int(n), int(D), int(K)
+        self.dims = ((self.N, D), (self.N, D, D), (self.N - 1, D, D))
+        given = tuple(plates) if plates is not None else ()
+        self.plates = broadcasted_shape(given, mupl, Lpl, Bpl[:-2], Zpl[:-1], nupl[:-2])
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))

@@ -679,6 +679,11 @@ def slice_nodes_case(name):
     _shared_case(name, 'make_slice_inputs', 'run_slice_cases', 2718, ('sl_plates', 'sl_L', 'ch_doc', 'ch_L'))
 
 
+def switching_case(name):
+    """Switching linear state-space model (demos/lssm_sd.py)."""
+    _shared_case(name, 'make_switching_inputs', 'run_switching_case', 606, ('sw_L',))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -768,6 +773,7 @@ def main():
     plate_nodes_case('plate_nodes')
     markov_chain_case('markov_chains')
     slice_nodes_case('slice_nodes')
+    switching_case('switching_lssm')
 
 
 if __name__ == '__main__':

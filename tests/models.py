@@ -571,3 +571,59 @@ def run_slice_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     for nm, nd in dict(Z=Z, x0=x0, x1=x1, x2=x2).items():
         out['ch_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
     return out
+
+
+def make_switching_inputs(rs):
+    """Seeded inputs of run_switching_case (tests/golden/switching_lssm.npz)."""
+    M, N, D, K = 6, 40, 3, 2
+    th = 0.4
+    A0 = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 0.9]])
+    A1 = 0.5 * np.identity(3)
+    z = (np.arange(N - 1) // 10) % 2
+    x = np.zeros((N, D))
+    x[0] = rs.normal(size=D)
+    for n in range(N - 1):
+        x[n + 1] = (A0 if z[n] == 0 else A1) @ x[n] + 0.3 * rs.normal(size=D)
+    C = rs.normal(size=(M, D))
+    return dict(sw_y=C @ x.T + 0.1 * rs.normal(size=(M, N)),
+                sw_A0=np.identity(D) * np.ones((K, D, D)) + 0.1 * rs.normal(size=(K, D, D)),
+                sw_X0=rs.normal(size=(N, D)), sw_C0=rs.normal(size=(M, 1, D)),
+                sw_z0=rs.randint(K, size=N - 1))
+
+
+def run_switching_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Linear state-space model with switching dynamics, bayespy/demos/lssm_sd.py:36-115 at a
+    small size: Dirichlet -> CategoricalMarkovChain -> SwitchingGaussianMarkovChain ->
+    SumMultiply -> GaussianARD, ARD priors on the dynamics and loading matrices."""
+    N_ = nodes_mod
+    y = g['sw_y']
+    M, N = y.shape
+    K, D = g['sw_A0'].shape[0], g['sw_A0'].shape[-1]
+    rho = N_.Dirichlet(1e-3 * np.ones(K), name='rho')
+    V = N_.Dirichlet(1e-3 * np.ones(K), plates=(K,), name='V')
+    v = 10 * np.identity(K) + 1 * np.ones((K, K))
+    V.initialize_from_value(v / np.sum(v, axis=-1, keepdims=True))
+    Z = N_.CategoricalMarkovChain(rho, V, states=N - 1, name='Z')
+    Z.initialize_from_value(g['sw_z0'])
+    alpha = N_.Gamma(1e-5, 1e-5, plates=(K, 1, D), name='alpha')
+    A = N_.GaussianARD(0, alpha, shape=(D,), plates=(K, D), name='A')
+    A.initialize_from_value(g['sw_A0'])
+    X = N_.SwitchingGaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, Z, np.ones(D),
+                                        n=N, name='X')
+    X.initialize_from_value(g['sw_X0'])
+    gamma = N_.Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    C = N_.GaussianARD(0, gamma, shape=(D,), plates=(M, 1), name='C')
+    C.initialize_from_value(g['sw_C0'])
+    F = N_.SumMultiply('i,i', C, X, name='F')
+    tau = N_.Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    Y = N_.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = vb_cls(Y, F, Z, rho, V, C, gamma, X, A, alpha, tau, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=5, verbose=False)
+    out = {'sw_L': np.array(Q.L[:5])}
+    for nm, nd in dict(X=X, A=A, Z=Z, V=V, rho=rho, C=C, tau=tau, alpha=alpha).items():
+        out['sw_%s_u' % nm] = [np.array(u) for u in nd.get_moments()]
+        out['sw_%s_Lterm' % nm] = np.array(Q.l[nd][:5])
+    return out

@@ -127,3 +127,25 @@ def test_lssm_matches_reference(golden_dir, tag, B, gamma_nu):
             ref = g['%s_%s_u%d' % (tag, nm, i)]
             np.testing.assert_allclose(np.broadcast_to(ui, ref.shape), ref, rtol=1e-7, atol=1e-9,
                                        err_msg='%s u[%d]' % (nm, i))
+
+
+def test_switching_state_space_model_matches_reference(golden_dir):
+    """SwitchingGaussianMarkovChain inside the model of bayespy/demos/lssm_sd.py (a categorical
+    Markov chain picks the dynamics matrix of every transition): five VB iterations against
+    the live reference, bound and every node's moments and bound term."""
+    import os
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_switching_case
+    f = np.load(os.path.join(golden_dir, 'switching_lssm.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_switching_case(N_, VB, g)
+    np.testing.assert_allclose(res['sw_L'], f['sw_L'], rtol=1e-8)
+    for k, v in res.items():
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                ref = f['%s_%d' % (k, i)]
+                np.testing.assert_allclose(np.broadcast_to(vi, ref.shape), ref, rtol=1e-6,
+                                           atol=1e-8, err_msg='%s[%d]' % (k, i))
+        else:
+            np.testing.assert_allclose(v, f[k], rtol=1e-7, atol=1e-6, err_msg=k)
