@@ -20,7 +20,8 @@ from ...utils import misc, linalg
 from ...utils import random as drandom
 from .generic import (Family, DirichletFamily, GaussianMarkovChainFamily, _arr, _trail, _const,
                       _check_device)
-from ...nodes.gaussian_markov_chain import SwitchingGaussianMarkovChain
+from ...nodes.gaussian_markov_chain import (SwitchingGaussianMarkovChain,
+                                            VaryingGaussianMarkovChain)
 
 
 def _flip2(x):
@@ -737,7 +738,101 @@ class SwitchingGaussianMarkovChainFamily(GaussianMarkovChainFamily):
         return [m0]
 
 
+class VaryingGaussianMarkovChainFamily(SwitchingGaussianMarkovChainFamily):
+    """gaussian_markov_chain.py:930-1198: the dynamics of transition n are sum_k <s_nk> B_k with
+    Gaussian weights s_n; B has shape (D, K) per row plate."""
+
+    def plates_to_parent(self, index):
+        p = self.node.plates
+        if index < 2:
+            return p
+        if index == 2:
+            return p + (self.D,)
+        if index == 3:
+            return p + (self.N - 1,)
+        return p + (self.N - 1, self.D)
+
+    def mask_to_parent(self, index, mask):
+        mask = np.asarray(mask)
+        if index < 2:
+            return mask
+        return mask[..., None, None] if index == 4 else mask[..., None]
+
+    def constant_moments(self, index, value):
+        if index in (2, 3):
+            raise NotImplementedError('the dynamics matrices and their weights must be nodes')
+        return super().constant_moments(index, value)
+
+    def _vBB(self, up):
+        """sum_d v_d <b_d b_d^T> with b_d = B[d] of shape (D, K):  (..., D_i, K_k, D_j, K_l)."""
+        D = self.D
+        v = self._v(up, 0)
+        return misc.sum_multiply(v.reshape(v.shape[:-1] + (D, 1, 1, 1, 1)), _arr(up[2][1]), axis=-5)
+
+    def phi_from_parents(self, up):
+        D, N, K = self.D, self.N, self.K
+        m, Lam = up[0][0], up[1][0]
+        Bm = _arr(up[2][0])                                  # (..., D_j, D_i, K)
+        S, SS = _arr(up[3][0]), _arr(up[3][1])               # (..., N-1, K), (..., N-1, K, K)
+        v = self._v(up, 0)
+        Lm = linalg.mvdot(Lam, m)
+        phi0 = fuse(lambda e, q: e * q, self._e0v, _arr(Lm).reshape(_arr(Lm).shape[:-1] + (1, D)))
+        vBB = self._vBB(up)                                  # (..., i, k, j, l)
+        # sum_kl vBB[i,k,j,l] <s_nk s_nl>  ->  (..., N-1, i, j)
+        dyn = misc.sum_multiply(SS.reshape(SS.shape[:-2] + (1, K, 1, K)),
+                                vBB.reshape(vBB.shape[:-4] + (1,) + vBB.shape[-4:]),
+                                axis=(-1, -3))
+        dyn = misc.concatenate([dyn, DArray.zeros((1, D, D))], axis=-3)
+        dv = misc.diag(v.reshape(v.shape[:-1] + (1, D)), ndim=1)
+        L = _arr(Lam)
+        L = L.reshape(L.shape[:-2] + (1,) + L.shape[-2:])
+        phi1 = fuse(lambda a, b, l, d, q: -0.5 * (a * l + b * d + q), self._e0, self._en0, L, dv,
+                    dyn)
+        # phi2[n, i, j] = sum_k B[j, i, k] s_nk v_j
+        Bt = Bm.swapaxes(-2, -3)                             # [i][j][k]
+        phi2 = misc.sum_multiply(Bt.reshape(Bt.shape[:-3] + (1,) + Bt.shape[-3:]),
+                                 S.reshape(S.shape[:-1] + (1, 1, K)),
+                                 v.reshape(v.shape[:-1] + (1, 1, D, 1)), axis=-1)
+        return [phi0, phi1, phi2]
+
+    def message_to_parent(self, index, u, up):
+        if index < 2:
+            return GaussianMarkovChainFamily.message_to_parent(self, index, u, up)
+        if index == 4:
+            raise NotImplementedError('message to the innovation precision of a varying chain')
+        D, K = self.D, self.K
+        XX, XpXn = _arr(u[1]), _arr(u[2])
+        XXp = XX[..., :-1, :, :]
+        S, SS = _arr(up[3][0]), _arr(up[3][1])
+        v = self._v(up, 0)
+        XnXp = XpXn.swapaxes(-1, -2)                         # [i][j] = <x_n[i] x_{n-1}[j]>
+        if index == 2:
+            # m0[i, j, k] = sum_n <x_n[i] x_{n-1}[j]> s_nk v_i
+            m0 = misc.sum_multiply(XnXp.reshape(XnXp.shape + (1,)),
+                                   S.reshape(S.shape[:-1] + (1, 1, K)),
+                                   v.reshape(v.shape[:-1] + (1, D, 1, 1)), axis=-4)
+            # m1[d, i, k, j, l] = -1/2 v_d sum_n <x x^T>[n, i, j] <s s^T>[n, k, l]
+            t = misc.sum_multiply(XXp.reshape(XXp.shape[:-2] + (D, 1, D, 1)),
+                                  SS.reshape(SS.shape[:-2] + (1, K, 1, K)), axis=-5)
+            m1 = fuse(lambda a, b: -0.5 * a * b,
+                      t.reshape(t.shape[:-4] + (1,) + t.shape[-4:]),
+                      v.reshape(v.shape[:-1] + (D, 1, 1, 1, 1)))
+            return [m0, m1]
+        # index == 3
+        Bm = _arr(up[2][0])                                  # (..., D_i, D_j, K)
+        m0 = misc.sum_multiply(XnXp.reshape(XnXp.shape + (1,)),
+                               Bm.reshape(Bm.shape[:-3] + (1,) + Bm.shape[-3:]),
+                               v.reshape(v.shape[:-1] + (1, D, 1, 1)), axis=(-2, -3))
+        vBB = self._vBB(up)                                  # (..., i, k, j, l)
+        m1 = misc.sum_multiply(XXp.reshape(XXp.shape[:-2] + (D, 1, D, 1)),
+                               vBB.reshape(vBB.shape[:-4] + (1,) + vBB.shape[-4:]),
+                               axis=(-2, -4))
+        return [m0, fuse(lambda q: -0.5 * q, m1)]
+
+
 def make_extra_family(node):
+    if isinstance(node, VaryingGaussianMarkovChain):
+        return VaryingGaussianMarkovChainFamily(node)
     if isinstance(node, SwitchingGaussianMarkovChain):
         return SwitchingGaussianMarkovChainFamily(node)
     if isinstance(node, Slice):

@@ -16,11 +16,12 @@ from .poisson import Poisson
 from .add import Add
 from .take import Take, Concatenate, Gate, Choose
 from .mixture import Mixture
-from .gaussian_markov_chain import GaussianMarkovChain, SwitchingGaussianMarkovChain
+from .gaussian_markov_chain import (GaussianMarkovChain, SwitchingGaussianMarkovChain,
+                                    VaryingGaussianMarkovChain)
 from .categorical_markov_chain import CategoricalMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
            'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add',
            'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain',
-           'SwitchingGaussianMarkovChain']
+           'SwitchingGaussianMarkovChain', 'VaryingGaussianMarkovChain']

@@ -165,3 +165,67 @@ class SwitchingGaussianMarkovChain(GaussianMarkovChain):
         self.plates = broadcasted_shape(given, mupl, Lpl, Bpl[:-2], Zpl[:-1], nupl[:-2])
         if plates is not None and self.plates != given:
             raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
+
+
+class VaryingGaussianMarkovChain(GaussianMarkovChain):
+    """``VaryingGaussianMarkovChain(mu, Lambda, B, S, nu, n=N)``: a Gaussian Markov chain whose
+    dynamics matrix is a time-varying linear combination of K matrices,
+    x_n ~ N((sum_k s_{n-1,k} B_k) x_{n-1}, diag(nu)^-1)  (reference
+    gaussian_markov_chain.py:930-1452).  ``B``: Gaussian with shape (D, K) and last plate D (the
+    rows of the matrices); ``S``: Gaussian with shape (K,) and plates (..., N-1) (e.g. the
+    Gaussian view of another chain, sliced ``[1:]``); ``nu``: gamma-like with last plate D,
+    constant in time.  Messages go to ``B`` and ``S`` (and to mu / Lambda)."""
+
+    def __init__(self, mu, Lambda, B, S, nu, n=None, plates=None, name=None):
+        if isinstance(S, GaussianMarkovChain):
+            S = S.as_gaussian()
+        Stochastic.__init__(self, mu, Lambda, B, S, nu, plates=(), dims=((), (), ()), name=name)
+        mu_n, L_n, B_n, S_n, nu_n = self.parents
+        if isinstance(L_n, Constant):
+            if L_n.value.ndim < 2 or L_n.value.shape[-1] != L_n.value.shape[-2]:
+                raise ValueError("Second parent has wrong dimensionality")
+            D, Lpl = L_n.value.shape[-1], L_n.value.shape[:-2]
+        else:
+            D, Lpl = L_n.dims[0][0], L_n.plates
+        if isinstance(mu_n, Constant):
+            if mu_n.value.ndim < 1 or mu_n.value.shape[-1] != D:
+                raise ValueError("First parent has wrong dimensionality")
+            mupl = mu_n.value.shape[:-1]
+        else:
+            if mu_n.dims[0] != (D,):
+                raise ValueError("First parent has wrong dimensionality")
+            mupl = mu_n.plates
+        if isinstance(B_n, Constant) or isinstance(S_n, Constant):
+            raise NotImplementedError('the dynamics matrices and their weights must be nodes')
+        if len(B_n.dims[0]) != 2 or B_n.dims[0][0] != D:
+            raise ValueError("Third parent has wrong dimensionality")
+        K = B_n.dims[0][1]
+        if len(B_n.plates) == 0 or B_n.plates[-1] != D:
+            raise ValueError("Third parent should have a last plate equal to the "
+                             "dimensionality of the system.")
+        if tuple(S_n.dims[0]) != (K,):
+            raise ValueError("Fourth parent has wrong dimensionality")
+        if len(S_n.plates) == 0:
+            raise ValueError("The weights must have a temporal axis on their plates")
+        nupl = nu_n.value.shape if isinstance(nu_n, Constant) else nu_n.plates
+        if len(nupl) == 0 or nupl[-1] != D:
+            raise Exception("Fifth parent should have a last plate equal to the "
+                            "dimensionality of the system.")
+        if len(nupl) >= 2 and nupl[-2] != 1:
+            raise NotImplementedError('a time-dependent innovation precision is not built')
+        n_S = S_n.plates[-1]
+        if n is None:
+            if n_S == 1:
+                raise Exception("The number of time instances could not be determined "
+                                "automatically. Give the number of time instances.")
+            n = n_S + 1
+        if n_S != n - 1:
+            raise ValueError("The last plate of the fourth parent should have length equal to "
+                             "N-1, where N is the number of time instances.")
+        self.N, self.D, self.K = int(n), int(D), int(K)
+        self.dims = ((self.N, D), (self.N, D, D), (self.N - 1, D, D))
+        given = tuple(plates) if plates is not None else ()
+        self.plates = broadcasted_shape(given, mupl, Lpl, B_n.plates[:-1], S_n.plates[:-1],
+                                        nupl[:-2])
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))

@@ -684,6 +684,11 @@ def switching_case(name):
     _shared_case(name, 'make_switching_inputs', 'run_switching_case', 606, ('sw_L',))
 
 
+def varying_case(name):
+    """Linear state-space model with time-varying dynamics (demos/lssm_tvd.py)."""
+    _shared_case(name, 'make_varying_inputs', 'run_varying_case', 909, ('tv_L',))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -774,6 +779,7 @@ def main():
     markov_chain_case('markov_chains')
     slice_nodes_case('slice_nodes')
     switching_case('switching_lssm')
+    varying_case('varying_lssm')
 
 
 if __name__ == '__main__':

@@ -627,3 +627,65 @@ def run_switching_case(nodes_mod, vb_cls, g, **vb_kwargs):
         out['sw_%s_u' % nm] = [np.array(u) for u in nd.get_moments()]
         out['sw_%s_Lterm' % nm] = np.array(Q.l[nd][:5])
     return out
+
+
+def make_varying_inputs(rs):
+    """Seeded inputs of run_varying_case (tests/golden/varying_lssm.npz)."""
+    M, N, D, K = 5, 30, 2, 2
+    x = np.zeros((N, D))
+    x[0] = rs.normal(size=D)
+    for n in range(N - 1):
+        th = 0.3 + 0.4 * np.sin(2 * np.pi * n / N)
+        An = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        x[n + 1] = An @ x[n] + 0.2 * rs.normal(size=D)
+    C = rs.normal(size=(M, D))
+    s0 = 10 * rs.normal(size=(N, K))
+    s0[:, 0] = 10
+    a0 = np.zeros((D, D, K))
+    a0[:, :, 0] = np.identity(D) / s0[0, 0]
+    a0[:, :, 1:] = 0.1 / s0[0, 0] * rs.normal(size=(D, D, K - 1))
+    return dict(tv_y=C @ x.T + 0.1 * rs.normal(size=(M, N)), tv_s0=s0, tv_a0=a0,
+                tv_x0=rs.normal(size=(N, D)), tv_c0=rs.normal(size=(M, 1, D)))
+
+
+def run_varying_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """Linear state-space model with time-varying dynamics, bayespy/demos/lssm_tvd.py:40-140
+    at a small size: the dynamics matrix of X is a combination of K matrices weighted by a
+    second Gaussian Markov chain S (its Gaussian view sliced [1:])."""
+    N_ = nodes_mod
+    y = g['tv_y']
+    M, N = y.shape
+    D, K = g['tv_a0'].shape[0], g['tv_a0'].shape[-1]
+    beta = N_.Gamma(1e-5, 1e-5, plates=(K,), name='beta')
+    B = N_.GaussianARD(np.identity(K), beta, shape=(K,), plates=(K,), name='B')
+    B.initialize_from_value(np.identity(K))
+    S = N_.GaussianMarkovChain(np.ones(K), 1e-6 * np.identity(K), B, np.ones(K), n=N, name='S')
+    S.initialize_from_value(g['tv_s0'])
+    alpha = N_.Gamma(1e-5, 1e-5, plates=(D, K), name='alpha')
+    alpha.initialize_from_value(1 * np.ones((D, K)))
+    A = N_.GaussianARD(0, alpha, shape=(D, K), plates=(D,), name='A')
+    A.initialize_from_value(g['tv_a0'])
+    if hasattr(S, 'as_gaussian'):
+        Sg = S.as_gaussian()
+    else:
+        from bayespy.inference.vmp.nodes.gaussian import GaussianMoments
+        Sg = S._ensure_moments(S, GaussianMoments, ndim=1)
+    X = N_.VaryingGaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, Sg[1:], np.ones(D),
+                                      n=N, name='X')
+    X.initialize_from_value(g['tv_x0'])
+    gamma = N_.Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    C = N_.GaussianARD(0, gamma, shape=(D,), plates=(M, 1), name='C')
+    C.initialize_from_value(g['tv_c0'])
+    F = N_.SumMultiply('i,i', C, X, name='F')
+    tau = N_.Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    Y = N_.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = vb_cls(Y, F, C, gamma, X, A, alpha, tau, S, B, beta, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=5, verbose=False)
+    out = {'tv_L': np.array(Q.L[:5])}
+    for nm, nd in dict(X=X, A=A, S=S, B=B, C=C, tau=tau, alpha=alpha, beta=beta).items():
+        out['tv_%s_u' % nm] = [np.array(u) for u in nd.get_moments()]
+        out['tv_%s_Lterm' % nm] = np.array(Q.l[nd][:5])
+    return out

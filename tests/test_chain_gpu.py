@@ -149,3 +149,24 @@ def test_switching_state_space_model_matches_reference(golden_dir):
                                            atol=1e-8, err_msg='%s[%d]' % (k, i))
         else:
             np.testing.assert_allclose(v, f[k], rtol=1e-7, atol=1e-6, err_msg=k)
+
+
+def test_time_varying_state_space_model_matches_reference(golden_dir):
+    """VaryingGaussianMarkovChain inside the model of bayespy/demos/lssm_tvd.py (a second
+    Gaussian Markov chain, seen as Gaussian variables and sliced [1:], mixes K dynamics
+    matrices): five VB iterations against the live reference."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_varying_case
+    f = np.load(os.path.join(golden_dir, 'varying_lssm.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_varying_case(N_, VB, g)
+    np.testing.assert_allclose(res['tv_L'], f['tv_L'], rtol=1e-8)
+    for k, v in res.items():
+        if isinstance(v, list):
+            for i, vi in enumerate(v):
+                ref = f['%s_%d' % (k, i)]
+                np.testing.assert_allclose(np.broadcast_to(vi, ref.shape), ref, rtol=1e-6,
+                                           atol=1e-8, err_msg='%s[%d]' % (k, i))
+        else:
+            np.testing.assert_allclose(v, f[k], rtol=1e-7, atol=1e-6, err_msg=k)
