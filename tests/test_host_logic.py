@@ -92,3 +92,99 @@ def test_checkpoint_container_round_trip(tmp_path):
     with pytest.raises(KeyError):
         r.get('missing')
     r.close()
+
+
+def test_plate_rules_of_the_plate_moving_nodes():
+    """Plates and argument checks of Take / Concatenate / Gate / Slice / Choose follow the
+    reference (take.py:41-66, :126-131; concatenate.py:27-78; gate.py:33-80,
+    nodes/tests/test_gate.py:35-80; node.py:868-1015) -- construction only, no device."""
+    import bayespy_amd.nodes as N
+    a = N.Gamma(np.ones(3), np.ones(3))
+    assert N.Take(a, [1, 1, 2, 2, 1, 0]).plates == (6,)
+    assert N.Take(a, [[0, 2], [1, 1]]).plates == (2, 2)
+    X = N.GaussianARD(0, 1, shape=(2,), plates=(3, 4))
+    t = N.Take(X, [[0, 2], [1, 1]], plate_axis=-2)
+    assert t.plates == (2, 2, 4) and t.dims == X.dims
+    assert N.Concatenate(N.GaussianARD(0, 1, plates=(3,)), N.GaussianARD(0, 1, plates=(2,))).plates == (5,)
+    c = N.Concatenate(N.GaussianARD(0, 1, shape=(2,), plates=(2, 1)),
+                      N.GaussianARD(0, 1, shape=(2,), plates=(1, 1)), axis=-2)
+    assert c.plates == (3, 1)
+    # test_gate.py:35-80
+    Z = N.Categorical(np.ones(3) / 3)
+    assert N.Gate(Z, N.GaussianARD(0, 1, shape=(), plates=(3,))).plates == ()
+    G = N.Gate(Z, N.GaussianARD(0, 1, shape=(2,), plates=(3,)))
+    assert G.plates == () and G.dims == ((2,), (2, 2))
+    Z4 = N.Categorical(np.ones(3) / 3, plates=(4,))
+    assert N.Gate(Z4, N.GaussianARD(0, 1, shape=(2,), plates=(3,))).plates == (4,)
+    assert N.Gate(Z, N.GaussianARD(0, 1, shape=(2,), plates=(4, 3))).plates == (4,)
+    Z5 = N.Categorical(np.ones(3) / 3, plates=(5,))
+    assert N.Gate(Z5, N.GaussianARD(0, 1, shape=(2,), plates=(4, 1, 3))).plates == (4, 5)
+    assert N.Gate(Z, N.GaussianARD(0, 1, shape=(), plates=(3, 4)), gated_plate=-2).plates == (4,)
+    with pytest.raises(ValueError, match='negative'):
+        N.Gate(Z, N.GaussianARD(0, 1, plates=(3,)), gated_plate=0)
+    # slicing
+    X = N.GaussianARD(0, 1, plates=(4, 5, 6))
+    assert X[1:3].plates == (2, 5, 6)
+    assert X[..., 0].plates == (4, 5)
+    assert X[:, None, ::2].plates == (4, 1, 3, 6)
+    assert X[-1, ..., 2:].plates == (5, 4)
+    assert X[2].plates == (5, 6) and X[None].plates == (1, 4, 5, 6)
+    assert X[::-1, 1].plates == (4, 6)
+    assert N.Choose([0, 1, 1], N.GaussianARD(0, 1), N.GaussianARD(1, 1)).plates == (3,)
+
+
+def test_markov_chain_constructors():
+    """categorical_markov_chain.py:283-330 and gaussian_markov_chain.py:1866-1985 / :1331-1452:
+    chain lengths, plates and the parent checks."""
+    import bayespy_amd.nodes as N
+    K = 3
+    Z = N.CategoricalMarkovChain(np.ones(K) / K, np.ones((K, K)) / K, states=7)
+    assert Z.plates == () and Z.dims == ((K,), (6, K, K))
+    A = N.Dirichlet(np.ones((9, K, K)))                # time-varying transitions: plates (9, K)
+    Z = N.CategoricalMarkovChain(N.Dirichlet(np.ones(K), plates=(4,)), A)
+    assert Z.plates == (4,) and Z.states == 10
+    assert Z.as_categorical().plates == (4, 10) and Z.as_categorical() is Z.as_categorical()
+    with pytest.raises(ValueError, match='inconsistent'):
+        N.CategoricalMarkovChain(np.ones(K) / K, A, states=5)
+    with pytest.raises(ValueError, match='not square'):
+        N.CategoricalMarkovChain(np.ones(K) / K, N.Dirichlet(np.ones((9, 2, K))))
+    D = 2
+    B = N.GaussianARD(0, 1, shape=(D,), plates=(K, D))
+    Zc = N.CategoricalMarkovChain(np.ones(K) / K, np.ones((K, K)) / K, states=5)
+    X = N.SwitchingGaussianMarkovChain(np.zeros(D), np.identity(D), B, Zc, np.ones(D))
+    assert (X.N, X.D, X.K) == (6, D, K) and X.plates == ()
+    assert X.as_gaussian().plates == (6,)
+    with pytest.raises(ValueError, match='N-1'):
+        N.SwitchingGaussianMarkovChain(np.zeros(D), np.identity(D), B, Zc, np.ones(D), n=9)
+    with pytest.raises(ValueError, match='Fourth parent'):
+        N.SwitchingGaussianMarkovChain(np.zeros(D), np.identity(D), B,
+                                       N.Categorical(np.ones(2) / 2, plates=(5,)), np.ones(D))
+    Bv = N.GaussianARD(0, 1, shape=(D, K), plates=(D,))
+    S = N.GaussianMarkovChain(np.zeros(K), np.identity(K), np.identity(K), np.ones(K), n=6)
+    Xv = N.VaryingGaussianMarkovChain(np.zeros(D), np.identity(D), Bv, S.as_gaussian()[1:],
+                                      np.ones(D))
+    assert (Xv.N, Xv.D, Xv.K) == (6, D, K)
+    with pytest.raises(ValueError, match='Third parent'):
+        N.VaryingGaussianMarkovChain(np.zeros(D), np.identity(D), B, S.as_gaussian()[1:],
+                                     np.ones(D))
+
+
+def test_count_node_constructors():
+    """binomial.py:66-76, :214-240; beta.py:134-160; poisson.py:122-150; add.py:52-85."""
+    import bayespy_amd.nodes as N
+    p = N.Beta([[1.0, 2.0], [0.5, 0.5], [3.0, 1.0]])
+    assert p.plates == (3,) and p.dims == ((2,),)
+    assert N.Binomial([10, 7, 12], p, plates=(4, 3)).plates == (4, 3)
+    assert N.Bernoulli(p.complement(), plates=(6, 3)).plates == (6, 3)
+    assert N.Bernoulli(0.3).plates == () and N.Binomial(5, [0.2, 0.4]).plates == (2,)
+    assert N.Poisson(N.Gamma(np.ones(3), np.ones(3)), plates=(20, 3)).plates == (20, 3)
+    with pytest.raises(ValueError, match=r'\[0, 1\]'):
+        N.Bernoulli(1.5)
+    with pytest.raises(ValueError, match='beta-like'):
+        N.Bernoulli(N.Dirichlet(np.ones(3)))
+    a = N.GaussianARD(0, 1, shape=(2,), plates=(5, 1))
+    b = N.GaussianARD(0, 1, shape=(2,), plates=(1, 3))
+    s = N.Add(a, b, np.zeros(2))
+    assert s.plates == (5, 3) and s.dims == ((2,), (2, 2))
+    Y = N.GaussianARD(s, 1.0)
+    assert Y.plates == (5, 3) and Y.shape == (2,)
