@@ -18,7 +18,6 @@ import numbers
 
 import numpy as np
 
-from . import _lib
 from .device import get_runtime
 
 # opcodes of include/vmp_hip.h

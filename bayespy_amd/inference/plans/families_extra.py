@@ -18,8 +18,7 @@ from ...nodes.categorical_markov_chain import (CategoricalMarkovChain,
                                                 CategoricalMarkovChainToCategorical)
 from ...utils import misc, linalg
 from ...utils import random as drandom
-from .generic import (Family, DirichletFamily, GaussianMarkovChainFamily, _arr, _trail, _const,
-                      _check_device)
+from .generic import Family, DirichletFamily, GaussianMarkovChainFamily, _arr, _trail, _const
 from ...nodes.gaussian_markov_chain import (SwitchingGaussianMarkovChain,
                                             VaryingGaussianMarkovChain)
 

@@ -38,8 +38,7 @@ from ...nodes.multinomial import Multinomial
 from ...nodes.mixture import Mixture
 from ...nodes.gaussian_markov_chain import GaussianMarkovChain, MarkovChainToGaussian
 from ...utils import misc, linalg
-from ...utils.shapes import (broadcasted_shape, broadcasting_multiplier, is_shape_subset,
-                             multiplier_factor)
+from ...utils.shapes import broadcasted_shape, is_shape_subset, multiplier_factor
 
 LOG2PI = float(np.log(2 * np.pi))
 

@@ -8,7 +8,7 @@ and diagonal (ARD) prior precision ``alpha``; the posterior has a full
 (``WrapToGaussianGamma``, gaussian.py:2299-2371) is folded into the plan's
 kernels instead of being a separate deterministic node.
 """
-from .node import Node, Stochastic
+from .node import Stochastic
 from ..utils.shapes import broadcasted_shape
 
 

@@ -5,7 +5,6 @@ Wishart node (reference: bayespy/inference/vmp/nodes/wishart.py:228-305).
 ``V`` (wishart.py:126-128).  Moments u = [<Lambda>, <log|Lambda|>]
 (wishart.py:45-60), natural parameters phi = [-V/2, n/2] (:153-163).
 """
-import numpy as np
 
 from .node import Stochastic, Constant
 from ..utils.shapes import broadcasted_shape

@@ -15,7 +15,7 @@ import operator
 import numpy as np
 
 from ..darray import DArray, asdarray, fuse, contiguous, is_scalar, _strides
-from ..darray import exp as _exp, digamma as _digamma
+from ..darray import digamma as _digamma
 from ..device import get_runtime
 from .shapes import broadcasted_shape, broadcasting_multiplier, is_shape_subset  # noqa: F401
 
