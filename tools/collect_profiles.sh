@@ -40,4 +40,12 @@ python bench.py --steps 20 --warmup 3 > $O/bench_n1_gram.json 2>/dev/null
 python bench.py --steps 20 --warmup 3 --stats stream --no-cpu-baseline > $O/bench_n1_stream.json 2>/dev/null
 python tools/bench_gmm.py > $O/bench_gmm_n1.json 2>/dev/null
 tools/microbench.bin > $O/microbench.txt 2>&1
+# forward-backward kernel of categorical Markov chains and the generic kernels (incl. the
+# matrix-core SPD sweep)
+H="python $R/tools/bench_hmm.py --reps 3"
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats_hmm -o r -- $H > $R/$O/bench_under_rocprof_hmm.log 2>&1)
+python tools/rocpd_summary.py /tmp/p_stats_hmm/r_results.db > $O/kernel_stats_hmm.txt 2>&1
+(python tools/bench_hmm.py; python tools/bench_hmm.py --k 3 --chains 50000; python tools/bench_hmm.py --k 16 --chains 8000 --steps 500; python tools/bench_hmm.py --chains 1 --steps 100000) > $O/bench_hmm.json 2>/dev/null
+python tools/bench_generic.py > $O/bench_generic.json 2>/dev/null
+python tools/bench_masked_pca.py --n 200000 --d 128 --k 32 --steps 5 > $O/bench_masked_pca_n2e5_d128_k32.json 2>/dev/null
 ls -la $O
