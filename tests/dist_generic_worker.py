@@ -102,6 +102,31 @@ def main():
         for nm, nd in dict(A=A, C=C, tau=tau, alpha=alpha, gamma=gamma, nu=nu).items():
             res['L_' + nm] = np.array(Q.l[nd][:n])
         res['A_u0'] = np.asarray(A.u[0])
+    elif case == 'hmm':
+        # a batch of hidden Markov chains (case 3 of tests/models.py run_markov_chain_cases)
+        # with the chain plate split over the ranks; emission and transition parameters are
+        # replicated and receive all-reduced messages
+        g = np.load(os.path.join(golden, 'markov_chains.npz'))
+        yb, prior, z0 = g['in_hmm3_y'], g['in_hmm3_prior'], g['in_hmm3_z0']
+        B, T = yb.shape
+        K = prior.shape[-1]
+        lo, hi = B * rank // world, B * (rank + 1) // world
+        a0 = nodes.Dirichlet(np.ones(K), plates=(hi - lo,), name='a0').shard(-1)
+        A = nodes.Dirichlet(prior, name='A')
+        Z = nodes.CategoricalMarkovChain(a0, A, name='Z')
+        m = nodes.GaussianARD(0, 1e-2, plates=(K,), name='m')
+        t = nodes.Gamma(1e-1, 1e-1, plates=(K,), name='t')
+        Y = nodes.Mixture(Z, nodes.GaussianARD, m, t, name='Y')
+        Z.initialize_from_value(z0[lo:hi])
+        Y.observe(yb[lo:hi])
+        Q = VB(Y, m, t, Z, A, a0)
+        Q.ignore_bound_checks = True
+        Q.update(repeat=4, verbose=False)
+        res['L'] = np.array(Q.L[:4])
+        res['m_u0'], res['t_u0'] = np.asarray(m.u[0]), np.asarray(t.u[0])
+        res['A_u0'] = np.asarray(A.u[0])
+        res['Z_u0'] = np.asarray(Z.u[0])
+        res['lo'], res['hi'] = lo, hi
     else:
         raise SystemExit('unknown case ' + case)
     np.savez(os.path.join(out, 'rank%d.npz' % rank), **res)

@@ -68,3 +68,20 @@ def test_sharded_lssm_matches_reference(golden_dir, tmp_path):
             np.testing.assert_allclose(r['L_' + nm], g['lssmB_%s_L' % nm], rtol=1e-8, atol=1e-7,
                                        err_msg=nm)
     assert np.array_equal(r0['A_u0'], r1['A_u0'])
+
+
+def test_sharded_hidden_markov_chains_match_reference(golden_dir, tmp_path):
+    """A batch of hidden Markov chains with the chain plate split over two ranks: only the
+    initial-state node is declared sharded, the chain, its categorical view and the mixture
+    inherit the partition; messages to the replicated transition and emission parameters and
+    the bound terms of the sharded nodes are all-reduced."""
+    r0, r1 = _launch('hmm', golden_dir, tmp_path, 29547)
+    g = np.load(os.path.join(golden_dir, 'markov_chains.npz'))
+    for r in (r0, r1):
+        np.testing.assert_allclose(r['L'], g['hmm3_L'], rtol=1e-9)
+        np.testing.assert_allclose(r['m_u0'], g['hmm3_m_u_0'], rtol=1e-7)
+        np.testing.assert_allclose(r['t_u0'], g['hmm3_t_u_0'], rtol=1e-7)
+        np.testing.assert_allclose(r['A_u0'], g['hmm3_A_u_0'], rtol=1e-7)
+        lo, hi = int(r['lo']), int(r['hi'])
+        np.testing.assert_allclose(r['Z_u0'], g['hmm3_Z_u_0'][lo:hi], rtol=1e-7, atol=1e-12)
+    assert np.array_equal(r0['m_u0'], r1['m_u0'])
