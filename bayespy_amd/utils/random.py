@@ -68,3 +68,128 @@ def alpha_beta_recursion(logp0, logP):
         ctypes.c_void_p(zz.t.data_ptr()), ctypes.c_void_p(g.t.data_ptr()),
         ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8))
     return z0, zz, g
+
+
+# ---------------------------------------------------------------------------
+# Host-side data-generation helpers of bayespy.utils.random (set-up of demos and tests: masks,
+# random covariance matrices, draws from discrete distributions).  NumPy on the host, the
+# global numpy.random state like the reference; none of this is on the inference path.
+# ---------------------------------------------------------------------------
+def mask(*shape, p=0.5):
+    """Boolean array, each element True with probability ``p`` (utils/random.py:45-56)."""
+    return np.random.rand(*shape) < p
+
+
+def covariance(D, size=(), nu=None):
+    """Random SPD matrix (or a ``size`` stack of them) from an inverse-Wishart distribution
+    with ``nu`` degrees of freedom, default ``D`` (utils/random.py:80-113)."""
+    nu = D if nu is None else nu
+    if nu < D:
+        raise ValueError("nu must be greater than or equal to D")
+    try:
+        size = tuple(size)
+    except TypeError:
+        size = (size,)
+    C = np.random.randn(*(size + (D, nu)))
+    return np.linalg.inv(C @ np.swapaxes(C, -1, -2) / nu)
+
+
+def correlation(D):
+    """Random correlation matrix (utils/random.py:116-123)."""
+    X = np.random.randn(D, D)
+    X = X / np.sqrt(np.sum(X ** 2, axis=-1, keepdims=True))
+    return X @ X.T
+
+
+def orth(D):
+    """Random orthogonal matrix (utils/random.py:208-213)."""
+    return np.linalg.qr(np.random.randn(D, D))[0]
+
+
+def svd(s):
+    """Random matrix with the given singular values (utils/random.py:216-222)."""
+    D = len(s)
+    return (orth(D) * s) @ orth(D).T
+
+
+def sphere(N=1):
+    """N points uniform on the unit sphere as (latitude, longitude) in degrees
+    (utils/random.py:225-233)."""
+    lon = np.random.uniform(-180, 180, N)
+    lat = np.arccos(np.random.uniform(-1, 1, N)) * 180 / np.pi - 90
+    return lat, lon
+
+
+def bernoulli(p, size=None):
+    """Bernoulli draws (boolean array) with success probability ``p`` (utils/random.py:236-244)."""
+    if isinstance(size, int):
+        size = (size,)
+    if size is None:
+        size = np.shape(p)
+    return np.random.rand(*size) < p
+
+
+def categorical(p, size=None):
+    """Class labels drawn with (unnormalised) probabilities ``p[..., k]``
+    (utils/random.py:247-287)."""
+    p = np.asarray(p, dtype=np.float64)
+    if size is None:
+        size = p.shape[:-1]
+    if isinstance(size, int):
+        size = (size,)
+    size = tuple(size)
+    if np.any(p < 0):
+        raise ValueError("Array contains negative probabilities")
+    try:
+        ok = broadcasted_shape(p.shape[:-1], size) == size
+    except ValueError:
+        ok = False
+    if not ok:
+        raise ValueError("Probability array shape and requested size are inconsistent")
+    c = np.cumsum(p / np.sum(p, axis=-1, keepdims=True), axis=-1)
+    x = np.random.rand(*size)
+    return np.sum(x[..., None] > np.broadcast_to(c, size + c.shape[-1:]), axis=-1) \
+        .clip(0, p.shape[-1] - 1).astype(int)
+
+
+def multinomial(n, p, size=None):
+    """Count vectors of ``n`` trials with probabilities ``p`` (utils/random.py:290-316)."""
+    n, p = np.asarray(n), np.asarray(p, dtype=np.float64)
+    k = p.shape[-1]
+    if size is None:
+        size = broadcasted_shape(n.shape, p.shape[:-1])
+    size = tuple(size)
+    n = np.broadcast_to(n, size)
+    p = np.broadcast_to(p, size + (k,))
+    x = np.empty(size + (k,))
+    for i in np.ndindex(*size):
+        x[i] = np.random.multinomial(n[i], p[i])
+    return x.astype(int)
+
+
+def gamma(a, b, size=None):
+    """Gamma draws with shape ``a`` and SCALE ``b`` (utils/random.py:319-326)."""
+    x = np.random.gamma(a, b, size=size)
+    if np.any(x == 0):
+        raise RuntimeError("Numerically zero samples. Try using a larger shape parameter in "
+                           "the gamma distribution.")
+    return x
+
+
+def dirichlet(alpha, size=None):
+    """Dirichlet draws with concentration ``alpha`` (utils/random.py:329-347)."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    if isinstance(size, int):
+        size = (size,)
+    size = alpha.shape if size is None else tuple(size) + alpha.shape[-1:]
+    p = np.random.gamma(alpha, size=size)
+    s = np.sum(p, axis=-1, keepdims=True)
+    if np.any(s == 0):
+        raise RuntimeError("Numerically zero samples. Try using a larger Dirichlet "
+                           "concentration parameter value.")
+    return p / s
+
+
+def logodds_to_probability(x):
+    """1 / (1 + exp(-x))  (utils/random.py:350-354)."""
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))

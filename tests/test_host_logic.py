@@ -188,3 +188,38 @@ def test_count_node_constructors():
     assert s.plates == (5, 3) and s.dims == ((2,), (2, 2))
     Y = N.GaussianARD(s, 1.0)
     assert Y.plates == (5, 3) and Y.shape == (2,)
+
+
+def test_random_data_generation_helpers():
+    """bayespy.utils.random set-up helpers (host, NumPy): shapes, ranges and basic statistics."""
+    from bayespy_amd.utils import random as r
+    np.random.seed(3)
+    m = r.mask(200, 50, p=0.8)
+    assert m.shape == (200, 50) and m.dtype == bool and abs(m.mean() - 0.8) < 0.02
+    C = r.covariance(4, size=(3,))
+    assert C.shape == (3, 4, 4) and np.all(np.linalg.eigvalsh(C) > 0)
+    np.testing.assert_allclose(C, np.swapaxes(C, -1, -2), rtol=1e-10)
+    Q = r.orth(5)
+    np.testing.assert_allclose(Q @ Q.T, np.identity(5), atol=1e-12)
+    np.testing.assert_allclose(np.linalg.svd(r.svd(np.array([3.0, 2.0, 1.0])))[1], [3, 2, 1], rtol=1e-10)
+    np.testing.assert_allclose(np.diag(r.correlation(4)), 1.0, rtol=1e-12)
+    z = r.categorical([0.1, 0.2, 0.7], size=5000)
+    assert z.shape == (5000,) and set(np.unique(z)) <= {0, 1, 2}
+    assert abs(np.mean(z == 2) - 0.7) < 0.03
+    z = r.categorical(np.array([[1.0, 0.0], [0.0, 1.0]]))
+    assert list(z) == [0, 1]
+    with pytest.raises(ValueError, match='negative'):
+        r.categorical([-0.1, 1.1])
+    x = r.multinomial([5, 9], [[0.5, 0.5, 0.0], [0.1, 0.1, 0.8]])
+    assert x.shape == (2, 3) and list(x.sum(-1)) == [5, 9] and x[0, 2] == 0
+    b = r.bernoulli(np.array([0.0, 1.0, 1.0]))
+    assert list(b) == [False, True, True]
+    d = r.dirichlet(np.ones(4), size=(6,))
+    assert d.shape == (6, 4)
+    np.testing.assert_allclose(d.sum(-1), 1.0, rtol=1e-12)
+    assert r.gamma(2.0, 3.0, size=(4,)).shape == (4,)
+    np.testing.assert_allclose(r.logodds_to_probability([0.0, np.log(3.0)]), [0.5, 0.75])
+    lat, lon = r.sphere(10)
+    assert np.all(np.abs(lat) <= 90) and np.all(np.abs(lon) <= 180)
+    with pytest.raises(ValueError, match='greater than'):
+        r.covariance(4, nu=3)
