@@ -618,3 +618,38 @@ def test_plate_indexing_and_choose_match_reference(golden_dir):
     u = np.asarray(X.get_moments()[0])
     np.testing.assert_array_equal(np.broadcast_to(r.get_moments()[0], (4, 2)),
                                   np.broadcast_to(u, (4, 5))[::-1, 1::2])
+
+
+def test_alpha_beta_recursion_at_scale_properties_and_oracle():
+    """2e4 chains x 500 transitions x 8 states (4 GB of transition slices): a random subset of
+    chains against the NumPy oracle (oracle/hmm.py, pinned to the reference), and for ALL
+    chains the size-independent properties -- every pairwise marginal sums to one, consecutive
+    slices agree on the marginal of the instance they share, q(z_0) is the row sum of the first
+    slice, the log-normalisers are finite, and two runs are bit-identical."""
+    import torch
+    from bayespy_amd.darray import DArray
+    from bayespy_amd.device import get_runtime
+    from bayespy_amd.utils import random as drandom
+    from oracle import hmm
+    rt = get_runtime()
+    B, N, K = 20000, 500, 8
+    gen = torch.Generator(device=rt.device).manual_seed(11)
+    logp0 = torch.randn(B, K, dtype=torch.float64, device=rt.device, generator=gen)
+    logP = 2.0 * torch.randn(B, N, K, K, dtype=torch.float64, device=rt.device, generator=gen)
+    z0, zz, g = drandom.alpha_beta_recursion(DArray(logp0), DArray(logP))
+    tot = zz.t.sum(dim=(-1, -2))
+    assert float((tot - 1.0).abs().max()) < 1e-12
+    out_n = zz.t[:, :-1].sum(dim=-2)             # q(z_{n+1}) from slice n
+    in_n = zz.t[:, 1:].sum(dim=-1)               # q(z_{n+1}) from slice n+1
+    assert float((out_n - in_n).abs().max()) < 1e-10
+    assert float((z0.t - zz.t[:, 0].sum(dim=-1)).abs().max()) < 1e-12
+    assert bool(torch.isfinite(g.t).all())
+    idx = np.random.RandomState(0).choice(B, size=40, replace=False)
+    ti = torch.from_numpy(idx).to(rt.device)
+    r0, rzz, rg = hmm.alpha_beta_recursion(logp0[ti].cpu().numpy(), logP[ti].cpu().numpy())
+    np.testing.assert_allclose(g.t[ti].cpu().numpy(), rg, rtol=1e-12)
+    np.testing.assert_allclose(z0.t[ti].cpu().numpy(), r0, rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(zz.t[ti].cpu().numpy(), rzz, rtol=1e-8, atol=1e-15)
+    # bit-reproducible from run to run
+    z0b, zzb, gb = drandom.alpha_beta_recursion(DArray(logp0), DArray(logP))
+    assert torch.equal(zz.t, zzb.t) and torch.equal(g.t, gb.t)

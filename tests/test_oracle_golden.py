@@ -50,3 +50,15 @@ def test_synthetic_data_is_deterministic():
     y2, x2 = make_pca_data(300, 8, 3, seed=5, chunk=128)
     assert np.array_equal(y1, y2) and np.array_equal(x1, x2)
     assert y1.shape == (8, 300) and x1.shape == (300, 3)
+
+
+def test_hmm_oracle_matches_reference_recursions(golden_dir):
+    """oracle/hmm.py against random.alpha_beta_recursion of the live reference (six shapes,
+    incl. an impossible state and 300 chains)."""
+    from oracle import hmm
+    f = np.load(os.path.join(golden_dir, 'markov_chains.npz'))
+    for tag in ('ab_a', 'ab_b', 'ab_c', 'ab_d', 'ab_e', 'ab_f'):
+        z0, zz, g = hmm.alpha_beta_recursion(f[tag + '_logp0'], f[tag + '_logP'])
+        np.testing.assert_allclose(g, f[tag + '_g'], rtol=1e-12, atol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(z0, f[tag + '_z0'], rtol=1e-10, atol=1e-15, err_msg=tag)
+        np.testing.assert_allclose(zz, f[tag + '_zz'], rtol=1e-10, atol=1e-15, err_msg=tag)
