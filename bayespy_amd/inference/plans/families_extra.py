@@ -12,7 +12,7 @@ from ...nodes.node import Constant
 from ...nodes.beta import Beta, Complement
 from ...nodes.binomial import Binomial
 from ...nodes.poisson import Poisson
-from ...nodes.add import Add
+from ...nodes.add import Add, ConcatGaussian
 from ...nodes.take import Take, Concatenate, Gate, Slice
 from ...nodes.categorical_markov_chain import (CategoricalMarkovChain,
                                                 CategoricalMarkovChainToCategorical)
@@ -189,6 +189,53 @@ class AddFamily:
         if mask is not None:
             out = [None if m is None else
                    fuse(lambda a, w: a * w, _arr(m), _trail(mask, (1 + i) * self.ndim))
+                   for i, m in enumerate(out)]
+        return out
+
+
+class ConcatGaussianFamily:
+    """concat_gaussian.py:63-116."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.off = node.offsets
+
+    def mask_to_parent(self, index, mask):
+        return mask
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        return [v, linalg.outer(v, v)]
+
+    def moments(self, ups):
+        xs = [_arr(u[0]) for u in ups]
+        x = misc.concatenate(xs, axis=-1)
+        rows = []
+        for a, ua in enumerate(ups):
+            blocks = [_arr(ua[1]) if a == b else linalg.outer(xs[a], xs[b])
+                      for b in range(len(ups))]
+            rows.append(misc.concatenate(blocks, axis=-1))
+        return [x, misc.concatenate(rows, axis=-2)]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        r = self.off
+        m0, m1 = m_child
+        a, b = r[index], r[index + 1]
+        out0 = None if m0 is None else _arr(m0)[..., a:b]
+        out1 = None
+        if m1 is not None:
+            m1 = _arr(m1)
+            out1 = m1[..., a:b, a:b]
+            for j, u in enumerate(ups):
+                if j == index:
+                    continue
+                t = linalg.mvdot(fuse(lambda q: 2.0 * q, m1[..., a:b, r[j]:r[j + 1]]), _arr(u[0]))
+                out0 = t if out0 is None else fuse(lambda p, q: p + q, out0, t)
+        out = [out0, out1]
+        if mask is not None:
+            out = [None if m is None else fuse(lambda p, w: p * w, _arr(m), _trail(mask, 1 + i))
                    for i, m in enumerate(out)]
         return out
 
@@ -830,6 +877,8 @@ class VaryingGaussianMarkovChainFamily(SwitchingGaussianMarkovChainFamily):
 
 
 def make_extra_family(node):
+    if isinstance(node, ConcatGaussian):
+        return ConcatGaussianFamily(node)
     if isinstance(node, VaryingGaussianMarkovChain):
         return VaryingGaussianMarkovChainFamily(node)
     if isinstance(node, SwitchingGaussianMarkovChain):

@@ -13,7 +13,7 @@ from .multinomial import Multinomial
 from .beta import Beta
 from .binomial import Binomial, Bernoulli
 from .poisson import Poisson
-from .add import Add
+from .add import Add, ConcatGaussian
 from .take import Take, Concatenate, Gate, Choose
 from .mixture import Mixture
 from .gaussian_markov_chain import (GaussianMarkovChain, SwitchingGaussianMarkovChain,
@@ -22,6 +22,6 @@ from .categorical_markov_chain import CategoricalMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
-           'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add',
+           'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add', 'ConcatGaussian',
            'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain',
            'SwitchingGaussianMarkovChain', 'VaryingGaussianMarkovChain']

@@ -42,3 +42,35 @@ class Add(Node):
         self.ndim = nd
         self.dims = (shape, shape + shape)
         self.plates = plates
+
+
+class ConcatGaussian(Node):
+    """``ConcatGaussian(X1, X2, ...)``: Gaussian vectors stacked into one vector along the
+    variable axis (reference concat_gaussian.py:15-116).  The parents are independent under
+    q: the cross blocks of <xx^T> are products of the means."""
+
+    def __init__(self, *nodes, name=None):
+        from .gaussian_markov_chain import GaussianMarkovChain
+        nodes = [n.as_gaussian() if isinstance(n, GaussianMarkovChain) else n for n in nodes]
+        super().__init__(*nodes, plates=(), dims=((), ()), name=name)
+        sizes, plates = [], ()
+        for p in self.parents:
+            if isinstance(p, Constant):
+                if p.value.ndim < 1:
+                    raise ValueError("Input nodes must be (Gaussian) vectors")
+                sizes.append(p.value.shape[-1])
+                plates = broadcasted_shape(plates, p.value.shape[:-1])
+            else:
+                if len(p.dims) != 2 or len(p.dims[0]) != 1:
+                    raise ValueError("Input nodes must be (Gaussian) vectors")
+                sizes.append(p.dims[0][0])
+                plates = broadcasted_shape(plates, p.plates)
+        self.sizes = [int(s) for s in sizes]
+        D = int(sum(sizes))
+        self.offsets = [0]
+        for sz in self.sizes:
+            self.offsets.append(self.offsets[-1] + sz)
+        self.shape = (D,)
+        self.ndim = 1
+        self.dims = ((D,), (D, D))
+        self.plates = plates

@@ -51,7 +51,7 @@ class GaussianARD(Stochastic):
 def _is_gaussian(node):
     from .dot import SumMultiply
     return isinstance(node, (GaussianARD, SumMultiply)) or type(node).__name__ in (
-        'Gaussian', 'MarkovChainToGaussian', 'Add') or getattr(node, '_gaussian_like', False)
+        'Gaussian', 'MarkovChainToGaussian', 'Add', 'ConcatGaussian') or getattr(node, '_gaussian_like', False)
 
 
 class Gaussian(Stochastic):

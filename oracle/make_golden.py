@@ -689,6 +689,11 @@ def varying_case(name):
     _shared_case(name, 'make_varying_inputs', 'run_varying_case', 909, ('tv_L',))
 
 
+def concat_gaussian_case(name):
+    """ConcatGaussian (concat_gaussian.py)."""
+    _shared_case(name, 'make_concat_gaussian_inputs', 'run_concat_gaussian_case', 4242, ('cg_L',))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -780,6 +785,7 @@ def main():
     slice_nodes_case('slice_nodes')
     switching_case('switching_lssm')
     varying_case('varying_lssm')
+    concat_gaussian_case('concat_gaussian')
 
 
 if __name__ == '__main__':

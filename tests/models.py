@@ -689,3 +689,33 @@ def run_varying_case(nodes_mod, vb_cls, g, **vb_kwargs):
         out['tv_%s_u' % nm] = [np.array(u) for u in nd.get_moments()]
         out['tv_%s_Lterm' % nm] = np.array(Q.l[nd][:5])
     return out
+
+
+def make_concat_gaussian_inputs(rs):
+    """Seeded inputs of run_concat_gaussian_case (tests/golden/concat_gaussian.npz)."""
+    def spd(d):
+        a = rs.normal(size=(d, d))
+        return a @ a.T + d * np.eye(d)
+    N, D1, D2, D3 = 5, 3, 4, 2
+    return dict(cg_m1=rs.normal(size=(N, D1)), cg_L1=spd(D1), cg_m2=rs.normal(size=(N, D2)),
+                cg_L2=spd(D2), cg_x3=rs.normal(size=(N, D3)), cg_V=spd(D1 + D2 + D3),
+                cg_y=rs.normal(size=(N, D1 + D2 + D3)))
+
+
+def run_concat_gaussian_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """ConcatGaussian of two latent Gaussian vectors and a constant under a full-covariance
+    Gaussian observation (nodes/tests/test_gaussian.py:1413-1500)."""
+    N_ = nodes_mod
+    X1 = N_.Gaussian(g['cg_m1'], g['cg_L1'], name='X1')
+    X2 = N_.Gaussian(g['cg_m2'], g['cg_L2'], name='X2')
+    Z = N_.ConcatGaussian(X1, X2, g['cg_x3'], name='Z')
+    Y = N_.Gaussian(Z, g['cg_V'], name='Y')
+    Y.observe(g['cg_y'])
+    out = {'cg_Z0_u': [np.array(v) for v in Z.get_moments()]}
+    Q = vb_cls(Y, X1, X2, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=3, verbose=False)
+    out['cg_L'] = np.array(Q.L[:3])
+    for nm, nd in dict(X1=X1, X2=X2, Z=Z).items():
+        out['cg_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
+    return out

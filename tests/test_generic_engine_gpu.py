@@ -653,3 +653,16 @@ def test_alpha_beta_recursion_at_scale_properties_and_oracle():
     # bit-reproducible from run to run
     z0b, zzb, gb = drandom.alpha_beta_recursion(DArray(logp0), DArray(logP))
     assert torch.equal(zz.t, zzb.t) and torch.equal(g.t, gb.t)
+
+
+def test_concat_gaussian_matches_reference(golden_dir):
+    """ConcatGaussian (concat_gaussian.py:15-116): block moments and the messages with the
+    cross terms through the means of the other blocks."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_concat_gaussian_case
+    f = np.load(os.path.join(golden_dir, 'concat_gaussian.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    _compare_shared(run_concat_gaussian_case(N_, VB, g), f)
+    with pytest.raises(ValueError, match='vectors'):
+        N_.ConcatGaussian(N_.GaussianARD(0, 1), N_.GaussianARD(0, 1, shape=(2,)))
