@@ -518,7 +518,8 @@ class MixtureFamily(Family):
 
     def constant_moments(self, index, value):
         if index == 0:
-            raise NotImplementedError('Mixture needs a Categorical node as its first parent')
+            # fixed class labels (categorical.py:30-46)
+            return [misc.onehot(np.asarray(value).astype(np.int64), self.K)]
         return self.base.constant_moments(index - 1, value)
 
     def _with_cluster_axis(self, u):
@@ -576,8 +577,10 @@ class MixtureFamily(Family):
                 out.append(None)
                 continue
             nd = len(parent.dims[i])
-            # weight by the responsibilities: a lazy product, fused with the plate sum
-            out.append((_arr(m), _trail(p, nd + extra)))
+            # weight by the responsibilities: a lazy product, fused with the plate sum (a nested
+            # mixture hands over a product already: one more factor)
+            inner = tuple(m) if isinstance(m, tuple) else (_arr(m),)
+            out.append(inner + (_trail(p, nd + extra),))
         return out
 
 

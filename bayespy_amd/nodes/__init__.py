@@ -15,13 +15,13 @@ from .binomial import Binomial, Bernoulli
 from .poisson import Poisson
 from .add import Add, ConcatGaussian
 from .take import Take, Concatenate, Gate, Choose
-from .mixture import Mixture
+from .mixture import Mixture, MultiMixture
 from .gaussian_markov_chain import (GaussianMarkovChain, SwitchingGaussianMarkovChain,
                                     VaryingGaussianMarkovChain)
 from .categorical_markov_chain import CategoricalMarkovChain
 
 __all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
-           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture',
+           'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture', 'MultiMixture',
            'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add', 'ConcatGaussian',
            'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain',
            'SwitchingGaussianMarkovChain', 'VaryingGaussianMarkovChain']

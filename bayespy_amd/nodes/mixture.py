@@ -5,7 +5,9 @@ Mixture node (reference: bayespy/inference/vmp/nodes/mixture.py:359-545).
 ``Dist(*params[k])`` where ``k`` is the class of the categorical node ``z`` and the
 parameters carry the cluster axis among their plates.
 """
-from .node import Stochastic
+import numpy as np
+
+from .node import Stochastic, Constant
 from ..utils.shapes import broadcasted_shape
 
 
@@ -15,24 +17,32 @@ class Mixture(Stochastic):
                  plates_multiplier=None, **node_kwargs):
         if cluster_plate != -1:
             raise NotImplementedError('only cluster_plate=-1 is built')
-        # positional arguments beyond the parents of the mixed class are constructor
-        # arguments of that class (the reference forwards them to ``_constructor``, e.g. the
-        # ``ndim`` of ``Mixture(z, GaussianARD, mu, alpha, 1)``; mixture.py:398-420)
         # a categorical Markov chain is seen through its categorical view: the time axis
         # becomes the last plate (moment converter of categorical_markov_chain.py:435-438)
         if hasattr(z, 'as_categorical'):
             z = z.as_categorical()
-        npar = getattr(node_class, '_parent_count', None)
-        extra = ()
-        if npar is not None and len(params) > npar:
-            params, extra = params[:npar], params[npar:]
-        super().__init__(z, *params, plates=(), dims=((), ()), name=name)
+        if node_class is Mixture:
+            # nested mixture, Mixture(z1, Mixture, z2, Dist, *params) (mixture.py:398-420 builds
+            # the mixed distribution recursively): the inner mixture is the mixed "class", its
+            # parents (inner selector first) follow the outer selector
+            proto = Mixture(*params, **node_kwargs)
+            inner = list(proto.parents)
+            super().__init__(z, *inner, plates=(), dims=((), ()), name=name)
+        else:
+            # positional arguments beyond the parents of the mixed class are constructor
+            # arguments of that class (the reference forwards them to ``_constructor``, e.g. the
+            # ``ndim`` of ``Mixture(z, GaussianARD, mu, alpha, 1)``)
+            npar = getattr(node_class, '_parent_count', None)
+            extra = ()
+            if npar is not None and len(params) > npar:
+                params, extra = params[:npar], params[npar:]
+            super().__init__(z, *params, plates=(), dims=((), ()), name=name)
+            # a throw-away instance of the mixed node class gives dims and plates
+            # (with the cluster axis still among the plates)
+            proto = node_class(*self.parents[1:], *extra, **node_kwargs)
         self._plates_multiplier_arg = plates_multiplier
         self.node_class = node_class
         self.cluster_plate = cluster_plate
-        # a throw-away instance of the mixed node class gives dims and plates
-        # (with the cluster axis still among the plates)
-        proto = node_class(*self.parents[1:], *extra, **node_kwargs)
         for p in self.parents[1:]:
             p.children = [(c, i) for (c, i) in p.children if c is not proto]
         self._proto = proto
@@ -40,14 +50,28 @@ class Mixture(Stochastic):
         if hasattr(proto, 'shape'):
             self.shape = proto.shape
             self.ndim = proto.ndim
-        K = self.parents[0].dims[0][0]
         pp = proto.plates
+        zn = self.parents[0]
+        if isinstance(zn, Constant):
+            # fixed class labels: the number of classes is the cluster plate of the parameters
+            # (CategoricalMoments.compute_fixed_moments, categorical.py:30-46)
+            if len(pp) < 1:
+                raise ValueError('The parameters have no cluster plate')
+            K = pp[-1]
+            if np.any(zn.value != np.round(zn.value)):
+                raise ValueError("Values must be integers")
+            if np.any(zn.value < 0) or np.any(zn.value >= K):
+                raise ValueError("Invalid category index")
+            zplates = zn.value.shape
+        else:
+            K = zn.dims[0][0]
+            zplates = zn.plates
         if len(pp) < 1 or pp[-1] not in (1, K):
             raise ValueError('The cluster plate (%s) of the parameters does not match the '
                              'number of categories %d' % (pp[-1:] or None, K))
         self.clusters = K
         given = tuple(plates) if plates is not None else ()
-        self.plates = broadcasted_shape(given, self.parents[0].plates, pp[:-1])
+        self.plates = broadcasted_shape(given, zplates, pp[:-1])
         if plates is not None and self.plates != given:
             raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
 
@@ -60,3 +84,16 @@ class Mixture(Stochastic):
             self._proto._check_value_shape(x)
         finally:
             self._proto.plates = saved
+
+
+def MultiMixture(thetas, *mixture_args, **kwargs):
+    """A mixture over several cluster axes with as many categorical selectors: selector i gets i
+    trailing unit plate axes and the mixtures are nested,
+    ``Mixture(t0, Mixture, t1, ..., Mixture, t_last, *mixture_args)``  (mixture.py:547-566)."""
+    from .node import Node
+    thetas = [t if isinstance(t, Node) else np.asanyarray(t) for t in thetas]
+    thetas = [t[(Ellipsis,) + i * (None,)] for i, t in enumerate(thetas)]
+    args = [thetas[0]]
+    for t in thetas[1:]:
+        args += [Mixture, t]
+    return Mixture(*(args + list(mixture_args)), **kwargs)

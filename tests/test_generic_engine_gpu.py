@@ -666,3 +666,69 @@ def test_concat_gaussian_matches_reference(golden_dir):
     _compare_shared(run_concat_gaussian_case(N_, VB, g), f)
     with pytest.raises(ValueError, match='vectors'):
         N_.ConcatGaussian(N_.GaussianARD(0, 1), N_.GaussianARD(0, 1, shape=(2,)))
+
+
+def test_nested_mixtures_known_answers():
+    """Nested mixtures with fixed and latent selectors: the Dirichlet counts pinned by the
+    reference's own test (nodes/tests/test_mixture.py:215-256), the equivalence of a nested
+    Mixture and nested Gates (:258-275), and the broadcast-g regression case (:208-212)."""
+    from bayespy_amd.nodes import Categorical, Dirichlet, Mixture, Gate
+    t1 = [1, 1, 0, 3, 3]
+    t2 = [2]
+    p = Dirichlet([1, 1], plates=(4, 3))
+    X = Mixture(t1, Mixture, t2, Categorical, p)
+    assert X.plates == (5,)
+    X.observe([1, 1, 0, 0, 0])
+    p.update()
+    np.testing.assert_allclose(
+        np.broadcast_to(p.phi[0], (4, 3, 2)),
+        [[[1, 1], [1, 1], [2, 1]],
+         [[1, 1], [1, 1], [1, 3]],
+         [[1, 1], [1, 1], [1, 1]],
+         [[1, 1], [1, 1], [3, 1]]], rtol=1e-12)
+    # sample plates in nested mixtures
+    t1 = Categorical([0.3, 0.7], plates=(5,))
+    t2 = [[1], [1], [0], [3], [3]]
+    t3 = 2
+    p = Dirichlet([1, 1], plates=(2, 4, 3))
+    X = Mixture(t1, Mixture, t2, Mixture, t3, Categorical, p)
+    X.observe([1, 1, 0, 0, 0])
+    p.update()
+    np.testing.assert_allclose(
+        np.broadcast_to(p.phi[0], (2, 4, 3, 2)),
+        [[[[1, 1], [1, 1], [1.3, 1]],
+          [[1, 1], [1, 1], [1, 1.6]],
+          [[1, 1], [1, 1], [1, 1]],
+          [[1, 1], [1, 1], [1.6, 1]]],
+         [[[1, 1], [1, 1], [1.7, 1]],
+          [[1, 1], [1, 1], [1, 2.4]],
+          [[1, 1], [1, 1], [1, 1]],
+          [[1, 1], [1, 1], [2.4, 1]]]], rtol=1e-12)
+
+    # Gate and nested Mixture are equal
+    def build(nested):
+        a = Categorical([0.3, 0.7], plates=(5,))
+        b = Categorical([0.1, 0.3, 0.6], plates=(5, 1))
+        q = Dirichlet([1, 2, 3, 4], plates=(2, 3))
+        Y = Mixture(a, Mixture, b, Categorical, q) if nested else Categorical(Gate(a, Gate(b, q)))
+        Y.observe([3, 3, 1, 2, 2])
+        for nd in (a, b, q):
+            nd.update()
+        return [np.asarray(nd.phi[0]) for nd in (a, b, q)]
+    for x, y in zip(build(True), build(False)):
+        np.testing.assert_allclose(x, y, rtol=1e-12)
+    # MultiMixture = the nesting with trailing unit axes on the selectors (mixture.py:547-566)
+    from bayespy_amd.nodes import MultiMixture
+    p = Dirichlet([1, 1], plates=(4, 3))
+    X = MultiMixture([[1, 1, 0, 3, 3], [2]], Categorical, p)
+    assert X.plates == (5,)
+    X.observe([1, 1, 0, 0, 0])
+    p.update()
+    np.testing.assert_allclose(np.broadcast_to(p.phi[0], (4, 3, 2))[:, 2],
+                               [[2, 1], [1, 3], [1, 1], [3, 1]], rtol=1e-12)
+    # the mixed distribution broadcasts g
+    Z = Categorical([0.3, 0.5, 0.2])
+    X = Mixture(Z, Categorical, [[0.2, 0.8], [0.1, 0.9], [0.3, 0.7]])
+    Z.update()
+    assert np.isfinite(X.lower_bound_contribution())
+    np.testing.assert_allclose(np.sum(Z.u[0]), 1.0, rtol=1e-12)
