@@ -732,3 +732,43 @@ def test_nested_mixtures_known_answers():
     Z.update()
     assert np.isfinite(X.lower_bound_contribution())
     np.testing.assert_allclose(np.sum(Z.u[0]), 1.0, rtol=1e-12)
+
+
+def test_latent_mixture_moments_and_messages_known_answers():
+    """A latent Mixture node (moments from its parents, a child above it): the known answers of
+    the reference's nodes/tests/test_mixture.py:60-160 -- moments 2 and 2^2+1, and the messages
+    to the selector and to the cluster means (incl. a precision without a cluster axis)."""
+    from bayespy_amd.nodes import GaussianARD, Gamma, Categorical, Mixture
+    K = 3
+    for mean in ([0, 2, 4], 2):
+        mu = GaussianARD(mean, 1, ndim=0, plates=(K,))
+        alpha = Gamma(1, 1, plates=(K,))
+        z = Categorical(np.ones(K) / K)
+        X = Mixture(z, GaussianARD, mu, alpha)
+        assert X.plates == () and X.dims == ((), ())
+        u = X.get_moments()
+        np.testing.assert_allclose(u[0], 2, rtol=1e-12)
+        np.testing.assert_allclose(u[1], 2 ** 2 + 1, rtol=1e-12)
+    for aplates in ((K,), ()):
+        Mu = GaussianARD(2, 1, ndim=0, plates=(K,))
+        Alpha = Gamma(3, 1, plates=aplates)
+        z = Categorical(np.ones(K) / K)
+        X = Mixture(z, GaussianARD, Mu, Alpha)
+        Y = GaussianARD(X, 4)
+        Y.observe(5)
+        m, mm = [np.asarray(v) for v in Mu.get_moments()]
+        a, loga = [np.asarray(v) for v in Alpha.get_moments()]
+        x, xx = [float(np.asarray(v)) for v in X.get_moments()]
+        # message to z: E[log N(x | mu_k, alpha_k^-1)]  (random.gaussian_logpdf, :131-137)
+        # with D = 0: the mixture passes f = 0, no log(2 pi) term (mixture.py:92-98)
+        logp = -0.5 * xx * a + x * a * m - 0.5 * mm * a + 0.5 * loga
+        prior = np.log(np.ones(K) / K)
+        z.update()
+        np.testing.assert_allclose(np.broadcast_to(z.phi[0], (K,)),
+                                   np.broadcast_to(prior + logp, (K,)), rtol=1e-12)
+        # message to Mu: [1/K alpha x, -1/2 1/K alpha] on top of the prior phi = [2, -1/2]
+        zk = np.asarray(z.get_moments()[0])
+        Mu.update()
+        np.testing.assert_allclose(np.broadcast_to(Mu.phi[0], (K,)), 2 + zk * a * x, rtol=1e-12)
+        np.testing.assert_allclose(np.broadcast_to(Mu.phi[1], (K,)), -0.5 - 0.5 * zk * a,
+                                   rtol=1e-12)
