@@ -207,18 +207,28 @@ class GaussianARDFamily(Family):
         self.shape = node.shape
         self.ndim = node.ndim
         mu = node.parents[0]
+        # a Gaussian mean parent with k variable axes: they are the LAST k axes of this node's
+        # (plates + shape) grid; with k > ndim (e.g. the reference's default ndim = 0 under a
+        # vector-valued mean, gaussian.py:1617-1640) the leading k - ndim of them are plates here
         self.mu_ndim = 0 if isinstance(mu, Constant) else len(mu.dims[0])
-        if self.mu_ndim not in (0, self.ndim):
+        self.mu_shape = () if isinstance(mu, Constant) else tuple(mu.dims[0])
+        if 0 < self.mu_ndim < self.ndim:
             raise NotImplementedError('mean parent with %d variable axes for a node with %d'
                                       % (self.mu_ndim, self.ndim))
 
     def plates_to_parent(self, index):
-        if index == 0 and self.mu_ndim == self.ndim:
-            return self.node.plates
-        return self.node.plates + self.shape
+        grid = self.node.plates + self.shape
+        if index == 0 and self.mu_ndim > 0:
+            return grid[:len(grid) - self.mu_ndim]
+        return grid
 
     def mask_to_parent(self, index, mask):
-        if index == 0 and self.mu_ndim == self.ndim:
+        if index == 0 and self.mu_ndim > 0:
+            j = self.mu_ndim - self.ndim
+            mask = np.asarray(mask)
+            if j > 0 and mask.ndim > 0:
+                # plates of this node that are variable axes of the mean: "sum" over them
+                mask = np.any(mask, axis=tuple(range(-min(j, mask.ndim), 0)))
             return mask
         return mask.reshape(mask.shape + (1,) * self.ndim) if self.ndim else mask
 
@@ -231,9 +241,8 @@ class GaussianARDFamily(Family):
     def _mu(self, up):
         """(m, m2) elementwise over plates + shape."""
         m, mm = up[0]
-        if self.mu_ndim == self.ndim and self.ndim > 0 and not isinstance(self.node.parents[0],
-                                                                           Constant):
-            return m, misc.get_diag(mm, ndim=self.ndim)
+        if self.mu_ndim > 0:
+            return m, misc.get_diag(mm, ndim=self.mu_ndim)
         return m, mm
 
     def phi_from_parents(self, up):
@@ -300,9 +309,9 @@ class GaussianARDFamily(Family):
         a = up[1][0]
         if index == 0:
             m0 = fuse(lambda a_, x_: a_ * x_, a, x)
-            if self.mu_ndim == self.ndim and self.ndim > 0:
-                d = fuse(lambda a_, o: -0.5 * a_ * o, a, _ones(self.shape))
-                return [m0, misc.diag(d, ndim=self.ndim)]
+            if self.mu_ndim > 0:
+                d = fuse(lambda a_, o: -0.5 * a_ * o, a, _ones(self.mu_shape))
+                return [m0, misc.diag(d, ndim=self.mu_ndim)]
             return [m0, fuse(lambda a_: -0.5 * a_, a)]
         m, m2 = self._mu(up)
         x2 = misc.get_diag(u[1], ndim=self.ndim) if self.ndim else u[1]
@@ -500,12 +509,26 @@ class MixtureFamily(Family):
         self.base = base                 # family of the mixed distribution (on node._proto)
         self.K = node.clusters
         self.ndims = [len(d) for d in node.dims]
+        # the cluster axis among the plates of the mixed distribution (negative; -1 = last).
+        # Internally the formulas always see it as the LAST of those plates: parameter moments
+        # are re-viewed with the axis moved there (_cluster_last) and messages moved back
+        self.cp = node.cluster_plate
+
+    def _plates_with_cluster(self, k):
+        """The node's plates with the cluster axis (of extent k) at its position."""
+        p = list(self.node.plates)
+        p.insert(len(p) + self.cp + 1, k)
+        return tuple(p)
+
+    def _extra(self, index):
+        """Number of variable axes the mixed family maps onto plates of parameter `index`."""
+        return len(self.plates_to_parent(index)) - len(self.node.plates) - 1
 
     def plates_to_parent(self, index):
         if index == 0:
             return self.node.plates
         saved = self.base.node.plates
-        self.base.node.plates = self.node.plates + (self.K,)
+        self.base.node.plates = self._plates_with_cluster(self.K)
         try:
             return self.base.plates_to_parent(index - 1)
         finally:
@@ -514,7 +537,52 @@ class MixtureFamily(Family):
     def mask_to_parent(self, index, mask):
         if index == 0:
             return mask
-        return self.base.mask_to_parent(index - 1, mask.reshape(mask.shape + (1,)))
+        mask = np.asarray(mask)
+        if self.cp == -1:
+            mask = mask.reshape(mask.shape + (1,))
+        elif mask.ndim >= -self.cp - 1:
+            mask = np.expand_dims(mask, mask.ndim + self.cp + 1)
+        return self.base.mask_to_parent(index - 1, mask)
+
+    def _cluster_last(self, up):
+        """Parameter moments with the cluster axis moved behind the other plates of the mixed
+        distribution (stride-only views)."""
+        if self.cp == -1:
+            return up
+        out = [up[0]]
+        for j, u in enumerate(up[1:], start=1):
+            ex = self._extra(j)
+            par = self.node.parents[j]
+            full = len(self.node.plates) + 1 + ex
+            moved = []
+            for i, x in enumerate(u):
+                if not isinstance(x, DArray):
+                    moved.append(x)
+                    continue
+                nd = 0 if isinstance(par, Constant) else len(par.dims[i])
+                # variable axes of a constant parameter: whatever exceeds the full plate rank
+                if isinstance(par, Constant):
+                    nd = max(0, x.ndim - full)
+                if x.ndim - nd < full:
+                    x = x.reshape((1,) * (full - (x.ndim - nd)) + x.shape)
+                moved.append(misc.moveaxis(x, self.cp - ex - nd, -1 - ex - nd))
+            out.append(moved)
+        return out
+
+    def _cluster_back(self, m, index, nd):
+        """A message to parameter `index` (cluster axis last of the plates) in the parameter's
+        own axis order."""
+        if self.cp == -1:
+            return m
+        ex = self._extra(index)
+        full = len(self.node.plates) + 1 + ex + nd
+
+        def back(x):
+            x = _arr(x)
+            if x.ndim < full:
+                x = x.reshape((1,) * (full - x.ndim) + x.shape)
+            return misc.moveaxis(x, -1 - ex - nd, self.cp - ex - nd)
+        return tuple(back(x) for x in m) if isinstance(m, tuple) else back(m)
 
     def constant_moments(self, index, value):
         if index == 0:
@@ -531,6 +599,7 @@ class MixtureFamily(Family):
         return out
 
     def phi_from_parents(self, up):
+        up = self._cluster_last(up)
         p = up[0][0]
         phik = self.base.phi_from_parents(up[1:])
         out = []
@@ -543,6 +612,7 @@ class MixtureFamily(Family):
         return self.base.moments_and_cgf(phi)
 
     def cgf_from_parents(self, up):
+        up = self._cluster_last(up)
         p = up[0][0]
         gk = self.base.cgf_from_parents(up[1:])
         return misc.sum_multiply(p, _arr(gk), axis=-1)
@@ -554,6 +624,7 @@ class MixtureFamily(Family):
         return self.base.gradient(rg, u, phi)          # mixture.py:352-356
 
     def message_to_parent(self, index, u, up):
+        up = self._cluster_last(up)
         uk = self._with_cluster_axis(u)
         if index == 0:
             # E[log p(y | cluster k)] for every cluster (mixture.py:67-104, expfamily.py:45-61)
@@ -571,7 +642,7 @@ class MixtureFamily(Family):
         parent = self.node.parents[index]
         # variable axes the mixed family maps onto plates of this parent (the precision of a
         # GaussianARD has the variable's shape among its plates) trail the cluster axis too
-        extra = len(self.plates_to_parent(index)) - len(self.node.plates) - 1
+        extra = self._extra(index)
         for i, m in enumerate(msgs):
             if m is None:
                 out.append(None)
@@ -580,7 +651,7 @@ class MixtureFamily(Family):
             # weight by the responsibilities: a lazy product, fused with the plate sum (a nested
             # mixture hands over a product already: one more factor)
             inner = tuple(m) if isinstance(m, tuple) else (_arr(m),)
-            out.append(inner + (_trail(p, nd + extra),))
+            out.append(self._cluster_back(inner + (_trail(p, nd + extra),), index, nd))
         return out
 
 

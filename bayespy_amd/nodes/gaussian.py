@@ -21,11 +21,18 @@ class GaussianARD(Stochastic):
         self._plates_multiplier_arg = plates_multiplier
         mu_node, alpha_node = self.parents
         mu_shape = mu_node.plates + (mu_node.dims[0] if _is_gaussian(mu_node) else ())
+        if shape is not None and ndim is not None and ndim != len(shape):
+            raise ValueError("Given shape and ndim inconsistent")
         if shape is None:
             if ndim is None:
-                shape = mu_node.dims[0] if _is_gaussian(mu_node) else ()
+                # like the reference: scalar-valued unless told otherwise, whatever the mean
+                # is; variable axes of a Gaussian mean become plates (gaussian.py:1617-1622)
+                shape = ()
             else:
                 full = broadcasted_shape(mu_shape, alpha_node.plates)
+                if ndim > len(full):
+                    raise ValueError("Cannot determine shape for ndim={0} because parent full "
+                                     "shape has ndim={1}.".format(ndim, len(full)))
                 shape = full[len(full) - ndim:] if ndim > 0 else ()
         shape = tuple(int(s) for s in shape)
         nd = len(shape)

@@ -15,8 +15,10 @@ class Mixture(Stochastic):
 
     def __init__(self, z, node_class, *params, cluster_plate=-1, plates=None, name=None,
                  plates_multiplier=None, **node_kwargs):
-        if cluster_plate != -1:
-            raise NotImplementedError('only cluster_plate=-1 is built')
+        if not isinstance(cluster_plate, (int, np.integer)) or cluster_plate >= 0:
+            raise ValueError("Cluster plate axis must be negative")
+        if cluster_plate != -1 and node_class is Mixture:
+            raise NotImplementedError('nested mixtures are built for cluster_plate=-1')
         # a categorical Markov chain is seen through its categorical view: the time axis
         # becomes the last plate (moment converter of categorical_markov_chain.py:435-438)
         if hasattr(z, 'as_categorical'):
@@ -55,9 +57,9 @@ class Mixture(Stochastic):
         if isinstance(zn, Constant):
             # fixed class labels: the number of classes is the cluster plate of the parameters
             # (CategoricalMoments.compute_fixed_moments, categorical.py:30-46)
-            if len(pp) < 1:
+            if len(pp) < -cluster_plate:
                 raise ValueError('The parameters have no cluster plate')
-            K = pp[-1]
+            K = pp[cluster_plate]
             if np.any(zn.value != np.round(zn.value)):
                 raise ValueError("Values must be integers")
             if np.any(zn.value < 0) or np.any(zn.value >= K):
@@ -66,12 +68,17 @@ class Mixture(Stochastic):
         else:
             K = zn.dims[0][0]
             zplates = zn.plates
-        if len(pp) < 1 or pp[-1] not in (1, K):
+        if len(pp) < -cluster_plate:
+            raise ValueError("The mixed distribution does not have a plates axis for the "
+                             "cluster plate axis")
+        if pp[cluster_plate] not in (1, K):
             raise ValueError('The cluster plate (%s) of the parameters does not match the '
-                             'number of categories %d' % (pp[-1:] or None, K))
+                             'number of categories %d' % (pp[cluster_plate], K))
         self.clusters = K
         given = tuple(plates) if plates is not None else ()
-        self.plates = broadcasted_shape(given, zplates, pp[:-1])
+        rest = list(pp)
+        rest.pop(cluster_plate)
+        self.plates = broadcasted_shape(given, zplates, tuple(rest))
         if plates is not None and self.plates != given:
             raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
 

@@ -694,6 +694,12 @@ def concat_gaussian_case(name):
     _shared_case(name, 'make_concat_gaussian_inputs', 'run_concat_gaussian_case', 4242, ('cg_L',))
 
 
+def default_ndim_case(name):
+    """GaussianARD's default ndim = 0 under vector- and matrix-valued means."""
+    _shared_case(name, 'make_default_ndim_inputs', 'run_default_ndim_case', 1234,
+                 ('dn_X_plates', 'dn_L', 'dn_Z_plates', 'dn_Z_shape', 'dn2_L'))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -786,6 +792,7 @@ def main():
     switching_case('switching_lssm')
     varying_case('varying_lssm')
     concat_gaussian_case('concat_gaussian')
+    default_ndim_case('default_ndim')
 
 
 if __name__ == '__main__':

@@ -719,3 +719,42 @@ def run_concat_gaussian_case(nodes_mod, vb_cls, g, **vb_kwargs):
     for nm, nd in dict(X1=X1, X2=X2, Z=Z).items():
         out['cg_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
     return out
+
+
+def make_default_ndim_inputs(rs):
+    """Seeded inputs of run_default_ndim_case (tests/golden/default_ndim.npz)."""
+    return dict(dn_y=rs.normal(size=(5, 4, 3)) + np.array([1.0, -1.0, 3.0]),
+                dn_mask=rs.rand(5, 4, 3) < 0.8, dn_y2=rs.normal(size=(4, 2, 3)))
+
+
+def run_default_ndim_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """GaussianARD without ndim / shape is scalar-valued whatever its mean is
+    (gaussian.py:1617-1640): the variable axes of a Gaussian mean become plates of the node, the
+    posterior factorises over them; ndim=1 under a matrix-valued mean keeps one axis."""
+    N_ = nodes_mod
+    out = {}
+    mu = N_.GaussianARD(0, 1e-1, shape=(3,), plates=(4,), name='mu')
+    alpha = N_.Gamma(1e-1, 1e-1, plates=(3,), name='alpha')
+    X = N_.GaussianARD(mu, alpha, name='X')
+    out['dn_X_plates'], out['dn_X_ndims'] = np.array(X.plates), np.array([len(d) for d in X.dims])
+    tau = N_.Gamma(1e-1, 1e-1, name='tau')
+    Y = N_.GaussianARD(X, tau, plates=(5, 4, 3), name='Y')
+    Y.observe(g['dn_y'], mask=g['dn_mask'])
+    Q = vb_cls(Y, X, mu, alpha, tau, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=3, verbose=False)
+    out['dn_L'] = np.array(Q.L[:3])
+    for nm, nd in dict(X=X, mu=mu, alpha=alpha, tau=tau).items():
+        out['dn_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
+    M = N_.GaussianARD(0, 1e-1, shape=(2, 3), plates=(4,), name='M')
+    Z = N_.GaussianARD(M, 2.0, ndim=1, name='Z')
+    out['dn_Z_plates'], out['dn_Z_shape'] = np.array(Z.plates), np.array(Z.dims[0])
+    Y2 = N_.GaussianARD(Z, 1.5, ndim=1, name='Y2')
+    Y2.observe(g['dn_y2'])
+    Q = vb_cls(Y2, Z, M, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=3, verbose=False)
+    out['dn2_L'] = np.array(Q.L[:3])
+    for nm, nd in dict(Z=Z, M=M).items():
+        out['dn2_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
+    return out

@@ -772,3 +772,88 @@ def test_latent_mixture_moments_and_messages_known_answers():
         np.testing.assert_allclose(np.broadcast_to(Mu.phi[0], (K,)), 2 + zk * a * x, rtol=1e-12)
         np.testing.assert_allclose(np.broadcast_to(Mu.phi[1], (K,)), -0.5 - 0.5 * zk * a,
                                    rtol=1e-12)
+
+
+def test_default_ndim_under_vector_means_matches_reference(golden_dir):
+    """GaussianARD(mu, alpha) with a vector-valued Gaussian mean and no ndim / shape: scalar
+    node, the mean's variable axis turns into a plate (the reference's default,
+    gaussian.py:1617-1640); and ndim=1 under a matrix-valued mean."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_default_ndim_case
+    f = np.load(os.path.join(golden_dir, 'default_ndim.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_default_ndim_case(N_, VB, g)
+    assert list(res['dn_X_plates']) == [4, 3] and list(res['dn_X_ndims']) == [0, 0]
+    assert list(res['dn_Z_plates']) == [4, 2] and list(res['dn_Z_shape']) == [3]
+    _compare_shared(res, f)
+
+
+def test_mixture_over_a_non_last_cluster_plate():
+    """``cluster_plate=-2`` / ``-3``.  The reference only supports this while the parameter
+    moments stay constant along the cluster axis (its compute_logpdf mixes the axis orders
+    otherwise), so the checks are: its own known answers (nodes/tests/test_mixture.py:163-200
+    messages, :291-318 masks), and for asymmetric parameters the equality with the same model
+    written with the cluster axis last."""
+    from bayespy_amd.nodes import GaussianARD, Gamma, Categorical, Dirichlet, Mixture
+    from bayespy_amd.inference import VB
+    K, M = 3, 2
+    Mu = GaussianARD(2, 1, ndim=0, plates=(K, M))
+    Alpha = Gamma(3, 1, plates=(K, M))
+    z = Categorical(np.ones(K) / K)
+    X = Mixture(z, GaussianARD, Mu, Alpha, cluster_plate=-2)
+    assert X.plates == (M,)
+    Y = GaussianARD(X, 4)
+    Y.observe(5 * np.ones(M))
+    m, mm = [np.broadcast_to(v, (K, M)) for v in Mu.get_moments()]
+    a, loga = [np.broadcast_to(v, (K, M)) for v in Alpha.get_moments()]
+    x, xx = [np.broadcast_to(v, (M,)) for v in X.get_moments()]
+    logp = -0.5 * xx * a + x * a * m - 0.5 * mm * a + 0.5 * loga
+    z.update()
+    np.testing.assert_allclose(np.broadcast_to(z.phi[0], (K,)),
+                               np.log(np.ones(K) / K) + logp.sum(-1), rtol=1e-12)
+    zk = np.asarray(z.get_moments()[0])
+    Mu.update()
+    np.testing.assert_allclose(np.broadcast_to(Mu.phi[0], (K, M)), 2 + zk[:, None] * a * x, rtol=1e-12)
+    np.testing.assert_allclose(np.broadcast_to(Mu.phi[1], (K, M)), -0.5 - 0.5 * zk[:, None] * a,
+                               rtol=1e-12)
+    # masks (test_mixture.py:291-318)
+    Z = Categorical(np.ones(K) / K, plates=(4, 5, 1))
+    Mu3 = GaussianARD(0, 1, shape=(2,), plates=(4, K, 5))
+    Alpha3 = Gamma(1, 1, plates=(4, K, 5, 2))
+    X3 = Mixture(Z, GaussianARD, Mu3, Alpha3, cluster_plate=-3)
+    assert X3.plates == (4, 5, 2)
+    Y3 = GaussianARD(X3, 1, ndim=1)
+    mask = np.reshape((np.mod(np.arange(4 * 5), 2) == 0), (4, 5))
+    Y3.observe(np.ones((4, 5, 2)), mask=mask)
+    np.testing.assert_array_equal(np.broadcast_to(Z.mask, (4, 5, 1)), mask[:, :, None])
+    np.testing.assert_array_equal(np.broadcast_to(Mu3.mask, (4, 1, 5)), mask[:, None, :])
+    np.testing.assert_array_equal(np.broadcast_to(Alpha3.mask, (4, 1, 5, 1)), mask[:, None, :, None])
+
+    # asymmetric parameters: cluster axis second-last vs. last
+    rs = np.random.RandomState(3)
+    y = rs.normal(size=(6, M)) * 2 + np.array([0.0, 3.0])
+    lab0 = np.array([[0], [1], [2], [0], [1], [2]])
+
+    def run(cp):
+        shape = (K, M) if cp == -2 else (M, K)
+        pi = Dirichlet(np.ones(K))
+        zz = Categorical(pi, plates=(6, 1))
+        mu = GaussianARD(0, 1e-1, ndim=0, plates=shape)
+        al = Gamma(1, 1, plates=shape)
+        Xc = Mixture(zz, GaussianARD, mu, al, cluster_plate=cp)
+        assert Xc.plates == (6, M)
+        zz.initialize_from_value(lab0)
+        Xc.observe(y)
+        Q = VB(Xc, mu, al, zz, pi)
+        Q.ignore_bound_checks = True
+        Q.update(repeat=4, verbose=False)
+        t = (lambda v: np.swapaxes(np.broadcast_to(v, (K, M)), 0, 1)) if cp == -2 else \
+            (lambda v: np.broadcast_to(v, (M, K)))
+        return Q.L[:4], t(mu.get_moments()[0]), t(al.get_moments()[0]), \
+            np.asarray(zz.get_moments()[0])
+    r2, r1 = run(-2), run(-1)
+    for p, q in zip(r2, r1):
+        np.testing.assert_allclose(p, q, rtol=1e-10)
+    with pytest.raises(ValueError, match='negative'):
+        Mixture(z, GaussianARD, Mu, Alpha, cluster_plate=0)

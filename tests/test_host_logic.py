@@ -186,8 +186,14 @@ def test_count_node_constructors():
     b = N.GaussianARD(0, 1, shape=(2,), plates=(1, 3))
     s = N.Add(a, b, np.zeros(2))
     assert s.plates == (5, 3) and s.dims == ((2,), (2, 2))
+    # like the reference, GaussianARD is scalar-valued unless ndim / shape says otherwise: the
+    # variable axis of a Gaussian mean becomes a plate (gaussian.py:1617-1640)
     Y = N.GaussianARD(s, 1.0)
+    assert Y.plates == (5, 3, 2) and Y.shape == ()
+    Y = N.GaussianARD(s, 1.0, ndim=1)
     assert Y.plates == (5, 3) and Y.shape == (2,)
+    with pytest.raises(ValueError, match='inconsistent'):
+        N.GaussianARD(s, 1.0, ndim=2, shape=(2,))
 
 
 def test_random_data_generation_helpers():

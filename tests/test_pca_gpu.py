@@ -262,6 +262,7 @@ def test_headline_size_properties(stats):
     # A was recomputed after the pass only by the NEXT prepare_x; re-run X.update so that
     # A, X and S belong to the same pass
     Q['X'].update()
+    plan.finish()        # the pass runs on the plate stream: join it before reading X directly
     A = plan.state[Lyt.off_A:Lyt.off_A + 32 * DP].reshape(32, DP)[:K, :D].clone()
     idx = torch.randint(0, N, (4096,), device=dev, generator=g)
     assert torch.allclose(plan.Xd[:, idx], A @ y[:, idx], rtol=1e-11, atol=1e-12)
