@@ -336,3 +336,57 @@ def test_fused_gaussian_moments(n, batch):
     bad[batch // 2] = np.eye(n)
     with pytest.raises(_lib.NotPositiveDefiniteError):
         linalg.gaussian_moments(phi0, bad)
+
+
+def test_cabi_of_the_index_and_chain_kernels_directly():
+    """vmp_take_axis / vmp_segment_sum_axis / vmp_alpha_beta_recursion through the raw C ABI:
+    results on plain device buffers, and the status codes for bad arguments."""
+    import torch
+    from bayespy_amd import _lib
+    from bayespy_amd.device import get_runtime, ptr
+    rt = get_runtime()
+    lib = rt.lib
+    dev = rt.device
+    rt.sync_stream()
+    src = torch.arange(2 * 5 * 3, dtype=torch.float64, device=dev)          # (outer 2, axis 5, inner 3)
+    idx = torch.tensor([4, 0, 0, 2], dtype=torch.int64, device=dev)
+    dst = torch.full((2, 6, 3), -1.0, dtype=torch.float64, device=dev)
+    rt.check(lib.vmp_take_axis(rt.ctx, 2, 5, 3, ptr(src), 4, ptr(idx), ptr(dst), 6, 1))
+    ref = src.reshape(2, 5, 3)[:, idx]
+    assert torch.equal(dst[:, 1:5], ref) and torch.all(dst[:, 0] == -1) and torch.all(dst[:, 5] == -1)
+    rt.check(lib.vmp_take_axis(rt.ctx, 2, 5, 3, ptr(src), 5, None, ptr(dst), 6, 0))   # block copy
+    assert torch.equal(dst[:, :5], src.reshape(2, 5, 3))
+    assert lib.vmp_take_axis(rt.ctx, 2, 5, 3, ptr(src), 4, ptr(idx), ptr(dst), 6, 3) == _lib.VMP_ERR_INVALID
+    assert lib.vmp_take_axis(rt.ctx, 2, 5, 3, None, 4, ptr(idx), ptr(dst), 6, 0) == _lib.VMP_ERR_INVALID
+    # segment sum: rows {1,2} -> target 0, row 0 -> target 2, target 1 empty
+    ptr_ = torch.tensor([0, 2, 2, 3], dtype=torch.int64, device=dev)
+    perm = torch.tensor([1, 2, 0], dtype=torch.int64, device=dev)
+    y = torch.arange(2 * 3 * 2, dtype=torch.float64, device=dev)             # (2, 3, 2)
+    out = torch.empty(2, 3, 2, dtype=torch.float64, device=dev)
+    rt.check(lib.vmp_segment_sum_axis(rt.ctx, 2, 3, 2, ptr(y), 3, ptr(ptr_), ptr(perm), ptr(out)))
+    yy = y.reshape(2, 3, 2)
+    assert torch.equal(out[:, 0], yy[:, 1] + yy[:, 2]) and torch.all(out[:, 1] == 0)
+    assert torch.equal(out[:, 2], yy[:, 0])
+    assert lib.vmp_segment_sum_axis(rt.ctx, 2, 3, 2, ptr(y), 3, None, ptr(perm), ptr(out)) == _lib.VMP_ERR_INVALID
+    # forward-backward recursion: two states, one transition -- by hand
+    logp0 = torch.log(torch.tensor([[0.25, 0.75]], dtype=torch.float64, device=dev))
+    P = torch.tensor([[[0.9, 0.1], [0.5, 0.5]]], dtype=torch.float64, device=dev)
+    z0 = torch.empty(1, 2, dtype=torch.float64, device=dev)
+    zz = torch.empty(1, 1, 2, 2, dtype=torch.float64, device=dev)
+    g = torch.empty(1, dtype=torch.float64, device=dev)
+    ws = torch.empty(16, dtype=torch.float64, device=dev)
+    rt.check(lib.vmp_alpha_beta_recursion(rt.ctx, 1, 2, 1, ptr(logp0), 2, ptr(torch.log(P)), 4, 4,
+                                          ptr(z0), ptr(zz), ptr(g), ptr(ws), ws.numel() * 8))
+    joint = torch.tensor([[0.25 * 0.9, 0.25 * 0.1], [0.75 * 0.5, 0.75 * 0.5]], dtype=torch.float64)
+    np.testing.assert_allclose(zz.cpu().numpy()[0, 0], joint.numpy(), rtol=1e-14)
+    np.testing.assert_allclose(z0.cpu().numpy()[0], [0.25, 0.75], rtol=1e-14)
+    np.testing.assert_allclose(g.cpu().numpy(), [0.0], atol=1e-15)
+    rc = lib.vmp_alpha_beta_recursion(rt.ctx, 1, 2, 1, ptr(logp0), 2, ptr(P), 4, 4, ptr(z0), ptr(zz),
+                                      ptr(g), ptr(ws), 8)
+    assert rc == _lib.VMP_ERR_INVALID                    # workspace too small
+    with pytest.raises(ValueError, match='workspace'):
+        rt.check(rc)
+    big = torch.zeros(65 * 65, dtype=torch.float64, device=dev)
+    rc = lib.vmp_alpha_beta_recursion(rt.ctx, 1, 65, 1, ptr(big), 65, ptr(big), 0, 0, ptr(big),
+                                      ptr(big), ptr(big), ptr(big), big.numel() * 8)
+    assert rc == _lib.VMP_ERR_UNSUPPORTED                # more than 64 states
