@@ -37,7 +37,10 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=3)
-    p.add_argument('--n', type=int, default=10_000_000, help='total observation plate size')
+    # (--plates: the same under `python -m torch.distributed.run`, whose own parser rejects the
+    # abbreviation-ambiguous `--n` even behind the script name)
+    p.add_argument('--n', '--plates', dest='n', type=int, default=10_000_000,
+                   help='total observation plate size')
     p.add_argument('--d', type=int, default=128)
     p.add_argument('--k', type=int, default=32)
     p.add_argument('--scaling', choices=['strong', 'weak'], default='strong')
