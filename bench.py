@@ -12,7 +12,9 @@ plus the full lower bound (one device->host read of the ELBO per iteration).
 Workload: BASELINE.json's metric config, PCA N=1e7, D=128, K=32, fully observed,
 fp64, synthetic data of demos/pca.py:70-74 generated on the device.  With N
 GPUs the observation plate N is sharded (strong scaling: the metric is quoted
-on N=1e7 at 1/2/4/8 GPUs) and the child->parent message sums are one RCCL
+on N=1e7 at 1/2/4/8 GPUs).  In the default Gram form the D x D Gram matrix of the data is
+all-reduced once (RCCL) when the model is set up and an iteration needs no exchange at all;
+in the streaming-statistics form (--stats stream) the child->parent message sums are one
 all-reduce per iteration.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
