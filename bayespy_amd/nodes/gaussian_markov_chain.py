@@ -91,6 +91,26 @@ class MarkovChainToGaussian(Node):
         self.ndim = 1
 
 
+def _initial_state(mu_n, L_n):
+    """Dimensionality and plates of the initial-state parents (mean, precision matrix) of a
+    chain (gaussian_markov_chain.py:1897-1907)."""
+    if isinstance(L_n, Constant):
+        if L_n.value.ndim < 2 or L_n.value.shape[-1] != L_n.value.shape[-2]:
+            raise ValueError("Second parent has wrong dimensionality")
+        D, Lpl = L_n.value.shape[-1], L_n.value.shape[:-2]
+    else:
+        D, Lpl = L_n.dims[0][0], L_n.plates
+    if isinstance(mu_n, Constant):
+        if mu_n.value.ndim < 1 or mu_n.value.shape[-1] != D:
+            raise ValueError("First parent has wrong dimensionality")
+        mupl = mu_n.value.shape[:-1]
+    else:
+        if mu_n.dims[0] != (D,):
+            raise ValueError("First parent has wrong dimensionality")
+        mupl = mu_n.plates
+    return D, mupl, Lpl
+
+
 class SwitchingGaussianMarkovChain(GaussianMarkovChain):
     """``SwitchingGaussianMarkovChain(mu, Lambda, B, Z, nu, n=N)``: a Gaussian Markov chain whose
     dynamics matrix at every transition is picked from K matrices by a categorical variable,
@@ -106,20 +126,7 @@ class SwitchingGaussianMarkovChain(GaussianMarkovChain):
             Z = Z.as_categorical()
         Stochastic.__init__(self, mu, Lambda, B, Z, nu, plates=(), dims=((), (), ()), name=name)
         mu_n, L_n, B_n, Z_n, nu_n = self.parents
-        if isinstance(L_n, Constant):
-            if L_n.value.ndim < 2 or L_n.value.shape[-1] != L_n.value.shape[-2]:
-                raise ValueError("Second parent has wrong dimensionality")
-            D, Lpl = L_n.value.shape[-1], L_n.value.shape[:-2]
-        else:
-            D, Lpl = L_n.dims[0][0], L_n.plates
-        if isinstance(mu_n, Constant):
-            if mu_n.value.ndim < 1 or mu_n.value.shape[-1] != D:
-                raise ValueError("First parent has wrong dimensionality")
-            mupl = mu_n.value.shape[:-1]
-        else:
-            if mu_n.dims[0] != (D,):
-                raise ValueError("First parent has wrong dimensionality")
-            mupl = mu_n.plates
+        D, mupl, Lpl = _initial_state(mu_n, L_n)
         if isinstance(B_n, Constant):
             if B_n.value.ndim < 3 or B_n.value.shape[-1] != D:
                 raise ValueError("Third parent has wrong dimensionality")
@@ -181,20 +188,7 @@ class VaryingGaussianMarkovChain(GaussianMarkovChain):
             S = S.as_gaussian()
         Stochastic.__init__(self, mu, Lambda, B, S, nu, plates=(), dims=((), (), ()), name=name)
         mu_n, L_n, B_n, S_n, nu_n = self.parents
-        if isinstance(L_n, Constant):
-            if L_n.value.ndim < 2 or L_n.value.shape[-1] != L_n.value.shape[-2]:
-                raise ValueError("Second parent has wrong dimensionality")
-            D, Lpl = L_n.value.shape[-1], L_n.value.shape[:-2]
-        else:
-            D, Lpl = L_n.dims[0][0], L_n.plates
-        if isinstance(mu_n, Constant):
-            if mu_n.value.ndim < 1 or mu_n.value.shape[-1] != D:
-                raise ValueError("First parent has wrong dimensionality")
-            mupl = mu_n.value.shape[:-1]
-        else:
-            if mu_n.dims[0] != (D,):
-                raise ValueError("First parent has wrong dimensionality")
-            mupl = mu_n.plates
+        D, mupl, Lpl = _initial_state(mu_n, L_n)
         if isinstance(B_n, Constant) or isinstance(S_n, Constant):
             raise NotImplementedError('the dynamics matrices and their weights must be nodes')
         if len(B_n.dims[0]) != 2 or B_n.dims[0][0] != D:
