@@ -14,6 +14,8 @@
 // the reference's broadcast-compressed plate semantics are preserved on the device.
 #include "vmp_common.h"
 
+#include <stdint.h>
+
 namespace {
 
 constexpr int NT = 256;
@@ -271,6 +273,7 @@ struct EwiseArgs {
     int32_t ops[VMP_EWISE_MAX_OPS];
     double consts[VMP_EWISE_MAX_CONSTS];
     int64_t total;
+    int pairmask;       // VEC instance: operands read as aligned pairs (the others broadcast)
 };
 
 __global__ void __launch_bounds__(NT)
@@ -328,23 +331,40 @@ ewise_kernel(EwiseArgs a, double *__restrict__ out)
 // the per-operation dispatch is paid once per NE elements.
 constexpr int EW_NE = 4;
 
-template <int NDIM, bool I32>
+// One shared body per special function for the fast instances: inlined into the four-element
+// interpreter they cost ~100 VGPRs, i.e. half of the wavefronts that keep loads in flight.
+__device__ __noinline__ double ew_digamma(double x) { return vmp_digamma(x); }
+__device__ __noinline__ double ew_lgamma(double x) { return vmp_lgamma(x); }
+__device__ __noinline__ double ew_trigamma(double x) { return vmp_trigamma(x); }
+
+// VEC: the innermost axis is contiguous (or broadcast) in every operand and holds an even number
+// of elements: the iteration space is in PAIRS (a.shape / a.total / the innermost strides are
+// set up that way by the launcher), every load and store moves 16 bytes per lane and the index
+// arithmetic is paid once per pair.
+// NI: operand slots compiled in (2, 4 or MAXIN): registers, and with them the number of
+// wavefronts that keep loads in flight, scale with it.
+template <int NDIM, bool I32, bool VEC = false, int NI = MAXIN>
 __global__ void __launch_bounds__(NT)
 ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
 {
-    const int64_t span = (int64_t)gridDim.x * NT;
-    for (int64_t e0 = (int64_t)blockIdx.x * NT + threadIdx.x; e0 < a.total; e0 += span * EW_NE) {
-        double v[MAXIN][EW_NE];
+    constexpr int NJ = VEC ? EW_NE / 2 : EW_NE;       // index decodes per thread and round
+    // a workgroup owns NJ * NT consecutive elements (pairs) per round: its NJ loads per operand
+    // are NT apart, rounds are a whole grid apart
+    constexpr int64_t span = NT;
+    for (int64_t e0 = (int64_t)blockIdx.x * (NT * NJ) + threadIdx.x; e0 < a.total;
+         e0 += (int64_t)gridDim.x * (NT * NJ)) {
+        double v[NI][EW_NE];
         bool ok[EW_NE];
 #pragma unroll
-        for (int j = 0; j < EW_NE; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int64_t e = e0 + j * span;
-            ok[j] = e < a.total;
-            const int64_t ee = ok[j] ? e : 0;
+            const bool okj = e < a.total;
+            if constexpr (!VEC) ok[j] = okj;
+            const int64_t ee = okj ? e : 0;
             // flat index -> one coordinate per (merged) axis; 32-bit divisions when they fit
-            int64_t off[MAXIN];
+            int64_t off[NI];
 #pragma unroll
-            for (int i = 0; i < MAXIN; ++i) off[i] = 0;
+            for (int i = 0; i < NI; ++i) off[i] = 0;
             if (I32) {
                 uint32_t t = (uint32_t)ee;
 #pragma unroll
@@ -353,10 +373,10 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
                     const uint32_t q = t / sz, c = t - q * sz;
                     t = q;
 #pragma unroll
-                    for (int i = 0; i < MAXIN; ++i) off[i] += (int64_t)c * a.stride[i][d];
+                    for (int i = 0; i < NI; ++i) off[i] += (int64_t)c * a.stride[i][d];
                 }
 #pragma unroll
-                for (int i = 0; i < MAXIN; ++i) off[i] += (int64_t)t * a.stride[i][0];
+                for (int i = 0; i < NI; ++i) off[i] += (int64_t)t * a.stride[i][0];
             } else {
                 int64_t t = ee;
 #pragma unroll
@@ -364,13 +384,31 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
                     const int64_t q = t / a.shape[d], c = t - q * a.shape[d];
                     t = q;
 #pragma unroll
-                    for (int i = 0; i < MAXIN; ++i) off[i] += c * a.stride[i][d];
+                    for (int i = 0; i < NI; ++i) off[i] += c * a.stride[i][d];
                 }
 #pragma unroll
-                for (int i = 0; i < MAXIN; ++i) off[i] += t * a.stride[i][0];
+                for (int i = 0; i < NI; ++i) off[i] += t * a.stride[i][0];
             }
+            if constexpr (VEC) {
+                ok[2 * j] = ok[2 * j + 1] = okj;
 #pragma unroll
-            for (int i = 0; i < MAXIN; ++i) v[i][j] = (i < a.nin) ? a.in[i][off[i]] : 0.0;
+                for (int i = 0; i < NI; ++i) {
+                    if (i < a.nin) {
+                        if ((a.pairmask >> i) & 1) {
+                            const v2f64 q = *reinterpret_cast<const v2f64 *>(a.in[i] + off[i]);
+                            v[i][2 * j] = q[0];
+                            v[i][2 * j + 1] = q[1];
+                        } else {
+                            v[i][2 * j] = v[i][2 * j + 1] = a.in[i][off[i]];
+                        }
+                    } else {
+                        v[i][2 * j] = v[i][2 * j + 1] = 0.0;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[i][j] = (i < a.nin) ? a.in[i][off[i]] : 0.0;
+            }
         }
         double s0[EW_NE], s1[EW_NE], s2[EW_NE], s3[EW_NE];
 #pragma unroll
@@ -385,8 +423,14 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
             switch (op) {
             case VMP_OP_IN:
                 // operand index is wave-uniform: a short chain of selects keeps v[] in registers
-                PUSH(arg == 0 ? v[0][j] : arg == 1 ? v[1][j] : arg == 2 ? v[2][j]
-                     : arg == 3 ? v[3][j] : arg == 4 ? v[4][j] : v[5][j]);
+                if constexpr (NI <= 2) {
+                    PUSH(arg == 0 ? v[0][j] : v[1][j]);
+                } else if constexpr (NI <= 4) {
+                    PUSH(arg == 0 ? v[0][j] : arg == 1 ? v[1][j] : arg == 2 ? v[2][j] : v[3][j]);
+                } else {
+                    PUSH(arg == 0 ? v[0][j] : arg == 1 ? v[1][j] : arg == 2 ? v[2][j]
+                         : arg == 3 ? v[3][j] : arg == 4 ? v[4][j] : v[5][j]);
+                }
                 break;
             case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
             case VMP_OP_ADD:     BIN(x + y); break;
@@ -399,9 +443,9 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
             case VMP_OP_SQR:     UNA(x * x); break;
             case VMP_OP_SQRT:    UNA(sqrt(x)); break;
             case VMP_OP_RECIP:   UNA(1.0 / x); break;
-            case VMP_OP_DIGAMMA: UNA(vmp_digamma(x)); break;
-            case VMP_OP_LGAMMA:  UNA(vmp_lgamma(x)); break;
-            case VMP_OP_TRIGAMMA: UNA(vmp_trigamma(x)); break;
+            case VMP_OP_DIGAMMA: UNA(ew_digamma(x)); break;
+            case VMP_OP_LGAMMA:  UNA(ew_lgamma(x)); break;
+            case VMP_OP_TRIGAMMA: UNA(ew_trigamma(x)); break;
             case VMP_OP_MAX:     BIN(fmax(x, y)); break;
             case VMP_OP_MIN:     BIN(fmin(x, y)); break;
             case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;
@@ -416,9 +460,20 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
 #undef PUSH
 #undef BIN
 #undef UNA
+        if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < EW_NE; ++j)
-            if (ok[j]) out[e0 + j * span] = s0[j];
+            for (int j = 0; j < NJ; ++j)
+                if (ok[2 * j]) {
+                    v2f64 q;
+                    q[0] = s0[2 * j];
+                    q[1] = s0[2 * j + 1];
+                    *reinterpret_cast<v2f64 *>(out + 2 * (e0 + j * span)) = q;
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < EW_NE; ++j)
+                if (ok[j]) out[e0 + j * span] = s0[j];
+        }
     }
 }
 
@@ -915,13 +970,50 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
     }
     for (int c = 0; c < nconsts; ++c) a.consts[c] = consts[c];
     if (a.total == 0) return VMP_OK;
-    const dim3 grid((unsigned)grid_for(ctx, a.total, NT * 4));
     const bool i32 = a.total < ((int64_t)1 << 31);
+    // 16-byte accesses: innermost axis contiguous or broadcast in every operand, even extent,
+    // every pair aligned (even outer strides, 16-byte aligned bases)
+    bool vec = i32 && a.ndim >= 1 && a.ndim <= 4 && (a.shape[a.ndim - 1] % 2 == 0) &&
+               (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    int pairmask = 0;
+    for (int i = 0; i < nin && vec; ++i) {
+        const int64_t st = a.stride[i][a.ndim - 1];
+        if (st == 1) {
+            pairmask |= 1 << i;
+            if (reinterpret_cast<uintptr_t>(a.in[i]) % 16 != 0) vec = false;
+            for (int d = 0; d < a.ndim - 1; ++d)
+                if (a.stride[i][d] % 2 != 0) vec = false;
+        } else if (st != 0) {
+            vec = false;
+        }
+    }
+    if (vec) {
+        const int k = a.ndim - 1;
+        a.shape[k] /= 2;
+        a.total /= 2;
+        for (int i = 0; i < nin; ++i)
+            if ((pairmask >> i) & 1) a.stride[i][k] = 2;
+        a.pairmask = pairmask;
+    }
+    const dim3 grid((unsigned)grid_for(ctx, a.total, NT * (vec ? 2 : 4)));
+#define VMP_EW_NI(nd, V)                                                                       \
+    do {                                                                                       \
+        if (nin <= 2)                                                                          \
+            hipLaunchKernelGGL((ewise_small_kernel<nd, true, V, 2>), grid, dim3(NT), 0,        \
+                               ctx->stream, a, out);                                           \
+        else if (nin <= 4)                                                                     \
+            hipLaunchKernelGGL((ewise_small_kernel<nd, true, V, 4>), grid, dim3(NT), 0,        \
+                               ctx->stream, a, out);                                           \
+        else                                                                                   \
+            hipLaunchKernelGGL((ewise_small_kernel<nd, true, V, MAXIN>), grid, dim3(NT), 0,    \
+                               ctx->stream, a, out);                                           \
+    } while (0)
 #define VMP_EW(nd)                                                                             \
     do {                                                                                       \
-        if (i32)                                                                               \
-            hipLaunchKernelGGL((ewise_small_kernel<nd, true>), grid, dim3(NT), 0, ctx->stream, \
-                               a, out);                                                        \
+        if (vec)                                                                               \
+            VMP_EW_NI(nd, true);                                                               \
+        else if (i32)                                                                          \
+            VMP_EW_NI(nd, false);                                                              \
         else                                                                                   \
             hipLaunchKernelGGL((ewise_small_kernel<nd, false>), grid, dim3(NT), 0,             \
                                ctx->stream, a, out);                                           \
@@ -932,6 +1024,7 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
     else if (a.ndim == 4) VMP_EW(4);
     else hipLaunchKernelGGL(ewise_kernel, grid, dim3(NT), 0, ctx->stream, a, out);
 #undef VMP_EW
+#undef VMP_EW_NI
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
