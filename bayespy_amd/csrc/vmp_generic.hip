@@ -149,13 +149,14 @@ sum_multiply_block_kernel(Iter it, int nsplit, double *__restrict__ partial, dou
     }
 }
 
-// Few outputs, long reduction, kept axes NOT dense (e.g. sum over sequences and time of
-// (B, T, D, D) blocks against a broadcast factor): every thread walks reduce positions and
-// accumulates ALL kept elements of its position in registers, so each 128-byte line of the
-// big operand is consumed by one lane instead of being re-read once per kept element.
+// Up to 16 kept elements, long reduction, kept axes not one dense axis: every thread walks reduce
+// positions and accumulates ALL kept elements of its position in registers, so each 128-byte
+// line of the big operand is consumed by one lane and the index arithmetic is paid once per
+// position (2.1 TB/s on (N,16)x(N,1)->(16,); the lane-group form below reaches 1.7 there but
+// wins beyond 16 kept elements, where this form runs out of registers).
 template <int NK>
 __global__ void __launch_bounds__(NT)
-sum_multiply_fat_kernel(Iter it, int nsplit, double *__restrict__ partial)
+sum_multiply_fatthread_kernel(Iter it, int nsplit, double *__restrict__ partial)
 {
     __shared__ int64_t koff[MAXIN][NK];
     __shared__ double wsum[NT / 64][NK];
@@ -211,6 +212,70 @@ sum_multiply_fat_kernel(Iter it, int nsplit, double *__restrict__ partial)
         for (int w = 0; w < NT / 64; ++w) v += wsum[w][tid];
         partial[(int64_t)blockIdx.x * it.nkeep + tid] = v;
     }
+}
+
+// Few outputs (<= 64 kept elements), long reduction, kept axes not one dense axis (e.g. the sum
+// over sequences and time of (B, T, D, D) blocks against a broadcast factor): a group of NK lanes
+// owns a reduce position, lane k its kept element k, so the kept elements of one position --
+// contiguous in the big operand -- are read by neighbouring lanes (coalesced), every lane keeps
+// ONE accumulator, and a thread runs U positions per round to keep loads in flight.  (The first
+// form of this kernel gave every thread all kept elements of its position: 64 cache lines per
+// load instruction, 0.85 TB/s.)
+template <int NK>
+__global__ void __launch_bounds__(NT)
+sum_multiply_fat_kernel(Iter it, int nsplit, double *__restrict__ partial)
+{
+    constexpr int RPB = NT / NK;          // reduce positions per workgroup and step
+    constexpr int U = 8;
+    __shared__ double red[NT];
+    const int tid = threadIdx.x;
+    const int k = tid % NK, rs = tid / NK;
+    const int nkeep = (int)it.nkeep;
+    const bool kact = k < nkeep;
+    int64_t koff[MAXIN], ooff;
+    decode_keep(it, kact ? k : 0, koff, ooff);
+    double acc = 0.0;
+    const int64_t step = (int64_t)gridDim.x * RPB;
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB + rs; r0 < it.nred; r0 += step * U) {
+        double p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * step;
+            const bool ok = kact && r < it.nred;
+            int64_t roff[MAXIN];
+            for (int i = 0; i < it.nin; ++i) roff[i] = 0;
+            if (it.i32) {
+                uint32_t q = ok ? (uint32_t)r : 0u;
+                for (int d = it.nr - 1; d >= 0; --d) {
+                    const uint32_t sz = (uint32_t)it.rsize[d];
+                    const uint32_t q2 = q / sz, c = q - q2 * sz;
+                    q = q2;
+                    for (int i = 0; i < it.nin; ++i) roff[i] += (int64_t)c * it.rstride[i][d];
+                }
+            } else {
+                int64_t q = ok ? r : 0;
+                for (int d = it.nr - 1; d >= 0; --d) {
+                    const int64_t q2 = q / it.rsize[d];
+                    const int64_t c = q - q2 * it.rsize[d];
+                    q = q2;
+                    for (int i = 0; i < it.nin; ++i) roff[i] += c * it.rstride[i][d];
+                }
+            }
+            double v = ok ? it.in[0][roff[0] + koff[0]] : 0.0;
+            for (int i = 1; i < it.nin; ++i) v *= ok ? it.in[i][roff[i] + koff[i]] : 0.0;
+            p[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += p[u];
+    }
+    // fixed-order combination of the RPB position-lanes of every kept element
+    red[tid] = acc;
+    __syncthreads();
+    for (int half = RPB / 2; half >= 1; half >>= 1) {
+        if (rs < half) red[tid] += red[tid + half * NK];
+        __syncthreads();
+    }
+    if (rs == 0 && kact) partial[(int64_t)blockIdx.x * it.nkeep + k] = red[k];
 }
 
 // Column reduce: the innermost kept axis is dense in the operands that carry it, so
@@ -841,19 +906,22 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
     const bool use_fat = it.nkeep <= 64 && it.nkeep >= 2 && it.nred >= 65536 &&
                          !(use_column && it.ksize[it.nk - 1] >= 16) && workspace;
     if (use_fat) {
-        int64_t nsplit = (int64_t)ctx->num_cu * 4;
+        int64_t nsplit = (int64_t)ctx->num_cu * 8;
         const int64_t maxsplit = (it.nred + NT - 1) / NT;
         if (nsplit > maxsplit) nsplit = maxsplit;
         VMP_REQUIRE(ctx, workspace_bytes >= (size_t)(it.nkeep * nsplit) * sizeof(double),
                     VMP_ERR_INVALID, "sum_multiply workspace too small (%lld doubles needed)",
                     (long long)(it.nkeep * nsplit));
         double *partial = reinterpret_cast<double *>(workspace);
+#define VMP_FAT(nk)                                                                             \
+    hipLaunchKernelGGL(sum_multiply_fat_kernel<nk>, dim3((unsigned)nsplit), dim3(NT), 0, s, it, \
+                       (int)nsplit, partial)
         if (it.nkeep <= 16)
-            hipLaunchKernelGGL(sum_multiply_fat_kernel<16>, dim3((unsigned)nsplit), dim3(NT), 0, s,
-                               it, (int)nsplit, partial);
-        else
-            hipLaunchKernelGGL(sum_multiply_fat_kernel<64>, dim3((unsigned)nsplit), dim3(NT), 0, s,
-                               it, (int)nsplit, partial);
+            hipLaunchKernelGGL(sum_multiply_fatthread_kernel<16>, dim3((unsigned)nsplit), dim3(NT),
+                               0, s, it, (int)nsplit, partial);
+        else if (it.nkeep <= 32) VMP_FAT(32);
+        else VMP_FAT(64);
+#undef VMP_FAT
         hipLaunchKernelGGL(sum_multiply_finish_kernel,
                            dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
                            (int)nsplit, scale, partial, out);
