@@ -700,6 +700,39 @@ def default_ndim_case(name):
                  ('dn_X_plates', 'dn_L', 'dn_Z_plates', 'dn_Z_shape', 'dn2_L'))
 
 
+def bmm_doctest_case(name):
+    """doc/source/examples/bmm.rst:8-95 verbatim (numpy.random.seed(1) from its testsetup): the
+    Bernoulli mixture whose doctest pins "Iteration 1: loglike=-6.872145e+02" and
+    "Iteration 17: loglike=-5.236921e+02".  The drawn data and the random initial value of P are
+    recorded so that the run can be repeated without sharing the RNG stream."""
+    from bayespy.utils import random as brandom
+    from bayespy.nodes import Categorical, Dirichlet, Beta, Mixture, Bernoulli
+    from bayespy.inference import VB
+    np.random.seed(1)
+    p0 = [0.1, 0.9, 0.1, 0.9, 0.1, 0.9, 0.1, 0.9, 0.1, 0.9]
+    p1 = [0.1, 0.1, 0.1, 0.1, 0.1, 0.9, 0.9, 0.9, 0.9, 0.9]
+    p2 = [0.9, 0.9, 0.9, 0.9, 0.9, 0.1, 0.1, 0.1, 0.1, 0.1]
+    p = np.array([p0, p1, p2])
+    z = brandom.categorical([1 / 3, 1 / 3, 1 / 3], size=100)
+    x = brandom.bernoulli(p[z])
+    N, D, K = 100, 10, 10
+    R = Dirichlet(K * [1e-5], name='R')
+    Z = Categorical(R, plates=(N, 1), name='Z')
+    P = Beta([0.5, 0.5], plates=(D, K), name='P')
+    X = Mixture(Z, Bernoulli, P)
+    Q = VB(Z, R, X, P)
+    P.initialize_from_random()
+    p_init = np.exp(np.array(P.u[0])[..., 0])
+    X.observe(x)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Q.update(repeat=1000, verbose=False)
+    out = dict(x=np.array(x, dtype=np.int64), p_init=p_init, L=np.array(Q.L[:Q.iter]),
+               R_u0=np.array(R.u[0]), P_u0=np.array(P.u[0]))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, '%e' % out['L'][0], '%e' % out['L'][-1], len(out['L']))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -793,6 +826,7 @@ def main():
     varying_case('varying_lssm')
     concat_gaussian_case('concat_gaussian')
     default_ndim_case('default_ndim')
+    bmm_doctest_case('bmm_doctest')
 
 
 if __name__ == '__main__':

@@ -857,3 +857,27 @@ def test_mixture_over_a_non_last_cluster_plate():
         np.testing.assert_allclose(p, q, rtol=1e-10)
     with pytest.raises(ValueError, match='negative'):
         Mixture(z, GaussianARD, Mu, Alpha, cluster_plate=0)
+
+
+def test_reference_bernoulli_mixture_doctest_known_answer(golden_dir):
+    """doc/source/examples/bmm.rst: "Iteration 1: loglike=-6.872145e+02 ... Iteration 17:
+    loglike=-5.236921e+02", converged at iteration 17 (the data and the random initial value of
+    P drawn by the reference under its testsetup seed are in tests/golden/bmm_doctest.npz)."""
+    from bayespy_amd.nodes import Categorical, Dirichlet, Beta, Mixture, Bernoulli
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'bmm_doctest.npz'))
+    N, D, K = 100, 10, 10
+    R = Dirichlet(K * [1e-5], name='R')
+    Z = Categorical(R, plates=(N, 1), name='Z')
+    P = Beta([0.5, 0.5], plates=(D, K), name='P')
+    X = Mixture(Z, Bernoulli, P)
+    Q = VB(Z, R, X, P)
+    P.initialize_from_value(g['p_init'])
+    X.observe(g['x'])
+    Q.update(repeat=1000, verbose=False)
+    L = Q.L[:Q.iter]
+    assert '%e' % L[0] == '-6.872145e+02'
+    assert Q.iter == 17 and '%e' % L[-1] == '-5.236921e+02'
+    np.testing.assert_allclose(L, g['L'], rtol=1e-9)
+    np.testing.assert_allclose(R.u[0], g['R_u0'], rtol=1e-6)
+    np.testing.assert_allclose(P.u[0], g['P_u0'], rtol=1e-6, atol=1e-9)
