@@ -733,6 +733,37 @@ def bmm_doctest_case(name):
     print(name, '%e' % out['L'][0], '%e' % out['L'][-1], len(out['L']))
 
 
+def gmm_doctest_case(name):
+    """doc/source/examples/gmm.rst:26-117 verbatim (numpy seed 1): the Gaussian mixture whose
+    doctest pins "Iteration 1: loglike=-1.402345e+03" and "Iteration 61: loglike=-8.888464e+02".
+    The drawn data and the random initial labels of Z are recorded."""
+    from bayespy.nodes import Dirichlet, Categorical, Gaussian, Wishart, Mixture
+    from bayespy.inference import VB
+    np.random.seed(1)
+    y0 = np.random.multivariate_normal([0, 0], [[2, 0], [0, 0.1]], size=50)
+    y1 = np.random.multivariate_normal([0, 0], [[0.1, 0], [0, 2]], size=50)
+    y2 = np.random.multivariate_normal([2, 2], [[2, -1.5], [-1.5, 2]], size=50)
+    y3 = np.random.multivariate_normal([-2, -2], [[0.5, 0], [0, 0.5]], size=50)
+    y = np.vstack([y0, y1, y2, y3])
+    N, D, K = 200, 2, 10
+    alpha = Dirichlet(1e-5 * np.ones(K), name='alpha')
+    Z = Categorical(alpha, plates=(N,), name='z')
+    mu = Gaussian(np.zeros(D), 1e-5 * np.identity(D), plates=(K,), name='mu')
+    Lambda = Wishart(D, 1e-5 * np.identity(D), plates=(K,), name='Lambda')
+    Y = Mixture(Z, Gaussian, mu, Lambda, name='Y')
+    Z.initialize_from_random()
+    z_init = np.argmax(np.array(Z.u[0]), axis=-1)
+    Q = VB(Y, mu, Lambda, Z, alpha)
+    Y.observe(y)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Q.update(repeat=1000, verbose=False)
+    out = dict(y=y, z_init=z_init, L=np.array(Q.L[:Q.iter]), alpha_u0=np.array(alpha.u[0]),
+               mu_u0=np.array(mu.u[0]))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, '%e' % out['L'][0], '%e' % out['L'][-1], len(out['L']))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -827,6 +858,7 @@ def main():
     concat_gaussian_case('concat_gaussian')
     default_ndim_case('default_ndim')
     bmm_doctest_case('bmm_doctest')
+    gmm_doctest_case('gmm_doctest')
 
 
 if __name__ == '__main__':

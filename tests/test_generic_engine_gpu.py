@@ -881,3 +881,29 @@ def test_reference_bernoulli_mixture_doctest_known_answer(golden_dir):
     np.testing.assert_allclose(L, g['L'], rtol=1e-9)
     np.testing.assert_allclose(R.u[0], g['R_u0'], rtol=1e-6)
     np.testing.assert_allclose(P.u[0], g['P_u0'], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('engine', [None, 'generic'])
+def test_reference_gaussian_mixture_doctest_known_answer(golden_dir, engine):
+    """doc/source/examples/gmm.rst: "Iteration 1: loglike=-1.402345e+03 ... Iteration 61:
+    loglike=-8.888464e+02" (data and random initial labels of the reference's seeded run in
+    tests/golden/gmm_doctest.npz), on the fused mixture block and on the generic engine."""
+    from bayespy_amd.nodes import Dirichlet, Categorical, Gaussian, Wishart, Mixture
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'gmm_doctest.npz'))
+    y = g['y']
+    N, D, K = 200, 2, 10
+    alpha = Dirichlet(1e-5 * np.ones(K), name='alpha')
+    Z = Categorical(alpha, plates=(N,), name='z')
+    mu = Gaussian(np.zeros(D), 1e-5 * np.identity(D), plates=(K,), name='mu')
+    Lambda = Wishart(D, 1e-5 * np.identity(D), plates=(K,), name='Lambda')
+    Y = Mixture(Z, Gaussian, mu, Lambda, name='Y')
+    Z.initialize_from_value(g['z_init'])
+    Q = VB(Y, mu, Lambda, Z, alpha, engine=engine)
+    Y.observe(y)
+    Q.update(repeat=1000, verbose=False)
+    L = Q.L[:Q.iter]
+    assert '%e' % L[0] == '-1.402345e+03'
+    assert Q.iter == 61 and '%e' % L[-1] == '-8.888464e+02'
+    np.testing.assert_allclose(L, g['L'], rtol=1e-8)
+    np.testing.assert_allclose(alpha.u[0], g['alpha_u0'], rtol=1e-5, atol=1e-6)
