@@ -764,6 +764,45 @@ def gmm_doctest_case(name):
     print(name, '%e' % out['L'][0], '%e' % out['L'][-1], len(out['L']))
 
 
+def inference_doctest_case(name):
+    """doc/source/user_guide/inference.rst:8-235 verbatim (numpy seed 1): the PCA model observed
+    with whole rows masked, X initialised from parameters, updates of node subsets in a given
+    order, and convergence at the default and at a tighter tolerance.  The doctest pins
+    iterations 1-14 and "Converged at iteration 488." / "... 847."."""
+    from bayespy.nodes import GaussianARD, Gamma, Dot
+    from bayespy.inference import VB
+    np.random.seed(1)
+    D = 3
+    X = GaussianARD(0, 1, shape=(D,), plates=(1, 100), name='X')
+    alpha = Gamma(1e-3, 1e-3, plates=(D,), name='alpha')
+    C = GaussianARD(0, alpha, shape=(D,), plates=(10, 1), name='C')
+    F = Dot(C, X)
+    tau = Gamma(1e-3, 1e-3, name='tau')
+    Y = GaussianARD(F, tau)
+    c = np.random.randn(10, 2)
+    x = np.random.randn(2, 100)
+    data = np.dot(c, x) + 0.1 * np.random.randn(10, 100)
+    Y.observe(data)
+    mask = [[True], [False], [False], [True], [True], [False], [True], [True], [True], [False]]
+    Y.observe(data, mask=mask)
+    Q = VB(Y, C, X, alpha, tau)
+    x_init = np.random.randn(1, 100, D)
+    X.initialize_from_parameters(x_init, 10)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Q.update(verbose=False)
+        Q.update(C, X, verbose=False)
+        Q.update(C, X, C, tau, verbose=False)
+        Q.update(repeat=10, verbose=False)
+        Q.update(repeat=1000, verbose=False)
+        n1 = Q.iter
+        Q.update(repeat=10000, tol=1e-6, verbose=False)
+    out = dict(data=data, mask=np.array(mask), x_init=x_init, L=np.array(Q.L[:Q.iter]),
+               n_default=n1, n_tight=Q.iter, tau_u0=np.array(tau.u[0]), alpha_u0=np.array(alpha.u[0]))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, ['%e' % v for v in out['L'][:4]], n1, Q.iter, '%e' % out['L'][n1 - 1], '%e' % out['L'][-1])
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -859,6 +898,7 @@ def main():
     default_ndim_case('default_ndim')
     bmm_doctest_case('bmm_doctest')
     gmm_doctest_case('gmm_doctest')
+    inference_doctest_case('inference_doctest')
 
 
 if __name__ == '__main__':

@@ -907,3 +907,46 @@ def test_reference_gaussian_mixture_doctest_known_answer(golden_dir, engine):
     assert Q.iter == 61 and '%e' % L[-1] == '-8.888464e+02'
     np.testing.assert_allclose(L, g['L'], rtol=1e-8)
     np.testing.assert_allclose(alpha.u[0], g['alpha_u0'], rtol=1e-5, atol=1e-6)
+
+
+def test_reference_user_guide_inference_doctest(golden_dir):
+    """doc/source/user_guide/inference.rst:52-235: the PCA model (Dot node) observed with whole
+    rows masked, X initialised from parameters, ``Q.update()``, ``Q.update(C, X)``,
+    ``Q.update(C, X, C, tau)``, ``repeat=10``, then convergence at the default and at a tighter
+    tolerance.  The doctest prints iterations 1-14 and "Converged at iteration 488." / "847."."""
+    from bayespy_amd.nodes import GaussianARD, Gamma, Dot
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'inference_doctest.npz'))
+    D = 3
+    X = GaussianARD(0, 1, shape=(D,), plates=(1, 100), name='X')
+    alpha = Gamma(1e-3, 1e-3, plates=(D,), name='alpha')
+    C = GaussianARD(0, alpha, shape=(D,), plates=(10, 1), name='C')
+    F = Dot(C, X)
+    tau = Gamma(1e-3, 1e-3, name='tau')
+    Y = GaussianARD(F, tau)
+    Y.observe(g['data'])
+    Y.observe(g['data'], mask=g['mask'])
+    Q = VB(Y, C, X, alpha, tau)
+    assert Q['X'] is X
+    X.initialize_from_parameters(g['x_init'], 10)
+    Q.update(verbose=False)
+    Q.update(C, X, verbose=False)
+    Q.update(C, X, C, tau, verbose=False)
+    Q.update(repeat=10, verbose=False)
+    want = ['-9.305259e+02', '-8.818976e+02', '-8.071222e+02', '-7.167588e+02', '-6.827873e+02',
+            '-6.259477e+02', '-4.725400e+02', '-3.270816e+02', '-2.208865e+02', '-1.658761e+02',
+            '-1.469468e+02', '-1.420311e+02', '-1.405139e+02']
+    assert ['%e' % v for v in Q.L[:13]] == want
+    Q.update(repeat=1000, verbose=False)
+    n1 = Q.iter
+    assert '%e' % Q.L[13] == '-1.396481e+02'
+    # hundreds of iterations on a slowly rising bound: the stopping iteration may move by a
+    # few steps with round-off, the value it stops at may not
+    assert Q.converged and abs(n1 - 488) <= 3
+    np.testing.assert_allclose(Q.L[n1 - 1], -1.224106e+02, rtol=2e-6)
+    Q.update(repeat=10000, tol=1e-6, verbose=False)
+    assert Q.converged and abs(Q.iter - 847) <= 5
+    np.testing.assert_allclose(Q.L[Q.iter - 1], -1.222506e+02, rtol=2e-6)
+    m = min(Q.iter, len(g['L']))
+    np.testing.assert_allclose(Q.L[:m], g['L'][:m], rtol=1e-7)
+    np.testing.assert_allclose(tau.u[0], g['tau_u0'], rtol=1e-4)
