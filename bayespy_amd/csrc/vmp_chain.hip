@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int CHAIN_MAXK = 8;
+constexpr int CHAIN_MAXK = 16;      // K <= 8: a wavefront per matrix sequence; 8 < K <= 16: a workgroup
 
 // C = P * Q for K x K matrices held one element per lane (through the wave's LDS buffers)
 __device__ inline double wave_matmul(double p, double q, int K, int i, int j, bool act,
@@ -113,6 +113,122 @@ bbs_backward_kernel(int T, int K, int64_t nm, double *__restrict__ V, double *__
     }
 }
 
+// ---- 8 < K <= 16: the same recursions with one matrix element per THREAD of a 256-thread
+// workgroup (one matrix sequence per workgroup), exchanges through LDS behind workgroup barriers
+struct BlockMat {
+    double *Ms, *Ps, *Qs;
+    int K, i, j;
+    bool act;
+
+    __device__ double symmetrize(double v) const
+    {
+        Ps[threadIdx.x] = v;
+        __syncthreads();
+        const double r = act ? 0.5 * (Ps[i * K + j] + Ps[j * K + i]) : 0.0;
+        __syncthreads();
+        return r;
+    }
+
+    __device__ double matmul(double p, double q, bool tp, bool tq) const
+    {
+        Ps[threadIdx.x] = p;
+        Qs[threadIdx.x] = q;
+        __syncthreads();
+        double s = 0.0;
+        if (act)
+            for (int k = 0; k < K; ++k)
+                s += (tp ? Ps[k * K + i] : Ps[i * K + k]) * (tq ? Qs[j * K + k] : Qs[k * K + j]);
+        __syncthreads();
+        return s;
+    }
+
+    // in-place Gauss-Jordan inverse of an SPD matrix, log-determinant, definiteness flag
+    __device__ double spd_inverse(double v, double *logdet, int *bad) const
+    {
+        double ld = 0.0, prod = 1.0;
+        for (int p = 0; p < K; ++p) {
+            Ms[threadIdx.x] = v;
+            __syncthreads();
+            const double piv = Ms[p * K + p];
+            const double ci = act ? Ms[i * K + p] : 0.0, rj = act ? Ms[p * K + j] : 0.0;
+            if (!(piv > 0.0)) *bad = 1;
+            logdet_accumulate(piv, prod, ld);
+            const double d = fast_recip(piv);
+            if (i == p) v = (j == p) ? d : rj * d;
+            else if (j == p) v = -ci * d;
+            else v = v - ci * rj * d;
+            __syncthreads();
+        }
+        *logdet = logdet_finish(prod, ld);
+        return v;
+    }
+};
+
+__global__ void __launch_bounds__(NT)
+bbs_forward_block_kernel(int T, int K, int64_t nm, const double *__restrict__ A,
+                         const double *__restrict__ B, double *__restrict__ V,
+                         double *__restrict__ C, double *__restrict__ ldet,
+                         int32_t *__restrict__ info)
+{
+    __shared__ double Ms[NT], Ps[NT], Qs[NT];
+    const int t = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const bool act = t < K * K;
+    const int i = act ? t / K : 0, j = act ? t - i * K : 0;
+    const BlockMat m{Ms, Ps, Qs, K, i, j, act};
+    const int KK = K * K;
+    const double *Ab = A + b * (int64_t)T * KK;
+    const double *Bb = B + b * (int64_t)(T - 1) * KK;
+    double *Vb = V + b * (int64_t)T * KK;
+    double *Cb = C + b * (int64_t)(T - 1) * KK;
+    double v = m.symmetrize(act ? Ab[t] : 0.0);
+    double total = 0.0;
+    int bad = 0;
+    for (int n = 0; n < T; ++n) {
+        double ld;
+        const double vi = m.spd_inverse(v, &ld, &bad);
+        total += ld;
+        if (act) Vb[(int64_t)n * KK + t] = vi;
+        if (n < T - 1) {
+            const double bn = act ? Bb[(int64_t)n * KK + t] : 0.0;
+            const double c = m.matmul(vi, bn, false, false);
+            if (act) Cb[(int64_t)n * KK + t] = c;
+            const double sden = m.matmul(bn, c, true, false);          // B_n^T C_n
+            v = m.symmetrize((act ? Ab[(int64_t)(n + 1) * KK + t] : 0.0) - sden);
+        }
+    }
+    if (t == 0) {
+        ldet[b] = total;
+        if (bad) info[b] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+bbs_backward_block_kernel(int T, int K, int64_t nm, double *__restrict__ V, double *__restrict__ C)
+{
+    __shared__ double Ps[NT], Qs[NT];
+    const int t = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const bool act = t < K * K;
+    const int i = act ? t / K : 0, j = act ? t - i * K : 0;
+    const BlockMat m{nullptr, Ps, Qs, K, i, j, act};
+    const int KK = K * K;
+    double *Vb = V + b * (int64_t)T * KK;
+    double *Cb = C + b * (int64_t)(T - 1) * KK;
+    double S = act ? Vb[(int64_t)(T - 1) * KK + t] : 0.0;
+    for (int n = T - 2; n >= 0; --n) {
+        const double c = act ? Cb[(int64_t)n * KK + t] : 0.0;
+        const double vi = act ? Vb[(int64_t)n * KK + t] : 0.0;
+        const double t1 = m.matmul(c, S, false, false);          // C S
+        const double s2 = m.matmul(t1, c, false, true);          // (C S) C^T
+        S = m.symmetrize(vi + s2);
+        if (act) {
+            Vb[(int64_t)n * KK + t] = S;
+            Cb[(int64_t)n * KK + t] = -t1;
+        }
+    }
+}
+
 // vector recursions, one thread per right-hand side; Vinv / Cg are the outputs of the
 // forward kernel (shared when nm == 1)
 template <int K>
@@ -193,8 +309,14 @@ int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, i
                 "block_banded_solve kernels support state dimension <= %d", CHAIN_MAXK);
     hipStream_t s = ctx->stream;
     VMP_HIP_CHECK(ctx, hipMemsetAsync(info, 0, (size_t)nm * sizeof(int32_t), s));
-    const dim3 gm((unsigned)((nm + 3) / 4));
-    hipLaunchKernelGGL(bbs_forward_kernel, gm, dim3(NT), 0, s, T, K, nm, A, B, V, C, ldet, info);
+    const bool wide = K > 8;           // a workgroup per matrix sequence instead of a wavefront
+    const dim3 gm((unsigned)(wide ? nm : (nm + 3) / 4));
+    if (wide)
+        hipLaunchKernelGGL(bbs_forward_block_kernel, gm, dim3(NT), 0, s, T, K, nm, A, B, V, C,
+                           ldet, info);
+    else
+        hipLaunchKernelGGL(bbs_forward_kernel, gm, dim3(NT), 0, s, T, K, nm, A, B, V, C, ldet,
+                           info);
     if (ny > 0) {
         const dim3 gv((unsigned)((ny + NT - 1) / NT));
 #define VMP_VCASE(k)                                                                          \
@@ -204,11 +326,18 @@ int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, i
         switch (K) {
             VMP_VCASE(1) VMP_VCASE(2) VMP_VCASE(3) VMP_VCASE(4)
             VMP_VCASE(5) VMP_VCASE(6) VMP_VCASE(7) VMP_VCASE(8)
+            VMP_VCASE(9) VMP_VCASE(10) VMP_VCASE(11) VMP_VCASE(12)
+            VMP_VCASE(13) VMP_VCASE(14) VMP_VCASE(15) VMP_VCASE(16)
         default: break;
         }
 #undef VMP_VCASE
     }
-    if (T > 1) hipLaunchKernelGGL(bbs_backward_kernel, gm, dim3(NT), 0, s, T, K, nm, V, C);
+    if (T > 1) {
+        if (wide)
+            hipLaunchKernelGGL(bbs_backward_block_kernel, gm, dim3(NT), 0, s, T, K, nm, V, C);
+        else
+            hipLaunchKernelGGL(bbs_backward_kernel, gm, dim3(NT), 0, s, T, K, nm, V, C);
+    }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

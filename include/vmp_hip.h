@@ -376,7 +376,7 @@ int32_t vmp_alpha_beta_recursion(vmp_ctx *ctx, int32_t N, int32_t K, int64_t nch
  * super-diagonal blocks, y: ny x T x K right-hand sides; nm == 1 (shared dynamics) or
  * nm == ny.  Out: V (diagonal blocks of the inverse), C (super-diagonal blocks), x
  * (solutions), ldet[nm] (log-determinant); info[b] = 1 where a block is not positive
- * definite.  K <= 8. */
+ * definite.  K <= 16 (a wavefront per matrix sequence up to K = 8, a workgroup above). */
 int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, int64_t ny,
                                const double *A, const double *B, const double *y, double *V,
                                double *C, double *x, double *ldet, int32_t *info);

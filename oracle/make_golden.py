@@ -803,6 +803,52 @@ def inference_doctest_case(name):
     print(name, ['%e' % v for v in out['L'][:4]], n1, Q.iter, '%e' % out['L'][n1 - 1], '%e' % out['L'][-1])
 
 
+def lssm_doctest_case(name):
+    """doc/source/examples/lssm.rst:45-202 verbatim (numpy seed 1): linear state-space model with
+    a 10-dimensional latent chain, 400 time instances, 30 observed dimensions, 80 % missing
+    values.  The doctest pins "Iteration 1: loglike=-1.439704e+05" and "Iteration 10:
+    loglike=-1.051441e+04".  Data, mask and the random initial value of C are recorded."""
+    from bayespy.nodes import GaussianARD, GaussianMarkovChain, Gamma, Dot
+    from bayespy.inference import VB
+    from bayespy.utils import random as brandom
+    np.random.seed(1)
+    M, N, D = 30, 400, 10
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=N, name='X')
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1), name='C')
+    F = Dot(C, X, name='F')
+    C.initialize_from_random()
+    C_init = np.array(C.u[0])
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    Q = VB(X, C, gamma, A, alpha, tau, Y)
+    w = 0.3
+    a = np.array([[np.cos(w), -np.sin(w), 0, 0], [np.sin(w), np.cos(w), 0, 0], [0, 0, 1, 0],
+                  [0, 0, 0, 0]])
+    c = np.random.randn(M, 4)
+    x = np.empty((N, 4))
+    f = np.empty((M, N))
+    y = np.empty((M, N))
+    x[0] = 10 * np.random.randn(4)
+    f[:, 0] = np.dot(c, x[0])
+    y[:, 0] = f[:, 0] + 3 * np.random.randn(M)
+    for n in range(N - 1):
+        x[n + 1] = np.dot(a, x[n]) + [1, 1, 10, 10] * np.random.randn(4)
+        f[:, n + 1] = np.dot(c, x[n + 1])
+        y[:, n + 1] = f[:, n + 1] + 3 * np.random.randn(M)
+    mask = brandom.mask(M, N, p=0.2)
+    Y.observe(y, mask=mask)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Q.update(repeat=10, verbose=False)
+    out = dict(y=y, mask=mask, C_init=C_init, L=np.array(Q.L[:Q.iter]), tau_u0=np.array(tau.u[0]),
+               A_u0=np.array(A.u[0]), X_u0=np.array(X.u[0]))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, '%e' % out['L'][0], '%e' % out['L'][-1], len(out['L']))
+
+
 def markov_chain_case(name):
     """Categorical Markov chains: raw alpha-beta recursions (utils/random.py:357-422) and the
     models of tests/models.py run_markov_chain_cases.  The data of the two doctest models of
@@ -899,6 +945,7 @@ def main():
     bmm_doctest_case('bmm_doctest')
     gmm_doctest_case('gmm_doctest')
     inference_doctest_case('inference_doctest')
+    lssm_doctest_case('lssm_doctest')
 
 
 if __name__ == '__main__':

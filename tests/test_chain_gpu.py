@@ -70,11 +70,47 @@ def test_block_banded_solve_errors():
     with pytest.raises(ValueError):
         linalg.block_banded_solve(np.ones((3, 2, 2)), np.ones((2, 2, 2)), np.ones((4, 2)))
     with pytest.raises(NotImplementedError):
-        linalg.block_banded_solve(np.tile(np.eye(9), (3, 1, 1)), np.zeros((2, 9, 9)),
-                                  np.ones((3, 9)))
+        linalg.block_banded_solve(np.tile(np.eye(17), (3, 1, 1)), np.zeros((2, 17, 17)),
+                                  np.ones((3, 17)))
     bad = np.tile(-np.eye(2), (3, 1, 1))
     with pytest.raises(_lib.NotPositiveDefiniteError):
         linalg.block_banded_solve(bad, np.zeros((2, 2, 2)), np.ones((3, 2)))
+
+
+def test_block_banded_solve_wide_states_against_dense_solves():
+    """8 < K <= 16: the workgroup-per-sequence form of the matrix recursions against dense
+    NumPy solves of the assembled block-tridiagonal system (shared and per-sequence matrices)."""
+    from bayespy_amd.utils import linalg
+    rs = np.random.RandomState(17)
+    for K, T, nm, ny in ((9, 5, 1, 3), (12, 7, 4, 4), (16, 4, 1, 2)):
+        Bm = 0.3 * rs.normal(size=(nm, T - 1, K, K))
+        Am = np.empty((nm, T, K, K))
+        for b in range(nm):
+            for t in range(T):
+                q = rs.normal(size=(K, K))
+                Am[b, t] = q @ q.T + 3 * K * np.eye(K)
+        y = rs.normal(size=(ny, T, K))
+        V, C, x, ld = linalg.block_banded_solve(Am if nm > 1 else Am[0], Bm if nm > 1 else Bm[0], y)
+        V, C, x, ld = V.numpy(), C.numpy(), x.numpy(), ld.numpy()
+        for s in range(ny):
+            b = s if nm > 1 else 0
+            big = np.zeros((T * K, T * K))
+            for t in range(T):
+                big[t * K:(t + 1) * K, t * K:(t + 1) * K] = Am[b, t]
+                if t < T - 1:
+                    big[t * K:(t + 1) * K, (t + 1) * K:(t + 2) * K] = Bm[b, t]
+                    big[(t + 1) * K:(t + 2) * K, t * K:(t + 1) * K] = Bm[b, t].T
+            inv = np.linalg.inv(big)
+            np.testing.assert_allclose(x[s].reshape(-1), inv @ y[s].reshape(-1), rtol=1e-9, atol=1e-12)
+            Vb = V[b] if nm > 1 else V
+            Cb = C[b] if nm > 1 else C
+            for t in range(T):
+                np.testing.assert_allclose(Vb[t], inv[t * K:(t + 1) * K, t * K:(t + 1) * K],
+                                           rtol=1e-9, atol=1e-12)
+                if t < T - 1:
+                    np.testing.assert_allclose(Cb[t], inv[t * K:(t + 1) * K, (t + 1) * K:(t + 2) * K],
+                                               rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(np.ravel(ld)[b], np.linalg.slogdet(big)[1], rtol=1e-10)
 
 
 def _build_lssm(g, tag, B, gamma_nu):
@@ -170,3 +206,34 @@ def test_time_varying_state_space_model_matches_reference(golden_dir):
                                            atol=1e-8, err_msg='%s[%d]' % (k, i))
         else:
             np.testing.assert_allclose(v, f[k], rtol=1e-7, atol=1e-6, err_msg=k)
+
+
+def test_reference_lssm_doctest_known_answer(golden_dir):
+    """doc/source/examples/lssm.rst: linear state-space model with a TEN-dimensional latent
+    chain (the workgroup-per-sequence form of the smoother kernels), 400 instances, 80 % of the
+    30 x 400 observations missing: "Iteration 1: loglike=-1.439704e+05 ... Iteration 10:
+    loglike=-1.051441e+04" (data, mask and the reference's random initial C in
+    tests/golden/lssm_doctest.npz)."""
+    from bayespy_amd.nodes import GaussianARD, GaussianMarkovChain, Gamma, Dot
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'lssm_doctest.npz'))
+    M, N, D = 30, 400, 10
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=N, name='X')
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1), name='C')
+    F = Dot(C, X, name='F')
+    assert F.plates == (M, N)
+    C.initialize_from_value(g['C_init'])
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    Q = VB(X, C, gamma, A, alpha, tau, Y)
+    Y.observe(g['y'], mask=g['mask'])
+    Q.update(repeat=10, verbose=False)
+    L = Q.L[:10]
+    assert '%e' % L[0] == '-1.439704e+05' and '%e' % L[9] == '-1.051441e+04'
+    np.testing.assert_allclose(L, g['L'], rtol=1e-8)
+    np.testing.assert_allclose(tau.u[0], g['tau_u0'], rtol=1e-6)
+    np.testing.assert_allclose(A.u[0], g['A_u0'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(X.u[0], g['X_u0'], rtol=1e-5, atol=1e-7)
