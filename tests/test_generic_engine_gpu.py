@@ -950,3 +950,15 @@ def test_reference_user_guide_inference_doctest(golden_dir):
     m = min(Q.iter, len(g['L']))
     np.testing.assert_allclose(Q.L[:m], g['L'][:m], rtol=1e-7)
     np.testing.assert_allclose(tau.u[0], g['tau_u0'], rtol=1e-4)
+
+
+def test_add_node_doctest_known_answer():
+    """The doctest of add.py:19-33: mean [[1, 1]] and second moment [[[3, 1], [1, 3]]]."""
+    from bayespy_amd import nodes
+    X = nodes.Gaussian(np.zeros(2), np.identity(2), plates=(3,))
+    Y = nodes.Gaussian(np.ones(2), np.identity(2))
+    Z = nodes.Add(X, Y)
+    u = Z.get_moments()
+    np.testing.assert_allclose(np.broadcast_to(u[0], (3, 2)), np.ones((3, 2)), rtol=1e-13)
+    np.testing.assert_allclose(np.broadcast_to(u[1], (3, 2, 2)),
+                               np.broadcast_to([[3.0, 1.0], [1.0, 3.0]], (3, 2, 2)), rtol=1e-13)
