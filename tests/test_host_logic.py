@@ -229,3 +229,33 @@ def test_random_data_generation_helpers():
     assert np.all(np.abs(lat) <= 90) and np.all(np.abs(lon) <= 180)
     with pytest.raises(ValueError, match='greater than'):
         r.covariance(4, nu=3)
+
+
+def test_user_guide_plate_doctests():
+    """The plate examples of doc/source/user_guide/modelconstruct.rst:205-220, :315-328,
+    :350-393, :500-511 -- construction only."""
+    from bayespy_amd.nodes import (Gaussian, GaussianARD, Gamma, Wishart, Categorical, Mixture, Dot)
+    mu0 = Gaussian(np.zeros(3), np.identity(3))
+    Lam0 = Wishart(3, np.identity(3))
+    y = Gaussian(mu0, Lam0, plates=(10, 30))
+    assert y[0].plates == (30,)
+    assert y[:, ::2].plates == (10, 15)
+    assert y[:5, 10:20:5].plates == (5, 2)
+    mu = [[0, 0], [1, 1], [2, 2]]
+    Lambda = [[[1.0, 0.0], [0.0, 1.0]], [[1.0, 0.9], [0.9, 1.0]], [[1.0, -0.3], [-0.3, 1.0]]]
+    X = Gaussian(mu, Lambda)
+    assert X.plates == (3,)
+    mu = Gaussian([[0], [0], [0]], [[[1]], [[1]], [[1]]])
+    Lambda = Wishart(1, [[[1]], [[1]], [[1]]])
+    Z = Categorical([1 / 3, 1 / 3, 1 / 3], plates=(100,))
+    X = Mixture(Z, Gaussian, mu, Lambda)
+    assert mu.plates == (3,) and Lambda.plates == (3,) and Z.plates == (100,)
+    assert X.plates == (100,)
+    tau = Gamma(1, 1, plates=(5, 4, 3))
+    X = GaussianARD(0, tau, shape=(4, 3))
+    assert tau.plates == (5, 4, 3) and X.plates == (5,)
+    D = 3
+    X = GaussianARD(0, 1, shape=(D,), plates=(1, 100))
+    alpha = Gamma(1e-3, 1e-3, plates=(D,))
+    C = GaussianARD(0, alpha, shape=(D,), plates=(10, 1))
+    assert Dot(C, X).plates == (10, 100)
