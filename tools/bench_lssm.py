@@ -17,6 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+# At the config-5 size (B = 1e5 sequences, 99 GB of live arrays) the default caching allocator
+# fragments: 0.36 s/iter; with expandable segments 0.19 s/iter (same numbers at B <= 5e4).
+os.environ.setdefault('PYTORCH_HIP_ALLOC_CONF', 'expandable_segments:True')
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument('--b', type=int, default=1000)
