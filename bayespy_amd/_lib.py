@@ -86,6 +86,12 @@ SIGNATURES = {
     'vmp_pca_prepare_x': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_vp]),
     'vmp_pca_pass': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'vmp_pca_xpass': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'vmp_pca_tiled_doubles': (c_i32, [c_i32, c_i32, c_i64, P(c_i64), P(c_i64)]),
+    'vmp_pca_tile_y': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    'vmp_pca_tile_x': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    'vmp_pca_xpass_tiled': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp,
+                                    c_vp]),
+    'vmp_tune_set': (c_i32, [ctypes.c_char_p, c_i32]),
     'vmp_pca_gram': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'vmp_pca_update_tau': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_vp]),
     'vmp_pca_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_vp]),

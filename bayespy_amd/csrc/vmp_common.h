@@ -60,6 +60,9 @@ static inline hipEvent_t *vmp_next_events(vmp_ctx *ctx)
         }                                   \
     } while (0)
 
+// Measurement knobs (vmp_tune_set, include/vmp_hip.h): `dflt` unless a value was set for `key`.
+int vmp_tune_get(const char *key, int dflt);
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 

@@ -5,7 +5,36 @@
 
 static char g_err[512] = "no context";
 
+// ---- measurement knobs ---------------------------------------------------------------------
+namespace {
+struct tune_entry { char key[32]; int value; };
+tune_entry g_tune[32];
+int g_ntune = 0;
+}  // namespace
+
+int vmp_tune_get(const char *key, int dflt)
+{
+    for (int i = 0; i < g_ntune; ++i)
+        if (strcmp(g_tune[i].key, key) == 0) return g_tune[i].value;
+    return dflt;
+}
+
 extern "C" {
+
+int32_t vmp_tune_set(const char *key, int32_t value)
+{
+    if (!key || strlen(key) >= sizeof(g_tune[0].key)) return VMP_ERR_INVALID;
+    for (int i = 0; i < g_ntune; ++i)
+        if (strcmp(g_tune[i].key, key) == 0) {
+            g_tune[i].value = value;
+            return VMP_OK;
+        }
+    if (g_ntune >= (int)(sizeof(g_tune) / sizeof(g_tune[0]))) return VMP_ERR_INVALID;
+    strcpy(g_tune[g_ntune].key, key);
+    g_tune[g_ntune].value = value;
+    g_ntune += 1;
+    return VMP_OK;
+}
 
 const char *vmp_version(void) { return "libvmp_hip 0.1 (gfx950)"; }
 

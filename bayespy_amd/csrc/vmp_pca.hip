@@ -303,7 +303,13 @@ sum_partials_kernel(const double *__restrict__ partial, int n, double *__restric
 //
 // GUARD = false: only full 32-column tiles, D == DP and K == KP -- no predication
 // anywhere in the loop; GUARD = true handles ragged D, K and the last partial tile.
-template <int DB, int KT, bool GUARD, int OCC, int NTM = 0>
+//
+// LAY bit 0: Y is the tile-major copy made by vmp_pca_tile_y ([tile][DP][32] doubles, zero
+// padded): a wavefront then streams ONE contiguous 32 KB span per tile and every load
+// instruction covers 1 KB of consecutive addresses (lane l reads bytes 16 l .. 16 l + 15 of
+// k-step q's 1 KB) instead of four 256-byte row segments that lie ldy*8 bytes apart.
+// LAY bit 1: X is tile-major as well ([tile][KP][32]); every store instruction writes 1 KB.
+template <int DB, int KT, bool GUARD, int OCC, int NTM = 0, int LAY = 0>
 __global__ void __launch_bounds__(NT, OCC)
 pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
                  const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
@@ -313,6 +319,8 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
     constexpr int KS = DP / 4;                 // MFMA k-steps per tile
     constexpr int NCH = (DB < 2) ? 2 : DB;     // chunks per tile (even)
     constexpr int CH = KS / NCH;               // k-steps per chunk
+    constexpr bool YT = (LAY & 1) != 0, XT = (LAY & 2) != 0;
+    static_assert(!(GUARD && LAY != 0), "tile-major arrays are padded: no guarded instance");
 
     __shared__ double Af[KT * KS * 64];        // A fragments: [(it*KS + q)*64 + lane]
 
@@ -338,6 +346,16 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
     const int64_t stride = (int64_t)gridDim.x * 4;
 
     auto issue = [&](int64_t tile, int c, v2f64 *dst) {
+        if (YT) {
+            const char *base = reinterpret_cast<const char *>(Y)
+                               + ((tile * (DP * TN) + (int64_t)(c * CH) * (4 * TN)) << 3);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const v2f64 *src = reinterpret_cast<const v2f64 *>(base + i * (4 * TN * 8) + l * 16);
+                dst[i] = (NTM & 1) ? __builtin_nontemporal_load(src) : *src;
+            }
+            return;
+        }
         const char *base = reinterpret_cast<const char *>(Y)
                            + ((tile * TN + (int64_t)(4 * c * CH) * ldy) << 3);
         if (!GUARD) {
@@ -397,7 +415,18 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
         }
         // C/D layout: col = lane&15 -> column pair, row = (lane>>4) + 4*reg -> k
         char *xbase = reinterpret_cast<char *>(X) + ((tile * TN) << 3);
-        if (!GUARD) {
+        if (XT) {
+            char *xt = reinterpret_cast<char *>(X) + ((tile * (16 * KT * TN)) << 3) + l * 16;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v2f64 *dstp = reinterpret_cast<v2f64 *>(xt + (it * 16 + 4 * r) * (TN * 8));
+                    const v2f64 val = v2f64{acc[it][0][r], acc[it][1][r]};
+                    if (NTM & 2) __builtin_nontemporal_store(val, dstp);
+                    else *dstp = val;
+                }
+        } else if (!GUARD) {
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
@@ -532,14 +561,14 @@ int xpass_wgs_per_cu()
 {
     static int v = -1;
     if (v < 0) v = env_int("VMP_PCA_XPASS_WGS_PER_CU", 3, 1, 8);
-    return v;
+    return vmp_tune_get("xpass_wgs_per_cu", v);
 }
 
 int xpass_occupancy()
 {
     static int v = -1;
     if (v < 0) v = env_int("VMP_PCA_XPASS_OCC", 3, 2, 3);
-    return v;
+    return vmp_tune_get("xpass_occ", v);
 }
 
 int64_t max_grid(vmp_ctx *ctx) { return (int64_t)ctx->num_cu * wgs_per_cu(); }
@@ -702,6 +731,125 @@ int32_t run_gram_stats(vmp_ctx *ctx, const vmp_pca_layout &L, int D, int K, doub
     return VMP_OK;
 }
 
+// row-major (rows, ld) <-> tile-major [tile][RP][32] (rows >= `rows` and columns >= N are
+// zero in the tile-major copy).  One workgroup per tile; 16 bytes per lane on both sides.
+template <bool TO_TILED>
+__global__ void __launch_bounds__(NT)
+pca_tile_kernel(double *__restrict__ R, int64_t ld, int64_t N, int rows, int RP,
+                double *__restrict__ T, int64_t ntiles)
+{
+    const int tid = threadIdx.x;
+    const int c2 = (tid & 15) * 2;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n = tile * TN + c2;
+        double *tb = T + tile * ((int64_t)RP * TN);
+        for (int row = tid >> 4; row < RP; row += NT / 16) {
+            double *rp = R + (int64_t)row * ld + n;
+            v2f64 *tp = reinterpret_cast<v2f64 *>(tb + row * TN + c2);
+            if (TO_TILED) {
+                v2f64 v = v2f64{0.0, 0.0};
+                if (row < rows) {
+                    if (n + 1 < N) v = *reinterpret_cast<const v2f64 *>(rp);
+                    else if (n < N) v.x = rp[0];
+                }
+                *tp = v;
+            } else if (row < rows) {
+                const v2f64 v = *tp;
+                if (n + 1 < N) *reinterpret_cast<v2f64 *>(rp) = v;
+                else if (n < N) rp[0] = v.x;
+            }
+        }
+    }
+}
+
+// lay: 0 = row-major Y and X; 1 = tile-major Y, row-major X with KP rows; 3 = both tile-major
+int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, int K, double *X,
+                  int64_t ldx, double *state, void *workspace, int lay)
+{
+    int32_t rc;
+    vmp_pca_layout L;
+    fill_layout(D, K, &L);
+    const int DB = (int)(L.DP / 32), KT = (int)(L.KP / 16);
+    const int64_t ntiles = (N + TN - 1) / TN;
+    // full tiles with unpadded D, K run the predication-free instance
+    const bool exact = (D == L.DP && K == L.KP);
+    // a ragged last tile also runs predication-free when both arrays are padded to whole
+    // tiles (its pad columns of X are then written too: <x> of whatever Y holds there)
+    const bool padded = (ldy >= ntiles * TN && ldx >= ntiles * TN);
+    const int64_t nfast = lay ? ntiles : (exact ? (padded ? ntiles : N / TN) : 0);
+    const int occ = xpass_occupancy();
+    const int ntm = vmp_tune_get("xpass_nt", env_int("VMP_PCA_XPASS_NT", 3, 0, 3));
+    hipStream_t m = ctx->stream;
+    // VMP_PCA_PLATE_STREAM=0: everything in order on the caller's stream (A/B measurements)
+    const int overlap = vmp_tune_get("plate_stream", env_int("VMP_PCA_PLATE_STREAM", 1, 0, 1));
+    hipStream_t s = m;
+    const double *A = state + L.off_A;
+    int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
+    if (overlap) {
+        rc = ensure_plate_stream(ctx);
+        if (rc != VMP_OK) return rc;
+        gmax = (int64_t)ctx->xs_cus * xpass_wgs_per_cu();
+        // Nothing in a Gram-form iteration reads X: the latent pass is a pure by-product of
+        // (A, Y).  It runs on the plate stream from a private copy of A, so the
+        // replicated-node kernels of the NEXT iteration (main stream, reserved CUs) overlap
+        // it; the only ordering kept is pass(i) before pass(i+1) and before anything that
+        // touches X.
+        double *Ax = plate_stream_A(ctx, L, workspace);
+        if (ctx->x_pending) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(m, ctx->ev_xdone, 0));
+        VMP_HIP_CHECK(ctx, hipMemcpyAsync(Ax, state + L.off_A,
+                                          (size_t)(L.KP * L.DP) * sizeof(double),
+                                          hipMemcpyDeviceToDevice, m));
+        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xfork, m));
+        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->xs, ctx->ev_xfork, 0));
+        s = ctx->xs;
+        A = Ax;
+    }
+    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool guard = (pass == 1);
+        const int64_t t0 = guard ? nfast : 0, t1 = guard ? ntiles : nfast;
+        if (t1 <= t0) continue;
+        int64_t g = (t1 - t0 + 3) / 4;
+        if (g > gmax) g = gmax;
+        const dim3 grid((unsigned)g);
+#define VMP_XP(db, kt, gd, oc, nt, ly)                                                          \
+    hipLaunchKernelGGL((pca_xpass_kernel<db, kt, gd, oc, nt, ly>), grid, dim3(NT), 0, s, Y, ldy, \
+                       N, D, K, A, X, ldx, t0, t1)
+#define VMP_CASE(db, kt)                                                                        \
+    if (DB == db && KT == kt) {                                                                 \
+        if (guard) VMP_XP(db, kt, true, 2, 0, 0);                                               \
+        else if (lay == 3 && kt < 4 && ntm == 3) VMP_XP(db, kt, false, 3, 3, 3);                \
+        else if (lay == 3 && kt < 4) VMP_XP(db, kt, false, 3, 0, 3);                            \
+        else if (lay == 3) VMP_XP(db, kt, false, 2, 0, 3);                                      \
+        else if (lay == 1 && kt < 4 && ntm == 3) VMP_XP(db, kt, false, 3, 3, 1);                \
+        else if (lay == 1 && kt < 4) VMP_XP(db, kt, false, 3, 0, 1);                            \
+        else if (lay == 1) VMP_XP(db, kt, false, 2, 0, 1);                                      \
+        else if (ntm == 3 && kt < 4) VMP_XP(db, kt, false, 3, 3, 0);                            \
+        else if (occ >= 3 && kt < 4) VMP_XP(db, kt, false, 3, 0, 0);                            \
+        else VMP_XP(db, kt, false, 2, 0, 0);                                                    \
+    } else
+        VMP_FOR_EACH_INSTANCE(VMP_CASE)
+        {
+            VMP_SET_ERR(ctx, "no kernel instance for DB=%d KT=%d", DB, KT);
+            return VMP_ERR_UNSUPPORTED;
+        }
+#undef VMP_CASE
+#undef VMP_XP
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (ev) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
+        VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    }
+    if (overlap) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xdone, s));
+        ctx->x_pending = 1;
+    }
+    // messages to W from (G, A): main stream, concurrent with the pass
+    return run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), m);
+}
+
 }  // namespace
 
 extern "C" {
@@ -822,85 +970,87 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int
 {
     int32_t rc = check_pass_args(ctx, Y, X, state, workspace, ldy, ldx, N, D, K);
     if (rc != VMP_OK) return rc;
+    return run_xpass(ctx, Y, ldy, N, D, K, X, ldx, state, workspace, 0);
+}
+
+int32_t vmp_pca_tiled_doubles(int32_t D, int32_t K, int64_t N, int64_t *y_doubles,
+                              int64_t *x_doubles)
+{
+    if (D < 1 || K < 1 || N < 0) return VMP_ERR_INVALID;
+    if (D > MAX_DP || K > MAX_KP) return VMP_ERR_UNSUPPORTED;
     vmp_pca_layout L;
     fill_layout(D, K, &L);
-    const int DB = (int)(L.DP / 32), KT = (int)(L.KP / 16);
     const int64_t ntiles = (N + TN - 1) / TN;
-    // full tiles with unpadded D, K run the predication-free instance
-    const bool exact = (D == L.DP && K == L.KP);
-    // a ragged last tile also runs predication-free when both arrays are padded to whole
-    // tiles (its pad columns of X are then written too: <x> of whatever Y holds there)
-    const bool padded = (ldy >= ntiles * TN && ldx >= ntiles * TN);
-    const int64_t nfast = exact ? (padded ? ntiles : N / TN) : 0;
-    const int occ = xpass_occupancy();
-    static const int ntm = env_int("VMP_PCA_XPASS_NT", 3, 0, 3);   // nontemporal Y loads + X stores: +3%
-    hipStream_t m = ctx->stream;
-    // VMP_PCA_PLATE_STREAM=0: everything in order on the caller's stream (A/B measurements)
-    static const int overlap = env_int("VMP_PCA_PLATE_STREAM", 1, 0, 1);
-    hipStream_t s = m;
-    const double *A = state + L.off_A;
-    int64_t gmax = (int64_t)ctx->num_cu * xpass_wgs_per_cu();
-    if (overlap) {
-        rc = ensure_plate_stream(ctx);
-        if (rc != VMP_OK) return rc;
-        gmax = (int64_t)ctx->xs_cus * xpass_wgs_per_cu();
-        // Nothing in a Gram-form iteration reads X: the latent pass is a pure by-product of
-        // (A, Y).  It runs on the plate stream from a private copy of A, so the
-        // replicated-node kernels of the NEXT iteration (main stream, reserved CUs) overlap
-        // it; the only ordering kept is pass(i) before pass(i+1) and before anything that
-        // touches X.
-        double *Ax = plate_stream_A(ctx, L, workspace);
-        if (ctx->x_pending) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(m, ctx->ev_xdone, 0));
-        VMP_HIP_CHECK(ctx, hipMemcpyAsync(Ax, state + L.off_A,
-                                          (size_t)(L.KP * L.DP) * sizeof(double),
-                                          hipMemcpyDeviceToDevice, m));
-        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xfork, m));
-        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->xs, ctx->ev_xfork, 0));
-        s = ctx->xs;
-        A = Ax;
+    if (y_doubles) *y_doubles = ntiles * L.DP * TN;
+    if (x_doubles) *x_doubles = ntiles * L.KP * TN;
+    return VMP_OK;
+}
+
+int32_t vmp_pca_tile_y(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
+                       double *Yt)
+{
+    VMP_REQUIRE(ctx, ctx && Y && Yt, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, (ldy % 2) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)Yt % 16) == 0
+                && ldy >= N, VMP_ERR_INVALID,
+                "Y must be 16-byte aligned with an even leading dimension >= N");
+    vmp_pca_layout L;
+    int32_t rc = vmp_pca_get_layout(D, K, &L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "unsupported dims D=%d K=%d", D, K);
+    const int64_t ntiles = (N + TN - 1) / TN;
+    if (ntiles == 0) return VMP_OK;
+    int64_t g = ntiles < (int64_t)ctx->num_cu * 16 ? ntiles : (int64_t)ctx->num_cu * 16;
+    hipLaunchKernelGGL(pca_tile_kernel<true>, dim3((unsigned)g), dim3(NT), 0, ctx->stream,
+                       const_cast<double *>(Y), ldy, N, D, (int)L.DP, Yt, ntiles);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_tile_x(vmp_ctx *ctx, int32_t to_tiled, double *X, int64_t ldx, int64_t N,
+                       int32_t D, int32_t K, double *Xt)
+{
+    VMP_REQUIRE(ctx, ctx && X && Xt, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, (ldx % 2) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Xt % 16) == 0
+                && ldx >= N, VMP_ERR_INVALID,
+                "X must be 16-byte aligned with an even leading dimension >= N");
+    vmp_pca_layout L;
+    int32_t rc = vmp_pca_get_layout(D, K, &L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "unsupported dims D=%d K=%d", D, K);
+    rc = join_plate_stream(ctx);
+    if (rc != VMP_OK) return rc;
+    const int64_t ntiles = (N + TN - 1) / TN;
+    if (ntiles == 0) return VMP_OK;
+    int64_t g = ntiles < (int64_t)ctx->num_cu * 16 ? ntiles : (int64_t)ctx->num_cu * 16;
+    if (to_tiled)
+        hipLaunchKernelGGL(pca_tile_kernel<true>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, X,
+                           ldx, N, K, (int)L.KP, Xt, ntiles);
+    else
+        hipLaunchKernelGGL(pca_tile_kernel<false>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, X,
+                           ldx, N, K, (int)L.KP, Xt, ntiles);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_pca_xpass_tiled(vmp_ctx *ctx, const double *Yt, int64_t N, int32_t D, int32_t K,
+                            double *X, int64_t ldx, int32_t x_tiled, double *state,
+                            void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx != nullptr, VMP_ERR_INVALID, "null context");
+    VMP_REQUIRE(ctx, Yt && X && state && workspace, VMP_ERR_INVALID, "null pointer argument");
+    VMP_REQUIRE(ctx, D >= 1 && K >= 1 && N >= 0, VMP_ERR_INVALID, "bad dims D=%d K=%d N=%lld", D,
+                K, (long long)N);
+    VMP_REQUIRE(ctx, D <= MAX_DP && K <= MAX_KP, VMP_ERR_UNSUPPORTED,
+                "fused PCA block supports D <= %d, K <= %d (got D=%d, K=%d)", MAX_DP, MAX_KP, D, K);
+    VMP_REQUIRE(ctx, ((uintptr_t)Yt % 16) == 0 && ((uintptr_t)X % 16) == 0, VMP_ERR_INVALID,
+                "tile-major arrays must be 16-byte aligned");
+    const int64_t ntiles = (N + TN - 1) / TN;
+    if (!x_tiled) {
+        VMP_REQUIRE(ctx, (ldx % 2) == 0 && ldx >= ntiles * TN, VMP_ERR_INVALID,
+                    "row-major X beside a tile-major Y needs KP rows of an even leading "
+                    "dimension >= 32 ceil(N/32) (ldx=%lld)", (long long)ldx);
+        VMP_REQUIRE(ctx, ldx < (int64_t)170000000, VMP_ERR_UNSUPPORTED,
+                    "leading dimension >= 1.7e8 elements per shard is not supported");
     }
-    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
-    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool guard = (pass == 1);
-        const int64_t t0 = guard ? nfast : 0, t1 = guard ? ntiles : nfast;
-        if (t1 <= t0) continue;
-        int64_t g = (t1 - t0 + 3) / 4;
-        if (g > gmax) g = gmax;
-        const dim3 grid((unsigned)g);
-#define VMP_CASE(db, kt)                                                                        \
-    if (DB == db && KT == kt) {                                                                 \
-        if (guard)                                                                              \
-            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, true, 2>), grid, dim3(NT), 0, s, Y,    \
-                               ldy, N, D, K, A, X, ldx, t0, t1);                                \
-        else if (ntm == 3 && kt < 4)                                                            \
-            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3, 3>), grid, dim3(NT), 0, s,   \
-                               Y, ldy, N, D, K, A, X, ldx, t0, t1);                             \
-        else if (occ >= 3 && kt < 4)                                                            \
-            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 3>), grid, dim3(NT), 0, s, Y,   \
-                               ldy, N, D, K, A, X, ldx, t0, t1);                                \
-        else                                                                                    \
-            hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, 2>), grid, dim3(NT), 0, s, Y,   \
-                               ldy, N, D, K, A, X, ldx, t0, t1);                                \
-    } else
-        VMP_FOR_EACH_INSTANCE(VMP_CASE)
-        {
-            VMP_SET_ERR(ctx, "no kernel instance for DB=%d KT=%d", DB, KT);
-            return VMP_ERR_UNSUPPORTED;
-        }
-#undef VMP_CASE
-        VMP_HIP_CHECK(ctx, hipGetLastError());
-    }
-    if (ev) {
-        VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
-        VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
-    }
-    if (overlap) {
-        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xdone, s));
-        ctx->x_pending = 1;
-    }
-    // messages to W from (G, A): main stream, concurrent with the pass
-    return run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), m);
+    return run_xpass(ctx, Yt, 0, N, D, K, X, ldx, state, workspace, x_tiled ? 3 : 1);
 }
 
 int32_t vmp_pca_xjoin(vmp_ctx *ctx)

@@ -23,7 +23,10 @@ Two forms of that pass (``stats=``):
 * ``'gram'`` (default): ``vmp_pca_xpass`` writes <x_n> = A y_n (read Y once,
   write <x> once -- HBM-bound) and the messages to W come from the constant
   Gram matrix G = Y Y^T, computed and summed over ranks ONCE at set-up; no
-  per-iteration collective is left.
+  per-iteration collective is left.  Y is constant after ``observe()``, so the
+  plan keeps a tile-major copy of it (``layout='tiled'``, 32 plate elements per
+  contiguous block, ``vmp_pca_tile_y``) that the pass streams instead of D row
+  segments per tile; ``layout='rows'`` passes over the row-major array.
 * ``'stream'``: ``vmp_pca_pass`` additionally accumulates sum y<x>^T and
   sum <x><x>^T while streaming (fp64-MFMA-bound); the partial sums are
   all-reduced over ranks every iteration (the reference's plate sums,
@@ -98,12 +101,25 @@ class HIPKernels:
     def xjoin(self):
         self.rt.check(self.lib.vmp_pca_xjoin(self.ctx))
 
+    def tile_y(self, Y, ldy, N, D, K):
+        """Tile-major copy of the constant data (vmp_pca_tile_y): [tile][DP][32]."""
+        n = ctypes.c_int64()
+        self.rt.check(self.lib.vmp_pca_tiled_doubles(D, K, N, ctypes.byref(n), None))
+        Yt = self.rt.empty(max(int(n.value), 1))
+        self.rt.check(self.lib.vmp_pca_tile_y(self.ctx, ptr(Y), ldy, N, D, K, ptr(Yt)))
+        return Yt
+
+    def xpass_tiled(self, Yt, N, D, K, X, ldx, state, ws):
+        self.rt.check(self.lib.vmp_pca_xpass_tiled(self.ctx, ptr(Yt), N, D, K, ptr(X), ldx, 0,
+                                                   ptr(state), ptr(ws)))
+
     def rotate_rows(self, R, X, N):
         """X[:, :N] <- R X[:, :N] on the device (vmp_gemm_strided via utils.linalg)."""
         from ...darray import DArray
         from ...utils import linalg
-        xn = linalg.mmdot(DArray.from_host(np.ascontiguousarray(R)), DArray(X[:, :N]))
-        X[:, :N].copy_(xn.t)
+        K = R.shape[0]
+        xn = linalg.mmdot(DArray.from_host(np.ascontiguousarray(R)), DArray(X[:K, :N]))
+        X[:K, :N].copy_(xn.t)
 
     def set_timing(self, on):
         self.rt.check(self.lib.vmp_ctx_set_timing(self.ctx, 1 if on else 0))
@@ -196,12 +212,18 @@ class PCAPlan:
         return None
 
     # -- construction ------------------------------------------------------------------
-    def __init__(self, roles, runtime=None, kernels=None, stats=None):
+    def __init__(self, roles, runtime=None, kernels=None, stats=None, layout=None):
         if stats is None:
             stats = os.environ.get('BAYESPY_AMD_PCA_STATS', 'gram')
         if stats not in ('gram', 'stream'):
             raise ValueError("stats must be 'gram' or 'stream'")
         self.stats = stats
+        if layout is None:
+            layout = os.environ.get('BAYESPY_AMD_PCA_LAYOUT', 'tiled')
+        if layout not in ('tiled', 'rows'):
+            raise ValueError("layout must be 'tiled' or 'rows'")
+        self.plate_layout = layout
+        self.Yt = None
         self.roles = roles
         self.Y, self.F, self.W, self.X = roles['Y'], roles['F'], roles['W'], roles['X']
         self.tau, self.alpha = roles['tau'], roles['alpha']
@@ -294,8 +316,10 @@ class PCAPlan:
             rt.all_reduce_sum_(self.state[L.off_G:L.off_G + DP * DP])
         # ---- X: delta moments (initialize_from_value/random) or the prior --------------
         init = self.X._init
+        KPx = int(L.KP)       # pad rows: the tile-major pass writes whole 16-row blocks of <x>
+        self.Yt = None
         if init is None:
-            self.Xd = rt.zeros(K, self.ldx)
+            self.Xd = rt.zeros(KPx, self.ldx)
             self._set_block(L.off_CX, np.eye(K) / self.x_prec)
         else:
             if init[0] == 'value':
@@ -304,12 +328,13 @@ class PCAPlan:
                     x0 = x0.detach().cpu().numpy()
                 x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
                                      self.X.plates + (K,)).reshape(N, K)
-                self.Xd = rt.zeros(K, self.ldx)
-                self.Xd[:, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
+                self.Xd = rt.zeros(KPx, self.ldx)
+                self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
             else:
                 # a draw from the current q = prior N(0, I/x_prec) (expfamily.py:206-212);
                 # RNG streams are not part of the parity contract
-                self.Xd = torch.randn(K, self.ldx, dtype=torch.float64, device=rt.device)
+                self.Xd = rt.zeros(KPx, self.ldx)
+                self.Xd[:K].copy_(torch.randn(K, self.ldx, dtype=torch.float64, device=rt.device))
                 if self.x_prec != 1.0:
                     self.Xd.mul_(self.x_prec ** -0.5)
             k.stats_from_x(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
@@ -358,7 +383,12 @@ class PCAPlan:
             rt.sync_stream()
             if self.stats == 'gram':
                 # messages to W from the global Gram matrix: nothing to exchange
-                k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+                if self.plate_layout == 'tiled':
+                    if self.Yt is None:
+                        self.Yt = k.tile_y(self.Yd, self.ldy, N, D, K)
+                    k.xpass_tiled(self.Yt, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+                else:
+                    k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
             else:
                 k.pass_(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
                 # child -> parent message sum over the sharded plate (node.py:650, dot.py:581)
@@ -457,7 +487,7 @@ class PCAPlan:
             return [w.reshape(self.W.plates + (K,)), u1.reshape(self.W.plates + (K, K))]
         if node is self.X:
             self.finish()
-            x = self.Xd[:, :N].cpu().numpy().T.copy()
+            x = self.Xd[:K, :N].cpu().numpy().T.copy()
             cx = self._block(L.off_CX, K, K, KP)
             u1 = x[:, :, None] * x[:, None, :] + cx
             return [x.reshape(self.X.plates + (K,)), u1.reshape(self.X.plates + (K, K))]
@@ -489,7 +519,7 @@ class PCAPlan:
             return self._block(L.off_W, self.D, K, KP), self._block(L.off_CW, K, K, KP)
         if node is self.X:
             self.finish()
-            return (self.Xd[:, :self.N].cpu().numpy().T.copy(),
+            return (self.Xd[:K, :self.N].cpu().numpy().T.copy(),
                     self._block(L.off_CX, K, K, KP))
         raise NotImplementedError
 
@@ -521,7 +551,7 @@ class PCAPlan:
         put(base + 'kind', np.array([ord(c) for c in 'pca'], dtype=np.uint8))
         put(base + 'dims', np.array([self.D, self.N, self.K], dtype=np.int64))
         put(base + 'state', self.state.cpu().numpy())
-        put(base + 'X', self.Xd[:, :self.N].cpu().numpy())
+        put(base + 'X', self.Xd[:self.K, :self.N].cpu().numpy())
         for node in nodes:
             if node in (self.W, self.tau, self.alpha):
                 for i, ui in enumerate(self.get_moments(node)):
@@ -541,8 +571,8 @@ class PCAPlan:
         torch = self.rt.torch
         st = np.array(reader.get(base + 'state'), dtype=np.float64)
         self.state.copy_(torch.from_numpy(st))
-        self.Xd[:, :self.N].copy_(torch.from_numpy(np.array(reader.get(base + 'X'),
-                                                           dtype=np.float64)))
+        self.Xd[:self.K, :self.N].copy_(torch.from_numpy(np.array(reader.get(base + 'X'),
+                                                                 dtype=np.float64)))
         self._version += 1
 
     # -- rotations (inference/transformations.py) ----------------------------------------------------

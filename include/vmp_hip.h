@@ -167,6 +167,27 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
 /* Make the context's stream wait for the outstanding vmp_pca_xpass (no host block). */
 int32_t vmp_pca_xjoin(vmp_ctx *ctx);
 
+/* Tile-major layout of the plate arrays.  Y is constant after Y.observe()
+ * (stochastic.py:223-250), so it is re-laid-out ONCE into blocks of 32 plate elements,
+ *     Yt[tile][d][j] = Y[d][32 tile + j],   tile < ceil(N/32), d < DP, j < 32,
+ * zero padded in d and in the last tile.  The plate pass then streams one contiguous
+ * 8*32*DP-byte span per tile (every load instruction of a wavefront covers 1 KB of consecutive
+ * addresses) instead of DP row streams that lie 8*ldy bytes apart.  X may use the same layout
+ * with KP rows per tile ([tile][k][j]).  vmp_pca_tiled_doubles gives the array sizes. */
+int32_t vmp_pca_tiled_doubles(int32_t D, int32_t K, int64_t N, int64_t *y_doubles,
+                              int64_t *x_doubles);
+int32_t vmp_pca_tile_y(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
+                       int32_t D, int32_t K, double *Yt);
+/* to_tiled != 0: Xt <- X (K rows of the row-major (K, ldx) array); else X <- Xt. */
+int32_t vmp_pca_tile_x(vmp_ctx *ctx, int32_t to_tiled, double *X, int64_t ldx, int64_t N,
+                       int32_t D, int32_t K, double *Xt);
+/* vmp_pca_xpass on a tile-major Y.  x_tiled != 0: X is tile-major too (ldx ignored);
+ * x_tiled == 0: X is row-major with KP rows and ldx >= 32*ceil(N/32) (pad rows / columns are
+ * written).  Results are bit-identical to vmp_pca_xpass. */
+int32_t vmp_pca_xpass_tiled(vmp_ctx *ctx, const double *Yt, int64_t N, int32_t D, int32_t K,
+                            double *X, int64_t ldx, int32_t x_tiled,
+                            double *state, void *workspace);
+
 /* X.update(), plate half, streaming-statistics form: for every local n
  *   <x_n> = A y_n  (written to X, (K,N) row-major),
  *   S <- [sum y_n <x_n>^T ; sum <x_n><x_n>^T]  (local partial; caller all-reduces:
@@ -380,6 +401,11 @@ int32_t vmp_alpha_beta_recursion(vmp_ctx *ctx, int32_t N, int32_t K, int64_t nch
 int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, int64_t ny,
                                const double *A, const double *B, const double *y, double *V,
                                double *C, double *x, double *ldet, int32_t *info);
+
+/* Measurement knob: overrides a launch parameter the library otherwise takes from its
+ * environment variable / default ("xpass_nt", "xpass_wgs_per_cu", "xpass_occ",
+ * "plate_stream", ...); process-wide, for A/B harnesses (tools/xpass_lab.hip). */
+int32_t vmp_tune_set(const char *key, int32_t value);
 
 /* Elapsed milliseconds of the most recent vmp_pca_xpass / vmp_pca_pass on this context,
  * measured with HIP events on the stream the pass kernel was launched on (blocks until done);

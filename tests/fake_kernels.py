@@ -72,7 +72,7 @@ class CPURuntimeKernels:
     def stats_from_x(self, Y, ldy, N, D, K, X, ldx, state, ws):
         self.calls.append('stats_from_x')
         v = self._v(state, D, K)
-        y, x = Y.numpy()[:, :N], X.numpy()[:, :N]
+        y, x = Y.numpy()[:, :N], X.numpy()[:K, :N]
         v['S'][:] = 0
         v['S'][:D, :K] = y @ x.T
         v['S'][v['DP']:v['DP'] + K, :K] = x @ x.T
@@ -106,7 +106,7 @@ class CPURuntimeKernels:
         v = self._v(state, D, K)
         y = Y.numpy()[:, :N]
         x = v['A'][:K, :D] @ y
-        X.numpy()[:, :N] = x
+        X.numpy()[:K, :N] = x
         v['S'][:] = 0
         v['S'][:D, :K] = y @ x.T
         v['S'][v['DP']:v['DP'] + K, :K] = x @ x.T
@@ -121,7 +121,7 @@ class CPURuntimeKernels:
         self.calls.append('xpass')
         v = self._v(state, D, K)
         A = v['A'][:K, :D]
-        X.numpy()[:, :N] = A @ Y.numpy()[:, :N]
+        X.numpy()[:K, :N] = A @ Y.numpy()[:, :N]
         syx = v['G'][:D, :D] @ A.T
         v['S'][:] = 0
         v['S'][:D, :K] = syx
@@ -129,6 +129,26 @@ class CPURuntimeKernels:
 
     def xjoin(self):
         self.calls.append('xjoin')
+
+    def tile_y(self, Y, ldy, N, D, K):
+        """vmp_pca_tile_y: [tile][DP][32], zero padded."""
+        self.calls.append('tile_y')
+        import torch
+        DP = int(self.layout(D, K).DP)
+        nt = (N + 31) // 32
+        buf = np.zeros((DP, nt * 32))
+        buf[:D, :N] = Y.numpy()[:, :N]
+        return torch.from_numpy(np.ascontiguousarray(
+            buf.reshape(DP, nt, 32).transpose(1, 0, 2)).reshape(-1))
+
+    def xpass_tiled(self, Yt, N, D, K, X, ldx, state, ws):
+        self.calls.append('xpass_tiled')
+        import torch
+        DP = int(self.layout(D, K).DP)
+        nt = (N + 31) // 32
+        y = Yt.numpy().reshape(nt, DP, 32).transpose(1, 0, 2).reshape(DP, nt * 32)[:D, :N]
+        self.xpass(torch.from_numpy(np.ascontiguousarray(y)), N, N, D, K, X, ldx, state, ws)
+        self.calls.pop()
 
     def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state):
         """vmp_pca_small_ops: the operations in order (launch fusion is not modelled)."""
@@ -183,7 +203,8 @@ class CPURuntimeKernels:
         v['Lt'][:6] = [LY, LX, LW, Lt, La, LY + LX + LW + Lt + La]
 
     def rotate_rows(self, R, X, N):
-        X.numpy()[:, :N] = R @ X.numpy()[:, :N]
+        K = R.shape[0]
+        X.numpy()[:K, :N] = R @ X.numpy()[:K, :N]
 
     def set_timing(self, on):
         pass

@@ -317,3 +317,77 @@ def test_config2_size_vs_oracle():
         xs, cx = Q.plans[0].posterior_parameters(Q['X'])
         np.testing.assert_allclose(xs, o.X, rtol=MOM_RTOL, atol=1e-9)
         np.testing.assert_allclose(Q['tau'].u[0], o.moments()['tau'][0], rtol=1e-9)
+
+
+@pytest.mark.parametrize('N,D,K', [(1, 1, 1), (33, 17, 3), (4097, 100, 10), (70001, 128, 32),
+                                   (2000, 256, 64)])
+def test_tile_major_pass_is_bit_identical_to_row_major(N, D, K):
+    """vmp_pca_tile_y / vmp_pca_xpass_tiled / vmp_pca_tile_x through the raw C ABI: the
+    tile-major copy of the constant data changes addresses only, so <x> must agree with the
+    row-major pass bit for bit (both X layouts), and both with A y to round-off."""
+    import torch
+    from bayespy_amd import _lib
+    from bayespy_amd.device import get_runtime, ptr
+    rt = get_runtime()
+    lib = rt.lib
+    rs = np.random.RandomState(N + D)
+    L = _lib.PCALayout()
+    assert lib.vmp_pca_get_layout(D, K, ctypes.byref(L)) == 0
+    DP, KP = int(L.DP), int(L.KP)
+    nbytes = ctypes.c_size_t()
+    rt.check(lib.vmp_pca_workspace_bytes(rt.ctx, D, K, ctypes.byref(nbytes)))
+    ws = rt.empty(nbytes.value // 8)
+    state = rt.zeros(int(L.total))
+    A = rs.normal(size=(K, D))
+    y = rs.normal(size=(D, N))
+    Ap = np.zeros((KP, DP))
+    Ap[:K, :D] = A
+    state[L.off_A:L.off_A + KP * DP].copy_(torch.from_numpy(Ap.reshape(-1)))
+    ld = (N + 31) // 32 * 32
+    Yd = rt.zeros(D, ld)
+    Yd[:, :N].copy_(torch.from_numpy(y))
+    ny, nx = ctypes.c_int64(), ctypes.c_int64()
+    rt.check(lib.vmp_pca_tiled_doubles(D, K, N, ctypes.byref(ny), ctypes.byref(nx)))
+    nt = (N + 31) // 32
+    assert ny.value == nt * DP * 32 and nx.value == nt * KP * 32
+    Yt = rt.empty(ny.value)
+    Xt = rt.empty(nx.value)
+    X0, X1, X2 = rt.zeros(KP, ld), rt.zeros(KP, ld), rt.zeros(KP, ld)
+    rt.sync_stream()
+    rt.check(lib.vmp_pca_tile_y(rt.ctx, ptr(Yd), ld, N, D, K, ptr(Yt)))
+    yt = Yt.cpu().numpy().reshape(nt, DP, 32)
+    ref = np.zeros((DP, nt * 32))
+    ref[:D, :N] = y
+    np.testing.assert_array_equal(yt, ref.reshape(DP, nt, 32).transpose(1, 0, 2))
+    rt.check(lib.vmp_pca_xpass(rt.ctx, ptr(Yd), ld, N, D, K, ptr(X0), ld, ptr(state), ptr(ws)))
+    rt.check(lib.vmp_pca_xpass_tiled(rt.ctx, ptr(Yt), N, D, K, ptr(X1), ld, 0, ptr(state),
+                                     ptr(ws)))
+    rt.check(lib.vmp_pca_xpass_tiled(rt.ctx, ptr(Yt), N, D, K, ptr(Xt), ld, 1, ptr(state),
+                                     ptr(ws)))
+    rt.check(lib.vmp_pca_tile_x(rt.ctx, 0, ptr(X2), ld, N, D, K, ptr(Xt)))
+    rt.check(lib.vmp_ctx_sync(rt.ctx))
+    x0, x1, x2 = (t[:K, :N].cpu().numpy() for t in (X0, X1, X2))
+    np.testing.assert_allclose(x0, A @ y, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(x1, x0)
+    np.testing.assert_array_equal(x2, x0)
+    # round trip of the X layout
+    Xt2 = rt.zeros(nx.value)
+    rt.check(lib.vmp_pca_tile_x(rt.ctx, 1, ptr(X0), ld, N, D, K, ptr(Xt2)))
+    np.testing.assert_array_equal(
+        Xt2.cpu().numpy().reshape(nt, KP, 32)[:, :K].transpose(1, 0, 2).reshape(K, -1)[:, :N], x0)
+
+
+def test_plan_layouts_agree():
+    from oracle.pca import make_pca_data
+    y, x0 = make_pca_data(5003, 40, 7, seed=5)
+    Ls = []
+    for layout in ('tiled', 'rows'):
+        import bayespy_amd.nodes as nodes
+        from bayespy_amd.inference import VB
+        from models import build_pca
+        Q = build_pca(nodes, VB, y, x0, 7)
+        Q.plans[0].plate_layout = layout
+        Q.update(repeat=3, verbose=False)
+        Ls.append((Q.L[:3].copy(), Q['X'].u[0].copy()))
+    np.testing.assert_array_equal(Ls[0][0], Ls[1][0])
+    np.testing.assert_array_equal(Ls[0][1], Ls[1][1])

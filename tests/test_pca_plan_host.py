@@ -52,12 +52,20 @@ def test_update_order_and_one_pass_per_iteration(golden_dir):
     Q.update(repeat=2, verbose=False)
     calls = Q.plans[0].kernels.calls
     assert calls[:2] == ['gram', 'stats_from_x']
-    per_iter = ['update_w', 'prepare_x', 'xpass', 'update_tau', 'update_alpha']
-    # the latent pass stays in flight across iterations; it is joined once per VB.update()
-    assert calls[2:] == per_iter * 2 + ['xjoin']
+    per_iter = ['update_w', 'prepare_x', 'xpass_tiled', 'update_tau', 'update_alpha']
+    # the constant data is re-laid-out tile-major ONCE (before the first pass); the latent pass
+    # stays in flight across iterations and is joined once per VB.update()
+    assert calls[2:] == (['update_w', 'prepare_x', 'tile_y', 'xpass_tiled', 'update_tau',
+                          'update_alpha'] + per_iter + ['xjoin'])
     # explicit node order, as VB.update(*nodes) allows (vmp.py:139-141)
     Q.update(Q['X'], Q['W'], repeat=1, verbose=False)
-    assert Q.plans[0].kernels.calls[-4:] == ['prepare_x', 'xpass', 'update_w', 'xjoin']
+    assert Q.plans[0].kernels.calls[-4:] == ['prepare_x', 'xpass_tiled', 'update_w', 'xjoin']
+    # layout='rows': the pass over the row-major array
+    Q3 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q3.plans[0].plate_layout = 'rows'
+    Q3.update(repeat=1, verbose=False)
+    assert 'xpass' in Q3.plans[0].kernels.calls and 'tile_y' not in Q3.plans[0].kernels.calls
+    np.testing.assert_array_equal(Q3.L[:1], Q.L[:1])
     # streaming-statistics form: one fused pass per iteration instead
     Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3), 'stream')
     Q2.update(repeat=1, verbose=False)

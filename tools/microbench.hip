@@ -59,6 +59,46 @@ __global__ void __launch_bounds__(256) stream_copy(const v2f64 *in, v2f64 *out, 
         out[i] = in[i];
 }
 
+// copy with U independent 16-byte loads in flight per thread; NT = nontemporal accesses
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) stream_copy_u(const v2f64 *in, v2f64 *out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        v2f64 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            v[u] = NT ? __builtin_nontemporal_load(in + i + u * stride) : in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], out + i + u * stride);
+            else out[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n; i += stride) out[i] = in[i];
+}
+
+// the traffic mix of the PCA plate pass: read 4 units, write 1 (Y is D = 128 rows, X is K = 32)
+template <bool NT>
+__global__ void __launch_bounds__(256) stream_r4w1(const v2f64 *in, v2f64 *out, size_t nout)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nout; i += stride) {
+        v2f64 a, b, c, d;
+        if (NT) {
+            a = __builtin_nontemporal_load(in + i);
+            b = __builtin_nontemporal_load(in + nout + i);
+            c = __builtin_nontemporal_load(in + 2 * nout + i);
+            d = __builtin_nontemporal_load(in + 3 * nout + i);
+            __builtin_nontemporal_store((a + b) + (c + d), out + i);
+        } else {
+            a = in[i]; b = in[nout + i]; c = in[2 * nout + i]; d = in[3 * nout + i];
+            out[i] = (a + b) + (c + d);
+        }
+    }
+}
+
 template <typename F>
 float time_ms(F f, int reps)
 {
@@ -118,6 +158,23 @@ int main()
         float ms = time_ms([&] { hipLaunchKernelGGL(stream_read, dim3(g), dim3(256), 0, 0, a, out, n); }, 5);
         float mc = time_ms([&] { hipLaunchKernelGGL(stream_copy, dim3(g), dim3(256), 0, 0, a, b, n); }, 5);
         printf("grid %5d: stream read %.0f GB/s, copy (r+w) %.0f GB/s\n", g, bytes / ms / 1e6, 2.0 * bytes / mc / 1e6);
+    }
+    for (int g = 1024; g <= 8192; g *= 2) {
+        float m1 = time_ms([&] { hipLaunchKernelGGL((stream_copy_u<4, false>), dim3(g), dim3(256), 0, 0, a, b, n); }, 5);
+        float m2 = time_ms([&] { hipLaunchKernelGGL((stream_copy_u<4, true>), dim3(g), dim3(256), 0, 0, a, b, n); }, 5);
+        float m3 = time_ms([&] { hipLaunchKernelGGL((stream_copy_u<8, true>), dim3(g), dim3(256), 0, 0, a, b, n); }, 5);
+        printf("grid %5d: copy (r+w) 4 loads in flight %.0f GB/s, nontemporal %.0f GB/s, 8 in flight nontemporal %.0f GB/s\n",
+               g, 2.0 * bytes / m1 / 1e6, 2.0 * bytes / m2 / 1e6, 2.0 * bytes / m3 / 1e6);
+    }
+    {
+        // 4:1 read:write stream (the plate pass of PCA at D=128, K=32): 4 GB read, 1 GB written
+        const size_t nout = n / 4;
+        for (int g = 1024; g <= 8192; g *= 2) {
+            float m1 = time_ms([&] { hipLaunchKernelGGL(stream_r4w1<false>, dim3(g), dim3(256), 0, 0, a, b, nout); }, 5);
+            float m2 = time_ms([&] { hipLaunchKernelGGL(stream_r4w1<true>, dim3(g), dim3(256), 0, 0, a, b, nout); }, 5);
+            printf("grid %5d: 4:1 read:write stream %.0f GB/s, nontemporal %.0f GB/s\n", g,
+                   1.25 * bytes / m1 / 1e6, 1.25 * bytes / m2 / 1e6);
+        }
     }
     return 0;
 }
