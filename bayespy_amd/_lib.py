@@ -76,6 +76,11 @@ SIGNATURES = {
     'vmp_memcpy_h2d': (c_i32, [c_vp, c_vp, c_vp, c_sz]),
     'vmp_memcpy_d2h': (c_i32, [c_vp, c_vp, c_vp, c_sz]),
     'vmp_memset_zero': (c_i32, [c_vp, c_vp, c_sz]),
+    'vmp_comm_unique_id': (c_i32, [c_vp, c_vp]),
+    'vmp_comm_init_rank': (c_i32, [c_vp, c_vp, c_i32, c_i32]),
+    'vmp_comm_destroy': (c_i32, [c_vp]),
+    'vmp_comm_info': (c_i32, [c_vp, P(c_i32), P(c_i32)]),
+    'vmp_allreduce_sum_f64': (c_i32, [c_vp, c_vp, c_i64]),
     'vmp_pca_get_layout': (c_i32, [c_i32, c_i32, P(PCALayout)]),
     'vmp_pca_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, P(c_sz)]),
     'vmp_pca_init_state': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_vp]),

@@ -26,6 +26,9 @@ struct vmp_ctx {
     hipEvent_t ev_xfork, ev_xdone;
     int x_pending;
     int xs_cus;                // compute units the plate stream may use
+    // RCCL communicator (vmp_comm.hip); null = a world of one rank
+    void *comm;
+    int comm_rank, comm_world;
     char err[512];
 };
 

@@ -64,6 +64,9 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     ctx->ev_xfork = ctx->ev_xdone = nullptr;
     ctx->x_pending = 0;
     ctx->xs_cus = 0;
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
     VMP_HIP_CHECK(ctx, hipSetDevice(device));
     int cu = 0;
     VMP_HIP_CHECK(ctx, hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device));
@@ -75,6 +78,7 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
 int32_t vmp_ctx_destroy(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_OK;
+    (void)vmp_comm_destroy(ctx);
     for (int i = 0; i < 3 * VMP_EV_RING; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->xs) {

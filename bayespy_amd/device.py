@@ -32,6 +32,7 @@ class Runtime:
             self.device = torch.device(device)
         self.lib = None
         self.ctx = None
+        self._comm_state = None     # None: not decided; True: the library owns an RCCL communicator
         self._op_depth = 0
         self._deferred = []
         if self.device.type == 'cuda':
@@ -60,12 +61,47 @@ class Runtime:
         else:
             self.rank, self.world = 0, 1
 
+    def _ensure_comm(self):
+        """Give the library its own RCCL communicator over the ranks of the
+        ``torch.distributed`` world (``vmp_comm_init_rank``).  torch.distributed is the
+        rendezvous only: it ships rank 0's 128-byte id.  Worlds on another backend (gloo: CPU
+        tests, several ranks on one GPU) keep torch's collective."""
+        if self._comm_state is not None:
+            return self._comm_state
+        self._comm_state = False
+        dist = self.torch.distributed
+        if self.ctx is None or not (dist.is_available() and dist.is_initialized()):
+            return False
+        if dist.get_backend() != 'nccl' or os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'torch':
+            return False
+        cid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            self.check(self.lib.vmp_comm_unique_id(self.ctx, cid))
+        box = [cid.raw if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        cid = ctypes.create_string_buffer(box[0], 128)
+        self.check(self.lib.vmp_comm_init_rank(self.ctx, cid, self.rank, self.world))
+        self._comm_state = True
+        return True
+
     def all_reduce_sum_(self, tensor):
-        """In-place sum over ranks (RCCL all-reduce over xGMI on GPUs).  This is
-        the ONLY data-path collective: it stands where the reference sums a
-        message over a plate the parent lacks (node.py:650, dot.py:581) and
-        where it sums the per-node lower bound (expfamily.py:470-480)."""
+        """In-place sum over ranks: ``vmp_allreduce_sum_f64`` (RCCL all-reduce over xGMI,
+        enqueued on the context's stream by the library).  This is the ONLY data-path
+        collective: it stands where the reference sums a message over a plate the parent
+        lacks (node.py:650, dot.py:581) and where it sums the per-node lower bound
+        (expfamily.py:470-480)."""
         self._refresh_dist()
+        if self._ensure_comm():
+            if tensor.numel() == 0:
+                return tensor
+            buf = tensor if tensor.is_contiguous() else tensor.contiguous()
+            if buf.dtype != self.torch.float64:
+                raise TypeError('plate sums are fp64')
+            self.sync_stream()
+            self.check(self.lib.vmp_allreduce_sum_f64(self.ctx, ptr(buf), buf.numel()))
+            if buf is not tensor:
+                tensor.copy_(buf)
+            return tensor
         if self.world > 1:
             self.torch.distributed.all_reduce(tensor)
         return tensor

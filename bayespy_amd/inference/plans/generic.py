@@ -181,6 +181,8 @@ class GammaFamily(Family):
     def cgf_from_parents(self, up):
         return fuse(lambda a, lga, logb: a * logb - lga, up[0][0], up[0][1], up[1][1])
 
+    missing_fill = 1.0       # finite log at masked-out entries
+
     def fixed_moments_and_f(self, x):
         x = _arr(x)
         _check_device(x, lambda t: t < 0, ValueError, "Values must be positive")
@@ -961,7 +963,8 @@ def make_family(node):
 # the plan: state + routing
 # ---------------------------------------------------------------------------
 class _State:
-    __slots__ = ('u', 'phi', 'g', 'f', 'observed', 'mask', 'ready')
+    __slots__ = ('u', 'phi', 'g', 'f', 'observed', 'mask', 'ready', 'u_obs', 'obs_mask',
+                 'partial', 'stale')
 
     def __init__(self):
         self.u = self.phi = None
@@ -969,6 +972,10 @@ class _State:
         self.observed = False
         self.mask = None
         self.ready = False
+        self.u_obs = None        # fixed moments of the data (partially observed node)
+        self.obs_mask = None     # 0/1 device array over the plates: where data were given
+        self.partial = False     # observed with an array mask that leaves plates latent
+        self.stale = False       # q of the latent plates awaits a refresh (leaf nodes: lazily)
 
 
 def _operation(method):
@@ -1035,8 +1042,21 @@ class GenericPlan:
         fam = self.family[id(node)]
         st.ready = True          # guards recursion through parents
         if node.observed:
-            u, f = fam.fixed_moments_and_f(node._data)
+            data, om = node._data, node._mask
+            st.partial = om is not True and not bool(np.all(om))
+            if st.partial:
+                # Missing entries usually carry NaN / inf placeholders.  The reference never
+                # reads them: it writes moments with np.copyto(where=mask)
+                # (stochastic.py:223-250).  Here masks multiply, so the placeholders are
+                # replaced by a finite value before upload (0 * finite = 0, never NaN).
+                data = self._fill_missing(node, fam, data, om)
+                st.obs_mask = DArray.from_host(
+                    np.ascontiguousarray(np.broadcast_to(np.asarray(om, dtype=bool), node.plates)
+                                         .astype(np.float64)))
+            u, f = fam.fixed_moments_and_f(data)
             st.u, st.f, st.g = u, f, None
+            st.u_obs = u
+            st.stale = st.partial
             st.observed = True
             st.phi = None
         else:
@@ -1068,6 +1088,31 @@ class GenericPlan:
                 st.g = np.inf
             st.f = None
         return st
+
+    def _fill_missing(self, node, fam, data, om):
+        """``data`` with a finite placeholder where the observation mask is False."""
+        fill = float(getattr(fam, 'missing_fill', 0.0))
+        nd = len(node.dims[0])
+        m = np.asarray(om, dtype=bool)
+        m = m.reshape(m.shape + (1,) * nd)
+        torch = self.rt.torch
+        if isinstance(data, torch.Tensor):
+            mt = torch.from_numpy(np.ascontiguousarray(m)).to(data.device)
+            return torch.where(mt, data, torch.full((), fill, dtype=data.dtype, device=data.device))
+        a = np.asarray(data)
+        return np.where(m, a, np.asarray(fill, dtype=a.dtype if a.dtype.kind == 'f' else np.float64))
+
+    def _refresh_partial(self, node, st):
+        """A partially observed node: the plates without data are ordinary latent plates, the
+        reference updates them (stochastic.py:276-282 with ``mask = not observed``).  q of
+        those plates = prior from the parents + messages of the children; the observed plates
+        keep the fixed moments of the data."""
+        fam = self.family[id(node)]
+        phi = self._optimal_phi(node)
+        uq, _ = fam.moments_and_cgf(phi)
+        st.u = [fuse(lambda m, a, b: m * a + (1.0 - m) * b, _trail(st.obs_mask, len(node.dims[i])),
+                     _arr(st.u_obs[i]), _arr(uq[i])) for i in range(len(uq))]
+        st.stale = False
 
     def _sample(self, node, fam, u):
         """A draw from the current q (initialize_from_random, expfamily.py:206-212); set-up
@@ -1321,6 +1366,11 @@ class GenericPlan:
             return
         st = self._ensure(node)
         if st.observed:
+            if st.partial:
+                if node.children:
+                    self._refresh_partial(node, st)   # children read the latent plates
+                else:
+                    st.stale = True                   # a leaf: refreshed when inspected
             return
         phi = self._optimal_phi(node)
         st.phi = phi
@@ -1414,7 +1464,12 @@ class GenericPlan:
         vals = iter(self.rt.torch.cat(dev).cpu().numpy() if dev else ())
         return [f if t is None else float(next(vals)) * f for t, f in parts]
 
+    @_operation
     def get_moments(self, node):
+        if isinstance(node, Stochastic):
+            st = self._ensure(node)
+            if st.observed and st.partial and st.stale:
+                self._refresh_partial(node, st)
         return [np.asarray(_arr(m).numpy()) for m in self._moments(node)]
 
     # -- persistence (stochastic.py:305-355, expfamily.py:507-535) ------------------------------

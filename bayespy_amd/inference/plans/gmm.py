@@ -174,6 +174,10 @@ class GMMPlan:
             GenericPlan(self.nodes())
 
     def _all_reduce_stats(self):
+        """Plate sums over the ranks (node.py:650) -- only when the observation plate was
+        declared sharded with Node.shard() on z or Y (the same contract as every other plan)."""
+        if not any(getattr(n, '_shard_axis', None) is not None for n in (self.z, self.Y)):
+            return
         L = self.layout
         self.rt.all_reduce_sum_(self.state[L.off_T:L.off_T + L.len_T])
         self.rt.all_reduce_sum_(self.state[L.off_zs:L.off_zs + 2])

@@ -166,6 +166,28 @@ class PCAPlan:
 
     # -- pattern matching -----------------------------------------------------------
     @staticmethod
+    def unsupported_state(roles):
+        """Why the block cannot represent the nodes' current observation / initialisation
+        state (None if it can).  The block starts tau, alpha from their priors, W from its
+        prior / a value / a draw, X likewise, and updates every role but Y: anything else
+        (``tau.observe``, ``alpha.initialize_from_value``, ``initialize_from_parameters``, a
+        mask on Y ...) belongs to the generic engine, which keeps per-node state like the
+        reference (stochastic.py:223-250, expfamily.py:168-212)."""
+        if roles['Y']._mask is not True:
+            return 'Y has missing values'
+        for key in ('W', 'X', 'tau', 'alpha', 'F'):
+            if getattr(roles[key], 'observed', False):
+                return '%s is observed' % roles[key].name
+        for key in ('W', 'X'):
+            init = roles[key]._init
+            if init is not None and init[0] not in ('value', 'random'):
+                return '%s.initialize_from_%s' % (roles[key].name, init[0])
+        for key in ('tau', 'alpha'):
+            if roles[key]._init is not None:
+                return '%s.initialize_from_%s' % (roles[key].name, roles[key]._init[0])
+        return None
+
+    @staticmethod
     def match(nodes):
         # mini-batch multipliers (stochastic VI) go through the generic engine
         if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
@@ -208,7 +230,10 @@ class PCAPlan:
             if len(W.children) != 1 or len(X.children) != 1 or len(F.children) != 1 \
                     or len(tau.children) != 1 or len(alpha.children) != 1:
                 continue
-            return dict(Y=Y, F=F, W=W, X=X, tau=tau, alpha=alpha)
+            roles = dict(Y=Y, F=F, W=W, X=X, tau=tau, alpha=alpha)
+            if PCAPlan.unsupported_state(roles) is not None:
+                continue          # e.g. a fixed tau: per-node state -> generic engine
+            return roles
         return None
 
     # -- construction ------------------------------------------------------------------
@@ -265,9 +290,10 @@ class PCAPlan:
         self.finish()
         self._ready = False
         self._version += 1
-        if node is self.Y and node._mask is not True:
-            # missing data: per-plate posteriors, outside this fused block -> the model
-            # moves to the generic device message-passing engine
+        if self.unsupported_state(self.roles) is not None:
+            # missing data (per-plate posteriors), an observed / specially initialised role:
+            # outside this fused block -> the model moves to the generic device
+            # message-passing engine (Node.shard declarations travel with the nodes)
             from .generic import GenericPlan
             GenericPlan(self.nodes())
 
@@ -281,10 +307,18 @@ class PCAPlan:
         if self.Y._data is None:
             raise ValueError('Node %s has not been observed; the fused PCA block needs '
                              'Y.observe(y)' % self.Y.name)
-        assert self.Y._mask is True, 'masked models never reach the fused PCA block'
+        why = self.unsupported_state(self.roles)
+        if why is not None:
+            raise NotImplementedError('the fused PCA block does not cover this model state (%s); '
+                                      "use VB(..., engine='generic')" % why)
         rt.sync_stream()
         self.layout = L = k.layout(D, K)
-        self.n_total = rt.all_reduce_int(N)
+        # ONE sharding contract for every plan: the observation plate is
+        # partitioned over the ranks iff a node that carries it was declared with Node.shard();
+        # an undeclared model under torch.distributed is an independent replica per rank
+        self.sharded = any(getattr(n, '_shard_axis', None) is not None
+                           for n in (self.X, self.F, self.Y))
+        self.n_total = rt.all_reduce_int(N) if self.sharded else N
         # ---- Y: (D, ldy), plate contiguous, 16-byte aligned rows -----------------------
         y = self.Y._data
         if isinstance(y, torch.Tensor) and y.device == rt.device and y.dtype == torch.float64 \
@@ -309,11 +343,11 @@ class PCAPlan:
         self.ws = rt.empty(int(k.workspace_doubles(D, K)))
         k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)
         k.syy(self.Yd, self.ldy, N, D, K, self.state, self.ws)
-        rt.all_reduce_sum_(self.state[L.off_Syy:L.off_Syy + 1])
+        self._reduce(self.state[L.off_Syy:L.off_Syy + 1])
         if self.stats == 'gram':
             k.gram(self.Yd, self.ldy, N, D, K, self.state, self.ws)
             DP = int(L.DP)
-            rt.all_reduce_sum_(self.state[L.off_G:L.off_G + DP * DP])
+            self._reduce(self.state[L.off_G:L.off_G + DP * DP])
         # ---- X: delta moments (initialize_from_value/random) or the prior --------------
         init = self.X._init
         KPx = int(L.KP)       # pad rows: the tile-major pass writes whole 16-row blocks of <x>
@@ -338,7 +372,7 @@ class PCAPlan:
                 if self.x_prec != 1.0:
                     self.Xd.mul_(self.x_prec ** -0.5)
             k.stats_from_x(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
-            rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
+            self._reduce(self.state[L.off_S:L.off_S + L.len_S])
         # ---- W: prior (mean 0, Cov diag(1/<alpha>)) or a given value ---------------------
         KP = int(L.KP)
         init = self.W._init
@@ -361,6 +395,11 @@ class PCAPlan:
             self._set_block(L.off_Sww, w0.T @ w0)
         self._ready = True
         self._version += 1
+
+    def _reduce(self, view):
+        """Plate sum over the ranks (node.py:650, dot.py:581) -- only for a declared shard."""
+        if self.sharded:
+            self.rt.all_reduce_sum_(view)
 
     def _set_block(self, off, mat):
         """Upload a small K x K host matrix into a KP x KP state block (set-up only)."""
@@ -392,7 +431,7 @@ class PCAPlan:
             else:
                 k.pass_(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
                 # child -> parent message sum over the sharded plate (node.py:650, dot.py:581)
-                rt.all_reduce_sum_(self.state[L.off_S:L.off_S + L.len_S])
+                self._reduce(self.state[L.off_S:L.off_S + L.len_S])
         elif node is self.tau:
             self._pending.append(OP_TAU)
         elif node is self.alpha:

@@ -8,6 +8,7 @@ bound, warn if it decreased by more than 1e-6, stop when the relative change
 drops below ``tol``), same log line.  The numbers come from the compiled
 plans, i.e. from HIP kernels.
 """
+import os
 import time
 import warnings
 
@@ -137,6 +138,28 @@ class VB:
                     fin()
 
     # -- persistence (vmp.py:237-356) ------------------------------------------------------
+    def _shard_info(self, nodes):
+        """(rank, world) when the model holds a plate sharded over several ranks, else None."""
+        try:
+            import torch.distributed as dist
+        except Exception:       # noqa: BLE001
+            return None
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return None
+        if not any(getattr(n, '_shard_axis', None) is not None for n in self.model):
+            return None
+        return dist.get_rank(), dist.get_world_size()
+
+    def _checkpoint_name(self, filename, nodes):
+        """A model with a sharded plate keeps rank-local state: every rank writes / reads its own
+        file ``<filename>.rank<r>of<w>`` (one shared name would be a concurrent-write race and
+        would restore another rank's shard)."""
+        info = self._shard_info(nodes)
+        if info is None:
+            return filename, None
+        root, ext = os.path.splitext(filename)
+        return '%s.rank%dof%d%s' % (root, info[0], info[1], ext), info
+
     def save(self, *nodes, filename=None):
         """Write the state of ``nodes`` (default: all) and the iteration statistics; device
         state is read back once.  Layout: inference/checkpoint.py."""
@@ -148,7 +171,11 @@ class VB:
         names = [n.name for n in nodes]
         if len(set(names)) != len(names) or any(nm == '' for nm in names):
             raise Exception("In order to save nodes, they must have (unique) names.")
+        filename, info = self._checkpoint_name(filename, nodes)
         w = Writer(filename)
+        if info is not None:
+            w.put('shard/rank', info[0])
+            w.put('shard/world', info[1])
         seen = []
         for n in nodes:
             p = n._plan
@@ -173,8 +200,14 @@ class VB:
         filename = filename or self.autosave_filename
         if not filename:
             raise Exception("Filename must be given.")
+        filename, info = self._checkpoint_name(filename, nodes)
         r = Reader(filename)
         try:
+            if info is not None and r.has('shard/rank'):
+                got = (int(r.get('shard/rank')), int(r.get('shard/world')))
+                if got != info:
+                    raise ValueError('checkpoint %s holds the shard of rank %d of %d, this process '
+                                     'is rank %d of %d' % ((filename,) + got + info))
             seen = []
             for n in nodes:
                 p = n._plan

@@ -266,8 +266,10 @@ class Stochastic(Node):
     # -- inference ------------------------------------------------------------------
     def update(self):
         """Recompute q(node) from the current moments of its Markov blanket
-        (stochastic.py:276-282).  Observed nodes are skipped like in the reference."""
-        if self.observed:
+        (stochastic.py:276-282).  Fully observed nodes are skipped like in the reference; the
+        plates of a partially observed node that carry no data are updated (``if not
+        np.all(self.observed)``)."""
+        if self.observed and (self._mask is True or bool(np.all(self._mask))):
             return
         self._require_plan().update(self)
 

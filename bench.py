@@ -186,6 +186,8 @@ def main():
     alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
     W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
     X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, n_local), name='X')
+    if world > 1:
+        X.shard(-1)      # the observation plate is partitioned over the ranks
     F = nodes.SumMultiply('i,i', W, X, name='F')
     tau = nodes.Gamma(1e-2, 1e-2, name='tau')
     Y = nodes.GaussianARD(F, tau, name='Y')

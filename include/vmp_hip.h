@@ -57,6 +57,24 @@ int32_t vmp_memcpy_h2d(vmp_ctx *ctx, void *dst, const void *src, size_t bytes);
 int32_t vmp_memcpy_d2h(vmp_ctx *ctx, void *dst, const void *src, size_t bytes);
 int32_t vmp_memset_zero(vmp_ctx *ctx, void *dst, size_t bytes);
 
+/* ---- collective: plate sums over ranks ------------------------------------- *
+ *
+ * One process per GPU, the outermost observation plate sharded over the ranks.  Every sum
+ * the reference takes over that plate -- child -> parent messages (node.py:650 ->
+ * utils/misc.py:805, dot.py:581) and per-node lower-bound terms (expfamily.py:470-480) --
+ * is a local partial sum followed by vmp_allreduce_sum_f64: an fp64 sum all-reduce (RCCL
+ * over xGMI) enqueued on the context's stream, in place.  The communicator lives in the
+ * context: rank 0 calls vmp_comm_unique_id, the caller ships the 128 bytes to the other
+ * ranks by any means (MPI, a file, torch.distributed), every rank calls vmp_comm_init_rank.
+ * A context without a communicator is a world of one rank (the all-reduce is the identity).
+ * RCCL is loaded on first use (dlopen "librccl.so.1"); single-GPU use never touches it. */
+typedef struct vmp_comm_id { char bytes[128]; } vmp_comm_id;
+int32_t vmp_comm_unique_id(vmp_ctx *ctx, vmp_comm_id *id);
+int32_t vmp_comm_init_rank(vmp_ctx *ctx, const vmp_comm_id *id, int32_t rank, int32_t world);
+int32_t vmp_comm_destroy(vmp_ctx *ctx);
+int32_t vmp_comm_info(vmp_ctx *ctx, int32_t *rank, int32_t *world);
+int32_t vmp_allreduce_sum_f64(vmp_ctx *ctx, double *buf, int64_t count);
+
 /* ---- fused probabilistic-PCA / factor-analysis block --------------------- *
  *
  * Model block  Y = GaussianARD(SumMultiply('i,i', W, X), tau),  W ~ GaussianARD(0, alpha),

@@ -700,6 +700,12 @@ def default_ndim_case(name):
                  ('dn_X_plates', 'dn_L', 'dn_Z_plates', 'dn_Z_shape', 'dn2_L'))
 
 
+def masked_pca_case(name):
+    """PCA with missing values (NaN placeholders), partially observed nodes."""
+    _shared_case(name, 'make_masked_pca_inputs', 'run_masked_pca_cases', 5150,
+                 ('m0_L', 'm1_L', 'm2_L', 'm3_L', 'po_L'))
+
+
 def bmm_doctest_case(name):
     """doc/source/examples/bmm.rst:8-95 verbatim (numpy.random.seed(1) from its testsetup): the
     Bernoulli mixture whose doctest pins "Iteration 1: loglike=-6.872145e+02" and
@@ -916,6 +922,12 @@ def markov_chain_case(name):
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
+    if len(sys.argv) > 1:
+        # regenerate selected fixtures only: python oracle/make_golden.py masked_pca_case:masked_pca
+        for spec in sys.argv[1:]:
+            fn, _, nm = spec.partition(':')
+            globals()[fn](nm)
+        return
     quickstart_case('quickstart_n10', N=10, n_iter=4, seed=1)
     quickstart_case('quickstart_n1000', N=1000, n_iter=6, seed=1)
     pca_case('pca_n500_d6_k3', N=500, D=6, K=3, n_iter=5, seed=7)
@@ -942,6 +954,7 @@ def main():
     varying_case('varying_lssm')
     concat_gaussian_case('concat_gaussian')
     default_ndim_case('default_ndim')
+    masked_pca_case('masked_pca')
     bmm_doctest_case('bmm_doctest')
     gmm_doctest_case('gmm_doctest')
     inference_doctest_case('inference_doctest')

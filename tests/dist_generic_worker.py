@@ -18,7 +18,11 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % ndev)
-    dist.init_process_group(os.environ.get('VMP_TEST_BACKEND', 'gloo'))
+    backend = os.environ.get('VMP_TEST_BACKEND', 'gloo')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend)
     import bayespy_amd.nodes as nodes
     from bayespy_amd.inference import VB, transformations
     res = {}

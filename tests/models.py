@@ -2,12 +2,15 @@
 import numpy as np
 
 
-def build_pca(nodes_mod, vb_cls, y, x0, K, a0=1e-2, b0=1e-2, **vb_kwargs):
-    """bayespy/demos/pca.py:22-61 with X initialised from ``x0`` (N,K) and Y fully observed."""
+def build_pca(nodes_mod, vb_cls, y, x0, K, a0=1e-2, b0=1e-2, shard=False, **vb_kwargs):
+    """bayespy/demos/pca.py:22-61 with X initialised from ``x0`` (N,K) and Y fully observed.
+    ``shard``: the arrays are this rank's part of the observation plate (X.shard(-1))."""
     D, N = y.shape
     alpha = nodes_mod.Gamma(a0, b0, plates=(K,), name='alpha')
     W = nodes_mod.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
     X = nodes_mod.GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    if shard:
+        X.shard(-1)
     F = nodes_mod.SumMultiply('i,i', W, X, name='F')
     tau = nodes_mod.Gamma(a0, b0, name='tau')
     Y = nodes_mod.GaussianARD(F, tau, name='Y')
@@ -758,3 +761,88 @@ def run_default_ndim_case(nodes_mod, vb_cls, g, **vb_kwargs):
     for nm, nd in dict(Z=Z, M=M).items():
         out['dn2_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# PCA with missing values (demos/pca.py:80-82: the demo's default use) -- the fused masked block,
+# NaN placeholders at the missing entries, partially observed nodes.  Shared statement for
+# statement by oracle/make_golden.py (live reference) and the device tests.
+# ---------------------------------------------------------------------------------------------
+MASKED_PCA_SIZES = (('m0', 5, 60, 2, 0.8, 5), ('m1', 12, 300, 4, 0.8, 5),
+                    ('m2', 40, 333, 17, 0.6, 4), ('m3', 128, 1024, 32, 0.9, 3))
+
+
+def make_masked_pca_inputs(rs):
+    g = {}
+    for tag, D, N, K, keep, n_iter in MASKED_PCA_SIZES:
+        w, x = rs.normal(size=(D, K)), rs.normal(size=(N, K))
+        y = w @ x.T + 0.1 * rs.normal(size=(D, N))
+        mask = rs.rand(D, N) < keep
+        mask[0, :3] = False                 # a plate with several holes in one row ...
+        mask[:, 5] = mask[:, 5] & (np.arange(D) % 2 == 0)
+        if tag == 'm0':
+            mask[:, 7] = False              # ... and one plate without any observation
+        y = np.where(mask, y, np.nan)       # the usual encoding of missing data
+        g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'] = y, mask, rs.normal(size=(N, K))
+    # a partially observed node WITH a child: its latent plates take part in the updates
+    n = 30
+    g['po_z'] = np.where(rs.rand(n) < 0.5, rs.normal(2.0, 1.0, size=n), np.nan)
+    g['po_y'] = rs.normal(2.0, 1.5, size=n)
+    return g
+
+
+def build_masked_pca(nodes_mod, vb_cls, y, mask, x0, a0=1e-2, b0=1e-2, shard=False, **vb_kwargs):
+    D, N = y.shape
+    K = x0.shape[1]
+    alpha = nodes_mod.Gamma(a0, b0, plates=(K,), name='alpha')
+    W = nodes_mod.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = nodes_mod.GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    if shard:
+        X.shard(-1)
+    F = nodes_mod.SumMultiply('i,i', W, X, name='F')
+    tau = nodes_mod.Gamma(a0, b0, name='tau')
+    Y = nodes_mod.GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(np.asarray(x0)[None, :, :])
+    Y.observe(y, mask=mask)
+    Q = vb_cls(Y, F, W, X, tau, alpha, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    return Q
+
+
+def run_masked_pca_cases(nodes_mod, vb_cls, g, only=None, **vb_kwargs):
+    res = {}
+    for tag, D, N, K, keep, n_iter in MASKED_PCA_SIZES:
+        if only is not None and tag not in only:
+            continue
+        Q = build_masked_pca(nodes_mod, vb_cls, g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'],
+                             **vb_kwargs)
+        Q.update(repeat=n_iter, verbose=False)
+        res[tag + '_L'] = np.array(Q.L[:Q.iter])
+        for nm in ('Y', 'W', 'X', 'tau', 'alpha'):
+            res['%s_L_%s' % (tag, nm)] = np.array(Q.l[Q[nm]][:Q.iter])
+        W, X, tau, alpha, Y = Q['W'], Q['X'], Q['tau'], Q['alpha'], Q['Y']
+        res[tag + '_W_u0'], res[tag + '_W_u1'] = np.array(W.u[0]), np.array(W.u[1])
+        res[tag + '_X_u0'] = np.array(X.u[0])
+        res[tag + '_X_u1_first'] = np.array(X.u[1][0, :8])
+        res[tag + '_tau_u'] = np.array([np.asarray(u) for u in tau.u], dtype=np.float64)
+        res[tag + '_alpha_u0'], res[tag + '_alpha_u1'] = np.array(alpha.u[0]), np.array(alpha.u[1])
+        if D * N <= 4000:
+            # q of the missing entries of the partially observed leaf (the predictive moments)
+            res[tag + '_Y_u0'], res[tag + '_Y_u1'] = np.array(Y.u[0]), np.array(Y.u[1])
+    if only is None or 'po' in only:
+        zdat, ydat = g['po_z'], g['po_y']
+        n = zdat.shape[0]
+        mu = nodes_mod.GaussianARD(0, 1e-3, name='mu')
+        z = nodes_mod.GaussianARD(mu, 1.0, plates=(n,), name='z')
+        tau = nodes_mod.Gamma(1e-2, 1e-2, name='tau')
+        y = nodes_mod.GaussianARD(z, tau, plates=(n,), name='y')
+        y.observe(ydat)
+        z.observe(zdat, mask=~np.isnan(zdat))
+        Q = vb_cls(y, z, mu, tau, **vb_kwargs)
+        Q.ignore_bound_checks = True
+        Q.update(repeat=5, verbose=False)
+        res['po_L'] = np.array(Q.L[:Q.iter])
+        res['po_z_u0'], res['po_z_u1'] = np.array(z.u[0]), np.array(z.u[1])
+        res['po_mu_u'] = np.array([np.asarray(u) for u in mu.u], dtype=np.float64)
+        res['po_tau_u'] = np.array([np.asarray(u) for u in tau.u], dtype=np.float64)
+    return res

@@ -157,6 +157,31 @@ def test_plan_selection_and_loud_failures():
     Y.observe(np.zeros((D, N)), mask=np.ones((D, N), dtype=bool))
     assert isinstance(Q2.plans[0], GenericPlan)
     assert VB(Y, W, X, engine='generic') is not None
+
+    # the fused block starts tau / alpha from their priors and updates every role: a fixed
+    # (observed) tau, an initialised alpha or initialize_from_parameters keep per-node state like
+    # the reference -> generic engine, before and after VB(...) (never silently ignored)
+    def fresh():
+        al = nodes.Gamma(1e-2, 1e-2, plates=(K,))
+        Wn = nodes.GaussianARD(0, al, shape=(K,), plates=(D, 1))
+        Xn = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, N))
+        ta = nodes.Gamma(1e-2, 1e-2)
+        Yn = nodes.GaussianARD(nodes.Dot(Wn, Xn), ta)
+        Yn.observe(np.zeros((D, N)))
+        return Yn, Wn, Xn, ta, al
+    tweaks = [lambda Yn, Wn, Xn, ta, al: ta.observe(2.0),
+              lambda Yn, Wn, Xn, ta, al: al.initialize_from_value(np.ones(K)),
+              lambda Yn, Wn, Xn, ta, al: Wn.initialize_from_parameters(np.zeros(K), np.ones(K)),
+              lambda Yn, Wn, Xn, ta, al: Wn.observe(np.ones((D, 1, K)))]
+    for tw in tweaks:
+        ns = fresh()
+        tw(*ns)
+        assert isinstance(VB(*ns).plans[0], GenericPlan)
+        ns = fresh()
+        Qf = VB(*ns)
+        assert isinstance(Qf.plans[0], PCAPlan)
+        tw(*ns)
+        assert isinstance(Qf.plans[0], GenericPlan)
     with pytest.raises(ValueError):
         Y.observe(np.zeros((D + 1, N)))
     with pytest.raises(ValueError):

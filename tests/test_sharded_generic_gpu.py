@@ -5,7 +5,8 @@ to the replicated nodes and the lower-bound terms are completed by all-reduce.
 
 The ranks are launched with ``torch.distributed.run`` exactly like the driver launches
 bench.py.  On a one-GPU box both ranks share the device and the collective backend is gloo
-(RCCL refuses two ranks on one device); on a multi-GPU node set VMP_TEST_BACKEND=nccl.
+(RCCL refuses two ranks on one device); with two or more GPUs the ranks take one GPU each and
+the collective is the library's RCCL all-reduce (backend nccl, chosen automatically).
 """
 import os
 import subprocess
@@ -21,7 +22,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def _launch(case, golden_dir, tmp_path, port):
     env = dict(os.environ)
-    env.setdefault('VMP_TEST_BACKEND', 'gloo')
+    import torch
+    # two GPUs or more: one rank per GPU over RCCL; one GPU: both ranks share it over gloo
+    env.setdefault('VMP_TEST_BACKEND', 'nccl' if torch.cuda.device_count() >= 2 else 'gloo')
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
