@@ -36,7 +36,10 @@ int32_t vmp_tune_set(const char *key, int32_t value)
     return VMP_OK;
 }
 
-const char *vmp_version(void) { return "libvmp_hip 0.1 (gfx950)"; }
+#ifndef VMP_BUILD_ID
+#define VMP_BUILD_ID "unknown"
+#endif
+const char *vmp_version(void) { return "libvmp_hip 0.2 (gfx950) build " VMP_BUILD_ID; }
 
 int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
 {

@@ -358,12 +358,18 @@ class PCAPlan:
         else:
             if init[0] == 'value':
                 x0 = init[1]
-                if isinstance(x0, torch.Tensor):
-                    x0 = x0.detach().cpu().numpy()
-                x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
-                                     self.X.plates + (K,)).reshape(N, K)
                 self.Xd = rt.zeros(KPx, self.ldx)
-                self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
+                if isinstance(x0, torch.Tensor) and x0.device == rt.device:
+                    # resident already: (.., N, K) -> the plate-contiguous (K, N) layout
+                    self.Xd[:K, :N].copy_(x0.to(torch.float64).expand(self.X.plates + (K,))
+                                          .reshape(N, K).t())
+                else:
+                    if isinstance(x0, torch.Tensor):
+                        x0 = x0.detach().cpu().numpy()
+                    x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
+                                         self.X.plates + (K,)).reshape(N, K)
+                    self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64,
+                                                                    order='C')))
             else:
                 # a draw from the current q = prior N(0, I/x_prec) (expfamily.py:206-212);
                 # RNG streams are not part of the parity contract

@@ -3,6 +3,7 @@
 bench.py -- VB iterations/sec of probabilistic PCA (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --config {gmm,masked,lssm}        # the secondary BASELINE configurations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -49,7 +50,15 @@ def parse():
     p.add_argument('--stats', choices=['gram', 'stream'], default='gram',
                    help="form of X.update()'s plate pass (see bayespy_amd/inference/plans/pca.py)")
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-sample-n', type=int, default=200_000)
+    p.add_argument('--cpu-sample-n', type=int, default=0,
+                   help='columns of the CPU-baseline sample; 0 = the whole workload when the '
+                        'host has the memory for it (direct parity at the metric size)')
+    p.add_argument('--config', choices=['pca', 'gmm', 'masked', 'lssm'], default='pca',
+                   help="pca = the BASELINE.json metric (default); the others print the "
+                        "secondary configurations of tools/workloads.py as the JSON line")
+    p.add_argument('--no-extra', action='store_true',
+                   help='default run: do not append the secondary configurations under "extra"')
+    p.add_argument('--layout', choices=['tiled', 'rows'], default=None)
     return p.parse_args()
 
 
@@ -73,73 +82,124 @@ def make_shard(torch, dev, n_local, D, K, seed, rank):
     return y[:, :n_local]
 
 
-def pmc_traffic(stats, D, K, n_local):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of
-    this same command (profiles/r*/pmc_pca_<stats>.txt; separate FETCH_SIZE / WRITE_SIZE passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the profile is not
-    for this workload or is absent."""
+def library_build_id():
+    from bayespy_amd import _lib
+    v = _lib.load().vmp_version().decode()
+    return v.split('build ')[-1] if 'build ' in v else None
+
+
+def pmc_traffic(kernel, D, K, n_local):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary
+    (profiles/r*/pmc_*.txt; separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950) -- ONLY if that profile was taken on this very
+    build of the kernels (header line ``# build_id:`` written by tools/collect_profiles.sh ==
+    vmp_version()) and on this workload (``# workload:``); otherwise (None, reason)."""
     import glob
     import re
-    if (D, K, n_local) != (128, 32, 10_000_000):
-        return None, None
-    kern = 'pca_xpass_kernel' if stats == 'gram' else 'pca_pass_kernel<4, 2, true>'
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_pca_%s.txt' % stats)),
-                       reverse=True):
+    bid = library_build_id()
+    want = 'D=%d K=%d n_local=%d' % (D, K, n_local)
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_*.txt')), reverse=True):
+        head = {}
         vals, cur = {}, None
         for line in open(path):
+            m = re.match(r'#\s*(build_id|workload):\s*(.+)', line)
+            if m:
+                head[m.group(1)] = m.group(2).strip()
+                continue
             if not line.startswith(' '):
                 cur = line.strip()
                 continue
             m = re.match(r'\s+(FETCH_SIZE|WRITE_SIZE)\s+avg\s+([0-9.]+)', line)
-            if m and cur and cur.startswith(kern):
+            if m and cur and cur.startswith(kernel):
                 vals[m.group(1)] = float(m.group(2))
+        if head.get('build_id') != bid or head.get('workload') != want:
+            continue
         if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
             return 2.0 * vals['FETCH_SIZE'] * 1024 + vals['WRITE_SIZE'] * 1024, \
                 os.path.relpath(path, ROOT)
-    return None, None
+    return None, 'no committed PMC profile of build %s for %s' % (bid, want)
 
 
-def cpu_baseline(D, K, n_sample, n_full):
-    """The NumPy oracle (kind 'port') timed on this box's host cores on a bounded
-    sample of the same workload; linear in N (measured linear)."""
+def cpu_baseline(y_dev, x0_dev, D, K, n_total, L_gpu, Q, sample_n):
+    """The NumPy oracle (kind 'port') timed on this box's host cores on a bounded sample of the
+    SAME workload -- by default the whole of it: the data and the injected initial <x> of this
+    very run are pulled to the host, the oracle runs three iterations from them (two timed,
+    ~10 s at N=1e7), and its lower bounds are compared with the first iterations of the run
+    that was just timed (``elbo_rel_err_full``: direct parity at the metric size), its
+    posterior means of W and of a strided sample of X with the device's."""
     import numpy as np
-    from oracle.pca import PCAOracle, make_pca_data
+    import psutil
+    from oracle.pca import PCAOracle
     try:
         from threadpoolctl import threadpool_info
         cores = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
-    except Exception:
+    except Exception:       # noqa: BLE001
         cores = os.cpu_count() or 1
-    y, x0 = make_pca_data(n_sample, D, K, seed=42)
-    o = PCAOracle(y, x0, keep_x=True)
-    o.iterate(1)
+    need = 8.0 * n_total * (D + 3 * K) * 1.25
+    full = sample_n <= 0 or sample_n >= n_total
+    if full and psutil.virtual_memory().available < need:
+        full, sample_n = False, 200_000
+    n = n_total if full else min(sample_n, n_total)
+    y = np.empty((D, n))
+    step = max(1, (1 << 27) // D)
+    for s0 in range(0, n, step):                       # bounded staging copies
+        e = min(n, s0 + step)
+        y[:, s0:e] = y_dev[:, s0:e].cpu().numpy()
+    x0 = x0_dev[:n].cpu().numpy()
     iters = 3
+    o = PCAOracle(y, x0, keep_x=True, chunk=1 << 17)
+    o.iterate(1)
     t = time.time()
-    o.iterate(iters)
-    dt = (time.time() - t) / iters
-    it_s = 1.0 / (dt * (n_full / float(n_sample)))
-    # the other half of the metric: the HIP path on the very same sample and initial moments,
-    # lower bound against the oracle's after the same number of iterations
+    o.iterate(iters - 1)
+    dt = (time.time() - t) / (iters - 1)
+    out = {'unit': 'VB iterations/s', 'cores': int(cores), 'kind': 'port'}
+    if full:
+        ncmp = min(iters, len(L_gpu))
+        rel = max(abs(a - b) / abs(b) for a, b in zip(L_gpu[:ncmp], o.L[:ncmp]))
+        out.update({
+            'value': 1.0 / dt, 'elbo_rel_err_full': float(rel), 'elbo_iterations_compared': ncmp,
+            'sample': 'oracle/pca.py (NumPy fp64, chunked BLAS GEMMs) on the WHOLE workload '
+                      '(N=%d, D=%d, K=%d; the data and initial <x> of this run), %d timed '
+                      'iterations at %.2f s/iter; the unmodified reference measured 35.4 s/iter '
+                      'at N=1e5 on 8 vCPU (BASELINE.md section 2) = 2.8e-4 it/s at N=1e7'
+                      % (n, D, K, iters - 1, dt)})
+        return out
+    # memory-bound host: the HIP path on the same sample, from the same initial moments
     from bayespy_amd import nodes
     from bayespy_amd.inference import VB
     alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,))
     W = nodes.GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
-    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, n_sample))
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, n))
     tau = nodes.Gamma(1e-2, 1e-2)
     Y = nodes.GaussianARD(nodes.SumMultiply('i,i', W, X), tau)
     X.initialize_from_value(x0[None])
     Y.observe(y)
-    Q = VB(Y, W, X, tau, alpha)
-    Q.ignore_bound_checks = True
-    Q.update(repeat=1 + iters, verbose=False)
-    rel = max(abs(a - b) / abs(b) for a, b in zip(Q.L[:1 + iters], o.L))
-    return {
-        'value': it_s, 'unit': 'VB iterations/s', 'cores': int(cores), 'kind': 'port',
-        'elbo_rel_err_hip_vs_oracle': float(rel), 'elbo_iterations_compared': 1 + iters,
-        'sample': 'oracle/pca.py (NumPy fp64, BLAS GEMMs) on N=%d columns of the same D=%d,K=%d '
-                  'workload, %d timed iterations at %.3f s/iter, extrapolated linearly to N=%d; '
-                  'the unmodified reference measured 35.4 s/iter at N=1e5 on 8 vCPU '
-                  '(BASELINE.md section 2) = 2.8e-4 it/s at N=1e7' % (n_sample, D, K, iters, dt, n_full),
-    }
+    Qs = VB(Y, W, X, tau, alpha)
+    Qs.ignore_bound_checks = True
+    Qs.update(repeat=iters, verbose=False)
+    rel = max(abs(a - b) / abs(b) for a, b in zip(Qs.L[:iters], o.L))
+    out.update({
+        'value': 1.0 / (dt * (n_total / float(n))), 'elbo_rel_err_hip_vs_oracle': float(rel),
+        'elbo_iterations_compared': iters,
+        'sample': 'oracle/pca.py (NumPy fp64, BLAS GEMMs) on the first N=%d columns of the same '
+                  'D=%d,K=%d data, %d timed iterations at %.3f s/iter, extrapolated linearly to '
+                  'N=%d (the host lacks the memory for the whole workload)'
+                  % (n, D, K, iters - 1, dt, n_total)})
+    return out
+
+
+def run_extra(name, fn, budget_s, **kw):
+    """One secondary configuration for the "extra" list of the default run; a failure there is
+    reported, never fatal to the headline line."""
+    import torch
+    t = time.time()
+    try:
+        out = fn(**kw)
+    except Exception as e:       # noqa: BLE001
+        out = {'metric': name, 'error': '%s: %s' % (type(e).__name__, e)}
+    out['wall_s'] = time.time() - t
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -170,6 +230,21 @@ def main():
 
     rt = get_runtime()
     dev = rt.device
+    if args.config != 'pca':
+        # the secondary BASELINE configurations share the JSON contract (tools/workloads.py)
+        from tools import workloads
+        if args.config == 'gmm':
+            out = workloads.run_gmm(steps=args.steps, warmup=args.warmup,
+                                    cpu_baseline=not args.no_cpu_baseline)
+        elif args.config == 'masked':
+            out = workloads.run_masked(steps=min(args.steps, 5), warmup=min(args.warmup, 1))
+        else:
+            out = workloads.run_lssm(steps=min(args.steps, 5), warmup=min(args.warmup, 1))
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     D, K = args.d, args.k
     if args.scaling == 'strong':
         n_total = args.n
@@ -191,12 +266,19 @@ def main():
     F = nodes.SumMultiply('i,i', W, X, name='F')
     tau = nodes.Gamma(1e-2, 1e-2, name='tau')
     Y = nodes.GaussianARD(F, tau, name='Y')
-    X.initialize_from_random()
+    # the initial <x> are injected draws (initialize_from_value), the same
+    # arrays the CPU baseline starts from
+    gx = torch.Generator(device=dev)
+    gx.manual_seed(4242 + rank)
+    x0 = torch.randn(n_local, K, generator=gx, device=dev, dtype=torch.float64)
+    X.initialize_from_value(x0[None])
     Y.observe(y)
     Q = VB(Y, F, W, X, tau, alpha)
     Q.ignore_bound_checks = True          # never stop early: time exactly K iterations
     plan = Q.plans[0]
     plan.stats = args.stats
+    if args.layout:
+        plan.plate_layout = args.layout
 
     def barrier():
         if world > 1:
@@ -260,10 +342,27 @@ def main():
             'elbo_first': float(L[0]), 'elbo_last': float(L[-1]),
             'roofline': roof,
         }
-        roof['traffic'], roof['traffic_source'] = pmc_traffic(args.stats, D, K, n_local)
+        roof['traffic'], roof['traffic_source'] = pmc_traffic(roof['kernel'], D, K, n_local)
+        roof['library_build'] = library_build_id()
         out['config']['stats'] = args.stats
+        out['config']['plate_layout'] = plan.plate_layout if args.stats == 'gram' else 'rows'
+        out['config']['initial_x'] = 'initialize_from_value (injected normal draws)'
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(D, K, min(args.cpu_sample_n, n_total), n_total)
+            out['cpu_baseline'] = cpu_baseline(y, x0, D, K, n_total, [float(v) for v in L], Q,
+                                               args.cpu_sample_n)
+        if world == 1 and not args.no_extra and (n_total, D, K) == (10_000_000, 128, 32):
+            # the other BASELINE configurations that fit one GPU, on the driver-visible line
+            del Q, plan, Y, F, W, X, tau, alpha, y, x0
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            from tools import workloads
+            out['extra'] = [
+                run_extra('gmm', workloads.run_gmm, 120, steps=10, warmup=2,
+                          cpu_baseline=not args.no_cpu_baseline),
+                run_extra('masked', workloads.run_masked, 120, steps=3, warmup=1),
+                run_extra('lssm', workloads.run_lssm, 120, steps=3, warmup=1),
+            ]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

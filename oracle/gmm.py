@@ -126,15 +126,17 @@ class GMMOracle:
         for s in range(0, self.N, self.chunk):
             e = min(self.N, s + self.chunk)
             yc = self.y[s:e]
-            phi = (self.logpi + c)[None, :] + yc @ b.T \
-                - 0.5 * np.einsum('ni,kij,nj->nk', yc, self.Lam, yc)
+            # y^T Lam_k y as one GEMM over the D^2 products y_i y_j (BLAS; the three-operand
+            # einsum of the same contraction runs a scalar loop)
+            yy = (yc[:, :, None] * yc[:, None, :]).reshape(e - s, D * D)
+            phi = (self.logpi + c)[None, :] + yc @ b.T - 0.5 * (yy @ self.Lam.reshape(K, D * D).T)
             m = phi.max(axis=1, keepdims=True)
             lse = np.log(np.exp(phi - m).sum(axis=1, keepdims=True)) + m
             p = np.exp(phi - lse)
             p /= p.sum(axis=1, keepdims=True)              # utils/misc.py:1399
             R += p.sum(axis=0)
             S1 += p.T @ yc
-            S2 += np.einsum('nk,ni,nj->kij', p, yc, yc)
+            S2 += (p.T @ yy).reshape(K, D, D)
             lse_sum += float(lse.sum())
             rphi += float((p * phi).sum())
             if keep_r:

@@ -1,0 +1,256 @@
+"""
+The secondary BASELINE.json configurations as functions that return the bench.py JSON fields
+(metric / value / ms_per_step / roofline / cpu_baseline):
+
+    run_gmm     config 3  Gaussian mixture N=1e7, D=8, K=64
+    run_masked  SURVEY.md 8(d) secondary run: PCA N=1e7, D=128, K=32 with 10 % missing values
+    run_lssm    config 5  linear state-space model, T=1e3 x B=1e5 sequences
+
+``bench.py --config {gmm,masked,lssm}`` prints one of them as its JSON line; the default
+``bench.py`` run (the PCA headline) appends all of them under "extra".  tools/bench_*.py are the
+stand-alone command lines of the same functions.
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
+
+
+def _cores():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([i.get('num_threads', 1) for i in threadpool_info()] or [1]))
+    except Exception:       # noqa: BLE001
+        return os.cpu_count() or 1
+
+
+def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_sample_n=100_000):
+    import numpy as np
+    import torch
+    from bayespy_amd.nodes import GaussianARD, Gaussian, Wishart, Dirichlet, Categorical, Mixture
+    from bayespy_amd.inference import VB
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    centers = 3 * torch.randn(K, D, generator=g, device=dev, dtype=torch.float64)
+    lab = torch.randint(0, K, (N,), generator=g, device=dev)
+    y = centers[lab] + 0.5 * torch.randn(N, D, generator=g, device=dev, dtype=torch.float64)
+    lab0 = torch.randint(0, K, (N,), generator=g, device=dev)
+    alpha = Dirichlet(1e-3 * np.ones(K), name='alpha')
+    z = Categorical(alpha, plates=(N,), name='z')
+    mu = GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
+    Lam = Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
+    Y = Mixture(z, Gaussian, mu, Lam, plates=(N,), name='Y')
+    z.initialize_from_value(lab0.cpu().numpy())       # one-hot initial moments
+    Y.observe(y)
+    Q = VB(Y, mu, Lam, z, alpha)
+    Q.ignore_bound_checks = True
+    plan = Q.plans[0]
+    Q.update(repeat=warmup, verbose=False)
+    plan.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Q.update(repeat=steps, verbose=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = plan.pass_times_ms(64)                    # HIP events recorded inside the timed region
+    avg = sum(m[0] for m in ms) / len(ms)
+    FS = D * D + D + 1
+    flops = 4.0 * N * K * FS                       # 4 N K (D^2 + D + 1)
+    byts = 8.0 * N * (D + K)
+    tflops = flops / (avg * 1e-3) / 1e12
+    out = {
+        'metric': 'VB iterations/sec, GMM N=%d D=%d K=%d' % (N, D, K), 'value': steps / dt,
+        'unit': 'VB iterations/s', 'n_gpus': 1, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'Gaussian mixture (Mixture+Categorical+GaussianARD+Wishart+'
+                               'Dirichlet), N=%d D=%d K=%d, one VB iteration = mu, Lambda, z, '
+                               'alpha updates + full ELBO' % (N, D, K)},
+        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]),
+        'roofline': {'kernel': 'gmm_pass_kernel', 'bound': 'mfma', 'achieved': tflops,
+                     'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': tflops / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'avg_launch_ms': avg, 'reduce_ms': sum(m[1] for m in ms) / len(ms),
+                     'hbm_achieved_GBs': byts / (avg * 1e-3) / 1e9,
+                     'alg_flops_per_launch': flops, 'alg_bytes_per_launch': byts},
+    }
+    if cpu_baseline:
+        from oracle.gmm import GMMOracle
+        ns = min(cpu_sample_n, N)
+        # the FIRST ns rows of the very data of this run, same initial labels: the lower bound of
+        # the HIP path on that sample against the oracle's, and the oracle's time per iteration
+        ys, l0 = y[:ns].cpu().numpy(), lab0[:ns].cpu().numpy()
+        o = GMMOracle(ys, l0, K)
+        o.iterate(1, keep_r=False)
+        t = time.time()
+        o.iterate(2, keep_r=False)
+        dtc = (time.time() - t) / 2
+        zs = Categorical(Dirichlet(1e-3 * np.ones(K)), plates=(ns,))
+        mus = GaussianARD(0, 1e-3, shape=(D,), plates=(K,))
+        Ls = Wishart(D, 0.01 * np.identity(D), plates=(K,))
+        Ysm = Mixture(zs, Gaussian, mus, Ls, plates=(ns,))
+        zs.initialize_from_value(l0)
+        Ysm.observe(ys)
+        Qs = VB(Ysm, mus, Ls, zs, zs.parents[0])
+        Qs.ignore_bound_checks = True
+        Qs.update(repeat=3, verbose=False)
+        rel = max(abs(a - b) / abs(b) for a, b in zip(Qs.L[:3], o.L))
+        out['cpu_baseline'] = {
+            'value': 1.0 / (dtc * (N / float(ns))), 'unit': 'VB iterations/s', 'cores': _cores(),
+            'kind': 'port', 'elbo_rel_err_hip_vs_oracle': float(rel),
+            'sample': 'oracle/gmm.py (NumPy fp64, chunked) on the first N=%d rows of the same '
+                      'data, 2 timed iterations at %.3f s/iter, extrapolated linearly to N=%d'
+                      % (ns, dtc, N)}
+    return out
+
+
+def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine=None):
+    """PCA with missing values at random (``mask = rng.rand(D, N) < 0.9``)."""
+    import numpy as np
+    import torch
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy_amd.inference import VB
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)
+    y = torch.empty(D, N, device=dev, dtype=torch.float64)
+    mask = torch.empty(D, N, device=dev, dtype=torch.bool)
+    step = 1 << 20
+    for s in range(0, N, step):
+        e = min(N, s + step)
+        x = torch.randn(K, e - s, generator=g, device=dev, dtype=torch.float64)
+        y[:, s:e] = w @ x
+        y[:, s:e] += 0.1 * torch.randn(D, e - s, generator=g, device=dev, dtype=torch.float64)
+        mask[:, s:e] = torch.rand(D, e - s, generator=g, device=dev) >= missing
+    x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
+    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    F = SumMultiply('i,i', W, X, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None])
+    Y.observe(y, mask=mask)
+    Q = VB(Y, F, W, X, tau, alpha, engine=engine)
+    Q.ignore_bound_checks = True
+    plan = Q.plans[0]
+    if type(plan).__name__ == 'GenericPlan' and 8.0 * N * K * K > 16e9:
+        raise RuntimeError('no fused block took this model: the generic engine would '
+                           'materialise (N, K, K) arrays of %.0f GB' % (8e-9 * N * K * K))
+    Q.update(repeat=warmup, verbose=False)
+    timed = hasattr(plan, 'enable_timing')
+    if timed:
+        plan.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Q.update(repeat=steps, verbose=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # 2NDK^2 (messages to W) + 2NDK^2 (precisions of X) + NK^3/3 (Cholesky)
+    flops = 4.0 * N * D * K * K + N * K ** 3 / 3.0
+    out = {
+        'metric': 'VB iterations/sec, PCA N=%d D=%d K=%d, %d%% missing' % (N, D, K,
+                                                                          round(100 * missing)),
+        'value': steps / dt, 'unit': 'VB iterations/s', 'n_gpus': 1, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'probabilistic PCA with values missing at random (array mask), '
+                               'N=%d D=%d K=%d: per-plate K x K posteriors for X and W'
+                               % (N, D, K), 'engine': type(plan).__name__},
+        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]),
+        'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
+        'roofline': {'bound': 'mfma', 'achieved': flops / (dt / steps) / 1e12,
+                     'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': flops / (dt / steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'alg_flops_per_iteration': flops,
+                     'note': 'whole iteration (several kernels) against the algorithmic flops of '
+                             'SURVEY.md 8(d)'},
+    }
+    if timed:
+        out['roofline']['kernel_ms'] = plan.kernel_times_ms()
+    return out
+
+
+def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
+    """Linear state-space model of bayespy/demos/lssm.py:34-103 with a sequence plate."""
+    import json  # noqa: F401
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+    from bayespy_amd.inference import VB
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    Bl = B * (rank + 1) // world - B * rank // world     # this rank's sequences
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(100 + rank)
+    rs = np.random.RandomState(0)
+    a_true = torch.from_numpy(0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]).to(dev)
+    c_true = torch.from_numpy(rs.normal(size=(M, D))).to(dev)
+    x = torch.empty(Bl, T, D, device=dev, dtype=torch.float64)
+    x[:, 0] = torch.randn(Bl, D, generator=g, device=dev, dtype=torch.float64)
+    for t in range(1, T):
+        x[:, t] = x[:, t - 1] @ a_true.T + torch.randn(Bl, D, generator=g, device=dev,
+                                                       dtype=torch.float64)
+    y = torch.einsum('md,btd->mbt', c_true, x)
+    y += 0.3 * torch.randn(M, Bl, T, generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.randn(Bl, T, D, generator=g, device=dev, dtype=torch.float64)
+    del x
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    A.initialize_from_value(np.identity(D))
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T, plates=(Bl,),
+                            name='X')
+    if world > 1:
+        X.shard(-1)
+    X.initialize_from_value(x0)
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(D))
+    C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
+    C.initialize_from_value(rs.normal(size=(M, 1, 1, D)))
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = SumMultiply('i,i', C, X, name='F')
+    Y = GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = VB(Y, F, C, gamma, X, A, alpha, tau)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=warmup, verbose=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    Q.update(repeat=steps, verbose=False)
+    barrier()
+    dt = (time.perf_counter() - t0) / steps
+    # algorithmic traffic per iteration: read Y (M B T), read + write the chain means (B T D)
+    byts = 8.0 * B * T * (M + 2 * D)
+    return {
+        'metric': 'VB iterations/sec, LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D),
+        'value': 1.0 / dt, 'unit': 'VB iterations/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': 1e3 * dt, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'linear state-space model (GaussianMarkovChain + SumMultiply), '
+                               '%d sequences x %d steps, observations %d-dim, states %d-dim'
+                               % (B, T, M, D), 'engine': type(Q.plans[0]).__name__,
+                   'sequences_per_rank': Bl},
+        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]),
+        'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
+        'roofline': {'bound': 'hbm', 'achieved': byts / dt / 1e9, 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': byts / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'alg_bytes_per_iteration': byts,
+                     'note': 'whole iteration against read Y once + read/write <x> once'},
+    }
