@@ -1367,10 +1367,9 @@ class GenericPlan:
         st = self._ensure(node)
         if st.observed:
             if st.partial:
-                if node.children:
-                    self._refresh_partial(node, st)   # children read the latent plates
-                else:
-                    st.stale = True                   # a leaf: refreshed when inspected
+                # the latent plates see the Markov blanket as it is NOW, like any other update
+                # (VB.update visits an observed leaf first: its q is one iteration behind W, X)
+                self._refresh_partial(node, st)
             return
         phi = self._optimal_phi(node)
         st.phi = phi

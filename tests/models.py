@@ -846,3 +846,14 @@ def run_masked_pca_cases(nodes_mod, vb_cls, g, only=None, **vb_kwargs):
         res['po_mu_u'] = np.array([np.asarray(u) for u in mu.u], dtype=np.float64)
         res['po_tau_u'] = np.array([np.asarray(u) for u in tau.u], dtype=np.float64)
     return res
+
+
+def make_seeded_pca(seed, N, D, K):
+    """Inputs of the seeded live-reference fixture (tests/golden/pca_seeded_n100000_d128_k32.npz
+    stores the seed and the reference's OUTPUTS only): demos/pca.py:70-74 data + initial <x>."""
+    rs = np.random.RandomState(seed)
+    w = rs.normal(0, 1, (D, K))
+    x = rs.normal(0, 1, (N, K))
+    y = w @ x.T + 0.1 * rs.normal(size=(D, N))
+    x0 = rs.normal(0, 1, (N, K))
+    return y, x0

@@ -62,3 +62,47 @@ def test_hmm_oracle_matches_reference_recursions(golden_dir):
         np.testing.assert_allclose(g, f[tag + '_g'], rtol=1e-12, atol=1e-12, err_msg=tag)
         np.testing.assert_allclose(z0, f[tag + '_z0'], rtol=1e-10, atol=1e-15, err_msg=tag)
         np.testing.assert_allclose(zz, f[tag + '_zz'], rtol=1e-10, atol=1e-15, err_msg=tag)
+
+
+def test_pca_oracle_matches_seeded_reference_run(golden_dir):
+    """D=128, K=32 at N=1e5: the chunked oracle against the largest live-reference run."""
+    from models import make_seeded_pca
+    g = np.load(os.path.join(golden_dir, 'pca_seeded_n100000_d128_k32.npz'))
+    N, D, K, n = int(g['N']), int(g['D']), int(g['K']), int(g['n_iter'])
+    y, x0 = make_seeded_pca(int(g['seed']), N, D, K)
+    o = PCAOracle(y, x0, chunk=1 << 14)
+    o.iterate(n)
+    np.testing.assert_allclose(np.array(o.L), g['L'], rtol=1e-11)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose([t[k] for t in o.L_terms], g['L_' + k], rtol=1e-9, atol=1e-6)
+    m = o.moments()
+    np.testing.assert_allclose(m['W'], g['W_u0'][:, 0, :], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m['X'][::97], g['X_u0_strided'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m['CX'], g['X_cov'], rtol=1e-7, atol=1e-14)
+
+
+@pytest.mark.parametrize('tag', ['m0', 'm1', 'm2', 'm3'])
+@pytest.mark.parametrize('chunk', [7, 1 << 12])
+def test_masked_pca_oracle_matches_reference(golden_dir, tag, chunk):
+    """oracle/masked_pca.py (chunked sufficient-statistics form) against the live-reference
+    traces with NaN placeholders at the missing entries."""
+    from oracle.masked_pca import MaskedPCAOracle
+    g = np.load(os.path.join(golden_dir, 'masked_pca.npz'))
+    y, mask, x0 = g['in_%s_y' % tag], g['in_%s_mask' % tag], g['in_%s_x0' % tag]
+    L = g[tag + '_L']
+    o = MaskedPCAOracle(y, mask, x0, chunk=chunk)
+    o.iterate(len(L) - 1)
+    # VB.update visits Y first (vmp.py:154-160): its latent entries see W, X of the previous
+    # iteration
+    f_prev, _ = o.predictive_Y()
+    o.iterate(1)
+    np.testing.assert_allclose(np.array(o.L), L, rtol=1e-11)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose([t[k] for t in o.L_terms], g['%s_L_%s' % (tag, k)], rtol=1e-9,
+                                   atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(o.W, g[tag + '_W_u0'][:, 0, :], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(o.WW, g[tag + '_W_u1'][:, 0], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(o.X, g[tag + '_X_u0'][0], rtol=1e-8, atol=1e-11)
+    if tag + '_Y_u0' in g.files:
+        miss = ~mask
+        np.testing.assert_allclose(f_prev[miss], g[tag + '_Y_u0'][miss], rtol=1e-8, atol=1e-10)

@@ -319,6 +319,29 @@ def test_config2_size_vs_oracle():
         np.testing.assert_allclose(Q['tau'].u[0], o.moments()['tau'][0], rtol=1e-9)
 
 
+def test_live_reference_at_headline_dims_n1e5(golden_dir):
+    """D=128, K=32 at N=1e5 -- the largest run of the unmodified reference made for this path
+    (35 s per iteration, three iterations; oracle/make_golden.py pca_seeded_case).  The fixture
+    holds the seed and the reference's outputs only; inputs come from models.make_seeded_pca."""
+    from models import make_seeded_pca
+    g = np.load(os.path.join(golden_dir, 'pca_seeded_n100000_d128_k32.npz'))
+    N, D, K, n = int(g['N']), int(g['D']), int(g['K']), int(g['n_iter'])
+    y, x0 = make_seeded_pca(int(g['seed']), N, D, K)
+    Q = _run(y, x0, K, n)
+    np.testing.assert_allclose(Q.L[:n], g['L'], rtol=ELBO_RTOL)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[k]][:n], g['L_' + k], rtol=1e-9, atol=1e-5)
+    plan = Q.plans[0]
+    ws, cw = plan.posterior_parameters(Q['W'])
+    np.testing.assert_allclose(ws.reshape(g['W_u0'].shape), g['W_u0'], rtol=MOM_RTOL, atol=1e-10)
+    xs, cx = plan.posterior_parameters(Q['X'])
+    np.testing.assert_allclose(xs[::97], g['X_u0_strided'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(cx, g['X_cov'], rtol=1e-7, atol=1e-13)
+    np.testing.assert_allclose(Q['tau'].u[0], g['tau_u0'], rtol=MOM_RTOL)
+    np.testing.assert_allclose(Q['alpha'].u[0], g['alpha_u0'], rtol=MOM_RTOL)
+    np.testing.assert_allclose(Q['alpha'].u[1], g['alpha_u1'], rtol=MOM_RTOL)
+
+
 def test_headline_size_direct_oracle_parity():
     """BASELINE.json metric config, N=1e7, D=128, K=32, DIRECT parity ("against
     the validated chunked restatement at N=1e7"): the chunked NumPy oracle (pinned on the live
