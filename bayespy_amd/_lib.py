@@ -51,6 +51,18 @@ class PCALayout(ctypes.Structure):
         'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_G', 'off_scal', 'off_L', 'total')]
 
 
+class MPCALayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        'DP', 'KP', 'P', 'PT', 'LR', 'off_tau', 'off_alpha', 'off_scal', 'off_L', 'off_W',
+        'off_WW', 'off_ldW', 'off_M', 'off_panel', 'off_panel_x', 'total')]
+
+
+class MPCASizes(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        'ymt_doubles', 'mask_words', 'xm_doubles', 'lam_doubles', 'xxf_doubles',
+        'workspace_doubles')]
+
+
 class GMMLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in (
         'DP', 'KP', 'FS', 'FP', 'F2P', 'off_T', 'len_T', 'off_zs', 'off_alpha', 'off_mu',
@@ -102,6 +114,18 @@ SIGNATURES = {
     'vmp_pca_update_alpha': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_vp]),
     'vmp_pca_lower_bound': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
                                     c_f64, c_vp]),
+    'vmp_mpca_get_layout': (c_i32, [c_i32, c_i32, P(MPCALayout)]),
+    'vmp_mpca_sizes': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, P(MPCASizes)]),
+    'vmp_mpca_init_state': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_vp]),
+    'vmp_mpca_prepare': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp]),
+    'vmp_mpca_x_begin': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp]),
+    'vmp_mpca_x_chunk': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_i32, c_f64, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_mpca_update_w': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
+    'vmp_mpca_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_f64, c_i32,
+                                   P(c_i32), c_vp]),
+    'vmp_mpca_unpack_xx': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_vp]),
     'vmp_gmm_get_layout': (c_i32, [c_i32, c_i32, P(GMMLayout)]),
     'vmp_gmm_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, P(c_sz)]),
     'vmp_gmm_init_state': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_f64, c_f64, c_vp, c_vp]),

@@ -1,0 +1,1032 @@
+// vmp_mpca.hip -- fused probabilistic-PCA / factor-analysis VB block WITH MISSING VALUES (gfx950).
+//
+// Model block of bayespy/demos/pca.py:22-61 with Y.observe(y, mask=array) (demos/pca.py:80-82,
+// how the reference's PCA is normally used).  An array mask gives every plate its own posterior
+// covariance; the reference then
+//   * builds (1,N,K,K) / (D,1,K,K) arrays of second moments and contracts them with einsum
+//     (dot.py:355,403,581: 2 N D K^2 flops each for the message to W and to X),
+//   * loops in PYTHON over the N + D plates calling SciPy's Cholesky (utils/linalg.py:31-63),
+//   * applies masks by multiplication and plate sums (node.py:457-526, :650; misc.py:805).
+// Here one X.update() is three kernels per chunk of plates, all on the fp64 matrix cores, and
+// no (N,K,K) array ever exists:
+//   mpca_lambda   Lam~_n = sum_d m_dn <w w^T>_d  and  rhs~_n = sum_d m_dn y_dn <w_d>
+//                 GEMM (n x d) . (d x P), P = packed lower triangle of the K x K matrix
+//   mpca_sweep    per plate: Lam_n = c I + <tau> Lam~_n inverted in registers by the symmetric
+//                 sweep operator (vmp_sweep.h), <x_n>, <x x^T>_n = Cov_n + <x_n><x_n>^T, log|Cov_n|
+//   mpca_stats    M_d = sum_n m_dn <x x^T>_n,  r_d = sum_n m_dn y_dn <x_n>
+//                 GEMM (d x n) . (n x P), the only things W, tau and the bound consume
+// W.update() is one wavefront per row d (the same sweep), tau / alpha / bound are one small kernel.
+//
+// Layouts (all fp64 unless noted; "plate" = the observation axis n; sub = 16 consecutive plates):
+//   Ymt  [tile][DP][32]      m * y, tile-major, zero where masked / padded  (as vmp_pca_tile_y)
+//   Mb1  [sub][64] uint32    lane l, bit q      = m[4q + (l>>4)][16 sub + (l&15)]    (A operand of mpca_lambda)
+//   Mb2  [sub][64] uint32    lane l, bit 4dt+qq = m[16dt + (l&15)][16 sub + 4qq + (l>>4)] (A operand of mpca_stats)
+//   Xm   [n][KP]             <x_n>, plate-major (the reference's (1,N,K) view)
+//   packed symmetric index   p(i,j) = i(i+1)/2 + j, i >= j, over the PADDED size KP; PT = ceil(P/16)
+//   panel [c][DQ/2][64][2]   B operands of mpca_lambda in fragment order: column tile c < PT of the
+//                            packed <w w^T>_d, then KT tiles of <w_d>; element (d, col) at
+//                            ((c*(DQ/2) + (d/8))*64 + (d%4)*16 + col%16)*2 + (d/4)%2
+//   Lam  [n][LR]             scratch of a chunk, LR = 16 (PT + KT): packed Lam~_n | rhs~_n
+//   XXf  [n/4][PT][4][16]    scratch of a chunk: packed <x x^T>_n in the B-operand order of mpca_stats
+//   Mst  [DP][LR]            packed M_d | r_d  (what ranks all-reduce)
+#include "vmp_sweep.h"
+
+namespace {
+
+using namespace vmp_sweep;
+
+constexpr int NT = 256;
+constexpr int TN = 32;          // plates per tile of Ymt
+
+__host__ __device__ inline int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+struct mpca_dims {
+    int D, K, DP, KP, DQ, DT, KT, P, PT, CT, LR;
+};
+
+inline mpca_dims make_dims(int D, int K)
+{
+    mpca_dims m;
+    m.D = D;
+    m.K = K;
+    int db = 1;
+    while (32 * db < D) db <<= 1;
+    m.DP = 32 * db;
+    m.KP = K <= 16 ? 16 : 32;
+    m.DQ = m.DP / 4;
+    m.DT = m.DP / 16;
+    m.KT = m.KP / 16;
+    m.P = m.KP * (m.KP + 1) / 2;
+    m.PT = (m.P + 15) / 16;
+    m.CT = m.PT + m.KT;
+    m.LR = 16 * m.CT;
+    return m;
+}
+
+inline void fill_layout(int D, int K, vmp_mpca_layout *L)
+{
+    const mpca_dims m = make_dims(D, K);
+    int64_t o = 0;
+    L->DP = m.DP;
+    L->KP = m.KP;
+    L->P = m.P;
+    L->PT = m.PT;
+    L->LR = m.LR;
+    L->off_tau = o;      o += 8;
+    L->off_alpha = o;    o += 4 * m.KP;
+    L->off_scal = o;     o += 16;
+    L->off_L = o;        o += 8;
+    L->off_W = o;        o += (int64_t)m.DP * m.KP;
+    L->off_WW = o;       o += (int64_t)m.DP * m.KP * m.KP;
+    L->off_ldW = o;      o += m.DP;
+    L->off_M = o;        o += (int64_t)m.DP * m.LR;
+    L->off_panel = o;    o += (int64_t)m.CT * (m.DQ / 2) * 128;
+    L->off_panel_x = o;  o += (int64_t)m.CT * (m.DQ / 2) * 128;
+    L->total = (o + 7) / 8 * 8;
+}
+
+// scal block: [0] sum m y^2  [1] sum m  [2] sum_n tr<xx>_n  [3] sum_n log|Cov_n|  [4] plates N
+//             [5] status     [6] <tau> used by the last X.update()   [7] residual (diagnostic)
+enum { SC_SYY = 0, SC_NOBS, SC_TRXX, SC_LDX, SC_N, SC_STATUS, SC_TAUX, SC_RESID };
+
+__device__ inline int64_t panel_index(int DQ, int c, int d, int col16)
+{
+    const int q = d >> 2;
+    return (((int64_t)c * (DQ / 2) + (q >> 1)) * 64 + (d & 3) * 16 + col16) * 2 + (q & 1);
+}
+
+// -------------------------------------------------------------------------------------------
+// set-up: masked tile-major data, the two bit layouts of the mask, sum m y^2, sum m
+// -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+mpca_prepare_kernel(const double *__restrict__ Y, int64_t ldy, const uint8_t *__restrict__ mask,
+                    int64_t ldm, int64_t N, int D, int DP, double *__restrict__ Ymt,
+                    uint32_t *__restrict__ Mb1, uint32_t *__restrict__ Mb2,
+                    double *__restrict__ partial, int64_t ntiles)
+{
+    __shared__ uint8_t ms[128 * TN];
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x;
+    double syy = 0.0, nobs = 0.0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        double *tb = Ymt + tile * ((int64_t)DP * TN);
+        for (int e = tid; e < DP * TN; e += NT) {
+            const int d = e / TN, j = e - d * TN;
+            const int64_t n = tile * TN + j;
+            uint8_t mv = 0;
+            double v = 0.0;
+            if (d < D && n < N) {
+                mv = mask ? (mask[(int64_t)d * ldm + n] != 0) : 1;
+                if (mv) v = Y[(int64_t)d * ldy + n];
+            }
+            ms[e] = mv;
+            tb[e] = v;
+            syy += v * v;
+            nobs += (double)mv;
+        }
+        __syncthreads();
+        // bit words: 2 subtiles x 64 lanes x 2 layouts = 256 words per tile, one per thread
+        {
+            const int lay = tid >> 7, s = (tid >> 6) & 1, l = tid & 63;
+            const int l15 = l & 15, l4 = l >> 4;
+            uint32_t w = 0;
+            if (lay == 0) {
+                for (int q = 0; q < DP / 4; ++q) w |= (uint32_t)ms[(4 * q + l4) * TN + 16 * s + l15] << q;
+                Mb1[(tile * 2 + s) * 64 + l] = w;
+            } else {
+                for (int dt = 0; dt < DP / 16; ++dt)
+                    for (int qq = 0; qq < 4; ++qq)
+                        w |= (uint32_t)ms[(16 * dt + l15) * TN + 16 * s + 4 * qq + l4] << (4 * dt + qq);
+                Mb2[(tile * 2 + s) * 64 + l] = w;
+            }
+        }
+    }
+    syy = block_sum<NT>(syy, red);
+    nobs = block_sum<NT>(nobs, red);
+    if (tid == 0) {
+        partial[2 * blockIdx.x] = syy;
+        partial[2 * blockIdx.x + 1] = nobs;
+    }
+}
+
+// out[j] (+)= sum_b partial[b * stride + j], fixed order (deterministic)
+__global__ void __launch_bounds__(NT)
+mpca_reduce_kernel(const double *__restrict__ partial, int nb, int64_t stride, int64_t len,
+                   double *__restrict__ out, int accumulate)
+{
+    const int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (e >= len) return;
+    double s0 = 0.0, s1 = 0.0;
+    int b = 0;
+    for (; b + 1 < nb; b += 2) {
+        s0 += partial[(int64_t)b * stride + e];
+        s1 += partial[(int64_t)(b + 1) * stride + e];
+    }
+    if (b < nb) s0 += partial[(int64_t)b * stride + e];
+    const double s = s0 + s1;
+    out[e] = accumulate ? out[e] + s : s;
+}
+
+// -------------------------------------------------------------------------------------------
+// mpca_lambda: Lam~[n][:] = sum_d m_dn panel[d][:]   (columns: packed <ww>, then <w>)
+//   A operand (n x d): mask bits -> 0.0 / 1.0 (packed columns), m*y from Ymt (the KT last columns)
+//   B operand (d x col): the panel in fragment order, 16 bytes per lane = two k-steps
+// One workgroup = 16*NSUB plates; wavefront w owns column tiles c = w, w+4, ...
+// -------------------------------------------------------------------------------------------
+template <int DB, int KT, int NSUB>
+__global__ void __launch_bounds__(NT, 2)
+mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ Mb1,
+                   const double *__restrict__ panel, int64_t sub0, int64_t nsub_chunk,
+                   int64_t nplates_chunk, double *__restrict__ Lam)
+{
+    constexpr int DP = 32 * DB, DQ = DP / 4;
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
+    constexpr int LR = 16 * CT;
+    constexpr int CW = (CT + 3) / 4;            // column tiles per wavefront (upper bound)
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = l & 15, l4 = l >> 4;
+    const int64_t ngroups = (nsub_chunk + NSUB - 1) / NSUB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        v4f64 acc[CW][NSUB];
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci)
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) acc[ci][s] = v4f64{0.0, 0.0, 0.0, 0.0};
+        uint32_t mw[NSUB];
+        const double *yb[NSUB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int64_t sub = sub0 + grp * NSUB + s;         // global 16-plate subtile
+            const bool ok = (grp * NSUB + s) < nsub_chunk;
+            mw[s] = ok ? Mb1[sub * 64 + l] : 0u;
+            // Ymt element (d = 4q + l4, n = 16 sub + l15): tile = sub/2, column (sub&1)*16 + l15
+            yb[s] = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l4 * TN + (sub & 1) * 16 + l15;
+        }
+        // the KT last column tiles (c >= PT) take m*y as their A operand; by construction of
+        // c = w + 4 ci they sit in the LAST column slot(s) of a wavefront
+#pragma unroll 2
+        for (int q2 = 0; q2 < DQ / 2; ++q2) {
+            v2f64 b[CW];
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) {
+                const int c = w + 4 * ci;
+                b[ci] = (c < CT) ? *reinterpret_cast<const v2f64 *>(
+                                       panel + (((int64_t)c * (DQ / 2) + q2) * 64 + l) * 2)
+                                 : v2f64{0.0, 0.0};
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = 2 * q2 + e;
+                double am[NSUB], ay[NSUB];
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) {
+                    am[s] = (double)((mw[s] >> q) & 1u);
+                    // masked entries of Ymt are zero already; subtiles beyond the chunk have a
+                    // zero mask word and must not contribute either
+                    ay[s] = (mw[s] >> q) & 1u ? yb[s][(int64_t)(4 * q) * TN] : 0.0;
+                }
+#pragma unroll
+                for (int ci = 0; ci < CW; ++ci) {
+                    const int c = w + 4 * ci;
+                    if (c < CT) {
+                        const double bb = e ? b[ci].y : b[ci].x;
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s)
+                            acc[ci][s] = mfma((c >= PT) ? ay[s] : am[s], bb, acc[ci][s]);
+                    }
+                }
+            }
+        }
+        // C/D layout: row (plate) = (l>>4) + 4 r, column = l&15
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) {
+            const int c = w + 4 * ci;
+            if (c < CT) {
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t n = (grp * NSUB + s) * 16 + l4 + 4 * r;   // plate in the chunk
+                        if (n < nplates_chunk) Lam[n * LR + 16 * c + l15] = acc[ci][s][r];
+                    }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// mpca_sweep: per plate  Lam_n = c I + tau Lam~_n  ->  Cov_n, <x_n>, <xx>_n, log|Cov_n|, tr<xx>_n
+// One wavefront per plate (two plates in flight per wavefront to hide the serial pivot chains).
+// FROM_VALUE: delta moments of a given <x> (initialize_from_value): <xx> = x x^T, no inverse.
+// -------------------------------------------------------------------------------------------
+template <int KT>
+__device__ __forceinline__ void load_sym_tiles(v4f64 (&T)[2][2], const double *__restrict__ row,
+                                               int K, double diag, double scale, int l15, int l4)
+{
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                double v;
+                if (i < K && j < K) {
+                    const int a = i > j ? i : j, b = i > j ? j : i;
+                    v = scale * row[tri(a, b)] + ((i == j) ? diag : 0.0);
+                } else {
+                    v = (i == j) ? 1.0 : 0.0;
+                }
+                T[tr][tc][r] = v;
+            }
+}
+
+struct plate_result {
+    double x0, x1;        // <x>[l15], <x>[16 + l15] in the lanes l4 == 0
+    double logdet;        // log|Lam|
+    int bad;
+};
+
+// T (= Lam) -> T = Cov + x x^T, x = Cov rhs
+__device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const double *__restrict__ pb,
+                                                     double scale, int K, int l15, int l4,
+                                                     double prod, double ld, int bad)
+{
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                T[tr][tc][r] = (i < K && j < K) ? -T[tr][tc][r] : T[tr][tc][r];
+            }
+    // x^T = rhs^T Cov: the tiles are B operands as they are (rows l4 + 4r), rhs enters through
+    // row 0 of the A operand
+    v4f64 xa[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * tr + 4 * r + l4;
+            const double a = (l15 == 0 && m < K) ? scale * pb[m] : 0.0;
+            xa[0] = mfma(a, T[tr][0][r], xa[0]);
+            xa[1] = mfma(a, T[tr][1][r], xa[1]);
+        }
+    plate_result res;
+    res.x0 = (l4 == 0) ? xa[0][0] : 0.0;
+    res.x1 = (l4 == 0) ? xa[1][0] : 0.0;
+    T[0][0] = mfma(res.x0, res.x0, T[0][0]);
+    T[0][1] = mfma(res.x0, res.x1, T[0][1]);
+    T[1][0] = mfma(res.x1, res.x0, T[1][0]);
+    T[1][1] = mfma(res.x1, res.x1, T[1][1]);
+    res.logdet = sweep_logdet(prod, ld);
+    res.bad = bad;
+    return res;
+}
+
+template <int KT>
+__device__ __forceinline__ void store_plate(const v4f64 (&T)[2][2], const plate_result &res,
+                                            int64_t n_chunk, int64_t n_glob, int K,
+                                            double *__restrict__ XXf, double *__restrict__ Xm,
+                                            int l15, int l4, double &trl)
+{
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+    double *xb = XXf + ((n_chunk >> 2) * PT) * 64 + (n_chunk & 3) * 16;
+#pragma unroll
+    for (int tr = 0; tr < KT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc <= tr; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                if (i >= j) {
+                    const int p = tri(i, j);
+                    const double v = (i < K && j < K) ? T[tr][tc][r] : 0.0;
+                    xb[(p >> 4) * 64 + (p & 15)] = v;
+                    if (i == j) trl += v;
+                }
+            }
+    if (l4 == 0) {
+        double *xr = Xm + n_glob * KP;
+        xr[l15] = (l15 < K) ? res.x0 : 0.0;
+        if (KT > 1) xr[16 + l15] = (16 + l15 < K) ? res.x1 : 0.0;
+    }
+}
+
+// NM = plates in flight per wavefront: 1 (<= 256 registers: two wavefronts per SIMD hide the serial
+// pivot chains of each other) or 2 (one wavefront per SIMD, the two sweeps interleaved in one
+// instruction stream).
+template <int KT, bool FROM_VALUE, int NM>
+__global__ void __launch_bounds__(NT, (NM == 2 && !FROM_VALUE) ? 1 : 2)
+mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t nplates_chunk, int K,
+                  double x_prec, double xx_diag, const double *__restrict__ tau_ptr,
+                  double *__restrict__ XXf, double *__restrict__ Xm, double *__restrict__ partial)
+{
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+    __shared__ double red[NT / 64];
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = l & 15, l4 = l >> 4;
+    const double tau = FROM_VALUE ? 0.0 : tau_ptr[0];
+    const int nblocks = (K + 3) / 4;
+    double trl = 0.0, ldsum = 0.0;
+    int anybad = 0;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    if (FROM_VALUE) {
+        for (int64_t n = (int64_t)blockIdx.x * 4 + w; n < nplates_chunk; n += nwaves) {
+            const double *xr = Xm + (n0 + n) * KP;
+            // <xx> = x x^T through the same store path: T = outer product
+            v4f64 T[2][2];
+            const double xa = (l4 == 0 && l15 < K) ? xr[l15] : 0.0;
+            const double xb = (KT > 1 && l4 == 0 && 16 + l15 < K) ? xr[16 + l15] : 0.0;
+            const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+            T[0][0] = mfma(xa, xa, z);
+            T[0][1] = mfma(xa, xb, z);
+            T[1][0] = mfma(xb, xa, z);
+            T[1][1] = mfma(xb, xb, z);
+            if (xx_diag != 0.0) {      // prior moments: <xx> = I / c + x x^T
+#pragma unroll
+                for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * tr + l4 + 4 * r == 16 * tr + l15) T[tr][tr][r] += xx_diag;
+            }
+            plate_result res;
+            res.x0 = xa;
+            res.x1 = xb;
+            res.logdet = 0.0;
+            res.bad = 0;
+            store_plate<KT>(T, res, n, n0 + n, K, XXf, Xm, l15, l4, trl);
+        }
+    } else if (NM == 1) {
+        for (int64_t n = (int64_t)blockIdx.x * 4 + w; n < nplates_chunk; n += nwaves) {
+            const double *ra = Lam + n * LR;
+            v4f64 Ta[2][2];
+            load_sym_tiles<KT>(Ta, ra, K, x_prec, tau, l15, l4);
+            double pa = 1.0, la = 0.0;
+            int ba = 0;
+            sweep_upto<0>(Ta, nblocks, l15, l4, pa, la, ba);
+            const plate_result A = finish_plate(Ta, ra + 16 * PT, tau, K, l15, l4, pa, la, ba);
+            store_plate<KT>(Ta, A, n, n0 + n, K, XXf, Xm, l15, l4, trl);
+            ldsum -= A.logdet;
+            anybad |= A.bad;
+        }
+    } else {
+        for (int64_t n = ((int64_t)blockIdx.x * 4 + w) * 2; n < nplates_chunk; n += nwaves * 2) {
+            const bool two = (n + 1) < nplates_chunk;
+            const double *ra = Lam + n * LR, *rb = Lam + (two ? n + 1 : n) * LR;
+            v4f64 Ta[2][2], Tb[2][2];
+            load_sym_tiles<KT>(Ta, ra, K, x_prec, tau, l15, l4);
+            load_sym_tiles<KT>(Tb, rb, K, x_prec, tau, l15, l4);
+            double pa = 1.0, la = 0.0, pbb = 1.0, lb = 0.0;
+            int ba = 0, bb = 0;
+            sweep_pair<0>(Ta, Tb, nblocks, l15, l4, pa, la, ba, pbb, lb, bb);
+            const plate_result A = finish_plate(Ta, ra + 16 * PT, tau, K, l15, l4, pa, la, ba);
+            const plate_result B = finish_plate(Tb, rb + 16 * PT, tau, K, l15, l4, pbb, lb, bb);
+            store_plate<KT>(Ta, A, n, n0 + n, K, XXf, Xm, l15, l4, trl);
+            ldsum -= A.logdet;
+            anybad |= A.bad;
+            if (two) {
+                store_plate<KT>(Tb, B, n + 1, n0 + n + 1, K, XXf, Xm, l15, l4, trl);
+                ldsum -= B.logdet;
+                anybad |= B.bad;
+            }
+        }
+    }
+    // per-workgroup partial sums: tr<xx>, log|Cov| (uniform per wavefront: count once), status
+    const double tr = block_sum<NT>(trl, red);
+    const double ldw = block_sum<NT>(l == 0 ? ldsum : 0.0, red);
+    const double bd = block_sum<NT>((double)anybad, red);
+    if (threadIdx.x == 0) {
+        partial[3 * blockIdx.x + 0] = tr;
+        partial[3 * blockIdx.x + 1] = ldw;
+        partial[3 * blockIdx.x + 2] = bd;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// mpca_stats: Mst[d][:] += sum_n m_dn [ packed <xx>_n | <x_n> y_dn ]
+//   A operand (d x n): mask bits (packed columns), m*y from Ymt (the KT last columns)
+//   B operand (n x col): XXf / Xm
+// A workgroup owns the column tiles [c0, c1) of one slice and ALL rows d; wavefront w owns
+// the row tiles dt = w, w+4, ...; it walks the 16-plate subtiles of its share of the chunk.
+// -------------------------------------------------------------------------------------------
+template <int DB, int KT, int TS>
+__global__ void __launch_bounds__(NT, 2)
+mpca_stats_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ Mb2,
+                  const double *__restrict__ XXf, const double *__restrict__ Xm, int64_t sub0,
+                  int64_t nsub_chunk, int64_t n0, int nslices, double *__restrict__ partial)
+{
+    constexpr int DP = 32 * DB, DT = DP / 16, DW = (DT + 3) / 4;
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
+    constexpr int LR = 16 * CT;
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = l & 15, l4 = l >> 4;
+    const int slice = blockIdx.x % nslices, wg = blockIdx.x / nslices, nwg = gridDim.x / nslices;
+    const int c0 = slice * TS;
+    v4f64 acc[DW][TS];
+#pragma unroll
+    for (int i = 0; i < DW; ++i)
+#pragma unroll
+        for (int t = 0; t < TS; ++t) acc[i][t] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const bool active = w < DT;             // DT < 4: the upper wavefronts have no row tile
+    for (int64_t sc = wg; sc < nsub_chunk; sc += nwg) {
+        const int64_t sub = sub0 + sc;
+        const uint32_t mw = Mb2[sub * 64 + l];
+        // Ymt element (d = 16 dt + l15, n = 16 sub + 4 qq + l4)
+        const double *ybase = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l15 * TN
+                              + (sub & 1) * 16 + l4;
+        const double *xxb = XXf + (sc * 4) * ((int64_t)PT * 64) + l;
+        const double *xmb = Xm + (n0 + sc * 16 + l4) * KP + l15;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            double bfr[TS];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                const int c = c0 + t;
+                bfr[t] = (c < PT) ? xxb[((int64_t)qq * PT + c) * 64]
+                                  : (c < CT ? xmb[(int64_t)(4 * qq) * KP + 16 * (c - PT)] : 0.0);
+            }
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < DW; ++i) {
+                    const int dt = w + 4 * i;
+                    if (dt < DT) {
+                        const bool on = (mw >> (4 * dt + qq)) & 1u;
+                        const double am = on ? 1.0 : 0.0;
+                        double ay = 0.0;
+                        if (c0 + TS > PT) ay = on ? ybase[(int64_t)(16 * dt) * TN + 4 * qq] : 0.0;
+#pragma unroll
+                        for (int t = 0; t < TS; ++t) {
+                            const int c = c0 + t;
+                            if (c < CT) acc[i][t] = mfma((c >= PT) ? ay : am, bfr[t], acc[i][t]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // partial[wg][d][col]; C/D layout: row (d) = (l>>4) + 4r, column = l&15
+    double *pb = partial + (int64_t)wg * DP * LR;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < DW; ++i) {
+            const int dt = w + 4 * i;
+            if (dt < DT) {
+#pragma unroll
+                for (int t = 0; t < TS; ++t) {
+                    const int c = c0 + t;
+                    if (c < CT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            pb[(int64_t)(16 * dt + l4 + 4 * r) * LR + 16 * c + l15] = acc[i][t][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// W.update(): one wavefront per row d.  Lam_d = diag<alpha> + <tau> M_d  (gaussian.py:649-706
+// with the masked messages of dot.py:425-633), w_d = Cov_d <tau> r_d, <ww>_d = Cov_d + w w^T.
+// Writes the plain moments (W, WW, log|Cov_d|) and the B-operand panel of mpca_lambda.
+// mode 0: VB update;  mode 1: delta moments of the <w_d> already in st[off_W] (initialize_from_value)
+// mode 2: prior moments: mean 0, covariance diag(1/<alpha>)
+// -------------------------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(NT, 2)
+mpca_w_kernel(vmp_mpca_layout L, int D, int K, int DQ, int mode, double *__restrict__ st)
+{
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l15 = l & 15, l4 = l >> 4;
+    const int d = blockIdx.x * 4 + w;
+    if (d >= D) return;
+    const double tau = st[L.off_tau + 2];
+    const double *alpha = st + L.off_alpha + 2 * KP;
+    const double *mrow = st + L.off_M + (int64_t)d * L.LR;
+    double *wrow = st + L.off_W + (int64_t)d * KP;
+    v4f64 T[2][2];
+    plate_result res;
+    if (mode == 0) {
+        load_sym_tiles<KT>(T, mrow, K, 0.0, tau, l15, l4);
+        // + diag<alpha>
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tr + l15;
+                if (i == j && i < K) T[tr][tr][r] += alpha[i];
+            }
+        double prod = 1.0, ld = 0.0;
+        int bad = 0;
+        sweep_upto<0>(T, (K + 3) / 4, l15, l4, prod, ld, bad);
+        res = finish_plate(T, mrow + 16 * PT, tau, K, l15, l4, prod, ld, bad);
+    } else {
+        const double xa = (mode == 1 && l4 == 0 && l15 < K) ? wrow[l15] : 0.0;
+        const double xb = (mode == 1 && KT > 1 && l4 == 0 && 16 + l15 < K) ? wrow[16 + l15] : 0.0;
+        const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+        T[0][0] = mfma(xa, xa, z);
+        T[0][1] = mfma(xa, xb, z);
+        T[1][0] = mfma(xb, xa, z);
+        T[1][1] = mfma(xb, xb, z);
+        double ldp = 0.0;
+        if (mode == 2) {
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * tr + l4 + 4 * r, j = 16 * tr + l15;
+                    if (i == j && i < K) T[tr][tr][r] += 1.0 / alpha[i];
+                }
+            for (int k = 0; k < K; ++k) ldp += log(alpha[k]);     // log|Lam| of the prior
+        }
+        res.x0 = xa;
+        res.x1 = xb;
+        res.logdet = ldp;
+        res.bad = 0;
+    }
+    // plain moments
+    double *ww = st + L.off_WW + (int64_t)d * KP * KP;
+    double *panel = st + L.off_panel;
+#pragma unroll
+    for (int tr = 0; tr < KT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < KT; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                const double v = (i < K && j < K) ? T[tr][tc][r] : 0.0;
+                ww[i * KP + j] = v;
+                if (i >= j) {
+                    const int p = tri(i, j);
+                    panel[panel_index(DQ, p >> 4, d, p & 15)] = v;
+                }
+            }
+    if (l4 == 0) {
+        const double v0 = (l15 < K) ? res.x0 : 0.0;
+        wrow[l15] = v0;
+        panel[panel_index(DQ, PT, d, l15)] = v0;
+        if (KT > 1) {
+            const double v1 = (16 + l15 < K) ? res.x1 : 0.0;
+            wrow[16 + l15] = v1;
+            panel[panel_index(DQ, PT + 1, d, l15)] = v1;
+        }
+    }
+    if (l == 0) {
+        st[L.off_ldW + d] = -res.logdet;            // log|Cov_d|
+        if (res.bad) st[L.off_scal + SC_STATUS] = (double)VMP_ERR_NOT_POSDEF;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// tau / alpha / lower bound: one workgroup (gamma.py:116-148, expfamily.py:400-480)
+// -------------------------------------------------------------------------------------------
+struct small_args {
+    vmp_mpca_layout L;
+    int D, K, nops;
+    int ops[8];
+    double x_prec, a0t, b0t, a0a, b0a;
+};
+
+__device__ inline double gamma_term(double a0, double b0, double a, double b, double x, double lx)
+{
+    // E[log p(x | a0, b0) - log q(x)],  q = Gamma(a, b)
+    return (a0 * log(b0) - vmp_lgamma(a0)) - (a * log(b) - vmp_lgamma(a)) + (b - b0) * x
+           + (a0 - a) * lx;
+}
+
+__global__ void __launch_bounds__(NT)
+mpca_small_kernel(small_args A, double *__restrict__ st)
+{
+    __shared__ double red[NT / 64];
+    const vmp_mpca_layout &L = A.L;
+    const int D = A.D, K = A.K, KP = (int)L.KP, PP = 16 * (int)L.PT, LR = (int)L.LR;
+    const int tid = threadIdx.x;
+    double *sc = st + L.off_scal;
+    for (int oi = 0; oi < A.nops; ++oi) {
+        const int op = A.ops[oi];
+        __syncthreads();
+        if (op == VMP_MPCA_OP_TAU || op == VMP_MPCA_OP_ELBO) {
+            // residual = sum m y^2 - 2 sum_d <w_d>.r_d + sum_d <ww>_d : M_d
+            double s = 0.0;
+            for (int e = tid; e < D * K * K; e += NT) {
+                const int d = e / (K * K), ij = e - d * K * K, i = ij / K, j = ij - i * K;
+                const int a = i > j ? i : j, b = i > j ? j : i;
+                s += st[L.off_WW + ((int64_t)d * KP + i) * KP + j] * st[L.off_M + (int64_t)d * LR + tri(a, b)];
+            }
+            for (int e = tid; e < D * K; e += NT) {
+                const int d = e / K, k = e - d * K;
+                s -= 2.0 * st[L.off_W + (int64_t)d * KP + k] * st[L.off_M + (int64_t)d * LR + PP + k];
+            }
+            s = block_sum<NT>(s, red);
+            if (tid == 0) sc[SC_RESID] = sc[SC_SYY] + s;
+            __syncthreads();
+        }
+        if (op == VMP_MPCA_OP_TAU) {
+            if (tid == 0) {
+                const double a = A.a0t + 0.5 * sc[SC_NOBS], b = A.b0t + 0.5 * sc[SC_RESID];
+                st[L.off_tau + 0] = a;
+                st[L.off_tau + 1] = b;
+                st[L.off_tau + 2] = a / b;
+                st[L.off_tau + 3] = vmp_digamma(a) - log(b);
+                if (!(b > 0.0)) sc[SC_STATUS] = (double)VMP_ERR_FLOATING;
+            }
+        } else if (op == VMP_MPCA_OP_ALPHA) {
+            for (int k = tid; k < K; k += NT) {
+                double s = 0.0;
+                for (int d = 0; d < D; ++d) s += st[L.off_WW + ((int64_t)d * KP + k) * KP + k];
+                const double a = A.a0a + 0.5 * D, b = A.b0a + 0.5 * s;
+                st[L.off_alpha + 0 * KP + k] = a;
+                st[L.off_alpha + 1 * KP + k] = b;
+                st[L.off_alpha + 2 * KP + k] = a / b;
+                st[L.off_alpha + 3 * KP + k] = vmp_digamma(a) - log(b);
+            }
+        } else if (op == VMP_MPCA_OP_ELBO) {
+            const double tau = st[L.off_tau + 2], ltau = st[L.off_tau + 3];
+            // W term: sum_d [ 1/2 sum_k <log a_k> - 1/2 sum_k <a_k> <ww>_d[k][k] + 1/2 log|Cov_d| + K/2 ]
+            double sw = 0.0;
+            for (int e = tid; e < D * K; e += NT) {
+                const int d = e / K, k = e - d * K;
+                sw += 0.5 * st[L.off_alpha + 3 * KP + k]
+                      - 0.5 * st[L.off_alpha + 2 * KP + k] * st[L.off_WW + ((int64_t)d * KP + k) * KP + k];
+            }
+            for (int d = tid; d < D; d += NT) sw += 0.5 * st[L.off_ldW + d] + 0.5 * K;
+            sw = block_sum<NT>(sw, red);
+            double sa = 0.0;
+            for (int k = tid; k < K; k += NT)
+                sa += gamma_term(A.a0a, A.b0a, st[L.off_alpha + k], st[L.off_alpha + KP + k],
+                                 st[L.off_alpha + 2 * KP + k], st[L.off_alpha + 3 * KP + k]);
+            sa = block_sum<NT>(sa, red);
+            if (tid == 0) {
+                const double N = sc[SC_N];
+                const double LY = sc[SC_NOBS] * (-0.5 * 1.8378770664093453 + 0.5 * ltau)
+                                  - 0.5 * tau * sc[SC_RESID];
+                const double LX = -0.5 * A.x_prec * sc[SC_TRXX] + 0.5 * sc[SC_LDX]
+                                  + N * (0.5 * K * log(A.x_prec) + 0.5 * K);
+                const double Lt = gamma_term(A.a0t, A.b0t, st[L.off_tau], st[L.off_tau + 1], tau, ltau);
+                double *Lo = st + L.off_L;
+                Lo[0] = LY;
+                Lo[1] = LX;
+                Lo[2] = sw;
+                Lo[3] = Lt;
+                Lo[4] = sa;
+                Lo[5] = LY + LX + sw + Lt + sa;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+mpca_init_state_kernel(vmp_mpca_layout L, int K, double a0t, double b0t, double a0a, double b0a,
+                       double *st)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        st[L.off_tau + 0] = a0t;
+        st[L.off_tau + 1] = b0t;
+        st[L.off_tau + 2] = a0t / b0t;
+        st[L.off_tau + 3] = vmp_digamma(a0t) - log(b0t);
+    }
+    for (int k = tid; k < K; k += NT) {
+        st[L.off_alpha + 0 * L.KP + k] = a0a;
+        st[L.off_alpha + 1 * L.KP + k] = b0a;
+        st[L.off_alpha + 2 * L.KP + k] = a0a / b0a;
+        st[L.off_alpha + 3 * L.KP + k] = vmp_digamma(a0a) - log(b0a);
+    }
+}
+
+__global__ void mpca_set_scalar_kernel(double *p, double v) { p[0] = v; }
+
+// <xx>_n of plates [0, nplates) of the chunk, unpacked to (nplates, K, K) (inspection: X.u[1])
+__global__ void __launch_bounds__(NT)
+mpca_unpack_kernel(const double *__restrict__ XXf, int PT, int K, int64_t nplates,
+                   double *__restrict__ out)
+{
+    const int64_t total = nplates * K * K;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * NT) {
+        const int64_t n = e / (K * K);
+        const int ij = (int)(e - n * K * K), i = ij / K, j = ij - i * K;
+        const int a = i > j ? i : j, b = i > j ? j : i, p = tri(a, b);
+        out[e] = XXf[((n >> 2) * PT + (p >> 4)) * 64 + (n & 3) * 16 + (p & 15)];
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------
+constexpr int TSMAX = 9;      // column tiles per slice of mpca_stats (accumulators: 2 x 9 tiles)
+
+int stats_slices(const mpca_dims &m) { return (m.CT + TSMAX - 1) / TSMAX; }
+
+int64_t grid_cap(vmp_ctx *ctx, int per_cu) { return (int64_t)ctx->num_cu * per_cu; }
+
+int32_t check_dims(vmp_ctx *ctx, int D, int K)
+{
+    VMP_REQUIRE(ctx, D >= 1 && K >= 1, VMP_ERR_INVALID, "bad dims D=%d K=%d", D, K);
+    VMP_REQUIRE(ctx, D <= 128 && K <= 32, VMP_ERR_UNSUPPORTED,
+                "the fused missing-data PCA block supports D <= 128, K <= 32 (got D=%d, K=%d)", D, K);
+    return VMP_OK;
+}
+
+#define MPCA_FOR_EACH(M) M(1, 1) M(2, 1) M(4, 1) M(1, 2) M(2, 2) M(4, 2)
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_mpca_get_layout(int32_t D, int32_t K, vmp_mpca_layout *out)
+{
+    if (!out || D < 1 || K < 1) return VMP_ERR_INVALID;
+    if (D > 128 || K > 32) return VMP_ERR_UNSUPPORTED;
+    fill_layout(D, K, out);
+    return VMP_OK;
+}
+
+int32_t vmp_mpca_sizes(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t chunk,
+                       vmp_mpca_sizes_t *out)
+{
+    VMP_REQUIRE(ctx, ctx && out, VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, N >= 0 && chunk >= 32 && chunk % 32 == 0, VMP_ERR_INVALID,
+                "the chunk must be a positive multiple of 32 plates");
+    const mpca_dims m = make_dims(D, K);
+    const int64_t ntiles = (N + TN - 1) / TN;
+    out->ymt_doubles = (ntiles > 0 ? ntiles : 1) * m.DP * TN;
+    out->mask_words = (ntiles > 0 ? ntiles : 1) * 2 * 64;
+    out->xm_doubles = (ntiles > 0 ? ntiles : 1) * TN * m.KP;
+    out->lam_doubles = chunk * m.LR;
+    out->xxf_doubles = (chunk / 4) * m.PT * 64;
+    // partial sums: mpca_stats (workgroups x DP x LR), sweep / prepare scalars
+    const int64_t gst = grid_cap(ctx, 2) / stats_slices(m);
+    int64_t p = gst * m.DP * m.LR;
+    const int64_t p2 = grid_cap(ctx, 16) * 4;
+    out->workspace_doubles = p + p2 + 64;
+    return VMP_OK;
+}
+
+int32_t vmp_mpca_init_state(vmp_ctx *ctx, int32_t D, int32_t K, double a0_tau, double b0_tau,
+                            double a0_alpha, double b0_alpha, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, a0_tau > 0 && b0_tau > 0 && a0_alpha > 0 && b0_alpha > 0, VMP_ERR_INVALID,
+                "Gamma prior parameters must be positive");
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, (size_t)L.total * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(mpca_init_state_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, K, a0_tau,
+                       b0_tau, a0_alpha, b0_alpha, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_mpca_prepare(vmp_ctx *ctx, const double *Y, int64_t ldy, const uint8_t *mask,
+                         int64_t ldm, int64_t N, int32_t D, int32_t K, double *Ymt, uint32_t *Mb1,
+                         uint32_t *Mb2, double *state, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Y && Ymt && Mb1 && Mb2 && state && workspace, VMP_ERR_INVALID,
+                "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, ldy >= N && (!mask || ldm >= N), VMP_ERR_INVALID, "leading dimension < N");
+    const mpca_dims m = make_dims(D, K);
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    const int64_t ntiles = (N + TN - 1) / TN;
+    double *partial = reinterpret_cast<double *>(workspace);
+    int64_t g = ntiles < grid_cap(ctx, 8) ? ntiles : grid_cap(ctx, 8);
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(mpca_prepare_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, Y, ldy,
+                       mask, ldm, N, D, m.DP, Ymt, Mb1, Mb2, partial, ntiles);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, ctx->stream, partial, (int)g,
+                       (int64_t)2, (int64_t)2, state + L.off_scal + SC_SYY, 0);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+// One chunk of X.update() (from_value = 0) or of the statistics of a given <x> (from_value = 1):
+// plates [n0, n0 + nplates), n0 a multiple of 32.  Accumulates the chunk's statistics into
+// state[off_M] and the scalars (first = 1: overwrite, i.e. the first chunk of a pass).
+int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t nplates,
+                         int32_t flags, double x_prec, const double *Ymt,
+                         const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam,
+                         double *XXf, double *state, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Ymt && Mb1 && Mb2 && Xm && Lam && XXf && state && workspace,
+                VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, n0 >= 0 && n0 % 32 == 0 && nplates >= 0, VMP_ERR_INVALID,
+                "a chunk starts at a multiple of 32 plates");
+    if (nplates == 0) return VMP_OK;
+    const bool first = (flags & VMP_MPCA_FIRST) != 0, inspect = (flags & VMP_MPCA_INSPECT) != 0;
+    const bool from_value = (flags & (VMP_MPCA_FROM_VALUE | VMP_MPCA_PRIOR)) != 0;
+    const double xx_diag = (flags & VMP_MPCA_PRIOR) ? 1.0 / x_prec : 0.0;
+    const mpca_dims m = make_dims(D, K);
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    hipStream_t s = ctx->stream;
+    const int64_t sub0 = n0 / 16, nsub = (nplates + 15) / 16;
+    double *partial = reinterpret_cast<double *>(workspace);
+    const int ns = stats_slices(m);
+    const int64_t gst_wg = grid_cap(ctx, 2) / ns;
+    double *pscal = partial + gst_wg * m.DP * m.LR;
+    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
+    if (!from_value) {
+        constexpr int NSUB = 2;
+        int64_t g = (nsub + NSUB - 1) / NSUB;
+        if (g > grid_cap(ctx, 2)) g = grid_cap(ctx, 2);
+#define MPCA_CASE(db, kt)                                                                       \
+    if (m.DP == 32 * db && m.KT == kt)                                                          \
+        hipLaunchKernelGGL((mpca_lambda_kernel<db, kt, NSUB>), dim3((unsigned)g), dim3(NT), 0, s, \
+                           Ymt, Mb1, state + L.off_panel_x, sub0, nsub, nplates, Lam);          \
+    else
+        MPCA_FOR_EACH(MPCA_CASE) { return VMP_ERR_UNSUPPORTED; }
+#undef MPCA_CASE
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
+    const int nm = vmp_tune_get("mpca_sweep_pair", 0) ? 2 : 1;
+    int64_t gs = (nplates + 4 * nm - 1) / (4 * nm);
+    const int64_t gs_cap = grid_cap(ctx, nm == 2 ? 4 : 8);
+    if (gs > gs_cap) gs = gs_cap;
+    if (gs < 1) gs = 1;
+#define MPCA_SWEEP(kt, fv, nmm)                                                                    \
+    hipLaunchKernelGGL((mpca_sweep_kernel<kt, fv, nmm>), dim3((unsigned)gs), dim3(NT), 0, s, Lam, \
+                       m.LR, n0, nplates, K, x_prec, xx_diag, state + L.off_scal + SC_TAUX, XXf,  \
+                       Xm, pscal)
+    if (m.KT == 1) {
+        if (from_value) MPCA_SWEEP(1, true, 1);
+        else if (nm == 2) MPCA_SWEEP(1, false, 2);
+        else MPCA_SWEEP(1, false, 1);
+    } else {
+        if (from_value) MPCA_SWEEP(2, true, 1);
+        else if (nm == 2) MPCA_SWEEP(2, false, 2);
+        else MPCA_SWEEP(2, false, 1);
+    }
+#undef MPCA_SWEEP
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    if (inspect) return VMP_OK;
+    // tr<xx>, log|Cov|, status
+    hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal, (int)gs, (int64_t)3,
+                       (int64_t)2, state + L.off_scal + SC_TRXX, first ? 0 : 1);
+    hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal + 2, (int)gs, (int64_t)3,
+                       (int64_t)1, state + L.off_scal + SC_STATUS, 1);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    hipEvent_t *ev2 = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[0], s));
+    {
+        int64_t gw = gst_wg < nsub ? gst_wg : nsub;
+        if (gw < 1) gw = 1;
+        const dim3 grid((unsigned)(gw * ns));
+#define MPCA_CASE(db, kt)                                                                       \
+    if (m.DP == 32 * db && m.KT == kt)                                                          \
+        hipLaunchKernelGGL((mpca_stats_kernel<db, kt, (kt == 1 ? 5 : TSMAX)>), grid, dim3(NT), 0, s, \
+                           Ymt, Mb2, XXf, Xm, sub0, nsub, n0, ns, partial);                     \
+    else
+        MPCA_FOR_EACH(MPCA_CASE) { return VMP_ERR_UNSUPPORTED; }
+#undef MPCA_CASE
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[1], s));
+        const int64_t len = (int64_t)m.DP * m.LR;
+        hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((len + NT - 1) / NT)), dim3(NT), 0,
+                           s, partial, (int)gw, len, len, state + L.off_M, first ? 0 : 1);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[2], s));
+    }
+    return VMP_OK;
+}
+
+// Snapshot what X.update() reads of its Markov blanket (the panel of <ww>, <w> and <tau>): the
+// chunks of one pass must all see the same values, and X.u[1] is re-derived from it later.
+int32_t vmp_mpca_x_begin(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_plates, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    const mpca_dims m = make_dims(D, K);
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    const size_t pbytes = (size_t)m.CT * (m.DQ / 2) * 128 * sizeof(double);
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(state + L.off_panel_x, state + L.off_panel, pbytes,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(state + L.off_scal + SC_TAUX, state + L.off_tau + 2,
+                                      sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(mpca_set_scalar_kernel, dim3(1), dim3(1), 0, ctx->stream,
+                       state + L.off_scal + SC_N, (double)n_plates);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_mpca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int32_t mode, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && state, VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, mode >= 0 && mode <= 2, VMP_ERR_INVALID, "bad mode %d", mode);
+    const mpca_dims m = make_dims(D, K);
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    const dim3 grid((unsigned)((D + 3) / 4));
+    if (m.KT == 1)
+        hipLaunchKernelGGL(mpca_w_kernel<1>, grid, dim3(NT), 0, ctx->stream, L, D, K, m.DQ, mode, state);
+    else
+        hipLaunchKernelGGL(mpca_w_kernel<2>, grid, dim3(NT), 0, ctx->stream, L, D, K, m.DQ, mode, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_mpca_small_ops(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, double a0_tau,
+                           double b0_tau, double a0_alpha, double b0_alpha, int32_t nops,
+                           const int32_t *ops, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && state && ops, VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, nops >= 1 && nops <= 8, VMP_ERR_INVALID, "1..8 operations per call");
+    small_args A;
+    fill_layout(D, K, &A.L);
+    A.D = D;
+    A.K = K;
+    A.nops = nops;
+    for (int i = 0; i < nops; ++i) {
+        VMP_REQUIRE(ctx, ops[i] >= VMP_MPCA_OP_TAU && ops[i] <= VMP_MPCA_OP_ELBO, VMP_ERR_INVALID,
+                    "unknown operation %d", ops[i]);
+        A.ops[i] = ops[i];
+    }
+    A.x_prec = x_prec;
+    A.a0t = a0_tau;
+    A.b0t = b0_tau;
+    A.a0a = a0_alpha;
+    A.b0a = b0_alpha;
+    hipLaunchKernelGGL(mpca_small_kernel, dim3(1), dim3(NT), 0, ctx->stream, A, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_mpca_unpack_xx(vmp_ctx *ctx, int32_t D, int32_t K, int64_t nplates, const double *XXf,
+                           double *out)
+{
+    VMP_REQUIRE(ctx, ctx && XXf && out, VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    if (nplates <= 0) return VMP_OK;
+    const mpca_dims m = make_dims(D, K);
+    int64_t g = (nplates * K * K + NT - 1) / NT;
+    if (g > grid_cap(ctx, 8)) g = grid_cap(ctx, 8);
+    hipLaunchKernelGGL(mpca_unpack_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, XXf, m.PT, K,
+                       nplates, out);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+}  // extern "C"

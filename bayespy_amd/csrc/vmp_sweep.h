@@ -120,4 +120,20 @@ __device__ __forceinline__ void sweep_upto(v4f64 (&T)[2][2], int nblocks, int l1
     }
 }
 
+// Two independent matrices swept block by block in one instruction stream: the serial pivot
+// chain of one (v_readlane -> 4 x 4 Cholesky -> solve -> MFMA) fills the latency gaps of the other.
+template <int P>
+__device__ __forceinline__ void sweep_pair(v4f64 (&Ta)[2][2], v4f64 (&Tb)[2][2], int nblocks,
+                                           int l15, int l4, double &pa, double &la, int &ba,
+                                           double &pb, double &lb, int &bb)
+{
+    if constexpr (P < 8) {
+        if (P < nblocks) {
+            sweep_block<P>(Ta, l15, l4, pa, la, ba);
+            sweep_block<P>(Tb, l15, l4, pb, lb, bb);
+        }
+        sweep_pair<P + 1>(Ta, Tb, nblocks, l15, l4, pa, la, ba, pb, lb, bb);
+    }
+}
+
 }  // namespace vmp_sweep

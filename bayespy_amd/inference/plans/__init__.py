@@ -4,9 +4,10 @@ block and maps the reference's per-node operations (``update``,
 ``lower_bound_contribution``, ``get_moments``) onto HIP kernel launches.
 """
 from .pca import PCAPlan
+from .masked_pca import MaskedPCAPlan
 from .gmm import GMMPlan
 
-PLAN_TYPES = [PCAPlan, GMMPlan]
+PLAN_TYPES = [PCAPlan, MaskedPCAPlan, GMMPlan]
 
 
 def compile_model(nodes, engine=None, **options):

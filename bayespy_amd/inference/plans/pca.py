@@ -189,6 +189,14 @@ class PCAPlan:
 
     @staticmethod
     def match(nodes):
+        roles = PCAPlan.match_graph(nodes)
+        if roles is None or PCAPlan.unsupported_state(roles) is not None:
+            return None           # e.g. missing values, a fixed tau: other plans
+        return roles
+
+    @staticmethod
+    def match_graph(nodes):
+        """The graph pattern alone (shared with the missing-data block, plans/masked_pca.py)."""
         # mini-batch multipliers (stochastic VI) go through the generic engine
         if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
             return None
@@ -203,8 +211,6 @@ class PCAPlan:
                 continue
             if any(p != 1 for p in tau.plates) or len(Y.plates) != 2:
                 continue
-            if Y._mask is not True:
-                continue          # missing data: per-plate posteriors -> generic engine
             D, N = Y.plates
             A, B = F.parents
             if not (isinstance(A, GaussianARD) and isinstance(B, GaussianARD)):
@@ -230,10 +236,7 @@ class PCAPlan:
             if len(W.children) != 1 or len(X.children) != 1 or len(F.children) != 1 \
                     or len(tau.children) != 1 or len(alpha.children) != 1:
                 continue
-            roles = dict(Y=Y, F=F, W=W, X=X, tau=tau, alpha=alpha)
-            if PCAPlan.unsupported_state(roles) is not None:
-                continue          # e.g. a fixed tau: per-node state -> generic engine
-            return roles
+            return dict(Y=Y, F=F, W=W, X=X, tau=tau, alpha=alpha)
         return None
 
     # -- construction ------------------------------------------------------------------
@@ -291,11 +294,16 @@ class PCAPlan:
         self._ready = False
         self._version += 1
         if self.unsupported_state(self.roles) is not None:
-            # missing data (per-plate posteriors), an observed / specially initialised role:
-            # outside this fused block -> the model moves to the generic device
+            # missing data (per-plate posteriors): the fused missing-data block when it covers
+            # the sizes; an observed / specially initialised role: the generic device
             # message-passing engine (Node.shard declarations travel with the nodes)
-            from .generic import GenericPlan
-            GenericPlan(self.nodes())
+            from .masked_pca import MaskedPCAPlan
+            roles = MaskedPCAPlan.match(self.nodes())
+            if roles is not None and not getattr(self, 'generic_only', False):
+                MaskedPCAPlan(roles)
+            else:
+                from .generic import GenericPlan
+                GenericPlan(self.nodes())
 
     # -- device state --------------------------------------------------------------------
     def _materialize(self):

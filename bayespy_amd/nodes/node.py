@@ -131,6 +131,20 @@ def ensure_node(x):
     return Constant(x)
 
 
+class DeviceMask:
+    """An observation mask that already lives in HBM (a boolean tensor): kept in place for the
+    fused blocks; converts to a host array on demand (``np.asarray``) for everything else."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor.to(dtype=tensor.new_empty(0, dtype=bool).dtype)
+        self.shape = tuple(tensor.shape)
+        self.all_true = bool(self.tensor.all().item())
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.tensor.cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
 class Stochastic(Node):
     """Base of the exponential-family nodes (stochastic.py:83-376,
     expfamily.py:94-542)."""
@@ -148,10 +162,14 @@ class Stochastic(Node):
         """Fix the node to data.  ``x`` may be a host ndarray or a fp64 tensor
         already resident in HBM (then it is used in place)."""
         self._check_value_shape(x)
-        if mask is True or (np.ndim(mask) == 0 and bool(mask)):
+        if hasattr(mask, 'is_cuda') and mask.is_cuda:
+            mask = DeviceMask(mask)
+        if mask is True or (not isinstance(mask, DeviceMask) and np.ndim(mask) == 0
+                            and bool(mask)):
             mask = True
         else:
-            mask = np.asarray(mask, dtype=bool)
+            if not isinstance(mask, DeviceMask):
+                mask = np.asarray(mask, dtype=bool)
             try:
                 ok = broadcasted_shape(mask.shape, self.plates) == self.plates
             except ValueError:
@@ -161,6 +179,8 @@ class Stochastic(Node):
                                  % (mask.shape, self.plates))
         self._data = x
         self._mask = mask
+        self._fully_observed = (mask is True or (mask.all_true if isinstance(mask, DeviceMask)
+                                                 else bool(np.all(mask))))
         self.observed = True
         if self._plan is not None:
             self._plan.invalidate(self)
@@ -269,7 +289,7 @@ class Stochastic(Node):
         (stochastic.py:276-282).  Fully observed nodes are skipped like in the reference; the
         plates of a partially observed node that carry no data are updated (``if not
         np.all(self.observed)``)."""
-        if self.observed and (self._mask is True or bool(np.all(self._mask))):
+        if self.observed and getattr(self, '_fully_observed', True):
             return
         self._require_plan().update(self)
 

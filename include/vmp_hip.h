@@ -231,6 +231,82 @@ int32_t vmp_pca_lower_bound(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total,
                             double a0_alpha, double b0_alpha, double *state);
 
 
+/* ---- fused PCA block WITH MISSING VALUES ---------------------------------------------- *
+ *
+ * The model block of the fused PCA entry points above with Y.observe(y, mask=array)
+ * (bayespy/demos/pca.py:80-82; masks: node.py:457-526, stochastic.py:223-250).  Every plate
+ * n (and every row d) has its own K x K posterior; the reference materialises (1,N,K,K)
+ * second moments, contracts them with einsum (dot.py:355,403,581) and loops in Python over
+ * the plates for the Cholesky factorisations (utils/linalg.py:31-63).  Here X.update() runs
+ * chunk by chunk over the plates, three kernels per chunk on the fp64 matrix cores
+ * (bayespy_amd/csrc/vmp_mpca.hip), and only the statistics
+ *     M_d = sum_n m_dn <x x^T>_n  (packed lower triangle),   r_d = sum_n m_dn y_dn <x_n>
+ * survive a chunk (state[off_M]: what ranks all-reduce).  D <= 128, K <= 32.
+ * Array layouts (Ymt, the two bit layouts of the mask, Xm, the scratch of a chunk) are
+ * documented at the top of vmp_mpca.hip; vmp_mpca_sizes gives their sizes. */
+typedef struct vmp_mpca_layout {
+    int64_t DP, KP;      /* padded dims: DP in {32,64,128}, KP in {16,32}                        */
+    int64_t P, PT, LR;   /* packed triangle size KP(KP+1)/2, its 16-column tiles, row length
+                            LR = 16 (PT + KP/16) of [packed | K-vector] rows                      */
+    int64_t off_tau;     /* 8 : a, b, <tau>, <log tau>                                            */
+    int64_t off_alpha;   /* 4*KP : a, b, <alpha>, <log alpha>                                     */
+    int64_t off_scal;    /* 16: [0] sum m y^2 [1] sum m [2] sum_n tr<xx>_n [3] sum_n log|Cov_n|
+                            [4] plates N [5] status [6] <tau> of the last X pass [7] residual     */
+    int64_t off_L;       /* 8 : L_Y, L_X, L_W, L_tau, L_alpha, L_total                            */
+    int64_t off_W;       /* DP x KP      <w_d>                                                    */
+    int64_t off_WW;      /* DP x KP x KP <w_d w_d^T>                                              */
+    int64_t off_ldW;     /* DP           log|Cov_d|                                               */
+    int64_t off_M;       /* DP x LR      packed M_d | r_d                                         */
+    int64_t off_panel;   /* B operands of the precision GEMM (fragment order), current W          */
+    int64_t off_panel_x; /* ... as seen by the last X.update()                                    */
+    int64_t total;
+} vmp_mpca_layout;
+
+typedef struct vmp_mpca_sizes_t {
+    int64_t ymt_doubles;        /* tile-major m*y                                                 */
+    int64_t mask_words;         /* uint32 words of EACH of the two bit layouts of the mask        */
+    int64_t xm_doubles;         /* <x_n>, plate-major (32 ceil(N/32)) x KP                        */
+    int64_t lam_doubles;        /* scratch of one chunk: chunk x LR                               */
+    int64_t xxf_doubles;        /* scratch of one chunk: packed <xx>_n                            */
+    int64_t workspace_doubles;  /* per-workgroup partial statistics                               */
+} vmp_mpca_sizes_t;
+
+enum vmp_mpca_op { VMP_MPCA_OP_TAU = 1, VMP_MPCA_OP_ALPHA = 2, VMP_MPCA_OP_ELBO = 3 };
+
+int32_t vmp_mpca_get_layout(int32_t D, int32_t K, vmp_mpca_layout *out);
+int32_t vmp_mpca_sizes(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t chunk,
+                       vmp_mpca_sizes_t *out);
+int32_t vmp_mpca_init_state(vmp_ctx *ctx, int32_t D, int32_t K, double a0_tau, double b0_tau,
+                            double a0_alpha, double b0_alpha, double *state);
+/* Set-up after Y.observe(y, mask): Ymt <- m*y tile-major (values at masked entries are never
+ * read: NaN placeholders are fine), the two bit layouts of the mask, sum m y^2 and sum m into
+ * the state.  mask: uint8 (D, ldm) row-major, NULL = all observed. */
+int32_t vmp_mpca_prepare(vmp_ctx *ctx, const double *Y, int64_t ldy, const uint8_t *mask,
+                         int64_t ldm, int64_t N, int32_t D, int32_t K, double *Ymt,
+                         uint32_t *Mb1, uint32_t *Mb2, double *state, void *workspace);
+/* X.update() = vmp_mpca_x_begin (snapshot of <tau>, <w>, <ww> and the plate count, summed over
+ * ranks by the caller) + vmp_mpca_x_chunk over consecutive chunks of plates (n0 a multiple of
+ * 32; VMP_MPCA_FIRST on the first).  VMP_MPCA_FROM_VALUE: statistics of the <x_n> already in Xm
+ * (initialize_from_value, expfamily.py:193-204) instead of an update. */
+int32_t vmp_mpca_x_begin(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_plates, double *state);
+#define VMP_MPCA_FIRST      1   /* first chunk of a pass: statistics are overwritten, not added to */
+#define VMP_MPCA_FROM_VALUE 2   /* delta moments of the <x_n> in Xm instead of an update           */
+#define VMP_MPCA_PRIOR      4   /* prior moments: <x_n> = 0, <xx>_n = I / x_prec                   */
+#define VMP_MPCA_INSPECT    8   /* recompute <x_n>, <xx>_n of the chunk only (no statistics)       */
+int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t nplates,
+                         int32_t flags, double x_prec, const double *Ymt,
+                         const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam,
+                         double *XXf, double *state, void *workspace);
+/* W.update() (mode 0); mode 1: delta moments of the <w_d> in state[off_W]; mode 2: prior. */
+int32_t vmp_mpca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int32_t mode, double *state);
+/* tau.update(), alpha.update(), the lower bound terms: a list of vmp_mpca_op, one launch. */
+int32_t vmp_mpca_small_ops(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, double a0_tau,
+                           double b0_tau, double a0_alpha, double b0_alpha, int32_t nops,
+                           const int32_t *ops, double *state);
+/* <x x^T>_n of the first nplates plates of the chunk scratch, unpacked to (nplates, K, K). */
+int32_t vmp_mpca_unpack_xx(vmp_ctx *ctx, int32_t D, int32_t K, int64_t nplates,
+                           const double *XXf, double *out);
+
 /* ---- fused full-covariance Gaussian-mixture block -------------------------- *
  *
  * Model block  Y = Mixture(z, Gaussian, mu, Lambda), z = Categorical(alpha),

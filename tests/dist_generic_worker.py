@@ -48,6 +48,22 @@ def main():
         res['alpha_u0'] = np.asarray(alpha.u[0])
         res['X_u0'] = np.asarray(X.u[0])
         res['lo'], res['hi'] = lo, hi
+    elif case == 'masked_pca_fused':
+        # the fused missing-data block with the plate split over the ranks: M_d, r_d and the
+        # scalar sums are all-reduced after every X pass
+        from models import build_masked_pca
+        g = np.load(os.path.join(golden, 'masked_pca.npz'))
+        y, mask, x0 = g['in_m2_y'], g['in_m2_mask'], g['in_m2_x0']
+        N = y.shape[1]
+        lo, hi = N * rank // world, N * (rank + 1) // world
+        Q = build_masked_pca(nodes, VB, y[:, lo:hi], mask[:, lo:hi], x0[lo:hi], shard=True)
+        assert type(Q.plans[0]).__name__ == 'MaskedPCAPlan'
+        Q.update(repeat=len(g['m2_L']), verbose=False)
+        res['L'] = np.array(Q.L[:Q.iter])
+        res['W_u0'] = np.asarray(Q['W'].u[0])
+        res['X_u0'] = np.asarray(Q['X'].u[0])
+        res['tau_u'] = np.array([np.asarray(u) for u in Q['tau'].u], dtype=np.float64)
+        res['lo'], res['hi'] = lo, hi
     elif case == 'rotation':
         g = np.load(os.path.join(golden, 'rotations.npz'))
         y, mask, x0 = g['rotm_y'], g['rotm_mask'], g['rotm_x0']

@@ -76,8 +76,8 @@ def test_masked_pca_matches_reference(golden_dir):
     tau = Gamma(1e-2, 1e-2, name='tau')
     Y = GaussianARD(F, tau, name='Y')
     X.initialize_from_value(x0[None])
-    Q = VB(Y, F, W, X, tau, alpha)
-    Y.observe(y, mask=mask)          # after VB: the fused block hands over to the generic engine
+    Y.observe(y, mask=mask)
+    Q = VB(Y, F, W, X, tau, alpha, engine='generic')
     assert isinstance(Q.plans[0], GenericPlan)
     L = _trace(Q, 4)
     np.testing.assert_allclose(L, g['mpca_L'], rtol=ELBO_RTOL)
@@ -201,7 +201,7 @@ def test_rotation_parameter_expansion_matches_reference(golden_dir, case):
     tag = 'rotm' if case == 'masked' else 'rot'
     y, x0 = g[tag + '_y'], g[tag + '_x0']
     K = x0.shape[1]
-    Q = build_pca(nodes, VB, y, x0, K, engine='generic' if case == 'generic' else None)
+    Q = build_pca(nodes, VB, y, x0, K, engine=None if case == 'fused' else 'generic')
     if case == 'masked':
         Q['Y'].observe(y, mask=g[tag + '_mask'])
     assert isinstance(Q.plans[0], PCAPlan if case == 'fused' else GenericPlan)

@@ -46,3 +46,140 @@ def test_generic_engine_masked_pca_with_nan_placeholders(golden_dir):
     np.testing.assert_allclose(res['po_L'], g['po_L'], rtol=ELBO_RTOL)
     for key in ('po_z_u0', 'po_z_u1', 'po_mu_u', 'po_tau_u'):
         np.testing.assert_allclose(res[key], g[key], rtol=1e-8, err_msg=key)
+
+
+def test_fused_block_matches_reference(golden_dir):
+    """The fused missing-data block (vmp_mpca_*) on the live-reference traces: four sizes incl.
+    D=128, K=32, ragged K=17, a plate without observations, NaN at the missing entries."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.masked_pca import MaskedPCAPlan
+    from models import build_masked_pca, run_masked_pca_cases
+    g, inp = _inputs(golden_dir)
+    Q = build_masked_pca(nodes, VB, inp['m1_y'], inp['m1_mask'], inp['m1_x0'])
+    assert isinstance(Q.plans[0], MaskedPCAPlan)
+    res = run_masked_pca_cases(nodes, VB, inp, only=('m0', 'm1', 'm2', 'm3'))
+    # q of Y's latent entries: the fused block evaluates it when read (current W, X), the
+    # reference as of Y's last update -- compared separately below
+    for k in list(res):
+        if k.endswith('_Y_u0') or k.endswith('_Y_u1'):
+            del res[k]
+    g2 = {k: g[k] for k in g.files if not (k.endswith('_Y_u0') or k.endswith('_Y_u1'))}
+
+    class G(dict):
+        files = list(g2)
+    _check(res, G(g2), ('m0', 'm1', 'm2', 'm3'))
+
+
+@pytest.mark.parametrize('N,D,K,keep', [(1, 1, 1, 1.0), (33, 5, 2, 0.7), (100, 20, 16, 0.5),
+                                        (77, 33, 17, 0.8), (1000, 128, 32, 0.9),
+                                        (5000, 64, 16, 0.9), (4099, 100, 9, 0.3)])
+def test_fused_block_vs_oracle_ragged_sizes(N, D, K, keep):
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_masked_pca
+    from oracle.masked_pca import MaskedPCAOracle
+    rs = np.random.RandomState(N + D + K)
+    y = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+    mask = rs.rand(D, N) < keep
+    y = np.where(mask, y, np.nan)
+    x0 = rs.normal(size=(N, K))
+    Q = build_masked_pca(nodes, VB, y, mask, x0)
+    assert type(Q.plans[0]).__name__ == 'MaskedPCAPlan'
+    iters = 3
+    Q.update(repeat=iters, verbose=False)
+    o = MaskedPCAOracle(y, mask, x0)
+    o.iterate(iters)
+    np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=ELBO_RTOL)
+    for nm in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[nm]][:iters], [t[nm] for t in o.L_terms], rtol=1e-8,
+                                   atol=1e-7, err_msg=nm)
+    W, X = Q['W'], Q['X']
+    np.testing.assert_allclose(W.u[0][:, 0], o.W, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(W.u[1][:, 0], o.WW, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(X.u[0][0], o.X, rtol=1e-7, atol=1e-10)
+    # second moments of X: re-derived per plate on request
+    xx = Q.plans[0].x_second_moments(0, min(N, 50)).cpu().numpy()
+    tau_x = float(Q.plans[0].state[Q.plans[0].layout.off_scal + 6].item())
+    WWf = o.WW.reshape(D, K * K)
+    lam = np.eye(K)[None] + tau_x * (mask[:, :min(N, 50)].T.astype(float) @ WWf).reshape(-1, K, K)
+    cov = np.linalg.inv(lam)
+    np.testing.assert_allclose(xx, cov + o.X[:min(N, 50), :, None] * o.X[:min(N, 50), None, :],
+                               rtol=1e-7, atol=1e-10)
+
+
+def test_fused_block_chunking_and_device_inputs():
+    """Several chunks per pass == one chunk (up to summation order); data and mask may already be
+    device tensors (NaN at the missing entries)."""
+    import torch
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.device import get_runtime
+    from models import build_masked_pca
+    rs = np.random.RandomState(3)
+    D, N, K = 24, 1000, 6
+    y = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+    mask = rs.rand(D, N) < 0.85
+    y = np.where(mask, y, np.nan)
+    x0 = rs.normal(size=(N, K))
+    Ls = []
+    for chunk, dev in ((1 << 20, False), (96, False), (160, True)):
+        os.environ['BAYESPY_AMD_MPCA_CHUNK'] = str(chunk)
+        try:
+            if dev:
+                d = get_runtime().device
+                Q = build_masked_pca(nodes, VB, torch.from_numpy(y).to(d),
+                                     torch.from_numpy(mask).to(d), x0)
+            else:
+                Q = build_masked_pca(nodes, VB, y, mask, x0)
+            Q.update(repeat=3, verbose=False)
+        finally:
+            del os.environ['BAYESPY_AMD_MPCA_CHUNK']
+        Ls.append((Q.L[:3].copy(), Q['W'].u[0].copy(), Q['X'].u[0].copy()))
+    for L, w, x in Ls[1:]:
+        np.testing.assert_allclose(L, Ls[0][0], rtol=1e-12)
+        np.testing.assert_allclose(w, Ls[0][1], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(x, Ls[0][2], rtol=1e-10, atol=1e-13)
+
+
+def test_fused_block_predictive_moments_of_missing_entries(golden_dir):
+    """Y.u at the missing entries after an explicit Y.update(): <f>, <f^2> + 1/<tau> from the
+    current W, X, tau -- the reference's value when Y is updated last."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_masked_pca
+    from oracle.masked_pca import MaskedPCAOracle
+    g, inp = _inputs(golden_dir)
+    y, mask, x0 = inp['m1_y'], inp['m1_mask'], inp['m1_x0']
+    Q = build_masked_pca(nodes, VB, y, mask, x0)
+    Q.update(repeat=3, verbose=False)
+    Q['Y'].update()
+    u0, u1 = Q['Y'].u
+    o = MaskedPCAOracle(y, mask, x0)
+    o.iterate(3)
+    f, tau = o.predictive_Y()
+    np.testing.assert_allclose(u0[~mask], f[~mask], rtol=1e-7, atol=1e-10)
+    np.testing.assert_array_equal(u0[mask], y[mask])
+    assert np.all(np.isfinite(u1)) and np.all(u1[~mask] > f[~mask] ** 2)
+
+
+def test_fused_block_direct_oracle_parity_n2e5():
+    """D=128, K=32 (the headline dims), N=2e5, 10 % missing: three iterations against the
+    chunked oracle on the same data."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_masked_pca
+    from oracle.masked_pca import MaskedPCAOracle
+    rs = np.random.RandomState(42)
+    D, N, K = 128, 200_000, 32
+    y = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+    mask = rs.rand(D, N) < 0.9
+    x0 = rs.normal(size=(N, K))
+    Q = build_masked_pca(nodes, VB, y, mask, x0)
+    Q.update(repeat=3, verbose=False)
+    o = MaskedPCAOracle(y, mask, x0, chunk=1 << 13)
+    o.iterate(3)
+    np.testing.assert_allclose(Q.L[:3], np.array(o.L), rtol=ELBO_RTOL)
+    np.testing.assert_allclose(Q['W'].u[0][:, 0], o.W, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(Q.plans[0].Xm[:N:97, :K].cpu().numpy(), o.X[::97], rtol=1e-7,
+                               atol=1e-10)

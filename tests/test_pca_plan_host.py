@@ -153,9 +153,13 @@ def test_plan_selection_and_loud_failures():
     Y = nodes.GaussianARD(nodes.Dot(W, X), nodes.Gamma(1e-2, 1e-2))
     Q2 = VB(Y, W, X)
     assert isinstance(Q2.plans[0], PCAPlan)
-    # ... and moves to the generic engine as soon as data are missing (array mask)
+    # ... and moves to the fused missing-data block as soon as data are missing (array mask)
+    from bayespy_amd.inference.plans.masked_pca import MaskedPCAPlan
     Y.observe(np.zeros((D, N)), mask=np.ones((D, N), dtype=bool))
-    assert isinstance(Q2.plans[0], GenericPlan)
+    assert isinstance(Q2.plans[0], MaskedPCAPlan)
+    Y.observe(np.zeros((D, N)))                        # the mask is gone again
+    assert isinstance(Q2.plans[0], PCAPlan)
+    Y.observe(np.zeros((D, N)), mask=np.ones((D, N), dtype=bool))
     assert VB(Y, W, X, engine='generic') is not None
 
     # the fused block starts tau / alpha from their priors and updates every role: a fixed

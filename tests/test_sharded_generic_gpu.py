@@ -48,6 +48,18 @@ def test_sharded_masked_pca_matches_reference(golden_dir, tmp_path):
     assert np.array_equal(r0['W_u0'], r1['W_u0']) and np.array_equal(r0['L'], r1['L'])
 
 
+def test_sharded_fused_masked_pca_matches_reference(golden_dir, tmp_path):
+    r0, r1 = _launch('masked_pca_fused', golden_dir, tmp_path, 29548)
+    g = np.load(os.path.join(golden_dir, 'masked_pca.npz'))
+    for r in (r0, r1):
+        np.testing.assert_allclose(r['L'], g['m2_L'], rtol=1e-9)
+        np.testing.assert_allclose(r['W_u0'], g['m2_W_u0'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r['tau_u'], g['m2_tau_u'], rtol=1e-8)
+        np.testing.assert_allclose(r['X_u0'], g['m2_X_u0'][:, int(r['lo']):int(r['hi'])],
+                                   rtol=1e-7, atol=1e-10)
+    assert np.array_equal(r0['W_u0'], r1['W_u0']) and np.array_equal(r0['L'], r1['L'])
+
+
 def test_sharded_rotation_matches_reference(golden_dir, tmp_path):
     r0, r1 = _launch('rotation', golden_dir, tmp_path, 29542)
     g = np.load(os.path.join(golden_dir, 'rotations.npz'))
