@@ -27,7 +27,9 @@
 //                            packed <w w^T>_d, then KT tiles of <w_d>; element (d, col) at
 //                            ((c*(DQ/2) + (d/8))*64 + (d%4)*16 + col%16)*2 + (d/4)%2
 //   Lam  [n][LR]             scratch of a chunk, LR = 16 (PT + KT): packed Lam~_n | rhs~_n
-//   XXf  [n/4][PT][4][16]    scratch of a chunk: packed <x x^T>_n in the B-operand order of mpca_stats
+//   XXf  [n/8][PT][64][2]    scratch of a chunk: packed <x x^T>_n in the B-operand order of mpca_stats,
+//                            two k-steps per 16 bytes: element (n, p) at
+//                            (((n/8)*PT + p/16)*64 + (n%4)*16 + p%16)*2 + (n/4)%2
 //   Mst  [DP][LR]            packed M_d | r_d  (what ranks all-reduce)
 #include "vmp_sweep.h"
 
@@ -82,6 +84,7 @@ inline void fill_layout(int D, int K, vmp_mpca_layout *L)
     L->off_M = o;        o += (int64_t)m.DP * m.LR;
     L->off_panel = o;    o += (int64_t)m.CT * (m.DQ / 2) * 128;
     L->off_panel_x = o;  o += (int64_t)m.CT * (m.DQ / 2) * 128;
+    L->off_Sxx = o;      o += (int64_t)m.KP * m.KP;
     L->total = (o + 7) / 8 * 8;
 }
 
@@ -330,10 +333,15 @@ template <int KT>
 __device__ __forceinline__ void store_plate(const v4f64 (&T)[2][2], const plate_result &res,
                                             int64_t n_chunk, int64_t n_glob, int K,
                                             double *__restrict__ XXf, double *__restrict__ Xm,
-                                            int l15, int l4, double &trl)
+                                            int l15, int l4, double &trl, v4f64 (&SA)[2][2])
 {
+    // sum over the plates of <x x^T>_n (RotateGaussianARD needs it, transformations.py:476-640)
+#pragma unroll
+    for (int tr = 0; tr < KT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < KT; ++tc) SA[tr][tc] += T[tr][tc];
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
-    double *xb = XXf + ((n_chunk >> 2) * PT) * 64 + (n_chunk & 3) * 16;
+    double *xb = XXf + (((n_chunk >> 3) * PT) * 64 + (n_chunk & 3) * 16) * 2 + ((n_chunk >> 2) & 1);
 #pragma unroll
     for (int tr = 0; tr < KT; ++tr)
 #pragma unroll
@@ -344,28 +352,33 @@ __device__ __forceinline__ void store_plate(const v4f64 (&T)[2][2], const plate_
                 if (i >= j) {
                     const int p = tri(i, j);
                     const double v = (i < K && j < K) ? T[tr][tc][r] : 0.0;
-                    xb[(p >> 4) * 64 + (p & 15)] = v;
+                    xb[((p >> 4) * 64 + (p & 15)) * 2] = v;
                     if (i == j) trl += v;
                 }
             }
-    if (l4 == 0) {
+    if (l4 == 0 && Xm) {
         double *xr = Xm + n_glob * KP;
         xr[l15] = (l15 < K) ? res.x0 : 0.0;
         if (KT > 1) xr[16 + l15] = (16 + l15 < K) ? res.x1 : 0.0;
     }
 }
 
-// NM = plates in flight per wavefront: 1 (<= 256 registers: two wavefronts per SIMD hide the serial
-// pivot chains of each other) or 2 (one wavefront per SIMD, the two sweeps interleaved in one
-// instruction stream).
-template <int KT, bool FROM_VALUE, int NM>
-__global__ void __launch_bounds__(NT, (NM == 2 && !FROM_VALUE) ? 1 : 2)
+// NM = plates in flight per wavefront (their sweeps interleaved in one instruction stream: the
+// serial pivot chain of one fills the latency gaps of the others), OCC = wavefronts per SIMD the
+// register allocation is held to.
+template <int KT, bool FROM_VALUE, int NM, int OCC>
+__global__ void __launch_bounds__(NT, OCC)
 mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t nplates_chunk, int K,
                   double x_prec, double xx_diag, const double *__restrict__ tau_ptr,
-                  double *__restrict__ XXf, double *__restrict__ Xm, double *__restrict__ partial)
+                  double *__restrict__ XXf, double *__restrict__ Xm, int write_x,
+                  double *__restrict__ partial, double *__restrict__ partial_sxx)
 {
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
     __shared__ double red[NT / 64];
+    __shared__ double sxs[4 * KP * KP];
+    v4f64 SA[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}},
+                      {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+    double *Xw = write_x ? Xm : nullptr;
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = l & 15, l4 = l >> 4;
     const double tau = FROM_VALUE ? 0.0 : tau_ptr[0];
@@ -397,40 +410,33 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
             res.x1 = xb;
             res.logdet = 0.0;
             res.bad = 0;
-            store_plate<KT>(T, res, n, n0 + n, K, XXf, Xm, l15, l4, trl);
-        }
-    } else if (NM == 1) {
-        for (int64_t n = (int64_t)blockIdx.x * 4 + w; n < nplates_chunk; n += nwaves) {
-            const double *ra = Lam + n * LR;
-            v4f64 Ta[2][2];
-            load_sym_tiles<KT>(Ta, ra, K, x_prec, tau, l15, l4);
-            double pa = 1.0, la = 0.0;
-            int ba = 0;
-            sweep_upto<0>(Ta, nblocks, l15, l4, pa, la, ba);
-            const plate_result A = finish_plate(Ta, ra + 16 * PT, tau, K, l15, l4, pa, la, ba);
-            store_plate<KT>(Ta, A, n, n0 + n, K, XXf, Xm, l15, l4, trl);
-            ldsum -= A.logdet;
-            anybad |= A.bad;
+            store_plate<KT>(T, res, n, n0 + n, K, XXf, Xw, l15, l4, trl, SA);
         }
     } else {
-        for (int64_t n = ((int64_t)blockIdx.x * 4 + w) * 2; n < nplates_chunk; n += nwaves * 2) {
-            const bool two = (n + 1) < nplates_chunk;
-            const double *ra = Lam + n * LR, *rb = Lam + (two ? n + 1 : n) * LR;
-            v4f64 Ta[2][2], Tb[2][2];
-            load_sym_tiles<KT>(Ta, ra, K, x_prec, tau, l15, l4);
-            load_sym_tiles<KT>(Tb, rb, K, x_prec, tau, l15, l4);
-            double pa = 1.0, la = 0.0, pbb = 1.0, lb = 0.0;
-            int ba = 0, bb = 0;
-            sweep_pair<0>(Ta, Tb, nblocks, l15, l4, pa, la, ba, pbb, lb, bb);
-            const plate_result A = finish_plate(Ta, ra + 16 * PT, tau, K, l15, l4, pa, la, ba);
-            const plate_result B = finish_plate(Tb, rb + 16 * PT, tau, K, l15, l4, pbb, lb, bb);
-            store_plate<KT>(Ta, A, n, n0 + n, K, XXf, Xm, l15, l4, trl);
-            ldsum -= A.logdet;
-            anybad |= A.bad;
-            if (two) {
-                store_plate<KT>(Tb, B, n + 1, n0 + n + 1, K, XXf, Xm, l15, l4, trl);
-                ldsum -= B.logdet;
-                anybad |= B.bad;
+        for (int64_t n = ((int64_t)blockIdx.x * 4 + w) * NM; n < nplates_chunk; n += nwaves * NM) {
+            v4f64 T[NM][2][2];
+            const double *rows[NM];
+            double pr[NM], lg[NM];
+            int bd[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int64_t nn = (n + m < nplates_chunk) ? n + m : n;     // tail: redo plate n
+                rows[m] = Lam + nn * LR;
+                load_sym_tiles<KT>(T[m], rows[m], K, x_prec, tau, l15, l4);
+                pr[m] = 1.0;
+                lg[m] = 0.0;
+                bd[m] = 0;
+            }
+            sweep_multi<0, NM>(T, nblocks, l15, l4, pr, lg, bd);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const plate_result A = finish_plate(T[m], rows[m] + 16 * PT, tau, K, l15, l4,
+                                                    pr[m], lg[m], bd[m]);
+                if (n + m < nplates_chunk) {
+                    store_plate<KT>(T[m], A, n + m, n0 + n + m, K, XXf, Xw, l15, l4, trl, SA);
+                    ldsum -= A.logdet;
+                    anybad |= A.bad;
+                }
             }
         }
     }
@@ -443,6 +449,20 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
         partial[3 * blockIdx.x + 1] = ldw;
         partial[3 * blockIdx.x + 2] = bd;
     }
+    // sum_n <xx>_n of this workgroup: the four wavefronts through LDS, fixed order
+#pragma unroll
+    for (int tr = 0; tr < KT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < KT; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                sxs[w * KP * KP + i * KP + j] = (i < K && j < K) ? SA[tr][tc][r] : 0.0;
+            }
+    __syncthreads();
+    for (int e = threadIdx.x; e < KP * KP; e += NT)
+        partial_sxx[(int64_t)blockIdx.x * KP * KP + e] =
+            (sxs[e] + sxs[KP * KP + e]) + (sxs[2 * KP * KP + e] + sxs[3 * KP * KP + e]);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -477,7 +497,7 @@ mpca_stats_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ M
         // Ymt element (d = 16 dt + l15, n = 16 sub + 4 qq + l4)
         const double *ybase = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l15 * TN
                               + (sub & 1) * 16 + l4;
-        const double *xxb = XXf + (sc * 4) * ((int64_t)PT * 64) + l;
+        const double *xxb = XXf + ((sc * 2) * ((int64_t)PT * 64) + l) * 2;
         const double *xmb = Xm + (n0 + sc * 16 + l4) * KP + l15;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -485,7 +505,7 @@ mpca_stats_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ M
 #pragma unroll
             for (int t = 0; t < TS; ++t) {
                 const int c = c0 + t;
-                bfr[t] = (c < PT) ? xxb[((int64_t)qq * PT + c) * 64]
+                bfr[t] = (c < PT) ? xxb[(((int64_t)(qq >> 1) * PT + c) * 64) * 2 + (qq & 1)]
                                   : (c < CT ? xmb[(int64_t)(4 * qq) * KP + 16 * (c - PT)] : 0.0);
             }
             if (active) {
@@ -524,6 +544,144 @@ mpca_stats_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ M
                     }
                 }
             }
+        }
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// mpca_stats, second form: M_d only (the packed columns), wavefronts split the COLUMN tiles.
+// Wavefront w owns NCW column tiles of its workgroup's slice and ALL row tiles dt: its B operands
+// (two k-steps per 16-byte load, XXf order) are loaded by no other wavefront, the A operand is the
+// mask bit of (d, n) -- no loads at all.  r_d comes from mpca_ryx_kernel.
+// -------------------------------------------------------------------------------------------
+template <int DB, int KT, int NCW>
+__global__ void __launch_bounds__(NT, NCW >= 3 ? 1 : 2)
+mpca_stats2_kernel(const uint32_t *__restrict__ Mb2, const double *__restrict__ XXf, int64_t sub0,
+                   int64_t nsub_chunk, int nslices, double *__restrict__ partial)
+{
+    constexpr int DP = 32 * DB, DT = DP / 16;
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
+    constexpr int LR = 16 * CT;
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = l & 15, l4 = l >> 4;
+    const int slice = blockIdx.x % nslices, wg = blockIdx.x / nslices, nwg = gridDim.x / nslices;
+    const int c0 = (slice * 4 + w) * NCW;           // first column tile of this wavefront
+    v4f64 acc[DT][NCW];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int t = 0; t < NCW; ++t) acc[i][t] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int64_t npair = (nsub_chunk + 1) / 2;     // 32 plates: 8 k-steps, 4 pair-loads per column
+    v2f64 bcur[NCW][4], bnxt[NCW][4];
+    auto issue = [&](int64_t pr, v2f64 (&b)[NCW][4]) {
+        // plates 32 pr .. 32 pr + 31 of the chunk: n/8 = 4 pr + j
+        const double *base = XXf + ((pr * 4) * ((int64_t)PT * 64) + l) * 2;
+#pragma unroll
+        for (int t = 0; t < NCW; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[t][j] = (c0 + t < PT) ? *reinterpret_cast<const v2f64 *>(
+                                              base + (((int64_t)j * PT + c0 + t) * 64) * 2)
+                                        : v2f64{0.0, 0.0};
+    };
+    int64_t pr = wg;
+    if (pr < npair) issue(pr, bcur);
+    for (; pr < npair; pr += nwg) {
+        const int64_t s0 = sub0 + 2 * pr;
+        const uint32_t mw0 = Mb2[s0 * 64 + l];
+        const uint32_t mw1 = (2 * pr + 1 < nsub_chunk) ? Mb2[(s0 + 1) * 64 + l] : 0u;
+        if (pr + nwg < npair) issue(pr + nwg, bnxt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int qq = (2 * j + e) & 3;                     // k-step inside its subtile
+                const uint32_t mw = (j < 2) ? mw0 : mw1;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    const double am = (double)((mw >> (4 * i + qq)) & 1u);
+#pragma unroll
+                    for (int t = 0; t < NCW; ++t)
+                        acc[i][t] = mfma(am, e ? bcur[t][j].y : bcur[t][j].x, acc[i][t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NCW; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bcur[t][j] = bnxt[t][j];
+    }
+    double *pb = partial + (int64_t)wg * DP * LR;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int t = 0; t < NCW; ++t) {
+            const int c = c0 + t;
+            if (c < PT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pb[(int64_t)(16 * i + l4 + 4 * r) * LR + 16 * c + l15] = acc[i][t][r];
+            }
+        }
+}
+
+// r_d = sum_n (m y)_dn <x_n>: the message product of the fully observed block on the masked data
+// (zero where missing).  One 32-plate tile of Ymt (contiguous) and of Xm per trip through LDS,
+// S += Ymt_tile . Xm_tile on the matrix cores (contraction over the plates).
+template <int DB, int KT>
+__global__ void __launch_bounds__(NT, 2)
+mpca_ryx_kernel(const double *__restrict__ Ymt, const double *__restrict__ Xm, int64_t tile0,
+                int64_t ntiles_chunk, double *__restrict__ partial, int LR, int col0)
+{
+    constexpr int DP = 32 * DB, DT = DP / 16, KP = 16 * KT;
+    constexpr int SY = TN + 2;                        // LDS row strides (doubles)
+    __shared__ double Ys[DP * SY];
+    __shared__ double Xs[KP * SY];
+    const int tid = threadIdx.x;
+    const int l = tid & 63, w = tid >> 6, l15 = l & 15, l4 = l >> 4;
+    constexpr int T2 = DT * KT, R2 = (T2 + 3) / 4;
+    v4f64 acc[R2];
+#pragma unroll
+    for (int m = 0; m < R2; ++m) acc[m] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int64_t tile = blockIdx.x; tile < ntiles_chunk; tile += gridDim.x) {
+        const double *yt = Ymt + (tile0 + tile) * ((int64_t)DP * TN);
+        __syncthreads();
+        for (int e = tid; e < DP * TN / 2; e += NT) {
+            const int d = e / (TN / 2), j2 = (e - d * (TN / 2)) * 2;
+            *reinterpret_cast<v2f64 *>(&Ys[d * SY + j2]) =
+                *reinterpret_cast<const v2f64 *>(yt + d * TN + j2);
+        }
+        const double *xt = Xm + (tile0 + tile) * ((int64_t)TN * KP);
+        for (int e = tid; e < TN * KP; e += NT) {
+            const int n = e / KP, k = e - n * KP;
+            Xs[k * SY + n] = xt[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < TN / 4; ++q) {
+#pragma unroll
+            for (int m = 0; m < R2; ++m) {
+                const int t2 = w + 4 * m;
+                if (t2 < T2) {
+                    const int dt = t2 / KT, kt = t2 - dt * KT;
+                    // A[i = d][k = n]: lane (l15, l4);  B[k = n][j = kcol]: lane (l4, l15)
+                    const double a = Ys[(16 * dt + l15) * SY + 4 * q + l4];
+                    const double b = Xs[(16 * kt + l15) * SY + 4 * q + l4];
+                    acc[m] = mfma(a, b, acc[m]);
+                }
+            }
+        }
+    }
+    double *pb = partial + (int64_t)blockIdx.x * DP * LR;
+#pragma unroll
+    for (int m = 0; m < R2; ++m) {
+        const int t2 = w + 4 * m;
+        if (t2 < T2) {
+            const int dt = t2 / KT, kt = t2 - dt * KT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pb[(int64_t)(16 * dt + l4 + 4 * r) * LR + col0 + 16 * kt + l15] = acc[m][r];
         }
     }
 }
@@ -751,7 +909,7 @@ mpca_unpack_kernel(const double *__restrict__ XXf, int PT, int K, int64_t nplate
         const int64_t n = e / (K * K);
         const int ij = (int)(e - n * K * K), i = ij / K, j = ij - i * K;
         const int a = i > j ? i : j, b = i > j ? j : i, p = tri(a, b);
-        out[e] = XXf[((n >> 2) * PT + (p >> 4)) * 64 + (n & 3) * 16 + (p & 15)];
+        out[e] = XXf[(((n >> 3) * PT + (p >> 4)) * 64 + (n & 3) * 16 + (p & 15)) * 2 + ((n >> 2) & 1)];
     }
 }
 
@@ -800,12 +958,13 @@ int32_t vmp_mpca_sizes(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t ch
     out->mask_words = (ntiles > 0 ? ntiles : 1) * 2 * 64;
     out->xm_doubles = (ntiles > 0 ? ntiles : 1) * TN * m.KP;
     out->lam_doubles = chunk * m.LR;
-    out->xxf_doubles = (chunk / 4) * m.PT * 64;
+    out->xxf_doubles = ((chunk + 7) / 8) * m.PT * 128;
     // partial sums: mpca_stats (workgroups x DP x LR), sweep / prepare scalars
     const int64_t gst = grid_cap(ctx, 2) / stats_slices(m);
     int64_t p = gst * m.DP * m.LR;
     const int64_t p2 = grid_cap(ctx, 16) * 4;
-    out->workspace_doubles = p + p2 + 64;
+    const int64_t p3 = grid_cap(ctx, 8) * m.KP * m.KP;     // sum_n <xx>_n per sweep workgroup
+    out->workspace_doubles = p + p2 + p3 + 64;
     return VMP_OK;
 }
 
@@ -878,6 +1037,7 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
     const int ns = stats_slices(m);
     const int64_t gst_wg = grid_cap(ctx, 2) / ns;
     double *pscal = partial + gst_wg * m.DP * m.LR;
+    double *psxx = pscal + grid_cap(ctx, 16) * 4;
     hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
     if (!from_value) {
@@ -894,24 +1054,30 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
         VMP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
-    const int nm = vmp_tune_get("mpca_sweep_pair", 0) ? 2 : 1;
+    int nm = vmp_tune_get("mpca_sweep_nm", 2), occ = vmp_tune_get("mpca_sweep_occ", 2);
+    if (m.KT == 1 || from_value) { nm = 1; occ = 2; }
     int64_t gs = (nplates + 4 * nm - 1) / (4 * nm);
-    const int64_t gs_cap = grid_cap(ctx, nm == 2 ? 4 : 8);
+    const int64_t gs_cap = grid_cap(ctx, 8);
     if (gs > gs_cap) gs = gs_cap;
     if (gs < 1) gs = 1;
-#define MPCA_SWEEP(kt, fv, nmm)                                                                    \
-    hipLaunchKernelGGL((mpca_sweep_kernel<kt, fv, nmm>), dim3((unsigned)gs), dim3(NT), 0, s, Lam, \
-                       m.LR, n0, nplates, K, x_prec, xx_diag, state + L.off_scal + SC_TAUX, XXf,  \
-                       Xm, pscal)
+#define MPCA_SWEEP(kt, fv, nmm, oc)                                                                \
+    hipLaunchKernelGGL((mpca_sweep_kernel<kt, fv, nmm, oc>), dim3((unsigned)gs), dim3(NT), 0, s,   \
+                       Lam, m.LR, n0, nplates, K, x_prec, xx_diag, state + L.off_scal + SC_TAUX,   \
+                       XXf, Xm, inspect ? 0 : 1, pscal, psxx)
     if (m.KT == 1) {
-        if (from_value) MPCA_SWEEP(1, true, 1);
-        else if (nm == 2) MPCA_SWEEP(1, false, 2);
-        else MPCA_SWEEP(1, false, 1);
-    } else {
-        if (from_value) MPCA_SWEEP(2, true, 1);
-        else if (nm == 2) MPCA_SWEEP(2, false, 2);
-        else MPCA_SWEEP(2, false, 1);
-    }
+        if (from_value) MPCA_SWEEP(1, true, 1, 2);
+        else MPCA_SWEEP(1, false, 1, 2);
+    } else if (from_value) {
+        MPCA_SWEEP(2, true, 1, 2);
+    } else if (nm == 1 && occ == 2) MPCA_SWEEP(2, false, 1, 2);
+    else if (nm == 1 && occ == 3) MPCA_SWEEP(2, false, 1, 3);
+    else if (nm == 1 && occ == 4) MPCA_SWEEP(2, false, 1, 4);
+    else if (nm == 2 && occ == 1) MPCA_SWEEP(2, false, 2, 1);
+    else if (nm == 2 && occ == 2) MPCA_SWEEP(2, false, 2, 2);
+    else if (nm == 2 && occ == 3) MPCA_SWEEP(2, false, 2, 3);
+    else if (nm == 4 && occ == 1) MPCA_SWEEP(2, false, 4, 1);
+    else if (nm == 4 && occ == 2) MPCA_SWEEP(2, false, 4, 2);
+    else MPCA_SWEEP(2, false, 1, 2);
 #undef MPCA_SWEEP
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (inspect) return VMP_OK;
@@ -920,11 +1086,15 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
                        (int64_t)2, state + L.off_scal + SC_TRXX, first ? 0 : 1);
     hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal + 2, (int)gs, (int64_t)3,
                        (int64_t)1, state + L.off_scal + SC_STATUS, 1);
+    hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((m.KP * m.KP + NT - 1) / NT)), dim3(NT),
+                       0, s, psxx, (int)gs, (int64_t)(m.KP * m.KP), (int64_t)(m.KP * m.KP),
+                       state + L.off_Sxx, first ? 0 : 1);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
     hipEvent_t *ev2 = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[0], s));
-    {
+    const int stats_v = vmp_tune_get("mpca_stats_v", 2);
+    if (stats_v == 1) {
         int64_t gw = gst_wg < nsub ? gst_wg : nsub;
         if (gw < 1) gw = 1;
         const dim3 grid((unsigned)(gw * ns));
@@ -938,6 +1108,38 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
         VMP_HIP_CHECK(ctx, hipGetLastError());
         if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[1], s));
         const int64_t len = (int64_t)m.DP * m.LR;
+        hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((len + NT - 1) / NT)), dim3(NT), 0,
+                           s, partial, (int)gw, len, len, state + L.off_M, first ? 0 : 1);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[2], s));
+    } else {
+        // packed columns: column tiles split over the wavefronts; r_d: its own small kernel.
+        // Both write disjoint columns of the same per-workgroup partial rows.
+        const int ncw = vmp_tune_get("mpca_stats_ncw", 2);
+        const int ns2 = (m.PT + 4 * ncw - 1) / (4 * ncw);
+        const int64_t npair = (nsub + 1) / 2;
+        int64_t gw = grid_cap(ctx, ncw >= 3 ? 1 : 2) / ns2;
+        if (gw > gst_wg) gw = gst_wg;
+        if (gw > npair) gw = npair;
+        if (gw < 1) gw = 1;
+        const int64_t len = (int64_t)m.DP * m.LR;
+        VMP_HIP_CHECK(ctx, hipMemsetAsync(partial, 0, (size_t)(gw * len) * sizeof(double), s));
+        const dim3 grid((unsigned)(gw * ns2));
+#define MPCA_CASE(db, kt)                                                                       \
+    if (m.DP == 32 * db && m.KT == kt) {                                                        \
+        if (ncw == 2)                                                                           \
+            hipLaunchKernelGGL((mpca_stats2_kernel<db, kt, 2>), grid, dim3(NT), 0, s, Mb2, XXf, \
+                               sub0, nsub, ns2, partial);                                       \
+        else                                                                                    \
+            hipLaunchKernelGGL((mpca_stats2_kernel<db, kt, 3>), grid, dim3(NT), 0, s, Mb2, XXf, \
+                               sub0, nsub, ns2, partial);                                       \
+        hipLaunchKernelGGL((mpca_ryx_kernel<db, kt>), dim3((unsigned)gw), dim3(NT), 0, s, Ymt,  \
+                           Xm, n0 / TN, (nplates + TN - 1) / TN, partial, m.LR, 16 * m.PT);     \
+    } else
+        MPCA_FOR_EACH(MPCA_CASE) { return VMP_ERR_UNSUPPORTED; }
+#undef MPCA_CASE
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[1], s));
         hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((len + NT - 1) / NT)), dim3(NT), 0,
                            s, partial, (int)gw, len, len, state + L.off_M, first ? 0 : 1);
         VMP_HIP_CHECK(ctx, hipGetLastError());

@@ -136,4 +136,18 @@ __device__ __forceinline__ void sweep_pair(v4f64 (&Ta)[2][2], v4f64 (&Tb)[2][2],
     }
 }
 
+// NM independent matrices swept block by block in one instruction stream.
+template <int P, int NM>
+__device__ __forceinline__ void sweep_multi(v4f64 (&T)[NM][2][2], int nblocks, int l15, int l4,
+                                            double (&prod)[NM], double (&ld)[NM], int (&bad)[NM])
+{
+    if constexpr (P < 8) {
+        if (P < nblocks) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) sweep_block<P>(T[m], l15, l4, prod[m], ld[m], bad[m]);
+        }
+        sweep_multi<P + 1, NM>(T, nblocks, l15, l4, prod, ld, bad);
+    }
+}
+
 }  // namespace vmp_sweep

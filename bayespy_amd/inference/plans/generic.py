@@ -1109,9 +1109,10 @@ class GenericPlan:
         keep the fixed moments of the data."""
         fam = self.family[id(node)]
         phi = self._optimal_phi(node)
-        uq, _ = fam.moments_and_cgf(phi)
+        uq, gq = fam.moments_and_cgf(phi)
         st.u = [fuse(lambda m, a, b: m * a + (1.0 - m) * b, _trail(st.obs_mask, len(node.dims[i])),
                      _arr(st.u_obs[i]), _arr(uq[i])) for i in range(len(uq))]
+        st.phi, st.g = phi, gq          # q of the latent plates (bound term, expfamily.py:431-466)
         st.stale = False
 
     def _sample(self, node, fam, u):
@@ -1409,7 +1410,16 @@ class GenericPlan:
         # annealing temperature: the entropy part of the term, i.e. phi and g of q, is
         # multiplied by T (expfamily.py:403-411)
         T = 1.0 / float(getattr(node, 'annealing', 1.0))
-        if st.observed:
+        partial = st.observed and st.partial
+        if partial:
+            # np.where(observed, f, -T g) and phi_q zeroed on the observed plates
+            # (expfamily.py:431-466): the latent plates of the node count like any latent node
+            if st.stale:
+                self._refresh_partial(node, st)
+            fobs = st.f if isinstance(st.f, DArray) else float(st.f)
+            L = fuse(lambda a, m, f, g, T_=T: a + m * f - (1.0 - m) * T_ * g, L, st.obs_mask,
+                     fobs, _arr(st.g))
+        elif st.observed:
             L = fuse(lambda a, b: a + b, L, st.f if isinstance(st.f, DArray) else float(st.f))
         else:
             if not isinstance(st.g, DArray):
@@ -1427,7 +1437,11 @@ class GenericPlan:
                          misc.sum_multiply(_arr(phi_p[i]), _arr(st.u[i]),
                                            axis=tuple(range(-nd, 0))))
                 continue
-            if st.observed or closed is not None:
+            if partial:
+                t = fuse(lambda pp, pq, m, u, T_=T:
+                         da.where_nonzero(u, pp - T_ * (1.0 - m) * pq) * u,
+                         _arr(phi_p[i]), _arr(st.phi[i]), _trail(st.obs_mask, nd), _arr(st.u[i]))
+            elif st.observed or closed is not None:
                 t = fuse(lambda pp, u: da.where_nonzero(u, pp) * u, _arr(phi_p[i]), _arr(st.u[i]))
             else:
                 t = fuse(lambda pp, pq, u, T_=T: da.where_nonzero(u, pp - T_ * pq) * u,

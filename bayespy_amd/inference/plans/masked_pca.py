@@ -253,6 +253,7 @@ class MaskedPCAPlan:
                 self.Xm[:N, :K].copy_(torch.randn(N, K, dtype=torch.float64, device=rt.device)
                                       * self.x_prec ** -0.5)
         self._x_updated = False
+        self._x_rot = None          # rotation applied to q(X) since its last update
         k.x_begin(D, K, self.n_total, self.state)
         self._x_pass(flags)
         # ---- W: prior moments or a given value -----------------------------------------------------
@@ -293,6 +294,7 @@ class MaskedPCAPlan:
         if self.sharded:
             self._reduce(self.state[L.off_M:L.off_M + int(L.DP) * self.LR])
             self._reduce(self.state[L.off_scal + SC_TRXX:L.off_scal + SC_LDX + 1])
+            self._reduce(self.state[L.off_Sxx:L.off_Sxx + self.KP * self.KP])
 
     # -- node operations ---------------------------------------------------------------------------------
     def update(self, node):
@@ -309,6 +311,7 @@ class MaskedPCAPlan:
             k.x_begin(D, K, self.n_total, self.state)
             self._x_pass(0)
             self._x_updated = True
+            self._x_rot = None
         elif node is self.tau:
             self._pending.append(OP_TAU)
         elif node is self.alpha:
@@ -376,8 +379,8 @@ class MaskedPCAPlan:
         return w, ww
 
     def x_second_moments(self, n0=0, n1=None):
-        """<x x^T>_n of the plates [n0, n1) as a device tensor (n, K, K), re-derived from what the
-        last X.update() saw of its Markov blanket (or from the initial value)."""
+        """<x x^T>_n of the plates [n0, n1) as a host array (n, K, K), re-derived on the device from
+        what the last X.update() saw of its Markov blanket (or from the initial value)."""
         self._materialize()
         self._flush()
         k = self.kernels
@@ -396,6 +399,10 @@ class MaskedPCAPlan:
             k.unpack_xx(D, K, npl, self.XXf, tmp)
             a, b = max(n0, s), min(n1, s + npl)
             out[a - n0:b - n0].copy_(tmp[a - s:b - s])
+        out = out.cpu().numpy()
+        if self._x_rot is not None and out.size:
+            # q(X) was rotated after its update: <xx>_n -> R <xx>_n R^T
+            out = np.einsum('ik,nkl,jl->nij', self._x_rot, out, self._x_rot)
         return out
 
     def get_moments(self, node):
@@ -411,7 +418,7 @@ class MaskedPCAPlan:
             if 8.0 * N * K * K > 8e9:
                 raise MemoryError('X.u[1] would take %.0f GB on the host; read slices with '
                                   'plan.x_second_moments(n0, n1)' % (8e-9 * N * K * K))
-            xx = self.x_second_moments().cpu().numpy()
+            xx = self.x_second_moments()
             return [x.reshape(self.X.plates + (K,)), xx.reshape(self.X.plates + (K, K))]
         if node is self.tau:
             t = self.state[L.off_tau:L.off_tau + 4].cpu().numpy()
@@ -427,7 +434,7 @@ class MaskedPCAPlan:
             m = np.broadcast_to(np.asarray(self.Y._mask, dtype=bool), (D, N))
             w, ww = self._w_moments()
             x = self.Xm[:N, :K].cpu().numpy()
-            xx = self.x_second_moments().cpu().numpy()
+            xx = self.x_second_moments()
             tau = float(self.state[L.off_tau + 2].item())
             f = w @ x.T
             f2 = np.einsum('dij,nij->dn', ww, xx)
@@ -493,10 +500,105 @@ class MaskedPCAPlan:
         self._x_updated = bool(reader.get(base + 'x_updated'))
         self._version += 1
 
-    # -- rotations -------------------------------------------------------------------------------------------
+    # -- rotations (inference/transformations.py; demos/pca.py:85-94 rotates a model with missing
+    #    values in the VB callback) ---------------------------------------------------------------
+    def gamma_posterior_shape(self, node):
+        return self.posterior_parameters(node)[0]
+
+    def _tri_index(self):
+        K = self.K
+        i, j = np.meshgrid(np.arange(K), np.arange(K), indexing='ij')
+        a, b = np.maximum(i, j), np.minimum(i, j)
+        return a * (a + 1) // 2 + b                      # packed position of (i, j)
+
     def rotation_statistics(self, node):
-        raise NotImplementedError("rotations of the fused missing-data PCA block are not built; "
-                                  "use VB(..., engine='generic') with RotationOptimizer")
+        """sum over the plates of <x x^T> (K x K, global over ranks) and the plate count."""
+        self._materialize()
+        self._flush()
+        L = self.layout
+        K, KP = self.K, self.KP
+        if node is self.W:
+            _, ww = self._w_moments()
+            return dict(XX=ww.sum(axis=0), nplates=self.D)
+        if node is self.X:
+            sxx = self.state[L.off_Sxx:L.off_Sxx + KP * KP].cpu().numpy().reshape(KP, KP)[:K, :K]
+            return dict(XX=0.5 * (sxx + sxx.T), nplates=self.n_total)
+        raise NotImplementedError('rotation of %s' % node.name)
+
+    def _panel_from_moments(self, w, ww):
+        """The B-operand panel of the precision GEMM (fragment order, vmp_mpca.hip) from <w_d>,
+        <w_d w_d^T> on the host (set-up / rotation only; W.update() writes it on the device)."""
+        L = self.layout
+        D, K, KP, PT = self.D, self.K, self.KP, int(L.PT)
+        DQ = int(L.DP) // 4
+        CT = PT + KP // 16
+        panel = np.zeros(CT * (DQ // 2) * 128)
+        d = np.arange(D)
+        q = d >> 2
+
+        def put(c, col16, vals):                          # vals[d] -> element (d, 16 c + col16)
+            idx = ((c * (DQ // 2) + (q >> 1)) * 64 + (d & 3) * 16 + col16) * 2 + (q & 1)
+            panel[idx] = vals
+        for i in range(K):
+            for j in range(i + 1):
+                p = i * (i + 1) // 2 + j
+                put(p >> 4, p & 15, ww[:, i, j])
+        for k in range(K):
+            put(PT + (k >> 4), k & 15, w[:, k])
+        return panel
+
+    def rotate_node(self, node, R, invR, logdetR):
+        """q(node) <- the distribution of R x (gaussian.py:1693-1741).  The K x K / D x K state is
+        rotated on the host (O(D K^3)); the (N, K) array of <x_n> on the device through the fp64
+        MFMA contraction kernel.  <xx>_n itself is never stored: its plate sums M_d, sum_n <xx>_n
+        rotate exactly, and later read-outs of X.u[1] apply the accumulated rotation."""
+        self._materialize()
+        self._flush()
+        rt, L = self.rt, self.layout
+        torch = rt.torch
+        D, K, KP, DP, LR, PT = self.D, self.K, self.KP, int(L.DP), self.LR, int(L.PT)
+        if node is self.W:
+            w, ww = self._w_moments()
+            w = w @ R.T
+            ww = np.einsum('ik,dkl,jl->dij', R, ww, R)
+            wp = np.zeros((DP, KP))
+            wp[:D, :K] = w
+            wwp = np.zeros((DP, KP, KP))
+            wwp[:D, :K, :K] = ww
+            self.state[L.off_W:L.off_W + wp.size].copy_(torch.from_numpy(wp.reshape(-1)))
+            self.state[L.off_WW:L.off_WW + wwp.size].copy_(torch.from_numpy(wwp.reshape(-1)))
+            ld = self.state[L.off_ldW:L.off_ldW + D].cpu().numpy() + 2.0 * logdetR
+            self.state[L.off_ldW:L.off_ldW + D].copy_(torch.from_numpy(ld))
+            panel = self._panel_from_moments(w, ww)
+            self.state[L.off_panel:L.off_panel + panel.size].copy_(torch.from_numpy(panel))
+        elif node is self.X:
+            from ...darray import DArray
+            from ...utils import linalg
+            N = self.N
+            if N:
+                xn = linalg.mmdot(DArray(self.Xm[:N, :K]), DArray.from_host(np.ascontiguousarray(R.T)))
+                self.Xm[:N, :K].copy_(xn.t)
+            tri = self._tri_index()
+            mst = self.state[L.off_M:L.off_M + DP * LR].cpu().numpy().reshape(DP, LR).copy()
+            M = mst[:D][:, tri]                                      # (D, K, K)
+            M = np.einsum('ik,dkl,jl->dij', R, M, R)
+            r = mst[:D, 16 * PT:16 * PT + K] @ R.T
+            iu = np.tril_indices(K)
+            mst[:D, iu[0] * (iu[0] + 1) // 2 + iu[1]] = M[:, iu[0], iu[1]]
+            mst[:D, 16 * PT:16 * PT + K] = r
+            self.state[L.off_M:L.off_M + DP * LR].copy_(torch.from_numpy(mst.reshape(-1)))
+            sxx = self.state[L.off_Sxx:L.off_Sxx + KP * KP].cpu().numpy().reshape(KP, KP)
+            sx = np.zeros((KP, KP))
+            sx[:K, :K] = R @ sxx[:K, :K] @ R.T
+            self.state[L.off_Sxx:L.off_Sxx + KP * KP].copy_(torch.from_numpy(sx.reshape(-1)))
+            sc = self.state[L.off_scal:L.off_scal + 8].cpu().numpy()
+            sc[SC_TRXX] = float(np.trace(sx))
+            sc[SC_LDX] += 2.0 * self.n_total * logdetR
+            self.state[L.off_scal:L.off_scal + 8].copy_(torch.from_numpy(sc))
+            self._x_rot = R if self._x_rot is None else R @ self._x_rot
+        else:
+            raise NotImplementedError('rotation of %s' % node.name)
+        self._version += 1
 
     # -- measurement -----------------------------------------------------------------------------------------
     def enable_timing(self, on=True):

@@ -259,6 +259,7 @@ typedef struct vmp_mpca_layout {
     int64_t off_M;       /* DP x LR      packed M_d | r_d                                         */
     int64_t off_panel;   /* B operands of the precision GEMM (fragment order), current W          */
     int64_t off_panel_x; /* ... as seen by the last X.update()                                    */
+    int64_t off_Sxx;     /* KP x KP      sum_n <x x^T>_n (all plates; rotations)                  */
     int64_t total;
 } vmp_mpca_layout;
 

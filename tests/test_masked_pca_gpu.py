@@ -99,7 +99,7 @@ def test_fused_block_vs_oracle_ragged_sizes(N, D, K, keep):
     np.testing.assert_allclose(W.u[1][:, 0], o.WW, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(X.u[0][0], o.X, rtol=1e-7, atol=1e-10)
     # second moments of X: re-derived per plate on request
-    xx = Q.plans[0].x_second_moments(0, min(N, 50)).cpu().numpy()
+    xx = Q.plans[0].x_second_moments(0, min(N, 50))
     tau_x = float(Q.plans[0].state[Q.plans[0].layout.off_scal + 6].item())
     WWf = o.WW.reshape(D, K * K)
     lam = np.eye(K)[None] + tau_x * (mask[:, :min(N, 50)].T.astype(float) @ WWf).reshape(-1, K, K)
@@ -183,3 +183,19 @@ def test_fused_block_direct_oracle_parity_n2e5():
     np.testing.assert_allclose(Q['W'].u[0][:, 0], o.W, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(Q.plans[0].Xm[:N:97, :K].cpu().numpy(), o.X[::97], rtol=1e-7,
                                atol=1e-10)
+
+
+def test_fused_block_rotation_matches_reference(golden_dir):
+    """RotationOptimizer / RotateGaussianARD as the VB callback on a model with missing values
+    (demos/pca.py:80-94, the demo's default use) on the fused missing-data block."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB, transformations
+    from models import build_pca, run_rotation_sequence, check_rotation_results
+    g = np.load(os.path.join(golden_dir, 'rotations.npz'))
+    y, x0 = g['rotm_y'], g['rotm_x0']
+    K = x0.shape[1]
+    Q = build_pca(nodes, VB, y, x0, K)
+    Q['Y'].observe(y, mask=g['rotm_mask'])
+    assert type(Q.plans[0]).__name__ == 'MaskedPCAPlan'
+    res = run_rotation_sequence(Q, K, transformations)
+    check_rotation_results(res, g, 'rotm')
