@@ -1054,7 +1054,7 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
         VMP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
-    int nm = vmp_tune_get("mpca_sweep_nm", 2), occ = vmp_tune_get("mpca_sweep_occ", 2);
+    int nm = vmp_tune_get("mpca_sweep_nm", 1), occ = vmp_tune_get("mpca_sweep_occ", 2);
     if (m.KT == 1 || from_value) { nm = 1; occ = 2; }
     int64_t gs = (nplates + 4 * nm - 1) / (4 * nm);
     const int64_t gs_cap = grid_cap(ctx, 8);
