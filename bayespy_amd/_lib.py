@@ -63,6 +63,13 @@ class MPCASizes(ctypes.Structure):
         'workspace_doubles')]
 
 
+class LSSMLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        'off_tau', 'off_gamma', 'off_alpha', 'off_nu', 'off_mu0', 'off_Lam0', 'off_ldLam0',
+        'off_Cm', 'off_CovC', 'off_SCC', 'off_Am', 'off_AA', 'off_ldA', 'off_Dg', 'off_h0',
+        'off_covsums', 'off_raw', 'len_raw', 'off_S', 'off_scal', 'off_L', 'total')]
+
+
 class GMMLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in (
         'DP', 'KP', 'FS', 'FP', 'F2P', 'off_T', 'len_T', 'off_zs', 'off_alpha', 'off_mu',
@@ -126,6 +133,16 @@ SIGNATURES = {
     'vmp_mpca_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_f64, c_i32,
                                    P(c_i32), c_vp]),
     'vmp_mpca_unpack_xx': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_vp]),
+    'vmp_lssm_limits': (c_i32, [P(c_i32), P(c_i32)]),
+    'vmp_lssm_get_layout': (c_i32, [c_i32, c_i32, P(LSSMLayout)]),
+    'vmp_lssm_workspace_doubles': (c_i32, [c_i32, c_i32, c_i64, c_i32, P(c_i64)]),
+    'vmp_lssm_relayout_y': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    'vmp_lssm_x_layout': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32]),
+    'vmp_lssm_cov': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssm_smooth': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp,
+                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssm_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f64, P(c_f64), c_i32, c_i32,
+                                   P(c_i32), c_vp]),
     'vmp_gmm_get_layout': (c_i32, [c_i32, c_i32, P(GMMLayout)]),
     'vmp_gmm_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, P(c_sz)]),
     'vmp_gmm_init_state': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_f64, c_f64, c_vp, c_vp]),

@@ -1,0 +1,781 @@
+// vmp_lssm.hip -- fused linear state-space model block (BASELINE.json config 5; gfx950).
+//
+// Model (bayespy/demos/lssm.py:34-103 with a plate of B sequences):
+//   x_b0 ~ N(mu0, Lam0^-1),  x_bt ~ N(A x_b,t-1, diag(nu)^-1)        GaussianMarkovChain, n = T
+//   y_mbt ~ N(c_m . x_bt, 1/tau)                                      observed, scalar mask
+// With dynamics, noise and mask shared by all sequences the block-tridiagonal precision of
+// q(X_b) is the SAME matrix for every b (gaussian_markov_chain.py:89-123).  The
+// reference's linalg.block_banded_solve (utils/linalg.py:468-575: a Python loop over T calling
+// SciPy per block, on (B,T,D,D) arrays) therefore splits into
+//   lssm_cov_kernel       ONE D x D recursion over T: block LDL^T forward (S_t^-1, J_t = S_t^-1 E_t,
+//                         log|Phi|), inverse blocks backward (V_t, Cov(x_t, x_t+1)) and their sums;
+//   lssm_forward_kernel   per sequence: h_t = <tau> sum_m y_mbt <c_m> (+ Lam0 mu0),
+//                         z_t = h_t - J_t-1^T z_t-1                      (state in registers)
+//   lssm_backward_kernel  per sequence: <x_t> = S_t^-1 z_t - J_t <x_t+1>, written over z, and the
+//                         plate sums every other node and the bound read:
+//                           sum <x_t><x_t>^T, sum <x_t+1><x_t>^T, sum y_mbt <x_bt>, first / last terms.
+// One thread owns one sequence; arrays are TIME-MAJOR so that the B threads of a time step read
+// and write consecutive addresses:  Yt[t][m][b] (re-laid-out once: Y is constant after observe()),
+// Z[t][i][b].  No (B,T,D,D) array exists; per iteration Y is read twice and Z written twice.
+#include "vmp_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int DMAX = 8;
+
+// ---------------------------------------------------------------------------------------------
+// set-up: Y (M, B, T) sequence-major -> Yt (T, M, BL) time-major, BL >= B (pad columns zero)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT)
+lssm_relayout_kernel(const double *__restrict__ Y, int M, int64_t B, int T, int64_t BL,
+                     double *__restrict__ Yt, double *__restrict__ partial)
+{
+    // 32 x 32 tiles of the (b, t) plane through LDS: both sides coalesced
+    __shared__ double tile[32][33];
+    __shared__ double red[NT / 64];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int64_t nbt = (B + 31) / 32, ntt = (T + 31) / 32;
+    double syy = 0.0;
+    for (int64_t blk = blockIdx.x; blk < nbt * ntt * M; blk += gridDim.x) {
+        const int m = (int)(blk / (nbt * ntt));
+        const int64_t r = blk - (int64_t)m * nbt * ntt;
+        const int64_t bt = r / ntt, tt = r - bt * ntt;
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t b = bt * 32 + j;
+            const int t = (int)(tt * 32) + tx;
+            double v = 0.0;
+            if (b < B && t < T) v = Y[((int64_t)m * B + b) * T + t];
+            tile[j][tx] = v;
+            syy += v * v;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int t = (int)(tt * 32) + j;
+            const int64_t b = bt * 32 + tx;
+            if (t < T && b < BL) Yt[((int64_t)t * M + m) * BL + b] = tile[tx][j];
+        }
+    }
+    syy = block_sum<NT>(syy, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = syy;
+}
+
+// Z (T, D, BL) time-major <-> X (B, T, D) sequence-major (set-up / read-out)
+__global__ void __launch_bounds__(NT)
+lssm_x_layout_kernel(double *__restrict__ X, int D, int64_t B, int T, int64_t BL,
+                     double *__restrict__ Z, int to_time_major)
+{
+    const int64_t total = (int64_t)B * T * D;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * NT) {
+        // e enumerates (t, i, b) so that the time-major side is coalesced
+        const int64_t t = e / ((int64_t)D * B);
+        const int64_t r = e - t * D * B;
+        const int i = (int)(r / B);
+        const int64_t b = r - (int64_t)i * B;
+        double *zp = Z + (t * D + i) * BL + b;
+        double *xp = X + (b * T + t) * D + i;
+        if (to_time_major) *zp = *xp;
+        else *xp = *zp;
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+lssm_sum_kernel(const double *__restrict__ partial, int n, int stride, int len, double *__restrict__ out)
+{
+    // out[j] = sum_b partial[b * stride + j], fixed order
+    for (int j = threadIdx.x; j < len; j += NT) {
+        double s0 = 0.0, s1 = 0.0;
+        int b = 0;
+        for (; b + 1 < n; b += 2) {
+            s0 += partial[(int64_t)b * stride + j];
+            s1 += partial[(int64_t)(b + 1) * stride + j];
+        }
+        if (b < n) s0 += partial[(int64_t)b * stride + j];
+        out[j] = s0 + s1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared covariance recursion: ONE wavefront, lane (i, j) = l / D, l % D owns one matrix element
+// ---------------------------------------------------------------------------------------------
+struct cov_args {
+    int T, D;
+    // inputs (device, D x D row-major unless noted)
+    const double *Dg0, *Dgm, *DgT;   // diagonal blocks of Phi: t = 0, 0 < t < T-1, t = T-1
+    const double *E;                 // super-diagonal block Phi[t, t+1] (same for all t)
+    // outputs
+    double *Sinv;                    // T x D x D
+    double *J;                       // (T-1) x D x D      J_t = S_t^-1 E
+    double *sums;                    // 5 D^2 + 2: sum_t V_t | V_0 | V_{T-1} | sum_t Cov(x_t,x_t+1) | (unused)
+                                     //            then log|Phi| and a not-positive-definite flag
+};
+
+__device__ inline double lds_matmul(const double *A, const double *Bm, int D, int i, int j, bool act)
+{
+    double s = 0.0;
+    if (act)
+        for (int k = 0; k < D; ++k) s += A[i * D + k] * Bm[k * D + j];
+    return s;
+}
+
+__global__ void __launch_bounds__(64)
+lssm_cov_kernel(cov_args a)
+{
+    __shared__ double Ms[64], Es[64], Js[64], Vs[64], Ts[64];
+    const int l = threadIdx.x, D = a.D, T = a.T;
+    const bool act = l < D * D;
+    const int i = act ? l / D : 0, j = act ? l % D : 0;
+    const double e = act ? a.E[i * D + j] : 0.0;
+    Es[l] = e;
+    double ldsum = 0.0;
+    int bad = 0;
+    // ---- forward: S_0 = Dg_0; S_t+1 = Dg_t+1 - E^T J_t,  J_t = S_t^-1 E -----------------------
+    double s = act ? a.Dg0[i * D + j] : 0.0;
+    for (int t = 0; t < T; ++t) {
+        double ld;
+        const double sinv = wave_spd_inverse(s, D, i, j, act, Ms, &ld, &bad);
+        ldsum += ld;
+        if (act) a.Sinv[(int64_t)t * D * D + l] = sinv;
+        if (t < T - 1) {
+            Ms[l] = sinv;
+            lds_fence();
+            const double jt = lds_matmul(Ms, Es, D, i, j, act);       // S^-1 E
+            if (act) a.J[(int64_t)t * D * D + l] = jt;
+            Js[l] = jt;
+            lds_fence();
+            // (E^T J)[i][j] = sum_k E[k][i] J[k][j]
+            double ej = 0.0;
+            if (act)
+                for (int k = 0; k < D; ++k) ej += Es[k * D + i] * Js[k * D + j];
+            const double dg = act ? ((t + 1 < T - 1) ? a.Dgm[i * D + j] : a.DgT[i * D + j]) : 0.0;
+            s = dg - ej;
+            lds_fence();
+        }
+    }
+    // ---- backward: V_T-1 = S_T-1^-1;  C_t = -J_t V_t+1;  V_t = S_t^-1 - C_t J_t^T -----------------
+    double v = act ? a.Sinv[(int64_t)(T - 1) * D * D + l] : 0.0;
+    double sv = v, sc = 0.0;
+    const double vlast = v;
+    for (int t = T - 2; t >= 0; --t) {
+        Vs[l] = v;
+        Js[l] = act ? a.J[(int64_t)t * D * D + l] : 0.0;
+        lds_fence();
+        const double c = -lds_matmul(Js, Vs, D, i, j, act);           // Cov(x_t, x_t+1)
+        Ts[l] = c;
+        lds_fence();
+        double cj = 0.0;                                               // (C J^T)[i][j] = sum_k C[i][k] J[j][k]
+        if (act)
+            for (int k = 0; k < D; ++k) cj += Ts[i * D + k] * Js[j * D + k];
+        v = (act ? a.Sinv[(int64_t)t * D * D + l] : 0.0) - cj;
+        sv += v;
+        sc += c;
+        lds_fence();
+    }
+    if (act) {
+        a.sums[0 * D * D + l] = sv;
+        a.sums[1 * D * D + l] = v;         // V_0
+        a.sums[2 * D * D + l] = vlast;
+        a.sums[3 * D * D + l] = sc;
+    }
+    if (l == 0) {
+        a.sums[5 * D * D + 0] = ldsum;
+        a.sums[5 * D * D + 1] = (double)bad;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-sequence recursions
+// ---------------------------------------------------------------------------------------------
+// z_t = h_t - J_t-1^T z_t-1,  h_t = tau sum_m y_mbt c_m  (+ h0 at t = 0)
+template <int D, int MM>
+__global__ void __launch_bounds__(NT)
+lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
+                    const double *__restrict__ Cm /* M x D */, const double *__restrict__ tau_ptr,
+                    const double *__restrict__ h0 /* D */, const double *__restrict__ J,
+                    double *__restrict__ Z)
+{
+    const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (b >= B) return;
+    const double tau = tau_ptr[0];
+    double tc[MM][D];                       // tau * c_m (uniform: scalar registers)
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int i = 0; i < D; ++i) tc[m][i] = (m < M) ? tau * Cm[m * D + i] : 0.0;
+    double z[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) z[i] = 0.0;
+    const double *yp = Yt + b;
+    double ycur[MM], ynxt[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) ycur[m] = (m < M) ? yp[(int64_t)m * BL] : 0.0;
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                ynxt[m] = (m < M) ? yp[((int64_t)(t + 1) * M + m) * BL] : 0.0;
+        }
+        double h[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = (t == 0) ? h0[i] : 0.0;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) s += ycur[m] * tc[m][i];
+            h[i] = s;
+        }
+        if (t > 0) {
+            const double *Jt = J + (int64_t)(t - 1) * D * D;     // uniform
+            double zn[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = h[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s -= Jt[k * D + i] * z[k];     // (J^T z)_i
+                zn[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = zn[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = h[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) Z[((int64_t)t * D + i) * BL + b] = z[i];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) ycur[m] = ynxt[m];
+    }
+}
+
+// x_t = S_t^-1 z_t - J_t x_t+1 (in place over Z) and the plate sums of this workgroup:
+//   [0, D^2)            sum_bt x_t x_t^T
+//   [D^2, 2 D^2)        sum_b sum_{t<T-1} x_t+1 x_t^T
+//   [2 D^2, 3 D^2)      sum_b x_0 x_0^T
+//   [3 D^2, 4 D^2)      sum_b x_T-1 x_T-1^T
+//   [4 D^2, 4 D^2 + D)  sum_b x_0
+//   then M x D          sum_bt y_mbt x_bt
+template <int D, int MM>
+__global__ void __launch_bounds__(NT)
+lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
+                     const double *__restrict__ Sinv, const double *__restrict__ J,
+                     double *__restrict__ Z, double *__restrict__ partial, int plen, int given)
+{
+    __shared__ double red[NT / 64];
+    const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const bool live = b < B;
+    const int64_t bb = live ? b : 0;
+    double sxx[D][D], snp[D][D], sx0[D][D], sxT[D][D], s0[D], syx[MM][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        s0[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) sxx[i][j] = snp[i][j] = sx0[i][j] = sxT[i][j] = 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int i = 0; i < D; ++i) syx[m][i] = 0.0;
+    double xn[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) xn[i] = 0.0;
+    double *zp = Z + bb;
+    const double *yp = Yt + bb;
+    double zc[D], yc[MM];
+#pragma unroll
+    for (int i = 0; i < D; ++i) zc[i] = zp[((int64_t)(T - 1) * D + i) * BL];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) yc[m] = (m < M) ? yp[((int64_t)(T - 1) * M + m) * BL] : 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        double zq[D], yq[MM];
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) zq[i] = zp[((int64_t)(t - 1) * D + i) * BL];
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                yq[m] = (m < M) ? yp[((int64_t)(t - 1) * M + m) * BL] : 0.0;
+        }
+        double x[D];
+        if (given) {                        // delta moments of a given X (initialize_from_value)
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = zc[i];
+        } else {
+            const double *St = Sinv + (int64_t)t * D * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += St[i * D + k] * zc[k];
+                x[i] = s;
+            }
+        }
+        if (!given && t < T - 1) {
+            const double *Jt = J + (int64_t)t * D * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = x[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s -= Jt[i * D + k] * xn[k];
+                x[i] = s;
+            }
+        }
+        if (live) {
+            if (!given) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) zp[((int64_t)t * D + i) * BL] = x[i];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) sxx[i][j] += x[i] * x[j];
+            if (t < T - 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) snp[i][j] += xn[i] * x[j];
+            }
+            if (t == T - 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) sxT[i][j] = x[i] * x[j];
+            }
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    s0[i] = x[i];
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) sx0[i][j] = x[i] * x[j];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int i = 0; i < D; ++i) syx[m][i] += yc[m] * x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            xn[i] = x[i];
+            zc[i] = zq[i];
+        }
+#pragma unroll
+        for (int m = 0; m < MM; ++m) yc[m] = yq[m];
+    }
+    // workgroup sums (fixed order), symmetric halves mirrored
+    double *pb = partial + (int64_t)blockIdx.x * plen;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double a = block_sum<NT>(j <= i ? sxx[i][j] : sxx[j][i], red);
+            const double c = block_sum<NT>(snp[i][j], red);
+            const double d0 = block_sum<NT>(j <= i ? sx0[i][j] : sx0[j][i], red);
+            const double dT = block_sum<NT>(j <= i ? sxT[i][j] : sxT[j][i], red);
+            if (threadIdx.x == 0) {
+                pb[i * D + j] = a;
+                pb[D * D + i * D + j] = c;
+                pb[2 * D * D + i * D + j] = d0;
+                pb[3 * D * D + i * D + j] = dT;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double a = block_sum<NT>(s0[i], red);
+        if (threadIdx.x == 0) pb[4 * D * D + i] = a;
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double a = block_sum<NT>(syx[m][i], red);
+            if (threadIdx.x == 0 && m < M) pb[4 * D * D + D + m * D + i] = a;
+        }
+}
+
+int plen_of(int D, int M) { return 4 * D * D + D + M * D; }
+
+// ---------------------------------------------------------------------------------------------
+// replicated-node updates and the bound: D x D / M x D algebra, one thread (a few 10^4 flops).
+// Formulas: oracle/lssm.py (pinned on the live reference); reference code: GaussianARD
+// gaussian.py:649-706 with the Gamma wrapper :2299-2371 and the messages of dot.py:425-633 /
+// gaussian_markov_chain.py:443-475, Gamma gamma.py:116-148, bound expfamily.py:400-480.
+// ---------------------------------------------------------------------------------------------
+struct lssm_small_args {
+    vmp_lssm_layout L;
+    int D, M, T, nops;
+    int ops[12];
+    double B;                 // sequences, summed over ranks
+    double pri[8];            // Gamma priors (a0, b0) of tau, gamma, alpha, nu
+    int nu_latent;
+};
+
+// in-place inverse of the SPD matrix A (D x D) by Gauss-Jordan; returns log|A|, flags bad pivots
+__device__ double serial_spd_inverse(double *A, int D, int *bad)
+{
+    double ld = 0.0;
+    for (int p = 0; p < D; ++p) {
+        const double piv = A[p * D + p];
+        if (!(piv > 0.0)) *bad = 1;
+        ld += log(piv);
+        const double d = 1.0 / piv;
+        for (int j = 0; j < D; ++j) A[p * D + j] *= d;
+        A[p * D + p] = d;
+        for (int i = 0; i < D; ++i) {
+            if (i == p) continue;
+            const double c = A[i * D + p];
+            for (int j = 0; j < D; ++j) A[i * D + j] -= c * A[p * D + j];
+            A[i * D + p] = -c * d;
+        }
+    }
+    return ld;
+}
+
+__device__ inline void set_gamma(double *g, int n, int k, double a, double b)
+{
+    g[0 * n + k] = a;
+    g[1 * n + k] = b;
+    g[2 * n + k] = a / b;
+    g[3 * n + k] = vmp_digamma(a) - log(b);
+}
+
+__device__ inline double gamma_term(double a0, double b0, const double *g, int n, int k)
+{
+    const double a = g[0 * n + k], b = g[1 * n + k];
+    return (a0 * log(b0) - vmp_lgamma(a0)) - (a * log(b) - vmp_lgamma(a)) + (b - b0) * g[2 * n + k]
+           + (a0 - a) * g[3 * n + k];
+}
+
+__global__ void __launch_bounds__(64)
+lssm_small_kernel(lssm_small_args A, double *__restrict__ st)
+{
+    if (threadIdx.x != 0) return;
+    __shared__ double tmp[DMAX * DMAX];
+    const vmp_lssm_layout &L = A.L;
+    const int D = A.D, M = A.M, T = A.T, DD = D * D;
+    double *tau = st + L.off_tau, *gam = st + L.off_gamma, *alp = st + L.off_alpha, *nu = st + L.off_nu;
+    double *Cm = st + L.off_Cm, *CovC = st + L.off_CovC, *SCC = st + L.off_SCC;
+    double *Am = st + L.off_Am, *AA = st + L.off_AA, *ldA = st + L.off_ldA;
+    double *S = st + L.off_S;       // full statistics: Sxx | Spp | Snn | Snp | S00 | s0[D] | Syx[M*D]
+    double *Sxx = S, *Spp = S + DD, *Snn = S + 2 * DD, *Snp = S + 3 * DD, *S00 = S + 4 * DD;
+    double *s0 = S + 5 * DD, *Syx = S + 5 * DD + D;
+    double *sc = st + L.off_scal;   // [0] Syy [1] log|Phi| [2] status [3] tau of the last X pass [4] log|CovC|
+    int bad = 0;
+    for (int oi = 0; oi < A.nops; ++oi) {
+        const int op = A.ops[oi];
+        if (op == VMP_LSSM_OP_STATS) {
+            // mean-part sums of the smoother (already summed over ranks) + B x covariance sums
+            const double *raw = st + L.off_raw, *cs = st + L.off_covsums;
+            for (int e = 0; e < DD; ++e) {
+                const int i = e / D, j = e % D;
+                const double xx = raw[e], np_ = raw[DD + e], x0 = raw[2 * DD + e], xT = raw[3 * DD + e];
+                Sxx[e] = A.B * cs[e] + xx;
+                Spp[e] = A.B * (cs[e] - cs[2 * DD + e]) + xx - xT;
+                Snn[e] = A.B * (cs[e] - cs[DD + e]) + xx - x0;
+                // <x_t+1 x_t^T> = Cov(x_t, x_t+1)^T + means
+                Snp[e] = A.B * cs[3 * DD + j * D + i] + np_;
+                S00[e] = A.B * cs[DD + e] + x0;
+            }
+            for (int i = 0; i < D; ++i) s0[i] = raw[4 * DD + i];
+            for (int e = 0; e < M * D; ++e) Syx[e] = raw[4 * DD + D + e];
+            sc[1] = cs[5 * DD];
+            if (cs[5 * DD + 1] != 0.0) bad = 1;
+        } else if (op == VMP_LSSM_OP_C) {
+            // Lam_C = diag<gamma> + <tau> Sxx (shared by all m), c_m = Cov_C <tau> Syx[m]
+            for (int e = 0; e < DD; ++e) tmp[e] = tau[2] * Sxx[e];
+            for (int i = 0; i < D; ++i) tmp[i * D + i] += gam[2 * D + i];
+            const double ld = serial_spd_inverse(tmp, D, &bad);
+            for (int e = 0; e < DD; ++e) CovC[e] = tmp[e];
+            sc[4] = -ld;
+            for (int m = 0; m < M; ++m)
+                for (int i = 0; i < D; ++i) {
+                    double s = 0.0;
+                    for (int k = 0; k < D; ++k) s += CovC[i * D + k] * tau[2] * Syx[m * D + k];
+                    Cm[m * D + i] = s;
+                }
+            for (int e = 0; e < DD; ++e) {
+                const int i = e / D, j = e % D;
+                double s = M * CovC[e];
+                for (int m = 0; m < M; ++m) s += Cm[m * D + i] * Cm[m * D + j];
+                SCC[e] = s;
+            }
+        } else if (op == VMP_LSSM_OP_GAMMA) {
+            for (int j = 0; j < D; ++j) set_gamma(gam, D, j, A.pri[2] + 0.5 * M, A.pri[3] + 0.5 * SCC[j * D + j]);
+        } else if (op == VMP_LSSM_OP_XPREP) {
+            // blocks of the chain precision (gaussian_markov_chain.py:270-441) and h_0
+            double *Dg0 = st + L.off_Dg, *Dgm = Dg0 + DD, *DgT = Dg0 + 2 * DD, *E = Dg0 + 3 * DD;
+            double *h0 = st + L.off_h0;
+            const double *Lam0 = st + L.off_Lam0, *mu0 = st + L.off_mu0;
+            for (int e = 0; e < DD; ++e) {
+                const int j = e / D, k = e % D;
+                double anua = 0.0;
+                for (int i = 0; i < D; ++i) anua += nu[2 * D + i] * AA[(i * D + j) * D + k];
+                const double obs = tau[2] * SCC[e];
+                const double dn = (j == k) ? nu[2 * D + j] : 0.0;
+                Dg0[e] = obs + Lam0[e] + (T > 1 ? anua : 0.0);
+                Dgm[e] = obs + dn + anua;
+                DgT[e] = obs + (T > 1 ? dn : Lam0[e]);
+                E[e] = -nu[2 * D + k] * Am[k * D + j];          // Phi[t, t+1][j][k] = -nu_k A_kj
+            }
+            for (int i = 0; i < D; ++i) {
+                double s = 0.0;
+                for (int k = 0; k < D; ++k) s += Lam0[i * D + k] * mu0[k];
+                h0[i] = s;
+            }
+            sc[3] = tau[2];
+        } else if (op == VMP_LSSM_OP_A) {
+            for (int i = 0; i < D; ++i) {
+                for (int e = 0; e < DD; ++e) tmp[e] = nu[2 * D + i] * Spp[e];
+                for (int j = 0; j < D; ++j) tmp[j * D + j] += alp[2 * D + j];
+                const double ld = serial_spd_inverse(tmp, D, &bad);
+                ldA[i] = -ld;
+                for (int j = 0; j < D; ++j) {
+                    double s = 0.0;
+                    for (int k = 0; k < D; ++k) s += tmp[j * D + k] * nu[2 * D + i] * Snp[i * D + k];
+                    Am[i * D + j] = s;
+                }
+                for (int j = 0; j < D; ++j)
+                    for (int k = 0; k < D; ++k)
+                        AA[(i * D + j) * D + k] = tmp[j * D + k] + Am[i * D + j] * Am[i * D + k];
+            }
+        } else if (op == VMP_LSSM_OP_ALPHA) {
+            for (int j = 0; j < D; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < D; ++i) s += AA[(i * D + j) * D + j];
+                set_gamma(alp, D, j, A.pri[4] + 0.5 * D, A.pri[5] + 0.5 * s);
+            }
+        } else if (op == VMP_LSSM_OP_TAU || op == VMP_LSSM_OP_NU || op == VMP_LSSM_OP_ELBO) {
+            // residual and innovation sums from the statistics
+            double syf = 0.0, sff = 0.0;
+            for (int e = 0; e < M * D; ++e) syf += Cm[e] * Syx[e];
+            for (int e = 0; e < DD; ++e) sff += SCC[e] * Sxx[e];
+            const double resid = sc[0] - 2.0 * syf + sff;
+            double innov[DMAX];
+            for (int i = 0; i < D; ++i) {
+                double s = Snn[i * D + i];
+                for (int j = 0; j < D; ++j) s -= 2.0 * Am[i * D + j] * Snp[i * D + j];
+                for (int j = 0; j < D; ++j)
+                    for (int k = 0; k < D; ++k) s += AA[(i * D + j) * D + k] * Spp[j * D + k];
+                innov[i] = s;
+            }
+            if (op == VMP_LSSM_OP_TAU) {
+                set_gamma(tau, 1, 0, A.pri[0] + 0.5 * M * A.B * T, A.pri[1] + 0.5 * resid);
+                if (!(tau[1] > 0.0)) sc[2] = (double)VMP_ERR_FLOATING;
+            } else if (op == VMP_LSSM_OP_NU) {
+                for (int i = 0; i < D; ++i)
+                    set_gamma(nu, D, i, A.pri[6] + 0.5 * A.B * (T - 1), A.pri[7] + 0.5 * innov[i]);
+            } else {
+                const double LOG2PI = 1.8378770664093453;
+                double *Lo = st + L.off_L;
+                const double *Lam0 = st + L.off_Lam0, *mu0 = st + L.off_mu0;
+                Lo[0] = M * A.B * T * (-0.5 * LOG2PI + 0.5 * tau[3]) - 0.5 * tau[2] * resid;          // Y
+                double lc = M * (0.5 * sc[4] + 0.5 * D);
+                for (int j = 0; j < D; ++j) lc += 0.5 * M * gam[3 * D + j] - 0.5 * gam[2 * D + j] * SCC[j * D + j];
+                Lo[1] = lc;                                                                             // C
+                double la = 0.5 * D * D;
+                for (int i = 0; i < D; ++i) la += 0.5 * ldA[i];
+                for (int j = 0; j < D; ++j) {
+                    double s = 0.0;
+                    for (int i = 0; i < D; ++i) s += AA[(i * D + j) * D + j];
+                    la += 0.5 * D * alp[3 * D + j] - 0.5 * alp[2 * D + j] * s;
+                }
+                Lo[2] = la;                                                                             // A
+                double lx = 0.0, slognu = 0.0;
+                for (int i = 0; i < D; ++i) slognu += nu[3 * D + i];
+                lx = A.B * (0.5 * T * D + 0.5 * st[L.off_ldLam0] + 0.5 * (T - 1) * slognu - 0.5 * sc[1]);
+                for (int e = 0; e < DD; ++e) {
+                    const int i = e / D, j = e % D;
+                    lx -= 0.5 * Lam0[e] * (S00[e] - s0[i] * mu0[j] - mu0[i] * s0[j] + A.B * mu0[i] * mu0[j]);
+                }
+                for (int i = 0; i < D; ++i) lx -= 0.5 * nu[2 * D + i] * innov[i];
+                Lo[3] = lx;                                                                             // X
+                double lg = 0.0, lal = 0.0, lnu = 0.0;
+                for (int j = 0; j < D; ++j) {
+                    lg += gamma_term(A.pri[2], A.pri[3], gam, D, j);
+                    lal += gamma_term(A.pri[4], A.pri[5], alp, D, j);
+                    if (A.nu_latent) lnu += gamma_term(A.pri[6], A.pri[7], nu, D, j);
+                }
+                Lo[4] = lg;
+                Lo[5] = lal;
+                Lo[6] = gamma_term(A.pri[0], A.pri[1], tau, 1, 0);
+                Lo[7] = lnu;
+                Lo[8] = Lo[0] + Lo[1] + Lo[2] + Lo[3] + Lo[4] + Lo[5] + Lo[6] + Lo[7];
+            }
+        }
+    }
+    if (bad) sc[2] = (double)VMP_ERR_NOT_POSDEF;
+}
+
+inline void fill_lssm_layout(int D, int M, vmp_lssm_layout *L)
+{
+    int64_t o = 0;
+    const int DD = D * D;
+    L->off_tau = o;      o += 4;
+    L->off_gamma = o;    o += 4 * D;
+    L->off_alpha = o;    o += 4 * D;
+    L->off_nu = o;       o += 4 * D;
+    L->off_mu0 = o;      o += D;
+    L->off_Lam0 = o;     o += DD;
+    L->off_ldLam0 = o;   o += 1;
+    L->off_Cm = o;       o += (int64_t)M * D;
+    L->off_CovC = o;     o += DD;
+    L->off_SCC = o;      o += DD;
+    L->off_Am = o;       o += DD;
+    L->off_AA = o;       o += (int64_t)DD * D;
+    L->off_ldA = o;      o += D;
+    L->off_Dg = o;       o += 4 * DD;
+    L->off_h0 = o;       o += D;
+    L->off_covsums = o;  o += 5 * DD + 2;
+    L->off_raw = o;      o += plen_of(D, M);
+    L->len_raw = plen_of(D, M);
+    L->off_S = o;        o += 5 * DD + D + (int64_t)M * D;
+    L->off_scal = o;     o += 8;
+    L->off_L = o;        o += 16;
+    L->total = (o + 7) / 8 * 8;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_lssm_limits(int32_t *max_D, int32_t *max_M)
+{
+    if (max_D) *max_D = DMAX;
+    if (max_M) *max_M = 16;
+    return VMP_OK;
+}
+
+int32_t vmp_lssm_relayout_y(vmp_ctx *ctx, const double *Y, int32_t M, int64_t B, int32_t T,
+                            int64_t BL, double *Yt, double *syy, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Y && Yt && syy && workspace, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, M >= 1 && B >= 1 && T >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    double *partial = reinterpret_cast<double *>(workspace);
+    const int64_t nblk = ((B + 31) / 32) * ((T + 31) / 32) * M;
+    int64_t g = nblk < (int64_t)ctx->num_cu * 8 ? nblk : (int64_t)ctx->num_cu * 8;
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(Yt, 0, (size_t)T * M * BL * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(lssm_relayout_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, Y, M, B, T,
+                       BL, Yt, partial);
+    hipLaunchKernelGGL(lssm_sum_kernel, dim3(1), dim3(NT), 0, ctx->stream, partial, (int)g, 1, 1, syy);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssm_x_layout(vmp_ctx *ctx, double *X, int32_t D, int64_t B, int32_t T, int64_t BL,
+                          double *Z, int32_t to_time_major)
+{
+    VMP_REQUIRE(ctx, ctx && X && Z, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, D >= 1 && B >= 1 && T >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    int64_t g = ((int64_t)B * T * D + NT - 1) / NT;
+    if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
+    hipLaunchKernelGGL(lssm_x_layout_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, X, D, B, T,
+                       BL, Z, to_time_major);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
+                     const double *DgT, const double *E, double *Sinv, double *J, double *sums)
+{
+    VMP_REQUIRE(ctx, ctx && Dg0 && Dgm && DgT && E && Sinv && J && sums, VMP_ERR_INVALID,
+                "null argument");
+    VMP_REQUIRE(ctx, T >= 1 && D >= 1, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, D <= DMAX, VMP_ERR_UNSUPPORTED, "the fused LSSM block supports D <= %d", DMAX);
+    cov_args a;
+    a.T = T;
+    a.D = D;
+    a.Dg0 = Dg0;
+    a.Dgm = Dgm;
+    a.DgT = DgT;
+    a.E = E;
+    a.Sinv = Sinv;
+    a.J = J;
+    a.sums = sums;
+    hipLaunchKernelGGL(lssm_cov_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+#define LSSM_FOR_EACH(MACRO)                                                               \
+    MACRO(1, 8) MACRO(2, 8) MACRO(3, 8) MACRO(4, 8) MACRO(5, 8) MACRO(6, 8) MACRO(7, 8)    \
+    MACRO(8, 8) MACRO(1, 16) MACRO(2, 16) MACRO(3, 16) MACRO(4, 16)
+
+int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M, int64_t B,
+                        int32_t T, int64_t BL, int32_t D, const double *Cm, const double *tau,
+                        const double *h0, const double *Sinv, const double *J, double *Z,
+                        double *stats, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Yt && Z && stats && workspace, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, given || (Cm && tau && h0 && Sinv && J), VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, M >= 1 && B >= 1 && T >= 1 && BL >= B && D >= 1, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, D <= DMAX && M <= 16 && (M <= 8 || D <= 4), VMP_ERR_UNSUPPORTED,
+                "the fused LSSM block supports D <= 8 with M <= 8, D <= 4 with M <= 16");
+    const int MM = M <= 8 ? 8 : 16;
+    const int64_t g = (B + NT - 1) / NT;
+    const int plen = plen_of(D, M);
+    double *partial = reinterpret_cast<double *>(workspace);
+    hipStream_t s = ctx->stream;
+    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
+#define LSSM_CASE(d, mm)                                                                      \
+    if (D == d && MM == mm) {                                                                 \
+        if (!given)                                                                           \
+            hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(NT), 0, s, \
+                               Yt, M, B, T, BL, Cm, tau, h0, J, Z);                           \
+        if (ev) (void)hipEventRecord(ev[1], s);                                               \
+        hipLaunchKernelGGL((lssm_backward_kernel<d, mm>), dim3((unsigned)g), dim3(NT), 0, s,  \
+                           Yt, M, B, T, BL, Sinv, J, Z, partial, plen, given);                \
+    } else
+    LSSM_FOR_EACH(LSSM_CASE) { return VMP_ERR_UNSUPPORTED; }
+#undef LSSM_CASE
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(lssm_sum_kernel, dim3(1), dim3(NT), 0, s, partial, (int)g, plen, plen, stats);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssm_get_layout(int32_t D, int32_t M, vmp_lssm_layout *out)
+{
+    if (!out || D < 1 || M < 1) return VMP_ERR_INVALID;
+    if (D > DMAX || M > 16 || (M > 8 && D > 4)) return VMP_ERR_UNSUPPORTED;
+    fill_lssm_layout(D, M, out);
+    return VMP_OK;
+}
+
+int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double B_total,
+                           const double *priors, int32_t nu_latent, int32_t nops,
+                           const int32_t *ops, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && ops && state && priors, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, nops >= 1 && nops <= 12, VMP_ERR_INVALID, "1..12 operations per call");
+    lssm_small_args A;
+    int32_t rc = vmp_lssm_get_layout(D, M, &A.L);
+    VMP_REQUIRE(ctx, rc == VMP_OK, rc, "unsupported dims D=%d M=%d", D, M);
+    A.D = D;
+    A.M = M;
+    A.T = T;
+    A.nops = nops;
+    for (int i = 0; i < nops; ++i) {
+        VMP_REQUIRE(ctx, ops[i] >= VMP_LSSM_OP_STATS && ops[i] <= VMP_LSSM_OP_ELBO, VMP_ERR_INVALID,
+                    "unknown operation %d", ops[i]);
+        A.ops[i] = ops[i];
+    }
+    A.B = B_total;
+    for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
+    A.nu_latent = nu_latent;
+    hipLaunchKernelGGL(lssm_small_kernel, dim3(1), dim3(64), 0, ctx->stream, A, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
+{
+    if (!n || D < 1 || M < 1 || B < 1) return VMP_ERR_INVALID;
+    const int64_t g = (B + NT - 1) / NT;
+    int64_t a = g * plen_of(D, M);
+    const int64_t r = 256 * 8 * 2;            // relayout partials (<= num_cu * 8 workgroups)
+    *n = (a > r ? a : r) + 64;
+    return VMP_OK;
+}
+
+}  // extern "C"

@@ -6,8 +6,9 @@ block and maps the reference's per-node operations (``update``,
 from .pca import PCAPlan
 from .masked_pca import MaskedPCAPlan
 from .gmm import GMMPlan
+from .lssm import LSSMPlan
 
-PLAN_TYPES = [PCAPlan, MaskedPCAPlan, GMMPlan]
+PLAN_TYPES = [PCAPlan, MaskedPCAPlan, GMMPlan, LSSMPlan]
 
 
 def compile_model(nodes, engine=None, **options):

@@ -1,0 +1,538 @@
+"""
+Execution plan of the linear state-space model block (BASELINE.json config 5)
+
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,));  X = GaussianMarkovChain(mu0, Lam0, A, nu, n=T, plates=(B,))
+    C = GaussianARD(0, gamma, shape=(D,), plates=(M,1,1));  Y = GaussianARD(SumMultiply('i,i', C, X), tau)
+
+(bayespy/demos/lssm.py:34-103 with a plate of sequences), Y fully observed.  Dynamics, noise and
+mask are shared by the sequences, so the block-tridiagonal precision of q(X_b) is one matrix: its
+covariance recursion (linalg.block_banded_solve, utils/linalg.py:468-575) runs ONCE per X.update()
+(``vmp_lssm_cov``), the per-sequence mean recursions run one thread per sequence over time-major
+arrays (``vmp_lssm_smooth``), and every other node and the bound read plate sums
+(bayespy_amd/csrc/vmp_lssm.hip; formulas pinned in oracle/lssm.py).  No (B,T,D,D) array exists.
+
+HBM: ``Yt`` (T, M, BL) the data re-laid-out time-major once, ``Z`` (T, D, BL) the posterior means
+(forward pass writes z_t, backward pass overwrites with <x_t>), (T, D, D) shared recursion
+matrices, one small state block (``vmp_lssm_layout``).
+"""
+import ctypes
+
+import numpy as np
+
+from ... import _lib
+from ...device import get_runtime, ptr
+from ...nodes.node import Constant
+from ...nodes.gamma import Gamma
+from ...nodes.gaussian import GaussianARD
+from ...nodes.dot import SumMultiply
+from ...nodes.gaussian_markov_chain import GaussianMarkovChain, MarkovChainToGaussian
+
+(OP_STATS, OP_C, OP_GAMMA, OP_XPREP, OP_A, OP_ALPHA, OP_TAU, OP_NU, OP_ELBO) = range(1, 10)
+
+
+def _const_scalar(node):
+    return isinstance(node, Constant) and node.is_scalar()
+
+
+def _gamma_const(node, plates):
+    return (isinstance(node, Gamma) and _const_scalar(node.parents[0])
+            and _const_scalar(node.parents[1]) and tuple(node.plates) == tuple(plates))
+
+
+def _const_zero(node):
+    return isinstance(node, Constant) and not np.any(node.value)
+
+
+class LSSMKernels:
+
+    def __init__(self, rt):
+        self.rt, self.lib, self.ctx = rt, rt.lib, rt.ctx
+
+    def layout(self, D, M):
+        L = _lib.LSSMLayout()
+        rc = self.lib.vmp_lssm_get_layout(D, M, ctypes.byref(L))
+        if rc != _lib.VMP_OK:
+            _lib.raise_for_status(rc, 'the fused LSSM block supports D <= 8 (M <= 8) or D <= 4 '
+                                      '(M <= 16)')
+        return L
+
+    def workspace_doubles(self, D, M, B, T):
+        n = ctypes.c_int64()
+        self.rt.check(self.lib.vmp_lssm_workspace_doubles(D, M, B, T, ctypes.byref(n)))
+        return n.value
+
+    def relayout_y(self, Y, M, B, T, BL, Yt, syy, ws):
+        self.rt.check(self.lib.vmp_lssm_relayout_y(self.ctx, ptr(Y), M, B, T, BL, ptr(Yt), ptr(syy),
+                                                   ptr(ws)))
+
+    def x_layout(self, X, D, B, T, BL, Z, to_time_major):
+        self.rt.check(self.lib.vmp_lssm_x_layout(self.ctx, ptr(X), D, B, T, BL, ptr(Z),
+                                                 1 if to_time_major else 0))
+
+    def cov(self, T, D, Dg, Sinv, J, sums):
+        DD = D * D
+        self.rt.check(self.lib.vmp_lssm_cov(self.ctx, T, D, ptr(Dg[0:]), ptr(Dg[DD:]),
+                                            ptr(Dg[2 * DD:]), ptr(Dg[3 * DD:]), ptr(Sinv), ptr(J),
+                                            ptr(sums)))
+
+    def smooth(self, given, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats, ws):
+        self.rt.check(self.lib.vmp_lssm_smooth(self.ctx, 1 if given else 0, ptr(Yt), M, B, T, BL, D,
+                                               ptr(Cm), ptr(tau), ptr(h0), ptr(Sinv), ptr(J),
+                                               ptr(Z), ptr(stats), ptr(ws)))
+
+    def small_ops(self, D, M, T, B_total, priors, nu_latent, ops, state):
+        pr = (ctypes.c_double * 8)(*priors)
+        arr = (ctypes.c_int32 * len(ops))(*ops)
+        self.rt.check(self.lib.vmp_lssm_small_ops(self.ctx, D, M, T, float(B_total), pr,
+                                                  1 if nu_latent else 0, len(ops), arr, ptr(state)))
+
+    def set_timing(self, on):
+        self.rt.check(self.lib.vmp_ctx_set_timing(self.ctx, 1 if on else 0))
+
+    def pass_times_ms(self, cap=64):
+        a = (ctypes.c_double * cap)()
+        b = (ctypes.c_double * cap)()
+        n = ctypes.c_int32()
+        self.rt.check(self.lib.vmp_pass_times_ms(self.ctx, a, b, cap, ctypes.byref(n)))
+        return [(a[i], b[i]) for i in range(n.value)]
+
+
+class LSSMPlan:
+
+    @staticmethod
+    def describe():
+        return ("GaussianARD(SumMultiply('i,i', C, GaussianMarkovChain(mu0, Lam0, A, nu)), tau) fully "
+                "observed, shared dynamics, D <= 8 states")
+
+    # -- pattern matching ---------------------------------------------------------------------------
+    @staticmethod
+    def unsupported_state(r):
+        if r['Y']._mask is not True or not r['Y'].observed:
+            return 'Y must be fully observed'
+        for key in ('C', 'gamma', 'X', 'A', 'alpha', 'tau', 'nu'):
+            n = r.get(key)
+            if n is None:
+                continue
+            if getattr(n, 'observed', False):
+                return '%s is observed' % n.name
+            init = n._init
+            if init is not None and init[0] != 'value':
+                return '%s.initialize_from_%s' % (n.name, init[0])
+        if r['X']._init is None:
+            return 'X needs initialize_from_value'
+        return None
+
+    @staticmethod
+    def match(nodes):
+        if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
+            return None
+        for Y in nodes:
+            if not isinstance(Y, GaussianARD) or Y.ndim != 0:
+                continue
+            F, tau = Y.parents
+            if not isinstance(F, SumMultiply) or not _gamma_const(tau, tau.plates) \
+                    or any(p != 1 for p in tau.plates):
+                continue
+            if len(F.parents) != 2 or F.out_keys != [] or F.in_keys[0] != F.in_keys[1] \
+                    or len(F.in_keys[0]) != 1:
+                continue
+            P, Q = F.parents
+            if isinstance(P, MarkovChainToGaussian):
+                P, Q = Q, P
+            if not (isinstance(Q, MarkovChainToGaussian) and isinstance(P, GaussianARD)):
+                continue
+            G, C = Q, P
+            X = G.parents[0]
+            if type(X) is not GaussianMarkovChain or len(X.plates) > 1:
+                continue
+            D, T = X.D, X.N
+            mu, Lam, A, nu = X.parents
+            if not (isinstance(mu, Constant) and isinstance(Lam, Constant)):
+                continue
+            if np.shape(mu.value) != (D,) or np.shape(Lam.value) != (D, D):
+                continue
+            if not (isinstance(A, GaussianARD) and A.ndim == 1 and A.shape == (D,)
+                    and tuple(A.plates) == (D,) and _const_zero(A.parents[0])):
+                continue
+            alpha = A.parents[1]
+            if not _gamma_const(alpha, (D,)):
+                continue
+            if isinstance(nu, Constant):
+                if np.shape(nu.value) != (D,):
+                    continue
+                nu_node = None
+            elif _gamma_const(nu, (D,)):
+                nu_node = nu
+            else:
+                continue
+            Bp = tuple(X.plates)
+            if C.ndim != 1 or C.shape != (D,) or not _const_zero(C.parents[0]):
+                continue
+            M = C.plates[0] if len(C.plates) == len(Bp) + 2 else None
+            if M is None or tuple(C.plates) != (M,) + (1,) * (len(Bp) + 1):
+                continue
+            gamma = C.parents[1]
+            if not _gamma_const(gamma, (D,)):
+                continue
+            if tuple(Y.plates) != (M,) + Bp + (T,):
+                continue
+            mx_d, mx_m = ctypes.c_int32(), ctypes.c_int32()
+            try:
+                _lib.load().vmp_lssm_limits(ctypes.byref(mx_d), ctypes.byref(mx_m))
+            except Exception:       # noqa: BLE001
+                continue
+            if D > mx_d.value or M > mx_m.value or (M > 8 and D > 4):
+                continue
+            priv = [C, gamma, X, A, alpha, tau, F, G] + ([nu_node] if nu_node is not None else [])
+            if any(len(n.children) != 1 for n in priv):
+                continue
+            roles = dict(Y=Y, F=F, G=G, C=C, gamma=gamma, X=X, A=A, alpha=alpha, tau=tau)
+            if nu_node is not None:
+                roles['nu'] = nu_node
+            if LSSMPlan.unsupported_state(roles) is not None:
+                continue
+            return roles
+        return None
+
+    # -- construction -----------------------------------------------------------------------------------
+    def __init__(self, roles, runtime=None, kernels=None):
+        self.roles = roles
+        for k, v in roles.items():
+            setattr(self, k, v)
+        self.nu = roles.get('nu')
+        self.D, self.T = self.X.D, self.X.N
+        self.M = self.C.plates[0]
+        self.B = self.X.plates[0] if self.X.plates else 1
+        self.mu0 = np.asarray(self.X.parents[0].value, dtype=np.float64)
+        self.Lam0 = np.asarray(self.X.parents[1].value, dtype=np.float64)
+        self.nu_const = None if self.nu is not None else \
+            np.asarray(self.X.parents[3].value, dtype=np.float64)
+
+        def prior(n):
+            return [n.parents[0].scalar(), n.parents[1].scalar()]
+        self.priors = prior(self.tau) + prior(self.gamma) + prior(self.alpha) + \
+            (prior(self.nu) if self.nu is not None else [1.0, 1.0])
+        self._rt, self._kernels = runtime, kernels
+        self._ready = False
+        self._version = 0
+        self._L_version = -1
+        self._L = None
+        self._pending = []
+        self._x_updated = False
+        for n in roles.values():
+            n._plan = self
+
+    @property
+    def rt(self):
+        if self._rt is None:
+            self._rt = get_runtime()
+        return self._rt
+
+    @property
+    def kernels(self):
+        if self._kernels is None:
+            self._kernels = LSSMKernels(self.rt)
+        return self._kernels
+
+    def nodes(self):
+        return list(self.roles.values())
+
+    def invalidate(self, node):
+        self._ready = False
+        self._version += 1
+        self._pending = []
+        if self.unsupported_state(self.roles) is not None:
+            from .generic import GenericPlan
+            GenericPlan(self.nodes())
+
+    # -- device state -------------------------------------------------------------------------------------
+    def _gamma_init(self, node, a0, b0, n):
+        """(a, b, mean, log-mean) rows of a Gamma node: prior or delta moments of a value."""
+        from scipy.special import digamma
+        out = np.zeros((4, n))
+        init = node._init
+        if init is None:
+            out[0], out[1] = a0, b0
+            out[2], out[3] = a0 / b0, digamma(a0) - np.log(b0)
+        else:
+            v = np.broadcast_to(np.asarray(init[1], dtype=np.float64).reshape(-1), (n,))
+            out[0], out[1] = a0, b0                   # unused until the node is updated
+            out[2], out[3] = v, np.log(v)
+        return out.reshape(-1)
+
+    def _materialize(self):
+        if self._ready:
+            return
+        rt, k = self.rt, self.kernels
+        torch = rt.torch
+        D, M, B, T = self.D, self.M, self.B, self.T
+        why = self.unsupported_state(self.roles)
+        if why is not None:
+            raise NotImplementedError('the fused LSSM block does not cover this model state (%s); '
+                                      "use VB(..., engine='generic')" % why)
+        rt.sync_stream()
+        self.layout = L = k.layout(D, M)
+        self.sharded = any(getattr(n, '_shard_axis', None) is not None
+                           for n in (self.X, self.G, self.F, self.Y))
+        self.B_total = rt.all_reduce_int(B) if self.sharded else B
+        self.BL = BL = (B + 63) // 64 * 64
+        self.ws = rt.empty(int(k.workspace_doubles(D, M, B, T)))
+        st = np.zeros(int(L.total))
+        pr = self.priors
+        st[L.off_tau:L.off_tau + 4] = self._gamma_init(self.tau, pr[0], pr[1], 1)
+        st[L.off_gamma:L.off_gamma + 4 * D] = self._gamma_init(self.gamma, pr[2], pr[3], D)
+        st[L.off_alpha:L.off_alpha + 4 * D] = self._gamma_init(self.alpha, pr[4], pr[5], D)
+        if self.nu is not None:
+            st[L.off_nu:L.off_nu + 4 * D] = self._gamma_init(self.nu, pr[6], pr[7], D)
+        else:
+            st[L.off_nu + 2 * D:L.off_nu + 3 * D] = self.nu_const
+            st[L.off_nu + 3 * D:L.off_nu + 4 * D] = np.log(self.nu_const)
+        st[L.off_mu0:L.off_mu0 + D] = self.mu0
+        st[L.off_Lam0:L.off_Lam0 + D * D] = self.Lam0.reshape(-1)
+        st[L.off_ldLam0] = np.linalg.slogdet(self.Lam0)[1]
+        # C, A: delta moments of a value or the prior moments (mean 0, covariance diag(1/prec))
+        gmean = st[L.off_gamma + 2 * D:L.off_gamma + 3 * D]
+        amean = st[L.off_alpha + 2 * D:L.off_alpha + 3 * D]
+        if self.C._init is None:
+            cm, covc = np.zeros((M, D)), np.diag(1.0 / gmean)
+        else:
+            cm = np.broadcast_to(np.asarray(self.C._init[1], dtype=np.float64),
+                                 self.C.plates + (D,)).reshape(M, D)
+            covc = np.zeros((D, D))
+        st[L.off_Cm:L.off_Cm + M * D] = cm.reshape(-1)
+        st[L.off_CovC:L.off_CovC + D * D] = covc.reshape(-1)
+        st[L.off_SCC:L.off_SCC + D * D] = (M * covc + cm.T @ cm).reshape(-1)
+        if self.A._init is None:
+            am = np.zeros((D, D))
+            aa = np.broadcast_to(np.diag(1.0 / amean), (D, D, D)).copy()
+        else:
+            am = np.broadcast_to(np.asarray(self.A._init[1], dtype=np.float64), (D, D)).copy()
+            aa = am[:, :, None] * am[:, None, :]
+        st[L.off_Am:L.off_Am + D * D] = am.reshape(-1)
+        st[L.off_AA:L.off_AA + D * D * D] = aa.reshape(-1)
+        self.state = torch.from_numpy(st).to(rt.device)
+        # ---- data: (M, [B,] T) -> time-major Yt, sum y^2 ------------------------------------------------
+        y = self.Y._data
+        if isinstance(y, torch.Tensor):
+            yd = y.to(device=rt.device, dtype=torch.float64).reshape(M, B, T).contiguous()
+        else:
+            yd = torch.from_numpy(np.array(np.broadcast_to(np.asarray(y, dtype=np.float64),
+                                                           self.Y.plates).reshape(M, B, T),
+                                           order='C')).to(rt.device)
+        self.Yt = rt.empty(T * M * BL)
+        k.relayout_y(yd, M, B, T, BL, self.Yt, self.state[L.off_scal:L.off_scal + 1], self.ws)
+        del yd
+        self._reduce(self.state[L.off_scal:L.off_scal + 1])
+        # ---- X: delta moments of the given value; their plate sums ---------------------------------------
+        x0 = self.X._init[1]
+        if isinstance(x0, torch.Tensor):
+            xd = x0.to(device=rt.device, dtype=torch.float64).reshape(B, T, D).contiguous()
+        else:
+            xd = torch.from_numpy(np.array(np.broadcast_to(np.asarray(x0, dtype=np.float64),
+                                                           self.X.plates + (T, D)).reshape(B, T, D),
+                                           order='C')).to(rt.device)
+        self.Z = rt.zeros(T * D * BL)
+        k.x_layout(xd, D, B, T, BL, self.Z, True)
+        del xd
+        self.Sinv = rt.zeros(T * D * D)
+        self.J = rt.zeros(max(T - 1, 1) * D * D)
+        self._smooth(given=True)
+        self._x_updated = False
+        self._ready = True
+        self._version += 1
+
+    def _reduce(self, view):
+        if self.sharded:
+            self.rt.all_reduce_sum_(view)
+
+    def _smooth(self, given):
+        k, L = self.kernels, self.layout
+        D, M, B, T = self.D, self.M, self.B, self.T
+        st = self.state
+        if given:
+            st[L.off_covsums:L.off_covsums + 5 * D * D + 2].zero_()
+        else:
+            k.cov(T, D, st[L.off_Dg:L.off_Dg + 4 * D * D], self.Sinv, self.J,
+                  st[L.off_covsums:L.off_covsums + 5 * D * D + 2])
+        k.smooth(given, self.Yt, M, B, T, self.BL, D, st[L.off_Cm:], st[L.off_scal + 3:],
+                 st[L.off_h0:], self.Sinv, self.J, self.Z, st[L.off_raw:], self.ws)
+        self._reduce(st[L.off_raw:L.off_raw + int(L.len_raw)])
+        self._ops([OP_STATS])
+
+    def _ops(self, ops):
+        self.kernels.small_ops(self.D, self.M, self.T, self.B_total, self.priors,
+                               self.nu is not None, ops, self.state)
+
+    # -- node operations -------------------------------------------------------------------------------------
+    def update(self, node):
+        self._materialize()
+        code = {id(self.C): OP_C, id(self.gamma): OP_GAMMA, id(self.A): OP_A,
+                id(self.alpha): OP_ALPHA, id(self.tau): OP_TAU}
+        if self.nu is not None:
+            code[id(self.nu)] = OP_NU
+        if node is self.X:
+            self._pending.append(OP_XPREP)
+            self._flush()
+            self.rt.sync_stream()
+            self._smooth(given=False)
+            self._x_updated = True
+        elif id(node) in code:
+            self._pending.append(code[id(node)])
+        else:
+            return
+        self._version += 1
+
+    def _flush(self):
+        if not self._pending:
+            return
+        ops, self._pending = self._pending, []
+        self.rt.sync_stream()
+        for i in range(0, len(ops), 12):
+            self._ops(ops[i:i + 12])
+
+    def finish(self):
+        if self._ready:
+            self._flush()
+
+    def _lower_bound_terms(self):
+        self._materialize()
+        if self._L_version != self._version:
+            L = self.layout
+            self._pending.append(OP_ELBO)
+            self._flush()
+            host = self.state[L.off_scal:L.off_L + 16].cpu().numpy()
+            status = host[2]
+            if status != 0:
+                self.state[L.off_scal + 2] = 0.0
+                _lib.raise_for_status(int(status))
+            t = host[8:]
+            self._L = dict(Y=t[0], C=t[1], A=t[2], X=t[3], gamma=t[4], alpha=t[5], tau=t[6], nu=t[7],
+                           total=t[8])
+            self._L_version = self._version
+        return self._L
+
+    def lower_bound_contribution(self, node):
+        terms = self._lower_bound_terms()
+        for key in ('Y', 'C', 'A', 'X', 'gamma', 'alpha', 'tau', 'nu'):
+            if node is self.roles.get(key):
+                return float(terms[key])
+        return 0.0
+
+    def lower_bound(self):
+        return float(self._lower_bound_terms()['total'])
+
+    # -- host views (reference shapes) ---------------------------------------------------------------------------
+    def _gamma_view(self, off, n, plates):
+        g = self.state[off:off + 4 * n].cpu().numpy().reshape(4, n)
+        return [g[2].reshape(plates), g[3].reshape(plates)]
+
+    def chain_covariances(self):
+        """V_t = Cov(x_t) (T,D,D) and Cov(x_t, x_t+1) (T-1,D,D), shared by the sequences, from the
+        recursion matrices of the last X.update() (zero for a delta-initialised X)."""
+        T, D = self.T, self.D
+        if not self._x_updated:
+            return np.zeros((T, D, D)), np.zeros((max(T - 1, 0), D, D))
+        Sinv = self.Sinv.cpu().numpy().reshape(T, D, D)
+        J = self.J.cpu().numpy().reshape(-1, D, D)
+        V = np.empty((T, D, D))
+        Cn = np.empty((max(T - 1, 0), D, D))
+        V[T - 1] = Sinv[T - 1]
+        for t in range(T - 2, -1, -1):
+            Cn[t] = -J[t] @ V[t + 1]
+            V[t] = Sinv[t] - Cn[t] @ J[t].T
+        return V, Cn
+
+    def x_means(self):
+        """<x> as a host array (B, T, D)."""
+        self._materialize()
+        self._flush()
+        out = self.rt.empty(self.B, self.T, self.D)
+        self.kernels.x_layout(out, self.D, self.B, self.T, self.BL, self.Z, False)
+        return out.cpu().numpy()
+
+    def get_moments(self, node):
+        self._materialize()
+        self._flush()
+        L = self.layout
+        D, M, B, T = self.D, self.M, self.B, self.T
+        st = self.state
+        if node is self.tau:
+            return self._gamma_view(L.off_tau, 1, self.tau.plates)
+        if node is self.gamma:
+            return self._gamma_view(L.off_gamma, D, self.gamma.plates)
+        if node is self.alpha:
+            return self._gamma_view(L.off_alpha, D, self.alpha.plates)
+        if self.nu is not None and node is self.nu:
+            return self._gamma_view(L.off_nu, D, self.nu.plates)
+        if node is self.C:
+            cm = st[L.off_Cm:L.off_Cm + M * D].cpu().numpy().reshape(M, D)
+            cov = st[L.off_CovC:L.off_CovC + D * D].cpu().numpy().reshape(D, D)
+            u1 = cov[None] + cm[:, :, None] * cm[:, None, :]
+            return [cm.reshape(self.C.plates + (D,)), u1.reshape(self.C.plates + (D, D))]
+        if node is self.A:
+            am = st[L.off_Am:L.off_Am + D * D].cpu().numpy().reshape(D, D)
+            aa = st[L.off_AA:L.off_AA + D * D * D].cpu().numpy().reshape(D, D, D)
+            return [am.copy(), aa.copy()]
+        if node is self.X:
+            if 8.0 * B * T * D * D > 8e9:
+                raise MemoryError('X.u[1] would take %.0f GB on the host; use plan.x_means() and '
+                                  'plan.chain_covariances()' % (8e-9 * B * T * D * D))
+            x = self.x_means()
+            V, Cn = self.chain_covariances()
+            u1 = V[None] + x[:, :, :, None] * x[:, :, None, :]
+            u2 = Cn[None] + x[:, :-1, :, None] * x[:, 1:, None, :]
+            pl = self.X.plates
+            return [x.reshape(pl + (T, D)), u1.reshape(pl + (T, D, D)),
+                    u2.reshape(pl + (T - 1, D, D))]
+        raise NotImplementedError('moments of %s are never materialised by the fused LSSM block'
+                                  % node.name)
+
+    def get_mask(self, node):
+        return np.array(True)
+
+    # -- persistence ---------------------------------------------------------------------------------------------
+    def save_state(self, put, nodes, index):
+        self._materialize()
+        self._flush()
+        base = 'plans/%d/' % index
+        put(base + 'kind', np.array([ord(c) for c in 'lssm'], dtype=np.uint8))
+        put(base + 'dims', np.array([self.D, self.M, self.B, self.T], dtype=np.int64))
+        put(base + 'state', self.state.cpu().numpy())
+        put(base + 'X', self.x_means())
+        put(base + 'Sinv', self.Sinv.cpu().numpy())
+        put(base + 'J', self.J.cpu().numpy())
+        put(base + 'x_updated', bool(self._x_updated))
+
+    def load_state(self, reader, nodes, index):
+        self._materialize()
+        base = 'plans/%d/' % index
+        if not reader.has(base + 'state'):
+            raise Exception("File does not contain the state of the fused LSSM block")
+        dims = tuple(int(v) for v in reader.get(base + 'dims'))
+        if dims != (self.D, self.M, self.B, self.T):
+            raise ValueError('checkpoint is for (D, M, B, T) = %s, the model has %s'
+                             % (dims, (self.D, self.M, self.B, self.T)))
+        torch = self.rt.torch
+        self.state.copy_(torch.from_numpy(np.array(reader.get(base + 'state'), dtype=np.float64)))
+        xd = torch.from_numpy(np.array(reader.get(base + 'X'), dtype=np.float64)).to(self.rt.device)
+        self.kernels.x_layout(xd.contiguous(), self.D, self.B, self.T, self.BL, self.Z, True)
+        self.Sinv.copy_(torch.from_numpy(np.array(reader.get(base + 'Sinv'), dtype=np.float64)))
+        self.J.copy_(torch.from_numpy(np.array(reader.get(base + 'J'), dtype=np.float64)))
+        self._x_updated = bool(reader.get(base + 'x_updated'))
+        self._version += 1
+
+    def rotation_statistics(self, node):
+        raise NotImplementedError("rotations of the fused LSSM block are not built; use "
+                                  "VB(..., engine='generic')")
+
+    # -- measurement ---------------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._materialize()
+        self.kernels.set_timing(on)
+
+    def kernel_times_ms(self):
+        t = self.kernels.pass_times_ms(64)
+        if not t:
+            return None
+        n = float(len(t))
+        return dict(lssm_forward=sum(a for a, _ in t) / n, lssm_backward=sum(b for _, b in t) / n)

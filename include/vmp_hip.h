@@ -308,6 +308,63 @@ int32_t vmp_mpca_small_ops(vmp_ctx *ctx, int32_t D, int32_t K, double x_prec, do
 int32_t vmp_mpca_unpack_xx(vmp_ctx *ctx, int32_t D, int32_t K, int64_t nplates,
                            const double *XXf, double *out);
 
+/* ---- fused linear state-space model block (BASELINE.json config 5) ----------------------- *
+ *
+ * bayespy/demos/lssm.py:34-103 with a plate of B sequences: X = GaussianMarkovChain(mu0, Lam0,
+ * A, nu, n=T, plates=(B,)), Y = GaussianARD(SumMultiply('i,i', C, X), tau) fully observed.
+ * Dynamics, noise and mask are shared by the sequences, so the covariance recursion of
+ * linalg.block_banded_solve (utils/linalg.py:468-575, gaussian_markov_chain.py:89-123) runs ONCE
+ * (vmp_lssm_cov) and only the means are per-sequence (vmp_lssm_smooth: one thread per
+ * sequence, time-major arrays Yt[t][m][b], Z[t][i][b], b contiguous); the other nodes and the
+ * bound read plate sums only.  D <= 8 states with M <= 8 observations per step, or D <= 4 with
+ * M <= 16.  Details: bayespy_amd/csrc/vmp_lssm.hip, formulas: oracle/lssm.py. */
+typedef struct vmp_lssm_layout {
+    int64_t off_tau;      /* 4: a, b, <tau>, <log tau>                                             */
+    int64_t off_gamma, off_alpha, off_nu;   /* 4*D each: a[D], b[D], mean[D], log-mean[D]          */
+    int64_t off_mu0, off_Lam0, off_ldLam0;  /* D, D*D, 1: constants of the initial state           */
+    int64_t off_Cm, off_CovC, off_SCC;      /* M*D <c_m>, D*D shared Cov_C, D*D sum_m <c c^T>      */
+    int64_t off_Am, off_AA, off_ldA;        /* D*D <a_i>, D*D*D <a_i a_i^T>, D log|Cov_A_i|        */
+    int64_t off_Dg;       /* 4*D*D: diagonal blocks of the chain precision (t=0, inner, last), E   */
+    int64_t off_h0;       /* D: Lam0 mu0                                                           */
+    int64_t off_covsums;  /* 5*D*D+2: output of vmp_lssm_cov                                       */
+    int64_t off_raw, len_raw;  /* mean-part plate sums of vmp_lssm_smooth (what ranks all-reduce)  */
+    int64_t off_S;        /* Sxx | Spp | Snn | Snp | S00 (D*D each) | s0 (D) | Syx (M*D)           */
+    int64_t off_scal;     /* 8: [0] sum y^2 [1] log|Phi| [2] status [3] <tau> of the last X pass
+                                [4] log|Cov_C|                                                     */
+    int64_t off_L;        /* 16: L_Y, L_C, L_A, L_X, L_gamma, L_alpha, L_tau, L_nu, total          */
+    int64_t total;
+} vmp_lssm_layout;
+
+enum vmp_lssm_op {
+    VMP_LSSM_OP_STATS = 1, VMP_LSSM_OP_C, VMP_LSSM_OP_GAMMA, VMP_LSSM_OP_XPREP, VMP_LSSM_OP_A,
+    VMP_LSSM_OP_ALPHA, VMP_LSSM_OP_TAU, VMP_LSSM_OP_NU, VMP_LSSM_OP_ELBO
+};
+
+int32_t vmp_lssm_limits(int32_t *max_D, int32_t *max_M);
+int32_t vmp_lssm_get_layout(int32_t D, int32_t M, vmp_lssm_layout *out);
+int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n);
+/* Y (M, B, T) -> Yt (T, M, BL) time-major (once: Y is constant after observe); sum y^2 -> *syy. */
+int32_t vmp_lssm_relayout_y(vmp_ctx *ctx, const double *Y, int32_t M, int64_t B, int32_t T,
+                            int64_t BL, double *Yt, double *syy, void *workspace);
+/* X (B, T, D) <-> Z (T, D, BL) */
+int32_t vmp_lssm_x_layout(vmp_ctx *ctx, double *X, int32_t D, int64_t B, int32_t T, int64_t BL,
+                          double *Z, int32_t to_time_major);
+/* The shared D x D recursion over T.  Dg0 / Dgm / DgT: diagonal blocks of the precision at t = 0,
+ * 0 < t < T-1, t = T-1; E = Phi[t, t+1].  Out: Sinv (T,D,D), J (T-1,D,D), sums (5 D^2 + 2). */
+int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
+                     const double *DgT, const double *E, double *Sinv, double *J, double *sums);
+/* Forward + backward vector recursions of all sequences and their plate sums (given != 0: the
+ * sums of the <x> already in Z, no recursion: initialize_from_value). */
+int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M, int64_t B,
+                        int32_t T, int64_t BL, int32_t D, const double *Cm, const double *tau,
+                        const double *h0, const double *Sinv, const double *J, double *Z,
+                        double *stats, void *workspace);
+/* Replicated-node updates / the bound, a list of vmp_lssm_op in one launch.  priors: host array
+ * of 8 doubles, the Gamma (a0, b0) of tau, gamma, alpha, nu. */
+int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double B_total,
+                           const double *priors, int32_t nu_latent, int32_t nops,
+                           const int32_t *ops, double *state);
+
 /* ---- fused full-covariance Gaussian-mixture block -------------------------- *
  *
  * Model block  Y = Mixture(z, Gaussian, mu, Lambda), z = Categorical(alpha),

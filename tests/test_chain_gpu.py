@@ -113,7 +113,7 @@ def test_block_banded_solve_wide_states_against_dense_solves():
             np.testing.assert_allclose(np.ravel(ld)[b], np.linalg.slogdet(big)[1], rtol=1e-10)
 
 
-def _build_lssm(g, tag, B, gamma_nu):
+def _build_lssm(g, tag, B, gamma_nu, engine=None):
     from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
     from bayespy_amd.inference import VB
     y, x0, c0 = g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0']
@@ -140,7 +140,7 @@ def _build_lssm(g, tag, B, gamma_nu):
     nodes = [Y, F, C, gamma, X, A, alpha, tau]
     if gamma_nu:
         nodes.append(nu)
-    Q = VB(*nodes)
+    Q = VB(*nodes, engine=engine)
     Q.ignore_bound_checks = True
     track = dict(X=X, A=A, C=C, tau=tau, alpha=alpha, gamma=gamma)
     if gamma_nu:
@@ -150,9 +150,13 @@ def _build_lssm(g, tag, B, gamma_nu):
 
 @pytest.mark.parametrize('tag,B,gamma_nu', [('lssm1', None, False), ('lssm1g', None, True),
                                              ('lssmBc', 6, False), ('lssmB', 6, True)])
-def test_lssm_matches_reference(golden_dir, tag, B, gamma_nu):
+@pytest.mark.parametrize('engine', ['fused', 'generic'])
+def test_lssm_matches_reference(golden_dir, tag, B, gamma_nu, engine):
+    """Both engines: the fused block (vmp_lssm_*: one shared covariance recursion, per-sequence
+    mean recursions, plate sums) and the generic message passing."""
     g = np.load(os.path.join(golden_dir, 'lssm.npz'))
-    Q, track = _build_lssm(g, tag, B, gamma_nu)
+    Q, track = _build_lssm(g, tag, B, gamma_nu, engine=None if engine == 'fused' else 'generic')
+    assert type(Q.plans[0]).__name__ == ('LSSMPlan' if engine == 'fused' else 'GenericPlan')
     n = len(g[tag + '_L'])
     Q.update(repeat=n, verbose=False)
     np.testing.assert_allclose(Q.L[:n], g[tag + '_L'], rtol=1e-9)

@@ -1,0 +1,101 @@
+"""
+GPU: the fused linear state-space model block (BASELINE.json config 5; vmp_lssm_* through
+LSSMPlan) against the chunk-free NumPy oracle (oracle/lssm.py, pinned on the live reference) on
+seeded inputs incl. tiny / ragged sizes; the live-reference traces themselves are in
+tests/test_chain_gpu.py::test_lssm_matches_reference[fused].
+Bars: bound rtol 1e-9 per iteration and per node term; moments rtol 1e-7.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(M, B, T, D, seed):
+    rs = np.random.RandomState(seed)
+    a_true = 0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]
+    x = np.zeros((B, T, D))
+    x[:, 0] = rs.normal(size=(B, D))
+    for t in range(1, T):
+        x[:, t] = x[:, t - 1] @ a_true.T + rs.normal(size=(B, D))
+    c_true = rs.normal(size=(M, D))
+    y = np.einsum('md,btd->mbt', c_true, x) + 0.3 * rs.normal(size=(M, B, T))
+    return y, rs.normal(size=(B, T, D)), rs.normal(size=(M, D))
+
+
+def _build(y, x0, c0, gamma_nu, shard=False):
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+    from bayespy_amd.inference import VB
+    M, B, T = y.shape
+    D = x0.shape[-1]
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    A.initialize_from_value(np.identity(D))
+    nu = Gamma(1e-3, 1e-3, plates=(D,), name='nu') if gamma_nu else np.ones(D)
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, nu, n=T, plates=(B,), name='X')
+    if shard:
+        X.shard(-1)
+    X.initialize_from_value(x0)
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(D))
+    C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
+    C.initialize_from_value(c0.reshape(M, 1, 1, D))
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = SumMultiply('i,i', C, X, name='F')
+    Y = GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    nodes = [Y, F, C, gamma, X, A, alpha, tau] + ([nu] if gamma_nu else [])
+    Q = VB(*nodes)
+    Q.ignore_bound_checks = True
+    return Q
+
+
+@pytest.mark.parametrize('M,B,T,D', [(1, 1, 1, 1), (3, 5, 2, 2), (8, 70, 33, 4), (16, 300, 20, 3),
+                                     (5, 1000, 50, 8), (8, 257, 1000, 4), (2, 64, 3, 5)])
+@pytest.mark.parametrize('gamma_nu', [False, True])
+def test_fused_lssm_vs_oracle(M, B, T, D, gamma_nu):
+    from oracle.lssm import LSSMOracle
+    y, x0, c0 = _data(M, B, T, D, seed=M + B + T + D)
+    Q = _build(y, x0, c0, gamma_nu)
+    assert type(Q.plans[0]).__name__ == 'LSSMPlan'
+    iters = 3
+    Q.update(repeat=iters, verbose=False)
+    o = LSSMOracle(y, x0, c0, nu_prior=(1e-3, 1e-3) if gamma_nu else None)
+    o.iterate(iters)
+    np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=1e-9)
+    for nm in ('Y', 'C', 'A', 'X', 'gamma', 'alpha', 'tau') + (('nu',) if gamma_nu else ()):
+        np.testing.assert_allclose(Q.l[Q[nm]][:iters], [t[nm] for t in o.L_terms], rtol=1e-8,
+                                   atol=1e-7, err_msg=nm)
+    np.testing.assert_allclose(Q['A'].u[0], o.Am, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(Q['A'].u[1], o.AA, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(Q['C'].u[0].reshape(M, D), o.Cm, rtol=1e-7, atol=1e-10)
+    xu = Q['X'].u
+    np.testing.assert_allclose(xu[0], o.X, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(xu[1], o.V[None] + o.X[:, :, :, None] * o.X[:, :, None, :],
+                               rtol=1e-7, atol=1e-9)
+    if T > 1:
+        np.testing.assert_allclose(xu[2], o.Cn[None] + o.X[:, :-1, :, None] * o.X[:, 1:, None, :],
+                                   rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(Q['tau'].u, dtype=np.float64).ravel(),
+                               [o.tau, o.logtau], rtol=1e-9)
+
+
+def test_fused_lssm_device_inputs_and_checkpoint(tmp_path):
+    import torch
+    from bayespy_amd.device import get_runtime
+    y, x0, c0 = _data(8, 300, 40, 4, seed=9)
+    d = get_runtime().device
+    Q = _build(torch.from_numpy(y).to(d), torch.from_numpy(x0).to(d), c0, False)
+    Qh = _build(y, x0, c0, False)
+    Q.update(repeat=2, verbose=False)
+    Qh.update(repeat=2, verbose=False)
+    np.testing.assert_array_equal(Q.L[:2], Qh.L[:2])
+    fn = str(tmp_path / 'lssm.ckpt')
+    Q.save(filename=fn)
+    Q.update(repeat=2, verbose=False)
+    Q2 = _build(y, x0, c0, False)
+    Q2.load(filename=fn)
+    Q2.update(repeat=2, verbose=False)
+    np.testing.assert_array_equal(Q2.L[:4], Q.L[:4])
+    np.testing.assert_array_equal(Q2['X'].u[0], Q['X'].u[0])

@@ -225,6 +225,10 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
     Q = VB(Y, F, C, gamma, X, A, alpha, tau)
     Q.ignore_bound_checks = True
     Q.update(repeat=warmup, verbose=False)
+    plan = Q.plans[0]
+    timed = hasattr(plan, 'kernel_times_ms')
+    if timed:
+        plan.enable_timing(True)
 
     def barrier():
         if world > 1:
@@ -238,6 +242,7 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
     dt = (time.perf_counter() - t0) / steps
     # algorithmic traffic per iteration: read Y (M B T), read + write the chain means (B T D)
     byts = 8.0 * B * T * (M + 2 * D)
+    kms = plan.kernel_times_ms() if timed else None
     return {
         'metric': 'VB iterations/sec, LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D),
         'value': 1.0 / dt, 'unit': 'VB iterations/s', 'n_gpus': world, 'steps': steps,
@@ -251,6 +256,7 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'hbm', 'achieved': byts / dt / 1e9, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': byts / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                     'alg_bytes_per_iteration': byts,
-                     'note': 'whole iteration against read Y once + read/write <x> once'},
+                     'alg_bytes_per_iteration': byts, 'kernel_ms': kms,
+                     'note': 'whole iteration against read Y once + read/write <x> once (the two '
+                             'recursion sweeps read Y twice and move the means three times)'},
     }
