@@ -132,7 +132,11 @@ lssm_cov_kernel(cov_args a)
     double ldsum = 0.0;
     int bad = 0;
     // ---- forward: S_0 = Dg_0; S_t+1 = Dg_t+1 - E^T J_t,  J_t = S_t^-1 E -----------------------
+    // In the interior (0 < t < T-1) every step applies the SAME map to S_t.  Once S_t+1 == S_t
+    // bit for bit the map has reached a fixed point and every later interior step would reproduce
+    // the same S^-1, J and log-pivots exactly: they are filled in without being recomputed.
     double s = act ? a.Dg0[i * D + j] : 0.0;
+    int fix_from = -1;                 // steps fix_from .. T-2 share one (S^-1, J)
     for (int t = 0; t < T; ++t) {
         double ld;
         const double sinv = wave_spd_inverse(s, D, i, j, act, Ms, &ld, &bad);
@@ -150,17 +154,48 @@ lssm_cov_kernel(cov_args a)
             if (act)
                 for (int k = 0; k < D; ++k) ej += Es[k * D + i] * Js[k * D + j];
             const double dg = act ? ((t + 1 < T - 1) ? a.Dgm[i * D + j] : a.DgT[i * D + j]) : 0.0;
-            s = dg - ej;
+            const double snew = dg - ej;
             lds_fence();
+            // fixed point inside the interior: steps t+1 .. T-2 repeat this one
+            if (t >= 1 && t + 1 < T - 1 && __all(!act || snew == s)) {
+                const int t1 = T - 2;                                   // last interior step
+                for (int tt = t + 1; tt <= t1; ++tt) {
+                    if (act) {
+                        a.Sinv[(int64_t)tt * D * D + l] = sinv;
+                        a.J[(int64_t)tt * D * D + l] = jt;
+                    }
+                }
+                ldsum += (double)(t1 - t) * ld;
+                fix_from = t;
+                // S_T-1 = Dg_T-1 - E^T J_T-2 (J_T-2 == jt)
+                s = (act ? a.DgT[i * D + j] : 0.0) - ej;
+                t = t1;
+                continue;
+            }
+            s = snew;
         }
     }
     // ---- backward: V_T-1 = S_T-1^-1;  C_t = -J_t V_t+1;  V_t = S_t^-1 - C_t J_t^T -----------------
     double v = act ? a.Sinv[(int64_t)(T - 1) * D * D + l] : 0.0;
     double sv = v, sc = 0.0;
     const double vlast = v;
+    double vprev = 0.0, cprev = 0.0;
+    int have_prev = 0;
     for (int t = T - 2; t >= 0; --t) {
+        const double jt = act ? a.J[(int64_t)t * D * D + l] : 0.0;
+        const double si = act ? a.Sinv[(int64_t)t * D * D + l] : 0.0;
+        // same (S^-1, J) as the step before and the same V_t+1 as that step saw: the same V, C
+        // again, down to the first step of the stationary stretch
+        if (have_prev && fix_from >= 0 && t >= fix_from && t + 1 <= T - 2
+            && __all(!act || v == vprev)) {
+            const double cnt = (double)(t - fix_from + 1);
+            sv += cnt * v;
+            sc += cnt * cprev;
+            t = fix_from;
+            continue;
+        }
         Vs[l] = v;
-        Js[l] = act ? a.J[(int64_t)t * D * D + l] : 0.0;
+        Js[l] = jt;
         lds_fence();
         const double c = -lds_matmul(Js, Vs, D, i, j, act);           // Cov(x_t, x_t+1)
         Ts[l] = c;
@@ -168,7 +203,10 @@ lssm_cov_kernel(cov_args a)
         double cj = 0.0;                                               // (C J^T)[i][j] = sum_k C[i][k] J[j][k]
         if (act)
             for (int k = 0; k < D; ++k) cj += Ts[i * D + k] * Js[j * D + k];
-        v = (act ? a.Sinv[(int64_t)t * D * D + l] : 0.0) - cj;
+        vprev = v;
+        v = si - cj;
+        have_prev = 1;
+        cprev = c;
         sv += v;
         sc += c;
         lds_fence();

@@ -84,7 +84,11 @@ def timeline(db, count):
 if __name__ == '__main__':
     args = sys.argv[1:]
     if args and args[0] == '--pmc':
-        pmc(args[1:])
+        only = 'pass_kernel'
+        rest = args[1:]
+        if rest and rest[0] == '--only':            # substring of the kernel names to keep
+            only, rest = rest[1], rest[2:]
+        pmc(rest, only)
     elif args and args[0] == '--timeline':
         timeline(args[2], int(args[1]))
     else:
