@@ -112,52 +112,92 @@ struct cov_args {
                                      //            then log|Phi| and a not-positive-definite flag
 };
 
-__device__ inline double lds_matmul(const double *A, const double *Bm, int D, int i, int j, bool act)
+// ---- D x D algebra of ONE wavefront in registers: lane l = (i, j) = (l / D, l % D) owns element
+// (i, j); operands travel by lane permutes (ds_bpermute, no LDS storage, no barriers) ----------
+__device__ inline double lane_get(double v, int src)
+{
+    return __shfl(v, src, 64);
+}
+
+// (A B)[i][j] for this lane; ta / tb: take A / B transposed
+template <int D>
+__device__ __forceinline__ double reg_matmul(double a, double b, int i, int j, bool ta, bool tb)
 {
     double s = 0.0;
-    if (act)
-        for (int k = 0; k < D; ++k) s += A[i * D + k] * Bm[k * D + j];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double x = lane_get(a, ta ? k * D + i : i * D + k);
+        const double y = lane_get(b, tb ? j * D + k : k * D + j);
+        s += x * y;
+    }
     return s;
 }
 
+// in: element (i, j) of an SPD matrix; out: element of the inverse.  Pivot-free Gauss-Jordan,
+// the pivots multiplied into (prod, ex) = mantissa x 2^ex (no logarithm on the serial path).
+template <int D>
+__device__ __forceinline__ double reg_spd_inverse(double v, int i, int j, bool act, double &prod,
+                                                  double &ex, int &bad)
+{
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+        const double piv = lane_get(v, p * D + p);
+        const double ci = lane_get(v, i * D + p), rj = lane_get(v, p * D + j);
+        if (!(piv > 0.0)) bad = 1;
+        const double q = prod * piv;
+        ex += (double)__builtin_amdgcn_frexp_exp(q);
+        prod = __builtin_amdgcn_frexp_mant(q);
+        const double d = fast_recip(piv);
+        if (i == p) v = (j == p) ? d : rj * d;
+        else if (j == p) v = -ci * d;
+        else v = v - ci * rj * d;
+    }
+    return act ? v : 0.0;
+}
+
+// all elements of the two D x D iterates agree within 8 ulp of the largest magnitude
+__device__ inline bool stationary(double a, double b, bool act)
+{
+    double m = act ? fabs(a) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    return __all(!act || fabs(a - b) <= 8.0 * 2.220446049250313e-16 * m);
+}
+
+template <int D>
 __global__ void __launch_bounds__(64)
 lssm_cov_kernel(cov_args a)
 {
-    __shared__ double Ms[64], Es[64], Js[64], Vs[64], Ts[64];
-    const int l = threadIdx.x, D = a.D, T = a.T;
+    const int l = threadIdx.x, T = a.T;
     const bool act = l < D * D;
     const int i = act ? l / D : 0, j = act ? l % D : 0;
     const double e = act ? a.E[i * D + j] : 0.0;
-    Es[l] = e;
-    double ldsum = 0.0;
+    const double dgm = act ? a.Dgm[i * D + j] : 0.0, dgT = act ? a.DgT[i * D + j] : 0.0;
+    double prod = 1.0, ex = 0.0;
     int bad = 0;
     // ---- forward: S_0 = Dg_0; S_t+1 = Dg_t+1 - E^T J_t,  J_t = S_t^-1 E -----------------------
-    // In the interior (0 < t < T-1) every step applies the SAME map to S_t.  Once S_t+1 == S_t
-    // bit for bit the map has reached a fixed point and every later interior step would reproduce
-    // the same S^-1, J and log-pivots exactly: they are filled in without being recomputed.
+    // In the interior (0 < t < T-1) every step applies the SAME map to S_t, a contraction towards
+    // the stationary solution of the filter's Riccati equation.  Once S_t+1 agrees with S_t to
+    // working precision (every element within 8 ulp of the largest element) the sequence has
+    // converged and further steps would only reproduce rounding noise: S^-1, J and the
+    // log-pivots of the remaining interior steps are filled in without being recomputed.
     double s = act ? a.Dg0[i * D + j] : 0.0;
     int fix_from = -1;                 // steps fix_from .. T-2 share one (S^-1, J)
     for (int t = 0; t < T; ++t) {
-        double ld;
-        const double sinv = wave_spd_inverse(s, D, i, j, act, Ms, &ld, &bad);
-        ldsum += ld;
+        double p1 = 1.0, e1 = 0.0;
+        const double sinv = reg_spd_inverse<D>(s, i, j, act, p1, e1, bad);
+        {
+            const double q = prod * p1;
+            ex += e1 + (double)__builtin_amdgcn_frexp_exp(q);
+            prod = __builtin_amdgcn_frexp_mant(q);
+        }
         if (act) a.Sinv[(int64_t)t * D * D + l] = sinv;
         if (t < T - 1) {
-            Ms[l] = sinv;
-            lds_fence();
-            const double jt = lds_matmul(Ms, Es, D, i, j, act);       // S^-1 E
+            const double jt = reg_matmul<D>(sinv, e, i, j, false, false);      // S^-1 E
             if (act) a.J[(int64_t)t * D * D + l] = jt;
-            Js[l] = jt;
-            lds_fence();
-            // (E^T J)[i][j] = sum_k E[k][i] J[k][j]
-            double ej = 0.0;
-            if (act)
-                for (int k = 0; k < D; ++k) ej += Es[k * D + i] * Js[k * D + j];
-            const double dg = act ? ((t + 1 < T - 1) ? a.Dgm[i * D + j] : a.DgT[i * D + j]) : 0.0;
-            const double snew = dg - ej;
-            lds_fence();
-            // fixed point inside the interior: steps t+1 .. T-2 repeat this one
-            if (t >= 1 && t + 1 < T - 1 && __all(!act || snew == s)) {
+            const double ej = reg_matmul<D>(e, jt, i, j, true, false);         // E^T J
+            const double snew = ((t + 1 < T - 1) ? dgm : dgT) - ej;
+            if (t >= 1 && t + 1 < T - 1 && stationary(snew, s, act)) {
                 const int t1 = T - 2;                                   // last interior step
                 for (int tt = t + 1; tt <= t1; ++tt) {
                     if (act) {
@@ -165,51 +205,54 @@ lssm_cov_kernel(cov_args a)
                         a.J[(int64_t)tt * D * D + l] = jt;
                     }
                 }
-                ldsum += (double)(t1 - t) * ld;
+                // (t1 - t) more copies of this step's pivots
+                ex += (double)(t1 - t) * (e1 + log2(p1));
                 fix_from = t;
-                // S_T-1 = Dg_T-1 - E^T J_T-2 (J_T-2 == jt)
-                s = (act ? a.DgT[i * D + j] : 0.0) - ej;
+                s = dgT - ej;                                            // S_T-1
                 t = t1;
                 continue;
             }
             s = snew;
         }
     }
+    const double ldsum = (log(prod) + ex * 0.69314718055994530942);
     // ---- backward: V_T-1 = S_T-1^-1;  C_t = -J_t V_t+1;  V_t = S_t^-1 - C_t J_t^T -----------------
     double v = act ? a.Sinv[(int64_t)(T - 1) * D * D + l] : 0.0;
     double sv = v, sc = 0.0;
     const double vlast = v;
     double vprev = 0.0, cprev = 0.0;
-    int have_prev = 0;
+    int bfix = -1, have_prev = 0;
+    double jn = (T >= 2 && act) ? a.J[(int64_t)(T - 2) * D * D + l] : 0.0;
+    double sn = (T >= 2 && act) ? a.Sinv[(int64_t)(T - 2) * D * D + l] : 0.0;
     for (int t = T - 2; t >= 0; --t) {
-        const double jt = act ? a.J[(int64_t)t * D * D + l] : 0.0;
-        const double si = act ? a.Sinv[(int64_t)t * D * D + l] : 0.0;
-        // same (S^-1, J) as the step before and the same V_t+1 as that step saw: the same V, C
+        const double jt = jn, si = sn;
+        if (t > 0) {                                   // next step's operands: off the serial path
+            jn = act ? a.J[(int64_t)(t - 1) * D * D + l] : 0.0;
+            sn = act ? a.Sinv[(int64_t)(t - 1) * D * D + l] : 0.0;
+        }
+        // same (S^-1, J) as the step before and a V_t+1 that has stopped moving: the same V, C
         // again, down to the first step of the stationary stretch
         if (have_prev && fix_from >= 0 && t >= fix_from && t + 1 <= T - 2
-            && __all(!act || v == vprev)) {
+            && stationary(v, vprev, act)) {
             const double cnt = (double)(t - fix_from + 1);
             sv += cnt * v;
             sc += cnt * cprev;
+            bfix = t;
             t = fix_from;
+            if (t > 0) {
+                jn = act ? a.J[(int64_t)(t - 1) * D * D + l] : 0.0;
+                sn = act ? a.Sinv[(int64_t)(t - 1) * D * D + l] : 0.0;
+            }
             continue;
         }
-        Vs[l] = v;
-        Js[l] = jt;
-        lds_fence();
-        const double c = -lds_matmul(Js, Vs, D, i, j, act);           // Cov(x_t, x_t+1)
-        Ts[l] = c;
-        lds_fence();
-        double cj = 0.0;                                               // (C J^T)[i][j] = sum_k C[i][k] J[j][k]
-        if (act)
-            for (int k = 0; k < D; ++k) cj += Ts[i * D + k] * Js[j * D + k];
+        const double c = -reg_matmul<D>(jt, v, i, j, false, false);          // Cov(x_t, x_t+1)
+        const double cj = reg_matmul<D>(c, jt, i, j, false, true);           // C J^T
         vprev = v;
         v = si - cj;
         have_prev = 1;
         cprev = c;
         sv += v;
         sc += c;
-        lds_fence();
     }
     if (act) {
         a.sums[0 * D * D + l] = sv;
@@ -220,6 +263,9 @@ lssm_cov_kernel(cov_args a)
     if (l == 0) {
         a.sums[5 * D * D + 0] = ldsum;
         a.sums[5 * D * D + 1] = (double)bad;
+        // diagnostics: the steps at which the forward / backward maps became stationary (-1: never)
+        a.sums[5 * D * D + 2] = (double)fix_from;
+        a.sums[5 * D * D + 3] = (double)bfix;
     }
 }
 
@@ -662,7 +708,7 @@ inline void fill_lssm_layout(int D, int M, vmp_lssm_layout *L)
     L->off_ldA = o;      o += D;
     L->off_Dg = o;       o += 4 * DD;
     L->off_h0 = o;       o += D;
-    L->off_covsums = o;  o += 5 * DD + 2;
+    L->off_covsums = o;  o += 5 * DD + 4;
     L->off_raw = o;      o += plen_of(D, M);
     L->len_raw = plen_of(D, M);
     L->off_S = o;        o += 5 * DD + D + (int64_t)M * D;
@@ -728,7 +774,11 @@ int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, cons
     a.Sinv = Sinv;
     a.J = J;
     a.sums = sums;
-    hipLaunchKernelGGL(lssm_cov_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+    switch (D) {
+#define LSSM_COV(d) case d: hipLaunchKernelGGL(lssm_cov_kernel<d>, dim3(1), dim3(64), 0, ctx->stream, a); break;
+        LSSM_COV(1) LSSM_COV(2) LSSM_COV(3) LSSM_COV(4) LSSM_COV(5) LSSM_COV(6) LSSM_COV(7) LSSM_COV(8)
+#undef LSSM_COV
+    }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

@@ -350,10 +350,10 @@ class LSSMPlan:
         D, M, B, T = self.D, self.M, self.B, self.T
         st = self.state
         if given:
-            st[L.off_covsums:L.off_covsums + 5 * D * D + 2].zero_()
+            st[L.off_covsums:L.off_covsums + 5 * D * D + 4].zero_()
         else:
             k.cov(T, D, st[L.off_Dg:L.off_Dg + 4 * D * D], self.Sinv, self.J,
-                  st[L.off_covsums:L.off_covsums + 5 * D * D + 2])
+                  st[L.off_covsums:L.off_covsums + 5 * D * D + 4])
         k.smooth(given, self.Yt, M, B, T, self.BL, D, st[L.off_Cm:], st[L.off_scal + 3:],
                  st[L.off_h0:], self.Sinv, self.J, self.Z, st[L.off_raw:], self.ws)
         self._reduce(st[L.off_raw:L.off_raw + int(L.len_raw)])
@@ -535,4 +535,7 @@ class LSSMPlan:
         if not t:
             return None
         n = float(len(t))
-        return dict(lssm_forward=sum(a for a, _ in t) / n, lssm_backward=sum(b for _, b in t) / n)
+        L, D = self.layout, self.D
+        fix = self.state[L.off_covsums + 5 * D * D + 2:L.off_covsums + 5 * D * D + 4].cpu().numpy()
+        return dict(lssm_forward=sum(a for a, _ in t) / n, lssm_backward=sum(b for _, b in t) / n,
+                    cov_stationary_from=[int(fix[0]), int(fix[1])])

@@ -326,7 +326,7 @@ typedef struct vmp_lssm_layout {
     int64_t off_Am, off_AA, off_ldA;        /* D*D <a_i>, D*D*D <a_i a_i^T>, D log|Cov_A_i|        */
     int64_t off_Dg;       /* 4*D*D: diagonal blocks of the chain precision (t=0, inner, last), E   */
     int64_t off_h0;       /* D: Lam0 mu0                                                           */
-    int64_t off_covsums;  /* 5*D*D+2: output of vmp_lssm_cov                                       */
+    int64_t off_covsums;  /* 5*D*D+4: output of vmp_lssm_cov                                       */
     int64_t off_raw, len_raw;  /* mean-part plate sums of vmp_lssm_smooth (what ranks all-reduce)  */
     int64_t off_S;        /* Sxx | Spp | Snn | Snp | S00 (D*D each) | s0 (D) | Syx (M*D)           */
     int64_t off_scal;     /* 8: [0] sum y^2 [1] log|Phi| [2] status [3] <tau> of the last X pass
@@ -350,7 +350,7 @@ int32_t vmp_lssm_relayout_y(vmp_ctx *ctx, const double *Y, int32_t M, int64_t B,
 int32_t vmp_lssm_x_layout(vmp_ctx *ctx, double *X, int32_t D, int64_t B, int32_t T, int64_t BL,
                           double *Z, int32_t to_time_major);
 /* The shared D x D recursion over T.  Dg0 / Dgm / DgT: diagonal blocks of the precision at t = 0,
- * 0 < t < T-1, t = T-1; E = Phi[t, t+1].  Out: Sinv (T,D,D), J (T-1,D,D), sums (5 D^2 + 2). */
+ * 0 < t < T-1, t = T-1; E = Phi[t, t+1].  Out: Sinv (T,D,D), J (T-1,D,D), sums (5 D^2 + 4). */
 int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
                      const double *DgT, const double *E, double *Sinv, double *J, double *sums);
 /* Forward + backward vector recursions of all sequences and their plate sums (given != 0: the
