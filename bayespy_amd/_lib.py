@@ -129,6 +129,8 @@ SIGNATURES = {
     'vmp_mpca_x_begin': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp]),
     'vmp_mpca_x_chunk': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_i32, c_f64, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_mpca_x_pass': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_i32, c_i32, c_f64, c_vp, c_vp,
+                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_mpca_update_w': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     'vmp_mpca_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_f64, c_f64, c_f64, c_f64, c_f64, c_i32,
                                    P(c_i32), c_vp]),

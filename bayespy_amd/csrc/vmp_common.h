@@ -26,6 +26,9 @@ struct vmp_ctx {
     hipEvent_t ev_xfork, ev_xdone;
     int x_pending;
     int xs_cus;                // compute units the plate stream may use
+    // streams / events of the pipelined plate pass of the missing-data PCA block (vmp_mpca.hip)
+    hipStream_t ms[3];
+    hipEvent_t me[8];
     // RCCL communicator (vmp_comm.hip); null = a world of one rank
     void *comm;
     int comm_rank, comm_world;

@@ -67,6 +67,8 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     ctx->ev_xfork = ctx->ev_xdone = nullptr;
     ctx->x_pending = 0;
     ctx->xs_cus = 0;
+    for (int i = 0; i < 3; ++i) ctx->ms[i] = nullptr;
+    for (int i = 0; i < 8; ++i) ctx->me[i] = nullptr;
     ctx->comm = nullptr;
     ctx->comm_rank = 0;
     ctx->comm_world = 1;
@@ -88,6 +90,13 @@ int32_t vmp_ctx_destroy(vmp_ctx *ctx)
         (void)hipStreamSynchronize(ctx->xs);
         (void)hipStreamDestroy(ctx->xs);
     }
+    for (int i = 0; i < 3; ++i)
+        if (ctx->ms[i]) {
+            (void)hipStreamSynchronize(ctx->ms[i]);
+            (void)hipStreamDestroy(ctx->ms[i]);
+        }
+    for (int i = 0; i < 8; ++i)
+        if (ctx->me[i]) (void)hipEventDestroy(ctx->me[i]);
     if (ctx->ev_xfork) (void)hipEventDestroy(ctx->ev_xfork);
     if (ctx->ev_xdone) (void)hipEventDestroy(ctx->ev_xdone);
     delete ctx;
@@ -106,6 +115,8 @@ int32_t vmp_ctx_sync(vmp_ctx *ctx)
     if (!ctx) return VMP_ERR_INVALID;
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->xs) VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->xs));
+    for (int i = 0; i < 3; ++i)
+        if (ctx->ms[i]) VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->ms[i]));
     return VMP_OK;
 }
 

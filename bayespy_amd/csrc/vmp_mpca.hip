@@ -1010,54 +1010,61 @@ int32_t vmp_mpca_prepare(vmp_ctx *ctx, const double *Y, int64_t ldy, const uint8
     return VMP_OK;
 }
 
-// One chunk of X.update() (from_value = 0) or of the statistics of a given <x> (from_value = 1):
-// plates [n0, n0 + nplates), n0 a multiple of 32.  Accumulates the chunk's statistics into
-// state[off_M] and the scalars (first = 1: overwrite, i.e. the first chunk of a pass).
-int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t nplates,
-                         int32_t flags, double x_prec, const double *Ymt,
-                         const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam,
-                         double *XXf, double *state, void *workspace)
+}  // extern "C"
+
+namespace {
+
+struct chunk_streams {
+    hipStream_t sL, sS, sG;          // precision GEMM, sweep, statistics GEMM
+    hipEvent_t eL, eS, eG;           // recorded after each stage (null: one stream, in order)
+    int wgs_lambda, wgs_sweep, wgs_stats;   // workgroups per CU each stage may occupy
+    bool timed;
+};
+
+// One chunk of plates: the three stages on their streams.  With one stream (all three equal, no
+// events) this is the in-order form; with three, the caller pipelines consecutive chunks so that
+// the VALU-bound sweep of chunk c runs beside the MFMA-bound GEMMs of chunks c+1 and c-1.
+int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, int K, int64_t n0,
+                  int64_t nplates, int flags, double x_prec, const double *Ymt,
+                  const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam, double *XXf,
+                  double *state, void *workspace, const chunk_streams &cs)
 {
-    VMP_REQUIRE(ctx, ctx && Ymt && Mb1 && Mb2 && Xm && Lam && XXf && state && workspace,
-                VMP_ERR_INVALID, "null argument");
-    int32_t rc = check_dims(ctx, D, K);
-    if (rc != VMP_OK) return rc;
-    VMP_REQUIRE(ctx, n0 >= 0 && n0 % 32 == 0 && nplates >= 0, VMP_ERR_INVALID,
-                "a chunk starts at a multiple of 32 plates");
-    if (nplates == 0) return VMP_OK;
     const bool first = (flags & VMP_MPCA_FIRST) != 0, inspect = (flags & VMP_MPCA_INSPECT) != 0;
     const bool from_value = (flags & (VMP_MPCA_FROM_VALUE | VMP_MPCA_PRIOR)) != 0;
     const double xx_diag = (flags & VMP_MPCA_PRIOR) ? 1.0 / x_prec : 0.0;
-    const mpca_dims m = make_dims(D, K);
-    vmp_mpca_layout L;
-    fill_layout(D, K, &L);
-    hipStream_t s = ctx->stream;
     const int64_t sub0 = n0 / 16, nsub = (nplates + 15) / 16;
     double *partial = reinterpret_cast<double *>(workspace);
     const int ns = stats_slices(m);
     const int64_t gst_wg = grid_cap(ctx, 2) / ns;
     double *pscal = partial + gst_wg * m.DP * m.LR;
     double *psxx = pscal + grid_cap(ctx, 16) * 4;
-    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
-    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
+    hipEvent_t *ev = (ctx->timing && cs.timed) ? vmp_next_events(ctx) : nullptr;
+    // ---- stage 1: Lam~ = mask^T . panel ---------------------------------------------------------
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], cs.sL));
     if (!from_value) {
         constexpr int NSUB = 2;
         int64_t g = (nsub + NSUB - 1) / NSUB;
-        if (g > grid_cap(ctx, 2)) g = grid_cap(ctx, 2);
-#define MPCA_CASE(db, kt)                                                                       \
-    if (m.DP == 32 * db && m.KT == kt)                                                          \
-        hipLaunchKernelGGL((mpca_lambda_kernel<db, kt, NSUB>), dim3((unsigned)g), dim3(NT), 0, s, \
-                           Ymt, Mb1, state + L.off_panel_x, sub0, nsub, nplates, Lam);          \
+        if (g > grid_cap(ctx, cs.wgs_lambda)) g = grid_cap(ctx, cs.wgs_lambda);
+#define MPCA_CASE(db, kt)                                                                          \
+    if (m.DP == 32 * db && m.KT == kt)                                                             \
+        hipLaunchKernelGGL((mpca_lambda_kernel<db, kt, NSUB>), dim3((unsigned)g), dim3(NT), 0,     \
+                           cs.sL, Ymt, Mb1, state + L.off_panel_x, sub0, nsub, nplates, Lam);      \
     else
         MPCA_FOR_EACH(MPCA_CASE) { return VMP_ERR_UNSUPPORTED; }
 #undef MPCA_CASE
         VMP_HIP_CHECK(ctx, hipGetLastError());
     }
-    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], cs.sL));
+    if (cs.eL) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(cs.eL, cs.sL));
+        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(cs.sS, cs.eL, 0));
+    }
+    // ---- stage 2: per-plate sweep ---------------------------------------------------------------
+    hipStream_t s = cs.sS;
     int nm = vmp_tune_get("mpca_sweep_nm", 1), occ = vmp_tune_get("mpca_sweep_occ", 2);
     if (m.KT == 1 || from_value) { nm = 1; occ = 2; }
     int64_t gs = (nplates + 4 * nm - 1) / (4 * nm);
-    const int64_t gs_cap = grid_cap(ctx, 8);
+    const int64_t gs_cap = grid_cap(ctx, cs.wgs_sweep);
     if (gs > gs_cap) gs = gs_cap;
     if (gs < 1) gs = 1;
 #define MPCA_SWEEP(kt, fv, nmm, oc)                                                                \
@@ -1069,19 +1076,14 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
         else MPCA_SWEEP(1, false, 1, 2);
     } else if (from_value) {
         MPCA_SWEEP(2, true, 1, 2);
-    } else if (nm == 1 && occ == 2) MPCA_SWEEP(2, false, 1, 2);
-    else if (nm == 1 && occ == 3) MPCA_SWEEP(2, false, 1, 3);
-    else if (nm == 1 && occ == 4) MPCA_SWEEP(2, false, 1, 4);
+    } else if (nm == 1 && occ == 3) MPCA_SWEEP(2, false, 1, 3);
     else if (nm == 2 && occ == 1) MPCA_SWEEP(2, false, 2, 1);
     else if (nm == 2 && occ == 2) MPCA_SWEEP(2, false, 2, 2);
-    else if (nm == 2 && occ == 3) MPCA_SWEEP(2, false, 2, 3);
-    else if (nm == 4 && occ == 1) MPCA_SWEEP(2, false, 4, 1);
-    else if (nm == 4 && occ == 2) MPCA_SWEEP(2, false, 4, 2);
     else MPCA_SWEEP(2, false, 1, 2);
 #undef MPCA_SWEEP
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (inspect) return VMP_OK;
-    // tr<xx>, log|Cov|, status
+    // tr<xx>, log|Cov|, status, sum_n <xx>_n
     hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal, (int)gs, (int64_t)3,
                        (int64_t)2, state + L.off_scal + SC_TRXX, first ? 0 : 1);
     hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal + 2, (int)gs, (int64_t)3,
@@ -1091,39 +1093,25 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
                        state + L.off_Sxx, first ? 0 : 1);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
-    hipEvent_t *ev2 = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (cs.eS) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(cs.eS, cs.sS));
+        VMP_HIP_CHECK(ctx, hipStreamWaitEvent(cs.sG, cs.eS, 0));
+    }
+    // ---- stage 3: M_d, r_d --------------------------------------------------------------------------
+    s = cs.sG;
+    hipEvent_t *ev2 = (ctx->timing && cs.timed) ? vmp_next_events(ctx) : nullptr;
     if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[0], s));
-    const int stats_v = vmp_tune_get("mpca_stats_v", 2);
-    if (stats_v == 1) {
-        int64_t gw = gst_wg < nsub ? gst_wg : nsub;
-        if (gw < 1) gw = 1;
-        const dim3 grid((unsigned)(gw * ns));
-#define MPCA_CASE(db, kt)                                                                       \
-    if (m.DP == 32 * db && m.KT == kt)                                                          \
-        hipLaunchKernelGGL((mpca_stats_kernel<db, kt, (kt == 1 ? 5 : TSMAX)>), grid, dim3(NT), 0, s, \
-                           Ymt, Mb2, XXf, Xm, sub0, nsub, n0, ns, partial);                     \
-    else
-        MPCA_FOR_EACH(MPCA_CASE) { return VMP_ERR_UNSUPPORTED; }
-#undef MPCA_CASE
-        VMP_HIP_CHECK(ctx, hipGetLastError());
-        if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[1], s));
-        const int64_t len = (int64_t)m.DP * m.LR;
-        hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((len + NT - 1) / NT)), dim3(NT), 0,
-                           s, partial, (int)gw, len, len, state + L.off_M, first ? 0 : 1);
-        VMP_HIP_CHECK(ctx, hipGetLastError());
-        if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[2], s));
-    } else {
+    {
         // packed columns: column tiles split over the wavefronts; r_d: its own small kernel.
         // Both write disjoint columns of the same per-workgroup partial rows.
         const int ncw = vmp_tune_get("mpca_stats_ncw", 2);
         const int ns2 = (m.PT + 4 * ncw - 1) / (4 * ncw);
         const int64_t npair = (nsub + 1) / 2;
-        int64_t gw = grid_cap(ctx, ncw >= 3 ? 1 : 2) / ns2;
+        int64_t gw = grid_cap(ctx, cs.wgs_stats) / ns2;
         if (gw > gst_wg) gw = gst_wg;
         if (gw > npair) gw = npair;
         if (gw < 1) gw = 1;
         const int64_t len = (int64_t)m.DP * m.LR;
-        VMP_HIP_CHECK(ctx, hipMemsetAsync(partial, 0, (size_t)(gw * len) * sizeof(double), s));
         const dim3 grid((unsigned)(gw * ns2));
 #define MPCA_CASE(db, kt)                                                                       \
     if (m.DP == 32 * db && m.KT == kt) {                                                        \
@@ -1145,6 +1133,105 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
         VMP_HIP_CHECK(ctx, hipGetLastError());
         if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[2], s));
     }
+    if (cs.eG) VMP_HIP_CHECK(ctx, hipEventRecord(cs.eG, cs.sG));
+    return VMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One chunk of X.update() or of the statistics of a given <x>: plates [n0, n0 + nplates), n0 a
+// multiple of 32, in order on the context's stream.
+int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t nplates,
+                         int32_t flags, double x_prec, const double *Ymt,
+                         const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam,
+                         double *XXf, double *state, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Ymt && Mb1 && Mb2 && Xm && Lam && XXf && state && workspace,
+                VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, n0 >= 0 && n0 % 32 == 0 && nplates >= 0, VMP_ERR_INVALID,
+                "a chunk starts at a multiple of 32 plates");
+    if (nplates == 0) return VMP_OK;
+    const mpca_dims m = make_dims(D, K);
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    chunk_streams cs = {ctx->stream, ctx->stream, ctx->stream, nullptr, nullptr, nullptr, 2, 8, 2, true};
+    return run_chunk(ctx, m, L, K, n0, nplates, flags, x_prec, Ymt, Mb1, Mb2, Xm, Lam, XXf, state,
+                     workspace, cs);
+}
+
+// All chunks of one pass over the plates [0, N).  nsets = 1: in order on the context's stream.
+// nsets = 2 (Lam and XXf hold TWO chunks each): consecutive chunks are pipelined over three
+// library streams -- the precision GEMM of chunk c+1 and the statistics GEMM of chunk c-1
+// (matrix cores) run beside the sweep of chunk c (vector ALU); the statistics are accumulated in
+// chunk order on one stream, so the result does not depend on the interleaving.
+int32_t vmp_mpca_x_pass(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t chunk, int32_t nsets,
+                        int32_t flags, double x_prec, const double *Ymt, const uint32_t *Mb1,
+                        const uint32_t *Mb2, double *Xm, double *Lam, double *XXf, double *state,
+                        void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Ymt && Mb1 && Mb2 && Xm && Lam && XXf && state && workspace,
+                VMP_ERR_INVALID, "null argument");
+    int32_t rc = check_dims(ctx, D, K);
+    if (rc != VMP_OK) return rc;
+    VMP_REQUIRE(ctx, N >= 0 && chunk >= 32 && chunk % 32 == 0 && (nsets == 1 || nsets == 2),
+                VMP_ERR_INVALID, "bad chunking");
+    const mpca_dims m = make_dims(D, K);
+    vmp_mpca_layout L;
+    fill_layout(D, K, &L);
+    const int64_t lam_n = chunk * m.LR, xxf_n = ((chunk + 7) / 8) * m.PT * 128;
+    const bool pipelined = nsets == 2 && N > chunk && !(flags & VMP_MPCA_INSPECT)
+                           && vmp_tune_get("mpca_streams", 1) != 0;
+    if (!pipelined) {
+        chunk_streams cs = {ctx->stream, ctx->stream, ctx->stream, nullptr, nullptr, nullptr, 2, 8, 2, true};
+        int f = flags | VMP_MPCA_FIRST;
+        for (int64_t n0 = 0; n0 < (N > 0 ? N : 1); n0 += chunk) {
+            const int64_t npl = (N - n0) < chunk ? (N - n0) : chunk;
+            rc = run_chunk(ctx, m, L, K, n0, npl, f, x_prec, Ymt, Mb1, Mb2, Xm, Lam, XXf, state,
+                           workspace, cs);
+            if (rc != VMP_OK) return rc;
+            f = flags & ~VMP_MPCA_FIRST;
+        }
+        return VMP_OK;
+    }
+    // three streams, two scratch sets
+    if (!ctx->ms[0]) {
+        for (int i = 0; i < 3; ++i)
+            VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->ms[i], hipStreamNonBlocking));
+        for (int i = 0; i < 8; ++i)
+            VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->me[i], hipEventDisableTiming));
+    }
+    hipEvent_t eStart = ctx->me[6], eEnd = ctx->me[7];
+    VMP_HIP_CHECK(ctx, hipEventRecord(eStart, ctx->stream));
+    for (int i = 0; i < 3; ++i) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[i], eStart, 0));
+    int f = flags | VMP_MPCA_FIRST;
+    int64_t c = 0;
+    for (int64_t n0 = 0; n0 < N; n0 += chunk, ++c) {
+        const int64_t npl = (N - n0) < chunk ? (N - n0) : chunk;
+        const int set = (int)(c & 1);
+        hipEvent_t eL = ctx->me[0 + set], eS = ctx->me[2 + set], eG = ctx->me[4 + set];
+        if (c >= 2) {
+            // Lam[set] is free once the sweep of chunk c-2 has read it; XXf[set] once the
+            // statistics of chunk c-2 have
+            VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[0], eS, 0));
+            VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[1], eG, 0));
+        }
+        chunk_streams cs = {ctx->ms[0], ctx->ms[1], ctx->ms[2], eL, eS, eG,
+                            vmp_tune_get("mpca_lambda_wgs", 1), vmp_tune_get("mpca_sweep_wgs", 4),
+                            vmp_tune_get("mpca_stats_wgs", 1), false};
+        rc = run_chunk(ctx, m, L, K, n0, npl, f, x_prec, Ymt, Mb1, Mb2, Xm, Lam + set * lam_n,
+                       XXf + set * xxf_n, state, workspace, cs);
+        if (rc != VMP_OK) return rc;
+        f = flags & ~VMP_MPCA_FIRST;
+    }
+    // the caller's stream continues after the last sweep and the last statistics
+    VMP_HIP_CHECK(ctx, hipEventRecord(eEnd, ctx->ms[1]));
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, eEnd, 0));
+    VMP_HIP_CHECK(ctx, hipEventRecord(eEnd, ctx->ms[2]));
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, eEnd, 0));
     return VMP_OK;
 }
 

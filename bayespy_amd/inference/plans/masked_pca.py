@@ -66,6 +66,11 @@ class MaskedHIPKernels:
             self.ctx, D, K, n0, nplates, flags, x_prec, ptr(Ymt), ptr(Mb1), ptr(Mb2), ptr(Xm),
             ptr(Lam), ptr(XXf), ptr(state), ptr(ws)))
 
+    def x_pass(self, D, K, N, chunk, nsets, flags, x_prec, Ymt, Mb1, Mb2, Xm, Lam, XXf, state, ws):
+        self.rt.check(self.lib.vmp_mpca_x_pass(
+            self.ctx, D, K, N, chunk, nsets, flags, x_prec, ptr(Ymt), ptr(Mb1), ptr(Mb2), ptr(Xm),
+            ptr(Lam), ptr(XXf), ptr(state), ptr(ws)))
+
     def update_w(self, D, K, mode, state):
         self.rt.check(self.lib.vmp_mpca_update_w(self.ctx, D, K, mode, ptr(state)))
 
@@ -224,8 +229,10 @@ class MaskedPCAPlan:
         self.Mb2 = torch.empty(int(sz.mask_words), dtype=torch.int32, device=rt.device)
         self.Xm = rt.zeros(int(sz.xm_doubles)).view(-1, self.KP)
         # the scratch must hold finite values everywhere: pad plates are read with a zero mask
-        self.Lam = rt.zeros(int(sz.lam_doubles))
-        self.XXf = rt.zeros(int(sz.xxf_doubles))
+        # two chunks of scratch when the pass has several chunks: they are pipelined (x_pass)
+        self.nsets = 2 if N > self.chunk_eff else 1
+        self.Lam = rt.zeros(self.nsets * int(sz.lam_doubles))
+        self.XXf = rt.zeros(self.nsets * int(sz.xxf_doubles))
         k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)
         k.prepare(Yd, ldy, Md, N, N, D, K, self.Ymt, self.Mb1, self.Mb2, self.state, self.ws)
         del Md
@@ -285,12 +292,8 @@ class MaskedPCAPlan:
         """All chunks of the plate; then the statistics are summed over ranks."""
         k, L = self.kernels, self.layout
         D, N, K = self.D, self.N, self.K
-        first = FIRST
-        for n0 in range(0, max(N, 1), self.chunk_eff):
-            npl = min(self.chunk_eff, N - n0)
-            k.x_chunk(D, K, n0, npl, flags | first, self.x_prec, self.Ymt, self.Mb1, self.Mb2,
-                      self.Xm, self.Lam, self.XXf, self.state, self.ws)
-            first = 0
+        k.x_pass(D, K, N, self.chunk_eff, self.nsets, flags, self.x_prec, self.Ymt, self.Mb1,
+                 self.Mb2, self.Xm, self.Lam, self.XXf, self.state, self.ws)
         if self.sharded:
             self._reduce(self.state[L.off_M:L.off_M + int(L.DP) * self.LR])
             self._reduce(self.state[L.off_scal + SC_TRXX:L.off_scal + SC_LDX + 1])

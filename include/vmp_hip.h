@@ -298,6 +298,15 @@ int32_t vmp_mpca_x_chunk(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n0, int64_t
                          int32_t flags, double x_prec, const double *Ymt,
                          const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam,
                          double *XXf, double *state, void *workspace);
+/* All chunks of one pass over the plates [0, N) (flags as above, VMP_MPCA_FIRST implied).
+ * nsets = 1: Lam / XXf hold one chunk, the chunks run in order on the context's stream.
+ * nsets = 2: they hold two chunks each and consecutive chunks are pipelined over three library
+ * streams: the matrix-core GEMMs of the neighbouring chunks run beside the vector-ALU-bound sweep
+ * of a chunk.  The statistics accumulate in chunk order either way (identical results). */
+int32_t vmp_mpca_x_pass(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t chunk,
+                        int32_t nsets, int32_t flags, double x_prec, const double *Ymt,
+                        const uint32_t *Mb1, const uint32_t *Mb2, double *Xm, double *Lam,
+                        double *XXf, double *state, void *workspace);
 /* W.update() (mode 0); mode 1: delta moments of the <w_d> in state[off_W]; mode 2: prior. */
 int32_t vmp_mpca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int32_t mode, double *state);
 /* tau.update(), alpha.update(), the lower bound terms: a list of vmp_mpca_op, one launch. */

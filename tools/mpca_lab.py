@@ -1,14 +1,15 @@
 #!/usr/bin/env python
-"""A/B harness of the three plate kernels of the fused missing-data PCA block (one chunk of plates,
-same data, every variant in ONE process): python tools/mpca_lab.py [N=1048576] [D=128] [K=32]"""
+"""A/B harness of the plate pass of the fused missing-data PCA block (same data, every variant in
+ONE process): python tools/mpca_lab.py [N=4194304] [D=128] [K=32]"""
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
     D = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     import torch
@@ -24,41 +25,46 @@ def main():
     y = w @ x + 0.1 * torch.randn(D, N, generator=g, device=dev, dtype=torch.float64)
     mask = torch.rand(D, N, generator=g, device=dev) >= 0.1
     x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
-    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
-    W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
-    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
-    F = SumMultiply('i,i', W, X, name='F')
-    tau = Gamma(1e-2, 1e-2, name='tau')
-    Y = GaussianARD(F, tau, name='Y')
-    X.initialize_from_value(x0[None])
-    Y.observe(y, mask=mask)
-    Q = VB(Y, F, W, X, tau, alpha)
-    Q.ignore_bound_checks = True
-    plan = Q.plans[0]
-    Q.update(repeat=2, verbose=False)
-    L_ref = Q.L[1]
-    plan.enable_timing(True)
-    variants = [dict(mpca_sweep_nm=1, mpca_sweep_occ=2), dict(mpca_sweep_nm=1, mpca_sweep_occ=3),
-                dict(mpca_sweep_nm=1, mpca_sweep_occ=4), dict(mpca_sweep_nm=2, mpca_sweep_occ=1),
-                dict(mpca_sweep_nm=2, mpca_sweep_occ=2), dict(mpca_sweep_nm=2, mpca_sweep_occ=3),
-                dict(mpca_sweep_nm=4, mpca_sweep_occ=1), dict(mpca_sweep_nm=4, mpca_sweep_occ=2)]
-    extra = [dict(mpca_stats_v=1), dict(mpca_stats_v=2, mpca_stats_ncw=2),
-             dict(mpca_stats_v=2, mpca_stats_ncw=3)]
-    print('N=%d D=%d K=%d one chunk; ms per chunk' % (N, D, K))
-    for rnd in range(2):
-        for v in variants + extra:
-            for k, val in v.items():
-                rt.lib.vmp_tune_set(k.encode(), val)
-            for _ in range(3):
-                X.update()
-            torch.cuda.synchronize()
-            t = plan.kernel_times_ms()
-            if rnd:
-                print('%-46s lambda %.3f  sweep %.3f  stats %.3f' % (v, t['mpca_lambda'],
-                                                                    t['mpca_sweep'], t['mpca_stats']))
-    # every variant must leave the same state behind: the bound after one more iteration
-    Q.update(repeat=1, verbose=False)
-    print('L after the variants: %r (second iteration was %r)' % (Q.L[2], L_ref))
+    del x
+
+    def build(chunk):
+        os.environ['BAYESPY_AMD_MPCA_CHUNK'] = str(chunk)
+        alpha = Gamma(1e-2, 1e-2, plates=(K,))
+        W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
+        X = GaussianARD(0, 1, shape=(K,), plates=(1, N))
+        F = SumMultiply('i,i', W, X)
+        tau = Gamma(1e-2, 1e-2)
+        Y = GaussianARD(F, tau)
+        X.initialize_from_value(x0[None])
+        Y.observe(y, mask=mask)
+        Q = VB(Y, F, W, X, tau, alpha)
+        Q.ignore_bound_checks = True
+        return Q, X
+
+    variants = [
+        (1 << 20, dict(mpca_streams=0)),
+        (1 << 20, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=4, mpca_stats_wgs=1)),
+        (1 << 18, dict(mpca_streams=0)),
+        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=4, mpca_stats_wgs=1)),
+        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=2, mpca_stats_wgs=1)),
+        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=2, mpca_sweep_wgs=8, mpca_stats_wgs=2)),
+        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=8, mpca_stats_wgs=1)),
+        (1 << 17, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=4, mpca_stats_wgs=1)),
+    ]
+    print('N=%d D=%d K=%d; ms per X.update() and bound after two iterations' % (N, D, K))
+    for chunk, knobs in variants:
+        for k, val in knobs.items():
+            rt.lib.vmp_tune_set(k.encode(), val)
+        Q, X = build(chunk)
+        Q.update(repeat=2, verbose=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            X.update()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / 3
+        print('chunk %8d %-78s %8.2f ms   L=%r' % (chunk, knobs, 1e3 * dt, Q.L[1]))
+        del Q, X
 
 
 if __name__ == '__main__':
