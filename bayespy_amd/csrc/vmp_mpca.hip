@@ -305,21 +305,27 @@ __device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const dou
                 const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
                 T[tr][tc][r] = (i < K && j < K) ? -T[tr][tc][r] : T[tr][tc][r];
             }
-    // x^T = rhs^T Cov: the tiles are B operands as they are (rows l4 + 4r), rhs enters through
-    // row 0 of the A operand
-    v4f64 xa[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    // x = Cov rhs on the vector ALU: this lane holds rows {16 tr + 4 r + l4} of the columns
+    // {l15, 16 + l15}; eight products per column, then the four lane groups (l4) are summed with
+    // two lane exchanges.  (On the matrix core the same product takes 16 MFMAs with one useful
+    // row of 16 each.)
+    double p0 = 0.0, p1 = 0.0;
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = 16 * tr + 4 * r + l4;
-            const double a = (l15 == 0 && m < K) ? scale * pb[m] : 0.0;
-            xa[0] = mfma(a, T[tr][0][r], xa[0]);
-            xa[1] = mfma(a, T[tr][1][r], xa[1]);
+            const double h = (m < K) ? scale * pb[m] : 0.0;
+            p0 += h * T[tr][0][r];
+            p1 += h * T[tr][1][r];
         }
+    p0 += __shfl_xor(p0, 16, 64);
+    p1 += __shfl_xor(p1, 16, 64);
+    p0 += __shfl_xor(p0, 32, 64);
+    p1 += __shfl_xor(p1, 32, 64);
     plate_result res;
-    res.x0 = (l4 == 0) ? xa[0][0] : 0.0;
-    res.x1 = (l4 == 0) ? xa[1][0] : 0.0;
+    res.x0 = (l4 == 0) ? p0 : 0.0;
+    res.x1 = (l4 == 0) ? p1 : 0.0;
     T[0][0] = mfma(res.x0, res.x0, T[0][0]);
     T[0][1] = mfma(res.x0, res.x1, T[0][1]);
     T[1][0] = mfma(res.x1, res.x0, T[1][0]);

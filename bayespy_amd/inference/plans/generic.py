@@ -826,9 +826,15 @@ class SumMultiplyFamily:
 
     def __init__(self, node):
         self.node = node
-        for p in node.parents:
-            if isinstance(p, Constant):
-                raise NotImplementedError('constant parents of SumMultiply')
+
+    def constant_moments(self, index, value):
+        """Delta moments [x, x x^T] of a numeric parent over its key axes (dot.py:186-197,
+        gaussian.py:74-84)."""
+        x = _arr(value)
+        nd = len(self.node.in_keys[index])
+        if nd == 0:
+            return [x, fuse(lambda v: v * v, x)]
+        return [x, linalg.outer(x, x, ndim=nd)]
 
     def _labels(self, plan_plates):
         n = self.node

@@ -229,8 +229,12 @@ class MaskedPCAPlan:
         self.Mb2 = torch.empty(int(sz.mask_words), dtype=torch.int32, device=rt.device)
         self.Xm = rt.zeros(int(sz.xm_doubles)).view(-1, self.KP)
         # the scratch must hold finite values everywhere: pad plates are read with a zero mask
-        # two chunks of scratch when the pass has several chunks: they are pipelined (x_pass)
-        self.nsets = 2 if N > self.chunk_eff else 1
+        # one chunk of scratch: the chunks of a pass run in order.  (Two sets + three streams,
+        # vmp_mpca_x_pass with nsets = 2, pipeline the GEMMs of neighbouring chunks beside the
+        # sweep; measured on MI355X it is 5-10 % SLOWER than in order -- the three kernels
+        # compete for the same issue slots -- so it stays an opt-in for experiments.)
+        self.nsets = 2 if (N > self.chunk_eff
+                           and os.environ.get('BAYESPY_AMD_MPCA_PIPELINE') == '1') else 1
         self.Lam = rt.zeros(self.nsets * int(sz.lam_doubles))
         self.XXf = rt.zeros(self.nsets * int(sz.xxf_doubles))
         k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)

@@ -53,7 +53,11 @@ class SumMultiply(Node):
         # a Gaussian Markov chain parent is seen through its Gaussian view (moment
         # converter search of the reference, node.py:110-179)
         from .gaussian_markov_chain import GaussianMarkovChain
+        from .node import GaussianConstant
         nodes = [n.as_gaussian() if isinstance(n, GaussianMarkovChain) else n for n in nodes]
+        # numeric parents: constants with the delta moments of a Gaussian (dot.py:186-197)
+        nodes = [n if isinstance(n, Node) else GaussianConstant(n, len(k))
+                 for n, k in zip(nodes, in_keys)]
         super().__init__(*nodes, plates=(), dims=((), ()), name=name)
         self.in_keys = in_keys
         self.out_keys = out_keys

@@ -124,6 +124,22 @@ class Constant(Node):
         return [self.value]
 
 
+class GaussianConstant(Constant):
+    """A numeric array standing in for a Gaussian-moment parent: the reference wraps it in a
+    constant node with DeltaMoments of GaussianMoments (node.py:110-179, gaussian.py:35-84):
+    moments [x, x x^T] over the last ``ndim`` axes, the leading axes are plates."""
+
+    def __init__(self, value, ndim, name=None):
+        super().__init__(value, name=name)
+        shp = self.value.shape
+        if ndim > len(shp):
+            raise ValueError('Array of shape %s has fewer than %d variable axes' % (shp, ndim))
+        tail = tuple(shp[len(shp) - ndim:]) if ndim else ()
+        self.plates = tuple(shp[:len(shp) - ndim])
+        self.dims = (tail, tail + tail)
+        self.ndim = ndim
+
+
 def ensure_node(x):
     """Numeric arguments become Constant nodes (node.py:360-376)."""
     if isinstance(x, Node):

@@ -857,3 +857,54 @@ def make_seeded_pca(seed, N, D, K):
     y = w @ x.T + 0.1 * rs.normal(size=(D, N))
     x0 = rs.normal(0, 1, (N, K))
     return y, x0
+
+
+# ---------------------------------------------------------------------------------------------
+# numeric arrays as Gaussian-moment parents of SumMultiply / Dot (dot.py:186-197: the reference
+# wraps them in constants with delta moments); shared by oracle/make_golden.py and the tests
+# ---------------------------------------------------------------------------------------------
+def make_constant_parent_inputs(rs):
+    N, K = 40, 3
+    c = rs.normal(size=(N, K))                       # known regressors
+    w = rs.normal(size=K)
+    y = c @ w + 0.2 * rs.normal(size=N)
+    d = rs.normal(size=(5, 1, K))
+    y2 = np.einsum('mik,nk->mn', d, c) + 0.1 * rs.normal(size=(5, N))
+    return dict(c=c, y=y, d=d, y2=y2)
+
+
+def run_constant_parent_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    res = {}
+    c, y = g['c'], g['y']
+    N, K = c.shape
+    # (a) Bayesian linear regression with known inputs: F = Dot(w, c)
+    alpha = nodes_mod.Gamma(1e-3, 1e-3, plates=(K,), name='alpha')
+    w = nodes_mod.GaussianARD(0, alpha, shape=(K,), name='w')
+    F = nodes_mod.SumMultiply('i,i', w, c, name='F')
+    tau = nodes_mod.Gamma(1e-3, 1e-3, name='tau')
+    Y = nodes_mod.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = vb_cls(Y, w, alpha, tau, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=5, verbose=False)
+    res['lr_L'] = np.array(Q.L[:Q.iter])
+    res['lr_w_u0'], res['lr_w_u1'] = np.array(w.u[0]), np.array(w.u[1])
+    res['lr_tau_u0'], res['lr_alpha_u0'] = np.array(tau.u[0]), np.array(alpha.u[0])
+    res['lr_F_u0'], res['lr_F_u1'] = np.array(F.get_moments()[0]), np.array(F.get_moments()[1])
+    # (b) a constant in the middle of a three-factor product with an output key
+    d, y2 = g['d'], g['y2']
+    M = d.shape[0]
+    z = nodes_mod.GaussianARD(0, 1, shape=(K,), plates=(M, 1), name='z')
+    s = nodes_mod.GaussianARD(1, 1, plates=(1, N), name='s')
+    F2 = nodes_mod.SumMultiply('i,i,', z, c, s, name='F2')
+    tau2 = nodes_mod.Gamma(1e-3, 1e-3, name='tau2')
+    Y2 = nodes_mod.GaussianARD(F2, tau2, name='Y2')
+    z.initialize_from_value(d)
+    Y2.observe(y2)
+    Q2 = vb_cls(Y2, z, s, tau2, **vb_kwargs)
+    Q2.ignore_bound_checks = True
+    Q2.update(repeat=4, verbose=False)
+    res['tp_L'] = np.array(Q2.L[:Q2.iter])
+    res['tp_z_u0'], res['tp_s_u0'] = np.array(z.u[0]), np.array(s.u[0])
+    res['tp_s_u1'] = np.array(s.u[1])
+    return res
