@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Secondary measurement: BASELINE.json config 5 shape (linear state-space model,
-GaussianMarkovChain + SumMultiply, T time steps x B sequences) on the generic device
-engine with the batched smoother kernels.  Prints one JSON line.
+GaussianMarkovChain + SumMultiply, T time steps x B sequences) on the fused state-space block
+(vmp_lssm_*; BAYESPY_AMD_ENGINE=generic selects the generic engine with the batched smoother
+kernels).  Prints one JSON line; `python bench.py --config lssm` is the same measurement.
 
 Multi-GPU (config 5 is quoted on 8 GPUs): launch with ``python -m torch.distributed.run
 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_lssm.py --b 100000``; the B sequences
