@@ -197,6 +197,33 @@ __device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool ac
 // ---------------------------------------------------------------------------
 // Wavefront (64 lanes) and workgroup reductions, fixed order => deterministic.
 // ---------------------------------------------------------------------------
+// exp(x) for x <= 0 (softmax arguments after subtracting the maximum; -inf allowed): the
+// library routine spends a third of its instructions on overflow / special-case handling that
+// cannot occur here, and on this chip fp64 VALU work is not hidden behind fp64 MFMA work (both
+// run on the same fp64 units).  Cody-Waite reduction by ln 2, degree-12 Taylor polynomial on
+// |r| <= ln2/2 (truncation 2e-16 relative), scaling by ldexp (underflows to 0 by itself).
+__device__ __forceinline__ double exp_nonpos(double x)
+{
+    x = fmax(x, -800.0);
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
 __device__ inline double wave_sum(double v)
 {
 #pragma unroll

@@ -311,6 +311,163 @@ sum_multiply_column_kernel(Iter it, int nsplit, double *__restrict__ partial)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Dense two-axis forms.  After merging, many plate sums and row contractions of the engine are
+// a product of operands over a [outer][inner] index space in which every operand is either
+// dense ([outer][inner] contiguous), a vector along one of the two axes, or a scalar, and
+// `inner` is a power of two: the messages to plate-less parents (sum over N of (N, K) or
+// (N, K, K) arrays times per-plate weights), traces and row dot products.  Lanes then run over
+// the flat index in PAIRS (16-byte loads, four in flight per lane), a lane's inner position
+// never changes, and no index is ever divided.
+//   class 0: dense   in[o * inner + i]      class 1: per-outer vector  in[o]
+//   class 2: per-inner vector  in[i]        class 3: scalar            in[0]
+// ---------------------------------------------------------------------------
+struct Dense2D {
+    const double *in[MAXIN];
+    int cls[MAXIN];
+    int nin, inner;
+    int64_t outer;
+};
+
+constexpr int D2_U = 4;
+
+// reduce over OUTER (column sums): partial[block][inner]
+__global__ void __launch_bounds__(NT)
+sum_multiply_colsum_kernel(Dense2D a, double *__restrict__ partial)
+{
+    __shared__ double red[NT][2];
+    const int tid = threadIdx.x;
+    const int half = a.inner >> 1;                 // pairs per row, a power of two <= NT
+    const int kp = tid & (half - 1);
+    const int rb = NT / half;                      // rows a workgroup covers per load round
+    const int rt = tid / half;
+    // factors that do not depend on the row
+    double c0 = 1.0, c1 = 1.0;
+    const double *pf[MAXIN];
+#pragma unroll
+    for (int i = 0; i < MAXIN; ++i) {
+        pf[i] = nullptr;
+        if (i < a.nin) {
+            if (a.cls[i] == 2) {
+                const v2f64 q = *reinterpret_cast<const v2f64 *>(a.in[i] + 2 * kp);
+                c0 *= q[0];
+                c1 *= q[1];
+            } else if (a.cls[i] == 3) {
+                c0 *= a.in[i][0];
+                c1 *= a.in[i][0];
+            } else {
+                pf[i] = a.in[i] + (a.cls[i] == 0 ? 2 * kp : 0);
+            }
+        }
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    const int64_t rstep = (int64_t)gridDim.x * rb * D2_U;
+    for (int64_t r0 = (int64_t)blockIdx.x * rb * D2_U + rt; r0 < a.outer; r0 += rstep) {
+        double p0[D2_U], p1[D2_U];
+#pragma unroll
+        for (int u = 0; u < D2_U; ++u) {
+            const int64_t r = r0 + (int64_t)u * rb;
+            const bool ok = r < a.outer;
+            const int64_t rr = ok ? r : 0;
+            double x0 = ok ? 1.0 : 0.0, x1 = x0;
+#pragma unroll
+            for (int i = 0; i < MAXIN; ++i) {
+                if (i < a.nin && pf[i]) {
+                    if (a.cls[i] == 0) {
+                        const v2f64 q = __builtin_nontemporal_load(
+                            reinterpret_cast<const v2f64 *>(pf[i] + rr * a.inner));
+                        x0 *= q[0];
+                        x1 *= q[1];
+                    } else {
+                        const double w = pf[i][rr];
+                        x0 *= w;
+                        x1 *= w;
+                    }
+                }
+            }
+            p0[u] = x0;
+            p1[u] = x1;
+        }
+#pragma unroll
+        for (int u = 0; u < D2_U; ++u) {
+            acc0 += p0[u];
+            acc1 += p1[u];
+        }
+    }
+    red[tid][0] = acc0 * c0;
+    red[tid][1] = acc1 * c1;
+    __syncthreads();
+    for (int k = tid; k < a.inner; k += NT) {
+        double v = 0.0;
+        for (int j = 0; j < rb; ++j) v += red[j * half + (k >> 1)][k & 1];   // fixed order
+        partial[(int64_t)blockIdx.x * a.inner + k] = v;
+    }
+}
+
+// reduce over INNER (row sums): out[o * ostride] = scale * sum_i prod
+__global__ void __launch_bounds__(NT)
+sum_multiply_rowsum_kernel(Dense2D a, double scale, int64_t ostride, double *__restrict__ out)
+{
+    const int tid = threadIdx.x;
+    const int half = a.inner >> 1;                 // lanes per row, a power of two <= 64
+    const int ip = tid & (half - 1);
+    const int rb = NT / half;
+    const int rt = tid / half;
+    double c0 = 1.0, c1 = 1.0, cs = 1.0;
+    const double *pf[MAXIN];
+#pragma unroll
+    for (int i = 0; i < MAXIN; ++i) {
+        pf[i] = nullptr;
+        if (i < a.nin) {
+            if (a.cls[i] == 2) {
+                const v2f64 q = *reinterpret_cast<const v2f64 *>(a.in[i] + 2 * ip);
+                c0 *= q[0];
+                c1 *= q[1];
+            } else if (a.cls[i] == 3) {
+                cs *= a.in[i][0];
+            } else {
+                pf[i] = a.in[i] + (a.cls[i] == 0 ? 2 * ip : 0);
+            }
+        }
+    }
+    cs *= scale;
+    const int64_t rstep = (int64_t)gridDim.x * rb * D2_U;
+    // every lane of a wavefront runs the same number of rounds (the shuffles need all lanes)
+    for (int64_t rbase = (int64_t)blockIdx.x * rb * D2_U; rbase < a.outer; rbase += rstep) {
+        double acc[D2_U];
+#pragma unroll
+        for (int u = 0; u < D2_U; ++u) {
+            const int64_t r = rbase + rt + (int64_t)u * rb;
+            const bool ok = r < a.outer;
+            const int64_t rr = ok ? r : 0;
+            double x0 = c0, x1 = c1;
+#pragma unroll
+            for (int i = 0; i < MAXIN; ++i) {
+                if (i < a.nin && pf[i]) {
+                    if (a.cls[i] == 0) {
+                        const v2f64 q = __builtin_nontemporal_load(
+                            reinterpret_cast<const v2f64 *>(pf[i] + rr * a.inner));
+                        x0 *= q[0];
+                        x1 *= q[1];
+                    } else {
+                        const double w = pf[i][rr];
+                        x0 *= w;
+                        x1 *= w;
+                    }
+                }
+            }
+            acc[u] = x0 + x1;
+        }
+#pragma unroll
+        for (int u = 0; u < D2_U; ++u) {
+            double v = acc[u];
+            for (int off = half >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            const int64_t r = rbase + rt + (int64_t)u * rb;
+            if (ip == 0 && r < a.outer) out[r * ostride] = cs * v;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(NT)
 sum_multiply_finish_kernel(Iter it, int nsplit, double scale, const double *__restrict__ partial,
                            double *__restrict__ out)
@@ -323,6 +480,42 @@ sum_multiply_finish_kernel(Iter it, int nsplit, double scale, const double *__re
         // slice-major partials: consecutive outputs are consecutive addresses
         for (int s = 0; s < nsplit; ++s) acc += partial[(int64_t)s * it.nkeep + o];
         out[ooff] = scale * acc;
+    }
+}
+
+// Few outputs, many slices: with a thread per output the slices are summed by a handful of
+// threads one dependent load after the other (2048 slices x ~0.4 us measured: longer than the
+// reduction pass itself).  Here 16 row-lanes split the slices of 16 neighbouring outputs, eight
+// loads in flight each, and meet in LDS in fixed order.
+__global__ void __launch_bounds__(NT)
+sum_multiply_finish_few_kernel(Iter it, int nsplit, double scale,
+                               const double *__restrict__ partial, double *__restrict__ out)
+{
+    __shared__ double tile[16][17];
+    const int kx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int64_t o = (int64_t)blockIdx.x * 16 + kx;
+    const bool act = o < it.nkeep;
+    double acc = 0.0;
+    if (act) {
+        int sidx = ry;
+        for (; sidx + 7 * 16 < nsplit; sidx += 8 * 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(sidx + 16 * u) * it.nkeep + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; sidx < nsplit; sidx += 16) acc += partial[(int64_t)sidx * it.nkeep + o];
+    }
+    tile[ry][kx] = acc;
+    __syncthreads();
+    if (ry == 0 && act) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += tile[j][kx];
+        int64_t base[MAXIN], ooff;
+        decode_keep(it, o, base, ooff);
+        out[ooff] = scale * v;
     }
 }
 
@@ -786,9 +979,87 @@ spd_batched_rows_kernel(int n, int64_t batch, const double *__restrict__ A,
 }
 
 // ---------------------------------------------------------------------------
-// Row softmax with the reference's exact recipe: stable log-sum-exp, exp, then a
-// second renormalisation (utils/misc.py:1388-1401).  One wavefront per row.
+// Row softmax with the reference's recipe: stable log-sum-exp, exp, then a second
+// renormalisation (utils/misc.py:1388-1401).
+// K <= 256: LPR lanes per row, four elements per lane held in registers: ONE pass over HBM
+// (16-byte accesses when K is even), one exponential per element (exp(x - lse) =
+// exp(x - max) / sum), reductions over the LPR lanes by xor-shuffles.
 // ---------------------------------------------------------------------------
+template <int LPR, bool VEC>
+__global__ void __launch_bounds__(NT)
+softmax_rows_kernel(int64_t rows, int K, const double *__restrict__ phi, double *__restrict__ p,
+                    double *__restrict__ lse)
+{
+    constexpr int RPB = NT / LPR;                  // rows per workgroup and round
+    const int lr = threadIdx.x % LPR, rt = threadIdx.x / LPR;
+    const int64_t rounds = (rows + (int64_t)gridDim.x * RPB - 1) / ((int64_t)gridDim.x * RPB);
+    for (int64_t t = 0; t < rounds; ++t) {
+        const int64_t r = (t * gridDim.x + blockIdx.x) * RPB + rt;
+        const bool rok = r < rows;
+        const double *x = phi + (rok ? r : 0) * K;
+        double v[4];
+        bool ok[4];
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = 2 * (lr + LPR * j);
+                ok[2 * j] = ok[2 * j + 1] = rok && k < K;
+                v2f64 q = {-INFINITY, -INFINITY};
+                if (ok[2 * j]) q = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(x + k));
+                v[2 * j] = q[0];
+                v[2 * j + 1] = q[1];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = lr + LPR * j;
+                ok[j] = rok && k < K;
+                v[j] = ok[j] ? x[k] : -INFINITY;
+            }
+        }
+        double mx = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        if (!isfinite(mx)) mx = 0.0;                       // misc.py:1375-1378
+        double e[4], s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = ok[j] ? exp_nonpos(v[j] - mx) : 0.0;
+            s += e[j];
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const double ls = log(s) + mx;
+        const double is = 1.0 / s;
+        double s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] *= is;
+            s2 += e[j];
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+        const double inv = 1.0 / s2;
+        double *o = p + (rok ? r : 0) * K;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (ok[2 * j]) {
+                    v2f64 q;
+                    q[0] = e[2 * j] * inv;
+                    q[1] = e[2 * j + 1] * inv;
+                    __builtin_nontemporal_store(q, reinterpret_cast<v2f64 *>(o + 2 * (lr + LPR * j)));
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) o[lr + LPR * j] = e[j] * inv;
+        }
+        if (rok && lr == 0 && lse) lse[r] = ls;
+    }
+}
+
+// K > 256: one wavefront per row, the row is re-read from cache.
 __global__ void __launch_bounds__(NT)
 softmax_kernel(int64_t rows, int K, const double *__restrict__ phi, double *__restrict__ p,
                double *__restrict__ lse)
@@ -802,15 +1073,17 @@ softmax_kernel(int64_t rows, int K, const double *__restrict__ phi, double *__re
         for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
         if (!isfinite(mx)) mx = 0.0;                       // misc.py:1375-1378
         double s = 0.0;
-        for (int k = l; k < K; k += 64) s += exp(x[k] - mx);
+        for (int k = l; k < K; k += 64) s += exp_nonpos(x[k] - mx);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         const double ls = log(s) + mx;
+        const double is = 1.0 / s;
         double s2 = 0.0;
-        for (int k = l; k < K; k += 64) s2 += exp(x[k] - ls);
+        for (int k = l; k < K; k += 64) s2 += exp_nonpos(x[k] - mx) * is;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
-        for (int k = l; k < K; k += 64) p[r * K + k] = exp(x[k] - ls) / s2;
+        const double inv = is / s2;
+        for (int k = l; k < K; k += 64) p[r * K + k] = exp_nonpos(x[k] - mx) * inv;
         if (l == 0 && lse) lse[r] = ls;
     }
 }
@@ -836,6 +1109,18 @@ int64_t grid_for(vmp_ctx *ctx, int64_t work_items, int per_block)
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return g;
+}
+
+void launch_finish(vmp_ctx *ctx, const Iter &it, int nsplit, double scale, const double *partial,
+                   double *out)
+{
+    if (it.nkeep < 4096 && nsplit >= 32)
+        hipLaunchKernelGGL(sum_multiply_finish_few_kernel, dim3((unsigned)((it.nkeep + 15) / 16)),
+                           dim3(NT), 0, ctx->stream, it, nsplit, scale, partial, out);
+    else
+        hipLaunchKernelGGL(sum_multiply_finish_kernel,
+                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, ctx->stream,
+                           it, nsplit, scale, partial, out);
 }
 
 }  // namespace
@@ -877,8 +1162,83 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         }
     }
     if (it.nkeep == 0) return VMP_OK;
+    // merge neighbouring axes of the same kind that are jointly contiguous (or jointly
+    // broadcast) in every operand: fewer index divisions, and the dense forms below apply
+    for (int k = it.nk - 2; k >= 0; --k) {
+        bool ok = it.okstride[k] == it.okstride[k + 1] * it.ksize[k + 1];
+        for (int i = 0; i < nin && ok; ++i)
+            ok = it.kstride[i][k] == it.kstride[i][k + 1] * it.ksize[k + 1];
+        if (!ok) continue;
+        it.ksize[k] *= it.ksize[k + 1];
+        it.okstride[k] = it.okstride[k + 1];
+        for (int i = 0; i < nin; ++i) it.kstride[i][k] = it.kstride[i][k + 1];
+        for (int j = k + 1; j < it.nk - 1; ++j) {
+            it.ksize[j] = it.ksize[j + 1];
+            it.okstride[j] = it.okstride[j + 1];
+            for (int i = 0; i < nin; ++i) it.kstride[i][j] = it.kstride[i][j + 1];
+        }
+        --it.nk;
+    }
+    for (int k = it.nr - 2; k >= 0; --k) {
+        bool ok = true;
+        for (int i = 0; i < nin && ok; ++i)
+            ok = it.rstride[i][k] == it.rstride[i][k + 1] * it.rsize[k + 1];
+        if (!ok) continue;
+        it.rsize[k] *= it.rsize[k + 1];
+        for (int i = 0; i < nin; ++i) it.rstride[i][k] = it.rstride[i][k + 1];
+        for (int j = k + 1; j < it.nr - 1; ++j) {
+            it.rsize[j] = it.rsize[j + 1];
+            for (int i = 0; i < nin; ++i) it.rstride[i][j] = it.rstride[i][j + 1];
+        }
+        --it.nr;
+    }
     it.i32 = (it.nkeep < ((int64_t)1 << 31) && it.nred < ((int64_t)1 << 31)) ? 1 : 0;
     hipStream_t s = ctx->stream;
+    // ---- dense two-axis forms -------------------------------------------------------------
+    if (it.nk == 1 && it.nr == 1 && it.nred > 0) {
+        auto pow2 = [](int64_t v) { return v >= 2 && (v & (v - 1)) == 0; };
+        // column sums: reduce the outer axis
+        const int64_t kin = it.ksize[0], rin = it.rsize[0];
+        for (int mode = 0; mode < 2; ++mode) {
+            const int64_t inner = mode == 0 ? kin : rin, outer = mode == 0 ? rin : kin;
+            if (!pow2(inner) || inner > (mode == 0 ? 2 * NT : 128)) continue;
+            if (mode == 0 ? (outer < 4096 || !workspace) : (outer < 4096)) continue;
+            Dense2D a;
+            memset(&a, 0, sizeof(a));
+            a.nin = nin;
+            a.inner = (int)inner;
+            a.outer = outer;
+            bool ok = true, dense = false;
+            for (int i = 0; i < nin && ok; ++i) {
+                const int64_t si = mode == 0 ? it.kstride[i][0] : it.rstride[i][0];
+                const int64_t so = mode == 0 ? it.rstride[i][0] : it.kstride[i][0];
+                a.in[i] = in[i];
+                const bool al = reinterpret_cast<uintptr_t>(in[i]) % 16 == 0;
+                if (si == 1 && so == inner && al) { a.cls[i] = 0; dense = true; }
+                else if (si == 0 && so == 1) a.cls[i] = 1;
+                else if (si == 1 && so == 0 && al) a.cls[i] = 2;
+                else if (si == 0 && so == 0) a.cls[i] = 3;
+                else ok = false;
+            }
+            if (!ok || !dense) continue;
+            const int rb = NT / (int)(inner / 2);
+            int64_t nb = (outer + (int64_t)rb * D2_U - 1) / ((int64_t)rb * D2_U);
+            const int64_t cap = (int64_t)ctx->num_cu * 8;
+            if (nb > cap) nb = cap;
+            if (mode == 0) {
+                if (workspace_bytes < (size_t)(nb * inner) * sizeof(double)) continue;
+                double *partial = reinterpret_cast<double *>(workspace);
+                hipLaunchKernelGGL(sum_multiply_colsum_kernel, dim3((unsigned)nb), dim3(NT), 0, s,
+                                   a, partial);
+                launch_finish(ctx, it, (int)nb, scale, partial, out);
+            } else {
+                hipLaunchKernelGGL(sum_multiply_rowsum_kernel, dim3((unsigned)nb), dim3(NT), 0, s,
+                                   a, scale, it.okstride[0], out);
+            }
+            VMP_HIP_CHECK(ctx, hipGetLastError());
+            return VMP_OK;
+        }
+    }
     if (it.nred == 0) {
         // empty sum -> zeros
         it.nred = 0;
@@ -922,9 +1282,7 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         else if (it.nkeep <= 32) VMP_FAT(32);
         else VMP_FAT(64);
 #undef VMP_FAT
-        hipLaunchKernelGGL(sum_multiply_finish_kernel,
-                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
-                           (int)nsplit, scale, partial, out);
+        launch_finish(ctx, it, (int)nsplit, scale, partial, out);
     } else if (use_column) {
         const int64_t kin = it.ksize[it.nk - 1];
         const int64_t kouter = it.nkeep / kin;
@@ -950,9 +1308,7 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         else
             hipLaunchKernelGGL(sum_multiply_column_kernel<4>, grid, dim3(NT), 0, s, it,
                                (int)nsplit, partial);
-        hipLaunchKernelGGL(sum_multiply_finish_kernel,
-                           dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
-                           (int)nsplit, scale, partial, out);
+        launch_finish(ctx, it, (int)nsplit, scale, partial, out);
     } else if (!use_block && it.nred >= 8 && it.nkeep >= 4096 && dense_reduce) {
         // short dense reductions: a lane group per output (coalesced), else a thread per output
         const int G = it.nred >= 64 ? 64 : (it.nred >= 32 ? 32 : (it.nred >= 16 ? 16 : 8));
@@ -981,9 +1337,7 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         hipLaunchKernelGGL(sum_multiply_block_kernel, dim3((unsigned)it.nkeep, (unsigned)nsplit),
                            dim3(NT), 0, s, it, (int)nsplit, partial, scale, out);
         if (nsplit > 1)
-            hipLaunchKernelGGL(sum_multiply_finish_kernel,
-                               dim3((unsigned)grid_for(ctx, it.nkeep, NT)), dim3(NT), 0, s, it,
-                               (int)nsplit, scale, partial, out);
+            launch_finish(ctx, it, (int)nsplit, scale, partial, out);
     }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -1146,8 +1500,35 @@ int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double 
     VMP_REQUIRE(ctx, ctx && phi && p, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, rows >= 0 && K >= 1, VMP_ERR_INVALID, "bad dims");
     if (rows == 0) return VMP_OK;
-    hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)grid_for(ctx, rows, 4)), dim3(NT), 0,
-                       ctx->stream, rows, K, phi, p, lse);
+    if (K <= 256) {
+        int lpr = 1;
+        while (lpr * 4 < K) lpr <<= 1;
+        const bool vec = (K % 2 == 0) && reinterpret_cast<uintptr_t>(phi) % 16 == 0
+                         && reinterpret_cast<uintptr_t>(p) % 16 == 0;
+        const dim3 grid((unsigned)grid_for(ctx, rows, NT / lpr));
+#define VMP_SM(L)                                                                              \
+    do {                                                                                       \
+        if (vec)                                                                               \
+            hipLaunchKernelGGL((softmax_rows_kernel<L, true>), grid, dim3(NT), 0, ctx->stream, \
+                               rows, K, phi, p, lse);                                          \
+        else                                                                                   \
+            hipLaunchKernelGGL((softmax_rows_kernel<L, false>), grid, dim3(NT), 0,             \
+                               ctx->stream, rows, K, phi, p, lse);                             \
+    } while (0)
+        switch (lpr) {
+        case 1: VMP_SM(1); break;
+        case 2: VMP_SM(2); break;
+        case 4: VMP_SM(4); break;
+        case 8: VMP_SM(8); break;
+        case 16: VMP_SM(16); break;
+        case 32: VMP_SM(32); break;
+        default: VMP_SM(64); break;
+        }
+#undef VMP_SM
+    } else {
+        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)grid_for(ctx, rows, 4)), dim3(NT), 0,
+                           ctx->stream, rows, K, phi, p, lse);
+    }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

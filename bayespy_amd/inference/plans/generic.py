@@ -48,7 +48,15 @@ def _shape(x):
 
 
 def _arr(x):
-    return x if isinstance(x, DArray) else DArray.from_host(np.asarray(x, dtype=np.float64))
+    if isinstance(x, DArray):
+        return x
+    if hasattr(x, 'is_cuda'):
+        # a tensor handed to observe() / initialize_from_value(): used in place when it is
+        # fp64 and already resident in HBM
+        from ...device import get_runtime
+        rt = get_runtime()
+        return DArray(x.to(device=rt.device, dtype=rt.torch.float64))
+    return DArray.from_host(np.asarray(x, dtype=np.float64))
 
 
 def _trail(x, n):

@@ -65,6 +65,19 @@ SM_CASES = [
     (((4100, 3, 40), (1, 3, 40)), dict(axis=(2,))),
     (((4500, 70), (4500, 1), (1, 70)), dict(axis=(1,), keepdims=True)),
     (((300, 20, 6, 6), (300, 20, 6, 6)), dict(axis=(2, 3))),
+    # dense two-axis forms (16-byte lanes over the flat index): column sums with per-plate /
+    # per-column / scalar factors, merged trailing axes, widest and narrowest inner extents
+    (((100000, 16), (100000, 1)), dict(axis=(0,))),
+    (((50001, 4, 4), (50001, 1, 1), (1, 4, 4)), dict(axis=(0,))),
+    (((70000, 8), (70000, 8), ()), dict(axis=(0,), keepdims=True)),
+    (((4097, 512),), dict(axis=(0,))),
+    (((9000, 2), (9000, 1)), dict(axis=(0,))),
+    (((3, 40000, 2, 2), (1, 40000, 1, 1)), dict(axis=(0, 1))),
+    # ... and row sums
+    (((4500, 64), (4500, 1), (1, 64)), dict(axis=(1,), keepdims=True)),
+    (((6001, 2, 2),), dict(axis=(1, 2))),
+    (((4099, 128), (4099, 128), ()), dict(axis=(1,))),
+    (((5000, 4, 4), (5000, 4, 4)), dict(axis=(-1, -2))),
 ]
 
 
@@ -84,6 +97,26 @@ def test_sum_multiply_matches_bruteforce(shapes, kw):
         got = misc.sum_multiply(a0, *arrs[1:], **kw).numpy()
         np.testing.assert_allclose(got, ref, rtol=1e-12,
                                    atol=1e-12 * max(1.0, np.max(np.abs(ref))))
+
+
+def test_sum_multiply_dense_forms_fall_back_on_unaligned_operands():
+    """The 16-byte forms need aligned bases; an operand that starts at an odd element takes the
+    strided kernels and gives the same sums."""
+    import torch
+    from bayespy_amd.darray import DArray
+    from bayespy_amd.device import get_runtime
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(5)
+    N = 20000
+    flat = rs.normal(size=N * 16 + 1)
+    w = rs.normal(size=(N, 1))
+    t = torch.from_numpy(flat).to(get_runtime().device)
+    a = DArray(t[1:].view(N, 16))
+    ref = flat[1:].reshape(N, 16)
+    np.testing.assert_allclose(misc.sum_multiply(a, w, axis=(0,)).numpy(), (ref * w).sum(0),
+                               rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(misc.sum_multiply(a, a, axis=(1,)).numpy(), (ref * ref).sum(1),
+                               rtol=1e-12, atol=1e-10)
 
 
 def test_sum_multiply_errors():
@@ -134,6 +167,41 @@ def test_large_softmax_rows():
     ref_p /= ref_p.sum(axis=1, keepdims=True)
     np.testing.assert_allclose(lse.numpy(), ref_l, rtol=1e-13)
     np.testing.assert_allclose(p.numpy(), ref_p, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize('K', [1, 2, 3, 5, 16, 17, 64, 100, 255, 256, 257, 300])
+def test_softmax_row_widths_and_impossible_states(K):
+    """Every lanes-per-row instance (K <= 256: registers, one pass) and the wide-row kernel;
+    -inf entries give exact zeros, an all -inf row follows misc.py:1375-1378 (max -> 0)."""
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(K)
+    x = rs.normal(size=(1003, K)) * 20
+    x[rs.rand(1003, K) < 0.1] = -np.inf
+    x[7] = -np.inf
+    x[11, :] = 0.0
+    p, lse = misc.normalized_exp(x)
+    with np.errstate(all='ignore'):
+        m = x.max(axis=1, keepdims=True)
+        m[~np.isfinite(m)] = 0.0
+        ref_l = np.log(np.exp(x - m).sum(axis=1, keepdims=True)) + m
+        ref_p = np.exp(x - ref_l)
+        ref_p /= ref_p.sum(axis=1, keepdims=True)
+    got_p, got_l = p.numpy(), lse.numpy()
+    ok = np.isfinite(ref_l[:, 0])
+    np.testing.assert_allclose(got_l[ok], ref_l[ok], rtol=1e-13)
+    np.testing.assert_allclose(got_p[ok], ref_p[ok], rtol=1e-12, atol=1e-300)
+    assert np.all(got_p[ok][~np.isfinite(x[ok])] == 0.0)
+    assert np.all(np.isnan(got_p[~ok])) and np.all(got_l[~ok] == -np.inf)
+    # an odd row stride (K odd) or an odd base take the 8-byte instance: the same values
+    if K % 2 == 0 and K > 1:
+        import torch
+        from bayespy_amd.darray import DArray
+        from bayespy_amd.device import get_runtime
+        flat = np.concatenate([[0.0], x.ravel()])
+        t = torch.from_numpy(flat).to(get_runtime().device)
+        p2, lse2 = misc.normalized_exp(DArray(t[1:].view(1003, K)))
+        np.testing.assert_allclose(p2.numpy()[ok], got_p[ok], rtol=1e-14, atol=1e-300)
+        np.testing.assert_allclose(lse2.numpy()[ok], got_l[ok], rtol=1e-14)
 
 
 def test_batched_spd_known_answers_and_random(golden_dir):
