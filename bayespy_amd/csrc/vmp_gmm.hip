@@ -20,6 +20,7 @@
 // Layout: Y (N, D) row-major as in the reference (plates (N,), dims (D,)); a wave reads
 // 16 consecutive rows = one contiguous block.  r (N, K) row-major, written as whole rows.
 #include "vmp_common.h"
+#include "vmp_exp2_table.h"
 
 namespace {
 
@@ -68,44 +69,144 @@ __device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// exp(x) for x <= 0 (softmax arguments after subtracting the maximum; -inf allowed).  On this
+// chip fp64 vector work is not hidden behind fp64 matrix work (both run on the same fp64 units),
+// so the exponential is the second largest cost of the pass after the MFMAs.  Table form:
+// x = (256 m + j) ln2/256 + r, |r| <= ln2/512, exp(x) = 2^m * T[j] * (1 + r + r^2/2 + r^3/6 +
+// r^4/24) (truncation 4e-17 relative); T = 2^(j/256) correctly rounded, in LDS.  11 fp64
+// instructions instead of 21 for the polynomial-only form (exp_nonpos, vmp_common.h); <= 2 ulp.
+typedef __attribute__((address_space(3))) double lds_f64;
+
+__device__ __forceinline__ double lds_read(uint32_t byte_addr)
+{
+    return *(const lds_f64 *)(uintptr_t)byte_addr;
+}
+
+// v_max_f64 without the canonicalising v_max x, x the compiler puts in front of fmax() operands
+// it cannot prove quiet (MFMA results, shuffled values): they never hold signalling NaNs.
+// The compiler's hazard recogniser does not look inside inline assembly, and a vector
+// instruction that reads a register too soon after the MFMA that writes it gets stale data:
+// mfma_settle() below must separate the matrix instructions from the first max_raw().
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// 32 wait states after the MFMAs that produce `acc` (the longest MFMA-write -> VALU-read
+// requirement on this target is below 20), tied to the accumulators so that neither the
+// MFMAs nor their consumers can be scheduled across it.
+template <int KT>
+__device__ __forceinline__ void mfma_settle(v4f64 (&acc)[KT])
+{
+    if constexpr (KT == 1)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
+    else if constexpr (KT == 2)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    else
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+
+// NV exponentials at once, staged so that the NV table reads are in flight together:
+// v[i] <- exp(v[i] - mx)
+template <int NV>
+__device__ __forceinline__ void exp_tab_batch(double (&v)[NV], double mx, uint32_t tab_addr)
+{
+    int ki[NV];
+    double t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double x = max_raw(v[i] - mx, -800.0);
+        const double kf = __builtin_rint(x * 0x1.71547652b82fep+8);            // 256 / ln 2
+        double r = __builtin_fma(kf, -0x1.62e42fee00000p-9, x);                 // ln2_hi / 256
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-41, r);                       // ln2_lo / 256
+        ki[i] = (int)kf;
+        t[i] = lds_read(tab_addr + 8u * __builtin_amdgcn_ubfe((uint32_t)ki[i], 0u, 8u));
+        v[i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double r = v[i];
+        double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
+        p = __builtin_fma(p, r, 0.5);
+        p = __builtin_fma(p, r, 1.0);
+        v[i] = __builtin_fma(p, r, 1.0);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_ldexp(t[i] * v[i], ki[i] >> 8);
+}
+
+// 1 / s for 1 <= s <= 2^10: hardware estimate + two Newton steps (no scaling, no special cases)
+__device__ __forceinline__ double recip_small(double s)
+{
+    double y = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-s, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
 // ---------------------------------------------------------------------------
 // The pass.  DPT = DP/4 in {1,2}, KT = KP/16 in {1,2,4}, FT2 = F2P/16 in {1,2,3}.
 // FROM_LABELS: responsibilities are the one-hot of given labels
 // (z.initialize_from_value, categorical.py:30-46) instead of the softmax.
+//
+// One workgroup of eight wavefronts per CU (two per SIMD, 256 VGPRs each: the phase-2
+// accumulators alone are 96); a wavefront owns 16-column tiles.  Per tile:
+//   features   lane (g, n) forms feat[4q + g] of column n from the y tile in LDS (per-lane
+//              LDS addresses precomputed), feeds it to phase 1 as the B operand AND stores it
+//              once in LDS in the operand order of phase 2
+//   phase 1    Phi(K x 16) = C * feat        softmax: one table exponential per element,
+//              p = e / sum (the reference's second renormalisation changes p by <= 2 ulp and
+//              is not repeated), sum_n lse_n accumulated as sum max + log of a running product
+//   r tile     k-major in LDS (stride 18: conflict-free for both the writes and the A-operand
+//              reads), aliased with the y tile; rows written to HBM as whole (N, K) rows
+//   phase 2    T += r * feat^T
+// sum_nk r phi (bound term of z) is not accumulated here: it equals <C, T> exactly and is
+// formed from the reduced statistics (gmm_rphi_kernel).
 // ---------------------------------------------------------------------------
+constexpr int NTP = 512;
+constexpr int RS = 18;
+
 template <int DPT, int KT, int FT2, bool FROM_LABELS>
-__global__ void __launch_bounds__(NT, 2)
+__global__ void __launch_bounds__(NTP, 2)
 gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
                 const double *__restrict__ Cmat, const int64_t *__restrict__ labels,
                 double *__restrict__ Rout, double *__restrict__ P, int64_t ntiles)
 {
     constexpr int DP = 4 * DPT, KP = 16 * KT;
     constexpr int YS = DP + 3;                    // y tile row stride (ONE at DP, ZERO at DP+1)
-    constexpr int RS = KP + 1;                    // r tile row stride
     constexpr int F2P = 16 * FT2;                 // compact features: y_a y_b (a<=b), y_d, 1
+    constexpr int FS = F2P + 2;                   // feature tile row stride
     constexpr int KS1 = F2P / 4;                  // phase-1 k-steps over the same features
+    constexpr int WAVES = NTP / 64;
+    constexpr int YR = (TNC * YS > KP * RS) ? TNC * YS : KP * RS;   // y tile / r tile (aliased)
+    constexpr int NCF = FROM_LABELS ? 0 : KT * KS1 * 64;
+    constexpr int NTAB = FROM_LABELS ? 0 : 256;
 
     extern __shared__ double lds[];
     double *Cf = lds;                                            // KT*KS1*64
-    double *wbase = lds + (FROM_LABELS ? 0 : KT * KS1 * 64);
+    double *tab = lds + NCF;                                     // 256
+    double *wbase = tab + NTAB;
     const int tid = threadIdx.x;
     const int l = tid & 63, l15 = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *ytile = wbase + w * (TNC * YS + TNC * RS);           // [16][YS]
-    double *rtile = ytile + TNC * YS;                            // [16][RS]
+    double *ytile = wbase + w * (YR + TNC * FS);                 // [16][YS]
+    double *rtile = ytile;                                       // [KP][RS]   (after phase 1)
+    double *ftile = ytile + YR;                                  // [16][FS]
 
     if (!FROM_LABELS) {
         // A fragments of phase 1: lane holds C[it*16 + l15][4q + g]
-        for (int e = tid; e < KT * KS1 * 64; e += NT) {
+        for (int e = tid; e < KT * KS1 * 64; e += NTP) {
             const int lane = e & 63, fq = e >> 6;
             const int it = fq / KS1, q = fq - it * KS1;
             Cf[e] = Cmat[(int64_t)(it * 16 + (lane & 15)) * F2P + 4 * q + (lane >> 4)];
         }
+        for (int e = tid; e < 256; e += NTP) tab[e] = VMP_EXP2_TAB[e];
     }
-    // constant slots of the y tile
-    ytile[l15 * YS + DP] = 1.0;
-    ytile[l15 * YS + DP + 1] = 0.0;
     __syncthreads();
+    const uint32_t tab_addr = (uint32_t)(uintptr_t)(lds_f64 *)tab;
 
     // feature f of a column n is ytile[n][fa(f)] * ytile[n][fb(f)] (slot DP holds 1, DP+1 holds 0)
     auto feature = [&](int f, int &a, int &b) {
@@ -121,23 +222,15 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             a = DP; b = DP;                          // constant
         }
     };
-    // phase 2: this lane generates feat2[ft*16 + l15]; phase 1: feature 4q + g of its column,
-    // packed two 4-bit slots per byte to keep the tables in a few registers
-    uint32_t f2 = 0;
-#pragma unroll
-    for (int ft = 0; ft < FT2; ++ft) {
-        int a, b;
-        feature(ft * 16 + l15, a, b);
-        f2 |= (uint32_t)((a << 4) | b) << (8 * ft);
-    }
-    uint32_t f1[(KS1 + 3) / 4];
-#pragma unroll
-    for (int i = 0; i < (KS1 + 3) / 4; ++i) f1[i] = 0;
+    // LDS byte addresses of the two factors of feature 4q + g of this lane's column
+    const uint32_t yrow_addr = (uint32_t)(uintptr_t)(lds_f64 *)(ytile + l15 * YS);
+    uint32_t fa[KS1], fb[KS1];
 #pragma unroll
     for (int q = 0; q < KS1; ++q) {
         int a, b;
         feature(4 * q + g, a, b);
-        f1[q >> 2] |= (uint32_t)((a << 4) | b) << (8 * (q & 3));
+        fa[q] = yrow_addr + 8u * (uint32_t)a;
+        fb[q] = yrow_addr + 8u * (uint32_t)b;
     }
 
     v4f64 acc2[KT][FT2];
@@ -145,84 +238,88 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     for (int it = 0; it < KT; ++it)
 #pragma unroll
         for (int ft = 0; ft < FT2; ++ft) acc2[it][ft] = v4f64{0.0, 0.0, 0.0, 0.0};
-    double s_lse = 0.0, s_rphi = 0.0;
+    double s_mx = 0.0, s_log = 0.0, prod = 1.0;
+    int since = 0;
 
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += stride) {
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + w; tile < ntiles; tile += stride) {
         const int64_t n0 = tile * TNC;
         const int64_t n = n0 + l15;
         const bool nok = n < N;
         // ---- y: lane (g, l15) owns y[n][4j + g] ------------------------------------
-        double yb[DPT];
 #pragma unroll
         for (int j = 0; j < DPT; ++j) {
             const int d = 4 * j + g;
-            yb[j] = (nok && d < D) ? Y[n * D + d] : 0.0;
-            ytile[l15 * YS + d] = yb[j];
+            ytile[l15 * YS + d] = (nok && d < D) ? Y[n * D + d] : 0.0;
+        }
+        if (g == 0) {
+            // constant slots (the r tile of the previous round overwrote them)
+            ytile[l15 * YS + DP] = 1.0;
+            ytile[l15 * YS + DP + 1] = 0.0;
         }
         lds_fence();
 
-        if (!FROM_LABELS) {
-            // ---- phase 1: Phi = C * feat(y) over the compact features ------------------
-            v4f64 acc1[KT];
+        // ---- features (+ phase 1: Phi = C * feat over the compact features) -------------
+        v4f64 acc1[KT];
 #pragma unroll
-            for (int it = 0; it < KT; ++it) acc1[it] = v4f64{0.0, 0.0, 0.0, 0.0};
-            asm volatile("" ::: "memory");
-            const double *yrow = ytile + l15 * YS;
+        for (int it = 0; it < KT; ++it) acc1[it] = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < KS1; ++q) {
-                // keep the feature reads next to their use (hoisted together they spill)
-                if ((q & 3) == 0) asm volatile("" ::: "memory");
-                const uint32_t ab = (f1[q >> 2] >> (8 * (q & 3))) & 0xffu;
-                const double b = yrow[ab >> 4] * yrow[ab & 15];
+        for (int q = 0; q < KS1; ++q) {
+            // keep the operand reads next to their use (hoisted together they spill)
+            if ((q & 3) == 0) asm volatile("" ::: "memory");
+            const double b = lds_read(fa[q]) * lds_read(fb[q]);
+            ftile[l15 * FS + 4 * q + g] = b;
+            if (!FROM_LABELS) {
 #pragma unroll
                 for (int it = 0; it < KT; ++it)
                     acc1[it] = mfma_f64(Cf[(it * KS1 + q) * 64 + l], b, acc1[it]);
             }
+        }
+        lds_fence();             // every lane is done with the y tile: the r tile may overwrite it
+
+        if (!FROM_LABELS) {
             // ---- softmax over k for column n (utils/misc.py:1388-1401) ------------------
             // lane holds Phi[k = it*16 + g + 4r][n]
-            double mx = -INFINITY;
+            mfma_settle<KT>(acc1);
+            double mx = max_raw(acc1[0][0], acc1[0][1]);
+            mx = max_raw(mx, max_raw(acc1[0][2], acc1[0][3]));
 #pragma unroll
-            for (int it = 0; it < KT; ++it)
+            for (int it = 1; it < KT; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmax(mx, acc1[it][r]);
-            mx = fmax(mx, __shfl_xor(mx, 16, 64));
-            mx = fmax(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 0; r < 4; ++r) mx = max_raw(mx, acc1[it][r]);
+            mx = max_raw(mx, __shfl_xor(mx, 16, 64));
+            mx = max_raw(mx, __shfl_xor(mx, 32, 64));
             if (!isfinite(mx)) mx = 0.0;
-            double e[KT][4], s = 0.0;
+            double s = 0.0;
 #pragma unroll
-            for (int it = 0; it < KT; ++it)
+            for (int h = 0; h < KT; h += 2) {
+                constexpr int NV = KT >= 2 ? 8 : 4;
+                double v[NV];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[it][r] = exp_nonpos(acc1[it][r] - mx);
-                    s += e[it][r];
+                for (int i = 0; i < NV; ++i) v[i] = acc1[h + (i >> 2)][i & 3];
+                exp_tab_batch<NV>(v, mx, tab_addr);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    acc1[h + (i >> 2)][i & 3] = v[i];
+                    s += v[i];
                 }
+            }
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            const double lse = log(s) + mx;
-            // exp(phi - lse) = exp(phi - mx) / s; then the reference's second
-            // renormalisation p / sum(p) (utils/misc.py:1399)
-            const double is = 1.0 / s;
-            double s2 = 0.0;
+            // lse_n = mx + log s; the logarithm is taken of a running product (1 <= s <= KP)
+            s_mx += nok ? mx : 0.0;
+            prod *= nok ? s : 1.0;
+            if (++since == 16) {
+                s_log += log(prod);
+                prod = 1.0;
+                since = 0;
+            }
+            const double is = nok ? recip_small(s) : 0.0;
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[it][r] *= is;
-                    s2 += e[it][r];
-                }
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            const double inv = nok ? 1.0 / s2 : 0.0;
-            if (nok && g == 0) s_lse += lse;
-#pragma unroll
-            for (int it = 0; it < KT; ++it)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double p = e[it][r] * inv;
-                    if (p != 0.0) s_rphi += p * acc1[it][r];
-                    rtile[l15 * RS + it * 16 + g + 4 * r] = p;
-                }
+                for (int r = 0; r < 4; ++r)
+                    rtile[(it * 16 + g + 4 * r) * RS + l15] = acc1[it][r] * is;
         } else {
             const int64_t lab = nok ? labels[n] : -1;
 #pragma unroll
@@ -230,7 +327,7 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = it * 16 + g + 4 * r;
-                    rtile[l15 * RS + k] = (lab == k) ? 1.0 : 0.0;
+                    rtile[k * RS + l15] = (lab == k) ? 1.0 : 0.0;
                 }
         }
         lds_fence();
@@ -239,7 +336,7 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
 #pragma unroll 4
         for (int rr = 0; rr < TNC; ++rr) {
             if (n0 + rr < N) {
-                for (int k = l; k < K; k += 64) Rout[(n0 + rr) * K + k] = rtile[rr * RS + k];
+                for (int k = l; k < K; k += 64) Rout[(n0 + rr) * K + k] = rtile[k * RS + rr];
             }
         }
 
@@ -249,12 +346,10 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             const int nn = 4 * q + g;
             double bf[FT2];
 #pragma unroll
-            for (int ft = 0; ft < FT2; ++ft)
-                bf[ft] = ytile[nn * YS + ((f2 >> (8 * ft + 4)) & 15u)]
-                         * ytile[nn * YS + ((f2 >> (8 * ft)) & 15u)];
+            for (int ft = 0; ft < FT2; ++ft) bf[ft] = ftile[nn * FS + ft * 16 + l15];
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
-                const double a = rtile[nn * RS + it * 16 + l15];
+                const double a = rtile[(it * 16 + l15) * RS + nn];
 #pragma unroll
                 for (int ft = 0; ft < FT2; ++ft) acc2[it][ft] = mfma_f64(a, bf[ft], acc2[it][ft]);
             }
@@ -265,9 +360,10 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     // ---- per-WORKGROUP partials: [KP][F2P] + 2 scalars (waves combined in fixed order) ----
     __syncthreads();                       // every wave is done with the LDS tiles / fragments
     double *scr = lds;                     // KP*F2P + 2 doubles
+    // the four lane groups of a column hold identical (mx, s): count group 0 only
+    double s_lse = (g == 0) ? s_mx + s_log + log(prod) : 0.0;
     s_lse = wave_sum(s_lse);
-    s_rphi = wave_sum(s_rphi);
-    for (int ww = 0; ww < 4; ++ww) {
+    for (int ww = 0; ww < WAVES; ++ww) {
         if (w == ww) {
 #pragma unroll
             for (int it = 0; it < KT; ++it)
@@ -280,20 +376,20 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
                     }
             if (l == 0) {
                 scr[KP * F2P + 0] = (ww == 0 ? 0.0 : scr[KP * F2P + 0]) + s_lse;
-                scr[KP * F2P + 1] = (ww == 0 ? 0.0 : scr[KP * F2P + 1]) + s_rphi;
+                scr[KP * F2P + 1] = 0.0;
             }
         }
         __syncthreads();
     }
     const int64_t plen = (int64_t)KP * F2P + 8;
     double *Pb = P + (int64_t)blockIdx.x * plen;
-    for (int e2 = tid; e2 < KP * F2P + 2; e2 += NT) Pb[e2] = scr[e2];
+    for (int e2 = tid; e2 < KP * F2P + 2; e2 += NTP) Pb[e2] = scr[e2];
 }
 
 // T (natural layout) <- sum over wave partials (fixed order), compact -> natural.
 __global__ void __launch_bounds__(NT)
 gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, int nb,
-                  int update_zs, double *__restrict__ st)
+                  int update_zs, double *__restrict__ Tc, double *__restrict__ st)
 {
     __shared__ double part[4][64];
     const int KP = (int)L.KP, F2P = (int)L.F2P;
@@ -322,6 +418,7 @@ gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, 
         return;
     }
     const int k = e / F2P, f = e - k * F2P;
+    Tc[e] = (k < K) ? v : 0.0;               // compact order, for <C, T> (gmm_rphi_kernel)
     if (k >= K) return;
     double *T = st + L.off_T + (int64_t)k * L.FS;
     const int npair = D * (D + 1) / 2;
@@ -336,6 +433,24 @@ gmm_reduce_kernel(vmp_gmm_layout L, int D, int K, const double *__restrict__ P, 
     } else if (f == npair + D) {
         T[0] = v;
     }
+}
+
+// sum_nk r_nk phi_nk = sum_kf C_kf T_kf (Phi = C feat and T = r feat^T are the same contraction
+// summed in the other order); 0 * -inf (impossible clusters) counts as 0 like the p != 0 guard of
+// the reference (expfamily.py:455-460 via the masked sum).
+__global__ void __launch_bounds__(NT)
+gmm_rphi_kernel(vmp_gmm_layout L, const double *__restrict__ Tc, double *__restrict__ st)
+{
+    __shared__ double red[NT / 64];
+    const int total = (int)(L.KP * L.F2P);
+    const double *C = st + L.off_C;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < total; e += NT) {
+        const double t = Tc[e];
+        if (t != 0.0) acc += C[e] * t;
+    }
+    acc = block_sum<NT>(acc, red);
+    if (threadIdx.x == 0) st[L.off_zs + 1] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -634,8 +749,10 @@ int gmm_wgs_per_cu()
 {
     static int v = -1;
     if (v < 0) {
+        // one 8-wavefront workgroup per CU = two wavefronts per SIMD (the register budget of
+        // the pass); the LDS tiles of the K = 64 instance (148 KB) admit no second one
         const char *e = getenv("VMP_GMM_WGS_PER_CU");
-        v = e ? atoi(e) : 2;
+        v = e ? atoi(e) : 1;
         if (v < 1) v = 1;
         if (v > 4) v = 4;
     }
@@ -651,8 +768,11 @@ int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, dim3 grid, const double 
 {
     constexpr int DP = 4 * DPT, KP = 16 * KT;
     constexpr int KS1 = 4 * FT2;                  // k-steps of phase 1 (compact features)
-    const size_t per_wave = (size_t)(TNC * (DP + 3) + TNC * (KP + 1));
-    const size_t lds = ((from_labels ? 0 : (size_t)KT * KS1 * 64) + 4 * per_wave) * sizeof(double);
+    constexpr int F2P = 16 * FT2;
+    const size_t ytile = (size_t)TNC * (DP + 3), rtile = (size_t)KP * RS;
+    const size_t per_wave = (ytile > rtile ? ytile : rtile) + (size_t)TNC * (F2P + 2);
+    const size_t lds = ((from_labels ? 0 : (size_t)KT * KS1 * 64 + 256) + (NTP / 64) * per_wave)
+                       * sizeof(double);
     hipStream_t s = ctx->stream;
     if (from_labels) {
         auto kern = gmm_pass_kernel<DPT, KT, FT2, true>;
@@ -663,7 +783,7 @@ int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, dim3 grid, const double 
                                                    160 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NTP), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
     } else {
         auto kern = gmm_pass_kernel<DPT, KT, FT2, false>;
         static bool attr = false;
@@ -673,7 +793,7 @@ int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, dim3 grid, const double 
                                                    160 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NTP), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
     }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -691,7 +811,7 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
     fill_layout(D, K, &L);
     const int DPT = (int)(L.DP / 4), KT = (int)(L.KP / 16), FT2 = (int)(L.F2P / 16);
     const int64_t ntiles = (N + TNC - 1) / TNC;
-    int64_t g = (ntiles + 3) / 4;
+    int64_t g = (ntiles + NTP / 64 - 1) / (NTP / 64);
     if (g > gmm_max_grid(ctx)) g = gmm_max_grid(ctx);
     if (g < 1) g = 1;
     double *P = reinterpret_cast<double *>(workspace);
@@ -716,8 +836,11 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
     }
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
     const int total = (int)(L.KP * L.F2P + 2);
+    double *Tc = P + gmm_max_grid(ctx) * (L.KP * L.F2P + 8);
     hipLaunchKernelGGL(gmm_reduce_kernel, dim3((total + 63) / 64), dim3(NT), 0, ctx->stream,
-                       L, D, K, P, (int)g, from_labels ? 0 : 1, state);
+                       L, D, K, P, (int)g, from_labels ? 0 : 1, Tc, state);
+    if (!from_labels)
+        hipLaunchKernelGGL(gmm_rphi_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, Tc, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
     return VMP_OK;
@@ -741,7 +864,7 @@ int32_t vmp_gmm_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *byte
     vmp_gmm_layout L;
     int32_t rc = vmp_gmm_get_layout(D, K, &L);
     VMP_REQUIRE(ctx, rc == VMP_OK, rc, "fused GMM block supports D <= %d, K <= %d", MAXD, MAXK);
-    *bytes = (size_t)(gmm_max_grid(ctx) * (L.KP * L.F2P + 8) + 64) * sizeof(double);
+    *bytes = (size_t)(gmm_max_grid(ctx) * (L.KP * L.F2P + 8) + L.KP * L.F2P + 64) * sizeof(double);
     return VMP_OK;
 }
 
