@@ -194,9 +194,6 @@ __device__ inline double wave_spd_inverse(double v, int D, int i, int j, bool ac
     return v;
 }
 
-// ---------------------------------------------------------------------------
-// Wavefront (64 lanes) and workgroup reductions, fixed order => deterministic.
-// ---------------------------------------------------------------------------
 // exp(x) for x <= 0 (softmax arguments after subtracting the maximum; -inf allowed): the
 // library routine spends a third of its instructions on overflow / special-case handling that
 // cannot occur here, and on this chip fp64 VALU work is not hidden behind fp64 MFMA work (both
@@ -224,6 +221,9 @@ __device__ __forceinline__ double exp_nonpos(double x)
     return __builtin_ldexp(p, (int)k);
 }
 
+// ---------------------------------------------------------------------------
+// Wavefront (64 lanes) and workgroup reductions, fixed order => deterministic.
+// ---------------------------------------------------------------------------
 __device__ inline double wave_sum(double v)
 {
 #pragma unroll

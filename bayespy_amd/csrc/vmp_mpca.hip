@@ -263,9 +263,65 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
 // One wavefront per plate (two plates in flight per wavefront to hide the serial pivot chains).
 // FROM_VALUE: delta moments of a given <x> (initialize_from_value): <xx> = x x^T, no inverse.
 // -------------------------------------------------------------------------------------------
+// The packed row of one plate as this lane needs it: 16 matrix elements (the 2 x 2 accumulator
+// tiles) and its 8 right-hand-side entries.
+struct plate_raw {
+    double a[2][2][4];
+    double h[2][4];
+};
+
 template <int KT>
-__device__ __forceinline__ void load_sym_tiles(v4f64 (&T)[2][2], const double *__restrict__ row,
-                                               int K, double diag, double scale, int l15, int l4)
+__device__ __forceinline__ void load_raw(plate_raw &q, const double *row, int K, int l15, int l4)
+{
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                const int a = i > j ? i : j, b = i > j ? j : i;
+                q.a[tr][tc][r] = (i < K && j < K) ? row[tri(a, b)] : 0.0;
+            }
+    const double *pb = row + 16 * PT;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * tr + 4 * r + l4;
+            q.h[tr][r] = (m < K) ? pb[m] : 0.0;
+        }
+}
+
+// One packed row (LR doubles, 16-byte aligned) as whole 16-byte lanes: the copy of the NEXT
+// plate's row that a wavefront keeps in flight while it sweeps the current one.
+template <int LR>
+struct row_copy {
+    static constexpr int NV = (LR / 2 + 63) / 64;
+    v2f64 v[NV];
+    __device__ __forceinline__ void load(const double *__restrict__ row, int l)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int pidx = l + 64 * i;
+            v[i] = (pidx < LR / 2) ? __builtin_nontemporal_load(
+                                         reinterpret_cast<const v2f64 *>(row) + pidx)
+                                   : v2f64{0.0, 0.0};
+        }
+    }
+    __device__ __forceinline__ void store(double *stage, int l) const
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int pidx = l + 64 * i;
+            if (pidx < LR / 2) reinterpret_cast<v2f64 *>(stage)[pidx] = v[i];
+        }
+    }
+};
+
+__device__ __forceinline__ void tiles_from_raw(v4f64 (&T)[2][2], const plate_raw &q, int K,
+                                               double diag, double scale, int l15, int l4)
 {
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr)
@@ -274,14 +330,8 @@ __device__ __forceinline__ void load_sym_tiles(v4f64 (&T)[2][2], const double *_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
-                double v;
-                if (i < K && j < K) {
-                    const int a = i > j ? i : j, b = i > j ? j : i;
-                    v = scale * row[tri(a, b)] + ((i == j) ? diag : 0.0);
-                } else {
-                    v = (i == j) ? 1.0 : 0.0;
-                }
-                T[tr][tc][r] = v;
+                T[tr][tc][r] = (i < K && j < K) ? scale * q.a[tr][tc][r] + ((i == j) ? diag : 0.0)
+                                                : ((i == j) ? 1.0 : 0.0);
             }
 }
 
@@ -292,7 +342,7 @@ struct plate_result {
 };
 
 // T (= Lam) -> T = Cov + x x^T, x = Cov rhs
-__device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const double *__restrict__ pb,
+__device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const double (&hh)[2][4],
                                                      double scale, int K, int l15, int l4,
                                                      double prod, double ld, int bad)
 {
@@ -314,8 +364,7 @@ __device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const dou
     for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = 16 * tr + 4 * r + l4;
-            const double h = (m < K) ? scale * pb[m] : 0.0;
+            const double h = scale * hh[tr][r];
             p0 += h * T[tr][0][r];
             p1 += h * T[tr][1][r];
         }
@@ -382,6 +431,7 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
     __shared__ double red[NT / 64];
     __shared__ double sxs[4 * KP * KP];
+    __shared__ __attribute__((aligned(16))) double stg[4][16 * (PT + KT)];
     v4f64 SA[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}},
                       {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
     double *Xw = write_x ? Xm : nullptr;
@@ -419,31 +469,36 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
             store_plate<KT>(T, res, n, n0 + n, K, XXf, Xw, l15, l4, trl, SA);
         }
     } else {
-        for (int64_t n = ((int64_t)blockIdx.x * 4 + w) * NM; n < nplates_chunk; n += nwaves * NM) {
-            v4f64 T[NM][2][2];
-            const double *rows[NM];
-            double pr[NM], lg[NM];
-            int bd[NM];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int64_t nn = (n + m < nplates_chunk) ? n + m : n;     // tail: redo plate n
-                rows[m] = Lam + nn * LR;
-                load_sym_tiles<KT>(T[m], rows[m], K, x_prec, tau, l15, l4);
-                pr[m] = 1.0;
-                lg[m] = 0.0;
-                bd[m] = 0;
-            }
-            sweep_multi<0, NM>(T, nblocks, l15, l4, pr, lg, bd);
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const plate_result A = finish_plate(T[m], rows[m] + 16 * PT, tau, K, l15, l4,
-                                                    pr[m], lg[m], bd[m]);
-                if (n + m < nplates_chunk) {
-                    store_plate<KT>(T[m], A, n + m, n0 + n + m, K, XXf, Xw, l15, l4, trl, SA);
-                    ldsum -= A.logdet;
-                    anybad |= A.bad;
-                }
-            }
+        static_assert(NM == 1, "one plate per wavefront at a time (more were measured: slower)");
+        // One wavefront works on one plate at a time, so without a prefetch every plate pays the
+        // full memory latency before its sweep starts (measured: 2.6 of 9.0 ms per 2^20 plates,
+        // plus 1 ms for the right-hand side that was fetched after the sweep).  The packed row of
+        // plate n+1 is therefore copied HBM -> registers (16-byte lanes, coalesced) while plate n
+        // is swept, parked in LDS at the end of the iteration, and gathered from there.
+        constexpr int LRC = 16 * (PT + KT);
+        double *stage = stg[w];
+        row_copy<LRC> rc;
+        int64_t n = (int64_t)blockIdx.x * 4 + w;
+        if (n < nplates_chunk) {
+            rc.load(Lam + n * LRC, l);
+            rc.store(stage, l);
+        }
+        for (; n < nplates_chunk; n += nwaves) {
+            const bool more = n + nwaves < nplates_chunk;
+            if (more) rc.load(Lam + (n + nwaves) * LRC, l);
+            lds_fence();
+            plate_raw cur;
+            load_raw<KT>(cur, stage, K, l15, l4);
+            v4f64 T[2][2];
+            tiles_from_raw(T, cur, K, x_prec, tau, l15, l4);
+            double pr = 1.0, lg = 0.0;
+            int bd = 0;
+            sweep_upto<0>(T, nblocks, l15, l4, pr, lg, bd);
+            const plate_result A = finish_plate(T, cur.h, tau, K, l15, l4, pr, lg, bd);
+            store_plate<KT>(T, A, n, n0 + n, K, XXf, Xw, l15, l4, trl, SA);
+            ldsum -= A.logdet;
+            anybad |= A.bad;
+            if (more) rc.store(stage, l);
         }
     }
     // per-workgroup partial sums: tr<xx>, log|Cov| (uniform per wavefront: count once), status
@@ -715,7 +770,9 @@ mpca_w_kernel(vmp_mpca_layout L, int D, int K, int DQ, int mode, double *__restr
     v4f64 T[2][2];
     plate_result res;
     if (mode == 0) {
-        load_sym_tiles<KT>(T, mrow, K, 0.0, tau, l15, l4);
+        plate_raw q;
+        load_raw<KT>(q, mrow, K, l15, l4);
+        tiles_from_raw(T, q, K, 0.0, tau, l15, l4);
         // + diag<alpha>
 #pragma unroll
         for (int tr = 0; tr < 2; ++tr)
@@ -727,7 +784,7 @@ mpca_w_kernel(vmp_mpca_layout L, int D, int K, int DQ, int mode, double *__restr
         double prod = 1.0, ld = 0.0;
         int bad = 0;
         sweep_upto<0>(T, (K + 3) / 4, l15, l4, prod, ld, bad);
-        res = finish_plate(T, mrow + 16 * PT, tau, K, l15, l4, prod, ld, bad);
+        res = finish_plate(T, q.h, tau, K, l15, l4, prod, ld, bad);
     } else {
         const double xa = (mode == 1 && l4 == 0 && l15 < K) ? wrow[l15] : 0.0;
         const double xb = (mode == 1 && KT > 1 && l4 == 0 && 16 + l15 < K) ? wrow[16 + l15] : 0.0;
@@ -1067,9 +1124,9 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     }
     // ---- stage 2: per-plate sweep ---------------------------------------------------------------
     hipStream_t s = cs.sS;
-    int nm = vmp_tune_get("mpca_sweep_nm", 1), occ = vmp_tune_get("mpca_sweep_occ", 2);
-    if (m.KT == 1 || from_value) { nm = 1; occ = 2; }
-    int64_t gs = (nplates + 4 * nm - 1) / (4 * nm);
+    int occ = vmp_tune_get("mpca_sweep_occ", 2);
+    if (m.KT == 1 || from_value) occ = 2;
+    int64_t gs = (nplates + 3) / 4;
     const int64_t gs_cap = grid_cap(ctx, cs.wgs_sweep);
     if (gs > gs_cap) gs = gs_cap;
     if (gs < 1) gs = 1;
@@ -1082,9 +1139,7 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         else MPCA_SWEEP(1, false, 1, 2);
     } else if (from_value) {
         MPCA_SWEEP(2, true, 1, 2);
-    } else if (nm == 1 && occ == 3) MPCA_SWEEP(2, false, 1, 3);
-    else if (nm == 2 && occ == 1) MPCA_SWEEP(2, false, 2, 1);
-    else if (nm == 2 && occ == 2) MPCA_SWEEP(2, false, 2, 2);
+    } else if (occ == 3) MPCA_SWEEP(2, false, 1, 3);
     else MPCA_SWEEP(2, false, 1, 2);
 #undef MPCA_SWEEP
     VMP_HIP_CHECK(ctx, hipGetLastError());
