@@ -80,7 +80,19 @@ class Runtime:
         box = [cid.raw if self.rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         cid = ctypes.create_string_buffer(box[0], 128)
-        self.check(self.lib.vmp_comm_init_rank(self.ctx, cid, self.rank, self.world))
+        rc = self.lib.vmp_comm_init_rank(self.ctx, cid, self.rank, self.world)
+        # every rank must take the same path: agree on the outcome through the rendezvous
+        ok = self.torch.tensor([1 if rc == 0 else 0], dtype=self.torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            import warnings
+            msg = self.lib.vmp_last_error(self.ctx)
+            warnings.warn('library RCCL communicator not available (%s): plate sums go through '
+                          'torch.distributed.all_reduce'
+                          % (msg.decode() if msg else 'a rank failed to join'))
+            if rc == 0:
+                self.lib.vmp_comm_destroy(self.ctx)
+            return False
         self._comm_state = True
         return True
 

@@ -47,6 +47,14 @@ class Reader:
     def has(self, path):
         return (path in self._h5) if self._h5 is not None else (path in self._npz.files)
 
+    def keys(self):
+        """All leaf paths."""
+        if self._h5 is None:
+            return list(self._npz.files)
+        out = []
+        self._h5.visititems(lambda name, obj: out.append(name) if hasattr(obj, 'shape') else None)
+        return out
+
     def get(self, path):
         if not self.has(path):
             raise KeyError(path)

@@ -52,10 +52,12 @@ class VB:
         for i, n in enumerate(nodes):
             if not isinstance(n, Node):
                 raise ValueError("Argument number %d is not a node" % (i + 1))
-        self.autosave_filename = autosave_filename
+        # vmp.py:87-99: without a name the autosave goes to a temporary file
         self.autosave_iterations = int(autosave_iterations or 0)
-        if self.autosave_iterations and not autosave_filename:
-            raise ValueError('autosave_iterations needs autosave_filename')
+        self.autosave_nodes = None
+        self.filename = autosave_filename or None
+        self._autosave_tmp = None
+        self.autosave_filename = autosave_filename or None
         if use_logging:
             import logging
             self.print = logging.getLogger(__name__).info
@@ -101,6 +103,34 @@ class VB:
     def set_callback(self, callback):
         self.callback = callback
 
+    def set_autosave(self, filename, iterations=None, nodes=None):
+        """vmp.py:121-126."""
+        self.autosave_filename = filename
+        self.filename = filename
+        self.autosave_nodes = nodes
+        if iterations is not None:
+            self.autosave_iterations = int(iterations)
+
+    def _autosave_target(self):
+        if not self.autosave_filename:
+            import datetime
+            import tempfile
+            prefix = 'vb_autosave_%s_' % datetime.datetime.today().strftime('%Y%m%d%H%M%S')
+            self._autosave_tmp = tempfile.NamedTemporaryFile(prefix=prefix, suffix='.ckpt')
+            self.autosave_filename = self._autosave_tmp.name
+        return self.autosave_filename
+
+    @staticmethod
+    def load_user_data(filename):
+        """The ``user_data`` dictionary stored by ``save`` (vmp.py:295-305)."""
+        from .checkpoint import Reader
+        r = Reader(filename)
+        try:
+            return {k[len('user_data/'):]: np.array(r.get(k)) for k in r.keys()
+                    if k.startswith('user_data/')}
+        finally:
+            r.close()
+
     def _append_iterations(self, k):
         self.L = np.append(self.L, np.full(k, np.nan))
         self.cputime = np.append(self.cputime, np.full(k, np.nan))
@@ -127,8 +157,6 @@ class VB:
                     tqdm.update()
                 if self._end_iteration_step(None, cputime, tol=tol, verbose=verbose):
                     return
-                if self.autosave_iterations and self.iter % self.autosave_iterations == 0:
-                    self.save()
         finally:
             # plans may keep plate-sized work in flight on their own streams across
             # iterations; order the caller's stream after it before handing back control
@@ -192,6 +220,9 @@ class VB:
             w.put('callback_output', self.callback_output)
         for n in nodes:
             w.put('boundterms/' + n.name, self.l[n])
+        if self.user_data is not None:
+            for key, value in self.user_data.items():
+                w.put('user_data/%s' % key, np.asarray(value))
         w.close()
 
     def load(self, *nodes, filename=None, nodes_only=False):
@@ -221,7 +252,8 @@ class VB:
                 self.iter = int(r.get('iter'))
                 self.converged = bool(r.get('converged'))
                 for n in nodes:
-                    self.l[n] = np.array(r.get('boundterms/' + n.name))
+                    if r.has('boundterms/' + n.name):       # a file of an autosave_nodes subset
+                        self.l[n] = np.array(r.get('boundterms/' + n.name))
                 if r.has('callback_output'):
                     self.callback_output = np.array(r.get('callback_output'))
         finally:
@@ -509,4 +541,13 @@ class VB:
                 self.converged = True
         self.iter += 1
         self.annealing_changed = False
+        # auto-save (vmp.py:749-758): here, so that every iteration driver (update, optimize,
+        # pattern_search) and the converging iteration are covered
+        if self.autosave_iterations > 0 and self.iter % self.autosave_iterations == 0:
+            if self.autosave_nodes is not None:
+                self.save(*self.autosave_nodes, filename=self._autosave_target())
+            else:
+                self.save(filename=self._autosave_target())
+            if verbose:
+                self.print('Auto-saved to %s' % self.autosave_filename)
         return self.converged
