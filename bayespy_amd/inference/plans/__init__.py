@@ -11,6 +11,31 @@ from .lssm import LSSMPlan
 PLAN_TYPES = [PCAPlan, MaskedPCAPlan, GMMPlan, LSSMPlan]
 
 
+def _reusable_plans(nodes, engine):
+    """In the reference the state of q lives in the nodes, so a second ``VB`` over nodes that
+    were already updated continues from their posteriors.  Here it lives in the plans: when the
+    plans that own these nodes cover exactly what is asked for, they are kept."""
+    from ...nodes.node import Stochastic
+    from .generic import GenericPlan
+    plans = []
+    for n in nodes:
+        if not isinstance(n, Stochastic):
+            continue
+        p = n._plan
+        if p is None:
+            return None
+        if not any(p is q for q in plans):
+            plans.append(p)
+    if not plans:
+        return None
+    if engine == 'generic' and not all(isinstance(p, GenericPlan) for p in plans):
+        return None
+    covered = set(id(m) for p in plans for m in p.nodes())
+    if not all(id(n) in covered for n in nodes):
+        return None
+    return plans
+
+
 def compile_model(nodes, engine=None, **options):
     """Cover the stochastic nodes of ``nodes`` with plans.  Raises
     NotImplementedError (loudly -- there is no CPU fallback) when a node is not
@@ -19,6 +44,15 @@ def compile_model(nodes, engine=None, **options):
     import os
     if engine is None:
         engine = os.environ.get('BAYESPY_AMD_ENGINE', 'auto')
+    kept = _reusable_plans(nodes, engine)
+    if kept is not None:
+        return kept
+    stale = [n.name for n in nodes if isinstance(n, Stochastic) and n._plan is not None
+             and getattr(n._plan, 'has_state', lambda: False)()]
+    if stale:
+        import warnings
+        warnings.warn('nodes %s already hold posterior state in another execution plan; the new '
+                      'plan starts from their initialisation' % ', '.join(stale))
     if engine == 'generic':
         from .generic import GenericPlan
         return [GenericPlan(nodes)]

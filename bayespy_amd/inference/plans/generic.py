@@ -1041,6 +1041,10 @@ class GenericPlan:
     def nodes(self):
         return [n for n in self.all if not isinstance(n, Constant)]
 
+    def has_state(self):
+        """Device state exists (a recompilation would discard it)."""
+        return any(st.ready for st in self.state.values())
+
     def invalidate(self, node):
         st = self.state.get(id(node))
         if st is not None:

@@ -237,6 +237,10 @@ class LSSMPlan:
     def nodes(self):
         return list(self.roles.values())
 
+    def has_state(self):
+        """Device state exists (a recompilation would discard it)."""
+        return bool(self._ready)
+
     def invalidate(self, node):
         self._ready = False
         self._version += 1

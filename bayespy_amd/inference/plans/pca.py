@@ -288,6 +288,10 @@ class PCAPlan:
     def nodes(self):
         return list(self.roles.values())
 
+    def has_state(self):
+        """Device state exists (a recompilation would discard it)."""
+        return bool(self._ready)
+
     def invalidate(self, node):
         """Data or initial value of ``node`` changed: rebuild device state lazily."""
         self.finish()

@@ -144,6 +144,27 @@ def test_checkpoint_round_trip(golden_dir, tmp_path):
     assert os.path.exists(Q6.autosave_filename)
 
 
+def test_second_vb_over_the_same_nodes_continues(golden_dir):
+    """The reference keeps q in the nodes: VB(...) over already-updated nodes continues from their
+    posteriors.  Here the plans own the state and are kept when they cover what is asked for."""
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.update(repeat=4, verbose=False)
+    Qa = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Qa.update(repeat=2, verbose=False)
+    plan = Qa.plans[0]
+    Qb = VB(*Qa.model)
+    assert Qb.plans[0] is plan and Qb.iter == 0
+    Qb.update(repeat=2, verbose=False)
+    assert np.array_equal(Qb.L[:2], Q.L[2:4])
+    # another engine cannot take the state over: a fresh plan, and a warning that says so
+    with pytest.warns(UserWarning, match='already hold posterior state'):
+        try:
+            VB(*Qa.model, engine='generic')
+        except Exception:       # noqa: BLE001 -- no device in the CPU suite
+            pass
+
+
 def test_lower_bound_cache_and_observed_skip(golden_dir):
     g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
