@@ -15,8 +15,10 @@ by orders of magnitude per iteration.  The split of work follows SURVEY.md 8(f).
 
 Supported: ``RotateGaussianARD(X)`` / ``RotateGaussianARD(X, alpha)`` for a zero-mean
 GaussianARD rotated along its last axis with the precision shared over the plates
-(``alpha`` with plates ``(K,)`` or a constant) -- the PCA / factor-analysis use.  Plate
-rotations (``Q``), subsets and non-zero prior means raise ``NotImplementedError``.
+(``alpha`` with plates ``(K,)`` or a constant) -- the PCA / factor-analysis use --, of all
+components or of a ``subset`` of them (transformations.py:425-455, :639-690: the statistics are
+restricted to the subset, the rotation is the identity elsewhere).  Plate rotations (``Q``)
+and non-zero prior means raise ``NotImplementedError``.
 """
 import warnings
 
@@ -50,12 +52,20 @@ class RotateGaussianARD:
             axis -= X.ndim
         if axis < -X.ndim or axis >= 0:
             raise ValueError("Axis out of bounds")
-        if subset is not None:
-            raise NotImplementedError('subset rotations are not supported')
         if len(alpha) > 1:
             raise ValueError('Too many arguments')
         self.node_X = X
-        self.D = X.dims[0][-1]
+        self.Dfull = X.dims[0][-1]
+        # only a subset of the components is rotated (transformations.py:425-455)
+        if subset is None:
+            self.subset = None
+            self.D = self.Dfull
+        else:
+            self.subset = [int(i) for i in subset]
+            if len(set(self.subset)) != len(self.subset) or not all(
+                    0 <= i < self.Dfull for i in self.subset):
+                raise ValueError('subset must hold distinct component indices')
+            self.D = len(self.subset)
         self.update_alpha = len(alpha) == 1
         mu, prec = X.parents
         if not (isinstance(mu, Constant) and np.all(np.asarray(mu.value) == 0)):
@@ -64,18 +74,30 @@ class RotateGaussianARD:
             self.node_alpha = alpha[0]
             if self.node_alpha is not prec:
                 raise ValueError('alpha must be the precision parent of X')
-            if not isinstance(prec, Gamma) or prec.plates not in ((self.D,), (1,), ()):
+            if not isinstance(prec, Gamma) or prec.plates not in ((self.Dfull,), (1,), ()):
                 raise NotImplementedError('alpha must be a Gamma node with plates (K,) or scalar')
         else:
             if not isinstance(prec, Constant):
                 raise NotImplementedError('without alpha the precision must be a constant')
             a = np.asarray(prec.value, dtype=np.float64)
-            if a.ndim > 1 or a.size not in (1, self.D):
+            if a.ndim > 1 or a.size not in (1, self.Dfull):
                 raise NotImplementedError('constant precision must be a scalar or a (K,) vector')
-            self.alpha = np.broadcast_to(a, (self.D,)).astype(np.float64)
+            self.alpha = self._sub(np.broadcast_to(a, (self.Dfull,)).astype(np.float64))
 
     def nodes(self):
         return [self.node_X, self.node_alpha] if self.update_alpha else [self.node_X]
+
+    def _sub(self, v):
+        """Restrict a per-component vector to the rotated subset."""
+        return v if self.subset is None else v[..., self.subset]
+
+    def _embed(self, R):
+        """The rotation of all components: ``R`` on the subset, the identity elsewhere."""
+        if self.subset is None:
+            return R
+        full = np.identity(self.Dfull)
+        full[np.ix_(self.subset, self.subset)] = R
+        return full
 
     # -- statistics ---------------------------------------------------------------------------
     def setup(self, plate_axis=None):
@@ -88,15 +110,18 @@ class RotateGaussianARD:
             raise RuntimeError('node %s is not part of a VB engine' % self.node_X.name)
         st = plan.rotation_statistics(self.node_X)
         self.XX = np.asarray(st['XX'], dtype=np.float64)
+        if self.subset is not None:
+            self.XX = self.XX[np.ix_(self.subset, self.subset)]
         self.nplates = float(st['nplates'])
         if self.update_alpha:
+            K = self.Dfull
             a = self.node_alpha._plan.gamma_posterior_shape(self.node_alpha)
-            self.a = np.broadcast_to(np.asarray(a, dtype=np.float64).reshape(-1), (self.D,))
+            self.a = self._sub(np.broadcast_to(np.asarray(a, dtype=np.float64).reshape(-1), (K,)))
             a0 = np.asarray(self.node_alpha.parents[0].value, dtype=np.float64).reshape(-1)
             b0 = np.asarray(self.node_alpha.parents[1].value, dtype=np.float64).reshape(-1)
-            self.a0 = np.broadcast_to(a0, (self.D,))
-            self.b0 = np.broadcast_to(b0, (self.D,))
-            if self.node_alpha.plates != (self.D,):
+            self.a0 = self._sub(np.broadcast_to(a0, (K,)))
+            self.b0 = self._sub(np.broadcast_to(b0, (K,)))
+            if self.node_alpha.plates != (K,):
                 raise NotImplementedError('a precision shared over the rotated axis is not '
                                           'supported')
 
@@ -156,7 +181,7 @@ class RotateGaussianARD:
             inv = np.linalg.inv(R)
         if logdet is None:
             logdet = np.linalg.slogdet(R)[1]
-        self.node_X._plan.rotate_node(self.node_X, R, inv, float(logdet))
+        self.node_X._plan.rotate_node(self.node_X, self._embed(R), self._embed(inv), float(logdet))
         if self.update_alpha:
             self.node_alpha.update()
 
