@@ -267,13 +267,11 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
 // tiles) and its 8 right-hand-side entries.
 struct plate_raw {
     double a[2][2][4];
-    double h[2][4];
 };
 
 template <int KT>
 __device__ __forceinline__ void load_raw(plate_raw &q, const double *row, int K, int l15, int l4)
 {
-    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
@@ -284,14 +282,6 @@ __device__ __forceinline__ void load_raw(plate_raw &q, const double *row, int K,
                 const int a = i > j ? i : j, b = i > j ? j : i;
                 q.a[tr][tc][r] = (i < K && j < K) ? row[tri(a, b)] : 0.0;
             }
-    const double *pb = row + 16 * PT;
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 16 * tr + 4 * r + l4;
-            q.h[tr][r] = (m < K) ? pb[m] : 0.0;
-        }
 }
 
 // One packed row (LR doubles, 16-byte aligned) as whole 16-byte lanes: the copy of the NEXT
@@ -342,7 +332,7 @@ struct plate_result {
 };
 
 // T (= Lam) -> T = Cov + x x^T, x = Cov rhs
-__device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const double (&hh)[2][4],
+__device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const double *pb,
                                                      double scale, int K, int l15, int l4,
                                                      double prod, double ld, int bad)
 {
@@ -364,7 +354,8 @@ __device__ __forceinline__ plate_result finish_plate(v4f64 (&T)[2][2], const dou
     for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double h = scale * hh[tr][r];
+            const int m = 16 * tr + 4 * r + l4;
+            const double h = (m < K) ? scale * pb[m] : 0.0;
             p0 += h * T[tr][0][r];
             p1 += h * T[tr][1][r];
         }
@@ -388,14 +379,22 @@ template <int KT>
 __device__ __forceinline__ void store_plate(const v4f64 (&T)[2][2], const plate_result &res,
                                             int64_t n_chunk, int64_t n_glob, int K,
                                             double *__restrict__ XXf, double *__restrict__ Xm,
-                                            int l15, int l4, double &trl, v4f64 (&SA)[2][2])
+                                            int l15, int l4, double &trl, double *sa)
 {
-    // sum over the plates of <x x^T>_n (RotateGaussianARD needs it, transformations.py:476-640)
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+    // sum over the plates of <x x^T>_n (RotateGaussianARD needs it, transformations.py:476-640):
+    // this wavefront's K x K accumulator lives in LDS (every element has one owner lane, so
+    // read-add-write needs no atomics); in registers it cost 32 VGPRs of a kernel that is bound
+    // by the number of plates it can keep in flight
 #pragma unroll
     for (int tr = 0; tr < KT; ++tr)
 #pragma unroll
-        for (int tc = 0; tc < KT; ++tc) SA[tr][tc] += T[tr][tc];
-    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+        for (int tc = 0; tc < KT; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
+                sa[i * KP + j] += T[tr][tc][r];
+            }
     double *xb = XXf + (((n_chunk >> 3) * PT) * 64 + (n_chunk & 3) * 16) * 2 + ((n_chunk >> 2) & 1);
 #pragma unroll
     for (int tr = 0; tr < KT; ++tr)
@@ -429,11 +428,10 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
                   double *__restrict__ partial, double *__restrict__ partial_sxx)
 {
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+    constexpr int LRC = 16 * (PT + KT);
     __shared__ double red[NT / 64];
     __shared__ double sxs[4 * KP * KP];
-    __shared__ __attribute__((aligned(16))) double stg[4][16 * (PT + KT)];
-    v4f64 SA[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}},
-                      {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+    __shared__ __attribute__((aligned(16))) double stg[4][NM][LRC];
     double *Xw = write_x ? Xm : nullptr;
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = l & 15, l4 = l >> 4;
@@ -442,6 +440,9 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
     double trl = 0.0, ldsum = 0.0;
     int anybad = 0;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    double *sa = sxs + w * KP * KP;          // this wavefront's sum of <x x^T>_n
+    for (int e = l; e < KP * KP; e += 64) sa[e] = 0.0;
+    lds_fence();
     if (FROM_VALUE) {
         for (int64_t n = (int64_t)blockIdx.x * 4 + w; n < nplates_chunk; n += nwaves) {
             const double *xr = Xm + (n0 + n) * KP;
@@ -466,39 +467,58 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
             res.x1 = xb;
             res.logdet = 0.0;
             res.bad = 0;
-            store_plate<KT>(T, res, n, n0 + n, K, XXf, Xw, l15, l4, trl, SA);
+            store_plate<KT>(T, res, n, n0 + n, K, XXf, Xw, l15, l4, trl, sa);
         }
     } else {
-        static_assert(NM == 1, "one plate per wavefront at a time (more were measured: slower)");
-        // One wavefront works on one plate at a time, so without a prefetch every plate pays the
-        // full memory latency before its sweep starts (measured: 2.6 of 9.0 ms per 2^20 plates,
-        // plus 1 ms for the right-hand side that was fetched after the sweep).  The packed row of
-        // plate n+1 is therefore copied HBM -> registers (16-byte lanes, coalesced) while plate n
-        // is swept, parked in LDS at the end of the iteration, and gathered from there.
-        constexpr int LRC = 16 * (PT + KT);
-        double *stage = stg[w];
-        row_copy<LRC> rc;
-        int64_t n = (int64_t)blockIdx.x * 4 + w;
-        if (n < nplates_chunk) {
-            rc.load(Lam + n * LRC, l);
-            rc.store(stage, l);
-        }
-        for (; n < nplates_chunk; n += nwaves) {
-            const bool more = n + nwaves < nplates_chunk;
-            if (more) rc.load(Lam + (n + nwaves) * LRC, l);
+        // A wavefront works on NM plates at a time, their sweeps interleaved in one instruction
+        // stream (the serial pivot chain of one fills the latency gaps of the other).  The packed
+        // rows of the NEXT NM plates are copied HBM -> registers (16-byte lanes, coalesced) while
+        // the current ones are swept, parked in LDS at the end of the iteration and gathered
+        // from there: without the prefetch every plate paid the full memory latency before its
+        // sweep started (measured: 2.6 of 9.0 ms per 2^20 plates, plus 1 ms for the right-hand
+        // side that was fetched after the sweep).
+        row_copy<LRC> rc[NM];
+        int64_t n = ((int64_t)blockIdx.x * 4 + w) * NM;
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+            if (n + m < nplates_chunk) {
+                rc[m].load(Lam + (n + m) * LRC, l);
+                rc[m].store(stg[w][m], l);
+            }
+        for (; n < nplates_chunk; n += nwaves * NM) {
+            const int64_t nn = n + nwaves * NM;
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (nn + m < nplates_chunk) rc[m].load(Lam + (nn + m) * LRC, l);
             lds_fence();
-            plate_raw cur;
-            load_raw<KT>(cur, stage, K, l15, l4);
-            v4f64 T[2][2];
-            tiles_from_raw(T, cur, K, x_prec, tau, l15, l4);
-            double pr = 1.0, lg = 0.0;
-            int bd = 0;
-            sweep_upto<0>(T, nblocks, l15, l4, pr, lg, bd);
-            const plate_result A = finish_plate(T, cur.h, tau, K, l15, l4, pr, lg, bd);
-            store_plate<KT>(T, A, n, n0 + n, K, XXf, Xw, l15, l4, trl, SA);
-            ldsum -= A.logdet;
-            anybad |= A.bad;
-            if (more) rc.store(stage, l);
+            v4f64 T[NM][2][2];
+            double pr[NM], lg[NM];
+            int bd[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                plate_raw cur;
+                // a plate beyond the end re-does the previous content of its slot; not stored
+                load_raw<KT>(cur, stg[w][m], K, l15, l4);
+                tiles_from_raw(T[m], cur, K, x_prec, tau, l15, l4);
+                pr[m] = 1.0;
+                lg[m] = 0.0;
+                bd[m] = 0;
+            }
+            sweep_multi<0, NM>(T, nblocks, l15, l4, pr, lg, bd);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const plate_result A = finish_plate(T[m], stg[w][m] + 16 * PT, tau, K, l15, l4,
+                                                    pr[m], lg[m], bd[m]);
+                if (n + m < nplates_chunk) {
+                    store_plate<KT>(T[m], A, n + m, n0 + n + m, K, XXf, Xw, l15, l4, trl, sa);
+                    ldsum -= A.logdet;
+                    anybad |= A.bad;
+                }
+            }
+            lds_fence();
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (nn + m < nplates_chunk) rc[m].store(stg[w][m], l);
         }
     }
     // per-workgroup partial sums: tr<xx>, log|Cov| (uniform per wavefront: count once), status
@@ -510,20 +530,13 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
         partial[3 * blockIdx.x + 1] = ldw;
         partial[3 * blockIdx.x + 2] = bd;
     }
-    // sum_n <xx>_n of this workgroup: the four wavefronts through LDS, fixed order
-#pragma unroll
-    for (int tr = 0; tr < KT; ++tr)
-#pragma unroll
-        for (int tc = 0; tc < KT; ++tc)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
-                sxs[w * KP * KP + i * KP + j] = (i < K && j < K) ? SA[tr][tc][r] : 0.0;
-            }
+    // sum_n <xx>_n of this workgroup: the four wavefronts' LDS accumulators, fixed order
     __syncthreads();
-    for (int e = threadIdx.x; e < KP * KP; e += NT)
-        partial_sxx[(int64_t)blockIdx.x * KP * KP + e] =
-            (sxs[e] + sxs[KP * KP + e]) + (sxs[2 * KP * KP + e] + sxs[3 * KP * KP + e]);
+    for (int e = threadIdx.x; e < KP * KP; e += NT) {
+        const int i = e / KP, j = e - i * KP;
+        const double v = (sxs[e] + sxs[KP * KP + e]) + (sxs[2 * KP * KP + e] + sxs[3 * KP * KP + e]);
+        partial_sxx[(int64_t)blockIdx.x * KP * KP + e] = (i < K && j < K) ? v : 0.0;
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -784,7 +797,7 @@ mpca_w_kernel(vmp_mpca_layout L, int D, int K, int DQ, int mode, double *__restr
         double prod = 1.0, ld = 0.0;
         int bad = 0;
         sweep_upto<0>(T, (K + 3) / 4, l15, l4, prod, ld, bad);
-        res = finish_plate(T, q.h, tau, K, l15, l4, prod, ld, bad);
+        res = finish_plate(T, mrow + 16 * PT, tau, K, l15, l4, prod, ld, bad);
     } else {
         const double xa = (mode == 1 && l4 == 0 && l15 < K) ? wrow[l15] : 0.0;
         const double xb = (mode == 1 && KT > 1 && l4 == 0 && 16 + l15 < K) ? wrow[16 + l15] : 0.0;
@@ -1124,9 +1137,9 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     }
     // ---- stage 2: per-plate sweep ---------------------------------------------------------------
     hipStream_t s = cs.sS;
-    int occ = vmp_tune_get("mpca_sweep_occ", 2);
-    if (m.KT == 1 || from_value) occ = 2;
-    int64_t gs = (nplates + 3) / 4;
+    int nm = vmp_tune_get("mpca_sweep_nm", 2);
+    if (m.KT == 1 || from_value) nm = 1;
+    int64_t gs = (nplates + 4 * nm - 1) / (4 * nm);
     const int64_t gs_cap = grid_cap(ctx, cs.wgs_sweep);
     if (gs > gs_cap) gs = gs_cap;
     if (gs < 1) gs = 1;
@@ -1139,7 +1152,7 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         else MPCA_SWEEP(1, false, 1, 2);
     } else if (from_value) {
         MPCA_SWEEP(2, true, 1, 2);
-    } else if (occ == 3) MPCA_SWEEP(2, false, 1, 3);
+    } else if (nm == 2) MPCA_SWEEP(2, false, 2, 2);
     else MPCA_SWEEP(2, false, 1, 2);
 #undef MPCA_SWEEP
     VMP_HIP_CHECK(ctx, hipGetLastError());

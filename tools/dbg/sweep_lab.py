@@ -26,7 +26,8 @@ Q.ignore_bound_checks = True
 Q.update(repeat=2, verbose=False)
 plan = Q.plans[0]
 plan.enable_timing(True)
-for dbg in (0, 1):
+for dbg in (1, 2, 1, 2):
+    rt.lib.vmp_tune_set(b'mpca_sweep_nm', dbg)
     for _ in range(2):
         X.update()
     torch.cuda.synchronize()
