@@ -32,4 +32,5 @@ prof lssm lssm $Ls
 pmcs lssm lssm "LSSM B=100000 T=1000 M=8 D=4" $Ls
 G="python $R/bench.py --config gmm --steps 5 --no-cpu-baseline"
 prof gmm gmm_pass $G
+pmcs gmm gmm_pass "GMM N=10000000 D=8 K=64" $G
 ls -la $O

@@ -1,0 +1,23 @@
+#!/bin/bash
+O=gpurun_out/r02h
+mkdir -p $O
+export TMPDIR=/tmp
+s=$(date +%s)
+( timeout 1500 python -m pytest tests -m gpu -q --durations=10 > $O/pytest_all.txt 2>&1 ); echo "rc=$?" >> $O/pytest_all.txt
+echo "pytest secs: $(( $(date +%s) - s ))"
+tail -16 $O/pytest_all.txt
+grep -E "^(FAILED|ERROR)|^E  " $O/pytest_all.txt | head -30
+( timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ); cut -c1-700 $O/bench_default.json; tail -2 $O/bench_default.err
+python - <<PY
+import json
+d=json.load(open('$O/bench_default.json'))
+print('roofline', d['roofline'])
+print('cpu', d.get('cpu_baseline'))
+for e in d.get('extra', []):
+    print(e.get('metric'), e.get('value'), e.get('ms_per_step'), (e.get('roofline') or {}).get('frac'), e.get('error'))
+PY
+bash tools/collect_profiles_r02.sh $O/prof > $O/collect.log 2>&1
+tail -3 $O/collect.log
+( timeout 600 python bench.py --no-extra > $O/bench_after_profiles.json 2>> $O/bench_default.err ); python -c "
+import json; d=json.load(open('$O/bench_after_profiles.json')); print('traffic', d['roofline'].get('traffic'), d['value'])"
+echo "total secs: $(( $(date +%s) - s ))"
