@@ -540,6 +540,245 @@ mpca_sweep_kernel(const double *__restrict__ Lam, int LR, int64_t n0, int64_t np
 }
 
 // -------------------------------------------------------------------------------------------
+// mpca_rows: the same stage for 16 < K <= 32 on the vector ALU only -- a MEASURED ALTERNATIVE
+// (vmp_tune_set("mpca_rows", 1)), not the default.  The sweep form above spends ~2,400
+// instructions per plate, most of them on the 4 x 4 pivot blocks, and fp64 vector and matrix
+// instructions do not overlap on this chip.  Here a group of 16 lanes (one DPP row) owns a plate,
+// lane i of the group holds rows i and 16 + i of the 32 x 32 matrix in 128 VGPRs, and a
+// Gauss-Jordan step is: the pivot lane scales its row, every element of that row is broadcast to
+// the group with v_mov_b64_dpp row_newbcast (one instruction, no LDS), and each lane updates its
+// two rows (64 FMAs): ~150 instructions per step, 32 steps, FOUR plates per wavefront = 1,375
+// instructions per plate including gather, <x>, <x x^T> and the stores (counted: SQ_INSTS_VALU).
+// One wavefront per workgroup (4 x 4.4 KB of staged rows + the packed K x K accumulator = 22 KB
+// of LDS: seven wavefronts per CU).  Result: bit-identical bound, 5.9-6.8 ms per 2^20 plates
+// against 5.8 ms of the sweep form -- the vector ALU issues only 58 % of the time (1.75
+// wavefronts per SIMD, half of their cycles in s_waitcnt: LDS gather, the HBM round trip of the
+// next rows, a 45 KB loop body in the instruction cache).  What was needed to get there: the next
+// rows are fetched AFTER the elimination (held across it, their 36 registers spill the matrix, and
+// a spill reload waits for every outstanding store), the outer-product FMAs are kept out of one
+// big `if (valid)` block (the compiler sinks them next to the stores and keeps 32 broadcasts
+// alive), per-lane index bases are re-materialised every iteration (otherwise 128 offsets are
+// hoisted), the logarithm is taken once per wavefront.
+// -------------------------------------------------------------------------------------------
+template <int LANE>
+__device__ __forceinline__ double row_bcast(double x)
+{
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + LANE, 0xf, 0xf, true);
+}
+
+template <int P>
+__device__ __forceinline__ void rows2_steps(double (&m)[2][32], int gl, int K, double &prod,
+                                            double &ld, int &bad)
+{
+    if constexpr (P < 32) {
+        if (P < K) {
+            constexpr int HP = P >> 4, LP = P & 15;
+            const double piv = row_bcast<LP>(m[HP][P]);
+            if (!(piv > 0.0)) bad = 1;
+            // running determinant as mantissa x 2^exponent
+            const double q = prod * piv;
+            ld += (double)__builtin_amdgcn_frexp_exp(q);
+            prod = __builtin_amdgcn_frexp_mant(q);
+            const double d = fast_recip3(piv);
+            const bool isp = (gl == LP);
+            // multipliers of this lane's two rows (the pivot row itself is only scaled)
+            double c0 = m[0][P], c1 = m[1][P];
+            if (HP == 0) c0 = isp ? 0.0 : c0;
+            else c1 = isp ? 0.0 : c1;
+            // the pivot lane scales its pivot row by 1 / piv (the other lanes multiply by one: no
+            // select, no branch); the pivot element becomes 1 / piv, and column p of every other
+            // row becomes 0 - c_i * (1 / piv) in the loop below
+            const double dd = isp ? d : 1.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                m[HP][j] *= dd;
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            m[HP][P] = isp ? d : 0.0;
+            m[1 - HP][P] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double r = row_bcast<LP>(m[HP][j]);
+                m[0][j] = __builtin_fma(-c0, r, m[0][j]);
+                m[1][j] = __builtin_fma(-c1, r, m[1][j]);
+                // keep broadcast and use together: hoisting the 32 broadcasts of a step costs 64
+                // VGPRs on top of the 128 of the matrix
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        rows2_steps<P + 1>(m, gl, K, prod, ld, bad);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void rows2_outer(double (&m)[2][32], double x0, double x1)
+{
+    if constexpr (J < 32) {
+        const double xj = row_bcast<(J & 15)>(J < 16 ? x0 : x1);
+        m[0][J] = __builtin_fma(x0, xj, m[0][J]);
+        m[1][J] = __builtin_fma(x1, xj, m[1][J]);
+        if ((J & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        rows2_outer<J + 1>(m, x0, x1);
+    }
+}
+
+constexpr int RW_NT = 64;
+
+template <bool FULLK>
+__global__ void __launch_bounds__(RW_NT, 2)
+mpca_rows_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chunk, int K,
+                 double x_prec, const double *__restrict__ tau_ptr, double *__restrict__ XXf,
+                 double *__restrict__ Xm, int write_x, double *__restrict__ partial,
+                 double *__restrict__ partial_sxx)
+{
+    constexpr int KP = 32, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, LRC = 16 * (PT + 2);
+    constexpr int NPAIR = 4 * LRC / 2, NV = (NPAIR + 63) / 64;
+    __shared__ __attribute__((aligned(16))) double stg[4 * LRC];
+    __shared__ double sa[P];                     // packed sum of <x x^T>_n of this workgroup
+    const int l = threadIdx.x, gl = l & 15, grp = l >> 4;
+    const double tau = tau_ptr[0];
+    const int i0c = gl, i1c = 16 + gl;
+    const int b0c = tri(i0c, 0), b1c = tri(i1c, 0);
+    for (int e = l; e < P; e += RW_NT) sa[e] = 0.0;
+    double pm = 1.0, le = 0.0;                   // product of the pivots of this group's plates
+    int anybad = 0;
+    v2f64 nxt[NV];
+    auto fetch = [&](int64_t n) {
+        const int64_t left = nplates_chunk - n;
+        const v2f64 *src = reinterpret_cast<const v2f64 *>(Lam + n * LRC);
+        if (left >= 4) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int pidx = l + 64 * i;
+                nxt[i] = (i < NV - 1 || pidx < NPAIR) ? __builtin_nontemporal_load(src + pidx)
+                                                      : v2f64{0.0, 0.0};
+            }
+        } else {
+            const int npair = (int)(left * (LRC / 2));
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int pidx = l + 64 * i;
+                nxt[i] = (pidx < npair) ? __builtin_nontemporal_load(src + pidx) : v2f64{0.0, 0.0};
+            }
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int pidx = l + 64 * i;
+            if (pidx < NPAIR) reinterpret_cast<v2f64 *>(stg)[pidx] = nxt[i];
+        }
+    };
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t n = (int64_t)blockIdx.x * 4;
+    if (n < nplates_chunk) {
+        fetch(n);
+        park();
+    }
+    for (; n < nplates_chunk; n += step) {
+        lds_fence();
+        // the per-lane index bases are re-materialised every iteration: left loop-invariant, the
+        // compiler hoists the 64 gather offsets and the 64 store offsets of a lane out of the loop
+        // (192 VGPRs) and spills the matrix instead
+        int i0 = i0c, i1 = i1c, b0 = b0c, b1 = b1c;
+        asm volatile("" : "+v"(i0), "+v"(i1), "+v"(b0), "+v"(b1));
+        const double *row = stg + grp * LRC;
+        const bool valid = n + grp < nplates_chunk;
+        // ---- gather: m[h][j] = c delta_ij + tau Lam~[i][j], i = 16 h + gl ------------------------
+        double m[2][32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int cj = tri(j, 0);
+            const double v0 = row[(i0 >= j) ? b0 + j : cj + i0];
+            const double u1 = row[(i1 >= j) ? b1 + j : cj + i1];
+            double a0 = __builtin_fma(tau, v0, (j == i0) ? x_prec : 0.0);
+            double a1 = __builtin_fma(tau, u1, (j == i1) ? x_prec : 0.0);
+            if (!FULLK) {
+                a0 = (i0 < K && j < K) ? a0 : ((j == i0) ? 1.0 : 0.0);
+                a1 = (i1 < K && j < K) ? a1 : ((j == i1) ? 1.0 : 0.0);
+            }
+            m[0][j] = a0;
+            m[1][j] = a1;
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        double prod = 1.0, ld = 0.0;
+        int bad = 0;
+        rows2_steps<0>(m, gl, K, prod, ld, bad);
+        // ---- <x> = Cov (tau rhs), <x x^T> = Cov + <x><x>^T ----------------------------------------
+        double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const double hj = row[16 * PT + j];
+            x0 = __builtin_fma(m[0][j], hj, x0);
+            x1 = __builtin_fma(m[1][j], hj, x1);
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        x0 *= tau;
+        x1 *= tau;
+        rows2_outer<0>(m, x0, x1);
+        // ---- stores (predicated per element: inside one `if (valid)` block the compiler sinks the
+        //      64 outer-product FMAs next to the stores and keeps all 32 broadcasts alive) ------------
+        {
+            const int64_t nc = n + grp;
+            double *xb = XXf + (((nc >> 3) * PT) * 64 + (nc & 3) * 16) * 2 + ((nc >> 2) & 1);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (valid && j <= i0) {
+                    const int p = b0 + j;
+                    const double v = (FULLK || i0 < K) ? m[0][j] : 0.0;
+                    xb[8 * p - 6 * (p & 15)] = v;
+                    __hip_atomic_fetch_add(&sa[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (valid && j <= i1) {
+                    const int p = b1 + j;
+                    const double v = (FULLK || (i1 < K && j < K)) ? m[1][j] : 0.0;
+                    xb[8 * p - 6 * (p & 15)] = v;
+                    __hip_atomic_fetch_add(&sa[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (valid && write_x) {
+                double *xr = Xm + (n0 + nc) * KP;
+                xr[i0] = x0;
+                xr[i1] = x1;
+            }
+            if (valid) {
+                // log|Lam_n| = log(prod) + ld ln 2: mantissas and exponents are accumulated, the
+                // logarithm is taken once per wavefront
+                const double q = pm * prod;
+                le += ld + (double)__builtin_amdgcn_frexp_exp(q);
+                pm = __builtin_amdgcn_frexp_mant(q);
+                anybad |= bad;
+            }
+        }
+        lds_fence();
+        // the next four packed rows: HBM -> registers -> LDS at the end of the iteration (the
+        // other wavefront of the SIMD runs meanwhile); held across the elimination, their 36
+        // registers spill the matrix, and a spill reload waits for every outstanding store
+        if (n + step < nplates_chunk) {
+            fetch(n + step);
+            park();
+        }
+    }
+    lds_fence();
+    // per-workgroup partials: tr<xx> = trace of the accumulated sum, log|Cov|, status
+    double tr = (l < K) ? sa[tri(l, l)] : 0.0;
+    tr = wave_sum(tr);
+    const double ldw = wave_sum(gl == 0 ? -(log(pm) + le * 0.69314718055994530942) : 0.0);
+    const double bd = wave_sum((double)anybad);
+    if (l == 0) {
+        partial[3 * blockIdx.x + 0] = tr;
+        partial[3 * blockIdx.x + 1] = ldw;
+        partial[3 * blockIdx.x + 2] = bd;
+    }
+    for (int e = l; e < KP * KP; e += RW_NT) {
+        const int i = e / KP, j = e - i * KP;
+        const int a = i > j ? i : j, b = i > j ? j : i;
+        partial_sxx[(int64_t)blockIdx.x * KP * KP + e] = (i < K && j < K) ? sa[tri(a, b)] : 0.0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // mpca_stats: Mst[d][:] += sum_n m_dn [ packed <xx>_n | <x_n> y_dn ]
 //   A operand (d x n): mask bits (packed columns), m*y from Ymt (the KT last columns)
 //   B operand (n x col): XXf / Xm
@@ -1152,6 +1391,19 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         else MPCA_SWEEP(1, false, 1, 2);
     } else if (from_value) {
         MPCA_SWEEP(2, true, 1, 2);
+    } else if (vmp_tune_get("mpca_rows", 0) != 0) {
+        // measured alternative, not the default: see the note above mpca_rows_kernel
+        gs = (nplates + 3) / 4;
+        const int64_t cap = grid_cap(ctx, 7);
+        if (gs > cap) gs = cap;
+        if (K == 32)
+            hipLaunchKernelGGL((mpca_rows_kernel<true>), dim3((unsigned)gs), dim3(RW_NT), 0, s, Lam,
+                               n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm,
+                               inspect ? 0 : 1, pscal, psxx);
+        else
+            hipLaunchKernelGGL((mpca_rows_kernel<false>), dim3((unsigned)gs), dim3(RW_NT), 0, s, Lam,
+                               n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm,
+                               inspect ? 0 : 1, pscal, psxx);
     } else if (nm == 2) MPCA_SWEEP(2, false, 2, 2);
     else MPCA_SWEEP(2, false, 1, 2);
 #undef MPCA_SWEEP

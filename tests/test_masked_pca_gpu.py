@@ -142,6 +142,43 @@ def test_fused_block_chunking_and_device_inputs():
         np.testing.assert_allclose(x, Ls[0][2], rtol=1e-10, atol=1e-13)
 
 
+@pytest.mark.parametrize('N,D,K', [(777, 40, 32), (333, 17, 20), (64, 128, 32)])
+def test_plate_stage_variants_agree(N, D, K):
+    """The per-plate stage has three forms (vmp_tune_set): two plates per wavefront on the
+    matrix-core sweep (default), one plate per wavefront, and the vector-ALU Gauss-Jordan with a
+    plate per 16 lanes (16 < K <= 32).  Same inputs -> the same bound, moments and rotation
+    statistic to round-off."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.device import get_runtime
+    from models import build_masked_pca
+    rs = np.random.RandomState(N + K)
+    y = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+    mask = rs.rand(D, N) < 0.8
+    x0 = rs.normal(size=(N, K))
+    lib = get_runtime().lib
+    res = []
+    try:
+        for knobs in ({}, {'mpca_sweep_nm': 1}, {'mpca_rows': 1}):
+            for k, v in knobs.items():
+                lib.vmp_tune_set(k.encode(), v)
+            Q = build_masked_pca(nodes, VB, y, mask, x0)
+            Q.update(repeat=3, verbose=False)
+            st = Q.plans[0].rotation_statistics(Q['X'])
+            res.append((Q.L[:3].copy(), Q['W'].u[0].copy(), Q['X'].u[0].copy(),
+                        np.array(st['XX'])))
+            for k in knobs:
+                lib.vmp_tune_set(k.encode(), {'mpca_sweep_nm': 2, 'mpca_rows': 0}[k])
+    finally:
+        lib.vmp_tune_set(b'mpca_sweep_nm', 2)
+        lib.vmp_tune_set(b'mpca_rows', 0)
+    for L, w, x, xx in res[1:]:
+        np.testing.assert_allclose(L, res[0][0], rtol=1e-11)
+        np.testing.assert_allclose(w, res[0][1], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(x, res[0][2], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(xx, res[0][3], rtol=1e-9, atol=1e-9)
+
+
 def test_fused_block_predictive_moments_of_missing_entries(golden_dir):
     """Y.u at the missing entries after an explicit Y.update(): <f>, <f^2> + 1/<tau> from the
     current W, X, tau -- the reference's value when Y is updated last."""
