@@ -153,22 +153,50 @@ mpca_prepare_kernel(const double *__restrict__ Y, int64_t ldy, const uint8_t *__
     }
 }
 
-// out[j] (+)= sum_b partial[b * stride + j], fixed order (deterministic)
+// out[j] (+)= sum_b partial[b * stride + j], fixed order (deterministic).  A workgroup owns KX
+// neighbouring outputs; its NT / KX row-lanes split the partial blocks (eight loads in flight each)
+// and meet in LDS.  (With a thread per output the 1024 partial blocks of the sweep stage were summed
+// one dependent load after the other: 0.4-0.5 ms per chunk on the critical path.)
+template <int KX>
 __global__ void __launch_bounds__(NT)
 mpca_reduce_kernel(const double *__restrict__ partial, int nb, int64_t stride, int64_t len,
                    double *__restrict__ out, int accumulate)
 {
-    const int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (e >= len) return;
-    double s0 = 0.0, s1 = 0.0;
-    int b = 0;
-    for (; b + 1 < nb; b += 2) {
-        s0 += partial[(int64_t)b * stride + e];
-        s1 += partial[(int64_t)(b + 1) * stride + e];
+    constexpr int RY = NT / KX;
+    __shared__ double tile[RY][KX + 1];
+    const int kx = threadIdx.x % KX, ry = threadIdx.x / KX;
+    const int64_t e = (int64_t)blockIdx.x * KX + kx;
+    double acc = 0.0;
+    if (e < len) {
+        int b = ry;
+        for (; b + 7 * RY < nb; b += 8 * RY) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * RY) * stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < nb; b += RY) acc += partial[(int64_t)b * stride + e];
     }
-    if (b < nb) s0 += partial[(int64_t)b * stride + e];
-    const double s = s0 + s1;
-    out[e] = accumulate ? out[e] + s : s;
+    tile[ry][kx] = acc;
+    __syncthreads();
+    if (ry == 0 && e < len) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < RY; ++j) s += tile[j][kx];
+        out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+void launch_reduce(hipStream_t s, const double *partial, int nb, int64_t stride, int64_t len,
+                   double *out, int accumulate)
+{
+    if (len >= 16384)
+        hipLaunchKernelGGL(mpca_reduce_kernel<64>, dim3((unsigned)((len + 63) / 64)), dim3(NT), 0, s,
+                           partial, nb, stride, len, out, accumulate);
+    else
+        hipLaunchKernelGGL(mpca_reduce_kernel<16>, dim3((unsigned)((len + 15) / 16)), dim3(NT), 0, s,
+                           partial, nb, stride, len, out, accumulate);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -957,20 +985,43 @@ mpca_ryx_kernel(const double *__restrict__ Ymt, const double *__restrict__ Xm, i
     v4f64 acc[R2];
 #pragma unroll
     for (int m = 0; m < R2; ++m) acc[m] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int64_t tile = blockIdx.x; tile < ntiles_chunk; tile += gridDim.x) {
-        const double *yt = Ymt + (tile0 + tile) * ((int64_t)DP * TN);
-        __syncthreads();
-        for (int e = tid; e < DP * TN / 2; e += NT) {
-            const int d = e / (TN / 2), j2 = (e - d * (TN / 2)) * 2;
-            *reinterpret_cast<v2f64 *>(&Ys[d * SY + j2]) =
-                *reinterpret_cast<const v2f64 *>(yt + d * TN + j2);
-        }
+    // The next tile travels HBM -> registers while the current one is multiplied out of LDS (the
+    // first form loaded, synchronised, multiplied, synchronised: 1.5 ms per 2^20 plates against
+    // 0.3 ms of traffic).
+    constexpr int NY = DP * TN / 2 / NT;              // 16-byte pieces of the Ymt tile per thread
+    constexpr int NX = TN * KP / NT;                  // doubles of the Xm tile per thread
+    static_assert(DP * TN / 2 % NT == 0 && TN * KP % NT == 0, "tile sizes are multiples of the block");
+    v2f64 ry[NY];
+    double rx[NX];
+    auto fetch = [&](int64_t tile) {
+        const v2f64 *yt = reinterpret_cast<const v2f64 *>(Ymt + (tile0 + tile) * ((int64_t)DP * TN));
         const double *xt = Xm + (tile0 + tile) * ((int64_t)TN * KP);
-        for (int e = tid; e < TN * KP; e += NT) {
-            const int n = e / KP, k = e - n * KP;
-            Xs[k * SY + n] = xt[e];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) ry[i] = __builtin_nontemporal_load(yt + tid + i * NT);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rx[i] = xt[tid + i * NT];
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int e = tid + i * NT;
+            const int d = e / (TN / 2), j2 = (e - d * (TN / 2)) * 2;
+            *reinterpret_cast<v2f64 *>(&Ys[d * SY + j2]) = ry[i];
         }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * NT;
+            const int n = e / KP, k = e - n * KP;
+            Xs[k * SY + n] = rx[i];
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles_chunk) fetch(tile);
+    for (; tile < ntiles_chunk; tile += gridDim.x) {
+        __syncthreads();                              // the previous tile has been consumed
+        park();
         __syncthreads();
+        if (tile + gridDim.x < ntiles_chunk) fetch(tile + gridDim.x);
 #pragma unroll
         for (int q = 0; q < TN / 4; ++q) {
 #pragma unroll
@@ -1319,8 +1370,7 @@ int32_t vmp_mpca_prepare(vmp_ctx *ctx, const double *Y, int64_t ldy, const uint8
     hipLaunchKernelGGL(mpca_prepare_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, Y, ldy,
                        mask, ldm, N, D, m.DP, Ymt, Mb1, Mb2, partial, ntiles);
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, ctx->stream, partial, (int)g,
-                       (int64_t)2, (int64_t)2, state + L.off_scal + SC_SYY, 0);
+    launch_reduce(ctx->stream, partial, (int)g, 2, 2, state + L.off_scal + SC_SYY, 0);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -1410,13 +1460,10 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (inspect) return VMP_OK;
     // tr<xx>, log|Cov|, status, sum_n <xx>_n
-    hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal, (int)gs, (int64_t)3,
-                       (int64_t)2, state + L.off_scal + SC_TRXX, first ? 0 : 1);
-    hipLaunchKernelGGL(mpca_reduce_kernel, dim3(1), dim3(NT), 0, s, pscal + 2, (int)gs, (int64_t)3,
-                       (int64_t)1, state + L.off_scal + SC_STATUS, 1);
-    hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((m.KP * m.KP + NT - 1) / NT)), dim3(NT),
-                       0, s, psxx, (int)gs, (int64_t)(m.KP * m.KP), (int64_t)(m.KP * m.KP),
-                       state + L.off_Sxx, first ? 0 : 1);
+    launch_reduce(s, pscal, (int)gs, 3, 2, state + L.off_scal + SC_TRXX, first ? 0 : 1);
+    launch_reduce(s, pscal + 2, (int)gs, 3, 1, state + L.off_scal + SC_STATUS, 1);
+    launch_reduce(s, psxx, (int)gs, (int64_t)(m.KP * m.KP), (int64_t)(m.KP * m.KP),
+                  state + L.off_Sxx, first ? 0 : 1);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
     if (cs.eS) {
@@ -1454,8 +1501,7 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
 #undef MPCA_CASE
         VMP_HIP_CHECK(ctx, hipGetLastError());
         if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[1], s));
-        hipLaunchKernelGGL(mpca_reduce_kernel, dim3((unsigned)((len + NT - 1) / NT)), dim3(NT), 0,
-                           s, partial, (int)gw, len, len, state + L.off_M, first ? 0 : 1);
+        launch_reduce(s, partial, (int)gw, len, len, state + L.off_M, first ? 0 : 1);
         VMP_HIP_CHECK(ctx, hipGetLastError());
         if (ev2) VMP_HIP_CHECK(ctx, hipEventRecord(ev2[2], s));
     }
