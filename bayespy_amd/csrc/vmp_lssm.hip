@@ -84,16 +84,31 @@ lssm_x_layout_kernel(double *__restrict__ X, int D, int64_t B, int T, int64_t BL
 __global__ void __launch_bounds__(NT)
 lssm_sum_kernel(const double *__restrict__ partial, int n, int stride, int len, double *__restrict__ out)
 {
-    // out[j] = sum_b partial[b * stride + j], fixed order
-    for (int j = threadIdx.x; j < len; j += NT) {
-        double s0 = 0.0, s1 = 0.0;
-        int b = 0;
-        for (; b + 1 < n; b += 2) {
-            s0 += partial[(int64_t)b * stride + j];
-            s1 += partial[(int64_t)(b + 1) * stride + j];
+    // out[j] = sum_b partial[b * stride + j], fixed order.  A workgroup owns 16 neighbouring outputs;
+    // its 16 row-lanes split the partial blocks (eight loads in flight each) and meet in LDS -- with
+    // a thread per output the ~400 blocks were summed one dependent load after the other (80 us).
+    __shared__ double tile[16][17];
+    const int kx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + kx;
+    double acc = 0.0;
+    if (j < len) {
+        int b = ry;
+        for (; b + 7 * 16 < n; b += 8 * 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 16 * u) * stride + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        if (b < n) s0 += partial[(int64_t)b * stride + j];
-        out[j] = s0 + s1;
+        for (; b < n; b += 16) acc += partial[(int64_t)b * stride + j];
+    }
+    tile[ry][kx] = acc;
+    __syncthreads();
+    if (ry == 0 && j < len) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += tile[r][kx];
+        out[j] = s;
     }
 }
 
@@ -817,7 +832,8 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
 #undef LSSM_CASE
     VMP_HIP_CHECK(ctx, hipGetLastError());
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(lssm_sum_kernel, dim3(1), dim3(NT), 0, s, partial, (int)g, plen, plen, stats);
+    hipLaunchKernelGGL(lssm_sum_kernel, dim3((unsigned)((plen + 15) / 16)), dim3(NT), 0, s, partial,
+                       (int)g, plen, plen, stats);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
