@@ -544,11 +544,12 @@ __device__ inline double gamma_term(double a0, double b0, const double *g, int n
            + (a0 - a) * g[3 * n + k];
 }
 
-__global__ void __launch_bounds__(64)
-lssm_small_kernel(lssm_small_args A, double *__restrict__ st)
+// The replicated-node algebra is a few 10^4 flops of branchy scalar code: one thread.  It runs on
+// a copy of the state vector in LDS (<= 18 KB, loaded and stored back by the whole wavefront):
+// on the state in global memory every one of its ~50 dependent reads was an HBM round trip
+// (58 us per launch, three launches per iteration).
+__device__ __noinline__ void lssm_small_body(const lssm_small_args &A, double *st, double *tmp)
 {
-    if (threadIdx.x != 0) return;
-    __shared__ double tmp[DMAX * DMAX];
     const vmp_lssm_layout &L = A.L;
     const int D = A.D, M = A.M, T = A.T, DD = D * D;
     double *tau = st + L.off_tau, *gam = st + L.off_gamma, *alp = st + L.off_alpha, *nu = st + L.off_nu;
@@ -702,6 +703,19 @@ lssm_small_kernel(lssm_small_args A, double *__restrict__ st)
         }
     }
     if (bad) sc[2] = (double)VMP_ERR_NOT_POSDEF;
+}
+
+__global__ void __launch_bounds__(64)
+lssm_small_kernel(lssm_small_args A, double *__restrict__ gst)
+{
+    extern __shared__ double st_lds[];
+    __shared__ double tmp[DMAX * DMAX];
+    const int total = (int)A.L.total;
+    for (int e = threadIdx.x; e < total; e += 64) st_lds[e] = gst[e];
+    __syncthreads();
+    if (threadIdx.x == 0) lssm_small_body(A, st_lds, tmp);
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += 64) gst[e] = st_lds[e];
 }
 
 inline void fill_lssm_layout(int D, int M, vmp_lssm_layout *L)
@@ -867,7 +881,8 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
     A.B = B_total;
     for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
     A.nu_latent = nu_latent;
-    hipLaunchKernelGGL(lssm_small_kernel, dim3(1), dim3(64), 0, ctx->stream, A, state);
+    hipLaunchKernelGGL(lssm_small_kernel, dim3(1), dim3(64), (size_t)A.L.total * sizeof(double),
+                       ctx->stream, A, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
