@@ -215,9 +215,21 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
     constexpr int LR = 16 * CT;
     constexpr int CW = (CT + 3) / 4;            // column tiles per wavefront (upper bound)
+    // Column tile c = w + 4 ci.  The slots ci < CW - 1 always hold packed-<ww> tiles (A operand =
+    // the mask); only the LAST slot differs between the wavefronts: a packed tile, a <w> tile
+    // (A operand = m*y) or nothing.  The kind is fixed per wavefront, so the k-loop is compiled
+    // three times and each copy is straight-line code (with the tests inside the loop every MFMA
+    // carried a scalar branch or two selects: 5.8 vector instructions per MFMA, which on this chip
+    // add to the matrix time).
+    static_assert(4 * (CW - 1) <= PT && PT + KT <= 4 * CW, "the <w> tiles sit in the last slot");
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = l & 15, l4 = l >> 4;
+    const int c_last = w + 4 * (CW - 1);
+    const int kind = c_last >= CT ? 0 : (c_last >= PT ? 2 : 1);
     const int64_t ngroups = (nsub_chunk + NSUB - 1) / NSUB;
+    // B fragments: panel + ((c (DQ/2) + q2) 64 + l) 2 doubles; the lane part is the only VGPR term
+    const char *pl = reinterpret_cast<const char *>(panel) + (size_t)l * 16;
+    constexpr size_t TILE_B = (size_t)(DQ / 2) * 64 * 16;      // bytes of one column tile
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         v4f64 acc[CW][NSUB];
 #pragma unroll
@@ -234,41 +246,42 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
             // Ymt element (d = 4q + l4, n = 16 sub + l15): tile = sub/2, column (sub&1)*16 + l15
             yb[s] = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l4 * TN + (sub & 1) * 16 + l15;
         }
-        // the KT last column tiles (c >= PT) take m*y as their A operand; by construction of
-        // c = w + 4 ci they sit in the LAST column slot(s) of a wavefront
+        auto kloop = [&](auto KIND) {
+            constexpr int LASTK = decltype(KIND)::value;          // 0 none, 1 mask, 2 m*y
+            constexpr int NC = LASTK ? CW : CW - 1;
+            const char *pw = pl + (size_t)w * TILE_B;
 #pragma unroll 2
-        for (int q2 = 0; q2 < DQ / 2; ++q2) {
-            v2f64 b[CW];
+            for (int q2 = 0; q2 < DQ / 2; ++q2) {
+                v2f64 b[NC];
 #pragma unroll
-            for (int ci = 0; ci < CW; ++ci) {
-                const int c = w + 4 * ci;
-                b[ci] = (c < CT) ? *reinterpret_cast<const v2f64 *>(
-                                       panel + (((int64_t)c * (DQ / 2) + q2) * 64 + l) * 2)
-                                 : v2f64{0.0, 0.0};
-            }
+                for (int ci = 0; ci < NC; ++ci)
+                    b[ci] = *reinterpret_cast<const v2f64 *>(pw + (size_t)(4 * ci) * TILE_B
+                                                             + (size_t)q2 * (64 * 16));
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int q = 2 * q2 + e;
-                double am[NSUB], ay[NSUB];
+                for (int e = 0; e < 2; ++e) {
+                    const int q = 2 * q2 + e;
+                    double am[NSUB], al[NSUB];
 #pragma unroll
-                for (int s = 0; s < NSUB; ++s) {
-                    am[s] = (double)((mw[s] >> q) & 1u);
-                    // masked entries of Ymt are zero already; subtiles beyond the chunk have a
-                    // zero mask word and must not contribute either
-                    ay[s] = (mw[s] >> q) & 1u ? yb[s][(int64_t)(4 * q) * TN] : 0.0;
-                }
+                    for (int s = 0; s < NSUB; ++s) {
+                        am[s] = (double)((mw[s] >> q) & 1u);
+                        // masked entries of Ymt are zero already; subtiles beyond the chunk have a
+                        // zero mask word and must not contribute either
+                        if (LASTK == 2) al[s] = (mw[s] >> q) & 1u ? yb[s][(int64_t)(4 * q) * TN] : 0.0;
+                        else al[s] = am[s];
+                    }
 #pragma unroll
-                for (int ci = 0; ci < CW; ++ci) {
-                    const int c = w + 4 * ci;
-                    if (c < CT) {
+                    for (int ci = 0; ci < NC; ++ci) {
                         const double bb = e ? b[ci].y : b[ci].x;
 #pragma unroll
                         for (int s = 0; s < NSUB; ++s)
-                            acc[ci][s] = mfma((c >= PT) ? ay[s] : am[s], bb, acc[ci][s]);
+                            acc[ci][s] = mfma((ci == CW - 1) ? al[s] : am[s], bb, acc[ci][s]);
                     }
                 }
             }
-        }
+        };
+        if (kind == 2) kloop(std::integral_constant<int, 2>{});
+        else if (kind == 1) kloop(std::integral_constant<int, 1>{});
+        else kloop(std::integral_constant<int, 0>{});
         // C/D layout: row (plate) = (l>>4) + 4 r, column = l&15
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
