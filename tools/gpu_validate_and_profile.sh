@@ -1,4 +1,7 @@
 #!/bin/bash
+# One GPU-box call: full `pytest -m gpu`, the default bench line, rocprofv3 summaries of every block
+# (tools/collect_profiles_r02.sh) and a bench run that reads the fresh counter files.  Usage:
+#   gpurun --timeout 2400 -- bash tools/gpu_validate_and_profile.sh ; then copy gpurun_out/r02h/prof/* to profiles/r02/
 O=gpurun_out/r02h
 mkdir -p $O
 export TMPDIR=/tmp
