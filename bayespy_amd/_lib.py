@@ -143,6 +143,8 @@ SIGNATURES = {
     'vmp_lssm_cov': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_lssm_smooth': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssm_x_update': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                  c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_lssm_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f64, P(c_f64), c_i32, c_i32,
                                    P(c_i32), c_vp]),
     'vmp_gmm_get_layout': (c_i32, [c_i32, c_i32, P(GMMLayout)]),

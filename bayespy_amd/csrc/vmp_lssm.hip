@@ -179,9 +179,12 @@ __device__ inline bool stationary(double a, double b, bool act)
     return __all(!act || fabs(a - b) <= 8.0 * 2.220446049250313e-16 * m);
 }
 
+// phase bit 0: forward recursion (S^-1, J, log|Phi|, status); bit 1: backward recursion (V_t,
+// Cov(x_t, x_t+1) and their sums).  Only the forward half is needed by the per-sequence passes,
+// so vmp_lssm_x_update runs the backward half on a side stream beside them.
 template <int D>
 __global__ void __launch_bounds__(64)
-lssm_cov_kernel(cov_args a)
+lssm_cov_kernel(cov_args a, int phase)
 {
     const int l = threadIdx.x, T = a.T;
     const bool act = l < D * D;
@@ -198,7 +201,8 @@ lssm_cov_kernel(cov_args a)
     // log-pivots of the remaining interior steps are filled in without being recomputed.
     double s = act ? a.Dg0[i * D + j] : 0.0;
     int fix_from = -1;                 // steps fix_from .. T-2 share one (S^-1, J)
-    for (int t = 0; t < T; ++t) {
+    if (!(phase & 1)) fix_from = (int)a.sums[5 * D * D + 2];       // left by the forward launch
+    for (int t = 0; (phase & 1) && t < T; ++t) {
         double p1 = 1.0, e1 = 0.0;
         const double sinv = reg_spd_inverse<D>(s, i, j, act, p1, e1, bad);
         {
@@ -231,6 +235,16 @@ lssm_cov_kernel(cov_args a)
         }
     }
     const double ldsum = (log(prod) + ex * 0.69314718055994530942);
+    if (phase & 1) {
+        if (l == 0) {
+            a.sums[5 * D * D + 0] = ldsum;
+            a.sums[5 * D * D + 1] = (double)bad;
+            // diagnostics: the step at which the forward map became stationary (-1: never)
+            a.sums[5 * D * D + 2] = (double)fix_from;
+        }
+        if (!(phase & 2)) return;
+        __threadfence();            // the backward half below re-reads S^-1, J from memory
+    }
     // ---- backward: V_T-1 = S_T-1^-1;  C_t = -J_t V_t+1;  V_t = S_t^-1 - C_t J_t^T -----------------
     double v = act ? a.Sinv[(int64_t)(T - 1) * D * D + l] : 0.0;
     double sv = v, sc = 0.0;
@@ -275,13 +289,7 @@ lssm_cov_kernel(cov_args a)
         a.sums[2 * D * D + l] = vlast;
         a.sums[3 * D * D + l] = sc;
     }
-    if (l == 0) {
-        a.sums[5 * D * D + 0] = ldsum;
-        a.sums[5 * D * D + 1] = (double)bad;
-        // diagnostics: the steps at which the forward / backward maps became stationary (-1: never)
-        a.sums[5 * D * D + 2] = (double)fix_from;
-        a.sums[5 * D * D + 3] = (double)bfix;
-    }
+    if (l == 0) a.sums[5 * D * D + 3] = (double)bfix;      // diagnostics, backward map
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,8 +794,9 @@ int32_t vmp_lssm_x_layout(vmp_ctx *ctx, double *X, int32_t D, int64_t B, int32_t
     return VMP_OK;
 }
 
-int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
-                     const double *DgT, const double *E, double *Sinv, double *J, double *sums)
+static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int32_t D,
+                          const double *Dg0, const double *Dgm, const double *DgT, const double *E,
+                          double *Sinv, double *J, double *sums)
 {
     VMP_REQUIRE(ctx, ctx && Dg0 && Dgm && DgT && E && Sinv && J && sums, VMP_ERR_INVALID,
                 "null argument");
@@ -804,12 +813,18 @@ int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, cons
     a.J = J;
     a.sums = sums;
     switch (D) {
-#define LSSM_COV(d) case d: hipLaunchKernelGGL(lssm_cov_kernel<d>, dim3(1), dim3(64), 0, ctx->stream, a); break;
+#define LSSM_COV(d) case d: hipLaunchKernelGGL(lssm_cov_kernel<d>, dim3(1), dim3(64), 0, s, a, phase); break;
         LSSM_COV(1) LSSM_COV(2) LSSM_COV(3) LSSM_COV(4) LSSM_COV(5) LSSM_COV(6) LSSM_COV(7) LSSM_COV(8)
 #undef LSSM_COV
     }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
+}
+
+int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
+                     const double *DgT, const double *E, double *Sinv, double *J, double *sums)
+{
+    return launch_cov(ctx, ctx ? ctx->stream : nullptr, 3, T, D, Dg0, Dgm, DgT, E, Sinv, J, sums);
 }
 
 #define LSSM_FOR_EACH(MACRO)                                                               \
@@ -858,6 +873,35 @@ int32_t vmp_lssm_get_layout(int32_t D, int32_t M, vmp_lssm_layout *out)
     if (D > DMAX || M > 16 || (M > 8 && D > 4)) return VMP_ERR_UNSUPPORTED;
     fill_lssm_layout(D, M, out);
     return VMP_OK;
+}
+
+// X.update() in one call: covariance recursion + per-sequence passes.  The per-sequence passes
+// need only the FORWARD half of the covariance recursion (S^-1, J); its backward half (one
+// wavefront, ~0.5 ms at T = 1000) runs on a side stream beside them and is joined before return
+// (stream-ordered: the caller's stream continues after both).
+int32_t vmp_lssm_x_update(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
+                          const double *DgT, const double *E, double *Sinv, double *J,
+                          double *covsums, const double *Yt, int32_t M, int64_t B, int64_t BL,
+                          const double *Cm, const double *tau, const double *h0, double *Z,
+                          double *stats, void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx != nullptr, VMP_ERR_INVALID, "null context");
+    if (!ctx->ms[0]) {
+        for (int i = 0; i < 3; ++i)
+            VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->ms[i], hipStreamNonBlocking));
+        for (int i = 0; i < 8; ++i)
+            VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->me[i], hipEventDisableTiming));
+    }
+    int32_t rc = launch_cov(ctx, ctx->stream, 1, T, D, Dg0, Dgm, DgT, E, Sinv, J, covsums);
+    if (rc != VMP_OK) return rc;
+    VMP_HIP_CHECK(ctx, hipEventRecord(ctx->me[0], ctx->stream));
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[0], ctx->me[0], 0));
+    rc = launch_cov(ctx, ctx->ms[0], 2, T, D, Dg0, Dgm, DgT, E, Sinv, J, covsums);
+    if (rc == VMP_OK) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->me[1], ctx->ms[0]));
+    const int32_t rc2 = vmp_lssm_smooth(ctx, 0, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats,
+                                        workspace);
+    if (rc == VMP_OK) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->me[1], 0));
+    return rc != VMP_OK ? rc : rc2;
 }
 
 int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double B_total,

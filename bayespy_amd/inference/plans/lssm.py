@@ -80,6 +80,13 @@ class LSSMKernels:
                                                ptr(Cm), ptr(tau), ptr(h0), ptr(Sinv), ptr(J),
                                                ptr(Z), ptr(stats), ptr(ws)))
 
+    def x_update(self, T, D, Dg, Sinv, J, sums, Yt, M, B, BL, Cm, tau, h0, Z, stats, ws):
+        DD = D * D
+        self.rt.check(self.lib.vmp_lssm_x_update(
+            self.ctx, T, D, ptr(Dg[0:]), ptr(Dg[DD:]), ptr(Dg[2 * DD:]), ptr(Dg[3 * DD:]),
+            ptr(Sinv), ptr(J), ptr(sums), ptr(Yt), M, B, BL, ptr(Cm), ptr(tau), ptr(h0), ptr(Z),
+            ptr(stats), ptr(ws)))
+
     def small_ops(self, D, M, T, B_total, priors, nu_latent, ops, state):
         pr = (ctypes.c_double * 8)(*priors)
         arr = (ctypes.c_int32 * len(ops))(*ops)
@@ -355,11 +362,15 @@ class LSSMPlan:
         st = self.state
         if given:
             st[L.off_covsums:L.off_covsums + 5 * D * D + 4].zero_()
+            k.smooth(True, self.Yt, M, B, T, self.BL, D, st[L.off_Cm:], st[L.off_scal + 3:],
+                     st[L.off_h0:], self.Sinv, self.J, self.Z, st[L.off_raw:], self.ws)
         else:
-            k.cov(T, D, st[L.off_Dg:L.off_Dg + 4 * D * D], self.Sinv, self.J,
-                  st[L.off_covsums:L.off_covsums + 5 * D * D + 4])
-        k.smooth(given, self.Yt, M, B, T, self.BL, D, st[L.off_Cm:], st[L.off_scal + 3:],
-                 st[L.off_h0:], self.Sinv, self.J, self.Z, st[L.off_raw:], self.ws)
+            # covariance recursion + per-sequence passes; the backward half of the recursion runs
+            # beside the passes on a side stream inside the library
+            k.x_update(T, D, st[L.off_Dg:L.off_Dg + 4 * D * D], self.Sinv, self.J,
+                       st[L.off_covsums:L.off_covsums + 5 * D * D + 4], self.Yt, M, B, self.BL,
+                       st[L.off_Cm:], st[L.off_scal + 3:], st[L.off_h0:], self.Z, st[L.off_raw:],
+                       self.ws)
         self._reduce(st[L.off_raw:L.off_raw + int(L.len_raw)])
         self._ops([OP_STATS])
 

@@ -368,6 +368,14 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
                         int32_t T, int64_t BL, int32_t D, const double *Cm, const double *tau,
                         const double *h0, const double *Sinv, const double *J, double *Z,
                         double *stats, void *workspace);
+/* X.update() in one call = vmp_lssm_cov + vmp_lssm_smooth(given = 0), with the backward half of the
+ * covariance recursion (not needed by the per-sequence passes) on a side stream beside them;
+ * stream-ordered: everything is complete for later work on the context's stream. */
+int32_t vmp_lssm_x_update(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, const double *Dgm,
+                          const double *DgT, const double *E, double *Sinv, double *J,
+                          double *covsums, const double *Yt, int32_t M, int64_t B, int64_t BL,
+                          const double *Cm, const double *tau, const double *h0, double *Z,
+                          double *stats, void *workspace);
 /* Replicated-node updates / the bound, a list of vmp_lssm_op in one launch.  priors: host array
  * of 8 doubles, the Gamma (a0, b0) of tau, gamma, alpha, nu. */
 int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double B_total,
