@@ -134,6 +134,73 @@ __device__ inline double lane_get(double v, int src)
     return __shfl(v, src, 64);
 }
 
+// ---- D = 4: the matrix occupies ONE 16-lane DPP row (lane = 4 i + j), so the operands travel by
+// DPP moves (vector ALU, a few cycles) instead of ds_bpermute (the LDS crossbar, ~130 cycles each
+// on the serial path of the recursion):
+//   element (i, K) to the lanes of row i     : quad_perm [K, K, K, K]
+//   element (K, j) to the lanes of column j  : four row_newbcast of lanes 4 K + 0..3, selected by j
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int LANE>
+__device__ __forceinline__ double row16_bcast(double v)
+{
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + LANE, 0xf, 0xf, true);
+}
+
+__device__ __forceinline__ double sel4(double b0, double b1, double b2, double b3, int idx)
+{
+    const double lo = (idx & 1) ? b1 : b0, hi = (idx & 1) ? b3 : b2;
+    return (idx & 2) ? hi : lo;
+}
+
+// element (K, c) of a 4 x 4 matrix for this lane's c (c = j: column operand; c = i: transposed use)
+template <int K>
+__device__ __forceinline__ double col_get4(double v, int c)
+{
+    return sel4(row16_bcast<4 * K + 0>(v), row16_bcast<4 * K + 1>(v), row16_bcast<4 * K + 2>(v),
+                row16_bcast<4 * K + 3>(v), c);
+}
+
+template <int P>
+__device__ __forceinline__ void spd_inverse4_steps(double &v, int i, int j, double &prod, double &ex,
+                                                   int &bad)
+{
+    if constexpr (P < 4) {
+        const double piv = row16_bcast<5 * P>(v);
+        const double ci = quad_bcast<P>(v), rj = col_get4<P>(v, j);
+        if (!(piv > 0.0)) bad = 1;
+        const double q = prod * piv;
+        ex += (double)__builtin_amdgcn_frexp_exp(q);
+        prod = __builtin_amdgcn_frexp_mant(q);
+        const double d = fast_recip(piv);
+        if (i == P) v = (j == P) ? d : rj * d;
+        else if (j == P) v = -ci * d;
+        else v = v - ci * rj * d;
+        spd_inverse4_steps<P + 1>(v, i, j, prod, ex, bad);
+    }
+}
+
+// sum_k a[i][k] * bk[k]   (bk[k] = the lane's element (k, j) of the right operand, given)
+__device__ __forceinline__ double rowdot4(double a, const double (&bk)[4])
+{
+    return quad_bcast<0>(a) * bk[0] + quad_bcast<1>(a) * bk[1] + quad_bcast<2>(a) * bk[2]
+           + quad_bcast<3>(a) * bk[3];
+}
+
+// sum_k ak[k] * b[k][j]   (ak[k] given per lane)
+__device__ __forceinline__ double coldot4(const double (&ak)[4], double b, int j)
+{
+    return ak[0] * col_get4<0>(b, j) + ak[1] * col_get4<1>(b, j) + ak[2] * col_get4<2>(b, j)
+           + ak[3] * col_get4<3>(b, j);
+}
+
 // (A B)[i][j] for this lane; ta / tb: take A / B transposed
 template <int D>
 __device__ __forceinline__ double reg_matmul(double a, double b, int i, int j, bool ta, bool tb)
@@ -202,9 +269,24 @@ lssm_cov_kernel(cov_args a, int phase)
     double s = act ? a.Dg0[i * D + j] : 0.0;
     int fix_from = -1;                 // steps fix_from .. T-2 share one (S^-1, J)
     if (!(phase & 1)) fix_from = (int)a.sums[5 * D * D + 2];       // left by the forward launch
+    // D = 4: the constant operand E is fetched once: E[k][j] and E[k][i] for this lane
+    double ekj[4] = {0.0, 0.0, 0.0, 0.0}, eki[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (D == 4) {
+        ekj[0] = col_get4<0>(e, j); ekj[1] = col_get4<1>(e, j);
+        ekj[2] = col_get4<2>(e, j); ekj[3] = col_get4<3>(e, j);
+        eki[0] = col_get4<0>(e, i); eki[1] = col_get4<1>(e, i);
+        eki[2] = col_get4<2>(e, i); eki[3] = col_get4<3>(e, i);
+    }
     for (int t = 0; (phase & 1) && t < T; ++t) {
         double p1 = 1.0, e1 = 0.0;
-        const double sinv = reg_spd_inverse<D>(s, i, j, act, p1, e1, bad);
+        double sinv;
+        if constexpr (D == 4) {
+            sinv = s;
+            spd_inverse4_steps<0>(sinv, i, j, p1, e1, bad);
+            sinv = act ? sinv : 0.0;
+        } else {
+            sinv = reg_spd_inverse<D>(s, i, j, act, p1, e1, bad);
+        }
         {
             const double q = prod * p1;
             ex += e1 + (double)__builtin_amdgcn_frexp_exp(q);
@@ -212,9 +294,15 @@ lssm_cov_kernel(cov_args a, int phase)
         }
         if (act) a.Sinv[(int64_t)t * D * D + l] = sinv;
         if (t < T - 1) {
-            const double jt = reg_matmul<D>(sinv, e, i, j, false, false);      // S^-1 E
+            double jt, ej;
+            if constexpr (D == 4) {
+                jt = rowdot4(sinv, ekj);                                        // S^-1 E
+                ej = coldot4(eki, jt, j);                                       // E^T J
+            } else {
+                jt = reg_matmul<D>(sinv, e, i, j, false, false);
+                ej = reg_matmul<D>(e, jt, i, j, true, false);
+            }
             if (act) a.J[(int64_t)t * D * D + l] = jt;
-            const double ej = reg_matmul<D>(e, jt, i, j, true, false);         // E^T J
             const double snew = ((t + 1 < T - 1) ? dgm : dgT) - ej;
             if (t >= 1 && t + 1 < T - 1 && stationary(snew, s, act)) {
                 const int t1 = T - 2;                                   // last interior step
