@@ -304,7 +304,8 @@ lssm_cov_kernel(cov_args a, int phase)
             }
             if (act) a.J[(int64_t)t * D * D + l] = jt;
             const double snew = ((t + 1 < T - 1) ? dgm : dgT) - ej;
-            if (t >= 1 && t + 1 < T - 1 && stationary(snew, s, act)) {
+            // (tested every eighth step: the test itself is a 64-lane max reduction on the serial path)
+            if (t >= 1 && (t & 7) == 0 && t + 1 < T - 1 && stationary(snew, s, act)) {
                 const int t1 = T - 2;                                   // last interior step
                 for (int tt = t + 1; tt <= t1; ++tt) {
                     if (act) {

@@ -545,12 +545,18 @@ class LSSMPlan:
         self._materialize()
         self.kernels.set_timing(on)
 
+    def cov_stationary_from(self):
+        """Time steps from which the forward / backward covariance recursions of the last
+        X.update() reused a converged iterate (-1: every step was computed)."""
+        L, D = self.layout, self.D
+        self.rt.sync_stream()
+        fix = self.state[L.off_covsums + 5 * D * D + 2:L.off_covsums + 5 * D * D + 4].cpu().numpy()
+        return [int(fix[0]), int(fix[1])]
+
     def kernel_times_ms(self):
         t = self.kernels.pass_times_ms(64)
         if not t:
             return None
         n = float(len(t))
-        L, D = self.layout, self.D
-        fix = self.state[L.off_covsums + 5 * D * D + 2:L.off_covsums + 5 * D * D + 4].cpu().numpy()
         return dict(lssm_forward=sum(a for a, _ in t) / n, lssm_backward=sum(b for _, b in t) / n,
-                    cov_stationary_from=[int(fix[0]), int(fix[1])])
+                    cov_stationary_from=self.cov_stationary_from())

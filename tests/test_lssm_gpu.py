@@ -83,6 +83,25 @@ def test_fused_lssm_vs_oracle(M, B, T, D, gamma_nu):
                                [o.tau, o.logtau], rtol=1e-9)
 
 
+def test_stationary_stretch_of_the_covariance_recursion_is_filled_in():
+    """Long chains: once the filter's Riccati map has converged to working precision (8 ulp) the
+    remaining interior steps reuse one (S^-1, J) and one (V, C).  In the first iteration of this
+    model both recursions converge after a few hundred steps: the shortcut is taken (diagnostics)
+    and the results still match the oracle, which computes every step."""
+    from oracle.lssm import LSSMOracle
+    M, B, T, D = 2, 70, 600, 2
+    y, x0, c0 = _data(M, B, T, D, seed=5)
+    Q = _build(y, x0, c0, False)
+    Q.update(repeat=1, verbose=False)
+    fwd, bwd = Q.plans[0].cov_stationary_from()
+    assert 0 < fwd < T - 2 and 0 < bwd < T - 2
+    Q.update(repeat=2, verbose=False)
+    o = LSSMOracle(y, x0, c0, nu_prior=None)
+    o.iterate(3)
+    np.testing.assert_allclose(Q.L[:3], np.array(o.L), rtol=1e-9)
+    np.testing.assert_allclose(Q['X'].u[0], o.X, rtol=1e-7, atol=1e-8 * float(np.abs(o.X).max()))
+
+
 def test_fused_lssm_device_inputs_and_checkpoint(tmp_path):
     import torch
     from bayespy_amd.device import get_runtime
