@@ -22,6 +22,10 @@
 namespace {
 
 constexpr int NT = 256;
+// threads per workgroup of the per-sequence passes (one thread per sequence).  1e5 sequences are
+// only 1563 wavefronts for 1024 SIMDs; single-wavefront workgroups spread them more evenly over the
+// CUs but measured no better (forward 1.83 vs 1.72 ms, backward equal): kept at 256.
+constexpr int SNT = 256;
 constexpr int DMAX = 8;
 
 // ---------------------------------------------------------------------------------------------
@@ -386,13 +390,13 @@ lssm_cov_kernel(cov_args a, int phase)
 // ---------------------------------------------------------------------------------------------
 // z_t = h_t - J_t-1^T z_t-1,  h_t = tau sum_m y_mbt c_m  (+ h0 at t = 0)
 template <int D, int MM>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(SNT)
 lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
                     const double *__restrict__ Cm /* M x D */, const double *__restrict__ tau_ptr,
                     const double *__restrict__ h0 /* D */, const double *__restrict__ J,
                     double *__restrict__ Z)
 {
-    const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
     if (b >= B) return;
     const double tau = tau_ptr[0];
     double tc[MM][D];                       // tau * c_m (uniform: scalar registers)
@@ -406,12 +410,12 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
     const double *yp = Yt + b;
     double ycur[MM], ynxt[MM];
 #pragma unroll
-    for (int m = 0; m < MM; ++m) ycur[m] = (m < M) ? yp[(int64_t)m * BL] : 0.0;
+    for (int m = 0; m < MM; ++m) ycur[m] = (m < M) ? __builtin_nontemporal_load(&yp[(int64_t)m * BL]) : 0.0;
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) {
 #pragma unroll
             for (int m = 0; m < MM; ++m)
-                ynxt[m] = (m < M) ? yp[((int64_t)(t + 1) * M + m) * BL] : 0.0;
+                ynxt[m] = (m < M) ? __builtin_nontemporal_load(&yp[((int64_t)(t + 1) * M + m) * BL]) : 0.0;
         }
         double h[D];
 #pragma unroll
@@ -438,7 +442,7 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
             for (int i = 0; i < D; ++i) z[i] = h[i];
         }
 #pragma unroll
-        for (int i = 0; i < D; ++i) Z[((int64_t)t * D + i) * BL + b] = z[i];
+        for (int i = 0; i < D; ++i) __builtin_nontemporal_store(z[i], &Z[((int64_t)t * D + i) * BL + b]);
 #pragma unroll
         for (int m = 0; m < MM; ++m) ycur[m] = ynxt[m];
     }
@@ -452,13 +456,13 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
 //   [4 D^2, 4 D^2 + D)  sum_b x_0
 //   then M x D          sum_bt y_mbt x_bt
 template <int D, int MM>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(SNT)
 lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
                      const double *__restrict__ Sinv, const double *__restrict__ J,
                      double *__restrict__ Z, double *__restrict__ partial, int plen, int given)
 {
-    __shared__ double red[NT / 64];
-    const int64_t b = (int64_t)blockIdx.x * NT + threadIdx.x;
+    __shared__ double red[SNT / 64];
+    const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
     const bool live = b < B;
     const int64_t bb = live ? b : 0;
     double sxx[D][D], snp[D][D], sx0[D][D], sxT[D][D], s0[D], syx[MM][D];
@@ -479,17 +483,17 @@ lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int
     const double *yp = Yt + bb;
     double zc[D], yc[MM];
 #pragma unroll
-    for (int i = 0; i < D; ++i) zc[i] = zp[((int64_t)(T - 1) * D + i) * BL];
+    for (int i = 0; i < D; ++i) zc[i] = __builtin_nontemporal_load(&zp[((int64_t)(T - 1) * D + i) * BL]);
 #pragma unroll
-    for (int m = 0; m < MM; ++m) yc[m] = (m < M) ? yp[((int64_t)(T - 1) * M + m) * BL] : 0.0;
+    for (int m = 0; m < MM; ++m) yc[m] = (m < M) ? __builtin_nontemporal_load(&yp[((int64_t)(T - 1) * M + m) * BL]) : 0.0;
     for (int t = T - 1; t >= 0; --t) {
         double zq[D], yq[MM];
         if (t > 0) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) zq[i] = zp[((int64_t)(t - 1) * D + i) * BL];
+            for (int i = 0; i < D; ++i) zq[i] = __builtin_nontemporal_load(&zp[((int64_t)(t - 1) * D + i) * BL]);
 #pragma unroll
             for (int m = 0; m < MM; ++m)
-                yq[m] = (m < M) ? yp[((int64_t)(t - 1) * M + m) * BL] : 0.0;
+                yq[m] = (m < M) ? __builtin_nontemporal_load(&yp[((int64_t)(t - 1) * M + m) * BL]) : 0.0;
         }
         double x[D];
         if (given) {                        // delta moments of a given X (initialize_from_value)
@@ -518,7 +522,7 @@ lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int
         if (live) {
             if (!given) {
 #pragma unroll
-                for (int i = 0; i < D; ++i) zp[((int64_t)t * D + i) * BL] = x[i];
+                for (int i = 0; i < D; ++i) __builtin_nontemporal_store(x[i], &zp[((int64_t)t * D + i) * BL]);
             }
 #pragma unroll
             for (int i = 0; i < D; ++i)
@@ -563,10 +567,10 @@ lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            const double a = block_sum<NT>(j <= i ? sxx[i][j] : sxx[j][i], red);
-            const double c = block_sum<NT>(snp[i][j], red);
-            const double d0 = block_sum<NT>(j <= i ? sx0[i][j] : sx0[j][i], red);
-            const double dT = block_sum<NT>(j <= i ? sxT[i][j] : sxT[j][i], red);
+            const double a = block_sum<SNT>(j <= i ? sxx[i][j] : sxx[j][i], red);
+            const double c = block_sum<SNT>(snp[i][j], red);
+            const double d0 = block_sum<SNT>(j <= i ? sx0[i][j] : sx0[j][i], red);
+            const double dT = block_sum<SNT>(j <= i ? sxT[i][j] : sxT[j][i], red);
             if (threadIdx.x == 0) {
                 pb[i * D + j] = a;
                 pb[D * D + i * D + j] = c;
@@ -576,14 +580,14 @@ lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int
         }
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        const double a = block_sum<NT>(s0[i], red);
+        const double a = block_sum<SNT>(s0[i], red);
         if (threadIdx.x == 0) pb[4 * D * D + i] = a;
     }
 #pragma unroll
     for (int m = 0; m < MM; ++m)
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double a = block_sum<NT>(syx[m][i], red);
+            const double a = block_sum<SNT>(syx[m][i], red);
             if (threadIdx.x == 0 && m < M) pb[4 * D * D + D + m * D + i] = a;
         }
 }
@@ -931,7 +935,7 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
     VMP_REQUIRE(ctx, D <= DMAX && M <= 16 && (M <= 8 || D <= 4), VMP_ERR_UNSUPPORTED,
                 "the fused LSSM block supports D <= 8 with M <= 8, D <= 4 with M <= 16");
     const int MM = M <= 8 ? 8 : 16;
-    const int64_t g = (B + NT - 1) / NT;
+    const int64_t g = (B + SNT - 1) / SNT;
     const int plen = plen_of(D, M);
     double *partial = reinterpret_cast<double *>(workspace);
     hipStream_t s = ctx->stream;
@@ -940,10 +944,10 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
 #define LSSM_CASE(d, mm)                                                                      \
     if (D == d && MM == mm) {                                                                 \
         if (!given)                                                                           \
-            hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(NT), 0, s, \
+            hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, s, \
                                Yt, M, B, T, BL, Cm, tau, h0, J, Z);                           \
         if (ev) (void)hipEventRecord(ev[1], s);                                               \
-        hipLaunchKernelGGL((lssm_backward_kernel<d, mm>), dim3((unsigned)g), dim3(NT), 0, s,  \
+        hipLaunchKernelGGL((lssm_backward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, s,  \
                            Yt, M, B, T, BL, Sinv, J, Z, partial, plen, given);                \
     } else
     LSSM_FOR_EACH(LSSM_CASE) { return VMP_ERR_UNSUPPORTED; }
@@ -1023,7 +1027,7 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
 int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
 {
     if (!n || D < 1 || M < 1 || B < 1) return VMP_ERR_INVALID;
-    const int64_t g = (B + NT - 1) / NT;
+    const int64_t g = (B + SNT - 1) / SNT;
     int64_t a = g * plen_of(D, M);
     const int64_t r = 256 * 8 * 2;            // relayout partials (<= num_cu * 8 workgroups)
     *n = (a > r ? a : r) + 64;
