@@ -292,7 +292,8 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t n = (grp * NSUB + s) * 16 + l4 + 4 * r;   // plate in the chunk
-                        if (n < nplates_chunk) Lam[n * LR + 16 * c + l15] = acc[ci][s][r];
+                        if (n < nplates_chunk)
+                            __builtin_nontemporal_store(acc[ci][s][r], &Lam[n * LR + 16 * c + l15]);
                     }
             }
         }
