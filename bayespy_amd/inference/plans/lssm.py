@@ -125,8 +125,6 @@ class LSSMPlan:
             init = n._init
             if init is not None and init[0] != 'value':
                 return '%s.initialize_from_%s' % (n.name, init[0])
-        if r['X']._init is None:
-            return 'X needs initialize_from_value'
         return None
 
     @staticmethod
@@ -334,21 +332,32 @@ class LSSMPlan:
         k.relayout_y(yd, M, B, T, BL, self.Yt, self.state[L.off_scal:L.off_scal + 1], self.ws)
         del yd
         self._reduce(self.state[L.off_scal:L.off_scal + 1])
-        # ---- X: delta moments of the given value; their plate sums ---------------------------------------
-        x0 = self.X._init[1]
-        if isinstance(x0, torch.Tensor):
-            xd = x0.to(device=rt.device, dtype=torch.float64).reshape(B, T, D).contiguous()
-        else:
-            xd = torch.from_numpy(np.array(np.broadcast_to(np.asarray(x0, dtype=np.float64),
-                                                           self.X.plates + (T, D)).reshape(B, T, D),
-                                           order='C')).to(rt.device)
         self.Z = rt.zeros(T * D * BL)
-        k.x_layout(xd, D, B, T, BL, self.Z, True)
-        del xd
         self.Sinv = rt.zeros(T * D * D)
         self.J = rt.zeros(max(T - 1, 1) * D * D)
-        self._smooth(given=True)
-        self._x_updated = False
+        if self.X._init is None:
+            # ---- X from its prior (expfamily.py:168-184): q(X) = p(X | <A>, <nu>, mu0, Lam0), i.e.
+            # the smoother without the message from the observations (<tau> taken as 0) -----------
+            tau_mean = self.state[L.off_tau + 2].clone()
+            self.state[L.off_tau + 2] = 0.0
+            self._ops([OP_XPREP])
+            self._smooth(given=False)
+            self.state[L.off_tau + 2] = tau_mean
+            prior_init = True
+        else:
+            prior_init = False
+            # ---- X: delta moments of the given value; their plate sums -----------------------------------
+            x0 = self.X._init[1]
+            if isinstance(x0, torch.Tensor):
+                xd = x0.to(device=rt.device, dtype=torch.float64).reshape(B, T, D).contiguous()
+            else:
+                xd = torch.from_numpy(np.array(np.broadcast_to(np.asarray(x0, dtype=np.float64),
+                                                               self.X.plates + (T, D))
+                                               .reshape(B, T, D), order='C')).to(rt.device)
+            k.x_layout(xd, D, B, T, BL, self.Z, True)
+            del xd
+            self._smooth(given=True)
+        self._x_updated = prior_init          # a proper q(X) (covariances exist), not delta moments
         self._ready = True
         self._version += 1
 

@@ -169,6 +169,44 @@ def test_lssm_matches_reference(golden_dir, tag, B, gamma_nu, engine):
                                        err_msg='%s u[%d]' % (nm, i))
 
 
+@pytest.mark.parametrize('engine', ['fused', 'generic'])
+def test_lssm_from_prior_initialisation_matches_reference(golden_dir, engine):
+    """Every node at its default (prior) initialisation except C: the chain starts from
+    p(X | <A>, nu, mu0, Lam0) (expfamily.py:168-184) -- on the fused block the smoother without the
+    message of the observations.  Initial moments and the trace against the live reference."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    g = np.load(os.path.join(golden_dir, 'lssm_prior_init.npz'))
+    y, c0 = g['y'], g['c0']
+    M, B, T = y.shape
+    D = c0.shape[-1]
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(D,), name='alpha')
+    A = nodes.GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    X = nodes.GaussianMarkovChain(np.zeros(D), 1e-2 * np.identity(D), A, np.ones(D), n=T,
+                                  plates=(B,), name='X')
+    gamma = nodes.Gamma(1e-2, 1e-2, plates=(D,), name='gamma')
+    C = nodes.GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
+    C.initialize_from_value(c0)
+    tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+    F = nodes.SumMultiply('i,i', C, X, name='F')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = VB(Y, F, C, gamma, X, A, alpha, tau, engine=None if engine == 'fused' else 'generic')
+    Q.ignore_bound_checks = True
+    assert type(Q.plans[0]).__name__ == ('LSSMPlan' if engine == 'fused' else 'GenericPlan')
+    for i in range(3):
+        # the reference keeps the (sequence-independent) prior moments with a unit plate
+        got, ref = np.broadcast_arrays(np.asarray(X.u[i]), g['X_u%d_init' % i])
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12, err_msg='initial X.u[%d]' % i)
+    n = len(g['L'])
+    Q.update(repeat=n, verbose=False)
+    np.testing.assert_allclose(Q.L[:n], g['L'], rtol=1e-9)
+    for nm, nd in dict(X=X, A=A, C=C, tau=tau, alpha=alpha, gamma=gamma).items():
+        for i, ui in enumerate(nd.u):
+            got, ref = np.broadcast_arrays(np.asarray(ui), g['%s_u%d' % (nm, i)])
+            np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-9, err_msg='%s u[%d]' % (nm, i))
+
+
 def test_switching_state_space_model_matches_reference(golden_dir):
     """SwitchingGaussianMarkovChain inside the model of bayespy/demos/lssm_sd.py (a categorical
     Markov chain picks the dynamics matrix of every transition): five VB iterations against
