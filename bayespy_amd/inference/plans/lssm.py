@@ -123,7 +123,8 @@ class LSSMPlan:
             if getattr(n, 'observed', False):
                 return '%s is observed' % n.name
             init = n._init
-            if init is not None and init[0] != 'value':
+            if init is not None and init[0] != 'value' \
+                    and not (init[0] == 'random' and key in ('C', 'A')):
                 return '%s.initialize_from_%s' % (n.name, init[0])
         return None
 
@@ -304,6 +305,10 @@ class LSSMPlan:
         amean = st[L.off_alpha + 2 * D:L.off_alpha + 3 * D]
         if self.C._init is None:
             cm, covc = np.zeros((M, D)), np.diag(1.0 / gmean)
+        elif self.C._init[0] == 'random':
+            # initialize_from_random (expfamily.py:206-212): delta moments of a draw from the
+            # current q = the prior N(0, diag(1 / <gamma>)); host-side set-up, NumPy's global stream
+            cm, covc = np.random.normal(size=(M, D)) / np.sqrt(gmean), np.zeros((D, D))
         else:
             cm = np.broadcast_to(np.asarray(self.C._init[1], dtype=np.float64),
                                  self.C.plates + (D,)).reshape(M, D)
@@ -314,6 +319,9 @@ class LSSMPlan:
         if self.A._init is None:
             am = np.zeros((D, D))
             aa = np.broadcast_to(np.diag(1.0 / amean), (D, D, D)).copy()
+        elif self.A._init[0] == 'random':
+            am = np.random.normal(size=(D, D)) / np.sqrt(amean)
+            aa = am[:, :, None] * am[:, None, :]
         else:
             am = np.broadcast_to(np.asarray(self.A._init[1], dtype=np.float64), (D, D)).copy()
             aa = am[:, :, None] * am[:, None, :]

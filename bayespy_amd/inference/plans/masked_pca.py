@@ -450,6 +450,18 @@ class MaskedPCAPlan:
             f = w @ x.T
             f2 = np.einsum('dij,nij->dn', ww, xx)
             return [np.where(m, y, f), np.where(m, y * y, f2 + 1.0 / tau)]
+        if node is self.F:
+            # <f_dn> = <w_d>.<x_n>, <f_dn^2> = <ww>_d : <xx>_n (dot.py:316-415) -- a read-out on the
+            # host (predictions at the missing entries); the updates never form these arrays
+            if 8.0 * N * K * K > 8e9:
+                raise MemoryError('F.u would need %.0f GB of <xx> on the host; form predictions from '
+                                  'W.u[0] and X.u[0]' % (8e-9 * N * K * K))
+            w, ww = self._w_moments()
+            x = self.Xm[:N, :K].cpu().numpy()
+            xx = self.x_second_moments()
+            f = (w @ x.T).reshape(self.F.plates)
+            f2 = np.einsum('dij,nij->dn', ww, xx).reshape(self.F.plates)
+            return [f, f2]
         raise NotImplementedError('moments of %s are never materialised by the fused block'
                                   % node.name)
 

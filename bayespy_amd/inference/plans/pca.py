@@ -557,6 +557,19 @@ class PCAPlan:
         if node is self.Y:
             y = self.Yd[:, :N].cpu().numpy()
             return [y, y * y]
+        if node is self.roles.get('F'):
+            # <f_dn> = <w_d>.<x_n>; <f_dn^2> = <ww>_d : <xx>_n with the shared covariances C_W, C_X
+            # (dot.py:316-415) -- a read-out on the host; the updates never form these arrays
+            self.finish()
+            w = self._block(L.off_W, D, K, KP)
+            cw = self._block(L.off_CW, K, K, KP)
+            cx = self._block(L.off_CX, K, K, KP)
+            x = self.Xd[:K, :N].cpu().numpy().T
+            f = w @ x.T
+            f2 = f * f + np.einsum('nk,kl,nl->n', x, cw, x)[None, :] \
+                + np.einsum('dk,kl,dl->d', w, cx, w)[:, None] + np.sum(cw * cx)
+            F = self.roles['F']
+            return [f.reshape(F.plates), f2.reshape(F.plates)]
         raise NotImplementedError('moments of %s are never materialised by the fused PCA block'
                                   % node.name)
 

@@ -29,13 +29,13 @@ X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T, 
                         name='X')
 gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
 C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
-C.initialize_from_value(np.random.randn(M, 1, 1, D))
+C.initialize_from_random()
 tau = Gamma(1e-5, 1e-5, name='tau')
 F = SumMultiply('i,i', C, X, name='F')
 Y = GaussianARD(F, tau, name='Y')
 Y.observe(y)
 
-Q = VB(Y, F, C, gamma, X, A, alpha, tau)
+Q = VB(X, C, gamma, A, alpha, tau, F, Y)        # update order of demos/lssm.py:103: X first
 print('engine:', type(Q.plans[0]).__name__)
 Q.update(repeat=30, tol=1e-7)
 print('noise sd: true 0.5, estimated %.3f' % (1.0 / np.sqrt(tau.u[0])))

@@ -29,6 +29,7 @@ X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
 F = SumMultiply('i,i', W, X, name='F')
 tau = Gamma(1e-2, 1e-2, name='tau')
 Y = GaussianARD(F, tau, name='Y')
+X.initialize_from_random()
 W.initialize_from_random()
 Y.observe(y_obs, mask=mask)
 

@@ -142,6 +142,28 @@ def test_fused_block_chunking_and_device_inputs():
         np.testing.assert_allclose(x, Ls[0][2], rtol=1e-10, atol=1e-13)
 
 
+@pytest.mark.parametrize('masked', [True, False])
+def test_moments_of_the_deterministic_product_are_read_out_on_request(masked):
+    """F.u = [<w.x>, <(w.x)^2>] (dot.py:316-415) is never formed by the fused blocks' updates, but a
+    script may read it (predictions at the missing entries): same values as the generic engine."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_masked_pca
+    rs = np.random.RandomState(8)
+    D, N, K = 12, 300, 4
+    y = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+    mask = (rs.rand(D, N) < 0.8) if masked else True
+    x0 = rs.normal(size=(N, K))
+    res = []
+    for engine in (None, 'generic'):
+        Q = build_masked_pca(nodes, VB, y, mask, x0, engine=engine)
+        Q.update(repeat=3, verbose=False)
+        res.append((type(Q.plans[0]).__name__, [np.asarray(u) for u in Q['F'].u]))
+    assert res[0][0] == ('MaskedPCAPlan' if masked else 'PCAPlan') and res[1][0] == 'GenericPlan'
+    for a, b in zip(res[0][1], res[1][1]):
+        np.testing.assert_allclose(a, np.broadcast_to(b, a.shape), rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.parametrize('N,D,K', [(777, 40, 32), (333, 17, 20), (64, 128, 32)])
 def test_plate_stage_variants_agree(N, D, K):
     """The per-plate stage has three forms (vmp_tune_set): two plates per wavefront on the
