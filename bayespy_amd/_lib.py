@@ -143,6 +143,7 @@ SIGNATURES = {
     'vmp_lssm_cov': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_lssm_smooth': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssm_rotate_x': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),
     'vmp_lssm_x_update': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_lssm_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f64, P(c_f64), c_i32, c_i32,

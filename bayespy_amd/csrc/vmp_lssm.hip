@@ -85,6 +85,34 @@ lssm_x_layout_kernel(double *__restrict__ X, int D, int64_t B, int T, int64_t BL
     }
 }
 
+// <x_bt> <- R <x_bt> for every sequence and time step (the rotation x -> R x of the state space,
+// transformations.py:1167-1176 / gaussian_markov_chain.py:51-65); Z is time-major (T, D, BL).
+template <int D>
+__global__ void __launch_bounds__(NT)
+lssm_rotate_kernel(const double *__restrict__ R, int T, int64_t B, int64_t BL, double *__restrict__ Z)
+{
+    double r[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) r[i][j] = R[i * D + j];
+    const int64_t total = (int64_t)T * B;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t t = e / B, b = e - t * B;
+        double *zp = Z + t * D * BL + b;
+        double x[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = zp[(int64_t)i * BL];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) s += r[i][j] * x[j];
+            zp[(int64_t)i * BL] = s;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(NT)
 lssm_sum_kernel(const double *__restrict__ partial, int n, int stride, int len, double *__restrict__ out)
 {
@@ -995,6 +1023,23 @@ int32_t vmp_lssm_x_update(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0,
                                         workspace);
     if (rc == VMP_OK) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->me[1], 0));
     return rc != VMP_OK ? rc : rc2;
+}
+
+int32_t vmp_lssm_rotate_x(vmp_ctx *ctx, int32_t D, int32_t T, int64_t B, int64_t BL, const double *R,
+                          double *Z)
+{
+    VMP_REQUIRE(ctx, ctx && R && Z, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, D >= 1 && D <= DMAX && T >= 1 && B >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    int64_t g = ((int64_t)T * B + NT - 1) / NT;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (g > cap) g = cap;
+    switch (D) {
+#define LSSM_ROT(d) case d: hipLaunchKernelGGL(lssm_rotate_kernel<d>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, R, T, B, BL, Z); break;
+        LSSM_ROT(1) LSSM_ROT(2) LSSM_ROT(3) LSSM_ROT(4) LSSM_ROT(5) LSSM_ROT(6) LSSM_ROT(7) LSSM_ROT(8)
+#undef LSSM_ROT
+    }
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
 }
 
 int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double B_total,

@@ -1547,8 +1547,51 @@ class GenericPlan:
         return np.asarray(_arr(st.phi[1]).numpy())
 
     @_operation
+    def rotation_rows(self, node):
+        """Per-plate means (N, K) and covariances (N, K, K) of a vector GaussianARD with ONE plate
+        axis (the dynamics matrix of a state-space model, whose rows rotate with the state space)."""
+        if not isinstance(node, GaussianARD) or node.ndim != 1 or len(node.plates) != 1:
+            raise NotImplementedError('row statistics of %s' % node.name)
+        st = self._ensure(node)
+        N, K = node.plates[0], node.dims[0][-1]
+        m = np.broadcast_to(np.asarray(_arr(st.u[0]).numpy()), (N, K)).copy()
+        mm = np.broadcast_to(np.asarray(_arr(st.u[1]).numpy()), (N, K, K))
+        return dict(mean=m, cov=mm - m[:, :, None] * m[:, None, :])
+
+    def _chain_sums(self, node):
+        """K x K sums over sequences and time of the chain's moments (transformations.py:1239-1273)."""
+        st = self._ensure(node)
+        T, D = node.N, node.D
+        nseq = int(np.prod(node.plates)) if node.plates else 1
+        u0 = _arr(st.u[0]).broadcast_to(node.plates + (T, D))
+        u1 = _arr(st.u[1]).broadcast_to(node.plates + (T, D, D))
+        u2 = _arr(st.u[2]).broadcast_to(node.plates + (max(T - 1, 0), D, D))
+        npl = len(node.plates)
+        lead = tuple(range(npl + 1))            # sequence plates and time
+
+        def total(a, axes):
+            return misc.sum_multiply(a, axis=axes) if axes else a
+
+        pick = (slice(None),) * npl
+        out = dict(nvec=float(T * nseq),
+                   X0=total(DArray(u0.t[pick + (0,)]), tuple(range(npl))),
+                   X0X0=total(DArray(u1.t[pick + (0,)]), tuple(range(npl))),
+                   XnXn=total(DArray(u1.t[pick + (slice(1, None),)]), lead),
+                   XpXp=total(DArray(u1.t[pick + (slice(0, T - 1),)]), lead),
+                   XpXn=total(u2, lead))
+        if self._is_sharded(node):
+            for k in ('X0', 'X0X0', 'XnXn', 'XpXp', 'XpXn'):
+                v = fuse(lambda x: x + 0.0, _arr(out[k]))
+                self.rt.all_reduce_sum_(v.t)
+                out[k] = v
+            out['nvec'] = float(T * self.rt.all_reduce_int(nseq))
+        return {k: (np.asarray(_arr(v).numpy()) if k != 'nvec' else v) for k, v in out.items()}
+
     def rotation_statistics(self, node):
-        """sum over the plates of <x x^T> (K x K) and the plate count of a vector GaussianARD."""
+        """sum over the plates of <x x^T> (K x K) and the plate count of a vector GaussianARD; for a
+        GaussianMarkovChain the sums of its moments over sequences and time."""
+        if isinstance(node, GaussianMarkovChain) and type(node) is GaussianMarkovChain:
+            return self._chain_sums(node)
         if not isinstance(node, GaussianARD) or node.ndim != 1:
             raise NotImplementedError('rotation of %s' % node.name)
         st = self._ensure(node)
@@ -1563,10 +1606,15 @@ class GenericPlan:
         return dict(XX=np.asarray(xx.numpy()), nplates=nplates)
 
     @_operation
-    def rotate_node(self, node, R, invR, logdetR):
+    def rotate_node(self, node, R, invR, logdetR, Q=None):
         """q(node) <- distribution of R x: phi0 <- R^-T phi0, phi1 <- R^-T phi1 R^-1,
-        u0 <- R u0, u1 <- R u1 R^T, g <- g - log|det R|  (gaussian.py:1693-1741)."""
-        if not isinstance(node, GaussianARD) or node.ndim != 1:
+        u0 <- R u0, u1 <- R u1 R^T, g <- g - log|det R|  (gaussian.py:1693-1741); the same with the
+        cross moments and T log|det R| for a GaussianMarkovChain (gaussian_markov_chain.py:51-65,
+        :167-185).  ``Q``: additionally the (approximate) rotation of the single plate axis of a
+        GaussianARD: means exactly, precisions scaled by the inverse squared column sums of Q
+        (gaussian.py:1743-1772)."""
+        chain = isinstance(node, GaussianMarkovChain) and type(node) is GaussianMarkovChain
+        if not chain and (not isinstance(node, GaussianARD) or node.ndim != 1):
             raise NotImplementedError('rotation of %s' % node.name)
         st = self._ensure(node)
         if st.observed:
@@ -1575,12 +1623,33 @@ class GenericPlan:
         Rt = DArray.from_host(np.ascontiguousarray(R.T))
         Ri = DArray.from_host(np.ascontiguousarray(invR))
         Rit = DArray.from_host(np.ascontiguousarray(invR.T))
-        phi0, phi1 = _arr(st.phi[0]), _arr(st.phi[1])
-        u0, u1 = _arr(st.u[0]), _arr(st.u[1])
-        st.phi = [linalg.mvdot(Rit, phi0), linalg.mmdot(linalg.mmdot(Rit, phi1), Ri)]
-        st.u = [linalg.mvdot(Rd, u0), linalg.mmdot(linalg.mmdot(Rd, u1), Rt)]
+
+        def rot2(L_, a, R_):
+            return linalg.mmdot(linalg.mmdot(L_, _arr(a)), R_)
+        if st.phi is not None:
+            phi = [linalg.mvdot(Rit, _arr(st.phi[0]))] + [rot2(Rit, p, Ri) for p in st.phi[1:]]
+        else:
+            phi = None                       # delta moments (initialize_from_value): no parameters
+        st.phi = phi
+        st.u = [linalg.mvdot(Rd, _arr(st.u[0]))] + [rot2(Rd, u, Rt) for u in st.u[1:]]
+        scale = float(node.N) if chain else 1.0
         if isinstance(st.g, DArray):
-            st.g = fuse(lambda g: g - float(logdetR), st.g)
+            st.g = fuse(lambda g: g - scale * float(logdetR), st.g)
+        if Q is None:
+            return
+        if chain or len(node.plates) != 1:
+            raise NotImplementedError('plate rotation of %s' % node.name)
+        if st.phi is None:
+            raise ValueError('%s holds delta moments: its plates cannot be rotated' % node.name)
+        sQ = Q.sum(axis=0)
+        Qd = DArray.from_host(np.ascontiguousarray(Q))
+        u0 = linalg.mmdot(Qd, _arr(st.u[0]))                         # rows mixed: (N, K)
+        inv2 = DArray.from_host((1.0 / (sQ * sQ)).reshape(-1, 1, 1))
+        phi1 = fuse(lambda p, w: p * w, _arr(st.phi[1]).broadcast_to(node.plates + node.dims[1]),
+                    inv2)
+        phi0 = fuse(lambda v: -2.0 * v, linalg.mvdot(phi1, u0))
+        st.phi = [phi0, phi1]
+        st.u, st.g = self.family[id(node)].moments_and_cgf(st.phi)
 
     # -- natural parameters, gradients, densities (expfamily.py:258-340, :483-542) --------------
     def _latent_state(self, node):

@@ -87,6 +87,9 @@ class LSSMKernels:
             ptr(Sinv), ptr(J), ptr(sums), ptr(Yt), M, B, BL, ptr(Cm), ptr(tau), ptr(h0), ptr(Z),
             ptr(stats), ptr(ws)))
 
+    def rotate_x(self, D, T, B, BL, R, Z):
+        self.rt.check(self.lib.vmp_lssm_rotate_x(self.ctx, D, T, B, BL, ptr(R), ptr(Z)))
+
     def small_ops(self, D, M, T, B_total, priors, nu_latent, ops, state):
         pr = (ctypes.c_double * 8)(*priors)
         arr = (ctypes.c_int32 * len(ops))(*ops)
@@ -225,6 +228,7 @@ class LSSMPlan:
         self._L = None
         self._pending = []
         self._x_updated = False
+        self._x_rot = None
         for n in roles.values():
             n._plan = self
 
@@ -366,6 +370,7 @@ class LSSMPlan:
             del xd
             self._smooth(given=True)
         self._x_updated = prior_init          # a proper q(X) (covariances exist), not delta moments
+        self._x_rot = None                    # rotation applied to q(X) since its last update
         self._ready = True
         self._version += 1
 
@@ -408,6 +413,7 @@ class LSSMPlan:
             self.rt.sync_stream()
             self._smooth(given=False)
             self._x_updated = True
+            self._x_rot = None
         elif id(node) in code:
             self._pending.append(code[id(node)])
         else:
@@ -472,6 +478,11 @@ class LSSMPlan:
         for t in range(T - 2, -1, -1):
             Cn[t] = -J[t] @ V[t + 1]
             V[t] = Sinv[t] - Cn[t] @ J[t].T
+        if self._x_rot is not None:
+            # q(X) was rotated after its update (rotate_node): covariances follow
+            R = self._x_rot
+            V = np.einsum('ik,tkl,jl->tij', R, V, R)
+            Cn = np.einsum('ik,tkl,jl->tij', R, Cn, R)
         return V, Cn
 
     def x_means(self):
@@ -534,6 +545,8 @@ class LSSMPlan:
         put(base + 'Sinv', self.Sinv.cpu().numpy())
         put(base + 'J', self.J.cpu().numpy())
         put(base + 'x_updated', bool(self._x_updated))
+        if self._x_rot is not None:
+            put(base + 'x_rot', self._x_rot)
 
     def load_state(self, reader, nodes, index):
         self._materialize()
@@ -551,11 +564,96 @@ class LSSMPlan:
         self.Sinv.copy_(torch.from_numpy(np.array(reader.get(base + 'Sinv'), dtype=np.float64)))
         self.J.copy_(torch.from_numpy(np.array(reader.get(base + 'J'), dtype=np.float64)))
         self._x_updated = bool(reader.get(base + 'x_updated'))
+        self._x_rot = np.array(reader.get(base + 'x_rot')) if reader.has(base + 'x_rot') else None
+        self._version += 1
+
+    # -- rotation parameter expansion (inference/transformations.py) ------------------------------------------
+    # The rotated quantities of this block are the replicated moments and the K x K plate sums of the
+    # state vector (host arithmetic, O(D^3)) plus the plate-sized means of the chain (one device pass).
+    def _host_state(self):
+        self._materialize()
+        self._flush()
+        self.rt.sync_stream()
+        return self.state.cpu().numpy()
+
+    def _put_state(self, st):
+        self.state.copy_(self.rt.torch.from_numpy(st))
         self._version += 1
 
     def rotation_statistics(self, node):
-        raise NotImplementedError("rotations of the fused LSSM block are not built; use "
-                                  "VB(..., engine='generic')")
+        st, L = self._host_state(), self.layout
+        D, M, T, DD = self.D, self.M, self.T, self.D * self.D
+        if node is self.C:
+            return dict(XX=st[L.off_SCC:L.off_SCC + DD].reshape(D, D).copy(), nplates=float(M))
+        if node is self.X:
+            S = st[L.off_S:]
+            mat = lambda k: S[k * DD:(k + 1) * DD].reshape(D, D).copy()       # noqa: E731
+            Sxx, Spp, Snn, Snp, S00 = (mat(k) for k in range(5))
+            return dict(nvec=float(T) * float(self.B_total), X0=S[5 * DD:5 * DD + D].copy(),
+                        X0X0=S00, XnXn=Snn, XpXn=Snp.T.copy(), XpXp=Spp)
+        raise NotImplementedError('rotation of %s' % node.name)
+
+    def rotation_rows(self, node):
+        """Per-row means (D, D) and covariances (D, D, D) of the dynamics matrix."""
+        if node is not self.A:
+            raise NotImplementedError('row statistics of %s' % node.name)
+        st, L, D = self._host_state(), self.layout, self.D
+        am = st[L.off_Am:L.off_Am + D * D].reshape(D, D).copy()
+        aa = st[L.off_AA:L.off_AA + D * D * D].reshape(D, D, D)
+        return dict(mean=am, cov=aa - am[:, :, None] * am[:, None, :])
+
+    def gamma_posterior_shape(self, node):
+        st, L, D = self._host_state(), self.layout, self.D
+        off = {id(self.gamma): L.off_gamma, id(self.alpha): L.off_alpha}.get(id(node))
+        if off is None:
+            raise NotImplementedError('shape parameter of %s' % node.name)
+        return st[off:off + D].copy()
+
+    def rotate_node(self, node, R, invR, logdetR, Q=None):
+        st, L = self._host_state(), self.layout
+        D, M, T, DD = self.D, self.M, self.T, self.D * self.D
+        if node is self.X:
+            # the chain: plate sums in the state, the means on the device, log|Phi| of q(X)
+            # (gaussian_markov_chain.py:51-65, :167-185: u <- R u R^T, g <- g - T log|R|)
+            if Q is not None:
+                raise ValueError('the chain has no plate rotation')
+            S = st[L.off_S:]
+            for k in range(5):
+                S[k * DD:(k + 1) * DD] = (R @ S[k * DD:(k + 1) * DD].reshape(D, D) @ R.T).reshape(-1)
+            S[5 * DD:5 * DD + D] = R @ S[5 * DD:5 * DD + D]
+            o = 5 * DD + D
+            S[o:o + M * D] = (S[o:o + M * D].reshape(M, D) @ R.T).reshape(-1)
+            st[L.off_scal + 1] -= 2.0 * T * logdetR
+            Rd = self.rt.torch.from_numpy(np.ascontiguousarray(R, dtype=np.float64)).to(self.rt.device)
+            self.kernels.rotate_x(D, T, self.B, self.BL, Rd, self.Z)
+            self._x_rot = R if self._x_rot is None else R @ self._x_rot
+        elif node is self.C:
+            cm = st[L.off_Cm:L.off_Cm + M * D].reshape(M, D) @ R.T
+            covc = R @ st[L.off_CovC:L.off_CovC + DD].reshape(D, D) @ R.T
+            st[L.off_Cm:L.off_Cm + M * D] = cm.reshape(-1)
+            st[L.off_CovC:L.off_CovC + DD] = covc.reshape(-1)
+            st[L.off_SCC:L.off_SCC + DD] = (M * covc + cm.T @ cm).reshape(-1)
+            st[L.off_scal + 4] += 2.0 * logdetR
+        elif node is self.A:
+            am = st[L.off_Am:L.off_Am + DD].reshape(D, D)
+            aa = st[L.off_AA:L.off_AA + D * DD].reshape(D, D, D)
+            cov = aa - am[:, :, None] * am[:, None, :]
+            am = am @ R.T                                           # columns: a_d <- R a_d
+            cov = np.einsum('ik,dkl,jl->dij', R, cov, R)
+            ld = st[L.off_ldA:L.off_ldA + D] + 2.0 * logdetR
+            if Q is not None:
+                # rows: means exactly, covariances scaled by the squared column sums of Q
+                # (gaussian.py:1743-1772)
+                sQ = Q.sum(axis=0)
+                am = Q @ am
+                cov = cov * (sQ * sQ)[:, None, None]
+                ld = ld + 2.0 * D * np.log(np.abs(sQ))
+            st[L.off_Am:L.off_Am + DD] = am.reshape(-1)
+            st[L.off_AA:L.off_AA + D * DD] = (cov + am[:, :, None] * am[:, None, :]).reshape(-1)
+            st[L.off_ldA:L.off_ldA + D] = ld
+        else:
+            raise NotImplementedError('rotation of %s' % node.name)
+        self._put_state(st)
 
     # -- measurement ---------------------------------------------------------------------------------------------
     def enable_timing(self, on=True):

@@ -17,8 +17,11 @@ Supported: ``RotateGaussianARD(X)`` / ``RotateGaussianARD(X, alpha)`` for a zero
 GaussianARD rotated along its last axis with the precision shared over the plates
 (``alpha`` with plates ``(K,)`` or a constant) -- the PCA / factor-analysis use --, of all
 components or of a ``subset`` of them (transformations.py:425-455, :639-690: the statistics are
-restricted to the subset, the rotation is the identity elsewhere).  Plate rotations (``Q``)
-and non-zero prior means raise ``NotImplementedError``.
+restricted to the subset, the rotation is the identity elsewhere), and -- for a node whose single
+plate axis is rotated as well (``setup(plate_axis=-1)``, ``Q``) -- the dynamics matrix of a linear
+state-space model: ``RotateGaussianMarkovChain(X, RotateGaussianARD(A, alpha))`` rotates the state
+space of a ``GaussianMarkovChain`` with unit innovation noise (transformations.py:1096-1450; the
+speed-up of demos/lssm.py:134-190).  Non-zero prior means raise ``NotImplementedError``.
 """
 import warnings
 
@@ -102,17 +105,30 @@ class RotateGaussianARD:
     # -- statistics ---------------------------------------------------------------------------
     def setup(self, plate_axis=None):
         """Fetch  XX = sum_plates <x x^T>  (K x K) and the number of plates from the plan that
-        owns X (transformations.py:476-640 for mu = 0, axis = -1, no plate rotation)."""
+        owns X (transformations.py:476-640 for mu = 0, axis = -1).  With ``plate_axis`` the rows
+        (plates) are rotated too: the per-row means (N, K) and covariances (N, K, K) are kept, and
+        XX becomes a function of the plate rotation Q (transformations.py:714-752)."""
         if plate_axis is not None:
-            raise NotImplementedError('plate rotations are not supported')
+            if len(self.node_X.plates) != 1 or plate_axis not in (-1, 0):
+                raise NotImplementedError('plate rotations are built for a node with one plate axis')
+            if self.subset is not None:
+                raise NotImplementedError('a subset cannot be combined with a plate rotation')
         plan = self.node_X._plan
         if plan is None:
             raise RuntimeError('node %s is not part of a VB engine' % self.node_X.name)
-        st = plan.rotation_statistics(self.node_X)
-        self.XX = np.asarray(st['XX'], dtype=np.float64)
-        if self.subset is not None:
-            self.XX = self.XX[np.ix_(self.subset, self.subset)]
-        self.nplates = float(st['nplates'])
+        self.plate_axis = plate_axis
+        if plate_axis is not None:
+            rows = plan.rotation_rows(self.node_X)
+            self.Xm = np.asarray(rows['mean'], dtype=np.float64)         # (N, K)
+            self.CovX = np.asarray(rows['cov'], dtype=np.float64)        # (N, K, K)
+            self.XX = self.CovX.sum(axis=0) + self.Xm.T @ self.Xm
+            self.nplates = float(self.Xm.shape[0])
+        else:
+            st = plan.rotation_statistics(self.node_X)
+            self.XX = np.asarray(st['XX'], dtype=np.float64)
+            if self.subset is not None:
+                self.XX = self.XX[np.ix_(self.subset, self.subset)]
+            self.nplates = float(st['nplates'])
         if self.update_alpha:
             K = self.Dfull
             a = self.node_alpha._plan.gamma_posterior_shape(self.node_alpha)
@@ -126,8 +142,31 @@ class RotateGaussianARD:
                                           'supported')
 
     # -- bound and gradient (transformations.py:693-960) ------------------------------------------
-    def _terms(self, R, logdet, inv):
-        RXX = R @ self.XX
+    def _terms(self, R, logdet, inv, Q=None):
+        """(bound of X, bound of alpha, gradient w.r.t. R[, gradient w.r.t. Q]).
+
+        With a plate rotation Q (rows i of the node: mean_i <- sum_k Q_ik mean_k exactly, covariance_i
+        <- s_i^2 Cov_i with s = column sums of Q -- the approximation of gaussian.py:1743-1772):
+        XX(Q) = sum_i s_i^2 Cov_i + X^T Q^T Q X, and the entropy gains K sum_i log|s_i|."""
+        if Q is None:
+            XX = self.XX
+        else:
+            sQ = Q.sum(axis=0)
+            QX = Q @ self.Xm
+            XX = np.einsum('i,ikl->kl', sQ * sQ, self.CovX) + QX.T @ QX
+        bx, ba, grad, coef = self._terms_xx(R, logdet, inv, XX)
+        if Q is None:
+            return bx, ba, grad
+        K = self.D
+        bx = bx + K * np.sum(np.log(np.abs(sQ)))
+        # d bound / d XX = R^T diag(coef / 2) R =: G;  XX depends on Q through both of its terms
+        G = R.T @ (0.5 * coef[:, None] * R)
+        dQ = 2.0 * (QX @ G @ self.Xm.T) \
+            + (2.0 * sQ * np.einsum('kl,ikl->i', G, self.CovX) + K / sQ)[None, :]
+        return bx, ba, grad, dQ
+
+    def _terms_xx(self, R, logdet, inv, XX):
+        RXX = R @ XX
         v = np.einsum('ik,ik->i', RXX, R)           # <(R x)_k^2> summed over the plates
         N = self.nplates
         if self.update_alpha:
@@ -149,24 +188,29 @@ class RotateGaussianARD:
         else:
             coef = -alpha
         grad = N * inv.T + coef[:, None] * RXX
-        return logp_X + logH_X, logp_alpha, grad
+        return logp_X + logH_X, logp_alpha, grad, coef
+
+    def _check_q(self, Q):
+        if (Q is None) != (getattr(self, 'plate_axis', None) is None):
+            raise ValueError('a plate rotation Q goes with setup(plate_axis=...) and only with it')
 
     def bound(self, R, logdet=None, inv=None, Q=None):
-        if Q is not None:
-            raise NotImplementedError('plate rotations are not supported')
+        """(bound, d bound / d R) -- and d bound / d Q as a third item when the plates rotate."""
+        self._check_q(Q)
         if logdet is None:
             logdet = np.linalg.slogdet(R)[1]
         if inv is None:
             inv = np.linalg.inv(R)
-        bx, ba, grad = self._terms(R, logdet, inv)
-        return bx + ba, grad
+        t = self._terms(R, logdet, inv, Q)
+        return (t[0] + t[1],) + tuple(t[2:])
 
     def get_bound_terms(self, R, logdet=None, inv=None, Q=None):
+        self._check_q(Q)
         if logdet is None:
             logdet = np.linalg.slogdet(R)[1]
         if inv is None:
             inv = np.linalg.inv(R)
-        bx, ba, _ = self._terms(R, logdet, inv)
+        bx, ba = self._terms(R, logdet, inv, Q)[:2]
         terms = {self.node_X: bx}
         if self.update_alpha:
             terms[self.node_alpha] = ba
@@ -174,16 +218,116 @@ class RotateGaussianARD:
 
     # -- apply -------------------------------------------------------------------------------------
     def rotate(self, R, inv=None, logdet=None, Q=None):
-        if Q is not None:
-            raise NotImplementedError('plate rotations are not supported')
+        self._check_q(Q)
         R = np.asarray(R, dtype=np.float64)
         if inv is None:
             inv = np.linalg.inv(R)
         if logdet is None:
             logdet = np.linalg.slogdet(R)[1]
-        self.node_X._plan.rotate_node(self.node_X, self._embed(R), self._embed(inv), float(logdet))
+        if Q is None:
+            self.node_X._plan.rotate_node(self.node_X, self._embed(R), self._embed(inv),
+                                          float(logdet))
+        else:
+            self.node_X._plan.rotate_node(self.node_X, R, inv, float(logdet),
+                                          Q=np.asarray(Q, dtype=np.float64))
         if self.update_alpha:
             self.node_alpha.update()
+
+
+class RotateGaussianMarkovChain:
+    """Rotation x_t -> R x_t of the state space of a ``GaussianMarkovChain`` with unit innovation
+    noise, together with its dynamics matrix A -> R A R^-1 (``A_rotator`` =
+    ``RotateGaussianARD(A[, alpha])``, whose columns rotate by R^-T and whose rows by Q = R)
+    (transformations.py:1096-1450).  The statistics are K x K plate sums handed over by the plan
+    that owns the chain; the plate-sized means are rotated on the device."""
+
+    def __init__(self, X, *args):
+        from ..nodes.gaussian_markov_chain import GaussianMarkovChain
+        if not isinstance(X, GaussianMarkovChain):
+            raise ValueError('RotateGaussianMarkovChain needs a GaussianMarkovChain')
+        if len(args) != 1:
+            if len(args) == 0:
+                raise NotImplementedError()
+            raise ValueError("Wrong number of arguments")
+        self.X_node = X
+        self.A_rotator = args[0]
+        mu, Lam, A, nu = X.parents[:4]
+        if len(X.parents) > 4:
+            raise NotImplementedError('input signals of the chain are not built')
+        if self.A_rotator.node_X is not A:
+            raise ValueError('the rotator of the dynamics must rotate the A of this chain')
+        if not (isinstance(nu, Constant) and np.all(np.asarray(nu.value) == 1)):
+            raise NotImplementedError('RotateGaussianMarkovChain assumes unit innovation noise')
+        if not (isinstance(mu, Constant) and isinstance(Lam, Constant)):
+            raise NotImplementedError('the initial state must have constant mean and precision')
+        self.A_node = A
+        self.mu0 = np.asarray(mu.value, dtype=np.float64)
+        self.Lambda = np.asarray(Lam.value, dtype=np.float64)
+        self.D = X.D
+
+    def nodes(self):
+        return [self.X_node] + self.A_rotator.nodes()
+
+    def setup(self):
+        """K x K sums over time and sequences of the chain's moments, combined with the moments
+        of A (transformations.py:1239-1290; A has no time plate here)."""
+        st = self.X_node._plan.rotation_statistics(self.X_node)
+        self.M = float(st['nvec'])                       # rotated vectors: T x sequences
+        self.X0X0 = np.asarray(st['X0X0'], dtype=np.float64)
+        self.XnXn = np.asarray(st['XnXn'], dtype=np.float64)
+        XpXn = np.asarray(st['XpXn'], dtype=np.float64)      # sum <x_t-1 x_t^T>
+        XpXp = np.asarray(st['XpXp'], dtype=np.float64)
+        self.Lambda_mu_X0 = np.outer(self.Lambda @ self.mu0, np.asarray(st['X0'], dtype=np.float64))
+        self.A_rotator.setup(plate_axis=-1)
+        Am, CovA = self.A_rotator.Xm, self.A_rotator.CovX
+        self.A_XpXn = Am @ XpXn
+        self.A_XpXp_A = Am @ XpXp @ Am.T
+        self.CovA_XpXp = np.einsum('dij,ij->d', CovA, XpXp)
+
+    def _x_terms(self, R, logdet, inv):
+        """<log p(X | A)> + H(q(X)) after x -> R x, and its gradient (transformations.py:1296-1386)."""
+        sumr = R.sum(axis=0)
+        R_XnXn = R @ self.XnXn
+        L_R_X0X0 = self.Lambda @ R @ self.X0X0
+        RA_XpXp_A = R @ self.A_XpXp_A
+        yy = np.sum(R_XnXn * R) + np.sum(L_R_X0X0 * R)
+        yz = np.sum((R @ self.A_XpXn) * R) + np.sum(self.Lambda_mu_X0 * R)
+        zz = np.sum(RA_XpXp_A * R) + np.sum(sumr * sumr * self.CovA_XpXp)
+        bound = -0.5 * yy + yz - 0.5 * zz + self.M * logdet
+        dyy = 2.0 * (R_XnXn + L_R_X0X0)
+        dyz = R @ (self.A_XpXn + self.A_XpXn.T) + self.Lambda_mu_X0
+        dzz = 2.0 * (RA_XpXp_A + (sumr * self.CovA_XpXp)[None, :])
+        grad = -0.5 * dyy + dyz - 0.5 * dzz + self.M * inv.T
+        return bound, grad
+
+    def bound(self, R, logdet=None, inv=None):
+        if inv is None:
+            inv = np.linalg.inv(R)
+        if logdet is None:
+            logdet = np.linalg.slogdet(R)[1]
+        bx, dx = self._x_terms(R, logdet, inv)
+        # A: columns by R^-T, rows by Q = R
+        ba, dRa, dQa = self.A_rotator.bound(inv.T, inv=R.T, logdet=-logdet, Q=R)
+        dRa = -inv.T @ dRa.T @ inv.T
+        return bx + ba, dx + dRa + dQa
+
+    def get_bound_terms(self, R, logdet=None, inv=None):
+        if inv is None:
+            inv = np.linalg.inv(R)
+        if logdet is None:
+            logdet = np.linalg.slogdet(R)[1]
+        terms = self.A_rotator.get_bound_terms(inv.T, inv=R.T, logdet=-logdet, Q=R)
+        terms[self.X_node] = self._x_terms(R, logdet, inv)[0]
+        return terms
+
+    def rotate(self, R, inv=None, logdet=None):
+        R = np.asarray(R, dtype=np.float64)
+        if inv is None:
+            inv = np.linalg.inv(R)
+        if logdet is None:
+            logdet = np.linalg.slogdet(R)[1]
+        self.X_node._plan.rotate_node(self.X_node, R, inv, float(logdet))
+        self.A_rotator.rotate(inv.T, inv=R.T, logdet=-logdet, Q=R)
 
 
 class RotationOptimizer:

@@ -11,6 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain  # noqa: E402
 from bayespy_amd.inference import VB                                               # noqa: E402
+from bayespy_amd.inference import transformations                                  # noqa: E402
 
 np.random.seed(3)
 M, B, T, D = 6, 2000, 200, 3
@@ -37,6 +38,11 @@ Y.observe(y)
 
 Q = VB(X, C, gamma, A, alpha, tau, F, Y)        # update order of demos/lssm.py:103: X first
 print('engine:', type(Q.plans[0]).__name__)
+# the rotation speed-up of demos/lssm.py:134-190: the state space (X, A, C) is rotated after every
+# iteration; the D x D optimisation runs on the host on plate sums, the means rotate on the device
+rotX = transformations.RotateGaussianMarkovChain(X, transformations.RotateGaussianARD(A, alpha))
+rot = transformations.RotationOptimizer(rotX, transformations.RotateGaussianARD(C, gamma), D)
+Q.set_callback(rot.rotate)
 Q.update(repeat=30, tol=1e-7)
 print('noise sd: true 0.5, estimated %.3f' % (1.0 / np.sqrt(tau.u[0])))
 ev = np.sort(np.abs(np.linalg.eigvals(A.u[0])))[::-1]

@@ -376,6 +376,10 @@ int32_t vmp_lssm_x_update(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0,
                           double *covsums, const double *Yt, int32_t M, int64_t B, int64_t BL,
                           const double *Cm, const double *tau, const double *h0, double *Z,
                           double *stats, void *workspace);
+/* <x_bt> <- R <x_bt> on the time-major means Z (T, D, BL): the state-space rotation of
+ * transformations.py:1167-1176 applied to the plate-sized array; R: D x D row-major, device. */
+int32_t vmp_lssm_rotate_x(vmp_ctx *ctx, int32_t D, int32_t T, int64_t B, int64_t BL, const double *R,
+                          double *Z);
 /* Replicated-node updates / the bound, a list of vmp_lssm_op in one launch.  priors: host array
  * of 8 doubles, the Gamma (a0, b0) of tau, gamma, alpha, nu. */
 int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double B_total,

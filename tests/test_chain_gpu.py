@@ -207,6 +207,71 @@ def test_lssm_from_prior_initialisation_matches_reference(golden_dir, engine):
             np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-9, err_msg='%s u[%d]' % (nm, i))
 
 
+@pytest.mark.parametrize('tag,B', [('one', None), ('batch', 5)])
+@pytest.mark.parametrize('engine', ['fused', 'generic'])
+def test_lssm_rotations_match_reference(golden_dir, tag, B, engine):
+    """The rotation speed-up of demos/lssm.py:134-190 -- RotateGaussianMarkovChain(X,
+    RotateGaussianARD(A, alpha)) against RotateGaussianARD(C, gamma) -- on both engines: one
+    stand-alone rotation after two plain iterations (bound, rotated moments), then five iterations
+    with the rotation after each.  The K x K optimisation is a truncated nonlinear CG on the host
+    (see models.check_rotation_results): early values tight, the tail loose."""
+    import warnings
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference import transformations
+    g = np.load(os.path.join(golden_dir, 'lssm_rotations.npz'))
+    y, x0, c0 = g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0']
+    D = x0.shape[-1]
+    T = x0.shape[-2]
+    M = y.shape[0]
+    px = () if B is None else (B,)
+    alpha = nodes.Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = nodes.GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    A.initialize_from_value(np.identity(D))
+    X = nodes.GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T,
+                                  plates=px, name='X')
+    X.initialize_from_value(x0)
+    gamma = nodes.Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(D))
+    C = nodes.GaussianARD(0, gamma, shape=(D,), plates=(M, 1) if B is None else (M, 1, 1), name='C')
+    C.initialize_from_value(c0)
+    tau = nodes.Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = nodes.SumMultiply('i,i', C, X, name='F')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = VB(Y, F, C, gamma, X, A, alpha, tau, engine=None if engine == 'fused' else 'generic')
+    Q.ignore_bound_checks = True
+    assert type(Q.plans[0]).__name__ == ('LSSMPlan' if engine == 'fused' else 'GenericPlan')
+    rotA = transformations.RotateGaussianARD(A, alpha, axis=0)
+    rotX = transformations.RotateGaussianMarkovChain(X, rotA)
+    rotC = transformations.RotateGaussianARD(C, gamma, axis=0)
+    R = transformations.RotationOptimizer(rotX, rotC, D)
+    Q.update(repeat=2, verbose=False)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g[tag + '_L_before'], rtol=1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        R.rotate(maxiter=10)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g[tag + '_L_after'], rtol=1e-6)
+    for nm, nd in dict(A=A, C=C, alpha=alpha, gamma=gamma, X=X).items():
+        for i, ui in enumerate(nd.u):
+            got, ref = np.broadcast_arrays(np.asarray(ui), g['%s_%s_u%d_rot' % (tag, nm, i)])
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(),
+                                       err_msg='%s u[%d] after the rotation' % (nm, i))
+    Ls = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(5):
+            Q.update(repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+            R.rotate(maxiter=10)
+    Ls = np.array(Ls)
+    np.testing.assert_allclose(Ls[:2], g[tag + '_L'][:2], rtol=1e-5)
+    np.testing.assert_allclose(Ls, g[tag + '_L'], rtol=2e-2)
+    assert np.all(np.diff(Ls) > 0)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g[tag + '_L_final'], rtol=2e-2)
+
+
 def test_switching_state_space_model_matches_reference(golden_dir):
     """SwitchingGaussianMarkovChain inside the model of bayespy/demos/lssm_sd.py (a categorical
     Markov chain picks the dynamics matrix of every transition): five VB iterations against

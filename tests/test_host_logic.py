@@ -74,7 +74,61 @@ def test_rotation_block_argument_checks():
     with pytest.raises(NotImplementedError):
         T.RotateGaussianARD(nodes.GaussianARD(0, 1, plates=(3,)))                # scalar node
     with pytest.raises(NotImplementedError):
-        T.RotateGaussianARD(X).setup(plate_axis=0)
+        T.RotateGaussianARD(X).setup(plate_axis=0)        # two plate axes: no plate rotation
+
+
+def test_state_space_rotation_gradients_by_finite_differences():
+    """RotateGaussianMarkovChain + RotateGaussianARD with a plate rotation (transformations.py:693-1093,
+    :1296-1450): the analytic gradient of the bound w.r.t. R (through x -> R x, the columns of A by
+    R^-T and its rows by Q = R) against central differences, on statistics served by a plan double."""
+    from scipy import optimize
+    from bayespy_amd.inference import transformations as T
+    rs = np.random.RandomState(12)
+    D, N = 3, 40
+
+    def spd(n=D):
+        a = rs.normal(size=(n, n + 2))
+        return a @ a.T
+
+    class Plan:
+        def rotation_statistics(self, node):
+            return dict(nvec=float(N), X0=rs_x0, X0X0=s00, XnXn=snn, XpXn=spn, XpXp=spp)
+
+        def rotation_rows(self, node):
+            return dict(mean=am, cov=cova)
+
+        def gamma_posterior_shape(self, node):
+            return np.full(D, 1e-5 + 0.5 * D)
+
+    rs_x0, s00, snn, spp = rs.normal(size=D), spd(), N * spd(), N * spd()
+    spn = 0.5 * N * rs.normal(size=(D, D))
+    am = rs.normal(size=(D, D))
+    cova = np.stack([0.1 * spd() for _ in range(D)])
+    alpha = nodes.Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = nodes.GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    X = nodes.GaussianMarkovChain(np.zeros(D) + 0.3, 1e-1 * spd(), A, np.ones(D), n=N, name='X')
+    for n in (alpha, A, X):
+        n._plan = Plan()
+    for with_alpha in (True, False):
+        rotA = T.RotateGaussianARD(A, alpha, axis=0) if with_alpha else None
+        if rotA is None:
+            A2 = nodes.GaussianARD(0, 2.0, shape=(D,), plates=(D,), name='A2')
+            X2 = nodes.GaussianMarkovChain(np.zeros(D), np.identity(D), A2, np.ones(D), n=N, name='X2')
+            A2._plan = X2._plan = Plan()
+            rotX = T.RotateGaussianMarkovChain(X2, T.RotateGaussianARD(A2, axis=0))
+        else:
+            rotX = T.RotateGaussianMarkovChain(X, rotA)
+        rotX.setup()
+        R0 = np.identity(D) + 0.2 * rs.normal(size=(D, D))
+        f = lambda r: rotX.bound(r.reshape(D, D))[0]        # noqa: E731
+        g = rotX.bound(R0)[1]
+        gn = optimize.approx_fprime(R0.ravel(), f, 1e-6).reshape(D, D)
+        np.testing.assert_allclose(g, gn, rtol=2e-5, atol=2e-5 * np.abs(gn).max())
+        # the terms reported per node add up to the bound
+        terms = rotX.get_bound_terms(R0)
+        np.testing.assert_allclose(sum(terms.values()), rotX.bound(R0)[0], rtol=1e-12)
+    with pytest.raises(ValueError):
+        T.RotateGaussianARD(A, alpha).bound(np.identity(D), Q=np.identity(D))    # Q without plate_axis
 
 
 def test_checkpoint_container_round_trip(tmp_path):
