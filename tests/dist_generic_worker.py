@@ -122,6 +122,47 @@ def main():
         for nm, nd in dict(A=A, C=C, tau=tau, alpha=alpha, gamma=gamma, nu=nu).items():
             res['L_' + nm] = np.array(Q.l[nd][:n])
         res['A_u0'] = np.asarray(A.u[0])
+    elif case == 'lssm_rotation':
+        # the batch case of tests/golden/lssm_rotations.npz with the sequences split over the ranks:
+        # the rotation statistics are global plate sums, every rank finds the same R and rotates
+        # its own sequences
+        import warnings
+        from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+        g = np.load(os.path.join(golden, 'lssm_rotations.npz'))
+        y, x0, c0 = g['batch_y'], g['batch_x0'], g['batch_c0']
+        M, B = y.shape[0], y.shape[1]
+        T, D = x0.shape[-2], x0.shape[-1]
+        lo, hi = B * rank // world, B * (rank + 1) // world
+        alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+        A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+        A.initialize_from_value(np.identity(D))
+        X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T,
+                                plates=(hi - lo,), name='X').shard(-1)
+        X.initialize_from_value(x0[lo:hi])
+        gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+        gamma.initialize_from_value(1e-2 * np.ones(D))
+        C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
+        C.initialize_from_value(c0)
+        tau = Gamma(1e-5, 1e-5, name='tau')
+        tau.initialize_from_value(1e2)
+        F = SumMultiply('i,i', C, X, name='F')
+        Y = GaussianARD(F, tau, name='Y')
+        Y.observe(y[:, lo:hi])
+        Q = VB(Y, F, C, gamma, X, A, alpha, tau)
+        Q.ignore_bound_checks = True
+        res['engine'] = type(Q.plans[0]).__name__
+        rotX = transformations.RotateGaussianMarkovChain(
+            X, transformations.RotateGaussianARD(A, alpha, axis=0))
+        R = transformations.RotationOptimizer(rotX, transformations.RotateGaussianARD(C, gamma, axis=0), D)
+        Q.update(repeat=2, verbose=False)
+        res['L_before'] = Q.compute_lowerbound()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            R.rotate(maxiter=10)
+        res['L_after'] = Q.compute_lowerbound()
+        res['A_u0_rot'] = np.asarray(A.u[0])
+        res['X_u0_rot'] = np.asarray(X.u[0])
+        res['lo'], res['hi'] = lo, hi
     elif case == 'hmm':
         # a batch of hidden Markov chains (case 3 of tests/models.py run_markov_chain_cases)
         # with the chain plate split over the ranks; emission and transition parameters are

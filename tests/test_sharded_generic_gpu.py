@@ -85,6 +85,22 @@ def test_sharded_lssm_matches_reference(golden_dir, tmp_path):
     assert np.array_equal(r0['A_u0'], r1['A_u0'])
 
 
+def test_sharded_lssm_rotation_matches_reference(golden_dir, tmp_path):
+    """The state-space rotation on the fused block with the sequences split over two ranks: same
+    bound before / after and the same rotated moments as the single-process reference run."""
+    r0, r1 = _launch('lssm_rotation', golden_dir, tmp_path, 29549)
+    g = np.load(os.path.join(golden_dir, 'lssm_rotations.npz'))
+    for r in (r0, r1):
+        assert str(r['engine']) == 'LSSMPlan'
+        np.testing.assert_allclose(r['L_before'], g['batch_L_before'], rtol=1e-9)
+        np.testing.assert_allclose(r['L_after'], g['batch_L_after'], rtol=1e-6)
+        np.testing.assert_allclose(r['A_u0_rot'], g['batch_A_u0_rot'], rtol=1e-5, atol=1e-6)
+        lo, hi = int(r['lo']), int(r['hi'])
+        ref = g['batch_X_u0_rot'][lo:hi]
+        np.testing.assert_allclose(r['X_u0_rot'], ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+    assert np.array_equal(r0['A_u0_rot'], r1['A_u0_rot'])
+
+
 def test_sharded_hidden_markov_chains_match_reference(golden_dir, tmp_path):
     """A batch of hidden Markov chains with the chain plate split over two ranks: only the
     initial-state node is declared sharded, the chain, its categorical view and the mixture
