@@ -54,7 +54,8 @@ class PCALayout(ctypes.Structure):
 class MPCALayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in (
         'DP', 'KP', 'P', 'PT', 'LR', 'off_tau', 'off_alpha', 'off_scal', 'off_L', 'off_W',
-        'off_WW', 'off_ldW', 'off_M', 'off_panel', 'off_panel_x', 'off_Sxx', 'total')]
+        'off_WW', 'off_ldW', 'off_M', 'off_panel', 'off_panel_x', 'off_Sxx', 'off_rowobs',
+        'total')]
 
 
 class MPCASizes(ctypes.Structure):

@@ -85,6 +85,7 @@ inline void fill_layout(int D, int K, vmp_mpca_layout *L)
     L->off_panel = o;    o += (int64_t)m.CT * (m.DQ / 2) * 128;
     L->off_panel_x = o;  o += (int64_t)m.CT * (m.DQ / 2) * 128;
     L->off_Sxx = o;      o += (int64_t)m.KP * m.KP;
+    L->off_rowobs = o;   o += m.DP;
     L->total = (o + 7) / 8 * 8;
 }
 
@@ -107,10 +108,11 @@ mpca_prepare_kernel(const double *__restrict__ Y, int64_t ldy, const uint8_t *__
                     uint32_t *__restrict__ Mb1, uint32_t *__restrict__ Mb2,
                     double *__restrict__ partial, int64_t ntiles)
 {
-    __shared__ uint8_t ms[128 * TN];
+    __shared__ __attribute__((aligned(16))) uint8_t ms[128 * TN];
     __shared__ double red[NT / 64];
     const int tid = threadIdx.x;
     double syy = 0.0, nobs = 0.0;
+    int rowobs = 0;              // thread d < DP: observations of dimension d in this workgroup's tiles
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
         double *tb = Ymt + tile * ((int64_t)DP * TN);
@@ -129,6 +131,11 @@ mpca_prepare_kernel(const double *__restrict__ Y, int64_t ldy, const uint8_t *__
             nobs += (double)mv;
         }
         __syncthreads();
+        if (tid < DP) {
+            const uint32_t *mr = reinterpret_cast<const uint32_t *>(ms + tid * TN);
+#pragma unroll
+            for (int q = 0; q < TN / 4; ++q) rowobs += __popc(mr[q]);
+        }
         // bit words: 2 subtiles x 64 lanes x 2 layouts = 256 words per tile, one per thread
         {
             const int lay = tid >> 7, s = (tid >> 6) & 1, l = tid & 63;
@@ -151,6 +158,7 @@ mpca_prepare_kernel(const double *__restrict__ Y, int64_t ldy, const uint8_t *__
         partial[2 * blockIdx.x] = syy;
         partial[2 * blockIdx.x + 1] = nobs;
     }
+    if (tid < DP) partial[2 * (int64_t)gridDim.x + (int64_t)blockIdx.x * DP + tid] = (double)rowobs;
 }
 
 // out[j] (+)= sum_b partial[b * stride + j], fixed order (deterministic).  A workgroup owns KX
@@ -1213,10 +1221,17 @@ mpca_small_kernel(small_args A, double *__restrict__ st)
                 if (!(b > 0.0)) sc[SC_STATUS] = (double)VMP_ERR_FLOATING;
             }
         } else if (op == VMP_MPCA_OP_ALPHA) {
+            // rows of W without any observation are ignored plates of W (mask propagation,
+            // node.py:457-526): no message to alpha (node.py:624-650), no bound term
             for (int k = tid; k < K; k += NT) {
                 double s = 0.0;
-                for (int d = 0; d < D; ++d) s += st[L.off_WW + ((int64_t)d * KP + k) * KP + k];
-                const double a = A.a0a + 0.5 * D, b = A.b0a + 0.5 * s;
+                int de = 0;
+                for (int d = 0; d < D; ++d)
+                    if (st[L.off_rowobs + d] > 0.0) {
+                        s += st[L.off_WW + ((int64_t)d * KP + k) * KP + k];
+                        ++de;
+                    }
+                const double a = A.a0a + 0.5 * de, b = A.b0a + 0.5 * s;
                 st[L.off_alpha + 0 * KP + k] = a;
                 st[L.off_alpha + 1 * KP + k] = b;
                 st[L.off_alpha + 2 * KP + k] = a / b;
@@ -1228,10 +1243,13 @@ mpca_small_kernel(small_args A, double *__restrict__ st)
             double sw = 0.0;
             for (int e = tid; e < D * K; e += NT) {
                 const int d = e / K, k = e - d * K;
-                sw += 0.5 * st[L.off_alpha + 3 * KP + k]
-                      - 0.5 * st[L.off_alpha + 2 * KP + k] * st[L.off_WW + ((int64_t)d * KP + k) * KP + k];
+                if (st[L.off_rowobs + d] > 0.0)
+                    sw += 0.5 * st[L.off_alpha + 3 * KP + k]
+                          - 0.5 * st[L.off_alpha + 2 * KP + k]
+                                * st[L.off_WW + ((int64_t)d * KP + k) * KP + k];
             }
-            for (int d = tid; d < D; d += NT) sw += 0.5 * st[L.off_ldW + d] + 0.5 * K;
+            for (int d = tid; d < D; d += NT)
+                if (st[L.off_rowobs + d] > 0.0) sw += 0.5 * st[L.off_ldW + d] + 0.5 * K;
             sw = block_sum<NT>(sw, red);
             double sa = 0.0;
             for (int k = tid; k < K; k += NT)
@@ -1385,6 +1403,7 @@ int32_t vmp_mpca_prepare(vmp_ctx *ctx, const double *Y, int64_t ldy, const uint8
                        mask, ldm, N, D, m.DP, Ymt, Mb1, Mb2, partial, ntiles);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     launch_reduce(ctx->stream, partial, (int)g, 2, 2, state + L.off_scal + SC_SYY, 0);
+    launch_reduce(ctx->stream, partial + 2 * g, (int)g, m.DP, m.DP, state + L.off_rowobs, 0);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

@@ -1227,6 +1227,11 @@ class GenericPlan:
                 axes = tuple(i for i in range(nd) if n.plates[i] == 1 and pm.shape[i] != 1)
                 if axes:
                     pm = np.any(pm, axis=axes, keepdims=True)
+                if self._is_sharded(c) and not self._is_sharded(n):
+                    # the "or" over a plate partitioned over the ranks is global: a replicated node
+                    # is an ignored plate only where NO rank has an active child (node.py:457-526)
+                    pm = self._any_over_ranks(np.broadcast_to(pm, np.broadcast_shapes(
+                        pm.shape, tuple(n.plates))))
                 m = np.logical_or(m, pm)
             if isinstance(n, Stochastic) and n.observed:
                 om = np.asarray(n._mask, dtype=bool)
@@ -1241,6 +1246,12 @@ class GenericPlan:
                 n._gmask = m
         self._dev_masks = {}
         self._masks_ready = True
+
+    def _any_over_ranks(self, mask):
+        rt = self.rt
+        t = rt.torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float64)).to(rt.device)
+        rt.all_reduce_sum_(t)
+        return t.cpu().numpy() > 0.0
 
     def _mask_array(self, node):
         self._update_masks()

@@ -247,6 +247,8 @@ class MaskedPCAPlan:
         self._Ydev = Yd if Yd is y else None     # own staging copies are dropped after set-up
         sc = self.state[L.off_scal:L.off_scal + 2]
         self._reduce(sc)
+        # observations per dimension: a row of W is an ignored plate only if NO rank observes it
+        self._reduce(self.state[L.off_rowobs:L.off_rowobs + int(L.DP)])
         self._scal_host = None
         # ---- X: delta moments (value / random) or the prior; their statistics -----------------
         init = self.X._init

@@ -260,6 +260,8 @@ typedef struct vmp_mpca_layout {
     int64_t off_panel;   /* B operands of the precision GEMM (fragment order), current W          */
     int64_t off_panel_x; /* ... as seen by the last X.update()                                    */
     int64_t off_Sxx;     /* KP x KP      sum_n <x x^T>_n (all plates; rotations)                  */
+    int64_t off_rowobs;  /* DP           observations per dimension d (summed over ranks by the
+                            caller); rows with none are ignored plates of W (node.py:457-526)      */
     int64_t total;
 } vmp_mpca_layout;
 
@@ -280,8 +282,8 @@ int32_t vmp_mpca_sizes(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t ch
 int32_t vmp_mpca_init_state(vmp_ctx *ctx, int32_t D, int32_t K, double a0_tau, double b0_tau,
                             double a0_alpha, double b0_alpha, double *state);
 /* Set-up after Y.observe(y, mask): Ymt <- m*y tile-major (values at masked entries are never
- * read: NaN placeholders are fine), the two bit layouts of the mask, sum m y^2 and sum m into
- * the state.  mask: uint8 (D, ldm) row-major, NULL = all observed. */
+ * read: NaN placeholders are fine), the two bit layouts of the mask, sum m y^2, sum m and the
+ * observation count of every dimension into the state.  mask: uint8 (D, ldm) row-major, NULL = all observed. */
 int32_t vmp_mpca_prepare(vmp_ctx *ctx, const double *Y, int64_t ldy, const uint8_t *mask,
                          int64_t ldm, int64_t N, int32_t D, int32_t K, double *Ymt,
                          uint32_t *Mb1, uint32_t *Mb2, double *state, void *workspace);

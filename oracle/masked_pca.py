@@ -14,7 +14,8 @@ every plate has its own posterior covariance:
 * X: ``Lam_n = c I + <tau> sum_d m_dn <w w^T>_d``, ``x_n = Lam_n^-1 <tau> sum_d m_dn y_dn <w_d>``;
 * tau (gamma.py:116-148, message gaussian.py:2352-2371): ``a = a0 + 1/2 sum m``,
   ``b = b0 + 1/2 sum_dn m_dn (y^2 - 2 y <w_d>.<x_n> + tr(<ww>_d <xx>_n))``;
-* alpha: ``a = a0 + D/2``, ``b_k = b0 + 1/2 sum_d <ww>_d[k,k]``;
+* alpha: ``a = a0 + D'/2``, ``b_k = b0 + 1/2 sum_d' <ww>_d[k,k]`` over the D' rows of W with at least
+  one observation (rows without any are ignored plates of W: node.py:457-526, :624-650);
 * bound terms: expfamily.py:400-480 per node, masked sums.
 
 Sufficient-statistics form, chunked over the plate N: the only plate-sized state is <x_n>
@@ -53,6 +54,11 @@ class MaskedPCAOracle:
         self.chunk = int(chunk)
         D, K = self.D, self.K
         self.nobs = float(self.m.sum())
+        # rows of W that no observation reaches are "ignored" plates of W (mask propagation,
+        # node.py:457-526): still updated (to their prior given <alpha>), but left out of the message
+        # to alpha (node.py:624-650) and of W's bound term (expfamily.py:470-474)
+        self.wm = self.mask.any(axis=1)
+        self.D_eff = float(self.wm.sum())
         self.Syy = float(np.sum(self.y * self.y))
         self.tau_a, self.tau_b = self.a0, self.b0
         self.alpha_a = np.full(K, self.a0)
@@ -118,8 +124,8 @@ class MaskedPCAOracle:
         self.tau_b = self.b0 + 0.5 * self._residual()
 
     def update_alpha(self):
-        self.alpha_a = np.full(self.K, self.a0 + 0.5 * self.D)
-        self.alpha_b = self.b0 + 0.5 * np.einsum('dkk->k', self.WW)
+        self.alpha_a = np.full(self.K, self.a0 + 0.5 * self.D_eff)
+        self.alpha_b = self.b0 + 0.5 * np.einsum('dkk->k', self.WW[self.wm])
 
     # -- lower bound ----------------------------------------------------------------------------
     def lower_bound(self):
@@ -129,8 +135,10 @@ class MaskedPCAOracle:
         L_Y = self.nobs * (-0.5 * LOG2PI + 0.5 * logtau) - 0.5 * tau * self._residual()
         L_X = (-0.5 * self.c * self.trXX + 0.5 * self.logdetCX
                + N * (0.5 * K * np.log(self.c) + 0.5 * K))
-        L_W = (0.5 * D * np.sum(logalpha) - 0.5 * np.sum(alpha * np.einsum('dkk->k', self.WW))
-               + 0.5 * float(np.sum(self.logdetCW)) + 0.5 * D * K)
+        De = self.D_eff
+        L_W = (0.5 * De * np.sum(logalpha)
+               - 0.5 * np.sum(alpha * np.einsum('dkk->k', self.WW[self.wm]))
+               + 0.5 * float(np.sum(self.logdetCW[self.wm])) + 0.5 * De * K)
         L_tau = gamma_elbo(self.a0, self.b0, self.tau_a, self.tau_b)
         L_alpha = gamma_elbo(self.a0, self.b0, self.alpha_a, self.alpha_b)
         terms = dict(Y=float(L_Y), X=float(L_X), W=float(L_W), tau=float(L_tau),

@@ -64,6 +64,23 @@ def main():
         res['X_u0'] = np.asarray(Q['X'].u[0])
         res['tau_u'] = np.array([np.asarray(u) for u in Q['tau'].u], dtype=np.float64)
         res['lo'], res['hi'] = lo, hi
+    elif case in ('erasures_fused', 'erasures_generic'):
+        # a dimension observed on ONE rank only is not an ignored plate of W on the other, a dimension
+        # observed nowhere is one on both (tests/golden/masked_pca_erasures.npz, case e1)
+        from models import build_masked_pca
+        g = np.load(os.path.join(golden, 'masked_pca_erasures.npz'))
+        y, mask, x0 = g['in_e1_y'], g['in_e1_mask'], g['in_e1_x0']
+        N = y.shape[1]
+        lo, hi = N * rank // world, N * (rank + 1) // world
+        kw = {'engine': 'generic'} if case == 'erasures_generic' else {}
+        Q = build_masked_pca(nodes, VB, y[:, lo:hi], mask[:, lo:hi], x0[lo:hi], shard=True, **kw)
+        res['engine'] = type(Q.plans[0]).__name__
+        Q.update(repeat=len(g['e1_L']), verbose=False)
+        res['L'] = np.array(Q.L[:Q.iter])
+        res['W_u0'] = np.asarray(Q['W'].u[0])
+        res['alpha_u0'] = np.asarray(Q['alpha'].u[0])
+        res['X_u0'] = np.asarray(Q['X'].u[0])
+        res['lo'], res['hi'] = lo, hi
     elif case == 'rotation':
         g = np.load(os.path.join(golden, 'rotations.npz'))
         y, mask, x0 = g['rotm_y'], g['rotm_mask'], g['rotm_x0']

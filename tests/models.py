@@ -809,9 +809,8 @@ def build_masked_pca(nodes_mod, vb_cls, y, mask, x0, a0=1e-2, b0=1e-2, shard=Fal
     return Q
 
 
-def run_masked_pca_cases(nodes_mod, vb_cls, g, only=None, **vb_kwargs):
-    res = {}
-    for tag, D, N, K, keep, n_iter in MASKED_PCA_SIZES:
+def _run_masked_pca(nodes_mod, vb_cls, g, sizes, res, only=None, **vb_kwargs):
+    for tag, D, N, K, keep, n_iter in sizes:
         if only is not None and tag not in only:
             continue
         Q = build_masked_pca(nodes_mod, vb_cls, g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'],
@@ -829,6 +828,37 @@ def run_masked_pca_cases(nodes_mod, vb_cls, g, only=None, **vb_kwargs):
         if D * N <= 4000:
             # q of the missing entries of the partially observed leaf (the predictive moments)
             res[tag + '_Y_u0'], res[tag + '_Y_u1'] = np.array(Y.u[0]), np.array(Y.u[1])
+    return res
+
+
+# Erasure patterns at the edges (tests/golden/masked_pca_erasures.npz): plates without any observed
+# dimension, dimensions without any observed plate (ignored plates of W: left out of the message to
+# alpha and of W's bound term, node.py:457-526, :624-650), a dimension seen on one plate only.
+ERASURE_SIZES = (('e0', 9, 70, 4, 0.8, 4), ('e1', 40, 300, 32, 0.8, 4), ('e2', 128, 200, 16, 0.5, 3))
+
+
+def make_erasure_inputs(rs):
+    g = {}
+    for tag, D, N, K, keep, n_iter in ERASURE_SIZES:
+        y = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+        mask = rs.rand(D, N) < keep
+        mask[:, [0, N // 2, N - 1]] = False          # plates without data (first / middle / last)
+        mask[2, :] = False                           # a dimension without data
+        mask[D - 1, :] = False
+        mask[D - 1, 5] = True                        # a dimension seen once
+        if tag == 'e2':
+            mask[64:96, :] = False                   # a whole block of dimensions without data
+        g[tag + '_y'], g[tag + '_mask'] = np.where(mask, y, np.nan), mask
+        g[tag + '_x0'] = rs.normal(size=(N, K))
+    return g
+
+
+def run_erasure_cases(nodes_mod, vb_cls, g, only=None, **vb_kwargs):
+    return _run_masked_pca(nodes_mod, vb_cls, g, ERASURE_SIZES, {}, only=only, **vb_kwargs)
+
+
+def run_masked_pca_cases(nodes_mod, vb_cls, g, only=None, **vb_kwargs):
+    res = _run_masked_pca(nodes_mod, vb_cls, g, MASKED_PCA_SIZES, {}, only=only, **vb_kwargs)
     if only is None or 'po' in only:
         zdat, ydat = g['po_z'], g['po_y']
         n = zdat.shape[0]

@@ -108,6 +108,39 @@ def test_fused_block_vs_oracle_ragged_sizes(N, D, K, keep):
                                rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize('engine', ['fused', 'generic'])
+def test_plates_and_dimensions_without_any_observation_match_reference(golden_dir, engine):
+    """Erasure patterns at the edges (tests/golden/masked_pca_erasures.npz, live reference):
+    plates with no observed dimension (their q(x_n) falls back to the prior), dimensions observed on
+    no plate -- ignored plates of W: updated to diag(1/<alpha>), but left out of the message to
+    alpha and of W's bound term (node.py:457-526, :624-650) -- and a dimension seen once."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import run_erasure_cases, build_masked_pca
+    g = np.load(os.path.join(golden_dir, 'masked_pca_erasures.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+    kw = {} if engine == 'fused' else {'engine': 'generic'}
+    Q = build_masked_pca(nodes, VB, inp['e0_y'], inp['e0_mask'], inp['e0_x0'], **kw)
+    assert type(Q.plans[0]).__name__ == ('MaskedPCAPlan' if engine == 'fused' else 'GenericPlan')
+    tags = ('e0', 'e1', 'e2') if engine == 'fused' else ('e0', 'e1')
+    res = run_erasure_cases(nodes, VB, inp, only=tags, **kw)
+    if engine == 'fused':
+        # q of Y's latent entries is evaluated on request there (test_fused_block_predictive_...)
+        res = {k: v for k, v in res.items() if not (k.endswith('_Y_u0') or k.endswith('_Y_u1'))}
+    keep = [k for k in g.files if engine != 'fused' or not (k.endswith('_Y_u0') or k.endswith('_Y_u1'))]
+
+    class G(dict):
+        files = keep
+    _check(res, G({k: g[k] for k in keep}), tags)
+    for tag in tags:
+        mask = inp[tag + '_mask']
+        N = mask.shape[1]
+        empty = ~mask.any(axis=0)
+        assert empty.sum() >= 3
+        assert np.all(res[tag + '_X_u0'][0][empty] == 0.0)       # no message reaches them
+        assert np.all(res[tag + '_W_u0'][2, 0] == 0.0)
+
+
 def test_fused_block_chunking_and_device_inputs():
     """Several chunks per pass == one chunk (up to summation order); data and mask may already be
     device tensors (NaN at the missing entries)."""

@@ -81,13 +81,15 @@ def test_pca_oracle_matches_seeded_reference_run(golden_dir):
     np.testing.assert_allclose(m['CX'], g['X_cov'], rtol=1e-7, atol=1e-14)
 
 
-@pytest.mark.parametrize('tag', ['m0', 'm1', 'm2', 'm3'])
+@pytest.mark.parametrize('tag', ['m0', 'm1', 'm2', 'm3', 'e0', 'e1', 'e2'])
 @pytest.mark.parametrize('chunk', [7, 1 << 12])
 def test_masked_pca_oracle_matches_reference(golden_dir, tag, chunk):
     """oracle/masked_pca.py (chunked sufficient-statistics form) against the live-reference
-    traces with NaN placeholders at the missing entries."""
+    traces with NaN placeholders at the missing entries (e*: plates and dimensions without any
+    observation, tests/golden/masked_pca_erasures.npz)."""
     from oracle.masked_pca import MaskedPCAOracle
-    g = np.load(os.path.join(golden_dir, 'masked_pca.npz'))
+    g = np.load(os.path.join(golden_dir, 'masked_pca.npz' if tag[0] == 'm'
+                             else 'masked_pca_erasures.npz'))
     y, mask, x0 = g['in_%s_y' % tag], g['in_%s_mask' % tag], g['in_%s_x0' % tag]
     L = g[tag + '_L']
     o = MaskedPCAOracle(y, mask, x0, chunk=chunk)

@@ -60,6 +60,22 @@ def test_sharded_fused_masked_pca_matches_reference(golden_dir, tmp_path):
     assert np.array_equal(r0['W_u0'], r1['W_u0']) and np.array_equal(r0['L'], r1['L'])
 
 
+@pytest.mark.parametrize('engine,port', [('fused', 29550), ('generic', 29551)])
+def test_sharded_erasure_patterns_match_reference(golden_dir, tmp_path, engine, port):
+    """Dimensions without observations under a sharded plate: "ignored" is a global property (the
+    observation counts per dimension are summed over the ranks)."""
+    r0, r1 = _launch('erasures_' + engine, golden_dir, tmp_path, port)
+    g = np.load(os.path.join(golden_dir, 'masked_pca_erasures.npz'))
+    for r in (r0, r1):
+        assert str(r['engine']) == ('MaskedPCAPlan' if engine == 'fused' else 'GenericPlan')
+        np.testing.assert_allclose(r['L'], g['e1_L'], rtol=1e-9)
+        np.testing.assert_allclose(r['W_u0'], g['e1_W_u0'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r['alpha_u0'], g['e1_alpha_u0'], rtol=1e-8)
+        np.testing.assert_allclose(r['X_u0'], g['e1_X_u0'][:, int(r['lo']):int(r['hi'])],
+                                   rtol=1e-7, atol=1e-10)
+    assert np.array_equal(r0['W_u0'], r1['W_u0']) and np.array_equal(r0['L'], r1['L'])
+
+
 def test_sharded_rotation_matches_reference(golden_dir, tmp_path):
     r0, r1 = _launch('rotation', golden_dir, tmp_path, 29542)
     g = np.load(os.path.join(golden_dir, 'rotations.npz'))
