@@ -83,6 +83,41 @@ def test_fused_lssm_vs_oracle(M, B, T, D, gamma_nu):
                                [o.tau, o.logtau], rtol=1e-9)
 
 
+def _lssm_edge_cases():
+    rs = np.random.RandomState(3)
+
+    def mk(M, B, T, D, scale=1.0):
+        return rs.normal(size=(M, B, T)) * scale, rs.normal(size=(B, T, D)), rs.normal(size=(M, D))
+    return [('one_step', mk(2, 3, 1, 2)), ('all_ones', mk(1, 1, 2, 1)),
+            ('zero_data', mk(3, 4, 6, 2, 0.0)), ('tiny_scale', mk(3, 4, 6, 2, 1e-6)),
+            ('huge_scale', mk(3, 4, 6, 2, 1e6)), ('more_states_than_observed', mk(2, 6, 12, 5)),
+            ('white_noise_long', mk(4, 40, 700, 4))]
+
+
+@pytest.mark.parametrize('gamma_nu', [False, True])
+@pytest.mark.parametrize('case', _lssm_edge_cases(), ids=lambda c: c[0])
+def test_fused_lssm_edge_regimes_vs_oracle(case, gamma_nu):
+    """Degenerate inputs of the state-space block: a single time step, all-zero data, data without
+    any dynamics, extreme scales, D > M.  The oracle agrees with the live reference to <= 1e-15 on
+    these inputs (1e-4 at the 1e6 scale, where the reference's own phi . u sums cancel)."""
+    from oracle.lssm import LSSMOracle
+    _, (y, x0, c0) = case
+    M, B, T = y.shape
+    Q = _build(y, x0, c0, gamma_nu)
+    assert type(Q.plans[0]).__name__ == 'LSSMPlan'
+    iters = 4
+    Q.update(repeat=iters, verbose=False)
+    o = LSSMOracle(y, x0, c0, nu_prior=(1e-3, 1e-3) if gamma_nu else None)
+    o.iterate(iters)
+    assert np.all(np.isfinite(Q.L[:iters]))
+    np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=1e-8)
+    sx = max(float(np.abs(o.X).max()), 1e-300)
+    np.testing.assert_allclose(Q['X'].u[0], o.X, rtol=1e-6, atol=1e-8 * sx)
+    np.testing.assert_allclose(Q['A'].u[0], o.Am, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.array(Q['tau'].u, dtype=np.float64).ravel(), [o.tau, o.logtau],
+                               rtol=1e-8)
+
+
 def test_stationary_stretch_of_the_covariance_recursion_is_filled_in():
     """Long chains: once the filter's Riccati map has converged to working precision (8 ulp) the
     remaining interior steps reuse one (S^-1, J) and one (V, C).  In the first iteration of this
