@@ -890,13 +890,16 @@ int32_t vmp_lssm_relayout_y(vmp_ctx *ctx, const double *Y, int32_t M, int64_t B,
                             int64_t BL, double *Yt, double *syy, void *workspace)
 {
     VMP_REQUIRE(ctx, ctx && Y && Yt && syy && workspace, VMP_ERR_INVALID, "null argument");
-    VMP_REQUIRE(ctx, M >= 1 && B >= 1 && T >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    // B = 0 (no sequence on this rank of a sharded run) is legal: every sum comes out as zero
+    VMP_REQUIRE(ctx, M >= 1 && B >= 0 && T >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
     double *partial = reinterpret_cast<double *>(workspace);
     const int64_t nblk = ((B + 31) / 32) * ((T + 31) / 32) * M;
     int64_t g = nblk < (int64_t)ctx->num_cu * 8 ? nblk : (int64_t)ctx->num_cu * 8;
-    VMP_HIP_CHECK(ctx, hipMemsetAsync(Yt, 0, (size_t)T * M * BL * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(lssm_relayout_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, Y, M, B, T,
-                       BL, Yt, partial);
+    if (g > 0) {
+        VMP_HIP_CHECK(ctx, hipMemsetAsync(Yt, 0, (size_t)T * M * BL * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(lssm_relayout_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, Y, M, B,
+                           T, BL, Yt, partial);
+    }
     hipLaunchKernelGGL(lssm_sum_kernel, dim3(1), dim3(NT), 0, ctx->stream, partial, (int)g, 1, 1, syy);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -906,9 +909,10 @@ int32_t vmp_lssm_x_layout(vmp_ctx *ctx, double *X, int32_t D, int64_t B, int32_t
                           double *Z, int32_t to_time_major)
 {
     VMP_REQUIRE(ctx, ctx && X && Z, VMP_ERR_INVALID, "null argument");
-    VMP_REQUIRE(ctx, D >= 1 && B >= 1 && T >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, D >= 1 && B >= 0 && T >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
     int64_t g = ((int64_t)B * T * D + NT - 1) / NT;
     if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
+    if (g == 0) return VMP_OK;
     hipLaunchKernelGGL(lssm_x_layout_kernel, dim3((unsigned)g), dim3(NT), 0, ctx->stream, X, D, B, T,
                        BL, Z, to_time_major);
     VMP_HIP_CHECK(ctx, hipGetLastError());
@@ -959,7 +963,7 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
 {
     VMP_REQUIRE(ctx, ctx && Yt && Z && stats && workspace, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, given || (Cm && tau && h0 && Sinv && J), VMP_ERR_INVALID, "null argument");
-    VMP_REQUIRE(ctx, M >= 1 && B >= 1 && T >= 1 && BL >= B && D >= 1, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, M >= 1 && B >= 0 && T >= 1 && BL >= B && D >= 1, VMP_ERR_INVALID, "bad dims");
     VMP_REQUIRE(ctx, D <= DMAX && M <= 16 && (M <= 8 || D <= 4), VMP_ERR_UNSUPPORTED,
                 "the fused LSSM block supports D <= 8 with M <= 8, D <= 4 with M <= 16");
     const int MM = M <= 8 ? 8 : 16;
@@ -970,7 +974,8 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
     hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
 #define LSSM_CASE(d, mm)                                                                      \
-    if (D == d && MM == mm) {                                                                 \
+    if (g == 0) {                                                                             \
+    } else if (D == d && MM == mm) {                                                          \
         if (!given)                                                                           \
             hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, s, \
                                Yt, M, B, T, BL, Cm, tau, h0, J, Z);                           \
@@ -1029,7 +1034,8 @@ int32_t vmp_lssm_rotate_x(vmp_ctx *ctx, int32_t D, int32_t T, int64_t B, int64_t
                           double *Z)
 {
     VMP_REQUIRE(ctx, ctx && R && Z, VMP_ERR_INVALID, "null argument");
-    VMP_REQUIRE(ctx, D >= 1 && D <= DMAX && T >= 1 && B >= 1 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, D >= 1 && D <= DMAX && T >= 1 && B >= 0 && BL >= B, VMP_ERR_INVALID, "bad dims");
+    if (B == 0) return VMP_OK;
     int64_t g = ((int64_t)T * B + NT - 1) / NT;
     const int64_t cap = (int64_t)ctx->num_cu * 16;
     if (g > cap) g = cap;
@@ -1071,7 +1077,7 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
 
 int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
 {
-    if (!n || D < 1 || M < 1 || B < 1) return VMP_ERR_INVALID;
+    if (!n || D < 1 || M < 1 || B < 0) return VMP_ERR_INVALID;
     const int64_t g = (B + SNT - 1) / SNT;
     int64_t a = g * plen_of(D, M);
     const int64_t r = 256 * 8 * 2;            // relayout partials (<= num_cu * 8 workgroups)

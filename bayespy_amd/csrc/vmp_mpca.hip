@@ -1430,6 +1430,18 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     const bool first = (flags & VMP_MPCA_FIRST) != 0, inspect = (flags & VMP_MPCA_INSPECT) != 0;
     const bool from_value = (flags & (VMP_MPCA_FROM_VALUE | VMP_MPCA_PRIOR)) != 0;
     const double xx_diag = (flags & VMP_MPCA_PRIOR) ? 1.0 / x_prec : 0.0;
+    if (nplates <= 0) {
+        // an empty plate (N = 0 on this rank): the statistics of the pass are zero
+        if (first && !inspect) {
+            VMP_HIP_CHECK(ctx, hipMemsetAsync(state + L.off_scal + SC_TRXX, 0, 2 * sizeof(double),
+                                              cs.sG));
+            VMP_HIP_CHECK(ctx, hipMemsetAsync(state + L.off_Sxx, 0,
+                                              (size_t)(m.KP * m.KP) * sizeof(double), cs.sG));
+            VMP_HIP_CHECK(ctx, hipMemsetAsync(state + L.off_M, 0,
+                                              (size_t)m.DP * m.LR * sizeof(double), cs.sG));
+        }
+        return VMP_OK;
+    }
     const int64_t sub0 = n0 / 16, nsub = (nplates + 15) / 16;
     double *partial = reinterpret_cast<double *>(workspace);
     const int ns = stats_slices(m);

@@ -222,5 +222,19 @@ def set_runtime(rt):
     _runtime = rt
 
 
+_EMPTY_SENTINEL = {}
+
+
 def ptr(tensor):
-    return ctypes.c_void_p(tensor.data_ptr())
+    """Device address of a tensor for the C ABI.  An EMPTY tensor (an empty local plate: a rank of
+    a sharded run without any observation) has no storage; the entry points get the address of a
+    small per-device scratch block instead of NULL -- with a zero count nothing of it is accessed,
+    and NULL keeps meaning "argument missing"."""
+    p = tensor.data_ptr()
+    if p == 0 and tensor.numel() == 0 and tensor.is_cuda:
+        key = tensor.device.index
+        if key not in _EMPTY_SENTINEL:
+            import torch
+            _EMPTY_SENTINEL[key] = torch.zeros(64, dtype=torch.float64, device=tensor.device)
+        p = _EMPTY_SENTINEL[key].data_ptr()
+    return ctypes.c_void_p(p)

@@ -221,7 +221,12 @@ class MaskedPCAPlan:
                 Yd = torch.from_numpy(ya).to(rt.device)
             ldy = N
         m = self.Y._mask
-        if isinstance(m, DeviceMask):
+        if N == 0:
+            # an empty local plate (a rank of a sharded run without observations): one tile of
+            # padding keeps every pointer valid; nothing of it is read
+            Yd, ldy = rt.zeros(D, 32), 32
+            Md = torch.zeros(D, 32, dtype=torch.uint8, device=rt.device)
+        elif isinstance(m, DeviceMask):
             Md = m.tensor.expand(D, N).to(torch.uint8).contiguous()
         else:
             Md = torch.from_numpy(np.ascontiguousarray(

@@ -335,10 +335,12 @@ class PCAPlan:
         y = self.Y._data
         if isinstance(y, torch.Tensor) and y.device == rt.device and y.dtype == torch.float64 \
                 and tuple(y.shape) == (D, N) and y.stride(1) == 1 and y.stride(0) % 2 == 0 \
-                and y.data_ptr() % 16 == 0:
+                and y.data_ptr() % 16 == 0 and N > 0:
             self.Yd, self.ldy = y, y.stride(0)
         else:
-            ldy = (N + 31) // 32 * 32        # whole 32-column tiles: no ragged-tail launch
+            # whole 32-column tiles: no ragged-tail launch.  (An empty local plate -- a rank of a
+            # sharded run without any observation -- keeps one tile of padding: valid pointers.)
+            ldy = max(32, (N + 31) // 32 * 32)
             self.Yd = rt.zeros(D, ldy)
             if isinstance(y, torch.Tensor):
                 src = y
@@ -349,7 +351,7 @@ class PCAPlan:
                 src = torch.from_numpy(ya)
             self.Yd[:, :N].copy_(src)
             self.ldy = ldy
-        self.ldx = (N + 31) // 32 * 32
+        self.ldx = max(32, (N + 31) // 32 * 32)
         self.state = rt.zeros(int(L.total))
         self._scal_host = None
         self.ws = rt.empty(int(k.workspace_doubles(D, K)))

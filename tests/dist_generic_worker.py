@@ -81,6 +81,33 @@ def main():
         res['alpha_u0'] = np.asarray(Q['alpha'].u[0])
         res['X_u0'] = np.asarray(Q['X'].u[0])
         res['lo'], res['hi'] = lo, hi
+    elif case == 'empty_rank':
+        # fewer plate elements than ranks: rank 0 holds NOTHING, rank 1 everything; every fused
+        # block must take part in the collectives with zero statistics
+        from models import build_pca, build_masked_pca
+        from test_gmm_gpu import _build as build_gmm
+        from test_lssm_gpu import _build as build_lssm
+        rs = np.random.RandomState(11)
+        D, K = 5, 2
+        n = 0 if rank == 0 else 3
+        y, x0 = rs.normal(size=(D, 3)), rs.normal(size=(3, K))
+        Q = build_pca(nodes, VB, y[:, :n], x0[:n], K, shard=True)
+        Q.update(repeat=3, verbose=False)
+        res['pca_L'], res['pca_engine'] = np.array(Q.L[:3]), type(Q.plans[0]).__name__
+        mask = rs.rand(D, 3) < 0.8
+        Q = build_masked_pca(nodes, VB, y[:, :n], mask[:, :n], x0[:n], shard=True)
+        Q.update(repeat=3, verbose=False)
+        res['mpca_L'], res['mpca_engine'] = np.array(Q.L[:3]), type(Q.plans[0]).__name__
+        yg, lab = rs.normal(size=(3, 2)), np.array([0, 1, 1])
+        Q = build_gmm(yg[:n], lab[:n], 2, shard=True)
+        Q.update(repeat=3, verbose=False)
+        res['gmm_L'], res['gmm_engine'] = np.array(Q.L[:3]), type(Q.plans[0]).__name__
+        yl, xl, cl = rs.normal(size=(2, 3, 6)), rs.normal(size=(3, 6, 2)), rs.normal(size=(2, 2))
+        Q = build_lssm(yl[:, :n], xl[:n], cl, False, shard=True)
+        Q.update(repeat=3, verbose=False)
+        res['lssm_L'], res['lssm_engine'] = np.array(Q.L[:3]), type(Q.plans[0]).__name__
+        for k_, v_ in dict(y=y, x0=x0, mask=mask, yg=yg, lab=lab, yl=yl, xl=xl, cl=cl).items():
+            res['in_' + k_] = v_
     elif case == 'rotation':
         g = np.load(os.path.join(golden, 'rotations.npz'))
         y, mask, x0 = g['rotm_y'], g['rotm_mask'], g['rotm_x0']

@@ -11,13 +11,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _build(y, lab0, K, engine=None):
+def _build(y, lab0, K, engine=None, shard=False):
     from bayespy_amd.nodes import (GaussianARD, Gaussian, Wishart, Dirichlet, Categorical,
                                    Mixture)
     from bayespy_amd.inference import VB
     N, D = y.shape
     alpha = Dirichlet(1e-3 * np.ones(K), name='alpha')
     z = Categorical(alpha, plates=(N,), name='z')
+    if shard:
+        z.shard(-1)
     mu = GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
     Lam = Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
     Y = Mixture(z, Gaussian, mu, Lam, plates=(N,), name='Y')

@@ -76,6 +76,29 @@ def test_sharded_erasure_patterns_match_reference(golden_dir, tmp_path, engine, 
     assert np.array_equal(r0['W_u0'], r1['W_u0']) and np.array_equal(r0['L'], r1['L'])
 
 
+def test_a_rank_without_any_plate_element(golden_dir, tmp_path):
+    """Fewer plate elements than ranks: rank 0 of the two holds an EMPTY local plate in each of the
+    four fused blocks; both ranks reproduce the single-process oracle run on all the data."""
+    from oracle.pca import PCAOracle
+    from oracle.masked_pca import MaskedPCAOracle
+    from oracle.gmm import GMMOracle
+    from oracle.lssm import LSSMOracle
+    r0, r1 = _launch('empty_rank', golden_dir, tmp_path, 29552)
+    g = r1
+    oracles = dict(
+        pca=PCAOracle(g['in_y'], g['in_x0']),
+        mpca=MaskedPCAOracle(np.where(g['in_mask'], g['in_y'], np.nan), g['in_mask'], g['in_x0']),
+        gmm=GMMOracle(g['in_yg'], g['in_lab'], 2),
+        lssm=LSSMOracle(g['in_yl'], g['in_xl'], g['in_cl']))
+    engines = dict(pca='PCAPlan', mpca='MaskedPCAPlan', gmm='GMMPlan', lssm='LSSMPlan')
+    for nm, o in oracles.items():
+        o.iterate(3)
+        for r in (r0, r1):
+            assert str(r[nm + '_engine']) == engines[nm]
+            np.testing.assert_allclose(r[nm + '_L'], np.array(o.L), rtol=1e-9, err_msg=nm)
+        assert np.array_equal(r0[nm + '_L'], r1[nm + '_L'])
+
+
 def test_sharded_rotation_matches_reference(golden_dir, tmp_path):
     r0, r1 = _launch('rotation', golden_dir, tmp_path, 29542)
     g = np.load(os.path.join(golden_dir, 'rotations.npz'))
