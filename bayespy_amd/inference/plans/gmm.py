@@ -15,6 +15,8 @@ import ctypes
 
 import numpy as np
 
+from . import _delta
+
 from ... import _lib
 from ...device import get_runtime, ptr
 from ...nodes.node import Constant
@@ -189,6 +191,7 @@ class GMMPlan:
     def _materialize(self):
         if self._ready:
             return
+        self._delta = _delta.delta_roles(self.roles)    # point masses until their first update
         rt, k = self.rt, self.kernels
         torch = rt.torch
         N, D, K = self.N, self.D, self.K
@@ -233,6 +236,7 @@ class GMMPlan:
 
     def update(self, node):
         self._materialize()
+        _delta.updated(self._delta, self.roles, node)
         rt, k = self.rt, self.kernels
         rt.sync_stream()
         D, K = self.D, self.K
@@ -265,7 +269,7 @@ class GMMPlan:
             self._L = dict(Y=float(t[0]), z=float(t[1]), alpha=float(t[2]), mu=float(t[3]),
                            Lambda=float(t[4]), total=float(t[5]))
             self._L_version = self._version
-        return self._L
+        return _delta.bound_terms(self._L, self._delta)
 
     def lower_bound_contribution(self, node):
         terms = self._lower_bound_terms()
@@ -282,6 +286,7 @@ class GMMPlan:
     def save_state(self, put, nodes, index):
         self._materialize()
         base = 'plans/%d/' % index
+        _delta.save(put, base, self._delta)
         put(base + 'kind', np.array([ord(c) for c in 'gmm'], dtype=np.uint8))
         put(base + 'dims', np.array([self.N, self.D, self.K], dtype=np.int64))
         put(base + 'state', self.state.cpu().numpy())
@@ -290,6 +295,7 @@ class GMMPlan:
     def load_state(self, reader, nodes, index):
         self._materialize()
         base = 'plans/%d/' % index
+        self._delta = _delta.load(reader, base)
         if not reader.has(base + 'state'):
             raise Exception("File does not contain the state of the fused mixture block")
         dims = tuple(int(v) for v in reader.get(base + 'dims'))

@@ -19,6 +19,8 @@ import ctypes
 
 import numpy as np
 
+from . import _delta
+
 from ... import _lib
 from ...device import get_runtime, ptr
 from ...nodes.node import Constant
@@ -277,6 +279,7 @@ class LSSMPlan:
     def _materialize(self):
         if self._ready:
             return
+        self._delta = _delta.delta_roles(self.roles)    # point masses until their first update
         rt, k = self.rt, self.kernels
         torch = rt.torch
         D, M, B, T = self.D, self.M, self.B, self.T
@@ -403,6 +406,7 @@ class LSSMPlan:
     # -- node operations -------------------------------------------------------------------------------------
     def update(self, node):
         self._materialize()
+        _delta.updated(self._delta, self.roles, node)
         code = {id(self.C): OP_C, id(self.gamma): OP_GAMMA, id(self.A): OP_A,
                 id(self.alpha): OP_ALPHA, id(self.tau): OP_TAU}
         if self.nu is not None:
@@ -447,7 +451,7 @@ class LSSMPlan:
             self._L = dict(Y=t[0], C=t[1], A=t[2], X=t[3], gamma=t[4], alpha=t[5], tau=t[6], nu=t[7],
                            total=t[8])
             self._L_version = self._version
-        return self._L
+        return _delta.bound_terms(self._L, self._delta)
 
     def lower_bound_contribution(self, node):
         terms = self._lower_bound_terms()
@@ -538,6 +542,7 @@ class LSSMPlan:
         self._materialize()
         self._flush()
         base = 'plans/%d/' % index
+        _delta.save(put, base, self._delta)
         put(base + 'kind', np.array([ord(c) for c in 'lssm'], dtype=np.uint8))
         put(base + 'dims', np.array([self.D, self.M, self.B, self.T], dtype=np.int64))
         put(base + 'state', self.state.cpu().numpy())
@@ -551,6 +556,7 @@ class LSSMPlan:
     def load_state(self, reader, nodes, index):
         self._materialize()
         base = 'plans/%d/' % index
+        self._delta = _delta.load(reader, base)
         if not reader.has(base + 'state'):
             raise Exception("File does not contain the state of the fused LSSM block")
         dims = tuple(int(v) for v in reader.get(base + 'dims'))

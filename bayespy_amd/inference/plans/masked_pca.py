@@ -22,6 +22,8 @@ import os
 
 import numpy as np
 
+from . import _delta
+
 from ... import _lib
 from ...device import get_runtime, ptr
 from ...nodes.node import DeviceMask
@@ -192,6 +194,7 @@ class MaskedPCAPlan:
     def _materialize(self):
         if self._ready:
             return
+        self._delta = _delta.delta_roles(self.roles)    # point masses until their first update
         rt, k = self.rt, self.kernels
         torch = rt.torch
         D, N, K = self.D, self.N, self.K
@@ -317,6 +320,7 @@ class MaskedPCAPlan:
     # -- node operations ---------------------------------------------------------------------------------
     def update(self, node):
         self._materialize()
+        _delta.updated(self._delta, self.roles, node)
         k = self.kernels
         D, K = self.D, self.K
         if node is self.W:
@@ -375,7 +379,7 @@ class MaskedPCAPlan:
             self._L = dict(Y=float(t[0]), X=float(t[1]), W=float(t[2]), tau=float(t[3]),
                            alpha=float(t[4]), total=float(t[5]))
             self._L_version = self._version
-        return self._L
+        return _delta.bound_terms(self._L, self._delta)
 
     def lower_bound_contribution(self, node):
         terms = self._lower_bound_terms()
@@ -503,6 +507,7 @@ class MaskedPCAPlan:
         self._materialize()
         self._flush()
         base = 'plans/%d/' % index
+        _delta.save(put, base, self._delta)
         put(base + 'kind', np.array([ord(c) for c in 'mpca'], dtype=np.uint8))
         put(base + 'dims', np.array([self.D, self.N, self.K], dtype=np.int64))
         put(base + 'state', self.state.cpu().numpy())
@@ -517,6 +522,7 @@ class MaskedPCAPlan:
     def load_state(self, reader, nodes, index):
         self._materialize()
         base = 'plans/%d/' % index
+        self._delta = _delta.load(reader, base)
         if not reader.has(base + 'state'):
             raise Exception("File does not contain the state of the fused missing-data PCA block")
         dims = tuple(int(v) for v in reader.get(base + 'dims'))

@@ -37,6 +37,8 @@ import os
 
 import numpy as np
 
+from . import _delta
+
 from ... import _lib
 from ...device import get_runtime, ptr
 from ...nodes.node import Constant
@@ -313,6 +315,7 @@ class PCAPlan:
     def _materialize(self):
         if self._ready:
             return
+        self._delta = _delta.delta_roles(self.roles)    # point masses until their first update
         rt, k = self.rt, self.kernels
         torch = rt.torch
         D, N, K = self.D, self.N, self.K
@@ -432,6 +435,7 @@ class PCAPlan:
     # -- node operations ---------------------------------------------------------------------
     def update(self, node):
         self._materialize()
+        _delta.updated(self._delta, self.roles, node)
         rt, k, L = self.rt, self.kernels, self.layout
         D, N, K = self.D, self.N, self.K
         if node is self.W:
@@ -517,7 +521,7 @@ class PCAPlan:
             self._L = dict(Y=float(t[0]), X=float(t[1]), W=float(t[2]), tau=float(t[3]),
                            alpha=float(t[4]), total=float(t[5]))
             self._L_version = self._version
-        return self._L
+        return _delta.bound_terms(self._L, self._delta)
 
     def lower_bound_contribution(self, node):
         terms = self._lower_bound_terms()
@@ -620,6 +624,7 @@ class PCAPlan:
         self._materialize()
         self.finish()
         base = 'plans/%d/' % index
+        _delta.save(put, base, self._delta)
         put(base + 'kind', np.array([ord(c) for c in 'pca'], dtype=np.uint8))
         put(base + 'dims', np.array([self.D, self.N, self.K], dtype=np.int64))
         put(base + 'state', self.state.cpu().numpy())
@@ -634,6 +639,7 @@ class PCAPlan:
         self._materialize()
         self.finish()
         base = 'plans/%d/' % index
+        self._delta = _delta.load(reader, base)
         if not reader.has(base + 'state'):
             raise Exception("File does not contain the state of the fused PCA block")
         dims = tuple(int(v) for v in reader.get(base + 'dims'))

@@ -938,3 +938,92 @@ def run_constant_parent_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     res['tp_z_u0'], res['tp_s_u0'] = np.array(z.u[0]), np.array(s.u[0])
     res['tp_s_u1'] = np.array(s.u[1])
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# Update-order probes (tests/golden/order_probes.npz): node-level update sequences that differ
+# from the constructor order -- repeated updates of one node, the bound evaluated in between --
+# on the three fused model families.  Every update must see the latest moments of its Markov
+# blanket (vmp.py:154-172), whatever a fused block caches.
+# ---------------------------------------------------------------------------------------------
+PCA_PROBE_SEQ = ('L', 'W', 'L', 'X', 'W', 'L', 'W', 'tau', 'L', 'alpha', 'X', 'X', 'L', 'tau', 'alpha', 'W', 'L',
+                 'tau', 'tau', 'X', 'alpha', 'L')
+GMM_PROBE_SEQ = ('L', 'mu', 'Lambda', 'L', 'z', 'mu', 'L', 'Lambda', 'alpha', 'L', 'z', 'z', 'L', 'mu', 'Lambda', 'L', 'alpha',
+                 'Lambda', 'mu', 'z', 'L')
+LSSM_PROBE_SEQ = ('X', 'C', 'L', 'A', 'tau', 'L', 'gamma', 'alpha', 'X', 'L', 'C', 'C', 'tau', 'X',
+                  'A', 'L')
+
+
+def make_order_probe_inputs(rs):
+    g = {}
+    D, N, K = 6, 50, 3
+    g['pca_y'] = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.1 * rs.normal(size=(D, N))
+    g['pca_x0'] = rs.normal(size=(N, K))
+    g['pca_mask'] = rs.rand(D, N) < 0.8
+    g['gmm_y'] = np.concatenate([rs.normal(size=(30, 2)), rs.normal(size=(30, 2)) + 4])
+    g['gmm_lab0'] = rs.randint(3, size=60)
+    M, B, T, Dx = 3, 4, 12, 2
+    g['lssm_y'] = rs.normal(size=(M, B, T))
+    g['lssm_x0'] = rs.normal(size=(B, T, Dx))
+    g['lssm_c0'] = rs.normal(size=(M, 1, 1, Dx))
+    return g
+
+
+def _run_sequence(Q, seq, out):
+    for step in seq:
+        if step == 'L':
+            out.append(float(Q.compute_lowerbound()))
+        else:
+            Q.update(Q[step], repeat=1, verbose=False)
+    return out
+
+
+def run_order_probes(nodes_mod, vb_cls, g, **vb_kwargs):
+    N_ = nodes_mod
+    res = {}
+    Q = build_pca(N_, vb_cls, g['pca_y'], g['pca_x0'], g['pca_x0'].shape[1], **vb_kwargs)
+    res['pca_L'] = np.array(_run_sequence(Q, PCA_PROBE_SEQ, []))
+    res['pca_W_u0'], res['pca_X_u0'] = np.array(Q['W'].u[0]), np.array(Q['X'].u[0])
+    Q = build_masked_pca(N_, vb_cls, np.where(g['pca_mask'], g['pca_y'], np.nan), g['pca_mask'],
+                         g['pca_x0'], **vb_kwargs)
+    res['mpca_L'] = np.array(_run_sequence(Q, PCA_PROBE_SEQ, []))
+    res['mpca_W_u0'], res['mpca_X_u0'] = np.array(Q['W'].u[0]), np.array(Q['X'].u[0])
+    # mixture (demos/mog.py:17-64)
+    y, lab0 = g['gmm_y'], g['gmm_lab0']
+    N, D = y.shape
+    K = 3
+    alpha = N_.Dirichlet(1e-3 * np.ones(K), name='alpha')
+    z = N_.Categorical(alpha, plates=(N,), name='z')
+    mu = N_.GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
+    Lam = N_.Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
+    Y = N_.Mixture(z, N_.Gaussian, mu, Lam, plates=(N,), name='Y')
+    z.initialize_from_value(lab0)
+    Y.observe(y)
+    Q = vb_cls(Y, mu, Lam, z, alpha, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    res['gmm_L'] = np.array(_run_sequence(Q, GMM_PROBE_SEQ, []))
+    res['gmm_z_u0'], res['gmm_mu_u0'] = np.array(z.u[0]), np.array(mu.u[0])
+    # linear state-space model (demos/lssm.py:33-103) with a sequence plate
+    y, x0, c0 = g['lssm_y'], g['lssm_x0'], g['lssm_c0']
+    M, B, T = y.shape
+    Dx = x0.shape[-1]
+    al = N_.Gamma(1e-5, 1e-5, plates=(Dx,), name='alpha')
+    A = N_.GaussianARD(0, al, shape=(Dx,), plates=(Dx,), name='A')
+    A.initialize_from_value(np.identity(Dx))
+    X = N_.GaussianMarkovChain(np.zeros(Dx), 1e-3 * np.identity(Dx), A, np.ones(Dx), n=T,
+                               plates=(B,), name='X')
+    X.initialize_from_value(x0)
+    gamma = N_.Gamma(1e-5, 1e-5, plates=(Dx,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(Dx))
+    C = N_.GaussianARD(0, gamma, shape=(Dx,), plates=(M, 1, 1), name='C')
+    C.initialize_from_value(c0)
+    tau = N_.Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = N_.SumMultiply('i,i', C, X, name='F')
+    Yl = N_.GaussianARD(F, tau, name='Y')
+    Yl.observe(y)
+    Q = vb_cls(Yl, F, C, gamma, X, A, al, tau, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    res['lssm_L'] = np.array(_run_sequence(Q, LSSM_PROBE_SEQ, []))
+    res['lssm_X_u0'], res['lssm_A_u0'] = np.array(X.u[0]), np.array(A.u[0])
+    return res

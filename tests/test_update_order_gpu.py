@@ -1,0 +1,41 @@
+"""
+GPU: node-level update sequences out of constructor order (VB.update(*nodes), vmp.py:132-172) --
+one node updated twice in a row, the bound evaluated in between -- on the PCA, missing-data PCA,
+mixture and state-space models, against the live-reference traces of tests/golden/order_probes.npz
+(oracle/make_golden.py order_probes_case; tests/models.py run_order_probes runs unchanged on both
+sides).  Whatever a fused block queues or caches, every update sees the latest moments of its
+Markov blanket.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('engine', ['fused', 'fused-stream', 'generic'])
+def test_update_sequences_match_reference(golden_dir, engine, monkeypatch):
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import run_order_probes
+    g = np.load(os.path.join(golden_dir, 'order_probes.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+    kw = {'engine': 'generic'} if engine == 'generic' else {}
+    if engine == 'fused-stream':
+        monkeypatch.setenv('BAYESPY_AMD_PCA_STATS', 'stream')
+    seen = []
+    if engine != 'generic':
+        class Spy(VB):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                seen.append(type(self.plans[0]).__name__)
+        res = run_order_probes(nodes, Spy, inp, **kw)
+        assert seen == ['PCAPlan', 'MaskedPCAPlan', 'GMMPlan', 'LSSMPlan']
+    else:
+        res = run_order_probes(nodes, VB, inp, **kw)
+    for tag in ('pca', 'mpca', 'gmm', 'lssm'):
+        np.testing.assert_allclose(res[tag + '_L'], g[tag + '_L'], rtol=1e-9, err_msg=tag)
+    for key in ('pca_W_u0', 'pca_X_u0', 'mpca_W_u0', 'mpca_X_u0', 'gmm_z_u0', 'gmm_mu_u0',
+                'lssm_X_u0', 'lssm_A_u0'):
+        np.testing.assert_allclose(res[key], g[key], rtol=1e-7, atol=1e-9, err_msg=key)
