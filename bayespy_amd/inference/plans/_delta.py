@@ -6,6 +6,8 @@ Point-mass initial states in the fused blocks.
 -inf (expfamily.py:433-447: ``z = -g``), and so is the total.  The fused blocks keep only moments,
 so they track which of their roles are still point masses.
 """
+import warnings
+
 import numpy as np
 
 
@@ -40,3 +42,16 @@ def load(reader, base):
         return set()
     txt = ''.join(chr(int(c)) for c in np.asarray(reader.get(base + 'delta_roles')).ravel())
     return set(t for t in txt.split(',') if t)
+
+
+def warn_state_discarded(plan, node):
+    """observe() / initialize_from_*() on a node of a fused block that has already been updated:
+    the block rebuilds ALL of its device state from the nodes' initial values, whereas the
+    reference changes the touched node only and keeps the other posteriors (stochastic.py:223-273).
+    Loud, because results differ from there on; the generic engine keeps per-node state."""
+    if getattr(plan, '_ready', False) and getattr(plan, '_version', 0) > 1:
+        warnings.warn("%s: %s was observed / initialised after the block had been updated; the fused "
+                      "block restarts from the initial state of every node (the reference would "
+                      "keep the other posteriors) -- use VB(..., engine='generic') to continue from "
+                      "the current state" % (type(plan).__name__, node.name), RuntimeWarning,
+                      stacklevel=4)

@@ -173,6 +173,7 @@ class GMMPlan:
         return bool(self._ready)
 
     def invalidate(self, node):
+        _delta.warn_state_discarded(self, node)
         self._ready = False
         self._version += 1
         if node is self.Y and node._mask is not True:

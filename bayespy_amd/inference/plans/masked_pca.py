@@ -179,6 +179,7 @@ class MaskedPCAPlan:
         return bool(self._ready)
 
     def invalidate(self, node):
+        _delta.warn_state_discarded(self, node)
         self._ready = False
         self._version += 1
         self._pending = []

@@ -297,6 +297,7 @@ class PCAPlan:
     def invalidate(self, node):
         """Data or initial value of ``node`` changed: rebuild device state lazily."""
         self.finish()
+        _delta.warn_state_discarded(self, node)
         self._ready = False
         self._version += 1
         if self.unsupported_state(self.roles) is not None:

@@ -322,3 +322,25 @@ def test_node_state_access_on_the_fused_block(golden_dir):
     with pytest.raises(NotImplementedError, match="engine='generic'"):
         W.get_riemannian_gradient()
     Q.set_annealing(1.0)                 # the standard updates are always allowed
+
+
+def test_bound_of_point_mass_states_and_warning_on_a_restart(golden_dir):
+    """initialize_from_value leaves a point mass: the bound is -inf until that node is updated
+    (expfamily.py:193-212, :433-447).  Re-observing after updates restarts the fused block from the
+    nodes' initial values -- unlike the reference, hence a loud warning."""
+    import warnings
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    assert Q.compute_lowerbound() == -np.inf
+    assert Q['X'].lower_bound_contribution() == -np.inf
+    assert np.isfinite(Q['W'].lower_bound_contribution())
+    Q.update(Q['W'], repeat=1, verbose=False)
+    assert Q.compute_lowerbound() == -np.inf
+    Q.update(Q['X'], repeat=1, verbose=False)
+    assert np.isfinite(Q.compute_lowerbound())
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+        Q2['Y'].observe(g['y'])               # nothing learned yet: silent
+    with pytest.warns(RuntimeWarning, match='restarts from the initial state'):
+        Q['Y'].observe(g['y'] + 1.0)
