@@ -100,6 +100,17 @@ class VB:
                 return n
         raise KeyError(name)
 
+    def use_logging(self, use):
+        """Route the iteration messages through ``logging`` instead of ``print`` (vmp.py:111-118;
+        the reference tests the module-level name there, so its method always raises NameError --
+        this one does what its comment says)."""
+        import logging
+        self.print = logging.getLogger(__name__).info if use else print
+
+    def get_iteration_by_nodes(self):
+        """Per-node lower-bound traces, {node: array over iterations} (vmp.py:233-234)."""
+        return self.l
+
     def set_callback(self, callback):
         self.callback = callback
 

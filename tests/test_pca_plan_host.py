@@ -344,3 +344,17 @@ def test_bound_of_point_mass_states_and_warning_on_a_restart(golden_dir):
         Q2['Y'].observe(g['y'])               # nothing learned yet: silent
     with pytest.warns(RuntimeWarning, match='restarts from the initial state'):
         Q['Y'].observe(g['y'] + 1.0)
+
+
+def test_logging_switch_and_per_node_traces(golden_dir, caplog):
+    import logging
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.use_logging(True)
+    with caplog.at_level(logging.INFO):
+        Q.update(repeat=2)
+    assert any('Iteration 1: loglike=' in r.getMessage() for r in caplog.records)
+    Q.use_logging(False)
+    traces = Q.get_iteration_by_nodes()
+    assert traces is Q.l and set(traces) >= {Q['W'], Q['X'], Q['tau'], Q['alpha'], Q['Y']}
+    np.testing.assert_allclose(sum(traces[n][:2] for n in traces), Q.L[:2], rtol=1e-12)
