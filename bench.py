@@ -53,7 +53,7 @@ def parse():
     p.add_argument('--cpu-sample-n', type=int, default=0,
                    help='columns of the CPU-baseline sample; 0 = the whole workload when the '
                         'host has the memory for it (direct parity at the metric size)')
-    p.add_argument('--config', choices=['pca', 'gmm', 'masked', 'lssm'], default='pca',
+    p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'masked', 'lssm'], default='pca',
                    help="pca = the BASELINE.json metric (default); the others print the "
                         "secondary configurations of tools/workloads.py as the JSON line")
     p.add_argument('--no-extra', action='store_true',
@@ -233,7 +233,10 @@ def main():
     if args.config != 'pca':
         # the secondary BASELINE configurations share the JSON contract (tools/workloads.py)
         from tools import workloads
-        if args.config == 'gmm':
+        if args.config == 'pca_c2':
+            out = workloads.run_pca_c2(steps=max(args.steps, 20), warmup=args.warmup,
+                                       cpu_baseline=not args.no_cpu_baseline)
+        elif args.config == 'gmm':
             out = workloads.run_gmm(steps=args.steps, warmup=args.warmup,
                                     cpu_baseline=not args.no_cpu_baseline)
         elif args.config == 'masked':
@@ -358,6 +361,8 @@ def main():
             torch.cuda.empty_cache()
             from tools import workloads
             out['extra'] = [
+                run_extra('pca_c2', workloads.run_pca_c2, 60, steps=50, warmup=5,
+                          cpu_baseline=not args.no_cpu_baseline),
                 run_extra('gmm', workloads.run_gmm, 120, steps=10, warmup=2,
                           cpu_baseline=not args.no_cpu_baseline),
                 run_extra('masked', workloads.run_masked, 120, steps=3, warmup=1),

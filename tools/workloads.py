@@ -2,11 +2,12 @@
 The secondary BASELINE.json configurations as functions that return the bench.py JSON fields
 (metric / value / ms_per_step / roofline / cpu_baseline):
 
+    run_pca_c2  config 2  probabilistic PCA N=1e6, D=64, K=16 (launch / latency-bound: SURVEY.md 8d)
     run_gmm     config 3  Gaussian mixture N=1e7, D=8, K=64
     run_masked  SURVEY.md 8(d) secondary run: PCA N=1e7, D=128, K=32 with 10 % missing values
     run_lssm    config 5  linear state-space model, T=1e3 x B=1e5 sequences
 
-``bench.py --config {gmm,masked,lssm}`` prints one of them as its JSON line; the default
+``bench.py --config {pca_c2,gmm,masked,lssm}`` prints one of them as its JSON line; the default
 ``bench.py`` run (the PCA headline) appends all of them under "extra".  tools/bench_*.py are the
 stand-alone command lines of the same functions.
 """
@@ -28,6 +29,76 @@ def _cores():
         return int(max([i.get('num_threads', 1) for i in threadpool_info()] or [1]))
     except Exception:       # noqa: BLE001
         return os.cpu_count() or 1
+
+
+def run_pca_c2(N=1_000_000, D=64, K=16, steps=50, warmup=5, cpu_baseline=True):
+    """BASELINE config 2: the headline model at a size where the replicated-node chain, not the
+    plate pass, sets the step (bytes 0.64 GB = 0.08 ms at 8 TB/s): absolute it/s is the figure."""
+    import numpy as np
+    import torch
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy_amd.inference import VB
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)
+    x = torch.randn(K, N, generator=g, device=dev, dtype=torch.float64)
+    y = w @ x + 0.1 * torch.randn(D, N, generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
+    del w, x
+    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    F = SumMultiply('i,i', W, X, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau')
+    Y = GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None])
+    Y.observe(y)
+    Q = VB(Y, F, W, X, tau, alpha)
+    Q.ignore_bound_checks = True
+    plan = Q.plans[0]
+    Q.update(repeat=warmup, verbose=False)
+    plan.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Q.update(repeat=steps, verbose=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pass_ms = plan.pass_times_ms(64)
+    avg_pass = sum(p[0] for p in pass_ms) / len(pass_ms)
+    alg_bytes = 8.0 * N * (D + K)
+    gbs = alg_bytes / (avg_pass * 1e-3) / 1e9
+    L = [float(v) for v in Q.L[:Q.iter]]
+    out = {
+        'metric': 'VB iterations/sec, PCA N=%d D=%d K=%d' % (N, D, K),
+        'value': steps / dt, 'unit': 'VB iterations/s', 'n_gpus': 1, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'probabilistic PCA (BASELINE config 2), N=%d D=%d K=%d, fully observed'
+                               % (N, D, K), 'stats': plan.stats, 'plate_layout': plan.plate_layout},
+        'elbo_first': L[0], 'elbo_last': L[-1],
+        'roofline': {'kernel': 'pca_xpass_kernel', 'bound': 'hbm', 'achieved': gbs,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                     'traffic': None, 'avg_launch_ms': avg_pass,
+                     'alg_bytes_per_launch': alg_bytes,
+                     'note': 'the step (ms_per_step) is set by the replicated-node chain at this '
+                             'size, not by this kernel'},
+    }
+    if cpu_baseline:
+        from oracle.pca import PCAOracle
+        yh, xh = y.cpu().numpy(), x0.cpu().numpy()
+        o = PCAOracle(yh, xh, keep_x=False)
+        n_it = min(3, len(L))
+        t0 = time.perf_counter()
+        o.iterate(n_it)
+        dtc = time.perf_counter() - t0
+        out['cpu_baseline'] = {
+            'value': n_it / dtc, 'unit': 'VB iterations/s', 'cores': _cores(), 'kind': 'port',
+            'elbo_rel_err_full': float(np.max(np.abs((np.array(o.L) - np.array(L[:n_it]))
+                                                     / np.array(o.L)))),
+            'sample': 'oracle/pca.py on the whole workload, %d iterations at %.2f s/iter'
+                      % (n_it, dtc / n_it)}
+    return out
 
 
 def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_sample_n=100_000):
