@@ -25,6 +25,10 @@ struct vmp_ctx {
     hipStream_t xs;
     hipEvent_t ev_xfork, ev_xdone;
     int x_pending;
+    // the pass reads A from one of two private copies in turn (vmp_pca.hip run_xpass)
+    hipEvent_t ev_xbuf[2];
+    int x_buf_pending[2];
+    int64_t x_count;
     int xs_cus;                // compute units the plate stream may use
     // streams / events of the pipelined plate pass of the missing-data PCA block (vmp_mpca.hip)
     hipStream_t ms[3];

@@ -66,6 +66,9 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     ctx->xs = nullptr;
     ctx->ev_xfork = ctx->ev_xdone = nullptr;
     ctx->x_pending = 0;
+    ctx->x_buf_pending[0] = ctx->x_buf_pending[1] = 0;
+    ctx->x_count = 0;
+    ctx->ev_xbuf[0] = ctx->ev_xbuf[1] = nullptr;
     ctx->xs_cus = 0;
     for (int i = 0; i < 3; ++i) ctx->ms[i] = nullptr;
     for (int i = 0; i < 8; ++i) ctx->me[i] = nullptr;
@@ -99,6 +102,8 @@ int32_t vmp_ctx_destroy(vmp_ctx *ctx)
         if (ctx->me[i]) (void)hipEventDestroy(ctx->me[i]);
     if (ctx->ev_xfork) (void)hipEventDestroy(ctx->ev_xfork);
     if (ctx->ev_xdone) (void)hipEventDestroy(ctx->ev_xdone);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->ev_xbuf[i]) (void)hipEventDestroy(ctx->ev_xbuf[i]);
     delete ctx;
     return VMP_OK;
 }

@@ -685,6 +685,8 @@ int32_t ensure_plate_stream(vmp_ctx *ctx)
     ctx->xs = xs;
     VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_xfork, hipEventDisableTiming));
     VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_xdone, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i)
+        VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_xbuf[i], hipEventDisableTiming));
     return VMP_OK;
 }
 
@@ -794,8 +796,16 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
         // replicated-node kernels of the NEXT iteration (main stream, reserved CUs) overlap
         // it; the only ordering kept is pass(i) before pass(i+1) and before anything that
         // touches X.
-        double *Ax = plate_stream_A(ctx, L, workspace);
-        if (ctx->x_pending) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(m, ctx->ev_xdone, 0));
+        // TWO private copies, used in turn: the copy for pass i+1 is made while pass i still
+        // reads the other one, so the main stream never waits for the pass in flight (only for
+        // the one before it) and consecutive passes run back to back
+        const int b = (int)(ctx->x_count & 1);
+        ctx->x_count += 1;
+        double *Ax = plate_stream_A(ctx, L, workspace) + (int64_t)b * L.KP * L.DP;
+        if (ctx->x_buf_pending[b]) {
+            VMP_HIP_CHECK(ctx, hipStreamWaitEvent(m, ctx->ev_xbuf[b], 0));
+            ctx->x_buf_pending[b] = 0;
+        }
         VMP_HIP_CHECK(ctx, hipMemcpyAsync(Ax, state + L.off_A,
                                           (size_t)(L.KP * L.DP) * sizeof(double),
                                           hipMemcpyDeviceToDevice, m));
@@ -845,6 +855,9 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
     if (overlap) {
         VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xdone, s));
         ctx->x_pending = 1;
+        const int b = (int)((ctx->x_count - 1) & 1);
+        VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xbuf[b], s));
+        ctx->x_buf_pending[b] = 1;
     }
     // messages to W from (G, A): main stream, concurrent with the pass
     return run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), m);
@@ -872,7 +885,7 @@ int32_t vmp_pca_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *byte
     fill_layout(D, K, &L);
     // per-workgroup partial statistics + one scratch statistics block (Gram set-up)
     // (+ the plate stream's private copy of A)
-    *bytes = (size_t)(plate_stream_A_offset(ctx, L) + L.KP * L.DP) * sizeof(double);
+    *bytes = (size_t)(plate_stream_A_offset(ctx, L) + 2 * L.KP * L.DP) * sizeof(double);
     return VMP_OK;
 }
 

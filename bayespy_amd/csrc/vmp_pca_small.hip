@@ -13,6 +13,7 @@
 // dot.py:581 (message E4), gaussian.py:2344-2369 (WrapToGaussianGamma), gamma.py:116-160,
 // expfamily.py:400-480 (lower bound), utils/linalg.py:31-223 (chol, chol_inv, chol_logdet).
 #include "vmp_common.h"
+#include "vmp_sweep.h"
 
 #include <stdlib.h>
 
@@ -89,6 +90,53 @@ __device__ void gj_inverse(double *M, int n, double *logdet, int *bad)
     if (tid == 0) {
         *logdet = ld + sf_log(prod);
         if (isbad) *bad = 1;
+    }
+    __syncthreads();
+}
+
+// The same inverse for KP <= 32 by ONE wavefront in registers (vmp_sweep.h: symmetric sweep with
+// 4 x 4 pivot blocks on the matrix cores): no LDS traffic and no barriers between the pivots.
+// gj_inverse above takes 2 barriers and 16 LDS accesses per pivot -- 14 of the 41 us of the fused
+// W / X-prepare kernel per inverse when it runs alone, and 70+ us each beside the streaming grid of
+// the plate pass, whose wavefronts keep the CU's LDS pipeline busy (measured with wall_clock64
+// stamps at N = 1.25e6, the shard one of 8 ranks holds at the headline size).
+template <int KP>
+__device__ void sweep_inverse(double *M, int n, double *logdet, int *bad)
+{
+    static_assert(KP == 16 || KP == 32, "one 32 x 32 register tile set");
+    constexpr int LDM = KP + 1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4;
+        v4f64 T[2][2];
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * tr + l4 + 4 * r, col = 16 * tc + l15;
+                    T[tr][tc][r] = (row < KP && col < KP) ? M[row * LDM + col]
+                                                          : (row == col ? 1.0 : 0.0);
+                }
+        double prod = 1.0, ld = 0.0;
+        int isbad = 0;
+        vmp_sweep::sweep_upto<0>(T, (n + 3) / 4, l15, l4, prod, ld, isbad);
+#pragma unroll
+        for (int tr = 0; tr < KP / 16; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < KP / 16; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * tr + l4 + 4 * r, col = 16 * tc + l15;
+                    // rows / columns beyond n were not swept: they keep the identity
+                    M[row * LDM + col] = (row < 4 * ((n + 3) / 4) && col < 4 * ((n + 3) / 4))
+                                             ? -T[tr][tc][r] : T[tr][tc][r];
+                }
+        if (l == 0) {
+            *logdet = vmp_sweep::sweep_logdet(prod, ld);
+            if (isbad) *bad = 1;
+        }
     }
     __syncthreads();
 }
@@ -417,8 +465,12 @@ __device__ __forceinline__ v4f64 wave_tile_mma(const double *As, int am, int ak,
 }
 
 // (W.update(), X.update() replicated half)
+// __launch_bounds__(NTF, 4): at most 128 VGPRs, so that the workgroup finds room on a CU whose
+// SIMDs already hold three wavefronts of the plate pass (3 x 128 of 512 registers): with the 170
+// registers the sweep would take otherwise it is placed only once the persistent grid of the pass
+// drains (measured: first instruction 15 us after the pass's last workgroup).
 template <int KP>
-__global__ void __launch_bounds__(NTF)
+__global__ void __launch_bounds__(NTF, 4)
 pca_head_fast_kernel(small_args a, double *st)
 {
     constexpr int LDM = KP + 1, E = KP * KP / NTF, RB = 32;
@@ -488,7 +540,7 @@ pca_head_fast_kernel(small_args a, double *st)
             M[(e / KP) * LDM + (e % KP)] = lam[m];
         }
     }
-    gj_inverse<KP, NTF>(M, K, &logdet, &bad);
+    sweep_inverse<KP>(M, K, &logdet, &bad);
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const int e = tid + m * NTF;
@@ -554,7 +606,7 @@ pca_head_fast_kernel(small_args a, double *st)
         }
         M[i * LDM + j] = v;
     }
-    gj_inverse<KP, NTF>(M, K, &logdet, &bad);
+    sweep_inverse<KP>(M, K, &logdet, &bad);
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const int e = tid + m * NTF;

@@ -23,4 +23,5 @@ bash tools/collect_profiles_r02.sh $O/prof > $O/collect.log 2>&1
 tail -3 $O/collect.log
 ( timeout 600 python bench.py --no-extra > $O/bench_after_profiles.json 2>> $O/bench_default.err ); python -c "
 import json; d=json.load(open('$O/bench_after_profiles.json')); print('traffic', d['roofline'].get('traffic'), d['value'])"
+bash tools/timeline.sh > $O/timeline.log 2>&1; cp gpurun_out/tl/timeline_*.txt $O/prof/ 2>/dev/null
 echo "total secs: $(( $(date +%s) - s ))"
