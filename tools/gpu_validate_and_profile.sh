@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box call: full `pytest -m gpu`, the default bench line, rocprofv3 summaries of every block
-# (tools/collect_profiles_r02.sh) and a bench run that reads the fresh counter files.  Usage:
+# (tools/collect_profiles_r02.sh) and the dispatch timelines of the small-size steps (tools/timeline.sh).  Usage:
 #   gpurun --timeout 2400 -- bash tools/gpu_validate_and_profile.sh ; then copy gpurun_out/r02h/prof/* to profiles/r02/
 O=gpurun_out/r02h
 mkdir -p $O
@@ -21,7 +21,5 @@ for e in d.get('extra', []):
 PY
 bash tools/collect_profiles_r02.sh $O/prof > $O/collect.log 2>&1
 tail -3 $O/collect.log
-( timeout 600 python bench.py --no-extra > $O/bench_after_profiles.json 2>> $O/bench_default.err ); python -c "
-import json; d=json.load(open('$O/bench_after_profiles.json')); print('traffic', d['roofline'].get('traffic'), d['value'])"
 bash tools/timeline.sh > $O/timeline.log 2>&1; cp gpurun_out/tl/timeline_*.txt $O/prof/ 2>/dev/null
 echo "total secs: $(( $(date +%s) - s ))"
