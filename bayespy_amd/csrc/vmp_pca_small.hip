@@ -101,7 +101,7 @@ __device__ void gj_inverse(double *M, int n, double *logdet, int *bad)
 // the plate pass, whose wavefronts keep the CU's LDS pipeline busy (measured with wall_clock64
 // stamps at N = 1.25e6, the shard one of 8 ranks holds at the headline size).
 template <int KP>
-__device__ void sweep_inverse(double *M, int n, double *logdet, int *bad)
+__device__ __forceinline__ void sweep_inverse(double *M, int n, double *logdet, int *bad)
 {
     static_assert(KP == 16 || KP == 32, "one 32 x 32 register tile set");
     constexpr int LDM = KP + 1;
@@ -465,32 +465,58 @@ __device__ __forceinline__ v4f64 wave_tile_mma(const double *As, int am, int ak,
 }
 
 // (W.update(), X.update() replicated half)
-// __launch_bounds__(NTF, 4): at most 128 VGPRs, so that the workgroup finds room on a CU whose
-// SIMDs already hold three wavefronts of the plate pass (3 x 128 of 512 registers): with the 170
-// registers the sweep would take otherwise it is placed only once the persistent grid of the pass
-// drains (measured: first instruction 15 us after the pass's last workgroup).
+// accumulate form of wave_tile_mma
+__device__ __forceinline__ v4f64 wave_tile_mma_acc(v4f64 acc, const double *As, int am, int ak,
+                                                   const double *Bs, int bk, int bn, int kc)
+{
+    const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
+#pragma unroll 4
+    for (int q = 0; q < kc; q += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[l15 * am + (q + l4) * ak],
+                                                   Bs[(q + l4) * bk + l15 * bn], acc, 0, 0, 0);
+    return acc;
+}
+
+// (W.update(), X.update() replicated half)
+//
+// Placement beside the plate pass decides this kernel's latency at the multi-GPU shard size, and
+// what decides the placement was measured (tools/timeline.sh, tools/experiments/
+// placement_microbench.hip): beside three resident pass workgroups per CU (32 KB of
+// LDS, 122 VGPRs each) a workgroup asking for 52 KB of LDS is not placed until the persistent grid
+// drains, whatever its register count; one asking for 26 KB and <= 96 registers is placed at once.
+// So the D x K operand is staged through ONE 32-row block (8.4 KB) instead of a D-row array
+// (33.8 KB), the rows of sum y<x>^T are loaded only after the first sweep and the rows of <W> come
+// back from global memory for the last product instead of waiting in registers, the inverses are
+// inlined (no call, no scratch) and the file is compiled with the VGPR form of the MFMAs (Makefile):
+// 25.6 KB, 96 VGPRs, no AGPRs, no scratch.
 template <int KP>
 __global__ void __launch_bounds__(NTF, 4)
 pca_head_fast_kernel(small_args a, double *st)
 {
     constexpr int LDM = KP + 1, E = KP * KP / NTF, RB = 32;
+    constexpr int KT = KP / 16;
+    constexpr int NB = FAST_D / RB;               // row blocks
+    constexpr int NLB = RB * KP / NTF;            // loads per thread and row block
+    constexpr int TPB = 2 * KT;                   // 16 x 16 tiles of a row block
+    constexpr int WT = (TPB + 3) / 4;             // ... per wavefront
+    constexpr int ST = (KT * KT + 3) / 4;         // tiles of Sww per wavefront
     __shared__ double M[KP * LDM];          // Lambda_W -> Cov_W -> Lambda_X -> Cov_X
     __shared__ double T[KP * LDM];          // sum <x x^T> (shard sum) -> Sww
-    __shared__ double SW[FAST_D * LDM];     // Syx rows -> <W> rows, in place
+    __shared__ double SWb[RB * LDM];        // one row block: Syx rows -> <W> rows
     __shared__ double alm[KP];
     __shared__ double logdet;
     __shared__ int bad;
     const lay32 L(a.L);
-    const int tid = threadIdx.x, D = a.D, K = a.K;
+    int tid = threadIdx.x;
+    const int D = a.D, K = a.K;
     const int DP = (int)L.DP;
-    const int Dc = (D + RB - 1) / RB * RB;
+    const int nb = (D + RB - 1) / RB;
     __builtin_amdgcn_s_setprio(3);   // latency-critical: win issue arbitration on a shared CU
     if (tid == 0) bad = 0;
     // ---- one batch of loads ------------------------------------------------------------
     const double tau = st[L.off_tau + 2];
     {
-        constexpr int NL = FAST_D * KP / NTF;
-        double cx[E], sx[E], v[NL];
+        double cx[E], sx[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             const int e = tid + m * NTF;
@@ -499,23 +525,12 @@ pca_head_fast_kernel(small_args a, double *st)
             cx[m] = in ? st[L.off_CX + i * KP + j] : 0.0;
             sx[m] = in ? st[L.off_S + (L.DP + i) * KP + j] : 0.0;
         }
-#pragma unroll
-        for (int m = 0; m < NL; ++m) {
-            const int e = tid + m * NTF;
-            const int r = e / KP, k = e % KP;
-            v[m] = (r < D && k < K) ? st[L.off_S + r * KP + k] : 0.0;
-        }
         if (tid < KP) alm[tid] = tid < K ? st[L.off_alpha + 2 * KP + tid] : 0.0;
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             const int e = tid + m * NTF;
             M[(e / KP) * LDM + (e % KP)] = cx[m];
             T[(e / KP) * LDM + (e % KP)] = sx[m];
-        }
-#pragma unroll
-        for (int m = 0; m < NL; ++m) {
-            const int e = tid + m * NTF;
-            SW[(e / KP) * LDM + (e % KP)] = v[m];
         }
     }
     __syncthreads();
@@ -526,12 +541,12 @@ pca_head_fast_kernel(small_args a, double *st)
         for (int m = 0; m < E; ++m) {
             const int e = tid + m * NTF;
             const int i = e / KP, j = e % KP;
-            double v = (i == j) ? 1.0 : 0.0;
+            double x = (i == j) ? 1.0 : 0.0;
             if (i < K && j < K) {
-                v = tau * (a.n_total * M[i * LDM + j] + 0.5 * (T[i * LDM + j] + T[j * LDM + i]));
-                if (i == j) v += alm[i];
+                x = tau * (a.n_total * M[i * LDM + j] + 0.5 * (T[i * LDM + j] + T[j * LDM + i]));
+                if (i == j) x += alm[i];
             }
-            lam[m] = v;
+            lam[m] = x;
         }
         __syncthreads();
 #pragma unroll
@@ -540,7 +555,9 @@ pca_head_fast_kernel(small_args a, double *st)
             M[(e / KP) * LDM + (e % KP)] = lam[m];
         }
     }
+    asm volatile("" : "+v"(tid));     // nothing derived from the thread index stays live across the sweep
     sweep_inverse<KP>(M, K, &logdet, &bad);
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const int e = tid + m * NTF;
@@ -548,49 +565,77 @@ pca_head_fast_kernel(small_args a, double *st)
         if (i < K && j < K) st[L.off_CW + i * KP + j] = M[i * LDM + j];
     }
     if (tid == 0) st[L.off_scal + 0] = logdet;
-    const int w = tid >> 6, l15 = tid & 15, l4 = (tid & 63) >> 4;
-    constexpr int KT = KP / 16;
-    // <w_d> = <tau> Cov_W Syx[d]  (gaussian.py:694): (Dc x KP) = (Dc x KP)(KP x KP) on the
-    // matrix cores, written back over the Syx rows once every tile has been computed
-    // (64 rows per round: rows are only rewritten after every tile that reads them is done)
-    for (int r0 = 0; r0 < Dc; r0 += 64) {
-        constexpr int MAXT = 4 * KT / 4;
-        const int nrt = (Dc - r0) < 64 ? (Dc - r0) / 16 : 4;
-        const int ntile = nrt * KT;
-        v4f64 acc[MAXT];
+    int w = tid >> 6, l15 = tid & 15, l4 = (tid & 63) >> 4;
+    // <w_d> = <tau> Cov_W Syx[d]  (gaussian.py:694), one 32-row block at a time on the matrix cores;
+    // Sww = D Cov_W + W^T W  (gaussian.py:695) accumulated over the blocks
+    // rows of sum y<x>^T: one batch of loads, issued only now so that they do not occupy registers
+    // during the sweep (the kernel must stay within ~90 VGPRs to be placed beside the plate pass)
+    double v[NB][NLB];
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const int tile = w + 4 * t;
-            if (tile < ntile)
-                acc[t] = wave_tile_mma(SW + (r0 + (tile / KT) * 16) * LDM, LDM, 1,
-                                       M + (tile % KT) * 16, LDM, 1, KP);
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int m = 0; m < NLB; ++m) {
+            const int e = tid + m * NTF;
+            const int r = b * RB + e / KP, k = e % KP;
+            v[b][m] = (r < D && k < K) ? st[L.off_S + r * KP + k] : 0.0;
         }
-        __syncthreads();
+    v4f64 wt[WT];
+    v4f64 sacc[ST];
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const int tile = w + 4 * t;
-            if (tile < ntile) {
+    for (int t = 0; t < ST; ++t) sacc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = r0 + (tile / KT) * 16 + l4 + 4 * r, k = (tile % KT) * 16 + l15;
-                    const double v = tau * acc[t][r];
-                    SW[row * LDM + k] = v;
-                    if (row < D && k < K) st[L.off_W + row * KP + k] = v;
+    for (int b = 0; b < NB; ++b) {
+        if (b < nb) {
+#pragma unroll
+            for (int m = 0; m < NLB; ++m) {
+                const int e = tid + m * NTF;
+                SWb[(e / KP) * LDM + (e % KP)] = v[b][m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                const int tile = w + 4 * t;
+                if (tile < TPB)
+                    wt[t] = wave_tile_mma(SWb + (tile / KT) * 16 * LDM, LDM, 1,
+                                             M + (tile % KT) * 16, LDM, 1, KP);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                const int tile = w + 4 * t;
+                if (tile < TPB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lr = (tile / KT) * 16 + l4 + 4 * r, k = (tile % KT) * 16 + l15;
+                        const double x = tau * wt[t][r];
+                        SWb[lr * LDM + k] = x;
+                        const int row = b * RB + lr;
+                        if (row < D && k < K) st[L.off_W + row * KP + k] = x;
+                    }
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                const int tile = w + 4 * t;
+                if (tile < KT * KT)
+                    sacc[t] = wave_tile_mma_acc(sacc[t], SWb + (tile / KT) * 16, 1, LDM,
+                                                SWb + (tile % KT) * 16, LDM, 1, RB);
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
-    // Sww = D Cov_W + W^T W  (gaussian.py:695)
-    for (int tile = w; tile < KT * KT; tile += 4) {
-        const int ti = tile / KT, tj = tile % KT;
-        const v4f64 acc = wave_tile_mma(SW + ti * 16, 1, LDM, SW + tj * 16, LDM, 1, Dc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = ti * 16 + l4 + 4 * r, j = tj * 16 + l15;
-            const double sww = (double)D * M[i * LDM + j] + acc[r];
-            T[i * LDM + j] = sww;
-            if (i < K && j < K) st[L.off_Sww + i * KP + j] = sww;
+    for (int t = 0; t < ST; ++t) {
+        const int tile = w + 4 * t;
+        if (tile < KT * KT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = (tile / KT) * 16 + l4 + 4 * r, j = (tile % KT) * 16 + l15;
+                const double sww = (double)D * M[i * LDM + j] + sacc[t][r];
+                T[i * LDM + j] = sww;
+                if (i < K && j < K) st[L.off_Sww + i * KP + j] = sww;
+            }
         }
     }
     __syncthreads();
@@ -599,28 +644,59 @@ pca_head_fast_kernel(small_args a, double *st)
     for (int m = 0; m < E; ++m) {
         const int e = tid + m * NTF;
         const int i = e / KP, j = e % KP;
-        double v = (i == j) ? 1.0 : 0.0;
+        double x = (i == j) ? 1.0 : 0.0;
         if (i < K && j < K) {
-            v = tau * 0.5 * (T[i * LDM + j] + T[j * LDM + i]);
-            if (i == j) v += a.x_prec;
+            x = tau * 0.5 * (T[i * LDM + j] + T[j * LDM + i]);
+            if (i == j) x += a.x_prec;
         }
-        M[i * LDM + j] = v;
+        M[i * LDM + j] = x;
     }
+    asm volatile("" : "+v"(tid));
     sweep_inverse<KP>(M, K, &logdet, &bad);
+    asm volatile("" : "+v"(tid));
+    w = tid >> 6, l15 = tid & 15, l4 = (tid & 63) >> 4;
 #pragma unroll
     for (int m = 0; m < E; ++m) {
         const int e = tid + m * NTF;
         const int i = e / KP, j = e % KP;
         if (i < K && j < K) st[L.off_CX + i * KP + j] = M[i * LDM + j];
     }
-    // A = <tau> Cov_X W^T : (KP x Dc) = (KP x KP)(KP x Dc)
-    for (int tile = w; tile < KT * (Dc / 16); tile += 4) {
-        const int tk = tile % KT, td = tile / KT;
-        const v4f64 acc = wave_tile_mma(M + tk * 16 * LDM, LDM, 1, SW + td * 16 * LDM, 1, LDM, KP);
+    // A = <tau> Cov_X W^T : per row block (KP x 32) = (KP x KP)(KP x 32); the rows of <W> come back
+    // from global memory (written above by this workgroup, ordered by the barriers since; these
+    // addresses were not read before, so no stale line can be hit)
+    double wv[NB][NLB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = tk * 16 + l4 + 4 * r, d = td * 16 + l15;
-            if (k < K && d < D) st[L.off_A + k * DP + d] = tau * acc[r];
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int m = 0; m < NLB; ++m) {
+            const int e = tid + m * NTF;
+            const int r = b * RB + e / KP, k = e % KP;
+            wv[b][m] = (r < D && k < K) ? st[L.off_W + r * KP + k] : 0.0;
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b < nb) {
+#pragma unroll
+            for (int m = 0; m < NLB; ++m) {
+                const int e = tid + m * NTF;
+                SWb[(e / KP) * LDM + (e % KP)] = wv[b][m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                const int tile = w + 4 * t;
+                if (tile < TPB) {
+                    const int tk = tile % KT, td = tile / KT;
+                    const v4f64 acc = wave_tile_mma(M + tk * 16 * LDM, LDM, 1, SWb + td * 16 * LDM, 1,
+                                                    LDM, KP);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = tk * 16 + l4 + 4 * r, d = b * RB + td * 16 + l15;
+                        if (k < K && d < D) st[L.off_A + k * DP + d] = tau * acc[r];
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
     if (tid == 0) {
