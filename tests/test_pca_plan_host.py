@@ -358,3 +358,21 @@ def test_logging_switch_and_per_node_traces(golden_dir, caplog):
     traces = Q.get_iteration_by_nodes()
     assert traces is Q.l and set(traces) >= {Q['W'], Q['X'], Q['tau'], Q['alpha'], Q['Y']}
     np.testing.assert_allclose(sum(traces[n][:2] for n in traces), Q.L[:2], rtol=1e-12)
+
+
+def test_checkpoint_keeps_point_mass_states(golden_dir, tmp_path):
+    """A model saved while X is still the point mass of initialize_from_value reports -inf after
+    load as well (the reference stores g = inf with the node, vmp.py:237-285)."""
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.update(Q['W'], repeat=1, verbose=False)
+    assert Q.compute_lowerbound() == -np.inf
+    fn = str(tmp_path / 'delta.bin')
+    Q.save(filename=fn)
+    Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q2.load(filename=fn)
+    assert Q2.compute_lowerbound() == -np.inf
+    Q2.update(Q2['X'], repeat=1, verbose=False)
+    Q.update(Q['X'], repeat=1, verbose=False)
+    assert np.isfinite(Q2.compute_lowerbound())
+    assert Q2.compute_lowerbound() == Q.compute_lowerbound()
