@@ -1027,3 +1027,105 @@ def run_order_probes(nodes_mod, vb_cls, g, **vb_kwargs):
     res['lssm_L'] = np.array(_run_sequence(Q, LSSM_PROBE_SEQ, []))
     res['lssm_X_u0'], res['lssm_A_u0'] = np.array(X.u[0]), np.array(A.u[0])
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# Hyperparameter probes (tests/golden/hyper_probes.npz): the four fused model families with
+# priors, prior means / precisions and fixed parameters away from the demos' defaults -- every
+# constant a fused block reads from its nodes' parents.
+# ---------------------------------------------------------------------------------------------
+def make_hyper_probe_inputs(rs):
+    g = {}
+    D, N, K = 7, 60, 3
+    g['pca_y'] = rs.normal(size=(D, K)) @ rs.normal(size=(K, N)) + 0.3 * rs.normal(size=(D, N))
+    g['pca_x0'] = rs.normal(size=(N, K))
+    g['pca_mask'] = rs.rand(D, N) < 0.75
+    g['gmm_y'] = np.concatenate([rs.normal(size=(40, 3)), rs.normal(size=(30, 3)) * 0.5 + 3])
+    g['gmm_lab0'] = rs.randint(3, size=70)
+    a = rs.normal(size=(3, 3))
+    g['gmm_V0'] = a @ a.T + 3 * np.identity(3)
+    M, B, T, Dx = 3, 5, 10, 2
+    g['lssm_y'] = rs.normal(size=(M, B, T))
+    g['lssm_x0'] = rs.normal(size=(B, T, Dx))
+    g['lssm_c0'] = rs.normal(size=(M, 1, 1, Dx))
+    g['lssm_a0'] = 0.5 * np.identity(Dx) + 0.1 * rs.normal(size=(Dx, Dx))
+    b = rs.normal(size=(Dx, Dx))
+    g['lssm_Lam0'] = b @ b.T + np.identity(Dx)
+    return g
+
+
+def _pca_with_priors(N_, vb_cls, y, x0, mask, **vb_kwargs):
+    D, N = y.shape
+    K = x0.shape[1]
+    alpha = N_.Gamma(0.5, 2.0, plates=(K,), name='alpha')
+    W = N_.GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = N_.GaussianARD(0, 2.5, shape=(K,), plates=(1, N), name='X')
+    F = N_.SumMultiply('i,i', W, X, name='F')
+    tau = N_.Gamma(3.0, 0.1, name='tau')
+    Y = N_.GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(np.asarray(x0)[None, :, :])
+    if mask is None:
+        Y.observe(y)
+    else:
+        Y.observe(np.where(mask, y, np.nan), mask=mask)
+    Q = vb_cls(Y, F, W, X, tau, alpha, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    return Q
+
+
+def run_hyper_probes(nodes_mod, vb_cls, g, **vb_kwargs):
+    N_ = nodes_mod
+    res = {}
+    for tag, mask in (('pca', None), ('mpca', g['pca_mask'])):
+        Q = _pca_with_priors(N_, vb_cls, g['pca_y'], g['pca_x0'], mask, **vb_kwargs)
+        Q.update(repeat=5, verbose=False)
+        res[tag + '_L'] = np.array(Q.L[:5])
+        res[tag + '_W_u0'], res[tag + '_X_u0'] = np.array(Q['W'].u[0]), np.array(Q['X'].u[0])
+        res[tag + '_tau_u0'], res[tag + '_alpha_u0'] = np.array(Q['tau'].u[0]), np.array(Q['alpha'].u[0])
+    # mixture: non-uniform Dirichlet, prior precision of the means, Wishart degrees and scale
+    y, lab0 = g['gmm_y'], g['gmm_lab0']
+    N, D = y.shape
+    K = 3
+    alpha = N_.Dirichlet(np.array([0.5, 2.0, 1.0]), name='alpha')
+    z = N_.Categorical(alpha, plates=(N,), name='z')
+    mu = N_.GaussianARD(0, 0.3, shape=(D,), plates=(K,), name='mu')
+    Lam = N_.Wishart(D + 2.5, g['gmm_V0'], plates=(K,), name='Lambda')
+    Y = N_.Mixture(z, N_.Gaussian, mu, Lam, plates=(N,), name='Y')
+    z.initialize_from_value(lab0)
+    Y.observe(y)
+    Q = vb_cls(Y, mu, Lam, z, alpha, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=5, verbose=False)
+    res['gmm_L'] = np.array(Q.L[:5])
+    res['gmm_z_u0'], res['gmm_mu_u0'] = np.array(z.u[0]), np.array(mu.u[0])
+    res['gmm_Lambda_u0'], res['gmm_alpha_u0'] = np.array(Lam.u[0]), np.array(alpha.u[0])
+    # state-space model: prior mean / precision of the first state, fixed and Gamma innovation
+    # precisions away from one, three different Gamma priors
+    y, x0, c0 = g['lssm_y'], g['lssm_x0'], g['lssm_c0']
+    M, B, T = y.shape
+    Dx = x0.shape[-1]
+    for tag, gamma_nu in (('lssm', False), ('lssmnu', True)):
+        al = N_.Gamma(0.5, 0.5, plates=(Dx,), name='alpha')
+        A = N_.GaussianARD(0, al, shape=(Dx,), plates=(Dx,), name='A')
+        A.initialize_from_value(g['lssm_a0'])
+        nu = N_.Gamma(2.0, 3.0, plates=(Dx,), name='nu') if gamma_nu else np.array([2.0, 0.5])
+        X = N_.GaussianMarkovChain(np.array([1.0, -1.0]), g['lssm_Lam0'], A, nu, n=T, plates=(B,),
+                                   name='X')
+        X.initialize_from_value(x0)
+        gamma = N_.Gamma(2.0, 1.0, plates=(Dx,), name='gamma')
+        gamma.initialize_from_value(0.5 * np.ones(Dx))
+        C = N_.GaussianARD(0, gamma, shape=(Dx,), plates=(M, 1, 1), name='C')
+        C.initialize_from_value(c0)
+        tau = N_.Gamma(1.5, 0.2, name='tau')
+        tau.initialize_from_value(3.0)
+        F = N_.SumMultiply('i,i', C, X, name='F')
+        Yl = N_.GaussianARD(F, tau, name='Y')
+        Yl.observe(y)
+        nodes_ = [Yl, F, C, gamma, X, A, al, tau] + ([nu] if gamma_nu else [])
+        Q = vb_cls(*nodes_, **vb_kwargs)
+        Q.ignore_bound_checks = True
+        Q.update(repeat=5, verbose=False)
+        res[tag + '_L'] = np.array(Q.L[:5])
+        res[tag + '_X_u0'], res[tag + '_A_u0'] = np.array(X.u[0]), np.array(A.u[0])
+        res[tag + '_C_u0'], res[tag + '_tau_u0'] = np.array(C.u[0]), np.array(tau.u[0])
+    return res
