@@ -297,6 +297,12 @@ class PCAPlan:
     def invalidate(self, node):
         """Data or initial value of ``node`` changed: rebuild device state lazily."""
         self.finish()
+        if node is self.Y and self._ready and self._version > 1 and self.Y._mask is True \
+                and self.unsupported_state(self.roles) is None \
+                and self.stats == getattr(self, '_stats_built', self.stats):
+            self._reobserve()
+            self._version += 1
+            return
         _delta.warn_state_discarded(self, node)
         self._ready = False
         self._version += 1
@@ -313,6 +319,56 @@ class PCAPlan:
                 GenericPlan(self.nodes())
 
     # -- device state --------------------------------------------------------------------
+    def _upload_y(self):
+        """Y: (D, ldy), plate contiguous, 16-byte aligned rows; resident tensors of that form are
+        used in place."""
+        rt = self.rt
+        torch = rt.torch
+        D, N = self.D, self.N
+        y = self.Y._data
+        if isinstance(y, torch.Tensor) and y.device == rt.device and y.dtype == torch.float64 \
+                and tuple(y.shape) == (D, N) and y.stride(1) == 1 and y.stride(0) % 2 == 0 \
+                and y.data_ptr() % 16 == 0 and N > 0:
+            self.Yd, self.ldy = y, y.stride(0)
+        else:
+            # whole 32-column tiles: no ragged-tail launch.  (An empty local plate -- a rank of a
+            # sharded run without any observation -- keeps one tile of padding: valid pointers.)
+            ldy = max(32, (N + 31) // 32 * 32)
+            self.Yd = rt.zeros(D, ldy)
+            if isinstance(y, torch.Tensor):
+                src = y
+            else:
+                ya = np.asarray(y, dtype=np.float64)
+                if ya.shape != (D, N) or not ya.flags.c_contiguous or not ya.flags.writeable:
+                    ya = np.array(np.broadcast_to(ya, (D, N)), dtype=np.float64, order='C')
+                src = torch.from_numpy(ya)
+            self.Yd[:, :N].copy_(src)
+            self.ldy = ldy
+        self.Yt = None
+
+    def _data_statistics(self):
+        """sum y^2 and (Gram form) G = Y Y^T of the current data, summed over the ranks."""
+        k, L = self.kernels, self.layout
+        D, N, K = self.D, self.N, self.K
+        k.syy(self.Yd, self.ldy, N, D, K, self.state, self.ws)
+        self._reduce(self.state[L.off_Syy:L.off_Syy + 1])
+        if self.stats == 'gram':
+            k.gram(self.Yd, self.ldy, N, D, K, self.state, self.ws)
+            DP = int(L.DP)
+            self._reduce(self.state[L.off_G:L.off_G + DP * DP])
+
+    def _reobserve(self):
+        """Y.observe(new data) AFTER updates: like in the reference only Y changes (stochastic.py:
+        223-273) -- q(W), q(X), q(tau), q(alpha) stay, and the messages from Y are those of the NEW
+        data with the CURRENT <x>: sum y^2, G and S = [sum y<x>^T ; sum <x><x>^T] are recomputed."""
+        self.rt.sync_stream()
+        k, L = self.kernels, self.layout
+        self._upload_y()
+        self._data_statistics()
+        k.stats_from_x(self.Yd, self.ldy, self.N, self.D, self.K, self.Xd, self.ldx, self.state,
+                       self.ws)
+        self._reduce(self.state[L.off_S:L.off_S + L.len_S])
+
     def _materialize(self):
         if self._ready:
             return
@@ -335,41 +391,17 @@ class PCAPlan:
         self.sharded = any(getattr(n, '_shard_axis', None) is not None
                            for n in (self.X, self.F, self.Y))
         self.n_total = rt.all_reduce_int(N) if self.sharded else N
-        # ---- Y: (D, ldy), plate contiguous, 16-byte aligned rows -----------------------
-        y = self.Y._data
-        if isinstance(y, torch.Tensor) and y.device == rt.device and y.dtype == torch.float64 \
-                and tuple(y.shape) == (D, N) and y.stride(1) == 1 and y.stride(0) % 2 == 0 \
-                and y.data_ptr() % 16 == 0 and N > 0:
-            self.Yd, self.ldy = y, y.stride(0)
-        else:
-            # whole 32-column tiles: no ragged-tail launch.  (An empty local plate -- a rank of a
-            # sharded run without any observation -- keeps one tile of padding: valid pointers.)
-            ldy = max(32, (N + 31) // 32 * 32)
-            self.Yd = rt.zeros(D, ldy)
-            if isinstance(y, torch.Tensor):
-                src = y
-            else:
-                ya = np.asarray(y, dtype=np.float64)
-                if ya.shape != (D, N) or not ya.flags.c_contiguous or not ya.flags.writeable:
-                    ya = np.array(np.broadcast_to(ya, (D, N)), dtype=np.float64, order='C')
-                src = torch.from_numpy(ya)
-            self.Yd[:, :N].copy_(src)
-            self.ldy = ldy
+        self._upload_y()
         self.ldx = max(32, (N + 31) // 32 * 32)
         self.state = rt.zeros(int(L.total))
         self._scal_host = None
         self.ws = rt.empty(int(k.workspace_doubles(D, K)))
         k.init_state(D, K, self.a0t, self.b0t, self.a0a, self.b0a, self.state)
-        k.syy(self.Yd, self.ldy, N, D, K, self.state, self.ws)
-        self._reduce(self.state[L.off_Syy:L.off_Syy + 1])
-        if self.stats == 'gram':
-            k.gram(self.Yd, self.ldy, N, D, K, self.state, self.ws)
-            DP = int(L.DP)
-            self._reduce(self.state[L.off_G:L.off_G + DP * DP])
+        self._stats_built = self.stats
+        self._data_statistics()
         # ---- X: delta moments (initialize_from_value/random) or the prior --------------
         init = self.X._init
         KPx = int(L.KP)       # pad rows: the tile-major pass writes whole 16-row blocks of <x>
-        self.Yt = None
         if init is None:
             self.Xd = rt.zeros(KPx, self.ldx)
             self._set_block(L.off_CX, np.eye(K) / self.x_prec)

@@ -1129,3 +1129,27 @@ def run_hyper_probes(nodes_mod, vb_cls, g, **vb_kwargs):
         res[tag + '_X_u0'], res[tag + '_A_u0'] = np.array(X.u[0]), np.array(A.u[0])
         res[tag + '_C_u0'], res[tag + '_tau_u0'] = np.array(C.u[0]), np.array(tau.u[0])
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# Re-observing data after updates (tests/golden/reobserve.npz): only Y changes, every posterior
+# stays (stochastic.py:223-273); the next messages combine the new data with the current <x>.
+# ---------------------------------------------------------------------------------------------
+def make_reobserve_inputs(rs):
+    D, N, K = 6, 80, 3
+    w = rs.normal(size=(D, K))
+    return dict(y1=w @ rs.normal(size=(K, N)) + 0.2 * rs.normal(size=(D, N)),
+                y2=w @ rs.normal(size=(K, N)) + 0.2 * rs.normal(size=(D, N)),
+                x0=rs.normal(size=(N, K)))
+
+
+def run_reobserve_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    Q = build_pca(nodes_mod, vb_cls, g['y1'], g['x0'], g['x0'].shape[1], **vb_kwargs)
+    Q.update(repeat=3, verbose=False)
+    Q['Y'].observe(g['y2'])
+    L_mid = float(Q.compute_lowerbound())
+    Q.update(Q['W'], repeat=1, verbose=False)
+    L_w = float(Q.compute_lowerbound())
+    Q.update(repeat=2, verbose=False)
+    return dict(L=np.array(Q.L[:Q.iter]), L_mid=L_mid, L_w=L_w, W_u0=np.array(Q['W'].u[0]),
+                X_u0=np.array(Q['X'].u[0]), tau_u0=np.array(Q['tau'].u[0]))

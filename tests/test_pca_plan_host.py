@@ -326,8 +326,9 @@ def test_node_state_access_on_the_fused_block(golden_dir):
 
 def test_bound_of_point_mass_states_and_warning_on_a_restart(golden_dir):
     """initialize_from_value leaves a point mass: the bound is -inf until that node is updated
-    (expfamily.py:193-212, :433-447).  Re-observing after updates restarts the fused block from the
-    nodes' initial values -- unlike the reference, hence a loud warning."""
+    (expfamily.py:193-212, :433-447).  Re-initialising a node after updates restarts the fused block from the
+    nodes' initial values -- unlike the reference, hence a loud warning (re-observing Y keeps the
+    posteriors: test_reobserving_data_keeps_the_posteriors)."""
     import warnings
     g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
@@ -343,7 +344,7 @@ def test_bound_of_point_mass_states_and_warning_on_a_restart(golden_dir):
         Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
         Q2['Y'].observe(g['y'])               # nothing learned yet: silent
     with pytest.warns(RuntimeWarning, match='restarts from the initial state'):
-        Q['Y'].observe(g['y'] + 1.0)
+        Q['X'].initialize_from_value(g['x0'][None])     # re-initialising a latent node does restart
 
 
 def test_logging_switch_and_per_node_traces(golden_dir, caplog):
@@ -376,3 +377,27 @@ def test_checkpoint_keeps_point_mass_states(golden_dir, tmp_path):
     Q.update(Q['X'], repeat=1, verbose=False)
     assert np.isfinite(Q2.compute_lowerbound())
     assert Q2.compute_lowerbound() == Q.compute_lowerbound()
+
+
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+def test_reobserving_data_keeps_the_posteriors(golden_dir, stats):
+    """Y.observe(new data) after updates changes Y only (stochastic.py:223-273): the fused PCA block
+    keeps q(W), q(X), q(tau), q(alpha) and recomputes the messages of the new data with the current
+    <x> -- live-reference trace tests/golden/reobserve.npz; no restart, no warning."""
+    import warnings
+    from models import run_reobserve_case
+    g = np.load(os.path.join(golden_dir, 'reobserve.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+
+    class CPUVB(VB):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            _attach_cpu(self, stats)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        res = run_reobserve_case(nodes, CPUVB, inp)
+    np.testing.assert_allclose(res['L'], g['L'], rtol=1e-10)
+    np.testing.assert_allclose(res['L_mid'], g['L_mid'], rtol=1e-10)
+    np.testing.assert_allclose(res['L_w'], g['L_w'], rtol=1e-10)
+    np.testing.assert_allclose(res['W_u0'], g['W_u0'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(res['X_u0'], g['X_u0'], rtol=1e-8, atol=1e-10)
