@@ -254,6 +254,11 @@ class LSSMPlan:
         return bool(self._ready)
 
     def invalidate(self, node):
+        if node is self.Y and self._ready and self._version > 1 and self.Y._mask is True \
+                and self.unsupported_state(self.roles) is None:
+            self._reobserve()
+            self._version += 1
+            return
         _delta.warn_state_discarded(self, node)
         self._ready = False
         self._version += 1
@@ -336,18 +341,8 @@ class LSSMPlan:
         st[L.off_Am:L.off_Am + D * D] = am.reshape(-1)
         st[L.off_AA:L.off_AA + D * D * D] = aa.reshape(-1)
         self.state = torch.from_numpy(st).to(rt.device)
-        # ---- data: (M, [B,] T) -> time-major Yt, sum y^2 ------------------------------------------------
-        y = self.Y._data
-        if isinstance(y, torch.Tensor):
-            yd = y.to(device=rt.device, dtype=torch.float64).reshape(M, B, T).contiguous()
-        else:
-            yd = torch.from_numpy(np.array(np.broadcast_to(np.asarray(y, dtype=np.float64),
-                                                           self.Y.plates).reshape(M, B, T),
-                                           order='C')).to(rt.device)
         self.Yt = rt.empty(T * M * BL)
-        k.relayout_y(yd, M, B, T, BL, self.Yt, self.state[L.off_scal:L.off_scal + 1], self.ws)
-        del yd
-        self._reduce(self.state[L.off_scal:L.off_scal + 1])
+        self._upload_y()
         self.Z = rt.zeros(T * D * BL)
         self.Sinv = rt.zeros(T * D * D)
         self.J = rt.zeros(max(T - 1, 1) * D * D)
@@ -378,16 +373,43 @@ class LSSMPlan:
         self._ready = True
         self._version += 1
 
+    def _upload_y(self):
+        """data: (M, [B,] T) -> time-major Yt, sum y^2 (summed over the ranks)."""
+        rt, k, L = self.rt, self.kernels, self.layout
+        torch = rt.torch
+        M, B, T = self.M, self.B, self.T
+        y = self.Y._data
+        if isinstance(y, torch.Tensor):
+            yd = y.to(device=rt.device, dtype=torch.float64).reshape(M, B, T).contiguous()
+        else:
+            yd = torch.from_numpy(np.array(np.broadcast_to(np.asarray(y, dtype=np.float64),
+                                                           self.Y.plates).reshape(M, B, T),
+                                           order='C')).to(rt.device)
+        k.relayout_y(yd, M, B, T, self.BL, self.Yt, self.state[L.off_scal:L.off_scal + 1], self.ws)
+        del yd
+        self._reduce(self.state[L.off_scal:L.off_scal + 1])
+
+    def _reobserve(self):
+        """Y.observe(new data) AFTER updates: only Y changes (stochastic.py:223-273).  q(X) and every
+        other posterior stay; the plate sums that involve the data (sum y^2, sum y<x>^T) are taken
+        again from the new data and the current <x> (the statistics pass in its "given <x>" form;
+        the covariance sums of q(X) are kept)."""
+        self._flush()
+        self.rt.sync_stream()
+        self._upload_y()
+        self._smooth(given=True, keep_cov=self._x_updated)
+
     def _reduce(self, view):
         if self.sharded:
             self.rt.all_reduce_sum_(view)
 
-    def _smooth(self, given):
+    def _smooth(self, given, keep_cov=False):
         k, L = self.kernels, self.layout
         D, M, B, T = self.D, self.M, self.B, self.T
         st = self.state
         if given:
-            st[L.off_covsums:L.off_covsums + 5 * D * D + 4].zero_()
+            if not keep_cov:
+                st[L.off_covsums:L.off_covsums + 5 * D * D + 4].zero_()
             k.smooth(True, self.Yt, M, B, T, self.BL, D, st[L.off_Cm:], st[L.off_scal + 3:],
                      st[L.off_h0:], self.Sinv, self.J, self.Z, st[L.off_raw:], self.ws)
         else:

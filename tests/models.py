@@ -1138,9 +1138,13 @@ def run_hyper_probes(nodes_mod, vb_cls, g, **vb_kwargs):
 def make_reobserve_inputs(rs):
     D, N, K = 6, 80, 3
     w = rs.normal(size=(D, K))
-    return dict(y1=w @ rs.normal(size=(K, N)) + 0.2 * rs.normal(size=(D, N)),
-                y2=w @ rs.normal(size=(K, N)) + 0.2 * rs.normal(size=(D, N)),
-                x0=rs.normal(size=(N, K)))
+    g = dict(y1=w @ rs.normal(size=(K, N)) + 0.2 * rs.normal(size=(D, N)),
+             y2=w @ rs.normal(size=(K, N)) + 0.2 * rs.normal(size=(D, N)),
+             x0=rs.normal(size=(N, K)))
+    M, B, T, Dx = 3, 4, 9, 2
+    g['lssm_y1'], g['lssm_y2'] = rs.normal(size=(M, B, T)), rs.normal(size=(M, B, T)) + 0.5
+    g['lssm_x0'], g['lssm_c0'] = rs.normal(size=(B, T, Dx)), rs.normal(size=(M, 1, 1, Dx))
+    return g
 
 
 def run_reobserve_case(nodes_mod, vb_cls, g, **vb_kwargs):
@@ -1153,3 +1157,37 @@ def run_reobserve_case(nodes_mod, vb_cls, g, **vb_kwargs):
     Q.update(repeat=2, verbose=False)
     return dict(L=np.array(Q.L[:Q.iter]), L_mid=L_mid, L_w=L_w, W_u0=np.array(Q['W'].u[0]),
                 X_u0=np.array(Q['X'].u[0]), tau_u0=np.array(Q['tau'].u[0]))
+
+
+def run_reobserve_lssm_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """The same for the linear state-space model: new observations, q(X) and every other posterior
+    kept; the messages to C and tau combine the new data with the current <x>."""
+    N_ = nodes_mod
+    y, x0, c0 = g['lssm_y1'], g['lssm_x0'], g['lssm_c0']
+    M, B, T = y.shape
+    Dx = x0.shape[-1]
+    al = N_.Gamma(1e-5, 1e-5, plates=(Dx,), name='alpha')
+    A = N_.GaussianARD(0, al, shape=(Dx,), plates=(Dx,), name='A')
+    A.initialize_from_value(np.identity(Dx))
+    X = N_.GaussianMarkovChain(np.zeros(Dx), 1e-3 * np.identity(Dx), A, np.ones(Dx), n=T,
+                               plates=(B,), name='X')
+    X.initialize_from_value(x0)
+    gamma = N_.Gamma(1e-5, 1e-5, plates=(Dx,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(Dx))
+    C = N_.GaussianARD(0, gamma, shape=(Dx,), plates=(M, 1, 1), name='C')
+    C.initialize_from_value(c0)
+    tau = N_.Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = N_.SumMultiply('i,i', C, X, name='F')
+    Y = N_.GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    Q = vb_cls(Y, F, C, gamma, X, A, al, tau, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=3, verbose=False)
+    Y.observe(g['lssm_y2'])
+    L_mid = float(Q.compute_lowerbound())
+    Q.update(C, tau, repeat=1, verbose=False)
+    L_c = float(Q.compute_lowerbound())
+    Q.update(repeat=2, verbose=False)
+    return dict(lssm_L=np.array(Q.L[:Q.iter]), lssm_L_mid=L_mid, lssm_L_c=L_c,
+                lssm_X_u0=np.array(X.u[0]), lssm_C_u0=np.array(C.u[0]), lssm_A_u0=np.array(A.u[0]))

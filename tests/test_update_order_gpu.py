@@ -63,3 +63,31 @@ def test_reobserving_data_keeps_the_posteriors(golden_dir, engine, monkeypatch):
     np.testing.assert_allclose(res['L_w'], g['L_w'], rtol=1e-9)
     np.testing.assert_allclose(res['W_u0'], g['W_u0'], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(res['X_u0'], g['X_u0'], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize('engine', ['fused', 'generic'])
+def test_reobserving_data_of_the_state_space_model(golden_dir, engine):
+    """The same for the fused state-space block: new observations, q(X) and every other posterior kept
+    (tests/golden/reobserve.npz, lssm_* entries)."""
+    import warnings
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import run_reobserve_lssm_case
+    g = np.load(os.path.join(golden_dir, 'reobserve.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+    seen = []
+
+    class Spy(VB):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            seen.append(type(self.plans[0]).__name__)
+    kw = {'engine': 'generic'} if engine == 'generic' else {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        res = run_reobserve_lssm_case(nodes, Spy, inp, **kw)
+    assert seen == (['LSSMPlan'] if engine == 'fused' else ['GenericPlan'])
+    np.testing.assert_allclose(res['lssm_L'], g['lssm_L'], rtol=1e-9)
+    np.testing.assert_allclose(res['lssm_L_mid'], g['lssm_L_mid'], rtol=1e-9)
+    np.testing.assert_allclose(res['lssm_L_c'], g['lssm_L_c'], rtol=1e-9)
+    for key in ('lssm_X_u0', 'lssm_C_u0', 'lssm_A_u0'):
+        np.testing.assert_allclose(res[key], g[key], rtol=1e-7, atol=1e-9, err_msg=key)
