@@ -303,6 +303,12 @@ class PCAPlan:
             self._reobserve()
             self._version += 1
             return
+        if node in (self.X, self.W) and self._ready and self._version > 1 \
+                and node._init is not None and node._init[0] == 'value' \
+                and self.unsupported_state(self.roles) is None:
+            self._reinitialise(node)
+            self._version += 1
+            return
         _delta.warn_state_discarded(self, node)
         self._ready = False
         self._version += 1
@@ -345,6 +351,53 @@ class PCAPlan:
             self.Yd[:, :N].copy_(src)
             self.ldy = ldy
         self.Yt = None
+
+    def _load_x_value(self, x0):
+        """<x> <- a given value, (.., N, K) -> the plate-contiguous (K, N) layout."""
+        rt = self.rt
+        torch = rt.torch
+        N, K = self.N, self.K
+        if isinstance(x0, torch.Tensor) and x0.device == rt.device:
+            self.Xd[:K, :N].copy_(x0.to(torch.float64).expand(self.X.plates + (K,))
+                                  .reshape(N, K).t())
+        else:
+            if isinstance(x0, torch.Tensor):
+                x0 = x0.detach().cpu().numpy()
+            x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
+                                 self.X.plates + (K,)).reshape(N, K)
+            self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
+
+    def _load_w_value(self, w0):
+        """<w_d> <- the rows of a (D, K) host array, Sww = W^T W (delta moments: no covariance)."""
+        L = self.layout
+        D, K, KP = self.D, self.K, int(L.KP)
+        wp = np.zeros((D, KP))
+        wp[:, :K] = w0
+        self.state[L.off_W:L.off_W + D * KP].copy_(self.rt.torch.from_numpy(wp.reshape(-1)))
+        self._set_block(L.off_Sww, w0.T @ w0)
+
+    def _reinitialise(self, node):
+        """initialize_from_value on X or W AFTER updates: that node becomes the point mass of the
+        value, every other posterior stays (expfamily.py:193-204)."""
+        self.rt.sync_stream()
+        L = self.layout
+        K = self.K
+        if node is self.X:
+            self._load_x_value(node._init[1])
+            self._set_block(L.off_CX, np.zeros((K, K)))
+            self.kernels.stats_from_x(self.Yd, self.ldy, self.N, self.D, K, self.Xd, self.ldx,
+                                      self.state, self.ws)
+            self._reduce(self.state[L.off_S:L.off_S + L.len_S])
+            self._delta.add('X')
+        else:
+            w0 = node._init[1]
+            if isinstance(w0, self.rt.torch.Tensor):
+                w0 = w0.detach().cpu().numpy()
+            w0 = np.broadcast_to(np.asarray(w0, dtype=np.float64),
+                                 self.W.plates + (K,)).reshape(self.D, K)
+            self._load_w_value(w0)
+            self._set_block(L.off_CW, np.zeros((K, K)))
+            self._delta.add('W')
 
     def _data_statistics(self):
         """sum y^2 and (Gram form) G = Y Y^T of the current data, summed over the ranks."""
@@ -407,19 +460,8 @@ class PCAPlan:
             self._set_block(L.off_CX, np.eye(K) / self.x_prec)
         else:
             if init[0] == 'value':
-                x0 = init[1]
                 self.Xd = rt.zeros(KPx, self.ldx)
-                if isinstance(x0, torch.Tensor) and x0.device == rt.device:
-                    # resident already: (.., N, K) -> the plate-contiguous (K, N) layout
-                    self.Xd[:K, :N].copy_(x0.to(torch.float64).expand(self.X.plates + (K,))
-                                          .reshape(N, K).t())
-                else:
-                    if isinstance(x0, torch.Tensor):
-                        x0 = x0.detach().cpu().numpy()
-                    x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
-                                         self.X.plates + (K,)).reshape(N, K)
-                    self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64,
-                                                                    order='C')))
+                self._load_x_value(init[1])
             else:
                 # a draw from the current q = prior N(0, I/x_prec) (expfamily.py:206-212);
                 # RNG streams are not part of the parity contract
@@ -445,10 +487,7 @@ class PCAPlan:
                                      self.W.plates + (K,)).reshape(D, K)
             else:
                 w0 = np.random.normal(size=(D, K)) * np.sqrt(self.b0a / self.a0a)
-            wp = np.zeros((D, KP))
-            wp[:, :K] = w0
-            self.state[L.off_W:L.off_W + D * KP].copy_(torch.from_numpy(wp.reshape(-1)))
-            self._set_block(L.off_Sww, w0.T @ w0)
+            self._load_w_value(w0)
         self._ready = True
         self._version += 1
 

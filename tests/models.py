@@ -1144,7 +1144,28 @@ def make_reobserve_inputs(rs):
     M, B, T, Dx = 3, 4, 9, 2
     g['lssm_y1'], g['lssm_y2'] = rs.normal(size=(M, B, T)), rs.normal(size=(M, B, T)) + 0.5
     g['lssm_x0'], g['lssm_c0'] = rs.normal(size=(B, T, Dx)), rs.normal(size=(M, 1, 1, Dx))
+    g['x1'], g['w1'] = rs.normal(size=(N, K)), rs.normal(size=(D, 1, K))
     return g
+
+
+def run_reinitialise_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """initialize_from_value on X, later on W, between updates: that node becomes a point mass (its
+    bound term -inf until updated), every other posterior stays (expfamily.py:193-204)."""
+    Q = build_pca(nodes_mod, vb_cls, g['y1'], g['x0'], g['x0'].shape[1], **vb_kwargs)
+    Q.update(repeat=3, verbose=False)
+    Q['X'].initialize_from_value(g['x1'][None])
+    out = [float(Q.compute_lowerbound())]
+    Q.update(Q['W'], Q['tau'], repeat=1, verbose=False)
+    out.append(float(Q.compute_lowerbound()))
+    Q.update(Q['X'], repeat=1, verbose=False)
+    out.append(float(Q.compute_lowerbound()))
+    Q['W'].initialize_from_value(g['w1'])
+    out.append(float(Q.compute_lowerbound()))
+    Q.update(Q['X'], Q['alpha'], repeat=1, verbose=False)
+    out.append(float(Q.compute_lowerbound()))
+    Q.update(repeat=2, verbose=False)
+    return dict(ri_steps=np.array(out), ri_L=np.array(Q.L[:Q.iter]), ri_W_u0=np.array(Q['W'].u[0]),
+                ri_X_u0=np.array(Q['X'].u[0]), ri_alpha_u0=np.array(Q['alpha'].u[0]))
 
 
 def run_reobserve_case(nodes_mod, vb_cls, g, **vb_kwargs):

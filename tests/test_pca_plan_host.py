@@ -326,9 +326,10 @@ def test_node_state_access_on_the_fused_block(golden_dir):
 
 def test_bound_of_point_mass_states_and_warning_on_a_restart(golden_dir):
     """initialize_from_value leaves a point mass: the bound is -inf until that node is updated
-    (expfamily.py:193-212, :433-447).  Re-initialising a node after updates restarts the fused block from the
+    (expfamily.py:193-212, :433-447).  A random re-initialisation after updates restarts the fused block from the
     nodes' initial values -- unlike the reference, hence a loud warning (re-observing Y keeps the
-    posteriors: test_reobserving_data_keeps_the_posteriors)."""
+    posteriors, and so does initialize_from_value: test_reobserving_data_keeps_the_posteriors,
+    test_reinitialising_a_node_keeps_the_other_posteriors)."""
     import warnings
     g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
@@ -344,7 +345,7 @@ def test_bound_of_point_mass_states_and_warning_on_a_restart(golden_dir):
         Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
         Q2['Y'].observe(g['y'])               # nothing learned yet: silent
     with pytest.warns(RuntimeWarning, match='restarts from the initial state'):
-        Q['X'].initialize_from_value(g['x0'][None])     # re-initialising a latent node does restart
+        Q['X'].initialize_from_random()      # a draw from the CURRENT q is not kept by the block: restart
 
 
 def test_logging_switch_and_per_node_traces(golden_dir, caplog):
@@ -401,3 +402,26 @@ def test_reobserving_data_keeps_the_posteriors(golden_dir, stats):
     np.testing.assert_allclose(res['L_w'], g['L_w'], rtol=1e-10)
     np.testing.assert_allclose(res['W_u0'], g['W_u0'], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(res['X_u0'], g['X_u0'], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+def test_reinitialising_a_node_keeps_the_other_posteriors(golden_dir, stats):
+    """initialize_from_value on X, later on W, between updates (expfamily.py:193-204): live-reference
+    trace tests/golden/reobserve.npz (ri_*); the re-initialised node is a point mass (bound -inf)
+    until its next update, nothing else restarts."""
+    import warnings
+    from models import run_reinitialise_case
+    g = np.load(os.path.join(golden_dir, 'reobserve.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+
+    class CPUVB(VB):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            _attach_cpu(self, stats)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        res = run_reinitialise_case(nodes, CPUVB, inp)
+    np.testing.assert_allclose(res['ri_steps'], g['ri_steps'], rtol=1e-10)
+    np.testing.assert_allclose(res['ri_L'], g['ri_L'], rtol=1e-10)
+    np.testing.assert_allclose(res['ri_W_u0'], g['ri_W_u0'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(res['ri_X_u0'], g['ri_X_u0'], rtol=1e-8, atol=1e-10)

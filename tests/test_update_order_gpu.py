@@ -91,3 +91,25 @@ def test_reobserving_data_of_the_state_space_model(golden_dir, engine):
     np.testing.assert_allclose(res['lssm_L_c'], g['lssm_L_c'], rtol=1e-9)
     for key in ('lssm_X_u0', 'lssm_C_u0', 'lssm_A_u0'):
         np.testing.assert_allclose(res[key], g[key], rtol=1e-7, atol=1e-9, err_msg=key)
+
+
+@pytest.mark.parametrize('engine', ['fused', 'fused-stream', 'generic'])
+def test_reinitialising_a_node_keeps_the_other_posteriors(golden_dir, engine, monkeypatch):
+    """initialize_from_value on X, later on W, between updates (expfamily.py:193-204): live-reference
+    trace tests/golden/reobserve.npz (ri_*)."""
+    import warnings
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import run_reinitialise_case
+    g = np.load(os.path.join(golden_dir, 'reobserve.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+    if engine == 'fused-stream':
+        monkeypatch.setenv('BAYESPY_AMD_PCA_STATS', 'stream')
+    kw = {'engine': 'generic'} if engine == 'generic' else {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        res = run_reinitialise_case(nodes, VB, inp, **kw)
+    np.testing.assert_allclose(res['ri_steps'], g['ri_steps'], rtol=1e-9)
+    np.testing.assert_allclose(res['ri_L'], g['ri_L'], rtol=1e-9)
+    for key in ('ri_W_u0', 'ri_X_u0', 'ri_alpha_u0'):
+        np.testing.assert_allclose(res[key], g[key], rtol=1e-7, atol=1e-9, err_msg=key)
