@@ -33,6 +33,8 @@ class Runtime:
         self.lib = None
         self.ctx = None
         self._comm_state = None     # None: not decided; True: the library owns an RCCL communicator
+        self._comm_reason = None    # why the library communicator is not in use, if it is not
+        self.collective_calls = {'library': 0, 'torch': 0}
         self._op_depth = 0
         self._deferred = []
         if self.device.type == 'cuda':
@@ -68,28 +70,38 @@ class Runtime:
         tests, several ranks on one GPU) keep torch's collective."""
         if self._comm_state is not None:
             return self._comm_state
-        self._comm_state = False
         dist = self.torch.distributed
         if self.ctx is None or not (dist.is_available() and dist.is_initialized()):
-            return False
+            return False          # not cached: a later init_process_group still gets RCCL
+        self._comm_state = False
         if dist.get_backend() != 'nccl' or os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'torch':
+            self._comm_reason = 'backend %s' % dist.get_backend()
             return False
         cid = ctypes.create_string_buffer(128)
+        box = [None]
         if self.rank == 0:
-            self.check(self.lib.vmp_comm_unique_id(self.ctx, cid))
-        box = [cid.raw if self.rank == 0 else None]
+            # a failure here (librccl missing, ...) must not strand the other ranks in the
+            # broadcast below: ship a sentinel and let every rank fall back together
+            if self.lib.vmp_comm_unique_id(self.ctx, cid) == 0:
+                box = [cid.raw]
         dist.broadcast_object_list(box, src=0)
-        cid = ctypes.create_string_buffer(box[0], 128)
-        rc = self.lib.vmp_comm_init_rank(self.ctx, cid, self.rank, self.world)
+        rc = -1
+        if box[0] is not None:
+            cid = ctypes.create_string_buffer(box[0], 128)
+            rc = self.lib.vmp_comm_init_rank(self.ctx, cid, self.rank, self.world)
         # every rank must take the same path: agree on the outcome through the rendezvous
         ok = self.torch.tensor([1 if rc == 0 else 0], dtype=self.torch.int32, device=self.device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) != 1:
             import warnings
             msg = self.lib.vmp_last_error(self.ctx)
+            self._comm_reason = msg.decode() if msg else 'a rank failed to join'
+            if os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'library':
+                raise RuntimeError('library RCCL communicator not available (%s) and '
+                                   'BAYESPY_AMD_COLLECTIVE=library forbids the '
+                                   'torch.distributed fallback' % self._comm_reason)
             warnings.warn('library RCCL communicator not available (%s): plate sums go through '
-                          'torch.distributed.all_reduce'
-                          % (msg.decode() if msg else 'a rank failed to join'))
+                          'torch.distributed.all_reduce' % self._comm_reason)
             if rc == 0:
                 self.lib.vmp_comm_destroy(self.ctx)
             return False
@@ -111,12 +123,49 @@ class Runtime:
                 raise TypeError('plate sums are fp64')
             self.sync_stream()
             self.check(self.lib.vmp_allreduce_sum_f64(self.ctx, ptr(buf), buf.numel()))
+            self.collective_calls['library'] += 1
             if buf is not tensor:
                 tensor.copy_(buf)
             return tensor
         if self.world > 1:
+            if os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'library':
+                raise RuntimeError('plate sum would go through torch.distributed.all_reduce (%s) '
+                                   'but BAYESPY_AMD_COLLECTIVE=library forbids that path'
+                                   % (self._comm_reason or 'no library communicator'))
             self.torch.distributed.all_reduce(tensor)
+            self.collective_calls['torch'] += 1
         return tensor
+
+    def comm_info(self):
+        """Which collective the plate sums of this process use and the world it spans:
+        ``path`` = 'vmp_allreduce_sum_f64' (the library's RCCL communicator), 'torch'
+        (torch.distributed.all_reduce: CPU test backend, or the fallback) or 'none' (one rank,
+        no process group); ``world`` as the LIBRARY's communicator reports it
+        (``vmp_comm_info``); ``rccl_loaded`` = librccl is mapped into this process."""
+        self._refresh_dist()
+        lib_world = 1
+        if self.ctx is not None:
+            r, w = ctypes.c_int32(0), ctypes.c_int32(1)
+            self.lib.vmp_comm_info(self.ctx, ctypes.byref(r), ctypes.byref(w))
+            lib_world = int(w.value)
+        dist = self.torch.distributed
+        have_group = dist.is_available() and dist.is_initialized()
+        if have_group and self._ensure_comm():
+            path = 'vmp_allreduce_sum_f64'
+            r, w = ctypes.c_int32(0), ctypes.c_int32(1)
+            self.lib.vmp_comm_info(self.ctx, ctypes.byref(r), ctypes.byref(w))
+            lib_world = int(w.value)
+        elif have_group and self.world > 1:
+            path = 'torch'
+        else:
+            path = 'none'
+        try:
+            rccl = any('librccl' in line for line in open('/proc/self/maps'))
+        except OSError:
+            rccl = None
+        return {'path': path, 'world': lib_world, 'torch_world': self.world,
+                'rccl_loaded': rccl, 'calls': dict(self.collective_calls),
+                'fallback_reason': self._comm_reason if path != 'vmp_allreduce_sum_f64' else None}
 
     def all_reduce_int(self, value):
         self._refresh_dist()

@@ -43,6 +43,7 @@ class HostBatchStream:
         self._ready = queue.Queue(maxsize=self.depth - 1)
         self._free = [threading.Event() for _ in range(self.depth)]
         self._release = [None] * self.depth      # event on the consumer's stream: slot may be reused
+        self._copied = [None] * self.depth       # event of the slot's last host->HBM copy
         for e in self._free:
             e.set()
         self._stop = False
@@ -77,6 +78,12 @@ class HostBatchStream:
                     idx = np.asarray(idx)
                     n = idx.shape[0]
                 host, dev = self._buffers(slot, (n,) + tuple(self.data.shape[1:]))
+                # the slot's previous host->HBM copy reads the pinned buffer asynchronously: a
+                # consumer that never blocks on the host could otherwise let this gather
+                # overwrite the source of a copy that is still queued
+                prev = self._copied[slot]
+                if prev is not None:
+                    prev.synchronize()
                 # gather into pinned memory (the only host work of a step), then an async copy
                 if isinstance(idx, slice):
                     host.numpy()[...] = self.data[idx]
@@ -89,6 +96,7 @@ class HostBatchStream:
                     dev.copy_(host, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(self._copy_stream)
+                self._copied[slot] = done
                 self._ready.put((slot, dev, idx, done))
                 k += 1
         except Exception as e:       # noqa: BLE001 -- surfaces in the consumer

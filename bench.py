@@ -6,6 +6,7 @@ bench.py -- VB iterations/sec of probabilistic PCA (BASELINE.json metric).
     python bench.py --config {gmm,masked,lssm}        # the secondary BASELINE configurations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    ... bench.py --gpus 8 --plates 100000000      # BASELINE config 4: N=1e8 over 8 ranks
 
 One "step" = one full VB iteration exactly as ``VB.update`` does it
 (vmp.py:154-172, :693-764): W, X, tau, alpha updated once in constructor order
@@ -83,41 +84,26 @@ def make_shard(torch, dev, n_local, D, K, seed, rank):
 
 
 def library_build_id():
-    from bayespy_amd import _lib
-    v = _lib.load().vmp_version().decode()
-    return v.split('build ')[-1] if 'build ' in v else None
+    from tools import workloads
+    return workloads.library_build_id()
 
 
 def pmc_traffic(kernel, D, K, n_local):
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary
     (profiles/r*/pmc_*.txt; separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950) -- ONLY if that profile was taken on this very
-    build of the kernels (header line ``# build_id:`` written by tools/collect_profiles.sh ==
-    vmp_version()) and on this workload (``# workload:``); otherwise (None, reason)."""
-    import glob
-    import re
-    bid = library_build_id()
-    want = 'D=%d K=%d n_local=%d' % (D, K, n_local)
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_*.txt')), reverse=True):
-        head = {}
-        vals, cur = {}, None
-        for line in open(path):
-            m = re.match(r'#\s*(build_id|workload):\s*(.+)', line)
-            if m:
-                head[m.group(1)] = m.group(2).strip()
-                continue
-            if not line.startswith(' '):
-                cur = line.strip()
-                continue
-            m = re.match(r'\s+(FETCH_SIZE|WRITE_SIZE)\s+avg\s+([0-9.]+)', line)
-            if m and cur and cur.startswith(kernel):
-                vals[m.group(1)] = float(m.group(2))
-        if head.get('build_id') != bid or head.get('workload') != want:
-            continue
-        if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
-            return 2.0 * vals['FETCH_SIZE'] * 1024 + vals['WRITE_SIZE'] * 1024, \
-                os.path.relpath(path, ROOT)
-    return None, 'no committed PMC profile of build %s for %s' % (bid, want)
+    build of the kernels (header line ``# build_id:`` written by tools/collect_profiles_r03.sh
+    == vmp_version()) and on this workload (``# workload:``); otherwise (None, reason)."""
+    from tools import workloads
+    prof, why = workloads.pmc_profile('D=%d K=%d n_local=%d' % (D, K, n_local))
+    if prof is None:
+        return None, why
+    for name, counters in prof['kernels'].items():
+        if name.startswith(kernel):
+            b = workloads.pmc_bytes(counters)
+            if b is not None:
+                return b, prof['path']
+    return None, 'no %s counters in %s' % (kernel, prof['path'])
 
 
 def cpu_baseline(y_dev, x0_dev, D, K, n_total, L_gpu, Q, sample_n):
@@ -209,7 +195,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # launched by torch.distributed.run (RANK is set) -- also with ONE rank, so that a world-1
+    # run exercises the library's RCCL communicator exactly as the N-rank runs do
+    launched = 'RANK' in os.environ and 'MASTER_PORT' in os.environ
+    if world > 1 or launched:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         ndev = torch.cuda.device_count()
@@ -218,6 +207,10 @@ def main():
         # path with several ranks on a one-GPU box (RCCL refuses two ranks on one device).
         backend = os.environ.get('VMP_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
+            # the plate sums of a benchmarked run must be the library's own RCCL all-reduce
+            # (vmp_allreduce_sum_f64): a fallback to torch.distributed.all_reduce is an ERROR
+            # here, not a warning (bayespy_amd/device.py)
+            os.environ.setdefault('BAYESPY_AMD_COLLECTIVE', 'library')
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ndev))
         else:
             dist.init_process_group(backend)
@@ -240,12 +233,17 @@ def main():
             out = workloads.run_gmm(steps=args.steps, warmup=args.warmup,
                                     cpu_baseline=not args.no_cpu_baseline)
         elif args.config == 'masked':
-            out = workloads.run_masked(steps=min(args.steps, 5), warmup=min(args.warmup, 1))
+            out = workloads.run_masked(steps=min(args.steps, 5), warmup=min(args.warmup, 1),
+                                       cpu_baseline=not args.no_cpu_baseline)
         else:
-            out = workloads.run_lssm(steps=min(args.steps, 5), warmup=min(args.warmup, 1))
+            out = workloads.run_lssm(steps=min(args.steps, 5), warmup=min(args.warmup, 1),
+                                     cpu_baseline=not args.no_cpu_baseline)
         if rank == 0:
+            out['comm'] = rt.comm_info()
             print(json.dumps(out))
-        if world > 1:
+        elif dist.is_initialized():
+            rt.comm_info()          # collective inside (_ensure_comm): every rank takes part
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     D, K = args.d, args.k
@@ -303,6 +301,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     L = Q.L[:Q.iter]
+    comm = rt.comm_info()          # every rank: the first call may create the communicator
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
@@ -350,6 +349,7 @@ def main():
         out['config']['stats'] = args.stats
         out['config']['plate_layout'] = plan.plate_layout if args.stats == 'gram' else 'rows'
         out['config']['initial_x'] = 'initialize_from_value (injected normal draws)'
+        out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(y, x0, D, K, n_total, [float(v) for v in L], Q,
                                                args.cpu_sample_n)
@@ -365,11 +365,13 @@ def main():
                           cpu_baseline=not args.no_cpu_baseline),
                 run_extra('gmm', workloads.run_gmm, 120, steps=10, warmup=2,
                           cpu_baseline=not args.no_cpu_baseline),
-                run_extra('masked', workloads.run_masked, 120, steps=3, warmup=1),
-                run_extra('lssm', workloads.run_lssm, 120, steps=3, warmup=1),
+                run_extra('masked', workloads.run_masked, 120, steps=3, warmup=1,
+                          cpu_baseline=not args.no_cpu_baseline),
+                run_extra('lssm', workloads.run_lssm, 120, steps=3, warmup=1,
+                          cpu_baseline=not args.no_cpu_baseline),
             ]
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -101,13 +101,13 @@ class LSSMOracle:
 
     def _stats(self, V, Cn):
         x, B = self.X, self.B
-        xx = np.einsum('bti,btj->ij', x, x)
+        xx = np.einsum('bti,btj->ij', x, x, optimize=True)
         self.Sxx = B * V.sum(axis=0) + xx
-        self.Spp = B * V[:-1].sum(axis=0) + np.einsum('bti,btj->ij', x[:, :-1], x[:, :-1])
-        self.Snn = B * V[1:].sum(axis=0) + np.einsum('bti,btj->ij', x[:, 1:], x[:, 1:])
+        self.Spp = B * V[:-1].sum(axis=0) + np.einsum('bti,btj->ij', x[:, :-1], x[:, :-1], optimize=True)
+        self.Snn = B * V[1:].sum(axis=0) + np.einsum('bti,btj->ij', x[:, 1:], x[:, 1:], optimize=True)
         # <x_t x_{t-1}^T> = Cov(x_{t-1}, x_t)^T + mean outer product
-        self.Snp = B * Cn.sum(axis=0).T + np.einsum('bti,btj->ij', x[:, 1:], x[:, :-1])
-        self.Syx = np.einsum('mbt,btd->md', self.y, x)
+        self.Snp = B * Cn.sum(axis=0).T + np.einsum('bti,btj->ij', x[:, 1:], x[:, :-1], optimize=True)
+        self.Syx = np.einsum('mbt,btd->md', self.y, x, optimize=True)
         self.S00 = B * V[0] + x[:, 0].T @ x[:, 0]
         self.s0 = x[:, 0].sum(axis=0)
 
@@ -136,16 +136,20 @@ class LSSMOracle:
             Dg[t] = obs + (self.Lam0 if t == 0 else np.diag(self.nu)) + (AnuA if t < T - 1 else 0.0)
         E = np.broadcast_to(-(self.nu[:, None] * self.Am).T, (max(T - 1, 0), D, D))
         Sinv, J, G, V, Cn, self.logdetPhi = chain_covariances(Dg, E)
-        h = self.tau * np.einsum('mbt,md->btd', self.y, self.Cm)
-        h[:, 0] += self.Lam0 @ self.mu0
+        # time-major work arrays (T, B, D): each step of the two recursions then touches one
+        # contiguous (B, D) slab instead of B rows 8*T*D bytes apart
+        h = self.tau * np.einsum('mbt,md->tbd', self.y, self.Cm, optimize=True)
+        h = np.ascontiguousarray(h)
+        h[0] += self.Lam0 @ self.mu0
         z = np.empty_like(h)
-        z[:, 0] = h[:, 0]
+        z[0] = h[0]
         for t in range(1, T):
-            z[:, t] = h[:, t] - z[:, t - 1] @ G[t - 1].T
-        x = np.empty_like(h)
-        x[:, T - 1] = z[:, T - 1] @ Sinv[T - 1].T
+            z[t] = h[t] - z[t - 1] @ G[t - 1].T
+        xt = np.empty_like(h)
+        xt[T - 1] = z[T - 1] @ Sinv[T - 1].T
         for t in range(T - 2, -1, -1):
-            x[:, t] = z[:, t] @ Sinv[t].T - x[:, t + 1] @ J[t].T
+            xt[t] = z[t] @ Sinv[t].T - xt[t + 1] @ J[t].T
+        x = np.ascontiguousarray(xt.transpose(1, 0, 2))
         self.X, self.V, self.Cn = x, V, Cn
         self._stats(V, Cn)
 

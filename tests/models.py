@@ -802,7 +802,7 @@ def build_masked_pca(nodes_mod, vb_cls, y, mask, x0, a0=1e-2, b0=1e-2, shard=Fal
     F = nodes_mod.SumMultiply('i,i', W, X, name='F')
     tau = nodes_mod.Gamma(a0, b0, name='tau')
     Y = nodes_mod.GaussianARD(F, tau, name='Y')
-    X.initialize_from_value(np.asarray(x0)[None, :, :])
+    X.initialize_from_value((x0 if hasattr(x0, 'device') else np.asarray(x0))[None, :, :])
     Y.observe(y, mask=mask)
     Q = vb_cls(Y, F, W, X, tau, alpha, **vb_kwargs)
     Q.ignore_bound_checks = True

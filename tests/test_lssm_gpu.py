@@ -83,6 +83,52 @@ def test_fused_lssm_vs_oracle(M, B, T, D, gamma_nu):
                                [o.tau, o.logtau], rtol=1e-9)
 
 
+def test_fused_lssm_config_scale_direct_oracle_parity():
+    """the dimensions of BASELINE config 5 (T=1e3, M=8, D=4) with B = 2e4 + 13
+    sequences -- 313 wavefronts x 1000 steps, a ragged last wavefront -- against the chunk-free
+    oracle on the same data (generated on the device), two iterations: the bound, every node's
+    term, <A>, <C>, <tau> and a strided sample of the chain means."""
+    import torch
+    from bayespy_amd.device import get_runtime
+    from oracle.lssm import LSSMOracle
+    dev = get_runtime().device
+    M, B, T, D = 8, 20_013, 1000, 4
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    rs = np.random.RandomState(11)
+    a_true = torch.from_numpy(0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]).to(dev)
+    c_true = torch.from_numpy(rs.normal(size=(M, D))).to(dev)
+    x = torch.empty(B, T, D, device=dev, dtype=torch.float64)
+    x[:, 0] = torch.randn(B, D, generator=g, device=dev, dtype=torch.float64)
+    for t in range(1, T):
+        x[:, t] = x[:, t - 1] @ a_true.T + torch.randn(B, D, generator=g, device=dev,
+                                                       dtype=torch.float64)
+    y = torch.einsum('md,btd->mbt', c_true, x)
+    y += 0.3 * torch.randn(M, B, T, generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.randn(B, T, D, generator=g, device=dev, dtype=torch.float64)
+    c0 = rs.normal(size=(M, D))
+    del x
+    Q = _build(y, x0, c0, False)
+    assert type(Q.plans[0]).__name__ == 'LSSMPlan'
+    iters = 2
+    Q.update(repeat=iters, verbose=False)
+    o = LSSMOracle(y.cpu().numpy(), x0.cpu().numpy(), c0)
+    del y, x0
+    o.iterate(iters)
+    np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=1e-9)
+    for nm in ('Y', 'C', 'A', 'X', 'gamma', 'alpha', 'tau'):
+        np.testing.assert_allclose(Q.l[Q[nm]][:iters], [t[nm] for t in o.L_terms], rtol=1e-8,
+                                   atol=1e-6, err_msg=nm)
+    np.testing.assert_allclose(Q['A'].u[0], o.Am, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(Q['C'].u[0].reshape(M, D), o.Cm, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(np.array(Q['tau'].u, dtype=np.float64).ravel(),
+                               [o.tau, o.logtau], rtol=1e-9)
+    xm = Q['X'].u[0]
+    sx = float(np.abs(o.X).max())
+    sel = np.r_[0:B:211, B - 14:B]
+    np.testing.assert_allclose(xm[sel], o.X[sel], rtol=1e-7, atol=1e-8 * sx)
+
+
 def _lssm_edge_cases():
     rs = np.random.RandomState(3)
 

@@ -277,6 +277,48 @@ def test_fused_block_direct_oracle_parity_n2e5():
                                atol=1e-10)
 
 
+def test_fused_block_config_scale_default_chunks_direct_oracle_parity():
+    """D=128, K=32, N = 2.5e6 + 77 (ragged), 10 % missing, the DEFAULT chunk of 2^20
+    plates -- two full chunk boundaries and a ragged tail are crossed with the default launch
+    parameters -- against the chunked oracle on the same data (generated on the device, NaN
+    at the missing entries), two iterations: bound, per-node terms, <w>, a strided sample of <x>."""
+    import torch
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.device import get_runtime
+    from models import build_masked_pca
+    from oracle.masked_pca import MaskedPCAOracle
+    dev = get_runtime().device
+    D, N, K = 128, 2_500_077, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)
+    y = w @ torch.randn(K, N, generator=g, device=dev, dtype=torch.float64)
+    y += 0.1 * torch.randn(D, N, generator=g, device=dev, dtype=torch.float64)
+    mask = torch.rand(D, N, generator=g, device=dev) >= 0.1
+    y[~mask] = float('nan')
+    x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
+    Q = build_masked_pca(nodes, VB, y, mask, x0)
+    plan = Q.plans[0]
+    assert type(plan).__name__ == 'MaskedPCAPlan'
+    assert plan.chunk == 1 << 20 and N > 2 * plan.chunk       # default chunking, > 2 boundaries
+    iters = 2
+    Q.update(repeat=iters, verbose=False)
+    yh, mh, xh = y.cpu().numpy(), mask.cpu().numpy(), x0.cpu().numpy()
+    del y, mask, x0
+    o = MaskedPCAOracle(yh, mh, xh, chunk=1 << 15)
+    o.iterate(iters)
+    np.testing.assert_allclose(Q.L[:iters], np.array(o.L), rtol=ELBO_RTOL)
+    for nm in ('Y', 'W', 'X', 'tau', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[nm]][:iters], [t[nm] for t in o.L_terms], rtol=1e-8,
+                                   atol=1e-7, err_msg=nm)
+    np.testing.assert_allclose(Q['W'].u[0][:, 0], o.W, rtol=1e-7, atol=1e-10)
+    # plates on both sides of each chunk boundary and the ragged tail
+    idx = np.r_[0:N:9973, (1 << 20) - 2:(1 << 20) + 2, (2 << 20) - 2:(2 << 20) + 2, N - 3:N]
+    xm = plan.Xm[torch.from_numpy(idx).to(dev), :K].cpu().numpy()
+    np.testing.assert_allclose(xm, o.X[idx], rtol=1e-7, atol=1e-10)
+
+
 def test_fused_block_rotation_matches_reference(golden_dir):
     """RotationOptimizer / RotateGaussianARD as the VB callback on a model with missing values
     (demos/pca.py:80-94, the demo's default use) on the fused missing-data block."""

@@ -31,6 +31,68 @@ def _cores():
         return os.cpu_count() or 1
 
 
+def library_build_id():
+    from bayespy_amd import _lib
+    v = _lib.load().vmp_version().decode()
+    return v.split('build ')[-1] if 'build ' in v else None
+
+
+def pmc_profile(workload):
+    """The committed rocprofv3 PMC summary (profiles/r*/pmc_*.txt, written by
+    tools/collect_profiles_r03.sh) of THIS build of the kernels (``# build_id:`` ==
+    vmp_version()) on THIS workload (``# workload:``), parsed into
+    ``{kernel: {counter: (avg, n)}}`` plus the header -- or (None, reason).  Never a replay of
+    another build's counters."""
+    import glob
+    import re
+    bid = library_build_id()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_*.txt')), reverse=True):
+        head, per, cur = {}, {}, None
+        for line in open(path):
+            m = re.match(r'#\s*(\w+):\s*(.+)', line)
+            if m:
+                head[m.group(1)] = m.group(2).strip()
+                continue
+            if line.startswith('=='):
+                continue
+            if not line.startswith(' '):
+                cur = line.strip()
+                continue
+            m = re.match(r'\s+(\w+)\s+avg\s+([0-9.eE+-]+)\s+\(n=(\d+)', line)
+            if m and cur:
+                per.setdefault(cur, {})[m.group(1)] = (float(m.group(2)), int(m.group(3)))
+        if head.get('build_id') == bid and head.get('workload') == workload:
+            return {'kernels': per, 'head': head, 'path': os.path.relpath(path, ROOT)}, None
+    return None, 'no committed PMC profile of build %s for "%s"' % (bid, workload)
+
+
+def pmc_bytes(counters):
+    """HBM bytes of one launch from the FETCH_SIZE / WRITE_SIZE averages (KB; FETCH_SIZE counts
+    half of a wide streaming read on gfx950: MI355X_MICROARCH.md, HBM section)."""
+    if 'FETCH_SIZE' not in counters or 'WRITE_SIZE' not in counters:
+        return None
+    return 2.0 * counters['FETCH_SIZE'][0] * 1024 + counters['WRITE_SIZE'][0] * 1024
+
+
+def pmc_iteration_traffic(prof, prefix):
+    """Sum over the kernels whose name starts with ``prefix``: bytes per launch x launches,
+    divided by the iterations the profiled command ran (``# iterations:``).  The set-up kernels
+    (relayout / prepare: run once) are excluded by name."""
+    its = float(prof['head'].get('iterations', 0) or 0)
+    if its <= 0:
+        return None
+    tot = 0.0
+    for k, c in prof['kernels'].items():
+        if not k.startswith(prefix) or any(w in k for w in ('prepare', 'relayout', 'x_layout',
+                                                            'init')):
+            continue
+        b = pmc_bytes(c)
+        if b is None:
+            return None
+        tot += b * c['FETCH_SIZE'][1]
+    return tot / its
+
+
 def run_pca_c2(N=1_000_000, D=64, K=16, steps=50, warmup=5, cpu_baseline=True):
     """BASELINE config 2: the headline model at a size where the replicated-node chain, not the
     plate pass, sets the step (bytes 0.64 GB = 0.08 ms at 8 TB/s): absolute it/s is the figure."""
@@ -182,7 +244,8 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
     return out
 
 
-def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine=None):
+def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine=None,
+               cpu_baseline=True, cpu_sample_n=200_000):
     """PCA with missing values at random (``mask = rng.rand(D, N) < 0.9``)."""
     import numpy as np
     import torch
@@ -227,6 +290,7 @@ def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine
     dt = time.perf_counter() - t0
     # 2NDK^2 (messages to W) + 2NDK^2 (precisions of X) + NK^3/3 (Cholesky)
     flops = 4.0 * N * D * K * K + N * K ** 3 / 3.0
+    L = [float(v) for v in Q.L[:Q.iter]]
     out = {
         'metric': 'VB iterations/sec, PCA N=%d D=%d K=%d, %d%% missing' % (N, D, K,
                                                                           round(100 * missing)),
@@ -236,21 +300,85 @@ def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine
         'config': {'workload': 'probabilistic PCA with values missing at random (array mask), '
                                'N=%d D=%d K=%d: per-plate K x K posteriors for X and W'
                                % (N, D, K), 'engine': type(plan).__name__},
-        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]),
+        'elbo_first': L[0], 'elbo_last': L[-1],
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'mfma', 'achieved': flops / (dt / steps) / 1e12,
                      'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flops / (dt / steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
                      'alg_flops_per_iteration': flops,
-                     'note': 'whole iteration (several kernels) against the algorithmic flops of '
-                             'SURVEY.md 8(d)'},
+                     'note': 'EFFICIENCY figure, not matrix-core utilisation: the ALGORITHMIC '
+                             'flops of SURVEY.md 8(d) (4NDK^2 + NK^3/3) over the whole iteration '
+                             '(several kernels); the kernels exploit the symmetry of <ww>, <xx> '
+                             'and issue about half of those flops'},
     }
     if timed:
-        out['roofline']['kernel_ms'] = plan.kernel_times_ms()
+        kms = plan.kernel_times_ms()
+        out['roofline']['kernel_ms'] = kms
+        if kms:
+            ch = float(kms['chunk_plates'])
+            P = K * (K + 1) // 2
+            # per chunk of plates: issued (symmetry-exploiting) MFMA flops of the two GEMM stages,
+            # K^3 (factor + inverse) + 2K^2 (mean) flops per plate for the sweep stage
+            out['roofline']['kernels'] = [
+                {'kernel': 'mpca_lambda_kernel', 'avg_launch_ms': kms['mpca_lambda'],
+                 'issued_TFLOPs': 2.0 * ch * D * (P + K) / kms['mpca_lambda'] / 1e9},
+                {'kernel': 'mpca_sweep_kernel', 'avg_launch_ms': kms['mpca_sweep'],
+                 'alg_TFLOPs': ch * (K ** 3 + 2.0 * K * K) / kms['mpca_sweep'] / 1e9,
+                 'plates_per_s': ch / kms['mpca_sweep'] * 1e3},
+                {'kernel': 'mpca_stats2_kernel+mpca_ryx_kernel', 'avg_launch_ms': kms['mpca_stats'],
+                 'issued_TFLOPs': 2.0 * ch * D * (P + K) / kms['mpca_stats'] / 1e9}]
+            out['roofline']['kernel'] = 'mpca_sweep_kernel (largest single kernel)'
+    wl = 'masked PCA N=%d D=%d K=%d' % (N, D, K)
+    prof, why = pmc_profile(wl)
+    if prof is not None:
+        out['roofline']['traffic'] = pmc_iteration_traffic(prof, 'mpca_')
+        out['roofline']['traffic_source'] = prof['path'] + ' (HBM bytes per VB iteration, all ' \
+                                                           'mpca_* kernels)'
+    else:
+        out['roofline']['traffic_source'] = why
+    if cpu_baseline and type(plan).__name__ == 'MaskedPCAPlan':
+        # the FIRST ns plates of the very data, mask and initial <x> of this run: the oracle
+        # (timed), and the HIP path re-run on that sample from the same initial moments
+        from oracle.masked_pca import MaskedPCAOracle
+        ns = min(cpu_sample_n, N)
+        ys = y[:, :ns].contiguous()
+        ms = mask[:, :ns].contiguous()
+        xs = x0[:ns].contiguous()
+        del Q, plan, Y, F, W, X, tau, alpha, y, mask, x0
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        n_it = 3
+        o = MaskedPCAOracle(ys.cpu().numpy(), ms.cpu().numpy(), xs.cpu().numpy(), chunk=1 << 14)
+        o.iterate(1)
+        t0 = time.perf_counter()
+        o.iterate(n_it - 1)
+        dtc = (time.perf_counter() - t0) / (n_it - 1)
+        alpha = Gamma(1e-2, 1e-2, plates=(K,))
+        W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
+        X = GaussianARD(0, 1, shape=(K,), plates=(1, ns))
+        tau = Gamma(1e-2, 1e-2)
+        Ys = GaussianARD(SumMultiply('i,i', W, X), tau)
+        X.initialize_from_value(xs[None])
+        Ys.observe(ys, mask=ms)
+        Qs = VB(Ys, W, X, tau, alpha, engine=engine)
+        Qs.ignore_bound_checks = True
+        Qs.update(repeat=n_it, verbose=False)
+        rel = max(abs(a - b) / abs(b) for a, b in zip(Qs.L[:n_it], o.L))
+        out['cpu_baseline'] = {
+            'value': 1.0 / (dtc * (N / float(ns))), 'unit': 'VB iterations/s', 'cores': _cores(),
+            'kind': 'port', 'elbo_rel_err_hip_vs_oracle': float(rel),
+            'elbo_iterations_compared': n_it,
+            'sample': 'oracle/masked_pca.py (NumPy fp64, chunked; batched inverses on a thread '
+                      'pool) on the first N=%d plates of the same data / mask / initial <x>, %d '
+                      'timed iterations at %.2f s/iter, extrapolated linearly to N=%d; the '
+                      'reference itself: 2.7 s/iter at N=2e4, D=64, K=16 (BASELINE.md)'
+                      % (ns, n_it - 1, dtc, N)}
     return out
 
 
-def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
+def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1, cpu_baseline=True,
+             cpu_sample_b=10_000):
     """Linear state-space model of bayespy/demos/lssm.py:34-103 with a sequence plate."""
     import json  # noqa: F401
     import numpy as np
@@ -287,7 +415,8 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
     gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
     gamma.initialize_from_value(1e-2 * np.ones(D))
     C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
-    C.initialize_from_value(rs.normal(size=(M, 1, 1, D)))
+    c_init = rs.normal(size=(M, 1, 1, D))
+    C.initialize_from_value(c_init)
     tau = Gamma(1e-5, 1e-5, name='tau')
     tau.initialize_from_value(1e2)
     F = SumMultiply('i,i', C, X, name='F')
@@ -314,7 +443,7 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
     # algorithmic traffic per iteration: read Y (M B T), read + write the chain means (B T D)
     byts = 8.0 * B * T * (M + 2 * D)
     kms = plan.kernel_times_ms() if timed else None
-    return {
+    out = {
         'metric': 'VB iterations/sec, LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D),
         'value': 1.0 / dt, 'unit': 'VB iterations/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'ms_per_step': 1e3 * dt, 'higher_is_better': True, 'scaling': 'strong',
@@ -328,6 +457,59 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1):
         'roofline': {'bound': 'hbm', 'achieved': byts / dt / 1e9, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': byts / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                      'alg_bytes_per_iteration': byts, 'kernel_ms': kms,
-                     'note': 'whole iteration against read Y once + read/write <x> once (the two '
-                             'recursion sweeps read Y twice and move the means three times)'},
+                     'note': 'whole iteration against the ALGORITHMIC bytes: read Y once + '
+                             'read/write <x> once'},
     }
+    prof, why = pmc_profile('LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D))
+    if prof is not None and world == 1:
+        out['roofline']['traffic'] = pmc_iteration_traffic(prof, 'lssm_')
+        out['roofline']['traffic_source'] = prof['path'] + ' (HBM bytes per VB iteration, all ' \
+                                                           'lssm_* kernels)'
+    else:
+        out['roofline']['traffic_source'] = why
+    if cpu_baseline and world == 1 and type(plan).__name__ == 'LSSMPlan':
+        # the FIRST bs sequences of the very data and initial moments of this run: the oracle
+        # (timed) and the HIP path re-run on that sample
+        from oracle.lssm import LSSMOracle
+        bs = min(cpu_sample_b, B)
+        ys = y[:, :bs].contiguous()
+        xs = x0[:bs].contiguous()
+        del Q, plan, Y, F, C, gamma, X, A, alpha, tau, y, x0
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        n_it = 3
+        o = LSSMOracle(ys.cpu().numpy(), xs.cpu().numpy(), c_init.reshape(M, D))
+        o.iterate(1)
+        t0 = time.perf_counter()
+        o.iterate(n_it - 1)
+        dtc = (time.perf_counter() - t0) / (n_it - 1)
+        alpha = Gamma(1e-5, 1e-5, plates=(D,))
+        A = GaussianARD(0, alpha, shape=(D,), plates=(D,))
+        A.initialize_from_value(np.identity(D))
+        X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T,
+                                plates=(bs,))
+        X.initialize_from_value(xs)
+        gamma = Gamma(1e-5, 1e-5, plates=(D,))
+        gamma.initialize_from_value(1e-2 * np.ones(D))
+        C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1))
+        C.initialize_from_value(c_init)
+        tau = Gamma(1e-5, 1e-5)
+        tau.initialize_from_value(1e2)
+        Ys = GaussianARD(SumMultiply('i,i', C, X), tau)
+        Ys.observe(ys)
+        Qs = VB(Ys, C, gamma, X, A, alpha, tau)
+        Qs.ignore_bound_checks = True
+        Qs.update(repeat=n_it, verbose=False)
+        rel = max(abs(a - b) / abs(b) for a, b in zip(Qs.L[:n_it], o.L))
+        out['cpu_baseline'] = {
+            'value': 1.0 / (dtc * (B / float(bs))), 'unit': 'VB iterations/s', 'cores': 1,
+            'kind': 'port', 'elbo_rel_err_hip_vs_oracle': float(rel),
+            'elbo_iterations_compared': n_it,
+            'sample': 'oracle/lssm.py (NumPy fp64: one shared covariance recursion + vectorised '
+                      'mean recursions over the sequences, single-threaded apart from BLAS) on '
+                      'the first B=%d sequences of the same data / initial moments, %d timed '
+                      'iterations at %.2f s/iter, extrapolated linearly to B=%d; the reference '
+                      'itself: ~3.6e2 s/iter extrapolated (BASELINE.md section 2)'
+                      % (bs, n_it - 1, dtc, B)}
+    return out
