@@ -33,6 +33,8 @@
 //   Mst  [DP][LR]            packed M_d | r_d  (what ranks all-reduce)
 #include "vmp_sweep.h"
 
+#include <type_traits>
+
 namespace {
 
 using namespace vmp_sweep;
@@ -829,6 +831,380 @@ mpca_rows_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
 }
 
 // -------------------------------------------------------------------------------------------
+// mpca_blk4: the per-plate stage on v_mfma_f64_4x4x4_4b_f64 -- the DEFAULT for the real update
+// (round 3).  That instruction multiplies FOUR independent 4 x 4 x 4 blocks per wavefront and is
+// the cheapest fp64 flop on this chip (tools/mfma4_lab.hip, profiles/r03/mfma4_lab.txt: 7.2 ns per
+// instruction and SIMD = 71 flop/ns against 59 for v_fma_f64 and 46 for the 16x16x4 form).  A
+// wavefront therefore inverts four plates at a time, one per block of the instruction, with the
+// K x K matrix of a plate cut into 4 x 4 blocks of which only the lower block triangle is kept
+// (36 registers for K = 32 instead of the 64 of a full matrix): lane l of a wavefront holds
+// element (4 I + (l >> 4), 4 J + (l & 3)) of block (I, J) of plate (l >> 2) & 3 -- the result
+// layout of the instruction (D[b][i][j] in lane j + 4 b + 16 i; probed, see the lab).  A register
+// X in that layout read as the B operand is X, read as the A operand it is X^T, so
+// mfma4(X, Y, Z) = X^T Y + Z and the symmetric sweep with 4 x 4 pivot blocks is, per pivot p:
+//     E = A_pp^-1                                  the only vector-ALU part (LDL^T, uniform per plate;
+//                                                  its 10 entries reach all 16 lanes of the plate by
+//                                                  4 MFMAs with a row selector + quad broadcasts)
+//     C~_I = A_pI (I < p, stored) or A_Ip^T (I > p: one MFMA with the identity)
+//     Q~_I = -E C~_I                               NB - 1 MFMAs
+//     A_IJ += Q~_I^T C~_J = A_IJ - A_Ip E A_pJ     for I >= J, both != p: NB (NB - 1) / 2 MFMAs
+//     A_pI = -Q~_I (I < p),  A_Ip = C~_I^T E (I > p),  A_pp = -E
+// Whole blocks are updated, so the symmetry of the matrix halves the work for free (K^3 flops),
+// and the pivot-block algebra is paid once per FOUR plates: ~300 vector + 370 matrix instructions
+// per wavefront-iteration = 170 per plate against ~2,400 of the 16x16x4 sweep form above.
+// <x> = Cov rhs: the half of the product that contracts the row index of a stored block runs on
+// the matrix core (36 MFMAs), the other half on the vector ALU (28 FMAs + quad reductions);
+// <x x^T> = Cov + <x><x>^T with the column form of <x> from one more transpose per block row.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mfma4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true);
+}
+
+__host__ __device__ constexpr int bidx(int I, int J) { return I * (I + 1) / 2 + J; }
+
+// One sweep over pivot block p of the NB x NB block matrix S (lower block triangle).
+template <int NB, int p>
+__device__ __forceinline__ void blk4_step(double (&S)[NB * (NB + 1) / 2], int li, int lj,
+                                          const double (&sel)[4], double ident, double &prod,
+                                          double &ld, int &bad)
+{
+    // ---- the pivot block in every lane of its plate: rw[a][i][j] = D[a][j], then the quad ------
+    const double Dp = S[bidx(p, p)];
+    const double rw0 = mfma4(sel[0], Dp, 0.0), rw1 = mfma4(sel[1], Dp, 0.0);
+    const double rw2 = mfma4(sel[2], Dp, 0.0), rw3 = mfma4(sel[3], Dp, 0.0);
+    const double d00 = dpp_f64<0x00>(rw0), d01 = dpp_f64<0x55>(rw0), d02 = dpp_f64<0xAA>(rw0);
+    const double d03 = dpp_f64<0xFF>(rw0);
+    const double d11 = dpp_f64<0x55>(rw1), d12 = dpp_f64<0xAA>(rw1), d13 = dpp_f64<0xFF>(rw1);
+    const double d22 = dpp_f64<0xAA>(rw2), d23 = dpp_f64<0xFF>(rw2);
+    const double d33 = dpp_f64<0xFF>(rw3);
+    // D = L diag(p) L^T, unit lower L (as vmp_sweep.h sweep_block)
+    const double p0 = d00;
+    const double r0 = fast_recip3(p0);
+    const double l10 = d01 * r0, l20 = d02 * r0, l30 = d03 * r0;
+    const double p1 = __builtin_fma(-l10, d01, d11);
+    const double r1 = fast_recip3(p1);
+    const double u21 = __builtin_fma(-l20, d01, d12);
+    const double u31 = __builtin_fma(-l30, d01, d13);
+    const double l21 = u21 * r1, l31 = u31 * r1;
+    const double p2 = __builtin_fma(-l21, u21, __builtin_fma(-l20, d02, d22));
+    const double r2 = fast_recip3(p2);
+    const double u32 = __builtin_fma(-l31, u21, __builtin_fma(-l30, d02, d23));
+    const double l32 = u32 * r2;
+    const double p3 = __builtin_fma(-l32, u32, __builtin_fma(-l31, u31,
+                                                             __builtin_fma(-l30, d03, d33)));
+    const double r3 = fast_recip3(p3);
+    if (!(p0 > 0.0 && p1 > 0.0 && p2 > 0.0 && p3 > 0.0)) bad = 1;
+    const double q0 = prod * (p0 * p1);
+    ld += (double)__builtin_amdgcn_frexp_exp(q0);
+    const double q1 = __builtin_amdgcn_frexp_mant(q0) * (p2 * p3);
+    ld += (double)__builtin_amdgcn_frexp_exp(q1);
+    prod = __builtin_amdgcn_frexp_mant(q1);
+    // column c = lj of D^-1: L y = e_c, z = y / p, L^T x = z; this lane keeps entry li
+    const double e0 = (lj == 0) ? 1.0 : 0.0, e1 = (lj == 1) ? 1.0 : 0.0;
+    const double e2 = (lj == 2) ? 1.0 : 0.0, e3 = (lj == 3) ? 1.0 : 0.0;
+    const double y1 = __builtin_fma(-l10, e0, e1);
+    const double y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, e0, e2));
+    const double y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, e0, e3)));
+    const double x3 = y3 * r3;
+    const double x2 = __builtin_fma(-l32, x3, y2 * r2);
+    const double x1 = __builtin_fma(-l31, x3, __builtin_fma(-l21, x2, y1 * r1));
+    const double x0 = __builtin_fma(-l30, x3, __builtin_fma(-l20, x2, __builtin_fma(-l10, x1, e0 * r0)));
+    const double E = (li == 0) ? x0 : (li == 1) ? x1 : (li == 2) ? x2 : x3;
+    const double nE = -E;
+    // ---- panels and the rank-4 update of every other block ------------------------------------
+    double Ct[NB], nQ[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        if (I < p) Ct[I] = S[bidx(p, I)];
+        else if (I > p) Ct[I] = mfma4(S[bidx(I, p)], ident, 0.0);
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+        if (I != p) nQ[I] = mfma4(nE, Ct[I], 0.0);
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J)
+            if (I != p && J != p) S[bidx(I, J)] = mfma4(nQ[I], Ct[J], S[bidx(I, J)]);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        if (I < p) S[bidx(p, I)] = -nQ[I];
+        else if (I > p) S[bidx(I, p)] = mfma4(Ct[I], E, 0.0);
+    }
+    S[bidx(p, p)] = nE;
+}
+
+// Packed index of element (4 I + li, 4 J + lj) of the symmetric matrix from four per-lane
+// constants (a table of the 36 indices per lane costs 36 registers of a kernel that needs them for
+// the matrix): off-diagonal blocks have row > column, diagonal blocks take (max, min).
+struct blk4_lane {
+    int li4, t0;      // I > J:  pk = 8 I^2 + 2 I + 4 J + I * li4 + t0,   t0 = li (li + 1) / 2 + lj
+    int m4, t0d;      // I == J: pk = 8 I^2 + 6 I     + I * m4  + t0d,  m = max(li, lj), n = min
+};
+
+template <int I, int J>
+__device__ __forceinline__ int blk4_pk(const blk4_lane &c)
+{
+    if constexpr (I == J) return 8 * I * I + 6 * I + I * c.m4 + c.t0d;
+    else return 8 * I * I + 2 * I + 4 * J + I * c.li4 + c.t0;
+}
+
+template <int NB, int p, typename F>
+__device__ __forceinline__ void blk4_sweep(double (&S)[NB * (NB + 1) / 2], int li, int lj,
+                                           const double (&sel)[4], double ident, double &prod,
+                                           double &ld, int &bad, F &&after_step)
+{
+    if constexpr (p < NB) {
+        blk4_step<NB, p>(S, li, lj, sel, ident, prod, ld, bad);
+        after_step(std::integral_constant<int, p>{});
+        blk4_sweep<NB, p + 1>(S, li, lj, sel, ident, prod, ld, bad, after_step);
+    }
+}
+
+template <int NB, int I, int J, typename F>
+__device__ __forceinline__ void blk4_for_blocks(F &&f)
+{
+    if constexpr (I < NB) {
+        f(std::integral_constant<int, I>{}, std::integral_constant<int, J>{});
+        if constexpr (J < I) blk4_for_blocks<NB, I, J + 1>(f);
+        else blk4_for_blocks<NB, I + 1, 0>(f);
+    }
+}
+
+template <int NB, bool FULLK>
+__global__ void __launch_bounds__(NT, 2)
+mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chunk, int K,
+                 double x_prec, const double *__restrict__ tau_ptr, double *__restrict__ XXf,
+                 double *__restrict__ Xm, int write_x, double *__restrict__ partial,
+                 double *__restrict__ partial_sxx)
+{
+    constexpr int KT = NB <= 4 ? 1 : 2, KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
+    constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2;
+    constexpr int NPAIR = 4 * LRC / 2, NV = (NPAIR + 63) / 64;
+    static_assert(4 * KP <= 128, "the four right-hand sides are one 16-byte pair per lane");
+    // staging of one wavefront: four packed rows (matrix | right-hand side) as they lie in Lam, and
+    // a copy of the four right-hand sides that outlives the rows (see the loop)
+    __shared__ __attribute__((aligned(16))) double stg[4][4 * LRC];
+    __shared__ __attribute__((aligned(16))) double hst[4][4 * KP];
+    __shared__ double sa[P];                     // packed sum of <x x^T>_n of this workgroup
+    __shared__ double red[NT / 64];
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = l >> 4, lb = (l >> 2) & 3, lj = l & 3;
+    const double tau = tau_ptr[0];
+    for (int e = threadIdx.x; e < P; e += NT) sa[e] = 0.0;
+    // operand constants: row selectors, the identity (both in the result layout)
+    double sel[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sel[a] = (li == a) ? 1.0 : 0.0;
+    const double ident = (li == lj) ? 1.0 : 0.0;
+    const double dgv = (li == lj) ? x_prec : 0.0;
+    blk4_lane lc;
+    {
+        const int m = li > lj ? li : lj, n = li > lj ? lj : li;
+        lc.li4 = 4 * li;
+        lc.t0 = li * (li + 1) / 2 + lj;
+        lc.m4 = 4 * m;
+        lc.t0d = m * (m + 1) / 2 + n;
+    }
+    // FULLK: K == 4 NB, no padded rows / columns in the last block row
+    const bool padr = !FULLK && 4 * (NB - 1) + li >= K, padc = !FULLK && 4 * (NB - 1) + lj >= K;
+    double pm = 1.0, le = 0.0;                   // product of the pivots of this lane's plates
+    int anybad = 0;
+    // the packed rows of plates 4 q .. 4 q + 3, contiguous in Lam (rows beyond the chunk: zeros),
+    // in two halves of NH 16-byte pairs per lane so that only one half is held in registers
+    constexpr int NH = (NV + 1) / 2;
+    v2f64 nxt[NH];
+    auto fetch = [&](int64_t q, auto half) {
+        constexpr int H = decltype(half)::value;
+        const int64_t left = nplates_chunk - 4 * q;
+        const v2f64 *src = reinterpret_cast<const v2f64 *>(Lam + 4 * q * LRC);
+        if (left >= 4) {
+#pragma unroll
+            for (int i = H * NH; i < NV && i < (H + 1) * NH; ++i) {
+                const int pidx = l + 64 * i;
+                nxt[i - H * NH] = (64 * (i + 1) <= NPAIR || pidx < NPAIR)
+                                      ? __builtin_nontemporal_load(src + pidx) : v2f64{0.0, 0.0};
+            }
+        } else {
+            const int npair = (int)(left * (LRC / 2));
+#pragma unroll
+            for (int i = H * NH; i < NV && i < (H + 1) * NH; ++i) {
+                const int pidx = l + 64 * i;
+                nxt[i - H * NH] = (pidx < npair) ? __builtin_nontemporal_load(src + pidx)
+                                                 : v2f64{0.0, 0.0};
+            }
+        }
+    };
+    auto park = [&](auto half) {
+        constexpr int H = decltype(half)::value;
+#pragma unroll
+        for (int i = H * NH; i < NV && i < (H + 1) * NH; ++i) {
+            const int pidx = l + 64 * i;
+            if (64 * (i + 1) <= NPAIR || pidx < NPAIR)
+                reinterpret_cast<v2f64 *>(stg[w])[pidx] = nxt[i - H * NH];
+        }
+    };
+    using half0 = std::integral_constant<int, 0>;
+    using half1 = std::integral_constant<int, 1>;
+    const int64_t ngroups = (nplates_chunk + 3) / 4;
+    const int64_t gstep = (int64_t)gridDim.x * 4;
+    int64_t q = (int64_t)blockIdx.x * 4 + w;
+    if (q < ngroups) {
+        fetch(q, half0{});
+        park(half0{});
+        fetch(q, half1{});
+        park(half1{});
+    }
+    __syncthreads();                              // sa zeroed
+    const blk4_lane lc0 = lc;
+    for (; q < ngroups; q += gstep) {
+        lds_fence();
+        // the per-lane index constants are re-materialised every iteration: left loop-invariant,
+        // the compiler hoists the 36 gather and the 36 store offsets of a lane out of the loop and
+        // spills the matrix instead
+        lc = lc0;
+        asm volatile("" : "+v"(lc.li4), "+v"(lc.t0), "+v"(lc.m4), "+v"(lc.t0d));
+        const double *row = stg[w] + lb * LRC;
+        const bool valid = 4 * q + lb < nplates_chunk;
+        const bool more = q + gstep < ngroups;
+        // ---- gather: S = c I + tau Lam~ (identity on the padding) ------------------------------
+        double S[NBB];
+        blk4_for_blocks<NB, 0, 0>([&](auto Ic, auto Jc) {
+            constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
+            const double v = row[blk4_pk<I, J>(lc)];
+            double a = (I == J) ? __builtin_fma(tau, v, dgv) : tau * v;
+            if (!FULLK && I == NB - 1) {
+                if (J == NB - 1) a = (padr || padc) ? ident : a;
+                else a = padr ? 0.0 : a;
+            }
+            S[bidx(I, J)] = a;
+        });
+        // the right-hand sides move to their own area (they are read after the sweep), so that ...
+        if (l < 2 * KP)
+            reinterpret_cast<v2f64 *>(hst[w])[l] =
+                reinterpret_cast<const v2f64 *>(stg[w] + (l / (KP / 2)) * LRC + 16 * PT)[l % (KP / 2)];
+        lds_fence();
+        // ... the next four rows can travel HBM -> registers -> the (now free) staging area
+        // during the pivot steps, one half after the other
+        constexpr int PA = NB >= 6 ? 1 : 0, PB = NB >= 6 ? 3 : (NB >= 2 ? 1 : 0);
+        if (more) fetch(q + gstep, half0{});
+        double prod = 1.0, ld = 0.0;
+        int bad = 0;
+        blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto pc) {
+            constexpr int pp = decltype(pc)::value;
+            if constexpr (pp == PA) {
+                if (more) {
+                    park(half0{});
+                    fetch(q + gstep, half1{});
+                }
+            }
+            if constexpr (pp == PB) {
+                if (more) park(half1{});
+            }
+        });
+        // ---- <x> = Cov (tau rhs), Cov = -S ---------------------------------------------------------
+        double hq[NB], hr[NB];                    // tau rhs at the lane's column / row index
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+            const double a = hst[w][lb * KP + 4 * J + lj];
+            const double b = hst[w][lb * KP + 4 * J + li];
+            hq[J] = (FULLK || 4 * J + lj < K) ? tau * a : 0.0;
+            hr[J] = (FULLK || 4 * J + li < K) ? tau * b : 0.0;
+        }
+        double xrow[NB];
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+            // contributions that contract the ROW index of a stored block: sum_{I >= J} S_IJ^T h_I
+            double t = 0.0;
+#pragma unroll
+            for (int I = J; I < NB; ++I) t = mfma4(S[bidx(I, J)], hr[I], t);
+            xrow[J] = t;
+        }
+#pragma unroll
+        for (int I = 1; I < NB; ++I) {
+            // ... and the COLUMN index: sum_{J < I} S_IJ h_J, summed over the quad
+            double t = 0.0;
+#pragma unroll
+            for (int J = 0; J < I; ++J) t = __builtin_fma(S[bidx(I, J)], hq[J], t);
+            t += dpp_f64<0xB1>(t);
+            t += dpp_f64<0x4E>(t);
+            xrow[I] += t;
+        }
+        double xcol[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            xrow[I] = -xrow[I];
+            xcol[I] = mfma4(xrow[I], ident, 0.0);
+        }
+        // ---- <x x^T> = Cov + <x><x>^T; stores ----------------------------------------------------
+        {
+            // element (n, p) of XXf at (((n/8) PT + p/16) 64 + (n%4) 16 + p%16) 2 + (n/4)%2, n = 4 q + lb
+            double *xb = XXf + ((q >> 1) * PT) * 128 + (q & 1) + lb * 32;
+            blk4_for_blocks<NB, 0, 0>([&](auto Ic, auto Jc) {
+                constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
+                double v = __builtin_fma(xrow[I], xcol[J], -S[bidx(I, J)]);
+                if (!FULLK && I == NB - 1) v = (padr || (J == NB - 1 && padc)) ? 0.0 : v;
+                if (valid && (I > J || li >= lj)) {
+                    const int pk = blk4_pk<I, J>(lc);
+                    xb[8 * pk - 6 * (pk & 15)] = v;
+                    __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            });
+            if (4 * NB < KP) {
+                // block rows beyond the last one that holds data: zeros (mpca_stats reads whole tiles)
+#pragma unroll
+                for (int I = NB; I < KP / 4; ++I)
+#pragma unroll
+                    for (int J = 0; J <= I; ++J) {
+                        const int r = 4 * I + li, c = 4 * J + lj;
+                        const int pk = tri(r > c ? r : c, r > c ? c : r);
+                        if (valid && (I > J || li >= lj)) xb[8 * pk - 6 * (pk & 15)] = 0.0;
+                    }
+            }
+            if (valid && write_x && lj == 0) {
+                double *xr = Xm + (n0 + 4 * q + lb) * KP;
+#pragma unroll
+                for (int I = 0; I < NB; ++I)
+                    xr[4 * I + li] = (FULLK || 4 * I + li < K) ? xrow[I] : 0.0;
+                if (4 * NB < KP)
+                    for (int r = 4 * NB + li; r < KP; r += 4) xr[r] = 0.0;
+            }
+            if (valid) {
+                const double qq = pm * prod;
+                le += ld + (double)__builtin_amdgcn_frexp_exp(qq);
+                pm = __builtin_amdgcn_frexp_mant(qq);
+                anybad |= bad;
+            }
+        }
+    }
+    // per-workgroup partials: tr<xx> = trace of the accumulated sum, log|Cov|, status
+    __syncthreads();
+    double tr = 0.0;
+    for (int k = threadIdx.x; k < K; k += NT) tr += sa[tri(k, k)];
+    tr = block_sum<NT>(tr, red);
+    const double ldw = block_sum<NT>((li == 0 && lj == 0)
+                                         ? -(log(pm) + le * 0.69314718055994530942) : 0.0, red);
+    const double bd = block_sum<NT>((double)anybad, red);
+    if (threadIdx.x == 0) {
+        partial[3 * blockIdx.x + 0] = tr;
+        partial[3 * blockIdx.x + 1] = ldw;
+        partial[3 * blockIdx.x + 2] = bd;
+    }
+    for (int e = threadIdx.x; e < KP * KP; e += NT) {
+        const int i = e / KP, j = e - i * KP;
+        const int a = i > j ? i : j, b = i > j ? j : i;
+        partial_sxx[(int64_t)blockIdx.x * KP * KP + e] = (i < K && j < K) ? sa[tri(a, b)] : 0.0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // mpca_stats: Mst[d][:] += sum_n m_dn [ packed <xx>_n | <x_n> y_dn ]
 //   A operand (d x n): mask bits (packed columns), m*y from Ymt (the KT last columns)
 //   B operand (n x col): XXf / Xm
@@ -1481,7 +1857,32 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     hipLaunchKernelGGL((mpca_sweep_kernel<kt, fv, nmm, oc>), dim3((unsigned)gs), dim3(NT), 0, s,   \
                        Lam, m.LR, n0, nplates, K, x_prec, xx_diag, state + L.off_scal + SC_TAUX,   \
                        XXf, Xm, inspect ? 0 : 1, pscal, psxx)
-    if (m.KT == 1) {
+    if (!from_value && vmp_tune_get("mpca_blk4", 1) != 0) {
+        // default: four plates per wavefront on the 4x4x4 matrix instruction (mpca_blk4_kernel)
+        gs = (nplates + 15) / 16;
+        const int64_t cap = grid_cap(ctx, vmp_tune_get("mpca_blk4_wgs", 2));
+        if (gs > cap) gs = cap;
+        if (gs < 1) gs = 1;
+        const int nb = (K + 3) / 4;
+#define MPCA_BLK4(NBV)                                                                             \
+    case NBV:                                                                                      \
+        if (K == 4 * NBV)                                                                          \
+            hipLaunchKernelGGL((mpca_blk4_kernel<NBV, true>), dim3((unsigned)gs), dim3(NT), 0, s,  \
+                               Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
+                               inspect ? 0 : 1, pscal, psxx);                                      \
+        else                                                                                       \
+            hipLaunchKernelGGL((mpca_blk4_kernel<NBV, false>), dim3((unsigned)gs), dim3(NT), 0, s, \
+                               Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
+                               inspect ? 0 : 1, pscal, psxx);                                      \
+        break;
+        switch (nb) {
+            MPCA_BLK4(1) MPCA_BLK4(2) MPCA_BLK4(3) MPCA_BLK4(4)
+            MPCA_BLK4(5) MPCA_BLK4(6) MPCA_BLK4(7) MPCA_BLK4(8)
+        default:
+            return VMP_ERR_UNSUPPORTED;
+        }
+#undef MPCA_BLK4
+    } else if (m.KT == 1) {
         if (from_value) MPCA_SWEEP(1, true, 1, 2);
         else MPCA_SWEEP(1, false, 1, 2);
     } else if (from_value) {

@@ -197,7 +197,8 @@ def test_moments_of_the_deterministic_product_are_read_out_on_request(masked):
         np.testing.assert_allclose(a, np.broadcast_to(b, a.shape), rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize('N,D,K', [(777, 40, 32), (333, 17, 20), (64, 128, 32)])
+@pytest.mark.parametrize('N,D,K', [(777, 40, 32), (333, 17, 20), (64, 128, 32), (203, 9, 7),
+                                   (150, 12, 16), (1, 3, 2), (1030, 33, 25)])
 def test_plate_stage_variants_agree(N, D, K):
     """The per-plate stage has three forms (vmp_tune_set): two plates per wavefront on the
     matrix-core sweep (default), one plate per wavefront, and the vector-ALU Gauss-Jordan with a
@@ -213,8 +214,10 @@ def test_plate_stage_variants_agree(N, D, K):
     x0 = rs.normal(size=(N, K))
     lib = get_runtime().lib
     res = []
+    defaults = {'mpca_blk4': 1, 'mpca_sweep_nm': 2, 'mpca_rows': 0}
     try:
-        for knobs in ({}, {'mpca_sweep_nm': 1}, {'mpca_rows': 1}):
+        for knobs in ({}, {'mpca_blk4': 0}, {'mpca_blk4': 0, 'mpca_sweep_nm': 1},
+                      {'mpca_blk4': 0, 'mpca_rows': 1}):
             for k, v in knobs.items():
                 lib.vmp_tune_set(k.encode(), v)
             Q = build_masked_pca(nodes, VB, y, mask, x0)
@@ -223,10 +226,10 @@ def test_plate_stage_variants_agree(N, D, K):
             res.append((Q.L[:3].copy(), Q['W'].u[0].copy(), Q['X'].u[0].copy(),
                         np.array(st['XX'])))
             for k in knobs:
-                lib.vmp_tune_set(k.encode(), {'mpca_sweep_nm': 2, 'mpca_rows': 0}[k])
+                lib.vmp_tune_set(k.encode(), defaults[k])
     finally:
-        lib.vmp_tune_set(b'mpca_sweep_nm', 2)
-        lib.vmp_tune_set(b'mpca_rows', 0)
+        for k, v in defaults.items():
+            lib.vmp_tune_set(k.encode(), v)
     for L, w, x, xx in res[1:]:
         np.testing.assert_allclose(L, res[0][0], rtol=1e-11)
         np.testing.assert_allclose(w, res[0][1], rtol=1e-8, atol=1e-11)

@@ -42,29 +42,32 @@ def main():
         return Q, X
 
     variants = [
-        (1 << 20, dict(mpca_streams=0)),
-        (1 << 20, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=4, mpca_stats_wgs=1)),
-        (1 << 18, dict(mpca_streams=0)),
-        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=4, mpca_stats_wgs=1)),
-        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=2, mpca_stats_wgs=1)),
-        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=2, mpca_sweep_wgs=8, mpca_stats_wgs=2)),
-        (1 << 18, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=8, mpca_stats_wgs=1)),
-        (1 << 17, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=4, mpca_stats_wgs=1)),
+        (1 << 20, dict(mpca_blk4=0)),
+        (1 << 20, dict(mpca_blk4=1)),
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_wgs=1)),
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_wgs=2)),
     ]
-    print('N=%d D=%d K=%d; ms per X.update() and bound after two iterations' % (N, D, K))
+    print('N=%d D=%d K=%d; ms per X.update(), per-chunk kernel times (HIP events), bound after two '
+          'iterations' % (N, D, K))
     for chunk, knobs in variants:
         for k, val in knobs.items():
             rt.lib.vmp_tune_set(k.encode(), val)
         Q, X = build(chunk)
         Q.update(repeat=2, verbose=False)
+        plan = Q.plans[0]
+        plan.enable_timing(True)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(3):
             X.update()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 3
-        print('chunk %8d %-78s %8.2f ms   L=%r' % (chunk, knobs, 1e3 * dt, Q.L[1]))
-        del Q, X
+        km = plan.kernel_times_ms()
+        plan.enable_timing(False)
+        print('chunk %8d %-40s %8.2f ms  %s  L=%r' % (
+            chunk, knobs, 1e3 * dt,
+            ' '.join('%s=%.3f' % (k, v) for k, v in km.items() if k != 'chunk_plates'), Q.L[1]))
+        del Q, X, plan
 
 
 if __name__ == '__main__':
