@@ -27,9 +27,14 @@
 //                            packed <w w^T>_d, then KT tiles of <w_d>; element (d, col) at
 //                            ((c*(DQ/2) + (d/8))*64 + (d%4)*16 + col%16)*2 + (d/4)%2
 //   Lam  [n][LR]             scratch of a chunk, LR = 16 (PT + KT): packed Lam~_n | rhs~_n
-//   XXf  [n/8][PT][64][2]    scratch of a chunk: packed <x x^T>_n in the B-operand order of mpca_stats,
-//                            two k-steps per 16 bytes: element (n, p) at
-//                            (((n/8)*PT + p/16)*64 + (n%4)*16 + p%16)*2 + (n/4)%2
+//   XXf  [n/4][PT2][64][2]   scratch of a chunk: packed <x x^T>_n in the B-operand order of mpca_stats,
+//                            PT2 = ceil(PT / 2) PAIRS of column tiles per 16 bytes: element (n, p) at
+//                            (((n/4)*PT2 + p/32)*64 + (n%4)*16 + p%16)*2 + (p/16)%2
+//                            -- every 1 KB block belongs to ONE group of four plates, i.e. to one
+//                            wavefront-iteration of the per-plate stage (round 3: with two k-steps
+//                            per 16 bytes a block was completed by two wavefronts at different
+//                            times and left the L2 half-written: 8.3 GB written per 2^20 plates
+//                            instead of 4.7, profiles/r03/pmc_blk4_before.txt)
 //   Mst  [DP][LR]            packed M_d | r_d  (what ranks all-reduce)
 #include "vmp_sweep.h"
 
@@ -43,6 +48,14 @@ constexpr int NT = 256;
 constexpr int TN = 32;          // plates per tile of Ymt
 
 __host__ __device__ inline int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// XXf (see the layout note above): offset of packed entry p inside the block row of its plate
+// group, and the start of plate n's lanes in that block row
+__host__ __device__ inline int xxf_off(int p) { return (p >> 5) * 128 + (p & 15) * 2 + ((p >> 4) & 1); }
+__host__ __device__ inline int64_t xxf_base(int64_t n, int PT)
+{
+    return ((n >> 2) * ((PT + 1) / 2) * 64 + (n & 3) * 16) * 2;
+}
 
 struct mpca_dims {
     int D, K, DP, KP, DQ, DT, KT, P, PT, CT, LR;
@@ -447,7 +460,7 @@ __device__ __forceinline__ void store_plate(const v4f64 (&T)[2][2], const plate_
                 const int i = 16 * tr + l4 + 4 * r, j = 16 * tc + l15;
                 sa[i * KP + j] += T[tr][tc][r];
             }
-    double *xb = XXf + (((n_chunk >> 3) * PT) * 64 + (n_chunk & 3) * 16) * 2 + ((n_chunk >> 2) & 1);
+    double *xb = XXf + xxf_base(n_chunk, PT);
 #pragma unroll
     for (int tr = 0; tr < KT; ++tr)
 #pragma unroll
@@ -458,7 +471,7 @@ __device__ __forceinline__ void store_plate(const v4f64 (&T)[2][2], const plate_
                 if (i >= j) {
                     const int p = tri(i, j);
                     const double v = (i < K && j < K) ? T[tr][tc][r] : 0.0;
-                    xb[((p >> 4) * 64 + (p & 15)) * 2] = v;
+                    xb[xxf_off(p)] = v;
                     if (i == j) trl += v;
                 }
             }
@@ -772,19 +785,19 @@ mpca_rows_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         //      64 outer-product FMAs next to the stores and keeps all 32 broadcasts alive) ------------
         {
             const int64_t nc = n + grp;
-            double *xb = XXf + (((nc >> 3) * PT) * 64 + (nc & 3) * 16) * 2 + ((nc >> 2) & 1);
+            double *xb = XXf + xxf_base(nc, PT);
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 if (valid && j <= i0) {
                     const int p = b0 + j;
                     const double v = (FULLK || i0 < K) ? m[0][j] : 0.0;
-                    xb[8 * p - 6 * (p & 15)] = v;
+                    xb[xxf_off(p)] = v;
                     __hip_atomic_fetch_add(&sa[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (valid && j <= i1) {
                     const int p = b1 + j;
                     const double v = (FULLK || (i1 < K && j < K)) ? m[1][j] : 0.0;
-                    xb[8 * p - 6 * (p & 15)] = v;
+                    xb[xxf_off(p)] = v;
                     __hip_atomic_fetch_add(&sa[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -983,7 +996,7 @@ __global__ void __launch_bounds__(NT, 2)
 mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chunk, int K,
                  double x_prec, const double *__restrict__ tau_ptr, double *__restrict__ XXf,
                  double *__restrict__ Xm, int write_x, double *__restrict__ partial,
-                 double *__restrict__ partial_sxx)
+                 double *__restrict__ partial_sxx, int dbg)
 {
     constexpr int KT = NB <= 4 ? 1 : 2, KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
     constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2;
@@ -1097,7 +1110,7 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         if (more) fetch(q + gstep, half0{});
         double prod = 1.0, ld = 0.0;
         int bad = 0;
-        blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto pc) {
+        if (!(dbg & 4)) blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto pc) {
             constexpr int pp = decltype(pc)::value;
             if constexpr (pp == PA) {
                 if (more) {
@@ -1145,16 +1158,18 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         }
         // ---- <x x^T> = Cov + <x><x>^T; stores ----------------------------------------------------
         {
-            // element (n, p) of XXf at (((n/8) PT + p/16) 64 + (n%4) 16 + p%16) 2 + (n/4)%2, n = 4 q + lb
-            double *xb = XXf + ((q >> 1) * PT) * 128 + (q & 1) + lb * 32;
+            // this wavefront's plates 4 q .. 4 q + 3 own the whole block row q of XXf
+            double *xb = XXf + xxf_base(4 * q + lb, PT);
             blk4_for_blocks<NB, 0, 0>([&](auto Ic, auto Jc) {
                 constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
                 double v = __builtin_fma(xrow[I], xcol[J], -S[bidx(I, J)]);
                 if (!FULLK && I == NB - 1) v = (padr || (J == NB - 1 && padc)) ? 0.0 : v;
                 if (valid && (I > J || li >= lj)) {
                     const int pk = blk4_pk<I, J>(lc);
-                    xb[8 * pk - 6 * (pk & 15)] = v;
-                    __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!(dbg & 2)) xb[xxf_off(pk)] = v;
+                    if (!(dbg & 1))
+                        __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (dbg & 8) pm += v;
                 }
             });
             if (4 * NB < KP) {
@@ -1165,7 +1180,7 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
                     for (int J = 0; J <= I; ++J) {
                         const int r = 4 * I + li, c = 4 * J + lj;
                         const int pk = tri(r > c ? r : c, r > c ? c : r);
-                        if (valid && (I > J || li >= lj)) xb[8 * pk - 6 * (pk & 15)] = 0.0;
+                        if (valid && (I > J || li >= lj)) xb[xxf_off(pk)] = 0.0;
                     }
             }
             if (valid && write_x && lj == 0) {
@@ -1205,124 +1220,39 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
 }
 
 // -------------------------------------------------------------------------------------------
-// mpca_stats: Mst[d][:] += sum_n m_dn [ packed <xx>_n | <x_n> y_dn ]
-//   A operand (d x n): mask bits (packed columns), m*y from Ymt (the KT last columns)
-//   B operand (n x col): XXf / Xm
-// A workgroup owns the column tiles [c0, c1) of one slice and ALL rows d; wavefront w owns
-// the row tiles dt = w, w+4, ...; it walks the 16-plate subtiles of its share of the chunk.
+// mpca_stats: M_d = sum_n m_dn <x x^T>_n (the packed columns), wavefronts split the COLUMN tiles.
+// Wavefront w owns ONE PAIR of column tiles of its workgroup's slice and ALL row tiles dt: its B
+// operands (16 bytes per lane = the two tiles of the pair for one k-step of four plates, XXf
+// order) are loaded by no other wavefront, the A operand is the mask bit of (d, n) -- no loads at
+// all.  r_d comes from mpca_ryx_kernel.
 // -------------------------------------------------------------------------------------------
-template <int DB, int KT, int TS>
+template <int DB, int KT>
 __global__ void __launch_bounds__(NT, 2)
-mpca_stats_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ Mb2,
-                  const double *__restrict__ XXf, const double *__restrict__ Xm, int64_t sub0,
-                  int64_t nsub_chunk, int64_t n0, int nslices, double *__restrict__ partial)
-{
-    constexpr int DP = 32 * DB, DT = DP / 16, DW = (DT + 3) / 4;
-    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
-    constexpr int LR = 16 * CT;
-    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l15 = l & 15, l4 = l >> 4;
-    const int slice = blockIdx.x % nslices, wg = blockIdx.x / nslices, nwg = gridDim.x / nslices;
-    const int c0 = slice * TS;
-    v4f64 acc[DW][TS];
-#pragma unroll
-    for (int i = 0; i < DW; ++i)
-#pragma unroll
-        for (int t = 0; t < TS; ++t) acc[i][t] = v4f64{0.0, 0.0, 0.0, 0.0};
-    const bool active = w < DT;             // DT < 4: the upper wavefronts have no row tile
-    for (int64_t sc = wg; sc < nsub_chunk; sc += nwg) {
-        const int64_t sub = sub0 + sc;
-        const uint32_t mw = Mb2[sub * 64 + l];
-        // Ymt element (d = 16 dt + l15, n = 16 sub + 4 qq + l4)
-        const double *ybase = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l15 * TN
-                              + (sub & 1) * 16 + l4;
-        const double *xxb = XXf + ((sc * 2) * ((int64_t)PT * 64) + l) * 2;
-        const double *xmb = Xm + (n0 + sc * 16 + l4) * KP + l15;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            double bfr[TS];
-#pragma unroll
-            for (int t = 0; t < TS; ++t) {
-                const int c = c0 + t;
-                bfr[t] = (c < PT) ? xxb[(((int64_t)(qq >> 1) * PT + c) * 64) * 2 + (qq & 1)]
-                                  : (c < CT ? xmb[(int64_t)(4 * qq) * KP + 16 * (c - PT)] : 0.0);
-            }
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < DW; ++i) {
-                    const int dt = w + 4 * i;
-                    if (dt < DT) {
-                        const bool on = (mw >> (4 * dt + qq)) & 1u;
-                        const double am = on ? 1.0 : 0.0;
-                        double ay = 0.0;
-                        if (c0 + TS > PT) ay = on ? ybase[(int64_t)(16 * dt) * TN + 4 * qq] : 0.0;
-#pragma unroll
-                        for (int t = 0; t < TS; ++t) {
-                            const int c = c0 + t;
-                            if (c < CT) acc[i][t] = mfma((c >= PT) ? ay : am, bfr[t], acc[i][t]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // partial[wg][d][col]; C/D layout: row (d) = (l>>4) + 4r, column = l&15
-    double *pb = partial + (int64_t)wg * DP * LR;
-    if (active) {
-#pragma unroll
-        for (int i = 0; i < DW; ++i) {
-            const int dt = w + 4 * i;
-            if (dt < DT) {
-#pragma unroll
-                for (int t = 0; t < TS; ++t) {
-                    const int c = c0 + t;
-                    if (c < CT) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            pb[(int64_t)(16 * dt + l4 + 4 * r) * LR + 16 * c + l15] = acc[i][t][r];
-                    }
-                }
-            }
-        }
-    }
-}
-
-
-// -------------------------------------------------------------------------------------------
-// mpca_stats, second form: M_d only (the packed columns), wavefronts split the COLUMN tiles.
-// Wavefront w owns NCW column tiles of its workgroup's slice and ALL row tiles dt: its B operands
-// (two k-steps per 16-byte load, XXf order) are loaded by no other wavefront, the A operand is the
-// mask bit of (d, n) -- no loads at all.  r_d comes from mpca_ryx_kernel.
-// -------------------------------------------------------------------------------------------
-template <int DB, int KT, int NCW>
-__global__ void __launch_bounds__(NT, NCW >= 3 ? 1 : 2)
 mpca_stats2_kernel(const uint32_t *__restrict__ Mb2, const double *__restrict__ XXf, int64_t sub0,
                    int64_t nsub_chunk, int nslices, double *__restrict__ partial)
 {
     constexpr int DP = 32 * DB, DT = DP / 16;
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
-    constexpr int LR = 16 * CT;
+    constexpr int PT2 = (PT + 1) / 2, LR = 16 * CT;
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = l & 15, l4 = l >> 4;
     const int slice = blockIdx.x % nslices, wg = blockIdx.x / nslices, nwg = gridDim.x / nslices;
-    const int c0 = (slice * 4 + w) * NCW;           // first column tile of this wavefront
-    v4f64 acc[DT][NCW];
+    const int cp = slice * 4 + w;                   // this wavefront's pair of column tiles
+    const int c0 = 2 * cp;
+    v4f64 acc[DT][2];
 #pragma unroll
     for (int i = 0; i < DT; ++i)
 #pragma unroll
-        for (int t = 0; t < NCW; ++t) acc[i][t] = v4f64{0.0, 0.0, 0.0, 0.0};
-    const int64_t npair = (nsub_chunk + 1) / 2;     // 32 plates: 8 k-steps, 4 pair-loads per column
-    v2f64 bcur[NCW][4], bnxt[NCW][4];
-    auto issue = [&](int64_t pr, v2f64 (&b)[NCW][4]) {
-        // plates 32 pr .. 32 pr + 31 of the chunk: n/8 = 4 pr + j
-        const double *base = XXf + ((pr * 4) * ((int64_t)PT * 64) + l) * 2;
+        for (int t = 0; t < 2; ++t) acc[i][t] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int64_t npair = (nsub_chunk + 1) / 2;     // 32 plates: 8 k-steps = 8 pair-loads
+    v2f64 bcur[8], bnxt[8];
+    auto issue = [&](int64_t pr, v2f64 (&b)[8]) {
+        // plates 32 pr .. 32 pr + 31 of the chunk: plate groups n/4 = 8 pr + ks
+        const double *base = XXf + (((pr * 8) * (int64_t)PT2 + cp) * 64 + l) * 2;
 #pragma unroll
-        for (int t = 0; t < NCW; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[t][j] = (c0 + t < PT) ? *reinterpret_cast<const v2f64 *>(
-                                              base + (((int64_t)j * PT + c0 + t) * 64) * 2)
-                                        : v2f64{0.0, 0.0};
+        for (int ks = 0; ks < 8; ++ks)
+            b[ks] = (cp < PT2) ? *reinterpret_cast<const v2f64 *>(base + ((int64_t)ks * PT2 * 64) * 2)
+                               : v2f64{0.0, 0.0};
     };
     int64_t pr = wg;
     if (pr < npair) issue(pr, bcur);
@@ -1332,30 +1262,24 @@ mpca_stats2_kernel(const uint32_t *__restrict__ Mb2, const double *__restrict__ 
         const uint32_t mw1 = (2 * pr + 1 < nsub_chunk) ? Mb2[(s0 + 1) * 64 + l] : 0u;
         if (pr + nwg < npair) issue(pr + nwg, bnxt);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int ks = 0; ks < 8; ++ks) {
+            const int qq = ks & 3;                              // k-step inside its subtile
+            const uint32_t mw = (ks < 4) ? mw0 : mw1;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int qq = (2 * j + e) & 3;                     // k-step inside its subtile
-                const uint32_t mw = (j < 2) ? mw0 : mw1;
-#pragma unroll
-                for (int i = 0; i < DT; ++i) {
-                    const double am = (double)((mw >> (4 * i + qq)) & 1u);
-#pragma unroll
-                    for (int t = 0; t < NCW; ++t)
-                        acc[i][t] = mfma(am, e ? bcur[t][j].y : bcur[t][j].x, acc[i][t]);
-                }
+            for (int i = 0; i < DT; ++i) {
+                const double am = (double)((mw >> (4 * i + qq)) & 1u);
+                acc[i][0] = mfma(am, bcur[ks].x, acc[i][0]);
+                acc[i][1] = mfma(am, bcur[ks].y, acc[i][1]);
             }
         }
 #pragma unroll
-        for (int t = 0; t < NCW; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bcur[t][j] = bnxt[t][j];
+        for (int ks = 0; ks < 8; ++ks) bcur[ks] = bnxt[ks];
     }
     double *pb = partial + (int64_t)wg * DP * LR;
 #pragma unroll
     for (int i = 0; i < DT; ++i)
 #pragma unroll
-        for (int t = 0; t < NCW; ++t) {
+        for (int t = 0; t < 2; ++t) {
             const int c = c0 + t;
             if (c < PT) {
 #pragma unroll
@@ -1683,7 +1607,7 @@ mpca_unpack_kernel(const double *__restrict__ XXf, int PT, int K, int64_t nplate
         const int64_t n = e / (K * K);
         const int ij = (int)(e - n * K * K), i = ij / K, j = ij - i * K;
         const int a = i > j ? i : j, b = i > j ? j : i, p = tri(a, b);
-        out[e] = XXf[(((n >> 3) * PT + (p >> 4)) * 64 + (n & 3) * 16 + (p & 15)) * 2 + ((n >> 2) & 1)];
+        out[e] = XXf[xxf_base(n, PT) + xxf_off(p)];
     }
 }
 
@@ -1732,7 +1656,7 @@ int32_t vmp_mpca_sizes(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t ch
     out->mask_words = (ntiles > 0 ? ntiles : 1) * 2 * 64;
     out->xm_doubles = (ntiles > 0 ? ntiles : 1) * TN * m.KP;
     out->lam_doubles = chunk * m.LR;
-    out->xxf_doubles = ((chunk + 7) / 8) * m.PT * 128;
+    out->xxf_doubles = ((chunk + 3) / 4) * ((m.PT + 1) / 2) * 128;
     // partial sums: mpca_stats (workgroups x DP x LR), sweep / prepare scalars
     const int64_t gst = grid_cap(ctx, 2) / stats_slices(m);
     int64_t p = gst * m.DP * m.LR;
@@ -1869,11 +1793,11 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         if (K == 4 * NBV)                                                                          \
             hipLaunchKernelGGL((mpca_blk4_kernel<NBV, true>), dim3((unsigned)gs), dim3(NT), 0, s,  \
                                Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
-                               inspect ? 0 : 1, pscal, psxx);                                      \
+                               inspect ? 0 : 1, pscal, psxx, vmp_tune_get("mpca_blk4_dbg", 0));    \
         else                                                                                       \
             hipLaunchKernelGGL((mpca_blk4_kernel<NBV, false>), dim3((unsigned)gs), dim3(NT), 0, s, \
                                Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
-                               inspect ? 0 : 1, pscal, psxx);                                      \
+                               inspect ? 0 : 1, pscal, psxx, vmp_tune_get("mpca_blk4_dbg", 0));    \
         break;
         switch (nb) {
             MPCA_BLK4(1) MPCA_BLK4(2) MPCA_BLK4(3) MPCA_BLK4(4)
@@ -1923,7 +1847,7 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     {
         // packed columns: column tiles split over the wavefronts; r_d: its own small kernel.
         // Both write disjoint columns of the same per-workgroup partial rows.
-        const int ncw = vmp_tune_get("mpca_stats_ncw", 2);
+        constexpr int ncw = 2;
         const int ns2 = (m.PT + 4 * ncw - 1) / (4 * ncw);
         const int64_t npair = (nsub + 1) / 2;
         int64_t gw = grid_cap(ctx, cs.wgs_stats) / ns2;
@@ -1934,12 +1858,8 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         const dim3 grid((unsigned)(gw * ns2));
 #define MPCA_CASE(db, kt)                                                                       \
     if (m.DP == 32 * db && m.KT == kt) {                                                        \
-        if (ncw == 2)                                                                           \
-            hipLaunchKernelGGL((mpca_stats2_kernel<db, kt, 2>), grid, dim3(NT), 0, s, Mb2, XXf, \
-                               sub0, nsub, ns2, partial);                                       \
-        else                                                                                    \
-            hipLaunchKernelGGL((mpca_stats2_kernel<db, kt, 3>), grid, dim3(NT), 0, s, Mb2, XXf, \
-                               sub0, nsub, ns2, partial);                                       \
+        hipLaunchKernelGGL((mpca_stats2_kernel<db, kt>), grid, dim3(NT), 0, s, Mb2, XXf, sub0,  \
+                           nsub, ns2, partial);                                                 \
         hipLaunchKernelGGL((mpca_ryx_kernel<db, kt>), dim3((unsigned)gw), dim3(NT), 0, s, Ymt,  \
                            Xm, n0 / TN, (nplates + TN - 1) / TN, partial, m.LR, 16 * m.PT);     \
     } else
@@ -2000,7 +1920,7 @@ int32_t vmp_mpca_x_pass(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t c
     const mpca_dims m = make_dims(D, K);
     vmp_mpca_layout L;
     fill_layout(D, K, &L);
-    const int64_t lam_n = chunk * m.LR, xxf_n = ((chunk + 7) / 8) * m.PT * 128;
+    const int64_t lam_n = chunk * m.LR, xxf_n = ((chunk + 3) / 4) * ((m.PT + 1) / 2) * 128;
     const bool pipelined = nsets == 2 && N > chunk && !(flags & VMP_MPCA_INSPECT)
                            && vmp_tune_get("mpca_streams", 1) != 0;
     if (!pipelined) {

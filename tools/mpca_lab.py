@@ -42,11 +42,16 @@ def main():
         return Q, X
 
     variants = [
-        (1 << 20, dict(mpca_blk4=0)),
-        (1 << 20, dict(mpca_blk4=1)),
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_wgs=1)),
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_wgs=2)),
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=0)),
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=1)),      # no LDS atomics
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=2 + 8)),  # no <xx> stores
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=3 + 8)),  # neither
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=4)),      # no sweep
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=7 + 8)),  # gather + <x> + prefetch only
+        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=0)),
     ]
+    if os.environ.get('MPCA_LAB_ONE'):
+        variants = variants[:1]
     print('N=%d D=%d K=%d; ms per X.update(), per-chunk kernel times (HIP events), bound after two '
           'iterations' % (N, D, K))
     for chunk, knobs in variants:
