@@ -57,6 +57,17 @@ __host__ __device__ inline int64_t xxf_base(int64_t n, int PT)
     return ((n >> 2) * ((PT + 1) / 2) * 64 + (n & 3) * 16) * 2;
 }
 
+__device__ __forceinline__ double mfma4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true);
+}
+
 struct mpca_dims {
     int D, K, DP, KP, DQ, DT, KT, P, PT, CT, LR;
 };
@@ -246,66 +257,129 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
     // add to the matrix time).
     static_assert(4 * (CW - 1) <= PT && PT + KT <= 4 * CW, "the <w> tiles sit in the last slot");
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l15 = l & 15, l4 = l >> 4;
+    const int l4 = l >> 4;
     const int c_last = w + 4 * (CW - 1);
     const int kind = c_last >= CT ? 0 : (c_last >= PT ? 2 : 1);
     const int64_t ngroups = (nsub_chunk + NSUB - 1) / NSUB;
     // B fragments: panel + ((c (DQ/2) + q2) 64 + l) 2 doubles; the lane part is the only VGPR term
-    const char *pl = reinterpret_cast<const char *>(panel) + (size_t)l * 16;
+    // (a 32-bit offset beside a scalar base: 64-bit vector addresses cost two registers per tile)
+    const char *pl = reinterpret_cast<const char *>(panel);
+    const uint32_t loff = (uint32_t)l * 16u;
     constexpr size_t TILE_B = (size_t)(DQ / 2) * 64 * 16;      // bytes of one column tile
+    // v_mfma_f64_4x4x4_4b_f64 (round 3): the four blocks are the four 4-column groups of a column
+    // tile (B operand unchanged: lane = column + 16 k), the A operand is the mask of the plate
+    // group R (plates 16 sub + 4 R + i) replicated over the blocks = the mask word of lane
+    // 4 R + i + 16 k, and a 16 x 16 result tile is four registers, one per R.
+    int src[4];
+#pragma unroll
+    for (int R = 0; R < 4; ++R) src[R] = 4 * ((l & 0x30) | (4 * R) | (l & 3));
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        v4f64 acc[CW][NSUB];
+        double acc[CW][NSUB][4];
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci)
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) acc[ci][s] = v4f64{0.0, 0.0, 0.0, 0.0};
-        uint32_t mw[NSUB];
+            for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                for (int R = 0; R < 4; ++R) acc[ci][s][R] = 0.0;
+        uint32_t mr[NSUB][4], mown[NSUB];
         const double *yb[NSUB];
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            const int64_t sub = sub0 + grp * NSUB + s;         // global 16-plate subtile
             const bool ok = (grp * NSUB + s) < nsub_chunk;
-            mw[s] = ok ? Mb1[sub * 64 + l] : 0u;
+            // global 16-plate subtile (one beyond the chunk: any valid one, its mask word is zero)
+            const int64_t sub = sub0 + (ok ? grp * NSUB + s : grp * NSUB);
+            const uint32_t mw = ok ? Mb1[sub * 64 + l] : 0u;
+            mown[s] = mw;
+#pragma unroll
+            for (int R = 0; R < 4; ++R)
+                mr[s][R] = (uint32_t)__builtin_amdgcn_ds_bpermute(src[R], (int)mw);
             // Ymt element (d = 4q + l4, n = 16 sub + l15): tile = sub/2, column (sub&1)*16 + l15
-            yb[s] = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l4 * TN + (sub & 1) * 16 + l15;
+            yb[s] = Ymt + (sub >> 1) * ((int64_t)DP * TN) + (int64_t)l4 * TN + (sub & 1) * 16 + (l & 15);
         }
         auto kloop = [&](auto KIND) {
             constexpr int LASTK = decltype(KIND)::value;          // 0 none, 1 mask, 2 m*y
             constexpr int NC = LASTK ? CW : CW - 1;
+            constexpr int NC4 = LASTK == 1 ? CW : CW - 1;         // slots on the 4x4x4 instruction
             const char *pw = pl + (size_t)w * TILE_B;
-#pragma unroll 2
+            // ONE buffer of B fragments, refilled slot by slot: within a step (two k-steps) the
+            // column slots are the outer loop, so the fragment of slot ci is dead after its 16
+            // MFMAs and the fragment of the NEXT step is requested into the same registers right
+            // there -- it has the other slots' MFMAs (~0.9 us) to arrive.  (Two alternating buffers
+            // spill: 144 accumulator + 2 x 36 fragment registers; and left to the compiler the
+            // loads of a step sit in front of their first use and every step pays the L2 latency.)
+            v2f64 bf[NC];
+            double yc[2][NSUB];
+            v4f64 accw[NSUB];                   // a <w> tile (last slot, kind 2): 16x16x4 form
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) accw[s] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci)
+                bf[ci] = *reinterpret_cast<const v2f64 *>(pw + (size_t)(4 * ci) * TILE_B + loff);
+            if (LASTK == 2) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int s = 0; s < NSUB; ++s) yc[e][s] = yb[s][(int64_t)(4 * e) * TN];
+            }
+#pragma unroll 1
             for (int q2 = 0; q2 < DQ / 2; ++q2) {
-                v2f64 b[NC];
+                const int q2n = q2 + 1 < DQ / 2 ? q2 + 1 : q2;
+                double am[2][NSUB][4];
 #pragma unroll
-                for (int ci = 0; ci < NC; ++ci)
-                    b[ci] = *reinterpret_cast<const v2f64 *>(pw + (size_t)(4 * ci) * TILE_B
-                                                             + (size_t)q2 * (64 * 16));
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int q = 2 * q2 + e;
-                    double am[NSUB], al[NSUB];
+                    for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-                    for (int s = 0; s < NSUB; ++s) {
-                        am[s] = (double)((mw[s] >> q) & 1u);
-                        // masked entries of Ymt are zero already; subtiles beyond the chunk have a
-                        // zero mask word and must not contribute either
-                        if (LASTK == 2) al[s] = (mw[s] >> q) & 1u ? yb[s][(int64_t)(4 * q) * TN] : 0.0;
-                        else al[s] = am[s];
-                    }
+                        for (int R = 0; R < 4; ++R)
+                            am[e][s][R] = (double)((mr[s][R] >> (2 * q2 + e)) & 1u);
 #pragma unroll
-                    for (int ci = 0; ci < NC; ++ci) {
-                        const double bb = e ? b[ci].y : b[ci].x;
+                for (int ci = 0; ci < NC4; ++ci) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
 #pragma unroll
                         for (int s = 0; s < NSUB; ++s)
-                            acc[ci][s] = mfma((ci == CW - 1) ? al[s] : am[s], bb, acc[ci][s]);
-                    }
+#pragma unroll
+                            for (int R = 0; R < 4; ++R)
+                                acc[ci][s][R] = mfma4(am[e][s][R], e ? bf[ci].y : bf[ci].x,
+                                                      acc[ci][s][R]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf[ci] = *reinterpret_cast<const v2f64 *>(pw + (size_t)(4 * ci) * TILE_B
+                                                              + (size_t)q2n * (64 * 16) + loff);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (LASTK == 2) {
+                    // masked entries of Ymt are zero already; subtiles beyond the chunk have a zero
+                    // mask word and must not contribute either
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s) {
+                            const double al = ((mown[s] >> (2 * q2 + e)) & 1u) ? yc[e][s] : 0.0;
+                            accw[s] = mfma(al, e ? bf[CW - 1].y : bf[CW - 1].x, accw[s]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf[CW - 1] = *reinterpret_cast<const v2f64 *>(pw + (size_t)(4 * (CW - 1)) * TILE_B
+                                                                  + (size_t)q2n * (64 * 16) + loff);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s)
+                            yc[e][s] = yb[s][(int64_t)(4 * (2 * q2n + e)) * TN];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (LASTK == 2) {
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[CW - 1][s][r] = accw[s][r];
             }
         };
         if (kind == 2) kloop(std::integral_constant<int, 2>{});
         else if (kind == 1) kloop(std::integral_constant<int, 1>{});
         else kloop(std::integral_constant<int, 0>{});
-        // C/D layout: row (plate) = (l>>4) + 4 r, column = l&15
+        // result layout of the 4x4x4 instruction: row (plate) 4 R + (l >> 4), column l & 15 of the
+        // tile; of the 16x16x4 one: row (l >> 4) + 4 r
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci) {
             const int c = w + 4 * ci;
@@ -313,10 +387,11 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t n = (grp * NSUB + s) * 16 + l4 + 4 * r;   // plate in the chunk
+                    for (int R = 0; R < 4; ++R) {
+                        const bool wt = (ci == CW - 1) && kind == 2;
+                        const int64_t n = (grp * NSUB + s) * 16 + (wt ? l4 + 4 * R : 4 * R + l4);
                         if (n < nplates_chunk)
-                            __builtin_nontemporal_store(acc[ci][s][r], &Lam[n * LR + 16 * c + l15]);
+                            __builtin_nontemporal_store(acc[ci][s][R], &Lam[n * LR + 16 * c + (l & 15)]);
                     }
             }
         }
@@ -869,17 +944,6 @@ mpca_rows_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
 // the matrix core (36 MFMAs), the other half on the vector ALU (28 FMAs + quad reductions);
 // <x x^T> = Cov + <x><x>^T with the column form of <x> from one more transpose per block row.
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ double mfma4(double a, double b, double c)
-{
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x)
-{
-    return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true);
-}
-
 __host__ __device__ constexpr int bidx(int I, int J) { return I * (I + 1) / 2 + J; }
 
 // One sweep over pivot block p of the NB x NB block matrix S (lower block triangle).
@@ -996,7 +1060,7 @@ __global__ void __launch_bounds__(NT, 2)
 mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chunk, int K,
                  double x_prec, const double *__restrict__ tau_ptr, double *__restrict__ XXf,
                  double *__restrict__ Xm, int write_x, double *__restrict__ partial,
-                 double *__restrict__ partial_sxx, int dbg)
+                 double *__restrict__ partial_sxx)
 {
     constexpr int KT = NB <= 4 ? 1 : 2, KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
     constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2;
@@ -1110,7 +1174,7 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         if (more) fetch(q + gstep, half0{});
         double prod = 1.0, ld = 0.0;
         int bad = 0;
-        if (!(dbg & 4)) blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto pc) {
+        blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto pc) {
             constexpr int pp = decltype(pc)::value;
             if constexpr (pp == PA) {
                 if (more) {
@@ -1166,10 +1230,8 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
                 if (!FULLK && I == NB - 1) v = (padr || (J == NB - 1 && padc)) ? 0.0 : v;
                 if (valid && (I > J || li >= lj)) {
                     const int pk = blk4_pk<I, J>(lc);
-                    if (!(dbg & 2)) xb[xxf_off(pk)] = v;
-                    if (!(dbg & 1))
-                        __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (dbg & 8) pm += v;
+                    xb[xxf_off(pk)] = v;
+                    __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             });
             if (4 * NB < KP) {
@@ -1225,6 +1287,13 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
 // operands (16 bytes per lane = the two tiles of the pair for one k-step of four plates, XXf
 // order) are loaded by no other wavefront, the A operand is the mask bit of (d, n) -- no loads at
 // all.  r_d comes from mpca_ryx_kernel.
+// (Round 3: the same GEMM on v_mfma_f64_4x4x4_4b_f64 -- the form mpca_lambda and the per-plate
+// stage now use -- was built and measured here: 4.1 ms per 2^20 plates against 3.5.  A wavefront of
+// this kernel owns two column tiles, so every mask operand (one v_bfe + v_cvt) feeds only two of
+// the short instructions where it feeds two long ones here, and at two wavefronts per SIMD the
+// vector instructions do not hide under the matrix ones: tools/mfma4_lab.hip, "bfe + cvt + 2
+// mfma4x4x4, VGPR acc" = 10.1 ns per instruction against 7.2 bare.  mpca_lambda amortises each mask
+// operand over nine column tiles.)
 // -------------------------------------------------------------------------------------------
 template <int DB, int KT>
 __global__ void __launch_bounds__(NT, 2)
@@ -1793,11 +1862,11 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         if (K == 4 * NBV)                                                                          \
             hipLaunchKernelGGL((mpca_blk4_kernel<NBV, true>), dim3((unsigned)gs), dim3(NT), 0, s,  \
                                Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
-                               inspect ? 0 : 1, pscal, psxx, vmp_tune_get("mpca_blk4_dbg", 0));    \
+                               inspect ? 0 : 1, pscal, psxx);                                      \
         else                                                                                       \
             hipLaunchKernelGGL((mpca_blk4_kernel<NBV, false>), dim3((unsigned)gs), dim3(NT), 0, s, \
                                Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
-                               inspect ? 0 : 1, pscal, psxx, vmp_tune_get("mpca_blk4_dbg", 0));    \
+                               inspect ? 0 : 1, pscal, psxx);                                      \
         break;
         switch (nb) {
             MPCA_BLK4(1) MPCA_BLK4(2) MPCA_BLK4(3) MPCA_BLK4(4)

@@ -26,7 +26,8 @@ __global__ void __launch_bounds__(64) probe(double *out)
         }
 }
 
-enum { K_FMA = 0, K_M4, K_M16, K_MIX_M4_FMA, K_MIX_M16_FMA, K_DPP_FMA, K_LDS_FMA, K_MIX_M4_DPP };
+enum { K_FMA = 0, K_M4, K_M16, K_MIX_M4_FMA, K_MIX_M16_FMA, K_DPP_FMA, K_LDS_FMA, K_MIX_M4_DPP,
+       K_M4_LDS2, K_M4_LDS1, K_M4_BITS, K_M4_VAR, K_M4_VAR16, K_M16_VAR, K_M4_VGPR, K_M4_VGPR_BITS };
 
 template <int KIND>
 __global__ void __launch_bounds__(256) loop(double *out, int iters)
@@ -77,6 +78,58 @@ __global__ void __launch_bounds__(256) loop(double *out, int iters)
                 x[2 * i] = __builtin_fma(r.x, b, x[2 * i]);
                 x[2 * i + 1] = __builtin_fma(r.y, b, x[2 * i + 1]);
             }
+        } else if (KIND == K_M4_LDS2) {
+            // A operand of two MFMAs from one ds_read_b64 (16 distinct values, each read by 4 lanes)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double av = sh[((it + i) & 7) * 40 + (l >> 4) * 20 + (l & 3) + 4 * (i & 3)];
+                m[2 * i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b, m[2 * i], 0, 0, 0);
+                m[2 * i + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a, m[2 * i + 1], 0, 0, 0);
+            }
+        } else if (KIND == K_M4_LDS1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double av = sh[((it + i) & 7) * 40 + (l >> 4) * 20 + (l & 3) + 4 * (i & 3)];
+                m[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b, m[i], 0, 0, 0);
+            }
+        } else if (KIND == K_M4_BITS) {
+            // A operand from a mask bit: bfe + cvt per two MFMAs
+            const unsigned mw = (unsigned)(it * 2654435761u) ^ (unsigned)l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double av = (double)((mw >> (4 * i + (it & 3))) & 1u);
+                m[2 * i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b, m[2 * i], 0, 0, 0);
+                m[2 * i + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, a, m[2 * i + 1], 0, 0, 0);
+            }
+        } else if (KIND == K_M4_VAR) {
+            // distinct A / B registers per instruction (no operand repeats back to back)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                m[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[(i * 3) & 7], x[(i * 5 + 1) & 7], m[i], 0, 0, 0);
+        } else if (KIND == K_M4_VAR16) {
+            // 16 accumulators, A changes every 2 instructions, B alternates (the GEMM stage pattern)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                m[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[i], a, m[i], 0, 0, 0);
+                acc[i >> 1][2 * (i & 1)] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[i], b, acc[i >> 1][2 * (i & 1)], 0, 0, 0);
+            }
+        } else if (KIND == K_M16_VAR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[i + 4], acc[i], 0, 0, 0);
+        } else if (KIND == K_M4_VGPR) {
+            // accumulators forced into VGPRs (the compiler's choice in the 2-waves-per-SIMD kernels)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(m[i]) : "v"(x[i]), "v"(b));
+        } else if (KIND == K_M4_VGPR_BITS) {
+            const unsigned mw = (unsigned)(it * 2654435761u) ^ (unsigned)l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double av = (double)((mw >> (4 * i + (it & 3))) & 1u);
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(m[2 * i]) : "v"(av), "v"(b));
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(m[2 * i + 1]) : "v"(av), "v"(a));
+            }
         } else if (KIND == K_MIX_M4_DPP) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -89,6 +142,58 @@ __global__ void __launch_bounds__(256) loop(double *out, int iters)
     for (int i = 0; i < 8; ++i) s += x[i] + m[i];
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[(size_t)blockIdx.x * 256 + l] = s;
+}
+
+// the inner loop of the GEMM stages: NA x 2 accumulators, A operand from a mask bit per pair of
+// instructions, B operands from registers; BITS = 0: A operand from a register instead
+template <int NA, int BITS>
+__global__ void __launch_bounds__(256, 2) gemm_loop(double *out, int iters)
+{
+    const int l = threadIdx.x;
+    double acc[NA][2];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i][0] = acc[i][1] = 0.0;
+    double bx[4], by[4], ar[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bx[k] = 1.0 + l * 1e-3 * (k + 1);
+        by[k] = 1.0 - l * 1e-3 * (k + 1);
+        ar[k] = (l >> k) & 1;
+    }
+    for (int it = 0; it < iters; ++it) {
+        const unsigned mw = (unsigned)(it * 2654435761u) ^ (unsigned)(l * 40503u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const double am = BITS ? (double)((mw >> ((i + 7 * k) & 31)) & 1u) : ar[(i + k) & 3];
+                acc[i][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, bx[k], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, by[k], acc[i][1], 0, 0, 0);
+            }
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s += acc[i][0] + acc[i][1];
+    out[(size_t)blockIdx.x * 256 + l] = s;
+}
+
+template <int NA, int BITS>
+static void run_gemm(const char *name, double *out, int wpsimd)
+{
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    gemm_loop<NA, BITS><<<256 * wpsimd, 256>>>(out, 10);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    gemm_loop<NA, BITS><<<256 * wpsimd, 256>>>(out, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s waves/SIMD %d  %8.3f ms   %7.2f ns per mfma per SIMD\n", name, wpsimd, ms,
+           ms * 1e6 / ((double)wpsimd * iters * 8 * NA));
 }
 
 template <int KIND>
@@ -161,9 +266,21 @@ int main()
             printf("\n");
         }
     if (getenv("LAB_PROBE_ONLY")) return 0;
+    if (getenv("LAB_GEMM")) {
+        double *og = out + 64 * 64 * 64;
+        run_gemm<8, 0>("gemm loop 16 acc, A from registers", og, 2);
+        run_gemm<8, 1>("gemm loop 16 acc, A from mask bits", og, 2);
+        run_gemm<16, 0>("gemm loop 32 acc, A from registers", og, 2);
+        run_gemm<16, 1>("gemm loop 32 acc, A from mask bits", og, 2);
+        run_gemm<32, 0>("gemm loop 64 acc, A from registers", og, 2);
+        run_gemm<32, 1>("gemm loop 64 acc, A from mask bits", og, 2);
+        run_gemm<36, 1>("gemm loop 72 acc, A from mask bits", og, 2);
+        return 0;
+    }
+    const int wmin = getenv("LAB_W4") ? 2 : 1;
     // ---- (2), (3) issue costs -----------------------------------------------------------------
     double *o2 = out + 64 * 64 * 64;
-    for (int w = 1; w <= 4; w *= 2) {
+    for (int w = wmin; w <= 4; w *= 2) {
         run<K_FMA>("v_fma_f64 x8", o2, 8, 0, w);
         run<K_M4>("mfma_f64_4x4x4_4b x8", o2, 8, 0, w);
         run<K_M16>("mfma_f64_16x16x4 x4", o2, 4, 0, w);
@@ -172,6 +289,14 @@ int main()
         run<K_DPP_FMA>("8 x (v_mov_b64_dpp + v_fma_f64)", o2, 8, 8, w);
         run<K_LDS_FMA>("4 x (ds_read_b128 + 2 v_fma_f64)", o2, 8, 4, w);
         run<K_MIX_M4_DPP>("8 x (mfma4x4x4 + v_mov_b64_dpp)", o2, 8, 8, w);
+        run<K_M4_LDS2>("4 x (ds_read_b64 + 2 mfma4x4x4)", o2, 8, 4, w);
+        run<K_M4_LDS1>("8 x (ds_read_b64 + mfma4x4x4)", o2, 8, 8, w);
+        run<K_M4_BITS>("4 x (bfe + cvt + 2 mfma4x4x4)", o2, 8, 8, w);
+        run<K_M4_VAR>("mfma4x4x4 x8, distinct A/B regs", o2, 8, 0, w);
+        run<K_M4_VAR16>("mfma4x4x4 x16, A per pair, B alternating", o2, 16, 0, w);
+        run<K_M16_VAR>("mfma16x16x4 x4, distinct A/B regs", o2, 4, 0, w);
+        run<K_M4_VGPR>("mfma4x4x4 x8, VGPR accumulators", o2, 8, 0, w);
+        run<K_M4_VGPR_BITS>("4 x (bfe + cvt + 2 mfma4x4x4), VGPR acc", o2, 8, 8, w);
     }
     return 0;
 }

@@ -42,16 +42,13 @@ def main():
         return Q, X
 
     variants = [
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=0)),
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=1)),      # no LDS atomics
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=2 + 8)),  # no <xx> stores
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=3 + 8)),  # neither
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=4)),      # no sweep
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=7 + 8)),  # gather + <x> + prefetch only
-        (1 << 20, dict(mpca_blk4=1, mpca_blk4_dbg=0)),
+        (1 << 20, dict(mpca_blk4=0)),       # round 2's per-plate stage (16x16x4 sweep form)
+        (1 << 20, dict(mpca_blk4=1)),       # 4x4x4 block sweep, four plates per wavefront
+        (1 << 20, dict(mpca_blk4=0)),
+        (1 << 20, dict(mpca_blk4=1)),
     ]
     if os.environ.get('MPCA_LAB_ONE'):
-        variants = variants[:1]
+        variants = variants[1:2]
     print('N=%d D=%d K=%d; ms per X.update(), per-chunk kernel times (HIP events), bound after two '
           'iterations' % (N, D, K))
     for chunk, knobs in variants:
