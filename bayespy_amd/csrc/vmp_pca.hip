@@ -309,7 +309,14 @@ sum_partials_kernel(const double *__restrict__ partial, int n, double *__restric
 // instruction covers 1 KB of consecutive addresses (lane l reads bytes 16 l .. 16 l + 15 of
 // k-step q's 1 KB) instead of four 256-byte row segments that lie ldy*8 bytes apart.
 // LAY bit 1: X is tile-major as well ([tile][KP][32]); every store instruction writes 1 KB.
-template <int DB, int KT, bool GUARD, int OCC, int NTM = 0, int LAY = 0>
+// MF = 1 (round 3): the product on v_mfma_f64_4x4x4_4b_f64 -- four independent 4 x 4 x 4 blocks
+// per instruction, 1.4-1.5x the flop rate of the 16x16x4 form on this chip (tools/mfma4_lab.hip).
+// The blocks are the four 4-column groups of a 16-column half tile, so the B operand is the SAME
+// 16 bytes of Y as before (lane = column pair + 16 k); the A operand is the fragment of the
+// component group R (rows 16 it + 4 R + i of A) replicated over the blocks -- element
+// 16 (l >> 4) + 4 R + (l & 3) of the (it, q) fragment in LDS -- and a result register holds rows
+// 4 R + (l >> 4), i.e. exactly the rows register r = R held before: the stores are unchanged.
+template <int DB, int KT, bool GUARD, int OCC, int NTM = 0, int LAY = 0, int MF = 0>
 __global__ void __launch_bounds__(NT, OCC)
 pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
                  const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
@@ -336,7 +343,7 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
     }
     __syncthreads();
 
-    const double *Afl = Af + l;
+    const double *Afl = MF ? Af + 16 * l4 + (l & 3) : Af + l;
     // per-lane byte offsets (32-bit; the host checks 3*ld*8 + 256 < 2^32): the
     // wave-uniform part of every address stays in SGPRs
     const uint32_t yoff = (uint32_t)(((int64_t)l4 * ldy + 2 * l15) * 8);
@@ -407,9 +414,18 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
                 const v2f64 b = buf[c & 1][i];
 #pragma unroll
                 for (int it = 0; it < KT; ++it) {
-                    const double a = Afl[(it * KS + q) * 64];
-                    acc[it][0] = mfma_f64(a, b.x, acc[it][0]);
-                    acc[it][1] = mfma_f64(a, b.y, acc[it][1]);
+                    if (MF) {
+#pragma unroll
+                        for (int R = 0; R < 4; ++R) {
+                            const double a = Afl[(it * KS + q) * 64 + 4 * R];
+                            acc[it][0][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.x, acc[it][0][R], 0, 0, 0);
+                            acc[it][1][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.y, acc[it][1][R], 0, 0, 0);
+                        }
+                    } else {
+                        const double a = Afl[(it * KS + q) * 64];
+                        acc[it][0] = mfma_f64(a, b.x, acc[it][0]);
+                        acc[it][1] = mfma_f64(a, b.y, acc[it][1]);
+                    }
                 }
             }
         }
@@ -781,6 +797,7 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
     const int64_t nfast = lay ? ntiles : (exact ? (padded ? ntiles : N / TN) : 0);
     const int occ = xpass_occupancy();
     const int ntm = vmp_tune_get("xpass_nt", env_int("VMP_PCA_XPASS_NT", 3, 0, 3));
+    const int mf4 = vmp_tune_get("xpass_mfma4", env_int("VMP_PCA_XPASS_MFMA4", 0, 0, 1));
     hipStream_t m = ctx->stream;
     // VMP_PCA_PLATE_STREAM=0: everything in order on the caller's stream (A/B measurements)
     const int overlap = vmp_tune_get("plate_stream", env_int("VMP_PCA_PLATE_STREAM", 1, 0, 1));
@@ -826,9 +843,14 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
 #define VMP_XP(db, kt, gd, oc, nt, ly)                                                          \
     hipLaunchKernelGGL((pca_xpass_kernel<db, kt, gd, oc, nt, ly>), grid, dim3(NT), 0, s, Y, ldy, \
                        N, D, K, A, X, ldx, t0, t1)
+#define VMP_XP4(db, kt, oc, ly)                                                                  \
+    hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, oc, 3, ly, 1>), grid, dim3(NT), 0, s, Y,  \
+                       ldy, N, D, K, A, X, ldx, t0, t1)
 #define VMP_CASE(db, kt)                                                                        \
     if (DB == db && KT == kt) {                                                                 \
         if (guard) VMP_XP(db, kt, true, 2, 0, 0);                                               \
+        else if (mf4 && lay == 1 && ntm == 3) VMP_XP4(db, kt, 2, 1);                            \
+        else if (mf4 && lay == 0 && ntm == 3) VMP_XP4(db, kt, 2, 0);                            \
         else if (lay == 3 && kt < 4 && ntm == 3) VMP_XP(db, kt, false, 3, 3, 3);                \
         else if (lay == 3 && kt < 4) VMP_XP(db, kt, false, 3, 0, 3);                            \
         else if (lay == 3) VMP_XP(db, kt, false, 2, 0, 3);                                      \
@@ -845,6 +867,7 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
             return VMP_ERR_UNSUPPORTED;
         }
 #undef VMP_CASE
+#undef VMP_XP4
 #undef VMP_XP
         VMP_HIP_CHECK(ctx, hipGetLastError());
     }

@@ -99,6 +99,50 @@ __global__ void __launch_bounds__(256) stream_r4w1(const v2f64 *in, v2f64 *out, 
     }
 }
 
+// the same 4:1 mix with the READS as LDS-DMA (global_load_lds_dwordx4: 1 KB per wavefront
+// instruction, HBM -> LDS without passing the registers; MI355X_MICROARCH.md quotes 6.4-6.8 TB/s
+// for such streams).  A wavefront keeps DEPTH output blocks (4 KB of reads each) in flight in a
+// private LDS ring; counted vmcnt waits (5 memory operations per block: 4 DMA reads + 1 store).
+template <int DEPTH, bool NTL>
+__global__ void __launch_bounds__(512) stream_r4w1_dma(const v2f64 *in, v2f64 *out, size_t nout)
+{
+    extern __shared__ __attribute__((aligned(16))) v2f64 ring[];      // [4 waves][DEPTH][4][64]
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v2f64 *my = ring + (size_t)w * DEPTH * 256;
+    const int nw = blockDim.x >> 6;
+    const size_t nblk = nout / 64, stride = (size_t)gridDim.x * nw, first = (size_t)blockIdx.x * nw + w;
+    auto issue = [&](size_t blk, int slot) {
+        const size_t bb = blk < nblk ? blk : nblk - 1;       // beyond the end: a redundant re-load
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(in + j * nout + bb * 64 + l),
+                (__attribute__((address_space(3))) void *)(my + (slot * 4 + j) * 64), 16, 0, NTL ? 2 : 0);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(first + d * stride, d);
+    const uint32_t rd = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) v2f64 *)(my + l);
+    for (size_t blk0 = first; blk0 < nblk; blk0 += DEPTH * stride) {
+#pragma unroll
+        for (int sl = 0; sl < DEPTH; ++sl) {
+            const size_t blk = blk0 + sl * stride;
+            // (DEPTH - 1) newer blocks are in flight behind this one: 5 operations each ...
+            // (the first DEPTH - 1 waits of the kernel see fewer stores: they only wait longer)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH > 1 ? 5 * (DEPTH - 1) - (DEPTH - 1) : 0) : "memory");
+            v2f64 a, b, c, d;
+            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                         "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                         : "v"(rd), "n"(sl * 4096), "n"(sl * 4096 + 1024), "n"(sl * 4096 + 2048),
+                           "n"(sl * 4096 + 3072)
+                         : "memory");
+            if (blk < nblk) __builtin_nontemporal_store((a + b) + (c + d), out + blk * 64 + l);
+            issue(blk + DEPTH * stride, sl);
+        }
+    }
+}
+
 template <typename F>
 float time_ms(F f, int reps)
 {
@@ -117,6 +161,7 @@ float time_ms(F f, int reps)
 
 int main()
 {
+    const bool stream_only = getenv("MB_STREAM_ONLY") != nullptr;
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s, CUs %d, clock %d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
@@ -132,6 +177,7 @@ int main()
                name, nacc, wgs, scale == 0.0 ? "zero" : "nonzero", flops / ms / 1e9,
                (double)cyc / ((double)iters * nacc * wgs), (double)cyc / (ms * 1e3));
     };
+    if (!stream_only)
     for (double scale : {1.0, 0.0}) {
         for (int wgs = 1; wgs <= 4; wgs *= 2) {
             int grid = p.multiProcessorCount * wgs;
@@ -143,7 +189,7 @@ int main()
             report("mfma_f64_16x16x4", 8, wgs, ms, scale);
         }
     }
-    {
+    if (!stream_only) {
         int grid = p.multiProcessorCount * 8;
         float ms = time_ms([&] { hipLaunchKernelGGL(fma_loop, dim3(grid), dim3(256), 0, 0, out, iters); }, 3);
         double flops = (double)grid * 256 * iters * 8 * 2.0;
@@ -169,11 +215,29 @@ int main()
     {
         // 4:1 read:write stream (the plate pass of PCA at D=128, K=32): 4 GB read, 1 GB written
         const size_t nout = n / 4;
-        for (int g = 1024; g <= 8192; g *= 2) {
+        for (int g = 256; g <= 8192; g *= 2) {
             float m1 = time_ms([&] { hipLaunchKernelGGL(stream_r4w1<false>, dim3(g), dim3(256), 0, 0, a, b, nout); }, 5);
             float m2 = time_ms([&] { hipLaunchKernelGGL(stream_r4w1<true>, dim3(g), dim3(256), 0, 0, a, b, nout); }, 5);
             printf("grid %5d: 4:1 read:write stream %.0f GB/s, nontemporal %.0f GB/s\n", g,
                    1.25 * bytes / m1 / 1e6, 1.25 * bytes / m2 / 1e6);
+        }
+    }
+    {
+        // the same mix with LDS-DMA reads (round 3): workgroups per CU x wavefronts per workgroup x
+        // blocks in flight per wavefront
+        const size_t nout = n / 4;
+        for (int g : {128, 256, 512}) {
+            for (int nw : {2, 4, 8}) {
+                const int nt = 64 * nw;
+                float m1 = time_ms([&] { hipLaunchKernelGGL((stream_r4w1_dma<1, true>), dim3(g), dim3(nt), nw * 1 * 4096, 0, a, b, nout); }, 5);
+                float m2 = time_ms([&] { hipLaunchKernelGGL((stream_r4w1_dma<2, true>), dim3(g), dim3(nt), nw * 2 * 4096, 0, a, b, nout); }, 5);
+                float m3 = time_ms([&] { hipLaunchKernelGGL((stream_r4w1_dma<3, true>), dim3(g), dim3(nt), nw * 3 * 4096, 0, a, b, nout); }, 5);
+                float m4 = time_ms([&] { hipLaunchKernelGGL((stream_r4w1_dma<4, true>), dim3(g), dim3(nt), nw * 4 * 4096, 0, a, b, nout); }, 5);
+                float m2p = time_ms([&] { hipLaunchKernelGGL((stream_r4w1_dma<2, false>), dim3(g), dim3(nt), nw * 2 * 4096, 0, a, b, nout); }, 5);
+                printf("grid %4d x %d waves: 4:1 read:write, LDS-DMA reads nt: depth 1 %.0f, 2 %.0f, 3 %.0f, 4 %.0f GB/s; depth 2 plain %.0f GB/s\n",
+                       g, nw, 1.25 * bytes / m1 / 1e6, 1.25 * bytes / m2 / 1e6, 1.25 * bytes / m3 / 1e6,
+                       1.25 * bytes / m4 / 1e6, 1.25 * bytes / m2p / 1e6);
+            }
         }
     }
     return 0;
