@@ -316,8 +316,17 @@ sum_partials_kernel(const double *__restrict__ partial, int n, double *__restric
 // component group R (rows 16 it + 4 R + i of A) replicated over the blocks -- element
 // 16 (l >> 4) + 4 R + (l & 3) of the (it, q) fragment in LDS -- and a result register holds rows
 // 4 R + (l >> 4), i.e. exactly the rows register r = R held before: the stores are unchanged.
+// The A fragments take KT DB 4 KB of LDS: 128 KB at D = 256, K = 64 (one workgroup per CU), 64 KB
+// at D = 256, K <= 32 or D = 128, K = 64 (two).  The register budget asked of the compiler follows
+// that limit; the pass itself is as fast at one workgroup per CU as at four
+// (profiles/r03/xpass_lab_n1e7.txt: one wavefront per SIMD holds 8 KB of loads in flight).
+constexpr int xpass_occ(int DB, int KT, int OCC)
+{
+    return KT * DB * 4096 > 80 * 1024 ? 1 : (KT * DB * 4096 > 53 * 1024 ? (OCC < 2 ? OCC : 2) : OCC);
+}
+
 template <int DB, int KT, bool GUARD, int OCC, int NTM = 0, int LAY = 0, int MF = 0>
-__global__ void __launch_bounds__(NT, OCC)
+__global__ void __launch_bounds__(NT, xpass_occ(DB, KT, OCC))
 pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
                  const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
                  int64_t tile0, int64_t tile1)
@@ -389,8 +398,16 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
         }
     };
 
+    // STG (round 3, measured and left off): tile t starts at chunk t % NCH and wraps, so that
+    // wavefronts advancing in step do not sit exactly 32 KB apart.  A bare stream kernel with this
+    // tile pattern gains 6 % from it at one workgroup per CU (tools/microbench.hip, "tile
+    // pattern": 6.0 -> 6.4 TB/s); this kernel does not (profiles/r03/xpass_lab_n1e7.txt: 5.41
+    // against 5.51 TB/s on the same box), and the results would no longer be bit-identical to the
+    // in-order sum.
+    constexpr bool STG = false;
+    auto first_chunk = [&](int64_t t) { return STG ? (int)(t & (NCH - 1)) : 0; };
     int64_t tile = tile0 + (int64_t)blockIdx.x * 4 + w;
-    if (tile < tile1) issue(tile, 0, buf[0]);
+    if (tile < tile1) issue(tile, first_chunk(tile), buf[0]);
 
     for (; tile < tile1; tile += stride) {
         v4f64 acc[KT][2];
@@ -399,30 +416,32 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
             acc[it][0] = v4f64{0.0, 0.0, 0.0, 0.0};
             acc[it][1] = v4f64{0.0, 0.0, 0.0, 0.0};
         }
+        const int rot = first_chunk(tile);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             // prefetch the next chunk (the next tile's first chunk at the end) so
             // that its loads are in flight while this chunk's MFMAs run
-            if (c + 1 < NCH) issue(tile, c + 1, buf[(c + 1) & 1]);
-            else if (tile + stride < tile1) issue(tile + stride, 0, buf[(c + 1) & 1]);
+            const int cc = STG ? ((c + rot) & (NCH - 1)) : c;
+            if (c + 1 < NCH) issue(tile, STG ? ((c + 1 + rot) & (NCH - 1)) : c + 1, buf[(c + 1) & 1]);
+            else if (tile + stride < tile1) issue(tile + stride, first_chunk(tile + stride), buf[(c + 1) & 1]);
             // compiler-only barrier: keeps the fragment reads of A inside the loop
             // (otherwise all KT*KS of them are hoisted into spilled registers)
             asm volatile("" ::: "memory");
+            const double *Afc = Afl + cc * (CH * 64);
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int q = c * CH + i;
                 const v2f64 b = buf[c & 1][i];
 #pragma unroll
                 for (int it = 0; it < KT; ++it) {
                     if (MF) {
 #pragma unroll
                         for (int R = 0; R < 4; ++R) {
-                            const double a = Afl[(it * KS + q) * 64 + 4 * R];
+                            const double a = Afc[(it * KS + i) * 64 + 4 * R];
                             acc[it][0][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.x, acc[it][0][R], 0, 0, 0);
                             acc[it][1][R] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b.y, acc[it][1][R], 0, 0, 0);
                         }
                     } else {
-                        const double a = Afl[(it * KS + q) * 64];
+                        const double a = Afc[(it * KS + i) * 64];
                         acc[it][0] = mfma_f64(a, b.x, acc[it][0]);
                         acc[it][1] = mfma_f64(a, b.y, acc[it][1]);
                     }

@@ -143,6 +143,40 @@ __global__ void __launch_bounds__(512) stream_r4w1_dma(const v2f64 *in, v2f64 *o
     }
 }
 
+// The access pattern of the PCA plate pass on tile-major data: a wavefront owns whole 32 KB tiles
+// (32 load instructions of 1 KB, 8 in flight) and writes 8 KB per tile.  STAG: the wavefronts start
+// at different 8 KB chunks of their tiles (do lock-stepped wavefronts 32 KB apart collide on the
+// memory channels?).  SPLIT: the four wavefronts of a workgroup share ONE tile, 8 KB each.
+template <int STAG, int SPLIT>
+__global__ void __launch_bounds__(256) stream_tiles(const v2f64 *in, v2f64 *out, size_t ntiles)
+{
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t stride = SPLIT ? (size_t)gridDim.x : (size_t)gridDim.x * 4;
+    for (size_t t = SPLIT ? (size_t)blockIdx.x : (size_t)blockIdx.x * 4 + w; t < ntiles; t += stride) {
+        const v2f64 *src = in + t * 2048;                // 32 KB = 2048 16-byte units
+        v2f64 acc[2] = {v2f64{0, 0}, v2f64{0, 0}};
+        const int rot = STAG ? (int)((blockIdx.x * 4 + w) & 3) : 0;
+        const int c0 = SPLIT ? w : 0, c1 = SPLIT ? w + 1 : 4;
+        for (int c = c0; c < c1; ++c) {
+            const int cc = (c + rot) & 3;
+            v2f64 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(src + (cc * 8 + i) * 64 + l);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i & 1] += v[i];
+            if (SPLIT) {
+                __builtin_nontemporal_store(acc[0], out + t * 512 + c * 128 + l);
+                __builtin_nontemporal_store(acc[1], out + t * 512 + c * 128 + 64 + l);
+            }
+        }
+        if (!SPLIT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_nontemporal_store(acc[i & 1] * (double)(i + 1), out + t * 512 + i * 64 + l);
+        }
+    }
+}
+
 template <typename F>
 float time_ms(F f, int reps)
 {
@@ -223,6 +257,15 @@ int main()
         }
     }
     {
+        // the tile pattern of the plate pass (round 3)
+        const size_t ntiles = bytes / 32768;
+        for (int g : {256, 512, 768, 1024}) {
+            float m0 = time_ms([&] { hipLaunchKernelGGL((stream_tiles<0, 0>), dim3(g), dim3(256), 0, 0, a, b, ntiles); }, 5);
+            float m1 = time_ms([&] { hipLaunchKernelGGL((stream_tiles<1, 0>), dim3(g), dim3(256), 0, 0, a, b, ntiles); }, 5);
+            float m2 = time_ms([&] { hipLaunchKernelGGL((stream_tiles<0, 1>), dim3(g), dim3(256), 0, 0, a, b, ntiles); }, 5);
+            printf("grid %5d: 4:1 tile pattern (32 KB per wavefront): %.0f GB/s, staggered chunks %.0f GB/s, tile split over the 4 wavefronts %.0f GB/s\n",
+                   g, 1.25 * bytes / m0 / 1e6, 1.25 * bytes / m1 / 1e6, 1.25 * bytes / m2 / 1e6);
+        }
         // the same mix with LDS-DMA reads (round 3): workgroups per CU x wavefronts per workgroup x
         // blocks in flight per wavefront
         const size_t nout = n / 4;
