@@ -101,36 +101,51 @@ class GMMPlan:
                 "D <= 8, K <= 64")
 
     @staticmethod
-    def match(nodes):
+    def match(nodes, why=None):
+        def no(Y, msg):
+            if why is not None:
+                why.append('fused Gaussian-mixture block, observed node %s: %s'
+                           % (Y.name or '<unnamed>', msg))
         # mini-batch multipliers (stochastic VI) go through the generic engine
         if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
             return None
         for Y in nodes:
             if not isinstance(Y, Mixture) or Y.node_class is not Gaussian:
                 continue
-            if len(Y.parents) != 3 or len(Y.plates) != 1 or Y._mask is not True:
+            if len(Y.parents) != 3 or len(Y.plates) != 1:
+                no(Y, 'it needs plates (N,) and parents (z, mu, Lambda)')
+                continue
+            if Y._mask is not True:
+                no(Y, 'it has missing values')
                 continue
             z, mu, Lam = Y.parents
             if not (isinstance(z, Categorical) and isinstance(mu, GaussianARD)
                     and isinstance(Lam, Wishart)):
+                no(Y, 'its parents are not (Categorical, GaussianARD, Wishart)')
                 continue
             alpha = z.parents[0]
             if not (isinstance(alpha, Dirichlet) and all(p == 1 for p in alpha.plates)):
+                no(Y, 'the assignment prior is not one Dirichlet node')
                 continue
             N = Y.plates[0]
             K, D = Y.clusters, Y.dims[0][0]
             if D > 8 or K > 64:
+                no(Y, 'D = %d, K = %d exceed the limits of the block (D <= 8, K <= 64)' % (D, K))
                 continue
             if z.plates != (N,) or mu.plates != (K,) or Lam.plates != (K,) or mu.shape != (D,):
+                no(Y, 'plates of z / mu / Lambda are not (N,), (K,), (K,)')
                 continue
             m0, b0 = mu.parents
             if not (isinstance(m0, Constant) and not np.any(m0.value)
                     and isinstance(b0, Constant) and b0.is_scalar()):
+                no(Y, 'the prior of the means is not N(0, c I) with constants')
                 continue
             n0, V0 = Lam.parents
             if not (n0.is_scalar() and V0.value.shape == (D, D)):
+                no(Y, 'the Wishart prior is not (scalar degrees, one D x D scale)')
                 continue
             if any(len(n.children) != 1 for n in (z, mu, Lam, alpha)) or Y.children:
+                no(Y, 'one of its roles has other children as well')
                 continue
             return dict(Y=Y, z=z, mu=mu, Lambda=Lam, alpha=alpha)
         return None

@@ -134,7 +134,11 @@ class LSSMPlan:
         return None
 
     @staticmethod
-    def match(nodes):
+    def match(nodes, why=None):
+        def no(Y, msg):
+            if why is not None:
+                why.append('fused state-space block, observed node %s: %s'
+                           % (Y.name or '<unnamed>', msg))
         if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
             return None
         for Y in nodes:
@@ -155,6 +159,8 @@ class LSSMPlan:
             G, C = Q, P
             X = G.parents[0]
             if type(X) is not GaussianMarkovChain or len(X.plates) > 1:
+                no(Y, 'the chain is a %s with plates %s (a plain GaussianMarkovChain with at most '
+                      'one plate axis is needed)' % (type(X).__name__, tuple(X.plates)))
                 continue
             D, T = X.D, X.N
             mu, Lam, A, nu = X.parents
@@ -193,6 +199,8 @@ class LSSMPlan:
             except Exception:       # noqa: BLE001
                 continue
             if D > mx_d.value or M > mx_m.value or (M > 8 and D > 4):
+                no(Y, 'D = %d states, M = %d observed dimensions exceed the limits of the block '
+                      '(D <= %d with M <= 8, D <= 4 with M <= %d)' % (D, M, mx_d.value, mx_m.value))
                 continue
             priv = [C, gamma, X, A, alpha, tau, F, G] + ([nu_node] if nu_node is not None else [])
             if any(len(n.children) != 1 for n in priv):
@@ -200,7 +208,9 @@ class LSSMPlan:
             roles = dict(Y=Y, F=F, G=G, C=C, gamma=gamma, X=X, A=A, alpha=alpha, tau=tau)
             if nu_node is not None:
                 roles['nu'] = nu_node
-            if LSSMPlan.unsupported_state(roles) is not None:
+            bad = LSSMPlan.unsupported_state(roles)
+            if bad is not None:
+                no(Y, bad)
                 continue
             return roles
         return None

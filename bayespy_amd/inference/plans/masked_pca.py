@@ -122,15 +122,23 @@ class MaskedPCAPlan:
         return None
 
     @staticmethod
-    def match(nodes):
+    def match(nodes, why=None):
         roles = PCAPlan.match_graph(nodes)
         if roles is None:
             return None
         D, N = roles['Y'].plates
         K = roles['W'].shape[0]
-        if D > MaskedPCAPlan.MAX_D or K > MaskedPCAPlan.MAX_K:
+        if not roles['Y'].observed or roles['Y']._mask is True:
             return None
-        if not roles['Y'].observed or MaskedPCAPlan.unsupported_state(roles) is not None:
+        if D > MaskedPCAPlan.MAX_D or K > MaskedPCAPlan.MAX_K:
+            if why is not None:
+                why.append('fused missing-data PCA block: D = %d, K = %d exceed its limits D <= %d, '
+                           'K <= %d' % (D, K, MaskedPCAPlan.MAX_D, MaskedPCAPlan.MAX_K))
+            return None
+        bad = MaskedPCAPlan.unsupported_state(roles)
+        if bad is not None:
+            if why is not None:
+                why.append('fused missing-data PCA block: %s' % bad)
             return None
         return roles
 

@@ -190,15 +190,26 @@ class PCAPlan:
         return None
 
     @staticmethod
-    def match(nodes):
-        roles = PCAPlan.match_graph(nodes)
-        if roles is None or PCAPlan.unsupported_state(roles) is not None:
-            return None           # e.g. missing values, a fixed tau: other plans
+    def match(nodes, why=None):
+        roles = PCAPlan.match_graph(nodes, why)
+        if roles is None:
+            return None
+        bad = PCAPlan.unsupported_state(roles)
+        if bad is not None:           # e.g. missing values, a fixed tau: other plans
+            if why is not None and bad != 'Y has missing values':
+                why.append('fused PCA block: %s' % bad)
+            return None
         return roles
 
     @staticmethod
-    def match_graph(nodes):
-        """The graph pattern alone (shared with the missing-data block, plans/masked_pca.py)."""
+    def match_graph(nodes, why=None):
+        """The graph pattern alone (shared with the missing-data block, plans/masked_pca.py).
+        ``why``: a list that receives, for every node that looks like the observed node of this
+        block, the first condition it fails (compile_model reports them when a model that
+        resembles a fused block ends up on the generic engine)."""
+        def no(Y, msg):
+            if why is not None:
+                why.append('fused PCA block, observed node %s: %s' % (Y.name or '<unnamed>', msg))
         # mini-batch multipliers (stochastic VI) go through the generic engine
         if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
             return None
@@ -206,18 +217,26 @@ class PCAPlan:
             if not isinstance(Y, GaussianARD) or Y.ndim != 0:
                 continue
             F, tau = Y.parents
-            if not isinstance(F, SumMultiply) or not _gamma_with_const_parents(tau):
+            if not isinstance(F, SumMultiply):
+                continue
+            if not _gamma_with_const_parents(tau):
+                no(Y, 'its precision is not a Gamma node with constant parameters')
                 continue
             if len(F.parents) != 2 or F.out_keys != [] or F.in_keys[0] != F.in_keys[1] \
                     or len(F.in_keys[0]) != 1:
+                no(Y, "its mean is not SumMultiply('i,i', W, X) / Dot(W, X) of two nodes")
                 continue
             if any(p != 1 for p in tau.plates) or len(Y.plates) != 2:
+                no(Y, 'it needs plates (D, N) and a scalar precision (got plates %s, precision '
+                      'plates %s)' % (tuple(Y.plates), tuple(tau.plates)))
                 continue
             D, N = Y.plates
             A, B = F.parents
             if not (isinstance(A, GaussianARD) and isinstance(B, GaussianARD)):
+                no(Y, 'both factors must be GaussianARD nodes')
                 continue
             if A.ndim != 1 or B.ndim != 1 or A.shape != B.shape:
+                no(Y, 'both factors need the same shape (K,)')
                 continue
             pa, pb = _lead(A.plates, 2), _lead(B.plates, 2)
             if pa == (D, 1) and pb == (1, N):
@@ -225,18 +244,26 @@ class PCAPlan:
             elif pb == (D, 1) and pa == (1, N):
                 W, X = B, A
             else:
+                no(Y, 'the factors need plates (D, 1) and (1, N) (got %s and %s)'
+                      % (tuple(A.plates), tuple(B.plates)))
                 continue
             K = W.shape[0]
             alpha = W.parents[1]
-            if not (_const_zero(W.parents[0]) and _gamma_with_const_parents(alpha)):
+            if not _const_zero(W.parents[0]):
+                no(Y, 'the prior mean of %s is not the constant 0' % (W.name or 'W'))
                 continue
-            if _lead(alpha.plates, 1) != (K,):
+            if not _gamma_with_const_parents(alpha) or _lead(alpha.plates, 1) != (K,):
+                no(Y, 'the prior precision of %s is not a Gamma node with plates (K,) and '
+                      'constant parameters' % (W.name or 'W'))
                 continue
             if not (_const_zero(X.parents[0]) and _const_scalar(X.parents[1])):
+                no(Y, 'the prior of %s is not N(0, c I) with constants' % (X.name or 'X'))
                 continue
             # every role must be private to this block
-            if len(W.children) != 1 or len(X.children) != 1 or len(F.children) != 1 \
-                    or len(tau.children) != 1 or len(alpha.children) != 1:
+            shared = [n.name or type(n).__name__ for n in (W, X, F, tau, alpha)
+                      if len(n.children) != 1]
+            if shared:
+                no(Y, '%s has other children as well' % ', '.join(shared))
                 continue
             return dict(Y=Y, F=F, W=W, X=X, tau=tau, alpha=alpha)
         return None

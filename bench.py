@@ -54,7 +54,8 @@ def parse():
     p.add_argument('--cpu-sample-n', type=int, default=0,
                    help='columns of the CPU-baseline sample; 0 = the whole workload when the '
                         'host has the memory for it (direct parity at the metric size)')
-    p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'masked', 'lssm'], default='pca',
+    p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'masked', 'lssm', 'generic_pca',
+                                        'generic_gmm'], default='pca',
                    help="pca = the BASELINE.json metric (default); the others print the "
                         "secondary configurations of tools/workloads.py as the JSON line")
     p.add_argument('--no-extra', action='store_true',
@@ -232,6 +233,10 @@ def main():
         elif args.config == 'gmm':
             out = workloads.run_gmm(steps=args.steps, warmup=args.warmup,
                                     cpu_baseline=not args.no_cpu_baseline)
+        elif args.config == 'generic_pca':
+            out = workloads.run_generic_pca(cpu_baseline=not args.no_cpu_baseline)
+        elif args.config == 'generic_gmm':
+            out = workloads.run_generic_gmm(cpu_baseline=not args.no_cpu_baseline)
         elif args.config == 'masked':
             out = workloads.run_masked(steps=min(args.steps, 5), warmup=min(args.warmup, 1),
                                        cpu_baseline=not args.no_cpu_baseline)
@@ -368,6 +373,10 @@ def main():
                 run_extra('masked', workloads.run_masked, 120, steps=3, warmup=1,
                           cpu_baseline=not args.no_cpu_baseline),
                 run_extra('lssm', workloads.run_lssm, 120, steps=3, warmup=1,
+                          cpu_baseline=not args.no_cpu_baseline),
+                run_extra('generic_pca', workloads.run_generic_pca, 60,
+                          cpu_baseline=not args.no_cpu_baseline),
+                run_extra('generic_gmm', workloads.run_generic_gmm, 60,
                           cpu_baseline=not args.no_cpu_baseline),
             ]
         print(json.dumps(out))
