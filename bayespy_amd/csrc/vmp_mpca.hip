@@ -1063,8 +1063,9 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
                  double *__restrict__ partial_sxx)
 {
     constexpr int KT = NB <= 4 ? 1 : 2, KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
-    constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2;
+    constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2, PT2 = (PT + 1) / 2;
     constexpr int NPAIR = 4 * LRC / 2, NV = (NPAIR + 63) / 64;
+    static_assert(PT2 * 128 <= 4 * LRC, "a block row of XXf fits in the staging area");
     static_assert(4 * KP <= 128, "the four right-hand sides are one 16-byte pair per lane");
     // staging of one wavefront: four packed rows (matrix | right-hand side) as they lie in Lam, and
     // a copy of the four right-hand sides that outlives the rows (see the loop)
@@ -1094,54 +1095,43 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
     const bool padr = !FULLK && 4 * (NB - 1) + li >= K, padc = !FULLK && 4 * (NB - 1) + lj >= K;
     double pm = 1.0, le = 0.0;                   // product of the pivots of this lane's plates
     int anybad = 0;
-    // the packed rows of plates 4 q .. 4 q + 3, contiguous in Lam (rows beyond the chunk: zeros),
-    // in two halves of NH 16-byte pairs per lane so that only one half is held in registers
-    constexpr int NH = (NV + 1) / 2;
-    v2f64 nxt[NH];
-    auto fetch = [&](int64_t q, auto half) {
-        constexpr int H = decltype(half)::value;
+    // The packed rows of plates 4 q .. 4 q + 3, contiguous in Lam, travel HBM -> staging area as
+    // LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no registers; rows beyond the chunk:
+    // zeros).  Through registers -- requested before the stores of an iteration, parked after
+    // them -- the compiler spilled two thirds of the 36 registers to scratch in the loop, and that
+    // traffic (3 GB written, 3.6 GB read per 2^20 plates, profiles/r03/pmc_blk4_spill.txt) cost
+    // more than the latency the prefetch hid.
+    auto fetch = [&](int64_t q) {
         const int64_t left = nplates_chunk - 4 * q;
+        const int npair = left >= 4 ? NPAIR : (int)(left * (LRC / 2));
         const v2f64 *src = reinterpret_cast<const v2f64 *>(Lam + 4 * q * LRC);
-        if (left >= 4) {
+        if (left < 4) {
 #pragma unroll
-            for (int i = H * NH; i < NV && i < (H + 1) * NH; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int pidx = l + 64 * i;
-                nxt[i - H * NH] = (64 * (i + 1) <= NPAIR || pidx < NPAIR)
-                                      ? __builtin_nontemporal_load(src + pidx) : v2f64{0.0, 0.0};
-            }
-        } else {
-            const int npair = (int)(left * (LRC / 2));
-#pragma unroll
-            for (int i = H * NH; i < NV && i < (H + 1) * NH; ++i) {
-                const int pidx = l + 64 * i;
-                nxt[i - H * NH] = (pidx < npair) ? __builtin_nontemporal_load(src + pidx)
-                                                 : v2f64{0.0, 0.0};
+                if (pidx >= npair && pidx < NPAIR)
+                    reinterpret_cast<v2f64 *>(stg[w])[pidx] = v2f64{0.0, 0.0};
             }
         }
-    };
-    auto park = [&](auto half) {
-        constexpr int H = decltype(half)::value;
 #pragma unroll
-        for (int i = H * NH; i < NV && i < (H + 1) * NH; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int pidx = l + 64 * i;
-            if (64 * (i + 1) <= NPAIR || pidx < NPAIR)
-                reinterpret_cast<v2f64 *>(stg[w])[pidx] = nxt[i - H * NH];
+            if (pidx < npair)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + pidx),
+                    (__attribute__((address_space(3))) void *)(stg[w] + 128 * i), 16, 0, 2);
         }
     };
-    using half0 = std::integral_constant<int, 0>;
-    using half1 = std::integral_constant<int, 1>;
     const int64_t ngroups = (nplates_chunk + 3) / 4;
     const int64_t gstep = (int64_t)gridDim.x * 4;
     int64_t q = (int64_t)blockIdx.x * 4 + w;
-    if (q < ngroups) {
-        fetch(q, half0{});
-        park(half0{});
-        fetch(q, half1{});
-        park(half1{});
-    }
+    if (q < ngroups) fetch(q);
     __syncthreads();                              // sa zeroed
     const blk4_lane lc0 = lc;
     for (; q < ngroups; q += gstep) {
+        // the rows requested at the end of the previous iteration have landed in the staging area
+        // (LDS-DMA completes on vmcnt; the compiler does not order the reads below behind it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_fence();
         // the per-lane index constants are re-materialised every iteration: left loop-invariant,
         // the compiler hoists the 36 gather and the 36 store offsets of a lane out of the loop and
@@ -1168,24 +1158,10 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
             reinterpret_cast<v2f64 *>(hst[w])[l] =
                 reinterpret_cast<const v2f64 *>(stg[w] + (l / (KP / 2)) * LRC + 16 * PT)[l % (KP / 2)];
         lds_fence();
-        // ... the next four rows can travel HBM -> registers -> the (now free) staging area
-        // during the pivot steps, one half after the other
-        constexpr int PA = NB >= 6 ? 1 : 0, PB = NB >= 6 ? 3 : (NB >= 2 ? 1 : 0);
-        if (more) fetch(q + gstep, half0{});
+        // ... the staging area is free: it collects this iteration's <x x^T> in XXf order below
         double prod = 1.0, ld = 0.0;
         int bad = 0;
-        blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto pc) {
-            constexpr int pp = decltype(pc)::value;
-            if constexpr (pp == PA) {
-                if (more) {
-                    park(half0{});
-                    fetch(q + gstep, half1{});
-                }
-            }
-            if constexpr (pp == PB) {
-                if (more) park(half1{});
-            }
-        });
+        blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto) {});
         // ---- <x> = Cov (tau rhs), Cov = -S ---------------------------------------------------------
         double hq[NB], hr[NB];                    // tau rhs at the lane's column / row index
 #pragma unroll
@@ -1222,28 +1198,49 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         }
         // ---- <x x^T> = Cov + <x><x>^T; stores ----------------------------------------------------
         {
-            // this wavefront's plates 4 q .. 4 q + 3 own the whole block row q of XXf
-            double *xb = XXf + xxf_base(4 * q + lb, PT);
+            // This wavefront's plates 4 q .. 4 q + 3 own the whole block row q of XXf (PT2 blocks
+            // of 1 KB).  The row is assembled in the staging area and leaves as whole 16-byte
+            // lanes, 1 KB per instruction: written from the registers as 8-byte scatters (two
+            // stores of two different blocks complete a 16-byte slot) the lines reached the HBM
+            // controllers partially filled on most boxes of the pool -- 6.1 GB written and 5.8 GB
+            // read per 2^20 plates for 4.7 + 4.9 (profiles/r03/pmc_blk4_scatter.txt), 3.3 ms
+            // against 2.3 on the boxes where the L2 happened to merge them.
+            double *ob = stg[w];
             blk4_for_blocks<NB, 0, 0>([&](auto Ic, auto Jc) {
                 constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
                 double v = __builtin_fma(xrow[I], xcol[J], -S[bidx(I, J)]);
                 if (!FULLK && I == NB - 1) v = (padr || (J == NB - 1 && padc)) ? 0.0 : v;
-                if (valid && (I > J || li >= lj)) {
+                if (I > J || li >= lj) {
                     const int pk = blk4_pk<I, J>(lc);
-                    xb[xxf_off(pk)] = v;
-                    __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ob[lb * 32 + xxf_off(pk)] = v;
+                    if (valid)
+                        __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             });
+            // packed entries beyond the data: block rows K/4 .. KP/4 - 1 and the padding of the
+            // last tile pair (mpca_stats reads whole tiles)
             if (4 * NB < KP) {
-                // block rows beyond the last one that holds data: zeros (mpca_stats reads whole tiles)
 #pragma unroll
                 for (int I = NB; I < KP / 4; ++I)
 #pragma unroll
                     for (int J = 0; J <= I; ++J) {
                         const int r = 4 * I + li, c = 4 * J + lj;
                         const int pk = tri(r > c ? r : c, r > c ? c : r);
-                        if (valid && (I > J || li >= lj)) xb[xxf_off(pk)] = 0.0;
+                        if (I > J || li >= lj) ob[lb * 32 + xxf_off(pk)] = 0.0;
                     }
+            }
+            for (int pk = P + (l & 15); pk < 32 * PT2; pk += 16) ob[(l >> 4) * 32 + xxf_off(pk)] = 0.0;
+            lds_fence();
+            v2f64 *xo = reinterpret_cast<v2f64 *>(XXf + q * ((int64_t)PT2 * 128)) + l;
+#pragma unroll
+            for (int i0 = 0; i0 < PT2; i0 += 4) {
+                v2f64 t[4];
+#pragma unroll
+                for (int i = i0; i < PT2 && i < i0 + 4; ++i)
+                    t[i - i0] = reinterpret_cast<const v2f64 *>(ob)[i * 64 + l];
+#pragma unroll
+                for (int i = i0; i < PT2 && i < i0 + 4; ++i) xo[i * 64] = t[i - i0];
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (valid && write_x && lj == 0) {
                 double *xr = Xm + (n0 + 4 * q + lb) * KP;
@@ -1260,6 +1257,8 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
                 anybad |= bad;
             }
         }
+        lds_fence();
+        if (more) fetch(q + gstep);
     }
     // per-workgroup partials: tr<xx> = trace of the accumulated sum, log|Cov|, status
     __syncthreads();
@@ -1356,6 +1355,119 @@ mpca_stats2_kernel(const uint32_t *__restrict__ Mb2, const double *__restrict__ 
                     pb[(int64_t)(16 * i + l4 + 4 * r) * LR + 16 * c + l15] = acc[i][t][r];
             }
         }
+}
+
+// -------------------------------------------------------------------------------------------
+// mpca_stats3: the same GEMM on v_mfma_f64_4x4x4_4b_f64 (round 3), shaped so that the mask
+// operand pays: a wavefront owns 2 row tiles (32 rows d) and NP PAIRS of column tiles, so every
+// mask operand (one v_bfe + v_cvt per 4 rows x 4 plates) feeds 2 NP of the short instructions
+// (two in the column-split form above, where that form lost to the 16x16x4 instruction).  The four
+// wavefronts of a workgroup take the four quarters of the rows and read the SAME B fragments
+// (XXf pair order: 16 bytes per lane = one k-step of a tile pair; the second to fourth reader hit
+// the caches).  The blocks of the instruction are the 4-column groups of a tile -- B operand as
+// stored --, the A operand is the mask of rows 16 dt + 4 R + i replicated over the blocks = the
+// mask word of lane 4 R + i + 16 k, fetched once per 16 plates (ds_bpermute).  B fragments: a
+// window of four k-steps in registers, each slot refilled (four k-steps ahead) right after its
+// last use; mask words one 32-plate step ahead; all loads unconditional from clamped indices.
+// -------------------------------------------------------------------------------------------
+template <int DB, int KT, int NP>
+__global__ void __launch_bounds__(NT, 2)
+mpca_stats3_kernel(const uint32_t *__restrict__ Mb2, const double *__restrict__ XXf, int64_t sub0,
+                   int64_t nsub_chunk, int nslices, double *__restrict__ partial)
+{
+    constexpr int DP = 32 * DB, DT = DP / 16, DTW = (DT + 3) / 4;
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
+    constexpr int PT2 = (PT + 1) / 2, LR = 16 * CT;
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = blockIdx.x % nslices, wg = blockIdx.x / nslices, nwg = gridDim.x / nslices;
+    const int cp0 = slice * NP;                     // first tile pair of this workgroup
+    const int dt0 = w * DTW;                        // first row tile of this wavefront
+    if (dt0 >= DT) return;
+    double acc[DTW][4][NP][2];
+#pragma unroll
+    for (int i = 0; i < DTW; ++i)
+#pragma unroll
+        for (int R = 0; R < 4; ++R)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) acc[i][R][pp][0] = acc[i][R][pp][1] = 0.0;
+    const int64_t npair = (nsub_chunk + 1) / 2;     // 32 plates: 8 k-steps
+    int cpl[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) cpl[pp] = cp0 + pp < PT2 ? cp0 + pp : PT2 - 1;
+    auto frag = [&](int64_t pr, int ks, int pp) {
+        // plates 32 pr .. 32 pr + 31 of the chunk: plate groups n/4 = 8 pr + ks
+        return *reinterpret_cast<const v2f64 *>(
+            XXf + (((pr * 8 + ks) * (int64_t)PT2 + cpl[pp]) * 64 + l) * 2);
+    };
+    auto masks = [&](int64_t pr, uint32_t (&m)[2]) {
+        const int64_t s0 = sub0 + 2 * pr;
+        const int64_t s1 = (2 * pr + 1 < nsub_chunk) ? s0 + 1 : s0;
+        m[0] = Mb2[s0 * 64 + l];
+        m[1] = Mb2[s1 * 64 + l];
+    };
+    int src[4];
+#pragma unroll
+    for (int R = 0; R < 4; ++R) src[R] = 4 * ((l & 0x30) | (4 * R) | (l & 3));
+    v2f64 bf[4][NP];
+    uint32_t mcur[2], mnxt[2];
+    int64_t pr = wg;
+    if (pr < npair) {
+        masks(pr, mcur);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) bf[ks][pp] = frag(pr, ks, pp);
+    }
+    for (; pr < npair; pr += nwg) {
+        const int64_t prn = pr + nwg < npair ? pr + nwg : pr;
+        masks(prn, mnxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * pr + 1 >= nsub_chunk) mcur[1] = 0u;     // an odd last subtile has no second half
+        uint32_t mr[2][4];
+#pragma unroll
+        for (int R = 0; R < 4; ++R) {
+            mr[0][R] = (uint32_t)__builtin_amdgcn_ds_bpermute(src[R], (int)mcur[0]) >> (4 * dt0);
+            mr[1][R] = (uint32_t)__builtin_amdgcn_ds_bpermute(src[R], (int)mcur[1]) >> (4 * dt0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int qq = ks & 3;                              // k-step inside its subtile
+#pragma unroll
+            for (int i = 0; i < DTW; ++i)
+#pragma unroll
+                for (int R = 0; R < 4; ++R) {
+                    const double am = (double)((mr[ks >> 2][R] >> (4 * i + qq)) & 1u);
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) {
+                        acc[i][R][pp][0] = mfma4(am, bf[ks & 3][pp].x, acc[i][R][pp][0]);
+                        acc[i][R][pp][1] = mfma4(am, bf[ks & 3][pp].y, acc[i][R][pp][1]);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+                bf[ks & 3][pp] = ks < 4 ? frag(pr, ks + 4, pp) : frag(prn, ks - 4, pp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mcur[0] = mnxt[0];
+        mcur[1] = mnxt[1];
+    }
+    // result layout of the instruction: row 4 R + (l >> 4), column l & 15 of the tile
+    double *pb = partial + (int64_t)wg * DP * LR;
+#pragma unroll
+    for (int i = 0; i < DTW; ++i)
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int c = 2 * (cp0 + pp) + t;
+                if (cp0 + pp < PT2 && c < PT && dt0 + i < DT) {
+#pragma unroll
+                    for (int R = 0; R < 4; ++R)
+                        pb[(int64_t)(16 * (dt0 + i) + 4 * R + (l >> 4)) * LR + 16 * c + (l & 15)] =
+                            acc[i][R][pp][t];
+                }
+            }
 }
 
 // r_d = sum_n (m y)_dn <x_n>: the message product of the fully observed block on the masked data
@@ -1916,8 +2028,12 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     {
         // packed columns: column tiles split over the wavefronts; r_d: its own small kernel.
         // Both write disjoint columns of the same per-workgroup partial rows.
-        constexpr int ncw = 2;
-        const int ns2 = (m.PT + 4 * ncw - 1) / (4 * ncw);
+        // default: mpca_stats3 (4x4x4 instruction, a wavefront owns 32 rows x 3 tile pairs);
+        // vmp_tune_set("mpca_stats3", 0): the 16x16x4 column-split form
+        const int use3 = vmp_tune_get("mpca_stats3", 1);
+        constexpr int NP3 = 3;
+        const int pt2 = (m.PT + 1) / 2;
+        const int ns2 = use3 ? (pt2 + NP3 - 1) / NP3 : (m.PT + 7) / 8;
         const int64_t npair = (nsub + 1) / 2;
         int64_t gw = grid_cap(ctx, cs.wgs_stats) / ns2;
         if (gw > gst_wg) gw = gst_wg;
@@ -1927,8 +2043,12 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
         const dim3 grid((unsigned)(gw * ns2));
 #define MPCA_CASE(db, kt)                                                                       \
     if (m.DP == 32 * db && m.KT == kt) {                                                        \
-        hipLaunchKernelGGL((mpca_stats2_kernel<db, kt>), grid, dim3(NT), 0, s, Mb2, XXf, sub0,  \
-                           nsub, ns2, partial);                                                 \
+        if (use3)                                                                               \
+            hipLaunchKernelGGL((mpca_stats3_kernel<db, kt, NP3>), grid, dim3(NT), 0, s, Mb2,    \
+                               XXf, sub0, nsub, ns2, partial);                                  \
+        else                                                                                    \
+            hipLaunchKernelGGL((mpca_stats2_kernel<db, kt>), grid, dim3(NT), 0, s, Mb2, XXf,    \
+                               sub0, nsub, ns2, partial);                                       \
         hipLaunchKernelGGL((mpca_ryx_kernel<db, kt>), dim3((unsigned)gw), dim3(NT), 0, s, Ymt,  \
                            Xm, n0 / TN, (nplates + TN - 1) / TN, partial, m.LR, 16 * m.PT);     \
     } else

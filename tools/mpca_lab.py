@@ -29,6 +29,7 @@ def main():
 
     def build(chunk):
         os.environ['BAYESPY_AMD_MPCA_CHUNK'] = str(chunk)
+        os.environ['BAYESPY_AMD_MPCA_PIPELINE'] = '1'
         alpha = Gamma(1e-2, 1e-2, plates=(K,))
         W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1))
         X = GaussianARD(0, 1, shape=(K,), plates=(1, N))
@@ -42,13 +43,14 @@ def main():
         return Q, X
 
     variants = [
-        (1 << 20, dict(mpca_blk4=0)),       # round 2's per-plate stage (16x16x4 sweep form)
-        (1 << 20, dict(mpca_blk4=1)),       # 4x4x4 block sweep, four plates per wavefront
-        (1 << 20, dict(mpca_blk4=0)),
-        (1 << 20, dict(mpca_blk4=1)),
+        (1 << 20, dict(mpca_streams=0)),
+        (1 << 20, dict(mpca_streams=1, mpca_lambda_wgs=2, mpca_sweep_wgs=2, mpca_stats_wgs=2)),
+        (1 << 19, dict(mpca_streams=1, mpca_lambda_wgs=2, mpca_sweep_wgs=2, mpca_stats_wgs=2)),
+        (1 << 19, dict(mpca_streams=0)),
+        (1 << 20, dict(mpca_streams=1, mpca_lambda_wgs=1, mpca_sweep_wgs=2, mpca_stats_wgs=1)),
     ]
     if os.environ.get('MPCA_LAB_ONE'):
-        variants = variants[1:2]
+        variants = variants[:1]
     print('N=%d D=%d K=%d; ms per X.update(), per-chunk kernel times (HIP events), bound after two '
           'iterations' % (N, D, K))
     for chunk, knobs in variants:
@@ -68,7 +70,7 @@ def main():
         plan.enable_timing(False)
         print('chunk %8d %-40s %8.2f ms  %s  L=%r' % (
             chunk, knobs, 1e3 * dt,
-            ' '.join('%s=%.3f' % (k, v) for k, v in km.items() if k != 'chunk_plates'), Q.L[1]))
+            ' '.join('%s=%.3f' % (k, v) for k, v in (km or {}).items() if k != 'chunk_plates'), Q.L[1]))
         del Q, X, plan
 
 
