@@ -417,6 +417,13 @@ class MaskedPCAPlan:
         k = self.kernels
         D, N, K = self.D, self.N, self.K
         n1 = N if n1 is None else n1
+        need = 8.0 * (max(n1 - n0, 0) + min(self.chunk_eff, N)) * K * K
+        free = self.rt.torch.cuda.mem_get_info(self.rt.device)[0] if self.rt.device.type == 'cuda' \
+            else float('inf')
+        if need > 0.9 * free:
+            raise MemoryError('the (n, K, K) second moments of plates [%d, %d) need %.1f GB on the '
+                              'device (%.1f GB free); ask for a smaller plate range (ADVICE r02)'
+                              % (n0, n1, need / 1e9, free / 1e9))
         out = self.rt.empty(max(n1 - n0, 0), K, K)
         init = self.X._init
         fresh = getattr(self, '_x_updated', False)

@@ -137,8 +137,14 @@ class VB:
         from .checkpoint import Reader
         r = Reader(filename)
         try:
-            return {k[len('user_data/'):]: np.array(r.get(k)) for k in r.keys()
-                    if k.startswith('user_data/')}
+            out = {k[len('user_data/'):]: np.array(r.get(k)) for k in r.keys()
+                   if k.startswith('user_data/')}
+            import json
+            for k in r.keys():
+                if k.startswith('user_data_json/'):
+                    out[k[len('user_data_json/'):]] = json.loads(
+                        bytes(np.asarray(r.get(k), dtype=np.uint8)).decode('utf-8'))
+            return out
         finally:
             r.close()
 
@@ -233,7 +239,23 @@ class VB:
             w.put('boundterms/' + n.name, self.l[n])
         if self.user_data is not None:
             for key, value in self.user_data.items():
-                w.put('user_data/%s' % key, np.asarray(value))
+                # numeric / string arrays as arrays; anything else (dicts, None, mixed lists) as
+                # JSON text -- an object array would be pickled by np.savez and could not be read
+                # back by the reader (allow_pickle=False)
+                try:
+                    arr = np.asarray(value)
+                except Exception:       # noqa: BLE001 -- ragged input
+                    arr = None
+                if arr is not None and arr.dtype != object:
+                    w.put('user_data/%s' % key, arr)
+                    continue
+                import json
+                try:
+                    text = json.dumps(value)
+                except (TypeError, ValueError):
+                    raise TypeError('user_data[%r] is neither an array nor JSON-serialisable; '
+                                    'it cannot be stored in a checkpoint' % key)
+                w.put('user_data_json/%s' % key, np.frombuffer(text.encode('utf-8'), dtype=np.uint8))
         w.close()
 
     def load(self, *nodes, filename=None, nodes_only=False):

@@ -166,7 +166,8 @@ def test_checkpoint_round_trip(golden_dir, tmp_path):
     # set_autosave / user_data (vmp.py:121-126, :286-305); the save happens in the end-of-iteration
     # step, i.e. also on the iteration that converges
     fn3 = str(tmp_path / 'auto3.bin')
-    Q4 = build_pca(nodes, VB, g['y'], g['x0'], 3, user_data={'seed': 7, 'note': np.arange(3.0)})
+    Q4 = build_pca(nodes, VB, g['y'], g['x0'], 3,
+                   user_data={'seed': 7, 'note': np.arange(3.0), 'cfg': {'a': [1, 'x'], 'b': None}})
     _attach_cpu(Q4)
     Q4.set_autosave(fn3, iterations=1, nodes=[Q4['W'], Q4['tau'], Q4['alpha'], Q4['X'], Q4['Y']])
     Q4.ignore_bound_checks = False
@@ -174,6 +175,7 @@ def test_checkpoint_round_trip(golden_dir, tmp_path):
     assert Q4.converged and os.path.exists(fn3)
     ud = VB.load_user_data(fn3)
     assert int(ud['seed']) == 7 and np.array_equal(ud['note'], np.arange(3.0))
+    assert ud['cfg'] == {'a': [1, 'x'], 'b': None}          # non-array values travel as JSON
     Q5 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
     Q5.load(filename=fn3)
     assert Q5.iter == Q4.iter and Q5.converged
