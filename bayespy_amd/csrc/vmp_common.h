@@ -11,6 +11,8 @@
 
 #define VMP_EV_RING 64
 
+constexpr int VMP_NME = 16;     // side-stream events of a context (vmp_mpca / vmp_lssm pipelines)
+
 struct vmp_ctx {
     int device;
     hipStream_t stream;
@@ -32,7 +34,7 @@ struct vmp_ctx {
     int xs_cus;                // compute units the plate stream may use
     // streams / events of the pipelined plate pass of the missing-data PCA block (vmp_mpca.hip)
     hipStream_t ms[3];
-    hipEvent_t me[8];
+    hipEvent_t me[VMP_NME];
     // RCCL communicator (vmp_comm.hip); null = a world of one rank
     void *comm;
     int comm_rank, comm_world;

@@ -71,7 +71,7 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     ctx->ev_xbuf[0] = ctx->ev_xbuf[1] = nullptr;
     ctx->xs_cus = 0;
     for (int i = 0; i < 3; ++i) ctx->ms[i] = nullptr;
-    for (int i = 0; i < 8; ++i) ctx->me[i] = nullptr;
+    for (int i = 0; i < VMP_NME; ++i) ctx->me[i] = nullptr;
     ctx->comm = nullptr;
     ctx->comm_rank = 0;
     ctx->comm_world = 1;
@@ -98,7 +98,7 @@ int32_t vmp_ctx_destroy(vmp_ctx *ctx)
             (void)hipStreamSynchronize(ctx->ms[i]);
             (void)hipStreamDestroy(ctx->ms[i]);
         }
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < VMP_NME; ++i)
         if (ctx->me[i]) (void)hipEventDestroy(ctx->me[i]);
     if (ctx->ev_xfork) (void)hipEventDestroy(ctx->ev_xfork);
     if (ctx->ev_xdone) (void)hipEventDestroy(ctx->ev_xdone);

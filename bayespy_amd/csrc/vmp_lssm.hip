@@ -281,9 +281,13 @@ __device__ inline bool stationary(double a, double b, bool act)
 // phase bit 0: forward recursion (S^-1, J, log|Phi|, status); bit 1: backward recursion (V_t,
 // Cov(x_t, x_t+1) and their sums).  Only the forward half is needed by the per-sequence passes,
 // so vmp_lssm_x_update runs the backward half on a side stream beside them.
+// Forward steps [t0, t1) per launch (round 3): the per-sequence forward sweep consumes J_t in time
+// order, so vmp_lssm_x_update cuts both recursions into segments and runs segment k + 1 of this
+// kernel beside segment k of the sweep.  The state between launches (S_t, the running pivot
+// product, status, the stationarity marker, "finished") lives in sums[4 D^2 ..] / sums[5 D^2 + 4 ..].
 template <int D>
 __global__ void __launch_bounds__(64)
-lssm_cov_kernel(cov_args a, int phase)
+lssm_cov_kernel(cov_args a, int phase, int t0, int t1)
 {
     const int l = threadIdx.x, T = a.T;
     const bool act = l < D * D;
@@ -301,6 +305,17 @@ lssm_cov_kernel(cov_args a, int phase)
     double s = act ? a.Dg0[i * D + j] : 0.0;
     int fix_from = -1;                 // steps fix_from .. T-2 share one (S^-1, J)
     if (!(phase & 1)) fix_from = (int)a.sums[5 * D * D + 2];       // left by the forward launch
+    if ((phase & 1) && t0 > 0) {
+        // a later segment: an earlier one that found the stationary stretch has finished the
+        // whole recursion already
+        if (a.sums[5 * D * D + 6] != 0.0) return;
+        s = act ? a.sums[4 * D * D + l] : 0.0;
+        prod = a.sums[5 * D * D + 4];
+        ex = a.sums[5 * D * D + 5];
+        bad = (int)a.sums[5 * D * D + 1];
+        fix_from = (int)a.sums[5 * D * D + 2];
+    }
+    int tend = t1 < T ? t1 : T;
     // D = 4: the constant operand E is fetched once: E[k][j] and E[k][i] for this lane
     double ekj[4] = {0.0, 0.0, 0.0, 0.0}, eki[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (D == 4) {
@@ -309,7 +324,7 @@ lssm_cov_kernel(cov_args a, int phase)
         eki[0] = col_get4<0>(e, i); eki[1] = col_get4<1>(e, i);
         eki[2] = col_get4<2>(e, i); eki[3] = col_get4<3>(e, i);
     }
-    for (int t = 0; (phase & 1) && t < T; ++t) {
+    for (int t = t0; (phase & 1) && t < tend; ++t) {
         double p1 = 1.0, e1 = 0.0;
         double sinv;
         if constexpr (D == 4) {
@@ -338,18 +353,19 @@ lssm_cov_kernel(cov_args a, int phase)
             const double snew = ((t + 1 < T - 1) ? dgm : dgT) - ej;
             // (tested every eighth step: the test itself is a 64-lane max reduction on the serial path)
             if (t >= 1 && (t & 7) == 0 && t + 1 < T - 1 && stationary(snew, s, act)) {
-                const int t1 = T - 2;                                   // last interior step
-                for (int tt = t + 1; tt <= t1; ++tt) {
+                const int tl = T - 2;                                   // last interior step
+                for (int tt = t + 1; tt <= tl; ++tt) {
                     if (act) {
                         a.Sinv[(int64_t)tt * D * D + l] = sinv;
                         a.J[(int64_t)tt * D * D + l] = jt;
                     }
                 }
-                // (t1 - t) more copies of this step's pivots
-                ex += (double)(t1 - t) * (e1 + log2(p1));
+                // (tl - t) more copies of this step's pivots
+                ex += (double)(tl - t) * (e1 + log2(p1));
                 fix_from = t;
                 s = dgT - ej;                                            // S_T-1
-                t = t1;
+                t = tl;
+                tend = T;                       // this launch finishes the recursion
                 continue;
             }
             s = snew;
@@ -357,11 +373,15 @@ lssm_cov_kernel(cov_args a, int phase)
     }
     const double ldsum = (log(prod) + ex * 0.69314718055994530942);
     if (phase & 1) {
+        if (act) a.sums[4 * D * D + l] = s;                 // state for the next segment
         if (l == 0) {
             a.sums[5 * D * D + 0] = ldsum;
             a.sums[5 * D * D + 1] = (double)bad;
             // diagnostics: the step at which the forward map became stationary (-1: never)
             a.sums[5 * D * D + 2] = (double)fix_from;
+            a.sums[5 * D * D + 4] = prod;
+            a.sums[5 * D * D + 5] = ex;
+            a.sums[5 * D * D + 6] = (tend >= T) ? 1.0 : 0.0;
         }
         if (!(phase & 2)) return;
         __threadfence();            // the backward half below re-reads S^-1, J from memory
@@ -422,7 +442,7 @@ __global__ void __launch_bounds__(SNT)
 lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
                     const double *__restrict__ Cm /* M x D */, const double *__restrict__ tau_ptr,
                     const double *__restrict__ h0 /* D */, const double *__restrict__ J,
-                    double *__restrict__ Z)
+                    double *__restrict__ Z, int t0, int t1)
 {
     const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
     if (b >= B) return;
@@ -433,14 +453,16 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
 #pragma unroll
         for (int i = 0; i < D; ++i) tc[m][i] = (m < M) ? tau * Cm[m * D + i] : 0.0;
     double z[D];
+    // steps [t0, t1): a later segment picks z_{t0-1} up where the previous launch left it
 #pragma unroll
-    for (int i = 0; i < D; ++i) z[i] = 0.0;
+    for (int i = 0; i < D; ++i) z[i] = t0 > 0 ? Z[((int64_t)(t0 - 1) * D + i) * BL + b] : 0.0;
     const double *yp = Yt + b;
     double ycur[MM], ynxt[MM];
 #pragma unroll
-    for (int m = 0; m < MM; ++m) ycur[m] = (m < M) ? __builtin_nontemporal_load(&yp[(int64_t)m * BL]) : 0.0;
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) {
+    for (int m = 0; m < MM; ++m)
+        ycur[m] = (m < M) ? __builtin_nontemporal_load(&yp[((int64_t)t0 * M + m) * BL]) : 0.0;
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) {
 #pragma unroll
             for (int m = 0; m < MM; ++m)
                 ynxt[m] = (m < M) ? __builtin_nontemporal_load(&yp[((int64_t)(t + 1) * M + m) * BL]) : 0.0;
@@ -866,7 +888,7 @@ inline void fill_lssm_layout(int D, int M, vmp_lssm_layout *L)
     L->off_ldA = o;      o += D;
     L->off_Dg = o;       o += 4 * DD;
     L->off_h0 = o;       o += D;
-    L->off_covsums = o;  o += 5 * DD + 4;
+    L->off_covsums = o;  o += 5 * DD + 8;
     L->off_raw = o;      o += plen_of(D, M);
     L->len_raw = plen_of(D, M);
     L->off_S = o;        o += 5 * DD + D + (int64_t)M * D;
@@ -921,8 +943,9 @@ int32_t vmp_lssm_x_layout(vmp_ctx *ctx, double *X, int32_t D, int64_t B, int32_t
 
 static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int32_t D,
                           const double *Dg0, const double *Dgm, const double *DgT, const double *E,
-                          double *Sinv, double *J, double *sums)
+                          double *Sinv, double *J, double *sums, int t0 = 0, int t1 = -1)
 {
+    if (t1 < 0) t1 = T;
     VMP_REQUIRE(ctx, ctx && Dg0 && Dgm && DgT && E && Sinv && J && sums, VMP_ERR_INVALID,
                 "null argument");
     VMP_REQUIRE(ctx, T >= 1 && D >= 1, VMP_ERR_INVALID, "bad dims");
@@ -938,7 +961,7 @@ static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int
     a.J = J;
     a.sums = sums;
     switch (D) {
-#define LSSM_COV(d) case d: hipLaunchKernelGGL(lssm_cov_kernel<d>, dim3(1), dim3(64), 0, s, a, phase); break;
+#define LSSM_COV(d) case d: hipLaunchKernelGGL(lssm_cov_kernel<d>, dim3(1), dim3(64), 0, s, a, phase, t0, t1); break;
         LSSM_COV(1) LSSM_COV(2) LSSM_COV(3) LSSM_COV(4) LSSM_COV(5) LSSM_COV(6) LSSM_COV(7) LSSM_COV(8)
 #undef LSSM_COV
     }
@@ -956,10 +979,12 @@ int32_t vmp_lssm_cov(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0, cons
     MACRO(1, 8) MACRO(2, 8) MACRO(3, 8) MACRO(4, 8) MACRO(5, 8) MACRO(6, 8) MACRO(7, 8)    \
     MACRO(8, 8) MACRO(1, 16) MACRO(2, 16) MACRO(3, 16) MACRO(4, 16)
 
-int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M, int64_t B,
-                        int32_t T, int64_t BL, int32_t D, const double *Cm, const double *tau,
-                        const double *h0, const double *Sinv, const double *J, double *Z,
-                        double *stats, void *workspace)
+// nseg > 1 (vmp_lssm_x_update): the forward sweep runs in nseg time segments, segment k after
+// seg_ready[k] (the covariance recursion has produced its J_t)
+static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M, int64_t B,
+                           int32_t T, int64_t BL, int32_t D, const double *Cm, const double *tau,
+                           const double *h0, const double *Sinv, const double *J, double *Z,
+                           double *stats, void *workspace, int nseg, const hipEvent_t *seg_ready)
 {
     VMP_REQUIRE(ctx, ctx && Yt && Z && stats && workspace, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, given || (Cm && tau && h0 && Sinv && J), VMP_ERR_INVALID, "null argument");
@@ -976,9 +1001,14 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
 #define LSSM_CASE(d, mm)                                                                      \
     if (g == 0) {                                                                             \
     } else if (D == d && MM == mm) {                                                          \
-        if (!given)                                                                           \
-            hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, s, \
-                               Yt, M, B, T, BL, Cm, tau, h0, J, Z);                           \
+        if (!given) {                                                                         \
+            for (int k = 0; k < nseg; ++k) {                                                  \
+                if (seg_ready) (void)hipStreamWaitEvent(s, seg_ready[k], 0);                  \
+                hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, \
+                                   s, Yt, M, B, T, BL, Cm, tau, h0, J, Z,                     \
+                                   (int)((int64_t)T * k / nseg), (int)((int64_t)T * (k + 1) / nseg)); \
+            }                                                                                 \
+        }                                                                                     \
         if (ev) (void)hipEventRecord(ev[1], s);                                               \
         hipLaunchKernelGGL((lssm_backward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, s,  \
                            Yt, M, B, T, BL, Sinv, J, Z, partial, plen, given);                \
@@ -991,6 +1021,15 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
                        (int)g, plen, plen, stats);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
+}
+
+int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M, int64_t B,
+                        int32_t T, int64_t BL, int32_t D, const double *Cm, const double *tau,
+                        const double *h0, const double *Sinv, const double *J, double *Z,
+                        double *stats, void *workspace)
+{
+    return smooth_impl(ctx, given, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats, workspace, 1,
+                       nullptr);
 }
 
 int32_t vmp_lssm_get_layout(int32_t D, int32_t M, vmp_lssm_layout *out)
@@ -1015,17 +1054,32 @@ int32_t vmp_lssm_x_update(vmp_ctx *ctx, int32_t T, int32_t D, const double *Dg0,
     if (!ctx->ms[0]) {
         for (int i = 0; i < 3; ++i)
             VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->ms[i], hipStreamNonBlocking));
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < VMP_NME; ++i)
             VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->me[i], hipEventDisableTiming));
     }
-    int32_t rc = launch_cov(ctx, ctx->stream, 1, T, D, Dg0, Dgm, DgT, E, Sinv, J, covsums);
-    if (rc != VMP_OK) return rc;
+    // The covariance recursion (one wavefront, ~0.45 us per step) runs on a side stream in NSEG
+    // time segments; the per-sequence forward sweep follows it segment by segment on the caller's
+    // stream, so only the first segment of the recursion is exposed (0.45 -> 0.11 ms at T = 1000).
+    // Its backward half (V_t, Cov(x_t, x_t+1)) runs on a second side stream beside the sweeps and
+    // is joined before return (stream-ordered: the caller's stream continues after all of it).
+    constexpr int NSEG = 8;
+    const int nseg = (T >= 64 * NSEG && vmp_tune_get("lssm_segments", 1) != 0) ? NSEG : 1;
     VMP_HIP_CHECK(ctx, hipEventRecord(ctx->me[0], ctx->stream));
-    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[0], ctx->me[0], 0));
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[1], ctx->me[0], 0));
+    int32_t rc = VMP_OK;
+    hipEvent_t ready[NSEG];
+    for (int k = 0; k < nseg && rc == VMP_OK; ++k) {
+        rc = launch_cov(ctx, ctx->ms[1], 1, T, D, Dg0, Dgm, DgT, E, Sinv, J, covsums,
+                        (int)((int64_t)T * k / nseg), (int)((int64_t)T * (k + 1) / nseg));
+        ready[k] = ctx->me[2 + k];
+        if (rc == VMP_OK) VMP_HIP_CHECK(ctx, hipEventRecord(ready[k], ctx->ms[1]));
+    }
+    if (rc != VMP_OK) return rc;
+    VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ms[0], ready[nseg - 1], 0));
     rc = launch_cov(ctx, ctx->ms[0], 2, T, D, Dg0, Dgm, DgT, E, Sinv, J, covsums);
     if (rc == VMP_OK) VMP_HIP_CHECK(ctx, hipEventRecord(ctx->me[1], ctx->ms[0]));
-    const int32_t rc2 = vmp_lssm_smooth(ctx, 0, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats,
-                                        workspace);
+    const int32_t rc2 = smooth_impl(ctx, 0, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats,
+                                    workspace, nseg, ready);
     if (rc == VMP_OK) VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->me[1], 0));
     return rc != VMP_OK ? rc : rc2;
 }

@@ -2128,7 +2128,7 @@ int32_t vmp_mpca_x_pass(vmp_ctx *ctx, int32_t D, int32_t K, int64_t N, int64_t c
     if (!ctx->ms[0]) {
         for (int i = 0; i < 3; ++i)
             VMP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->ms[i], hipStreamNonBlocking));
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < VMP_NME; ++i)
             VMP_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->me[i], hipEventDisableTiming));
     }
     hipEvent_t eStart = ctx->me[6], eEnd = ctx->me[7];

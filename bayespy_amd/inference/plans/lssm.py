@@ -419,14 +419,14 @@ class LSSMPlan:
         st = self.state
         if given:
             if not keep_cov:
-                st[L.off_covsums:L.off_covsums + 5 * D * D + 4].zero_()
+                st[L.off_covsums:L.off_covsums + 5 * D * D + 8].zero_()
             k.smooth(True, self.Yt, M, B, T, self.BL, D, st[L.off_Cm:], st[L.off_scal + 3:],
                      st[L.off_h0:], self.Sinv, self.J, self.Z, st[L.off_raw:], self.ws)
         else:
             # covariance recursion + per-sequence passes; the backward half of the recursion runs
             # beside the passes on a side stream inside the library
             k.x_update(T, D, st[L.off_Dg:L.off_Dg + 4 * D * D], self.Sinv, self.J,
-                       st[L.off_covsums:L.off_covsums + 5 * D * D + 4], self.Yt, M, B, self.BL,
+                       st[L.off_covsums:L.off_covsums + 5 * D * D + 8], self.Yt, M, B, self.BL,
                        st[L.off_Cm:], st[L.off_scal + 3:], st[L.off_h0:], self.Z, st[L.off_raw:],
                        self.ws)
         self._reduce(st[L.off_raw:L.off_raw + int(L.len_raw)])

@@ -337,7 +337,7 @@ typedef struct vmp_lssm_layout {
     int64_t off_Am, off_AA, off_ldA;        /* D*D <a_i>, D*D*D <a_i a_i^T>, D log|Cov_A_i|        */
     int64_t off_Dg;       /* 4*D*D: diagonal blocks of the chain precision (t=0, inner, last), E   */
     int64_t off_h0;       /* D: Lam0 mu0                                                           */
-    int64_t off_covsums;  /* 5*D*D+4: output of vmp_lssm_cov                                       */
+    int64_t off_covsums;  /* 5*D*D+8: output of vmp_lssm_cov (+ its state between segments)       */
     int64_t off_raw, len_raw;  /* mean-part plate sums of vmp_lssm_smooth (what ranks all-reduce)  */
     int64_t off_S;        /* Sxx | Spp | Snn | Snp | S00 (D*D each) | s0 (D) | Syx (M*D)           */
     int64_t off_scal;     /* 8: [0] sum y^2 [1] log|Phi| [2] status [3] <tau> of the last X pass
