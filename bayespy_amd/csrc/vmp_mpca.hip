@@ -1066,11 +1066,9 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
     constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2, PT2 = (PT + 1) / 2;
     constexpr int NPAIR = 4 * LRC / 2, NV = (NPAIR + 63) / 64;
     static_assert(PT2 * 128 <= 4 * LRC, "a block row of XXf fits in the staging area");
-    static_assert(4 * KP <= 128, "the four right-hand sides are one 16-byte pair per lane");
-    // staging of one wavefront: four packed rows (matrix | right-hand side) as they lie in Lam, and
-    // a copy of the four right-hand sides that outlives the rows (see the loop)
+    // staging of one wavefront: four packed rows (matrix | right-hand side) as they lie in Lam;
+    // later in the iteration the block row of XXf that leaves
     __shared__ __attribute__((aligned(16))) double stg[4][4 * LRC];
-    __shared__ __attribute__((aligned(16))) double hst[4][4 * KP];
     __shared__ double sa[P];                     // packed sum of <x x^T>_n of this workgroup
     __shared__ double red[NT / 64];
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1094,6 +1092,7 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
     // FULLK: K == 4 NB, no padded rows / columns in the last block row
     const bool padr = !FULLK && 4 * (NB - 1) + li >= K, padc = !FULLK && 4 * (NB - 1) + lj >= K;
     double pm = 1.0, le = 0.0;                   // product of the pivots of this lane's plates
+    double trl = 0.0;                            // this lane's share of sum_n tr<xx>_n
     int anybad = 0;
     // The packed rows of plates 4 q .. 4 q + 3, contiguous in Lam, travel HBM -> staging area as
     // LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no registers; rows beyond the chunk:
@@ -1153,12 +1152,8 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
             }
             S[bidx(I, J)] = a;
         });
-        // the right-hand sides move to their own area (they are read after the sweep), so that ...
-        if (l < 2 * KP)
-            reinterpret_cast<v2f64 *>(hst[w])[l] =
-                reinterpret_cast<const v2f64 *>(stg[w] + (l / (KP / 2)) * LRC + 16 * PT)[l % (KP / 2)];
         lds_fence();
-        // ... the staging area is free: it collects this iteration's <x x^T> in XXf order below
+        // (the rows stay in the staging area until this iteration's <x x^T> is assembled there)
         double prod = 1.0, ld = 0.0;
         int bad = 0;
         blk4_sweep<NB, 0>(S, li, lj, sel, ident, prod, ld, bad, [&](auto) {});
@@ -1166,8 +1161,8 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         double hq[NB], hr[NB];                    // tau rhs at the lane's column / row index
 #pragma unroll
         for (int J = 0; J < NB; ++J) {
-            const double a = hst[w][lb * KP + 4 * J + lj];
-            const double b = hst[w][lb * KP + 4 * J + li];
+            const double a = row[16 * PT + 4 * J + lj];
+            const double b = row[16 * PT + 4 * J + li];
             hq[J] = (FULLK || 4 * J + lj < K) ? tau * a : 0.0;
             hr[J] = (FULLK || 4 * J + li < K) ? tau * b : 0.0;
         }
@@ -1216,6 +1211,10 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
                     if (valid)
                         __hip_atomic_fetch_add(&sa[pk], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                // tr<xx> (a bound term) per lane, combined in fixed order below: the shared
+                // accumulator above (the rotation statistic sum_n <xx>_n) takes its additions in
+                // the order the four wavefronts happen to arrive
+                if (I == J && li == lj && valid) trl += v;
             });
             // packed entries beyond the data: block rows K/4 .. KP/4 - 1 and the padding of the
             // last tile pair (mpca_stats reads whole tiles)
@@ -1262,9 +1261,7 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
     }
     // per-workgroup partials: tr<xx> = trace of the accumulated sum, log|Cov|, status
     __syncthreads();
-    double tr = 0.0;
-    for (int k = threadIdx.x; k < K; k += NT) tr += sa[tri(k, k)];
-    tr = block_sum<NT>(tr, red);
+    const double tr = block_sum<NT>(trl, red);
     const double ldw = block_sum<NT>((li == 0 && lj == 0)
                                          ? -(log(pm) + le * 0.69314718055994530942) : 0.0, red);
     const double bd = block_sum<NT>((double)anybad, red);

@@ -201,3 +201,25 @@ def test_fused_lssm_device_inputs_and_checkpoint(tmp_path):
     Q2.update(repeat=2, verbose=False)
     np.testing.assert_array_equal(Q2.L[:4], Q.L[:4])
     np.testing.assert_array_equal(Q2['X'].u[0], Q['X'].u[0])
+
+
+def test_segmented_covariance_recursion_is_bit_identical():
+    """vmp_lssm_x_update runs the covariance recursion in time segments beside the forward sweep
+    (round 3); the arithmetic is that of the single launch: same bound, same moments, bit for bit,
+    also when the stationary stretch is found inside a segment."""
+    from bayespy_amd.device import get_runtime
+    lib = get_runtime().lib
+    for (M, B, T, D, seed) in [(8, 300, 1000, 4, 1), (2, 70, 600, 2, 5), (5, 200, 640, 8, 3)]:
+        y, x0, c0 = _data(M, B, T, D, seed=seed)
+        res = []
+        try:
+            for seg in (1, 0):
+                lib.vmp_tune_set(b'lssm_segments', seg)
+                Q = _build(y, x0, c0, False)
+                Q.update(repeat=3, verbose=False)
+                res.append((Q.L[:3].copy(), Q['X'].u[0].copy(), Q['A'].u[0].copy()))
+        finally:
+            lib.vmp_tune_set(b'lssm_segments', 1)
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_array_equal(res[0][2], res[1][2])

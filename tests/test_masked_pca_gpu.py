@@ -200,10 +200,11 @@ def test_moments_of_the_deterministic_product_are_read_out_on_request(masked):
 @pytest.mark.parametrize('N,D,K', [(777, 40, 32), (333, 17, 20), (64, 128, 32), (203, 9, 7),
                                    (150, 12, 16), (1, 3, 2), (1030, 33, 25)])
 def test_plate_stage_variants_agree(N, D, K):
-    """The per-plate stage has three forms (vmp_tune_set): two plates per wavefront on the
-    matrix-core sweep (default), one plate per wavefront, and the vector-ALU Gauss-Jordan with a
-    plate per 16 lanes (16 < K <= 32).  Same inputs -> the same bound, moments and rotation
-    statistic to round-off."""
+    """The per-plate stage has four forms (vmp_tune_set): four plates per wavefront on the 4x4x4
+    matrix instruction (default), two / one plate per wavefront on the 16x16x4 sweep, and the
+    vector-ALU Gauss-Jordan with a plate per 16 lanes (16 < K <= 32); the M_d GEMM has two (4x4x4
+    row-split default, 16x16x4 column-split).  Same inputs -> the same bound, moments and
+    rotation statistic to round-off."""
     import bayespy_amd.nodes as nodes
     from bayespy_amd.inference import VB
     from bayespy_amd.device import get_runtime
@@ -214,10 +215,10 @@ def test_plate_stage_variants_agree(N, D, K):
     x0 = rs.normal(size=(N, K))
     lib = get_runtime().lib
     res = []
-    defaults = {'mpca_blk4': 1, 'mpca_sweep_nm': 2, 'mpca_rows': 0}
+    defaults = {'mpca_blk4': 1, 'mpca_sweep_nm': 2, 'mpca_rows': 0, 'mpca_stats3': 1}
     try:
         for knobs in ({}, {'mpca_blk4': 0}, {'mpca_blk4': 0, 'mpca_sweep_nm': 1},
-                      {'mpca_blk4': 0, 'mpca_rows': 1}):
+                      {'mpca_blk4': 0, 'mpca_rows': 1}, {'mpca_stats3': 0}):
             for k, v in knobs.items():
                 lib.vmp_tune_set(k.encode(), v)
             Q = build_masked_pca(nodes, VB, y, mask, x0)
