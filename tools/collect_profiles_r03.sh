@@ -1,0 +1,39 @@
+#!/bin/bash
+# rocprofv3 evidence of round 3 (summaries only travel back).  Usage: tools/collect_profiles_r03.sh <outdir>
+# kernel-trace stats and, in SEPARATE runs, the PMC passes (FETCH_SIZE / WRITE_SIZE / SQ_*), every
+# file headed by the build id of the library, the workload string bench.py matches, and the number
+# of VB iterations the profiled command ran.
+O=${1:-gpurun_out/prof_r03}
+mkdir -p $O
+R=$PWD
+export TMPDIR=/tmp
+BID=$(python -c "import sys; sys.path.insert(0,'$R'); from bayespy_amd import _lib; print(_lib.load().vmp_version().decode().split('build ')[-1])")
+prof() {  # name, command...
+  local name=$1; shift
+  (cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_st_$name -o r -- "$@" > $R/$O/under_rocprof_$name.log 2>&1)
+  ( echo "# build_id: $BID"; python tools/rocpd_summary.py /tmp/p_st_$name/r_results.db ) > $O/kernel_stats_$name.txt 2>&1
+}
+pmcs() {  # name, only-filter, workload-string, iterations, command...
+  local name=$1 only=$2 wl=$3 its=$4; shift 4
+  local dbs=""
+  local i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    i=$((i+1))
+    (cd /tmp; timeout 600 rocprofv3 --pmc $set --kernel-trace -d /tmp/p_pmc_${name}_$i -o r -- "$@" > /dev/null 2>&1)
+    dbs="$dbs /tmp/p_pmc_${name}_$i/r_results.db"
+  done
+  ( echo "# build_id: $BID"; echo "# workload: $wl"; echo "# iterations: $its"; python tools/rocpd_summary.py --pmc --only $only $dbs ) > $O/pmc_$name.txt 2>&1
+}
+B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
+prof pca_gram $B
+pmcs pca_gram pass_kernel "D=128 K=32 n_local=10000000" 12 $B
+M="python $R/bench.py --config masked --steps 5 --warmup 1 --no-cpu-baseline"
+prof masked $M
+pmcs masked mpca_ "masked PCA N=10000000 D=128 K=32" 6 $M
+Ls="python $R/bench.py --config lssm --steps 5 --warmup 1 --no-cpu-baseline"
+prof lssm $Ls
+pmcs lssm lssm_ "LSSM B=100000 T=1000 M=8 D=4" 6 $Ls
+G="python $R/bench.py --config gmm --steps 5 --warmup 2 --no-cpu-baseline"
+prof gmm $G
+pmcs gmm gmm_pass "GMM N=10000000 D=8 K=64" 7 $G
+ls -la $O

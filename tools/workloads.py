@@ -214,6 +214,14 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
                      'hbm_achieved_GBs': byts / (avg * 1e-3) / 1e9,
                      'alg_flops_per_launch': flops, 'alg_bytes_per_launch': byts},
     }
+    prof, why = pmc_profile('GMM N=%d D=%d K=%d' % (N, D, K))
+    if prof is not None:
+        for name, counters in prof['kernels'].items():
+            if name.startswith('gmm_pass_kernel') and pmc_bytes(counters) is not None:
+                out['roofline']['traffic'] = pmc_bytes(counters)
+        out['roofline']['traffic_source'] = prof['path']
+    else:
+        out['roofline']['traffic_source'] = why
     if cpu_baseline:
         from oracle.gmm import GMMOracle
         ns = min(cpu_sample_n, N)
