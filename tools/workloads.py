@@ -214,6 +214,19 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
                      'hbm_achieved_GBs': byts / (avg * 1e-3) / 1e9,
                      'alg_flops_per_launch': flops, 'alg_bytes_per_launch': byts},
     }
+    # what the matrix unit actually executes: per 16-point tile KP/16 x F2P/4 (phase 1) +
+    # 4 x KP/16 x F2P/16 (phase 2) instructions of 2048 flops over the compact feature list
+    # (F2 = D(D+1)/2 + D + 1 padded to 16) -- about 2/3 of the algorithmic count, which prices the
+    # symmetric quadratic form as D^2 products
+    F2P = (D * (D + 1) // 2 + D + 1 + 15) // 16 * 16
+    KP = (K + 15) // 16 * 16
+    issued = (N / 16.0) * (KP // 16) * (F2P // 4 + 4 * (F2P // 16)) * 2048.0
+    out['roofline']['issued_mfma_flops_per_launch'] = issued
+    out['roofline']['issued_mfma_TFLOPs'] = issued / (avg * 1e-3) / 1e12
+    out['roofline']['note'] = ('achieved / frac are ALGORITHMIC flops (SURVEY.md 8d) over the pass '
+                               'time: an efficiency figure; issued_mfma_TFLOPs is what the matrix '
+                               'unit executes (ceiling of v_mfma_f64_16x16x4_f64 on this chip: '
+                               '44-47 TFLOP/s, tools/mfma4_lab.hip)')
     prof, why = pmc_profile('GMM N=%d D=%d K=%d' % (N, D, K))
     if prof is not None:
         for name, counters in prof['kernels'].items():
