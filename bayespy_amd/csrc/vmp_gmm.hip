@@ -15,7 +15,9 @@
 //   phase 2  T (K x F2) += r * feat2(y)^T          feat2 = [y_a y_b (a<=b), y_d, 1]
 // T = [R_k, sum r y, sum r y y^T] are the messages to mu / Lambda / alpha, i.e. the
 // plate sums of mixture.py:126-158 + node.py:650 that the reference materialises
-// as (N, K, D, D) arrays.  D <= 8, K <= 64 built.
+// as (N, K, D, D) arrays.  D <= 16, K <= 64 built (D <= 8: the tuned instances of config 3;
+// 9 <= D <= 16: the same pass with the features formed twice instead of staged in LDS, four
+// wavefronts per workgroup where the T accumulators need the whole register file).
 //
 // Layout: Y (N, D) row-major as in the reference (plates (N,), dims (D,)); a wave reads
 // 16 consecutive rows = one contiguous block.  r (N, K) row-major, written as whole rows.
@@ -26,7 +28,7 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int TNC = 16;          // columns (plate elements) per wave tile
-constexpr int MAXK = 64, MAXD = 8;
+constexpr int MAXK = 64, MAXD = 16;
 
 inline int round_pow2(int x, int unit)
 {
@@ -80,6 +82,12 @@ typedef __attribute__((address_space(3))) double lds_f64;
 __device__ __forceinline__ double lds_read(uint32_t byte_addr)
 {
     return *(const lds_f64 *)(uintptr_t)byte_addr;
+}
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t byte_addr)
+{
+    return *(const lds_u32 *)(uintptr_t)byte_addr;
 }
 
 // v_max_f64 without the canonicalising v_max x, x the compiler puts in front of fmax() operands
@@ -165,12 +173,27 @@ __device__ __forceinline__ double recip_small(double s)
 //   phase 2    T += r * feat^T
 // sum_nk r phi (bound term of z) is not accumulated here: it equals <C, T> exactly and is
 // formed from the reduced statistics (gmm_rphi_kernel).
+//
+// D > 8 (REGEN): the feature tile (16 x F2P doubles per wavefront; 20 KB at D = 16) is not staged:
+// phase 2 forms feature ft*16 + l15 of column 4q + g again from the y tile (two LDS reads and
+// one multiply per KT matrix instructions), the y tile keeps its own storage beside the r
+// tile, and the per-lane factor offsets (two 16-bit byte offsets per feature) live in an LDS
+// table shared by the wavefronts instead of 2 KS1 address registers.  NW = 4 (one wavefront per
+// SIMD, 512 registers) where the KTL x FT2 accumulator tiles do not leave room for two.
+//
+// KS = 2 (D > 8 and K > 32): the clusters are split between the two wavefronts of a pair that
+// walk the same tiles (KTL = KT/2 cluster tiles each: the 4 x 10 accumulator tiles of D = 16,
+// K = 64 are 320 registers, more than one wavefront can hold beside the rest).  Each wavefront
+// runs both phases for its own clusters on its own copy of the y tile; the pair exchanges only
+// the softmax normalisers -- the column maxima and the column sums, 16 doubles each, through
+// LDS with two workgroup barriers per tile (every wavefront of the grid walks the same number
+// of tiles; the surplus ones are empty).  Sums are combined as (half 0) + (half 1) in both
+// wavefronts, so the two halves of a row of r carry the same normaliser bit for bit.
 // ---------------------------------------------------------------------------
-constexpr int NTP = 512;
 constexpr int RS = 18;
 
-template <int DPT, int KT, int FT2, bool FROM_LABELS>
-__global__ void __launch_bounds__(NTP, 2)
+template <int DPT, int KT, int FT2, bool FROM_LABELS, int NW, bool REGEN, int KS>
+__global__ void __launch_bounds__(64 * NW, NW / 4)
 gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
                 const double *__restrict__ Cmat, const int64_t *__restrict__ labels,
                 double *__restrict__ Rout, double *__restrict__ P, int64_t ntiles)
@@ -180,21 +203,33 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     constexpr int F2P = 16 * FT2;                 // compact features: y_a y_b (a<=b), y_d, 1
     constexpr int FS = F2P + 2;                   // feature tile row stride
     constexpr int KS1 = F2P / 4;                  // phase-1 k-steps over the same features
-    constexpr int WAVES = NTP / 64;
-    constexpr int YR = (TNC * YS > KP * RS) ? TNC * YS : KP * RS;   // y tile / r tile (aliased)
+    constexpr int NTP = 64 * NW;
+    constexpr int WAVES = NW;
+    constexpr int GROUPS = NW / KS;               // tiles in flight per workgroup
+    constexpr int KTL = KT / KS, KPL = 16 * KTL;  // cluster tiles / clusters of one wavefront
+    static_assert(KS == 1 || (KS == 2 && KTL == 2 && REGEN), "cluster split: K > 32, D > 8 only");
+    // y tile / r tile: aliased when the features are staged, side by side when phase 2 re-reads y
+    constexpr int YR = REGEN ? TNC * YS + KPL * RS : ((TNC * YS > KPL * RS) ? TNC * YS : KPL * RS);
+    constexpr int FTL = REGEN ? 0 : TNC * FS;     // staged feature tile
     constexpr int NCF = FROM_LABELS ? 0 : KT * KS1 * 64;
     constexpr int NTAB = FROM_LABELS ? 0 : 256;
+    constexpr int NXCH = (KS == 2 && !FROM_LABELS) ? 2 * NW * 16 : 0;   // softmax normalisers
+    constexpr int NFTAB = REGEN ? (KS1 + FT2) * 32 : 0;                 // factor offsets (u32)
 
     extern __shared__ double lds[];
     double *Cf = lds;                                            // KT*KS1*64
     double *tab = lds + NCF;                                     // 256
-    double *wbase = tab + NTAB;
+    double *xch = tab + NTAB;                                    // [2][NW][16]  (KS == 2)
+    uint32_t *ftab = reinterpret_cast<uint32_t *>(xch + NXCH);   // [KS1 + FT2][64]  (REGEN)
+    double *wbase = xch + NXCH + NFTAB;
     const int tid = threadIdx.x;
     const int l = tid & 63, l15 = l & 15, g = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *ytile = wbase + w * (YR + TNC * FS);                 // [16][YS]
-    double *rtile = ytile;                                       // [KP][RS]   (after phase 1)
-    double *ftile = ytile + YR;                                  // [16][FS]
+    const int kh = (KS == 2) ? (w & 1) : 0;                      // which half of the clusters
+    const int grp = (KS == 2) ? (w >> 1) : w;                    // which tile of the workgroup
+    double *ytile = wbase + w * (YR + FTL);                      // [16][YS]
+    double *rtile = REGEN ? ytile + TNC * YS : ytile;            // [KP][RS]   (after phase 1)
+    double *ftile = ytile + YR;                                  // [16][FS]   (!REGEN)
 
     if (!FROM_LABELS) {
         // A fragments of phase 1: lane holds C[it*16 + l15][4q + g]
@@ -205,7 +240,6 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
         }
         for (int e = tid; e < 256; e += NTP) tab[e] = VMP_EXP2_TAB[e];
     }
-    __syncthreads();
     const uint32_t tab_addr = (uint32_t)(uintptr_t)(lds_f64 *)tab;
 
     // feature f of a column n is ytile[n][fa(f)] * ytile[n][fb(f)] (slot DP holds 1, DP+1 holds 0)
@@ -224,25 +258,43 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     };
     // LDS byte addresses of the two factors of feature 4q + g of this lane's column
     const uint32_t yrow_addr = (uint32_t)(uintptr_t)(lds_f64 *)(ytile + l15 * YS);
-    uint32_t fa[KS1], fb[KS1];
+    // staged form: full addresses in registers; REGEN: byte offsets of both factors packed in
+    // the table row [q][lane] (phase 1: feature 4q + g) / [KS1 + ft][lane] (phase 2: feature
+    // ft*16 + l15 of the rows 4q + g of the y tile)
+    uint32_t fa[REGEN ? 1 : KS1], fb[REGEN ? 1 : KS1];
+    if constexpr (REGEN) {
+        for (int e = tid; e < (KS1 + FT2) * 64; e += NTP) {
+            const int lane = e & 63, row = e >> 6;
+            int a, b;
+            feature(row < KS1 ? 4 * row + (lane >> 4) : (row - KS1) * 16 + (lane & 15), a, b);
+            ftab[e] = 8u * (uint32_t)a | (8u * (uint32_t)b) << 16;
+        }
+    } else {
 #pragma unroll
-    for (int q = 0; q < KS1; ++q) {
-        int a, b;
-        feature(4 * q + g, a, b);
-        fa[q] = yrow_addr + 8u * (uint32_t)a;
-        fb[q] = yrow_addr + 8u * (uint32_t)b;
+        for (int q = 0; q < KS1; ++q) {
+            int a, b;
+            feature(4 * q + g, a, b);
+            fa[q] = yrow_addr + 8u * (uint32_t)a;
+            fb[q] = yrow_addr + 8u * (uint32_t)b;
+        }
     }
+    const uint32_t ftab_addr = (uint32_t)(uintptr_t)(lds_u32 *)(ftab + l);
+    const uint32_t ygrp_addr = (uint32_t)(uintptr_t)(lds_f64 *)(ytile + g * YS);
+    __syncthreads();
 
-    v4f64 acc2[KT][FT2];
+    v4f64 acc2[KTL][FT2];
 #pragma unroll
-    for (int it = 0; it < KT; ++it)
+    for (int it = 0; it < KTL; ++it)
 #pragma unroll
         for (int ft = 0; ft < FT2; ++ft) acc2[it][ft] = v4f64{0.0, 0.0, 0.0, 0.0};
     double s_mx = 0.0, s_log = 0.0, prod = 1.0;
     int since = 0;
 
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + w; tile < ntiles; tile += stride) {
+    const int64_t stride = (int64_t)gridDim.x * GROUPS;
+    const int64_t tile0 = (int64_t)blockIdx.x * GROUPS + grp;
+    // KS == 2: the barriers of the exchange need the same trip count in every wavefront
+    const int64_t tile_end = (KS == 2) ? tile0 + (ntiles + stride - 1) / stride * stride : ntiles;
+    for (int64_t tile = tile0; tile < tile_end; tile += stride) {
         const int64_t n0 = tile * TNC;
         const int64_t n = n0 + l15;
         const bool nok = n < N;
@@ -260,40 +312,52 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
         lds_fence();
 
         // ---- features (+ phase 1: Phi = C * feat over the compact features) -------------
-        v4f64 acc1[KT];
+        v4f64 acc1[KTL];
 #pragma unroll
-        for (int it = 0; it < KT; ++it) acc1[it] = v4f64{0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < KTL; ++it) acc1[it] = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < KS1; ++q) {
             // keep the operand reads next to their use (hoisted together they spill)
             if ((q & 3) == 0) asm volatile("" ::: "memory");
-            const double b = lds_read(fa[q]) * lds_read(fb[q]);
-            ftile[l15 * FS + 4 * q + g] = b;
+            double b;
+            if constexpr (REGEN) {
+                const uint32_t pk = lds_read_u32(ftab_addr + 256u * q);
+                b = lds_read(yrow_addr + (pk & 0xffffu)) * lds_read(yrow_addr + (pk >> 16));
+            } else {
+                b = lds_read(fa[q]) * lds_read(fb[q]);
+                ftile[l15 * FS + 4 * q + g] = b;
+            }
             if (!FROM_LABELS) {
 #pragma unroll
-                for (int it = 0; it < KT; ++it)
-                    acc1[it] = mfma_f64(Cf[(it * KS1 + q) * 64 + l], b, acc1[it]);
+                for (int it = 0; it < KTL; ++it)
+                    acc1[it] = mfma_f64(Cf[((kh * KTL + it) * KS1 + q) * 64 + l], b, acc1[it]);
             }
         }
         lds_fence();             // every lane is done with the y tile: the r tile may overwrite it
 
         if (!FROM_LABELS) {
             // ---- softmax over k for column n (utils/misc.py:1388-1401) ------------------
-            // lane holds Phi[k = it*16 + g + 4r][n]
-            mfma_settle<KT>(acc1);
+            // lane holds Phi[k = (kh*KTL + it)*16 + g + 4r][n]
+            mfma_settle<KTL>(acc1);
             double mx = max_raw(acc1[0][0], acc1[0][1]);
             mx = max_raw(mx, max_raw(acc1[0][2], acc1[0][3]));
 #pragma unroll
-            for (int it = 1; it < KT; ++it)
+            for (int it = 1; it < KTL; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = max_raw(mx, acc1[it][r]);
             mx = max_raw(mx, __shfl_xor(mx, 16, 64));
             mx = max_raw(mx, __shfl_xor(mx, 32, 64));
+            if constexpr (KS == 2) {
+                // column maxima of the other half of the clusters
+                if (g == 0) xch[w * 16 + l15] = mx;
+                __syncthreads();
+                mx = fmax(mx, xch[(w ^ 1) * 16 + l15]);
+            }
             if (!isfinite(mx)) mx = 0.0;
             double s = 0.0;
 #pragma unroll
-            for (int h = 0; h < KT; h += 2) {
-                constexpr int NV = KT >= 2 ? 8 : 4;
+            for (int h = 0; h < KTL; h += 2) {
+                constexpr int NV = KTL >= 2 ? 8 : 4;
                 double v[NV];
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v[i] = acc1[h + (i >> 2)][i & 3];
@@ -306,6 +370,13 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             }
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
+            if constexpr (KS == 2) {
+                // column sums: (half 0) + (half 1) in both wavefronts
+                if (g == 0) xch[NW * 16 + w * 16 + l15] = s;
+                __syncthreads();
+                const double so = xch[NW * 16 + (w ^ 1) * 16 + l15];
+                s = kh == 0 ? s + so : so + s;
+            }
             // lse_n = mx + log s; the logarithm is taken of a running product (1 <= s <= KP)
             s_mx += nok ? mx : 0.0;
             prod *= nok ? s : 1.0;
@@ -316,27 +387,37 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             }
             const double is = nok ? recip_small(s) : 0.0;
 #pragma unroll
-            for (int it = 0; it < KT; ++it)
+            for (int it = 0; it < KTL; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     rtile[(it * 16 + g + 4 * r) * RS + l15] = acc1[it][r] * is;
         } else {
             const int64_t lab = nok ? labels[n] : -1;
 #pragma unroll
-            for (int it = 0; it < KT; ++it)
+            for (int it = 0; it < KTL; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int k = it * 16 + g + 4 * r;
-                    rtile[k * RS + l15] = (lab == k) ? 1.0 : 0.0;
+                    const int k = it * 16 + g + 4 * r;              // row of this wavefront's r tile
+                    rtile[k * RS + l15] = (lab == kh * KPL + k) ? 1.0 : 0.0;
                 }
         }
         lds_fence();
 
         // ---- r -> HBM, whole rows (N, K) ------------------------------------------------
+        if constexpr (KS == 1) {
 #pragma unroll 4
-        for (int rr = 0; rr < TNC; ++rr) {
-            if (n0 + rr < N) {
-                for (int k = l; k < K; k += 64) Rout[(n0 + rr) * K + k] = rtile[k * RS + rr];
+            for (int rr = 0; rr < TNC; ++rr) {
+                if (n0 + rr < N) {
+                    for (int k = l; k < K; k += 64) Rout[(n0 + rr) * K + k] = rtile[k * RS + rr];
+                }
+            }
+        } else {
+            // this wavefront's 32 columns of two rows per instruction
+            const int kk = l & 31, k = kh * KPL + kk;
+#pragma unroll 4
+            for (int rr = 0; rr < TNC; rr += 2) {
+                const int row = rr + (l >> 5);
+                if (n0 + row < N && k < K) Rout[(n0 + row) * K + k] = rtile[kk * RS + row];
             }
         }
 
@@ -344,14 +425,32 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
 #pragma unroll
         for (int q = 0; q < TNC / 4; ++q) {
             const int nn = 4 * q + g;
-            double bf[FT2];
+            if constexpr (REGEN) {
+                double a[KTL];
 #pragma unroll
-            for (int ft = 0; ft < FT2; ++ft) bf[ft] = ftile[nn * FS + ft * 16 + l15];
+                for (int it = 0; it < KTL; ++it) a[it] = rtile[(it * 16 + l15) * RS + nn];
+                const uint32_t yq = ygrp_addr + (uint32_t)(4 * q * YS * 8);
 #pragma unroll
-            for (int it = 0; it < KT; ++it) {
-                const double a = rtile[(it * 16 + l15) * RS + nn];
+                for (int ft = 0; ft < FT2; ++ft) {
+                    // operand reads stay next to their use (hoisted together they spill)
+                    if ((ft & 1) == 0) asm volatile("" ::: "memory");
+                    const uint32_t pk = lds_read_u32(ftab_addr + 256u * (KS1 + ft));
+                    const double b = lds_read(yq + (pk & 0xffffu)) * lds_read(yq + (pk >> 16));
 #pragma unroll
-                for (int ft = 0; ft < FT2; ++ft) acc2[it][ft] = mfma_f64(a, bf[ft], acc2[it][ft]);
+                    for (int it = 0; it < KTL; ++it)
+                        acc2[it][ft] = mfma_f64(a[it], b, acc2[it][ft]);
+                }
+            } else {
+                double bf[FT2];
+#pragma unroll
+                for (int ft = 0; ft < FT2; ++ft) bf[ft] = ftile[nn * FS + ft * 16 + l15];
+#pragma unroll
+                for (int it = 0; it < KTL; ++it) {
+                    const double a = rtile[(it * 16 + l15) * RS + nn];
+#pragma unroll
+                    for (int ft = 0; ft < FT2; ++ft)
+                        acc2[it][ft] = mfma_f64(a, bf[ft], acc2[it][ft]);
+                }
             }
         }
         lds_fence();
@@ -360,19 +459,21 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     // ---- per-WORKGROUP partials: [KP][F2P] + 2 scalars (waves combined in fixed order) ----
     __syncthreads();                       // every wave is done with the LDS tiles / fragments
     double *scr = lds;                     // KP*F2P + 2 doubles
-    // the four lane groups of a column hold identical (mx, s): count group 0 only
-    double s_lse = (g == 0) ? s_mx + s_log + log(prod) : 0.0;
+    // the four lane groups of a column (and both wavefronts of a pair) hold identical (mx, s):
+    // count group 0 (of half 0) only
+    double s_lse = (g == 0 && kh == 0) ? s_mx + s_log + log(prod) : 0.0;
     s_lse = wave_sum(s_lse);
     for (int ww = 0; ww < WAVES; ++ww) {
         if (w == ww) {
 #pragma unroll
-            for (int it = 0; it < KT; ++it)
+            for (int it = 0; it < KTL; ++it)
 #pragma unroll
                 for (int ft = 0; ft < FT2; ++ft)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int idx = (it * 16 + g + 4 * r) * F2P + ft * 16 + l15;
-                        scr[idx] = (ww == 0 ? 0.0 : scr[idx]) + acc2[it][ft][r];
+                        const int idx = ((kh * KTL + it) * 16 + g + 4 * r) * F2P + ft * 16 + l15;
+                        // the first KS wavefronts start the rows of their clusters
+                        scr[idx] = (ww < KS ? 0.0 : scr[idx]) + acc2[it][ft][r];
                     }
             if (l == 0) {
                 scr[KP * F2P + 0] = (ww == 0 ? 0.0 : scr[KP * F2P + 0]) + s_lse;
@@ -454,17 +555,51 @@ gmm_rphi_kernel(vmp_gmm_layout L, const double *__restrict__ Tc, double *__restr
 }
 
 // ---------------------------------------------------------------------------
-// Per-cluster small kernels: one wavefront per cluster, D*D <= 64 elements,
-// one matrix element per lane; SPD inverse by Gauss-Jordan sweeps.
+// Per-cluster small kernels: one matrix element per lane, SPD inverse by Gauss-Jordan sweeps.
+// WPC = wavefronts per cluster: 1 for D*D <= 64 (four clusters per workgroup, wavefront-level
+// ordering only), 4 for D*D <= 256 (one cluster per workgroup, workgroup barriers).
 // ---------------------------------------------------------------------------
+template <int WPC>
+__device__ __forceinline__ void grp_sync()
+{
+    if constexpr (WPC == 1) lds_fence();
+    else __syncthreads();
+}
+
+// in: v = element (i,j) of an SPD matrix (lanes >= D*D idle); out: element of the inverse
+template <int WPC>
+__device__ inline double grp_spd_inverse(double v, int D, int i, int j, bool act, int l, double *M,
+                                         double *logdet, int *bad)
+{
+    if constexpr (WPC == 1) return wave_spd_inverse(v, D, i, j, act, M, logdet, bad);
+    double ld = 0.0, prod = 1.0;
+    for (int p = 0; p < D; ++p) {
+        M[l] = v;
+        __syncthreads();
+        const double piv = M[p * D + p];
+        const double ci = act ? M[i * D + p] : 0.0, rj = act ? M[p * D + j] : 0.0;
+        if (!(piv > 0.0)) *bad = 1;
+        logdet_accumulate(piv, prod, ld);
+        const double d = fast_recip(piv);
+        if (i == p) v = (j == p) ? d : rj * d;
+        else if (j == p) v = -ci * d;
+        else v = v - ci * rj * d;
+        __syncthreads();
+    }
+    *logdet = logdet_finish(prod, ld);
+    return v;
+}
+
+template <int WPC>
 __global__ void __launch_bounds__(NT)
 gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, double *st)
 {
     // priors are already stored in st[off_prior..]; initialise every node from its prior
     // (ExponentialFamily.initialize_from_prior, expfamily.py:168-184)
-    __shared__ double Ms[4][64];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + w;
+    constexpr int TPC = 64 * WPC, CPB = 4 / WPC;
+    __shared__ double Ms[CPB][TPC];
+    const int w = threadIdx.x / TPC, l = threadIdx.x % TPC;
+    const int k = blockIdx.x * CPB + w;
     const bool act = (k < K) && (l < D * D);
     const int i = act ? l / D : 0, j = act ? l - i * D : 0;
     const double *pr = st + L.off_prior;
@@ -485,7 +620,7 @@ gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, d
     if (act && j == 0) st[L.off_mu + (int64_t)k * D + i] = 0.0;
     double ld;
     int bad = 0;
-    const double vinv = wave_spd_inverse(act ? V0[l] : 0.0, D, i, j, act, Ms[w], &ld, &bad);
+    const double vinv = grp_spd_inverse<WPC>(act ? V0[l] : 0.0, D, i, j, act, l, Ms[w], &ld, &bad);
     if (act) st[L.off_Lam + (int64_t)k * D * D + l] = n0 * vinv;
     if (k < K && l == 0) {
         double md = 0.0;
@@ -499,14 +634,16 @@ gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, d
 
 // mu.update(): Lambda_mu = beta0 I + R_k <Lambda_k>, Cov, mean = Cov <Lambda_k> S1_k
 // (gaussian.py:649-706 with the messages gaussian.py:2451-2454 weighted by r, mixture.py:126-158)
+template <int WPC>
 __global__ void __launch_bounds__(NT)
 gmm_update_mu_kernel(vmp_gmm_layout L, int D, int K, double *st)
 {
-    __shared__ double Ms[4][64];
-    __shared__ double Cs[4][64];
-    __shared__ double bs[4][8];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + w;
+    constexpr int TPC = 64 * WPC, CPB = 4 / WPC;
+    __shared__ double Ms[CPB][TPC];
+    __shared__ double Cs[CPB][TPC];
+    __shared__ double bs[CPB][MAXD];
+    const int w = threadIdx.x / TPC, l = threadIdx.x % TPC;
+    const int k = blockIdx.x * CPB + w;
     const bool act = (k < K) && (l < D * D);
     const int i = act ? l / D : 0, j = act ? l - i * D : 0;
     const double beta0 = st[L.off_prior + L.KP + 0];
@@ -517,14 +654,14 @@ gmm_update_mu_kernel(vmp_gmm_layout L, int D, int K, double *st)
     double v = act ? R * Lam[l] + ((i == j) ? beta0 : 0.0) : 0.0;
     double ld;
     int bad = 0;
-    v = wave_spd_inverse(v, D, i, j, act, Ms[w], &ld, &bad);
+    v = grp_spd_inverse<WPC>(v, D, i, j, act, l, Ms[w], &ld, &bad);
     Cs[w][l] = v;
     if (l < D) {
         double s = 0.0;
         for (int c = 0; c < D; ++c) s += Lam[l * D + c] * T[1 + c];     // <Lambda> S1
         bs[w][l] = s;
     }
-    lds_fence();
+    grp_sync<WPC>();
     if (act) st[L.off_Cmu + (int64_t)k * D * D + l] = v;
     if (k < K && l < D) {
         double s = 0.0;
@@ -539,12 +676,14 @@ gmm_update_mu_kernel(vmp_gmm_layout L, int D, int K, double *st)
 
 // Lambda.update(): n_k = n0 + R_k, V_k = V0 + S2 - S1 mu^T - mu S1^T + R <mu mu^T>
 // (wishart.py:153-188 with the message gaussian.py:2516-2520 weighted by r)
+template <int WPC>
 __global__ void __launch_bounds__(NT)
 gmm_update_lambda_kernel(vmp_gmm_layout L, int D, int K, double *st)
 {
-    __shared__ double Ms[4][64];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + w;
+    constexpr int TPC = 64 * WPC, CPB = 4 / WPC;
+    __shared__ double Ms[CPB][TPC];
+    const int w = threadIdx.x / TPC, l = threadIdx.x % TPC;
+    const int k = blockIdx.x * CPB + w;
     const bool act = (k < K) && (l < D * D);
     const int i = act ? l / D : 0, j = act ? l - i * D : 0;
     const int kk = k < K ? k : 0;
@@ -563,12 +702,12 @@ gmm_update_lambda_kernel(vmp_gmm_layout L, int D, int K, double *st)
     }
     // symmetrise before factorising
     Ms[w][l] = v;
-    lds_fence();
+    grp_sync<WPC>();
     if (act) v = 0.5 * (Ms[w][i * D + j] + Ms[w][j * D + i]);
-    lds_fence();
+    grp_sync<WPC>();
     double ld;
     int bad = 0;
-    v = wave_spd_inverse(v, D, i, j, act, Ms[w], &ld, &bad);
+    v = grp_spd_inverse<WPC>(v, D, i, j, act, l, Ms[w], &ld, &bad);
     if (act) st[L.off_Lam + (int64_t)k * D * D + l] = nk * v;               // wishart.py:184
     if (k < K && l == 0) {
         double md = 0.0;
@@ -658,7 +797,7 @@ __device__ __noinline__ double multigammaln_dev(double a, int d)
 }
 
 // expfamily.py:400-480 for Y, z, alpha, mu, Lambda.  One workgroup of 16
-// wavefronts; a wavefront owns clusters k = w, w+16, ... with one (i,j) matrix element per lane.
+// wavefronts; a wavefront owns clusters k = w, w+8, ... with the (i,j) matrix elements dealt to its lanes.
 constexpr int NTLB = 512;
 __global__ void __launch_bounds__(NTLB)
 gmm_lower_bound_kernel(vmp_gmm_layout L, int D, int K, double *st)
@@ -681,8 +820,6 @@ gmm_lower_bound_kernel(vmp_gmm_layout L, int D, int K, double *st)
         lgs[k][c] = vmp_lgamma(x);
     }
     __syncthreads();
-    const bool act = l < D * D;
-    const int i = act ? l / D : 0, j = act ? l - i * D : 0;
     const double mgc = (double)D * (D - 1) / 4.0 * log(M_PI);
     double LY = 0.0, Lz = 0.0, La = 0.0, Lmu = 0.0, LL = 0.0, sa0 = 0.0, sa = 0.0;
     for (int k = w; k < K; k += NTLB / 64) {
@@ -692,14 +829,16 @@ gmm_lower_bound_kernel(vmp_gmm_layout L, int D, int K, double *st)
         const double *Cmu = st + L.off_Cmu + (int64_t)k * D * D;
         const double *Vk = st + L.off_Vk + (int64_t)k * D * D;
         double bs = 0.0, ls2 = 0.0, trLmm = 0.0, trmm = 0.0, trV0 = 0.0, trVk = 0.0;
-        if (act) {
-            const double lam = Lam[l];
-            bs = lam * mu[j] * T[1 + i];                       // (Lambda mu) . S1
-            ls2 = lam * T[1 + D + l];                          // tr(Lambda S2)
-            trLmm = lam * (Cmu[l] + mu[i] * mu[j]);            // tr(Lambda <mu mu^T>)
-            trV0 = V0[l] * lam;
-            trVk = 0.5 * (Vk[l] + Vk[j * D + i]) * lam;
-            if (i == j) trmm = Cmu[l] + mu[i] * mu[i];
+        // one (i,j) element per lane and round (a single round while D*D <= 64)
+        for (int e = l; e < D * D; e += 64) {
+            const int i = e / D, j = e - i * D;
+            const double lam = Lam[e];
+            bs += lam * mu[j] * T[1 + i];                      // (Lambda mu) . S1
+            ls2 += lam * T[1 + D + e];                         // tr(Lambda S2)
+            trLmm += lam * (Cmu[e] + mu[i] * mu[j]);           // tr(Lambda <mu mu^T>)
+            trV0 += V0[e] * lam;
+            trVk += 0.5 * (Vk[e] + Vk[j * D + i]) * lam;
+            if (i == j) trmm += Cmu[e] + mu[i] * mu[i];
         }
         bs = wave_sum(bs); ls2 = wave_sum(ls2); trLmm = wave_sum(trLmm);
         trmm = wave_sum(trmm); trV0 = wave_sum(trV0); trVk = wave_sum(trVk);
@@ -761,42 +900,54 @@ int gmm_wgs_per_cu()
 
 int64_t gmm_max_grid(vmp_ctx *ctx) { return (int64_t)ctx->num_cu * gmm_wgs_per_cu(); }
 
-template <int DPT, int KT, int FT2>
-int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, dim3 grid, const double *Y, int64_t N,
-                        int D, int K, const double *C, const int64_t *labels, double *R,
-                        double *P, int64_t ntiles)
+// wavefronts per workgroup of an instance: eight (two per SIMD, 256 registers) while the
+// KT x FT2 accumulator tiles of phase 2 fit in 96 registers, else four (one per SIMD, 512)
+constexpr int gmm_waves(int KTL, int FT2) { return KTL * FT2 <= 20 ? 8 : 4; }
+
+template <int DPT, int KT, int FT2, bool FROM_LABELS>
+int32_t launch_gmm_pass_as(vmp_ctx *ctx, const double *Y, int64_t N, int D, int K,
+                           const double *C, const int64_t *labels, double *R, double *P,
+                           int64_t ntiles)
 {
     constexpr int DP = 4 * DPT, KP = 16 * KT;
     constexpr int KS1 = 4 * FT2;                  // k-steps of phase 1 (compact features)
     constexpr int F2P = 16 * FT2;
-    const size_t ytile = (size_t)TNC * (DP + 3), rtile = (size_t)KP * RS;
-    const size_t per_wave = (ytile > rtile ? ytile : rtile) + (size_t)TNC * (F2P + 2);
-    const size_t lds = ((from_labels ? 0 : (size_t)KT * KS1 * 64 + 256) + (NTP / 64) * per_wave)
-                       * sizeof(double);
-    hipStream_t s = ctx->stream;
-    if (from_labels) {
-        auto kern = gmm_pass_kernel<DPT, KT, FT2, true>;
-        static bool attr = false;
-        if (!attr) {
-            VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   160 * 1024));
-            attr = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(NTP), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
-    } else {
-        auto kern = gmm_pass_kernel<DPT, KT, FT2, false>;
-        static bool attr = false;
-        if (!attr) {
-            VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   160 * 1024));
-            attr = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(NTP), lds, s, Y, N, D, K, C, labels, R, P, ntiles);
+    constexpr bool REGEN = DPT > 2;
+    constexpr int KS = (REGEN && KT == 4) ? 2 : 1;             // cluster split over a wavefront pair
+    constexpr int KTL = KT / KS;
+    constexpr int NW = gmm_waves(KTL, FT2);
+    constexpr size_t ytile = (size_t)TNC * (DP + 3), rtile = (size_t)KTL * 16 * RS;
+    constexpr size_t per_wave = REGEN ? ytile + rtile
+                                      : (ytile > rtile ? ytile : rtile) + (size_t)TNC * (F2P + 2);
+    size_t ldsd = (FROM_LABELS ? 0 : (size_t)KT * KS1 * 64 + 256 + (KS == 2 ? 2 * NW * 16 : 0))
+                  + (REGEN ? (size_t)(KS1 + FT2) * 32 : 0) + NW * per_wave;
+    if (ldsd < (size_t)KP * F2P + 8) ldsd = (size_t)KP * F2P + 8;   // partials of the workgroup
+    const size_t lds = ldsd * sizeof(double);
+    int64_t g = (ntiles + NW / KS - 1) / (NW / KS);
+    if (g > gmm_max_grid(ctx)) g = gmm_max_grid(ctx);
+    if (g < 1) g = 1;
+    auto kern = gmm_pass_kernel<DPT, KT, FT2, FROM_LABELS, NW, REGEN, KS>;
+    static bool attr = false;
+    if (!attr) {
+        VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024));
+        attr = true;
     }
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64 * NW), lds, ctx->stream, Y, N, D, K, C,
+                       labels, R, P, ntiles);
     VMP_HIP_CHECK(ctx, hipGetLastError());
-    return VMP_OK;
+    return (int32_t)g + 1000;                     // > 0: number of workgroup partials + 1000
+}
+
+template <int DPT, int KT, int FT2>
+int32_t launch_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
+                        int D, int K, const double *C, const int64_t *labels, double *R,
+                        double *P, int64_t ntiles)
+{
+    return from_labels
+        ? launch_gmm_pass_as<DPT, KT, FT2, true>(ctx, Y, N, D, K, C, labels, R, P, ntiles)
+        : launch_gmm_pass_as<DPT, KT, FT2, false>(ctx, Y, N, D, K, C, labels, R, P, ntiles);
 }
 
 int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N, int D, int K,
@@ -811,34 +962,33 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
     fill_layout(D, K, &L);
     const int DPT = (int)(L.DP / 4), KT = (int)(L.KP / 16), FT2 = (int)(L.F2P / 16);
     const int64_t ntiles = (N + TNC - 1) / TNC;
-    int64_t g = (ntiles + NTP / 64 - 1) / (NTP / 64);
-    if (g > gmm_max_grid(ctx)) g = gmm_max_grid(ctx);
-    if (g < 1) g = 1;
     double *P = reinterpret_cast<double *>(workspace);
     const double *C = state + L.off_C;
-    dim3 grid((unsigned)g);
     int32_t rc = VMP_ERR_UNSUPPORTED;
     hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
 #define VMP_GCASE(dpt, kt, ft2)                                                                 \
     if (DPT == dpt && KT == kt && FT2 == ft2)                                                   \
-        rc = launch_gmm_pass<dpt, kt, ft2>(ctx, from_labels, grid, Y, N, D, K, C, labels, R, P, \
-                                           ntiles);
-    VMP_GCASE(1, 1, 1) VMP_GCASE(1, 2, 1) VMP_GCASE(1, 4, 1)
-    VMP_GCASE(2, 1, 1) VMP_GCASE(2, 2, 1) VMP_GCASE(2, 4, 1)
-    VMP_GCASE(2, 1, 2) VMP_GCASE(2, 2, 2) VMP_GCASE(2, 4, 2)
-    VMP_GCASE(2, 1, 3) VMP_GCASE(2, 2, 3) VMP_GCASE(2, 4, 3)
+        rc = launch_gmm_pass<dpt, kt, ft2>(ctx, from_labels, Y, N, D, K, C, labels, R, P, ntiles);
+#define VMP_GCASE_K(dpt, ft2) VMP_GCASE(dpt, 1, ft2) VMP_GCASE(dpt, 2, ft2) VMP_GCASE(dpt, 4, ft2)
+    VMP_GCASE_K(1, 1)
+    VMP_GCASE_K(2, 1) VMP_GCASE_K(2, 2) VMP_GCASE_K(2, 3)
+    // 9 <= D <= 16: DP = 16, F2P = 64 ... 160
+    VMP_GCASE_K(4, 4) VMP_GCASE_K(4, 5) VMP_GCASE_K(4, 6) VMP_GCASE_K(4, 7)
+    VMP_GCASE_K(4, 8) VMP_GCASE_K(4, 9) VMP_GCASE_K(4, 10)
+#undef VMP_GCASE_K
 #undef VMP_GCASE
-    if (rc != VMP_OK) {
+    if (rc < 1000) {
         if (rc == VMP_ERR_UNSUPPORTED)
             VMP_SET_ERR(ctx, "no GMM kernel instance for DPT=%d KT=%d FT2=%d", DPT, KT, FT2);
         return rc;
     }
+    const int g = rc - 1000;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
     const int total = (int)(L.KP * L.F2P + 2);
     double *Tc = P + gmm_max_grid(ctx) * (L.KP * L.F2P + 8);
     hipLaunchKernelGGL(gmm_reduce_kernel, dim3((total + 63) / 64), dim3(NT), 0, ctx->stream,
-                       L, D, K, P, (int)g, from_labels ? 0 : 1, Tc, state);
+                       L, D, K, P, g, from_labels ? 0 : 1, Tc, state);
     if (!from_labels)
         hipLaunchKernelGGL(gmm_rphi_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, Tc, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
@@ -889,8 +1039,12 @@ int32_t vmp_gmm_init_state(vmp_ctx *ctx, int32_t D, int32_t K, const double *alp
     VMP_HIP_CHECK(ctx, hipMemcpyAsync(state + L.off_prior + L.KP + 8, V0_host,
                                       (size_t)D * D * sizeof(double), hipMemcpyHostToDevice, s));
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(s));   // host buffers may be temporaries
-    hipLaunchKernelGGL(gmm_init_state_kernel, dim3((K + 3) / 4), dim3(NT), 0, s, L, D, K, beta0,
-                       n0, state);
+    if (D * D <= 64)
+        hipLaunchKernelGGL(gmm_init_state_kernel<1>, dim3((K + 3) / 4), dim3(NT), 0, s, L, D, K,
+                           beta0, n0, state);
+    else
+        hipLaunchKernelGGL(gmm_init_state_kernel<4>, dim3(K), dim3(NT), 0, s, L, D, K, beta0, n0,
+                           state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -919,8 +1073,12 @@ int32_t vmp_gmm_pass(vmp_ctx *ctx, const double *Y, int64_t N, int32_t D, int32_
 int32_t vmp_gmm_update_mu(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
 {
     VMP_GMM_PROLOGUE();
-    hipLaunchKernelGGL(gmm_update_mu_kernel, dim3((K + 3) / 4), dim3(NT), 0, ctx->stream, L, D, K,
-                       state);
+    if (D * D <= 64)
+        hipLaunchKernelGGL(gmm_update_mu_kernel<1>, dim3((K + 3) / 4), dim3(NT), 0, ctx->stream, L,
+                           D, K, state);
+    else
+        hipLaunchKernelGGL(gmm_update_mu_kernel<4>, dim3(K), dim3(NT), 0, ctx->stream, L, D, K,
+                           state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -928,8 +1086,12 @@ int32_t vmp_gmm_update_mu(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
 int32_t vmp_gmm_update_lambda(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
 {
     VMP_GMM_PROLOGUE();
-    hipLaunchKernelGGL(gmm_update_lambda_kernel, dim3((K + 3) / 4), dim3(NT), 0, ctx->stream, L, D,
-                       K, state);
+    if (D * D <= 64)
+        hipLaunchKernelGGL(gmm_update_lambda_kernel<1>, dim3((K + 3) / 4), dim3(NT), 0,
+                           ctx->stream, L, D, K, state);
+    else
+        hipLaunchKernelGGL(gmm_update_lambda_kernel<4>, dim3(K), dim3(NT), 0, ctx->stream, L, D, K,
+                           state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

@@ -54,8 +54,8 @@ def parse():
     p.add_argument('--cpu-sample-n', type=int, default=0,
                    help='columns of the CPU-baseline sample; 0 = the whole workload when the '
                         'host has the memory for it (direct parity at the metric size)')
-    p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'masked', 'lssm', 'generic_pca',
-                                        'generic_gmm'], default='pca',
+    p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'gmm_d16', 'masked', 'lssm',
+                                        'generic_pca', 'generic_gmm'], default='pca',
                    help="pca = the BASELINE.json metric (default); the others print the "
                         "secondary configurations of tools/workloads.py as the JSON line")
     p.add_argument('--no-extra', action='store_true',
@@ -233,6 +233,10 @@ def main():
         elif args.config == 'gmm':
             out = workloads.run_gmm(steps=args.steps, warmup=args.warmup,
                                     cpu_baseline=not args.no_cpu_baseline)
+        elif args.config == 'gmm_d16':
+            # the mixture block beyond config 3's D = 8
+            out = workloads.run_gmm(N=4_000_000, D=16, K=32, steps=args.steps, warmup=args.warmup,
+                                    cpu_baseline=not args.no_cpu_baseline, cpu_sample_n=50_000)
         elif args.config == 'generic_pca':
             out = workloads.run_generic_pca(cpu_baseline=not args.no_cpu_baseline)
         elif args.config == 'generic_gmm':
@@ -370,6 +374,8 @@ def main():
                           cpu_baseline=not args.no_cpu_baseline),
                 run_extra('gmm', workloads.run_gmm, 120, steps=10, warmup=2,
                           cpu_baseline=not args.no_cpu_baseline),
+                run_extra('gmm_d16', workloads.run_gmm, 120, N=4_000_000, D=16, K=32, steps=10,
+                          warmup=2, cpu_baseline=not args.no_cpu_baseline, cpu_sample_n=50_000),
                 run_extra('masked', workloads.run_masked, 120, steps=3, warmup=1,
                           cpu_baseline=not args.no_cpu_baseline),
                 run_extra('lssm', workloads.run_lssm, 120, steps=3, warmup=1,
