@@ -437,7 +437,10 @@ lssm_cov_kernel(cov_args a, int phase, int t0, int t1)
 // per-sequence recursions
 // ---------------------------------------------------------------------------------------------
 // z_t = h_t - J_t-1^T z_t-1,  h_t = tau sum_m y_mbt c_m  (+ h0 at t = 0)
-template <int D, int MM>
+// CK = 0: every z_t is written to Z (T, D, BL).  CK = S > 0 (checkpoint form): only z_{kS-1},
+// k = 1, 2, ..., is written, to Zc (T/S, D, BL); the backward kernel forms the S steps of a block
+// again from the checkpoint in front of it (lssm_backward_ck_kernel).  t0 is a multiple of S.
+template <int D, int MM, int CK>
 __global__ void __launch_bounds__(SNT)
 lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
                     const double *__restrict__ Cm /* M x D */, const double *__restrict__ tau_ptr,
@@ -455,7 +458,10 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
     double z[D];
     // steps [t0, t1): a later segment picks z_{t0-1} up where the previous launch left it
 #pragma unroll
-    for (int i = 0; i < D; ++i) z[i] = t0 > 0 ? Z[((int64_t)(t0 - 1) * D + i) * BL + b] : 0.0;
+    for (int i = 0; i < D; ++i) {
+        if constexpr (CK == 0) z[i] = t0 > 0 ? Z[((int64_t)(t0 - 1) * D + i) * BL + b] : 0.0;
+        else z[i] = t0 > 0 ? Z[((int64_t)(t0 / CK - 1) * D + i) * BL + b] : 0.0;
+    }
     const double *yp = Yt + b;
     double ycur[MM], ynxt[MM];
 #pragma unroll
@@ -491,8 +497,15 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
 #pragma unroll
             for (int i = 0; i < D; ++i) z[i] = h[i];
         }
+        if constexpr (CK == 0) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) __builtin_nontemporal_store(z[i], &Z[((int64_t)t * D + i) * BL + b]);
+            for (int i = 0; i < D; ++i)
+                __builtin_nontemporal_store(z[i], &Z[((int64_t)t * D + i) * BL + b]);
+        } else if ((t + 1) % CK == 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                __builtin_nontemporal_store(z[i], &Z[((int64_t)((t + 1) / CK - 1) * D + i) * BL + b]);
+        }
 #pragma unroll
         for (int m = 0; m < MM; ++m) ycur[m] = ynxt[m];
     }
@@ -642,7 +655,204 @@ lssm_backward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int
         }
 }
 
+// Checkpoint form of the backward sweep (round 3): the forward sweep has stored z only every S
+// steps (Zc), so z is neither written nor read as a (T, D, BL) array -- 2 x 8 B T D bytes less per
+// iteration; Y, which this kernel reads anyway for sum y x^T, is all it takes to form the S values
+// of z of a block again.  Blocks of S steps from the last to the first:
+//   forward in the block   z_t = h_t - J_t-1^T z_t-1 from the checkpoint z_{kS-1}: the arithmetic of
+//                          lssm_forward_kernel (same order: the values are the same bit for bit),
+//                          y_t and z_t of the block kept in registers
+//   backward in the block  x_t = S_t^-1 z_t - J_t x_t+1, written to Z, and the plate sums -- the
+//                          arithmetic and the order of lssm_backward_kernel
+// The sums of the first / last step are formed after the loop from x_0 (what the loop ends on) and x_T-1
+// (kept from its first step) instead of being carried through it as D x D accumulators.  Output as lssm_backward_kernel.
+template <int D, int MM, int S>
+__global__ void __launch_bounds__(SNT, 2)
+lssm_backward_ck_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
+                        const double *__restrict__ Cm, const double *__restrict__ tau_ptr,
+                        const double *__restrict__ h0, const double *__restrict__ Sinv,
+                        const double *__restrict__ J, const double *__restrict__ Zc,
+                        double *__restrict__ Z, double *__restrict__ partial, int plen)
+{
+    __shared__ double red[SNT / 64];
+    const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
+    const bool live = b < B;
+    const int64_t bb = live ? b : 0;
+    // tau * c_m in LDS (broadcast reads): in registers these 32 uniform values would cost the
+    // second wavefront per SIMD
+    __shared__ double tc[MM][D];
+    if (threadIdx.x < MM * D) {
+        const int m = threadIdx.x / D, i = threadIdx.x % D;
+        tc[m][i] = (m < M) ? tau_ptr[0] * Cm[m * D + i] : 0.0;
+    }
+    __syncthreads();
+    // the block's z and x_T-1 wait in LDS (per-thread slots, conflict-free): 40 registers less
+    __shared__ double zb[S][D][SNT];
+    __shared__ double xls[D][SNT];
+    const int tid = threadIdx.x;
+    double sxx[D][D], snp[D][D], syx[MM][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) sxx[i][j] = snp[i][j] = 0.0;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int i = 0; i < D; ++i) syx[m][i] = 0.0;
+    double xn[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) xn[i] = xls[i][tid] = 0.0;
+    double *zp = Z + bb;
+    const double *yp = Yt + bb;
+    const double *cp = Zc + bb;
+    const int nblk = (T + S - 1) / S;
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int tb = kb * S;
+        asm volatile("" ::: "memory");      // tc is read from LDS in every block, not hoisted
+        double yb[S][MM];
+        // ---- the block's observations and the checkpoint in front of it -------------------
+#pragma unroll
+        for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                yb[u][m] = (m < M && tb + u < T)
+                    ? __builtin_nontemporal_load(&yp[((int64_t)(tb + u) * M + m) * BL]) : 0.0;
+        double z[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            z[i] = kb > 0 ? __builtin_nontemporal_load(&cp[((int64_t)(kb - 1) * D + i) * BL]) : 0.0;
+        // ---- forward within the block ------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int t = tb + u;
+            if (t < T) {
+                double h[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double s = (t == 0) ? h0[i] : 0.0;
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) s += yb[u][m] * tc[m][i];
+                    h[i] = s;
+                }
+                if (t > 0) {
+                    const double *Jt = J + (int64_t)(t - 1) * D * D;     // uniform
+                    double zn[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double s = h[i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) s -= Jt[k * D + i] * z[k];     // (J^T z)_i
+                        zn[i] = s;
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) z[i] = zn[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) z[i] = h[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) zb[u][i][tid] = z[i];
+        }
+        // ---- backward within the block -----------------------------------------------------
+#pragma unroll
+        for (int u = S - 1; u >= 0; --u) {
+            const int t = tb + u;
+            if (t < T) {
+                const double *St = Sinv + (int64_t)t * D * D;
+                double x[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s += St[i * D + k] * zb[u][k][tid];
+                    x[i] = s;
+                }
+                if (t < T - 1) {
+                    const double *Jt = J + (int64_t)t * D * D;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double s = x[i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) s -= Jt[i * D + k] * xn[k];
+                        x[i] = s;
+                    }
+                }
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+                        __builtin_nontemporal_store(x[i], &zp[((int64_t)t * D + i) * BL]);
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) sxx[i][j] += x[i] * x[j];
+                    if (t < T - 1) {
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) snp[i][j] += xn[i] * x[j];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MM; ++m)
+#pragma unroll
+                        for (int i = 0; i < D; ++i) syx[m][i] += yb[u][m] * x[i];
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    xn[i] = x[i];
+                    if (t == T - 1) xls[i][tid] = x[i];
+                }
+            }
+        }
+    }
+    // x_0 is what the loop ended on; x_T-1 was kept from the first step
+    double xl[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) xl[i] = xls[i][tid];
+    // workgroup sums (fixed order), symmetric halves mirrored
+    double *pb = partial + (int64_t)blockIdx.x * plen;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double a = block_sum<SNT>(j <= i ? sxx[i][j] : sxx[j][i], red);
+            const double c = block_sum<SNT>(snp[i][j], red);
+            const double d0 = block_sum<SNT>(live ? (j <= i ? xn[i] * xn[j] : xn[j] * xn[i]) : 0.0, red);
+            const double dT = block_sum<SNT>(live ? (j <= i ? xl[i] * xl[j] : xl[j] * xl[i]) : 0.0, red);
+            if (threadIdx.x == 0) {
+                pb[i * D + j] = a;
+                pb[D * D + i * D + j] = c;
+                pb[2 * D * D + i * D + j] = d0;
+                pb[3 * D * D + i * D + j] = dT;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double a = block_sum<SNT>(live ? xn[i] : 0.0, red);
+        if (threadIdx.x == 0) pb[4 * D * D + i] = a;
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double a = block_sum<SNT>(syx[m][i], red);
+            if (threadIdx.x == 0 && m < M) pb[4 * D * D + D + m * D + i] = a;
+        }
+}
+
 int plen_of(int D, int M) { return 4 * D * D + D + M * D; }
+
+// workspace: [partial sums of the sweeps | relayout partials] then the checkpoints of the forward
+// sweep, (T / CKS, D, BL) with BL <= the sequences rounded up to 256
+constexpr int CKS = 4;
+inline int64_t ck_bl_max(int64_t B) { return (B + 255) / 256 * 256; }
+inline int64_t ws_base_doubles(int D, int M, int64_t B)
+{
+    const int64_t g = (B + SNT - 1) / SNT;
+    const int64_t a = g * plen_of(D, M);
+    const int64_t r = 256 * 8 * 2;            // relayout partials (<= num_cu * 8 workgroups)
+    return (a > r ? a : r) + 64;
+}
 
 // ---------------------------------------------------------------------------------------------
 // replicated-node updates and the bound: D x D / M x D algebra, one thread (a few 10^4 flops).
@@ -998,13 +1208,42 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
     hipStream_t s = ctx->stream;
     hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
+    // checkpoint form (D <= 4, M <= 8: the block's y and z fit the registers): z is kept every
+    // CKS steps only, in the workspace behind the partial sums (vmp_lssm_workspace_doubles)
+    if (!given && g > 0 && D <= 4 && MM == 8 && T >= 2 * CKS && BL <= ck_bl_max(B)
+        && vmp_tune_get("lssm_checkpoint", 1) != 0) {
+        double *Zc = partial + ws_base_doubles(D, M, B);
+#define LSSM_CK(d)                                                                             \
+    if (D == d) {                                                                              \
+        for (int k = 0; k < nseg; ++k) {                                                       \
+            if (seg_ready) (void)hipStreamWaitEvent(s, seg_ready[k], 0);                       \
+            const int t0 = (int)((int64_t)T * k / nseg) / CKS * CKS;                           \
+            const int t1 = k + 1 < nseg ? (int)((int64_t)T * (k + 1) / nseg) / CKS * CKS : T;  \
+            if (t1 > t0)                                                                       \
+                hipLaunchKernelGGL((lssm_forward_kernel<d, 8, CKS>), dim3((unsigned)g),        \
+                                   dim3(SNT), 0, s, Yt, M, B, T, BL, Cm, tau, h0, J, Zc, t0,   \
+                                   t1);                                                        \
+        }                                                                                      \
+        if (ev) (void)hipEventRecord(ev[1], s);                                                \
+        hipLaunchKernelGGL((lssm_backward_ck_kernel<d, 8, CKS>), dim3((unsigned)g), dim3(SNT),  \
+                           0, s, Yt, M, B, T, BL, Cm, tau, h0, Sinv, J, Zc, Z, partial, plen); \
+    }
+        LSSM_CK(1) LSSM_CK(2) LSSM_CK(3) LSSM_CK(4)
+#undef LSSM_CK
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+        hipLaunchKernelGGL(lssm_sum_kernel, dim3((unsigned)((plen + 15) / 16)), dim3(NT), 0, s,
+                           partial, (int)g, plen, plen, stats);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        return VMP_OK;
+    }
 #define LSSM_CASE(d, mm)                                                                      \
     if (g == 0) {                                                                             \
     } else if (D == d && MM == mm) {                                                          \
         if (!given) {                                                                         \
             for (int k = 0; k < nseg; ++k) {                                                  \
                 if (seg_ready) (void)hipStreamWaitEvent(s, seg_ready[k], 0);                  \
-                hipLaunchKernelGGL((lssm_forward_kernel<d, mm>), dim3((unsigned)g), dim3(SNT), 0, \
+                hipLaunchKernelGGL((lssm_forward_kernel<d, mm, 0>), dim3((unsigned)g), dim3(SNT), 0, \
                                    s, Yt, M, B, T, BL, Cm, tau, h0, J, Z,                     \
                                    (int)((int64_t)T * k / nseg), (int)((int64_t)T * (k + 1) / nseg)); \
             }                                                                                 \
@@ -1132,10 +1371,8 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
 int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
 {
     if (!n || D < 1 || M < 1 || B < 0) return VMP_ERR_INVALID;
-    const int64_t g = (B + SNT - 1) / SNT;
-    int64_t a = g * plen_of(D, M);
-    const int64_t r = 256 * 8 * 2;            // relayout partials (<= num_cu * 8 workgroups)
-    *n = (a > r ? a : r) + 64;
+    *n = ws_base_doubles(D, M, B);
+    if (D <= 4 && M <= 8) *n += (int64_t)((T + CKS - 1) / CKS) * D * ck_bl_max(B);
     return VMP_OK;
 }
 

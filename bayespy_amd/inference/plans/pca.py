@@ -548,6 +548,7 @@ class PCAPlan:
                 if self.plate_layout == 'tiled':
                     if self.Yt is None:
                         self.Yt = k.tile_y(self.Yd, self.ldy, N, D, K)
+                        self._place_plate_arrays()
                     k.xpass_tiled(self.Yt, N, D, K, self.Xd, self.ldx, self.state, self.ws)
                 else:
                     k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
@@ -562,6 +563,48 @@ class PCAPlan:
         else:
             return
         self._version += 1
+
+    def _place_plate_arrays(self):
+        """Where the driver puts a multi-GB allocation physically decides how fast the plate pass
+        streams it: the same kernel on the same data ran between 2.20 and 2.50 ms (N = 1e7, D = 128,
+        K = 32) over fresh allocations of X and of the tile-major Y within ONE process, while
+        offsets inside an allocation, the row stride of X or physically contiguous allocations
+        changed nothing (tools/xpass_place.hip, profiles/r03/xpass_place.txt).  So the plan tries
+        a few allocations at set-up -- first for X, then for the tile-major Y -- with the pass it
+        is about to run anyway (same A, same Y: every trial writes the <x> of this update, bit
+        for bit) and keeps the fastest; the others go back to the allocator.  Arrays below 2 GB
+        per pass, the CPU test double and BAYESPY_AMD_PLACEMENT_TRIES=1 skip it."""
+        rt, k = self.rt, self.kernels
+        torch = rt.torch
+        N, D, K = self.N, self.D, self.K
+        tries = int(os.environ.get('BAYESPY_AMD_PLACEMENT_TRIES', '4'))
+        self.placement = None
+        if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < 2e9:
+            return
+        set_bytes = 8 * (self.Yt.numel() + self.Xd.numel())
+        free = torch.cuda.mem_get_info(rt.device)[0]
+        tries = min(tries, 1 + int(max(free - (8 << 30), 0) // set_bytes))
+        if tries <= 1:
+            return
+
+        def timed(Yt, Xd):
+            k.set_timing(True)
+            for _ in range(2):
+                k.xpass_tiled(Yt, N, D, K, Xd, self.ldx, self.state, self.ws)
+            k.xjoin()
+            ms = min(a for a, _ in k.pass_times_ms(8))
+            k.set_timing(bool(getattr(self, 'timing', False)))
+            return ms
+
+        xs = [self.Xd] + [rt.empty(self.Xd.shape[0], self.Xd.shape[1]) for _ in range(tries - 1)]
+        x_ms = [timed(self.Yt, x) for x in xs]
+        self.Xd = xs[x_ms.index(min(x_ms))]
+        del xs
+        ys = [self.Yt] + [k.tile_y(self.Yd, self.ldy, N, D, K) for _ in range(tries - 1)]
+        y_ms = [x_ms[x_ms.index(min(x_ms))]] + [timed(y, self.Xd) for y in ys[1:]]
+        self.Yt = ys[y_ms.index(min(y_ms))]
+        del ys
+        self.placement = {'x_ms': x_ms, 'yt_ms': y_ms}
 
     def _flush(self):
         """Issue the queued replicated-node updates.  They are queued rather than launched

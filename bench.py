@@ -358,6 +358,8 @@ def main():
         out['config']['stats'] = args.stats
         out['config']['plate_layout'] = plan.plate_layout if args.stats == 'gram' else 'rows'
         out['config']['initial_x'] = 'initialize_from_value (injected normal draws)'
+        # set-up: allocations of X / tile-major Y tried, pass time on each (plans/pca.py)
+        out['config']['placement_trials_ms'] = getattr(plan, 'placement', None)
         out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(y, x0, D, K, n_total, [float(v) for v in L], Q,
