@@ -15,20 +15,19 @@
 //   phase 2  T (K x F2) += r * feat2(y)^T          feat2 = [y_a y_b (a<=b), y_d, 1]
 // T = [R_k, sum r y, sum r y y^T] are the messages to mu / Lambda / alpha, i.e. the
 // plate sums of mixture.py:126-158 + node.py:650 that the reference materialises
-// as (N, K, D, D) arrays.  D <= 16, K <= 64 built (D <= 8: the tuned instances of config 3;
-// 9 <= D <= 16: the same pass with the features formed twice instead of staged in LDS, four
-// wavefronts per workgroup where the T accumulators need the whole register file).
+// as (N, K, D, D) arrays.  D <= 32, K <= 64 built (D <= 8: the tuned instances of config 3;
+// 9 <= D <= 16: the same pass with the features formed twice instead of staged in LDS, the
+// clusters split over a wavefront pair at K > 32; 17 <= D <= 32: vmp_gmm_wide.hip, coefficient
+// fragments streamed from L2, one cluster tile per wavefront).
 //
 // Layout: Y (N, D) row-major as in the reference (plates (N,), dims (D,)); a wave reads
 // 16 consecutive rows = one contiguous block.  r (N, K) row-major, written as whole rows.
-#include "vmp_common.h"
-#include "vmp_exp2_table.h"
+#include "vmp_gmm_dev.h"
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int TNC = 16;          // columns (plate elements) per wave tile
-constexpr int MAXK = 64, MAXD = 16;
+constexpr int MAXK = 64, MAXD = 32;
 
 inline int round_pow2(int x, int unit)
 {
@@ -43,7 +42,8 @@ inline void fill_layout(int D, int K, vmp_gmm_layout *L)
 {
     const int64_t DP = round_pow2(D, 4), KP = round_pow2(K, 16);
     const int64_t FS = 1 + D + (int64_t)D * D;
-    const int64_t F2P = (n_feat2(D) + 15) / 16 * 16;
+    // D > 16 (vmp_gmm_wide.hip): whole groups of four feature tiles
+    const int64_t F2P = D > 16 ? (n_feat2(D) + 63) / 64 * 64 : (n_feat2(D) + 15) / 16 * 16;
     const int64_t FP = F2P;        // coefficient rows of C use the compact feature order
     int64_t o = 0;
     L->DP = DP; L->KP = KP; L->FS = FS; L->FP = FP;
@@ -64,95 +64,6 @@ inline void fill_layout(int D, int K, vmp_gmm_layout *L)
     L->off_scal = o;      o += 8;
     L->off_L = o;         o += 8;
     L->total = (o + 7) / 8 * 8;
-}
-
-__device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
-{
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-
-// exp(x) for x <= 0 (softmax arguments after subtracting the maximum; -inf allowed).  On this
-// chip fp64 vector work is not hidden behind fp64 matrix work (both run on the same fp64 units),
-// so the exponential is the second largest cost of the pass after the MFMAs.  Table form:
-// x = (256 m + j) ln2/256 + r, |r| <= ln2/512, exp(x) = 2^m * T[j] * (1 + r + r^2/2 + r^3/6 +
-// r^4/24) (truncation 4e-17 relative); T = 2^(j/256) correctly rounded, in LDS.  11 fp64
-// instructions instead of 21 for the polynomial-only form (exp_nonpos, vmp_common.h); <= 2 ulp.
-typedef __attribute__((address_space(3))) double lds_f64;
-
-__device__ __forceinline__ double lds_read(uint32_t byte_addr)
-{
-    return *(const lds_f64 *)(uintptr_t)byte_addr;
-}
-
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-__device__ __forceinline__ uint32_t lds_read_u32(uint32_t byte_addr)
-{
-    return *(const lds_u32 *)(uintptr_t)byte_addr;
-}
-
-// v_max_f64 without the canonicalising v_max x, x the compiler puts in front of fmax() operands
-// it cannot prove quiet (MFMA results, shuffled values): they never hold signalling NaNs.
-// The compiler's hazard recogniser does not look inside inline assembly, and a vector
-// instruction that reads a register too soon after the MFMA that writes it gets stale data:
-// mfma_settle() below must separate the matrix instructions from the first max_raw().
-__device__ __forceinline__ double max_raw(double a, double b)
-{
-    double d;
-    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
-// 32 wait states after the MFMAs that produce `acc` (the longest MFMA-write -> VALU-read
-// requirement on this target is below 20), tied to the accumulators so that neither the
-// MFMAs nor their consumers can be scheduled across it.
-template <int KT>
-__device__ __forceinline__ void mfma_settle(v4f64 (&acc)[KT])
-{
-    if constexpr (KT == 1)
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
-    else if constexpr (KT == 2)
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-    else
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-}
-
-// NV exponentials at once, staged so that the NV table reads are in flight together:
-// v[i] <- exp(v[i] - mx)
-template <int NV>
-__device__ __forceinline__ void exp_tab_batch(double (&v)[NV], double mx, uint32_t tab_addr)
-{
-    int ki[NV];
-    double t[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double x = max_raw(v[i] - mx, -800.0);
-        const double kf = __builtin_rint(x * 0x1.71547652b82fep+8);            // 256 / ln 2
-        double r = __builtin_fma(kf, -0x1.62e42fee00000p-9, x);                 // ln2_hi / 256
-        r = __builtin_fma(kf, -0x1.a39ef35793c76p-41, r);                       // ln2_lo / 256
-        ki[i] = (int)kf;
-        t[i] = lds_read(tab_addr + 8u * __builtin_amdgcn_ubfe((uint32_t)ki[i], 0u, 8u));
-        v[i] = r;
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double r = v[i];
-        double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
-        p = __builtin_fma(p, r, 0.5);
-        p = __builtin_fma(p, r, 1.0);
-        v[i] = __builtin_fma(p, r, 1.0);
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = __builtin_ldexp(t[i] * v[i], ki[i] >> 8);
-}
-
-// 1 / s for 1 <= s <= 2^10: hardware estimate + two Newton steps (no scaling, no special cases)
-__device__ __forceinline__ double recip_small(double s)
-{
-    double y = __builtin_amdgcn_rcp(s);
-    double e = __builtin_fma(-s, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-s, y, 1.0);
-    return __builtin_fma(y, e, y);
 }
 
 // ---------------------------------------------------------------------------
@@ -190,8 +101,6 @@ __device__ __forceinline__ double recip_small(double s)
 // of tiles; the surplus ones are empty).  Sums are combined as (half 0) + (half 1) in both
 // wavefronts, so the two halves of a row of r carry the same normaliser bit for bit.
 // ---------------------------------------------------------------------------
-constexpr int RS = 18;
-
 template <int DPT, int KT, int FT2, bool FROM_LABELS, int NW, bool REGEN, int KS>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
 gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
@@ -557,7 +466,8 @@ gmm_rphi_kernel(vmp_gmm_layout L, const double *__restrict__ Tc, double *__restr
 // ---------------------------------------------------------------------------
 // Per-cluster small kernels: one matrix element per lane, SPD inverse by Gauss-Jordan sweeps.
 // WPC = wavefronts per cluster: 1 for D*D <= 64 (four clusters per workgroup, wavefront-level
-// ordering only), 4 for D*D <= 256 (one cluster per workgroup, workgroup barriers).
+// ordering only), 4 for D*D <= 256 and 16 for D*D <= 1024 (one cluster per workgroup, workgroup
+// barriers).
 // ---------------------------------------------------------------------------
 template <int WPC>
 __device__ __forceinline__ void grp_sync()
@@ -590,13 +500,17 @@ __device__ inline double grp_spd_inverse(double v, int D, int i, int j, bool act
     return v;
 }
 
+// threads per workgroup of the per-cluster kernels: 256 (four clusters of <= 64 elements or one of
+// <= 256), 1024 for one cluster of <= 1024 elements
+constexpr int grp_threads(int WPC) { return WPC <= 4 ? NT : 64 * WPC; }
+
 template <int WPC>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(grp_threads(WPC))
 gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, double *st)
 {
     // priors are already stored in st[off_prior..]; initialise every node from its prior
     // (ExponentialFamily.initialize_from_prior, expfamily.py:168-184)
-    constexpr int TPC = 64 * WPC, CPB = 4 / WPC;
+    constexpr int TPC = 64 * WPC, CPB = grp_threads(WPC) / TPC;
     __shared__ double Ms[CPB][TPC];
     const int w = threadIdx.x / TPC, l = threadIdx.x % TPC;
     const int k = blockIdx.x * CPB + w;
@@ -635,10 +549,10 @@ gmm_init_state_kernel(vmp_gmm_layout L, int D, int K, double beta0, double n0, d
 // mu.update(): Lambda_mu = beta0 I + R_k <Lambda_k>, Cov, mean = Cov <Lambda_k> S1_k
 // (gaussian.py:649-706 with the messages gaussian.py:2451-2454 weighted by r, mixture.py:126-158)
 template <int WPC>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(grp_threads(WPC))
 gmm_update_mu_kernel(vmp_gmm_layout L, int D, int K, double *st)
 {
-    constexpr int TPC = 64 * WPC, CPB = 4 / WPC;
+    constexpr int TPC = 64 * WPC, CPB = grp_threads(WPC) / TPC;
     __shared__ double Ms[CPB][TPC];
     __shared__ double Cs[CPB][TPC];
     __shared__ double bs[CPB][MAXD];
@@ -677,10 +591,10 @@ gmm_update_mu_kernel(vmp_gmm_layout L, int D, int K, double *st)
 // Lambda.update(): n_k = n0 + R_k, V_k = V0 + S2 - S1 mu^T - mu S1^T + R <mu mu^T>
 // (wishart.py:153-188 with the message gaussian.py:2516-2520 weighted by r)
 template <int WPC>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(grp_threads(WPC))
 gmm_update_lambda_kernel(vmp_gmm_layout L, int D, int K, double *st)
 {
-    constexpr int TPC = 64 * WPC, CPB = 4 / WPC;
+    constexpr int TPC = 64 * WPC, CPB = grp_threads(WPC) / TPC;
     __shared__ double Ms[CPB][TPC];
     const int w = threadIdx.x / TPC, l = threadIdx.x % TPC;
     const int k = blockIdx.x * CPB + w;
@@ -967,6 +881,25 @@ int32_t run_gmm_pass(vmp_ctx *ctx, bool from_labels, const double *Y, int64_t N,
     int32_t rc = VMP_ERR_UNSUPPORTED;
     hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+    if (D > 16) {
+        // workspace: [partials | compact T | coefficient fragments]
+        int64_t pd = 0, fd = 0;
+        vmp_gmm_wide_workspace_doubles(ctx, D, K, L.F2P, L.KP, &pd, &fd);
+        double *Tcw = P + pd, *Cfrag = Tcw + L.KP * L.F2P;
+        int nb = 0;
+        rc = vmp_gmm_wide_pass(ctx, Y, N, D, K, L.F2P, L.KP, C, from_labels ? labels : nullptr, R,
+                               P, Cfrag, &nb);
+        if (rc != VMP_OK) return rc;
+        if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
+        const int totalw = (int)(L.KP * L.F2P + 2);
+        hipLaunchKernelGGL(gmm_reduce_kernel, dim3((totalw + 63) / 64), dim3(NT), 0, ctx->stream,
+                           L, D, K, P, nb, from_labels ? 0 : 1, Tcw, state);
+        if (!from_labels)
+            hipLaunchKernelGGL(gmm_rphi_kernel, dim3(1), dim3(NT), 0, ctx->stream, L, Tcw, state);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
+        return VMP_OK;
+    }
 #define VMP_GCASE(dpt, kt, ft2)                                                                 \
     if (DPT == dpt && KT == kt && FT2 == ft2)                                                   \
         rc = launch_gmm_pass<dpt, kt, ft2>(ctx, from_labels, Y, N, D, K, C, labels, R, P, ntiles);
@@ -1015,6 +948,11 @@ int32_t vmp_gmm_workspace_bytes(vmp_ctx *ctx, int32_t D, int32_t K, size_t *byte
     int32_t rc = vmp_gmm_get_layout(D, K, &L);
     VMP_REQUIRE(ctx, rc == VMP_OK, rc, "fused GMM block supports D <= %d, K <= %d", MAXD, MAXK);
     *bytes = (size_t)(gmm_max_grid(ctx) * (L.KP * L.F2P + 8) + L.KP * L.F2P + 64) * sizeof(double);
+    if (D > 16) {
+        int64_t pd = 0, fd = 0;
+        vmp_gmm_wide_workspace_doubles(ctx, D, K, L.F2P, L.KP, &pd, &fd);
+        *bytes = (size_t)(pd + L.KP * L.F2P + fd + 64) * sizeof(double);
+    }
     return VMP_OK;
 }
 
@@ -1042,9 +980,12 @@ int32_t vmp_gmm_init_state(vmp_ctx *ctx, int32_t D, int32_t K, const double *alp
     if (D * D <= 64)
         hipLaunchKernelGGL(gmm_init_state_kernel<1>, dim3((K + 3) / 4), dim3(NT), 0, s, L, D, K,
                            beta0, n0, state);
-    else
+    else if (D * D <= 256)
         hipLaunchKernelGGL(gmm_init_state_kernel<4>, dim3(K), dim3(NT), 0, s, L, D, K, beta0, n0,
                            state);
+    else
+        hipLaunchKernelGGL(gmm_init_state_kernel<16>, dim3(K), dim3(1024), 0, s, L, D, K, beta0,
+                           n0, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -1076,8 +1017,11 @@ int32_t vmp_gmm_update_mu(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
     if (D * D <= 64)
         hipLaunchKernelGGL(gmm_update_mu_kernel<1>, dim3((K + 3) / 4), dim3(NT), 0, ctx->stream, L,
                            D, K, state);
-    else
+    else if (D * D <= 256)
         hipLaunchKernelGGL(gmm_update_mu_kernel<4>, dim3(K), dim3(NT), 0, ctx->stream, L, D, K,
+                           state);
+    else
+        hipLaunchKernelGGL(gmm_update_mu_kernel<16>, dim3(K), dim3(1024), 0, ctx->stream, L, D, K,
                            state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -1089,9 +1033,12 @@ int32_t vmp_gmm_update_lambda(vmp_ctx *ctx, int32_t D, int32_t K, double *state)
     if (D * D <= 64)
         hipLaunchKernelGGL(gmm_update_lambda_kernel<1>, dim3((K + 3) / 4), dim3(NT), 0,
                            ctx->stream, L, D, K, state);
-    else
+    else if (D * D <= 256)
         hipLaunchKernelGGL(gmm_update_lambda_kernel<4>, dim3(K), dim3(NT), 0, ctx->stream, L, D, K,
                            state);
+    else
+        hipLaunchKernelGGL(gmm_update_lambda_kernel<16>, dim3(K), dim3(1024), 0, ctx->stream, L, D,
+                           K, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

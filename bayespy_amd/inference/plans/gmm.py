@@ -5,7 +5,7 @@ Execution plan of the full-covariance Gaussian-mixture block
     mu = GaussianARD(0, beta0, shape=(D,), plates=(K,)); Lambda = Wishart(n0, V0, plates=(K,));
     Y = Mixture(z, Gaussian, mu, Lambda)                     (bayespy/demos/mog.py:17-64)
 
-with a fully observed Y, D <= 16, K <= 64.  The plan owns, in HBM: ``Y`` (N, D), the
+with a fully observed Y, D <= 32, K <= 64.  The plan owns, in HBM: ``Y`` (N, D), the
 responsibilities ``R`` (N, K) (= z.u[0]) and one state block (``vmp_gmm_layout``)
 holding the statistics T = r^T [1, y, y y^T] that ranks all-reduce and every
 replicated quantity.  The only plate-sized work per VB iteration is ONE pass over
@@ -36,7 +36,7 @@ class GMMKernels:
         L = _lib.GMMLayout()
         rc = self.lib.vmp_gmm_get_layout(D, K, ctypes.byref(L))
         if rc != _lib.VMP_OK:
-            _lib.raise_for_status(rc, 'fused GMM block supports D <= 16 and K <= 64')
+            _lib.raise_for_status(rc, 'fused GMM block supports D <= 32 and K <= 64')
         return L
 
     def workspace_doubles(self, D, K):
@@ -98,7 +98,7 @@ class GMMPlan:
     def describe():
         return ("Mixture(Categorical(Dirichlet(const)), Gaussian, GaussianARD(0, const, "
                 "shape=(D,), plates=(K,)), Wishart(const, const, plates=(K,))), fully observed, "
-                "D <= 16, K <= 64")
+                "D <= 32, K <= 64")
 
     @staticmethod
     def match(nodes, why=None):
@@ -129,8 +129,8 @@ class GMMPlan:
                 continue
             N = Y.plates[0]
             K, D = Y.clusters, Y.dims[0][0]
-            if D > 16 or K > 64:
-                no(Y, 'D = %d, K = %d exceed the limits of the block (D <= 16, K <= 64)' % (D, K))
+            if D > 32 or K > 64:
+                no(Y, 'D = %d, K = %d exceed the limits of the block (D <= 32, K <= 64)' % (D, K))
                 continue
             if z.plates != (N,) or mu.plates != (K,) or Lam.plates != (K,) or mu.shape != (D,):
                 no(Y, 'plates of z / mu / Lambda are not (N,), (K,), (K,)')

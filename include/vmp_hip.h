@@ -393,7 +393,7 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
  * Model block  Y = Mixture(z, Gaussian, mu, Lambda), z = Categorical(alpha),
  * alpha = Dirichlet(a0), mu = GaussianARD(0, beta0, shape=(D,), plates=(K,)),
  * Lambda = Wishart(n0, V0, plates=(K,))   (bayespy/demos/mog.py:17-64), Y fully
- * observed, D <= 16, K <= 64.  One VB iteration reads Y exactly once and writes the
+ * observed, D <= 32, K <= 64.  One VB iteration reads Y exactly once and writes the
  * responsibilities once.  Y is (N, D) row-major (the reference's layout), the
  * responsibilities R are (N, K) row-major.
  */

@@ -218,8 +218,7 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
     # 4 x KP/16 x F2P/16 (phase 2) instructions of 2048 flops over the compact feature list
     # (F2 = D(D+1)/2 + D + 1 padded to 16) -- about 2/3 of the algorithmic count, which prices the
     # symmetric quadratic form as D^2 products
-    F2P = (D * (D + 1) // 2 + D + 1 + 15) // 16 * 16
-    KP = (K + 15) // 16 * 16
+    F2P, KP = int(plan.layout.F2P), int(plan.layout.KP)      # padded sizes the kernels run on
     issued = (N / 16.0) * (KP // 16) * (F2P // 4 + 4 * (F2P // 16)) * 2048.0
     out['roofline']['issued_mfma_flops_per_launch'] = issued
     out['roofline']['issued_mfma_TFLOPs'] = issued / (avg * 1e-3) / 1e12
