@@ -6,7 +6,11 @@
 //   * the coefficient fragments of ONE 16-cluster tile are 73.7 KB at D = 32 -- the four of
 //     K = 64 do not fit the LDS.  They are laid out in fragment order once per pass
 //     (gmm_cfrag_kernel, 295 KB: L2-resident) and phase 1 streams them: eight 512-byte loads per
-//     wavefront in flight ahead of the eight matrix instructions that use them;
+//     wavefront in flight ahead of the eight matrix instructions that use them (sixteen: +5 %
+//     at D = 32 but spills where two wavefronts per SIMD fit); the next tile's y values are
+//     fetched during the current tile.  Phi is summed in FOUR interleaved accumulators (k-steps
+//     q = 0, 1, 2, 3 mod 4), added at the end: one accumulator is a chain of 48 ... 144 dependent
+//     matrix instructions, which issue at about half the rate of independent ones;
 //   * one 16-cluster tile per wavefront (KS = KT wavefronts share a 16-point tile; the T
 //     accumulators of a tile are FT2 x 8 = 288 registers at D = 32: one wavefront per SIMD); the
 //     wavefronts of a tile exchange the softmax normalisers through LDS as in the pair-split form
@@ -96,15 +100,28 @@ gmm_wide_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
     const int64_t tile0 = (int64_t)blockIdx.x * GROUPS + grp;
     // the barriers of the exchange need the same trip count in every wavefront
     const int64_t tile_end = tile0 + (ntiles + stride - 1) / stride * stride;
+    // y of the first tile; inside the loop the next tile's values are fetched a tile ahead
+    double ynx[WDP / 4];
+#pragma unroll
+    for (int j = 0; j < WDP / 4; ++j) {
+        const int d = 4 * j + g;
+        const int64_t nf = tile0 * TNC + l15;
+        ynx[j] = (nf < N && d < D) ? Y[nf * D + d] : 0.0;
+    }
     for (int64_t tile = tile0; tile < tile_end; tile += stride) {
         const int64_t n0 = tile * TNC;
         const int64_t n = n0 + l15;
         const bool nok = n < N;
         // ---- y: lane (g, l15) owns y[n][4j + g] ------------------------------------
 #pragma unroll
-        for (int j = 0; j < WDP / 4; ++j) {
-            const int d = 4 * j + g;
-            ytile[l15 * WYS + d] = (nok && d < D) ? Y[n * D + d] : 0.0;
+        for (int j = 0; j < WDP / 4; ++j) ytile[l15 * WYS + 4 * j + g] = ynx[j];
+        {
+            const int64_t nn2 = (tile + stride) * TNC + l15;
+#pragma unroll
+            for (int j = 0; j < WDP / 4; ++j) {
+                const int d = 4 * j + g;
+                ynx[j] = (nn2 < N && d < D) ? Y[nn2 * D + d] : 0.0;
+            }
         }
         if (g == 0) {
             ytile[l15 * WYS + WDP] = 1.0;
@@ -114,8 +131,9 @@ gmm_wide_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
 
         if (!from_labels) {
             // ---- phase 1: Phi(16 x 16) = C_tile * feat, coefficients streamed from L2 --------
-            v4f64 acc1[1];
-            acc1[0] = v4f64{0.0, 0.0, 0.0, 0.0};
+            v4f64 acc1[1], accp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accp[c] = v4f64{0.0, 0.0, 0.0, 0.0};
             double cc[PF], cn[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) cc[u] = Cw[(int64_t)u * 64];
@@ -132,7 +150,7 @@ gmm_wide_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
                     const uint32_t pk = lds_read_u32(ftab_addr + 256u * (q0 + u));
                     const double b = lds_read(yrow_addr + (pk & 0xffffu))
                                      * lds_read(yrow_addr + (pk >> 16));
-                    acc1[0] = mfma_f64(cc[u], b, acc1[0]);
+                    accp[u & 3] = mfma_f64(cc[u], b, accp[u & 3]);
                 }
                 if (q0 + PF < KS1) {
 #pragma unroll
@@ -141,7 +159,10 @@ gmm_wide_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             }
             // ---- softmax over k for column n (utils/misc.py:1388-1401) ------------------
             // lane holds Phi[k = kh*16 + g + 4r][n]
-            mfma_settle<1>(acc1);
+            mfma_settle<4>(accp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc1[0][r] = (accp[0][r] + accp[1][r]) + (accp[2][r] + accp[3][r]);
             double mx = max_raw(acc1[0][0], acc1[0][1]);
             mx = max_raw(mx, max_raw(acc1[0][2], acc1[0][3]));
             mx = max_raw(mx, __shfl_xor(mx, 16, 64));
@@ -205,7 +226,9 @@ gmm_wide_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
             const uint32_t yq = ygrp_addr + (uint32_t)(4 * q * WYS * 8);
 #pragma unroll
             for (int ft = 0; ft < FT2; ++ft) {
-                if ((ft & 1) == 0) asm volatile("" ::: "memory");
+                // operand reads of four feature tiles ahead of their matrix instructions (one
+                // wavefront per SIMD: nothing else hides the LDS latency)
+                if ((ft & 3) == 0) asm volatile("" ::: "memory");
                 const uint32_t pk = lds_read_u32(ftab_addr + 256u * (KS1 + ft));
                 const double b = lds_read(yq + (pk & 0xffffu)) * lds_read(yq + (pk >> 16));
                 acc2[ft] = mfma_f64(a, b, acc2[ft]);
