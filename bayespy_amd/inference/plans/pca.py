@@ -111,9 +111,25 @@ class HIPKernels:
         self.rt.check(self.lib.vmp_pca_tile_y(self.ctx, ptr(Y), ldy, N, D, K, ptr(Yt)))
         return Yt
 
-    def xpass_tiled(self, Yt, N, D, K, X, ldx, state, ws):
-        self.rt.check(self.lib.vmp_pca_xpass_tiled(self.ctx, ptr(Yt), N, D, K, ptr(X), ldx, 0,
-                                                   ptr(state), ptr(ws)))
+    def xpass_tiled(self, Yt, N, D, K, X, ldx, state, ws, x_tiled=False):
+        self.rt.check(self.lib.vmp_pca_xpass_tiled(self.ctx, ptr(Yt), N, D, K, ptr(X), ldx,
+                                                   1 if x_tiled else 0, ptr(state), ptr(ws)))
+
+    # <x> may be kept tile-major as well ([tile][KP][32]): the pass then writes one contiguous
+    # 8 KB span per tile instead of KP row segments that lie 8*ldx bytes apart
+    # (opt-in: measured 2.29 / 2.39 ms against 2.21 / 2.33 ms for the row-major <x> with the
+    # placement trials of both, profiles/r03/placement_trials_ab.txt)
+    x_tiles = os.environ.get('BAYESPY_AMD_PCA_XTILES', '0') == '1'
+
+    def tiled_x_doubles(self, D, K, N):
+        n = ctypes.c_int64()
+        self.rt.check(self.lib.vmp_pca_tiled_doubles(D, K, N, None, ctypes.byref(n)))
+        return max(int(n.value), 1)
+
+    def tile_x(self, to_tiled, X, ldx, N, D, K, Xt):
+        """Xt <- X (row-major (KP, ldx)) or X <- Xt (vmp_pca_tile_x)."""
+        self.rt.check(self.lib.vmp_pca_tile_x(self.ctx, 1 if to_tiled else 0, ptr(X), ldx, N, D, K,
+                                              ptr(Xt)))
 
     def rotate_rows(self, R, X, N):
         """X[:, :N] <- R X[:, :N] on the device (vmp_gemm_strided via utils.linalg)."""
@@ -379,6 +395,36 @@ class PCAPlan:
             self.ldy = ldy
         self.Yt = None
 
+    # -- <x>: row-major (KP, ldx) until the first tile-major pass, tile-major afterwards ---------
+    _Xt = None
+    _Xrows = None
+    _x_form = 'rows'
+    _xrows_valid = True
+
+    @property
+    def Xd(self):
+        """Row-major (KP, ldx) view of <x>.  While <x> lives tile-major (after a tile-major pass)
+        this is a copy formed on demand (vmp_pca_tile_x) and kept until the next pass."""
+        if self._x_form == 'tiled' and not self._xrows_valid:
+            k, rt = self.kernels, self.rt
+            k.xjoin()                       # the pass that writes the tiles has finished
+            rt.sync_stream()
+            if self._Xrows is None:
+                self._Xrows = rt.zeros(int(self.layout.KP), self.ldx)
+            k.tile_x(False, self._Xrows, self.ldx, self.N, self.D, self.K, self._Xt)
+            self._xrows_valid = True
+        return self._Xrows
+
+    @Xd.setter
+    def Xd(self, value):
+        self._Xrows = value
+        self._x_form, self._xrows_valid = 'rows', True
+
+    def _x_rows_modified(self):
+        """The row-major array was changed in place (a loaded value, a rotation): it is the
+        current <x>; the next pass overwrites the tiles anyway."""
+        self._x_form, self._xrows_valid = 'rows', True
+
     def _load_x_value(self, x0):
         """<x> <- a given value, (.., N, K) -> the plate-contiguous (K, N) layout."""
         rt = self.rt
@@ -393,6 +439,7 @@ class PCAPlan:
             x0 = np.broadcast_to(np.asarray(x0, dtype=np.float64),
                                  self.X.plates + (K,)).reshape(N, K)
             self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
+        self._x_rows_modified()
 
     def _load_w_value(self, w0):
         """<w_d> <- the rows of a (D, K) host array, Sww = W^T W (delta moments: no covariance)."""
@@ -453,6 +500,8 @@ class PCAPlan:
         if self._ready:
             return
         self._delta = _delta.delta_roles(self.roles)    # point masses until their first update
+        self._Xt, self._Xrows = None, None
+        self._x_form, self._xrows_valid = 'rows', True
         rt, k = self.rt, self.kernels
         torch = rt.torch
         D, N, K = self.D, self.N, self.K
@@ -548,8 +597,18 @@ class PCAPlan:
                 if self.plate_layout == 'tiled':
                     if self.Yt is None:
                         self.Yt = k.tile_y(self.Yd, self.ldy, N, D, K)
+                        if getattr(k, 'x_tiles', False):
+                            # from here on <x> lives tile-major; the row-major view (self.Xd)
+                            # is formed on demand (_x_rows)
+                            self._Xt = rt.empty(k.tiled_x_doubles(D, K, N))
+                            self._Xrows = None
                         self._place_plate_arrays()
-                    k.xpass_tiled(self.Yt, N, D, K, self.Xd, self.ldx, self.state, self.ws)
+                    if self._Xt is not None:
+                        k.xpass_tiled(self.Yt, N, D, K, self._Xt, self.ldx, self.state, self.ws,
+                                      x_tiled=True)
+                        self._x_form, self._xrows_valid = 'tiled', False
+                    else:
+                        k.xpass_tiled(self.Yt, N, D, K, self.Xd, self.ldx, self.state, self.ws)
                 else:
                     k.xpass(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
             else:
@@ -581,27 +640,37 @@ class PCAPlan:
         self.placement = None
         if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < 2e9:
             return
-        set_bytes = 8 * (self.Yt.numel() + self.Xd.numel())
+        set_bytes = 8 * (self.Yt.numel() + (self._Xt if self._Xt is not None else self.Xd).numel())
         free = torch.cuda.mem_get_info(rt.device)[0]
         tries = min(tries, 1 + int(max(free - (8 << 30), 0) // set_bytes))
         if tries <= 1:
             return
 
-        def timed(Yt, Xd):
+        xt = self._Xt is not None
+        x_cur = self._Xt if xt else self.Xd
+
+        def timed(Yt, X):
             k.set_timing(True)
             for _ in range(2):
-                k.xpass_tiled(Yt, N, D, K, Xd, self.ldx, self.state, self.ws)
+                if xt:
+                    k.xpass_tiled(Yt, N, D, K, X, self.ldx, self.state, self.ws, x_tiled=True)
+                else:
+                    k.xpass_tiled(Yt, N, D, K, X, self.ldx, self.state, self.ws)
             k.xjoin()
             ms = min(a for a, _ in k.pass_times_ms(8))
             k.set_timing(bool(getattr(self, 'timing', False)))
             return ms
 
-        xs = [self.Xd] + [rt.empty(self.Xd.shape[0], self.Xd.shape[1]) for _ in range(tries - 1)]
+        xs = [x_cur] + [rt.empty(*x_cur.shape) for _ in range(tries - 1)]
         x_ms = [timed(self.Yt, x) for x in xs]
-        self.Xd = xs[x_ms.index(min(x_ms))]
+        x_cur = xs[x_ms.index(min(x_ms))]
+        if xt:
+            self._Xt = x_cur
+        else:
+            self.Xd = x_cur
         del xs
         ys = [self.Yt] + [k.tile_y(self.Yd, self.ldy, N, D, K) for _ in range(tries - 1)]
-        y_ms = [x_ms[x_ms.index(min(x_ms))]] + [timed(y, self.Xd) for y in ys[1:]]
+        y_ms = [x_ms[x_ms.index(min(x_ms))]] + [timed(y, x_cur) for y in ys[1:]]
         self.Yt = ys[y_ms.index(min(y_ms))]
         del ys
         self.placement = {'x_ms': x_ms, 'yt_ms': y_ms}
@@ -624,13 +693,13 @@ class PCAPlan:
         if self._ready:
             self._flush()
         self._pending = []
-        if getattr(self, 'Xd', None) is not None and self.stats == 'gram':
+        if (self._Xrows is not None or self._Xt is not None) and self.stats == 'gram':
             self.kernels.xjoin()
 
     def __del__(self):
         # the plate array must not return to the allocator while a pass still writes it
         try:
-            if getattr(self, 'Xd', None) is not None and self.stats == 'gram':
+            if (self._Xrows is not None or self._Xt is not None) and self.stats == 'gram':
                 self.kernels.xjoin()
         except Exception:       # noqa: BLE001 - interpreter shutdown
             pass
@@ -793,6 +862,7 @@ class PCAPlan:
         self.state.copy_(torch.from_numpy(st))
         self.Xd[:self.K, :self.N].copy_(torch.from_numpy(np.array(reader.get(base + 'X'),
                                                                  dtype=np.float64)))
+        self._x_rows_modified()
         self._version += 1
 
     # -- rotations (inference/transformations.py) ----------------------------------------------------
@@ -847,6 +917,7 @@ class PCAPlan:
             self._put_block(L.off_CX, R @ cx @ R.T, KP)
             sc[1] -= 2.0 * logdetR
             self.kernels.rotate_rows(R, self.Xd, self.N)
+            self._x_rows_modified()
         else:
             raise NotImplementedError('rotation of %s' % node.name)
         self.state[L.off_scal:L.off_scal + 2].copy_(torch.from_numpy(sc))
