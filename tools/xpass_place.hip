@@ -220,6 +220,50 @@ int main(int argc, char **argv)
         CK(hipFree(Yt2));
         CK(hipFree(spacer));
     }
+    // ---- (g) landscape: X after spacers of 0 ... 96 GB (Yt fixed), then Yt AND X after them -------
+    if (argc > 4) {
+        printf("(g) X after a spacer of S GB (kept allocated while timed), Yt fixed at %p\n", (void *)Yt);
+        for (int sg = 0; sg <= 96; sg += 4) {
+            char *spacer = nullptr;
+            if (sg) CK(hipMalloc(&spacer, (size_t)sg << 30));
+            double *X;
+            CK(hipMalloc(&X, xbytes));
+            double best;
+            const double avg = time_pass(Yt, N, D, K, X, ld, state, ws, 3, &best);
+            printf("  S = %3d GB   X at %p   avg %.4f ms   best %.4f\n", sg, (void *)X, avg, best);
+            CK(hipFree(X));
+            if (spacer) CK(hipFree(spacer));
+        }
+        printf("(h) Yt and X both after a spacer of S GB\n");
+        for (int sg = 0; sg <= 96; sg += 8) {
+            char *spacer = nullptr;
+            if (sg) CK(hipMalloc(&spacer, (size_t)sg << 30));
+            double *Yt2, *X;
+            CK(hipMalloc(&Yt2, (size_t)yt_n * 8));
+            CK(hipMalloc(&X, xbytes));
+            CK(hipMemcpyAsync(Yt2, Yt, (size_t)yt_n * 8, hipMemcpyDeviceToDevice, stream));
+            double best;
+            const double avg = time_pass(Yt2, N, D, K, X, ld, state, ws, 3, &best);
+            printf("  S = %3d GB   Yt at %p  X at %p   avg %.4f ms   best %.4f\n", sg, (void *)Yt2,
+                   (void *)X, avg, best);
+            CK(hipFree(X));
+            CK(hipFree(Yt2));
+            if (spacer) CK(hipFree(spacer));
+        }
+        // X candidates allocated one after the other and ALL kept (as the plan's trial does)
+        printf("(i) 24 allocations of X kept alive, in allocation order\n");
+        std::vector<double *> keep;
+        for (int c = 0; c < 24; ++c) {
+            double *X;
+            CK(hipMalloc(&X, xbytes));
+            keep.push_back(X);
+            double best;
+            const double avg = time_pass(Yt, N, D, K, X, ld, state, ws, 3, &best);
+            printf("  #%2d  X at %p   avg %.4f ms   best %.4f\n", c, (void *)X, avg, best);
+        }
+        for (double *x : keep) CK(hipFree(x));
+        return 0;
+    }
     // ---- (e) ten fresh default allocations of both arrays: the spread -----------------------------
     printf("(e) ten fresh default allocations of Yt and X\n");
     for (int rep = 0; rep < 10; ++rep) {
