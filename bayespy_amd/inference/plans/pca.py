@@ -640,7 +640,7 @@ class PCAPlan:
         self.placement = None
         if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < 2e9:
             return
-        set_bytes = 8 * (self.Yt.numel() + (self._Xt if self._Xt is not None else self.Xd).numel())
+        set_bytes = 8 * (self.Yt.numel() + 2 * (self._Xt if self._Xt is not None else self.Xd).numel())
         free = torch.cuda.mem_get_info(rt.device)[0]
         tries = min(tries, 1 + int(max(free - (8 << 30), 0) // set_bytes))
         if tries <= 1:
@@ -663,19 +663,28 @@ class PCAPlan:
 
         # the placement of <x> (the write stream) decides most of the spread and its candidates are
         # cheap (a fifth of the bytes, no re-layout): twice as many of them
-        xs = [x_cur] + [rt.empty(*x_cur.shape) for _ in range(2 * tries - 1)]
-        x_ms = [timed(self.Yt, x) for x in xs]
-        x_cur = xs[x_ms.index(min(x_ms))]
+        # (candidates a few GB apart: the pass time changes level over 8-18 GB of the allocation
+        # order, profiles/r03/xpass_place_landscape.txt; the spacers are freed with the losers)
+        xs, spacers = [x_cur], []
+        gap = 2 * x_cur.numel() if free > 16 * set_bytes else 0
+        for _ in range(2 * tries - 1):
+            if gap:
+                spacers.append(rt.empty(gap))
+            xs.append(rt.empty(*x_cur.shape))
+        ys = [self.Yt] + [k.tile_y(self.Yd, self.ldy, N, D, K) for _ in range(tries - 1)]
+        # every pair: neither array alone decides (a process can sit at 2.33 ms for all candidates
+        # of one array while another Y / X pair reaches 2.2); ~0.15 s once at the headline size
+        grid = [[timed(y, x) for x in xs] for y in ys]
+        best = min((ms, j, i) for j, row in enumerate(grid) for i, ms in enumerate(row))
+        x_cur = xs[best[2]]
         if xt:
             self._Xt = x_cur
         else:
             self.Xd = x_cur
-        del xs
-        ys = [self.Yt] + [k.tile_y(self.Yd, self.ldy, N, D, K) for _ in range(tries - 1)]
-        y_ms = [x_ms[x_ms.index(min(x_ms))]] + [timed(y, x_cur) for y in ys[1:]]
-        self.Yt = ys[y_ms.index(min(y_ms))]
-        del ys
-        self.placement = {'x_ms': x_ms, 'yt_ms': y_ms}
+        self.Yt = ys[best[1]]
+        del xs, ys, spacers
+        x_ms, y_ms = grid[0], [row[best[2]] for row in grid]
+        self.placement = {'x_ms': x_ms, 'yt_ms': y_ms, 'grid_ms': grid, 'kept': [best[1], best[2]]}
 
     def _flush(self):
         """Issue the queued replicated-node updates.  They are queued rather than launched
