@@ -631,14 +631,14 @@ class PCAPlan:
         changed nothing (tools/xpass_place.hip, profiles/r03/xpass_place.txt).  So the plan tries
         a few allocations at set-up -- first for X, then for the tile-major Y -- with the pass it
         is about to run anyway (same A, same Y: every trial writes the <x> of this update, bit
-        for bit) and keeps the fastest; the others go back to the allocator.  Arrays below 2 GB
+        for bit) and keeps the fastest; the others go back to the allocator.  Arrays below 1 GB
         per pass, the CPU test double and BAYESPY_AMD_PLACEMENT_TRIES=1 skip it."""
         rt, k = self.rt, self.kernels
         torch = rt.torch
         N, D, K = self.N, self.D, self.K
         tries = int(os.environ.get('BAYESPY_AMD_PLACEMENT_TRIES', '4'))
         self.placement = None
-        if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < 2e9:
+        if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < 1e9:
             return
         set_bytes = 8 * (self.Yt.numel() + 2 * (self._Xt if self._Xt is not None else self.Xd).numel())
         free = torch.cuda.mem_get_info(rt.device)[0]
