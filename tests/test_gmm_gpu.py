@@ -204,14 +204,15 @@ def test_config3_size_properties(N, D, K):
     np.testing.assert_allclose(plan.Rd[idx].cpu().numpy(), p, rtol=1e-8, atol=1e-13)
 
 
-def test_config3_dims_direct_oracle_parity():
+@pytest.mark.parametrize('N,D,K', [(2_000_000, 8, 64), (500_000, 16, 64), (200_000, 32, 64)])
+def test_config3_dims_direct_oracle_parity(N, D, K):
     """D=8, K=64 (BASELINE config 3 dims) at N=2e6, DIRECT parity: the chunked NumPy oracle on
     the same data and initial labels, two iterations (the reference itself builds (N,K,D,D)
     temporaries and stops at N~3e5); bound rel <= 1e-9 per iteration and node term,
-    responsibilities of a strided sample atol 1e-12, cluster moments rtol 1e-7."""
+    responsibilities of a strided sample atol 1e-12, cluster moments rtol 1e-7.  The same at
+    D = 16 (pair-split instance) and D = 32 (coefficients streamed from L2)."""
     import torch
     from oracle.gmm import GMMOracle
-    N, D, K = 2_000_000, 8, 64
     dev = torch.device('cuda')
     g = torch.Generator(device=dev)
     g.manual_seed(11)
