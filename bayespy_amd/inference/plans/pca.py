@@ -629,10 +629,11 @@ class PCAPlan:
         K = 32) over fresh allocations of X and of the tile-major Y within ONE process, while
         offsets inside an allocation, the row stride of X or physically contiguous allocations
         changed nothing (tools/xpass_place.hip, profiles/r03/xpass_place.txt).  So the plan tries
-        a few allocations at set-up -- first for X, then for the tile-major Y -- with the pass it
+        a few allocations of the tile-major Y and of X at set-up -- every pair, with the pass it
         is about to run anyway (same A, same Y: every trial writes the <x> of this update, bit
-        for bit) and keeps the fastest; the others go back to the allocator.  Arrays below 1 GB
-        per pass, the CPU test double and BAYESPY_AMD_PLACEMENT_TRIES=1 skip it."""
+        for bit) -- and keeps the fastest pair; the others go back to the allocator.  Arrays
+        below 1 GB per pass, the CPU test double and BAYESPY_AMD_PLACEMENT_TRIES=1 skip it; with
+        little free memory fewer candidates are tried, an allocation that fails ends the list."""
         rt, k = self.rt, self.kernels
         torch = rt.torch
         N, D, K = self.N, self.D, self.K
@@ -665,13 +666,18 @@ class PCAPlan:
         # cheap (a fifth of the bytes, no re-layout): twice as many of them
         # (candidates a few GB apart: the pass time changes level over 8-18 GB of the allocation
         # order, profiles/r03/xpass_place_landscape.txt; the spacers are freed with the losers)
-        xs, spacers = [x_cur], []
+        xs, ys, spacers = [x_cur], [self.Yt], []
         gap = 2 * x_cur.numel() if free > 16 * set_bytes else 0
-        for _ in range(2 * tries - 1):
-            if gap:
-                spacers.append(rt.empty(gap))
-            xs.append(rt.empty(*x_cur.shape))
-        ys = [self.Yt] + [k.tile_y(self.Yd, self.ldy, N, D, K) for _ in range(tries - 1)]
+        try:
+            for _ in range(2 * tries - 1):
+                if gap:
+                    spacers.append(rt.empty(gap))
+                xs.append(rt.empty(*x_cur.shape))
+            for _ in range(tries - 1):
+                ys.append(k.tile_y(self.Yd, self.ldy, N, D, K))
+        except RuntimeError:            # out of memory: the candidates made so far take part
+            spacers = []
+            torch.cuda.empty_cache()
         # every pair: neither array alone decides (a process can sit at 2.33 ms for all candidates
         # of one array while another Y / X pair reaches 2.2); ~0.15 s once at the headline size
         grid = [[timed(y, x) for x in xs] for y in ys]
