@@ -623,7 +623,23 @@ class PCAPlan:
             return
         self._version += 1
 
-    def _place_plate_arrays(self):
+    def place_plate_arrays(self):
+        """The placement trial of :meth:`_place_plate_arrays` as an explicit set-up step (otherwise
+        it is part of the first ``X.update()``): builds the device state and the tile-major Y, tries
+        the allocations with whatever A the state holds (the time of the pass does not depend on
+        the values) and keeps the current <x> -- the trial writes only into fresh candidates and
+        the kept one receives a copy."""
+        self._materialize()
+        if self.stats != 'gram' or self.plate_layout != 'tiled' or self.Yt is not None:
+            return
+        k = self.kernels
+        self.rt.sync_stream()
+        self.Yt = k.tile_y(self.Yd, self.ldy, self.N, self.D, self.K)
+        if getattr(k, 'x_tiles', False):
+            self._Xt = self.rt.empty(k.tiled_x_doubles(self.D, self.K, self.N))
+        self._place_plate_arrays(keep_x=True)
+
+    def _place_plate_arrays(self, keep_x=False):
         """Where the driver puts a multi-GB allocation physically decides how fast the plate pass
         streams it: the same kernel on the same data ran between 2.20 and 2.50 ms (N = 1e7, D = 128,
         K = 32) over fresh allocations of X and of the tile-major Y within ONE process, while
@@ -666,10 +682,13 @@ class PCAPlan:
         # cheap (a fifth of the bytes, no re-layout): twice as many of them
         # (candidates a few GB apart: the pass time changes level over 8-18 GB of the allocation
         # order, profiles/r03/xpass_place_landscape.txt; the spacers are freed with the losers)
-        xs, ys, spacers = [x_cur], [self.Yt], []
+        # keep_x: the current row-major <x> still holds values somebody may read (set-up before the
+        # first X.update()): it is not among the candidates, the kept one gets a copy of it
+        keep = keep_x and not xt
+        xs, ys, spacers = ([] if keep else [x_cur]), [self.Yt], []
         gap = 2 * x_cur.numel() if free > 16 * set_bytes else 0
         try:
-            for _ in range(2 * tries - 1):
+            for _ in range(2 * tries - (0 if keep else 1)):
                 if gap:
                     spacers.append(rt.empty(gap))
                 xs.append(rt.empty(*x_cur.shape))
@@ -678,10 +697,21 @@ class PCAPlan:
         except RuntimeError:            # out of memory: the candidates made so far take part
             spacers = []
             torch.cuda.empty_cache()
+        if not xs:
+            return
+        # the pass also queues S <- [G A^T; A G A^T] on the state: inside an iteration that is the
+        # statistic of this update, at set-up time (keep_x) the state must come back as it was
+        saved = self.state.clone() if keep_x else None
         # every pair: neither array alone decides (a process can sit at 2.33 ms for all candidates
         # of one array while another Y / X pair reaches 2.2); ~0.15 s once at the headline size
         grid = [[timed(y, x) for x in xs] for y in ys]
         best = min((ms, j, i) for j, row in enumerate(grid) for i, ms in enumerate(row))
+        if saved is not None:
+            k.xjoin()
+            rt.sync_stream()
+            self.state.copy_(saved)
+        if keep:
+            xs[best[2]].copy_(x_cur)
         x_cur = xs[best[2]]
         if xt:
             self._Xt = x_cur

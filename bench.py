@@ -290,6 +290,11 @@ def main():
     if args.layout:
         plan.plate_layout = args.layout
 
+    # set-up: device state, tile-major copy of Y, the placement trial of the plate arrays -- here
+    # rather than inside the first iteration, so that --warmup 0 times only iterations
+    if hasattr(plan, 'place_plate_arrays') and args.stats == 'gram':
+        plan.place_plate_arrays()
+
     def barrier():
         if world > 1:
             dist.barrier()

@@ -507,3 +507,40 @@ def test_plan_layouts_agree():
         Ls.append((Q.L[:3].copy(), Q['X'].u[0].copy()))
     np.testing.assert_array_equal(Ls[0][0], Ls[1][0])
     np.testing.assert_array_equal(Ls[0][1], Ls[1][1])
+
+
+@pytest.mark.parametrize('when', ['setup', 'first_update'])
+def test_placement_trial_leaves_the_results_untouched(when, monkeypatch):
+    """The set-up trial over allocations of <x> / the tile-major Y (PCAPlan._place_plate_arrays,
+    DESIGN.md 4.1) runs the plate pass on candidate arrays -- as an explicit set-up step
+    (place_plate_arrays: the state and the initial <x> must come back as they were; the pass also
+    queues statistics on the state) or inside the first X.update().  Bounds, <x> before and after
+    the updates and the replicated moments are those of a run without the trial, bit for bit."""
+    import torch
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_pca
+    N, D, K = 1_000_000, 128, 32            # 1.28 GB per pass: above the 1 GB threshold
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+    w = torch.randn(D, K, generator=g, device='cuda', dtype=torch.float64)
+    y = w @ torch.randn(K, N, generator=g, device='cuda', dtype=torch.float64)
+    y += 0.1 * torch.randn(D, N, generator=g, device='cuda', dtype=torch.float64)
+    x0 = torch.randn(N, K, generator=g, device='cuda', dtype=torch.float64).cpu().numpy()
+    res = []
+    for tries in ('1', '2'):
+        monkeypatch.setenv('BAYESPY_AMD_PLACEMENT_TRIES', tries)
+        Q = build_pca(nodes, VB, y, x0, K)
+        plan = Q.plans[0]
+        if tries == '2' and when == 'setup':
+            plan.place_plate_arrays()
+            assert plan.placement is not None and len(plan.placement['grid_ms']) == 2
+        xa = Q['X'].u[0][0, ::1000].copy()
+        Q.update(repeat=3, verbose=False)
+        if tries == '2':
+            assert plan.placement is not None
+        res.append((Q.L[:3].copy(), xa, Q['X'].u[0][0, ::1000].copy(), Q['W'].u[0].copy(),
+                    Q['tau'].u[0].copy()))
+        del Q, plan
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
