@@ -141,13 +141,39 @@ class CPURuntimeKernels:
         return torch.from_numpy(np.ascontiguousarray(
             buf.reshape(DP, nt, 32).transpose(1, 0, 2)).reshape(-1))
 
-    def xpass_tiled(self, Yt, N, D, K, X, ldx, state, ws):
+    # set by a test to exercise the tile-major <x> of the plan (PCAPlan.Xd property)
+    x_tiles = False
+
+    def tiled_x_doubles(self, D, K, N):
+        return int(self.layout(D, K).KP) * ((N + 31) // 32) * 32
+
+    def tile_x(self, to_tiled, X, ldx, N, D, K, Xt):
+        """vmp_pca_tile_x: Xt [tile][KP][32] <-> X (KP, ldx) row-major."""
+        self.calls.append('tile_x')
+        KP = int(self.layout(D, K).KP)
+        nt = (N + 31) // 32
+        t = Xt.numpy().reshape(nt, KP, 32)
+        x = X.numpy()
+        if to_tiled:
+            t[:] = x[:KP, :nt * 32].reshape(KP, nt, 32).transpose(1, 0, 2)
+        else:
+            x[:KP, :nt * 32] = t.transpose(1, 0, 2).reshape(KP, nt * 32)
+
+    def xpass_tiled(self, Yt, N, D, K, X, ldx, state, ws, x_tiled=False):
         self.calls.append('xpass_tiled')
         import torch
         DP = int(self.layout(D, K).DP)
         nt = (N + 31) // 32
         y = Yt.numpy().reshape(nt, DP, 32).transpose(1, 0, 2).reshape(DP, nt * 32)[:D, :N]
-        self.xpass(torch.from_numpy(np.ascontiguousarray(y)), N, N, D, K, X, ldx, state, ws)
+        if x_tiled:
+            KP = int(self.layout(D, K).KP)
+            rows = torch.zeros(KP, nt * 32, dtype=torch.float64)
+            self.xpass(torch.from_numpy(np.ascontiguousarray(y)), N, N, D, K, rows, nt * 32, state,
+                       ws)
+            self.tile_x(True, rows, nt * 32, N, D, K, X)
+            self.calls.pop()
+        else:
+            self.xpass(torch.from_numpy(np.ascontiguousarray(y)), N, N, D, K, X, ldx, state, ws)
         self.calls.pop()
 
     def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state):

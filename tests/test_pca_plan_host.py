@@ -462,3 +462,32 @@ def test_near_misses_of_the_fused_blocks_are_reported():
         assert isinstance(Q.plans[0], GenericPlan)
         Q = VB(*build())                                     # the fused block: no warning
         assert not isinstance(Q.plans[0], GenericPlan)
+
+
+def test_tile_major_x_is_invisible_behind_the_row_major_view(golden_dir):
+    """Opt-in BAYESPY_AMD_PCA_XTILES: after the first tile-major pass <x> lives tile-major and
+    ``PCAPlan.Xd`` forms the row-major copy on demand.  Same trace, moments, rotation and
+    checkpoint contents as with the row-major array."""
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+    out = []
+    for tiles in (False, True):
+        Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+        plan = Q.plans[0]
+        plan.kernels.x_tiles = tiles
+        Q.update(repeat=2, verbose=False)
+        assert (plan._Xt is not None) == tiles and plan._x_form == ('tiled' if tiles else 'rows')
+        x1 = Q['X'].u[0].copy()
+        if tiles:
+            assert plan.kernels.calls.count('tile_x') == 1      # formed once, kept until the next pass
+            Q['X'].u[0]
+            assert plan.kernels.calls.count('tile_x') == 1
+        # a rotation changes the row-major array in place: it becomes the current <x>
+        R = np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 2.0]])
+        plan.rotate_node(Q["X"], R, np.linalg.inv(R), np.log(2.0))
+        x2 = Q['X'].u[0].copy()
+        np.testing.assert_allclose(x2[0], x1[0] @ R.T, rtol=1e-13)
+        Q.update(repeat=2, verbose=False)
+        out.append((Q.L[:4].copy(), x1, x2, Q['X'].u[0].copy(), Q['W'].u[0].copy()))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
