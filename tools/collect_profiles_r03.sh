@@ -8,10 +8,10 @@ mkdir -p $O
 R=$PWD
 export TMPDIR=/tmp
 BID=$(python -c "import sys; sys.path.insert(0,'$R'); from bayespy_amd import _lib; print(_lib.load().vmp_version().decode().split('build ')[-1])")
-prof() {  # name, command...
-  local name=$1; shift
+prof() {  # name, steady-state kernel substring, its launches in the iterations, command...
+  local name=$1 sk=$2 sn=$3; shift 3
   (cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_st_$name -o r -- "$@" > $R/$O/under_rocprof_$name.log 2>&1)
-  ( echo "# build_id: $BID"; python tools/rocpd_summary.py /tmp/p_st_$name/r_results.db ) > $O/kernel_stats_$name.txt 2>&1
+  ( echo "# build_id: $BID"; python tools/rocpd_summary.py --steady $sk $sn /tmp/p_st_$name/r_results.db ) > $O/kernel_stats_$name.txt 2>&1
 }
 pmcs() {  # name, only-filter, workload-string, iterations, command...
   local name=$1 only=$2 wl=$3 its=$4; shift 4
@@ -25,15 +25,15 @@ pmcs() {  # name, only-filter, workload-string, iterations, command...
   ( echo "# build_id: $BID"; echo "# workload: $wl"; echo "# iterations: $its"; python tools/rocpd_summary.py --pmc --only $only $dbs ) > $O/pmc_$name.txt 2>&1
 }
 B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
-prof pca_gram $B
+prof pca_gram pca_xpass_kernel 12 $B
 pmcs pca_gram pass_kernel "D=128 K=32 n_local=10000000" 12 $B
 M="python $R/bench.py --config masked --steps 5 --warmup 1 --no-cpu-baseline"
-prof masked $M
+prof masked mpca_blk4 60 $M
 pmcs masked mpca_ "masked PCA N=10000000 D=128 K=32" 6 $M
 Ls="python $R/bench.py --config lssm --steps 5 --warmup 1 --no-cpu-baseline"
-prof lssm $Ls
+prof lssm lssm_backward_ck 6 $Ls
 pmcs lssm lssm_ "LSSM B=100000 T=1000 M=8 D=4" 6 $Ls
 G="python $R/bench.py --config gmm --steps 5 --warmup 2 --no-cpu-baseline"
-prof gmm $G
+prof gmm gmm_pass_kernel 7 $G
 pmcs gmm gmm_pass "GMM N=10000000 D=8 K=64" 7 $G
 ls -la $O

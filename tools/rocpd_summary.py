@@ -23,12 +23,19 @@ def short(name):
     return s[:70]
 
 
-def stats(db):
+def stats(db, steady=None):
+    """Per-kernel table.  ``steady = (substring, n)``: a second line for the matching kernels over
+    their LAST n launches only -- the iterations of the profiled command without its set-up
+    launches (the fused PCA block times its plate pass on candidate allocations first)."""
     con = sqlite3.connect(db)
-    rows = con.execute('select name, duration from kernels').fetchall()
+    rows = con.execute('select name, duration from kernels order by start').fetchall()
     agg = defaultdict(list)
     for n, d in rows:
         agg[short(n)].append(d)
+    if steady:
+        for k in [k for k in agg if steady[0] in k]:
+            v = agg[k][-steady[1]:]
+            agg['%s  [last %d launches: the iterations]' % (k, len(v))] = v
     tot = sum(sum(v) for v in agg.values())
     print('%-72s %6s %12s %12s %12s %12s %6s' % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us',
                                                 'max_us', '%'))
@@ -92,5 +99,8 @@ if __name__ == '__main__':
     elif args and args[0] == '--timeline':
         timeline(args[2], int(args[1]))
     else:
+        steady = None
+        if args and args[0] == '--steady':         # --steady <kernel substring> <n> db...
+            steady, args = (args[1], int(args[2])), args[3:]
         for a in args:
-            stats(a)
+            stats(a, steady)
