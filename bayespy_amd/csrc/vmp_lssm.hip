@@ -1107,6 +1107,107 @@ inline void fill_lssm_layout(int D, int M, vmp_lssm_layout *L)
     L->total = (o + 7) / 8 * 8;
 }
 
+// ---------------------------------------------------------------------------------------------
+// wide observations (M beyond what the sweeps hold in registers: M > 8, or > 16 at D <= 4).
+// The sweeps need y only through  h_bt = tau C^T y_bt  (D values) and through the plate sum
+// sum_bt y_bt <x_bt>^T, so they run on the PROJECTED data -- H (T, D, BL) as "observations" with
+// the identity as C and tau = 1, unchanged kernels -- between a projection pass in front and a
+// statistics pass behind:
+//   lssm_project_kernel   H[t][i][b] = sum_m y_mbt (tau c_mi)                reads Y once
+//   lssm_syx_kernel       sum_bt y_mbt <x_bt,i>, eight observed dimensions per thread, sequences
+//                         over the threads: reads Y once more, <x> once per eight dimensions
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(SNT)
+lssm_project_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
+                    const double *__restrict__ Cm, const double *__restrict__ tau_ptr,
+                    double *__restrict__ H)
+{
+    const double tau = tau_ptr[0];
+    const int64_t total = (int64_t)T * B;
+    for (int64_t e = (int64_t)blockIdx.x * SNT + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * SNT) {
+        const int64_t t = e / B, b = e - t * B;
+        const double *yp = Yt + t * M * BL + b;
+        double acc[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) acc[i] = 0.0;
+        for (int m = 0; m < M; ++m) {
+            const double y = __builtin_nontemporal_load(&yp[(int64_t)m * BL]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc[i] += y * (tau * Cm[m * D + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) H[(t * D + i) * BL + b] = acc[i];
+    }
+}
+
+constexpr int SYXM = 8;           // observed dimensions per thread of the statistics pass
+
+template <int D>
+__global__ void __launch_bounds__(SNT)
+lssm_syx_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
+                const double *__restrict__ Z, double *__restrict__ partial, int MP)
+{
+    __shared__ double red[SNT / 64];
+    const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
+    const bool live = b < B;
+    const int64_t bb = live ? b : 0;
+    const int m0 = blockIdx.y * SYXM;
+    double acc[SYXM][D];
+#pragma unroll
+    for (int j = 0; j < SYXM; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) acc[j][i] = 0.0;
+    // time descending, like the sums of the backward sweep
+    for (int t = T - 1; t >= 0; --t) {
+        double x[D], y[SYXM];
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = Z[((int64_t)t * D + i) * BL + bb];
+#pragma unroll
+        for (int j = 0; j < SYXM; ++j)
+            y[j] = (m0 + j < M) ? __builtin_nontemporal_load(&Yt[((int64_t)t * M + m0 + j) * BL + bb])
+                                : 0.0;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < SYXM; ++j)
+#pragma unroll
+                for (int i = 0; i < D; ++i) acc[j][i] += y[j] * x[i];
+        }
+    }
+    double *pb = partial + (int64_t)blockIdx.x * MP * D;
+#pragma unroll
+    for (int j = 0; j < SYXM; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double a = block_sum<SNT>(acc[j][i], red);
+            if (threadIdx.x == 0) pb[(m0 + j) * D + i] = a;
+        }
+}
+
+__global__ void __launch_bounds__(64)
+lssm_identity_kernel(int D, double *ident, double *one)
+{
+    const int l = threadIdx.x;
+    if (l < D * D) ident[l] = (l / D == l % D) ? 1.0 : 0.0;
+    if (l == 0) one[0] = 1.0;
+}
+
+inline bool lssm_wide(int D, int M) { return M > 16 || (M > 8 && D > 4); }
+constexpr int LSSM_MAXM = 64;
+// extra workspace of the wide form behind [partial sums | checkpoints]:
+//   H (T, D, BL) | identity (D x D) + one | sums of the projected sweeps | partials of the Syx pass
+inline int64_t wide_extra_doubles(int D, int M, int64_t B, int T)
+{
+    const int64_t g = (B + SNT - 1) / SNT;
+    const int64_t MP = (M + SYXM - 1) / SYXM * SYXM;
+    return (int64_t)T * D * ck_bl_max(B) + 64 + 64 + (plen_of(D, D) + 63) / 64 * 64 + g * MP * D + 64;
+}
+inline int64_t ck_doubles(int D, int64_t B, int T)
+{
+    return D <= 4 ? (int64_t)((T + CKS - 1) / CKS) * D * ck_bl_max(B) : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1114,7 +1215,7 @@ extern "C" {
 int32_t vmp_lssm_limits(int32_t *max_D, int32_t *max_M)
 {
     if (max_D) *max_D = DMAX;
-    if (max_M) *max_M = 16;
+    if (max_M) *max_M = LSSM_MAXM;
     return VMP_OK;
 }
 
@@ -1199,8 +1300,52 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
     VMP_REQUIRE(ctx, ctx && Yt && Z && stats && workspace, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, given || (Cm && tau && h0 && Sinv && J), VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, M >= 1 && B >= 0 && T >= 1 && BL >= B && D >= 1, VMP_ERR_INVALID, "bad dims");
-    VMP_REQUIRE(ctx, D <= DMAX && M <= 16 && (M <= 8 || D <= 4), VMP_ERR_UNSUPPORTED,
-                "the fused LSSM block supports D <= 8 with M <= 8, D <= 4 with M <= 16");
+    VMP_REQUIRE(ctx, D <= DMAX && M <= LSSM_MAXM, VMP_ERR_UNSUPPORTED,
+                "the fused LSSM block supports D <= %d states, M <= %d observed dimensions", DMAX,
+                LSSM_MAXM);
+    if (lssm_wide(D, M)) {
+        // projected data in front of the unchanged sweeps, the y <x>^T sums behind them
+        VMP_REQUIRE(ctx, BL <= ck_bl_max(B), VMP_ERR_INVALID,
+                    "leading dimension beyond the workspace contract (B rounded up to 256)");
+        double *wsd = reinterpret_cast<double *>(workspace);
+        double *H = wsd + ws_base_doubles(D, M, B) + ck_doubles(D, B, T);
+        double *ident = H + (int64_t)T * D * ck_bl_max(B);
+        double *one = ident + 64;
+        double *rawtmp = one + 64;
+        double *syxp = rawtmp + (plen_of(D, D) + 63) / 64 * 64;
+        const int64_t gw = (B + SNT - 1) / SNT;
+        const int MP = (M + SYXM - 1) / SYXM * SYXM;
+        hipStream_t sw = ctx->stream;
+        hipLaunchKernelGGL(lssm_identity_kernel, dim3(1), dim3(64), 0, sw, D, ident, one);
+        if (!given && gw > 0) {
+            int64_t gp = ((int64_t)T * B + SNT - 1) / SNT;
+            if (gp > (int64_t)ctx->num_cu * 16) gp = (int64_t)ctx->num_cu * 16;
+            switch (D) {
+#define LSSM_PROJ(d) case d: hipLaunchKernelGGL(lssm_project_kernel<d>, dim3((unsigned)gp), dim3(SNT), 0, sw, Yt, M, B, T, BL, Cm, tau, H); break;
+                LSSM_PROJ(1) LSSM_PROJ(2) LSSM_PROJ(3) LSSM_PROJ(4) LSSM_PROJ(5) LSSM_PROJ(6)
+                LSSM_PROJ(7) LSSM_PROJ(8)
+#undef LSSM_PROJ
+            }
+        }
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        const int32_t rcw = smooth_impl(ctx, given, H, D, B, T, BL, D, ident, one, h0, Sinv, J, Z,
+                                        rawtmp, workspace, nseg, seg_ready);
+        if (rcw != VMP_OK) return rcw;
+        VMP_HIP_CHECK(ctx, hipMemcpyAsync(stats, rawtmp, (size_t)(4 * D * D + D) * sizeof(double),
+                                          hipMemcpyDeviceToDevice, sw));
+        if (gw > 0) {
+            switch (D) {
+#define LSSM_SYX(d) case d: hipLaunchKernelGGL(lssm_syx_kernel<d>, dim3((unsigned)gw, (unsigned)(MP / SYXM)), dim3(SNT), 0, sw, Yt, M, B, T, BL, Z, syxp, MP); break;
+                LSSM_SYX(1) LSSM_SYX(2) LSSM_SYX(3) LSSM_SYX(4) LSSM_SYX(5) LSSM_SYX(6) LSSM_SYX(7)
+                LSSM_SYX(8)
+#undef LSSM_SYX
+            }
+        }
+        hipLaunchKernelGGL(lssm_sum_kernel, dim3((unsigned)((M * D + 15) / 16)), dim3(NT), 0, sw,
+                           syxp, (int)gw, MP * D, M * D, stats + 4 * D * D + D);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        return VMP_OK;
+    }
     const int MM = M <= 8 ? 8 : 16;
     const int64_t g = (B + SNT - 1) / SNT;
     const int plen = plen_of(D, M);
@@ -1274,7 +1419,7 @@ int32_t vmp_lssm_smooth(vmp_ctx *ctx, int32_t given, const double *Yt, int32_t M
 int32_t vmp_lssm_get_layout(int32_t D, int32_t M, vmp_lssm_layout *out)
 {
     if (!out || D < 1 || M < 1) return VMP_ERR_INVALID;
-    if (D > DMAX || M > 16 || (M > 8 && D > 4)) return VMP_ERR_UNSUPPORTED;
+    if (D > DMAX || M > LSSM_MAXM) return VMP_ERR_UNSUPPORTED;
     fill_lssm_layout(D, M, out);
     return VMP_OK;
 }
@@ -1371,8 +1516,8 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
 int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
 {
     if (!n || D < 1 || M < 1 || B < 0) return VMP_ERR_INVALID;
-    *n = ws_base_doubles(D, M, B);
-    if (D <= 4 && M <= 8) *n += (int64_t)((T + CKS - 1) / CKS) * D * ck_bl_max(B);
+    *n = ws_base_doubles(D, M, B) + ck_doubles(D, B, T);
+    if (lssm_wide(D, M)) *n += wide_extra_doubles(D, M, B, T);
     return VMP_OK;
 }
 

@@ -54,8 +54,8 @@ class LSSMKernels:
         L = _lib.LSSMLayout()
         rc = self.lib.vmp_lssm_get_layout(D, M, ctypes.byref(L))
         if rc != _lib.VMP_OK:
-            _lib.raise_for_status(rc, 'the fused LSSM block supports D <= 8 (M <= 8) or D <= 4 '
-                                      '(M <= 16)')
+            _lib.raise_for_status(rc, 'the fused LSSM block supports D <= 8 states and M <= 64 '
+                                      'observed dimensions')
         return L
 
     def workspace_doubles(self, D, M, B, T):
@@ -198,9 +198,9 @@ class LSSMPlan:
                 _lib.load().vmp_lssm_limits(ctypes.byref(mx_d), ctypes.byref(mx_m))
             except Exception:       # noqa: BLE001
                 continue
-            if D > mx_d.value or M > mx_m.value or (M > 8 and D > 4):
+            if D > mx_d.value or M > mx_m.value:
                 no(Y, 'D = %d states, M = %d observed dimensions exceed the limits of the block '
-                      '(D <= %d with M <= 8, D <= 4 with M <= %d)' % (D, M, mx_d.value, mx_m.value))
+                      '(D <= %d, M <= %d)' % (D, M, mx_d.value, mx_m.value))
                 continue
             priv = [C, gamma, X, A, alpha, tau, F, G] + ([nu_node] if nu_node is not None else [])
             if any(len(n.children) != 1 for n in priv):

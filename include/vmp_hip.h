@@ -327,8 +327,8 @@ int32_t vmp_mpca_unpack_xx(vmp_ctx *ctx, int32_t D, int32_t K, int64_t nplates,
  * linalg.block_banded_solve (utils/linalg.py:468-575, gaussian_markov_chain.py:89-123) runs ONCE
  * (vmp_lssm_cov) and only the means are per-sequence (vmp_lssm_smooth: one thread per
  * sequence, time-major arrays Yt[t][m][b], Z[t][i][b], b contiguous); the other nodes and the
- * bound read plate sums only.  D <= 8 states with M <= 8 observations per step, or D <= 4 with
- * M <= 16.  Details: bayespy_amd/csrc/vmp_lssm.hip, formulas: oracle/lssm.py. */
+ * bound read plate sums only.  D <= 8 states, M <= 64 observations per step (beyond M = 8, or 16
+ * at D <= 4, the sweeps run on the projected data tau C^T y with a separate y <x>^T pass).  Details: bayespy_amd/csrc/vmp_lssm.hip, formulas: oracle/lssm.py. */
 typedef struct vmp_lssm_layout {
     int64_t off_tau;      /* 4: a, b, <tau>, <log tau>                                             */
     int64_t off_gamma, off_alpha, off_nu;   /* 4*D each: a[D], b[D], mean[D], log-mean[D]          */

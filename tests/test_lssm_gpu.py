@@ -52,7 +52,11 @@ def _build(y, x0, c0, gamma_nu, shard=False):
 
 
 @pytest.mark.parametrize('M,B,T,D', [(1, 1, 1, 1), (3, 5, 2, 2), (8, 70, 33, 4), (16, 300, 20, 3),
-                                     (5, 1000, 50, 8), (8, 257, 1000, 4), (2, 64, 3, 5)])
+                                     (5, 1000, 50, 8), (8, 257, 1000, 4), (2, 64, 3, 5),
+                                     # wide observations: the sweeps on the projected data
+                                     # tau C^T y, a separate y <x>^T pass (M > 8, > 16 at D <= 4)
+                                     (30, 300, 40, 3), (9, 70, 33, 8), (17, 513, 9, 4),
+                                     (64, 40, 100, 8), (33, 1, 20, 1), (20, 260, 1000, 4)])
 @pytest.mark.parametrize('gamma_nu', [False, True])
 def test_fused_lssm_vs_oracle(M, B, T, D, gamma_nu):
     from oracle.lssm import LSSMOracle
