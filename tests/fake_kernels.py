@@ -237,3 +237,173 @@ class CPURuntimeKernels:
 
     def last_pass_ms(self):
         return 0.0, 0.0
+
+
+class CPUGMMKernels:
+    """TEST DOUBLE for ``bayespy_amd.inference.plans.gmm.GMMKernels``: the same method set on CPU
+    torch tensors, the formulas of oracle/gmm.py on the packed state of ``vmp_gmm_layout``
+    (host-only ``vmp_gmm_get_layout`` of the real library).  The statistics T = [R, S1, S2] and
+    the two softmax sums are LOCAL after ``pass_`` / ``stats_from_labels`` -- the plan all-reduces
+    them -- so the sharded host logic runs in CPU-only tests (world_size-2 gloo)."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.lib = _lib.load()
+        self.calls = []
+        self._prior_only = False
+
+    def layout(self, D, K):
+        L = _lib.GMMLayout()
+        _lib.raise_for_status(self.lib.vmp_gmm_get_layout(D, K, ctypes.byref(L)))
+        return L
+
+    def workspace_doubles(self, D, K):
+        return 16
+
+    def _v(self, state, D, K):
+        L = self.layout(D, K)
+        s = state.numpy()
+        KP, FS = int(L.KP), int(L.FS)
+        T = s[L.off_T:L.off_T + KP * FS].reshape(KP, FS)
+        pr = s[L.off_prior:]
+        return dict(
+            L=L, s=s, T=T, R=T[:K, 0], S1=T[:K, 1:1 + D], S2=T[:K, 1 + D:].reshape(K, D, D),
+            zs=s[L.off_zs:L.off_zs + 2], alpha=s[L.off_alpha:L.off_alpha + K],
+            logpi=s[L.off_alpha + KP:L.off_alpha + KP + K],
+            mu=s[L.off_mu:L.off_mu + K * D].reshape(K, D),
+            Cmu=s[L.off_Cmu:L.off_Cmu + K * D * D].reshape(K, D, D),
+            ldLmu=s[L.off_logdetLmu:L.off_logdetLmu + K], nk=s[L.off_nk:L.off_nk + K],
+            Vk=s[L.off_Vk:L.off_Vk + K * D * D].reshape(K, D, D),
+            Lam=s[L.off_Lam:L.off_Lam + K * D * D].reshape(K, D, D),
+            ldLam=s[L.off_logdetLam:L.off_logdetLam + K], ldV=s[L.off_logdetV:L.off_logdetV + K],
+            alpha0=pr[:K], hdr=pr[KP:KP + 8], V0=pr[KP + 8:KP + 8 + D * D].reshape(D, D),
+            scal=s[L.off_scal:L.off_scal + 8], Lout=s[L.off_L:L.off_L + 8])
+
+    @staticmethod
+    def _multidigamma(a, d):
+        return sum(special.digamma(a - 0.5 * i) for i in range(d))
+
+    @staticmethod
+    def _multigammaln(a, d):
+        return d * (d - 1) / 4.0 * np.log(np.pi) + sum(special.gammaln(a - 0.5 * i) for i in range(d))
+
+    def _lambda_moments(self, v, D):
+        v['Lam'][:] = v['nk'][:, None, None] * np.linalg.inv(v['Vk'])
+        v['ldV'][:] = np.linalg.slogdet(v['Vk'])[1]
+        v['ldLam'][:] = self._multidigamma(0.5 * v['nk'], D) + D * np.log(2.0) - v['ldV']
+
+    def init_state(self, D, K, alpha0, beta0, n0, V0, state):
+        self.calls.append('init_state')
+        state.zero_()
+        v = self._v(state, D, K)
+        v['alpha0'][:] = alpha0
+        v['hdr'][0], v['hdr'][1] = beta0, n0
+        v['V0'][:] = V0
+        v['hdr'][2] = np.linalg.slogdet(np.asarray(V0))[1]
+        v['alpha'][:] = alpha0
+        v['logpi'][:] = special.digamma(v['alpha']) - special.digamma(v['alpha'].sum())
+        v['mu'][:] = 0.0
+        v['Cmu'][:] = np.eye(D) / beta0
+        v['ldLmu'][:] = D * np.log(beta0)
+        v['nk'][:] = n0
+        v['Vk'][:] = V0
+        self._lambda_moments(v, D)
+
+    def _set_stats(self, v, r, y):
+        v['T'][:] = 0.0
+        v['R'][:] = r.sum(axis=0)
+        v['S1'][:] = r.T @ y
+        v['S2'][:] = np.einsum('nk,ni,nj->kij', r, y, y)
+
+    def stats_from_labels(self, Y, N, D, K, labels, R, state, ws):
+        self.calls.append('stats_from_labels')
+        v = self._v(state, D, K)
+        r = np.zeros((N, K))
+        r[np.arange(N), labels.numpy()[:N]] = 1.0
+        R.numpy()[:N, :K] = r
+        self._set_stats(v, r, Y.numpy()[:N, :D])
+
+    def update_mu(self, D, K, state):
+        self.calls.append('update_mu')
+        v = self._v(state, D, K)
+        Lmu = v['hdr'][0] * np.eye(D) + v['R'][:, None, None] * v['Lam']
+        v['Cmu'][:] = np.linalg.inv(Lmu)
+        v['ldLmu'][:] = np.linalg.slogdet(Lmu)[1]
+        v['mu'][:] = np.einsum('kij,kj->ki', v['Cmu'], np.einsum('kij,kj->ki', v['Lam'], v['S1']))
+
+    def update_lambda(self, D, K, state):
+        self.calls.append('update_lambda')
+        v = self._v(state, D, K)
+        mm = v['Cmu'] + v['mu'][:, :, None] * v['mu'][:, None, :]
+        sm = v['S1'][:, :, None] * v['mu'][:, None, :]
+        v['nk'][:] = v['hdr'][1] + v['R']
+        v['Vk'][:] = v['V0'] + v['S2'] - sm - np.swapaxes(sm, 1, 2) + v['R'][:, None, None] * mm
+        self._lambda_moments(v, D)
+
+    def _coefficients(self, v, D):
+        mm = v['Cmu'] + v['mu'][:, :, None] * v['mu'][:, None, :]
+        b = np.einsum('kij,kj->ki', v['Lam'], v['mu'])
+        c = 0.5 * v['ldLam'] - 0.5 * D * np.log(2 * np.pi) - 0.5 * np.einsum('kij,kij->k', v['Lam'], mm)
+        return c, b
+
+    def prepare_z(self, D, K, prior_only, state):
+        self.calls.append('prepare_z')
+        self._prior_only = bool(prior_only)
+
+    def pass_(self, Y, N, D, K, R, state, ws):
+        self.calls.append('pass')
+        v = self._v(state, D, K)
+        y = Y.numpy()[:N, :D]
+        if self._prior_only:
+            phi = np.tile(v['logpi'][None, :], (N, 1))
+        else:
+            c, b = self._coefficients(v, D)
+            phi = (v['logpi'] + c)[None, :] + y @ b.T \
+                - 0.5 * np.einsum('ni,kij,nj->nk', y, v['Lam'], y)
+        m = phi.max(axis=1, keepdims=True) if N else phi
+        lse = np.log(np.exp(phi - m).sum(axis=1, keepdims=True)) + m
+        p = np.exp(phi - lse)
+        p /= p.sum(axis=1, keepdims=True)
+        R.numpy()[:N, :K] = p
+        self._set_stats(v, p, y)
+        v['zs'][0] = float(lse.sum())
+        v['zs'][1] = float((p * phi).sum())
+
+    def update_alpha(self, D, K, state):
+        self.calls.append('update_alpha')
+        v = self._v(state, D, K)
+        v['alpha'][:] = v['alpha0'] + v['R']
+        v['logpi'][:] = special.digamma(v['alpha']) - special.digamma(v['alpha'].sum())
+
+    def lower_bound(self, D, K, state):
+        self.calls.append('lower_bound')
+        v = self._v(state, D, K)
+        c, b = self._coefficients(v, D)
+        beta0, n0, ldV0 = v['hdr'][0], v['hdr'][1], v['hdr'][2]
+        L_Y = float(np.sum(v['R'] * c) + np.sum(b * v['S1'])
+                    - 0.5 * np.einsum('kij,kij->', v['Lam'], v['S2']))
+        L_z = float(v['zs'][0] - v['zs'][1] + np.sum(v['R'] * v['logpi']))
+        a0, a = v['alpha0'], v['alpha']
+        L_pi = float(special.gammaln(a0.sum()) - special.gammaln(a0).sum()
+                     - special.gammaln(a.sum()) + special.gammaln(a).sum()
+                     + np.sum((a0 - a) * v['logpi']))
+        mm = v['Cmu'] + v['mu'][:, :, None] * v['mu'][:, None, :]
+        L_mu = float(np.sum(-0.5 * beta0 * np.einsum('kii->k', mm) + 0.5 * D * np.log(beta0)
+                            - 0.5 * v['ldLmu'] + 0.5 * D))
+        g_p = 0.5 * n0 * ldV0 - 0.5 * D * n0 * np.log(2.0) - self._multigammaln(0.5 * n0, D)
+        g_q = 0.5 * v['nk'] * v['ldV'] - 0.5 * D * v['nk'] * np.log(2.0) \
+            - self._multigammaln(0.5 * v['nk'], D)
+        t = -0.5 * np.einsum('ij,kij->k', v['V0'], v['Lam']) + 0.5 * n0 * v['ldLam'] \
+            + 0.5 * np.einsum('kij,kij->k', v['Vk'], v['Lam']) - 0.5 * v['nk'] * v['ldLam']
+        L_Lam = float(np.sum(g_p - g_q + t))
+        v['Lout'][:6] = [L_Y, L_z, L_pi, L_mu, L_Lam, L_Y + L_z + L_pi + L_mu + L_Lam]
+        v['scal'][3] = 0.0
+
+    def set_timing(self, on):
+        pass
+
+    def last_pass_ms(self):
+        return 0.0, 0.0
+
+    def pass_times_ms(self, cap=64):
+        return []
