@@ -407,3 +407,224 @@ class CPUGMMKernels:
 
     def pass_times_ms(self, cap=64):
         return []
+
+
+class CPULSSMKernels:
+    """TEST DOUBLE for ``bayespy_amd.inference.plans.lssm.LSSMKernels``: time-major arrays and the
+    packed ``vmp_lssm_layout`` state as in the library (host-only ``vmp_lssm_get_layout`` /
+    ``vmp_lssm_workspace_doubles``), arithmetic in NumPy: the covariance recursion of
+    oracle/lssm.py (chain_covariances), the per-sequence recursions and LOCAL plate sums of
+    vmp_lssm_smooth, and the replicated-node algebra of vmp_lssm_small_ops operation by
+    operation.  The plan all-reduces the raw sums -- world_size-2 gloo tests run on it."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.lib = _lib.load()
+        self.calls = []
+
+    def layout(self, D, M):
+        L = _lib.LSSMLayout()
+        _lib.raise_for_status(self.lib.vmp_lssm_get_layout(D, M, ctypes.byref(L)))
+        return L
+
+    def workspace_doubles(self, D, M, B, T):
+        return 16
+
+    def relayout_y(self, Y, M, B, T, BL, Yt, syy, ws):
+        self.calls.append('relayout_y')
+        y = Y.numpy().reshape(M, B, T)
+        yt = Yt.numpy().reshape(T, M, BL)
+        yt[:] = 0.0
+        yt[:, :, :B] = y.transpose(2, 0, 1)
+        syy.numpy()[0] = float(np.sum(y * y))
+
+    def x_layout(self, X, D, B, T, BL, Z, to_time_major):
+        self.calls.append('x_layout')
+        x = X.numpy().reshape(B, T, D)
+        z = Z.numpy().reshape(T, D, BL)
+        if to_time_major:
+            z[:, :, :B] = x.transpose(1, 2, 0)
+        else:
+            x[:] = z[:, :, :B].transpose(2, 0, 1)
+
+    def _cov(self, T, D, Dg, Sinv, J, sums):
+        from oracle.lssm import chain_covariances
+        d = Dg.numpy()[:4 * D * D].reshape(4, D, D)
+        dg = np.empty((T, D, D))
+        dg[:] = d[1]
+        dg[0] = d[0]
+        dg[T - 1] = d[2] if T > 1 else d[0]
+        E = np.broadcast_to(d[3], (max(T - 1, 0), D, D))
+        si, j, _, V, Cn, logdet = chain_covariances(dg, E)
+        Sinv.numpy()[:T * D * D] = si.reshape(-1)
+        if T > 1:
+            J.numpy()[:(T - 1) * D * D] = j.reshape(-1)
+        s = sums.numpy()
+        DD = D * D
+        s[0:DD] = V.sum(axis=0).reshape(-1)
+        s[DD:2 * DD] = V[0].reshape(-1)
+        s[2 * DD:3 * DD] = V[T - 1].reshape(-1)
+        s[3 * DD:4 * DD] = (Cn.sum(axis=0) if T > 1 else np.zeros((D, D))).reshape(-1)
+        s[5 * DD] = logdet
+        s[5 * DD + 1] = 0.0
+
+    def smooth(self, given, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats, ws):
+        self.calls.append('smooth_given' if given else 'smooth')
+        yt = Yt.numpy().reshape(T, M, BL)[:, :, :B]
+        z = Z.numpy().reshape(T, D, BL)
+        if given:
+            x = z[:, :, :B].copy()                                  # (T, D, B)
+        else:
+            cm = Cm.numpy()[:M * D].reshape(M, D)
+            t_ = float(tau.numpy()[0])
+            si = Sinv.numpy()[:T * D * D].reshape(T, D, D)
+            j = J.numpy()[:max(T - 1, 0) * D * D].reshape(-1, D, D)
+            h = t_ * np.einsum('tmb,md->tdb', yt, cm)
+            h[0] += h0.numpy()[:D, None]
+            zz = np.empty_like(h)
+            zz[0] = h[0]
+            for t in range(1, T):
+                zz[t] = h[t] - j[t - 1].T @ zz[t - 1]
+            x = np.empty_like(h)
+            x[T - 1] = si[T - 1] @ zz[T - 1]
+            for t in range(T - 2, -1, -1):
+                x[t] = si[t] @ zz[t] - j[t] @ x[t + 1]
+            z[:, :, :B] = x
+        raw = stats.numpy()
+        DD = D * D
+        raw[0:DD] = np.einsum('tib,tjb->ij', x, x).reshape(-1)
+        raw[DD:2 * DD] = np.einsum('tib,tjb->ij', x[1:], x[:-1]).reshape(-1)
+        raw[2 * DD:3 * DD] = (x[0] @ x[0].T).reshape(-1)
+        raw[3 * DD:4 * DD] = (x[T - 1] @ x[T - 1].T).reshape(-1)
+        raw[4 * DD:4 * DD + D] = x[0].sum(axis=1)
+        raw[4 * DD + D:4 * DD + D + M * D] = np.einsum('tmb,tib->mi', yt, x).reshape(-1)
+
+    def x_update(self, T, D, Dg, Sinv, J, sums, Yt, M, B, BL, Cm, tau, h0, Z, stats, ws):
+        self.calls.append('x_update')
+        self._cov(T, D, Dg, Sinv, J, sums)
+        self.smooth(False, Yt, M, B, T, BL, D, Cm, tau, h0, Sinv, J, Z, stats, ws)
+        self.calls.pop()
+
+    def rotate_x(self, D, T, B, BL, R, Z):
+        self.calls.append('rotate_x')
+        z = Z.numpy().reshape(T, D, BL)
+        z[:] = np.einsum('ij,tjb->tib', R.numpy().reshape(D, D), z)
+
+    def small_ops(self, D, M, T, B_total, priors, nu_latent, ops, state):
+        """vmp_lssm_small_ops (csrc/vmp_lssm.hip: lssm_small_body), operation by operation."""
+        self.calls.extend('op%d' % o for o in ops)
+        L = self.layout(D, M)
+        st = state.numpy()
+        DD = D * D
+        pri = list(priors)
+        tau = st[L.off_tau:L.off_tau + 4]
+        gam = st[L.off_gamma:L.off_gamma + 4 * D].reshape(4, D)
+        alp = st[L.off_alpha:L.off_alpha + 4 * D].reshape(4, D)
+        nu = st[L.off_nu:L.off_nu + 4 * D].reshape(4, D)
+        Cm = st[L.off_Cm:L.off_Cm + M * D].reshape(M, D)
+        CovC = st[L.off_CovC:L.off_CovC + DD].reshape(D, D)
+        SCC = st[L.off_SCC:L.off_SCC + DD].reshape(D, D)
+        Am = st[L.off_Am:L.off_Am + DD].reshape(D, D)
+        AA = st[L.off_AA:L.off_AA + DD * D].reshape(D, D, D)
+        ldA = st[L.off_ldA:L.off_ldA + D]
+        S = st[L.off_S:]
+        Sxx, Spp, Snn, Snp, S00 = (S[i * DD:(i + 1) * DD].reshape(D, D) for i in range(5))
+        s0 = S[5 * DD:5 * DD + D]
+        Syx = S[5 * DD + D:5 * DD + D + M * D].reshape(M, D)
+        sc = st[L.off_scal:L.off_scal + 8]
+        Lam0 = st[L.off_Lam0:L.off_Lam0 + DD].reshape(D, D)
+        mu0 = st[L.off_mu0:L.off_mu0 + D]
+        Bt = float(B_total)
+
+        def set_gamma(g, k, a, b):
+            g[0][k], g[1][k], g[2][k] = a, b, a / b
+            g[3][k] = special.digamma(a) - np.log(b)
+
+        def gamma_term(a0, b0, g, k):
+            a, b = g[0][k], g[1][k]
+            return (a0 * np.log(b0) - special.gammaln(a0)) - (a * np.log(b) - special.gammaln(a)) \
+                + (b - b0) * g[2][k] + (a0 - a) * g[3][k]
+
+        def residual_and_innovation():
+            resid = sc[0] - 2.0 * np.sum(Cm * Syx) + np.sum(SCC * Sxx)
+            innov = np.array([Snn[i, i] - 2.0 * Am[i] @ Snp[i] + np.sum(AA[i] * Spp)
+                              for i in range(D)])
+            return resid, innov
+
+        for op in ops:
+            if op == 1:                                                    # STATS
+                raw = st[L.off_raw:L.off_raw + int(L.len_raw)]
+                cs = st[L.off_covsums:L.off_covsums + 5 * DD + 8]
+                xx, npm, x0, xT = (raw[i * DD:(i + 1) * DD].reshape(D, D) for i in range(4))
+                cV, cV0, cVT, cC = (cs[i * DD:(i + 1) * DD].reshape(D, D) for i in range(4))
+                Sxx[:] = Bt * cV + xx
+                Spp[:] = Bt * (cV - cVT) + xx - xT
+                Snn[:] = Bt * (cV - cV0) + xx - x0
+                Snp[:] = Bt * cC.T + npm
+                S00[:] = Bt * cV0 + x0
+                s0[:] = raw[4 * DD:4 * DD + D]
+                Syx[:] = raw[4 * DD + D:4 * DD + D + M * D].reshape(M, D)
+                sc[1] = cs[5 * DD]
+            elif op == 2:                                                  # C
+                lam = tau[2] * Sxx + np.diag(gam[2])
+                CovC[:] = np.linalg.inv(lam)
+                sc[4] = -np.linalg.slogdet(lam)[1]
+                Cm[:] = tau[2] * Syx @ CovC.T
+                SCC[:] = M * CovC + Cm.T @ Cm
+            elif op == 3:                                                  # GAMMA
+                for j in range(D):
+                    set_gamma(gam, j, pri[2] + 0.5 * M, pri[3] + 0.5 * SCC[j, j])
+            elif op == 4:                                                  # XPREP
+                Dg = st[L.off_Dg:L.off_Dg + 4 * DD].reshape(4, D, D)
+                anua = np.einsum('i,ijk->jk', nu[2], AA)
+                obs = tau[2] * SCC
+                dn = np.diag(nu[2])
+                Dg[0] = obs + Lam0 + (anua if T > 1 else 0.0)
+                Dg[1] = obs + dn + anua
+                Dg[2] = obs + (dn if T > 1 else Lam0)
+                Dg[3] = -(nu[2][:, None] * Am).T
+                st[L.off_h0:L.off_h0 + D] = Lam0 @ mu0
+                sc[3] = tau[2]
+            elif op == 5:                                                  # A
+                for i in range(D):
+                    lam = nu[2][i] * Spp + np.diag(alp[2])
+                    cov = np.linalg.inv(lam)
+                    ldA[i] = -np.linalg.slogdet(lam)[1]
+                    Am[i] = cov @ (nu[2][i] * Snp[i])
+                    AA[i] = cov + np.outer(Am[i], Am[i])
+            elif op == 6:                                                  # ALPHA
+                for j in range(D):
+                    set_gamma(alp, j, pri[4] + 0.5 * D, pri[5] + 0.5 * np.sum(AA[:, j, j]))
+            elif op == 7:                                                  # TAU
+                resid, _ = residual_and_innovation()
+                tg = tau.reshape(4, 1)
+                set_gamma(tg, 0, pri[0] + 0.5 * M * Bt * T, pri[1] + 0.5 * resid)
+            elif op == 8:                                                  # NU
+                _, innov = residual_and_innovation()
+                for i in range(D):
+                    set_gamma(nu, i, pri[6] + 0.5 * Bt * (T - 1), pri[7] + 0.5 * innov[i])
+            elif op == 9:                                                  # ELBO
+                resid, innov = residual_and_innovation()
+                Lo = st[L.off_L:L.off_L + 16]
+                LOG2PI = np.log(2 * np.pi)
+                Lo[0] = M * Bt * T * (-0.5 * LOG2PI + 0.5 * tau[3]) - 0.5 * tau[2] * resid
+                Lo[1] = M * (0.5 * sc[4] + 0.5 * D) + np.sum(0.5 * M * gam[3] - 0.5 * gam[2] * np.diag(SCC))
+                saa = np.array([np.sum(AA[:, j, j]) for j in range(D)])
+                Lo[2] = 0.5 * D * D + 0.5 * np.sum(ldA) + np.sum(0.5 * D * alp[3] - 0.5 * alp[2] * saa)
+                lx = Bt * (0.5 * T * D + 0.5 * st[L.off_ldLam0] + 0.5 * (T - 1) * np.sum(nu[3])
+                           - 0.5 * sc[1])
+                lx -= 0.5 * np.sum(Lam0 * (S00 - np.outer(s0, mu0) - np.outer(mu0, s0)
+                                           + Bt * np.outer(mu0, mu0)))
+                lx -= 0.5 * np.sum(nu[2] * innov)
+                Lo[3] = lx
+                Lo[4] = sum(gamma_term(pri[2], pri[3], gam, j) for j in range(D))
+                Lo[5] = sum(gamma_term(pri[4], pri[5], alp, j) for j in range(D))
+                Lo[6] = gamma_term(pri[0], pri[1], tau.reshape(4, 1), 0)
+                Lo[7] = sum(gamma_term(pri[6], pri[7], nu, j) for j in range(D)) if nu_latent else 0.0
+                Lo[8] = float(np.sum(Lo[:8]))
+
+    def set_timing(self, on):
+        pass
+
+    def pass_times_ms(self, cap=64):
+        return []
