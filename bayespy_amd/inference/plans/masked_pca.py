@@ -367,6 +367,8 @@ class MaskedPCAPlan:
     def _read_scalars(self):
         L = self.layout
         view = self.state[L.off_scal:L.off_L + 8]
+        if self.rt.device.type != 'cuda':          # CPU kernel double of the host-logic tests
+            return view.numpy().copy()
         if self._scal_host is None:
             self._scal_host = self.rt.torch.empty(view.numel(), dtype=self.rt.torch.float64,
                                                   pin_memory=True)

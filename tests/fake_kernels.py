@@ -628,3 +628,204 @@ class CPULSSMKernels:
 
     def pass_times_ms(self, cap=64):
         return []
+
+
+class CPUMaskedKernels:
+    """TEST DOUBLE for ``bayespy_amd.inference.plans.masked_pca.MaskedHIPKernels``: the packed state
+    of ``vmp_mpca_layout`` (host-only ``vmp_mpca_get_layout``; Mst = packed M_d | r_d with
+    p(i,j) = i(i+1)/2 + j, tile-major Ymt), arithmetic of oracle/masked_pca.py in NumPy.  The
+    statistics a pass leaves in the state are LOCAL; the plan all-reduces them."""
+
+    SC_SYY, SC_NOBS, SC_TRXX, SC_LDX, SC_N, SC_STATUS, SC_TAUX, SC_RESID = range(8)
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.lib = _lib.load()
+        self.calls = []
+
+    def layout(self, D, K):
+        L = _lib.MPCALayout()
+        _lib.raise_for_status(self.lib.vmp_mpca_get_layout(D, K, ctypes.byref(L)))
+        return L
+
+    def sizes(self, D, K, N, chunk):
+        L = self.layout(D, K)
+        nt = max((N + 31) // 32, 1)
+        s = _lib.MPCASizes()
+        s.ymt_doubles = nt * int(L.DP) * 32
+        s.mask_words = nt * int(L.DP)
+        s.xm_doubles = nt * 32 * int(L.KP)
+        s.lam_doubles = 16
+        s.xxf_doubles = 16
+        s.workspace_doubles = 16
+        return s
+
+    def _v(self, state, D, K):
+        L = self.layout(D, K)
+        s = state.numpy()
+        DP, KP, LR, PT = int(L.DP), int(L.KP), int(L.LR), int(L.PT)
+        return dict(L=L, s=s, tau=s[L.off_tau:L.off_tau + 4],
+                    alpha=s[L.off_alpha:L.off_alpha + 4 * KP].reshape(4, KP),
+                    sc=s[L.off_scal:L.off_scal + 16], Lo=s[L.off_L:L.off_L + 8],
+                    W=s[L.off_W:L.off_W + DP * KP].reshape(DP, KP),
+                    WW=s[L.off_WW:L.off_WW + DP * KP * KP].reshape(DP, KP, KP),
+                    ldW=s[L.off_ldW:L.off_ldW + DP],
+                    Mst=s[L.off_M:L.off_M + DP * LR].reshape(DP, LR),
+                    Sxx=s[L.off_Sxx:L.off_Sxx + KP * KP].reshape(KP, KP),
+                    rowobs=s[L.off_rowobs:L.off_rowobs + DP], roff=16 * PT)
+
+    @staticmethod
+    def _tri(K):
+        i, j = np.tril_indices(K)
+        return i, j, i * (i + 1) // 2 + j
+
+    def _get_M(self, v, D, K):
+        i, j, p = self._tri(K)
+        M = np.zeros((D, K, K))
+        M[:, i, j] = v['Mst'][:D][:, p]
+        M[:, j, i] = v['Mst'][:D][:, p]
+        return M, v['Mst'][:D, v['roff']:v['roff'] + K]
+
+    def init_state(self, D, K, a0t, b0t, a0a, b0a, state):
+        self.calls.append('init_state')
+        state.zero_()
+        v = self._v(state, D, K)
+        v['tau'][:] = [a0t, b0t, a0t / b0t, special.digamma(a0t) - np.log(b0t)]
+        v['alpha'][0, :K], v['alpha'][1, :K] = a0a, b0a
+        v['alpha'][2, :K] = a0a / b0a
+        v['alpha'][3, :K] = special.digamma(a0a) - np.log(b0a)
+
+    def prepare(self, Y, ldy, mask, ldm, N, D, K, Ymt, Mb1, Mb2, state, ws):
+        self.calls.append('prepare')
+        v = self._v(state, D, K)
+        DP = int(v['L'].DP)
+        y = Y.numpy()[:D, :N]
+        m = (mask.numpy()[:D, :N] != 0) if mask is not None else np.ones((D, N), dtype=bool)
+        self._m = m.astype(np.float64)
+        self._y = np.where(m, y, 0.0)                    # values at masked entries are never read
+        nt = max((N + 31) // 32, 1)
+        buf = np.zeros((DP, nt * 32))
+        buf[:D, :N] = self._y
+        Ymt.numpy()[:nt * DP * 32] = buf.reshape(DP, nt, 32).transpose(1, 0, 2).reshape(-1)
+        v['sc'][self.SC_SYY] = float(np.sum(self._y ** 2))
+        v['sc'][self.SC_NOBS] = float(self._m.sum())
+        v['rowobs'][:] = 0.0
+        v['rowobs'][:D] = self._m.sum(axis=1)
+        self._xx = None
+
+    def x_begin(self, D, K, n_total, state):
+        self.calls.append('x_begin')
+        v = self._v(state, D, K)
+        v['sc'][self.SC_N] = n_total
+        v['sc'][self.SC_TRXX] = v['sc'][self.SC_LDX] = 0.0
+        v['Mst'][:] = 0.0
+        v['Sxx'][:] = 0.0
+
+    def _posterior_x(self, v, D, K, N, flags, x_prec, Xm):
+        x = Xm.numpy()[:N, :K]
+        if flags & 2:                                    # FROM_VALUE: delta moments
+            xm = x.copy()
+            cov = np.zeros((N, K, K))
+            ld = 0.0
+        elif flags & 4:                                  # PRIOR
+            xm = np.zeros((N, K))
+            cov = np.broadcast_to(np.eye(K) / x_prec, (N, K, K)).copy()
+            ld = -N * K * np.log(x_prec)
+        else:
+            tau = v['tau'][2]
+            WWf = v['WW'][:D, :K, :K].reshape(D, K * K)
+            lam = x_prec * np.eye(K)[None] + tau * (self._m.T @ WWf).reshape(N, K, K)
+            cov = np.linalg.inv(lam) if N else np.zeros((0, K, K))
+            ld = -float(np.sum(np.linalg.slogdet(lam)[1])) if N else 0.0
+            xm = np.einsum('nij,nj->ni', cov, tau * (self._y.T @ v['W'][:D, :K]))
+            v['sc'][self.SC_TAUX] = tau
+        return xm, cov + xm[:, :, None] * xm[:, None, :], ld
+
+    def x_pass(self, D, K, N, chunk, nsets, flags, x_prec, Ymt, Mb1, Mb2, Xm, Lam, XXf, state, ws):
+        self.calls.append('x_pass')
+        v = self._v(state, D, K)
+        xm, xx, ld = self._posterior_x(v, D, K, N, flags, x_prec, Xm)
+        Xm.numpy()[:N, :K] = xm
+        self._xx = xx
+        i, j, p = self._tri(K)
+        M = (self._m @ xx.reshape(N, K * K)).reshape(D, K, K)
+        v['Mst'][:D][:, p] = M[:, i, j]
+        v['Mst'][:D, v['roff']:v['roff'] + K] = self._y @ xm
+        v['Sxx'][:K, :K] = xx.sum(axis=0)
+        v['sc'][self.SC_TRXX] = float(np.einsum('nkk->', xx))
+        v['sc'][self.SC_LDX] = ld
+
+    def x_chunk(self, D, K, n0, nplates, flags, x_prec, Ymt, Mb1, Mb2, Xm, Lam, XXf, state, ws):
+        """Only the INSPECT use of the plan (x_second_moments): <xx> of plates [n0, n0 + nplates)
+        as the last pass left them."""
+        self.calls.append('x_chunk')
+        assert flags & 8
+        self._chunk = self._xx[n0:n0 + nplates]
+
+    def unpack_xx(self, D, K, nplates, XXf, out):
+        out.numpy()[:nplates] = self._chunk
+
+    def update_w(self, D, K, mode, state):
+        self.calls.append('update_w%d' % mode)
+        v = self._v(state, D, K)
+        alpha = v['alpha'][2, :K]
+        if mode == 2:                                    # prior moments given <alpha>
+            v['W'][:D, :K] = 0.0
+            v['WW'][:D, :K, :K] = np.diag(1.0 / alpha)
+            v['ldW'][:D] = -np.sum(np.log(alpha))
+        elif mode == 1:                                  # delta moments of the value in W
+            w = v['W'][:D, :K]
+            v['WW'][:D, :K, :K] = w[:, :, None] * w[:, None, :]
+            v['ldW'][:D] = 0.0
+        else:
+            M, r = self._get_M(v, D, K)
+            tau = v['tau'][2]
+            lam = np.diag(alpha)[None] + tau * M
+            cw = np.linalg.inv(lam)
+            w = np.einsum('dij,dj->di', cw, tau * r)
+            v['W'][:D, :K] = w
+            v['WW'][:D, :K, :K] = cw + w[:, :, None] * w[:, None, :]
+            v['ldW'][:D] = -np.linalg.slogdet(lam)[1]
+
+    def small_ops(self, D, K, x_prec, a0t, b0t, a0a, b0a, ops, state):
+        self.calls.extend('op%d' % o for o in ops)
+        v = self._v(state, D, K)
+        sc = v['sc']
+        wm = v['rowobs'][:D] > 0                          # rows some rank observes
+        De = float(wm.sum())
+
+        def resid():
+            M, r = self._get_M(v, D, K)
+            return sc[self.SC_SYY] - 2.0 * np.sum(v['W'][:D, :K] * r) \
+                + np.sum(v['WW'][:D, :K, :K] * M)
+        for op in ops:
+            if op == 1:                                  # TAU
+                a, b = a0t + 0.5 * sc[self.SC_NOBS], b0t + 0.5 * resid()
+                v['tau'][:] = [a, b, a / b, special.digamma(a) - np.log(b)]
+            elif op == 2:                                # ALPHA
+                a = a0a + 0.5 * De
+                b = b0a + 0.5 * np.einsum('dkk->k', v['WW'][:D, :K, :K][wm])
+                v['alpha'][0, :K], v['alpha'][1, :K] = a, b
+                v['alpha'][2, :K] = a / b
+                v['alpha'][3, :K] = special.digamma(a) - np.log(b)
+            else:                                        # ELBO
+                tau, logtau = v['tau'][2], v['tau'][3]
+                alpha, logalpha = v['alpha'][2, :K], v['alpha'][3, :K]
+                N = sc[self.SC_N]
+                LOG2PI = np.log(2 * np.pi)
+                L_Y = sc[self.SC_NOBS] * (-0.5 * LOG2PI + 0.5 * logtau) - 0.5 * tau * resid()
+                L_X = -0.5 * x_prec * sc[self.SC_TRXX] + 0.5 * sc[self.SC_LDX] \
+                    + N * (0.5 * K * np.log(x_prec) + 0.5 * K)
+                L_W = 0.5 * De * np.sum(logalpha) \
+                    - 0.5 * np.sum(alpha * np.einsum('dkk->k', v['WW'][:D, :K, :K][wm])) \
+                    + 0.5 * float(np.sum(v['ldW'][:D][wm])) + 0.5 * De * K
+                L_tau = gamma_elbo(a0t, b0t, v['tau'][0], v['tau'][1])
+                L_alpha = gamma_elbo(a0a, b0a, v['alpha'][0, :K], v['alpha'][1, :K])
+                v['Lo'][:6] = [L_Y, L_X, L_W, L_tau, L_alpha, L_Y + L_X + L_W + L_tau + L_alpha]
+                sc[self.SC_STATUS] = 0.0
+
+    def set_timing(self, on):
+        pass
+
+    def pass_times_ms(self, cap=64):
+        return []
