@@ -118,3 +118,21 @@ def test_two_rank_shard_matches_unsharded_reference(tmp_path):
         np.testing.assert_allclose(ri['r'], g['z_u0'][int(ri['lo']):int(ri['hi'])], rtol=1e-8,
                                    atol=1e-12)
     assert np.array_equal(r[0]['L'], r[1]['L'])
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """VB.save / VB.load (vmp.py:237-356) on the mixture block: the packed state and the
+    responsibilities travel; a restored model continues bit for bit."""
+    g = np.load(os.path.join(GOLDEN, 'gmm_n400_d3_k4.npz'))
+    Q = _build(g['y'], g['lab0'], 4)
+    Q.update(repeat=2, verbose=False)
+    fn = str(tmp_path / 'gmm.bin')
+    Q.save(filename=fn)
+    Q.update(repeat=2, verbose=False)
+    Q2 = _build(g['y'], g['lab0'], 4)
+    Q2.load(filename=fn)
+    assert Q2.iter == 2 and np.array_equal(Q2.L[:2], Q.L[:2])
+    Q2.update(repeat=2, verbose=False)
+    assert np.array_equal(Q2.L[:4], Q.L[:4])
+    np.testing.assert_array_equal(Q2['z'].u[0], Q['z'].u[0])
+    np.testing.assert_array_equal(Q2['mu'].u[0], Q['mu'].u[0])

@@ -130,3 +130,21 @@ def test_two_rank_shard_matches_unsharded_reference(tmp_path):
         np.testing.assert_allclose(ri['x'], g['lssmB_X_u0'][int(ri['lo']):int(ri['hi'])], rtol=1e-7,
                                    atol=1e-9)
     assert np.array_equal(r[0]['L'], r[1]['L'])
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """VB.save / VB.load on the state-space block: a restored model continues bit for bit."""
+    g = np.load(os.path.join(GOLDEN, 'lssm.npz'))
+    args = (g['lssmB_y'], g['lssmB_x0'], g['lssmB_c0'], 6, True)
+    Q, _ = _build(*args)
+    Q.update(repeat=2, verbose=False)
+    fn = str(tmp_path / 'lssm.bin')
+    Q.save(filename=fn)
+    Q.update(repeat=2, verbose=False)
+    Q2, _ = _build(*args)
+    Q2.load(filename=fn)
+    assert Q2.iter == 2 and np.array_equal(Q2.L[:2], Q.L[:2])
+    Q2.update(repeat=2, verbose=False)
+    assert np.array_equal(Q2.L[:4], Q.L[:4])
+    np.testing.assert_array_equal(Q2['X'].u[0], Q['X'].u[0])
+    np.testing.assert_array_equal(Q2['A'].u[0], Q['A'].u[0])

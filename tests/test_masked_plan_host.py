@@ -96,3 +96,21 @@ def test_two_rank_shard_matches_unsharded_reference(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % i)) for i in range(world)]
     assert np.array_equal(r[0]['L'], r[1]['L'])
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """VB.save / VB.load on the missing-data block: a restored model continues bit for bit."""
+    g, inp = _inputs('masked_pca.npz')
+    args = (inp['m1_y'], inp['m1_mask'], inp['m1_x0'])
+    Q = _build(*args)
+    Q.update(repeat=2, verbose=False)
+    fn = str(tmp_path / 'mpca.bin')
+    Q.save(filename=fn)
+    Q.update(repeat=2, verbose=False)
+    Q2 = _build(*args)
+    Q2.load(filename=fn)
+    assert Q2.iter == 2 and np.array_equal(Q2.L[:2], Q.L[:2])
+    Q2.update(repeat=2, verbose=False)
+    assert np.array_equal(Q2.L[:4], Q.L[:4])
+    np.testing.assert_array_equal(Q2['X'].u[0], Q['X'].u[0])
+    np.testing.assert_array_equal(Q2['W'].u[0], Q['W'].u[0])
