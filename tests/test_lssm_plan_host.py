@@ -148,3 +148,42 @@ def test_checkpoint_round_trip(tmp_path):
     assert np.array_equal(Q2.L[:4], Q.L[:4])
     np.testing.assert_array_equal(Q2['X'].u[0], Q['X'].u[0])
     np.testing.assert_array_equal(Q2['A'].u[0], Q['A'].u[0])
+
+
+@pytest.mark.parametrize('tag,B', [('one', None), ('batch', 5)])
+def test_rotations_match_reference(tag, B):
+    """The rotation speed-up of demos/lssm.py:134-190 on the fused block (the K x K state of the
+    plan rotated on the host, the plate-sized means through vmp_lssm_rotate_x) against the
+    live-reference golden lssm_rotations.npz: one stand-alone rotation after two iterations, then
+    five iterations with the rotation after each (a truncated nonlinear CG: early values tight)."""
+    import warnings
+    from bayespy_amd.inference import transformations
+    g = np.load(os.path.join(GOLDEN, 'lssm_rotations.npz'))
+    Q, nd = _build(g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0'], B, False)
+    D = g[tag + '_x0'].shape[-1]
+    rotA = transformations.RotateGaussianARD(nd['A'], nd['alpha'], axis=0)
+    rotX = transformations.RotateGaussianMarkovChain(nd['X'], rotA)
+    rotC = transformations.RotateGaussianARD(nd['C'], nd['gamma'], axis=0)
+    R = transformations.RotationOptimizer(rotX, rotC, D)
+    Q.update(repeat=2, verbose=False)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g[tag + '_L_before'], rtol=1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        R.rotate(maxiter=10)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g[tag + '_L_after'], rtol=1e-6)
+    for nm in ('A', 'C', 'alpha', 'gamma', 'X'):
+        for i, ui in enumerate(nd[nm].u):
+            got, ref = np.broadcast_arrays(np.asarray(ui), g['%s_%s_u%d_rot' % (tag, nm, i)])
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(),
+                                       err_msg='%s u[%d] after the rotation' % (nm, i))
+    Ls = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(5):
+            Q.update(repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+            R.rotate(maxiter=10)
+    Ls = np.array(Ls)
+    np.testing.assert_allclose(Ls[:2], g[tag + '_L'][:2], rtol=1e-5)
+    np.testing.assert_allclose(Ls, g[tag + '_L'], rtol=2e-2)
+    assert np.all(np.diff(Ls) > 0)
