@@ -187,3 +187,33 @@ def test_rotations_match_reference(tag, B):
     np.testing.assert_allclose(Ls[:2], g[tag + '_L'][:2], rtol=1e-5)
     np.testing.assert_allclose(Ls, g[tag + '_L'], rtol=2e-2)
     assert np.all(np.diff(Ls) > 0)
+
+
+def test_reobserving_data_keeps_the_posteriors():
+    """Y.observe(new data) after updates changes Y only (stochastic.py:223-273): the fused block
+    keeps every posterior and takes a statistics pass of the new data with the current <x>
+    (live-reference trace tests/golden/reobserve.npz, lssm_* entries); no restart, no warning."""
+    import warnings
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.device import Runtime
+    from fake_kernels import CPULSSMKernels
+    from models import run_reobserve_lssm_case
+    g = np.load(os.path.join(GOLDEN, 'reobserve.npz'))
+    inp = {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+
+    class CPUVB(VB):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            plan = self.plans[0]
+            assert type(plan).__name__ == 'LSSMPlan'
+            rt = Runtime(device='cpu')
+            plan._rt, plan._kernels = rt, CPULSSMKernels(rt)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        res = run_reobserve_lssm_case(nodes, CPUVB, inp)
+    np.testing.assert_allclose(res['lssm_L'], g['lssm_L'], rtol=1e-9)
+    np.testing.assert_allclose(res['lssm_L_mid'], g['lssm_L_mid'], rtol=1e-9)
+    np.testing.assert_allclose(res['lssm_L_c'], g['lssm_L_c'], rtol=1e-9)
+    for key in ('lssm_X_u0', 'lssm_C_u0', 'lssm_A_u0'):
+        np.testing.assert_allclose(res[key], g[key], rtol=1e-7, atol=1e-9, err_msg=key)
