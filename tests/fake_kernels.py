@@ -829,3 +829,16 @@ class CPUMaskedKernels:
 
     def pass_times_ms(self, cap=64):
         return []
+
+
+def attach_cpu(Q, stats=None):
+    """Give every fused plan of a VB object its CPU kernel double (and a CPU runtime)."""
+    from bayespy_amd.device import Runtime
+    doubles = {'PCAPlan': CPURuntimeKernels, 'GMMPlan': CPUGMMKernels, 'LSSMPlan': CPULSSMKernels,
+               'MaskedPCAPlan': CPUMaskedKernels}
+    rt = Runtime(device='cpu')
+    for p in Q.plans:
+        p._rt, p._kernels = rt, doubles[type(p).__name__](rt)
+        if stats is not None and type(p).__name__ == 'PCAPlan':
+            p.stats = stats
+    return Q
