@@ -74,7 +74,10 @@ class Runtime:
         if self.ctx is None or not (dist.is_available() and dist.is_initialized()):
             return False          # not cached: a later init_process_group still gets RCCL
         self._comm_state = False
-        if dist.get_backend() != 'nccl' or os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'torch':
+        if os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'torch':
+            self._comm_reason = 'BAYESPY_AMD_COLLECTIVE=torch'
+            return False
+        if dist.get_backend() != 'nccl':
             self._comm_reason = 'backend %s' % dist.get_backend()
             return False
         cid = ctypes.create_string_buffer(128)

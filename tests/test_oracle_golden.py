@@ -131,3 +131,27 @@ def test_lssm_oracle_matches_reference(golden_dir, tag, nu_prior):
     np.testing.assert_allclose(xx, g[tag + '_X_u1'], rtol=1e-8, atol=1e-11)
     xpxn = o.Cn[None] + o.X[:, :-1, :, None] * o.X[:, 1:, None, :]
     np.testing.assert_allclose(xpxn, g[tag + '_X_u2'], rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize('name', ['gmm_n400_d3_k4', 'gmm_n3000_d8_k16'])
+@pytest.mark.parametrize('chunk', [251, 1 << 15])
+def test_gmm_oracle_matches_reference(golden_dir, name, chunk):
+    """oracle/gmm.py directly against the live-reference traces of demos/mog.py's model (bound and
+    every node's term per iteration, responsibilities, cluster moments) -- VERDICT r03: until now
+    this oracle was pinned only through the kernel doubles and the GPU tests."""
+    from oracle.gmm import GMMOracle
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    K = g['mu_u0'].shape[0]
+    o = GMMOracle(g['y'], g['lab0'], K, chunk=chunk)
+    o.iterate(int(g['n_iter']))
+    np.testing.assert_allclose(np.array(o.L), g['L'], rtol=1e-11)
+    for k in ('Y', 'mu', 'Lambda', 'z', 'alpha'):
+        np.testing.assert_allclose([t[k] for t in o.L_terms], g['L_' + k], rtol=1e-9, atol=1e-7,
+                                   err_msg=k)
+    np.testing.assert_allclose(o.r, g['z_u0'], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(o.mu, g['mu_u0'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(o._mumu(), g['mu_u1'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(o.Lam, g['Lambda_u0'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(o.logdetLam, g['Lambda_u1'], rtol=1e-9)
+    np.testing.assert_allclose(o.logpi, g['alpha_u0'], rtol=1e-9)
+    np.testing.assert_allclose(o.alpha, g['alpha_phi0'], rtol=1e-10)

@@ -93,6 +93,67 @@ def pmc_iteration_traffic(prof, prefix):
     return tot / its
 
 
+def timed_update(Q, steps, barrier=None):
+    """``Q.update(repeat=steps)`` as ONE timed region (the contract of bench.py) plus the
+    per-iteration wall times VB records itself (``Q.cputime``: node updates + the lower bound's
+    device -> host read, vmp.py:712-717): mean over the region, median, max and where the max fell
+    -- a single stall (a first-touch allocation, a host hiccup) shows up as ``max`` at a step
+    index instead of silently moving a short region's mean."""
+    import numpy as np
+    import torch
+    sync = barrier or torch.cuda.synchronize
+    i0 = Q.iter
+    sync()
+    t0 = time.perf_counter()
+    Q.update(repeat=steps, verbose=False)
+    sync()
+    dt = time.perf_counter() - t0
+    per = 1e3 * np.asarray(Q.cputime[i0:i0 + steps], dtype=np.float64)
+    st = {'ms_mean': 1e3 * dt / steps, 'ms_median': float(np.median(per)),
+          'ms_max': float(per.max()), 'argmax_step': int(per.argmax()), 'timed_s': dt}
+    return dt, st
+
+
+def compact(rec, leg):
+    """The one-screen form of a leg's record for the "extra" list of the default bench line (the
+    driver keeps only the tail of that line): step time with its spread, the dominant kernel's
+    time and roofline fraction, in-run parity, CPU baseline.  No prose."""
+    if 'error' in rec:
+        return {'leg': leg, 'error': str(rec['error'])[:160], 'wall_s': round(rec.get('wall_s', 0), 1)}
+    roof = rec.get('roofline', {})
+    cpu = rec.get('cpu_baseline', {})
+    sp = rec.get('step_ms', {})
+
+    def r(v, n=4):
+        return None if v is None else float('%.*g' % (n, v))
+    out = {'leg': leg, 'steps': rec.get('steps'), 'ms_per_step': r(rec.get('ms_per_step')),
+           'ms_median': r(sp.get('ms_median')), 'ms_max': r(sp.get('ms_max')),
+           'argmax_step': sp.get('argmax_step'), 'it_s': r(rec.get('value')),
+           'bound': roof.get('bound'), 'frac': r(roof.get('frac'), 3),
+           'kernel_ms': r(roof.get('avg_launch_ms'))}
+    if roof.get('kernel_ms'):
+        out['kernel_ms'] = {k: r(v) for k, v in roof['kernel_ms'].items()
+                            if isinstance(v, (int, float))}
+    if roof.get('issued_mfma_TFLOPs') is not None:
+        out['issued_TFLOPs'] = r(roof['issued_mfma_TFLOPs'], 3)
+    if roof.get('traffic') is not None:
+        alg = roof.get('alg_bytes_per_launch') or roof.get('alg_bytes_per_iteration')
+        out['traffic_GB'] = r(roof['traffic'] / 1e9)
+        if alg:
+            out['traffic_over_alg'] = r(roof['traffic'] / alg, 3)
+    par = cpu.get('elbo_rel_err_full', cpu.get('elbo_rel_err_hip_vs_oracle'))
+    if par is not None:
+        out['elbo_rel_err'] = r(par, 2)
+        out['parity_on'] = 'whole' if 'elbo_rel_err_full' in cpu else 'sample'
+    if cpu.get('value') is not None:
+        out['cpu_it_s'] = r(cpu['value'], 3)
+        out['cpu_cores'] = cpu.get('cores')
+    if rec.get('peak_mem_GB') is not None:
+        out['peak_GB'] = r(rec['peak_mem_GB'], 3)
+    out['wall_s'] = round(rec.get('wall_s', 0), 1)
+    return out
+
+
 def run_pca_c2(N=1_000_000, D=64, K=16, steps=50, warmup=5, cpu_baseline=True):
     """BASELINE config 2: the headline model at a size where the replicated-node chain, not the
     plate pass, sets the step (bytes 0.64 GB = 0.08 ms at 8 TB/s): absolute it/s is the figure."""
@@ -121,11 +182,7 @@ def run_pca_c2(N=1_000_000, D=64, K=16, steps=50, warmup=5, cpu_baseline=True):
     plan = Q.plans[0]
     Q.update(repeat=warmup, verbose=False)
     plan.enable_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    Q.update(repeat=steps, verbose=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, step_ms = timed_update(Q, steps)
     pass_ms = plan.pass_times_ms(64)
     avg_pass = sum(p[0] for p in pass_ms) / len(pass_ms)
     alg_bytes = 8.0 * N * (D + K)
@@ -138,7 +195,7 @@ def run_pca_c2(N=1_000_000, D=64, K=16, steps=50, warmup=5, cpu_baseline=True):
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'probabilistic PCA (BASELINE config 2), N=%d D=%d K=%d, fully observed'
                                % (N, D, K), 'stats': plan.stats, 'plate_layout': plan.plate_layout},
-        'elbo_first': L[0], 'elbo_last': L[-1],
+        'elbo_first': L[0], 'elbo_last': L[-1], 'step_ms': step_ms,
         'roofline': {'kernel': 'pca_xpass_kernel', 'bound': 'hbm', 'achieved': gbs,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                      'traffic': None, 'avg_launch_ms': avg_pass,
@@ -187,11 +244,7 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
     plan = Q.plans[0]
     Q.update(repeat=warmup, verbose=False)
     plan.enable_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    Q.update(repeat=steps, verbose=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, step_ms = timed_update(Q, steps)
     ms = plan.pass_times_ms(64)                    # HIP events recorded inside the timed region
     avg = sum(m[0] for m in ms) / len(ms)
     FS = D * D + D + 1
@@ -206,7 +259,7 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
         'config': {'workload': 'Gaussian mixture (Mixture+Categorical+GaussianARD+Wishart+'
                                'Dirichlet), N=%d D=%d K=%d, one VB iteration = mu, Lambda, z, '
                                'alpha updates + full ELBO' % (N, D, K)},
-        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]),
+        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]), 'step_ms': step_ms,
         'roofline': {'kernel': 'gmm_pass_kernel', 'bound': 'mfma', 'achieved': tflops,
                      'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': tflops / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
@@ -294,11 +347,8 @@ def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=1, cpu_baseline=Tru
     Q = VB(Y, F, W, X, tau, alpha, engine='generic')
     Q.ignore_bound_checks = True
     Q.update(repeat=warmup, verbose=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    Q.update(repeat=steps, verbose=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt, step_ms = timed_update(Q, steps)
+    dt /= steps
     L = [float(v) for v in Q.L[:Q.iter]]
     # what the generic engine moves per iteration at the least: Y twice (both Dot messages), the
     # (N, K, K) second moments of X written by the moment kernel and read by both messages and the
@@ -313,7 +363,7 @@ def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=1, cpu_baseline=Tru
         'config': {'workload': 'probabilistic PCA (BASELINE config 2), N=%d D=%d K=%d, fully '
                                'observed, engine=generic (per-node kernels, no fused block)'
                                % (N, D, K), 'engine': type(Q.plans[0]).__name__},
-        'elbo_first': L[0], 'elbo_last': L[-1],
+        'elbo_first': L[0], 'elbo_last': L[-1], 'step_ms': step_ms,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'hbm', 'achieved': alg / dt / 1e9, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': alg / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
@@ -370,11 +420,8 @@ def run_generic_gmm(N=100_000, D=16, K=32, steps=3, warmup=1, cpu_baseline=True)
         Q = VB(Y, mu, Lam, z, alpha, engine='generic')
     Q.ignore_bound_checks = True
     Q.update(repeat=warmup, verbose=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    Q.update(repeat=steps, verbose=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt, step_ms = timed_update(Q, steps)
+    dt /= steps
     L = [float(v) for v in Q.L[:Q.iter]]
     FS = D * D + D + 1
     flops = 4.0 * N * K * FS
@@ -387,7 +434,7 @@ def run_generic_gmm(N=100_000, D=16, K=32, steps=3, warmup=1, cpu_baseline=True)
                                'with (N, K, D, D) intermediates' % (N, D, K),
                    'engine': type(Q.plans[0]).__name__,
                    'matcher_said': [str(w.message)[:300] for w in wlist][:1]},
-        'elbo_first': L[0], 'elbo_last': L[-1],
+        'elbo_first': L[0], 'elbo_last': L[-1], 'step_ms': step_ms,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'mfma', 'achieved': flops / dt / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
@@ -451,11 +498,7 @@ def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine
     timed = hasattr(plan, 'enable_timing')
     if timed:
         plan.enable_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    Q.update(repeat=steps, verbose=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, step_ms = timed_update(Q, steps)
     # 2NDK^2 (messages to W) + 2NDK^2 (precisions of X) + NK^3/3 (Cholesky)
     flops = 4.0 * N * D * K * K + N * K ** 3 / 3.0
     L = [float(v) for v in Q.L[:Q.iter]]
@@ -468,7 +511,7 @@ def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine
         'config': {'workload': 'probabilistic PCA with values missing at random (array mask), '
                                'N=%d D=%d K=%d: per-plate K x K posteriors for X and W'
                                % (N, D, K), 'engine': type(plan).__name__},
-        'elbo_first': L[0], 'elbo_last': L[-1],
+        'elbo_first': L[0], 'elbo_last': L[-1], 'step_ms': step_ms,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'mfma', 'achieved': flops / (dt / steps) / 1e12,
                      'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -603,11 +646,8 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1, cpu_baseline=True,
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    Q.update(repeat=steps, verbose=False)
-    barrier()
-    dt = (time.perf_counter() - t0) / steps
+    dt, step_ms = timed_update(Q, steps, barrier)
+    dt /= steps
     # algorithmic traffic per iteration: read Y (M B T), read + write the chain means (B T D)
     byts = 8.0 * B * T * (M + 2 * D)
     kms = plan.kernel_times_ms() if timed else None
@@ -620,7 +660,7 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1, cpu_baseline=True,
                                '%d sequences x %d steps, observations %d-dim, states %d-dim'
                                % (B, T, M, D), 'engine': type(Q.plans[0]).__name__,
                    'sequences_per_rank': Bl},
-        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]),
+        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]), 'step_ms': step_ms,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'hbm', 'achieved': byts / dt / 1e9, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': byts / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
