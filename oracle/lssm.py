@@ -222,3 +222,159 @@ class LSSMOracle:
             self.L.append(L)
             self.L_terms.append(terms)
         return self.L[-1]
+
+
+def _batched_spd_inv_logdet(S):
+    """(..., D, D) SPD matrices: inverses and log-determinants via Cholesky."""
+    L = np.linalg.cholesky(S)
+    Linv = np.linalg.solve(L, np.broadcast_to(np.eye(S.shape[-1]), S.shape))
+    inv = np.swapaxes(Linv, -1, -2) @ Linv
+    ld = 2.0 * np.sum(np.log(np.einsum('...ii->...i', L)), axis=-1)
+    return inv, ld
+
+
+class MaskedLSSMOracle(LSSMOracle):
+    """The same model observed through an ARRAY mask (``Y.observe(y, mask=mask)``,
+    bayespy/demos/lssm.py:132, :239-246), mask broadcastable to (M, B, T).  Pinned on the live
+    reference through tests/golden/lssm_masked.npz (oracle/make_golden.py lssm_masked_cases).
+
+    What changes against the fully observed block (node.py:457-526, :570-655: a message is
+    multiplied by the child's mask before the plate sum; expfamily.py:343-366: every latent plate
+    is updated, also an ignored one; expfamily.py:470-480: the bound skips ignored plates):
+
+    * every sequence has its OWN block-tridiagonal precision: diagonal blocks
+      prior + <tau> sum_m mask_mbt <c_m c_m^T>  (gaussian_markov_chain.py:542-627 with the message of
+      dot.py:425-633), hence its own covariance recursion (utils/linalg.py:468-575) and log|Phi_b|;
+    * every row of C has its own posterior: Lam_m = diag<gamma> + <tau> sum_bt mask_mbt <x_bt x_bt^T>;
+    * plates without any observation are IGNORED plates: a row m of C never observed is updated
+      to its prior-only posterior but sends nothing to gamma and adds nothing to the bound; a
+      sequence b never observed likewise for A / nu / the bound of X (mask of the parent = any()
+      over the child's plates, node.py:486-526).
+    Values at masked entries are never read (NaN placeholders are fine)."""
+
+    def __init__(self, y, mask, x0, c0, **kw):
+        y = np.asarray(y, dtype=np.float64)
+        self.mask = np.ascontiguousarray(np.broadcast_to(np.asarray(mask, dtype=bool), y.shape))
+        y = np.where(self.mask, y, 0.0)
+        self.m_obs = self.mask.any(axis=(1, 2))            # rows of C that see data
+        self.b_obs = self.mask.any(axis=(0, 2))            # sequences that see data
+        self.n_obs = float(self.mask.sum())
+        super().__init__(y, x0, c0, **kw)
+        self.CovCm = None                                   # (M, D, D) after the first C.update()
+        self.logdetCCm = None
+
+    # -- plate sums ---------------------------------------------------------------------------------
+    def _stats(self, V, Cn):
+        """V (B,T,D,D) / Cn (B,T-1,D,D) per sequence (zeros for delta moments)."""
+        x, B, T, D = self.X, self.B, self.T, self.D
+        if V.ndim == 3:
+            V = np.broadcast_to(V, (B,) + V.shape)
+            Cn = np.broadcast_to(Cn, (B,) + Cn.shape)
+        P = V + x[:, :, :, None] * x[:, :, None, :]                         # <x_bt x_bt^T>
+        w = self.b_obs.astype(np.float64)
+        self.Beff = float(w.sum())
+        self.Spp = np.einsum('b,btij->ij', w, P[:, :-1])
+        self.Snn = np.einsum('b,btij->ij', w, P[:, 1:])
+        # <x_t x_{t-1}^T> = Cov(x_{t-1}, x_t)^T + mean outer product
+        self.Snp = np.einsum('b,btji->ij', w, Cn) + np.einsum('b,bti,btj->ij', w, x[:, 1:], x[:, :-1])
+        self.S00 = np.einsum('b,bij->ij', w, P[:, 0])
+        self.s0 = w @ x[:, 0]
+        mk = self.mask.astype(np.float64)
+        self.XXm = np.einsum('mbt,btij->mij', mk, P)                        # per row of C
+        self.Syx = np.einsum('mbt,btd->md', self.y, x, optimize=True)       # y is zero where masked
+        self.P = P
+
+    # -- node updates -------------------------------------------------------------------------------
+    def _ccm(self):
+        """<c_m c_m^T> per row (M, D, D)."""
+        cc = self.Cm[:, :, None] * self.Cm[:, None, :]
+        return cc if self.CovCm is None else cc + self.CovCm
+
+    def _sum_cc(self):
+        return np.einsum('m,mij->ij', self.m_obs.astype(np.float64), self._ccm())
+
+    def update_C(self):
+        Lam = np.diag(self.gamma)[None] + self.tau * self.XXm
+        self.CovCm, ld = _batched_spd_inv_logdet(Lam)
+        self.logdetCCm = -ld
+        self.Cm = self.tau * np.einsum('mij,mj->mi', self.CovCm, self.Syx)
+
+    def update_gamma(self):
+        self.gamma_a = np.full(self.D, self.a0 + 0.5 * self.m_obs.sum())
+        self.gamma_b = self.b0 + 0.5 * np.diag(self._sum_cc())
+        self.gamma, self.loggamma = gamma_moments(self.gamma_a, self.gamma_b)
+
+    def update_X(self):
+        T, D, B = self.T, self.D, self.B
+        AnuA = np.einsum('i,ijk->jk', self.nu, self.AA)
+        base = np.empty((T, D, D))
+        for t in range(T):
+            base[t] = (self.Lam0 if t == 0 else np.diag(self.nu)) + (AnuA if t < T - 1 else 0.0)
+        obs = self.tau * np.einsum('mbt,mij->btij', self.mask.astype(np.float64), self._ccm())
+        Dg = base[None] + obs                                                # (B, T, D, D)
+        E = -(self.nu[:, None] * self.Am).T                                 # Phi[t, t+1]
+        h = self.tau * np.einsum('mbt,md->btd', self.y, self.Cm, optimize=True)
+        h[:, 0] += self.Lam0 @ self.mu0
+        Sinv = np.empty((B, T, D, D))
+        z = np.empty((B, T, D))
+        logdet = np.zeros(B)
+        S = Dg[:, 0]
+        for t in range(T):
+            Sinv[:, t], ld = _batched_spd_inv_logdet(S)
+            logdet += ld
+            if t == 0:
+                z[:, 0] = h[:, 0]
+            if t < T - 1:
+                J = Sinv[:, t] @ E                                           # (B, D, D)
+                S = Dg[:, t + 1] - E.T @ J
+                z[:, t + 1] = h[:, t + 1] - np.einsum('bji,bj->bi', J, z[:, t])
+        x = np.empty((B, T, D))
+        V = np.empty((B, T, D, D))
+        Cn = np.empty((B, max(T - 1, 0), D, D))
+        x[:, T - 1] = np.einsum('bij,bj->bi', Sinv[:, T - 1], z[:, T - 1])
+        V[:, T - 1] = Sinv[:, T - 1]
+        for t in range(T - 2, -1, -1):
+            J = Sinv[:, t] @ E
+            x[:, t] = np.einsum('bij,bj->bi', Sinv[:, t], z[:, t]) - np.einsum('bij,bj->bi', J, x[:, t + 1])
+            Cn[:, t] = -J @ V[:, t + 1]
+            V[:, t] = Sinv[:, t] - Cn[:, t] @ np.swapaxes(J, -1, -2)
+        self.X, self.V, self.Cn = x, V, Cn
+        self.logdetPhi_b = logdet
+        self.logdetPhi = float(np.sum(logdet[self.b_obs]))
+        self._stats(V, Cn)
+
+    def _residual(self):
+        return (self.Syy - 2.0 * float(np.sum(self.Cm * self.Syx))
+                + float(np.sum(self._ccm() * self.XXm)))
+
+    def update_tau(self):
+        self.tau_a = self.a0 + 0.5 * self.n_obs
+        self.tau_b = self.b0 + 0.5 * self._residual()
+        self.tau, self.logtau = gamma_moments(self.tau_a, self.tau_b)
+
+    def update_nu(self):
+        self.nu_a = np.full(self.D, self.nu_prior[0] + 0.5 * self.Beff * (self.T - 1))
+        self.nu_b = self.nu_prior[1] + 0.5 * self._innovation()
+        self.nu, self.lognu = gamma_moments(self.nu_a, self.nu_b)
+
+    def lower_bound(self):
+        T, D = self.T, self.D
+        Mo, Bo = float(self.m_obs.sum()), self.Beff
+        L_Y = self.n_obs * (-0.5 * LOG2PI + 0.5 * self.logtau) - 0.5 * self.tau * self._residual()
+        cc = self._sum_cc()
+        L_C = (0.5 * Mo * np.sum(self.loggamma) - 0.5 * np.sum(self.gamma * np.diag(cc))
+               + 0.5 * float(np.sum(self.logdetCCm[self.m_obs])) + 0.5 * Mo * D)
+        L_A = (0.5 * D * np.sum(self.logalpha) - 0.5 * np.sum(self.alpha * np.einsum('ijj->j', self.AA))
+               + 0.5 * np.sum(self.logdetCA) + 0.5 * D * D)
+        x0dev = (self.S00 - np.outer(self.s0, self.mu0) - np.outer(self.mu0, self.s0)
+                 + Bo * np.outer(self.mu0, self.mu0))
+        L_X = (Bo * (0.5 * T * D + 0.5 * np.linalg.slogdet(self.Lam0)[1]
+                     + 0.5 * (T - 1) * np.sum(self.lognu)) - 0.5 * self.logdetPhi
+               - 0.5 * np.sum(self.Lam0 * x0dev) - 0.5 * np.sum(self.nu * self._innovation()))
+        terms = dict(Y=float(L_Y), C=float(L_C), A=float(L_A), X=float(L_X),
+                     gamma=gamma_elbo(self.a0, self.b0, self.gamma_a, self.gamma_b),
+                     alpha=gamma_elbo(self.a0, self.b0, self.alpha_a, self.alpha_b),
+                     tau=gamma_elbo(self.a0, self.b0, self.tau_a, self.tau_b))
+        if self.nu_prior is not None:
+            terms['nu'] = gamma_elbo(self.nu_prior[0], self.nu_prior[1], self.nu_a, self.nu_b)
+        return float(sum(terms.values())), terms

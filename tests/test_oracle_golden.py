@@ -155,3 +155,44 @@ def test_gmm_oracle_matches_reference(golden_dir, name, chunk):
     np.testing.assert_allclose(o.logdetLam, g['Lambda_u1'], rtol=1e-9)
     np.testing.assert_allclose(o.logpi, g['alpha_u0'], rtol=1e-9)
     np.testing.assert_allclose(o.alpha, g['alpha_phi0'], rtol=1e-10)
+
+
+MASKED_LSSM = [('md', None), ('mb', (1e-3, 1e-3)), ('ms', None), ('me', (1e-3, 1e-3)), ('m1', None)]
+
+
+def load_masked_lssm(golden_dir, tag):
+    """(y (M,B,T), mask (M,B,T) as stored -- possibly broadcastable --, x0 (B,T,D), c0 (M,D), g)."""
+    g = np.load(os.path.join(golden_dir, 'lssm_masked.npz'))
+    y, mask, x0, c0 = g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'], g[tag + '_c0']
+    if y.ndim == 2:                       # the demo's shape: no sequence plate
+        y, mask, x0 = y[:, None, :], mask[:, None, :], x0[None]
+    return y, mask, x0, c0.reshape(y.shape[0], -1), g
+
+
+@pytest.mark.parametrize('tag,nu_prior', MASKED_LSSM)
+def test_masked_lssm_oracle_matches_reference(golden_dir, tag, nu_prior):
+    """oracle/lssm.py:MaskedLSSMOracle (one covariance recursion PER sequence, one posterior per
+    row of C, ignored plates) against live-reference traces of demos/lssm.py's model observed
+    through array masks: the demo's own (M, T) mask with a fully missing stretch (md), one mask
+    per sequence (mb), a mask shared by the sequences (ms), rows / sequences / time steps without
+    any observation (me), a single time step (m1).  mb / me come from the reference with its
+    chol_solve broadcast defect repaired (oracle/make_golden.py:lssm_masked_cases)."""
+    from oracle.lssm import MaskedLSSMOracle
+    y, mask, x0, c0, g = load_masked_lssm(golden_dir, tag)
+    o = MaskedLSSMOracle(y, mask, x0, c0, nu_prior=nu_prior)
+    n = len(g[tag + '_L'])
+    o.iterate(n)
+    np.testing.assert_allclose(np.array(o.L), g[tag + '_L'], rtol=1e-11)
+    for nm in ('Y', 'X', 'A', 'C', 'tau', 'alpha', 'gamma') + (('nu',) if nu_prior else ()):
+        np.testing.assert_allclose([t[nm] for t in o.L_terms], g['%s_%s_L' % (tag, nm)],
+                                   rtol=1e-9, atol=1e-8, err_msg=nm)
+    sh = o.X.shape
+    np.testing.assert_allclose(o.X, g[tag + '_X_u0'].reshape(sh), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(o.P, g[tag + '_X_u1'].reshape(sh + sh[-1:]), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(o.Cm, g[tag + '_C_u0'].reshape(o.Cm.shape), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(o._ccm(), g[tag + '_C_u1'].reshape(o._ccm().shape), rtol=1e-8,
+                               atol=1e-8)
+    np.testing.assert_allclose(o.Am, g[tag + '_A_u0'], rtol=1e-8, atol=1e-11)
+    if tag + '_L_defect' in g.files:
+        # the unrepaired reference gives every sequence the last one's S^-1 E: a different trace
+        assert np.max(np.abs(g[tag + '_L_defect'] - g[tag + '_L'])) > 1e-2
