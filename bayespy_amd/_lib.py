@@ -71,6 +71,13 @@ class LSSMLayout(ctypes.Structure):
         'off_covsums', 'off_raw', 'len_raw', 'off_S', 'off_scal', 'off_L', 'total')]
 
 
+class LSSMMLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        'NS', 'off_tau', 'off_gamma', 'off_alpha', 'off_nu', 'off_mu0', 'off_Lam0', 'off_ldLam0',
+        'off_Cm', 'off_CovC', 'off_ldC', 'off_SCC', 'off_Am', 'off_AA', 'off_ldA', 'off_tab',
+        'len_tab', 'off_setup', 'len_setup', 'off_raw', 'len_raw', 'off_scal', 'off_L', 'total')]
+
+
 class GMMLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in (
         'DP', 'KP', 'FS', 'FP', 'F2P', 'off_T', 'len_T', 'off_zs', 'off_alpha', 'off_mu',
@@ -149,6 +156,15 @@ SIGNATURES = {
                                   c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_lssm_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f64, P(c_f64), c_i32, c_i32,
                                    P(c_i32), c_vp]),
+    'vmp_lssmm_limits': (c_i32, [P(c_i32), P(c_i32)]),
+    'vmp_lssmm_get_layout': (c_i32, [c_i32, c_i32, P(LSSMMLayout)]),
+    'vmp_lssmm_workspace_doubles': (c_i32, [c_i32, c_i32, c_i64, c_i32, P(c_i64)]),
+    'vmp_lssmm_prepare': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i64, c_i32,
+                                  c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssmm_x_update': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i64,
+                                   c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssmm_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i32, P(c_f64), c_i32, c_i32, P(c_i32),
+                                    c_vp]),
     'vmp_gmm_get_layout': (c_i32, [c_i32, c_i32, P(GMMLayout)]),
     'vmp_gmm_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, P(c_sz)]),
     'vmp_gmm_init_state': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_f64, c_f64, c_vp, c_vp]),
@@ -187,6 +203,17 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def bind_lssmm(lib):
+    """Attach the vmp_lssmm_* signatures to another library that exports that part of the C ABI
+    (the host build of the same device code: tests/host_build.py)."""
+    for name, (restype, argtypes) in SIGNATURES.items():
+        if name.startswith('vmp_lssmm_'):
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+    return lib
 
 
 def header_symbols():

@@ -1,0 +1,432 @@
+// vmp_lssmm.hip -- fused linear state-space model block with ARRAY masks (gfx950).
+//
+// Model: bayespy/demos/lssm.py:34-103 (optionally with a plate of B sequences) observed through
+// ``Y.observe(y, mask=mask)`` with an array mask broadcastable to (M, B, T) -- the reference's own
+// canonical use (demos/lssm.py:239-246).  With a mask the block-tridiagonal precision of q(X_b)
+// differs per sequence (diagonal blocks prior + <tau> sum_m mask_mbt <c_m c_m^T>), so unlike
+// vmp_lssm.hip there is no shared covariance recursion: ONE THREAD PER SEQUENCE runs the D x D
+// block LDL^T recursion of linalg.block_banded_solve (utils/linalg.py:468-575) in registers beside
+// the mean recursion.  Sweeps over time-major arrays (b contiguous, every access of a time step
+// coalesced over the sequences):
+//   lssmm_forward_kernel    reads Yt, Mw; writes F = [S_t^-1 (packed) | z_t]
+//   lssmm_backward_kernel   reads F; writes Z = <x_t>, P = <x_t x_t^T> (packed); chain sums
+//   lssmm_stats_kernel      reads P, Z, Yt, Mw; XX_m = sum_bt mask P, Syx_m = sum_bt y x
+// Algorithmic bytes per (sequence, step): 8 (M + D + NS) read+write of the data, means and second
+// moments; the three sweeps move 8 (2M + 3 NS + 3 D) + 16 (mask word twice): F is written and read
+// back (the backward recursion needs S_t^-1 of every step).
+// The per-thread arithmetic lives in vmp_lssmm_dev.h (host+device; the CPU suite runs the same
+// text against oracle/lssm.py).  All plate sums are combined in a fixed order.
+#include "vmp_common.h"
+#include "vmp_lssmm_dev.h"
+
+namespace {
+
+constexpr int WNT = 64;       // one wavefront per workgroup: few sequences must spread over many CUs
+constexpr int RNT = 256;
+constexpr int MG = 4;         // rows of C per thread of the statistics pass
+
+struct dg_fn {
+    __host__ __device__ double operator()(double x) const { return vmp_digamma(x); }
+};
+struct lg_fn {
+    __host__ __device__ double operator()(double x) const { return vmp_lgamma(x); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// set-up: Y (M, B, T) + mask (strided bytes) -> Yt (T, M, BL), Mw (T, BL), counts
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RNT)
+lssmm_prepare_kernel(const double *__restrict__ Y, const uint8_t *__restrict__ mask, int64_t sm,
+                     int64_t sb, int64_t st, int M, int64_t B, int T, int64_t BL,
+                     double *__restrict__ Yt, unsigned long long *__restrict__ Mw,
+                     double *__restrict__ partial, unsigned long long *__restrict__ cnt)
+{
+    // 32 x 32 tiles of the (b, t) plane through LDS: both sides coalesced
+    __shared__ double tile[32][33];
+    __shared__ unsigned char mt[32][33];
+    __shared__ double red[RNT / 64];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int64_t nbt = (B + 31) / 32, ntt = (T + 31) / 32;
+    double syy = 0.0;
+    for (int64_t blk = blockIdx.x; blk < nbt * ntt * M; blk += gridDim.x) {
+        const int m = (int)(blk / (nbt * ntt));
+        const int64_t r = blk - (int64_t)m * nbt * ntt;
+        const int64_t bt = r / ntt, tt = r - bt * ntt;
+        __syncthreads();
+        unsigned long long c = 0;
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t b = bt * 32 + j;
+            const int t = (int)(tt * 32) + tx;
+            double v = 0.0;
+            unsigned char mk = 0;
+            if (b < B && t < T) {
+                mk = mask[m * sm + b * sb + (int64_t)t * st] ? 1 : 0;
+                if (mk) v = Y[((int64_t)m * B + b) * T + t];     // values at masked entries: never read
+            }
+            tile[j][tx] = v;
+            mt[j][tx] = mk;
+            syy += v * v;
+            c += mk;
+        }
+        // integer count of this row's observations (order-independent: exact)
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[m], c);
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int t = (int)(tt * 32) + j;
+            const int64_t b = bt * 32 + tx;
+            if (t < T && b < BL) {
+                Yt[((int64_t)t * M + m) * BL + b] = tile[tx][j];
+                if (mt[tx][j]) atomicOr(&Mw[(int64_t)t * BL + b], 1ull << m);
+            }
+        }
+    }
+    syy = block_sum<RNT>(syy, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = syy;
+}
+
+// seqobs[b] = 1.0 when sequence b has any observation (pad columns 0); their count
+__global__ void __launch_bounds__(RNT)
+lssmm_seqobs_kernel(const unsigned long long *__restrict__ Mw, int64_t B, int T, int64_t BL,
+                    double *__restrict__ seqobs, unsigned long long *__restrict__ cnt_b)
+{
+    const int64_t b = (int64_t)blockIdx.x * RNT + threadIdx.x;
+    unsigned long long any = 0;
+    if (b < B)
+        for (int t = 0; t < T; ++t) any |= Mw[(int64_t)t * BL + b];
+    if (b < BL) seqobs[b] = any ? 1.0 : 0.0;
+    unsigned long long c = any ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt_b, c);
+}
+
+__global__ void __launch_bounds__(64)
+lssmm_setup_finish_kernel(const double *__restrict__ partial, int n,
+                          const unsigned long long *__restrict__ cnt, int M, double *__restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        out[0] = s;
+        out[1] = (double)cnt[M];
+    }
+    for (int m = threadIdx.x; m < M; m += 64) out[2 + m] = (double)cnt[m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// sweeps: one thread per sequence
+// ---------------------------------------------------------------------------------------------
+struct sweep_args {
+    lssmm_seq_args S;
+    const double *seqobs;
+    int64_t B;
+    int tab_len;
+    double *partial;        // per workgroup
+    double *status;         // state[off_scal]
+    int given;
+};
+
+template <int D>
+__global__ void __launch_bounds__(WNT)
+lssmm_forward_kernel(sweep_args A)
+{
+    extern __shared__ double tab[];
+    for (int e = threadIdx.x; e < A.tab_len; e += WNT) tab[e] = A.S.tab[e];
+    __syncthreads();
+    lssmm_seq_args S = A.S;
+    S.tab = tab;
+    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    double ld = 0.0;
+    int bad = 0;
+    if (b < A.B) ld = lssmm_forward_seq<D>(S, b, bad);
+    // log|Phi_b| of the sequences with data (an ignored plate adds nothing to the bound)
+    ld = (b < A.B) ? ld * A.seqobs[b] : 0.0;
+    ld = wave_sum(ld);
+    if (threadIdx.x == 0) A.partial[blockIdx.x] = ld;
+    if (bad) A.status[0] = (double)VMP_ERR_NOT_POSDEF;
+}
+
+template <int D>
+__global__ void __launch_bounds__(WNT)
+lssmm_backward_kernel(sweep_args A)
+{
+    constexpr int NS = D * (D + 1) / 2;
+    constexpr int CL = 3 * NS + D * D + D;        // chain sums without log|Phi|
+    extern __shared__ double tab[];
+    for (int e = threadIdx.x; e < A.tab_len; e += WNT) tab[e] = A.S.tab[e];
+    __syncthreads();
+    lssmm_seq_args S = A.S;
+    S.tab = tab;
+    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    double acc[CL];
+#pragma unroll
+    for (int e = 0; e < CL; ++e) acc[e] = 0.0;
+    if (b < A.B) {
+        lssmm_backward_seq<D>(S, b, A.given, acc);
+        const double w = A.seqobs[b];
+#pragma unroll
+        for (int e = 0; e < CL; ++e) acc[e] *= w;
+    }
+#pragma unroll
+    for (int e = 0; e < CL; ++e) {
+        const double s = wave_sum(acc[e]);
+        if (threadIdx.x == 0) A.partial[(int64_t)blockIdx.x * CL + e] = s;
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(WNT)
+lssmm_stats_kernel(sweep_args A)
+{
+    constexpr int NS = D * (D + 1) / 2;
+    constexpr int AL = MG * (NS + D);
+    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    const int m0 = blockIdx.y * MG;
+    double acc[AL];
+#pragma unroll
+    for (int e = 0; e < AL; ++e) acc[e] = 0.0;
+    if (b < A.B) lssmm_stats_seq<D, MG>(A.S, b, m0, acc);
+#pragma unroll
+    for (int e = 0; e < AL; ++e) {
+        const double s = wave_sum(acc[e]);
+        if (threadIdx.x == 0)
+            A.partial[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * AL + e] = s;
+    }
+}
+
+// out[j] = sum_blk partial[blk * stride + j], fixed order; 16 row-lanes x 16 outputs per workgroup
+__global__ void __launch_bounds__(RNT)
+lssmm_sum_kernel(const double *__restrict__ partial, int n, int stride, int len,
+                 double *__restrict__ out)
+{
+    __shared__ double tile[16][17];
+    const int kx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + kx;
+    double acc = 0.0;
+    if (j < len)
+        for (int b = ry; b < n; b += 16) acc += partial[(int64_t)b * stride + j];
+    tile[ry][kx] = acc;
+    __syncthreads();
+    if (ry == 0 && j < len) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += tile[r][kx];
+        out[j] = s;
+    }
+}
+
+// the statistics partials [blk][group][MG][NS + D] -> XX (M, NS) | Syx (M, D)
+__global__ void __launch_bounds__(RNT)
+lssmm_sum_stats_kernel(const double *__restrict__ partial, int n, int ng, int M, int NS, int D,
+                       double *__restrict__ XX, double *__restrict__ Syx)
+{
+    __shared__ double tile[16][17];
+    const int kx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int stride = ng * MG * (NS + D);
+    const int j = blockIdx.x * 16 + kx;
+    double acc = 0.0;
+    if (j < stride)
+        for (int b = ry; b < n; b += 16) acc += partial[(int64_t)b * stride + j];
+    tile[ry][kx] = acc;
+    __syncthreads();
+    if (ry == 0 && j < stride) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += tile[r][kx];
+        const int m = j / (NS + D), f = j - m * (NS + D);
+        if (m < M) {
+            if (f < NS) XX[m * NS + f] = s;
+            else Syx[m * D + (f - NS)] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+lssmm_small_kernel(lssmm_small_args A, double *__restrict__ gst)
+{
+    extern __shared__ double st_lds[];
+    const int total = (int)A.L.total;
+    for (int e = threadIdx.x; e < total; e += 64) st_lds[e] = gst[e];
+    __syncthreads();
+    if (threadIdx.x == 0) lssmm_small_body(A, st_lds, dg_fn(), lg_fn());
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += 64) gst[e] = st_lds[e];
+}
+
+inline int64_t nwg(int64_t B) { return (B + WNT - 1) / WNT; }
+
+// workspace (doubles): [sweep partials | set-up partials] then M + 1 integer counters
+inline int64_t ws_partials(int D, int M, int64_t B)
+{
+    const int NS = D * (D + 1) / 2;
+    const int64_t g = nwg(B) > 0 ? nwg(B) : 1;
+    const int64_t ng = (M + MG - 1) / MG;
+    const int64_t a = g * (3 * NS + D * D + D) + g;            // backward + forward (log|Phi|)
+    const int64_t s = g * ng * MG * (NS + D);
+    const int64_t r = 256 * 8;                                 // prepare partials
+    int64_t n = a > s ? a : s;
+    if (r > n) n = r;
+    return n + 64;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vmp_lssmm_limits(int32_t *max_D, int32_t *max_M)
+{
+    if (max_D) *max_D = LSSMM_DMAX;
+    if (max_M) *max_M = LSSMM_MMAX;
+    return VMP_OK;
+}
+
+int32_t vmp_lssmm_get_layout(int32_t D, int32_t M, vmp_lssmm_layout *out)
+{
+    if (!out || D < 1 || D > LSSMM_DMAX || M < 1 || M > LSSMM_MMAX) return VMP_ERR_INVALID;
+    lssmm_fill_layout(D, M, out);
+    return VMP_OK;
+}
+
+int32_t vmp_lssmm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
+{
+    (void)T;
+    if (!n || D < 1 || D > LSSMM_DMAX || M < 1 || M > LSSMM_MMAX || B < 0) return VMP_ERR_INVALID;
+    *n = ws_partials(D, M, B) + LSSMM_MMAX + 8;
+    return VMP_OK;
+}
+
+int32_t vmp_lssmm_prepare(vmp_ctx *ctx, const double *Y, const uint8_t *mask, int64_t sm,
+                          int64_t sb, int64_t st, int32_t M, int64_t B, int32_t T, int64_t BL,
+                          int32_t D, double *Yt, uint64_t *Mw, double *seqobs, double *state,
+                          void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Y && mask && Yt && Mw && seqobs && state && workspace, VMP_ERR_INVALID,
+                "null argument");
+    VMP_REQUIRE(ctx, M >= 1 && M <= LSSMM_MMAX && D >= 1 && D <= LSSMM_DMAX && B >= 0 && T >= 1
+                && BL >= B && BL >= 1, VMP_ERR_INVALID, "bad dims");
+    vmp_lssmm_layout L;
+    lssmm_fill_layout(D, M, &L);
+    double *partial = reinterpret_cast<double *>(workspace);
+    unsigned long long *cnt =
+        reinterpret_cast<unsigned long long *>(partial + ws_partials(D, M, B));
+    const int64_t nblk = ((B + 31) / 32) * ((T + 31) / 32) * M;
+    int64_t g = nblk < (int64_t)ctx->num_cu * 8 ? nblk : (int64_t)ctx->num_cu * 8;
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, (M + 1) * sizeof(unsigned long long), ctx->stream));
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(Yt, 0, (size_t)T * M * BL * sizeof(double), ctx->stream));
+    VMP_HIP_CHECK(ctx, hipMemsetAsync(Mw, 0, (size_t)T * BL * sizeof(uint64_t), ctx->stream));
+    if (g > 0)
+        hipLaunchKernelGGL(lssmm_prepare_kernel, dim3((unsigned)g), dim3(RNT), 0, ctx->stream, Y, mask,
+                           sm, sb, st, M, B, T, BL, Yt, reinterpret_cast<unsigned long long *>(Mw),
+                           partial, cnt);
+    const int64_t gb = (BL + RNT - 1) / RNT;
+    hipLaunchKernelGGL(lssmm_seqobs_kernel, dim3((unsigned)gb), dim3(RNT), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long *>(Mw), B, T, BL, seqobs, cnt + M);
+    hipLaunchKernelGGL(lssmm_setup_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial, (int)g,
+                       cnt, M, state + L.off_setup);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const uint64_t *Mw,
+                           const double *seqobs, int32_t M, int64_t B, int32_t T, int64_t BL,
+                           int32_t D, double *state, double *F, double *Z, double *P,
+                           void *workspace)
+{
+    VMP_REQUIRE(ctx, ctx && Yt && Mw && seqobs && state && F && Z && P && workspace, VMP_ERR_INVALID,
+                "null argument");
+    VMP_REQUIRE(ctx, M >= 1 && M <= LSSMM_MMAX && D >= 1 && D <= LSSMM_DMAX && B >= 0 && T >= 1
+                && BL >= B, VMP_ERR_INVALID, "bad dims");
+    vmp_lssmm_layout L;
+    lssmm_fill_layout(D, M, &L);
+    const lssmm_raw ro = lssmm_raw_offsets(D, M);
+    const lssmm_tab to = lssmm_tab_offsets(D, M);
+    const int NS = (int)L.NS;
+    double *partial = reinterpret_cast<double *>(workspace);
+    double *raw = state + L.off_raw;
+    sweep_args A;
+    A.S.Yt = Yt;
+    A.S.Mw = Mw;
+    A.S.F = F;
+    A.S.Z = Z;
+    A.S.P = P;
+    A.S.tab = state + L.off_tab;
+    A.S.M = M;
+    A.S.T = T;
+    A.S.BL = BL;
+    A.seqobs = seqobs;
+    A.B = B;
+    A.tab_len = to.len;
+    A.partial = partial;
+    A.status = state + L.off_scal;
+    A.given = given == 1 ? 1 : 0;
+    const int64_t g = nwg(B);
+    const size_t lds = (size_t)to.len * sizeof(double);
+    hipStream_t s = ctx->stream;
+    hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
+    const int CL = ro.chain_len - 1;
+    double *pld = partial + g * CL;               // log|Phi| partials behind the backward partials
+#define LSSMM_FOR_D(MACRO) \
+    switch (D) { case 1: MACRO(1) break; case 2: MACRO(2) break; case 3: MACRO(3) break; default: MACRO(4) break; }
+    // given == 2: q(X) is unchanged (Y re-observed: new data / mask) -- only the sums that involve the
+    // data and the mask are taken again from the stored <x>, <x x^T>; chain sums and log|Phi| stay
+    if (given != 2) {
+        if (g > 0 && !given) {
+            sweep_args Af = A;
+            Af.partial = pld;
+#define LSSMM_FWD(d) hipLaunchKernelGGL(lssmm_forward_kernel<d>, dim3((unsigned)g), dim3(WNT), lds, s, Af);
+            LSSMM_FOR_D(LSSMM_FWD)
+#undef LSSMM_FWD
+        }
+        if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
+        if (g > 0) {
+#define LSSMM_BWD(d) hipLaunchKernelGGL(lssmm_backward_kernel<d>, dim3((unsigned)g), dim3(WNT), lds, s, A);
+            LSSMM_FOR_D(LSSMM_BWD)
+#undef LSSMM_BWD
+        }
+        // chain sums, log|Phi|: fixed-order sums over the workgroups (an empty local plate: zeros)
+        hipLaunchKernelGGL(lssmm_sum_kernel, dim3((unsigned)((CL + 15) / 16)), dim3(RNT), 0, s, partial,
+                           (int)g, CL, CL, raw);
+        if (given || g == 0)
+            VMP_HIP_CHECK(ctx, hipMemsetAsync(raw + ro.ld, 0, sizeof(double), s));
+        else
+            hipLaunchKernelGGL(lssmm_sum_kernel, dim3(1), dim3(RNT), 0, s, pld, (int)g, 1, 1, raw + ro.ld);
+    } else if (ev) {
+        VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
+    }
+    const int ng = (M + MG - 1) / MG;
+    if (g > 0) {
+#define LSSMM_STATS(d) hipLaunchKernelGGL(lssmm_stats_kernel<d>, dim3((unsigned)g, (unsigned)ng), dim3(WNT), 0, s, A);
+        LSSMM_FOR_D(LSSMM_STATS)
+#undef LSSMM_STATS
+    }
+    const int slen = ng * MG * (NS + D);
+    hipLaunchKernelGGL(lssmm_sum_stats_kernel, dim3((unsigned)((slen + 15) / 16)), dim3(RNT), 0, s,
+                       partial, (int)g, ng, M, NS, D, raw + ro.XX, raw + ro.Syx);
+    if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssmm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, const double *priors,
+                            int32_t nu_latent, int32_t nops, const int32_t *ops, double *state)
+{
+    VMP_REQUIRE(ctx, ctx && priors && ops && state, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, D >= 1 && D <= LSSMM_DMAX && M >= 1 && M <= LSSMM_MMAX && T >= 1 && nops >= 1
+                && nops <= 12, VMP_ERR_INVALID, "bad dims");
+    lssmm_small_args A;
+    lssmm_fill_layout(D, M, &A.L);
+    A.D = D;
+    A.M = M;
+    A.T = T;
+    A.nops = nops;
+    for (int i = 0; i < nops; ++i) A.ops[i] = ops[i];
+    for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
+    A.nu_latent = nu_latent;
+    hipLaunchKernelGGL(lssmm_small_kernel, dim3(1), dim3(64), (size_t)A.L.total * sizeof(double),
+                       ctx->stream, A, state);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+}  // extern "C"

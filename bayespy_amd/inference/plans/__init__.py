@@ -7,8 +7,9 @@ from .pca import PCAPlan
 from .masked_pca import MaskedPCAPlan
 from .gmm import GMMPlan
 from .lssm import LSSMPlan
+from .lssm_masked import MaskedLSSMPlan
 
-PLAN_TYPES = [PCAPlan, MaskedPCAPlan, GMMPlan, LSSMPlan]
+PLAN_TYPES = [PCAPlan, MaskedPCAPlan, GMMPlan, LSSMPlan, MaskedLSSMPlan]
 
 
 def _reusable_plans(nodes, engine, options=None):

@@ -111,6 +111,14 @@ class LSSMKernels:
 
 class LSSMPlan:
 
+    _label = 'fused state-space block'
+
+    @staticmethod
+    def _accepts_mask(Y):
+        """This block takes the model when Y is fully observed (the masked block reports the
+        near misses of models with array masks)."""
+        return Y._mask is True
+
     @staticmethod
     def describe():
         return ("GaussianARD(SumMultiply('i,i', C, GaussianMarkovChain(mu0, Lam0, A, nu)), tau) fully "
@@ -134,11 +142,17 @@ class LSSMPlan:
         return None
 
     @staticmethod
-    def match(nodes, why=None):
+    def _limits():
+        mx_d, mx_m = ctypes.c_int32(), ctypes.c_int32()
+        _lib.load().vmp_lssm_limits(ctypes.byref(mx_d), ctypes.byref(mx_m))
+        return mx_d.value, mx_m.value
+
+    @classmethod
+    def match(cls, nodes, why=None):
         def no(Y, msg):
             if why is not None:
-                why.append('fused state-space block, observed node %s: %s'
-                           % (Y.name or '<unnamed>', msg))
+                why.append('%s, observed node %s: %s'
+                           % (cls._label, Y.name or '<unnamed>', msg))
         if any(any(m != 1 for m in n.plates_multiplier) for n in nodes):
             return None
         for Y in nodes:
@@ -193,14 +207,14 @@ class LSSMPlan:
                 continue
             if tuple(Y.plates) != (M,) + Bp + (T,):
                 continue
-            mx_d, mx_m = ctypes.c_int32(), ctypes.c_int32()
             try:
-                _lib.load().vmp_lssm_limits(ctypes.byref(mx_d), ctypes.byref(mx_m))
+                mx_d, mx_m = cls._limits()
             except Exception:       # noqa: BLE001
                 continue
-            if D > mx_d.value or M > mx_m.value:
-                no(Y, 'D = %d states, M = %d observed dimensions exceed the limits of the block '
-                      '(D <= %d, M <= %d)' % (D, M, mx_d.value, mx_m.value))
+            if D > mx_d or M > mx_m:
+                if cls._accepts_mask(Y):
+                    no(Y, 'D = %d states, M = %d observed dimensions exceed the limits of the '
+                          'block (D <= %d, M <= %d)' % (D, M, mx_d, mx_m))
                 continue
             priv = [C, gamma, X, A, alpha, tau, F, G] + ([nu_node] if nu_node is not None else [])
             if any(len(n.children) != 1 for n in priv):
@@ -208,9 +222,10 @@ class LSSMPlan:
             roles = dict(Y=Y, F=F, G=G, C=C, gamma=gamma, X=X, A=A, alpha=alpha, tau=tau)
             if nu_node is not None:
                 roles['nu'] = nu_node
-            bad = LSSMPlan.unsupported_state(roles)
+            bad = cls.unsupported_state(roles)
             if bad is not None:
-                no(Y, bad)
+                if cls._accepts_mask(Y):
+                    no(Y, bad)
                 continue
             return roles
         return None
@@ -274,8 +289,15 @@ class LSSMPlan:
         self._version += 1
         self._pending = []
         if self.unsupported_state(self.roles) is not None:
-            from .generic import GenericPlan
-            GenericPlan(self.nodes())
+            # an array mask: the masked block when it covers the sizes; anything else: the
+            # generic device message-passing engine
+            from .lssm_masked import MaskedLSSMPlan
+            roles = MaskedLSSMPlan.match(self.nodes())
+            if roles is not None:
+                MaskedLSSMPlan(roles)
+            else:
+                from .generic import GenericPlan
+                GenericPlan(self.nodes())
 
     # -- device state -------------------------------------------------------------------------------------
     def _gamma_init(self, node, a0, b0, n):

@@ -388,6 +388,72 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
                            const double *priors, int32_t nu_latent, int32_t nops,
                            const int32_t *ops, double *state);
 
+/* ---- fused linear state-space model block, ARRAY masks ----------------- *
+ *
+ * The same model observed through ``Y.observe(y, mask=array)`` (bayespy/demos/lssm.py:132,
+ * :239-246: ``mask = random.mask(M, N, p=0.3); mask[:, 30:80] = False``), the mask
+ * broadcastable to (M, B, T).  A message is multiplied by the child's mask before the plate
+ * sum (node.py:570-655), so
+ *   - every sequence has its own block-tridiagonal precision: diagonal blocks
+ *     prior + <tau> sum_m mask_mbt <c_m c_m^T> (gaussian_markov_chain.py:542-627, dot.py:425-633),
+ *     hence its own D x D covariance recursion (linalg.block_banded_solve, utils/linalg.py:468-575),
+ *     run by ONE THREAD PER SEQUENCE in registers beside the mean recursion;
+ *   - every row of C has its own posterior (gaussian.py:649-706 with the per-row message
+ *     sum_bt mask_mbt <x_bt x_bt^T>);
+ *   - rows / sequences without any observation are ignored plates (node.py:486-526,
+ *     expfamily.py:470-480).
+ * Time-major arrays, b contiguous: Yt[t][m][b] (zero where masked), Mw[t][b] (uint64, bit m =
+ * mask_mbt), F[t][NS + D][b] (forward sweep: S_t^-1 packed lower triangle | z_t), Z[t][D][b] (<x>),
+ * P[t][NS][b] (<x x^T> packed), NS = D (D + 1) / 2.  D <= 4 states, M <= 64 observed dimensions.
+ * Details: bayespy_amd/csrc/vmp_lssmm.hip, vmp_lssmm_dev.h; formulas: oracle/lssm.py
+ * (MaskedLSSMOracle).  Ops: enum vmp_lssm_op (STATS is a no-op here). */
+typedef struct vmp_lssmm_layout {
+    int64_t NS;           /* D (D + 1) / 2                                                          */
+    int64_t off_tau;      /* 4: a, b, <tau>, <log tau>                                              */
+    int64_t off_gamma, off_alpha, off_nu;   /* 4*D each: a[D], b[D], mean[D], log-mean[D]           */
+    int64_t off_mu0, off_Lam0, off_ldLam0;  /* D, D*D, 1                                            */
+    int64_t off_Cm;       /* M*D  <c_m>                                                             */
+    int64_t off_CovC;     /* M*D*D  Cov(c_m) per row                                                */
+    int64_t off_ldC;      /* M  log|Cov(c_m)|                                                       */
+    int64_t off_SCC;      /* D*D  sum over the observed rows of <c_m c_m^T>                         */
+    int64_t off_Am, off_AA, off_ldA;        /* D*D, D*D*D, D                                        */
+    int64_t off_tab, len_tab;   /* tables of the forward sweep, written by XPREP:
+                                   base (3*NS: t = 0, inner, last) | E (D*D) | h0 (D) |
+                                   tau c_m (M*D) | tau <c_m c_m^T> packed (M*NS)                    */
+    int64_t off_setup, len_setup;  /* vmp_lssmm_prepare (summed over ranks): sum mask y^2 |
+                                   sequences with data | observations per row n_m (M)              */
+    int64_t off_raw, len_raw;   /* plate sums of an X pass (summed over ranks):
+                                   sum_t P (NS) | sum <x_t+1 x_t^T> (D*D) | P_0 (NS) | P_T-1 (NS) |
+                                   x_0 (D) | sum_b log|Phi_b| (1)   -- sequences with data only --
+                                   | XX_m = sum_bt mask P (M*NS) | Syx_m = sum_bt y x (M*D)         */
+    int64_t off_scal;     /* 8: [0] status [1] <tau> of the last XPREP                              */
+    int64_t off_L;        /* 16: L_Y, L_C, L_A, L_X, L_gamma, L_alpha, L_tau, L_nu, total           */
+    int64_t total;
+} vmp_lssmm_layout;
+
+int32_t vmp_lssmm_limits(int32_t *max_D, int32_t *max_M);
+int32_t vmp_lssmm_get_layout(int32_t D, int32_t M, vmp_lssmm_layout *out);
+int32_t vmp_lssmm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n);
+/* Set-up (the data are constant after observe): Y (M, B, T) row-major and the mask as bytes with
+ * ELEMENT strides (sm, sb, st; 0 = broadcast axis) -> Yt (zero where masked; values there are
+ * never read, NaN placeholders are fine), Mw, seqobs[b] = 1.0 if sequence b has any observation,
+ * state[off_setup ...]. */
+int32_t vmp_lssmm_prepare(vmp_ctx *ctx, const double *Y, const uint8_t *mask, int64_t sm,
+                          int64_t sb, int64_t st, int32_t M, int64_t B, int32_t T, int64_t BL,
+                          int32_t D, double *Yt, uint64_t *Mw, double *seqobs, double *state,
+                          void *workspace);
+/* X.update(): forward sweep (per-sequence covariance + mean recursions -> F), backward sweep
+ * (-> Z, P, chain sums), statistics pass (XX_m, Syx_m); the sums land in state[off_raw ...].
+ * given = 1: the sums of the <x> already in Z as point masses (initialize_from_value);
+ * given = 2: q(X) unchanged, only XX_m / Syx_m again from the stored Z, P (Y re-observed). */
+int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const uint64_t *Mw,
+                           const double *seqobs, int32_t M, int64_t B, int32_t T, int64_t BL,
+                           int32_t D, double *state, double *F, double *Z, double *P,
+                           void *workspace);
+/* Replicated-node updates / the bound: a list of vmp_lssm_op in one launch. */
+int32_t vmp_lssmm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, const double *priors,
+                            int32_t nu_latent, int32_t nops, const int32_t *ops, double *state);
+
 /* ---- fused full-covariance Gaussian-mixture block -------------------------- *
  *
  * Model block  Y = Mixture(z, Gaussian, mu, Lambda), z = Categorical(alpha),

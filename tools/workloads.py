@@ -721,3 +721,141 @@ def run_lssm(B=100_000, T=1000, M=8, D=4, steps=3, warmup=1, cpu_baseline=True,
                       'itself: ~3.6e2 s/iter extrapolated (BASELINE.md section 2)'
                       % (bs, n_it - 1, dtc, B)}
     return out
+
+
+def build_lssm_masked(B=10_000, T=1000, M=8, D=4, missing=0.3, seed=7):
+    """The state-space model of run_lssm observed through a per-sequence mask (30 % missing at
+    random plus a stretch of 50 steps without any data, as bayespy/demos/lssm.py:239-246 does on
+    its single chain); returns (VB, dict with the data / mask / initial values)."""
+    import numpy as np
+    import torch
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+    from bayespy_amd.inference import VB
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rs = np.random.RandomState(0)
+    a_true = torch.from_numpy(0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]).to(dev)
+    c_true = torch.from_numpy(rs.normal(size=(M, D))).to(dev)
+    x = torch.empty(B, T, D, device=dev, dtype=torch.float64)
+    x[:, 0] = torch.randn(B, D, generator=g, device=dev, dtype=torch.float64)
+    for t in range(1, T):
+        x[:, t] = x[:, t - 1] @ a_true.T + torch.randn(B, D, generator=g, device=dev,
+                                                       dtype=torch.float64)
+    y = torch.einsum('md,btd->mbt', c_true, x)
+    y += 0.3 * torch.randn(M, B, T, generator=g, device=dev, dtype=torch.float64)
+    mask = torch.rand(M, B, T, generator=g, device=dev) >= missing
+    lo = min(30, max(T - 2, 0))
+    mask[:, :, lo:min(lo + 50, T - 1)] = False
+    x0 = torch.randn(B, T, D, generator=g, device=dev, dtype=torch.float64)
+    del x
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    A.initialize_from_value(np.identity(D))
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T, plates=(B,),
+                            name='X')
+    X.initialize_from_value(x0)
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(D))
+    C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1), name='C')
+    c_init = rs.normal(size=(M, 1, 1, D))
+    C.initialize_from_value(c_init)
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = SumMultiply('i,i', C, X, name='F')
+    Y = GaussianARD(F, tau, name='Y')
+    Y.observe(y, mask=mask)
+    Q = VB(Y, F, C, gamma, X, A, alpha, tau)
+    Q.ignore_bound_checks = True
+    return Q, dict(y=y, mask=mask, x0=x0, c_init=c_init)
+
+
+def run_lssm_masked(B=10_000, T=1000, M=8, D=4, steps=50, warmup=2, cpu_baseline=True,
+                    cpu_sample_b=64):
+    """SURVEY.md 8(f).2 with array masks: B sequences x T steps, one mask per sequence."""
+    import numpy as np
+    import torch
+    Q, info = build_lssm_masked(B, T, M, D)
+    plan = Q.plans[0]
+    Q.update(repeat=warmup, verbose=False)
+    timed = type(plan).__name__ == 'MaskedLSSMPlan'
+    if timed:
+        plan.enable_timing(True)
+    dt, step_ms = timed_update(Q, steps)
+    dt /= steps
+    NS = D * (D + 1) // 2
+    # algorithmic traffic per iteration: read Y and the mask word once, write <x> and <x x^T> once
+    # (per-sequence second moments are part of the answer here: every sequence has its own)
+    byts = 8.0 * B * T * (M + 1 + D + NS)
+    kms = plan.kernel_times_ms() if timed else None
+    out = {
+        'metric': 'VB iterations/sec, masked LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D),
+        'value': 1.0 / dt, 'unit': 'VB iterations/s', 'n_gpus': 1, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': 1e3 * dt, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'linear state-space model observed through one mask per sequence '
+                               '(30 %% missing + a stretch without data), %d sequences x %d steps, '
+                               'observations %d-dim, states %d-dim' % (B, T, M, D),
+                   'engine': type(plan).__name__},
+        'elbo_first': float(Q.L[0]), 'elbo_last': float(Q.L[Q.iter - 1]), 'step_ms': step_ms,
+        'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
+        'roofline': {'bound': 'hbm', 'achieved': byts / dt / 1e9, 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': byts / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'alg_bytes_per_iteration': byts, 'kernel_ms': kms,
+                     'moved_bytes_per_iteration': 8.0 * B * T * (2 * M + 3 * NS + 3 * D + 2)},
+    }
+    prof, why = pmc_profile('masked LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D))
+    if prof is not None:
+        out['roofline']['traffic'] = pmc_iteration_traffic(prof, 'lssmm_')
+        out['roofline']['traffic_source'] = prof['path']
+    else:
+        out['roofline']['traffic_source'] = why
+    if cpu_baseline and timed:
+        # the FIRST bs sequences of the very data, mask and initial moments: oracle (timed) and the
+        # HIP path re-run on that sample
+        from oracle.lssm import MaskedLSSMOracle
+        from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+        from bayespy_amd.inference import VB
+        bs = min(cpu_sample_b, B)
+        ys = info['y'][:, :bs].contiguous()
+        ms = info['mask'][:, :bs].contiguous()
+        xs = info['x0'][:bs].contiguous()
+        c_init = info['c_init']
+        del Q, plan, info
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        n_it = 3
+        o = MaskedLSSMOracle(ys.cpu().numpy(), ms.cpu().numpy(), xs.cpu().numpy(),
+                             c_init.reshape(M, D))
+        o.iterate(1)
+        t0 = time.perf_counter()
+        o.iterate(n_it - 1)
+        dtc = (time.perf_counter() - t0) / (n_it - 1)
+        alpha = Gamma(1e-5, 1e-5, plates=(D,))
+        A = GaussianARD(0, alpha, shape=(D,), plates=(D,))
+        A.initialize_from_value(np.identity(D))
+        X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, np.ones(D), n=T,
+                                plates=(bs,))
+        X.initialize_from_value(xs)
+        gamma = Gamma(1e-5, 1e-5, plates=(D,))
+        gamma.initialize_from_value(1e-2 * np.ones(D))
+        C = GaussianARD(0, gamma, shape=(D,), plates=(M, 1, 1))
+        C.initialize_from_value(c_init)
+        tau = Gamma(1e-5, 1e-5)
+        tau.initialize_from_value(1e2)
+        Ys = GaussianARD(SumMultiply('i,i', C, X), tau)
+        Ys.observe(ys, mask=ms)
+        Qs = VB(Ys, C, gamma, X, A, alpha, tau)
+        Qs.ignore_bound_checks = True
+        Qs.update(repeat=n_it, verbose=False)
+        rel = max(abs(a - b) / abs(b) for a, b in zip(Qs.L[:n_it], o.L))
+        out['cpu_baseline'] = {
+            'value': 1.0 / (dtc * (B / float(bs))), 'unit': 'VB iterations/s', 'cores': 1,
+            'kind': 'port', 'elbo_rel_err_hip_vs_oracle': float(rel),
+            'elbo_iterations_compared': n_it,
+            'sample': 'oracle/lssm.py:MaskedLSSMOracle (NumPy fp64, batched over the sequences) on '
+                      'the first B=%d sequences of the same data / mask / initial moments, %d '
+                      'timed iterations at %.2f s/iter, extrapolated linearly to B=%d'
+                      % (bs, n_it - 1, dtc, B)}
+    return out
