@@ -183,24 +183,52 @@ VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int &bad)
 #pragma unroll
     for (int i = 0; i < D; ++i) z[i] = 0.0;
     double prod = 1.0, ld = 0.0;
+    // The operands of a step do not depend on the recursion: they are requested one chunk of MC
+    // observed dimensions (for M <= MC: one time step) ahead of their use, so that the HBM
+    // latency runs beside the arithmetic of the current step (a sequence's thread has the SIMD
+    // almost to itself: 1e4 sequences are 157 wavefronts for 1024 SIMDs).
+    constexpr int MC = 8;
+    const int nch = (M + MC - 1) / MC;
+    double yn[MC];
+    uint64_t wn = A.Mw[b];
+#pragma unroll
+    for (int g = 0; g < MC; ++g) yn[g] = (g < M) ? A.Yt[(int64_t)g * BL + b] : 0.0;
     for (int t = 0; t < T; ++t) {
-        const uint64_t w = A.Mw[(int64_t)t * BL + b];
+        const uint64_t w = wn;
+        if (t + 1 < T) wn = A.Mw[(int64_t)(t + 1) * BL + b];
         const double *bs = tab + to.base + (t == 0 ? 0 : (t < T - 1 ? NS : 2 * NS));
         double S[NS], h[D];
 #pragma unroll
         for (int s = 0; s < NS; ++s) S[s] = bs[s];
 #pragma unroll
         for (int i = 0; i < D; ++i) h[i] = (t == 0) ? tab[to.h0 + i] : 0.0;
-        const double *yp = A.Yt + (int64_t)t * M * BL + b;
-        for (int m = 0; m < M; ++m) {
-            const double y = yp[(int64_t)m * BL];
-            const double *c = tab + to.C + m * D;
+        for (int c = 0; c < nch; ++c) {
+            double y[MC];
 #pragma unroll
-            for (int i = 0; i < D; ++i) h[i] += y * c[i];
-            if ((w >> m) & 1) {
-                const double *cc = tab + to.CC + m * NS;
+            for (int g = 0; g < MC; ++g) y[g] = yn[g];
+            int tn = t, cn = c + 1;
+            if (cn == nch) {
+                tn = t + 1;
+                cn = 0;
+            }
+            if (tn < T) {
+                const double *yp = A.Yt + ((int64_t)tn * M + cn * MC) * BL + b;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) S[s] += cc[s];
+                for (int g = 0; g < MC; ++g) yn[g] = (cn * MC + g < M) ? yp[(int64_t)g * BL] : 0.0;
+            }
+#pragma unroll
+            for (int g = 0; g < MC; ++g) {
+                const int m = c * MC + g;
+                if (m < M) {
+                    const double *cm = tab + to.C + m * D;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) h[i] += y[g] * cm[i];
+                    if ((w >> m) & 1) {
+                        const double *cc = tab + to.CC + m * NS;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) S[s] += cc[s];
+                    }
+                }
             }
         }
         if (t > 0) {
@@ -282,6 +310,10 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int given, do
     for (int s = 0; s < NS; ++s) Pc[s] = 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = 0.0;
+    double fn[NS + D];
+#pragma unroll
+    for (int s = 0; s < NS + D; ++s)
+        fn[s] = given ? 0.0 : A.F[((int64_t)(T - 1) * (NS + D) + s) * BL + b];
     for (int t = T - 1; t >= 0; --t) {
         double V[NS];
         double *zp = A.Z + (int64_t)t * D * BL + b;
@@ -297,12 +329,17 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int given, do
                     for (int j = 0; j < D; ++j) Snp[i][j] += xn[i] * x[j];
             }
         } else {
-            const double *fp = A.F + (int64_t)t * (NS + D) * BL + b;
             double Sinv[NS], z[D];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) Sinv[s] = fp[(int64_t)s * BL];
+            for (int s = 0; s < NS; ++s) Sinv[s] = fn[s];
 #pragma unroll
-            for (int i = 0; i < D; ++i) z[i] = fp[(int64_t)(NS + i) * BL];
+            for (int i = 0; i < D; ++i) z[i] = fn[NS + i];
+            if (t > 0) {
+                // the forward quantities of the step before: requested now, used next round
+                const double *fp = A.F + (int64_t)(t - 1) * (NS + D) * BL + b;
+#pragma unroll
+                for (int s = 0; s < NS + D; ++s) fn[s] = fp[(int64_t)s * BL];
+            }
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 double s = 0.0;
@@ -414,24 +451,43 @@ VMP_HD void lssmm_stats_seq(const lssmm_seq_args &A, int64_t b, int m0, double *
 #pragma unroll
         for (int i = 0; i < D; ++i) yx[g][i] = 0.0;
     }
+    double pn[NS], xn[D], yn[MG];
+    uint64_t wn = A.Mw[b];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) pn[s] = A.P[(int64_t)s * BL + b];
+#pragma unroll
+    for (int i = 0; i < D; ++i) xn[i] = A.Z[(int64_t)i * BL + b];
+#pragma unroll
+    for (int g = 0; g < MG; ++g) yn[g] = (m0 + g < M) ? A.Yt[(int64_t)(m0 + g) * BL + b] : 0.0;
     for (int t = 0; t < T; ++t) {
-        const uint64_t w = A.Mw[(int64_t)t * BL + b] >> m0;
-        const double *pp = A.P + (int64_t)t * NS * BL + b;
-        const double *zp = A.Z + (int64_t)t * D * BL + b;
-        double p[NS], x[D];
+        const uint64_t w = wn >> m0;
+        double p[NS], x[D], y[MG];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) p[s] = pp[(int64_t)s * BL];
+        for (int s = 0; s < NS; ++s) p[s] = pn[s];
 #pragma unroll
-        for (int i = 0; i < D; ++i) x[i] = zp[(int64_t)i * BL];
+        for (int i = 0; i < D; ++i) x[i] = xn[i];
+#pragma unroll
+        for (int g = 0; g < MG; ++g) y[g] = yn[g];
+        if (t + 1 < T) {
+            wn = A.Mw[(int64_t)(t + 1) * BL + b];
+            const double *pp = A.P + (int64_t)(t + 1) * NS * BL + b;
+            const double *zp = A.Z + (int64_t)(t + 1) * D * BL + b;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pn[s] = pp[(int64_t)s * BL];
+#pragma unroll
+            for (int i = 0; i < D; ++i) xn[i] = zp[(int64_t)i * BL];
+#pragma unroll
+            for (int g = 0; g < MG; ++g)
+                yn[g] = (m0 + g < M) ? A.Yt[((int64_t)(t + 1) * M + m0 + g) * BL + b] : 0.0;
+        }
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
             if (m0 + g < M) {
-                const double y = A.Yt[((int64_t)t * M + m0 + g) * BL + b];
                 const double bit = ((w >> g) & 1) ? 1.0 : 0.0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) xx[g][s] += bit * p[s];
 #pragma unroll
-                for (int i = 0; i < D; ++i) yx[g][i] += y * x[i];
+                for (int i = 0; i < D; ++i) yx[g][i] += y[g] * x[i];
             }
         }
     }

@@ -65,9 +65,9 @@ def test_fused_block_vs_oracle(M, B, T, D, nu):
     for nm in ('Y', 'X', 'A', 'C', 'tau', 'alpha', 'gamma') + (('nu',) if nu else ()):
         np.testing.assert_allclose(Q.l[Q[nm]][:3], [t[nm] for t in o.L_terms], rtol=1e-8, atol=1e-6,
                                    err_msg=nm)
-    np.testing.assert_allclose(track['X'].u[0], o.X, rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(track['X'].u[1], o.P, rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(track['C'].u[0].reshape(M, D), o.Cm, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(track['X'].u[0], o.X, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(track['X'].u[1], o.P, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(track['C'].u[0].reshape(M, D), o.Cm, rtol=1e-8, atol=1e-9)
 
 
 def test_device_kernels_equal_their_host_build():
