@@ -186,6 +186,7 @@ def run_extra(name, fn, budget_s, **kw):
     reported, never fatal to the headline line."""
     import torch
     t = time.time()
+    torch.cuda.reset_peak_memory_stats()        # peak_mem_GB of a leg is that leg's own
     try:
         out = fn(**kw)
     except Exception as e:       # noqa: BLE001
