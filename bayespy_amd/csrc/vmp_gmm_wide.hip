@@ -263,12 +263,15 @@ int32_t launch_wide(vmp_ctx *ctx, int64_t g, const double *Y, int64_t N, int D, 
     const size_t lds = (256 + 2 * WNW * 16 + (size_t)(KS1 + FT2) * 32
                         + (size_t)WNW * (TNC * WYS + 16 * RS)) * sizeof(double);
     auto kern = gmm_wide_kernel<KT, FT2>;
-    static bool attr = false;
-    if (!attr) {
+    // function attributes are per device: one flag per device of this process (a context on a
+    // second GPU must set it again); the worst a race between two host threads does is set it twice
+    static unsigned long long attr_devs = 0;
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_devs & bit)) {
         VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024));
-        attr = true;
+        attr_devs |= bit;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64 * WNW), lds, ctx->stream, Y, N, D, K, Cfrag,
                        labels, R, P, ntiles);

@@ -1317,6 +1317,11 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
         const int MP = (M + SYXM - 1) / SYXM * SYXM;
         hipStream_t sw = ctx->stream;
         hipLaunchKernelGGL(lssm_identity_kernel, dim3(1), dim3(64), 0, sw, D, ident, one);
+        if (given) {
+            // the inner statistics pass still reads its "observations" for the y <x>^T sums it
+            // computes and discards: give it defined values, not whatever the workspace held
+            VMP_HIP_CHECK(ctx, hipMemsetAsync(H, 0, (size_t)T * D * ck_bl_max(B) * sizeof(double), sw));
+        }
         if (!given && gw > 0) {
             int64_t gp = ((int64_t)T * B + SNT - 1) / SNT;
             if (gp > (int64_t)ctx->num_cu * 16) gp = (int64_t)ctx->num_cu * 16;

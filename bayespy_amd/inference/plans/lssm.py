@@ -600,6 +600,7 @@ class LSSMPlan:
         _delta.save(put, base, self._delta)
         put(base + 'kind', np.array([ord(c) for c in 'lssm'], dtype=np.uint8))
         put(base + 'dims', np.array([self.D, self.M, self.B, self.T], dtype=np.int64))
+        put(base + 'state_len', np.array([int(self.layout.total)], dtype=np.int64))
         put(base + 'state', self.state.cpu().numpy())
         put(base + 'X', self.x_means())
         put(base + 'Sinv', self.Sinv.cpu().numpy())
@@ -619,7 +620,14 @@ class LSSMPlan:
             raise ValueError('checkpoint is for (D, M, B, T) = %s, the model has %s'
                              % (dims, (self.D, self.M, self.B, self.T)))
         torch = self.rt.torch
-        self.state.copy_(torch.from_numpy(np.array(reader.get(base + 'state'), dtype=np.float64)))
+        st = np.array(reader.get(base + 'state'), dtype=np.float64)
+        if st.size != int(self.layout.total):
+            # the packed state layout is part of the library build (vmp_lssm_get_layout)
+            raise ValueError('incompatible checkpoint: the packed state of the fused state-space '
+                             'block has %d doubles in the file, %d in this build of the library '
+                             '(written by another version; re-run from the node moments)'
+                             % (st.size, int(self.layout.total)))
+        self.state.copy_(torch.from_numpy(st))
         xd = torch.from_numpy(np.array(reader.get(base + 'X'), dtype=np.float64)).to(self.rt.device)
         self.kernels.x_layout(xd.contiguous(), self.D, self.B, self.T, self.BL, self.Z, True)
         self.Sinv.copy_(torch.from_numpy(np.array(reader.get(base + 'Sinv'), dtype=np.float64)))

@@ -718,9 +718,14 @@ class PCAPlan:
         else:
             self.Xd = x_cur
         self.Yt = ys[best[1]]
+        peak = torch.cuda.max_memory_allocated(rt.device)
         del xs, ys, spacers
+        # the losers go back to the DRIVER, not only to torch's cache: allocations outside the
+        # caching allocator (the library's own, RCCL buffers, another process) must see the memory
+        torch.cuda.empty_cache()
         x_ms, y_ms = grid[0], [row[best[2]] for row in grid]
-        self.placement = {'x_ms': x_ms, 'yt_ms': y_ms, 'grid_ms': grid, 'kept': [best[1], best[2]]}
+        self.placement = {'x_ms': x_ms, 'yt_ms': y_ms, 'grid_ms': grid, 'kept': [best[1], best[2]],
+                          'transient_peak_bytes': int(peak)}
 
     def _flush(self):
         """Issue the queued replicated-node updates.  They are queued rather than launched
