@@ -29,7 +29,8 @@ from ... import darray as da
 from ...darray import DArray, fuse
 from ...nodes.node import Constant, Stochastic
 from ...nodes.gamma import Gamma
-from ...nodes.gaussian import GaussianARD, Gaussian
+from ...nodes.gaussian import (GaussianARD, Gaussian, GaussianGamma, GaussianToGaussianGamma,
+                               WrapToGaussianGamma, is_gaussian_gamma)
 from ...nodes.dot import SumMultiply
 from ...nodes.wishart import Wishart
 from ...nodes.dirichlet import Dirichlet
@@ -217,6 +218,14 @@ class GaussianARDFamily(Family):
         self.shape = node.shape
         self.ndim = node.ndim
         mu = node.parents[0]
+        # a Gaussian-gamma mean parent (a GaussianGamma node, or the explicit converter /
+        # wrapper nodes): its own precision scale tau multiplies this node's alpha
+        # (WrapToGaussianGamma, gaussian.py:2299-2371); scalar-valued like in the reference
+        # (parent_moments = GaussianGammaMoments(()), gaussian.py:1646)
+        self.mu_gg = is_gaussian_gamma(mu)
+        if self.mu_gg and (len(mu.dims[0]) != 0 or self.ndim != 0):
+            raise NotImplementedError('a Gaussian-gamma mean parent must be scalar-valued (ndim=0) '
+                                      'under a scalar-valued GaussianARD')
         # a Gaussian mean parent with k variable axes: they are the LAST k axes of this node's
         # (plates + shape) grid; with k > ndim (e.g. the reference's default ndim = 0 under a
         # vector-valued mean, gaussian.py:1617-1640) the leading k - ndim of them are plates here
@@ -256,6 +265,10 @@ class GaussianARDFamily(Family):
         return m, mm
 
     def phi_from_parents(self, up):
+        if self.mu_gg:
+            tm, _, t, _ = up[0]
+            a = up[1][0]
+            return [fuse(lambda a_, m_: a_ * m_, a, tm), fuse(lambda a_, t_: -0.5 * a_ * t_, a, t)]
         m, _ = self._mu(up)
         a = up[1][0]
         if self.ndim == 0:
@@ -298,6 +311,10 @@ class GaussianARDFamily(Family):
         return _gaussian_gradient(rg, u, self.ndim, self.shape)
 
     def cgf_from_parents(self, up):
+        if self.mu_gg:
+            _, tmm, _, lt = up[0]
+            a, loga = up[1]
+            return fuse(lambda a_, q, la, lt_: -0.5 * a_ * q + 0.5 * (la + lt_), a, tmm, loga, lt)
         m, m2 = self._mu(up)
         a, loga = up[1]
         if self.ndim == 0:
@@ -317,6 +334,15 @@ class GaussianARDFamily(Family):
     def message_to_parent(self, index, u, up):
         x = u[0]
         a = up[1][0]
+        if self.mu_gg:
+            # [x, -1/2, -1/2 x^2, 1/2] (gaussian.py:609-632) through the wrapper (:2348-2369)
+            if index == 0:
+                return [fuse(lambda a_, x_: a_ * x_, a, x), fuse(lambda a_: -0.5 * a_, a),
+                        fuse(lambda a_, q: -0.5 * a_ * q, a, u[1]), 0.5]
+            tm, tmm, t, _ = up[0]
+            m0 = fuse(lambda x_, tm_, q, x2_, t_: x_ * tm_ - 0.5 * q - 0.5 * x2_ * t_,
+                      x, tm, tmm, u[1], t)
+            return [m0, 0.5]
         if index == 0:
             m0 = fuse(lambda a_, x_: a_ * x_, a, x)
             if self.mu_ndim > 0:
@@ -373,6 +399,171 @@ class GaussianFamily(Family):
         xm = linalg.outer(x, m)
         mx = linalg.outer(m, x)
         return [fuse(lambda a, b, c, d: -0.5 * (a - b - c + d), xx, xm, mx, mm), 0.5]
+
+
+class GaussianGammaFamily(Family):
+    """GaussianGammaDistribution (gaussian.py:892-1136) with the (mu, Lambda) wrapper
+    (WrapToGaussianWishart, gaussian.py:2374-2527) folded in: parents mu, Lambda, a, b;
+    moments u = [<tau x>, <tau x x^T>, <tau>, <log tau>]; phi = [Lambda mu, -Lambda / 2,
+    -mu^T Lambda mu / 2 - b, a]."""
+
+    def __init__(self, node):
+        super().__init__(node)
+        self.ndim = node.ndim
+        self.shape = node.shape
+        self.D = int(np.prod(node.shape)) if node.ndim else 1
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        if index == 0:
+            return [v, linalg.outer(v, v)] if self.ndim else [v, fuse(lambda m: m * m, v)]
+        if index == 1:
+            if self.ndim:
+                return [v, linalg.chol_logdet(linalg.chol(v))]
+            return [v, fuse(lambda l: da.log(l), v)]
+        if index == 2:
+            return [v, fuse(lambda a: da.gammaln(a), v)]          # GammaPriorMoments, gamma.py:33-58
+        return [v, fuse(lambda b: da.log(b), v)]
+
+    def phi_from_parents(self, up):
+        (m, mm), (L, _), (a, _), (b, _) = up[0][:2], up[1][:2], up[2], up[3]
+        if self.ndim:
+            return [linalg.mvdot(L, m), fuse(lambda l: -0.5 * l, L),
+                    fuse(lambda t, b_: -0.5 * t - b_, misc.sum_multiply(L, mm, axis=(-1, -2)), b),
+                    fuse(lambda a_: 1.0 * a_, a)]
+        return [fuse(lambda l, m_: l * m_, L, m), fuse(lambda l: -0.5 * l, L),
+                fuse(lambda l, q, b_: -0.5 * l * q - b_, L, mm, b), fuse(lambda a_: 1.0 * a_, a)]
+
+    def moments_and_cgf(self, phi):
+        p0, p1, p2, a = (_arr(p) for p in phi)
+        if self.ndim == 0:
+            mu = fuse(lambda p0_, p1_: -p0_ / (2 * p1_), p0, p1)
+            b = fuse(lambda p2_, mu_, p0_: -p2_ - 0.5 * mu_ * p0_, p2, mu, p0)
+            u2 = fuse(lambda a_, b_: a_ / b_, a, b)
+            u3 = fuse(lambda a_, b_: da.digamma(a_) - da.log(b_), a, b)
+            u0 = fuse(lambda mu_, t: mu_ * t, mu, u2)
+            u1 = fuse(lambda p1_, mu_, t: -1.0 / (2 * p1_) + mu_ * mu_ * t, p1, mu, u2)
+            g = fuse(lambda p1_, a_, b_: 0.5 * da.log(-2 * p1_) + a_ * da.log(b_) - da.gammaln(a_),
+                     p1, a, b)
+            return [u0, u1, u2, u3], g
+        D = self.D
+        U = linalg.chol(fuse(lambda p: -2 * p, p1))
+        cov = linalg.chol_inv(U)
+        mu = linalg.chol_solve(U, p0)
+        b = fuse(lambda p2_, s: -p2_ - 0.5 * s, p2, linalg.inner(mu, p0))
+        u2 = fuse(lambda a_, b_: a_ / b_, a, b)
+        u3 = fuse(lambda a_, b_: da.digamma(a_) - da.log(b_), a, b)
+        u0 = fuse(lambda mu_, t: mu_ * t, mu, _trail(u2, 1))
+        u1 = fuse(lambda c, x, y, t: c + x * y * t, cov, _trail(mu, 1),
+                  mu.reshape(mu.shape[:-1] + (1, D)), _trail(u2, 2))
+        g = fuse(lambda ld, a_, b_: 0.5 * ld + a_ * da.log(b_) - da.gammaln(a_),
+                 linalg.chol_logdet(U), a, b)
+        return [u0, u1, u2, u3], g
+
+    def cgf_from_parents(self, up):
+        ld = up[1][1]
+        a, gla = up[2]
+        logb = up[3][1]
+        return fuse(lambda ld_, a_, lb, g_: 0.5 * ld_ + a_ * lb - g_, ld, a, logb, gla)
+
+    def fixed_moments_and_f(self, x):
+        raise NotImplementedError('fixed values of a GaussianGamma node')
+
+    def message_to_parent(self, index, u, up):
+        tx, txx, t, lt = u
+        (m, mm), L = up[0][:2], up[1][0]
+        if index == 0:
+            # [<tau x>, -<tau>/2, ...] to (mu, Lambda) (gaussian.py:957-972), then the part of mu
+            # (gaussian.py:2464-2477): [Lambda <tau x>, -<tau> Lambda / 2]
+            if self.ndim:
+                return [linalg.mvdot(L, tx), fuse(lambda l, t_: -0.5 * l * t_, L, _trail(t, 2))]
+            return [fuse(lambda l, x_: l * x_, L, tx), fuse(lambda l, t_: -0.5 * l * t_, L, t)]
+        if index == 1:
+            if self.ndim:
+                xm = linalg.outer(tx, m)
+                mx = linalg.outer(m, tx)
+                return [fuse(lambda a, b, c, d, t_: -0.5 * (a - b - c + d * t_), txx, xm, mx, mm,
+                             _trail(t, 2)), 0.5]
+            return [fuse(lambda a, x_, m_, d, t_: -0.5 * (a - 2 * x_ * m_ + d * t_), txx, tx, m, mm, t),
+                    0.5]
+        if index == 2:
+            raise NotImplementedError('message from GaussianGamma to its shape parameter')
+        return [fuse(lambda t_: -t_, t), up[2][0]]
+
+
+class GaussianToGaussianGammaFamily:
+    """gaussian.py:2226-2276: u = [<x>, <x x^T>, 1, 0]; the message keeps the Gaussian part."""
+    deterministic = True
+
+    def __init__(self, node):
+        self.node = node
+
+    def mask_to_parent(self, index, mask):
+        return mask
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        nd = self.node.ndim
+        return [v, linalg.outer(v, v, ndim=nd) if nd else fuse(lambda m: m * m, v)]
+
+    def moments(self, ups):
+        return [ups[0][0], ups[0][1], 1.0, 0.0]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        return list(m_child[:2])
+
+
+class WrapToGaussianGammaFamily:
+    """gaussian.py:2299-2371: the joint (X, alpha) parent as a node of its own."""
+    deterministic = True
+    plate_sum = True
+
+    def __init__(self, node):
+        self.node = node
+        self.ndim = node.ndim
+
+    def mask_to_parent(self, index, mask):
+        return mask
+
+    def plates_to_parent(self, index):
+        return self.node.plates
+
+    def constant_moments(self, index, value):
+        v = _arr(value)
+        if index == 1:
+            return [v, fuse(lambda a: da.log(a), v)]
+        raise NotImplementedError('constant Gaussian-gamma parent of WrapToGaussianGamma')
+
+    def moments(self, ups):
+        (tx, txx, t, lt), (a, la) = ups[0], ups[1]
+        nd = self.ndim
+        return [fuse(lambda x, a_: x * a_, _arr(tx), _trail(_arr(a), nd)),
+                fuse(lambda x, a_: x * a_, _arr(txx), _trail(_arr(a), 2 * nd)),
+                fuse(lambda t_, a_: t_ * a_, _arr(t), _arr(a)),
+                fuse(lambda l, la_: l + la_, _arr(lt), _arr(la))]
+
+    def message_to_parent(self, index, m_child, ups, mask=None):
+        nd = self.ndim
+        (tx, txx, t, lt), (a, la) = ups[0], ups[1]
+        mk = (lambda x, k: x) if mask is None else \
+            (lambda x, k: fuse(lambda v, w: v * w, _arr(x), _trail(mask, k)))
+        if index == 0:
+            out = []
+            for i, k in enumerate((nd, 2 * nd, 0)):
+                m = m_child[i]
+                out.append(None if m is None else
+                           mk(fuse(lambda v, a_: v * a_, _arr(m), _trail(_arr(a), k)), k))
+            m3 = m_child[3]
+            out.append(None if m3 is None else mk(m3, 0))
+            return out
+        m0 = None
+        for m, uu, k in ((m_child[0], tx, nd), (m_child[1], txx, 2 * nd), (m_child[2], t, 0)):
+            if m is None:
+                continue
+            term = _sum_last(fuse(lambda v, w: v * w, _arr(m), _arr(uu)), k)
+            m0 = term if m0 is None else fuse(lambda p, q: p + q, m0, term)
+        m3 = m_child[3]
+        return [None if m0 is None else mk(m0, 0), None if m3 is None else mk(m3, 0)]
 
 
 class WishartFamily(Family):
@@ -952,6 +1143,12 @@ def make_family(node):
         return MixtureFamily(node, make_family(node._proto))
     if isinstance(node, Gamma):
         return GammaFamily(node)
+    if isinstance(node, GaussianGamma):
+        return GaussianGammaFamily(node)
+    if isinstance(node, GaussianToGaussianGamma):
+        return GaussianToGaussianGammaFamily(node)
+    if isinstance(node, WrapToGaussianGamma):
+        return WrapToGaussianGammaFamily(node)
     if isinstance(node, GaussianARD):
         return GaussianARDFamily(node)
     if isinstance(node, Gaussian):

@@ -4,7 +4,8 @@ Node classes with the reference's construction API
 """
 from .node import Node, Constant, Stochastic
 from .gamma import Gamma, Exponential
-from .gaussian import GaussianARD, Gaussian
+from .gaussian import (GaussianARD, Gaussian, GaussianGamma, GaussianToGaussianGamma,
+                       WrapToGaussianGamma)
 from .dot import SumMultiply, Dot
 from .wishart import Wishart
 from .dirichlet import Dirichlet
@@ -20,7 +21,8 @@ from .gaussian_markov_chain import (GaussianMarkovChain, SwitchingGaussianMarkov
                                     VaryingGaussianMarkovChain)
 from .categorical_markov_chain import CategoricalMarkovChain
 
-__all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'SumMultiply',
+__all__ = ['Node', 'Constant', 'Stochastic', 'Gamma', 'GaussianARD', 'Gaussian', 'GaussianGamma',
+           'GaussianToGaussianGamma', 'WrapToGaussianGamma', 'SumMultiply',
            'Dot', 'Wishart', 'Dirichlet', 'Categorical', 'Multinomial', 'Mixture', 'MultiMixture',
            'GaussianMarkovChain', 'Exponential', 'Beta', 'Binomial', 'Bernoulli', 'Poisson', 'Add', 'ConcatGaussian',
            'Take', 'Concatenate', 'Gate', 'Choose', 'CategoricalMarkovChain',

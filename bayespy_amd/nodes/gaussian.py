@@ -8,7 +8,7 @@ and diagonal (ARD) prior precision ``alpha``; the posterior has a full
 (``WrapToGaussianGamma``, gaussian.py:2299-2371) is folded into the plan's
 kernels instead of being a separate deterministic node.
 """
-from .node import Stochastic
+from .node import Node, Stochastic
 from ..utils.shapes import broadcasted_shape
 
 
@@ -58,7 +58,14 @@ class GaussianARD(Stochastic):
 def _is_gaussian(node):
     from .dot import SumMultiply
     return isinstance(node, (GaussianARD, SumMultiply)) or type(node).__name__ in (
-        'Gaussian', 'MarkovChainToGaussian', 'Add', 'ConcatGaussian') or getattr(node, '_gaussian_like', False)
+        'Gaussian', 'MarkovChainToGaussian', 'Add', 'ConcatGaussian') or getattr(node, '_gaussian_like', False) \
+        or is_gaussian_gamma(node)
+
+
+def is_gaussian_gamma(node):
+    """The node's moments are Gaussian-gamma moments [<tau x>, <tau x x^T>, <tau>, <log tau>]
+    (GaussianGammaMoments, gaussian.py:161-229)."""
+    return getattr(node, '_gaussian_gamma', False)
 
 
 class Gaussian(Stochastic):
@@ -96,3 +103,107 @@ class Gaussian(Stochastic):
         self.plates = broadcasted_shape(given, mu_plates, Lplates)
         if plates is not None and self.plates != given:
             raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
+
+
+class GaussianGamma(Stochastic):
+    """``GaussianGamma(mu, Lambda, a, b, ndim=1)``: the JOINT node of a Gaussian variable and its
+    precision scale,  p(x | tau) = N(x | mu, (tau Lambda)^-1),  p(tau) = Gamma(a, b)  -- reference
+    gaussian.py:1777-1840 (node), :892-1136 (GaussianGammaDistribution), moments
+    u = [<tau x>, <tau x x^T>, <tau>, <log tau>] (GaussianGammaMoments, :161-229).  q(x, tau) keeps the
+    Gaussian-gamma form: the dependence between the mean and the precision that the factorised
+    GaussianARD + Gamma pair gives up.  ``mu``: array or Gaussian node, ``Lambda``: SPD array /
+    Wishart node (``ndim=1``) or positive array / Gamma node (``ndim=0``), ``a``: array, ``b``:
+    array or Gamma node.  A scalar-valued node (``ndim=0``) is a valid mean parent of
+    ``GaussianARD`` (gaussian.py:1621, :1646)."""
+    _parent_count = 4
+    _gaussian_gamma = True
+
+    def __init__(self, mu, Lambda, a, b, ndim=1, plates=None, name=None):
+        super().__init__(mu, Lambda, a, b, plates=(), dims=((), (), (), ()), name=name)
+        from .node import Constant
+        if ndim not in (0, 1):
+            raise NotImplementedError('GaussianGamma with ndim = %d' % ndim)
+        mu_n, L_n, a_n, b_n = self.parents
+        if is_gaussian_gamma(mu_n):
+            raise NotImplementedError('a Gaussian-gamma mean of a GaussianGamma node')
+        if not isinstance(a_n, Constant):
+            raise NotImplementedError('the shape parameter a of GaussianGamma must be an array')
+        if ndim == 0:
+            shape = ()
+            mu_plates = mu_n.value.shape if isinstance(mu_n, Constant) else mu_n.plates
+            if not isinstance(mu_n, Constant) and tuple(mu_n.dims[0]) != ():
+                raise ValueError('mu and Lambda have wrong shape')
+            L_plates = L_n.value.shape if isinstance(L_n, Constant) else L_n.plates
+            if not isinstance(L_n, Constant) and tuple(L_n.dims[0]) != ():
+                raise ValueError('mu and Lambda have wrong shape')
+        else:
+            if isinstance(L_n, Constant):
+                Ls = L_n.value.shape
+                if len(Ls) < 2 or Ls[-1] != Ls[-2]:
+                    raise ValueError('mu and Lambda have wrong shape')
+                D, L_plates = Ls[-1], Ls[:-2]
+            else:
+                if len(L_n.dims[0]) != 2:
+                    raise ValueError('mu and Lambda have wrong shape')
+                D, L_plates = L_n.dims[0][0], L_n.plates
+            if isinstance(mu_n, Constant):
+                ms = mu_n.value.shape
+                if len(ms) < 1 or ms[-1] != D:
+                    raise ValueError('mu and Lambda have wrong shape')
+                mu_plates = ms[:-1]
+            else:
+                if tuple(mu_n.dims[0]) != (D,):
+                    raise ValueError('mu and Lambda have wrong shape')
+                mu_plates = mu_n.plates
+            shape = (D,)
+        self.shape = tuple(shape)
+        self.ndim = ndim
+        self.dims = (self.shape, self.shape + self.shape, (), ())
+        given = tuple(plates) if plates is not None else ()
+        try:
+            self.plates = broadcasted_shape(given, tuple(mu_plates), tuple(L_plates),
+                                            a_n.plates, b_n.plates)
+        except ValueError:
+            raise ValueError('The plates of the parents do not broadcast')
+        if plates is not None and self.plates != given:
+            raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))
+
+
+class GaussianToGaussianGamma(Node):
+    """Gaussian moments seen as Gaussian-gamma moments with the precision scale fixed to 1:
+    u = [<x>, <x x^T>, 1, 0]; the message back keeps the Gaussian part (reference
+    gaussian.py:2226-2276).  The reference inserts this converter itself wherever a Gaussian node
+    is given for a Gaussian-gamma parent; here that case is folded into the families, and the
+    explicit node does the same thing one step at a time."""
+    _gaussian_gamma = True
+
+    def __init__(self, X, name=None):
+        from .node import GaussianConstant
+        if not (_is_gaussian(X) and not is_gaussian_gamma(X)) and not isinstance(X, GaussianConstant):
+            raise ValueError("Wrong moments, should be Gaussian")
+        shape = tuple(X.dims[0])
+        super().__init__(X, plates=X.plates, dims=(shape, shape + shape, (), ()),
+                         name=name or (X.name + '_as_gaussian_gamma'))
+        self.shape, self.ndim = shape, len(shape)
+
+
+class WrapToGaussianGamma(Node):
+    """The joint parent (X, alpha) of a Gaussian child whose precision is ``alpha`` times the
+    scale of X: u = [<tau x> <alpha>, <tau x x^T> <alpha>, <tau><alpha>, <log tau> + <log alpha>]
+    (reference gaussian.py:2299-2371).  ``X``: Gaussian-gamma moments (a Gaussian node is
+    converted first), ``alpha``: Gamma node or positive array.  The stochastic nodes fold this
+    wrapper into their formulas; the explicit node exists for graphs that name it."""
+    _gaussian_gamma = True
+
+    def __init__(self, X, alpha, ndim=None, name=None):
+        from .node import ensure_node
+        X = ensure_node(X)
+        if not is_gaussian_gamma(X):
+            X = GaussianToGaussianGamma(X)
+        if ndim is not None and ndim != len(X.dims[0]):
+            raise NotImplementedError("Conversion to different ndim in GaussianMoments not yet "
+                                      "implemented.")
+        shape = tuple(X.dims[0])
+        super().__init__(X, alpha, plates=(), dims=(shape, shape + shape, (), ()), name=name)
+        self.plates = broadcasted_shape(self.parents[0].plates, self.parents[1].plates)
+        self.shape, self.ndim = shape, len(shape)

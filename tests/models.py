@@ -1212,3 +1212,72 @@ def run_reobserve_lssm_case(nodes_mod, vb_cls, g, **vb_kwargs):
     Q.update(repeat=2, verbose=False)
     return dict(lssm_L=np.array(Q.L[:Q.iter]), lssm_L_mid=L_mid, lssm_L_c=L_c,
                 lssm_X_u0=np.array(X.u[0]), lssm_C_u0=np.array(C.u[0]), lssm_A_u0=np.array(A.u[0]))
+
+
+# ---------------------------------------------------------------------------------------------
+# Gaussian-gamma nodes (GaussianGammaMoments gaussian.py:161-229, the GaussianGamma
+# node :1777-1840 with GaussianGammaDistribution :892-1136, WrapToGaussianGamma :2299-2371).
+# Shared statement for statement by oracle/make_golden.py (live reference) and the device tests.
+# ---------------------------------------------------------------------------------------------
+def make_gaussian_gamma_inputs(rs):
+    G, N = 3, 40
+    return dict(gg_y=rs.normal(size=(G, N)) * np.array([[0.5], [1.0], [2.0]])
+                + np.array([[1.0], [-2.0], [4.0]]),
+                gg_mask=rs.rand(G, N) < 0.85,
+                gg_mu0=np.array([0.5, -0.5, 0.0]), gg_lam0=np.array([0.1, 0.2, 0.3]),
+                gg_a0=np.array([0.6, 0.7, 0.8]), gg_b0=np.array([0.9, 1.0, 1.1]),
+                gg_V=np.array([[2.0, 0.3, 0.0], [0.3, 1.0, 0.2], [0.0, 0.2, 1.5]]))
+
+
+def run_gaussian_gamma_cases(nodes_mod, vb_cls, g, **vb_kwargs):
+    N_ = nodes_mod
+    out = {}
+    G, N = g['gg_y'].shape
+
+    def record(tag, Q, nodes, n_iter):
+        Ls = []
+        for _ in range(n_iter):
+            Q.update(repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+        out[tag + '_L'] = np.array(Ls)
+        for nm, nd in nodes.items():
+            out['%s_%s_u' % (tag, nm)] = [np.array(v) for v in nd.get_moments()]
+            out['%s_%s_l' % (tag, nm)] = np.array(Q.l[nd][:Q.iter])
+
+    # (a) the conjugate normal-gamma model of a group's mean and precision, jointly:
+    #     y_gn ~ N(x_g, 1 / tau_g), (x_g, tau_g) ~ GaussianGamma: exact after one update
+    XT = N_.GaussianGamma(g['gg_mu0'][:, None], g['gg_lam0'][:, None], g['gg_a0'][:, None],
+                          g['gg_b0'][:, None], ndim=0, name='XT')
+    out['a_plates'], out['a_ndims'] = np.array(XT.plates), np.array([len(d) for d in XT.dims])
+    Y = N_.GaussianARD(XT, 1, name='Y')
+    out['a_Y_plates'] = np.array(Y.plates)
+    Y = N_.GaussianARD(XT, 1, plates=(G, N), name='Y')
+    Y.observe(g['gg_y'])
+    Q = vb_cls(Y, XT, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    record('a', Q, dict(XT=XT, Y=Y), 2)
+
+    # (b) latent parents of the joint node (Gaussian mean, Gamma rate), an extra Gamma scale on
+    #     the child, an array mask
+    m = N_.GaussianARD(0, 1e-2, plates=(G, 1), name='m')
+    b = N_.Gamma(1e-1, 1e-1, plates=(G, 1), name='b')
+    XT2 = N_.GaussianGamma(m, g['gg_lam0'][:, None], 1.5, b, ndim=0, name='XT2')
+    s = N_.Gamma(1e-2, 1e-2, plates=(1, N), name='s')
+    Y2 = N_.GaussianARD(XT2, s, name='Y2')
+    Y2.observe(g['gg_y'], mask=g['gg_mask'])
+    Q = vb_cls(Y2, XT2, s, m, b, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    record('b', Q, dict(XT2=XT2, s=s, m=m, b=b, Y2=Y2), 4)
+
+    # (c) vector-valued joint node under a Gaussian mean, a Wishart precision and a Gamma rate
+    #     (the reference's own construction test, nodes/tests/test_gaussian.py:966-972): moments
+    #     and bound term of the prior-initialised node and after an update without children
+    mu = N_.Gaussian(np.array([1.0, -1.0, 0.5]), g['gg_V'], name='mu')
+    Lam = N_.Wishart(5, g['gg_V'], name='Lam')
+    b3 = N_.Gamma(2.0, 3.0, name='b3')
+    XV = N_.GaussianGamma(mu, Lam, 2.5, b3, name='XV')
+    out['c_dims'] = np.array([len(d) for d in XV.dims])
+    Q = vb_cls(XV, mu, Lam, b3, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    record('c', Q, dict(XV=XV, mu=mu, b3=b3), 2)
+    return out

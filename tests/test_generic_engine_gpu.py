@@ -1021,3 +1021,57 @@ def test_numeric_parents_of_summultiply_match_reference(golden_dir):
     for k, v in res.items():
         tol = dict(rtol=ELBO_RTOL) if k.endswith('_L') else dict(rtol=MOM_RTOL, atol=1e-10)
         np.testing.assert_allclose(v, g[k], err_msg=k, **tol)
+
+
+def test_gaussian_gamma_nodes_match_reference(golden_dir):
+    """GaussianGammaMoments / the GaussianGamma joint node / WrapToGaussianGamma /
+    GaussianToGaussianGamma (gaussian.py:161-229, :892-1136, :1777-1840, :2226-2371).  Live-reference
+    traces of tests/models.py:run_gaussian_gamma_cases: (a) the conjugate normal-gamma model
+    GaussianARD(GaussianGamma(..., ndim=0), 1) -- exact after one update --, (b) the joint node under
+    a latent Gaussian mean and Gamma rate, with a Gamma scale on the child and an array mask, (c) a
+    vector-valued joint node under Gaussian / Wishart / Gamma parents."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_gaussian_gamma_cases
+    f = np.load(os.path.join(golden_dir, 'gaussian_gamma.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    res = run_gaussian_gamma_cases(N_, VB, g)
+    assert list(res['a_plates']) == [3, 1] and list(res['a_ndims']) == [0, 0, 0, 0]
+    assert list(res['c_dims']) == [1, 2, 0, 0]
+    _compare_shared(res, f)
+    assert abs(res['a_L'][1] - res['a_L'][0]) < 1e-9 * abs(res['a_L'][0])
+
+
+def test_explicit_gaussian_gamma_converter_and_wrapper_nodes():
+    """GaussianToGaussianGamma(X) (gaussian.py:2226-2276) and WrapToGaussianGamma(X, alpha)
+    (:2299-2371) as nodes of their own give what the folded forms give: GaussianARD(X, s) ==
+    GaussianARD(GaussianToGaussianGamma(X), s) == GaussianARD(WrapToGaussianGamma(X, s), 1)."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    rs = np.random.RandomState(3)
+    y = rs.normal(size=(4, 30)) + np.arange(4)[:, None]
+
+    def run(kind):
+        X = N_.GaussianARD(0, 1e-2, plates=(4, 1), name='X')
+        s = N_.Gamma(1e-2, 1e-2, plates=(1, 30), name='s')
+        if kind == 'folded':
+            Y = N_.GaussianARD(X, s, name='Y')
+        elif kind == 'converter':
+            Y = N_.GaussianARD(N_.GaussianToGaussianGamma(X), s, name='Y')
+        else:
+            Y = N_.GaussianARD(N_.WrapToGaussianGamma(X, s), 1, name='Y')
+        Y.observe(y)
+        Q = VB(Y, X, s, engine='generic')
+        Q.ignore_bound_checks = True
+        Q.update(repeat=4, verbose=False)
+        return np.array(Q.L[:4]), X.u, s.u
+    L0, xu, su = run('folded')
+    for kind in ('converter', 'wrapper'):
+        L1, xu1, su1 = run(kind)
+        np.testing.assert_allclose(L1, L0, rtol=1e-12, err_msg=kind)
+        np.testing.assert_allclose(xu1[0], xu[0], rtol=1e-11)
+        np.testing.assert_allclose(su1[0], su[0], rtol=1e-11)
+    G = N_.GaussianToGaussianGamma(N_.GaussianARD(0, 1, shape=(3,), plates=(2,)))
+    assert G.dims == ((3,), (3, 3), (), ()) and G.plates == (2,)
+    with pytest.raises(ValueError, match='should be Gaussian'):
+        N_.GaussianToGaussianGamma(N_.Gamma(1, 1))
