@@ -67,6 +67,69 @@ def _trail(x, n):
     return x.reshape(x.shape + (1,) * n)
 
 
+class FactoredMoment(DArray):
+    """Second moment of Gaussian factors whose posterior covariance is SHARED over plates:
+    <x x^T> = Cov + <x><x>^T kept as the pair (Cov, <x>) instead of a plates x K x K array.
+
+    The reference materialises the array (gaussian.py:672-706: ``u1 = outer(u0, u0) + Cov``; 2 GB
+    at N = 1e6, K = 16 and 82 GB at the headline size) and contracts it with einsum (dot.py:355,
+    :403, :581).  Here the consumers that matter read the factors -- ``SumMultiplyFamily`` expands
+    the product of (Cov + x x^T) terms, the Gamma message takes diag(Cov) + x^2, the bound takes
+    phi : Cov + x^T phi x -- and anything else sees an ordinary device array: ``.t`` forms the
+    dense array on first use (same values as the reference's)."""
+    __slots__ = ('cov', 'mean', 'nd', '_dense')
+
+    def __init__(self, cov, mean, nd):
+        self.cov, self.mean, self.nd = cov, mean, int(nd)
+        self._dense = None
+
+    @property
+    def t(self):
+        if self._dense is None:
+            o = linalg.outer(self.mean, self.mean, ndim=self.nd)
+            self._dense = fuse(lambda c, o_: c + o_, self.cov, o).t
+        return self._dense
+
+    @property
+    def shape(self):
+        nd = self.nd
+        mp = self.mean.shape[:self.mean.ndim - nd]
+        cp = self.cov.shape[:self.cov.ndim - 2 * nd]
+        return tuple(broadcasted_shape(mp, cp)) + tuple(self.cov.shape[self.cov.ndim - 2 * nd:])
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+
+def _factored_min_plates():
+    return int(os.environ.get('BAYESPY_AMD_FACTORED_MIN_PLATES', '1024'))
+
+
+def _diag2(xx, nd):
+    """diag over the last 2 nd axes of a second moment, factored or dense."""
+    if isinstance(xx, FactoredMoment) and xx._dense is None:
+        return fuse(lambda c, x: c + x * x, misc.get_diag(xx.cov, ndim=nd), xx.mean)
+    return misc.get_diag(xx, ndim=nd)
+
+
+def _inner_second(phi, xx, nd):
+    """sum over the last 2 nd axes of phi * <x x^T>."""
+    axes = tuple(range(-2 * nd, 0))
+    if isinstance(xx, FactoredMoment) and xx._dense is None:
+        x = xx.mean
+        a = misc.sum_multiply(_arr(phi), xx.cov, axis=axes)
+        b = misc.sum_multiply(_arr(phi), x.reshape(x.shape + (1,) * nd),
+                              x.reshape(x.shape[:x.ndim - nd] + (1,) * nd + x.shape[x.ndim - nd:]),
+                              axis=axes)
+        return fuse(lambda p, q: p + q, a, b)
+    return misc.sum_multiply(_arr(phi), _arr(xx), axis=axes)
+
+
 _CONSTS = {}
 
 
@@ -261,7 +324,7 @@ class GaussianARDFamily(Family):
         """(m, m2) elementwise over plates + shape."""
         m, mm = up[0]
         if self.mu_ndim > 0:
-            return m, misc.get_diag(mm, ndim=self.mu_ndim)
+            return m, _diag2(mm, self.mu_ndim)
         return m, mm
 
     def phi_from_parents(self, up):
@@ -297,9 +360,18 @@ class GaussianARDFamily(Family):
         U = linalg.chol(fuse(lambda p: -2 * p, p1f))
         cov = linalg.chol_inv(U)
         u0 = linalg.chol_solve(U, p0f)
-        u1 = fuse(lambda a, b, c: a * b + c, _trail(u0, 1), u0.reshape(u0.shape[:-1] + (1, D)), cov)
         g = fuse(lambda s, ld: -0.5 * s + 0.5 * ld, misc.sum_multiply(u0, p0f, axis=-1),
                  linalg.chol_logdet(U))
+        # one covariance for many plates (a scalar mask: the precision carries no plate axis where
+        # the mean does): keep <x x^T> as (Cov, <x>) -- see FactoredMoment
+        pl0, pl1 = u0.shape[:-1], cov.shape[:-2]
+        pl1 = (1,) * (len(pl0) - len(pl1)) + tuple(pl1)
+        shared = [a for a, b in zip(pl0, pl1) if b == 1 and a > 1]
+        if len(pl1) == len(pl0) and shared and int(np.prod(shared)) >= _factored_min_plates():
+            u0 = u0.reshape(u0.shape[:-1] + self.shape)
+            covs = cov.reshape(pl1 + self.shape + self.shape)
+            return [u0, FactoredMoment(covs, u0, self.ndim)], g
+        u1 = fuse(lambda a, b, c: a * b + c, _trail(u0, 1), u0.reshape(u0.shape[:-1] + (1, D)), cov)
         u0 = u0.reshape(u0.shape[:-1] + self.shape)
         u1 = u1.reshape(u1.shape[:-2] + self.shape + self.shape)
         return [u0, u1], g
@@ -350,7 +422,7 @@ class GaussianARDFamily(Family):
                 return [m0, misc.diag(d, ndim=self.mu_ndim)]
             return [m0, fuse(lambda a_: -0.5 * a_, a)]
         m, m2 = self._mu(up)
-        x2 = misc.get_diag(u[1], ndim=self.ndim) if self.ndim else u[1]
+        x2 = _diag2(u[1], self.ndim) if self.ndim else u[1]
         m0 = fuse(lambda x_, m_, q, x2_: x_ * m_ - 0.5 * q - 0.5 * x2_, x, m, m2, x2)
         return [m0, 0.5]
 
@@ -1055,22 +1127,103 @@ class SumMultiplyFamily:
             ks = ks + ['K%d' % k for k in n.in_keys[i]]
         return list(lead) + ks
 
+    @staticmethod
+    def _is_factored(xx):
+        return isinstance(xx, FactoredMoment) and xx._dense is None
+
+    def _second_choices(self, ups, skip=None):
+        """The second-moment operands of the parents as a list of alternatives per parent: a dense
+        <x x^T> is one alternative; a factored one (Cov + <x><x>^T) is two -- [Cov] and
+        [<x> over the first key copy, <x> over the second].  The product of the parents' second
+        moments is the sum over one pick per parent."""
+        per_parent = []
+        for j, u in enumerate(ups):
+            if j == skip:
+                continue
+            xx = u[1]
+            l0 = self._parent_labels(j, False)
+            l1 = self._parent_labels(j, True)
+            if self._is_factored(xx):
+                x, cov = xx.mean, xx.cov
+                nk = len(self.node.in_keys[j])
+                lK = l0[:len(l0) - nk] + ['K%d' % k for k in self.node.in_keys[j]]
+                per_parent.append([
+                    ('cov', [(cov, l1[len(l1) - cov.ndim:])]),
+                    ('mean', [(x, l0[len(l0) - x.ndim:]), (x, lK[len(lK) - x.ndim:])])])
+            else:
+                a = _arr(xx)
+                per_parent.append([('dense', [(a, l1[len(l1) - a.ndim:])])])
+        return per_parent
+
+    @staticmethod
+    def _picks(per_parent):
+        import itertools
+        for combo in itertools.product(*per_parent):
+            kinds = [c[0] for c in combo]
+            ops = [o for c in combo for o in c[1]]
+            yield kinds, ops
+
+    @staticmethod
+    def _add_terms(terms):
+        acc = terms[0]
+        i = 1
+        while i < len(terms):
+            rest = terms[i:i + 3]
+            if len(rest) == 3:
+                acc = fuse(lambda a, b, c, d: a + b + c + d, acc, *rest)
+            elif len(rest) == 2:
+                acc = fuse(lambda a, b, c: a + b + c, acc, *rest)
+            else:
+                acc = fuse(lambda a, b: a + b, acc, rest[0])
+            i += 3
+        return acc
+
     def moments(self, ups):
         n = self.node
         pl, sizes = self._labels(None)
-        ops0, labs0, ops1, labs1 = [], [], [], []
+        ops0, labs0 = [], []
         for i, u in enumerate(ups):
-            x, xx = _arr(u[0]), _arr(u[1])
+            x = _arr(u[0])
             l0 = self._parent_labels(i, False)
-            l1 = self._parent_labels(i, True)
             ops0.append(x)
             labs0.append(l0[len(l0) - x.ndim:])
-            ops1.append(xx)
-            labs1.append(l1[len(l1) - xx.ndim:])
         out0 = pl + ['k%d' % k for k in n.out_keys]
         out1 = out0 + ['K%d' % k for k in n.out_keys]
-        return [misc.contract(ops0, labs0, out0, sizes, compress=pl),
-                misc.contract(ops1, labs1, out1, sizes, compress=pl)]
+        f0 = misc.contract(ops0, labs0, out0, sizes, compress=pl)
+        per_parent = self._second_choices(ups)
+        if not any(len(alts) > 1 for alts in per_parent):
+            ops1 = [o[0] for alts in per_parent for o in alts[0][1]]
+            labs1 = [o[1] for alts in per_parent for o in alts[0][1]]
+            return [f0, misc.contract(ops1, labs1, out1, sizes, compress=pl)]
+        # factored parents: <f f^T> = sum over the picks; the all-means pick is <f><f>^T itself when
+        # every parent is factored (no plates x K x K array is ever formed, dot.py:355,403)
+        terms = []
+        nk = len(n.out_keys)
+        for kinds, ops in self._picks(per_parent):
+            if all(k == 'mean' for k in kinds):
+                terms.append(('sq', None))
+                continue
+            if len(ops) > 6:
+                raise NotImplementedError('SumMultiply over %d factored parents' % len(ups))
+            terms.append(('t', misc.contract([o[0] for o in ops], [o[1] for o in ops], out1, sizes,
+                                             compress=pl)))
+        arrs = [t[1] for t in terms if t[0] == 't']
+        if any(t[0] == 'sq' for t in terms):
+            if nk == 0:
+                sq = f0
+                if len(arrs) == 1:
+                    f1 = fuse(lambda f, a: f * f + a, sq, arrs[0])
+                elif len(arrs) == 2:
+                    f1 = fuse(lambda f, a, b: f * f + a + b, sq, *arrs)
+                elif len(arrs) == 3:
+                    f1 = fuse(lambda f, a, b, c: f * f + a + b + c, sq, *arrs)
+                else:
+                    f1 = self._add_terms([fuse(lambda f: f * f, sq)] + arrs)
+            else:
+                f1 = self._add_terms([linalg.outer(f0, f0, ndim=nk)] + arrs)
+        else:
+            f1 = self._add_terms(arrs)
+        return [f0, f1]
 
     def message_to_parent(self, index, m_child, ups, mask=None):
         """Messages to parent ``index`` already summed to its plates (dot.py:425-633)."""
@@ -1078,27 +1231,8 @@ class SumMultiplyFamily:
         pl, sizes = self._labels(None)
         par = n.parents[index]
         npl, nparpl = len(pl), len(par.plates)
-        out = []
-        for second in (False, True):
-            m = m_child[1 if second else 0]
-            if m is None:
-                out.append(None)
-                continue
-            m = _arr(m)
-            lm = pl + ['k%d' % k for k in n.out_keys]
-            if second:
-                lm = lm + ['K%d' % k for k in n.out_keys]
-            ops, labs = [m], [lm[len(lm) - m.ndim:]]
-            for j, u in enumerate(ups):
-                if j == index:
-                    continue
-                a = _arr(u[1 if second else 0])
-                lj = self._parent_labels(j, second)
-                ops.append(a)
-                labs.append(lj[len(lj) - a.ndim:])
-            if mask is not None:
-                ops.append(mask)
-                labs.append(pl[npl - mask.ndim:])
+
+        def one_term(ops, labs, second):
             present = set()
             for a, ls in zip(ops, labs):
                 for ax, lab in enumerate(ls):
@@ -1130,7 +1264,57 @@ class SumMultiplyFamily:
                 keys = keys + ['K%d' % k for k in n.in_keys[index]]
             res = misc.contract(ops, labs, lout + keys, sizes, scale=float(mult))
             final = tuple(final) + tuple(sizes[k] for k in keys)
-            out.append(res.reshape(final))
+            return res.reshape(final)
+
+        out = []
+        for second in (False, True):
+            m = m_child[1 if second else 0]
+            if m is None:
+                out.append(None)
+                continue
+            m = _arr(m)
+            lm = pl + ['k%d' % k for k in n.out_keys]
+            if second:
+                lm = lm + ['K%d' % k for k in n.out_keys]
+            base_ops, base_labs = [m], [lm[len(lm) - m.ndim:]]
+            if mask is not None:
+                base_ops.append(mask)
+                base_labs.append(pl[npl - mask.ndim:])
+            if not second:
+                ops, labs = list(base_ops), list(base_labs)
+                for j, u in enumerate(ups):
+                    if j == index:
+                        continue
+                    a = _arr(u[0])
+                    lj = self._parent_labels(j, False)
+                    ops.append(a)
+                    labs.append(lj[len(lj) - a.ndim:])
+                out.append(one_term(ops, labs, False))
+                continue
+            # second moments of the other parents: dense, or factored (Cov + <x><x>^T) and then
+            # expanded term by term -- e.g. the message to W of a PCA model,
+            # m (N Cov_X + sum_n <x_n><x_n>^T), without the (N, K, K) array
+            per_parent = self._second_choices(ups, skip=index)
+            terms = []
+            for kinds, extra in self._picks(per_parent):
+                if len(base_ops) + len(extra) > 6:
+                    # more operands than one launch takes: fall back to the dense arrays
+                    terms = None
+                    break
+                terms.append(one_term(base_ops + [o[0] for o in extra],
+                                      base_labs + [o[1] for o in extra], True))
+            if terms is None:
+                ops, labs = list(base_ops), list(base_labs)
+                for j, u in enumerate(ups):
+                    if j == index:
+                        continue
+                    a = DArray(_arr(u[1]).t)
+                    lj = self._parent_labels(j, True)
+                    ops.append(a)
+                    labs.append(lj[len(lj) - a.ndim:])
+                out.append(one_term(ops, labs, True))
+            else:
+                out.append(self._add_terms(terms) if len(terms) > 1 else terms[0])
         return out
 
 
@@ -1659,6 +1843,9 @@ class GenericPlan:
         for i, nd in enumerate(len(d) for d in node.dims):
             if closed is not None and nd > 0:
                 # finite Gaussian prior parameters: phi_p . u as one contraction, no temporary
+                if i == 1 and isinstance(st.u[i], FactoredMoment):
+                    L = fuse(lambda a, b: a + b, L, _inner_second(phi_p[i], st.u[i], nd // 2))
+                    continue
                 L = fuse(lambda a, b: a + b, L,
                          misc.sum_multiply(_arr(phi_p[i]), _arr(st.u[i]),
                                            axis=tuple(range(-nd, 0))))

@@ -1075,3 +1075,64 @@ def test_explicit_gaussian_gamma_converter_and_wrapper_nodes():
     assert G.dims == ((3,), (3, 3), (), ()) and G.plates == (2,)
     with pytest.raises(ValueError, match='should be Gaussian'):
         N_.GaussianToGaussianGamma(N_.Gamma(1, 1))
+
+
+@pytest.mark.parametrize('name,K', [('pca_n500_d6_k3', 3), ('pca_n777_d20_k5', 5),
+                                    ('pca_n4000_d64_k16', 16)])
+def test_generic_pca_with_factored_second_moments(golden_dir, name, K, monkeypatch):
+    """A posterior covariance shared over a plate (scalar mask) is kept as (Cov, <x>) instead of
+    a plates x K x K array (plans/generic.py:FactoredMoment): same live-reference traces, and the
+    dense (N, K, K) array of X is never formed by an iteration; reading X.u[1] forms it."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.generic import GenericPlan, FactoredMoment
+    from models import build_pca
+    monkeypatch.setenv('BAYESPY_AMD_FACTORED_MIN_PLATES', '2')
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    Q = build_pca(nodes, VB, g['y'], g['x0'], K, engine='generic')
+    plan = Q.plans[0]
+    assert isinstance(plan, GenericPlan)
+    n = int(g['n_iter'])
+    np.testing.assert_allclose(_trace(Q, n), g['L'], rtol=ELBO_RTOL)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[k]][:n], g['L_' + k], rtol=1e-8, atol=1e-7, err_msg=k)
+    for nm in ('X', 'W'):
+        u1 = plan.state[id(Q[nm])].u[1]
+        assert isinstance(u1, FactoredMoment) and u1._dense is None, nm
+    np.testing.assert_allclose(Q['W'].u[0], g['W_u0'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Q['X'].u[0], g['X_u0'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(np.broadcast_to(Q['W'].u[1], g['W_u1'].shape), g['W_u1'],
+                               rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Q['X'].u[1][0, :3], g['X_u1_first'], rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Q['tau'].u[0], g['tau_u0'], rtol=1e-9)
+    np.testing.assert_allclose(Q['alpha'].u[1], g['alpha_u1'], rtol=1e-8)
+
+
+def test_factored_second_moments_keep_memory_flat():
+    """N = 2e5, K = 16: the (N, K, K) array would be 410 MB; an iteration of the generic engine
+    stays far below it, and equals the dense path (threshold raised) to rounding."""
+    import torch
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_pca
+    from oracle.pca import make_pca_data
+    N, D, K = 200_000, 32, 16
+    y, x0 = make_pca_data(N, D, K, seed=11)
+    out = {}
+    for mode, thr in (('factored', '1024'), ('dense', str(10 ** 9))):
+        os.environ['BAYESPY_AMD_FACTORED_MIN_PLATES'] = thr
+        try:
+            Q = build_pca(nodes, VB, y, x0, K, engine='generic')
+            Q.update(repeat=1, verbose=False)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            Q.update(repeat=2, verbose=False)
+            torch.cuda.synchronize()
+            out[mode] = (np.array(Q.L[:3]), torch.cuda.max_memory_allocated() - base)
+            del Q
+        finally:
+            os.environ.pop('BAYESPY_AMD_FACTORED_MIN_PLATES', None)
+    np.testing.assert_allclose(out['factored'][0], out['dense'][0], rtol=1e-12)
+    assert out['factored'][1] < 0.5 * 8 * N * K * K, out['factored'][1]
+    assert out['dense'][1] > 8 * N * K * K
