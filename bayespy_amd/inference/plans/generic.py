@@ -107,7 +107,7 @@ class FactoredMoment(DArray):
 
 
 def _factored_min_plates():
-    return int(os.environ.get('BAYESPY_AMD_FACTORED_MIN_PLATES', '1024'))
+    return int(os.environ.get('BAYESPY_AMD_FACTORED_MIN_PLATES', '2'))
 
 
 def _diag2(xx, nd):
@@ -1191,22 +1191,53 @@ class SumMultiplyFamily:
         out1 = out0 + ['K%d' % k for k in n.out_keys]
         f0 = misc.contract(ops0, labs0, out0, sizes, compress=pl)
         per_parent = self._second_choices(ups)
-        if not any(len(alts) > 1 for alts in per_parent):
-            ops1 = [o[0] for alts in per_parent for o in alts[0][1]]
-            labs1 = [o[1] for alts in per_parent for o in alts[0][1]]
+        if not all(len(alts) > 1 for alts in per_parent):
+            # some parent carries a dense second moment: the product needs the dense arrays of
+            # all of them (a quadratic form per plate pair: D N K^2 flops, the matrix-core GEMM
+            # of the dense path is the right tool)
+            ops1, labs1 = [], []
+            for i, u in enumerate(ups):
+                xx = _arr(u[1])
+                xx = DArray(xx.t) if isinstance(xx, FactoredMoment) else xx
+                l1 = self._parent_labels(i, True)
+                ops1.append(xx)
+                labs1.append(l1[len(l1) - xx.ndim:])
             return [f0, misc.contract(ops1, labs1, out1, sizes, compress=pl)]
-        # factored parents: <f f^T> = sum over the picks; the all-means pick is <f><f>^T itself when
-        # every parent is factored (no plates x K x K array is ever formed, dot.py:355,403)
+        # every parent factored: <f f^T> = sum over one pick (Cov | <x><x>^T) per parent; the
+        # all-means pick is <f><f>^T itself, a pick with means is contracted in two steps --
+        # T = (the rest) . <x> over the second key copy (a GEMM), then T . <x> over the first --
+        # so that no plates x K x K array is ever formed (the reference's dot.py:355,403)
         terms = []
         nk = len(n.out_keys)
-        for kinds, ops in self._picks(per_parent):
+        for kinds, _ in self._picks(per_parent):
             if all(k == 'mean' for k in kinds):
                 terms.append(('sq', None))
                 continue
-            if len(ops) > 6:
+            picked = [alts[0 if kd == 'cov' else 1] for alts, kd in zip(per_parent, kinds)]
+            first_mean = next((i for i, kd in enumerate(kinds) if kd == 'mean'), None)
+            if first_mean is None:
+                ops = [o for pk in picked for o in pk[1]]
+                terms.append(('t', misc.contract([o[0] for o in ops], [o[1] for o in ops], out1,
+                                                 sizes, compress=pl)))
+                continue
+            (xk, lk), (xK, lK) = picked[first_mean][1]
+            rest = [o for i, pk in enumerate(picked) if i != first_mean for o in pk[1]]
+            if len(rest) + 1 > 6:
                 raise NotImplementedError('SumMultiply over %d factored parents' % len(ups))
-            terms.append(('t', misc.contract([o[0] for o in ops], [o[1] for o in ops], out1, sizes,
-                                             compress=pl)))
+            keys_k = [l for l in lk if l.startswith('k')]
+            keys_K = [l for l in lK if l.startswith('K')]
+            # T keeps: the output labels, this parent's first key copy, every plate label in use
+            used = []
+            for _, ls in rest + [(xK, lK)]:
+                for l in ls:
+                    if l not in used:
+                        used.append(l)
+            t_out = [l for l in pl if l in used] + [l for l in out1 if l not in pl and l in used
+                                                    and l not in keys_K]
+            t_out += [l for l in keys_k if l not in t_out]
+            T = misc.contract([o[0] for o in rest] + [xK], [o[1] for o in rest] + [lK], t_out, sizes,
+                              compress=pl)
+            terms.append(('t', misc.contract([T, xk], [t_out, lk], out1, sizes, compress=pl)))
         arrs = [t[1] for t in terms if t[0] == 't']
         if any(t[0] == 'sq' for t in terms):
             if nk == 0:
@@ -1296,7 +1327,10 @@ class SumMultiplyFamily:
             # m (N Cov_X + sum_n <x_n><x_n>^T), without the (N, K, K) array
             per_parent = self._second_choices(ups, skip=index)
             terms = []
-            for kinds, extra in self._picks(per_parent):
+            if not all(len(alts) > 1 for alts in per_parent):
+                per_parent = []           # a dense second moment among them: the dense product
+                terms = None
+            for kinds, extra in (self._picks(per_parent) if terms is not None else ()):
                 if len(base_ops) + len(extra) > 6:
                     # more operands than one launch takes: fall back to the dense arrays
                     terms = None
