@@ -400,7 +400,12 @@ class GaussianARDFamily(Family):
         if self.ndim > 0 and x.shape[x.ndim - self.ndim:] != self.shape:
             raise ValueError("Invalid shape")
         k = int(np.prod(self.shape)) if self.ndim else 1
-        xx = linalg.outer(x, x, ndim=self.ndim) if self.ndim else fuse(lambda v: v * v, x)
+        if self.ndim and x.size >= k * _factored_min_plates():
+            # delta moments x x^T of many plates: the factored form with a zero covariance
+            xx = FactoredMoment(DArray.zeros((1,) * (x.ndim - self.ndim) + self.shape + self.shape),
+                                x, self.ndim)
+        else:
+            xx = linalg.outer(x, x, ndim=self.ndim) if self.ndim else fuse(lambda v: v * v, x)
         return [x, xx], -0.5 * k * LOG2PI
 
     def message_to_parent(self, index, u, up):
@@ -1143,6 +1148,16 @@ class SumMultiplyFamily:
             xx = u[1]
             l0 = self._parent_labels(j, False)
             l1 = self._parent_labels(j, True)
+            nkj = len(self.node.in_keys[j])
+            if not self._is_factored(xx) and nkj > 0 and isinstance(xx, DArray) \
+                    and not isinstance(xx, FactoredMoment):
+                # a small dense second moment without plates of its own (a prior-initialised
+                # node: one K x K matrix) factors trivially: Cov = <x x^T> - <x><x>^T
+                x0 = _arr(u[0])
+                if all(e == 1 for e in xx.shape[:xx.ndim - 2 * nkj]) \
+                        and all(e == 1 for e in x0.shape[:x0.ndim - nkj]) and xx.size <= (1 << 16):
+                    cov0 = fuse(lambda q, o: q - o, xx, linalg.outer(x0, x0, ndim=nkj))
+                    xx = FactoredMoment(cov0, x0, nkj)
             if self._is_factored(xx):
                 x, cov = xx.mean, xx.cov
                 nk = len(self.node.in_keys[j])
