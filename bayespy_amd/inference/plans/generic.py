@@ -122,10 +122,15 @@ def _inner_second(phi, xx, nd):
     axes = tuple(range(-2 * nd, 0))
     if isinstance(xx, FactoredMoment) and xx._dense is None:
         x = xx.mean
-        a = misc.sum_multiply(_arr(phi), xx.cov, axis=axes)
-        b = misc.sum_multiply(_arr(phi), x.reshape(x.shape + (1,) * nd),
-                              x.reshape(x.shape[:x.ndim - nd] + (1,) * nd + x.shape[x.ndim - nd:]),
-                              axis=axes)
+        phi = _arr(phi)
+        a = misc.sum_multiply(phi, xx.cov, axis=axes)
+        # x^T phi x per plate in two steps -- t = phi x (a GEMM over the plates), then the row
+        # products t . x -- instead of one three-operand contraction (a thread-group kernel that
+        # walks K^2 products per plate: 1.7 ms at N = 1e6, K = 16)
+        D = int(np.prod(x.shape[x.ndim - nd:]))
+        xf = x.reshape(x.shape[:x.ndim - nd] + (D,))
+        pf = phi.reshape(phi.shape[:phi.ndim - 2 * nd] + (D, D))
+        b = misc.sum_multiply(linalg.mvdot(pf, xf), xf, axis=-1)
         return fuse(lambda p, q: p + q, a, b)
     return misc.sum_multiply(_arr(phi), _arr(xx), axis=axes)
 
