@@ -99,10 +99,14 @@ class Runtime:
             import warnings
             msg = self.lib.vmp_last_error(self.ctx)
             self._comm_reason = msg.decode() if msg else 'a rank failed to join'
-            if os.environ.get('BAYESPY_AMD_COLLECTIVE') == 'library':
-                raise RuntimeError('library RCCL communicator not available (%s) and '
-                                   'BAYESPY_AMD_COLLECTIVE=library forbids the '
-                                   'torch.distributed fallback' % self._comm_reason)
+            if os.environ.get('BAYESPY_AMD_COLLECTIVE') != 'torch-fallback':
+                # ONE data-path collective: on the nccl backend the plate sums are the library's
+                # vmp_allreduce_sum_f64 or nothing.  (BAYESPY_AMD_COLLECTIVE=torch selects
+                # torch.distributed.all_reduce explicitly, =torch-fallback permits it when the
+                # communicator cannot be created.)
+                raise RuntimeError('library RCCL communicator not available (%s); set '
+                                   'BAYESPY_AMD_COLLECTIVE=torch to run the plate sums through '
+                                   'torch.distributed.all_reduce instead' % self._comm_reason)
             warnings.warn('library RCCL communicator not available (%s): plate sums go through '
                           'torch.distributed.all_reduce' % self._comm_reason)
             if rc == 0:
@@ -135,6 +139,8 @@ class Runtime:
                 raise RuntimeError('plate sum would go through torch.distributed.all_reduce (%s) '
                                    'but BAYESPY_AMD_COLLECTIVE=library forbids that path'
                                    % (self._comm_reason or 'no library communicator'))
+            # reached only on a non-nccl backend (gloo: the CPU test-suite, several ranks on one
+            # GPU), with BAYESPY_AMD_COLLECTIVE=torch, or with the permitted fallback
             self.torch.distributed.all_reduce(tensor)
             self.collective_calls['torch'] += 1
         return tensor
