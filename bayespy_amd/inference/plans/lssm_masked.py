@@ -517,9 +517,10 @@ class MaskedLSSMPlan(LSSMPlan):
         st, L = self._host_state(), self.layout
         D, M, T, NS = self.D, self.M, self.T, self.NS
         if node is self.C:
-            # over the rows that see data (the mask of C: node.py:486-526)
-            return dict(XX=st[L.off_SCC:L.off_SCC + D * D].reshape(D, D).copy(),
-                        nplates=float(self.row_observed.sum()))
+            # XX over the rows that see data (the mask of C), the plate count over ALL rows: what
+            # RotateGaussianARD uses (transformations.py:241-248: ``self.N = self.X.plates[0]
+            # #np.sum(mask)``)
+            return dict(XX=st[L.off_SCC:L.off_SCC + D * D].reshape(D, D).copy(), nplates=float(M))
         if node is self.X:
             raw, o = self._raw(st), self._raw_offsets()
             sumP = _sym_unpack(raw[o['sumP']:o['sumP'] + NS], D)

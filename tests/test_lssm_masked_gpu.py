@@ -153,3 +153,9 @@ def test_config_scale_masked_properties():
     xx = torch.einsum('tmb,tsb->ms', bits, P).cpu().numpy()
     np.testing.assert_allclose(raw[o['XX']:o['XX'] + M * NS].reshape(M, NS), xx, rtol=1e-9,
                                atol=1e-6)
+
+
+def test_rotations_on_the_masked_block_match_reference():
+    """demos/lssm.py as it ships: array mask + rotation after every iteration, on the device."""
+    from test_lssm_masked_host import run_masked_rotation_case
+    run_masked_rotation_case(host=False)

@@ -184,3 +184,43 @@ def test_sharded_sequence_plate_world2_gloo(tag):
         np.testing.assert_allclose(cu0, g[tag + '_C_u0'], rtol=1e-7, atol=1e-9)
         lo, hi = (0, 2) if rank == 0 else (2, g[tag + '_y'].shape[1])
         np.testing.assert_allclose(xu0, g[tag + '_X_u0'][lo:hi], rtol=1e-7, atol=1e-9)
+
+
+def run_masked_rotation_case(host):
+    """demos/lssm.py as it ships (array mask with a stretch without data + the rotation speed-up
+    after every iteration) against the live-reference golden lssm_masked_rotations.npz."""
+    import warnings
+    from bayespy_amd.inference import transformations
+    g = np.load(os.path.join(GOLDEN, 'lssm_masked_rotations.npz'))
+    Q, nd = build(g['y'], g['mask'], g['x0'], g['c0'], None, False, host=host)
+    D = g['x0'].shape[-1]
+    rotA = transformations.RotateGaussianARD(nd['A'], nd['alpha'], axis=0)
+    rotX = transformations.RotateGaussianMarkovChain(nd['X'], rotA)
+    rotC = transformations.RotateGaussianARD(nd['C'], nd['gamma'], axis=0)
+    R = transformations.RotationOptimizer(rotX, rotC, D)
+    Q.update(repeat=2, verbose=False)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g['L_before'], rtol=1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        R.rotate(maxiter=10)
+    np.testing.assert_allclose(Q.compute_lowerbound(), g['L_after'], rtol=1e-6)
+    for nm in ('A', 'C', 'alpha', 'gamma', 'X'):
+        for i, ui in enumerate(nd[nm].u):
+            got, ref = np.broadcast_arrays(np.asarray(ui), g['%s_u%d_rot' % (nm, i)])
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(),
+                                       err_msg='%s u[%d] after the rotation' % (nm, i))
+    Ls = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(5):
+            Q.update(repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+            R.rotate(maxiter=10)
+    Ls = np.array(Ls)
+    np.testing.assert_allclose(Ls[:2], g['L'][:2], rtol=1e-5)
+    np.testing.assert_allclose(Ls, g['L'], rtol=2e-2)
+    assert np.all(np.diff(Ls) > 0)
+
+
+def test_rotations_on_the_masked_block_match_reference():
+    run_masked_rotation_case(host=True)
