@@ -1245,16 +1245,15 @@ class SumMultiplyFamily:
             if len(rest) + 1 > 6:
                 raise NotImplementedError('SumMultiply over %d factored parents' % len(ups))
             keys_k = [l for l in lk if l.startswith('k')]
-            keys_K = [l for l in lK if l.startswith('K')]
             # T keeps: the output labels, this parent's first key copy, every plate label in use
             used = []
             for _, ls in rest + [(xK, lK)]:
                 for l in ls:
                     if l not in used:
                         used.append(l)
-            t_out = [l for l in pl if l in used] + [l for l in out1 if l not in pl and l in used
-                                                    and l not in keys_K]
-            t_out += [l for l in keys_k if l not in t_out]
+            # (a key of the second copy that is an OUTPUT key stays; one that is contracted goes)
+            t_out = [l for l in pl if l in used] + [l for l in out1 if l not in pl and l in used]
+            t_out += [l for l in keys_k if l in used and l not in t_out]
             T = misc.contract([o[0] for o in rest] + [xK], [o[1] for o in rest] + [lK], t_out, sizes,
                               compress=pl)
             terms.append(('t', misc.contract([T, xk], [t_out, lk], out1, sizes, compress=pl)))
