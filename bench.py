@@ -65,6 +65,9 @@ def parse():
     p.add_argument('--steady-steps', type=int, default=200,
                    help='a second, longer region after the timed one: per-step median / max '
                         '("steady" in the line); 0 to skip')
+    p.add_argument('--exact-steps', action='store_true',
+                   help='--config runs: time exactly --steps iterations (profiling runs); the '
+                        'default raises short requests to the per-leg floor of >= 50 steps')
     p.add_argument('--full-out', default=None,
                    help='write the full (verbose) records of the headline and of every extra leg '
                         'to this JSON file; the printed line carries their compact forms')
@@ -247,7 +250,10 @@ def main():
             'generic_gmm': ('run_generic_gmm', dict(), 50),
         }
         fname, kw, floor = table[args.config]
-        out = getattr(workloads, fname)(steps=max(args.steps, floor), warmup=max(args.warmup, 2),
+        if args.exact_steps:
+            floor = 1
+        out = getattr(workloads, fname)(steps=max(args.steps, floor),
+                                        warmup=args.warmup if args.exact_steps else max(args.warmup, 2),
                                         cpu_baseline=not args.no_cpu_baseline, **kw)
         if rank == 0:
             out['comm'] = rt.comm_info()
