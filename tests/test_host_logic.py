@@ -313,3 +313,28 @@ def test_user_guide_plate_doctests():
     alpha = Gamma(1e-3, 1e-3, plates=(D,))
     C = GaussianARD(0, alpha, shape=(D,), plates=(10, 1))
     assert Dot(C, X).plates == (10, 100)
+
+
+def test_bench_extra_records_are_compact():
+    """The default bench line must stay far below the ~8 KB tail the driver keeps: every leg of
+    "extra" is the one-screen record of tools/workloads.py:compact (VERDICT r03 #1)."""
+    import json
+    from tools import workloads
+    full = {
+        'metric': 'VB iterations/sec, GMM N=10000000 D=8 K=64', 'value': 342.5, 'steps': 200,
+        'ms_per_step': 2.92, 'step_ms': {'ms_mean': 2.92, 'ms_median': 2.913, 'ms_max': 3.16,
+                                         'argmax_step': 0, 'timed_s': 0.584},
+        'config': {'workload': 'x' * 300}, 'peak_mem_GB': 12.3456789, 'wall_s': 2.123,
+        'roofline': {'kernel': 'gmm_pass_kernel', 'bound': 'mfma', 'achieved': 66.9, 'peak': 78.6,
+                     'frac': 0.8512345, 'traffic': 5.767e9, 'alg_bytes_per_launch': 5.76e9,
+                     'avg_launch_ms': 2.7951234, 'issued_mfma_TFLOPs': 44.01234, 'note': 'y' * 400},
+        'cpu_baseline': {'value': 0.0335123, 'cores': 128, 'kind': 'port',
+                         'elbo_rel_err_hip_vs_oracle': 8.1234e-15, 'sample': 'z' * 300}}
+    c = workloads.compact(full, 'gmm')
+    assert c['leg'] == 'gmm' and c['ms_per_step'] == 2.92 and c['ms_max'] == 3.16
+    assert c['frac'] == 0.851 and c['kernel_ms'] == 2.795 and c['parity_on'] == 'sample'
+    assert abs(c['traffic_over_alg'] - 1.0) < 2e-3 and c['cpu_cores'] == 128
+    assert len(json.dumps(c)) < 420
+    err = workloads.compact({'error': 'RuntimeError: ' + 'q' * 500, 'wall_s': 1.0}, 'lssm')
+    assert err['leg'] == 'lssm' and len(json.dumps(err)) < 260
+    assert len(json.dumps([c] * 8)) < 3400
