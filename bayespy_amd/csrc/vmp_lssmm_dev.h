@@ -552,8 +552,11 @@ VMP_HD double lssmm_gamma_term(double a0, double b0, const double *g, int n, int
 
 // DG / LG: digamma and log-gamma (vmp_common.h: vmp_digamma, vmp_lgamma), passed in so that this
 // header stays free of the HIP runtime
+// tmp: >= LSSMM_DMAX^2 + LSSMM_DMAX doubles of scratch next to the state (LDS on the device: a
+// thread-private array indexed at run time would live in scratch memory, one HBM round trip per access)
 template <typename DG, typename LG>
-VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, DG digamma_fn, LG lgamma_fn)
+VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp, DG digamma_fn,
+                             LG lgamma_fn)
 {
     const vmp_lssmm_layout &L = A.L;
     const int D = A.D, M = A.M, T = A.T, DD = D * D, NS = D * (D + 1) / 2;
@@ -574,7 +577,7 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, DG digamma_f
         Mobs += nm[m] > 0.0 ? 1.0 : 0.0;
     }
     int bad = 0;
-    double tmp[LSSMM_DMAX * LSSMM_DMAX];
+    double *innov = tmp + LSSMM_DMAX * LSSMM_DMAX;
     // chain statistics from the raw sums (sequences with data only)
     const double *sumP = raw + ro.sumP, *Snp = raw + ro.Snp, *P0 = raw + ro.P0, *PT = raw + ro.PT;
     const double *s0 = raw + ro.x0, *XX = raw + ro.XX, *Syx = raw + ro.Syx;
@@ -677,7 +680,6 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, DG digamma_f
                         sff += (CovC[m * DD + i * D + j] + Cm[m * D + i] * Cm[m * D + j])
                                * XX[m * NS + sym_ix(i, j)];
             const double resid = setup[0] - 2.0 * syf + sff;
-            double innov[LSSMM_DMAX];
             for (int i = 0; i < D; ++i) {
                 double s = sumP[sym_ix(i, i)] - P0[sym_ix(i, i)];              // Snn[i][i]
                 for (int j = 0; j < D; ++j) s -= 2.0 * Am[i * D + j] * Snp[i * D + j];
