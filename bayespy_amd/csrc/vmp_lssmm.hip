@@ -174,29 +174,26 @@ lssmm_backward_kernel(sweep_args A)
     }
 }
 
-// Wavefront w of a workgroup takes row group blockIdx.y * SGW + w of the SAME 64 sequences: the
-// groups of a sequence block run together on one CU, so P / Z / the mask word come from HBM once
-// and from the cache for the other groups (as separate workgroups every group re-read them:
-// 3.04 GB per launch against 1.84 at M = 8, profiles/r04/pmc_lssm_masked.txt before this).
-constexpr int SGW = 4;
+// (The row groups of a sequence block as wavefronts of ONE workgroup -- so that P / Z come from HBM
+// once -- was measured and rejected: 1.84 instead of 3.04 GB per launch at M = 8, but 0.83 instead of
+// 0.75 ms: the pass is latency-bound, and one workgroup per group spreads over twice the CUs.)
 template <int D>
-__global__ void __launch_bounds__(WNT * SGW)
-lssmm_stats_kernel(sweep_args A, int ng)
+__global__ void __launch_bounds__(WNT)
+lssmm_stats_kernel(sweep_args A)
 {
     constexpr int NS = D * (D + 1) / 2;
     constexpr int AL = MG * (NS + D);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * WNT + lane;
-    const int grp = blockIdx.y * SGW + w;
+    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    const int m0 = blockIdx.y * MG;
     double acc[AL];
 #pragma unroll
     for (int e = 0; e < AL; ++e) acc[e] = 0.0;
-    if (b < A.B && grp < ng) lssmm_stats_seq<D, MG>(A.S, b, grp * MG, acc);
+    if (b < A.B) lssmm_stats_seq<D, MG>(A.S, b, m0, acc);
 #pragma unroll
     for (int e = 0; e < AL; ++e) {
         const double s = wave_sum(acc[e]);
-        if (lane == 0 && grp < ng)
-            A.partial[((int64_t)blockIdx.x * ng + grp) * AL + e] = s;
+        if (threadIdx.x == 0)
+            A.partial[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * AL + e] = s;
     }
 }
 
@@ -403,7 +400,7 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
     }
     const int ng = (M + MG - 1) / MG;
     if (g > 0) {
-#define LSSMM_STATS(d) hipLaunchKernelGGL(lssmm_stats_kernel<d>, dim3((unsigned)g, (unsigned)((ng + SGW - 1) / SGW)), dim3(WNT * SGW), 0, s, A, ng);
+#define LSSMM_STATS(d) hipLaunchKernelGGL(lssmm_stats_kernel<d>, dim3((unsigned)g, (unsigned)ng), dim3(WNT), 0, s, A);
         LSSMM_FOR_D(LSSMM_STATS)
 #undef LSSMM_STATS
     }
