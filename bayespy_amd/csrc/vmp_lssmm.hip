@@ -244,15 +244,19 @@ lssmm_sum_stats_kernel(const double *__restrict__ partial, int n, int ng, int M,
     }
 }
 
+struct wave_sync {
+    __device__ void operator()() const { __syncthreads(); }
+};
+
 __global__ void __launch_bounds__(64)
 lssmm_small_kernel(lssmm_small_args A, double *__restrict__ gst)
 {
     extern __shared__ double st_lds[];
-    __shared__ double tmp[LSSMM_DMAX * LSSMM_DMAX + LSSMM_DMAX];
+    __shared__ double scratch[lssmm_small_scratch(64)];
     const int total = (int)A.L.total;
     for (int e = threadIdx.x; e < total; e += 64) st_lds[e] = gst[e];
     __syncthreads();
-    if (threadIdx.x == 0) lssmm_small_body(A, st_lds, tmp, dg_fn(), lg_fn());
+    lssmm_small_body(A, st_lds, scratch, (int)threadIdx.x, 64, wave_sync(), dg_fn(), lg_fn());
     __syncthreads();
     for (int e = threadIdx.x; e < total; e += 64) gst[e] = st_lds[e];
 }

@@ -550,13 +550,25 @@ VMP_HD double lssmm_gamma_term(double a0, double b0, const double *g, int n, int
            + (a0 - a) * g[3 * n + k];
 }
 
+// scratch of the replicated-node routine (doubles): one D x D work matrix per thread, then shared
+// cells: innov[DMAX] | rowsum[MMAX] | gterm[3 DMAX + 1] | resid, nobs, Mobs, bad
+VMP_HD constexpr int lssmm_small_scratch(int nthr)
+{
+    return nthr * LSSMM_DMAX * LSSMM_DMAX + LSSMM_DMAX + LSSMM_MMAX + 3 * LSSMM_DMAX + 1 + 4;
+}
+
 // DG / LG: digamma and log-gamma (vmp_common.h: vmp_digamma, vmp_lgamma), passed in so that this
-// header stays free of the HIP runtime
-// tmp: >= LSSMM_DMAX^2 + LSSMM_DMAX doubles of scratch next to the state (LDS on the device: a
-// thread-private array indexed at run time would live in scratch memory, one HBM round trip per access)
-template <typename DG, typename LG>
-VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp, DG digamma_fn,
-                             LG lgamma_fn)
+// header stays free of the HIP runtime.
+// Cooperative form: ``nthr`` threads (one wavefront on the device, ONE on the host) run it
+// together; a section is row-parallel (rows of C / A dealt to the threads), entry-parallel
+// (matrix entries dealt to the threads) or serial (thread 0), ``sync()`` stands between dependent
+// sections.  Every sum over rows goes through a per-row cell and is added by thread 0 in row order,
+// so the result does not depend on nthr (the host build with one thread == the device with 64).
+// The state sits in LDS on the device: a single thread pays one LDS round trip per dependent access
+// (126 us per launch of ~5000 of them); dealt over the wavefront the launch is a few round trips deep.
+template <typename DG, typename LG, typename SYNC>
+VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *scratch, int tid, int nthr,
+                             SYNC sync, DG digamma_fn, LG lgamma_fn)
 {
     const vmp_lssmm_layout &L = A.L;
     const int D = A.D, M = A.M, T = A.T, DD = D * D, NS = D * (D + 1) / 2;
@@ -571,23 +583,33 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp,
     double *sc = st + L.off_scal;
     const double *nm = setup + 2;
     const double Beff = setup[1];
-    double nobs = 0.0, Mobs = 0.0;
-    for (int m = 0; m < M; ++m) {
-        nobs += nm[m];
-        Mobs += nm[m] > 0.0 ? 1.0 : 0.0;
+    double *tmp = scratch + tid * (LSSMM_DMAX * LSSMM_DMAX);       // this thread's work matrix
+    double *innov = scratch + nthr * (LSSMM_DMAX * LSSMM_DMAX);
+    double *rowsum = innov + LSSMM_DMAX;
+    double *gterm = rowsum + LSSMM_MMAX;
+    double *cell = gterm + 3 * LSSMM_DMAX + 1;                     // [0] resid [1] nobs [2] Mobs [3] bad
+    if (tid == 0) {
+        double nobs = 0.0, Mobs = 0.0;
+        for (int m = 0; m < M; ++m) {
+            nobs += nm[m];
+            Mobs += nm[m] > 0.0 ? 1.0 : 0.0;
+        }
+        cell[1] = nobs;
+        cell[2] = Mobs;
+        cell[3] = 0.0;
     }
+    sync();
     int bad = 0;
-    double *innov = tmp + LSSMM_DMAX * LSSMM_DMAX;
     // chain statistics from the raw sums (sequences with data only)
     const double *sumP = raw + ro.sumP, *Snp = raw + ro.Snp, *P0 = raw + ro.P0, *PT = raw + ro.PT;
     const double *s0 = raw + ro.x0, *XX = raw + ro.XX, *Syx = raw + ro.Syx;
     for (int oi = 0; oi < A.nops; ++oi) {
         const int op = A.ops[oi];
+        const double nobs = cell[1], Mobs = cell[2];
         if (op == VMP_LSSM_OP_C) {
             // Lam_m = diag<gamma> + <tau> XX_m;  c_m = Cov_m <tau> Syx_m;  a row without data gets
             // its prior-only posterior (expfamily.py:343-366 updates ignored plates too)
-            for (int e = 0; e < DD; ++e) SCC[e] = 0.0;
-            for (int m = 0; m < M; ++m) {
+            for (int m = tid; m < M; m += nthr) {
                 for (int i = 0; i < D; ++i)
                     for (int j = 0; j < D; ++j)
                         tmp[i * D + j] = tau[2] * XX[m * NS + sym_ix(i, j)] + (i == j ? gam[2 * D + i] : 0.0);
@@ -600,27 +622,31 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp,
                     Cm[m * D + i] = s;
                 }
             }
+            sync();
         }
         if (op == VMP_LSSM_OP_C || op == VMP_LSSM_OP_GAMMA || op == VMP_LSSM_OP_ELBO) {
             // sum over the observed rows of <c_m c_m^T> (the message to gamma: node.py:570-655)
-            for (int e = 0; e < DD; ++e) {
+            for (int e = tid; e < DD; e += nthr) {
                 const int i = e / D, j = e % D;
                 double s = 0.0;
                 for (int m = 0; m < M; ++m)
                     if (nm[m] > 0.0) s += CovC[m * DD + e] + Cm[m * D + i] * Cm[m * D + j];
                 SCC[e] = s;
             }
+            sync();
         }
         if (op == VMP_LSSM_OP_GAMMA) {
-            for (int j = 0; j < D; ++j)
+            for (int j = tid; j < D; j += nthr)
                 lssmm_set_gamma(gam, D, j, A.pri[2] + 0.5 * Mobs, A.pri[3] + 0.5 * SCC[j * D + j],
                                 digamma_fn);
+            sync();
         } else if (op == VMP_LSSM_OP_XPREP) {
             // shared parts of the chain precision (gaussian_markov_chain.py:270-441), h_0, and the
             // per-row observation terms tau c_m, tau <c_m c_m^T>
             const double *Lam0 = st + L.off_Lam0, *mu0 = st + L.off_mu0;
-            for (int j = 0; j < D; ++j)
-                for (int k = 0; k <= j; ++k) {
+            for (int e = tid; e < DD; e += nthr) {
+                const int j = e / D, k = e % D;
+                if (k <= j) {
                     double anua = 0.0;
                     for (int i = 0; i < D; ++i) anua += nu[2 * D + i] * AA[(i * D + j) * D + k];
                     const double dn = (j == k) ? nu[2 * D + j] : 0.0;
@@ -629,15 +655,14 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp,
                     tab[to.base + NS + s] = dn + anua;
                     tab[to.base + 2 * NS + s] = (T > 1 ? dn : Lam0[j * D + k]);
                 }
-            for (int j = 0; j < D; ++j)
-                for (int k = 0; k < D; ++k)
-                    tab[to.E + j * D + k] = -nu[2 * D + k] * Am[k * D + j];   // Phi[t, t+1][j][k]
-            for (int i = 0; i < D; ++i) {
+                tab[to.E + j * D + k] = -nu[2 * D + k] * Am[k * D + j];       // Phi[t, t+1][j][k]
+            }
+            for (int i = tid; i < D; i += nthr) {
                 double s = 0.0;
                 for (int k = 0; k < D; ++k) s += Lam0[i * D + k] * mu0[k];
                 tab[to.h0 + i] = s;
             }
-            for (int m = 0; m < M; ++m) {
+            for (int m = tid; m < M; m += nthr) {
                 for (int i = 0; i < D; ++i) {
                     tab[to.C + m * D + i] = tau[2] * Cm[m * D + i];
                     for (int j = 0; j <= i; ++j)
@@ -645,10 +670,11 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp,
                             tau[2] * (CovC[m * DD + i * D + j] + Cm[m * D + i] * Cm[m * D + j]);
                 }
             }
-            sc[1] = tau[2];
+            if (tid == 0) sc[1] = tau[2];
+            sync();
         } else if (op == VMP_LSSM_OP_A) {
             // Spp = sum_{t<T-1} P = sumP - P_T-1;  Snp[i] = sum <x_t+1,i x_t>
-            for (int i = 0; i < D; ++i) {
+            for (int i = tid; i < D; i += nthr) {
                 for (int j = 0; j < D; ++j)
                     for (int k = 0; k < D; ++k)
                         tmp[j * D + k] = nu[2 * D + i] * (sumP[sym_ix(j, k)] - PT[sym_ix(j, k)])
@@ -664,23 +690,27 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp,
                     for (int k = 0; k < D; ++k)
                         AA[(i * D + j) * D + k] = tmp[j * D + k] + Am[i * D + j] * Am[i * D + k];
             }
+            sync();
         } else if (op == VMP_LSSM_OP_ALPHA) {
-            for (int j = 0; j < D; ++j) {
+            for (int j = tid; j < D; j += nthr) {
                 double s = 0.0;
                 for (int i = 0; i < D; ++i) s += AA[(i * D + j) * D + j];
                 lssmm_set_gamma(alp, D, j, A.pri[4] + 0.5 * D, A.pri[5] + 0.5 * s, digamma_fn);
             }
+            sync();
         } else if (op == VMP_LSSM_OP_TAU || op == VMP_LSSM_OP_NU || op == VMP_LSSM_OP_ELBO) {
-            // residual sum mask <(y - c.x)^2> and the innovation sums from the statistics
-            double syf = 0.0, sff = 0.0;
-            for (int e = 0; e < M * D; ++e) syf += Cm[e] * Syx[e];
-            for (int m = 0; m < M; ++m)
+            // residual sum mask <(y - c.x)^2> = sum mask y^2 + sum_m (<c c^T>_m : XX_m - 2 c_m . Syx_m)
+            // and the innovation sums from the statistics
+            for (int m = tid; m < M; m += nthr) {
+                double syf = 0.0, sff = 0.0;
+                for (int k = 0; k < D; ++k) syf += Cm[m * D + k] * Syx[m * D + k];
                 for (int i = 0; i < D; ++i)
                     for (int j = 0; j < D; ++j)
                         sff += (CovC[m * DD + i * D + j] + Cm[m * D + i] * Cm[m * D + j])
                                * XX[m * NS + sym_ix(i, j)];
-            const double resid = setup[0] - 2.0 * syf + sff;
-            for (int i = 0; i < D; ++i) {
+                rowsum[m] = sff - 2.0 * syf;
+            }
+            for (int i = tid; i < D; i += nthr) {
                 double s = sumP[sym_ix(i, i)] - P0[sym_ix(i, i)];              // Snn[i][i]
                 for (int j = 0; j < D; ++j) s -= 2.0 * Am[i * D + j] * Snp[i * D + j];
                 for (int j = 0; j < D; ++j)
@@ -688,55 +718,84 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *tmp,
                         s += AA[(i * D + j) * D + k] * (sumP[sym_ix(j, k)] - PT[sym_ix(j, k)]);
                 innov[i] = s;
             }
+            sync();
+            if (tid == 0) {
+                double r = setup[0];
+                for (int m = 0; m < M; ++m) r += rowsum[m];
+                cell[0] = r;
+            }
+            sync();
+            const double resid = cell[0];
             if (op == VMP_LSSM_OP_TAU) {
-                lssmm_set_gamma(tau, 1, 0, A.pri[0] + 0.5 * nobs, A.pri[1] + 0.5 * resid, digamma_fn);
-                if (!(tau[1] > 0.0)) sc[0] = (double)VMP_ERR_FLOATING;
+                if (tid == 0) {
+                    lssmm_set_gamma(tau, 1, 0, A.pri[0] + 0.5 * nobs, A.pri[1] + 0.5 * resid, digamma_fn);
+                    if (!(tau[1] > 0.0)) sc[0] = (double)VMP_ERR_FLOATING;
+                }
+                sync();
             } else if (op == VMP_LSSM_OP_NU) {
-                for (int i = 0; i < D; ++i)
+                for (int i = tid; i < D; i += nthr)
                     lssmm_set_gamma(nu, D, i, A.pri[6] + 0.5 * Beff * (T - 1), A.pri[7] + 0.5 * innov[i],
                                     digamma_fn);
+                sync();
             } else {
-                const double LOG2PI = 1.8378770664093453;
-                double *Lo = st + L.off_L;
-                const double *Lam0 = st + L.off_Lam0, *mu0 = st + L.off_mu0;
-                Lo[0] = nobs * (-0.5 * LOG2PI + 0.5 * tau[3]) - 0.5 * tau[2] * resid;               // Y
-                double lc = 0.0;
-                for (int m = 0; m < M; ++m)
-                    if (nm[m] > 0.0) lc += 0.5 * ldC[m] + 0.5 * D;
-                for (int j = 0; j < D; ++j)
-                    lc += 0.5 * Mobs * gam[3 * D + j] - 0.5 * gam[2 * D + j] * SCC[j * D + j];
-                Lo[1] = lc;                                                                         // C
-                double la = 0.5 * D * D;
-                for (int i = 0; i < D; ++i) la += 0.5 * ldA[i];
-                for (int j = 0; j < D; ++j) {
-                    double s = 0.0;
-                    for (int i = 0; i < D; ++i) s += AA[(i * D + j) * D + j];
-                    la += 0.5 * D * alp[3 * D + j] - 0.5 * alp[2 * D + j] * s;
+                // the Gamma terms (two log-gammas each) dealt to the threads: gamma | alpha | nu | tau
+                for (int e = tid; e < 3 * D + 1; e += nthr) {
+                    double g = 0.0;
+                    if (e < D) g = lssmm_gamma_term(A.pri[2], A.pri[3], gam, D, e, lgamma_fn);
+                    else if (e < 2 * D) g = lssmm_gamma_term(A.pri[4], A.pri[5], alp, D, e - D, lgamma_fn);
+                    else if (e < 3 * D) {
+                        if (A.nu_latent) g = lssmm_gamma_term(A.pri[6], A.pri[7], nu, D, e - 2 * D, lgamma_fn);
+                    } else g = lssmm_gamma_term(A.pri[0], A.pri[1], tau, 1, 0, lgamma_fn);
+                    gterm[e] = g;
                 }
-                Lo[2] = la;                                                                         // A
-                double slognu = 0.0;
-                for (int i = 0; i < D; ++i) slognu += nu[3 * D + i];
-                double lx = Beff * (0.5 * T * D + 0.5 * st[L.off_ldLam0] + 0.5 * (T - 1) * slognu)
-                            - 0.5 * raw[ro.ld];
-                for (int i = 0; i < D; ++i)
+                sync();
+                if (tid == 0) {
+                    const double LOG2PI = 1.8378770664093453;
+                    double *Lo = st + L.off_L;
+                    const double *Lam0 = st + L.off_Lam0, *mu0 = st + L.off_mu0;
+                    Lo[0] = nobs * (-0.5 * LOG2PI + 0.5 * tau[3]) - 0.5 * tau[2] * resid;           // Y
+                    double lc = 0.0;
+                    for (int m = 0; m < M; ++m)
+                        if (nm[m] > 0.0) lc += 0.5 * ldC[m] + 0.5 * D;
                     for (int j = 0; j < D; ++j)
-                        lx -= 0.5 * Lam0[i * D + j]
-                              * (P0[sym_ix(i, j)] - s0[i] * mu0[j] - mu0[i] * s0[j] + Beff * mu0[i] * mu0[j]);
-                for (int i = 0; i < D; ++i) lx -= 0.5 * nu[2 * D + i] * innov[i];
-                Lo[3] = lx;                                                                         // X
-                double lg = 0.0, lal = 0.0, lnu = 0.0;
-                for (int j = 0; j < D; ++j) {
-                    lg += lssmm_gamma_term(A.pri[2], A.pri[3], gam, D, j, lgamma_fn);
-                    lal += lssmm_gamma_term(A.pri[4], A.pri[5], alp, D, j, lgamma_fn);
-                    if (A.nu_latent) lnu += lssmm_gamma_term(A.pri[6], A.pri[7], nu, D, j, lgamma_fn);
+                        lc += 0.5 * Mobs * gam[3 * D + j] - 0.5 * gam[2 * D + j] * SCC[j * D + j];
+                    Lo[1] = lc;                                                                     // C
+                    double la = 0.5 * D * D;
+                    for (int i = 0; i < D; ++i) la += 0.5 * ldA[i];
+                    for (int j = 0; j < D; ++j) {
+                        double s = 0.0;
+                        for (int i = 0; i < D; ++i) s += AA[(i * D + j) * D + j];
+                        la += 0.5 * D * alp[3 * D + j] - 0.5 * alp[2 * D + j] * s;
+                    }
+                    Lo[2] = la;                                                                     // A
+                    double slognu = 0.0;
+                    for (int i = 0; i < D; ++i) slognu += nu[3 * D + i];
+                    double lx = Beff * (0.5 * T * D + 0.5 * st[L.off_ldLam0] + 0.5 * (T - 1) * slognu)
+                                - 0.5 * raw[ro.ld];
+                    for (int i = 0; i < D; ++i)
+                        for (int j = 0; j < D; ++j)
+                            lx -= 0.5 * Lam0[i * D + j]
+                                  * (P0[sym_ix(i, j)] - s0[i] * mu0[j] - mu0[i] * s0[j]
+                                     + Beff * mu0[i] * mu0[j]);
+                    for (int i = 0; i < D; ++i) lx -= 0.5 * nu[2 * D + i] * innov[i];
+                    Lo[3] = lx;                                                                     // X
+                    double lg = 0.0, lal = 0.0, lnu = 0.0;
+                    for (int j = 0; j < D; ++j) {
+                        lg += gterm[j];
+                        lal += gterm[D + j];
+                        lnu += gterm[2 * D + j];
+                    }
+                    Lo[4] = lg;
+                    Lo[5] = lal;
+                    Lo[6] = gterm[3 * D];
+                    Lo[7] = lnu;
+                    Lo[8] = Lo[0] + Lo[1] + Lo[2] + Lo[3] + Lo[4] + Lo[5] + Lo[6] + Lo[7];
                 }
-                Lo[4] = lg;
-                Lo[5] = lal;
-                Lo[6] = lssmm_gamma_term(A.pri[0], A.pri[1], tau, 1, 0, lgamma_fn);
-                Lo[7] = lnu;
-                Lo[8] = Lo[0] + Lo[1] + Lo[2] + Lo[3] + Lo[4] + Lo[5] + Lo[6] + Lo[7];
+                sync();
             }
         }
     }
-    if (bad) sc[0] = (double)VMP_ERR_NOT_POSDEF;
+    if (bad) cell[3] = 1.0;
+    sync();
+    if (tid == 0 && cell[3] != 0.0) sc[0] = (double)VMP_ERR_NOT_POSDEF;
 }

@@ -139,8 +139,8 @@ int32_t vmp_lssmm_small_ops(vmp_ctx *, int32_t D, int32_t M, int32_t T, const do
     for (int i = 0; i < nops; ++i) A.ops[i] = ops[i];
     for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
     A.nu_latent = nu_latent;
-    double tmp[LSSMM_DMAX * LSSMM_DMAX + LSSMM_DMAX];
-    lssmm_small_body(A, state, tmp, dg_fn(), lg_fn());
+    double scratch[lssmm_small_scratch(1)];
+    lssmm_small_body(A, state, scratch, 0, 1, [] {}, dg_fn(), lg_fn());
     return VMP_OK;
 }
 
