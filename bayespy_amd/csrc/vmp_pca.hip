@@ -325,7 +325,10 @@ constexpr int xpass_occ(int DB, int KT, int OCC)
     return KT * DB * 4096 > 80 * 1024 ? 1 : (KT * DB * 4096 > 53 * 1024 ? (OCC < 2 ? OCC : 2) : OCC);
 }
 
-template <int DB, int KT, bool GUARD, int OCC, int NTM = 0, int LAY = 0, int MF = 0>
+// IL (round 4 experiment, tune key "pca_interleave"): ONE array [tile][DP + KP][32] -- the <x> rows of
+// a tile directly behind its data rows -- so that the relative placement of the read and the write
+// stream is fixed by construction instead of by two allocations.
+template <int DB, int KT, bool GUARD, int OCC, int NTM = 0, int LAY = 0, int MF = 0, bool IL = false>
 __global__ void __launch_bounds__(NT, xpass_occ(DB, KT, OCC))
 pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, int K,
                  const double *__restrict__ Apad, double *__restrict__ X, int64_t ldx,
@@ -364,7 +367,8 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
     auto issue = [&](int64_t tile, int c, v2f64 *dst) {
         if (YT) {
             const char *base = reinterpret_cast<const char *>(Y)
-                               + ((tile * (DP * TN) + (int64_t)(c * CH) * (4 * TN)) << 3);
+                               + ((tile * ((DP + (IL ? 16 * KT : 0)) * TN)
+                                   + (int64_t)(c * CH) * (4 * TN)) << 3);
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const v2f64 *src = reinterpret_cast<const v2f64 *>(base + i * (4 * TN * 8) + l * 16);
@@ -451,7 +455,8 @@ pca_xpass_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D, in
         // C/D layout: col = lane&15 -> column pair, row = (lane>>4) + 4*reg -> k
         char *xbase = reinterpret_cast<char *>(X) + ((tile * TN) << 3);
         if (XT) {
-            char *xt = reinterpret_cast<char *>(X) + ((tile * (16 * KT * TN)) << 3) + l * 16;
+            char *xt = reinterpret_cast<char *>(X)
+                       + ((tile * (((IL ? DP : 0) + 16 * KT) * TN)) << 3) + l * 16;
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
@@ -591,6 +596,8 @@ int wgs_per_cu()
     if (v < 0) v = env_int("VMP_PCA_WGS_PER_CU", 2, 1, 8);
     return v;
 }
+
+int pca_interleave() { return vmp_tune_get("pca_interleave", 0); }
 
 int xpass_wgs_per_cu()
 {
@@ -773,13 +780,13 @@ int32_t run_gram_stats(vmp_ctx *ctx, const vmp_pca_layout &L, int D, int K, doub
 template <bool TO_TILED>
 __global__ void __launch_bounds__(NT)
 pca_tile_kernel(double *__restrict__ R, int64_t ld, int64_t N, int rows, int RP,
-                double *__restrict__ T, int64_t ntiles)
+                double *__restrict__ T, int64_t ntiles, int64_t tstride)
 {
     const int tid = threadIdx.x;
     const int c2 = (tid & 15) * 2;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t n = tile * TN + c2;
-        double *tb = T + tile * ((int64_t)RP * TN);
+        double *tb = T + tile * tstride;
         for (int row = tid >> 4; row < RP; row += NT / 16) {
             double *rp = R + (int64_t)row * ld + n;
             v2f64 *tp = reinterpret_cast<v2f64 *>(tb + row * TN + c2);
@@ -865,6 +872,21 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
 #define VMP_XP4(db, kt, oc, ly)                                                                  \
     hipLaunchKernelGGL((pca_xpass_kernel<db, kt, false, oc, 3, ly, 1>), grid, dim3(NT), 0, s, Y,  \
                        ldy, N, D, K, A, X, ldx, t0, t1)
+        if (lay == 3 && pca_interleave()) {
+            // the experiment's instances: the headline and config-2 shapes
+            if (DB == 4 && KT == 2)
+                hipLaunchKernelGGL((pca_xpass_kernel<4, 2, false, 3, 3, 3, 0, true>), grid, dim3(NT),
+                                   0, s, Y, ldy, N, D, K, A, X, ldx, t0, t1);
+            else if (DB == 2 && KT == 1)
+                hipLaunchKernelGGL((pca_xpass_kernel<2, 1, false, 3, 3, 3, 0, true>), grid, dim3(NT),
+                                   0, s, Y, ldy, N, D, K, A, X, ldx, t0, t1);
+            else {
+                VMP_SET_ERR(ctx, "pca_interleave: no instance for DB=%d KT=%d", DB, KT);
+                return VMP_ERR_UNSUPPORTED;
+            }
+            VMP_HIP_CHECK(ctx, hipGetLastError());
+            continue;
+        }
 #define VMP_CASE(db, kt)                                                                        \
     if (DB == db && KT == kt) {                                                                 \
         if (guard) VMP_XP(db, kt, true, 2, 0, 0);                                               \
@@ -1036,7 +1058,7 @@ int32_t vmp_pca_tiled_doubles(int32_t D, int32_t K, int64_t N, int64_t *y_double
     vmp_pca_layout L;
     fill_layout(D, K, &L);
     const int64_t ntiles = (N + TN - 1) / TN;
-    if (y_doubles) *y_doubles = ntiles * L.DP * TN;
+    if (y_doubles) *y_doubles = ntiles * (L.DP + (pca_interleave() ? L.KP : 0)) * TN;
     if (x_doubles) *x_doubles = ntiles * L.KP * TN;
     return VMP_OK;
 }
@@ -1055,7 +1077,8 @@ int32_t vmp_pca_tile_y(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, in
     if (ntiles == 0) return VMP_OK;
     int64_t g = ntiles < (int64_t)ctx->num_cu * 16 ? ntiles : (int64_t)ctx->num_cu * 16;
     hipLaunchKernelGGL(pca_tile_kernel<true>, dim3((unsigned)g), dim3(NT), 0, ctx->stream,
-                       const_cast<double *>(Y), ldy, N, D, (int)L.DP, Yt, ntiles);
+                       const_cast<double *>(Y), ldy, N, D, (int)L.DP, Yt, ntiles,
+                       (int64_t)(L.DP + (pca_interleave() ? L.KP : 0)) * TN);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -1075,12 +1098,14 @@ int32_t vmp_pca_tile_x(vmp_ctx *ctx, int32_t to_tiled, double *X, int64_t ldx, i
     const int64_t ntiles = (N + TN - 1) / TN;
     if (ntiles == 0) return VMP_OK;
     int64_t g = ntiles < (int64_t)ctx->num_cu * 16 ? ntiles : (int64_t)ctx->num_cu * 16;
+    // interleaved layout: Xt points at the <x> rows of tile 0 inside the [tile][DP + KP][32] array
+    const int64_t xts = (int64_t)(L.KP + (pca_interleave() ? L.DP : 0)) * TN;
     if (to_tiled)
         hipLaunchKernelGGL(pca_tile_kernel<true>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, X,
-                           ldx, N, K, (int)L.KP, Xt, ntiles);
+                           ldx, N, K, (int)L.KP, Xt, ntiles, xts);
     else
         hipLaunchKernelGGL(pca_tile_kernel<false>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, X,
-                           ldx, N, K, (int)L.KP, Xt, ntiles);
+                           ldx, N, K, (int)L.KP, Xt, ntiles, xts);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

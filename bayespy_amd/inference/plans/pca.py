@@ -58,6 +58,9 @@ class HIPKernels:
         self.rt = rt
         self.lib = rt.lib
         self.ctx = rt.ctx
+        if self.interleave:
+            self.x_tiles = True
+            self.rt.check(self.lib.vmp_tune_set(b'pca_interleave', 1))
 
     def layout(self, D, K):
         L = _lib.PCALayout()
@@ -120,6 +123,10 @@ class HIPKernels:
     # (opt-in: measured 2.29 / 2.39 ms against 2.21 / 2.33 ms for the row-major <x> with the
     # placement trials of both, profiles/r03/placement_trials_ab.txt)
     x_tiles = os.environ.get('BAYESPY_AMD_PCA_XTILES', '0') == '1'
+    # round 4 experiment: ONE array [tile][DP + KP][32] for the data and <x> (tune key
+    # "pca_interleave"): the relative placement of the read and the write stream is then fixed by
+    # construction -- no placement trial, no second big allocation
+    interleave = os.environ.get('BAYESPY_AMD_PCA_INTERLEAVE', '0') == '1'
 
     def tiled_x_doubles(self, D, K, N):
         n = ctypes.c_int64()
@@ -597,12 +604,17 @@ class PCAPlan:
                 if self.plate_layout == 'tiled':
                     if self.Yt is None:
                         self.Yt = k.tile_y(self.Yd, self.ldy, N, D, K)
-                        if getattr(k, 'x_tiles', False):
+                        if getattr(k, 'interleave', False):
+                            # <x> of a tile sits behind its data rows in the same array
+                            self._Xt = self.Yt[int(L.DP) * 32:]
+                            self._Xrows = None
+                        elif getattr(k, 'x_tiles', False):
                             # from here on <x> lives tile-major; the row-major view (self.Xd)
                             # is formed on demand (_x_rows)
                             self._Xt = rt.empty(k.tiled_x_doubles(D, K, N))
                             self._Xrows = None
-                        self._place_plate_arrays()
+                        if not getattr(k, 'interleave', False):
+                            self._place_plate_arrays()
                     if self._Xt is not None:
                         k.xpass_tiled(self.Yt, N, D, K, self._Xt, self.ldx, self.state, self.ws,
                                       x_tiled=True)
@@ -635,6 +647,14 @@ class PCAPlan:
         k = self.kernels
         self.rt.sync_stream()
         self.Yt = k.tile_y(self.Yd, self.ldy, self.N, self.D, self.K)
+        if getattr(k, 'interleave', False):
+            # the current row-major <x> moves into the <x> rows of the interleaved array
+            self._Xt = self.Yt[int(self.layout.DP) * 32:]
+            k.tile_x(True, self._Xrows, self.ldx, self.N, self.D, self.K, self._Xt)
+            self._Xrows = None
+            self._x_form, self._xrows_valid = 'tiled', False
+            self.placement = None
+            return
         if getattr(k, 'x_tiles', False):
             self._Xt = self.rt.empty(k.tiled_x_doubles(self.D, self.K, self.N))
         self._place_plate_arrays(keep_x=True)
