@@ -838,6 +838,12 @@ def attach_cpu(Q, stats=None):
                'MaskedPCAPlan': CPUMaskedKernels}
     rt = Runtime(device='cpu')
     for p in Q.plans:
+        if type(p).__name__ == 'MaskedLSSMPlan':
+            # the double of this block is its own device code compiled for the host
+            import host_build
+            from bayespy_amd.inference.plans.lssm_masked import MaskedLSSMKernels
+            p._rt, p._kernels = rt, MaskedLSSMKernels(rt, lib=host_build.lssmm_host())
+            continue
         p._rt, p._kernels = rt, doubles[type(p).__name__](rt)
         if stats is not None and type(p).__name__ == 'PCAPlan':
             p.stats = stats

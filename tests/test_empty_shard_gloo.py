@@ -54,6 +54,13 @@ def _worker(rank, world, port, which, out_dir):
         n = g['y'].shape[0] if own else 0
         Q = _build(np.ascontiguousarray(g['y'][:n]), g['lab0'][:n], 4, shard=True)
         ref, iters = g['L'], int(g['n_iter'])
+    elif which == 'lssm_masked':
+        from test_lssm_masked_host import build
+        g = np.load(os.path.join(GOLDEN, 'lssm_masked.npz'))
+        b = 5 if own else 0
+        Q, _ = build(np.ascontiguousarray(g['mb_y'][:, :b]), np.ascontiguousarray(g['mb_mask'][:, :b]),
+                     np.ascontiguousarray(g['mb_x0'][:b]), g['mb_c0'], b, True, shard=True, host=False)
+        ref, iters = g['mb_L'], len(g['mb_L'])
     else:
         from test_lssm_plan_host import _build
         g = np.load(os.path.join(GOLDEN, 'lssm.npz'))
@@ -68,7 +75,7 @@ def _worker(rank, world, port, which, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('which', ['pca', 'masked', 'gmm', 'lssm'])
+@pytest.mark.parametrize('which', ['pca', 'masked', 'gmm', 'lssm', 'lssm_masked'])
 def test_a_rank_with_an_empty_shard(tmp_path, which):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), which, str(tmp_path)), nprocs=world, join=True)
