@@ -207,6 +207,24 @@ def main():
         res['A_u0_rot'] = np.asarray(A.u[0])
         res['X_u0_rot'] = np.asarray(X.u[0])
         res['lo'], res['hi'] = lo, hi
+    elif case == 'lssm_masked':
+        # the state-space block with one mask per sequence (live-reference trace 'mb' of
+        # lssm_masked.npz) on the DEVICE kernels, the sequences split 2 + 3 over the ranks: the set-up
+        # counts and the raw plate sums of every X pass are all-reduced
+        from test_lssm_masked_host import build
+        g = np.load(os.path.join(golden, 'lssm_masked.npz'))
+        y, mask, x0, c0 = g['mb_y'], g['mb_mask'], g['mb_x0'], g['mb_c0']
+        B = y.shape[1]
+        lo, hi = (0, 2) if rank == 0 else (2, B)
+        Q, track = build(np.ascontiguousarray(y[:, lo:hi]), np.ascontiguousarray(mask[:, lo:hi]),
+                         np.ascontiguousarray(x0[lo:hi]), c0, hi - lo, True, shard=True, host=False)
+        res['engine'] = type(Q.plans[0]).__name__
+        n = len(g['mb_L'])
+        Q.update(repeat=n, verbose=False)
+        res['L'] = np.array(Q.L[:n])
+        res['C_u0'], res['A_u0'] = np.asarray(track['C'].u[0]), np.asarray(track['A'].u[0])
+        res['X_u0'] = np.asarray(track['X'].u[0])
+        res['lo'], res['hi'] = lo, hi
     elif case == 'hmm':
         # a batch of hidden Markov chains (case 3 of tests/models.py run_markov_chain_cases)
         # with the chain plate split over the ranks; emission and transition parameters are

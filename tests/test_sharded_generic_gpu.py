@@ -155,3 +155,18 @@ def test_sharded_hidden_markov_chains_match_reference(golden_dir, tmp_path):
         lo, hi = int(r['lo']), int(r['hi'])
         np.testing.assert_allclose(r['Z_u0'], g['hmm3_Z_u_0'][lo:hi], rtol=1e-7, atol=1e-12)
     assert np.array_equal(r0['m_u0'], r1['m_u0'])
+
+
+def test_sharded_masked_lssm_matches_reference(golden_dir, tmp_path):
+    """The state-space block with array masks on the device kernels, the sequence plate split
+    2 + 3 over two ranks: the unsharded live-reference trace on both ranks, each rank's own <x>."""
+    r0, r1 = _launch('lssm_masked', golden_dir, tmp_path, 29551)
+    g = np.load(os.path.join(golden_dir, 'lssm_masked.npz'))
+    for r in (r0, r1):
+        assert str(r['engine']) == 'MaskedLSSMPlan'
+        np.testing.assert_allclose(r['L'], g['mb_L'], rtol=1e-9)
+        np.testing.assert_allclose(r['C_u0'], g['mb_C_u0'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(r['A_u0'], g['mb_A_u0'], rtol=1e-7, atol=1e-9)
+        lo, hi = int(r['lo']), int(r['hi'])
+        np.testing.assert_allclose(r['X_u0'], g['mb_X_u0'][lo:hi], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(r0['C_u0'], r1['C_u0'])
