@@ -217,6 +217,16 @@ def _gaussian_gradient(rg, u, ndim, shape):
 # ---------------------------------------------------------------------------
 # families: the five VMP formulas per node type
 # ---------------------------------------------------------------------------
+class Terms:
+    """A message entry (or a bound term) that is a SUM of products: ``[(coef, [factor, ...]), ...]``.
+    The router plate-sums every product with ONE fused launch and adds the (parent-sized) results,
+    so e.g. the message of an observed GaussianARD to its precision, sum_n (x m - q / 2 - x^2 / 2),
+    is three reductions over the data instead of a plates-sized temporary and its reduction."""
+
+    def __init__(self, terms):
+        self.terms = list(terms)
+
+
 class Family:
 
     def __init__(self, node):
@@ -433,8 +443,29 @@ class GaussianARDFamily(Family):
             return [m0, fuse(lambda a_: -0.5 * a_, a)]
         m, m2 = self._mu(up)
         x2 = _diag2(u[1], self.ndim) if self.ndim else u[1]
+        if self.ndim == 0 and all(isinstance(a, DArray) for a in (x, m, m2, x2)):
+            # x m - <m^2> / 2 - <x^2> / 2 as three plate sums (no plates-sized temporary)
+            return [Terms([(1.0, [x, m]), (-0.5, [m2]), (-0.5, [x2])]), 0.5]
         m0 = fuse(lambda x_, m_, q, x2_: x_ * m_ - 0.5 * q - 0.5 * x2_, x, m, m2, x2)
         return [m0, 0.5]
+
+    # the message to a parent does not depend on that parent's own moments (conjugacy): the
+    # router may reuse it while everything else it reads is unchanged
+    message_independent_of_target = True
+
+    def observed_bound_terms(self, u, up):
+        """cgf_from_parents + f + phi_p . u of a fully observed scalar-valued node as a sum of
+        products over its plates (expfamily.py:400-480): -a <m^2>/2 + log a / 2 - log(2 pi)/2 +
+        a m x - a x^2 / 2.  None when this form does not apply."""
+        if self.ndim != 0 or self.mu_gg:
+            return None
+        m, m2 = self._mu(up)
+        a, loga = up[1]
+        x, x2 = u
+        ops = (m, m2, a, loga, x, x2)
+        if not all(isinstance(o, DArray) for o in ops):
+            return None
+        return [(-0.5, [a, m2]), (0.5, [loga]), (-0.5 * LOG2PI, []), (1.0, [a, m, x]), (-0.5, [a, x2])]
 
 
 class GaussianFamily(Family):
@@ -1738,6 +1769,20 @@ class GenericPlan:
             return msgs
         u = self._moments(child)
         up = self._parent_moments(child)
+        # A message is a function of the child's moments and of the OTHER parents' moments
+        # (conjugacy): while those arrays are the same objects the last answer stands -- e.g. the
+        # message of the observed node of a PCA model to F, asked for once by W.update() and once
+        # by X.update() of every iteration (two (D, N) passes each time).
+        ckey = None
+        if getattr(fam, 'message_independent_of_target', False) \
+                and os.environ.get('BAYESPY_AMD_DET_CACHE', '1') != '0':
+            deps = list(u) + [a for j, pm in enumerate(up) if j != index for a in pm]
+            if all(isinstance(a, DArray) for a in deps):
+                self._update_masks()
+                ckey = (tuple(id(a) for a in deps), id(self._dev_masks), r)
+                hit = self.__dict__.setdefault('_msg_cache', {}).get((id(child), index))
+                if hit is not None and hit[0] == ckey:
+                    return list(hit[2])
         msgs = fam.message_to_parent(index, u, up)
         plates_self = tuple(fam.plates_to_parent(index))
         mask, _ = self._mask_factor(
@@ -1748,19 +1793,28 @@ class GenericPlan:
             if m is None:
                 out.append(None)
                 continue
-            factors = list(m) if isinstance(m, tuple) else [_arr(m)]
             nd = len(parent.dims[i])
-            mshape = broadcasted_shape(*[f.shape for f in factors])
-            dims = broadcasted_shape(mshape[len(mshape) - nd:], parent.dims[i]) if nd else ()
-            from_shape = plates_self + dims
             to_shape = parent.plates + parent.dims[i]
-            if mask is not None:
-                factors.append(_trail(mask, nd))
-            msg = misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
-                                              from_plates=from_shape, ndim=0)
-            if r != 1.0:
-                msg = fuse(lambda m_, r_=r: m_ * r_, msg)
+            terms = m.terms if isinstance(m, Terms) else \
+                [(1.0, list(m) if isinstance(m, tuple) else [_arr(m)])]
+            msg = None
+            for coef, factors in terms:
+                factors = list(factors)
+                mshape = broadcasted_shape(*[f.shape for f in factors])
+                dims = broadcasted_shape(mshape[len(mshape) - nd:], parent.dims[i]) if nd else ()
+                from_shape = plates_self + dims
+                if mask is not None:
+                    factors.append(_trail(mask, nd))
+                t = misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
+                                                from_plates=from_shape, ndim=0)
+                c = float(coef) * r
+                if msg is None:
+                    msg = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
+                else:
+                    msg = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, msg, t)
             out.append(msg)
+        if ckey is not None:
+            self._msg_cache[(id(child), index)] = (ckey, (u, up), list(out))    # keeps the keyed arrays alive
         return out
 
     @property
@@ -1874,6 +1928,12 @@ class GenericPlan:
         # multiplied by T (expfamily.py:403-411)
         T = 1.0 / float(getattr(node, 'annealing', 1.0))
         partial = st.observed and st.partial
+        if st.observed and not partial and hasattr(fam, 'observed_bound_terms'):
+            # a fully observed node: every part of its term is a product of moment arrays --
+            # plate-summed product by product, no plates-sized temporaries
+            terms = fam.observed_bound_terms(st.u, up)
+            if terms is not None:
+                return self._finish_bound(node, terms, ignore_masked)
         if partial:
             # np.where(observed, f, -T g) and phi_q zeroed on the observed plates
             # (expfamily.py:431-466): the latent plates of the node count like any latent node
@@ -1913,21 +1973,31 @@ class GenericPlan:
                 t = fuse(lambda pp, pq, u, T_=T: da.where_nonzero(u, pp - T_ * pq) * u,
                          _arr(phi_p[i]), _arr(st.phi[i]), _arr(st.u[i]))
             L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
-        factors = [L]
+        return self._finish_bound(node, [(1.0, [L])], ignore_masked)
+
+    def _finish_bound(self, node, terms, ignore_masked):
+        """sum over the node's plates of sum_k coef_k prod(factors_k), masked, completed over the
+        ranks for a sharded node, with the plate multiplier (expfamily.py:470-480)."""
         mask, any_active = self._mask_factor((id(node), 'self'), lambda: self._mask_array(node))
         if not ignore_masked:
             mask, any_active = None, True
-        if mask is not None:
-            factors.append(mask)
         sharded = self._is_sharded(node)
         if not any_active and not sharded:
             return None, 0.0
-        tot = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
+        tot = None
+        for coef, factors in terms:
+            factors = list(factors) if factors else [_ones(())]
+            if mask is not None:
+                factors.append(mask)
+            t = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
+            c = float(coef)
+            if tot is None:
+                tot = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
+            else:
+                tot = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, tot, t)
         if sharded:
-            # the node's term is a sum over its plates (expfamily.py:470-480): complete it
             tot = fuse(lambda x: x + 0.0, tot) if any_active else DArray.zeros(())
             self.rt.all_reduce_sum_(tot.t)
-        # ... times the plate multiplier (expfamily.py:475,480)
         return tot, float(np.prod(node.plates_multiplier))
 
     @_operation
@@ -2044,8 +2114,19 @@ class GenericPlan:
             raise NotImplementedError('rotation of %s' % node.name)
         st = self._ensure(node)
         K = node.dims[0][-1]
-        xx = misc.sum_multiply_to_plates(_arr(st.u[1]), to_plates=(K, K),
-                                         from_plates=node.plates + (K, K), ndim=0)
+        if isinstance(st.u[1], FactoredMoment) and st.u[1]._dense is None:
+            # (plates sharing the covariance) x Cov + sum over the plates of <x><x>^T
+            fm = st.u[1]
+            x = fm.mean
+            xx = fuse(lambda a, b: a + b,
+                      misc.sum_multiply_to_plates(fm.cov, to_plates=(K, K),
+                                                  from_plates=node.plates + (K, K), ndim=0),
+                      misc.sum_multiply_to_plates(x.reshape(x.shape + (1,)),
+                                                  x.reshape(x.shape[:-1] + (1, K)), to_plates=(K, K),
+                                                  from_plates=node.plates + (K, K), ndim=0))
+        else:
+            xx = misc.sum_multiply_to_plates(_arr(st.u[1]), to_plates=(K, K),
+                                             from_plates=node.plates + (K, K), ndim=0)
         nplates = float(np.prod(node.plates))
         if self._is_sharded(node):
             xx = fuse(lambda x: x + 0.0, xx)
@@ -2079,7 +2160,12 @@ class GenericPlan:
         else:
             phi = None                       # delta moments (initialize_from_value): no parameters
         st.phi = phi
-        st.u = [linalg.mvdot(Rd, _arr(st.u[0]))] + [rot2(Rd, u, Rt) for u in st.u[1:]]
+        if not chain and isinstance(st.u[1], FactoredMoment) and st.u[1]._dense is None:
+            # the factors rotate separately: Cov <- R Cov R^T, <x> <- R <x>
+            u0 = linalg.mvdot(Rd, _arr(st.u[0]))
+            st.u = [u0, FactoredMoment(rot2(Rd, st.u[1].cov, Rt), u0, node.ndim)]
+        else:
+            st.u = [linalg.mvdot(Rd, _arr(st.u[0]))] + [rot2(Rd, u, Rt) for u in st.u[1:]]
         scale = float(node.N) if chain else 1.0
         if isinstance(st.g, DArray):
             st.g = fuse(lambda g: g - scale * float(logdetR), st.g)
