@@ -443,8 +443,10 @@ class GaussianARDFamily(Family):
             return [m0, fuse(lambda a_: -0.5 * a_, a)]
         m, m2 = self._mu(up)
         x2 = _diag2(u[1], self.ndim) if self.ndim else u[1]
-        if self.ndim == 0 and all(isinstance(a, DArray) for a in (x, m, m2, x2)):
-            # x m - <m^2> / 2 - <x^2> / 2 as three plate sums (no plates-sized temporary)
+        if self.ndim == 0 and getattr(self, '_terms_ok', False) \
+                and all(isinstance(a, DArray) for a in (x, m, m2, x2)):
+            # x m - <m^2> / 2 - <x^2> / 2 as three plate sums (no plates-sized temporary); only
+            # for the engine's own call -- a wrapping family (mixture, gate) indexes the arrays
             return [Terms([(1.0, [x, m]), (-0.5, [m2]), (-0.5, [x2])]), 0.5]
         m0 = fuse(lambda x_, m_, q, x2_: x_ * m_ - 0.5 * q - 0.5 * x2_, x, m, m2, x2)
         return [m0, 0.5]
@@ -1783,7 +1785,11 @@ class GenericPlan:
                 hit = self.__dict__.setdefault('_msg_cache', {}).get((id(child), index))
                 if hit is not None and hit[0] == ckey:
                     return list(hit[2])
-        msgs = fam.message_to_parent(index, u, up)
+        fam._terms_ok = True
+        try:
+            msgs = fam.message_to_parent(index, u, up)
+        finally:
+            fam._terms_ok = False
         plates_self = tuple(fam.plates_to_parent(index))
         mask, _ = self._mask_factor(
             (id(child), index),
