@@ -30,7 +30,7 @@ MAX_OPS, MAX_CONSTS, MAX_IN, MAX_DIMS = 48, 8, 6, 8
 class DArray:
     """fp64 device array (possibly a broadcast / strided view)."""
 
-    __slots__ = ('t',)
+    __slots__ = ('t', '__weakref__')
     __array_priority__ = 1000
 
     def __init__(self, t):

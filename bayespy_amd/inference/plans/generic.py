@@ -106,6 +106,43 @@ class FactoredMoment(DArray):
         return int(np.prod(self.shape))
 
 
+class LazySum(DArray):
+    """A plates-sized array known as a SUM of products of smaller or already existing arrays,
+    ``[(coef, [factor, ...]), ...]`` -- e.g. <f^2> = <f>^2 + x^T Cov_w x + w^T Cov_x w + tr(Cov_w Cov_x)
+    of a dot product of factored parents, or tau * y of an observed node's message.  Consumers that
+    only plate-sum it (the message to a precision, the lower-bound term) or contract it
+    (SumMultiply messages) read the factors; anything else sees an ordinary device array: ``.t``
+    evaluates ``dense()`` on first use."""
+    __slots__ = ('terms', '_shape', '_make', '_dense')
+
+    def __init__(self, terms, shape, dense):
+        self.terms, self._shape, self._make = list(terms), tuple(shape), dense
+        self._dense = None
+
+    @property
+    def t(self):
+        if self._dense is None:
+            self._dense = self._make().t
+            self._make = None
+        return self._dense
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return len(self._shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self._shape))
+
+
+def _is_lazy(x):
+    return isinstance(x, LazySum) and x._dense is None
+
+
 def _factored_min_plates():
     return int(os.environ.get('BAYESPY_AMD_FACTORED_MIN_PLATES', '2'))
 
@@ -217,6 +254,26 @@ def _gaussian_gradient(rg, u, ndim, shape):
 # ---------------------------------------------------------------------------
 # families: the five VMP formulas per node type
 # ---------------------------------------------------------------------------
+class _Deferred:
+    def __init__(self, make):
+        self.make = make
+
+
+class _LazyList(list):
+    """A list whose _Deferred entries are evaluated when first read."""
+
+    def __getitem__(self, i):
+        v = list.__getitem__(self, i)
+        if isinstance(v, _Deferred):
+            v = v.make()
+            list.__setitem__(self, i, v)
+        return v
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
 class Terms:
     """A message entry (or a bound term) that is a SUM of products: ``[(coef, [factor, ...]), ...]``.
     The router plate-sums every product with ONE fused launch and adds the (parent-sized) results,
@@ -436,7 +493,11 @@ class GaussianARDFamily(Family):
                       x, tm, tmm, u[1], t)
             return [m0, 0.5]
         if index == 0:
-            m0 = fuse(lambda a_, x_: a_ * x_, a, x)
+            if getattr(self, '_terms_ok', False) and isinstance(a, DArray) and isinstance(x, DArray):
+                m0 = LazySum([(1.0, [a, x])], broadcasted_shape(a.shape, x.shape),
+                             lambda: fuse(lambda a_, x_: a_ * x_, a, x))
+            else:
+                m0 = fuse(lambda a_, x_: a_ * x_, a, x)
             if self.mu_ndim > 0:
                 d = fuse(lambda a_, o: -0.5 * a_ * o, a, _ones(self.mu_shape))
                 return [m0, misc.diag(d, ndim=self.mu_ndim)]
@@ -1292,7 +1353,20 @@ class SumMultiplyFamily:
             terms.append(('t', misc.contract([T, xk], [t_out, lk], out1, sizes, compress=pl)))
         arrs = [t[1] for t in terms if t[0] == 't']
         if any(t[0] == 'sq' for t in terms):
-            if nk == 0:
+            if nk == 0 and os.environ.get('BAYESPY_AMD_LAZY_SUMS', '1') != '0':
+                sq = f0
+                shape = broadcasted_shape(f0.shape, *[a.shape for a in arrs])
+
+                def dense(sq=sq, arrs=arrs):
+                    if len(arrs) == 1:
+                        return fuse(lambda f, a: f * f + a, sq, arrs[0])
+                    if len(arrs) == 2:
+                        return fuse(lambda f, a, b: f * f + a + b, sq, *arrs)
+                    if len(arrs) == 3:
+                        return fuse(lambda f, a, b, c: f * f + a + b + c, sq, *arrs)
+                    return self._add_terms([fuse(lambda f: f * f, sq)] + arrs)
+                f1 = LazySum([(1.0, [sq, sq])] + [(1.0, [a]) for a in arrs], shape, dense)
+            elif nk == 0:
                 sq = f0
                 if len(arrs) == 1:
                     f1 = fuse(lambda f, a: f * f + a, sq, arrs[0])
@@ -1359,7 +1433,13 @@ class SumMultiplyFamily:
             lm = pl + ['k%d' % k for k in n.out_keys]
             if second:
                 lm = lm + ['K%d' % k for k in n.out_keys]
-            base_ops, base_labs = [m], [lm[len(lm) - m.ndim:]]
+            if _is_lazy(m) and len(m.terms) == 1 and m.terms[0][0] == 1.0 \
+                    and len(m.terms[0][1]) + len(ups) + (mask is not None) <= 6:
+                # a product of arrays (tau * y): its factors join the contraction
+                base_ops = list(m.terms[0][1])
+                base_labs = [lm[len(lm) - f.ndim:] for f in base_ops]
+            else:
+                base_ops, base_labs = [m], [lm[len(lm) - m.ndim:]]
             if mask is not None:
                 base_ops.append(mask)
                 base_labs.append(pl[npl - mask.ndim:])
@@ -1655,17 +1735,25 @@ class GenericPlan:
             cache[id(node)] = (key, ups, out)          # `ups` keeps the keyed arrays alive
         return out
 
-    def _parent_moments(self, node):
+    def _parent_moments(self, node, skip=None):
+        """Moments of the parents; ``skip``: the index of a parent whose moments the caller does
+        not read (the target of a message, by conjugacy) -- they are evaluated only if somebody
+        indexes them after all."""
         fam = self.family[id(node)]
-        out = []
-        for i, p in enumerate(node.parents):
+
+        def one(i, p):
             if isinstance(p, Constant):
                 key = (id(node), i)
                 if key not in self._const_cache:
                     self._const_cache[key] = fam.constant_moments(i, p.value)
-                out.append(self._const_cache[key])
+                return self._const_cache[key]
+            return self._moments(p)
+        out = _LazyList()
+        for i, p in enumerate(node.parents):
+            if i == skip and not isinstance(p, Constant):
+                out.append(_Deferred(lambda i=i, p=p: one(i, p)))
             else:
-                out.append(self._moments(p))
+                out.append(one(i, p))
         return out
 
     # -- masks (node.py:457-526) -----------------------------------------------------------
@@ -1770,15 +1858,15 @@ class GenericPlan:
                         m, to_plates=parent.plates + dims, from_plates=own + dims, ndim=0)
             return msgs
         u = self._moments(child)
-        up = self._parent_moments(child)
+        indep = getattr(fam, 'message_independent_of_target', False)
+        up = self._parent_moments(child, skip=index if indep else None)
         # A message is a function of the child's moments and of the OTHER parents' moments
         # (conjugacy): while those arrays are the same objects the last answer stands -- e.g. the
         # message of the observed node of a PCA model to F, asked for once by W.update() and once
         # by X.update() of every iteration (two (D, N) passes each time).
         ckey = None
-        if getattr(fam, 'message_independent_of_target', False) \
-                and os.environ.get('BAYESPY_AMD_DET_CACHE', '1') != '0':
-            deps = list(u) + [a for j, pm in enumerate(up) if j != index for a in pm]
+        if indep and os.environ.get('BAYESPY_AMD_DET_CACHE', '1') != '0':
+            deps = list(u) + [a for j in range(len(up)) if j != index for a in up[j]]
             if all(isinstance(a, DArray) for a in deps):
                 self._update_masks()
                 ckey = (tuple(id(a) for a in deps), id(self._dev_masks), r)
@@ -1801,7 +1889,7 @@ class GenericPlan:
                 continue
             nd = len(parent.dims[i])
             to_shape = parent.plates + parent.dims[i]
-            terms = m.terms if isinstance(m, Terms) else \
+            terms = m.terms if isinstance(m, Terms) or _is_lazy(m) else \
                 [(1.0, list(m) if isinstance(m, tuple) else [_arr(m)])]
             msg = None
             for coef, factors in terms:
@@ -1811,7 +1899,9 @@ class GenericPlan:
                 from_shape = plates_self + dims
                 if mask is not None:
                     factors.append(_trail(mask, nd))
-                t = misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
+                t = self._plate_sum(factors, to_shape, from_shape) \
+                    if isinstance(m, Terms) or _is_lazy(m) else \
+                    misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
                                                 from_plates=from_shape, ndim=0)
                 c = float(coef) * r
                 if msg is None:
@@ -1927,8 +2017,6 @@ class GenericPlan:
         st = self._ensure(node)
         fam = self.family[id(node)]
         up = self._parent_moments(node)
-        phi_p = fam.phi_from_parents(up)
-        L = _arr(fam.cgf_from_parents(up))
         closed = None
         # annealing temperature: the entropy part of the term, i.e. phi and g of q, is
         # multiplied by T (expfamily.py:403-411)
@@ -1940,6 +2028,8 @@ class GenericPlan:
             terms = fam.observed_bound_terms(st.u, up)
             if terms is not None:
                 return self._finish_bound(node, terms, ignore_masked)
+        phi_p = fam.phi_from_parents(up)
+        L = _arr(fam.cgf_from_parents(up))
         if partial:
             # np.where(observed, f, -T g) and phi_q zeroed on the observed plates
             # (expfamily.py:431-466): the latent plates of the node count like any latent node
@@ -1981,6 +2071,46 @@ class GenericPlan:
             L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
         return self._finish_bound(node, [(1.0, [L])], ignore_masked)
 
+    def _plate_sum(self, factors, to_plates, from_plates):
+        """sum over the plates of prod(factors), remembered while the factor arrays live: the
+        same sums feed a node's message to its precision parent and its lower-bound term
+        (sum x <m>, sum <m^2>, sum x^2 of an observed Gaussian node), and the ones over constants
+        never change.  Plate-free factors multiply the sum afterwards so that they do not key it."""
+        import weakref
+        factors = list(factors)
+        for i, f in enumerate(factors):
+            if _is_lazy(f):
+                # a sum of products among the factors: one plate sum per product
+                rest = factors[:i] + factors[i + 1:]
+                tot = None
+                for coef, fs in f.terms:
+                    t = self._plate_sum(rest + list(fs), to_plates, from_plates)
+                    c = float(coef)
+                    if tot is None:
+                        tot = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
+                    else:
+                        tot = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, tot, t)
+                return tot
+        big = [f for f in factors if f.size > 1]
+        small = [f for f in factors if f.size <= 1]
+        if not big:
+            big, small = list(factors), []
+        big.sort(key=id)
+        key = (tuple(id(f) for f in big), tuple(to_plates), tuple(from_plates))
+        cache = self.__dict__.setdefault('_sum_cache', {})
+        hit = cache.get(key)
+        if hit is not None and all(r() is f for r, f in zip(hit[0], big)):
+            t = hit[1]
+        else:
+            t = misc.sum_multiply_to_plates(*big, to_plates=tuple(to_plates),
+                                            from_plates=tuple(from_plates), ndim=0)
+            for k in [k for k, v in cache.items() if any(r() is None for r in v[0])]:
+                del cache[k]
+            cache[key] = ([weakref.ref(f) for f in big], t)
+        for f in small:
+            t = fuse(lambda t_, s_: t_ * s_, t, f.reshape(()))
+        return t
+
     def _finish_bound(self, node, terms, ignore_masked):
         """sum over the node's plates of sum_k coef_k prod(factors_k), masked, completed over the
         ranks for a sharded node, with the plate multiplier (expfamily.py:470-480)."""
@@ -1995,7 +2125,7 @@ class GenericPlan:
             factors = list(factors) if factors else [_ones(())]
             if mask is not None:
                 factors.append(mask)
-            t = misc.sum_multiply_to_plates(*factors, to_plates=(), from_plates=node.plates, ndim=0)
+            t = self._plate_sum(factors, (), node.plates)
             c = float(coef)
             if tot is None:
                 tot = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
