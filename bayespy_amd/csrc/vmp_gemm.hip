@@ -157,15 +157,163 @@ gemm_kernel(GemmArgs g)
     }
 }
 
+// K-long contractions with a small output (ceil(M/16) * ceil(N/16) <= 4 blocks of 16 x 16, e.g. the
+// plate sums  sum_n <x_n><x_n>^T  and  sum_n y_dn <x_n>^T  of a PCA model with N = 1e6): the 64 x 64
+// tile above would run 1/16 .. 1/4 full and read with a quarter of its lanes.  Here every wavefront
+// owns a K slice and keeps the whole output in MT x NB accumulators; operands go global -> registers:
+// lane (l15, l4) holds A[16 i + l15][kb + 4 l4 + j] and B[kb + 4 l4 + j][16 n + l15], j = 0..3 -- the
+// instruction contracts lane group l4 of A with lane group l4 of B, so any assignment of k's to
+// (l4, j) that is the same on both sides is valid, and this one gives a lane four consecutive k's
+// (32 contiguous bytes of a K-contiguous operand) and sixteen consecutive m's or n's across l15
+// (a 128-byte line of an M- or N-contiguous operand).  The four wavefronts of a workgroup meet in LDS
+// in fixed order, the workgroups through the partial buffer and gemm_finish_kernel: deterministic.
+template <int MT, int NB>
+__global__ void __launch_bounds__(NT)
+gemm_skinny_kernel(GemmArgs g)
+{
+    __shared__ double red[(NT / 64 - 1) * MT * NB * 256];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, l15 = l & 15, l4 = l >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * (NT / 64) + w;
+    const int64_t k_begin = gw * g.kchunk;
+    const int64_t k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
+    const double *__restrict__ A = g.A;
+    const double *__restrict__ B = g.B;
+    v4f64 acc[MT][NB];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[i][n] = v4f64{0.0, 0.0, 0.0, 0.0};
+    int64_t arow[MT], bcol[NB];
+    bool aok[MT], bok[NB];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        aok[i] = 16 * i + l15 < g.M;
+        arow[i] = aok[i] ? (int64_t)(16 * i + l15) * g.a_ms : 0;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        bok[n] = 16 * n + l15 < g.N;
+        bcol[n] = bok[n] ? (int64_t)(16 * n + l15) * g.b_ns : 0;
+    }
+    const bool avec = g.a_ks == 1, bvec = g.b_ks == 1;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += 16) {
+        const int64_t kk = k0 + 4 * l4;
+        double a[MT][4], b[NB][4];
+        if (kk + 4 <= k_end) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const double *p = A + arow[i] + kk * g.a_ks;
+                if (avec) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[i][j] = p[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[i][j] = p[j * g.a_ks];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const double *p = B + bcol[n] + kk * g.b_ks;
+                if (bvec) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[n][j] = p[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[n][j] = p[j * g.b_ks];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool kok = kk + j < k_end;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    a[i][j] = kok ? A[arow[i] + (kk + j) * g.a_ks] : 0.0;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    b[n][j] = kok ? B[bcol[n] + (kk + j) * g.b_ks] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!aok[i]) a[i][j] = 0.0;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!bok[n]) b[n][j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[i][n] = mfma_f64(a[i][j], b[n][j], acc[i][n]);
+    }
+    // wavefronts 1..3 hand their blocks to wavefront 0, which adds them in order
+    if (w > 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[(((w - 1) * MT + i) * NB + n) * 256 + r * 64 + l] = acc[i][n][r];
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int ww = 0; ww < NT / 64 - 1; ++ww)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][n][r] += red[((ww * MT + i) * NB + n) * 256 + r * 64 + l];
+    const bool direct = gridDim.x == 1;
+    double *out = direct ? g.C : g.C + (int64_t)blockIdx.x * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = 16 * i + l4 + 4 * r, nn = 16 * n + l15;
+                if (m < g.M && nn < g.N) {
+                    if (direct) out[m * g.c_ms + nn * g.c_ns] = g.scale * acc[i][n][r];
+                    else out[m * g.N + nn] = acc[i][n][r];
+                }
+            }
+}
+
+// Combination of the K slices: 16 outputs per workgroup, 16 lanes per output walk the slices with a
+// stride of 16 (independent loads), then the 16 partial sums are added in order -- the result depends
+// on the number of slices only.  (One thread per output walking all slices was 0.24 ms for 256
+// outputs x 1024 slices: a chain of dependent-latency loads on a single workgroup.)
 __global__ void __launch_bounds__(NT)
 gemm_finish_kernel(GemmArgs g, const double *__restrict__ P, double *__restrict__ C,
                    int64_t nbatch)
 {
+    __shared__ double part[16][17];
     const int64_t total = nbatch * g.M * g.N;
-    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total;
-         e += (int64_t)gridDim.x * NT) {
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (int64_t e0 = (int64_t)blockIdx.x * 16; e0 < total; e0 += (int64_t)gridDim.x * 16) {
+        const int64_t e = e0 + o;
         double s = 0.0;
-        for (int sp = 0; sp < g.nsplit; ++sp) s += P[(int64_t)sp * total + e];
+        if (e < total)
+            for (int sp = sl; sp < g.nsplit; sp += 16) s += P[(int64_t)sp * total + e];
+        part[sl][o] = s;
+        __syncthreads();
+        if (sl == 0 && e < total) {
+            s = part[0][o];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) s += part[q][o];
+        }
+        __syncthreads();
+        if (sl != 0 || e >= total) continue;
         const int64_t bz = e / (g.M * g.N);
         const int64_t r = e - bz * g.M * g.N;
         const int64_t m = r / g.N, n = r - m * g.N;
@@ -209,6 +357,35 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
     if (M == 0 || N == 0 || nbatch == 0) return VMP_OK;
     g.a_ms = a_ms; g.a_ks = a_ks; g.b_ks = b_ks; g.b_ns = b_ns; g.c_ms = c_ms; g.c_ns = c_ns;
     g.A = A; g.B = B; g.scale = scale;
+    hipStream_t s = ctx->stream;
+    // a small output under a long contraction: K slices per wavefront, operands in registers
+    const int64_t mt = (M + 15) / 16, nbk = (N + 15) / 16;
+    if (nbatch == 1 && mt * nbk <= 4 && K >= 4096) {
+        int64_t waves = (int64_t)ctx->num_cu * 8;
+        const int64_t maxw = (K + 63) / 64;
+        if (waves > maxw) waves = maxw;
+        int64_t wgs = (waves + NT / 64 - 1) / (NT / 64);
+        if (wgs > 1 && (!workspace || (size_t)wgs * M * N * sizeof(double) > workspace_bytes))
+            wgs = workspace ? (int64_t)(workspace_bytes / ((size_t)M * N * sizeof(double))) : 1;
+        if (wgs < 1) wgs = 1;
+        waves = wgs * (NT / 64);
+        g.kchunk = (((K + waves - 1) / waves + 15) / 16) * 16;
+        g.nsplit = (int)wgs;
+        g.C = wgs > 1 ? reinterpret_cast<double *>(workspace) : C;
+#define VMP_SKINNY(a, b)                                                                          \
+    if (mt == a && nbk == b)                                                                      \
+        hipLaunchKernelGGL((gemm_skinny_kernel<a, b>), dim3((unsigned)wgs), dim3(NT), 0, s, g)
+        VMP_SKINNY(1, 1); VMP_SKINNY(1, 2); VMP_SKINNY(1, 3); VMP_SKINNY(1, 4);
+        VMP_SKINNY(2, 1); VMP_SKINNY(2, 2); VMP_SKINNY(3, 1); VMP_SKINNY(4, 1);
+#undef VMP_SKINNY
+        if (wgs > 1) {
+            int64_t gb = (M * N + 15) / 16;
+            hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)gb), dim3(NT), 0, s, g,
+                               reinterpret_cast<const double *>(workspace), C, (int64_t)1);
+        }
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        return VMP_OK;
+    }
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     VMP_REQUIRE(ctx, nbatch <= 65535, VMP_ERR_UNSUPPORTED, "too many batch elements (%lld)",
                 (long long)nbatch);
@@ -231,13 +408,12 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
     g.kchunk = ((ksteps + nsplit - 1) / nsplit) * BK;
     if (g.kchunk < BK) g.kchunk = BK;
     g.C = nsplit > 1 ? reinterpret_cast<double *>(workspace) : C;
-    hipStream_t s = ctx->stream;
     const dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)nbatch);
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(NT), 0, s, g);
     if (nsplit > 1) {
         const int64_t total = nbatch * M * N;
-        int64_t gb = (total + NT - 1) / NT;
-        if (gb > (int64_t)ctx->num_cu * 8) gb = (int64_t)ctx->num_cu * 8;
+        int64_t gb = (total + 15) / 16;
+        if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
         hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)gb), dim3(NT), 0, s, g,
                            reinterpret_cast<const double *>(workspace), C, nbatch);
     }

@@ -1247,8 +1247,10 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
     // axes -- also when there are many kept elements (e.g. per-sequence sums over T x D x D),
     // where a thread per output would read with a stride of the whole reduced extent
     const int64_t ws_doubles = workspace ? (int64_t)(workspace_bytes / sizeof(double)) : 0;
-    const bool use_block = (it.nred >= 1024) && (it.nkeep <= ws_doubles) &&
-                           (it.nkeep <= 0x7fffffff);
+    // (a handful of kept elements over 64 .. 1023 products -- tr(A B) of two K x K matrices -- too:
+    // one thread walking them alone is a chain of 256 dependent-latency loads, 0.12 ms)
+    const bool use_block = (it.nred >= 1024 || (it.nred >= 64 && it.nkeep <= 256)) &&
+                           (it.nkeep <= ws_doubles) && (it.nkeep <= 0x7fffffff);
     // column pattern: several kept elements along a dense innermost kept axis
     bool use_column = false;
     if (it.nred >= 512 && it.nk >= 1 && it.ksize[it.nk - 1] >= 4 && it.nkeep <= 65536) {

@@ -66,6 +66,7 @@ class DArray:
         return int(self.t.numel())
 
     def numpy(self):
+        get_runtime().host_access('DArray.numpy')
         return self.t.detach().cpu().numpy().copy()
 
     def __array__(self, dtype=None, copy=None):
@@ -73,6 +74,7 @@ class DArray:
         return a if dtype is None else a.astype(dtype)
 
     def item(self):
+        get_runtime().host_access('DArray.item')
         return float(self.t.reshape(-1)[0].item())
 
     # -- views (stride metadata only) ---------------------------------------------------

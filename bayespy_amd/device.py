@@ -37,6 +37,7 @@ class Runtime:
         self.collective_calls = {'library': 0, 'torch': 0}
         self._op_depth = 0
         self._deferred = []
+        self._capturing = False          # a plan is recording an iteration into a HIP graph
         if self.device.type == 'cuda':
             self.lib = _lib.load()
             ctx = ctypes.c_void_p()
@@ -115,12 +116,20 @@ class Runtime:
         self._comm_state = True
         return True
 
+    def host_access(self, what):
+        """Called where device data meets the host (a read-back, an upload, a collective): while a
+        plan records an iteration into a HIP graph such a step cannot be recorded, and the
+        recording is abandoned BEFORE the HIP call that would invalidate the capture."""
+        if self._capturing:
+            raise GraphCaptureAbort(what)
+
     def all_reduce_sum_(self, tensor):
         """In-place sum over ranks: ``vmp_allreduce_sum_f64`` (RCCL all-reduce over xGMI,
         enqueued on the context's stream by the library).  This is the ONLY data-path
         collective: it stands where the reference sums a message over a plate the parent
         lacks (node.py:650, dot.py:581) and where it sums the per-node lower bound
         (expfamily.py:470-480)."""
+        self.host_access('all_reduce_sum_')
         self._refresh_dist()
         if self._ensure_comm():
             if tensor.numel() == 0:
@@ -195,7 +204,10 @@ class Runtime:
         """Host ndarray (any float dtype) or torch tensor -> fp64 device tensor."""
         torch = self.torch
         if isinstance(array, torch.Tensor):
+            if not array.is_cuda:
+                self.host_access('to_device')
             return array.to(device=self.device, dtype=torch.float64)
+        self.host_access('to_device')
         a = np.array(array, dtype=np.float64, order='C', copy=True)   # keeps 0-d arrays 0-d
         return torch.from_numpy(a).to(self.device)
 
@@ -222,6 +234,7 @@ class Runtime:
     def defer_check(self, flag_tensor, exc_type, message):
         """``flag_tensor``: device tensor, any non-zero element means failure."""
         if self._op_depth == 0:
+            self.host_access('defer_check')
             if bool(flag_tensor.any().item()):
                 raise exc_type(message)
             return
@@ -230,6 +243,7 @@ class Runtime:
     def check_deferred(self):
         if not self._deferred:
             return
+        self.host_access('check_deferred')
         items, self._deferred = self._deferred, []
         flags = self.torch.cat([f for f, _, _ in items]).cpu().numpy()
         for bad, (_, exc_type, message) in zip(flags, items):
@@ -239,6 +253,10 @@ class Runtime:
     def synchronize(self):
         if self.device.type == 'cuda':
             self.torch.cuda.synchronize(self.device)
+
+
+class GraphCaptureAbort(RuntimeError):
+    """An iteration being recorded into a HIP graph needs the host (see Runtime.host_access)."""
 
 
 class _Operation:

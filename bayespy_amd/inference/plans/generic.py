@@ -40,6 +40,7 @@ from ...nodes.mixture import Mixture
 from ...nodes.gaussian_markov_chain import GaussianMarkovChain, MarkovChainToGaussian
 from ...utils import misc, linalg
 from ...utils.shapes import broadcasted_shape, is_shape_subset, multiplier_factor
+from .graph_iter import GraphIteration
 
 LOG2PI = float(np.log(2 * np.pi))
 
@@ -57,6 +58,10 @@ def _arr(x):
         from ...device import get_runtime
         rt = get_runtime()
         return DArray(x.to(device=rt.device, dtype=rt.torch.float64))
+    if isinstance(x, (int, float, np.floating, np.integer)) and len(_CONSTS) < 4096:
+        # numbers that recur every sweep (a constant prior's log-normaliser, ...): uploaded once
+        v = float(x)
+        return _const(('scalar', v), lambda: np.asarray(v, dtype=np.float64))
     return DArray.from_host(np.asarray(x, dtype=np.float64))
 
 
@@ -140,7 +145,8 @@ class LazySum(DArray):
 
 
 def _is_lazy(x):
-    return isinstance(x, LazySum) and x._dense is None
+    # (whether somebody has evaluated the dense form must not change what a consumer computes)
+    return isinstance(x, LazySum)
 
 
 def _factored_min_plates():
@@ -149,7 +155,7 @@ def _factored_min_plates():
 
 def _diag2(xx, nd):
     """diag over the last 2 nd axes of a second moment, factored or dense."""
-    if isinstance(xx, FactoredMoment) and xx._dense is None:
+    if isinstance(xx, FactoredMoment):
         return fuse(lambda c, x: c + x * x, misc.get_diag(xx.cov, ndim=nd), xx.mean)
     return misc.get_diag(xx, ndim=nd)
 
@@ -157,7 +163,7 @@ def _diag2(xx, nd):
 def _inner_second(phi, xx, nd):
     """sum over the last 2 nd axes of phi * <x x^T>."""
     axes = tuple(range(-2 * nd, 0))
-    if isinstance(xx, FactoredMoment) and xx._dense is None:
+    if isinstance(xx, FactoredMoment):
         x = xx.mean
         phi = _arr(phi)
         a = misc.sum_multiply(phi, xx.cov, axis=axes)
@@ -1233,7 +1239,7 @@ class SumMultiplyFamily:
 
     @staticmethod
     def _is_factored(xx):
-        return isinstance(xx, FactoredMoment) and xx._dense is None
+        return isinstance(xx, FactoredMoment)
 
     def _second_choices(self, ups, skip=None):
         """The second-moment operands of the parents as a list of alternatives per parent: a dense
@@ -1419,8 +1425,26 @@ class SumMultiplyFamily:
             keys = ['k%d' % k for k in n.in_keys[index]]
             if second:
                 keys = keys + ['K%d' % k for k in n.in_keys[index]]
-            res = misc.contract(ops, labs, lout + keys, sizes, scale=float(mult))
             final = tuple(final) + tuple(sizes[k] for k in keys)
+            # plate-free factors (tau of the observed child's message) multiply the result when
+            # that is the smaller array, else the smallest operand -- never the (D, N) data
+            ones = [a for a in ops if a.size == 1]
+            if ones and len(ops) - len(ones) >= 1:
+                rest = [(a, ls) for a, ls in zip(ops, labs) if a.size != 1]
+                small = min(range(len(rest)), key=lambda q: rest[q][0].size)
+                nres = int(np.prod(final))
+                if rest[small][0].size < nres:
+                    a0 = rest[small][0]
+                    for s_ in ones:
+                        a0 = fuse(lambda a_, b_: a_ * b_, a0, s_.reshape(()))
+                    rest[small] = (a0, rest[small][1])
+                    ones = []
+                res = misc.contract([a for a, _ in rest], [ls for _, ls in rest], lout + keys,
+                                    sizes, scale=float(mult)).reshape(final)
+                for s_ in ones:
+                    res = fuse(lambda a_, b_: a_ * b_, res, s_.reshape(()))
+                return res
+            res = misc.contract(ops, labs, lout + keys, sizes, scale=float(mult))
             return res.reshape(final)
 
         out = []
@@ -1546,12 +1570,39 @@ def _operation(method):
 
     @functools.wraps(method)
     def wrapped(self, *args, **kwargs):
-        with self.rt.operation():
+        rt = self.rt
+        if rt._op_depth == 0:
+            self._graph_note(method.__name__, args)
+        with rt.operation():
             return method(self, *args, **kwargs)
+    wrapped._notes_graph = True
     return wrapped
 
 
-class GenericPlan:
+def _noting(cls):
+    """Every public operation of the plan reports to the graph bookkeeping (graph_iter.py): an
+    operation outside the recorded sweep decides whether the recorded graph still stands."""
+    import functools
+    for name, fn in list(vars(cls).items()):
+        if name.startswith('_') or not callable(fn) or isinstance(fn, (staticmethod, classmethod,
+                                                                         property)) \
+                or getattr(fn, '_notes_graph', False):
+            continue
+
+        def make(fn):
+            @functools.wraps(fn)
+            def noted(self, *args, **kwargs):
+                if self.rt._op_depth == 0:
+                    self._graph_note(fn.__name__, args)
+                return fn(self, *args, **kwargs)
+            noted._notes_graph = True
+            return noted
+        setattr(cls, name, make(fn))
+    return cls
+
+
+@_noting
+class GenericPlan(GraphIteration):
 
     @staticmethod
     def describe():
@@ -1584,6 +1635,7 @@ class GenericPlan:
             n._plan = self
         self._const_cache = {}
         self._masks_ready = False
+        self._graph_init()
 
     def nodes(self):
         return [n for n in self.all if not isinstance(n, Constant)]
@@ -1801,6 +1853,7 @@ class GenericPlan:
                 n._gmask = m
         self._dev_masks = {}
         self._masks_ready = True
+        self._mask_epoch = getattr(self, '_mask_epoch', 0) + 1
 
     def _any_over_ranks(self, mask):
         rt = self.rt
@@ -1889,6 +1942,10 @@ class GenericPlan:
                 continue
             nd = len(parent.dims[i])
             to_shape = parent.plates + parent.dims[i]
+            if _is_lazy(m) and mask is None and r == 1.0 \
+                    and tuple(m.shape) == tuple(plates_self) + tuple(parent.dims[i]) == tuple(to_shape):
+                out.append(m)          # nothing to sum: the parent reads the factors (or .t)
+                continue
             terms = m.terms if isinstance(m, Terms) or _is_lazy(m) else \
                 [(1.0, list(m) if isinstance(m, tuple) else [_arr(m)])]
             msg = None
@@ -2144,6 +2201,9 @@ class GenericPlan:
     @_operation
     def lower_bound_contributions(self, nodes):
         """Terms of several nodes with ONE device->host read (VB.loglikelihood_lowerbound)."""
+        stash, self._g_stash = self._g_stash, None
+        if stash is not None and stash[0] == tuple(id(n) for n in nodes):
+            return list(stash[1])          # evaluated inside the recorded sweep (graph_iter.py)
         parts = [self._lower_bound_device(n) for n in nodes]
         dev = [t.t.reshape(1) for t, _ in parts if t is not None]
         vals = iter(self.rt.torch.cat(dev).cpu().numpy() if dev else ())
@@ -2250,7 +2310,7 @@ class GenericPlan:
             raise NotImplementedError('rotation of %s' % node.name)
         st = self._ensure(node)
         K = node.dims[0][-1]
-        if isinstance(st.u[1], FactoredMoment) and st.u[1]._dense is None:
+        if isinstance(st.u[1], FactoredMoment):
             # (plates sharing the covariance) x Cov + sum over the plates of <x><x>^T
             fm = st.u[1]
             x = fm.mean
@@ -2296,7 +2356,7 @@ class GenericPlan:
         else:
             phi = None                       # delta moments (initialize_from_value): no parameters
         st.phi = phi
-        if not chain and isinstance(st.u[1], FactoredMoment) and st.u[1]._dense is None:
+        if not chain and isinstance(st.u[1], FactoredMoment):
             # the factors rotate separately: Cov <- R Cov R^T, <x> <- R <x>
             u0 = linalg.mvdot(Rd, _arr(st.u[0]))
             st.u = [u0, FactoredMoment(rot2(Rd, st.u[1].cov, Rt), u0, node.ndim)]

@@ -1,0 +1,357 @@
+"""
+One VB iteration of the generic engine as a HIP graph.
+
+The reference's loop (vmp.py:132-172) visits the nodes one by one and evaluates the lower bound
+after every sweep; on the generic device engine a sweep of a PCA-sized model is ~130 kernel
+launches issued from Python (elementwise formulas, plate sums, contractions), and at N = 1e6 the
+host spends longer issuing them than the device spends running them.  The launches of a sweep are
+the same every iteration -- same kernels, same shapes, only the contents of the state arrays
+move -- so after two identical sweeps the plan records the third into a graph
+(hipStreamBeginCapture through ``torch.cuda.graph``; every kernel of the library launches on the
+context's stream, which is the capturing stream inside the recording) and replays it afterwards:
+
+    state of the previous sweep  --copy-->  the graph's input arrays
+    graph launch: all node updates, all lower-bound terms, all validity flags
+    ONE device -> host read: the bound terms and the flags
+
+The graph reads the arrays the state occupied when the recording started and writes the arrays it
+allocated while recording (the graph's private pool), so a replay needs the results of the previous
+sweep copied back into the inputs; everything else is the device work of the eager sweep, kernel for
+kernel, in the same order, hence with identical results.
+
+Anything the recording cannot hold abandons it before HIP sees the call (``Runtime.host_access``:
+host reads, uploads, collectives): the plan restores its state and stays on the eager path.  Any
+operation on the plan other than the recorded pattern (another ``update`` order, ``observe``,
+rotations, ``set_parameters``, a changed mask / annealing / plate multiplier) drops the graph; the
+state is coherent at every iteration boundary, and read-only operations (moments, bound terms,
+checkpoints) work between replays.
+
+``BAYESPY_AMD_GRAPH=0`` keeps every sweep eager.
+"""
+import os
+
+import numpy as np
+
+from ...darray import DArray
+from ...device import GraphCaptureAbort
+
+# operations that leave the state of the plan as it is
+READ_ONLY = frozenset((
+    'get_moments', 'get_mask', 'lower_bound_contribution', 'lower_bound_contributions', 'save_state',
+    'natural_parameters', 'get_parameters', 'log_normalizer', 'gamma_posterior_shape', 'nodes',
+    'has_state', 'describe', 'graph_iteration', 'graph_info'))
+
+_STATE_FIELDS = ('u', 'phi', 'g', 'f', 'u_obs', 'obs_mask')
+
+
+def _enabled():
+    return os.environ.get('BAYESPY_AMD_GRAPH', '1') != '0'
+
+
+class _Recording:
+    __slots__ = ('key', 'graph', 'copy_graph', 'pairs', 'outvec', 'n_bound', 'bound_index', 'factors',
+                 'checks', 'template', 'fresh', 'replays', 'pool_bytes')
+
+
+class GraphIteration:
+    """Mixin of GenericPlan: ``graph_iteration(update_nodes, bound_nodes)`` runs one sweep from the
+    recorded graph (returns True) or declines (returns False: the caller runs the eager sweep,
+    which this class watches through ``_graph_note``)."""
+
+    # -- bookkeeping ------------------------------------------------------------------------------
+    def _graph_init(self):
+        self._g_rec = None
+        self._g_log = []            # operations since the last graph_iteration call
+        self._g_warm = 0            # consecutive eager sweeps that followed the expected pattern
+        self._g_last_key = None
+        self._g_disabled = None     # reason when recording failed / is not possible
+        self._g_stash = None
+        self._g_inside = False
+        self._g_attempts = 0
+        self._mask_epoch = 0
+
+    def _graph_note(self, name, args):
+        """Called by the operation wrapper for every outermost operation on the plan."""
+        if self._g_inside:
+            return
+        if name == 'update':
+            self._g_log.append(('update', id(args[0]) if args else None))
+            if self._g_rec is not None:
+                self._graph_drop('update outside the recorded sweep')
+            self._g_stash = None
+            return
+        if name in READ_ONLY:
+            if name == 'lower_bound_contributions':
+                self._g_log.append(('bound', None))
+            return
+        self._g_log.append(('other', name))
+        self._g_stash = None
+        if self._g_rec is not None:
+            self._graph_drop(name)
+        self._g_warm = 0
+
+    def _graph_drop(self, why):
+        self._g_rec = None
+        self._g_warm = 0
+        self._g_last_key = None
+
+    def graph_info(self):
+        r = self._g_rec
+        return {'recorded': r is not None, 'replays': 0 if r is None else r.replays,
+                'disabled': self._g_disabled,
+                'pool_bytes': None if r is None else r.pool_bytes}
+
+    def _graph_key(self, upd, bound):
+        self._update_masks()
+        host = []
+        for n in self.all:
+            host.append((float(getattr(n, 'annealing', 1.0)),
+                         tuple(np.ravel(getattr(n, 'plates_multiplier', ()))),
+                         bool(getattr(n, 'observed', False))))
+        return (tuple(id(n) for n in upd), tuple(id(n) for n in bound), tuple(host),
+                self._mask_epoch)
+
+    # -- state leaves ------------------------------------------------------------------------------
+    def _graph_states(self):
+        from . import generic as G
+        return [(n, self.state[id(n)]) for n in self.all
+                if isinstance(n, G.Stochastic) and id(n) in self.state]
+
+    @staticmethod
+    def _leaves(obj, out, sig, path):
+        """Device tensors of a state field in a fixed traversal order (``out``) and the shape of
+        the structure around them (``sig``)."""
+        from . import generic as G
+        if obj is None or isinstance(obj, (bool, int, float, np.floating, np.integer)):
+            sig.append((path, 'host', None if obj is None else float(obj)))
+        elif isinstance(obj, np.ndarray):
+            sig.append((path, 'ndarray', obj.shape, obj.tobytes() if obj.size <= 64 else None))
+        elif isinstance(obj, G.FactoredMoment):
+            # (consumers read the factors whether or not the dense form has been evaluated)
+            sig.append((path, 'factored', obj.nd))
+            GraphIteration._leaves(obj.cov, out, sig, path + ('cov',))
+            GraphIteration._leaves(obj.mean, out, sig, path + ('mean',))
+        elif isinstance(obj, G.LazySum):
+            t = obj.t                       # a state array is read as a whole: evaluate it
+            out.append(t)
+            sig.append((path, 'tensor', tuple(t.shape)))
+        elif isinstance(obj, DArray):
+            out.append(obj.t)
+            sig.append((path, 'tensor', tuple(obj.t.shape)))
+        elif isinstance(obj, (list, tuple)):
+            sig.append((path, type(obj).__name__, len(obj)))
+            for i, o in enumerate(obj):
+                GraphIteration._leaves(o, out, sig, path + (i,))
+        else:
+            raise GraphCaptureAbort('state of type %s' % type(obj).__name__)
+
+    def _graph_snapshot(self):
+        leaves, sig = [], []
+        for n, st in self._graph_states():
+            for f in _STATE_FIELDS:
+                self._leaves(getattr(st, f), leaves, sig, (id(n), f))
+            sig.append((id(n), 'flags', st.observed, st.partial, st.ready, st.stale))
+        return leaves, sig
+
+    @staticmethod
+    def _rewrap(obj, memo):
+        """Fresh wrapper objects around the same device tensors: identity-keyed caches and lazily
+        evaluated dense forms made from the previous contents cannot be reached through them."""
+        from . import generic as G
+        if id(obj) in memo:
+            return memo[id(obj)]
+        if isinstance(obj, G.FactoredMoment):
+            new = G.FactoredMoment(GraphIteration._rewrap(obj.cov, memo),
+                                   GraphIteration._rewrap(obj.mean, memo), obj.nd)
+        elif isinstance(obj, G.LazySum):
+            new = DArray(obj.t)
+        elif isinstance(obj, DArray):
+            new = DArray(obj.t)
+        elif isinstance(obj, list):
+            new = [GraphIteration._rewrap(o, memo) for o in obj]
+        elif isinstance(obj, tuple):
+            new = tuple(GraphIteration._rewrap(o, memo) for o in obj)
+        else:
+            return obj
+        memo[id(obj)] = new
+        return new
+
+    def _graph_constant_ids(self):
+        """Arrays that no sweep changes: data of fully observed nodes, constants, masks."""
+        ids = set()
+
+        def add(o):
+            if isinstance(o, DArray):
+                ids.add(id(o))
+            elif isinstance(o, (list, tuple)):
+                for x in o:
+                    add(x)
+        for n, st in self._graph_states():
+            if st.observed and not st.partial:
+                add(st.u)
+        for v in self._const_cache.values():
+            add(v)
+        for v in self._dev_masks.values():
+            add(v[0])
+        return ids
+
+    def _graph_reset_caches(self):
+        """Forget everything derived from the state (it is about to change under the same
+        objects); sums over constants stay."""
+        self.__dict__.pop('_det_cache', None)
+        self.__dict__.pop('_msg_cache', None)
+        sums = self.__dict__.get('_sum_cache')
+        if sums:
+            const = self._graph_constant_ids()
+            for k in [k for k, v in sums.items()
+                      if not all(r() is not None and id(r()) in const for r in v[0])]:
+                del sums[k]
+
+    # -- recording ---------------------------------------------------------------------------------
+    def _graph_record(self, upd, bound, key):
+        from . import generic as G
+        rt = self.rt
+        torch = rt.torch
+        states = self._graph_states()
+        saved = [(st, {f: getattr(st, f) for f in _STATE_FIELDS + ('stale',)}) for _, st in states]
+        self._graph_reset_caches()
+        # fresh wrappers: nothing lazily evaluated from the present contents stays reachable
+        memo = {}
+        for _, st in states:
+            for f in _STATE_FIELDS:
+                setattr(st, f, self._rewrap(getattr(st, f), memo))
+        try:
+            old, sig_old = self._graph_snapshot()
+            for t in old:
+                # the graph's inputs are written by the copy-back: they must be ordinary arrays
+                if any(s == 0 and e > 1 for s, e in zip(t.stride(), t.shape)):
+                    raise GraphCaptureAbort('broadcast view in the state')
+            rec = _Recording()
+            rec.key = key
+            rec.graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(rt.device)
+            free0 = torch.cuda.memory_reserved(rt.device)
+            rt._capturing = True
+            try:
+                with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):
+                    with rt.operation():
+                        for n in upd:
+                            type(self).update.__wrapped__(self, n)
+                        parts = [self._lower_bound_device(n) for n in bound]
+                        items, rt._deferred = rt._deferred, []
+                        dev = [t.t.reshape(1) for t, _ in parts if t is not None]
+                        flags = [f.to(torch.float64) for f, _, _ in items]
+                        rec.outvec = torch.cat(dev + flags) if dev or flags else None
+            finally:
+                rt._capturing = False
+                rt._deferred = []
+            rec.bound_index = [None if t is None else 1 for t, _ in parts]
+            rec.factors = [f for _, f in parts]
+            rec.n_bound = len(dev)
+            rec.checks = [(e, m) for _, e, m in items]
+            new, sig_new = self._graph_snapshot()
+            if sig_old != sig_new:
+                raise GraphCaptureAbort('the sweep changed the structure of the state')
+            seen, pairs = set(), []
+            for o, n_ in zip(old, new):
+                ko = (o.data_ptr(), tuple(o.shape), tuple(o.stride()))
+                kn = (n_.data_ptr(), tuple(n_.shape), tuple(n_.stride()))
+                if ko == kn or ko in seen:
+                    continue
+                seen.add(ko)
+                pairs.append((o, n_))
+            rec.pairs = pairs
+            rec.copy_graph = None
+            if pairs:
+                rec.copy_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(rec.copy_graph, capture_error_mode='thread_local'):
+                    for o, n_ in pairs:
+                        o.copy_(n_)
+            rec.template = [(st, {f: getattr(st, f) for f in _STATE_FIELDS + ('stale',)})
+                            for _, st in states]
+            rec.fresh = True
+            rec.replays = 0
+            rec.pool_bytes = int(torch.cuda.memory_reserved(rt.device) - free0)
+            return rec
+        except Exception as e:       # noqa: BLE001 -- whatever went wrong, the eager path works
+            for st, fields in saved:
+                for f, v in fields.items():
+                    setattr(st, f, v)
+            self._graph_reset_caches()
+            torch.cuda.synchronize(rt.device)
+            if isinstance(e, GraphCaptureAbort):
+                self._g_disabled = 'needs the host: %s' % (e,)
+            else:
+                self._g_disabled = '%s: %s' % (type(e).__name__, str(e)[:200])
+            if os.environ.get('BAYESPY_AMD_GRAPH_DEBUG'):
+                import traceback
+                traceback.print_exc()
+            return None
+
+    def _graph_replay(self, rec):
+        rt = self.rt
+        torch = rt.torch
+        if not rec.fresh and rec.copy_graph is not None:
+            rec.copy_graph.replay()
+        rec.graph.replay()
+        rec.fresh = False
+        rec.replays += 1
+        vals = rec.outvec.cpu().numpy() if rec.outvec is not None else np.zeros(0)
+        # the state objects of the recording, as fresh wrappers (same device arrays)
+        memo = {}
+        for st, fields in rec.template:
+            for f, v in fields.items():
+                setattr(st, f, self._rewrap(v, memo) if f != 'stale' else v)
+        self._graph_reset_caches()
+        for bad, (exc_type, message) in zip(vals[rec.n_bound:], rec.checks):
+            if bad:
+                self._graph_drop('a validity check failed')
+                raise exc_type(message)
+        it = iter(vals[:rec.n_bound])
+        return [f if i is None else float(next(it)) * f
+                for i, f in zip(rec.bound_index, rec.factors)]
+
+    # -- entry point ---------------------------------------------------------------------------------
+    def graph_iteration(self, upd, bound):
+        """One sweep over ``upd`` plus the bound terms of ``bound`` from the recorded graph.  False:
+        nothing was done, the caller runs the sweep node by node."""
+        if not _enabled() or self._g_disabled is not None:
+            return False
+        rt = self.rt
+        if rt.device.type != 'cuda':
+            return False
+        rt._refresh_dist()
+        if rt.world > 1:
+            return False
+        key = self._graph_key(upd, bound)
+        log, self._g_log = self._g_log, []
+        rec = self._g_rec
+        if rec is not None and rec.key == key and not any(k == 'other' for k, _ in log):
+            pass
+        else:
+            if rec is not None:
+                self._graph_drop('another sweep')
+            expect = [('update', id(n)) for n in upd] + [('bound', None)]
+            if key == self._g_last_key and log == expect:
+                self._g_warm += 1
+            else:
+                self._g_warm = 0
+            self._g_last_key = key
+            if self._g_warm < 2:
+                return False
+            self._g_attempts += 1
+            self._g_inside = True
+            try:
+                rec = self._graph_record(upd, bound, key)
+            finally:
+                self._g_inside = False
+            if rec is None:
+                return False
+            self._g_rec = rec
+        self._g_inside = True
+        try:
+            vals = self._graph_replay(rec)
+        finally:
+            self._g_inside = False
+        self._g_stash = (tuple(id(n) for n in bound), vals)
+        return True

@@ -164,10 +164,11 @@ class VB:
         try:
             while repeat is None or i < repeat:
                 t = time.time()
-                for node in nodes:
-                    X = self[node]
-                    if hasattr(X, 'update') and callable(X.update):
-                        X.update()
+                if not self._graph_sweep(nodes):
+                    for node in nodes:
+                        X = self[node]
+                        if hasattr(X, 'update') and callable(X.update):
+                            X.update()
                 cputime = time.time() - t
                 i += 1
                 if tqdm is not None:
@@ -181,6 +182,31 @@ class VB:
                 fin = getattr(p, 'finish', None)
                 if fin is not None:
                     fin()
+
+    def _graph_sweep(self, nodes):
+        """A sweep over ``nodes`` and the bound terms of the model as ONE recorded HIP graph, when
+        a single generic plan owns the whole model and has seen this sweep twice
+        (plans/graph_iter.py).  False: not done, the caller visits the nodes one by one."""
+        plan = None
+        for n in self.model:
+            p = n._plan
+            if p is None or (plan is not None and p is not plan):
+                return False
+            plan = p
+        run = getattr(plan, 'graph_iteration', None)
+        if run is None:
+            return False
+        upd = []
+        for node in nodes:
+            X = self[node]
+            if not (hasattr(X, 'update') and callable(X.update)):
+                continue
+            if getattr(X, '_plan', None) is not plan:
+                return False
+            if X.observed and getattr(X, '_fully_observed', True):
+                continue
+            upd.append(X)
+        return bool(run(upd, list(self.model)))
 
     # -- persistence (vmp.py:237-356) ------------------------------------------------------
     def _shard_info(self, nodes):

@@ -55,8 +55,11 @@ def _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
     # fold operands of "subset" shape into a partner (e.g. a plate mask into its message)
     while len(ops) > 2:
         done = False
-        for i in range(len(ops)):
-            for j in range(len(ops)):
+        # (the smallest operand first, into the smallest partner that contains its shape: a
+        # plate-free factor multiplies a K x K matrix, not the (D, N) data)
+        order = sorted(range(len(ops)), key=lambda q: ops[q].size)
+        for i in order:
+            for j in order:
                 if i == j:
                     continue
                 try:
@@ -378,8 +381,10 @@ def diag(X, ndim=1):
         return X
     sh = X.shape[len(X.shape) - ndim:]
     n = int(np.prod(sh)) if sh else 1
-    eye = DArray.from_host(np.eye(n).reshape(sh + sh))
-    return fuse(lambda x, e: x * e, X.reshape(X.shape + (1,) * ndim), eye)
+    key = (id(get_runtime()), 'eye', tuple(sh))
+    if key not in _HALF_ARANGE:
+        _HALF_ARANGE[key] = DArray.from_host(np.eye(n).reshape(sh + sh))     # uploaded once
+    return fuse(lambda x, e: x * e, X.reshape(X.shape + (1,) * ndim), _HALF_ARANGE[key])
 
 
 def get_diag(X, ndim=1):

@@ -375,6 +375,54 @@ def test_gemm_path_is_taken_and_deterministic(monkeypatch):
     assert calls[-1] is False
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (16, 16, 100000, True, False),     # sum_n x_n x_n^T: both operands N-contiguous rows
+    (64, 16, 100003, False, False),    # sum_n y_dn x_nk: A K-contiguous, ragged K
+    (16, 64, 5000, True, True),
+    (20, 30, 4096 + 7, False, True),   # partial 16 x 16 blocks on both sides
+    (9, 48, 70001, True, False),
+    (33, 16, 4096, False, False)])
+def test_skinny_gemm_matches_numpy(M, N, K, ta, tb):
+    """gemm_skinny_kernel (csrc/vmp_gemm.hip): long contractions with at most four 16 x 16 output
+    blocks, K slices per wavefront, operands straight from HBM in every stride pattern the engine
+    produces (views of (K, M) / (M, K) arrays); fixed-order combination => run-to-run identical."""
+    from bayespy_amd.utils import misc
+    from bayespy_amd.darray import DArray
+    rs = np.random.RandomState(M * 131 + N * 7 + K)
+    a = rs.normal(size=(K, M) if ta else (M, K))
+    b = rs.normal(size=(N, K) if tb else (K, N))
+    A = DArray.from_host(a)
+    B = DArray.from_host(b)
+    A = A.swapaxes(0, 1) if ta else A                  # (M, K) view
+    B = B.swapaxes(0, 1) if tb else B                  # (K, N) view
+    A3 = DArray(A.t.unsqueeze(1))                      # (M, 1, K) view
+    B3 = DArray(B.t.transpose(0, 1).unsqueeze(0))      # (1, N, K) view
+    r1 = misc.sum_multiply(A3, B3, axis=(2,)).numpy()
+    r2 = misc.sum_multiply(A3, B3, axis=(2,)).numpy()
+    ref = (a.T if ta else a) @ (b.T if tb else b)
+    assert r1.shape == (M, N) and np.array_equal(r1, r2)
+    np.testing.assert_allclose(r1, ref, rtol=1e-12, atol=1e-12 * np.sqrt(K))
+
+
+@pytest.mark.parametrize('shape_a,shape_b,axes', [
+    ((1, 1, 16, 16), (1, 1, 16, 16), (0, 1, 2, 3)),     # tr(A B^T): one output, 256 products
+    ((16, 16), (1, 1, 16, 16), (0, 1, 2, 3)),
+    ((64, 1, 16), (1, 1, 16), (0,)),                    # 16 outputs over 64 products
+    ((7, 100), (7, 100), (1,)),
+    ((3, 5, 40), (1, 5, 40), (1, 2))])
+def test_short_reductions_with_few_outputs(shape_a, shape_b, axes):
+    """A handful of outputs over 64 .. 1023 products run on a workgroup per output
+    (sum_multiply_block_kernel), not on one thread per output."""
+    from bayespy_amd.utils import misc
+    rs = np.random.RandomState(sum(shape_a) + len(axes))
+    a, b = rs.normal(size=shape_a), rs.normal(size=shape_b)
+    got = misc.sum_multiply(a, b, axis=axes, keepdims=True).numpy()
+    full = a * b
+    ref = np.sum(full, axis=tuple(ax + full.ndim - max(a.ndim, b.ndim) for ax in axes), keepdims=True)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+
+
 @pytest.mark.parametrize('n,batch', [(9, 3000), (16, 4099), (12, 1025), (17, 1100), (32, 1029),
                                      (24, 2000)])
 def test_fused_gaussian_moments(n, batch):

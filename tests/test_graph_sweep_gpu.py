@@ -1,0 +1,130 @@
+"""
+GPU: sweeps of the generic engine replayed from a recorded HIP graph (plans/graph_iter.py) against
+the same sweeps issued launch by launch (``BAYESPY_AMD_GRAPH=0``).  A replay is the device work of
+the eager sweep, kernel for kernel, so everything must be BIT-identical: bound traces, moments, and
+the behaviour around operations that interleave with the sweeps -- read-only ones (the graph stays),
+mutating ones (the graph is dropped and recorded again), and models whose sweep needs the host
+(the recording is abandoned, the eager path continues from the restored state).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pca(N=20000, D=24, K=6, seed=5):
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from models import build_pca, make_seeded_pca
+    y, x0 = make_seeded_pca(seed, N, D, K)
+    return build_pca(nodes, VB, y, x0, K, engine='generic')
+
+
+def _script(Q):
+    """Sweeps with other operations in between; returns everything a caller could observe."""
+    out = []
+    W, X, tau = Q['W'], Q['X'], Q['tau']
+    Q.update(repeat=6, verbose=False)
+    out.append(W.get_moments()[0])                       # read-only between sweeps
+    out.append(np.array(Q.compute_lowerbound()))
+    Q.update(repeat=3, verbose=False)
+    X.update()                                           # a single update: not the recorded sweep
+    Q.update(repeat=5, verbose=False)
+    Q.update(W, X, repeat=4, verbose=False)              # another sweep (a subset of the nodes)
+    Q.update(repeat=4, verbose=False)
+    for n in (W, X, tau, Q['alpha']):
+        out.extend(n.get_moments())
+    out.append(Q.L[:Q.iter].copy())
+    return out, W._plan.graph_info()
+
+
+def test_graph_replay_is_bit_identical_to_eager_sweeps(monkeypatch):
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
+    eager, info0 = _script(_pca())
+    assert not info0['recorded']
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '1')
+    graph, info1 = _script(_pca())
+    assert info1['recorded'] and info1['replays'] >= 2 and info1['disabled'] is None, info1
+    assert len(eager) == len(graph)
+    for a, b in zip(eager, graph):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_graph_is_dropped_by_new_data_and_rotations(monkeypatch):
+    """observe() between sweeps and a rotation callback after every sweep (the reference's idiom,
+    demos/pca.py:63-68): both change the state outside the recorded sweep."""
+    import warnings
+    from bayespy_amd.inference.transformations import RotateGaussianARD, RotationOptimizer
+
+    def run():
+        Q = _pca(N=5000)
+        Y, W, X = Q['Y'], Q['W'], Q['X']
+        Q.update(repeat=5, verbose=False)
+        rs = np.random.RandomState(1)
+        Y.observe(np.asarray(Y.get_moments()[0]) + 0.01 * rs.normal(size=(24, 5000)))
+        Q.update(repeat=5, verbose=False)
+        rot = RotationOptimizer(RotateGaussianARD(W, Q['alpha']), RotateGaussianARD(X), 6)
+        Q.callback = rot.rotate
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Q.update(repeat=4, verbose=False)
+        return [Q.L[:Q.iter].copy()] + list(W.get_moments()) + list(X.get_moments())
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
+    eager = run()
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '1')
+    graph = run()
+    for a, b in zip(eager, graph):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_recording_that_needs_the_host_falls_back(monkeypatch):
+    """A sweep that reads device data on the host cannot be recorded: the attempt is abandoned
+    before HIP sees the read, the state is restored, results equal the eager run's."""
+    import bayespy_amd.inference.plans.generic as G
+    orig = G.GammaFamily.moments_and_cgf
+
+    def peeking(self, phi):
+        out = orig(self, phi)
+        G._arr(out[0][0]).numpy()              # a host read inside the sweep
+        return out
+
+    def run():
+        Q = _pca(N=4000)
+        Q.update(repeat=8, verbose=False)
+        return [Q.L[:Q.iter].copy()] + list(Q['X'].get_moments()), Q['W']._plan.graph_info()
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
+    eager, _ = run()
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '1')
+    monkeypatch.setattr(G.GammaFamily, 'moments_and_cgf', peeking)
+    graph, info = run()
+    assert not info['recorded'] and 'needs the host' in info['disabled'], info
+    for a, b in zip(eager, graph):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize('case', ['count', 'plate', 'markov'])
+def test_other_model_families_agree_with_eager(case, golden_dir, monkeypatch):
+    """Mixtures, categorical / count nodes, chains: whatever part of their sweeps is recorded or
+    not, the results equal the eager ones bit for bit."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    import models
+    fn, gold = {'count': (models.run_count_node_cases, 'count_nodes.npz'),
+                'plate': (models.run_plate_node_cases, 'plate_nodes.npz'),
+                'markov': (models.run_markov_chain_cases, 'markov_chains.npz')}[case]
+    f = np.load(os.path.join(golden_dir, gold))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
+    eager = fn(nodes, VB, g)
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH', '1')
+    graph = fn(nodes, VB, g)
+    assert sorted(eager) == sorted(graph)
+
+    def same(a, b):
+        if isinstance(a, (list, tuple)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return np.array_equal(np.asarray(a), np.asarray(b))
+    for k in eager:
+        assert same(eager[k], graph[k]), k
