@@ -232,6 +232,12 @@ class GraphIteration:
             torch.cuda.synchronize(rt.device)
             free0 = torch.cuda.memory_reserved(rt.device)
             rt._capturing = True
+            # no cyclic garbage collection while the stream records: collecting an older plan
+            # would destroy ITS graph (hipGraphExecDestroy, pool release) in the middle of this
+            # recording, which HIP answers by aborting the process
+            import gc
+            gc_was_on = gc.isenabled()
+            gc.disable()
             try:
                 with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):
                     with rt.operation():
@@ -245,6 +251,8 @@ class GraphIteration:
             finally:
                 rt._capturing = False
                 rt._deferred = []
+                if gc_was_on:
+                    gc.enable()
             rec.bound_index = [None if t is None else 1 for t, _ in parts]
             rec.factors = [f for _, f in parts]
             rec.n_bound = len(dev)
@@ -264,9 +272,14 @@ class GraphIteration:
             rec.copy_graph = None
             if pairs:
                 rec.copy_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(rec.copy_graph, capture_error_mode='thread_local'):
-                    for o, n_ in pairs:
-                        o.copy_(n_)
+                gc.disable()
+                try:
+                    with torch.cuda.graph(rec.copy_graph, capture_error_mode='thread_local'):
+                        for o, n_ in pairs:
+                            o.copy_(n_)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
             rec.template = [(st, {f: getattr(st, f) for f in _STATE_FIELDS + ('stale',)})
                             for _, st in states]
             rec.fresh = True
