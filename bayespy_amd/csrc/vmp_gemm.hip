@@ -289,6 +289,69 @@ gemm_skinny_kernel(GemmArgs g)
             }
 }
 
+// Many rows, few columns, short contraction (M >= 4096, N <= 64, K <= 64: a K x K matrix applied to
+// every plate, the Dot message to the plate-side parent): the 64 x 64 tile runs its B side 1/4 full
+// and pays two barriers per 16 k's for a kernel that only streams A in and C out.  Here B lives in
+// registers (KQ x NB fragments per lane, loaded once per wavefront), a wavefront walks blocks of 16
+// rows: KQ loads of A (128-byte lines of an M-contiguous operand, 32-byte pieces of a K-contiguous
+// one), KQ x NB matrix instructions, NB x 4 stores; the next block's loads are issued before the
+// current block's instructions.
+template <int KQ, int NB>
+__global__ void __launch_bounds__(NT)
+gemm_tall_kernel(GemmArgs g)
+{
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, l15 = l & 15, l4 = l >> 4;
+    const int64_t nblk = (g.M + 15) / 16;
+    const int64_t nw = (int64_t)gridDim.x * (NT / 64);
+    const double *__restrict__ A = g.A;
+    const double *__restrict__ B = g.B;
+    double b[KQ][NB];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int64_t k = 4 * q + l4, nn = 16 * n + l15;
+            b[q][n] = (k < g.K && nn < g.N) ? B[k * g.b_ks + nn * g.b_ns] : 0.0;
+        }
+    int64_t koff[KQ];
+    bool kok[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        kok[q] = 4 * q + l4 < g.K;
+        koff[q] = kok[q] ? (int64_t)(4 * q + l4) * g.a_ks : 0;
+    }
+    auto load = [&](int64_t blk, double *a) {
+        const int64_t m = blk * 16 + l15;
+        const bool ok = blk < nblk && m < g.M;
+        const double *p = A + (ok ? m : 0) * g.a_ms;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[q] = (ok && kok[q]) ? p[koff[q]] : 0.0;
+    };
+    double a0[KQ], a1[KQ];
+    int64_t blk = (int64_t)blockIdx.x * (NT / 64) + w;
+    load(blk, a0);
+    for (; blk < nblk; blk += nw) {
+        load(blk + nw, a1);
+        v4f64 acc[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[n] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[n] = mfma_f64(a0[q], b[q][n], acc[n]);
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = blk * 16 + l4 + 4 * r, nn = 16 * n + l15;
+                if (m < g.M && nn < g.N) g.C[m * g.c_ms + nn * g.c_ns] = g.scale * acc[n][r];
+            }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a0[q] = a1[q];
+    }
+}
+
 // Combination of the K slices: 16 outputs per workgroup, 16 lanes per output walk the slices with a
 // stride of 16 (independent loads), then the 16 partial sums are added in order -- the result depends
 // on the number of slices only.  (One thread per output walking all slices was 0.24 ms for 256
@@ -385,6 +448,25 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
         }
         VMP_HIP_CHECK(ctx, hipGetLastError());
         return VMP_OK;
+    }
+    // many rows, few columns, short contraction: B in registers, A streamed by row blocks
+    {
+        const int64_t kq = K <= 16 ? 4 : (K <= 32 ? 8 : 16), nb = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+        if (nbatch == 1 && M >= 4096 && N <= 64 && K <= 64 && kq * nb <= 32) {
+            g.C = C;
+            g.nsplit = 1;
+            int64_t wgs = ((M + 15) / 16 + NT / 64 - 1) / (NT / 64);
+            const int64_t cap = (int64_t)ctx->num_cu * 8;
+            if (wgs > cap) wgs = cap;
+#define VMP_TALL(a, b)                                                                            \
+    if (kq == a && nb == b)                                                                       \
+        hipLaunchKernelGGL((gemm_tall_kernel<a, b>), dim3((unsigned)wgs), dim3(NT), 0, s, g)
+            VMP_TALL(4, 1); VMP_TALL(4, 2); VMP_TALL(4, 4); VMP_TALL(8, 1); VMP_TALL(8, 2);
+            VMP_TALL(8, 4); VMP_TALL(16, 1); VMP_TALL(16, 2);
+#undef VMP_TALL
+            VMP_HIP_CHECK(ctx, hipGetLastError());
+            return VMP_OK;
+        }
     }
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     VMP_REQUIRE(ctx, nbatch <= 65535, VMP_ERR_UNSUPPORTED, "too many batch elements (%lld)",

@@ -116,6 +116,13 @@ def _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
     # full index decode per output element)
     if M < 8 or N < 8 or K < 4 or M * N * K * nbatch < (1 << 20) or nbatch > 65535:
         return False
+    if nbatch == 1 and N >= 4096 and M <= 64 and K <= 64 and c_ms == 1:
+        # few rows, many columns, output contiguous along the rows: the transposed problem
+        # C^T = B^T A^T is the library's row-streaming form (gemm_tall_kernel)
+        A, B = B, A
+        M, N = N, M
+        a_ms, a_ks, b_ks, b_ns = b_ns, b_ks, a_ks, a_ms
+        c_ms, c_ns = c_ns, c_ms
     c3 = ctypes.c_int64 * 3
     bshape = c3(*([shape[d] for d in Bd] + [1] * (3 - len(Bd))))
     a_bs = c3(*([sa[d] for d in Bd] + [0] * (3 - len(Bd))))

@@ -437,8 +437,8 @@ def main():
                 ('masked', 'run_masked', dict(steps=50, warmup=1)),
                 ('lssm', 'run_lssm', dict(steps=150, warmup=3)),
                 ('lssm_masked', 'run_lssm_masked', dict(steps=50, warmup=2)),
-                ('generic_pca', 'run_generic_pca', dict(steps=50, warmup=2)),
-                ('generic_gmm', 'run_generic_gmm', dict(steps=50, warmup=2)),
+                ('generic_pca', 'run_generic_pca', dict(steps=50, warmup=4)),
+                ('generic_gmm', 'run_generic_gmm', dict(steps=50, warmup=4)),
             ]
             out['extra'] = []
             for name, fname, kw in legs:

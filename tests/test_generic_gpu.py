@@ -404,6 +404,42 @@ def test_skinny_gemm_matches_numpy(M, N, K, ta, tb):
     np.testing.assert_allclose(r1, ref, rtol=1e-12, atol=1e-12 * np.sqrt(K))
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (100000, 16, 16, False, False),    # a K x K matrix applied to every plate (mvdot)
+    (50001, 16, 64, True, False),      # the Dot message to the plate-side parent: A M-contiguous
+    (4099, 64, 8, False, True),
+    (20000, 33, 20, True, True),
+    (8192, 9, 5, False, False),
+    (30000, 24, 50, False, False)])
+def test_tall_gemm_matches_numpy(M, N, K, ta, tb):
+    """gemm_tall_kernel (csrc/vmp_gemm.hip): many rows, at most 64 columns, K <= 64 -- B in
+    registers, A streamed by blocks of 16 rows, every stride pattern, ragged edges."""
+    from bayespy_amd.utils import misc
+    from bayespy_amd.darray import DArray
+    rs = np.random.RandomState(M + N * 7 + K)
+    a = rs.normal(size=(K, M) if ta else (M, K))
+    b = rs.normal(size=(N, K) if tb else (K, N))
+    A = DArray.from_host(a)
+    B = DArray.from_host(b)
+    A = A.swapaxes(0, 1) if ta else A
+    B = B.swapaxes(0, 1) if tb else B
+    A3 = DArray(A.t.unsqueeze(1))
+    B3 = DArray(B.t.transpose(0, 1).unsqueeze(0))
+    r1 = misc.sum_multiply(A3, B3, axis=(2,)).numpy()
+    ref = (a.T if ta else a) @ (b.T if tb else b)
+    assert r1.shape == (M, N)
+    np.testing.assert_allclose(r1, ref, rtol=1e-12, atol=1e-12)
+    # the same product asked for the other way round (few rows, many columns; rows contiguous in
+    # the output): routed to the same kernel as the transposed problem
+    r2 = misc.sum_multiply(B3, A3, axis=(2,)).numpy()
+    np.testing.assert_allclose(r2, ref, rtol=1e-12, atol=1e-12)
+    if K == N:
+        from bayespy_amd.utils import linalg
+        Mx = rs.normal(size=(K, K))
+        got = linalg.mvdot(Mx, A).numpy()                      # (M, K): Mx applied to every row
+        np.testing.assert_allclose(got, (a.T if ta else a) @ Mx.T, rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize('shape_a,shape_b,axes', [
     ((1, 1, 16, 16), (1, 1, 16, 16), (0, 1, 2, 3)),     # tr(A B^T): one output, 256 products
     ((16, 16), (1, 1, 16, 16), (0, 1, 2, 3)),

@@ -150,6 +150,9 @@ def compact(rec, leg):
         out['cpu_cores'] = cpu.get('cores')
     if rec.get('peak_mem_GB') is not None:
         out['peak_GB'] = r(rec['peak_mem_GB'], 3)
+    sg = rec.get('config', {}).get('sweep_graph')
+    if sg is not None:
+        out['sweep'] = 'graph' if sg.get('recorded') else 'eager'
     out['wall_s'] = round(rec.get('wall_s', 0), 1)
     return out
 
@@ -317,7 +320,7 @@ def run_gmm(N=10_000_000, D=8, K=64, steps=10, warmup=2, cpu_baseline=True, cpu_
     return out
 
 
-def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=1, cpu_baseline=True):
+def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=4, cpu_baseline=True):
     """BASELINE config 2 on the GENERIC engine (engine='generic'): the per-node kernels north_star
     names -- vmp_sum_multiply / vmp_gemm_strided (Dot messages), vmp_spd_batched (GaussianARD
     moments), vmp_ewise -- driven node by node as the reference drives NumPy, with the reference's
@@ -346,7 +349,9 @@ def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=1, cpu_baseline=Tru
     torch.cuda.reset_peak_memory_stats()
     Q = VB(Y, F, W, X, tau, alpha, engine='generic')
     Q.ignore_bound_checks = True
-    Q.update(repeat=warmup, verbose=False)
+    # (two eager sweeps, then the sweep is recorded into a HIP graph and replayed --
+    # plans/graph_iter.py; the warm-up covers the recording)
+    Q.update(repeat=max(warmup, 4), verbose=False)
     dt, step_ms = timed_update(Q, steps)
     dt /= steps
     L = [float(v) for v in Q.L[:Q.iter]]
@@ -362,7 +367,8 @@ def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=1, cpu_baseline=Tru
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'probabilistic PCA (BASELINE config 2), N=%d D=%d K=%d, fully '
                                'observed, engine=generic (per-node kernels, no fused block)'
-                               % (N, D, K), 'engine': type(Q.plans[0]).__name__},
+                               % (N, D, K), 'engine': type(Q.plans[0]).__name__,
+                   'sweep_graph': Q.plans[0].graph_info()},
         'elbo_first': L[0], 'elbo_last': L[-1], 'step_ms': step_ms,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
         'roofline': {'bound': 'hbm', 'achieved': alg / dt / 1e9, 'peak': HBM_PEAK_GBS,
@@ -390,7 +396,7 @@ def run_generic_pca(N=1_000_000, D=64, K=16, steps=5, warmup=1, cpu_baseline=Tru
     return out
 
 
-def run_generic_gmm(N=100_000, D=16, K=32, steps=3, warmup=1, cpu_baseline=True):
+def run_generic_gmm(N=100_000, D=16, K=32, steps=3, warmup=4, cpu_baseline=True):
     """A Gaussian mixture on the generic engine (engine='generic'; since round 3 the fused block
     takes D <= 16, run_gmm(D=16) is the same model on it): the reference's (N, K, D, D)
     intermediates (mixture.py:156, expfamily.py:45-61) -- 65 KB per point, which is why N stops
@@ -419,7 +425,7 @@ def run_generic_gmm(N=100_000, D=16, K=32, steps=3, warmup=1, cpu_baseline=True)
         warnings.simplefilter('always')
         Q = VB(Y, mu, Lam, z, alpha, engine='generic')
     Q.ignore_bound_checks = True
-    Q.update(repeat=warmup, verbose=False)
+    Q.update(repeat=max(warmup, 4), verbose=False)      # covers the recording of the sweep graph
     dt, step_ms = timed_update(Q, steps)
     dt /= steps
     L = [float(v) for v in Q.L[:Q.iter]]
@@ -433,6 +439,7 @@ def run_generic_gmm(N=100_000, D=16, K=32, steps=3, warmup=1, cpu_baseline=True)
         'config': {'workload': 'Gaussian mixture N=%d D=%d K=%d, engine="generic": per-node kernels '
                                'with (N, K, D, D) intermediates' % (N, D, K),
                    'engine': type(Q.plans[0]).__name__,
+                   'sweep_graph': Q.plans[0].graph_info(),
                    'matcher_said': [str(w.message)[:300] for w in wlist][:1]},
         'elbo_first': L[0], 'elbo_last': L[-1], 'step_ms': step_ms,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 1e9,
