@@ -518,6 +518,8 @@ class GaussianARDFamily(Family):
         m0 = fuse(lambda x_, m_, q, x2_: x_ * m_ - 0.5 * q - 0.5 * x2_, x, m, m2, x2)
         return [m0, 0.5]
 
+    finite_phi = True          # (alpha mu, -alpha / 2): 0 * phi needs no guard (MixtureFamily)
+
     # the message to a parent does not depend on that parent's own moments (conjugacy): the
     # router may reuse it while everything else it reads is unchanged
     message_independent_of_target = True
@@ -578,9 +580,19 @@ class GaussianFamily(Family):
         L = up[1][0]
         if index == 0:
             return [linalg.mvdot(L, x), fuse(lambda l: -0.5 * l, L)]
+        if getattr(self, '_terms_ok', False) and all(isinstance(a, DArray) for a in (x, xx, m, mm)):
+            # -(<xx^T> - <x><m>^T - <m><x>^T + <mm^T>) / 2 as four products: whoever sums it over
+            # plates (weighted by responsibilities under a mixture) contracts <xx^T> and <x>
+            # directly -- the plates x D x D array (x K clusters under a mixture) is never formed
+            xc, xr = x.reshape(x.shape + (1,)), x.reshape(x.shape[:-1] + (1, self.D))
+            mc, mr = m.reshape(m.shape + (1,)), m.reshape(m.shape[:-1] + (1, self.D))
+            return [Terms([(-0.5, [xx]), (0.5, [xc, mr]), (0.5, [mc, xr]), (-0.5, [mm])]), 0.5]
         xm = linalg.outer(x, m)
         mx = linalg.outer(m, x)
         return [fuse(lambda a, b, c, d: -0.5 * (a - b - c + d), xx, xm, mx, mm), 0.5]
+
+    # natural parameters are finite whatever the moments: 0 * phi needs no guard (MixtureFamily)
+    finite_phi = True
 
 
 class GaussianGammaFamily(Family):
@@ -1016,11 +1028,21 @@ class MixtureFamily(Family):
             # is the same for every cluster and cancels in the normalisation of q(z)
             L = _arr(self.base.cgf_from_parents(up[1:]))
             for ph, ui, nd in zip(phik, uk, self.ndims):
+                if nd > 0 and getattr(self.base, 'finite_phi', False):
+                    # phi_k . u_n as a contraction (plates x clusters, over the variable axes: a
+                    # matrix-core GEMM) -- not a plates x clusters x D x D product and its sum
+                    t = misc.sum_multiply(_arr(ph), ui, axis=tuple(range(-nd, 0)))
+                    L = fuse(lambda a, b: a + b, L, t)
+                    continue
                 t = fuse(lambda a, b: da.where_nonzero(b, a) * b, _arr(ph), ui)
                 L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
             return [L]
         p = up[0][0]
-        msgs = self.base.message_to_parent(index - 1, uk, up[1:])
+        self.base._terms_ok = getattr(self, '_terms_ok', False) and not isinstance(self.base, MixtureFamily)
+        try:
+            msgs = self.base.message_to_parent(index - 1, uk, up[1:])
+        finally:
+            self.base._terms_ok = False
         out = []
         parent = self.node.parents[index]
         # variable axes the mixed family maps onto plates of this parent (the precision of a
@@ -1033,8 +1055,13 @@ class MixtureFamily(Family):
             nd = len(parent.dims[i])
             # weight by the responsibilities: a lazy product, fused with the plate sum (a nested
             # mixture hands over a product already: one more factor)
+            w = _trail(p, nd + extra)
+            if isinstance(m, Terms) or _is_lazy(m):
+                out.append(Terms([(c, list(self._cluster_back(tuple(fs) + (w,), index, nd)))
+                                  for c, fs in m.terms]))
+                continue
             inner = tuple(m) if isinstance(m, tuple) else (_arr(m),)
-            out.append(self._cluster_back(inner + (_trail(p, nd + extra),), index, nd))
+            out.append(self._cluster_back(inner + (w,), index, nd))
         return out
 
 
@@ -2152,11 +2179,14 @@ class GenericPlan(GraphIteration):
         small = [f for f in factors if f.size <= 1]
         if not big:
             big, small = list(factors), []
-        big.sort(key=id)
-        key = (tuple(id(f) for f in big), tuple(to_plates), tuple(from_plates))
+        # two factors commute exactly, so either order may answer for both; three or more are
+        # multiplied left to right and only the same order is the same number
+        ids = tuple(id(f) for f in big)
+        key = (tuple(sorted(ids)) if len(big) <= 2 else ids, tuple(to_plates), tuple(from_plates))
         cache = self.__dict__.setdefault('_sum_cache', {})
         hit = cache.get(key)
-        if hit is not None and all(r() is f for r, f in zip(hit[0], big)):
+        if hit is not None and sorted(id(r()) for r in hit[0]) == sorted(ids):
+            # (a dead reference gives id(None): never among the ids of live factors)
             t = hit[1]
         else:
             t = misc.sum_multiply_to_plates(*big, to_plates=tuple(to_plates),
