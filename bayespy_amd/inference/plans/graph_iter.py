@@ -50,7 +50,7 @@ def _enabled():
 
 class _Recording:
     __slots__ = ('key', 'graph', 'copy_graph', 'pairs', 'outvec', 'n_bound', 'bound_index', 'factors',
-                 'checks', 'template', 'fresh', 'replays', 'pool_bytes')
+                 'checks', 'template', 'fresh', 'replays', 'copy_bytes')
 
 
 class GraphIteration:
@@ -99,7 +99,7 @@ class GraphIteration:
         r = self._g_rec
         return {'recorded': r is not None, 'replays': 0 if r is None else r.replays,
                 'disabled': self._g_disabled,
-                'pool_bytes': None if r is None else r.pool_bytes}
+                'state_copy_bytes': None if r is None else r.copy_bytes}
 
     def _graph_key(self, upd, bound):
         self._update_masks()
@@ -230,7 +230,6 @@ class GraphIteration:
             rec.key = key
             rec.graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(rt.device)
-            free0 = torch.cuda.memory_reserved(rt.device)
             rt._capturing = True
             # no cyclic garbage collection while the stream records: collecting an older plan
             # would destroy ITS graph (hipGraphExecDestroy, pool release) in the middle of this
@@ -284,7 +283,7 @@ class GraphIteration:
                             for _, st in states]
             rec.fresh = True
             rec.replays = 0
-            rec.pool_bytes = int(torch.cuda.memory_reserved(rt.device) - free0)
+            rec.copy_bytes = int(sum(o.numel() * o.element_size() for o, _ in pairs))
             return rec
         except Exception as e:       # noqa: BLE001 -- whatever went wrong, the eager path works
             for st, fields in saved:
