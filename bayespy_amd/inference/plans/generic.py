@@ -144,6 +144,47 @@ class LazySum(DArray):
         return int(np.prod(self._shape))
 
 
+class LazyContract(DArray):
+    """A plates-sized array known as a contraction of smaller arrays: the first moment <f> = W X of
+    a dot product.  Whoever plate-sums a product that contains it (sum y <f>, sum <f>^2: the message
+    to the precision of the observed child and its bound term) contracts the factors pair by pair
+    (``misc.contract_path``: sum_dn y_dn w_dk x_nk = sum_dk w_dk (Y X^T)_dk, a K-sliced GEMM, and
+    sum <f>^2 = (W^T W) : (X^T X)) without the (D, N) array; anything else sees an ordinary device
+    array: ``.t`` evaluates the contraction on first use."""
+    __slots__ = ('ops', 'labs', 'out', 'sizes', 'compress', '_shape', '_dense')
+
+    def __init__(self, ops, labs, out, sizes, compress):
+        self.ops, self.labs, self.out = list(ops), [list(l) for l in labs], list(out)
+        self.sizes, self.compress = dict(sizes), tuple(compress)
+        var = set()
+        for a, ls in zip(self.ops, self.labs):
+            for ax, lab in enumerate(ls):
+                if a.shape[ax] != 1:
+                    var.add(lab)
+        self._shape = tuple(int(sizes[lab]) if (lab not in self.compress or lab in var) else 1
+                            for lab in self.out)
+        self._dense = None
+
+    @property
+    def t(self):
+        if self._dense is None:
+            self._dense = misc.contract(self.ops, self.labs, self.out, self.sizes,
+                                        compress=self.compress).t
+        return self._dense
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return len(self._shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self._shape))
+
+
 def _is_lazy(x):
     # (whether somebody has evaluated the dense form must not change what a consumer computes)
     return isinstance(x, LazySum)
@@ -1336,8 +1377,14 @@ class SumMultiplyFamily:
             labs0.append(l0[len(l0) - x.ndim:])
         out0 = pl + ['k%d' % k for k in n.out_keys]
         out1 = out0 + ['K%d' % k for k in n.out_keys]
-        f0 = misc.contract(ops0, labs0, out0, sizes, compress=pl)
         per_parent = self._second_choices(ups)
+        all_factored = all(len(alts) > 1 for alts in per_parent)
+        if all_factored and not n.out_keys and os.environ.get('BAYESPY_AMD_LAZY_SUMS', '1') != '0' \
+                and os.environ.get('BAYESPY_AMD_LAZY_DOT', '1') != '0':
+            # <f> stays a contraction until somebody needs the array (LazyContract)
+            f0 = LazyContract(ops0, labs0, out0, sizes, pl)
+        else:
+            f0 = misc.contract(ops0, labs0, out0, sizes, compress=pl)
         if not all(len(alts) > 1 for alts in per_parent):
             # some parent carries a dense second moment: the product needs the dense arrays of
             # all of them (a quadratic form per plate pair: D N K^2 flops, the matrix-core GEMM
@@ -2175,6 +2222,8 @@ class GenericPlan(GraphIteration):
                     else:
                         tot = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, tot, t)
                 return tot
+        if any(isinstance(f, LazyContract) for f in factors):
+            return self._plate_sum_contract(factors, to_plates, from_plates)
         big = [f for f in factors if f.size > 1]
         small = [f for f in factors if f.size <= 1]
         if not big:
@@ -2196,6 +2245,60 @@ class GenericPlan(GraphIteration):
             cache[key] = ([weakref.ref(f) for f in big], t)
         for f in small:
             t = fuse(lambda t_, s_: t_ * s_, t, f.reshape(()))
+        return t
+
+    def _plate_sum_contract(self, factors, to_plates, from_plates):
+        """_plate_sum of a product that contains contractions (LazyContract): one labelled
+        contraction over the plate axes and the contractions' own keys, evaluated pair by pair.
+        Same result shape and plate multiplier as misc.sum_multiply_to_plates."""
+        import weakref
+        from ...utils.shapes import broadcasting_multiplier
+        small = [f for f in factors if f.size <= 1 and not isinstance(f, LazyContract)]
+        if small:
+            # plate-free factors multiply the result (and do not key it)
+            t = self._plate_sum_contract([f for f in factors if not any(f is s_ for s_ in small)],
+                                         to_plates, from_plates)
+            for f in small:
+                t = fuse(lambda t_, s_: t_ * s_, t, f.reshape(()))
+            return t
+        ids = tuple(id(f) for f in factors)
+        key = (ids, tuple(to_plates), tuple(from_plates), 'contract')
+        cache = self.__dict__.setdefault('_sum_cache', {})
+        hit = cache.get(key)
+        if hit is not None and [id(r()) for r in hit[0]] == list(ids):
+            return hit[1]
+        full = tuple(broadcasted_shape(*[f.shape for f in factors]))
+        n = len(full)
+        r = broadcasting_multiplier(tuple(from_plates), full, tuple(to_plates))
+        to = (1,) * (n - len(to_plates)) + tuple(to_plates) if n >= len(to_plates) \
+            else tuple(to_plates)[len(to_plates) - n:]
+        sizes = {'p%d' % i: full[i] for i in range(n)}
+        out_labels = ['p%d' % i for i in range(n) if full[i] != 1 and to[i] != 1]
+        ops, labs = [], []
+        for q, f in enumerate(factors):
+            if isinstance(f, LazyContract):
+                off = n - len(f.out)
+                ren = {lab: 'p%d' % (off + j) for j, lab in enumerate(f.out)}
+                for a, ls in zip(f.ops, f.labs):
+                    new = []
+                    for lab in ls:
+                        if lab not in ren:
+                            ren[lab] = 'c%d_%s' % (q, lab)
+                            sizes[ren[lab]] = f.sizes[lab]
+                        new.append(ren[lab])
+                    ops.append(a)
+                    labs.append(new)
+            else:
+                ops.append(f)
+                labs.append(['p%d' % (n - f.ndim + ax) for ax in range(f.ndim)])
+        t = misc.contract_path(ops, labs, out_labels, sizes, scale=float(r))
+        keep = tuple(full[i] if ('p%d' % i) in out_labels else 1 for i in range(n))
+        while len(keep) > len(to_plates) and keep[0] == 1:
+            keep = keep[1:]
+        t = t.reshape(keep)
+        for k in [k for k, v in cache.items() if any(r_() is None for r_ in v[0])]:
+            del cache[k]
+        cache[key] = ([weakref.ref(f) for f in factors], t)
         return t
 
     def _finish_bound(self, node, terms, ignore_masked):

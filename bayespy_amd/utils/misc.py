@@ -488,6 +488,48 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     return out.reshape(tuple(shape[i] for i in range(len(out_labels))))
 
 
+def contract_path(operands, labels, out_labels, sizes, scale=1.0):
+    """The contraction of :func:`contract` evaluated pair by pair (the reference's einsum runs
+    ``optimize=False``: one loop nest over every label, utils/misc.py:906).  Greedy: the pair whose
+    result is smallest goes first (ties: the cheaper product); a label leaves a pair's result as soon
+    as no other operand and not the output carries it.  E.g. sum_dn y_dn w_dk x_nk:
+    (y, x) -> (d, k) is a GEMM over n, then (T, w) -> a number -- never the (d, n) product."""
+    ops = [(asdarray(a), list(ls)) for a, ls in zip(operands, labels)]
+    order = list(out_labels)
+    for _, ls in ops:
+        for lab in ls:
+            if lab not in order:
+                order.append(lab)
+
+    def varying(a, ls):
+        return [lab for ax, lab in enumerate(ls) if a.shape[ax] != 1]
+
+    def extent(labs):
+        n = 1
+        for lab in labs:
+            n *= int(sizes[lab])
+        return n
+    while len(ops) > 2:
+        best = None
+        for i in range(len(ops)):
+            vi = varying(*ops[i])
+            for j in range(i + 1, len(ops)):
+                vj = varying(*ops[j])
+                others = set(out_labels)
+                for q, (a, ls) in enumerate(ops):
+                    if q != i and q != j:
+                        others.update(varying(a, ls))
+                union = [lab for lab in order if lab in vi or lab in vj]
+                res = [lab for lab in union if lab in others]
+                cand = (extent(res), extent(union), i, j, res)
+                if best is None or cand[:4] < best[:4]:
+                    best = cand
+        _, _, i, j, res = best
+        t = contract([ops[i][0], ops[j][0]], [ops[i][1], ops[j][1]], res, sizes)
+        ops = [o for q, o in enumerate(ops) if q != i and q != j] + [(t, res)]
+    return contract([a for a, _ in ops], [ls for _, ls in ops], out_labels, sizes, scale=scale)
+
+
 # ---------------------------------------------------------------------------
 # plate re-indexing (take / put_simple / concatenate, utils/misc.py:549-585 and the
 # np.take / np.concatenate call sites take.py:72-94, concatenate.py:130-167)
