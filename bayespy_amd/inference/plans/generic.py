@@ -1647,8 +1647,13 @@ def _operation(method):
         rt = self.rt
         if rt._op_depth == 0:
             self._graph_note(method.__name__, args)
-        with rt.operation():
-            return method(self, *args, **kwargs)
+        prev = misc._CUR_MEMO[0]
+        misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
+        try:
+            with rt.operation():
+                return method(self, *args, **kwargs)
+        finally:
+            misc._CUR_MEMO[0] = prev
     wrapped._notes_graph = True
     return wrapped
 
@@ -2261,6 +2266,9 @@ class GenericPlan(GraphIteration):
             for f in small:
                 t = fuse(lambda t_, s_: t_ * s_, t, f.reshape(()))
             return t
+        # a fixed order whatever the caller's (arrays before contractions, larger first): the same
+        # product asked for by the message and by the bound is the same contraction
+        factors = sorted(factors, key=lambda f: (isinstance(f, LazyContract), -f.size))
         ids = tuple(id(f) for f in factors)
         key = (ids, tuple(to_plates), tuple(from_plates), 'contract')
         cache = self.__dict__.setdefault('_sum_cache', {})
@@ -2338,6 +2346,7 @@ class GenericPlan(GraphIteration):
         if stash is not None and stash[0] == tuple(id(n) for n in nodes):
             return list(stash[1])          # evaluated inside the recorded sweep (graph_iter.py)
         parts = [self._lower_bound_device(n) for n in nodes]
+        self.__dict__.get('_contract_memo', {}).clear()       # a sweep ends here
         dev = [t.t.reshape(1) for t, _ in parts if t is not None]
         vals = iter(self.rt.torch.cat(dev).cpu().numpy() if dev else ())
         return [f if t is None else float(next(vals)) * f for t, f in parts]

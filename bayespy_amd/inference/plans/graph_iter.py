@@ -200,6 +200,7 @@ class GraphIteration:
         objects); sums over constants stay."""
         self.__dict__.pop('_det_cache', None)
         self.__dict__.pop('_msg_cache', None)
+        self.__dict__.get('_contract_memo', {}).clear()
         sums = self.__dict__.get('_sum_cache')
         if sums:
             const = self._graph_constant_ids()
@@ -238,6 +239,9 @@ class GraphIteration:
             gc_was_on = gc.isenabled()
             gc.disable()
             try:
+                from ...utils import misc
+                memo_was = misc._CUR_MEMO[0]
+                misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
                 with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):
                     with rt.operation():
                         for n in upd:
@@ -250,6 +254,8 @@ class GraphIteration:
             finally:
                 rt._capturing = False
                 rt._deferred = []
+                misc._CUR_MEMO[0] = memo_was
+                self.__dict__.get('_contract_memo', {}).clear()
                 if gc_was_on:
                     gc.enable()
             rec.bound_index = [None if t is None else 1 for t, _ in parts]

@@ -444,6 +444,20 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     broadcast-compressed moments, node.py:311-345).
     """
     ops = [asdarray(a) for a in operands]
+    memo, sig = _CUR_MEMO[0], None
+    if memo is not None and any(a.size >= (1 << 16) for a in ops):
+        # the same contraction of the same (immutable) arrays, asked for by two consumers of one
+        # sweep -- sum_n y_dn x_nk for the Dot message to W and for sum y <f> of the message to tau
+        ren = {}
+        sig = (tuple((a.t.data_ptr(), tuple(a.t.shape), tuple(a.t.stride()),
+                      tuple(ren.setdefault(lab, len(ren)) for lab in ls))
+                     for a, ls in zip(ops, labels)),
+               tuple(ren.setdefault(lab, len(ren)) for lab in out_labels),
+               tuple(sorted((ren[lab], int(sizes[lab])) for lab in ren)), float(scale),
+               tuple(ren[lab] for lab in compress if lab in ren))
+        hit = memo.get(sig)
+        if hit is not None:
+            return hit[0]
     all_labels = list(out_labels)
     for ls in labels:
         for lab in ls:
@@ -485,7 +499,16 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     red = [i for i, lab in enumerate(all_labels) if lab not in out_labels]
     keep_shape = tuple(1 if i in red else shape[i] for i in range(nd))
     out = _launch_sum_multiply(views, shape, red, keep_shape, scale)
-    return out.reshape(tuple(shape[i] for i in range(len(out_labels))))
+    out = out.reshape(tuple(shape[i] for i in range(len(out_labels))))
+    if sig is not None:
+        while len(memo) >= 16:
+            memo.pop(next(iter(memo)))
+        memo[sig] = (out, ops)            # the operands stay alive: their addresses stay theirs
+    return out
+
+
+# the memo of the plan whose operation is running (plans/generic.py sets and clears it); None: off
+_CUR_MEMO = [None]
 
 
 def contract_path(operands, labels, out_labels, sizes, scale=1.0):
