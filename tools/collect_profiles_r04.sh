@@ -5,7 +5,7 @@
 # of VB iterations the profiled command ran.  Every step runs under its own `timeout`.
 O=${1:-gpurun_out/prof_r04}
 shift
-WHICH=${@:-pca_gram lssm_masked masked lssm gmm}
+WHICH=${@:-pca_gram lssm_masked masked lssm gmm generic_pca}
 mkdir -p $O
 R=$PWD
 export TMPDIR=/tmp
@@ -44,6 +44,10 @@ for w in $WHICH; do
       Lm="python $R/bench.py --config lssm_masked --exact-steps --steps 5 --warmup 1 --no-cpu-baseline"
       prof lssm_masked lssmm_backward 6 $Lm
       pmcs lssm_masked lssmm_ "masked LSSM B=10000 T=1000 M=8 D=4" 6 $Lm ;;
+    generic_pca)
+      # the generic engine's sweep replayed from its HIP graph: per-kernel times of the ~130 launches
+      Gp="python $R/bench.py --config generic_pca --exact-steps --steps 20 --no-cpu-baseline"
+      prof generic_pca gemm_skinny 40 $Gp ;;
     gmm)
       G="python $R/bench.py --config gmm --exact-steps --steps 5 --warmup 2 --no-cpu-baseline"
       prof gmm gmm_pass_kernel 7 $G
