@@ -542,3 +542,53 @@ def test_cabi_of_the_index_and_chain_kernels_directly():
     rc = lib.vmp_alpha_beta_recursion(rt.ctx, 1, 65, 1, ptr(big), 65, ptr(big), 0, 0, ptr(big),
                                       ptr(big), ptr(big), ptr(big), big.numel() * 8)
     assert rc == _lib.VMP_ERR_UNSUPPORTED                # more than 64 states
+
+
+@pytest.mark.parametrize('spec,out', [
+    ('dn,dk,nk', ''),            # sum y <f>: (y, x) -> (d, k) first, never the (d, n) product
+    ('dk,nk,dl,nl', ''),         # sum <f>^2 = (W^T W) : (X^T X)
+    ('dn,dk,nk', 'd'),           # the same sums kept per row (a precision with plates (D, 1))
+    ('dn,dn,dk,nk', ''),         # with a plate mask
+    ('nk,kl,nl', 'n'),           # a chain of three with a kept plate
+    ('ab,bc,cd,de', 'ae')])      # a matrix chain
+def test_contract_path_matches_einsum(spec, out):
+    """misc.contract_path: the labelled contraction of misc.contract evaluated pair by pair
+    (smallest intermediate first) against np.einsum, deterministic."""
+    from bayespy_amd.utils import misc
+    sizes = dict(d=24, n=30000, k=6, l=6, a=40, b=50, c=30, e=20)
+    rs = np.random.RandomState(len(spec))
+    terms = spec.split(',')
+    arrs = [rs.normal(size=tuple(sizes[c] for c in t)) for t in terms]
+    ref = np.einsum(spec + '->' + out, *arrs)
+    got = misc.contract_path(arrs, [list(t) for t in terms], list(out), sizes)
+    got2 = misc.contract_path(arrs, [list(t) for t in terms], list(out), sizes)
+    assert got.shape == ref.shape and np.array_equal(got.numpy(), got2.numpy())
+    np.testing.assert_allclose(got.numpy(), ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+
+
+def test_plate_sums_over_lazy_dot_products():
+    """GenericPlan._plate_sum with LazyContract factors (the first moment of a Dot node kept as a
+    contraction): sum y <f>, sum <f>^2, with a plate-free factor and with a kept row axis, against
+    the dense arrays; the dense form itself (.t) equals W X^T."""
+    import bayespy_amd.inference.plans.generic as G
+    from bayespy_amd.darray import DArray
+    D, N, K = 12, 50000, 5
+    rs = np.random.RandomState(2)
+    w, x, y = rs.normal(size=(D, 1, K)), rs.normal(size=(1, N, K)), rs.normal(size=(D, N))
+    W, X, Y = DArray.from_host(w), DArray.from_host(x), DArray.from_host(y)
+    sizes = {'p0': D, 'p1': N, 'k0': K}
+    f = G.LazyContract([W, X], [['p0', 'p1', 'k0'], ['p0', 'p1', 'k0']], ['p0', 'p1'], sizes,
+                       ['p0', 'p1'])
+    fd = w[:, 0, :] @ x[0].T
+    assert f.shape == (D, N)
+    plan = object.__new__(G.GenericPlan)
+    a = DArray.from_host(np.asarray(0.7))
+    cases = [([Y, f], (), fd * y), ([f, f], (), fd * fd), ([a, f, Y], (), 0.7 * fd * y),
+             ([Y, f], (D, 1), fd * y), ([f, f], (1, N), fd * fd)]
+    for factors, to, dense in cases:
+        got = plan._plate_sum(factors, to, (D, N)).numpy()
+        axes = tuple(i for i in range(2) if len(to) == 0 or to[i] == 1)
+        ref = dense.sum(axis=axes, keepdims=len(to) > 0)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_allclose(f.numpy(), fd, rtol=1e-13, atol=1e-13)
