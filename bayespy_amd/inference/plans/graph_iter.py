@@ -20,11 +20,13 @@ sweep copied back into the inputs; everything else is the device work of the eag
 kernel, in the same order, hence with identical results.
 
 Anything the recording cannot hold abandons it before HIP sees the call (``Runtime.host_access``:
-host reads, uploads, collectives): the plan restores its state and stays on the eager path.  Any
-operation on the plan other than the recorded pattern (another ``update`` order, ``observe``,
-rotations, ``set_parameters``, a changed mask / annealing / plate multiplier) drops the graph; the
-state is coherent at every iteration boundary, and read-only operations (moments, bound terms,
-checkpoints) work between replays.
+host reads, uploads, collectives): the plan restores its state and stays on the eager path.  The
+state is coherent at every iteration boundary: read-only operations (moments, bound terms,
+checkpoints) work between replays, and operations that only replace state arrays (a single
+``update``, rotations, ``set_parameters``) keep the graph -- a replay compares the structure of the
+present state with the recorded one and copies whatever arrays it finds into the graph's inputs.
+Everything else drops the graph: ``observe``, ``load``, another sweep (node list), a changed
+mask / annealing / plate multiplier.
 
 ``BAYESPY_AMD_GRAPH=0`` keeps every sweep eager.
 """
@@ -39,7 +41,12 @@ from ...device import GraphCaptureAbort
 READ_ONLY = frozenset((
     'get_moments', 'get_mask', 'lower_bound_contribution', 'lower_bound_contributions', 'save_state',
     'natural_parameters', 'get_parameters', 'log_normalizer', 'gamma_posterior_shape', 'nodes',
-    'has_state', 'describe', 'graph_iteration', 'graph_info'))
+    'has_state', 'describe', 'graph_iteration', 'graph_info', 'rotation_rows',
+    'rotation_statistics', 'logpdf', 'riemannian_gradient', 'gradient'))
+
+# operations that replace state arrays by arrays of the same structure and touch nothing else: the
+# recorded sweep stays valid, a replay first copies the present state into the graph's inputs
+STATE_ONLY = frozenset(('rotate_node', 'set_parameters', 'gradient_step'))
 
 _STATE_FIELDS = ('u', 'phi', 'g', 'f', 'u_obs', 'obs_mask')
 
@@ -50,7 +57,7 @@ def _enabled():
 
 class _Recording:
     __slots__ = ('key', 'graph', 'copy_graph', 'pairs', 'outvec', 'n_bound', 'bound_index', 'factors',
-                 'checks', 'template', 'fresh', 'replays', 'copy_bytes')
+                 'checks', 'template', 'fresh', 'replays', 'copy_bytes', 'old', 'new', 'sig')
 
 
 class GraphIteration:
@@ -76,13 +83,15 @@ class GraphIteration:
             return
         if name == 'update':
             self._g_log.append(('update', id(args[0]) if args else None))
-            if self._g_rec is not None:
-                self._graph_drop('update outside the recorded sweep')
             self._g_stash = None
             return
         if name in READ_ONLY:
             if name == 'lower_bound_contributions':
                 self._g_log.append(('bound', None))
+            return
+        if name in STATE_ONLY:
+            self._g_log.append(('state', name))
+            self._g_stash = None
             return
         self._g_log.append(('other', name))
         self._g_stash = None
@@ -274,6 +283,7 @@ class GraphIteration:
                 seen.add(ko)
                 pairs.append((o, n_))
             rec.pairs = pairs
+            rec.old, rec.new, rec.sig = old, new, sig_old
             rec.copy_graph = None
             if pairs:
                 rec.copy_graph = torch.cuda.CUDAGraph()
@@ -309,8 +319,30 @@ class GraphIteration:
     def _graph_replay(self, rec):
         rt = self.rt
         torch = rt.torch
-        if not rec.fresh and rec.copy_graph is not None:
-            rec.copy_graph.replay()
+        if not rec.fresh:
+            # the graph reads rec.old: whatever the state is NOW goes there first.  Normally the
+            # state is what the previous replay wrote (rec.new: one recorded copy graph); arrays
+            # replaced since by eager operations (a single update, a rotation) are copied one by
+            # one; a state of another structure ends the recording's life
+            cur, sig = self._graph_snapshot()
+            if sig != rec.sig:
+                return None
+
+            def same(a, b):
+                return a.data_ptr() == b.data_ptr() and a.shape == b.shape \
+                    and a.stride() == b.stride()
+            extra, from_new = [], False
+            for c, o, n_ in zip(cur, rec.old, rec.new):
+                if same(c, o):
+                    continue
+                if same(c, n_):
+                    from_new = True
+                else:
+                    extra.append((o, c))
+            if from_new and rec.copy_graph is not None:
+                rec.copy_graph.replay()
+            for o, c in extra:
+                o.copy_(c)
         rec.graph.replay()
         rec.fresh = False
         rec.replays += 1
@@ -344,13 +376,20 @@ class GraphIteration:
         key = self._graph_key(upd, bound)
         log, self._g_log = self._g_log, []
         rec = self._g_rec
-        if rec is not None and rec.key == key and not any(k == 'other' for k, _ in log):
+        if rec is not None and rec.key == key:
             pass
         else:
             if rec is not None:
                 self._graph_drop('another sweep')
-            expect = [('update', id(n)) for n in upd] + [('bound', None)]
-            if key == self._g_last_key and log == expect:
+            # the eager sweep before this one: the updates of `upd` in order, then possibly a
+            # callback (a rotation: state-only operations, the update of a hyperparameter), then
+            # the bound -- and nothing that drops a graph
+            expect = [('update', id(n)) for n in upd]
+            seen = [e for e in log if e[0] != 'state']
+            clean = seen[:len(expect)] == expect and seen[len(expect):] \
+                and seen[-1] == ('bound', None) \
+                and all(e[0] == 'update' for e in seen[len(expect):-1])
+            if key == self._g_last_key and clean:
                 self._g_warm += 1
             else:
                 self._g_warm = 0
@@ -371,5 +410,8 @@ class GraphIteration:
             vals = self._graph_replay(rec)
         finally:
             self._g_inside = False
+        if vals is None:
+            self._graph_drop('the state changed its structure')
+            return False
         self._g_stash = (tuple(id(n) for n in bound), vals)
         return True

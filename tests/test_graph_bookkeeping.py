@@ -85,18 +85,35 @@ def test_read_only_operations_keep_the_graph_and_others_drop_it(monkeypatch):
     for name in sorted(READ_ONLY - {'lower_bound_contributions', 'graph_iteration'}):
         p._graph_note(name, (a,))
     assert p._g_rec is not None and _sweeps(p, [a, b], [a, b], 1) == [True]
-    # a single update is not the recorded sweep; the pattern has to be seen twice again
-    p._graph_note('update', (a,))
-    assert p._g_rec is None and p._g_stash is None
-    assert _sweeps(p, [a, b], [a, b], 4) == [False, False, True, True]
-    assert p.recorded == 2
-    # a mutating operation (anything not known to be read-only)
-    p._graph_note('rotate_node', (a,))
+    # operations that only replace state arrays keep the graph (the replay copies the present
+    # state into its inputs) but the bound terms of the last replay no longer describe the state
+    for name in ('update', 'rotate_node', 'set_parameters'):
+        assert _sweeps(p, [a, b], [a, b], 1) == [True] and p._g_stash is not None
+        p._graph_note(name, (a,))
+        assert p._g_rec is not None and p._g_stash is None
+    assert _sweeps(p, [a, b], [a, b], 2) == [True, True] and p.recorded == 1
+    # a state of another structure ends the recording's life at the next replay
+    p._graph_replay = lambda rec: None
+    assert _sweeps(p, [a, b], [a, b], 1) == [False] and p._g_rec is None
+    del p._graph_replay
+    assert _sweeps(p, [a, b], [a, b], 3) == [False, False, True] and p.recorded == 2
+    # anything not known to keep the state's structure drops the graph
+    p._graph_note('invalidate', (a,))
     assert p._g_rec is None
     assert _sweeps(p, [a, b], [a, b], 4) == [False, False, True, True]
     # another node list is another sweep
     assert _sweeps(p, [a], [a, b], 4) == [False, False, True, True]
     assert p.recorded == 4
+    # a rotation callback between the updates and the bound does not keep a sweep from being recorded
+    q = _Plan([a, b])
+    for _ in range(2):
+        assert not q.graph_iteration([a, b], [a, b])
+        for n in (a, b):
+            q._graph_note('update', (n,))
+        q._graph_note('rotate_node', (a,))
+        q._graph_note('update', (b,))            # the rotation's update of a hyperparameter
+        q._graph_note('lower_bound_contributions', ())
+    assert q.graph_iteration([a, b], [a, b]) and q.recorded == 1
 
 
 def test_host_side_settings_are_part_of_the_key(monkeypatch):
