@@ -52,9 +52,11 @@ def test_graph_replay_is_bit_identical_to_eager_sweeps(monkeypatch):
         assert np.array_equal(np.asarray(a), np.asarray(b))
 
 
-def test_graph_is_dropped_by_new_data_and_rotations(monkeypatch):
-    """observe() between sweeps and a rotation callback after every sweep (the reference's idiom,
-    demos/pca.py:63-68): both change the state outside the recorded sweep."""
+def test_new_data_drops_the_graph_and_rotation_callbacks_keep_it(monkeypatch):
+    """observe() between sweeps changes what a recording has baked in (dropped, recorded again); a
+    rotation callback after every sweep (the reference's idiom, demos/pca.py:63-68) only replaces
+    state arrays: the sweep is recorded with the callback in the loop, every replay first copies the
+    rotated state into the graph's inputs, and the bound is evaluated on the rotated state."""
     import warnings
     from bayespy_amd.inference.transformations import RotateGaussianARD, RotationOptimizer
 
@@ -69,12 +71,14 @@ def test_graph_is_dropped_by_new_data_and_rotations(monkeypatch):
         Q.callback = rot.rotate
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            Q.update(repeat=4, verbose=False)
-        return [Q.L[:Q.iter].copy()] + list(W.get_moments()) + list(X.get_moments())
+            Q.update(repeat=6, verbose=False)
+        return [Q.L[:Q.iter].copy()] + list(W.get_moments()) + list(X.get_moments()), \
+            W._plan.graph_info()
     monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
-    eager = run()
+    eager, _ = run()
     monkeypatch.setenv('BAYESPY_AMD_GRAPH', '1')
-    graph = run()
+    graph, info = run()
+    assert info['recorded'] and info['replays'] >= 3, info       # replays WITH the callback
     for a, b in zip(eager, graph):
         assert np.array_equal(np.asarray(a), np.asarray(b))
 
