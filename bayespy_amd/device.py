@@ -121,7 +121,7 @@ class Runtime:
         plan records an iteration into a HIP graph such a step cannot be recorded, and the
         recording is abandoned BEFORE the HIP call that would invalidate the capture."""
         if self._capturing:
-            raise GraphCaptureAbort(what)
+            raise GraphCaptureAbort('needs the host: %s' % what)
 
     def all_reduce_sum_(self, tensor):
         """In-place sum over ranks: ``vmp_allreduce_sum_f64`` (RCCL all-reduce over xGMI,

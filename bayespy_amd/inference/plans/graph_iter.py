@@ -236,6 +236,14 @@ class GraphIteration:
                 # the graph's inputs are written by the copy-back: they must be ordinary arrays
                 if any(s == 0 and e > 1 for s, e in zip(t.stride(), t.shape)):
                     raise GraphCaptureAbort('broadcast view in the state')
+            # the recording keeps a second copy of the state and the temporaries of one sweep: not
+            # for a model that fills the device (the eager sweep reuses the allocator's blocks)
+            state_bytes = sum(t.numel() * t.element_size() for t in old)
+            free_bytes = torch.cuda.mem_get_info(rt.device)[0] + \
+                torch.cuda.memory_reserved(rt.device) - torch.cuda.memory_allocated(rt.device)
+            if 4 * state_bytes > free_bytes:
+                raise GraphCaptureAbort('%.1f GB of state, %.1f GB free: no room for a recording'
+                                        % (state_bytes / 1e9, free_bytes / 1e9))
             rec = _Recording()
             rec.key = key
             rec.graph = torch.cuda.CUDAGraph()
@@ -308,7 +316,7 @@ class GraphIteration:
             self._graph_reset_caches()
             torch.cuda.synchronize(rt.device)
             if isinstance(e, GraphCaptureAbort):
-                self._g_disabled = 'needs the host: %s' % (e,)
+                self._g_disabled = str(e)
             else:
                 self._g_disabled = '%s: %s' % (type(e).__name__, str(e)[:200])
             if os.environ.get('BAYESPY_AMD_GRAPH_DEBUG'):
