@@ -75,12 +75,15 @@ class GraphIteration:
         self._g_stash = None
         self._g_inside = False
         self._g_attempts = 0
+        self._g_touched = True
         self._mask_epoch = 0
 
     def _graph_note(self, name, args):
         """Called by the operation wrapper for every outermost operation on the plan."""
         if self._g_inside:
             return
+        if name not in READ_ONLY:
+            self._g_touched = True          # the state may no longer be what the last replay wrote
         if name == 'update':
             self._g_log.append(('update', id(args[0]) if args else None))
             self._g_stash = None
@@ -327,7 +330,11 @@ class GraphIteration:
     def _graph_replay(self, rec):
         rt = self.rt
         torch = rt.torch
-        if not rec.fresh:
+        if not rec.fresh and not self._g_touched:
+            # nothing but read-only operations since the last replay: the state is its output
+            if rec.copy_graph is not None:
+                rec.copy_graph.replay()
+        elif not rec.fresh:
             # the graph reads rec.old: whatever the state is NOW goes there first.  Normally the
             # state is what the previous replay wrote (rec.new: one recorded copy graph); arrays
             # replaced since by eager operations (a single update, a rotation) are copied one by
@@ -353,6 +360,7 @@ class GraphIteration:
                 o.copy_(c)
         rec.graph.replay()
         rec.fresh = False
+        self._g_touched = False
         rec.replays += 1
         vals = rec.outvec.cpu().numpy() if rec.outvec is not None else np.zeros(0)
         # the state objects of the recording, as fresh wrappers (same device arrays)
