@@ -214,6 +214,7 @@ def block_banded_solve(A, B, y):
         ctypes.c_void_p(yc.t.data_ptr()), ctypes.c_void_p(V.t.data_ptr()),
         ctypes.c_void_p(C.t.data_ptr()), ctypes.c_void_p(x.t.data_ptr()),
         ctypes.c_void_p(ldet.t.data_ptr()), ctypes.c_void_p(info.data_ptr())))
-    if bool(info.any().item()):
-        raise _lib.NotPositiveDefiniteError("Matrix not positive definite")
+    # read with the other validity flags of the running plan operation (no sync per solve; inside a
+    # recorded sweep the flag is one of the graph's outputs)
+    rt.defer_check(info, _lib.NotPositiveDefiniteError, "Matrix not positive definite")
     return V, C, x, ldet

@@ -426,6 +426,7 @@ def onehot(labels, K):
     rt.check(rt.lib.vmp_onehot_i64(rt.ctx, n, K, ctypes.c_void_p(dl.data_ptr()),
                                    ctypes.c_void_p(out.t.data_ptr()),
                                    ctypes.c_void_p(info.data_ptr())))
+    rt.host_access('onehot')
     if int(info.item()) != 0:
         raise ValueError("Class indices out of range [0, %d)" % K)
     return out
