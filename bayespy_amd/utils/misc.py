@@ -512,43 +512,54 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
 _CUR_MEMO = [None]
 
 
-def contract_path(operands, labels, out_labels, sizes, scale=1.0):
-    """The contraction of :func:`contract` evaluated pair by pair (the reference's einsum runs
-    ``optimize=False``: one loop nest over every label, utils/misc.py:906).  Greedy: the pair whose
-    result is smallest goes first (ties: the cheaper product); a label leaves a pair's result as soon
-    as no other operand and not the output carries it.  E.g. sum_dn y_dn w_dk x_nk:
-    (y, x) -> (d, k) is a GEMM over n, then (T, w) -> a number -- never the (d, n) product."""
-    ops = [(asdarray(a), list(ls)) for a, ls in zip(operands, labels)]
+def plan_contraction(varying, out_labels, sizes):
+    """The pairwise order :func:`contract_path` uses, from shapes alone: ``varying[i]`` = the labels
+    operand i really varies along.  Returns steps ``(i, j, result_labels)`` over a growing operand
+    list (each step appends its result and retires i and j; indices refer to the list as it stands
+    when the step runs, results appended at the end) until at most two operands are left.  Greedy:
+    smallest result first, ties by the cheaper product, then by position -- deterministic."""
     order = list(out_labels)
-    for _, ls in ops:
+    for ls in varying:
         for lab in ls:
             if lab not in order:
                 order.append(lab)
-
-    def varying(a, ls):
-        return [lab for ax, lab in enumerate(ls) if a.shape[ax] != 1]
 
     def extent(labs):
         n = 1
         for lab in labs:
             n *= int(sizes[lab])
         return n
-    while len(ops) > 2:
+    live = [list(v) for v in varying]
+    steps = []
+    while len(live) > 2:
         best = None
-        for i in range(len(ops)):
-            vi = varying(*ops[i])
-            for j in range(i + 1, len(ops)):
-                vj = varying(*ops[j])
+        for i in range(len(live)):
+            for j in range(i + 1, len(live)):
                 others = set(out_labels)
-                for q, (a, ls) in enumerate(ops):
+                for q, v in enumerate(live):
                     if q != i and q != j:
-                        others.update(varying(a, ls))
-                union = [lab for lab in order if lab in vi or lab in vj]
+                        others.update(v)
+                union = [lab for lab in order if lab in live[i] or lab in live[j]]
                 res = [lab for lab in union if lab in others]
                 cand = (extent(res), extent(union), i, j, res)
                 if best is None or cand[:4] < best[:4]:
                     best = cand
         _, _, i, j, res = best
+        steps.append((i, j, res))
+        live = [v for q, v in enumerate(live) if q != i and q != j] + [res]
+    return steps
+
+
+def contract_path(operands, labels, out_labels, sizes, scale=1.0):
+    """The contraction of :func:`contract` evaluated pair by pair (the reference's einsum runs
+    ``optimize=False``: one loop nest over every label, utils/misc.py:906).  Greedy
+    (:func:`plan_contraction`): the pair whose result is smallest goes first (ties: the cheaper
+    product); a label leaves a pair's result as soon as no other operand and not the output carries
+    it.  E.g. sum_dn y_dn w_dk x_nk: (y, x) -> (d, k) is a GEMM over n, then (T, w) -> a number --
+    never the (d, n) product."""
+    ops = [(asdarray(a), list(ls)) for a, ls in zip(operands, labels)]
+    varying = [[lab for ax, lab in enumerate(ls) if a.shape[ax] != 1] for a, ls in ops]
+    for i, j, res in plan_contraction(varying, out_labels, sizes):
         t = contract([ops[i][0], ops[j][0]], [ops[i][1], ops[j][1]], res, sizes)
         ops = [o for q, o in enumerate(ops) if q != i and q != j] + [(t, res)]
     return contract([a for a, _ in ops], [ls for _, ls in ops], out_labels, sizes, scale=scale)
