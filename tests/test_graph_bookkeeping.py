@@ -155,3 +155,102 @@ def test_every_public_operation_of_the_plan_reports():
                 'gradient_step'}
     assert not (mutators & READ_ONLY)
     assert mutators <= set(vars(GenericPlan))
+
+
+@pytest.fixture
+def cpu_runtime():
+    """DArray wrappers over CPU tensors (no kernel is launched by the code under test here)."""
+    from bayespy_amd import device
+    prev = device._runtime
+    device.set_runtime(device.Runtime(device='cpu'))
+    yield
+    device.set_runtime(prev)
+
+
+def test_state_snapshots_and_rewrapping(cpu_runtime):
+    """The leaves of a plan's state (what a replay copies into the graph's inputs), the structure
+    signature that decides whether a recording still fits, and the re-wrapping after a replay:
+    fresh wrapper objects over the SAME tensors, shared wrappers stay shared, lazily evaluated dense
+    forms are left behind."""
+    import bayespy_amd.inference.plans.generic as G
+    from bayespy_amd.darray import DArray
+    mean = DArray.from_host(np.arange(12.0).reshape(1, 4, 3))
+    cov = DArray.from_host(np.eye(3).reshape(1, 1, 3, 3))
+    fm = G.FactoredMoment(cov, mean, 1)
+    assert fm.shape == (1, 4, 3, 3) and fm.size == 36 and fm._dense is None
+    state = [mean, fm]
+    leaves, sig = [], []
+    GraphIteration._leaves(state, leaves, sig, ('n', 'u'))
+    assert [t.data_ptr() for t in leaves] == [mean.t.data_ptr(), cov.t.data_ptr(), mean.t.data_ptr()]
+    kinds = [s[1] for s in sig]
+    assert kinds == ['list', 'tensor', 'factored', 'tensor', 'tensor']
+    # host-side values are part of the structure, by value
+    leaves2, sig2 = [], []
+    GraphIteration._leaves([np.inf, None, 2.5], leaves2, sig2, ('n', 'g'))
+    assert leaves2 == [] and [s[2] for s in sig2[1:]] == [float('inf'), None, 2.5]
+    with pytest.raises(Exception):
+        GraphIteration._leaves(object(), [], [], ())
+    # re-wrapping: new objects, same tensors, sharing kept, dense form dropped
+    fm._dense = object()
+    memo = {}
+    new = GraphIteration._rewrap(state, memo)
+    assert new is not state and new[0] is not mean and new[1] is not fm
+    assert new[0].t is mean.t and new[1].cov.t is cov.t
+    assert new[1].mean is new[0] and new[1]._dense is None
+    assert GraphIteration._rewrap((1.0, None), {}) == (1.0, None)
+    # the signature does not depend on whether somebody evaluated the dense form
+    leaves3, sig3 = [], []
+    GraphIteration._leaves(new, leaves3, sig3, ('n', 'u'))
+    assert sig3 == sig
+
+
+def test_lazy_arrays_know_their_shape_without_being_evaluated(cpu_runtime):
+    """LazySum / LazyContract: shape, size and the lazy flag come from the factors; nothing is
+    evaluated by asking (consumers that plate-sum them never form the array)."""
+    import bayespy_amd.inference.plans.generic as G
+    from bayespy_amd.darray import DArray
+    W = DArray.from_host(np.ones((5, 1, 3)))
+    X = DArray.from_host(np.ones((1, 7, 3)))
+    sizes = {'p0': 5, 'p1': 7, 'k0': 3}
+    f = G.LazyContract([W, X], [['p0', 'p1', 'k0']] * 2, ['p0', 'p1'], sizes, ['p0', 'p1'])
+    assert f.shape == (5, 7) and f.size == 35 and f.ndim == 2 and f._dense is None
+    # a compressed plate no operand varies along stays broadcast
+    g = G.LazyContract([W], [['p0', 'p1', 'k0']], ['p0', 'p1'], sizes, ['p0', 'p1'])
+    assert g.shape == (5, 1)
+    made = []
+    s = G.LazySum([(1.0, [f, f]), (1.0, [DArray.from_host(np.ones((1, 7)))])], (5, 7),
+                  lambda: made.append(1))
+    assert s.shape == (5, 7) and s.size == 35 and G._is_lazy(s) and made == []
+    assert not G._is_lazy(W) and not G._is_lazy(f)
+
+
+def test_vb_offers_a_sweep_to_one_generic_plan_only():
+    """VB._graph_sweep: the whole model must belong to ONE plan that knows graph_iteration; fully
+    observed nodes are not part of the sweep; anything else is visited node by node."""
+    from bayespy_amd.inference.vb import VB
+
+    class Plan:
+        def __init__(self):
+            self.calls = []
+
+        def graph_iteration(self, upd, bound):
+            self.calls.append(([n.name for n in upd], [n.name for n in bound]))
+            return True
+
+    def node(name, plan, observed=False):
+        n = types.SimpleNamespace(name=name, _plan=plan, observed=observed, _fully_observed=True)
+        n.update = lambda: None
+        return n
+    p, q = Plan(), Plan()
+    Q = object.__new__(VB)
+    y, w, x = node('y', p, observed=True), node('w', p), node('x', p)
+    Q.model = [y, w, x]
+    assert VB._graph_sweep(Q, ['y', 'w', 'x']) is True
+    assert p.calls == [(['w', 'x'], ['y', 'w', 'x'])]
+    # a second plan in the model, a plan without graphs, a node outside any plan
+    Q.model = [y, w, node('z', q)]
+    assert VB._graph_sweep(Q, ['w']) is False
+    Q.model = [node('a', object())]
+    assert VB._graph_sweep(Q, ['a']) is False
+    Q.model = [node('b', None)]
+    assert VB._graph_sweep(Q, ['b']) is False
