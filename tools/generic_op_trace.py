@@ -1,0 +1,76 @@
+"""Op-level trace of one generic-engine PCA iteration (BASELINE config 2): every fused elementwise
+launch and every sum_multiply / GEMM launch with shapes and its synchronous duration."""
+import os, sys, time, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bayespy_amd import darray
+from bayespy_amd.utils import misc
+import bayespy_amd.inference.plans.generic as G
+LOG = []
+ON = [False]
+def caller():
+    for fs in reversed(traceback.extract_stack()[:-3]):
+        if 'plans/generic.py' in fs.filename or 'utils/linalg.py' in fs.filename or 'utils/misc.py' in fs.filename:
+            return '%s:%d %s' % (os.path.basename(fs.filename), fs.lineno, fs.name)
+    return '?'
+def wrap(mod, name, kind):
+    orig = getattr(mod, name)
+    def f(*a, **k):
+        if not ON[0]:
+            return orig(*a, **k)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        ON[0] = False
+        try:
+            r = orig(*a, **k)
+        finally:
+            ON[0] = True
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        shapes = [tuple(x.shape) for x in a if hasattr(x, 'shape')]
+        if kind == 'sm':
+            shapes = [tuple(x.shape) for x in a[0]] + ['->', tuple(a[3])]
+        LOG.append((dt * 1e3, kind, str(shapes)[:110], caller()))
+        return r
+    setattr(mod, name, f)
+wrap(misc, '_launch_sum_multiply', 'sm')
+orig_fuse = darray.fuse
+def fuse_t(fn, *ops):
+    if not ON[0]:
+        return orig_fuse(fn, *ops)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    r = orig_fuse(fn, *ops)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    LOG.append((dt * 1e3, 'ew', str([tuple(x.shape) for x in ops if hasattr(x, 'shape')])[:110], caller()))
+    return r
+darray.fuse = fuse_t; G.fuse = fuse_t; misc.fuse = fuse_t
+import bayespy_amd.utils.linalg as LA
+if hasattr(LA, 'fuse'): LA.fuse = fuse_t
+from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+from bayespy_amd.inference import VB
+N, D, K = 1_000_000, 64, 16
+dev = torch.device('cuda', 0)
+g = torch.Generator(device=dev); g.manual_seed(42)
+w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)
+x = torch.randn(K, N, generator=g, device=dev, dtype=torch.float64)
+y = w @ x + 0.1 * torch.randn(D, N, generator=g, device=dev, dtype=torch.float64)
+x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
+alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha'); W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X'); F = SumMultiply('i,i', W, X, name='F')
+tau = Gamma(1e-2, 1e-2, name='tau'); Y = GaussianARD(F, tau, name='Y')
+X.initialize_from_value(x0[None]); Y.observe(y)
+Q = VB(Y, F, W, X, tau, alpha, engine='generic'); Q.ignore_bound_checks = True
+Q.update(repeat=2, verbose=False)
+torch.cuda.synchronize()
+t = time.perf_counter(); Q.update(repeat=3, verbose=False); torch.cuda.synchronize()
+print('untraced ms/iter', (time.perf_counter() - t) / 3 * 1e3)
+ON[0] = True
+Q.update(repeat=1, verbose=False)
+ON[0] = False
+tot = sum(l[0] for l in LOG)
+print('traced launches', len(LOG), 'sum ms', round(tot, 2))
+for l in sorted(LOG, key=lambda l: -l[0])[:40]:
+    print('%7.3f %-3s %-110s %s' % l)
+os.makedirs('gpurun_out', exist_ok=True)
+with open('gpurun_out/gen_trace_seq.txt', 'w') as f:
+    for l in LOG:
+        f.write('%7.3f %-3s %-110s %s\n' % l)
+print('peak GB', torch.cuda.max_memory_allocated() / 1e9)
