@@ -163,6 +163,7 @@ SIGNATURES = {
                                   c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'vmp_lssmm_x_update': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i64,
                                    c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_lssmm_rotate_p': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),
     'vmp_lssmm_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i32, P(c_f64), c_i32, c_i32, P(c_i32),
                                     c_vp]),
     'vmp_gmm_get_layout': (c_i32, [c_i32, c_i32, P(GMMLayout)]),

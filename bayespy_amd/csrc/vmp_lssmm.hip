@@ -23,7 +23,9 @@ namespace {
 
 constexpr int WNT = 64;       // one wavefront per workgroup: few sequences must spread over many CUs
 constexpr int RNT = 256;
-constexpr int MG = 4;         // rows of C per thread of the statistics pass
+constexpr int MG1 = 4;        // rows of C per thread of the statistics pass, one thread per sequence
+constexpr int MG4 = 8;        // rows of C per lane group of the statistics pass, D <= 4
+constexpr int MG8 = 4;        // ... D > 4 (two rows of the matrices per lane)
 
 struct dg_fn {
     __host__ __device__ double operator()(double x) const { return vmp_digamma(x); }
@@ -114,19 +116,29 @@ lssmm_setup_finish_kernel(const double *__restrict__ partial, int n,
 }
 
 // ---------------------------------------------------------------------------------------------
-// sweeps: one thread per sequence
+// sweeps: G lanes per sequence (vmp_lssmm_dev.h), one wavefront per workgroup
 // ---------------------------------------------------------------------------------------------
 struct sweep_args {
     lssmm_seq_args S;
     const double *seqobs;
     int64_t B;
     int tab_len;
+    int pstride;            // doubles per workgroup in ``partial``
     double *partial;        // per workgroup
     double *status;         // state[off_scal]
     int given;
 };
 
-template <int D>
+// sum over the sequences of the wavefront, separately for every lane position of the group
+template <int G>
+__device__ __forceinline__ double seqs_sum(double v)
+{
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int D, int G>
 __global__ void __launch_bounds__(WNT)
 lssmm_forward_kernel(sweep_args A)
 {
@@ -135,21 +147,31 @@ lssmm_forward_kernel(sweep_args A)
     __syncthreads();
     lssmm_seq_args S = A.S;
     S.tab = tab;
-    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
-    double ld = 0.0;
+    const int64_t tid = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    const int64_t bq = tid / G;
+    const int lane = (int)(tid % G);
+    const bool live = bq < A.B;
+    const int64_t b = live ? bq : A.B - 1;       // the tail of the last wavefront repeats a sequence
     int bad = 0;
-    if (b < A.B) ld = lssmm_forward_seq<D>(S, b, bad);
+    double ld = lssmm_forward_seq<D, G>(S, b, lane, live, bad);
     // log|Phi_b| of the sequences with data (an ignored plate adds nothing to the bound)
-    ld = (b < A.B) ? ld * A.seqobs[b] : 0.0;
+    ld = (live && lane == 0) ? ld * A.seqobs[b] : 0.0;
     ld = wave_sum(ld);
     if (threadIdx.x == 0) A.partial[blockIdx.x] = ld;
-    if (bad) A.status[0] = (double)VMP_ERR_NOT_POSDEF;
+    if (bad && live) A.status[0] = (double)VMP_ERR_NOT_POSDEF;
 }
 
-template <int D>
+struct put_store {
+    double *out;
+    __device__ void operator()(int slot, double v) const { out[slot] = v; }
+};
+
+// partial[blk]: chain sums (CL) and, MF > 0, the statistics XX (M, NS) | Syx (M, D) behind them
+template <int D, int G, int MF>
 __global__ void __launch_bounds__(WNT)
 lssmm_backward_kernel(sweep_args A)
 {
+    using AC = lssmm_acc<D, G, MF>;
     constexpr int NS = D * (D + 1) / 2;
     constexpr int CL = 3 * NS + D * D + D;        // chain sums without log|Phi|
     extern __shared__ double tab[];
@@ -157,44 +179,49 @@ lssmm_backward_kernel(sweep_args A)
     __syncthreads();
     lssmm_seq_args S = A.S;
     S.tab = tab;
-    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
-    double acc[CL];
+    const int64_t tid = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    const int64_t bq = tid / G;
+    const int lane = (int)(tid % G);
+    const bool live = bq < A.B;
+    const int64_t b = live ? bq : A.B - 1;
+    double acc[AC::len];
+    lssmm_backward_seq<D, G, MF>(S, b, lane, live, A.given, acc);
+    // chain sums: sequences with data only; the statistics carry the mask themselves
+    const double wc = live ? A.seqobs[b] : 0.0;
 #pragma unroll
-    for (int e = 0; e < CL; ++e) acc[e] = 0.0;
-    if (b < A.B) {
-        lssmm_backward_seq<D>(S, b, A.given, acc);
-        const double w = A.seqobs[b];
-#pragma unroll
-        for (int e = 0; e < CL; ++e) acc[e] *= w;
+    for (int e = 0; e < AC::len; ++e) {
+        const double v = e < AC::chain ? acc[e] * wc : (live ? acc[e] : 0.0);
+        acc[e] = seqs_sum<G>(v);
     }
-#pragma unroll
-    for (int e = 0; e < CL; ++e) {
-        const double s = wave_sum(acc[e]);
-        if (threadIdx.x == 0) A.partial[(int64_t)blockIdx.x * CL + e] = s;
+    if (threadIdx.x < G) {
+        double *out = A.partial + (int64_t)blockIdx.x * A.pstride;
+        lssmm_put_chain<D, G>(lane, acc, put_store{out});
+        if (MF > 0)
+            lssmm_put_stats<D, G, (MF > 0 ? MF : 1)>(lane, 0, S.M, acc + AC::XX, acc + AC::Syx,
+                                                    put_store{out + CL});
     }
 }
 
-// (The row groups of a sequence block as wavefronts of ONE workgroup -- so that P / Z come from HBM
-// once -- was measured and rejected: 1.84 instead of 3.04 GB per launch at M = 8, but 0.83 instead of
-// 0.75 ms: the pass is latency-bound, and one workgroup per group spreads over twice the CUs.)
-template <int D>
+// partial[blk]: XX (M, NS) | Syx (M, D); blockIdx.y = the group of MG rows of C
+template <int D, int G, int MG>
 __global__ void __launch_bounds__(WNT)
 lssmm_stats_kernel(sweep_args A)
 {
-    constexpr int NS = D * (D + 1) / 2;
-    constexpr int AL = MG * (NS + D);
-    const int64_t b = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    constexpr int R = (D + G - 1) / G;
+    constexpr int AL = MG * R * (D + 1);
+    const int64_t tid = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    const int64_t bq = tid / G;
+    const int lane = (int)(tid % G);
+    const bool live = bq < A.B;
+    const int64_t b = live ? bq : A.B - 1;
     const int m0 = blockIdx.y * MG;
     double acc[AL];
+    lssmm_stats_seq<D, G, MG>(A.S, b, lane, m0, acc);
 #pragma unroll
-    for (int e = 0; e < AL; ++e) acc[e] = 0.0;
-    if (b < A.B) lssmm_stats_seq<D, MG>(A.S, b, m0, acc);
-#pragma unroll
-    for (int e = 0; e < AL; ++e) {
-        const double s = wave_sum(acc[e]);
-        if (threadIdx.x == 0)
-            A.partial[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * AL + e] = s;
-    }
+    for (int e = 0; e < AL; ++e) acc[e] = seqs_sum<G>(live ? acc[e] : 0.0);
+    if (threadIdx.x < G)
+        lssmm_put_stats<D, G, MG>(lane, m0, A.S.M, acc, acc + MG * R * D,
+                                  put_store{A.partial + (int64_t)blockIdx.x * A.pstride});
 }
 
 // out[j] = sum_blk partial[blk * stride + j], fixed order; 16 row-lanes x 16 outputs per workgroup
@@ -218,29 +245,19 @@ lssmm_sum_kernel(const double *__restrict__ partial, int n, int stride, int len,
     }
 }
 
-// the statistics partials [blk][group][MG][NS + D] -> XX (M, NS) | Syx (M, D)
+// P[t][.][b] <- R P R^T: one thread per (step, sequence), R through scalar loads
+template <int D>
 __global__ void __launch_bounds__(RNT)
-lssmm_sum_stats_kernel(const double *__restrict__ partial, int n, int ng, int M, int NS, int D,
-                       double *__restrict__ XX, double *__restrict__ Syx)
+lssmm_rotate_p_kernel(const double *__restrict__ R, int T, int64_t B, int64_t BL, double *__restrict__ P)
 {
-    __shared__ double tile[16][17];
-    const int kx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int stride = ng * MG * (NS + D);
-    const int j = blockIdx.x * 16 + kx;
-    double acc = 0.0;
-    if (j < stride)
-        for (int b = ry; b < n; b += 16) acc += partial[(int64_t)b * stride + j];
-    tile[ry][kx] = acc;
+    constexpr int NS = D * (D + 1) / 2;
+    __shared__ double Rs[D * D];
+    if (threadIdx.x < D * D) Rs[threadIdx.x] = R[threadIdx.x];
     __syncthreads();
-    if (ry == 0 && j < stride) {
-        double s = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += tile[r][kx];
-        const int m = j / (NS + D), f = j - m * (NS + D);
-        if (m < M) {
-            if (f < NS) XX[m * NS + f] = s;
-            else Syx[m * D + (f - NS)] = s;
-        }
+    const int64_t n = (int64_t)T * B;
+    for (int64_t e = (int64_t)blockIdx.x * RNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * RNT) {
+        const int64_t t = e / B, b = e - t * B;
+        lssmm_rotate_packed<D>(Rs, P + t * NS * BL + b, BL);
     }
 }
 
@@ -261,20 +278,32 @@ lssmm_small_kernel(lssmm_small_args A, double *__restrict__ gst)
     for (int e = threadIdx.x; e < total; e += 64) gst[e] = st_lds[e];
 }
 
-inline int64_t nwg(int64_t B) { return (B + WNT - 1) / WNT; }
+constexpr int GMAX = 4;        // lanes per sequence of the default form
+
+inline int64_t nwg(int64_t B, int G) { return (B * G + WNT - 1) / WNT; }
+
+// lanes per sequence: 4 (rows dealt over a DPP quad) unless the tune key asks for the
+// one-thread-per-sequence form, which exists up to D = 4
+inline int lanes_for(int D)
+{
+    const int g = vmp_tune_get("lssmm_lanes", GMAX);
+    return (g == 1 && D <= 4) ? 1 : GMAX;
+}
+
+// the backward sweep carries the statistics of all rows of C (G = 4 only: 40 accumulators a lane)
+inline bool fused_stats(int D, int M, int G)
+{
+    return G == GMAX && D <= 4 && M <= LSSMM_MFUSE && vmp_tune_get("lssmm_fuse", 1) != 0;
+}
 
 // workspace (doubles): [sweep partials | set-up partials] then M + 1 integer counters
 inline int64_t ws_partials(int D, int M, int64_t B)
 {
     const int NS = D * (D + 1) / 2;
-    const int64_t g = nwg(B) > 0 ? nwg(B) : 1;
-    const int64_t ng = (M + MG - 1) / MG;
-    const int64_t a = g * (3 * NS + D * D + D) + g;            // backward + forward (log|Phi|)
-    const int64_t s = g * ng * MG * (NS + D);
+    const int64_t g = nwg(B, GMAX) > 0 ? nwg(B, GMAX) : 1;
+    const int64_t a = g * (3 * NS + D * D + D + (int64_t)M * (NS + D)) + g;   // backward (+ stats) + log|Phi|
     const int64_t r = 256 * 8;                                 // prepare partials
-    int64_t n = a > s ? a : s;
-    if (r > n) n = r;
-    return n + 64;
+    return (a > r ? a : r) + 64;
 }
 
 }  // namespace
@@ -290,7 +319,7 @@ int32_t vmp_lssmm_limits(int32_t *max_D, int32_t *max_M)
 
 int32_t vmp_lssmm_get_layout(int32_t D, int32_t M, vmp_lssmm_layout *out)
 {
-    if (!out || D < 1 || D > LSSMM_DMAX || M < 1 || M > LSSMM_MMAX) return VMP_ERR_INVALID;
+    if (!out || !lssmm_dims_ok(D, M)) return VMP_ERR_INVALID;
     lssmm_fill_layout(D, M, out);
     return VMP_OK;
 }
@@ -298,7 +327,7 @@ int32_t vmp_lssmm_get_layout(int32_t D, int32_t M, vmp_lssmm_layout *out)
 int32_t vmp_lssmm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, int64_t *n)
 {
     (void)T;
-    if (!n || D < 1 || D > LSSMM_DMAX || M < 1 || M > LSSMM_MMAX || B < 0) return VMP_ERR_INVALID;
+    if (!n || !lssmm_dims_ok(D, M) || B < 0) return VMP_ERR_INVALID;
     *n = ws_partials(D, M, B) + LSSMM_MMAX + 8;
     return VMP_OK;
 }
@@ -310,8 +339,8 @@ int32_t vmp_lssmm_prepare(vmp_ctx *ctx, const double *Y, const uint8_t *mask, in
 {
     VMP_REQUIRE(ctx, ctx && Y && mask && Yt && Mw && seqobs && state && workspace, VMP_ERR_INVALID,
                 "null argument");
-    VMP_REQUIRE(ctx, M >= 1 && M <= LSSMM_MMAX && D >= 1 && D <= LSSMM_DMAX && B >= 0 && T >= 1
-                && BL >= B && BL >= 1, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, lssmm_dims_ok(D, M) && B >= 0 && T >= 1 && BL >= B && BL >= 1, VMP_ERR_INVALID,
+                "bad dims (D <= 8, M <= 64, M D^2 <= 2048)");
     vmp_lssmm_layout L;
     lssmm_fill_layout(D, M, &L);
     double *partial = reinterpret_cast<double *>(workspace);
@@ -342,8 +371,8 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
 {
     VMP_REQUIRE(ctx, ctx && Yt && Mw && seqobs && state && F && Z && P && workspace, VMP_ERR_INVALID,
                 "null argument");
-    VMP_REQUIRE(ctx, M >= 1 && M <= LSSMM_MMAX && D >= 1 && D <= LSSMM_DMAX && B >= 0 && T >= 1
-                && BL >= B, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, lssmm_dims_ok(D, M) && B >= 0 && T >= 1 && BL >= B, VMP_ERR_INVALID,
+                "bad dims (D <= 8, M <= 64, M D^2 <= 2048)");
     vmp_lssmm_layout L;
     lssmm_fill_layout(D, M, &L);
     const lssmm_raw ro = lssmm_raw_offsets(D, M);
@@ -351,6 +380,10 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
     const int NS = (int)L.NS;
     double *partial = reinterpret_cast<double *>(workspace);
     double *raw = state + L.off_raw;
+    const int G = lanes_for(D);
+    const bool fuse = fused_stats(D, M, G) && given != 2;
+    const int CL = ro.chain_len - 1;
+    const int SL = M * (NS + D);
     sweep_args A;
     A.S.Yt = Yt;
     A.S.Mw = Mw;
@@ -364,37 +397,55 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
     A.seqobs = seqobs;
     A.B = B;
     A.tab_len = to.len;
+    A.pstride = fuse ? CL + SL : CL;
     A.partial = partial;
     A.status = state + L.off_scal;
     A.given = given == 1 ? 1 : 0;
-    const int64_t g = nwg(B);
+    const int64_t g = nwg(B, G);
     const size_t lds = (size_t)to.len * sizeof(double);
     hipStream_t s = ctx->stream;
     hipEvent_t *ev = ctx->timing ? vmp_next_events(ctx) : nullptr;
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], s));
-    const int CL = ro.chain_len - 1;
-    double *pld = partial + g * CL;               // log|Phi| partials behind the backward partials
-#define LSSMM_FOR_D(MACRO) \
-    switch (D) { case 1: MACRO(1) break; case 2: MACRO(2) break; case 3: MACRO(3) break; default: MACRO(4) break; }
+    double *pld = partial + g * (CL + SL);        // log|Phi| partials behind the backward partials
+    // D = 1..8 with four lanes per sequence; D <= 4 also as one thread per sequence
+#define LSSMM_FOR_DG(MACRO)                                                                          \
+    if (G == 1) {                                                                                    \
+        switch (D) { case 1: MACRO(1, 1) break; case 2: MACRO(2, 1) break; case 3: MACRO(3, 1) break; \
+                     default: MACRO(4, 1) break; }                                                   \
+    } else {                                                                                         \
+        switch (D) { case 1: MACRO(1, 4) break; case 2: MACRO(2, 4) break; case 3: MACRO(3, 4) break; \
+                     case 4: MACRO(4, 4) break; case 5: MACRO(5, 4) break; case 6: MACRO(6, 4) break; \
+                     case 7: MACRO(7, 4) break; default: MACRO(8, 4) break; }                        \
+    }
     // given == 2: q(X) is unchanged (Y re-observed: new data / mask) -- only the sums that involve the
     // data and the mask are taken again from the stored <x>, <x x^T>; chain sums and log|Phi| stay
     if (given != 2) {
         if (g > 0 && !given) {
             sweep_args Af = A;
             Af.partial = pld;
-#define LSSMM_FWD(d) hipLaunchKernelGGL(lssmm_forward_kernel<d>, dim3((unsigned)g), dim3(WNT), lds, s, Af);
-            LSSMM_FOR_D(LSSMM_FWD)
+#define LSSMM_FWD(d, gg) hipLaunchKernelGGL((lssmm_forward_kernel<d, gg>), dim3((unsigned)g), dim3(WNT), lds, s, Af);
+            LSSMM_FOR_DG(LSSMM_FWD)
 #undef LSSMM_FWD
         }
         if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
         if (g > 0) {
-#define LSSMM_BWD(d) hipLaunchKernelGGL(lssmm_backward_kernel<d>, dim3((unsigned)g), dim3(WNT), lds, s, A);
-            LSSMM_FOR_D(LSSMM_BWD)
+            if (fuse) {
+#define LSSMM_BWDF(d) hipLaunchKernelGGL((lssmm_backward_kernel<d, GMAX, LSSMM_MFUSE>), dim3((unsigned)g), dim3(WNT), lds, s, A);
+                switch (D) { case 1: LSSMM_BWDF(1) break; case 2: LSSMM_BWDF(2) break;
+                             case 3: LSSMM_BWDF(3) break; default: LSSMM_BWDF(4) break; }
+#undef LSSMM_BWDF
+            } else {
+#define LSSMM_BWD(d, gg) hipLaunchKernelGGL((lssmm_backward_kernel<d, gg, 0>), dim3((unsigned)g), dim3(WNT), lds, s, A);
+                LSSMM_FOR_DG(LSSMM_BWD)
 #undef LSSMM_BWD
+            }
         }
         // chain sums, log|Phi|: fixed-order sums over the workgroups (an empty local plate: zeros)
         hipLaunchKernelGGL(lssmm_sum_kernel, dim3((unsigned)((CL + 15) / 16)), dim3(RNT), 0, s, partial,
-                           (int)g, CL, CL, raw);
+                           (int)g, A.pstride, CL, raw);
+        if (fuse)
+            hipLaunchKernelGGL(lssmm_sum_kernel, dim3((unsigned)((SL + 15) / 16)), dim3(RNT), 0, s,
+                               partial + CL, (int)g, A.pstride, SL, raw + ro.XX);
         if (given || g == 0)
             VMP_HIP_CHECK(ctx, hipMemsetAsync(raw + ro.ld, 0, sizeof(double), s));
         else
@@ -402,16 +453,40 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
     } else if (ev) {
         VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
     }
-    const int ng = (M + MG - 1) / MG;
-    if (g > 0) {
-#define LSSMM_STATS(d) hipLaunchKernelGGL(lssmm_stats_kernel<d>, dim3((unsigned)g, (unsigned)ng), dim3(WNT), 0, s, A);
-        LSSMM_FOR_D(LSSMM_STATS)
+    if (!fuse) {
+        sweep_args As = A;
+        As.pstride = SL;
+        const int MGd = G == 1 ? MG1 : (D <= 4 ? MG4 : MG8);
+        const int ng = (M + MGd - 1) / MGd;
+        if (g > 0) {
+#define LSSMM_STATS(d, gg) hipLaunchKernelGGL((lssmm_stats_kernel<d, gg, (gg == 1 ? MG1 : (d <= 4 ? MG4 : MG8))>), dim3((unsigned)g, (unsigned)ng), dim3(WNT), 0, s, As);
+            LSSMM_FOR_DG(LSSMM_STATS)
 #undef LSSMM_STATS
+        }
+        hipLaunchKernelGGL(lssmm_sum_kernel, dim3((unsigned)((SL + 15) / 16)), dim3(RNT), 0, s, partial,
+                           (int)g, SL, SL, raw + ro.XX);
     }
-    const int slen = ng * MG * (NS + D);
-    hipLaunchKernelGGL(lssmm_sum_stats_kernel, dim3((unsigned)((slen + 15) / 16)), dim3(RNT), 0, s,
-                       partial, (int)g, ng, M, NS, D, raw + ro.XX, raw + ro.Syx);
+#undef LSSMM_FOR_DG
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[2], s));
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    return VMP_OK;
+}
+
+int32_t vmp_lssmm_rotate_p(vmp_ctx *ctx, int32_t D, int32_t T, int64_t B, int64_t BL, const double *R,
+                           double *P)
+{
+    VMP_REQUIRE(ctx, ctx && R && P, VMP_ERR_INVALID, "null argument");
+    VMP_REQUIRE(ctx, D >= 1 && D <= LSSMM_DMAX && T >= 1 && B >= 0 && BL >= B, VMP_ERR_INVALID,
+                "bad dims");
+    if (B == 0) return VMP_OK;
+    int64_t g = ((int64_t)T * B + RNT - 1) / RNT;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (g > cap) g = cap;
+    switch (D) {
+#define LSSMM_ROT(d) case d: hipLaunchKernelGGL(lssmm_rotate_p_kernel<d>, dim3((unsigned)g), dim3(RNT), 0, ctx->stream, R, T, B, BL, P); break;
+        LSSMM_ROT(1) LSSMM_ROT(2) LSSMM_ROT(3) LSSMM_ROT(4) LSSMM_ROT(5) LSSMM_ROT(6) LSSMM_ROT(7) LSSMM_ROT(8)
+#undef LSSMM_ROT
+    }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -420,8 +495,8 @@ int32_t vmp_lssmm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, const
                             int32_t nu_latent, int32_t nops, const int32_t *ops, double *state)
 {
     VMP_REQUIRE(ctx, ctx && priors && ops && state, VMP_ERR_INVALID, "null argument");
-    VMP_REQUIRE(ctx, D >= 1 && D <= LSSMM_DMAX && M >= 1 && M <= LSSMM_MMAX && T >= 1 && nops >= 1
-                && nops <= 12, VMP_ERR_INVALID, "bad dims");
+    VMP_REQUIRE(ctx, lssmm_dims_ok(D, M) && T >= 1 && nops >= 1 && nops <= 12, VMP_ERR_INVALID,
+                "bad dims");
     lssmm_small_args A;
     lssmm_fill_layout(D, M, &A.L);
     A.D = D;
@@ -431,8 +506,18 @@ int32_t vmp_lssmm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, const
     for (int i = 0; i < nops; ++i) A.ops[i] = ops[i];
     for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
     A.nu_latent = nu_latent;
-    hipLaunchKernelGGL(lssmm_small_kernel, dim3(1), dim3(64), (size_t)A.L.total * sizeof(double),
-                       ctx->stream, A, state);
+    const size_t lds = (size_t)A.L.total * sizeof(double);
+    if (lds + sizeof(double) * lssmm_small_scratch(64) > 64 * 1024) {
+        // beyond the default 64 KB of a workgroup (D = 8 with many rows of C): gfx950 has 160 KB
+        static bool raised = false;
+        if (!raised) {
+            VMP_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(lssmm_small_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   120 * 1024));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(lssmm_small_kernel, dim3(1), dim3(64), lds, ctx->stream, A, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }

@@ -1,9 +1,18 @@
 // vmp_lssmm_dev.h -- per-sequence and replicated-node arithmetic of the state-space block with
-// ARRAY masks (vmp_lssmm.hip).  Every function here is plain scalar code on the registers of ONE
-// thread (one sequence, or the single thread of the replicated-node kernel), written host+device:
-// the kernels of vmp_lssmm.hip call them with b = the thread's sequence, and tests/host/
-// lssmm_host.cpp compiles the SAME text with g++ and loops over b -- the CPU suite checks this
-// arithmetic against oracle/lssm.py (MaskedLSSMOracle, pinned on the live reference) without a GPU.
+// ARRAY masks (vmp_lssmm.hip).  Host+device text: the kernels of vmp_lssmm.hip call the sweeps with
+// b = the sequence and lane = the position of the calling thread inside the sequence's lane group,
+// and tests/host/lssmm_host.cpp compiles the SAME text with g++ (lane groups of one) and loops over
+// b -- the CPU suite checks this arithmetic against oracle/lssm.py (MaskedLSSMOracle, pinned on the
+// live reference) without a GPU.
+//
+// A sequence is dealt over G lanes of a wavefront (G = 4 on the device, 1 on the host and as the
+// device's alternative form): lane l owns the rows l R .. l R + R - 1, R = ceil(D / G), of every
+// D x D matrix of the recursion (S_t, S_t^-1, J_t, V_t, <x x^T>) and the matching entries of the
+// vectors.  A product with a constant right-hand side (E) is local; a product whose right-hand
+// side is a matrix of the recursion takes it from the owners (lssmm_lanes<G>::bc: DPP quad
+// permutes on the device, the identity for G = 1).  The arithmetic of an entry -- the terms of its
+// sums and their order -- does not depend on G.  Symmetric matrices are used through the lower
+// triangle of the row owners: entry (i, k), k <= i, is the one lane(i) computed.
 //
 // Reference code restated: linalg.block_banded_solve (utils/linalg.py:468-575) per sequence,
 // GaussianMarkovChainDistribution (gaussian_markov_chain.py:270-707), SumMultiply messages with
@@ -24,11 +33,29 @@
 #endif
 #endif
 
-constexpr int LSSMM_DMAX = 4;
-constexpr int LSSMM_MMAX = 64;
+constexpr int LSSMM_DMAX = 8;
+constexpr int LSSMM_MMAX = 64;           // one bit of the mask word per observed dimension
+constexpr int LSSMM_MDD_MAX = 2048;      // M D^2: the tables of the sweeps in LDS (16 KB)
+constexpr int LSSMM_MFUSE = 8;           // rows of C whose statistics the backward sweep carries
+
+VMP_HD constexpr bool lssmm_dims_ok(int D, int M)
+{
+    return D >= 1 && D <= LSSMM_DMAX && M >= 1 && M <= LSSMM_MMAX && M * D * D <= LSSMM_MDD_MAX;
+}
 
 // packed lower triangle: (i, j), i >= j  ->  i (i + 1) / 2 + j
 VMP_HD constexpr int sym_ix(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// offsets inside the table block (state + off_tab): full (unpacked) matrices, rows contiguous
+//   base (3 D^2: t = 0, inner, last) | E (D^2) | h0 (D) | tau c_m (M D) | tau <c_m c_m^T> (M D^2)
+struct lssmm_tab {
+    int base, E, h0, C, CC, len;
+};
+VMP_HD constexpr lssmm_tab lssmm_tab_offsets(int D, int M)
+{
+    return lssmm_tab{0, 3 * D * D, 4 * D * D, 4 * D * D + D, 4 * D * D + D + M * D,
+                     4 * D * D + D + M * D + M * D * D};
+}
 
 VMP_HD void lssmm_fill_layout(int D, int M, vmp_lssmm_layout *L)
 {
@@ -50,7 +77,7 @@ VMP_HD void lssmm_fill_layout(int D, int M, vmp_lssmm_layout *L)
     L->off_AA = o;       o += (int64_t)DD * D;
     L->off_ldA = o;      o += D;
     L->off_tab = o;
-    L->len_tab = 3 * NS + DD + D + (int64_t)M * D + (int64_t)M * NS;
+    L->len_tab = lssmm_tab_offsets(D, M).len;
     o += L->len_tab;
     L->off_setup = o;
     L->len_setup = 2 + M;
@@ -61,23 +88,6 @@ VMP_HD void lssmm_fill_layout(int D, int M, vmp_lssmm_layout *L)
     L->off_scal = o;     o += 8;
     L->off_L = o;        o += 16;
     L->total = (o + 7) / 8 * 8;
-}
-
-// offsets inside the table block (state + off_tab)
-struct lssmm_tab {
-    int base, E, h0, C, CC, len;
-};
-VMP_HD lssmm_tab lssmm_tab_offsets(int D, int M)
-{
-    const int NS = D * (D + 1) / 2;
-    lssmm_tab t;
-    t.base = 0;
-    t.E = 3 * NS;
-    t.h0 = t.E + D * D;
-    t.C = t.h0 + D;
-    t.CC = t.C + M * D;
-    t.len = t.CC + M * NS;
-    return t;
 }
 
 // offsets inside the raw plate sums (state + off_raw)
@@ -101,6 +111,57 @@ VMP_HD lssmm_raw lssmm_raw_offsets(int D, int M)
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// lane groups: G adjacent lanes of the wavefront hold one sequence.  bc(v, j): the value of v on
+// lane j of the caller's group, on every lane of the group (j a constant after unrolling).
+// ---------------------------------------------------------------------------------------------
+template <int G>
+struct lssmm_lanes;
+
+template <>
+struct lssmm_lanes<1> {
+    static VMP_HD double bc(double v, int) { return v; }
+};
+
+#if defined(__HIPCC__)
+template <>
+struct lssmm_lanes<4> {
+    template <int J>
+    static __device__ __forceinline__ double quad(double v)
+    {
+        // DPP quad_perm [J, J, J, J]: a vector-ALU move, no LDS crossbar
+        constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ double bc(double v, int j)
+    {
+        switch (j) {
+        case 0: return quad<0>(v);
+        case 1: return quad<1>(v);
+        case 2: return quad<2>(v);
+        default: return quad<3>(v);
+        }
+    }
+};
+#endif
+
+// 1 / x for a pivot (positive, far from the ends of the exponent range): on the device the
+// hardware estimate and two Newton steps (5 instructions, <= 1 ulp) instead of the IEEE division
+// sequence (~15) -- four to eight of them sit on the serial path of every time step
+VMP_HD double lssmm_recip(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
 // running log-determinant without a logarithm per pivot (the product is folded into ld only when
 // it leaves a safe range)
 VMP_HD void lssmm_ld_acc(double piv, double &prod, double &ld)
@@ -110,41 +171,6 @@ VMP_HD void lssmm_ld_acc(double piv, double &prod, double &ld)
         ld += log(prod);
         prod = 1.0;
     }
-}
-
-// in-place inverse of the SPD matrix a (packed lower triangle, D <= 4) by the symmetric
-// Gauss-Jordan sweep on the full matrix; pivots go into (prod, ld); a non-positive pivot sets *bad.
-template <int D>
-VMP_HD void lssmm_spd_inverse(double *a, double &prod, double &ld, int &bad)
-{
-    double m[D][D];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) m[i][j] = a[sym_ix(i, j)];
-#pragma unroll
-    for (int p = 0; p < D; ++p) {
-        const double piv = m[p][p];
-        if (!(piv > 0.0)) bad = 1;
-        lssmm_ld_acc(piv, prod, ld);
-        const double d = 1.0 / piv;
-#pragma unroll
-        for (int j = 0; j < D; ++j) m[p][j] *= d;
-        m[p][p] = d;
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            if (i == p) continue;
-            const double c = m[i][p];
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-                if (j != p) m[i][j] -= c * m[p][j];
-            m[i][p] = -c * d;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) a[sym_ix(i, j)] = 0.5 * (m[i][j] + m[j][i]);
 }
 
 // arrays of one sequence: element f of time step t at base[(t * nf + f) * BL + b]
@@ -159,34 +185,96 @@ struct lssmm_seq_args {
     int64_t BL;
 };
 
+// the rows of this lane: global index, index clamped into the matrix (a lane beyond the last row
+// works on a copy of row D - 1 and stores nothing), offset of the row in the packed triangle
+template <int D, int G>
+struct lssmm_rows {
+    static constexpr int R = (D + G - 1) / G;
+    int row[R], rowc[R], tri[R];
+    VMP_HD explicit lssmm_rows(int lane)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            row[r] = lane * R + r;
+            rowc[r] = row[r] < D ? row[r] : D - 1;
+            tri[r] = rowc[r] * (rowc[r] + 1) / 2;
+        }
+    }
+    VMP_HD bool valid(int r) const { return row[r] < D; }
+    // offset of entry (row r, k) in the packed lower triangle (either side of the diagonal)
+    VMP_HD int sym(int r, int k) const { return k <= rowc[r] ? tri[r] + k : k * (k + 1) / 2 + rowc[r]; }
+};
+
+// in-place inverse of the SPD matrix whose rows are dealt over the lanes (S[r][.] = row lane R + r)
+// by the Gauss-Jordan sweep: the pivot row travels from its owner, every lane updates its rows;
+// pivots go into (prod, ld) on every lane alike; a non-positive pivot sets bad.
+template <int D, int G>
+VMP_HD void lssmm_rows_inverse(double (*S)[D], const lssmm_rows<D, G> &rw, double &prod, double &ld,
+                               int &bad)
+{
+    using LN = lssmm_lanes<G>;
+    constexpr int R = (D + G - 1) / G;
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+        double prs[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) prs[k] = LN::bc(S[p % R][k], p / R);
+        const double piv = prs[p];
+        if (!(piv > 0.0)) bad = 1;
+        lssmm_ld_acc(piv, prod, ld);
+        const double d = lssmm_recip(piv);
+#pragma unroll
+        for (int k = 0; k < D; ++k) prs[k] *= d;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool isp = rw.row[r] == p;
+            const double c = S[r][p];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                if (k == p) continue;
+                const double u = fma(-c, prs[k], S[r][k]);
+                S[r][k] = isp ? prs[k] : u;
+            }
+            S[r][p] = isp ? d : -c * d;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward sweep of sequence b: S_t = Dg_t - E^T S_t-1^-1 E with Dg_t = base_t + sum_m mask tau<cc>_m,
-// z_t = h_t - (S_t-1^-1 E)^T z_t-1 with h_t = sum_m y tau c_m (+ Lam0 mu0 at t = 0); S_t^-1 and z_t
-// go to F.  Returns log|Phi_b| = sum_t log|S_t|; *bad on a non-positive pivot.
+// z_t = h_t - E^T S_t-1^-1 z_t-1 with h_t = sum_m y tau c_m (+ Lam0 mu0 at t = 0); S_t^-1 (packed
+// lower triangle) and z_t go to F.  Returns log|Phi_b| = sum_t log|S_t| (on every lane of the
+// group); bad on a non-positive pivot.  ``live`` = the lane stores (false for the clamped copies
+// that fill the last wavefront).
 // ---------------------------------------------------------------------------------------------
-template <int D>
-VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int &bad)
+template <int D, int G>
+VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int lane, bool live, int &bad)
 {
-    constexpr int NS = D * (D + 1) / 2;
-    const lssmm_tab to = lssmm_tab_offsets(D, A.M);
+    using LN = lssmm_lanes<G>;
+    constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2, DD = D * D;
+    constexpr int oE = 3 * DD, oh0 = 4 * DD, oC = 4 * DD + D;
+    const lssmm_rows<D, G> rw(lane);
     const double *tab = A.tab;
     const int M = A.M, T = A.T;
+    const int oCC = oC + M * D;
     const int64_t BL = A.BL;
-    double E[D][D];
+    // column i of E for the rows i of this lane (E^T . from the left)
+    double ET[R][D];
 #pragma unroll
-    for (int j = 0; j < D; ++j)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int k = 0; k < D; ++k) E[j][k] = tab[to.E + j * D + k];
-    double Sinv[NS], z[D];
+        for (int j = 0; j < D; ++j) ET[r][j] = tab[oE + j * D + rw.rowc[r]];
+    double S[R][D], zf[D];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) Sinv[s] = 0.0;
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int i = 0; i < D; ++i) z[i] = 0.0;
+        for (int k = 0; k < D; ++k) S[r][k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) zf[i] = 0.0;
     double prod = 1.0, ld = 0.0;
     // The operands of a step do not depend on the recursion: they are requested one chunk of MC
     // observed dimensions (for M <= MC: one time step) ahead of their use, so that the HBM
-    // latency runs beside the arithmetic of the current step (a sequence's thread has the SIMD
-    // almost to itself: 1e4 sequences are 157 wavefronts for 1024 SIMDs).
+    // latency runs beside the arithmetic of the current step.
     constexpr int MC = 8;
     const int nch = (M + MC - 1) / MC;
     double yn[MC];
@@ -196,12 +284,14 @@ VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int &bad)
     for (int t = 0; t < T; ++t) {
         const uint64_t w = wn;
         if (t + 1 < T) wn = A.Mw[(int64_t)(t + 1) * BL + b];
-        const double *bs = tab + to.base + (t == 0 ? 0 : (t < T - 1 ? NS : 2 * NS));
-        double S[NS], h[D];
+        const double *bs = tab + (t == 0 ? 0 : (t < T - 1 ? DD : 2 * DD));
+        double Sn[R][D], h[R];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) S[s] = bs[s];
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) h[i] = (t == 0) ? tab[to.h0 + i] : 0.0;
+            for (int k = 0; k < D; ++k) Sn[r][k] = bs[rw.rowc[r] * D + k];
+            h[r] = (t == 0) ? tab[oh0 + rw.rowc[r]] : 0.0;
+        }
         for (int c = 0; c < nch; ++c) {
             double y[MC];
 #pragma unroll
@@ -220,252 +310,374 @@ VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int &bad)
             for (int g = 0; g < MC; ++g) {
                 const int m = c * MC + g;
                 if (m < M) {
-                    const double *cm = tab + to.C + m * D;
+                    const double bd = (double)((w >> m) & 1);
 #pragma unroll
-                    for (int i = 0; i < D; ++i) h[i] += y[g] * cm[i];
-                    if ((w >> m) & 1) {
-                        const double *cc = tab + to.CC + m * NS;
+                    for (int r = 0; r < R; ++r) {
+                        const double *cc = tab + oCC + (m * D + rw.rowc[r]) * D;
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) S[s] += cc[s];
+                        for (int k = 0; k < D; ++k) Sn[r][k] = fma(bd, cc[k], Sn[r][k]);
+                        h[r] = fma(y[g], tab[oC + m * D + rw.rowc[r]], h[r]);
                     }
                 }
             }
         }
         if (t > 0) {
-            // J = S_t-1^-1 E;  S -= E^T J;  z = h - J^T z_prev
-            double J[D][D];
+            // Tm = E^T S_t-1^-1 (rows of this lane; S_t-1^-1 from the lower triangle of its owners)
+            double Tm[R][D];
 #pragma unroll
-            for (int i = 0; i < D; ++i)
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int l = 0; l < D; ++l) Tm[r][l] = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int l = 0; l <= j; ++l) {
+                    const double s = LN::bc(S[j % R][l], j / R);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        Tm[r][l] = fma(ET[r][j], s, Tm[r][l]);
+                        if (l != j) Tm[r][j] = fma(ET[r][l], s, Tm[r][j]);
+                    }
+                }
+            // S_t -= Tm E;  h -= Tm z_t-1
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    double s = 0.0;
+                    double a = Sn[r][k];
 #pragma unroll
-                    for (int j = 0; j < D; ++j) s += Sinv[sym_ix(i, j)] * E[j][k];
-                    J[i][k] = s;
+                    for (int l = 0; l < D; ++l) a = fma(-Tm[r][l], tab[oE + l * D + k], a);
+                    Sn[r][k] = a;
                 }
+                double a = h[r];
 #pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int k = 0; k <= i; ++k) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) s += E[j][i] * J[j][k];
-                    S[sym_ix(i, k)] -= s;
-                }
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < D; ++j) s += J[j][i] * z[j];
-                h[i] -= s;
+                for (int l = 0; l < D; ++l) a = fma(-Tm[r][l], zf[l], a);
+                h[r] = a;
             }
         }
-        lssmm_spd_inverse<D>(S, prod, ld, bad);
-        double *fp = A.F + (int64_t)t * (NS + D) * BL + b;
+        lssmm_rows_inverse<D, G>(Sn, rw, prod, ld, bad);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            Sinv[s] = S[s];
-            fp[(int64_t)s * BL] = S[s];
-        }
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            z[i] = h[i];
-            fp[(int64_t)(NS + i) * BL] = h[i];
+            for (int k = 0; k < D; ++k) S[r][k] = Sn[r][k];
+#pragma unroll
+        for (int l = 0; l < D; ++l) zf[l] = LN::bc(h[l % R], l / R);
+        if (live) {
+            double *fp = A.F + (int64_t)t * (NS + D) * BL + b;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rw.valid(r)) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        if (k <= rw.row[r]) fp[(int64_t)(rw.tri[r] + k) * BL] = Sn[r][k];
+                    fp[(int64_t)(NS + rw.row[r]) * BL] = h[r];
+                }
         }
     }
     return ld + log(prod);
 }
 
+// accumulators of a lane (rows of this lane): the chain sums, then -- when the backward sweep
+// carries the statistics of MF rows of C -- XX_m rows and Syx_m entries
+//   sumP[R][D] | SnpT[R][D] (column i of sum <x_t+1 x_t^T>) | P0[R][D] | PT[R][D] | x0[R] |
+//   XX[MF][R][D] | Syx[MF][R]
+template <int D, int G, int MF>
+struct lssmm_acc {
+    static constexpr int R = (D + G - 1) / G;
+    static constexpr int sumP = 0, Snp = R * D, P0 = 2 * R * D, PT = 3 * R * D, x0 = 4 * R * D;
+    static constexpr int chain = 4 * R * D + R;
+    static constexpr int XX = chain, Syx = chain + MF * R * D;
+    static constexpr int len = chain + MF * R * (D + 1);
+};
+
 // ---------------------------------------------------------------------------------------------
-// backward sweep of sequence b: x_t = S_t^-1 z_t - J_t x_t+1, Cov(x_t, x_t+1) = -J_t V_t+1,
-// V_t = S_t^-1 - Cov(x_t, x_t+1) J_t^T  (J_t = S_t^-1 E), P_t = V_t + x_t x_t^T; x -> Z, P -> P.
-// given: the <x> in Z are point masses (V = 0), no recursion.
-// acc (lssmm_raw chain part, chain_len doubles, ld NOT included): sum_t P | sum <x_t+1 x_t^T> |
-// P_0 | P_T-1 | x_0.
+// backward sweep of sequence b: x_t = S_t^-1 z_t - J_t x_t+1, W = J_t V_t+1 (= -Cov(x_t, x_t+1)),
+// V_t = S_t^-1 + W J_t^T  (J_t = S_t^-1 E), P_t = V_t + x_t x_t^T; x -> Z, P -> P (packed).
+// given: the <x> in Z are point masses (V = 0), no recursion.  MF > 0: the statistics of the rows
+// m < M <= MF of C (XX_m += mask_mbt P_bt, Syx_m += y_mbt x_bt) ride along -- P and <x> never come
+// back from HBM for them.  acc: lssmm_acc<D, G, MF> (this lane's rows; not weighted).
 // ---------------------------------------------------------------------------------------------
-template <int D>
-VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int given, double *acc)
+template <int D, int G, int MF>
+VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, bool live, int given,
+                               double *acc)
 {
-    constexpr int NS = D * (D + 1) / 2;
-    const lssmm_tab to = lssmm_tab_offsets(D, A.M);
-    const lssmm_raw ro = lssmm_raw_offsets(D, A.M);
-    const int T = A.T;
+    using LN = lssmm_lanes<G>;
+    using AC = lssmm_acc<D, G, MF>;
+    constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2, DD = D * D;
+    constexpr int oE = 3 * DD;
+    constexpr int MFR = MF > 0 ? MF : 1;
+    const lssmm_rows<D, G> rw(lane);
+    const double *tab = A.tab;
+    const int M = A.M, T = A.T;
     const int64_t BL = A.BL;
-    double E[D][D];
+    double sumP[R][D], snpT[R][D], XX[MFR][R][D], Syx[MFR][R];
 #pragma unroll
-    for (int j = 0; j < D; ++j)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int k = 0; k < D; ++k) E[j][k] = A.tab[to.E + j * D + k];
-    double sumP[NS], Snp[D][D], Vn[NS], xn[D], PT[NS];
+        for (int k = 0; k < D; ++k) sumP[r][k] = snpT[r][k] = 0.0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) sumP[s] = Vn[s] = PT[s] = 0.0;
+    for (int m = 0; m < MFR; ++m)
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        xn[i] = 0.0;
+        for (int r = 0; r < R; ++r) {
+            Syx[m][r] = 0.0;
 #pragma unroll
-        for (int j = 0; j < D; ++j) Snp[i][j] = 0.0;
-    }
-    double Pc[NS], x[D];
+            for (int k = 0; k < D; ++k) XX[m][r][k] = 0.0;
+        }
+    double Vnp[NS], xn[D];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) Pc[s] = 0.0;
+    for (int s = 0; s < NS; ++s) Vnp[s] = 0.0;
 #pragma unroll
-    for (int i = 0; i < D; ++i) x[i] = 0.0;
-    double fn[NS + D];
+    for (int i = 0; i < D; ++i) xn[i] = 0.0;
+    // operands of the step, requested one step ahead: this lane's rows of S_t^-1, z_t (given: <x_t>)
+    // in full, and for the statistics y_t and the mask word
+    double fn[R][D], zn[D], yn[MFR];
+    uint64_t wn = 0;
 #pragma unroll
-    for (int s = 0; s < NS + D; ++s)
-        fn[s] = given ? 0.0 : A.F[((int64_t)(T - 1) * (NS + D) + s) * BL + b];
-    for (int t = T - 1; t >= 0; --t) {
-        double V[NS];
-        double *zp = A.Z + (int64_t)t * D * BL + b;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) fn[r][k] = 0.0;
+#pragma unroll
+    for (int m = 0; m < MFR; ++m) yn[m] = 0.0;
+    {
+        const int t = T - 1;
         if (given) {
+            const double *zp = A.Z + (int64_t)t * D * BL + b;
 #pragma unroll
-            for (int i = 0; i < D; ++i) x[i] = zp[(int64_t)i * BL];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) V[s] = 0.0;
-            if (t < T - 1) {
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) Snp[i][j] += xn[i] * x[j];
-            }
+            for (int i = 0; i < D; ++i) zn[i] = zp[(int64_t)i * BL];
         } else {
-            double Sinv[NS], z[D];
+            const double *fp = A.F + (int64_t)t * (NS + D) * BL + b;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) Sinv[s] = fn[s];
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int i = 0; i < D; ++i) z[i] = fn[NS + i];
-            if (t > 0) {
-                // the forward quantities of the step before: requested now, used next round
+                for (int k = 0; k < D; ++k) fn[r][k] = fp[(int64_t)rw.sym(r, k) * BL];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zn[i] = fp[(int64_t)(NS + i) * BL];
+        }
+        if (MF > 0) {
+            wn = A.Mw[(int64_t)t * BL + b];
+#pragma unroll
+            for (int m = 0; m < MFR; ++m) yn[m] = (m < M) ? A.Yt[((int64_t)t * M + m) * BL + b] : 0.0;
+        }
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        double Si[R][D], z[D], y[MFR];
+        const uint64_t w = wn;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < D; ++k) Si[r][k] = fn[r][k];
+#pragma unroll
+        for (int i = 0; i < D; ++i) z[i] = zn[i];
+#pragma unroll
+        for (int m = 0; m < MFR; ++m) y[m] = yn[m];
+        if (t > 0) {
+            if (given) {
+                const double *zp = A.Z + (int64_t)(t - 1) * D * BL + b;
+#pragma unroll
+                for (int i = 0; i < D; ++i) zn[i] = zp[(int64_t)i * BL];
+            } else {
                 const double *fp = A.F + (int64_t)(t - 1) * (NS + D) * BL + b;
 #pragma unroll
-                for (int s = 0; s < NS + D; ++s) fn[s] = fp[(int64_t)s * BL];
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) fn[r][k] = fp[(int64_t)rw.sym(r, k) * BL];
+#pragma unroll
+                for (int i = 0; i < D; ++i) zn[i] = fp[(int64_t)(NS + i) * BL];
+            }
+            if (MF > 0) {
+                wn = A.Mw[(int64_t)(t - 1) * BL + b];
+#pragma unroll
+                for (int m = 0; m < MFR; ++m)
+                    yn[m] = (m < M) ? A.Yt[((int64_t)(t - 1) * M + m) * BL + b] : 0.0;
+            }
+        }
+        // V: rows of Cov(x_t); W: rows of J_t V_t+1 = -Cov(x_t, x_t+1); x: <x_t> of this lane's rows
+        double V[R][D], W[R][D], x[R], xf[D];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < D; ++k) V[r][k] = W[r][k] = 0.0;
+        if (given) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double s = z[0];
+#pragma unroll
+                for (int i = 1; i < D; ++i) s = (rw.rowc[r] == i) ? z[i] : s;
+                x[r] = s;
             }
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
+            for (int i = 0; i < D; ++i) xf[i] = z[i];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
                 double s = 0.0;
 #pragma unroll
-                for (int j = 0; j < D; ++j) s += Sinv[sym_ix(i, j)] * z[j];
-                x[i] = s;
+                for (int j = 0; j < D; ++j) s = fma(Si[r][j], z[j], s);
+                x[r] = s;
+#pragma unroll
+                for (int k = 0; k < D; ++k) V[r][k] = Si[r][k];
             }
-            if (t == T - 1) {
+            if (t < T - 1) {
+                double J[R][D];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) V[s] = Sinv[s];
-            } else {
-                double J[D][D], Cn[D][D];
-#pragma unroll
-                for (int i = 0; i < D; ++i)
+                for (int r = 0; r < R; ++r) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
                         double s = 0.0;
 #pragma unroll
-                        for (int j = 0; j < D; ++j) s += Sinv[sym_ix(i, j)] * E[j][k];
-                        J[i][k] = s;
+                        for (int j = 0; j < D; ++j) s = fma(Si[r][j], tab[oE + j * D + k], s);
+                        J[r][k] = s;
                     }
+                    double s = x[r];
 #pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    double s = 0.0;
+                    for (int k = 0; k < D; ++k) s = fma(-J[r][k], xn[k], s);
+                    x[r] = s;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) s += J[i][k] * xn[k];
-                    x[i] -= s;
+                    for (int k = 0; k < D; ++k) {
+                        double u = 0.0;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) u = fma(J[r][l], Vnp[sym_ix(l, k)], u);
+                        W[r][k] = u;
+                    }
                 }
+                // V_t = S_t^-1 + W J_t^T: the rows of J_t from their owners
 #pragma unroll
-                for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j)
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        double s = 0.0;
+                        const double jj = LN::bc(J[j % R][k], j / R);
 #pragma unroll
-                        for (int l = 0; l < D; ++l) s += J[i][l] * Vn[sym_ix(l, k)];
-                        Cn[i][k] = -s;
+                        for (int r = 0; r < R; ++r) V[r][j] = fma(W[r][k], jj, V[r][j]);
                     }
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        // symmetrised like the reference (utils/linalg.py:572): 1/2 (V + V^T)
-                        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            s1 += Cn[i][k] * J[j][k];
-                            s2 += Cn[j][k] * J[i][k];
-                        }
-                        V[sym_ix(i, j)] = Sinv[sym_ix(i, j)] - 0.5 * (s1 + s2);
-                    }
-                // <x_t+1 x_t^T> = Cov(x_t, x_t+1)^T + means
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) Snp[i][j] += Cn[j][i] + xn[i] * x[j];
             }
 #pragma unroll
-            for (int i = 0; i < D; ++i) zp[(int64_t)i * BL] = x[i];
+            for (int l = 0; l < D; ++l) xf[l] = LN::bc(x[l % R], l / R);
         }
-        double *pp = A.P + (int64_t)t * NS * BL + b;
+        if (t < T - 1) {
+            // column i of sum <x_t+1 x_t^T> = Cov(x_t, x_t+1)^T + the means
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                const int s = sym_ix(i, j);
-                Pc[s] = V[s] + x[i] * x[j];
-                pp[(int64_t)s * BL] = Pc[s];
-                sumP[s] += Pc[s];
+                for (int a = 0; a < D; ++a) snpT[r][a] += fma(xn[a], x[r], -W[r][a]);
+        }
+        // P_t = V_t + x_t x_t^T (rows of this lane), out; the sums
+        double Pr[R][D];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                Pr[r][k] = fma(x[r], xf[k], V[r][k]);
+                sumP[r][k] += Pr[r][k];
             }
+        if (live) {
+            double *zp = A.Z + (int64_t)t * D * BL + b;
+            double *pp = A.P + (int64_t)t * NS * BL + b;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rw.valid(r)) {
+                    if (!given) zp[(int64_t)rw.row[r] * BL] = x[r];
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        if (k <= rw.row[r]) pp[(int64_t)(rw.tri[r] + k) * BL] = Pr[r][k];
+                }
+        }
+        if (MF > 0) {
+#pragma unroll
+            for (int m = 0; m < MFR; ++m)
+                if (m < M) {
+                    const double bd = (double)((w >> m) & 1);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) XX[m][r][k] = fma(bd, Pr[r][k], XX[m][r][k]);
+                        Syx[m][r] = fma(y[m], x[r], Syx[m][r]);
+                    }
+                }
+        }
+        // what step t - 1 needs of this one: <x_t> in full, Cov(x_t) as the lower triangle of its owners
+#pragma unroll
+        for (int i = 0; i < D; ++i) xn[i] = xf[i];
+        if (!given) {
+#pragma unroll
+            for (int l = 0; l < D; ++l)
+#pragma unroll
+                for (int k = 0; k <= l; ++k) Vnp[sym_ix(l, k)] = LN::bc(V[l % R][k], l / R);
+        }
         if (t == T - 1) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) PT[s] = Pc[s];
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc[AC::PT + r * D + k] = Pr[r][k];
         }
+        if (t == 0) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) Vn[s] = V[s];
+            for (int r = 0; r < R; ++r) {
+                acc[AC::x0 + r] = x[r];
 #pragma unroll
-        for (int i = 0; i < D; ++i) xn[i] = x[i];
-    }
-    // the loop ends on t = 0: Pc = P_0, x = x_0
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        acc[ro.sumP + s] = sumP[s];
-        acc[ro.P0 + s] = Pc[s];
-        acc[ro.PT + s] = PT[s];
+                for (int k = 0; k < D; ++k) acc[AC::P0 + r * D + k] = Pr[r][k];
+            }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        acc[ro.x0 + i] = x[i];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int j = 0; j < D; ++j) acc[ro.Snp + i * D + j] = Snp[i][j];
+        for (int k = 0; k < D; ++k) {
+            acc[AC::sumP + r * D + k] = sumP[r][k];
+            acc[AC::Snp + r * D + k] = snpT[r][k];
+        }
+    if (MF > 0) {
+#pragma unroll
+        for (int m = 0; m < MFR; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[AC::Syx + m * R + r] = Syx[m][r];
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc[AC::XX + (m * R + r) * D + k] = XX[m][r][k];
+            }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// statistics of sequence b for the rows [m0, m0 + MG) of C: XX_m += mask_mbt P_bt (packed),
-// Syx_m += y_mbt x_bt (y is zero where masked).  acc: MG * (NS + D) doubles, [g][NS | D].
+// statistics of sequence b for the rows [m0, m0 + MG) of C from the stored <x>, <x x^T>:
+// XX_m += mask_mbt P_bt, Syx_m += y_mbt x_bt (y is zero where masked).  For the rows the backward
+// sweep does not carry, and after a re-observe (given = 2).
+// acc (this lane's rows): XX[MG][R][D] | Syx[MG][R]
 // ---------------------------------------------------------------------------------------------
-template <int D, int MG>
-VMP_HD void lssmm_stats_seq(const lssmm_seq_args &A, int64_t b, int m0, double *acc)
+template <int D, int G, int MG>
+VMP_HD void lssmm_stats_seq(const lssmm_seq_args &A, int64_t b, int lane, int m0, double *acc)
 {
-    constexpr int NS = D * (D + 1) / 2;
+    constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2;
+    const lssmm_rows<D, G> rw(lane);
     const int M = A.M, T = A.T;
     const int64_t BL = A.BL;
-    double xx[MG][NS], yx[MG][D];
+    double xx[MG][R][D], yx[MG][R];
 #pragma unroll
-    for (int g = 0; g < MG; ++g) {
+    for (int g = 0; g < MG; ++g)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) xx[g][s] = 0.0;
+        for (int r = 0; r < R; ++r) {
+            yx[g][r] = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) yx[g][i] = 0.0;
-    }
-    double pn[NS], xn[D], yn[MG];
+            for (int k = 0; k < D; ++k) xx[g][r][k] = 0.0;
+        }
+    double pn[R][D], xn[R], yn[MG];
     uint64_t wn = A.Mw[b];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) pn[s] = A.P[(int64_t)s * BL + b];
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) xn[i] = A.Z[(int64_t)i * BL + b];
+        for (int k = 0; k < D; ++k) pn[r][k] = A.P[(int64_t)rw.sym(r, k) * BL + b];
+        xn[r] = A.Z[(int64_t)rw.rowc[r] * BL + b];
+    }
 #pragma unroll
     for (int g = 0; g < MG; ++g) yn[g] = (m0 + g < M) ? A.Yt[(int64_t)(m0 + g) * BL + b] : 0.0;
     for (int t = 0; t < T; ++t) {
         const uint64_t w = wn >> m0;
-        double p[NS], x[D], y[MG];
+        double p[R][D], x[R], y[MG];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) p[s] = pn[s];
+        for (int r = 0; r < R; ++r) {
+            x[r] = xn[r];
 #pragma unroll
-        for (int i = 0; i < D; ++i) x[i] = xn[i];
+            for (int k = 0; k < D; ++k) p[r][k] = pn[r][k];
+        }
 #pragma unroll
         for (int g = 0; g < MG; ++g) y[g] = yn[g];
         if (t + 1 < T) {
@@ -473,9 +685,11 @@ VMP_HD void lssmm_stats_seq(const lssmm_seq_args &A, int64_t b, int m0, double *
             const double *pp = A.P + (int64_t)(t + 1) * NS * BL + b;
             const double *zp = A.Z + (int64_t)(t + 1) * D * BL + b;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) pn[s] = pp[(int64_t)s * BL];
+            for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) xn[i] = zp[(int64_t)i * BL];
+                for (int k = 0; k < D; ++k) pn[r][k] = pp[(int64_t)rw.sym(r, k) * BL];
+                xn[r] = zp[(int64_t)rw.rowc[r] * BL];
+            }
 #pragma unroll
             for (int g = 0; g < MG; ++g)
                 yn[g] = (m0 + g < M) ? A.Yt[((int64_t)(t + 1) * M + m0 + g) * BL + b] : 0.0;
@@ -483,21 +697,103 @@ VMP_HD void lssmm_stats_seq(const lssmm_seq_args &A, int64_t b, int m0, double *
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
             if (m0 + g < M) {
-                const double bit = ((w >> g) & 1) ? 1.0 : 0.0;
+                const double bd = (double)((w >> g) & 1);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) xx[g][s] += bit * p[s];
+                for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int i = 0; i < D; ++i) yx[g][i] += y[g] * x[i];
+                    for (int k = 0; k < D; ++k) xx[g][r][k] = fma(bd, p[r][k], xx[g][r][k]);
+                    yx[g][r] = fma(y[g], x[r], yx[g][r]);
+                }
             }
         }
     }
 #pragma unroll
-    for (int g = 0; g < MG; ++g) {
+    for (int g = 0; g < MG; ++g)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[g * (NS + D) + s] = xx[g][s];
+        for (int r = 0; r < R; ++r) {
+            acc[MG * R * D + g * R + r] = yx[g][r];
 #pragma unroll
-        for (int i = 0; i < D; ++i) acc[g * (NS + D) + NS + i] = yx[g][i];
+            for (int k = 0; k < D; ++k) acc[(g * R + r) * D + k] = xx[g][r][k];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a lane's row accumulators -> the packed layout of the raw sums (lssmm_raw); ``put(slot, value)``
+// stores or adds.  chain: acc = lssmm_acc chain part -> slots of [sumP | Snp | P0 | PT | x0];
+// stats: acc = XX[MG][R][D] | Syx[MG][R] -> slots relative to XX_0 (XX (M, NS) then Syx (M, D)).
+// ---------------------------------------------------------------------------------------------
+template <int D, int G, typename PUT>
+VMP_HD void lssmm_put_chain(int lane, const double *acc, PUT put)
+{
+    using AC = lssmm_acc<D, G, 0>;
+    constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2;
+    const lssmm_rows<D, G> rw(lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!rw.valid(r)) continue;
+        const int i = rw.row[r];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (k <= i) {
+                put(rw.tri[r] + k, acc[AC::sumP + r * D + k]);
+                put(NS + D * D + rw.tri[r] + k, acc[AC::P0 + r * D + k]);
+                put(2 * NS + D * D + rw.tri[r] + k, acc[AC::PT + r * D + k]);
+            }
+            put(NS + k * D + i, acc[AC::Snp + r * D + k]);            // Snp[k][i]: column i
+        }
+        put(3 * NS + D * D + i, acc[AC::x0 + r]);
     }
+}
+
+template <int D, int G, int MG, typename PUT>
+VMP_HD void lssmm_put_stats(int lane, int m0, int M, const double *xx, const double *yx, PUT put)
+{
+    constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2;
+    const lssmm_rows<D, G> rw(lane);
+#pragma unroll
+    for (int g = 0; g < MG; ++g) {
+        const int m = m0 + g;
+        if (m >= M) continue;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!rw.valid(r)) continue;
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (k <= rw.row[r]) put(m * NS + rw.tri[r] + k, xx[(g * R + r) * D + k]);
+            put(M * NS + m * D + rw.row[r], yx[g * R + r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// <x x^T> <- R <x x^T> R^T of one (step, sequence) on the packed triangle (the rotations of
+// inference/transformations.py applied to the plate array; reference: gaussian.py:1693-1741)
+// ---------------------------------------------------------------------------------------------
+template <int D>
+VMP_HD void lssmm_rotate_packed(const double *R, double *p, int64_t stride)
+{
+    constexpr int NS = D * (D + 1) / 2;
+    double a[NS], t[D][D];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = p[(int64_t)s * stride];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            double u = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) u = fma(R[i * D + k], a[sym_ix(k, l)], u);
+            t[i][l] = u;
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double u = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) u = fma(t[i][l], R[j * D + l], u);
+            p[(int64_t)sym_ix(i, j) * stride] = u;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -647,13 +943,14 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *scra
             for (int e = tid; e < DD; e += nthr) {
                 const int j = e / D, k = e % D;
                 if (k <= j) {
+                    // symmetric blocks, stored in full: entry (j, k) and its mirror
                     double anua = 0.0;
                     for (int i = 0; i < D; ++i) anua += nu[2 * D + i] * AA[(i * D + j) * D + k];
                     const double dn = (j == k) ? nu[2 * D + j] : 0.0;
-                    const int s = sym_ix(j, k);
-                    tab[to.base + s] = Lam0[j * D + k] + (T > 1 ? anua : 0.0);
-                    tab[to.base + NS + s] = dn + anua;
-                    tab[to.base + 2 * NS + s] = (T > 1 ? dn : Lam0[j * D + k]);
+                    const int s = j * D + k, sT = k * D + j;
+                    tab[to.base + s] = tab[to.base + sT] = Lam0[j * D + k] + (T > 1 ? anua : 0.0);
+                    tab[to.base + DD + s] = tab[to.base + DD + sT] = dn + anua;
+                    tab[to.base + 2 * DD + s] = tab[to.base + 2 * DD + sT] = (T > 1 ? dn : Lam0[j * D + k]);
                 }
                 tab[to.E + j * D + k] = -nu[2 * D + k] * Am[k * D + j];       // Phi[t, t+1][j][k]
             }
@@ -666,7 +963,7 @@ VMP_HD void lssmm_small_body(const lssmm_small_args &A, double *st, double *scra
                 for (int i = 0; i < D; ++i) {
                     tab[to.C + m * D + i] = tau[2] * Cm[m * D + i];
                     for (int j = 0; j <= i; ++j)
-                        tab[to.CC + m * NS + sym_ix(i, j)] =
+                        tab[to.CC + (m * D + i) * D + j] = tab[to.CC + (m * D + j) * D + i] =
                             tau[2] * (CovC[m * DD + i * D + j] + Cm[m * D + i] * Cm[m * D + j]);
                 }
             }

@@ -147,6 +147,12 @@ class LSSMPlan:
         _lib.load().vmp_lssm_limits(ctypes.byref(mx_d), ctypes.byref(mx_m))
         return mx_d.value, mx_m.value
 
+    _dims_note = ''
+
+    @staticmethod
+    def _dims_ok(D, M):
+        return True
+
     @classmethod
     def match(cls, nodes, why=None):
         def no(Y, msg):
@@ -211,10 +217,10 @@ class LSSMPlan:
                 mx_d, mx_m = cls._limits()
             except Exception:       # noqa: BLE001
                 continue
-            if D > mx_d or M > mx_m:
+            if D > mx_d or M > mx_m or not cls._dims_ok(D, M):
                 if cls._accepts_mask(Y):
                     no(Y, 'D = %d states, M = %d observed dimensions exceed the limits of the '
-                          'block (D <= %d, M <= %d)' % (D, M, mx_d, mx_m))
+                          'block (D <= %d, M <= %d%s)' % (D, M, mx_d, mx_m, cls._dims_note))
                 continue
             priv = [C, gamma, X, A, alpha, tau, F, G] + ([nu_node] if nu_node is not None else [])
             if any(len(n.children) != 1 for n in priv):

@@ -8,8 +8,9 @@ Execution plan of the linear state-space model block observed through an ARRAY m
 to (M, [B,] T).  The reference multiplies every message by the child's mask before the plate sum
 (node.py:570-655), so the chain precision differs per sequence and every row of C has its own
 posterior; rows / sequences without any observation are ignored plates (node.py:486-526,
-expfamily.py:470-480).  One thread per sequence runs the covariance AND the mean recursion of
-linalg.block_banded_solve (utils/linalg.py:468-575) in registers
+expfamily.py:470-480).  A group of four lanes per sequence (the rows of the D x D blocks dealt over
+them) runs the covariance AND the mean recursion of linalg.block_banded_solve
+(utils/linalg.py:468-575) in registers
 (bayespy_amd/csrc/vmp_lssmm.hip; formulas pinned in oracle/lssm.py:MaskedLSSMOracle).
 
 HBM: ``Yt`` (T, M, BL) data time-major, zero where masked; ``Mw`` (T, BL) one 64-bit mask word per
@@ -65,8 +66,8 @@ class MaskedLSSMKernels:
         L = _lib.LSSMMLayout()
         rc = self.lib.vmp_lssmm_get_layout(D, M, ctypes.byref(L))
         if rc != _lib.VMP_OK:
-            _lib.raise_for_status(rc, 'the masked state-space block supports D <= 4 states and '
-                                      'M <= 64 observed dimensions')
+            _lib.raise_for_status(rc, 'the masked state-space block supports D <= 8 states, '
+                                      'M <= 64 observed dimensions, M D^2 <= 2048')
         return L
 
     def workspace_doubles(self, D, M, B, T):
@@ -109,6 +110,9 @@ class MaskedLSSMKernels:
             return
         self.rt.check(self.rt.lib.vmp_lssm_rotate_x(self.ctx, D, T, B, BL, ptr(R), ptr(Z)))
 
+    def rotate_p(self, D, T, B, BL, R, P):
+        self._check(self.lib.vmp_lssmm_rotate_p(self.ctx, D, T, B, BL, ptr(R), ptr(P)))
+
     def set_timing(self, on):
         if self.rt.lib is not None:
             self.rt.check(self.rt.lib.vmp_ctx_set_timing(self.ctx, 1 if on else 0))
@@ -134,13 +138,19 @@ class MaskedLSSMPlan(LSSMPlan):
     @staticmethod
     def describe():
         return ("GaussianARD(SumMultiply('i,i', C, GaussianMarkovChain(mu0, Lam0, A, nu)), tau) "
-                "observed through an array mask, shared dynamics, D <= 4 states")
+                "observed through an array mask, shared dynamics, D <= 8 states")
 
     @staticmethod
     def _limits():
         mx_d, mx_m = ctypes.c_int32(), ctypes.c_int32()
         _lib.load().vmp_lssmm_limits(ctypes.byref(mx_d), ctypes.byref(mx_m))
         return mx_d.value, mx_m.value
+
+    _dims_note = ', M D^2 <= 2048'
+
+    @staticmethod
+    def _dims_ok(D, M):
+        return M * D * D <= 2048          # the tables of the sweeps in LDS (lssmm_dims_ok)
 
     @staticmethod
     def unsupported_state(r):
@@ -318,7 +328,11 @@ class MaskedLSSMPlan(LSSMPlan):
         self.rt.sync_stream()
         before = self.seqobs.clone()
         self._upload_y()
-        if not bool((before == self.seqobs).all().item()):
+        changed = int(not bool((before == self.seqobs).all().item()))
+        if self.sharded:
+            # every rank restarts or none does: the collectives of the two paths differ
+            changed = self.rt.all_reduce_int(changed)
+        if changed:
             _delta.warn_state_discarded(self, self.Y)
             self._ready = False
             self._pending = []
@@ -411,7 +425,7 @@ class MaskedLSSMPlan(LSSMPlan):
         V = P - x[..., :, None] * x[..., None, :]
         Sinv = _sym_unpack(self._plate_array(self.Fw, NS + D)[..., :NS], D)
         to = self.state[L.off_tab:L.off_tab + int(L.len_tab)].cpu().numpy()
-        E = to[3 * NS:3 * NS + D * D].reshape(D, D)
+        E = to[3 * D * D:4 * D * D].reshape(D, D)
         Cn = np.empty((B, max(T - 1, 0), D, D))
         for t in range(T - 1):
             Cn[:, t] = -(Sinv[:, t] @ E) @ V[:, t + 1]
@@ -552,16 +566,8 @@ class MaskedLSSMPlan(LSSMPlan):
             torch = self.rt.torch
             Rd = torch.from_numpy(np.ascontiguousarray(R, dtype=np.float64)).to(self.rt.device)
             self.kernels.rotate_x(D, T, self.B, self.BL, Rd, self.Z)
-            # <x x^T> <- R <x x^T> R^T on the packed plate array: one pass of device contractions
-            P = self.Pm.view(T, NS, self.BL)
-            full = torch.empty(T, D, D, self.BL, dtype=torch.float64, device=self.rt.device)
-            for i in range(D):
-                for j in range(i + 1):
-                    full[:, i, j] = full[:, j, i] = P[:, i * (i + 1) // 2 + j]
-            rot = torch.einsum('ik,tklb,jl->tijb', Rd, full, Rd)
-            for i in range(D):
-                for j in range(i + 1):
-                    P[:, i * (i + 1) // 2 + j] = rot[:, i, j]
+            # <x x^T> <- R <x x^T> R^T on the packed plate array, in place (vmp_lssmm_rotate_p)
+            self.kernels.rotate_p(D, T, self.B, self.BL, Rd, self.Pm)
             self._x_rot = R if self._x_rot is None else R @ self._x_rot
             return
         if node is self.C:

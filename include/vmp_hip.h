@@ -397,14 +397,17 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
  *   - every sequence has its own block-tridiagonal precision: diagonal blocks
  *     prior + <tau> sum_m mask_mbt <c_m c_m^T> (gaussian_markov_chain.py:542-627, dot.py:425-633),
  *     hence its own D x D covariance recursion (linalg.block_banded_solve, utils/linalg.py:468-575),
- *     run by ONE THREAD PER SEQUENCE in registers beside the mean recursion;
+ *     run by a group of FOUR LANES PER SEQUENCE (the rows of the blocks dealt over a DPP quad) in
+ *     registers beside the mean recursion; vmp_tune_set("lssmm_lanes", 1): one thread per sequence
+ *     (D <= 4);
  *   - every row of C has its own posterior (gaussian.py:649-706 with the per-row message
  *     sum_bt mask_mbt <x_bt x_bt^T>);
  *   - rows / sequences without any observation are ignored plates (node.py:486-526,
  *     expfamily.py:470-480).
  * Time-major arrays, b contiguous: Yt[t][m][b] (zero where masked), Mw[t][b] (uint64, bit m =
  * mask_mbt), F[t][NS + D][b] (forward sweep: S_t^-1 packed lower triangle | z_t), Z[t][D][b] (<x>),
- * P[t][NS][b] (<x x^T> packed), NS = D (D + 1) / 2.  D <= 4 states, M <= 64 observed dimensions.
+ * P[t][NS][b] (<x x^T> packed), NS = D (D + 1) / 2.  D <= 8 states, M <= 64 observed dimensions,
+ * M D^2 <= 2048 (the tables of the sweeps in LDS).
  * Details: bayespy_amd/csrc/vmp_lssmm.hip, vmp_lssmm_dev.h; formulas: oracle/lssm.py
  * (MaskedLSSMOracle).  Ops: enum vmp_lssm_op (STATS is a no-op here). */
 typedef struct vmp_lssmm_layout {
@@ -417,9 +420,9 @@ typedef struct vmp_lssmm_layout {
     int64_t off_ldC;      /* M  log|Cov(c_m)|                                                       */
     int64_t off_SCC;      /* D*D  sum over the observed rows of <c_m c_m^T>                         */
     int64_t off_Am, off_AA, off_ldA;        /* D*D, D*D*D, D                                        */
-    int64_t off_tab, len_tab;   /* tables of the forward sweep, written by XPREP:
-                                   base (3*NS: t = 0, inner, last) | E (D*D) | h0 (D) |
-                                   tau c_m (M*D) | tau <c_m c_m^T> packed (M*NS)                    */
+    int64_t off_tab, len_tab;   /* tables of the sweeps, written by XPREP (full matrices, rows
+                                   contiguous): base (3*D*D: t = 0, inner, last) | E (D*D) | h0 (D) |
+                                   tau c_m (M*D) | tau <c_m c_m^T> (M*D*D)                          */
     int64_t off_setup, len_setup;  /* vmp_lssmm_prepare (summed over ranks): sum mask y^2 |
                                    sequences with data | observations per row n_m (M)              */
     int64_t off_raw, len_raw;   /* plate sums of an X pass (summed over ranks):
@@ -443,13 +446,19 @@ int32_t vmp_lssmm_prepare(vmp_ctx *ctx, const double *Y, const uint8_t *mask, in
                           int32_t D, double *Yt, uint64_t *Mw, double *seqobs, double *state,
                           void *workspace);
 /* X.update(): forward sweep (per-sequence covariance + mean recursions -> F), backward sweep
- * (-> Z, P, chain sums), statistics pass (XX_m, Syx_m); the sums land in state[off_raw ...].
+ * (-> Z, P, chain sums; for D <= 4, M <= 8 also XX_m, Syx_m), otherwise a statistics pass over the
+ * stored Z, P (XX_m, Syx_m); the sums land in state[off_raw ...].
  * given = 1: the sums of the <x> already in Z as point masses (initialize_from_value);
  * given = 2: q(X) unchanged, only XX_m / Syx_m again from the stored Z, P (Y re-observed). */
 int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const uint64_t *Mw,
                            const double *seqobs, int32_t M, int64_t B, int32_t T, int64_t BL,
                            int32_t D, double *state, double *F, double *Z, double *P,
                            void *workspace);
+/* <x x^T> <- R <x x^T> R^T on the packed plate array P (T, NS, BL): the state rotation of
+ * inference/transformations.py (reference: gaussian_markov_chain.py rotate, gaussian.py:1693-1741)
+ * applied on the device; the means go through vmp_lssm_rotate_x. */
+int32_t vmp_lssmm_rotate_p(vmp_ctx *ctx, int32_t D, int32_t T, int64_t B, int64_t BL, const double *R,
+                           double *P);
 /* Replicated-node updates / the bound: a list of vmp_lssm_op in one launch. */
 int32_t vmp_lssmm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, const double *priors,
                             int32_t nu_latent, int32_t nops, const int32_t *ops, double *state);

@@ -35,7 +35,7 @@ def lssmm_host():
         with open(os.path.join(d, 'sf.h'), 'w') as f:
             f.write(sf)
         tmp = so + '.%d.tmp' % os.getpid()
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off',
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off', '-pthread',
                                '-include', os.path.join(d, 'sf.h'), srcs[0], '-o', tmp])
         os.replace(tmp, so)
     return ctypes.CDLL(so)

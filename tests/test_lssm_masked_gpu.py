@@ -11,17 +11,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-from test_lssm_masked_host import build, check_against_golden, CASES  # noqa: E402
+from test_lssm_masked_host import build, check_against_golden, golden_of, CASES, WIDE_CASES  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('tag,B,gamma_nu', CASES)
+@pytest.mark.parametrize('tag,B,gamma_nu', CASES + WIDE_CASES)
 def test_fused_block_matches_reference(tag, B, gamma_nu):
     """demos/lssm.py's own mask shape (md: (M, T), a fully missing stretch), one mask per sequence
     (mb), a shared mask (ms), erasures (me: a row / a sequence / the end points never observed),
-    a single step (m1); NaN placeholders at the masked entries."""
-    g = np.load(os.path.join(GOLDEN, 'lssm_masked.npz'))
+    a single step (m1); 5 ... 8 states (w8 / w6 / w5 / w7: two rows of the blocks per lane); NaN
+    placeholders at the masked entries."""
+    g = golden_of(tag)
     Q, track = build(g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'], g[tag + '_c0'], B, gamma_nu,
                      host=False)
     n = len(g[tag + '_L'])
@@ -46,7 +47,10 @@ def test_generic_engine_matches_the_same_traces(tag, B, gamma_nu):
 
 @pytest.mark.parametrize('M,B,T,D,nu', [(3, 1, 7, 1, False), (5, 3, 9, 2, True), (2, 70, 5, 3, False),
                                         (7, 130, 12, 4, True), (64, 2, 4, 2, False),
-                                        (6, 1, 200, 3, False), (8, 1000, 50, 4, False)])
+                                        (6, 1, 200, 3, False), (8, 1000, 50, 4, False),
+                                        (5, 37, 9, 6, True), (32, 3, 5, 8, True),
+                                        (9, 70, 7, 5, False), (12, 130, 6, 7, True),
+                                        (20, 5, 8, 4, False), (3, 300, 40, 8, False)])
 def test_fused_block_vs_oracle(M, B, T, D, nu):
     from oracle.lssm import MaskedLSSMOracle
     rs = np.random.RandomState(M + B + T + D)
@@ -70,19 +74,28 @@ def test_fused_block_vs_oracle(M, B, T, D, nu):
     np.testing.assert_allclose(track['C'].u[0].reshape(M, D), o.Cm, rtol=1e-8, atol=1e-9)
 
 
-def test_device_kernels_equal_their_host_build():
+@pytest.mark.parametrize('M,B,T,D,lanes', [(6, 75, 20, 3, 4), (6, 75, 20, 3, 1), (8, 33, 12, 4, 4),
+                                           (12, 40, 10, 4, 4), (7, 21, 9, 6, 4), (5, 18, 8, 8, 4)])
+def test_device_kernels_equal_their_host_build(M, B, T, D, lanes):
     """The packed state vector and the plate arrays after two iterations: libvmp_hip.so against the
     g++ build of the same header (tests/host_build.py) -- pins the CPU double of this block to the
-    kernels (only the order of the plate sums differs)."""
+    kernels (only the order of the plate sums, the contraction of products into fused
+    multiply-adds outside the sweeps and the device's reciprocal differ).  Four lanes per sequence
+    (statistics carried by the backward sweep for M <= 8, D <= 4; a separate pass otherwise) and one
+    thread per sequence."""
+    from bayespy_amd import _lib
     rs = np.random.RandomState(3)
-    M, B, T, D = 6, 75, 20, 3
     y = rs.normal(size=(M, B, T))
     mask = rs.rand(M, B, T) < 0.5
     x0, c0 = rs.normal(size=(B, T, D)), rs.normal(size=(M, 1, 1, D))
-    Qd, _ = build(y, mask, x0, c0, B, True, host=False)
-    Qh, _ = build(y, mask, x0, c0, B, True, host=True)
-    for Q in (Qd, Qh):
-        Q.update(repeat=2, verbose=False)
+    _lib.load().vmp_tune_set(b'lssmm_lanes', lanes)
+    try:
+        Qd, _ = build(y, mask, x0, c0, B, True, host=False)
+        Qh, _ = build(y, mask, x0, c0, B, True, host=True)
+        for Q in (Qd, Qh):
+            Q.update(repeat=2, verbose=False)
+    finally:
+        _lib.load().vmp_tune_set(b'lssmm_lanes', 4)
     pd, ph = Qd.plans[0], Qh.plans[0]
     L = pd.layout
     sd, sh = pd.state.cpu().numpy(), ph.state.numpy()

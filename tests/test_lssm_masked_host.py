@@ -16,6 +16,13 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 CASES = [('md', None, False), ('mb', 5, True), ('ms', 3, False), ('me', 4, True), ('m1', 3, False)]
+# 5 ... 8 states (two rows of the blocks per lane on the device): lssm_masked_wide.npz
+WIDE_CASES = [('w8', None, False), ('w6', 4, True), ('w5', 3, False), ('w7', 4, True)]
+
+
+def golden_of(tag):
+    return np.load(os.path.join(GOLDEN, 'lssm_masked_wide.npz' if tag.startswith('w')
+                                else 'lssm_masked.npz'))
 
 
 def build(y, mask, x0, c0, B, gamma_nu, shard=False, host=True):
@@ -69,15 +76,37 @@ def check_against_golden(Q, track, g, tag, n):
                                        err_msg='%s u[%d]' % (nm, i))
 
 
-@pytest.mark.parametrize('tag,B,gamma_nu', CASES)
+@pytest.mark.parametrize('tag,B,gamma_nu', CASES + WIDE_CASES)
 def test_plan_reproduces_reference_trace(tag, B, gamma_nu):
-    g = np.load(os.path.join(GOLDEN, 'lssm_masked.npz'))
+    g = golden_of(tag)
     Q, track = build(g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'], g[tag + '_c0'], B, gamma_nu)
     n = len(g[tag + '_L'])
     Q.update(repeat=n, verbose=False)
     check_against_golden(Q, track, g, tag, n)
     Y = Q['Y']
     np.testing.assert_allclose(Q.l[Y][:n], g[tag + '_Y_L'], rtol=1e-8, atol=1e-7)
+
+
+@pytest.mark.parametrize('tag,B,gamma_nu', [('mb', 5, True), ('ms', 3, False), ('w6', 4, True),
+                                           ('w7', 4, True)])
+def test_four_lane_form_of_the_sweeps_on_the_host(tag, B, gamma_nu, monkeypatch):
+    """The device's default form -- a sequence dealt over FOUR lanes, operands of other rows by lane
+    moves -- run on four host threads in lock step (tests/host/lssmm_host.cpp: lssmm_lanes<4> as an
+    exchange between barriers): the live-reference traces, and bit-for-bit the state of the
+    one-lane form (the arithmetic of an entry does not depend on the lane count)."""
+    g = golden_of(tag)
+    n = len(g[tag + '_L'])
+    res = []
+    for lanes in ('4', '1'):
+        monkeypatch.setenv('LSSMM_HOST_LANES', lanes)
+        Q, track = build(g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'], g[tag + '_c0'], B, gamma_nu)
+        Q.update(repeat=n, verbose=False)
+        if lanes == '4':
+            check_against_golden(Q, track, g, tag, n)
+        p = Q.plans[0]
+        res.append((p.state.numpy().copy(), p.x_means(), p.x_second_moments()))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
 
 
 def test_masks_propagate_like_the_reference():

@@ -157,12 +157,15 @@ def test_gmm_oracle_matches_reference(golden_dir, name, chunk):
     np.testing.assert_allclose(o.alpha, g['alpha_phi0'], rtol=1e-10)
 
 
-MASKED_LSSM = [('md', None), ('mb', (1e-3, 1e-3)), ('ms', None), ('me', (1e-3, 1e-3)), ('m1', None)]
+MASKED_LSSM = [('md', None), ('mb', (1e-3, 1e-3)), ('ms', None), ('me', (1e-3, 1e-3)), ('m1', None),
+               # 5 ... 8 states (lssm_masked_wide.npz)
+               ('w8', None), ('w6', (1e-3, 1e-3)), ('w5', None), ('w7', (1e-3, 1e-3))]
 
 
 def load_masked_lssm(golden_dir, tag):
     """(y (M,B,T), mask (M,B,T) as stored -- possibly broadcastable --, x0 (B,T,D), c0 (M,D), g)."""
-    g = np.load(os.path.join(golden_dir, 'lssm_masked.npz'))
+    g = np.load(os.path.join(golden_dir, 'lssm_masked_wide.npz' if tag.startswith('w')
+                             else 'lssm_masked.npz'))
     y, mask, x0, c0 = g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'], g[tag + '_c0']
     if y.ndim == 2:                       # the demo's shape: no sequence plate
         y, mask, x0 = y[:, None, :], mask[:, None, :], x0[None]
