@@ -123,6 +123,7 @@ struct sweep_args {
     const double *seqobs;
     int64_t B;
     int tab_len;
+    int nib_len;            // doubles of the nibble tables of the forward sweep (0: none)
     int pstride;            // doubles per workgroup in ``partial``
     double *partial;        // per workgroup
     double *status;         // state[off_scal]
@@ -138,7 +139,7 @@ __device__ __forceinline__ double seqs_sum(double v)
     return v;
 }
 
-template <int D, int G>
+template <int D, int G, int MB>
 __global__ void __launch_bounds__(WNT)
 lssmm_forward_kernel(sweep_args A)
 {
@@ -147,13 +148,21 @@ lssmm_forward_kernel(sweep_args A)
     __syncthreads();
     lssmm_seq_args S = A.S;
     S.tab = tab;
+    // sums of the observation blocks by mask nibble, behind the tables (when they fit)
+    S.nib = nullptr;
+    if (A.nib_len > 0) {
+        lssmm_build_nibbles(D, S.M, tab, tab + A.tab_len, (int)threadIdx.x, WNT);
+        __syncthreads();
+        S.nib = tab + A.tab_len;
+    }
     const int64_t tid = (int64_t)blockIdx.x * WNT + threadIdx.x;
     const int64_t bq = tid / G;
     const int lane = (int)(tid % G);
+    // the tail of the last wavefront works on the zero-filled padding columns b in [B, BL)
     const bool live = bq < A.B;
-    const int64_t b = live ? bq : A.B - 1;       // the tail of the last wavefront repeats a sequence
+    const int64_t b = bq;
     int bad = 0;
-    double ld = lssmm_forward_seq<D, G>(S, b, lane, live, bad);
+    double ld = lssmm_forward_seq<D, G, MB>(S, b, lane, bad);
     // log|Phi_b| of the sequences with data (an ignored plate adds nothing to the bound)
     ld = (live && lane == 0) ? ld * A.seqobs[b] : 0.0;
     ld = wave_sum(ld);
@@ -183,9 +192,9 @@ lssmm_backward_kernel(sweep_args A)
     const int64_t bq = tid / G;
     const int lane = (int)(tid % G);
     const bool live = bq < A.B;
-    const int64_t b = live ? bq : A.B - 1;
+    const int64_t b = bq;
     double acc[AC::len];
-    lssmm_backward_seq<D, G, MF>(S, b, lane, live, A.given, acc);
+    lssmm_backward_seq<D, G, MF>(S, b, lane, A.given, acc);
     // chain sums: sequences with data only; the statistics carry the mask themselves
     const double wc = live ? A.seqobs[b] : 0.0;
 #pragma unroll
@@ -213,7 +222,7 @@ lssmm_stats_kernel(sweep_args A)
     const int64_t bq = tid / G;
     const int lane = (int)(tid % G);
     const bool live = bq < A.B;
-    const int64_t b = live ? bq : A.B - 1;
+    const int64_t b = bq;
     const int m0 = blockIdx.y * MG;
     double acc[AL];
     lssmm_stats_seq<D, G, MG>(A.S, b, lane, m0, acc);
@@ -373,6 +382,8 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
                 "null argument");
     VMP_REQUIRE(ctx, lssmm_dims_ok(D, M) && B >= 0 && T >= 1 && BL >= B, VMP_ERR_INVALID,
                 "bad dims (D <= 8, M <= 64, M D^2 <= 2048)");
+    VMP_REQUIRE(ctx, BL % 64 == 0, VMP_ERR_INVALID,
+                "BL must be a multiple of 64 (the last wavefront works on the padding columns)");
     vmp_lssmm_layout L;
     lssmm_fill_layout(D, M, &L);
     const lssmm_raw ro = lssmm_raw_offsets(D, M);
@@ -397,6 +408,8 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
     A.seqobs = seqobs;
     A.B = B;
     A.tab_len = to.len;
+    A.nib_len = vmp_tune_get("lssmm_nibbles", 1) ? lssmm_nibble_len(D, M) : 0;
+    A.S.nib = nullptr;
     A.pstride = fuse ? CL + SL : CL;
     A.partial = partial;
     A.status = state + L.off_scal;
@@ -423,9 +436,17 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
         if (g > 0 && !given) {
             sweep_args Af = A;
             Af.partial = pld;
-#define LSSMM_FWD(d, gg) hipLaunchKernelGGL((lssmm_forward_kernel<d, gg>), dim3((unsigned)g), dim3(WNT), lds, s, Af);
-            LSSMM_FOR_DG(LSSMM_FWD)
+            const size_t ldsf = lds + (size_t)A.nib_len * sizeof(double);
+            // M <= 8 with the nibble tables: the straight-line step (observation terms a step ahead)
+            if (M <= 8 && D <= 4 && A.nib_len > 0) {
+#define LSSMM_FWD(d, gg) hipLaunchKernelGGL((lssmm_forward_kernel<d, gg, 8>), dim3((unsigned)g), dim3(WNT), ldsf, s, Af);
+                LSSMM_FOR_DG(LSSMM_FWD)
 #undef LSSMM_FWD
+            } else {
+#define LSSMM_FWD(d, gg) hipLaunchKernelGGL((lssmm_forward_kernel<d, gg, 64>), dim3((unsigned)g), dim3(WNT), ldsf, s, Af);
+                LSSMM_FOR_DG(LSSMM_FWD)
+#undef LSSMM_FWD
+            }
         }
         if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
         if (g > 0) {

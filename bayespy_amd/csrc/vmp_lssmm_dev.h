@@ -162,6 +162,43 @@ VMP_HD double lssmm_recip(double x)
 #endif
 }
 
+// a value that is the same on every lane (a table entry): kept in scalar registers on the device
+VMP_HD double lssmm_uniform(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+#else
+    return v;
+#endif
+}
+
+// Sums of the observation blocks by mask NIBBLE: nib[(n * 16 + c) D^2 + i D + k] = sum over the set
+// bits j of c (ascending) of tau <c_m c_m^T>[i][k], m = 4 n + j.  With them a time step adds ONE
+// table row per nibble of its mask word instead of one row per observed dimension.  Used when the
+// tables fit LSSMM_NIB_MAX doubles of LDS (M = 8: D <= 8; M = 32: D <= 4), else the per-row loop.
+constexpr int LSSMM_NIB_MAX = 2048;
+VMP_HD int lssmm_nibble_len(int D, int M)
+{
+    const int len = (M + 3) / 4 * 16 * D * D;
+    return len <= LSSMM_NIB_MAX ? len : 0;
+}
+VMP_HD void lssmm_build_nibbles(int D, int M, const double *tab, double *nib, int tid, int nthr)
+{
+    const int DD = D * D, len = lssmm_nibble_len(D, M);
+    const int oCC = 4 * DD + D + M * D;
+    for (int e = tid; e < len; e += nthr) {
+        const int n = e / (16 * DD), c = (e / DD) % 16, q = e % DD;
+        double s = 0.0;
+        for (int j = 0; j < 4; ++j) {
+            const int m = 4 * n + j;
+            if (m < M && ((c >> j) & 1)) s += tab[oCC + m * DD + q];
+        }
+        nib[e] = s;
+    }
+}
+
 // running log-determinant without a logarithm per pivot (the product is folded into ld only when
 // it leaves a safe range)
 VMP_HD void lssmm_ld_acc(double piv, double &prod, double &ld)
@@ -181,12 +218,14 @@ struct lssmm_seq_args {
     double *Z;              // (T, D, BL)
     double *P;              // (T, NS, BL)
     const double *tab;      // tables (lssmm_tab), LDS on the device
+    const double *nib;      // nibble tables (lssmm_build_nibbles) or null
     int M, T;
     int64_t BL;
 };
 
 // the rows of this lane: global index, index clamped into the matrix (a lane beyond the last row
-// works on a copy of row D - 1 and stores nothing), offset of the row in the packed triangle
+// is an exact clone of the owner of row D - 1: same operands, same arithmetic, and what it stores
+// is what the owner stores), offset of the row in the packed triangle
 template <int D, int G>
 struct lssmm_rows {
     static constexpr int R = (D + G - 1) / G;
@@ -204,6 +243,28 @@ struct lssmm_rows {
     // offset of entry (row r, k) in the packed lower triangle (either side of the diagonal)
     VMP_HD int sym(int r, int k) const { return k <= rowc[r] ? tri[r] + k : k * (k + 1) / 2 + rowc[r]; }
 };
+
+// the lower triangle of this lane's rows into a packed array (entry s of the triangle at
+// base[s * stride]).  Every lane issues the same D stores per row, none under a condition (a store
+// inside a branch makes the compiler wait for ALL outstanding memory operations where the
+// operands requested ahead are first used): an entry above the diagonal stores the diagonal
+// entry once more.
+template <int D, int G, int R>
+VMP_HD void lssmm_store_rows(double *base, int64_t stride, const lssmm_rows<D, G> &rw,
+                             const double (&m)[R][D])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double diag = m[r][0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) diag = (rw.rowc[r] == k) ? m[r][k] : diag;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const bool low = k <= rw.rowc[r];
+            base[(int64_t)(rw.tri[r] + (low ? k : rw.rowc[r])) * stride] = low ? m[r][k] : diag;
+        }
+    }
+}
 
 // in-place inverse of the SPD matrix whose rows are dealt over the lanes (S[r][.] = row lane R + r)
 // by the Gauss-Jordan sweep: the pivot row travels from its owner, every lane updates its rows;
@@ -227,7 +288,7 @@ VMP_HD void lssmm_rows_inverse(double (*S)[D], const lssmm_rows<D, G> &rw, doubl
         for (int k = 0; k < D; ++k) prs[k] *= d;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bool isp = rw.row[r] == p;
+            const bool isp = rw.rowc[r] == p;
             const double c = S[r][p];
 #pragma unroll
             for (int k = 0; k < D; ++k) {
@@ -241,23 +302,94 @@ VMP_HD void lssmm_rows_inverse(double (*S)[D], const lssmm_rows<D, G> &rw, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
+// the recursion part of a forward step on the rows of this lane: Sn (the diagonal block Dg_t) and
+// h (h_t) in, S (S_t-1^-1) and zf (z_t-1 in full) in / out:
+//   Sn -= E^T S E, h -= E^T S zf, S = Sn^-1, zf = h from its owners
+// (at t = 0 the previous inverse and z are zero and the step runs the same text)
+// ---------------------------------------------------------------------------------------------
+template <int D, int G, int R, int ED>
+VMP_HD void lssmm_forward_recur(double (&Sn)[R][D], double (&h)[R], double (&S)[R][D], double (&zf)[D],
+                                const double (&ET)[R][D], const double (&E)[ED][ED], const double *tab,
+                                const lssmm_rows<D, G> &rw, double &prod, double &ld, int &bad)
+{
+    using LN = lssmm_lanes<G>;
+    constexpr bool ER = ED == D;
+    constexpr int oE = 3 * D * D;
+    // Tm = E^T S_t-1^-1 (rows of this lane; S_t-1^-1 from the lower triangle of its owners)
+    double Tm[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int l = 0; l < D; ++l) Tm[r][l] = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int l = 0; l <= j; ++l) {
+            const double s = LN::bc(S[j % R][l], j / R);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                Tm[r][l] = fma(ET[r][j], s, Tm[r][l]);
+                if (l != j) Tm[r][j] = fma(ET[r][l], s, Tm[r][j]);
+            }
+        }
+    // S_t -= Tm E;  h -= Tm z_t-1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double a = Sn[r][k];
+#pragma unroll
+            for (int l = 0; l < D; ++l)
+                a = fma(-Tm[r][l], ER ? E[ER ? l : 0][ER ? k : 0] : tab[oE + l * D + k], a);
+            Sn[r][k] = a;
+        }
+        double a = h[r];
+#pragma unroll
+        for (int l = 0; l < D; ++l) a = fma(-Tm[r][l], zf[l], a);
+        h[r] = a;
+    }
+    lssmm_rows_inverse<D, G>(Sn, rw, prod, ld, bad);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) S[r][k] = Sn[r][k];
+#pragma unroll
+    for (int l = 0; l < D; ++l) zf[l] = LN::bc(h[l % R], l / R);
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward sweep of sequence b: S_t = Dg_t - E^T S_t-1^-1 E with Dg_t = base_t + sum_m mask tau<cc>_m,
 // z_t = h_t - E^T S_t-1^-1 z_t-1 with h_t = sum_m y tau c_m (+ Lam0 mu0 at t = 0); S_t^-1 (packed
 // lower triangle) and z_t go to F.  Returns log|Phi_b| = sum_t log|S_t| (on every lane of the
-// group); bad on a non-positive pivot.  ``live`` = the lane stores (false for the clamped copies
-// that fill the last wavefront).
+// group); bad on a non-positive pivot.  Every lane stores: the sequences b in [B, BL) that fill the
+// last wavefront are the zero-filled padding columns of the arrays (no data, no mask bit, weight 0).
+// MB = 8 (M <= 8, nibble tables present): the observation terms of step t + 1 -- table rows picked
+// by the mask nibbles, eight products with y -- are formed DURING step t, beside the serial chain
+// of its recursion, from operands requested two steps ahead; the step is one straight block of
+// code.  MB = 64: any M, the rows of C in chunks of eight.
 // ---------------------------------------------------------------------------------------------
-template <int D, int G>
-VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int lane, bool live, int &bad)
+template <int D, int G, int MB>
+VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int lane, int &bad)
 {
-    using LN = lssmm_lanes<G>;
     constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2, DD = D * D;
     constexpr int oE = 3 * DD, oh0 = 4 * DD, oC = 4 * DD + D;
+    constexpr bool ER = D <= 4;               // E in (scalar) registers; beyond: read from the table
+    constexpr int ED = ER ? D : 1;
     const lssmm_rows<D, G> rw(lane);
     const double *tab = A.tab;
+    const double *nib = A.nib;
     const int M = A.M, T = A.T;
     const int oCC = oC + M * D;
     const int64_t BL = A.BL;
+    double E[ED][ED];
+    if (ER) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < D; ++k) E[ER ? j : 0][ER ? k : 0] = lssmm_uniform(tab[oE + j * D + k]);
+    } else {
+        E[0][0] = 0.0;
+    }
     // column i of E for the rows i of this lane (E^T . from the left)
     double ET[R][D];
 #pragma unroll
@@ -272,9 +404,92 @@ VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int lane, bo
 #pragma unroll
     for (int i = 0; i < D; ++i) zf[i] = 0.0;
     double prod = 1.0, ld = 0.0;
+    if (MB == 8) {
+        // tau c_m for the rows of this lane (zero beyond the last row of C)
+        double Cr[8][R];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) Cr[m][r] = (m < M) ? tab[oC + m * D + rw.rowc[r]] : 0.0;
+        // observation terms of one step from its mask word and data
+        auto obs = [&](int tq, uint64_t w, const double (&y)[8], double (&So)[R][D], double (&ho)[R]) {
+            const double *bs = tab + (tq == 0 ? 0 : (tq < T - 1 ? DD : 2 * DD));
+            const int c0 = (int)(w & 15), c1 = (int)((w >> 4) & 15);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double *q0 = nib + (c0 * D + rw.rowc[r]) * D;
+                // M <= 4: one table; the (empty) second nibble picks its all-zero first row
+                const double *q1 = nib + (((M > 4 ? 16 : 0) + c1) * D + rw.rowc[r]) * D;
+#pragma unroll
+                for (int k = 0; k < D; ++k) So[r][k] = (bs[rw.rowc[r] * D + k] + q0[k]) + q1[k];
+                double a = (tq == 0) ? tab[oh0 + rw.rowc[r]] : 0.0;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) a = fma(y[m], Cr[m][r], a);
+                ho[r] = a;
+            }
+        };
+        auto fetch = [&](int tq, uint64_t &w, double (&y)[8]) {
+            w = A.Mw[(int64_t)tq * BL + b];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                // beyond the last row: the last row once more, as zero (no load under a condition)
+                const double v = A.Yt[((int64_t)tq * M + (m < M ? m : M - 1)) * BL + b];
+                y[m] = (m < M) ? v : 0.0;
+            }
+        };
+        double y1[8], So[R][D], ho[R];
+        uint64_t w1;
+        fetch(0, w1, y1);
+        obs(0, w1, y1, So, ho);
+        fetch(T > 1 ? 1 : 0, w1, y1);
+        // The results of a step are stored at the START of the next one: a wait for operands
+        // requested ahead also waits for every store still in flight (loads and stores complete
+        // out of order with each other), so the stores go out a whole step before the next wait.
+        double Sn[R][D], h[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            h[r] = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) Sn[r][k] = 0.0;
+        }
+        for (int t = 0; t < T; ++t) {
+            // step t + 1: its operands arrived during step t - 1; request those of step t + 2
+            // (beyond the end: the last step once more, unused)
+            const int t1 = t + 1 < T ? t + 1 : T - 1, t2 = t + 2 < T ? t + 2 : T - 1;
+            double Sc[R][D], hc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                hc[r] = ho[r];
+#pragma unroll
+                for (int k = 0; k < D; ++k) Sc[r][k] = So[r][k];
+            }
+            obs(t1, w1, y1, So, ho);
+            {
+                // step t - 1 out (at t = 0: zeros into the slots of step 0, rewritten next time)
+                const int ts = t > 0 ? t - 1 : 0;
+                lssmm_store_rows<D, G>(A.F + (int64_t)ts * (NS + D) * BL + b, BL, rw, Sn);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    A.F[((int64_t)ts * (NS + D) + NS + rw.rowc[r]) * BL + b] = h[r];
+            }
+            fetch(t2, w1, y1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                h[r] = hc[r];
+#pragma unroll
+                for (int k = 0; k < D; ++k) Sn[r][k] = Sc[r][k];
+            }
+            lssmm_forward_recur<D, G, R, ED>(Sn, h, S, zf, ET, E, tab, rw, prod, ld, bad);
+        }
+        lssmm_store_rows<D, G>(A.F + (int64_t)(T - 1) * (NS + D) * BL + b, BL, rw, Sn);
+#pragma unroll
+        for (int r = 0; r < R; ++r) A.F[((int64_t)(T - 1) * (NS + D) + NS + rw.rowc[r]) * BL + b] = h[r];
+        return ld + log(prod);
+    }
+    const int nn = (M + 3) / 4;
     // The operands of a step do not depend on the recursion: they are requested one chunk of MC
-    // observed dimensions (for M <= MC: one time step) ahead of their use, so that the HBM
-    // latency runs beside the arithmetic of the current step.
+    // observed dimensions ahead of their use, so that the HBM latency runs beside the arithmetic of
+    // the current step.
     constexpr int MC = 8;
     const int nch = (M + MC - 1) / MC;
     double yn[MC];
@@ -292,6 +507,17 @@ VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int lane, bo
             for (int k = 0; k < D; ++k) Sn[r][k] = bs[rw.rowc[r] * D + k];
             h[r] = (t == 0) ? tab[oh0 + rw.rowc[r]] : 0.0;
         }
+        if (nib) {
+            for (int n = 0; n < nn; ++n) {
+                const int c = (int)((w >> (4 * n)) & 15);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double *q = nib + ((n * 16 + c) * D + rw.rowc[r]) * D;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) Sn[r][k] += q[k];
+                }
+            }
+        }
         for (int c = 0; c < nch; ++c) {
             double y[MC];
 #pragma unroll
@@ -308,71 +534,25 @@ VMP_HD double lssmm_forward_seq(const lssmm_seq_args &A, int64_t b, int lane, bo
             }
 #pragma unroll
             for (int g = 0; g < MC; ++g) {
-                const int m = c * MC + g;
-                if (m < M) {
-                    const double bd = (double)((w >> m) & 1);
+                // beyond the last row: y = 0 and a zero mask bit against the (finite) entries of row M - 1
+                const int m = c * MC + g < M ? c * MC + g : M - 1;
+#pragma unroll
+                for (int r = 0; r < R; ++r) h[r] = fma(y[g], tab[oC + m * D + rw.rowc[r]], h[r]);
+                if (!nib) {
+                    const double bd = (c * MC + g < M) ? (double)((w >> m) & 1) : 0.0;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const double *cc = tab + oCC + (m * D + rw.rowc[r]) * D;
 #pragma unroll
                         for (int k = 0; k < D; ++k) Sn[r][k] = fma(bd, cc[k], Sn[r][k]);
-                        h[r] = fma(y[g], tab[oC + m * D + rw.rowc[r]], h[r]);
                     }
                 }
             }
         }
-        if (t > 0) {
-            // Tm = E^T S_t-1^-1 (rows of this lane; S_t-1^-1 from the lower triangle of its owners)
-            double Tm[R][D];
+        lssmm_forward_recur<D, G, R, ED>(Sn, h, S, zf, ET, E, tab, rw, prod, ld, bad);
+        lssmm_store_rows<D, G>(A.F + (int64_t)t * (NS + D) * BL + b, BL, rw, Sn);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int l = 0; l < D; ++l) Tm[r][l] = 0.0;
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-#pragma unroll
-                for (int l = 0; l <= j; ++l) {
-                    const double s = LN::bc(S[j % R][l], j / R);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        Tm[r][l] = fma(ET[r][j], s, Tm[r][l]);
-                        if (l != j) Tm[r][j] = fma(ET[r][l], s, Tm[r][j]);
-                    }
-                }
-            // S_t -= Tm E;  h -= Tm z_t-1
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    double a = Sn[r][k];
-#pragma unroll
-                    for (int l = 0; l < D; ++l) a = fma(-Tm[r][l], tab[oE + l * D + k], a);
-                    Sn[r][k] = a;
-                }
-                double a = h[r];
-#pragma unroll
-                for (int l = 0; l < D; ++l) a = fma(-Tm[r][l], zf[l], a);
-                h[r] = a;
-            }
-        }
-        lssmm_rows_inverse<D, G>(Sn, rw, prod, ld, bad);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int k = 0; k < D; ++k) S[r][k] = Sn[r][k];
-#pragma unroll
-        for (int l = 0; l < D; ++l) zf[l] = LN::bc(h[l % R], l / R);
-        if (live) {
-            double *fp = A.F + (int64_t)t * (NS + D) * BL + b;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (rw.valid(r)) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k)
-                        if (k <= rw.row[r]) fp[(int64_t)(rw.tri[r] + k) * BL] = Sn[r][k];
-                    fp[(int64_t)(NS + rw.row[r]) * BL] = h[r];
-                }
-        }
+        for (int r = 0; r < R; ++r) A.F[((int64_t)t * (NS + D) + NS + rw.rowc[r]) * BL + b] = h[r];
     }
     return ld + log(prod);
 }
@@ -398,7 +578,7 @@ struct lssmm_acc {
 // back from HBM for them.  acc: lssmm_acc<D, G, MF> (this lane's rows; not weighted).
 // ---------------------------------------------------------------------------------------------
 template <int D, int G, int MF>
-VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, bool live, int given,
+VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, int given,
                                double *acc)
 {
     using LN = lssmm_lanes<G>;
@@ -406,10 +586,18 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
     constexpr int R = (D + G - 1) / G, NS = D * (D + 1) / 2, DD = D * D;
     constexpr int oE = 3 * DD;
     constexpr int MFR = MF > 0 ? MF : 1;
+    constexpr bool ER = D <= 4;               // E in (scalar) registers; beyond: read from the table
     const lssmm_rows<D, G> rw(lane);
     const double *tab = A.tab;
     const int M = A.M, T = A.T;
     const int64_t BL = A.BL;
+    double E[ER ? D : 1][ER ? D : 1];
+    if (ER) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < D; ++k) E[ER ? j : 0][ER ? k : 0] = lssmm_uniform(tab[oE + j * D + k]);
+    }
     double sumP[R][D], snpT[R][D], XX[MFR][R][D], Syx[MFR][R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -423,6 +611,8 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
 #pragma unroll
             for (int k = 0; k < D; ++k) XX[m][r][k] = 0.0;
         }
+    // what a step hands to the one before it: <x_t+1> in full, Cov(x_t+1) as the lower triangle of
+    // its owners.  Zero behind the last step: the step T - 1 runs the same text (J x = 0, W = 0).
     double Vnp[NS], xn[D];
 #pragma unroll
     for (int s = 0; s < NS; ++s) Vnp[s] = 0.0;
@@ -456,9 +646,44 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
         if (MF > 0) {
             wn = A.Mw[(int64_t)t * BL + b];
 #pragma unroll
-            for (int m = 0; m < MFR; ++m) yn[m] = (m < M) ? A.Yt[((int64_t)t * M + m) * BL + b] : 0.0;
+            for (int m = 0; m < MFR; ++m) {
+                const double v = A.Yt[((int64_t)t * M + (m < M ? m : M - 1)) * BL + b];
+                yn[m] = (m < M) ? v : 0.0;
+            }
         }
     }
+    double Pr[R][D], x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        x[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) Pr[r][k] = 0.0;
+    }
+    // statistics of one step: XX_m += mask_m P, Syx_m += y_m x (rows m >= M: y = 0 and no mask
+    // bit -- their accumulators stay zero)
+    double Pq[R][D], xq[R], yq[MFR];
+    uint64_t wq = 0;
+#pragma unroll
+    for (int m = 0; m < MFR; ++m) yq[m] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        xq[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) Pq[r][k] = 0.0;
+    }
+    auto stats_of = [&](uint64_t w, const double (&y)[MFR], const double (&xs)[R],
+                        const double (&Ps)[R][D]) {
+#pragma unroll
+        for (int m = 0; m < MFR; ++m) {
+            const double bd = (double)((w >> m) & 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) XX[m][r][k] = fma(bd, Ps[r][k], XX[m][r][k]);
+                Syx[m][r] = fma(y[m], xs[r], Syx[m][r]);
+            }
+        }
+    };
     for (int t = T - 1; t >= 0; --t) {
         double Si[R][D], z[D], y[MFR];
         const uint64_t w = wn;
@@ -470,13 +695,15 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
         for (int i = 0; i < D; ++i) z[i] = zn[i];
 #pragma unroll
         for (int m = 0; m < MFR; ++m) y[m] = yn[m];
-        if (t > 0) {
+        {
+            // the step before (at t = 0: this step once more, unused)
+            const int tp = t > 0 ? t - 1 : 0;
             if (given) {
-                const double *zp = A.Z + (int64_t)(t - 1) * D * BL + b;
+                const double *zp = A.Z + (int64_t)tp * D * BL + b;
 #pragma unroll
                 for (int i = 0; i < D; ++i) zn[i] = zp[(int64_t)i * BL];
             } else {
-                const double *fp = A.F + (int64_t)(t - 1) * (NS + D) * BL + b;
+                const double *fp = A.F + (int64_t)tp * (NS + D) * BL + b;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -485,18 +712,29 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
                 for (int i = 0; i < D; ++i) zn[i] = fp[(int64_t)(NS + i) * BL];
             }
             if (MF > 0) {
-                wn = A.Mw[(int64_t)(t - 1) * BL + b];
+                wn = A.Mw[(int64_t)tp * BL + b];
 #pragma unroll
-                for (int m = 0; m < MFR; ++m)
-                    yn[m] = (m < M) ? A.Yt[((int64_t)(t - 1) * M + m) * BL + b] : 0.0;
+                for (int m = 0; m < MFR; ++m) {
+                    // beyond the last row: the last row once more, as zero (no load under a condition)
+                    const double v = A.Yt[((int64_t)tp * M + (m < M ? m : M - 1)) * BL + b];
+                    yn[m] = (m < M) ? v : 0.0;
+                }
             }
         }
+        {
+            // step t + 1 out, a whole step before the next wait for operands (a wait for a load also
+            // waits for every store in flight); in the first iteration: zeros into the slots of step
+            // T - 1, rewritten by the next iteration
+            const int ts = t < T - 1 ? t + 1 : T - 1;
+            lssmm_store_rows<D, G>(A.P + (int64_t)ts * NS * BL + b, BL, rw, Pr);
+            if (!given) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) A.Z[((int64_t)ts * D + rw.rowc[r]) * BL + b] = x[r];
+            }
+        }
+        if (MF > 0) stats_of(wq, yq, xq, Pq);      // step t + 1 (nothing in the first iteration)
         // V: rows of Cov(x_t); W: rows of J_t V_t+1 = -Cov(x_t, x_t+1); x: <x_t> of this lane's rows
-        double V[R][D], W[R][D], x[R], xf[D];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int k = 0; k < D; ++k) V[r][k] = W[r][k] = 0.0;
+        double V[R][D], W[R][D], xf[D];
         if (given) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -504,64 +742,56 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
 #pragma unroll
                 for (int i = 1; i < D; ++i) s = (rw.rowc[r] == i) ? z[i] : s;
                 x[r] = s;
+#pragma unroll
+                for (int k = 0; k < D; ++k) V[r][k] = W[r][k] = 0.0;
             }
 #pragma unroll
             for (int i = 0; i < D; ++i) xf[i] = z[i];
         } else {
+            double J[R][D];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double s = 0.0;
 #pragma unroll
                 for (int j = 0; j < D; ++j) s = fma(Si[r][j], z[j], s);
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double u = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j)
+                        u = fma(Si[r][j], ER ? E[ER ? j : 0][ER ? k : 0] : tab[oE + j * D + k], u);
+                    J[r][k] = u;
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) s = fma(-J[r][k], xn[k], s);
                 x[r] = s;
 #pragma unroll
-                for (int k = 0; k < D; ++k) V[r][k] = Si[r][k];
-            }
-            if (t < T - 1) {
-                double J[R][D];
+                for (int k = 0; k < D; ++k) {
+                    double u = 0.0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int j = 0; j < D; ++j) s = fma(Si[r][j], tab[oE + j * D + k], s);
-                        J[r][k] = s;
-                    }
-                    double s = x[r];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) s = fma(-J[r][k], xn[k], s);
-                    x[r] = s;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        double u = 0.0;
-#pragma unroll
-                        for (int l = 0; l < D; ++l) u = fma(J[r][l], Vnp[sym_ix(l, k)], u);
-                        W[r][k] = u;
-                    }
+                    for (int l = 0; l < D; ++l) u = fma(J[r][l], Vnp[sym_ix(l, k)], u);
+                    W[r][k] = u;
+                    V[r][k] = Si[r][k];
                 }
-                // V_t = S_t^-1 + W J_t^T: the rows of J_t from their owners
-#pragma unroll
-                for (int j = 0; j < D; ++j)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double jj = LN::bc(J[j % R][k], j / R);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) V[r][j] = fma(W[r][k], jj, V[r][j]);
-                    }
             }
+            // V_t = S_t^-1 + W J_t^T: the rows of J_t from their owners
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double jj = LN::bc(J[j % R][k], j / R);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) V[r][j] = fma(W[r][k], jj, V[r][j]);
+                }
 #pragma unroll
             for (int l = 0; l < D; ++l) xf[l] = LN::bc(x[l % R], l / R);
         }
-        if (t < T - 1) {
-            // column i of sum <x_t+1 x_t^T> = Cov(x_t, x_t+1)^T + the means
+        // column i of sum <x_t+1 x_t^T> = Cov(x_t, x_t+1)^T + the means (zero at t = T - 1: xn = W = 0)
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int a = 0; a < D; ++a) snpT[r][a] += fma(xn[a], x[r], -W[r][a]);
-        }
+            for (int a = 0; a < D; ++a) snpT[r][a] += fma(xn[a], x[r], -W[r][a]);
         // P_t = V_t + x_t x_t^T (rows of this lane), out; the sums
-        double Pr[R][D];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -569,32 +799,19 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
                 Pr[r][k] = fma(x[r], xf[k], V[r][k]);
                 sumP[r][k] += Pr[r][k];
             }
-        if (live) {
-            double *zp = A.Z + (int64_t)t * D * BL + b;
-            double *pp = A.P + (int64_t)t * NS * BL + b;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (rw.valid(r)) {
-                    if (!given) zp[(int64_t)rw.row[r] * BL] = x[r];
-#pragma unroll
-                    for (int k = 0; k < D; ++k)
-                        if (k <= rw.row[r]) pp[(int64_t)(rw.tri[r] + k) * BL] = Pr[r][k];
-                }
-        }
         if (MF > 0) {
+            // hand the step to the statistics of the NEXT iteration (there they run beside the
+            // serial chain of the recursion instead of behind it)
+            wq = w;
 #pragma unroll
-            for (int m = 0; m < MFR; ++m)
-                if (m < M) {
-                    const double bd = (double)((w >> m) & 1);
+            for (int m = 0; m < MFR; ++m) yq[m] = y[m];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
+            for (int r = 0; r < R; ++r) {
+                xq[r] = x[r];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) XX[m][r][k] = fma(bd, Pr[r][k], XX[m][r][k]);
-                        Syx[m][r] = fma(y[m], x[r], Syx[m][r]);
-                    }
-                }
+                for (int k = 0; k < D; ++k) Pq[r][k] = Pr[r][k];
+            }
         }
-        // what step t - 1 needs of this one: <x_t> in full, Cov(x_t) as the lower triangle of its owners
 #pragma unroll
         for (int i = 0; i < D; ++i) xn[i] = xf[i];
         if (!given) {
@@ -603,28 +820,26 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, boo
 #pragma unroll
                 for (int k = 0; k <= l; ++k) Vnp[sym_ix(l, k)] = LN::bc(V[l % R][k], l / R);
         }
-        if (t == T - 1) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc[AC::PT + r * D + k] = Pr[r][k];
-        }
-        if (t == 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                acc[AC::x0 + r] = x[r];
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc[AC::P0 + r * D + k] = Pr[r][k];
-            }
-        }
     }
+    lssmm_store_rows<D, G>(A.P + b, BL, rw, Pr);                              // step 0 out
+    if (!given) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r) A.Z[(int64_t)rw.rowc[r] * BL + b] = x[r];
+    }
+    if (MF > 0) stats_of(wq, yq, xq, Pq);          // step 0
+    // the loop ends on t = 0: Pr = P_0, x = x_0; P_T-1 (lower triangle) back from the array this
+    // thread wrote (a lane that stores nothing carries weight zero)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[AC::x0 + r] = x[r];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             acc[AC::sumP + r * D + k] = sumP[r][k];
             acc[AC::Snp + r * D + k] = snpT[r][k];
+            acc[AC::P0 + r * D + k] = Pr[r][k];
+            acc[AC::PT + r * D + k] = A.P[((int64_t)(T - 1) * NS + rw.sym(r, k)) * BL + b];
         }
+    }
     if (MF > 0) {
 #pragma unroll
         for (int m = 0; m < MFR; ++m)

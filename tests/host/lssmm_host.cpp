@@ -103,7 +103,9 @@ static void x_update_lanes(int given, const lssmm_seq_args &S, const double *seq
         if (given != 2) {
             std::vector<double> ld(B > 0 ? B : 1, 0.0);
             if (!given)
-                for (int64_t b = 0; b < B; ++b) ld[b] = lssmm_forward_seq<D, G>(S, b, lane, true, lbad);
+                for (int64_t b = 0; b < B; ++b)
+                    ld[b] = (M <= 8 && D <= 4 && S.nib) ? lssmm_forward_seq<D, G, 8>(S, b, lane, lbad)
+                                              : lssmm_forward_seq<D, G, 64>(S, b, lane, lbad);
             for (int64_t b = 0; b < B; ++b) {
                 const double w = seqobs[b];
                 auto put_chain = [&](int slot, double v) { raw[slot] += w * v; };
@@ -111,12 +113,12 @@ static void x_update_lanes(int given, const lssmm_seq_args &S, const double *seq
                 if (fuse) {
                     using AC = lssmm_acc<D, G, MF>;
                     double acc[AC::len];
-                    lssmm_backward_seq<D, G, MF>(S, b, lane, true, given, acc);
+                    lssmm_backward_seq<D, G, MF>(S, b, lane, given, acc);
                     lssmm_put_chain<D, G>(lane, acc, put_chain);
                     lssmm_put_stats<D, G, MF>(lane, 0, M, acc + AC::XX, acc + AC::Syx, put_stats);
                 } else {
                     double acc[lssmm_acc<D, G, 0>::len];
-                    lssmm_backward_seq<D, G, 0>(S, b, lane, true, given, acc);
+                    lssmm_backward_seq<D, G, 0>(S, b, lane, given, acc);
                     lssmm_put_chain<D, G>(lane, acc, put_chain);
                 }
                 if (lane == 0) raw[ro.ld] += w * ld[b];
@@ -213,6 +215,14 @@ int32_t vmp_lssmm_x_update(vmp_ctx *, int32_t given, const double *Yt, const uin
     lssmm_seq_args S;
     S.Yt = Yt; S.Mw = Mw; S.F = F; S.Z = Z; S.P = P; S.tab = state + L.off_tab;
     S.M = M; S.T = T; S.BL = BL;
+    // the nibble tables of the forward sweep, under the rule of the device (LSSMM_HOST_NIBBLES=0: off)
+    const char *e = getenv("LSSMM_HOST_NIBBLES");
+    std::vector<double> nib((e && atoi(e) == 0) ? 0 : lssmm_nibble_len(D, M));
+    S.nib = nullptr;
+    if (!nib.empty()) {
+        lssmm_build_nibbles(D, M, S.tab, nib.data(), 0, 1);
+        S.nib = nib.data();
+    }
     switch (D) {
     case 1: x_update_impl<1>(given, S, seqobs, B, state, L); break;
     case 2: x_update_impl<2>(given, S, seqobs, B, state, L); break;
