@@ -176,7 +176,7 @@ struct put_store {
 };
 
 // partial[blk]: chain sums (CL) and, MF > 0, the statistics XX (M, NS) | Syx (M, D) behind them
-template <int D, int G, int MF>
+template <int D, int G, int MF, bool GIVEN>
 __global__ void __launch_bounds__(WNT)
 lssmm_backward_kernel(sweep_args A)
 {
@@ -194,7 +194,7 @@ lssmm_backward_kernel(sweep_args A)
     const bool live = bq < A.B;
     const int64_t b = bq;
     double acc[AC::len];
-    lssmm_backward_seq<D, G, MF>(S, b, lane, A.given, acc);
+    lssmm_backward_seq<D, G, MF, GIVEN>(S, b, lane, acc);
     // chain sums: sequences with data only; the statistics carry the mask themselves
     const double wc = live ? A.seqobs[b] : 0.0;
 #pragma unroll
@@ -291,12 +291,18 @@ constexpr int GMAX = 4;        // lanes per sequence of the default form
 
 inline int64_t nwg(int64_t B, int G) { return (B * G + WNT - 1) / WNT; }
 
-// lanes per sequence: 4 (rows dealt over a DPP quad) unless the tune key asks for the
-// one-thread-per-sequence form, which exists up to D = 4
-inline int lanes_for(int D)
+// lanes per sequence: 4 (rows dealt over a DPP quad) while the sequences alone do not fill the
+// chip -- below 32768 of them four-lane groups are fewer than eight wavefronts per SIMD and the
+// shorter serial chain of a step wins (B = 1e4: 2.5 against 4.0 ms per iteration) --, one thread per
+// sequence beyond (a third of the instructions per sequence; B = 1e5: 14.5 against 17 ms).  D > 4
+// exists with four lanes only.  vmp_tune_set("lssmm_lanes", 1 | 4) fixes the form.
+inline int lanes_for(int D, int64_t B)
 {
-    const int g = vmp_tune_get("lssmm_lanes", GMAX);
-    return (g == 1 && D <= 4) ? 1 : GMAX;
+    const int g = vmp_tune_get("lssmm_lanes", 0);
+    if (D > 4) return GMAX;
+    if (g == 1) return 1;
+    if (g == GMAX) return GMAX;
+    return B >= 32768 ? 1 : GMAX;
 }
 
 // the backward sweep carries the statistics of all rows of C (G = 4 only: 40 accumulators a lane)
@@ -391,7 +397,7 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
     const int NS = (int)L.NS;
     double *partial = reinterpret_cast<double *>(workspace);
     double *raw = state + L.off_raw;
-    const int G = lanes_for(D);
+    const int G = lanes_for(D, B);
     const bool fuse = fused_stats(D, M, G) && given != 2;
     const int CL = ro.chain_len - 1;
     const int SL = M * (NS + D);
@@ -451,12 +457,16 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
         if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[1], s));
         if (g > 0) {
             if (fuse) {
-#define LSSMM_BWDF(d) hipLaunchKernelGGL((lssmm_backward_kernel<d, GMAX, LSSMM_MFUSE>), dim3((unsigned)g), dim3(WNT), lds, s, A);
+#define LSSMM_BWDF(d)                                                                                \
+    if (A.given) hipLaunchKernelGGL((lssmm_backward_kernel<d, GMAX, LSSMM_MFUSE, true>), dim3((unsigned)g), dim3(WNT), lds, s, A); \
+    else hipLaunchKernelGGL((lssmm_backward_kernel<d, GMAX, LSSMM_MFUSE, false>), dim3((unsigned)g), dim3(WNT), lds, s, A);
                 switch (D) { case 1: LSSMM_BWDF(1) break; case 2: LSSMM_BWDF(2) break;
                              case 3: LSSMM_BWDF(3) break; default: LSSMM_BWDF(4) break; }
 #undef LSSMM_BWDF
             } else {
-#define LSSMM_BWD(d, gg) hipLaunchKernelGGL((lssmm_backward_kernel<d, gg, 0>), dim3((unsigned)g), dim3(WNT), lds, s, A);
+#define LSSMM_BWD(d, gg)                                                                             \
+    if (A.given) hipLaunchKernelGGL((lssmm_backward_kernel<d, gg, 0, true>), dim3((unsigned)g), dim3(WNT), lds, s, A); \
+    else hipLaunchKernelGGL((lssmm_backward_kernel<d, gg, 0, false>), dim3((unsigned)g), dim3(WNT), lds, s, A);
                 LSSMM_FOR_DG(LSSMM_BWD)
 #undef LSSMM_BWD
             }

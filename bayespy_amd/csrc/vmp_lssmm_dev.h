@@ -577,9 +577,8 @@ struct lssmm_acc {
 // m < M <= MF of C (XX_m += mask_mbt P_bt, Syx_m += y_mbt x_bt) ride along -- P and <x> never come
 // back from HBM for them.  acc: lssmm_acc<D, G, MF> (this lane's rows; not weighted).
 // ---------------------------------------------------------------------------------------------
-template <int D, int G, int MF>
-VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, int given,
-                               double *acc)
+template <int D, int G, int MF, bool given>
+VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, double *acc)
 {
     using LN = lssmm_lanes<G>;
     using AC = lssmm_acc<D, G, MF>;
@@ -618,8 +617,9 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, int
     for (int s = 0; s < NS; ++s) Vnp[s] = 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i) xn[i] = 0.0;
-    // operands of the step, requested one step ahead: this lane's rows of S_t^-1, z_t (given: <x_t>)
-    // in full, and for the statistics y_t and the mask word
+    // operands of a step: this lane's rows of S_t^-1, z_t (given: <x_t>) in full, and for the
+    // statistics y_t and the mask word; with one row per lane (D <= 4) requested one step ahead
+    constexpr bool PF = R == 1;
     double fn[R][D], zn[D], yn[MFR];
     uint64_t wn = 0;
 #pragma unroll
@@ -628,30 +628,31 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, int
         for (int k = 0; k < D; ++k) fn[r][k] = 0.0;
 #pragma unroll
     for (int m = 0; m < MFR; ++m) yn[m] = 0.0;
-    {
-        const int t = T - 1;
+    auto load_step = [&](int tq, double (&f)[R][D], double (&zz)[D], double (&yy)[MFR], uint64_t &ww) {
         if (given) {
-            const double *zp = A.Z + (int64_t)t * D * BL + b;
+            const double *zp = A.Z + (int64_t)tq * D * BL + b;
 #pragma unroll
-            for (int i = 0; i < D; ++i) zn[i] = zp[(int64_t)i * BL];
+            for (int i = 0; i < D; ++i) zz[i] = zp[(int64_t)i * BL];
         } else {
-            const double *fp = A.F + (int64_t)t * (NS + D) * BL + b;
+            const double *fp = A.F + (int64_t)tq * (NS + D) * BL + b;
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int k = 0; k < D; ++k) fn[r][k] = fp[(int64_t)rw.sym(r, k) * BL];
+                for (int k = 0; k < D; ++k) f[r][k] = fp[(int64_t)rw.sym(r, k) * BL];
 #pragma unroll
-            for (int i = 0; i < D; ++i) zn[i] = fp[(int64_t)(NS + i) * BL];
+            for (int i = 0; i < D; ++i) zz[i] = fp[(int64_t)(NS + i) * BL];
         }
         if (MF > 0) {
-            wn = A.Mw[(int64_t)t * BL + b];
+            ww = A.Mw[(int64_t)tq * BL + b];
 #pragma unroll
             for (int m = 0; m < MFR; ++m) {
-                const double v = A.Yt[((int64_t)t * M + (m < M ? m : M - 1)) * BL + b];
-                yn[m] = (m < M) ? v : 0.0;
+                // beyond the last row: the last row once more, as zero (no load under a condition)
+                const double v = A.Yt[((int64_t)tq * M + (m < M ? m : M - 1)) * BL + b];
+                yy[m] = (m < M) ? v : 0.0;
             }
         }
-    }
+    };
+    if (PF) load_step(T - 1, fn, zn, yn, wn);
     double Pr[R][D], x[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -686,6 +687,7 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, int
     };
     for (int t = T - 1; t >= 0; --t) {
         double Si[R][D], z[D], y[MFR];
+        if (!PF) load_step(t, fn, zn, yn, wn);       // two rows per lane: no room for operands ahead
         const uint64_t w = wn;
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -695,32 +697,8 @@ VMP_HD void lssmm_backward_seq(const lssmm_seq_args &A, int64_t b, int lane, int
         for (int i = 0; i < D; ++i) z[i] = zn[i];
 #pragma unroll
         for (int m = 0; m < MFR; ++m) y[m] = yn[m];
-        {
-            // the step before (at t = 0: this step once more, unused)
-            const int tp = t > 0 ? t - 1 : 0;
-            if (given) {
-                const double *zp = A.Z + (int64_t)tp * D * BL + b;
-#pragma unroll
-                for (int i = 0; i < D; ++i) zn[i] = zp[(int64_t)i * BL];
-            } else {
-                const double *fp = A.F + (int64_t)tp * (NS + D) * BL + b;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) fn[r][k] = fp[(int64_t)rw.sym(r, k) * BL];
-#pragma unroll
-                for (int i = 0; i < D; ++i) zn[i] = fp[(int64_t)(NS + i) * BL];
-            }
-            if (MF > 0) {
-                wn = A.Mw[(int64_t)tp * BL + b];
-#pragma unroll
-                for (int m = 0; m < MFR; ++m) {
-                    // beyond the last row: the last row once more, as zero (no load under a condition)
-                    const double v = A.Yt[((int64_t)tp * M + (m < M ? m : M - 1)) * BL + b];
-                    yn[m] = (m < M) ? v : 0.0;
-                }
-            }
-        }
+        // the step before (at t = 0: this step once more, unused)
+        if (PF) load_step(t > 0 ? t - 1 : 0, fn, zn, yn, wn);
         {
             // step t + 1 out, a whole step before the next wait for operands (a wait for a load also
             // waits for every store in flight); in the first iteration: zeros into the slots of step

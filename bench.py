@@ -55,7 +55,7 @@ def parse():
                    help='columns of the CPU-baseline sample; 0 = the whole workload when the '
                         'host has the memory for it (direct parity at the metric size)')
     p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'gmm_d16', 'masked', 'lssm',
-                                        'lssm_masked', 'generic_pca', 'generic_gmm'],
+                                        'lssm_masked', 'lssm_masked_1e5', 'generic_pca', 'generic_gmm'],
                    default='pca',
                    help="pca = the BASELINE.json metric (default); the others print the "
                         "secondary configurations of tools/workloads.py as the JSON line")
@@ -246,6 +246,7 @@ def main():
             'masked': ('run_masked', dict(), 50),
             'lssm': ('run_lssm', dict(), 100),
             'lssm_masked': ('run_lssm_masked', dict(), 50),
+            'lssm_masked_1e5': ('run_lssm_masked', dict(B=100_000), 20),
             'generic_pca': ('run_generic_pca', dict(), 50),
             'generic_gmm': ('run_generic_gmm', dict(), 50),
         }
@@ -437,6 +438,7 @@ def main():
                 ('masked', 'run_masked', dict(steps=50, warmup=1)),
                 ('lssm', 'run_lssm', dict(steps=150, warmup=3)),
                 ('lssm_masked', 'run_lssm_masked', dict(steps=50, warmup=2)),
+                ('lssm_masked_1e5', 'run_lssm_masked', dict(B=100_000, steps=20, warmup=2)),
                 ('generic_pca', 'run_generic_pca', dict(steps=50, warmup=4)),
                 ('generic_gmm', 'run_generic_gmm', dict(steps=50, warmup=4)),
             ]

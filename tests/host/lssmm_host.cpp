@@ -113,12 +113,14 @@ static void x_update_lanes(int given, const lssmm_seq_args &S, const double *seq
                 if (fuse) {
                     using AC = lssmm_acc<D, G, MF>;
                     double acc[AC::len];
-                    lssmm_backward_seq<D, G, MF>(S, b, lane, given, acc);
+                    if (given) lssmm_backward_seq<D, G, MF, true>(S, b, lane, acc);
+                    else lssmm_backward_seq<D, G, MF, false>(S, b, lane, acc);
                     lssmm_put_chain<D, G>(lane, acc, put_chain);
                     lssmm_put_stats<D, G, MF>(lane, 0, M, acc + AC::XX, acc + AC::Syx, put_stats);
                 } else {
                     double acc[lssmm_acc<D, G, 0>::len];
-                    lssmm_backward_seq<D, G, 0>(S, b, lane, given, acc);
+                    if (given) lssmm_backward_seq<D, G, 0, true>(S, b, lane, acc);
+                    else lssmm_backward_seq<D, G, 0, false>(S, b, lane, acc);
                     lssmm_put_chain<D, G>(lane, acc, put_chain);
                 }
                 if (lane == 0) raw[ro.ld] += w * ld[b];

@@ -95,7 +95,7 @@ def test_device_kernels_equal_their_host_build(M, B, T, D, lanes):
         for Q in (Qd, Qh):
             Q.update(repeat=2, verbose=False)
     finally:
-        _lib.load().vmp_tune_set(b'lssmm_lanes', 4)
+        _lib.load().vmp_tune_set(b'lssmm_lanes', 0)
     pd, ph = Qd.plans[0], Qh.plans[0]
     L = pd.layout
     sd, sh = pd.state.cpu().numpy(), ph.state.numpy()

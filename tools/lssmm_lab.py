@@ -58,7 +58,7 @@ def main():
             del Q, plan
             gc.collect()
             torch.cuda.empty_cache()
-    lib.vmp_tune_set(b'lssmm_lanes', 4)
+    lib.vmp_tune_set(b'lssmm_lanes', 0)
     lib.vmp_tune_set(b'lssmm_fuse', 1)
 
 

@@ -812,7 +812,8 @@ def run_lssm_masked(B=10_000, T=1000, M=8, D=4, steps=50, warmup=2, cpu_baseline
         'roofline': {'bound': 'hbm', 'achieved': byts / dt / 1e9, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': byts / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                      'alg_bytes_per_iteration': byts, 'kernel_ms': kms,
-                     'moved_bytes_per_iteration': 8.0 * B * T * (2 * M + 3 * NS + 3 * D + 2)},
+                     # forward: Y, mask in, F out; backward (statistics carried): F, Y, mask in, <x>, <xx> out
+                     'moved_bytes_per_iteration': 8.0 * B * T * (2 * (M + 1) + 3 * (NS + D))},
     }
     prof, why = pmc_profile('masked LSSM B=%d T=%d M=%d D=%d' % (B, T, M, D))
     if prof is not None:
