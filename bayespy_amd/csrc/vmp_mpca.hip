@@ -239,11 +239,16 @@ void launch_reduce(hipStream_t s, const double *partial, int nb, int64_t stride,
 //   B operand (d x col): the panel in fragment order, 16 bytes per lane = two k-steps
 // One workgroup = 16*NSUB plates; wavefront w owns column tiles c = w, w+4, ...
 // -------------------------------------------------------------------------------------------
-template <int DB, int KT, int NSUB>
-__global__ void __launch_bounds__(NT, 2)
-mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ Mb1,
-                   const double *__restrict__ panel, int64_t sub0, int64_t nsub_chunk,
-                   int64_t nplates_chunk, double *__restrict__ Lam)
+// The accumulation of ONE group of 16 NSUB plates by the four wavefronts of a workgroup (wavefront
+// w: column tiles c = w, w + 4, ...), handed to ``store(c, s, R, wt, value)`` in the result layout
+// of the instructions: the value is entry (plate 16 s + (wt ? l4 + 4 R : 4 R + l4), column
+// 16 c + (l & 15)) of the group (l4 = l >> 4; wt = the <w> tile of the 16x16x4 form).  Shared by
+// mpca_lambda_kernel (-> Lam in HBM) and the fused form of mpca_blk4_kernel (-> its staging area).
+template <int DB, int KT, int NSUB, typename ST>
+__device__ __forceinline__ void
+mpca_lambda_group(const double *__restrict__ Ymt, const uint32_t *__restrict__ Mb1,
+                  const double *__restrict__ panel, int64_t sub0, int64_t nsub_chunk, int64_t grp,
+                  ST &&store)
 {
     constexpr int DP = 32 * DB, DQ = DP / 4;
     constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, CT = PT + KT;
@@ -260,7 +265,6 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
     const int l4 = l >> 4;
     const int c_last = w + 4 * (CW - 1);
     const int kind = c_last >= CT ? 0 : (c_last >= PT ? 2 : 1);
-    const int64_t ngroups = (nsub_chunk + NSUB - 1) / NSUB;
     // B fragments: panel + ((c (DQ/2) + q2) 64 + l) 2 doubles; the lane part is the only VGPR term
     // (a 32-bit offset beside a scalar base: 64-bit vector addresses cost two registers per tile)
     const char *pl = reinterpret_cast<const char *>(panel);
@@ -273,7 +277,7 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
     int src[4];
 #pragma unroll
     for (int R = 0; R < 4; ++R) src[R] = 4 * ((l & 0x30) | (4 * R) | (l & 3));
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    {
         double acc[CW][NSUB][4];
 #pragma unroll
         for (int ci = 0; ci < CW; ++ci)
@@ -387,15 +391,28 @@ mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ 
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-                    for (int R = 0; R < 4; ++R) {
-                        const bool wt = (ci == CW - 1) && kind == 2;
-                        const int64_t n = (grp * NSUB + s) * 16 + (wt ? l4 + 4 * R : 4 * R + l4);
-                        if (n < nplates_chunk)
-                            __builtin_nontemporal_store(acc[ci][s][R], &Lam[n * LR + 16 * c + (l & 15)]);
-                    }
+                    for (int R = 0; R < 4; ++R)
+                        store(c, s, R, (ci == CW - 1) && kind == 2, acc[ci][s][R]);
             }
         }
     }
+}
+
+template <int DB, int KT, int NSUB>
+__global__ void __launch_bounds__(NT, 2)
+mpca_lambda_kernel(const double *__restrict__ Ymt, const uint32_t *__restrict__ Mb1,
+                   const double *__restrict__ panel, int64_t sub0, int64_t nsub_chunk,
+                   int64_t nplates_chunk, double *__restrict__ Lam)
+{
+    constexpr int KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16, LR = 16 * (PT + KT);
+    const int l = threadIdx.x & 63, l4 = l >> 4;
+    const int64_t ngroups = (nsub_chunk + NSUB - 1) / NSUB;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
+        mpca_lambda_group<DB, KT, NSUB>(Ymt, Mb1, panel, sub0, nsub_chunk, grp,
+                                        [&](int c, int s, int R, bool wt, double v) {
+            const int64_t n = (grp * NSUB + s) * 16 + (wt ? l4 + 4 * R : 4 * R + l4);
+            if (n < nplates_chunk) __builtin_nontemporal_store(v, &Lam[n * LR + 16 * c + (l & 15)]);
+        });
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1055,12 +1072,25 @@ __device__ __forceinline__ void blk4_for_blocks(F &&f)
     }
 }
 
-template <int NB, bool FULLK>
+// DBF > 0: the FUSED form (round 5) -- the precision GEMM runs inside this kernel and Lam~ never
+// exists in HBM.  A workgroup owns the 16 plates of a subtile; per subtile:
+//   phase A  mpca_lambda_group<DBF, KT, 1>: the four wavefronts split the column tiles exactly as
+//            mpca_lambda_kernel does (B fragments straight from L2 into registers, no staging, no
+//            barrier inside the k-loop), each accumulating its tiles for all 16 plates;
+//   exchange the accumulators go to the staging area as the four packed rows of each plate group --
+//            what the LDS-DMA of the separate form delivers from HBM -- between two barriers;
+//   phase B  wavefront w runs the per-plate stage below, unchanged, on plate group w.
+// Two workgroups share a CU; the odd ones start late (half a subtile), so that a SIMD mostly holds
+// one wavefront in phase A (matrix pipe) beside one in phase B (mostly vector ALU).
+// Saves the 4.4 GB written + 4.4 GB read per 2^20 plates of the Lam~ round trip; costs the B
+// fragments twice as often from L2 (a workgroup of the separate GEMM owns 32 plates).
+template <int NB, bool FULLK, int DBF>
 __global__ void __launch_bounds__(NT, 2)
 mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chunk, int K,
                  double x_prec, const double *__restrict__ tau_ptr, double *__restrict__ XXf,
                  double *__restrict__ Xm, int write_x, double *__restrict__ partial,
-                 double *__restrict__ partial_sxx)
+                 double *__restrict__ partial_sxx, const double *__restrict__ Ymt,
+                 const uint32_t *__restrict__ Mb1, const double *__restrict__ panel, int stagger)
 {
     constexpr int KT = NB <= 4 ? 1 : 2, KP = 16 * KT, P = KP * (KP + 1) / 2, PT = (P + 15) / 16;
     constexpr int LRC = 16 * (PT + KT), NBB = NB * (NB + 1) / 2, PT2 = (PT + 1) / 2;
@@ -1122,16 +1152,9 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         }
     };
     const int64_t ngroups = (nplates_chunk + 3) / 4;
-    const int64_t gstep = (int64_t)gridDim.x * 4;
-    int64_t q = (int64_t)blockIdx.x * 4 + w;
-    if (q < ngroups) fetch(q);
-    __syncthreads();                              // sa zeroed
     const blk4_lane lc0 = lc;
-    for (; q < ngroups; q += gstep) {
-        // the rows requested at the end of the previous iteration have landed in the staging area
-        // (LDS-DMA completes on vmcnt; the compiler does not order the reads below behind it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_fence();
+    // the per-plate stage of the four plates 4 q .. 4 q + 3 whose packed rows lie in stg[w]
+    auto plate_stage = [&](int64_t q) {
         // the per-lane index constants are re-materialised every iteration: left loop-invariant,
         // the compiler hoists the 36 gather and the 36 store offsets of a lane out of the loop and
         // spills the matrix instead
@@ -1139,7 +1162,6 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
         asm volatile("" : "+v"(lc.li4), "+v"(lc.t0), "+v"(lc.m4), "+v"(lc.t0d));
         const double *row = stg[w] + lb * LRC;
         const bool valid = 4 * q + lb < nplates_chunk;
-        const bool more = q + gstep < ngroups;
         // ---- gather: S = c I + tau Lam~ (identity on the padding) ------------------------------
         double S[NBB];
         blk4_for_blocks<NB, 0, 0>([&](auto Ic, auto Jc) {
@@ -1231,15 +1253,17 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
             for (int pk = P + (l & 15); pk < 32 * PT2; pk += 16) ob[(l >> 4) * 32 + xxf_off(pk)] = 0.0;
             lds_fence();
             v2f64 *xo = reinterpret_cast<v2f64 *>(XXf + q * ((int64_t)PT2 * 128)) + l;
+            if (q < ngroups) {
 #pragma unroll
-            for (int i0 = 0; i0 < PT2; i0 += 4) {
-                v2f64 t[4];
+                for (int i0 = 0; i0 < PT2; i0 += 4) {
+                    v2f64 t[4];
 #pragma unroll
-                for (int i = i0; i < PT2 && i < i0 + 4; ++i)
-                    t[i - i0] = reinterpret_cast<const v2f64 *>(ob)[i * 64 + l];
+                    for (int i = i0; i < PT2 && i < i0 + 4; ++i)
+                        t[i - i0] = reinterpret_cast<const v2f64 *>(ob)[i * 64 + l];
 #pragma unroll
-                for (int i = i0; i < PT2 && i < i0 + 4; ++i) xo[i * 64] = t[i - i0];
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = i0; i < PT2 && i < i0 + 4; ++i) xo[i * 64] = t[i - i0];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (valid && write_x && lj == 0) {
                 double *xr = Xm + (n0 + 4 * q + lb) * KP;
@@ -1257,7 +1281,36 @@ mpca_blk4_kernel(const double *__restrict__ Lam, int64_t n0, int64_t nplates_chu
             }
         }
         lds_fence();
-        if (more) fetch(q + gstep);
+    };
+    if constexpr (DBF == 0) {
+        const int64_t gstep = (int64_t)gridDim.x * 4;
+        int64_t q = (int64_t)blockIdx.x * 4 + w;
+        if (q < ngroups) fetch(q);
+        __syncthreads();                              // sa zeroed
+        for (; q < ngroups; q += gstep) {
+            // the rows requested at the end of the previous iteration have landed in the staging
+            // area (LDS-DMA completes on vmcnt; the compiler does not order the reads below behind it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_fence();
+            plate_stage(q);
+            if (q + gstep < ngroups) fetch(q + gstep);
+        }
+    } else {
+        const int64_t sub0 = n0 / 16, nsub = (nplates_chunk + 15) / 16;
+        // the odd workgroups of the grid (the second one of a CU) start half a subtile late
+        if (stagger > 0 && (blockIdx.x & 1)) {
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+        for (int64_t sb = blockIdx.x; sb < nsub; sb += gridDim.x) {
+            __syncthreads();                          // the staging area is free (and sa zeroed)
+            mpca_lambda_group<DBF, KT, 1>(Ymt, Mb1, panel, sub0, nsub, sb,
+                                          [&](int c, int, int R, bool, double v) {
+                // plate 4 R + (l >> 4) of the subtile in either result layout: group R, row l >> 4
+                stg[R][(l >> 4) * LRC + 16 * c + (l & 15)] = v;
+            });
+            __syncthreads();
+            plate_stage(4 * sb + w);
+        }
     }
     // per-workgroup partials: tr<xx> = trace of the accumulated sum, log|Cov|, status
     __syncthreads();
@@ -1928,8 +1981,11 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
     double *psxx = pscal + grid_cap(ctx, 16) * 4;
     hipEvent_t *ev = (ctx->timing && cs.timed) ? vmp_next_events(ctx) : nullptr;
     // ---- stage 1: Lam~ = mask^T . panel ---------------------------------------------------------
+    // the fused form (round 5): stage 1 runs inside the per-plate kernel
+    const bool fused = !from_value && !inspect && vmp_tune_get("mpca_blk4", 1) != 0
+                       && vmp_tune_get("mpca_fuse", 1) != 0 && (K == 16 || K == 32);
     if (ev) VMP_HIP_CHECK(ctx, hipEventRecord(ev[0], cs.sL));
-    if (!from_value) {
+    if (!from_value && !fused) {
         constexpr int NSUB = 2;
         int64_t g = (nsub + NSUB - 1) / NSUB;
         if (g > grid_cap(ctx, cs.wgs_lambda)) g = grid_cap(ctx, cs.wgs_lambda);
@@ -1969,14 +2025,27 @@ int32_t run_chunk(vmp_ctx *ctx, const mpca_dims &m, const vmp_mpca_layout &L, in
 #define MPCA_BLK4(NBV)                                                                             \
     case NBV:                                                                                      \
         if (K == 4 * NBV)                                                                          \
-            hipLaunchKernelGGL((mpca_blk4_kernel<NBV, true>), dim3((unsigned)gs), dim3(NT), 0, s,  \
+            hipLaunchKernelGGL((mpca_blk4_kernel<NBV, true, 0>), dim3((unsigned)gs), dim3(NT), 0, s, \
                                Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
-                               inspect ? 0 : 1, pscal, psxx);                                      \
+                               inspect ? 0 : 1, pscal, psxx, nullptr, nullptr, nullptr, 0);        \
         else                                                                                       \
-            hipLaunchKernelGGL((mpca_blk4_kernel<NBV, false>), dim3((unsigned)gs), dim3(NT), 0, s, \
+            hipLaunchKernelGGL((mpca_blk4_kernel<NBV, false, 0>), dim3((unsigned)gs), dim3(NT), 0, s, \
                                Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, \
-                               inspect ? 0 : 1, pscal, psxx);                                      \
+                               inspect ? 0 : 1, pscal, psxx, nullptr, nullptr, nullptr, 0);        \
         break;
+        if (fused) {
+            // the precision GEMM inside the per-plate kernel (no Lam~ in HBM): K = 16 or 32
+            const int stg_n = vmp_tune_get("mpca_fuse_stagger", 2);
+#define MPCA_FUSED(NBV, db)                                                                        \
+    if (nb == NBV && m.DP == 32 * db)                                                              \
+        hipLaunchKernelGGL((mpca_blk4_kernel<NBV, true, db>), dim3((unsigned)gs), dim3(NT), 0, s,  \
+                           Lam, n0, nplates, K, x_prec, state + L.off_scal + SC_TAUX, XXf, Xm, 1,  \
+                           pscal, psxx, Ymt, Mb1, state + L.off_panel_x, stg_n);                   \
+    else
+            MPCA_FUSED(4, 1) MPCA_FUSED(4, 2) MPCA_FUSED(4, 4)
+            MPCA_FUSED(8, 1) MPCA_FUSED(8, 2) MPCA_FUSED(8, 4) { return VMP_ERR_UNSUPPORTED; }
+#undef MPCA_FUSED
+        } else
         switch (nb) {
             MPCA_BLK4(1) MPCA_BLK4(2) MPCA_BLK4(3) MPCA_BLK4(4)
             MPCA_BLK4(5) MPCA_BLK4(6) MPCA_BLK4(7) MPCA_BLK4(8)

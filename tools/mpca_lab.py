@@ -51,6 +51,12 @@ def main():
     ]
     if os.environ.get('MPCA_LAB_ONE'):
         variants = variants[:1]
+    if os.environ.get('MPCA_LAB_FUSE'):
+        # the fused form (precision GEMM inside the per-plate kernel, no Lam~ in HBM) against the
+        # separate one; MPCA_LAB_STAGGER = start delays of the odd workgroups to try (units of 3.5 us)
+        variants = [(1 << 20, dict(mpca_streams=0, mpca_fuse=0))]
+        for st in [int(v) for v in os.environ.get('MPCA_LAB_STAGGER', '0,6').split(',')]:
+            variants.append((1 << 20, dict(mpca_streams=0, mpca_fuse=1, mpca_fuse_stagger=st)))
     print('N=%d D=%d K=%d; ms per X.update(), per-chunk kernel times (HIP events), bound after two '
           'iterations' % (N, D, K))
     for chunk, knobs in variants:
