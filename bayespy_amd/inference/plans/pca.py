@@ -699,33 +699,50 @@ class PCAPlan:
             return ms
 
         # the placement of <x> (the write stream) decides most of the spread and its candidates are
-        # cheap (a fifth of the bytes, no re-layout): twice as many of them
-        # (candidates a few GB apart: the pass time changes level over 8-18 GB of the allocation
-        # order, profiles/r03/xpass_place_landscape.txt; the spacers are freed with the losers)
+        # cheap (a fifth of the bytes, no re-layout): more of them, all alive to the end.  The
+        # candidates of the tile-major Y (10 GB each at the headline size) are a tournament with ONE
+        # challenger alive at a time: the loser of a round goes back to the driver, then the next
+        # <x> candidate is allocated -- it takes the start of the hole, so that the next Y candidate
+        # cannot land where the loser was -- and then the next challenger.  A round times the holder
+        # and the challenger on the <x> candidates that exist by then; the kept Y is timed on all
+        # of them at the end.  (Round 4 held every candidate and 5 GB spacers to the end: 118 GB of
+        # transient memory; now one Y and 2 tries - 3 <x> candidates beside the kept pair.)
         # keep_x: the current row-major <x> still holds values somebody may read (set-up before the
         # first X.update()): it is not among the candidates, the kept one gets a copy of it
         keep = keep_x and not xt
-        xs, ys, spacers = ([] if keep else [x_cur]), [self.Yt], []
-        gap = 2 * x_cur.numel() if free > 16 * set_bytes else 0
-        try:
-            for _ in range(2 * tries - (0 if keep else 1)):
-                if gap:
-                    spacers.append(rt.empty(gap))
-                xs.append(rt.empty(*x_cur.shape))
-            for _ in range(tries - 1):
-                ys.append(k.tile_y(self.Yd, self.ldy, N, D, K))
-        except RuntimeError:            # out of memory: the candidates made so far take part
-            spacers = []
-            torch.cuda.empty_cache()
-        if not xs:
-            return
+        xs = [] if keep else [x_cur]
+        n_new = max(2 * tries - 3, 1)
         # the pass also queues S <- [G A^T; A G A^T] on the state: inside an iteration that is the
         # statistic of this update, at set-up time (keep_x) the state must come back as it was
         saved = self.state.clone() if keep_x else None
-        # every pair: neither array alone decides (a process can sit at 2.33 ms for all candidates
-        # of one array while another Y / X pair reaches 2.2); ~0.15 s once at the headline size
-        grid = [[timed(y, x) for x in xs] for y in ys]
-        best = min((ms, j, i) for j, row in enumerate(grid) for i, ms in enumerate(row))
+        y_best, rows = self.Yt, []
+        try:
+            for _ in range(max(n_new - (tries - 1), 1)):
+                xs.append(rt.empty(*x_cur.shape))
+            n_new -= max(n_new - (tries - 1), 1)
+            for r in range(tries - 1):
+                if r > 0 and n_new > 0:
+                    xs.append(rt.empty(*x_cur.shape))       # into the hole of the last loser
+                    n_new -= 1
+                cand = k.tile_y(self.Yd, self.ldy, N, D, K)
+                row_b = [timed(y_best, x) for x in xs]
+                row_c = [timed(cand, x) for x in xs]
+                if not rows:
+                    rows.append(row_b)
+                rows.append(row_c)
+                if min(row_c) < min(row_b):
+                    y_best = self.Yt = cand                 # (the old holder is the loser)
+                del cand
+                torch.cuda.empty_cache()                    # the loser: back to the driver
+        except RuntimeError:            # out of memory: the candidates made so far take part
+            torch.cuda.empty_cache()
+        if not xs:
+            return
+        row_best = [timed(y_best, x) for x in xs]
+        rows.append(row_best)
+        grid = rows
+        y_ms = [min(r) for r in rows]
+        best = (min(row_best), len(rows) - 1, row_best.index(min(row_best)))
         if saved is not None:
             k.xjoin()
             rt.sync_stream()
@@ -737,13 +754,13 @@ class PCAPlan:
             self._Xt = x_cur
         else:
             self.Xd = x_cur
-        self.Yt = ys[best[1]]
+        self.Yt = y_best
         peak = torch.cuda.max_memory_allocated(rt.device)
-        del xs, ys, spacers
+        del xs, y_best
         # the losers go back to the DRIVER, not only to torch's cache: allocations outside the
         # caching allocator (the library's own, RCCL buffers, another process) must see the memory
         torch.cuda.empty_cache()
-        x_ms, y_ms = grid[0], [row[best[2]] for row in grid]
+        x_ms = grid[0]
         self.placement = {'x_ms': x_ms, 'yt_ms': y_ms, 'grid_ms': grid, 'kept': [best[1], best[2]],
                           'transient_peak_bytes': int(peak)}
 

@@ -402,7 +402,7 @@ def main():
         pl = getattr(plan, 'placement', None)
         if pl:
             flat = [v for row in pl['grid_ms'] for v in row]
-            setup['placement'] = {'candidates': [len(pl['grid_ms']), len(pl['grid_ms'][0])],
+            setup['placement'] = {'candidates': [len(pl['yt_ms']) - 1, len(pl['grid_ms'][-1])],
                                   'kept_ms': round(min(flat), 4), 'first_ms': round(flat[0], 4),
                                   'worst_ms': round(max(flat), 4)}
         else:

@@ -534,7 +534,7 @@ def test_placement_trial_leaves_the_results_untouched(when, monkeypatch):
         plan = Q.plans[0]
         if tries == '2' and when == 'setup':
             plan.place_plate_arrays()
-            assert plan.placement is not None and len(plan.placement['grid_ms']) == 2
+            assert plan.placement is not None and len(plan.placement['grid_ms']) == 3   # holder, challenger, the kept one on every <x>
         xa = Q['X'].u[0][0, ::1000].copy()
         Q.update(repeat=3, verbose=False)
         if tries == '2':

@@ -540,15 +540,26 @@ def run_masked(N=10_000_000, D=128, K=32, steps=3, warmup=1, missing=0.1, engine
             P = K * (K + 1) // 2
             # per chunk of plates: issued (symmetry-exploiting) MFMA flops of the two GEMM stages,
             # K^3 (factor + inverse) + 2K^2 (mean) flops per plate for the sweep stage
-            out['roofline']['kernels'] = [
-                {'kernel': 'mpca_lambda_kernel', 'avg_launch_ms': kms['mpca_lambda'],
-                 'issued_TFLOPs': 2.0 * ch * D * (P + K) / kms['mpca_lambda'] / 1e9},
-                {'kernel': 'mpca_sweep_kernel', 'avg_launch_ms': kms['mpca_sweep'],
-                 'alg_TFLOPs': ch * (K ** 3 + 2.0 * K * K) / kms['mpca_sweep'] / 1e9,
-                 'plates_per_s': ch / kms['mpca_sweep'] * 1e3},
-                {'kernel': 'mpca_stats2_kernel+mpca_ryx_kernel', 'avg_launch_ms': kms['mpca_stats'],
-                 'issued_TFLOPs': 2.0 * ch * D * (P + K) / kms['mpca_stats'] / 1e9}]
-            out['roofline']['kernel'] = 'mpca_sweep_kernel (largest single kernel)'
+            fused = kms['mpca_lambda'] < 0.05          # the precision GEMM inside the per-plate kernel
+            gemm = 2.0 * ch * D * (P + K)
+            sweep = ch * (K ** 3 + 2.0 * K * K)
+            if fused:
+                out['roofline']['kernels'] = [
+                    {'kernel': 'mpca_blk4_kernel<fused: precision GEMM + per-plate stage>',
+                     'avg_launch_ms': kms['mpca_sweep'],
+                     'issued_TFLOPs': (gemm + sweep) / kms['mpca_sweep'] / 1e9,
+                     'plates_per_s': ch / kms['mpca_sweep'] * 1e3}]
+            else:
+                out['roofline']['kernels'] = [
+                    {'kernel': 'mpca_lambda_kernel', 'avg_launch_ms': kms['mpca_lambda'],
+                     'issued_TFLOPs': gemm / kms['mpca_lambda'] / 1e9},
+                    {'kernel': 'mpca_blk4_kernel', 'avg_launch_ms': kms['mpca_sweep'],
+                     'alg_TFLOPs': sweep / kms['mpca_sweep'] / 1e9,
+                     'plates_per_s': ch / kms['mpca_sweep'] * 1e3}]
+            out['roofline']['kernels'].append(
+                {'kernel': 'mpca_stats3_kernel+mpca_ryx_kernel', 'avg_launch_ms': kms['mpca_stats'],
+                 'issued_TFLOPs': gemm / kms['mpca_stats'] / 1e9})
+            out['roofline']['kernel'] = 'mpca_blk4_kernel (largest single kernel)'
     wl = 'masked PCA N=%d D=%d K=%d' % (N, D, K)
     prof, why = pmc_profile(wl)
     if prof is not None:
