@@ -300,6 +300,7 @@ int32_t vmp_block_banded_solve(vmp_ctx *ctx, int32_t T, int32_t K, int64_t nm, i
                                const double *A, const double *B, const double *y, double *V,
                                double *C, double *x, double *ldet, int32_t *info)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && A && y && V && x && ldet && info && (T == 1 || (B && C)),
                 VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, T >= 1 && K >= 1 && nm >= 1 && ny >= 0, VMP_ERR_INVALID, "bad dims");

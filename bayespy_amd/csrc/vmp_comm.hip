@@ -119,6 +119,7 @@ int32_t vmp_comm_info(vmp_ctx *ctx, int32_t *rank, int32_t *world)
 
 int32_t vmp_allreduce_sum_f64(vmp_ctx *ctx, double *buf, int64_t count)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && (buf || count == 0) && count >= 0, VMP_ERR_INVALID, "bad argument");
     if (count == 0) return VMP_OK;
     // without a communicator the context is its own world: the sum over one rank

@@ -38,8 +38,24 @@ struct vmp_ctx {
     // RCCL communicator (vmp_comm.hip); null = a world of one rank
     void *comm;
     int comm_rank, comm_world;
+    // queue of SMALL generic operations (vmp_generic.hip): while it is open, vmp_ewise /
+    // vmp_sum_multiply calls on a few thousand elements are recorded on the host and run later by
+    // ONE launch of an interpreter kernel (vmp_queue_begin / _flush / _end)
+    void *queue;
     char err[512];
 };
+
+// every entry point that puts work on ctx->stream behind the caller's back of the queue calls this
+// first: queued small operations run before anything that may read what they write
+int32_t vmp_queue_flush(vmp_ctx *ctx);
+int32_t destroy_small_queue(vmp_ctx *ctx);       // internal: frees the queue with the context
+#define VMP_FLUSH_SMALL(ctx)                                   \
+    do {                                                       \
+        if ((ctx) && (ctx)->queue) {                           \
+            const int32_t rc__ = vmp_queue_flush(ctx);         \
+            if (rc__ != VMP_OK) return rc__;                   \
+        }                                                      \
+    } while (0)
 
 // event triple of the plate pass being issued (timing enabled); advances the ring
 static inline hipEvent_t *vmp_next_events(vmp_ctx *ctx)

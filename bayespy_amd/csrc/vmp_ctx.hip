@@ -73,6 +73,7 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
     for (int i = 0; i < 3; ++i) ctx->ms[i] = nullptr;
     for (int i = 0; i < VMP_NME; ++i) ctx->me[i] = nullptr;
     ctx->comm = nullptr;
+    ctx->queue = nullptr;
     ctx->comm_rank = 0;
     ctx->comm_world = 1;
     VMP_HIP_CHECK(ctx, hipSetDevice(device));
@@ -86,6 +87,7 @@ int32_t vmp_ctx_create(int32_t device, void *stream, vmp_ctx **out)
 int32_t vmp_ctx_destroy(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_OK;
+    (void)destroy_small_queue(ctx);
     (void)vmp_comm_destroy(ctx);
     for (int i = 0; i < 3 * VMP_EV_RING; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -111,6 +113,7 @@ int32_t vmp_ctx_destroy(vmp_ctx *ctx)
 int32_t vmp_ctx_set_stream(vmp_ctx *ctx, void *stream)
 {
     if (!ctx) return VMP_ERR_INVALID;
+    if ((hipStream_t)stream != ctx->stream) VMP_FLUSH_SMALL(ctx);      // queued work belongs to the old stream
     ctx->stream = (hipStream_t)stream;
     return VMP_OK;
 }
@@ -118,6 +121,7 @@ int32_t vmp_ctx_set_stream(vmp_ctx *ctx, void *stream)
 int32_t vmp_ctx_sync(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_ERR_INVALID;
+    VMP_FLUSH_SMALL(ctx);
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->xs) VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->xs));
     for (int i = 0; i < 3; ++i)
@@ -180,6 +184,7 @@ int32_t vmp_free(vmp_ctx *ctx, void *ptr)
 
 int32_t vmp_memcpy_h2d(vmp_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
+    VMP_FLUSH_SMALL(ctx);
     if (!ctx) return VMP_ERR_INVALID;
     VMP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -188,6 +193,7 @@ int32_t vmp_memcpy_h2d(vmp_ctx *ctx, void *dst, const void *src, size_t bytes)
 
 int32_t vmp_memcpy_d2h(vmp_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
+    VMP_FLUSH_SMALL(ctx);
     if (!ctx) return VMP_ERR_INVALID;
     VMP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -196,6 +202,7 @@ int32_t vmp_memcpy_d2h(vmp_ctx *ctx, void *dst, const void *src, size_t bytes)
 
 int32_t vmp_memset_zero(vmp_ctx *ctx, void *dst, size_t bytes)
 {
+    VMP_FLUSH_SMALL(ctx);
     if (!ctx) return VMP_ERR_INVALID;
     VMP_HIP_CHECK(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
     return VMP_OK;

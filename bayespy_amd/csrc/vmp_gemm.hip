@@ -401,6 +401,7 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
                          int64_t c_ms, int64_t c_ns, double scale, void *workspace,
                          size_t workspace_bytes)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && A && B && C, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, nbatch_dims >= 0 && nbatch_dims <= 3, VMP_ERR_UNSUPPORTED,
                 "at most 3 batch axes");

@@ -534,53 +534,58 @@ struct EwiseArgs {
     int pairmask;       // VEC instance: operands read as aligned pairs (the others broadcast)
 };
 
+// one output element of a fused formula: flat index -> operand offsets, then the postfix program
+__device__ inline double ewise_element(const EwiseArgs &a, int64_t e)
+{
+    int64_t off[MAXIN];
+    for (int i = 0; i < a.nin; ++i) off[i] = 0;
+    int64_t t = e;
+    for (int d = a.ndim - 1; d >= 0; --d) {
+        const int64_t q = t / a.shape[d];
+        const int64_t c = t - q * a.shape[d];
+        t = q;
+        for (int i = 0; i < a.nin; ++i) off[i] += c * a.stride[i][d];
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
+#define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
+    for (int p = 0; p < a.nops; ++p) {
+        const int op = a.ops[p] & 0xff, arg = a.ops[p] >> 8;
+        switch (op) {
+        case VMP_OP_IN:      PUSH(a.in[arg][off[arg]]); break;
+        case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
+        case VMP_OP_ADD:     BIN(x + y); break;
+        case VMP_OP_SUB:     BIN(x - y); break;
+        case VMP_OP_MUL:     BIN(x * y); break;
+        case VMP_OP_DIV:     BIN(x / y); break;
+        case VMP_OP_NEG:     s0 = -s0; break;
+        case VMP_OP_LOG:     s0 = log(s0); break;
+        case VMP_OP_EXP:     s0 = exp(s0); break;
+        case VMP_OP_SQR:     s0 = s0 * s0; break;
+        case VMP_OP_SQRT:    s0 = sqrt(s0); break;
+        case VMP_OP_RECIP:   s0 = 1.0 / s0; break;
+        case VMP_OP_DIGAMMA: s0 = vmp_digamma(s0); break;
+        case VMP_OP_LGAMMA:  s0 = vmp_lgamma(s0); break;
+        case VMP_OP_TRIGAMMA: s0 = vmp_trigamma(s0); break;
+        case VMP_OP_MAX:     BIN(fmax(x, y)); break;
+        case VMP_OP_MIN:     BIN(fmin(x, y)); break;
+        case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;   // 0 * -inf guard
+        case VMP_OP_DUP:     PUSH(s0); break;
+        case VMP_OP_SWAP:    { const double tmp = s0; s0 = s1; s1 = tmp; } break;
+        default: break;
+        }
+    }
+#undef PUSH
+#undef BIN
+    return s0;
+}
+
 __global__ void __launch_bounds__(NT)
 ewise_kernel(EwiseArgs a, double *__restrict__ out)
 {
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < a.total;
-         e += (int64_t)gridDim.x * NT) {
-        int64_t off[MAXIN];
-        for (int i = 0; i < a.nin; ++i) off[i] = 0;
-        int64_t t = e;
-        for (int d = a.ndim - 1; d >= 0; --d) {
-            const int64_t q = t / a.shape[d];
-            const int64_t c = t - q * a.shape[d];
-            t = q;
-            for (int i = 0; i < a.nin; ++i) off[i] += c * a.stride[i][d];
-        }
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
-#define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
-        for (int p = 0; p < a.nops; ++p) {
-            const int op = a.ops[p] & 0xff, arg = a.ops[p] >> 8;
-            switch (op) {
-            case VMP_OP_IN:      PUSH(a.in[arg][off[arg]]); break;
-            case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
-            case VMP_OP_ADD:     BIN(x + y); break;
-            case VMP_OP_SUB:     BIN(x - y); break;
-            case VMP_OP_MUL:     BIN(x * y); break;
-            case VMP_OP_DIV:     BIN(x / y); break;
-            case VMP_OP_NEG:     s0 = -s0; break;
-            case VMP_OP_LOG:     s0 = log(s0); break;
-            case VMP_OP_EXP:     s0 = exp(s0); break;
-            case VMP_OP_SQR:     s0 = s0 * s0; break;
-            case VMP_OP_SQRT:    s0 = sqrt(s0); break;
-            case VMP_OP_RECIP:   s0 = 1.0 / s0; break;
-            case VMP_OP_DIGAMMA: s0 = vmp_digamma(s0); break;
-            case VMP_OP_LGAMMA:  s0 = vmp_lgamma(s0); break;
-            case VMP_OP_TRIGAMMA: s0 = vmp_trigamma(s0); break;
-            case VMP_OP_MAX:     BIN(fmax(x, y)); break;
-            case VMP_OP_MIN:     BIN(fmin(x, y)); break;
-            case VMP_OP_WHERE_NZ: BIN((x != 0.0) ? y : 0.0); break;   // 0 * -inf guard
-            case VMP_OP_DUP:     PUSH(s0); break;
-            case VMP_OP_SWAP:    { const double tmp = s0; s0 = s1; s1 = tmp; } break;
-            default: break;
-            }
-        }
-#undef PUSH
-#undef BIN
-        out[e] = s0;
-    }
+         e += (int64_t)gridDim.x * NT)
+        out[e] = ewise_element(a, e);
 }
 
 // Fast path: after dimension merging the iteration space has one or two axes.  A thread
@@ -1123,9 +1128,237 @@ void launch_finish(vmp_ctx *ctx, const Iter &it, int nsplit, double scale, const
                            it, nsplit, scale, partial, out);
 }
 
+// ---------------------------------------------------------------------------
+// The queue of small operations.  A sweep of the generic engine issues ~90 formulas and plate
+// sums on scalars and K x K arrays between its few plate-sized kernels; launched one by one they
+// are 5-30 us each of launch latency for < 1 us of work.  While the queue is open such calls are
+// recorded on the host (the very EwiseArgs / Iter the kernels take) and ONE launch of
+// small_ops_kernel -- a single workgroup that walks the records in order, a barrier between two
+// of them -- runs them when something else needs the stream (any other entry point of this
+// library flushes first), when the queue is full, or at vmp_queue_flush / vmp_queue_end.
+// Results do not depend on how the operations are grouped into launches.
+// Measured (bench.py --config generic_pca / generic_gmm, N = 1e6): eager sweeps 4.22 -> 3.83 ms /
+// 3.07 -> 3.04 ms; sweeps replayed from a HIP graph get SLOWER (2.10 -> 2.14, 1.76 -> 1.95 ms: a
+// graph node costs what one record costs the interpreter, a dependent round trip to memory), so
+// the recorder of the generic engine switches the queue off (tune keys small_queue_ew / _sm) and
+// the formulas -- whose interpreter arithmetic is that of ewise_kernel, bit for bit -- are the
+// default; queued plate sums use another summation order than the stand-alone kernels and stay
+// an opt-in (small_queue_sm = 1).
+// ---------------------------------------------------------------------------
+enum { SMALL_EWISE = 0, SMALL_SUM = 1 };
+struct SmallOp {
+    int32_t kind, pad;
+    double scale;
+    double *out;
+    union {
+        EwiseArgs ew;
+        Iter it;
+    };
+};
+constexpr int QUEUE_CAP = 64;                    // records per launch
+constexpr int64_t SMALL_EW_MAX = 2048;           // elements of a queued formula
+constexpr int64_t SMALL_SM_KEEP = 2048, SMALL_SM_WORK = 32768;   // outputs, products of a queued sum
+
+constexpr int QUEUE_SLOTS = 16;                  // staging buffers in rotation (eager flushes)
+constexpr int ARENA_RECORDS = 16384;             // records of flushes recorded into HIP graphs
+
+struct small_queue {
+    int open;
+    int n;                    // records collected in the current slot
+    int cur;                  // slot being filled
+    SmallOp *host;            // pinned: QUEUE_SLOTS x QUEUE_CAP records
+    SmallOp *dev;             // the device copies the kernel reads
+    hipEvent_t done[QUEUE_SLOTS];
+    int pending[QUEUE_SLOTS];
+    // a flush inside a stream capture is replayed with the graph: its records must stay where they
+    // are for as long as the graph lives, so they are moved into an arena that is never reused
+    // (allocated with the queue: nothing can be allocated while a stream records)
+    SmallOp *arena_host, *arena_dev;
+    int arena_used;
+    int64_t launches, ops;
+};
+
+__global__ void __launch_bounds__(NT)
+small_ops_kernel(const SmallOp *__restrict__ ops, int n)
+{
+    __shared__ SmallOp op;
+    __shared__ double red[NT];
+    for (int i = 0; i < n; ++i) {
+        // the record into LDS (uniform reads from there; 1 KB)
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(ops + i);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&op);
+            for (int e = threadIdx.x; e < (int)(sizeof(SmallOp) / 4); e += NT) dst[e] = src[e];
+        }
+        __syncthreads();
+        if (op.kind == SMALL_EWISE) {
+            for (int64_t e = threadIdx.x; e < op.ew.total; e += NT) op.out[e] = ewise_element(op.ew, e);
+        } else if (op.it.nkeep >= NT / 4 || op.it.nred < 64) {
+            // a thread per output, sequential sum (the order of sum_multiply_thread_kernel)
+            for (int64_t o = threadIdx.x; o < op.it.nkeep; o += NT) {
+                int64_t base[MAXIN], ooff;
+                decode_keep(op.it, o, base, ooff);
+                double acc = 0.0;
+                for (int64_t r = 0; r < op.it.nred; ++r) acc += product_at(op.it, base, r);
+                op.out[ooff] = op.scale * acc;
+            }
+        } else {
+            // few outputs, longer sums: the workgroup per output, lanes along the sum, partial
+            // sums combined in a fixed tree
+            for (int64_t o = 0; o < op.it.nkeep; ++o) {
+                int64_t base[MAXIN], ooff;
+                decode_keep(op.it, o, base, ooff);
+                double acc = 0.0;
+                for (int64_t r = threadIdx.x; r < op.it.nred; r += NT) acc += product_at(op.it, base, r);
+                red[threadIdx.x] = acc;
+                __syncthreads();
+                for (int st = NT / 2; st > 0; st >>= 1) {
+                    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) op.out[ooff] = op.scale * red[0];
+                __syncthreads();
+            }
+        }
+        // what this record wrote is visible to the next one (one workgroup, one CU)
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+inline small_queue *queue_of(vmp_ctx *ctx) { return reinterpret_cast<small_queue *>(ctx->queue); }
+
+inline bool stream_records(vmp_ctx *ctx)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &cap);
+    return cap == hipStreamCaptureStatusActive;
+}
+
+// room for one more record: *slot, or nullptr when the call has to launch on its own (the queue
+// is closed, or the arena of recorded flushes is used up)
+inline int32_t queue_slot(vmp_ctx *ctx, SmallOp **slot)
+{
+    *slot = nullptr;
+    small_queue *q = queue_of(ctx);
+    if (!q || q->open <= 0) return VMP_OK;
+    if (q->n == QUEUE_CAP) {
+        const int32_t rc = vmp_queue_flush(ctx);
+        if (rc != VMP_OK) return rc;
+    }
+    if (q->arena_used + q->n + 1 > ARENA_RECORDS && stream_records(ctx)) {
+        const int32_t rc = vmp_queue_flush(ctx);     // what is collected still fits; then on its own
+        if (rc != VMP_OK) return rc;
+        return VMP_OK;
+    }
+    *slot = q->host + (size_t)q->cur * QUEUE_CAP + q->n;
+    return VMP_OK;
+}
+
 }  // namespace
 
+int32_t destroy_small_queue(vmp_ctx *ctx)
+{
+    if (!ctx || !ctx->queue) return VMP_OK;
+    small_queue *q = queue_of(ctx);
+    for (int i = 0; i < QUEUE_SLOTS; ++i)
+        if (q->done[i]) (void)hipEventDestroy(q->done[i]);
+    if (q->host) (void)hipHostFree(q->host);
+    if (q->dev) (void)hipFree(q->dev);
+    if (q->arena_host) (void)hipHostFree(q->arena_host);
+    if (q->arena_dev) (void)hipFree(q->arena_dev);
+    delete q;
+    ctx->queue = nullptr;
+    return VMP_OK;
+}
+
 extern "C" {
+
+int32_t vmp_queue_begin(vmp_ctx *ctx)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
+    if (vmp_tune_get("small_queue", 1) == 0) return VMP_OK;
+    small_queue *q = queue_of(ctx);
+    if (!q) {
+        VMP_REQUIRE(ctx, !stream_records(ctx), VMP_ERR_INVALID,
+                    "the first vmp_queue_begin of a context allocates: not while its stream records");
+        q = new (std::nothrow) small_queue();
+        VMP_REQUIRE(ctx, q, VMP_ERR_HIP, "out of host memory");
+        memset(q, 0, sizeof(*q));
+        const size_t ring = (size_t)QUEUE_SLOTS * QUEUE_CAP * sizeof(SmallOp);
+        const size_t arena = (size_t)ARENA_RECORDS * sizeof(SmallOp);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&q->host), ring, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&q->dev), ring);
+        if (e == hipSuccess)
+            e = hipHostMalloc(reinterpret_cast<void **>(&q->arena_host), arena, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&q->arena_dev), arena);
+        for (int i = 0; i < QUEUE_SLOTS && e == hipSuccess; ++i)
+            e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
+        ctx->queue = q;
+        if (e != hipSuccess) {
+            (void)destroy_small_queue(ctx);
+            VMP_HIP_CHECK(ctx, e);
+        }
+    }
+    q->open += 1;
+    return VMP_OK;
+}
+
+int32_t vmp_queue_end(vmp_ctx *ctx)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
+    small_queue *q = queue_of(ctx);
+    if (!q || q->open <= 0) return VMP_OK;
+    q->open -= 1;
+    return q->open == 0 ? vmp_queue_flush(ctx) : VMP_OK;
+}
+
+int32_t vmp_queue_flush(vmp_ctx *ctx)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
+    small_queue *q = queue_of(ctx);
+    if (!q || q->n == 0) return VMP_OK;
+    const int n = q->n;
+    q->n = 0;
+    SmallOp *host = q->host + (size_t)q->cur * QUEUE_CAP, *dev = q->dev + (size_t)q->cur * QUEUE_CAP;
+    const bool rec = stream_records(ctx);
+    if (rec) {
+        // replayed with the graph: the records move into the arena (queue_slot made sure they fit)
+        VMP_REQUIRE(ctx, q->arena_used + n <= ARENA_RECORDS, VMP_ERR_UNSUPPORTED,
+                    "arena of recorded small operations exhausted");
+        memcpy(q->arena_host + q->arena_used, host, (size_t)n * sizeof(SmallOp));
+        host = q->arena_host + q->arena_used;
+        dev = q->arena_dev + q->arena_used;
+        q->arena_used += n;
+    }
+    VMP_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, (size_t)n * sizeof(SmallOp), hipMemcpyHostToDevice,
+                                      ctx->stream));
+    hipLaunchKernelGGL(small_ops_kernel, dim3(1), dim3(NT), 0, ctx->stream, dev, n);
+    VMP_HIP_CHECK(ctx, hipGetLastError());
+    q->launches += 1;
+    q->ops += n;
+    if (!rec) {
+        // the slot is reused QUEUE_SLOTS flushes from now: by then its copy must have left the
+        // pinned buffer (the event is waited for only if it has not fired, i.e. practically never)
+        VMP_HIP_CHECK(ctx, hipEventRecord(q->done[q->cur], ctx->stream));
+        q->pending[q->cur] = 1;
+        q->cur = (q->cur + 1) % QUEUE_SLOTS;
+        if (q->pending[q->cur]) {
+            VMP_HIP_CHECK(ctx, hipEventSynchronize(q->done[q->cur]));
+            q->pending[q->cur] = 0;
+        }
+    }
+    return VMP_OK;
+}
+
+int32_t vmp_queue_stats(vmp_ctx *ctx, int64_t *launches, int64_t *ops)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
+    small_queue *q = queue_of(ctx);
+    if (launches) *launches = q ? q->launches : 0;
+    if (ops) *ops = q ? q->ops : 0;
+    return VMP_OK;
+}
 
 int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
                          const double *const *in, const int64_t *in_strides,
@@ -1193,6 +1426,21 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         --it.nr;
     }
     it.i32 = (it.nkeep < ((int64_t)1 << 31) && it.nred < ((int64_t)1 << 31)) ? 1 : 0;
+    if (it.nkeep <= SMALL_SM_KEEP && it.nkeep * (it.nred > 0 ? it.nred : 1) <= SMALL_SM_WORK
+        && vmp_tune_get("small_queue_sm", 0)) {
+        SmallOp *slot = nullptr;
+        const int32_t rc = queue_slot(ctx, &slot);
+        if (rc != VMP_OK) return rc;
+        if (slot) {
+            slot->kind = SMALL_SUM;
+            slot->scale = scale;
+            slot->out = out;
+            slot->it = it;
+            queue_of(ctx)->n += 1;
+            return VMP_OK;
+        }
+    }
+    VMP_FLUSH_SMALL(ctx);
     hipStream_t s = ctx->stream;
     // ---- dense two-axis forms -------------------------------------------------------------
     if (it.nk == 1 && it.nr == 1 && it.nred > 0) {
@@ -1394,6 +1642,20 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
     }
     for (int c = 0; c < nconsts; ++c) a.consts[c] = consts[c];
     if (a.total == 0) return VMP_OK;
+    if (a.total <= SMALL_EW_MAX && vmp_tune_get("small_queue_ew", 1)) {
+        SmallOp *slot = nullptr;
+        const int32_t rc = queue_slot(ctx, &slot);
+        if (rc != VMP_OK) return rc;
+        if (slot) {
+            slot->kind = SMALL_EWISE;
+            slot->scale = 1.0;
+            slot->out = out;
+            slot->ew = a;
+            queue_of(ctx)->n += 1;
+            return VMP_OK;
+        }
+    }
+    VMP_FLUSH_SMALL(ctx);
     const bool i32 = a.total < ((int64_t)1 << 31);
     // 16-byte accesses: innermost axis contiguous or broadcast in every operand, even extent,
     // every pair aligned (even outer strides, 16-byte aligned bases)
@@ -1456,6 +1718,7 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
 int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A, double *Ainv,
                         double *logdet, int32_t *info)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && A, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, n >= 1 && batch >= 0, VMP_ERR_INVALID, "bad dims");
     VMP_REQUIRE(ctx, n <= SPD_MAXN, VMP_ERR_UNSUPPORTED, "batched SPD kernels support n <= %d",
@@ -1481,6 +1744,7 @@ int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A,
 int32_t vmp_gaussian_moments(vmp_ctx *ctx, int32_t n, int64_t batch, const double *phi0,
                              const double *phi1, double *u0, double *u1, double *g, int32_t *info)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && phi0 && phi1 && u0 && u1 && g, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, batch >= 0, VMP_ERR_INVALID, "bad dims");
     VMP_REQUIRE(ctx, n > 8 && n <= 32, VMP_ERR_UNSUPPORTED,
@@ -1499,6 +1763,7 @@ int32_t vmp_gaussian_moments(vmp_ctx *ctx, int32_t n, int64_t batch, const doubl
 int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double *phi, double *p,
                             double *lse)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && phi && p, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, rows >= 0 && K >= 1, VMP_ERR_INVALID, "bad dims");
     if (rows == 0) return VMP_OK;
@@ -1538,6 +1803,7 @@ int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double 
 int32_t vmp_onehot_i64(vmp_ctx *ctx, int64_t n, int32_t K, const int64_t *labels, double *out,
                        int32_t *info)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && labels && out && info, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, n >= 0 && K >= 1, VMP_ERR_INVALID, "bad dims");
     VMP_HIP_CHECK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));

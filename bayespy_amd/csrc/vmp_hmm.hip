@@ -257,6 +257,7 @@ int32_t vmp_alpha_beta_recursion(vmp_ctx *ctx, int32_t N, int32_t K, int64_t nch
                                  int64_t P_bstride, int64_t P_tstride, double *z0, double *zz,
                                  double *g, void *workspace, size_t workspace_bytes)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && logp0 && logP && z0 && zz && g, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, N >= 1 && K >= 1 && nchains >= 0, VMP_ERR_INVALID, "bad dims");
     VMP_REQUIRE(ctx, K <= 64, VMP_ERR_UNSUPPORTED,

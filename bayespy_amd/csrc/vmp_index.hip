@@ -67,6 +67,7 @@ int32_t vmp_take_axis(vmp_ctx *ctx, int64_t outer, int64_t src_len, int64_t inne
                       const double *src, int64_t n, const int64_t *idx, double *dst,
                       int64_t dst_len, int64_t dst_off)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && src && dst, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, outer >= 0 && src_len >= 0 && inner >= 0 && n >= 0 && dst_off >= 0 &&
                      dst_off + n <= dst_len && (idx || n <= src_len),
@@ -83,6 +84,7 @@ int32_t vmp_segment_sum_axis(vmp_ctx *ctx, int64_t outer, int64_t src_len, int64
                              const double *src, int64_t out_len, const int64_t *ptr,
                              const int64_t *perm, double *dst)
 {
+    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && src && dst && ptr && (perm || src_len == 0), VMP_ERR_INVALID,
                 "null argument");
     VMP_REQUIRE(ctx, outer >= 0 && src_len >= 0 && inner >= 0 && out_len >= 0, VMP_ERR_INVALID,

@@ -66,16 +66,18 @@ class DArray:
         return int(self.t.numel())
 
     def numpy(self):
+        t = self.t          # (a lazily evaluated array launches here: before the flush below)
         get_runtime().host_access('DArray.numpy')
-        return self.t.detach().cpu().numpy().copy()
+        return t.detach().cpu().numpy().copy()
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
         return a if dtype is None else a.astype(dtype)
 
     def item(self):
+        t = self.t
         get_runtime().host_access('DArray.item')
-        return float(self.t.reshape(-1)[0].item())
+        return float(t.reshape(-1)[0].item())
 
     # -- views (stride metadata only) ---------------------------------------------------
     def reshape(self, *shape):
@@ -291,6 +293,7 @@ def fuse(fn, *operands):
     rt.sync_stream()
     rt.check(rt.lib.vmp_ewise(rt.ctx, nd, c_shape, nin, c_in, c_str, nops, c_ops,
                               nconsts, c_consts, ctypes.c_void_p(out.t.data_ptr())))
+    rt.keep_until_flush(arrays, out)
     return out
 
 

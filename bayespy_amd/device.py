@@ -32,6 +32,8 @@ class Runtime:
             self.device = torch.device(device)
         self.lib = None
         self.ctx = None
+        self._queue_alive = []
+        self._queue_env = None
         self._comm_state = None     # None: not decided; True: the library owns an RCCL communicator
         self._comm_reason = None    # why the library communicator is not in use, if it is not
         self.collective_calls = {'library': 0, 'torch': 0}
@@ -122,6 +124,7 @@ class Runtime:
         recording is abandoned BEFORE the HIP call that would invalidate the capture."""
         if self._capturing:
             raise GraphCaptureAbort('needs the host: %s' % what)
+        self.flush_small()
 
     def all_reduce_sum_(self, tensor):
         """In-place sum over ranks: ``vmp_allreduce_sum_f64`` (RCCL all-reduce over xGMI,
@@ -217,6 +220,47 @@ class Runtime:
             msg = self.lib.vmp_last_error(self.ctx).decode(errors='replace')
             _lib.raise_for_status(rc, msg)
 
+    # -- the library's queue of small operations (include/vmp_hip.h: vmp_queue_*) ---------------
+    # open for the duration of a plan operation: the formulas and plate sums on scalars / K x K
+    # arrays of a sweep are run by a few launches of one interpreter kernel instead of one each.
+    # Whatever reads their outputs outside the library (a host read, a torch operation) flushes
+    # first: host_access() does.
+    def queue_begin(self):
+        if self.ctx is not None and self.lib is not None:
+            if self._queue_env is None:
+                self._queue_env = os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') != '0'
+                if not self._queue_env:
+                    self.check(self.lib.vmp_tune_set(b'small_queue', 0))
+            self.check(self.lib.vmp_queue_begin(self.ctx))
+
+    def queue_end(self):
+        if self.ctx is not None and self.lib is not None:
+            self.check(self.lib.vmp_queue_end(self.ctx))
+        self._queue_alive = []
+
+    def flush_small(self):
+        if self.ctx is not None and self.lib is not None:
+            self.check(self.lib.vmp_queue_flush(self.ctx))
+        self._queue_alive = []
+
+    def keep_until_flush(self, arrays, out):
+        """A queued operation runs LATER: its operands and its result must not go back to the
+        allocator before (a block handed out again would be written by something else first).
+        Only small arrays are ever queued; the list is dropped at every flush this side knows of."""
+        if self._op_depth > 0 and self.lib is not None:
+            self._queue_alive.append((arrays, out))
+
+    def set_tune(self, key, value):
+        if self.lib is not None:
+            self.check(self.lib.vmp_tune_set(key.encode(), int(value)))
+
+    def queue_stats(self):
+        if self.ctx is None or self.lib is None:
+            return None
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self.check(self.lib.vmp_queue_stats(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        return {'launches': a.value, 'operations': b.value}
+
     def sync_stream(self):
         """Point the context at torch's current stream before launches.  Inside a plan
         operation (``with rt.operation():``) the lookup is done once at entry, not per launch."""
@@ -238,14 +282,15 @@ class Runtime:
             if bool(flag_tensor.any().item()):
                 raise exc_type(message)
             return
-        self._deferred.append((flag_tensor.any().reshape(1), exc_type, message))
+        # (reduced when the checks are read: the flag may be the result of a queued operation)
+        self._deferred.append((flag_tensor, exc_type, message))
 
     def check_deferred(self):
         if not self._deferred:
             return
         self.host_access('check_deferred')
         items, self._deferred = self._deferred, []
-        flags = self.torch.cat([f for f, _, _ in items]).cpu().numpy()
+        flags = self.torch.cat([f.reshape(-1).any().reshape(1) for f, _, _ in items]).cpu().numpy()
         for bad, (_, exc_type, message) in zip(flags, items):
             if bad:
                 raise exc_type(message)
@@ -267,6 +312,7 @@ class _Operation:
         rt = self.rt
         if rt._op_depth == 0:
             rt.sync_stream()
+            rt.queue_begin()
         rt._op_depth += 1
         return rt
 
@@ -274,6 +320,7 @@ class _Operation:
         rt = self.rt
         rt._op_depth -= 1
         if rt._op_depth == 0:
+            rt.queue_end()
             if exc_type is None:
                 rt.check_deferred()
             else:

@@ -243,10 +243,19 @@ def _eye(shape):
 
 
 def _check_device(x, bad, exc_type, message):
-    """Raise ``exc_type(message)`` if ``bad(x)`` holds anywhere -- evaluated on the device and
-    read with the other checks of the running plan operation (device.Runtime.defer_check)."""
+    """Raise ``exc_type(message)`` if ``bad`` ('negative': x < 0, 'nonpositive': x <= 0 or NaN)
+    holds anywhere -- a count formed on the device by the library's own kernels (so that it
+    queues with the formulas around it) and read with the other checks of the running plan
+    operation (device.Runtime.defer_check)."""
     from ...device import get_runtime
-    get_runtime().defer_check(bad(_arr(x).t), exc_type, message)
+    x = _arr(x)
+    if bad == 'negative':
+        ind = fuse(lambda v: da.where_nonzero(da.maximum(-v, 0.0), 1.0), x)
+    elif bad == 'nonpositive':
+        ind = fuse(lambda v: 1.0 - da.where_nonzero(da.maximum(v, 0.0), 1.0), x)
+    else:
+        raise ValueError(bad)
+    get_runtime().defer_check(misc.sum_multiply(ind).t, exc_type, message)
 
 
 def _sum_last(x, n):
@@ -376,7 +385,7 @@ class GammaFamily(Family):
 
     def fixed_moments_and_f(self, x):
         x = _arr(x)
-        _check_device(x, lambda t: t < 0, ValueError, "Values must be positive")
+        _check_device(x, 'negative', ValueError, "Values must be positive")
         logx = fuse(lambda v: da.log(v), x)
         return [x, logx], fuse(lambda l: -l, logx)
 
@@ -853,7 +862,7 @@ class DirichletFamily(Family):
 
     def moments_and_cgf(self, phi):
         p = _arr(phi[0])
-        _check_device(p, lambda t: t <= 0, ValueError, "Natural parameters should be positive")
+        _check_device(p, 'nonpositive', ValueError, "Natural parameters should be positive")
         s = misc.sum_multiply(p, axis=-1, keepdims=True)
         u0 = fuse(lambda a, t: da.digamma(a) - da.digamma(t), p, s)
         lg = misc.sum_multiply(fuse(lambda a: da.gammaln(a), p), axis=-1)
@@ -2348,6 +2357,7 @@ class GenericPlan(GraphIteration):
         parts = [self._lower_bound_device(n) for n in nodes]
         self.__dict__.get('_contract_memo', {}).clear()       # a sweep ends here
         dev = [t.t.reshape(1) for t, _ in parts if t is not None]
+        self.rt.host_access('lower_bound_contributions')      # (flushes the queue of small operations)
         vals = iter(self.rt.torch.cat(dev).cpu().numpy() if dev else ())
         return [f if t is None else float(next(vals)) * f for t, f in parts]
 

@@ -262,6 +262,10 @@ class GraphIteration:
                 from ...utils import misc
                 memo_was = misc._CUR_MEMO[0]
                 misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
+                # the queue of small formulas (vmp_queue_*) pays in eager sweeps only: a graph node
+                # costs what a queued record costs its interpreter.  Same arithmetic either way.
+                rt.flush_small()
+                rt.set_tune('small_queue_ew', 0)
                 with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):
                     with rt.operation():
                         for n in upd:
@@ -269,9 +273,11 @@ class GraphIteration:
                         parts = [self._lower_bound_device(n) for n in bound]
                         items, rt._deferred = rt._deferred, []
                         dev = [t.t.reshape(1) for t, _ in parts if t is not None]
-                        flags = [f.to(torch.float64) for f, _, _ in items]
+                        rt.flush_small()        # the bound terms are about to be read by torch
+                        flags = [f.reshape(-1).any().reshape(1).to(torch.float64) for f, _, _ in items]
                         rec.outvec = torch.cat(dev + flags) if dev or flags else None
             finally:
+                rt.set_tune('small_queue_ew', 1)
                 rt._capturing = False
                 rt._deferred = []
                 misc._CUR_MEMO[0] = memo_was

@@ -235,6 +235,7 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
         rt.ctx, nd, c_shape, len(arrays), c_in, c_str, c_ostr, ctypes.c_uint32(mask),
         float(scale), ctypes.c_void_p(out.t.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
         ws.numel() * 8))
+    rt.keep_until_flush(arrays, out)
     return out
 
 

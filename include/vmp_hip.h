@@ -563,6 +563,22 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
                   const double *const *in, const int64_t *in_strides, int32_t nops,
                   const int32_t *ops, int32_t nconsts, const double *consts, double *out);
 
+/* Queue of SMALL operations.  Between vmp_queue_begin and vmp_queue_end, vmp_ewise and
+ * vmp_sum_multiply calls on small arrays (<= 2048 outputs, <= 32768 products) are recorded on the
+ * host and run, in order, by ONE launch of an interpreter kernel -- when any other entry point of
+ * the generic part of this library needs the stream (it flushes first), when 64 of them are
+ * collected, at vmp_queue_flush or at the outermost vmp_queue_end.  A VB sweep of the generic engine
+ * is ~90 such operations on scalars and K x K arrays (the Gamma / ARD formulas of gamma.py:142-148,
+ * gaussian.py:2344-2369, the bound terms of expfamily.py:449-468) between a dozen plate-sized
+ * kernels.  Results do not depend on the grouping.  The caller must flush before it reads an
+ * output on the host or hands it to work outside this library.  begin / end nest; a context whose
+ * stream records a HIP graph keeps the records of its flushes for the life of the context.
+ * vmp_tune_set("small_queue", 0) makes begin / end no-ops. */
+int32_t vmp_queue_begin(vmp_ctx *ctx);
+int32_t vmp_queue_flush(vmp_ctx *ctx);
+int32_t vmp_queue_end(vmp_ctx *ctx);
+int32_t vmp_queue_stats(vmp_ctx *ctx, int64_t *launches, int64_t *ops);
+
 /* Batched SPD inverse and log-determinant of `batch` contiguous n x n matrices
  * (n <= 64): linalg.chol + chol_inv + chol_logdet (utils/linalg.py:31-223), one
  * workgroup / wavefront per matrix instead of a Python loop over plates.
