@@ -82,11 +82,14 @@ class FactoredMoment(DArray):
     the product of (Cov + x x^T) terms, the Gamma message takes diag(Cov) + x^2, the bound takes
     phi : Cov + x^T phi x -- and anything else sees an ordinary device array: ``.t`` forms the
     dense array on first use (same values as the reference's)."""
-    __slots__ = ('cov', 'mean', 'nd', '_dense')
+    __slots__ = ('cov', 'mean', 'nd', '_dense', 'logdet_prec')
 
-    def __init__(self, cov, mean, nd):
+    def __init__(self, cov, mean, nd, logdet_prec=None):
         self.cov, self.mean, self.nd = cov, mean, int(nd)
         self._dense = None
+        # log|Cov^-1| with the plates of ``cov`` (no variable axes), or None when the maker does
+        # not have it (point masses, rotated moments): the bound term then takes the general route
+        self.logdet_prec = logdet_prec
 
     @property
     def t(self):
@@ -488,8 +491,8 @@ class GaussianARDFamily(Family):
         U = linalg.chol(fuse(lambda p: -2 * p, p1f))
         cov = linalg.chol_inv(U)
         u0 = linalg.chol_solve(U, p0f)
-        g = fuse(lambda s, ld: -0.5 * s + 0.5 * ld, misc.sum_multiply(u0, p0f, axis=-1),
-                 linalg.chol_logdet(U))
+        ld = linalg.chol_logdet(U)
+        g = fuse(lambda s, ld_: -0.5 * s + 0.5 * ld_, misc.sum_multiply(u0, p0f, axis=-1), ld)
         # one covariance for many plates (a scalar mask: the precision carries no plate axis where
         # the mean does): keep <x x^T> as (Cov, <x>) -- see FactoredMoment
         pl0, pl1 = u0.shape[:-1], cov.shape[:-2]
@@ -498,7 +501,7 @@ class GaussianARDFamily(Family):
         if len(pl1) == len(pl0) and shared and int(np.prod(shared)) >= _factored_min_plates():
             u0 = u0.reshape(u0.shape[:-1] + self.shape)
             covs = cov.reshape(pl1 + self.shape + self.shape)
-            return [u0, FactoredMoment(covs, u0, self.ndim)], g
+            return [u0, FactoredMoment(covs, u0, self.ndim, logdet_prec=ld.reshape(pl1))], g
         u1 = fuse(lambda a, b, c: a * b + c, _trail(u0, 1), u0.reshape(u0.shape[:-1] + (1, D)), cov)
         u0 = u0.reshape(u0.shape[:-1] + self.shape)
         u1 = u1.reshape(u1.shape[:-2] + self.shape + self.shape)
@@ -2175,6 +2178,10 @@ class GenericPlan(GraphIteration):
                 return self._finish_bound(node, terms, ignore_masked)
         phi_p = fam.phi_from_parents(up)
         L = _arr(fam.cgf_from_parents(up))
+        fast = self._shared_cov_bound(node, st, fam, phi_p, L, T, ignore_masked) \
+            if not st.observed else None
+        if fast is not None:
+            return fast
         if partial:
             # np.where(observed, f, -T g) and phi_q zeroed on the observed plates
             # (expfamily.py:431-466): the latent plates of the node count like any latent node
@@ -2215,6 +2222,62 @@ class GenericPlan(GraphIteration):
                          _arr(phi_p[i]), _arr(st.phi[i]), _arr(st.u[i]))
             L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
         return self._finish_bound(node, [(1.0, [L])], ignore_masked)
+
+    def _shared_cov_bound(self, node, st, fam, phi_p, cgf, T, ignore_masked):
+        """Bound term of a latent Gaussian node whose posterior covariance is shared over its plates
+        (a ``FactoredMoment``), from plate SUMS instead of per-plate arrays:
+
+            sum_n [ cgf_p + k/2 - log|Lambda|/2 + phi_p0 . <x_n> + phi_p1 : (Cov + <x_n><x_n>^T) ]
+
+        -- the entropy part -(g_q + phi_q . u_q) of a Gaussian is k/2 - log|Lambda|/2 whatever its mean
+        (expfamily.py:449-468 evaluates it per plate), and the quadratic part needs the plates only
+        through sum_n <x_n> and sum_n <x_n><x_n>^T, which the sweep has formed for the messages
+        anyway.  One pass over <x> (two when the second-moment sum is not remembered) instead of
+        eleven over plates x K arrays.  Declines (None) whenever a plate mask, annealing, a prior
+        that varies over the plates of <x>, or a moment without its log-determinant is involved."""
+        if T != 1.0 or getattr(fam, 'q_term', None) is None or len(node.dims) != 2:
+            return None
+        u0, xx = st.u
+        nd = len(node.dims[0])
+        if nd < 1 or not isinstance(xx, FactoredMoment) or xx.logdet_prec is None \
+                or not isinstance(st.g, DArray):
+            return None
+        mask, any_active = self._mask_factor((id(node), 'self'), lambda: self._mask_array(node))
+        if (mask is not None and ignore_masked) or not any_active:
+            return None
+        x, cov = _arr(xx.mean), _arr(xx.cov)
+        p0, p1 = _arr(phi_p[0]), _arr(phi_p[1])
+        npl = len(node.plates)
+        xpl = x.shape[:x.ndim - nd]
+        xpl = (1,) * (npl - len(xpl)) + tuple(xpl)
+        # the prior's parameters must not vary over a plate that <x> spans in full
+        for arr, nv in ((p0, nd), (p1, 2 * nd)):
+            apl = arr.shape[:arr.ndim - nv]
+            apl = (1,) * (npl - len(apl)) + tuple(apl)
+            if len(apl) != npl or any(a != 1 and b != 1 for a, b in zip(apl, xpl)):
+                return None
+        cpl = cov.shape[:cov.ndim - 2 * nd]
+        if any(c != 1 for c in cpl):
+            return None
+        k = float(np.prod(node.dims[0]))
+        # plate-constant parts: the plate sum multiplies them with the number of plates
+        qc = fuse(lambda ld, k_=k: 0.5 * k_ - 0.5 * ld, _arr(xx.logdet_prec))
+        tr = misc.sum_multiply(p1, cov, axis=tuple(range(-2 * nd, 0)))
+        terms = [(1.0, [cgf]), (1.0, [qc]), (1.0, [tr])]
+        # plate sums of <x> and <x><x>^T over the plates <x> spans (multiplier of the plates it
+        # lacks included), contracted with the prior's parameters
+        D = int(np.prod(node.dims[0]))
+        xf = x.reshape(x.shape[:x.ndim - nd] + (D,))
+        s1 = misc.sum_multiply_to_plates(xf, to_plates=(), from_plates=node.plates, ndim=1)
+        s2 = misc.sum_multiply_to_plates(_trail(xf, 1), xf.reshape(xf.shape[:-1] + (1, D)),
+                                         to_plates=(), from_plates=node.plates, ndim=2)
+        p0f = p0.reshape((-1, D)) if p0.size == D else None
+        p1f = p1.reshape((-1, D, D)) if p1.size == D * D else None
+        if p0f is None or p1f is None:
+            return None
+        pre = fuse(lambda a, b: a + b, misc.sum_multiply(p0f, s1.reshape((1, D))),
+                   misc.sum_multiply(p1f, s2.reshape((1, D, D))))
+        return self._finish_bound(node, terms, ignore_masked, presummed=pre)
 
     def _plate_sum(self, factors, to_plates, from_plates):
         """sum over the plates of prod(factors), remembered while the factor arrays live: the
@@ -2318,7 +2381,7 @@ class GenericPlan(GraphIteration):
         cache[key] = ([weakref.ref(f) for f in factors], t)
         return t
 
-    def _finish_bound(self, node, terms, ignore_masked):
+    def _finish_bound(self, node, terms, ignore_masked, presummed=None):
         """sum over the node's plates of sum_k coef_k prod(factors_k), masked, completed over the
         ranks for a sharded node, with the plate multiplier (expfamily.py:470-480)."""
         mask, any_active = self._mask_factor((id(node), 'self'), lambda: self._mask_array(node))
@@ -2338,6 +2401,9 @@ class GenericPlan(GraphIteration):
                 tot = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
             else:
                 tot = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, tot, t)
+        if presummed is not None:
+            # a part of the term that is a sum over this rank's plates already
+            tot = presummed if tot is None else fuse(lambda a_, b_: a_ + b_, tot, presummed)
         if sharded:
             tot = fuse(lambda x: x + 0.0, tot) if any_active else DArray.zeros(())
             self.rt.all_reduce_sum_(tot.t)

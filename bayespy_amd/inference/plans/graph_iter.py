@@ -174,7 +174,9 @@ class GraphIteration:
             return memo[id(obj)]
         if isinstance(obj, G.FactoredMoment):
             new = G.FactoredMoment(GraphIteration._rewrap(obj.cov, memo),
-                                   GraphIteration._rewrap(obj.mean, memo), obj.nd)
+                                   GraphIteration._rewrap(obj.mean, memo), obj.nd,
+                                   None if obj.logdet_prec is None
+                                   else GraphIteration._rewrap(obj.logdet_prec, memo))
         elif isinstance(obj, G.LazySum):
             new = DArray(obj.t)
         elif isinstance(obj, DArray):
