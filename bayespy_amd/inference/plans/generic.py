@@ -2013,7 +2013,7 @@ class GenericPlan(GraphIteration):
             deps = list(u) + [a for j in range(len(up)) if j != index for a in up[j]]
             if all(isinstance(a, DArray) for a in deps):
                 self._update_masks()
-                ckey = (tuple(id(a) for a in deps), id(self._dev_masks), r)
+                ckey = (tuple(id(a) for a in deps), self._mask_epoch, r)     # (a freed dict's id can come back)
                 hit = self.__dict__.setdefault('_msg_cache', {}).get((id(child), index))
                 if hit is not None and hit[0] == ckey:
                     return list(hit[2])

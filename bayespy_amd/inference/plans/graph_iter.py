@@ -326,7 +326,13 @@ class GraphIteration:
                     setattr(st, f, v)
             self._graph_reset_caches()
             torch.cuda.synchronize(rt.device)
-            if isinstance(e, GraphCaptureAbort):
+            # structural reasons end the attempts; "no room" / a one-off host access (an upload past a
+            # cache's cap) may be gone next time: up to three tries before the plan stays eager
+            transient = isinstance(e, GraphCaptureAbort) and ('no room' in str(e) or 'needs the host' in str(e))
+            if transient and self._g_attempts < 3:           # (counted by graph_iteration)
+                self._g_disabled = None
+                self._g_warm = 0
+            elif isinstance(e, GraphCaptureAbort):
                 self._g_disabled = str(e)
             else:
                 self._g_disabled = '%s: %s' % (type(e).__name__, str(e)[:200])

@@ -503,7 +503,11 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     out = _launch_sum_multiply(views, shape, red, keep_shape, scale)
     out = out.reshape(tuple(shape[i] for i in range(len(out_labels))))
     if sig is not None:
-        while len(memo) >= 16:
+        # bounded by entries AND by the bytes the entries keep alive (operands + results): a loop of
+        # single node.update() calls never reaches the end-of-sweep clear of the plan
+        def held(entry):
+            return sum(int(t.size) * 8 for t in [entry[0]] + list(entry[1]))
+        while len(memo) >= 16 or (memo and sum(held(e) for e in memo.values()) > _MEMO_BYTES):
             memo.pop(next(iter(memo)))
         memo[sig] = (out, ops)            # the operands stay alive: their addresses stay theirs
     return out
@@ -511,6 +515,7 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
 
 # the memo of the plan whose operation is running (plans/generic.py sets and clears it); None: off
 _CUR_MEMO = [None]
+_MEMO_BYTES = 512 << 20          # operands and results a memo may keep alive
 
 
 def plan_contraction(varying, out_labels, sizes):
