@@ -124,6 +124,10 @@ SIGNATURES = {
     'vmp_pca_xpass_tiled': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp,
                                     c_vp]),
     'vmp_tune_set': (c_i32, [ctypes.c_char_p, c_i32]),
+    'vmp_graph_begin': (c_i32, [c_vp]),
+    'vmp_graph_end': (c_i32, [c_vp, P(c_vp)]),
+    'vmp_graph_launch': (c_i32, [c_vp, c_vp]),
+    'vmp_graph_destroy': (c_i32, [c_vp, c_vp]),
     'vmp_queue_begin': (c_i32, [c_vp]),
     'vmp_queue_flush': (c_i32, [c_vp]),
     'vmp_queue_end': (c_i32, [c_vp]),

@@ -131,6 +131,70 @@ int32_t vmp_ctx_sync(vmp_ctx *ctx)
 
 int32_t vmp_ctx_num_cu(vmp_ctx *ctx) { return ctx ? ctx->num_cu : 0; }
 
+// ---- the launches of a call sequence as a HIP graph (a VB sweep: same kernels, same shapes every
+// iteration, only the contents of the arrays move) ------------------------------------------------
+struct vmp_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+int32_t vmp_graph_begin(vmp_ctx *ctx)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
+    VMP_REQUIRE(ctx, ctx->stream != nullptr, VMP_ERR_INVALID,
+                "the legacy default stream cannot record: give the context a stream of its own");
+    VMP_FLUSH_SMALL(ctx);                         // what is queued belongs in front of the recording
+    VMP_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return VMP_OK;
+}
+
+int32_t vmp_graph_end(vmp_ctx *ctx, void **graph)
+{
+    VMP_REQUIRE(ctx, ctx && graph, VMP_ERR_INVALID, "null argument");
+    *graph = nullptr;
+    const int32_t rcq = vmp_queue_flush(ctx);     // inside the recording (replayed with it)
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rcq != VMP_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rcq;
+    }
+    VMP_HIP_CHECK(ctx, e);
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        VMP_HIP_CHECK(ctx, e);
+    }
+    vmp_graph *h = new (std::nothrow) vmp_graph{g, x};
+    if (!h) {
+        (void)hipGraphExecDestroy(x);
+        (void)hipGraphDestroy(g);
+        VMP_REQUIRE(ctx, false, VMP_ERR_HIP, "out of host memory");
+    }
+    *graph = h;
+    return VMP_OK;
+}
+
+int32_t vmp_graph_launch(vmp_ctx *ctx, void *graph)
+{
+    VMP_REQUIRE(ctx, ctx && graph, VMP_ERR_INVALID, "null argument");
+    VMP_FLUSH_SMALL(ctx);
+    VMP_HIP_CHECK(ctx, hipGraphLaunch(reinterpret_cast<vmp_graph *>(graph)->exec, ctx->stream));
+    return VMP_OK;
+}
+
+int32_t vmp_graph_destroy(vmp_ctx *ctx, void *graph)
+{
+    (void)ctx;
+    if (!graph) return VMP_OK;
+    vmp_graph *h = reinterpret_cast<vmp_graph *>(graph);
+    (void)hipGraphExecDestroy(h->exec);
+    (void)hipGraphDestroy(h->graph);
+    delete h;
+    return VMP_OK;
+}
+
 const char *vmp_last_error(vmp_ctx *ctx) { return ctx ? ctx->err : g_err; }
 
 int32_t vmp_ctx_set_timing(vmp_ctx *ctx, int32_t enabled)

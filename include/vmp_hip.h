@@ -563,6 +563,19 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
                   const double *const *in, const int64_t *in_strides, int32_t nops,
                   const int32_t *ops, int32_t nconsts, const double *consts, double *out);
 
+/* A sequence of calls recorded into a HIP graph and replayed: the launches of a VB sweep are the
+ * same every iteration -- same kernels, same shapes, only the contents of the arrays move -- so a
+ * binding records one sweep (every call of this library between begin and end is recorded on the
+ * context's stream instead of run; the arrays must be allocated before, nothing may be read on
+ * the host inside) and launches the graph once per iteration afterwards.  The context needs a
+ * stream of its own (vmp_ctx_create / vmp_ctx_set_stream: not the legacy default stream).  The
+ * Python front end records through torch.cuda.graph (it also allocates inside a sweep and needs
+ * torch's graph memory pool); a binding that manages its own arrays uses these four. */
+int32_t vmp_graph_begin(vmp_ctx *ctx);
+int32_t vmp_graph_end(vmp_ctx *ctx, void **graph);
+int32_t vmp_graph_launch(vmp_ctx *ctx, void *graph);
+int32_t vmp_graph_destroy(vmp_ctx *ctx, void *graph);
+
 /* Queue of SMALL operations.  Between vmp_queue_begin and vmp_queue_end, vmp_ewise and
  * vmp_sum_multiply calls on small arrays (<= 2048 outputs, <= 32768 products) are recorded on the
  * host and run, in order, by ONE launch of an interpreter kernel -- when any other entry point of

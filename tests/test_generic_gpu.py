@@ -592,3 +592,88 @@ def test_plate_sums_over_lazy_dot_products():
         assert got.shape == ref.shape
         np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
     np.testing.assert_allclose(f.numpy(), fd, rtol=1e-13, atol=1e-13)
+
+
+def test_cabi_queue_and_graph_of_small_operations():
+    """The raw C ABI a binding would use for a sweep: small formulas / plate sums recorded by the
+    queue (vmp_queue_begin / _end) and the whole call sequence recorded into a HIP graph
+    (vmp_graph_begin / _end / _launch) on a stream of the context's own; replays with new
+    contents of the input arrays give what NumPy gives, and queued == unqueued bit for bit."""
+    import ctypes
+    import torch
+    from bayespy_amd import _lib
+    from bayespy_amd.darray import OP_IN, OP_MUL, OP_ADD, OP_CONST
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.Stream(dev)
+    ctx = ctypes.c_void_p()
+    assert lib.vmp_ctx_create(0, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx)) == 0
+    try:
+        K = 16
+        a = torch.randn(K, K, dtype=torch.float64, device=dev)
+        b = torch.randn(K, dtype=torch.float64, device=dev)
+        t1 = torch.empty(K, K, dtype=torch.float64, device=dev)      # a * b + 2
+        t2 = torch.empty(K, dtype=torch.float64, device=dev)         # sum_j t1[i, j] * b[j]
+        t3 = torch.empty((), dtype=torch.float64, device=dev)        # sum_i t2[i]
+        ws = torch.empty(1 << 20, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def sweep():
+            shape = (ctypes.c_int64 * 2)(K, K)
+            ins = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+            strides = (ctypes.c_int64 * 4)(K, 1, 0, 1)
+            ops = (ctypes.c_int32 * 5)(OP_IN | (0 << 8), OP_IN | (1 << 8), OP_MUL, OP_CONST | (0 << 8), OP_ADD)
+            consts = (ctypes.c_double * 1)(2.0)
+            assert lib.vmp_ewise(ctx, 2, shape, 2, ins, strides, 5, ops, 1, consts, vp(t1)) == 0
+            ins2 = (ctypes.c_void_p * 2)(t1.data_ptr(), b.data_ptr())
+            ostr = (ctypes.c_int64 * 2)(1, 0)
+            assert lib.vmp_sum_multiply(ctx, 2, shape, 2, ins2, strides, ostr, ctypes.c_uint32(2), 1.0,
+                                        vp(t2), vp(ws), ws.numel() * 8) == 0
+            shape1 = (ctypes.c_int64 * 1)(K)
+            ins3 = (ctypes.c_void_p * 1)(t2.data_ptr())
+            s3 = (ctypes.c_int64 * 1)(1)
+            o3 = (ctypes.c_int64 * 1)(0)
+            assert lib.vmp_sum_multiply(ctx, 1, shape1, 1, ins3, s3, o3, ctypes.c_uint32(1), 1.0,
+                                        vp(t3), vp(ws), ws.numel() * 8) == 0
+
+        def expect():
+            A, Bv = a.cpu().numpy(), b.cpu().numpy()
+            T1 = A * Bv + 2.0
+            return T1, T1 @ Bv, (T1 @ Bv).sum()
+
+        # unqueued, then queued (both kinds: the plate sums are an opt-in of the queue)
+        sweep()
+        assert lib.vmp_ctx_sync(ctx) == 0
+        ref = (t1.cpu().numpy().copy(), t2.cpu().numpy().copy(), float(t3.cpu()))
+        np.testing.assert_allclose(ref[0], expect()[0], rtol=1e-14)
+        np.testing.assert_allclose(ref[1], expect()[1], rtol=1e-12)
+        l0, n0 = ctypes.c_int64(), ctypes.c_int64()
+        assert lib.vmp_queue_begin(ctx) == 0
+        for t in (t1, t2, t3):
+            t.zero_()
+        torch.cuda.synchronize()
+        sweep()
+        assert lib.vmp_queue_end(ctx) == 0 and lib.vmp_ctx_sync(ctx) == 0
+        assert lib.vmp_queue_stats(ctx, ctypes.byref(l0), ctypes.byref(n0)) == 0
+        assert l0.value == 1 and n0.value == 1        # the formula waited for the first plate sum
+        assert np.array_equal(t1.cpu().numpy(), ref[0]) and np.array_equal(t2.cpu().numpy(), ref[1])
+        # the sweep as a graph (the queue open inside: its flush is recorded too), replayed on new data
+        g = ctypes.c_void_p()
+        assert lib.vmp_queue_begin(ctx) == 0
+        assert lib.vmp_graph_begin(ctx) == 0
+        sweep()
+        assert lib.vmp_graph_end(ctx, ctypes.byref(g)) == 0 and g.value
+        assert lib.vmp_queue_end(ctx) == 0
+        for rep in range(3):
+            with torch.cuda.stream(stream):
+                a.normal_()
+                b.normal_()
+            assert lib.vmp_graph_launch(ctx, g) == 0 and lib.vmp_ctx_sync(ctx) == 0
+            e1, e2, e3 = expect()
+            np.testing.assert_allclose(t1.cpu().numpy(), e1, rtol=1e-14)
+            np.testing.assert_allclose(t2.cpu().numpy(), e2, rtol=1e-12)
+            np.testing.assert_allclose(float(t3.cpu()), e3, rtol=1e-12)
+        assert lib.vmp_graph_destroy(ctx, g) == 0
+    finally:
+        lib.vmp_ctx_destroy(ctx)
