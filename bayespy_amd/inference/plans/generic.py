@@ -850,7 +850,10 @@ class WishartFamily(Family):
         return [x, ld], fuse(lambda l: -(self.D + 1) / 2.0 * l, ld)
 
     def message_to_parent(self, index, u, up):
-        raise NotImplementedError('Wishart parents are constants in the built path')
+        # wishart.py:142-150: to the inverse scale matrix V (a Wishart node): [-<Lambda>/2, n/2]
+        if index != 1:
+            raise NotImplementedError('the degrees of freedom of a Wishart node are numeric')
+        return [fuse(lambda l: -0.5 * l, _arr(u[0])), fuse(lambda n: 0.5 * n, _arr(up[0][0]))]
 
 
 class DirichletFamily(Family):

@@ -17,14 +17,23 @@ class Wishart(Stochastic):
         super().__init__(n, V, plates=(), dims=((), ()), name=name)
         self._plates_multiplier_arg = plates_multiplier
         n_node, V_node = self.parents
-        if not isinstance(n_node, Constant) or not isinstance(V_node, Constant):
-            raise NotImplementedError('Wishart parents must be numeric constants')
-        Vs = V_node.value.shape
-        if len(Vs) < 2 or Vs[-1] != Vs[-2]:
-            raise ValueError('V must be a (..., D, D) array')
-        D = Vs[-1]
+        if not isinstance(n_node, Constant):
+            raise NotImplementedError('the degrees of freedom of a Wishart node must be numeric '
+                                      '(the reference needs WishartPriorMoments there: wishart.py:96-115)')
+        if isinstance(V_node, Constant):
+            Vs = V_node.value.shape
+            if len(Vs) < 2 or Vs[-1] != Vs[-2]:
+                raise ValueError('V must be a (..., D, D) array')
+            D, v_plates = Vs[-1], Vs[:-2]
+        elif isinstance(V_node, Wishart):
+            # a hierarchical prior: the inverse scale matrix is itself Wishart; the message to it
+            # is [-<Lambda>/2, n/2] (wishart.py:142-150).  Runs on the generic engine.
+            D, v_plates = V_node.dims[0][0], V_node.plates
+        else:
+            raise NotImplementedError('the inverse scale matrix of a Wishart node must be numeric '
+                                      'or a Wishart node (WishartMoments, wishart.py:45-60)')
         self.dims = ((D, D), ())
         given = tuple(plates) if plates is not None else ()
-        self.plates = broadcasted_shape(given, n_node.value.shape, Vs[:-2])
+        self.plates = broadcasted_shape(given, n_node.value.shape, v_plates)
         if plates is not None and self.plates != given:
             raise ValueError('Plates of the parents do not broadcast to plates %s' % (given,))

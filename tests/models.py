@@ -1281,3 +1281,34 @@ def run_gaussian_gamma_cases(nodes_mod, vb_cls, g, **vb_kwargs):
     Q.ignore_bound_checks = True
     record('c', Q, dict(XV=XV, mu=mu, b3=b3), 2)
     return out
+
+
+def make_hierarchical_wishart_inputs(rs):
+    """Seeded inputs of run_hierarchical_wishart_case (tests/golden/hierarchical_wishart.npz)."""
+    D, P, N = 3, 4, 12
+    a = rs.normal(size=(D, D))
+    lam_true = [np.linalg.inv(0.3 * (i + 1) * (a @ a.T + D * np.eye(D))) for i in range(P)]
+    mu = rs.normal(size=(P, 1, D))
+    y = np.stack([rs.multivariate_normal(mu[i, 0], np.linalg.inv(lam_true[i]), size=N)
+                  for i in range(P)])
+    return dict(hw_V0=0.5 * np.eye(D) + 0.1 * (a @ a.T), hw_mu=mu, hw_y=y)
+
+
+def run_hierarchical_wishart_case(nodes_mod, vb_cls, g, **vb_kwargs):
+    """A Wishart node whose inverse scale matrix is a Wishart node (wishart.py:142-150: the
+    message [-<Lambda>/2, n/2] to V), precisions of P groups of Gaussian observations."""
+    N_ = nodes_mod
+    D = g['hw_V0'].shape[0]
+    P = g['hw_y'].shape[0]
+    V = N_.Wishart(D + 2.0, g['hw_V0'], name='V')
+    Lam = N_.Wishart(D + 1.0, V, plates=(P, 1), name='Lam')
+    Y = N_.Gaussian(g['hw_mu'], Lam, plates=g['hw_y'].shape[:2], name='Y')
+    Y.observe(g['hw_y'])
+    Q = vb_cls(Y, Lam, V, **vb_kwargs)
+    Q.ignore_bound_checks = True
+    Q.update(repeat=4, verbose=False)
+    out = {'hw_L': np.array(Q.L[:4]), 'hw_plates': np.array(Lam.plates)}
+    for nm, nd in dict(Lam=Lam, V=V).items():
+        out['hw_%s_u' % nm] = [np.array(v) for v in nd.get_moments()]
+        out['hw_%s_L' % nm] = np.array(Q.l[nd][:4])
+    return out

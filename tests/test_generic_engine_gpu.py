@@ -1136,3 +1136,17 @@ def test_factored_second_moments_keep_memory_flat():
     np.testing.assert_allclose(out['factored'][0], out['dense'][0], rtol=1e-12)
     assert out['factored'][1] < 0.6 * 8 * N * K * K, out['factored'][1]
     assert out['dense'][1] > 8 * N * K * K
+
+
+def test_hierarchical_wishart_matches_reference(golden_dir):
+    """Wishart(n, V) with V a Wishart node (wishart.py:142-150: the message [-<Lambda>/2, n/2] to
+    the inverse scale matrix): bound trace, moments of both nodes, per-node bound terms against the
+    live-reference golden (tests/models.py run_hierarchical_wishart_case on both sides)."""
+    import bayespy_amd.nodes as N_
+    from bayespy_amd.inference import VB
+    from models import run_hierarchical_wishart_case
+    f = np.load(os.path.join(golden_dir, 'hierarchical_wishart.npz'))
+    g = {k[3:]: f[k] for k in f.files if k.startswith('in_')}
+    _compare_shared(run_hierarchical_wishart_case(N_, VB, g), f)
+    with pytest.raises(NotImplementedError, match='degrees of freedom'):
+        N_.Wishart(N_.Gamma(1.0, 1.0), np.eye(2))
