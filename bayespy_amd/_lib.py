@@ -48,7 +48,8 @@ def raise_for_status(rc, msg=''):
 class PCALayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in (
         'DP', 'KP', 'off_S', 'len_S', 'off_Syy', 'off_tau', 'off_alpha', 'off_W',
-        'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_G', 'off_scal', 'off_L', 'total')]
+        'off_CW', 'off_Sww', 'off_CX', 'off_A', 'off_G', 'off_scal', 'off_L', 'total',
+        'off_mu', 'off_mstat')]
 
 
 class MPCALayout(ctypes.Structure):
@@ -207,6 +208,8 @@ SIGNATURES = {
     'vmp_pca_xjoin': (c_i32, [c_vp]),
     'vmp_pca_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                   c_i32, P(c_i32), c_vp]),
+    'vmp_pca_small_ops_mean': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
+                                       c_i32, P(c_i32), c_i32, c_vp]),
     'vmp_pass_times_ms': (c_i32, [c_vp, P(c_f64), P(c_f64), c_i32, P(c_i32)]),
     'vmp_pca_last_pass_ms': (c_i32, [c_vp, P(c_f64), P(c_f64)]),
 }

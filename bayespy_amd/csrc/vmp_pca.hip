@@ -64,6 +64,8 @@ inline void fill_layout(int D, int K, vmp_pca_layout *L)
     L->off_G = o;      o += DP * DP;
     L->off_scal = o;   o += 8;
     L->off_L = o;      o += 8;
+    L->off_mu = o;     o += (int64_t)D * KP;
+    L->off_mstat = o;  o += 2 * KP;
     L->total = (o + 7) / 8 * 8;
 }
 

@@ -24,7 +24,19 @@ struct small_args {
     vmp_pca_layout L;
     int D, K;
     double n_total, x_prec, a0t, b0t, a0a, b0a;
+    int has_mean;       // W has a constant non-zero prior mean mu (state[off_mu]); see op_update_w
 };
+
+// sum_d <(w_dk - mu_dk)^2> = Sww_kk - 2 sum_d mu_dk <w_dk> + sum_d mu_dk^2: what the Gamma message
+// of the ARD prior (gaussian.py:2344-2369) and the bound term of W see of a non-zero prior mean;
+// the two sums are kept in state[off_mstat] by op_update_w
+__device__ inline double ww_centred(const small_args &a, const double *st, int k)
+{
+    const vmp_pca_layout &L = a.L;
+    double v = st[L.off_Sww + k * L.KP + k];
+    if (a.has_mean) v += st[L.off_mstat + L.KP + k] - 2.0 * st[L.off_mstat + k];
+    return v;
+}
 
 // <x x^T> total statistic: n_total * Cov_X + sum_n <x><x>^T, symmetrised.
 __device__ inline double sxx_total(const double *st, const vmp_pca_layout &L, double n_total,
@@ -192,7 +204,11 @@ __device__ void op_update_w(const small_args &a, double *st, small_lds<KP, NTQ> 
 #pragma unroll 1
         for (int e = tid; e < RB * KP; e += NTQ) {
             const int r = e / KP, k = e % KP;
-            s.Sb[r * LDM + k] = (r < nr && k < K) ? Syx[(r0 + r) * KP + k] : 0.0;
+            double v = (r < nr && k < K) ? Syx[(r0 + r) * KP + k] : 0.0;
+            // a non-zero prior mean: phi0_d = <tau> Syx[d] + <alpha> * mu_d (gaussian.py:656-670)
+            if (a.has_mean && r < nr && k < K)
+                v = tau * v + st[L.off_alpha + 2 * KP + k] * st[L.off_mu + (r0 + r) * KP + k];
+            s.Sb[r * LDM + k] = v;
         }
         __syncthreads();
         // <w_d> = Cov_W phi0_d,  phi0_d = <tau> Syx[d]        (gaussian.py:694)
@@ -203,7 +219,7 @@ __device__ void op_update_w(const small_args &a, double *st, small_lds<KP, NTQ> 
             if (k < K)
 #pragma unroll 4
                 for (int j = 0; j < K; ++j) acc += s.Sb[r * LDM + j] * s.M[j * LDM + k];
-            acc *= tau;
+            if (!a.has_mean) acc *= tau;
             s.Wb[r * LDM + k] = acc;
             if (r < nr && k < K) W[(r0 + r) * KP + k] = acc;
         }
@@ -227,6 +243,21 @@ __device__ void op_update_w(const small_args &a, double *st, small_lds<KP, NTQ> 
             st[L.off_Sww + i * KP + j] = (double)D * s.M[i * LDM + j] + sw[m];
     }
     if (tid == 0) st[L.off_scal + 0] = s.logdet;
+    if (a.has_mean) {
+        // sum_d mu_dk <w_dk> and sum_d mu_dk^2 for the Gamma message and the bound term of W
+        __threadfence_block();
+        __syncthreads();
+        for (int k = tid; k < K; k += NTQ) {
+            double m1 = 0.0, m2 = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double mu = st[L.off_mu + d * KP + k];
+                m1 += mu * W[d * KP + k];
+                m2 += mu * mu;
+            }
+            st[L.off_mstat + k] = m1;
+            st[L.off_mstat + KP + k] = m2;
+        }
+    }
 }
 
 // X.update(), replicated half: Lambda_X = x_prec I + <tau> Sww ; Cov_X ; A = <tau> Cov_X W^T.
@@ -327,7 +358,7 @@ __device__ void op_update_alpha(const small_args &a, double *st)
     const int KP = (int)L.KP;
     for (int k = threadIdx.x; k < a.K; k += NTQ) {
         const double al = a.a0a + 0.5 * (double)a.D;
-        const double be = a.b0a + 0.5 * st[L.off_Sww + k * KP + k];
+        const double be = a.b0a + 0.5 * ww_centred(a, st, k);
         st[L.off_alpha + 0 * KP + k] = al;
         st[L.off_alpha + 1 * KP + k] = be;
         st[L.off_alpha + 2 * KP + k] = al / be;
@@ -367,7 +398,7 @@ __device__ void op_lower_bound(const small_args &a, double *st, double *red)
         } else {
             trx += sxx_total(st, L, a.n_total, k, k);
             sla += lx;
-            saw += x * st[L.off_Sww + k * KP + k];
+            saw += x * ww_centred(a, st, k);
             lal += g;
         }
     }
@@ -864,7 +895,7 @@ void launch_sequence(vmp_ctx *ctx, const small_args &a, double *state)
 
 int32_t launch_small(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
                      double a0t, double b0t, double a0a, double b0a, int32_t nops,
-                     const int32_t *ops, double *state)
+                     const int32_t *ops, double *state, int32_t has_mean = 0)
 {
     VMP_REQUIRE(ctx, ctx && state && ops, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, nops >= 1 && nops <= VMP_PCA_MAX_OPS, VMP_ERR_INVALID,
@@ -877,6 +908,7 @@ int32_t launch_small(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double
     a.n_total = (double)n_total;
     a.x_prec = x_prec;
     a.a0t = a0t; a.b0t = b0t; a.a0a = a0a; a.b0a = b0a;
+    a.has_mean = has_mean ? 1 : 0;
     for (int i = 0; i < nops; ++i) {
         const int op = ops[i];
         VMP_REQUIRE(ctx, op >= VMP_PCA_OP_W && op <= VMP_PCA_OP_ELBO, VMP_ERR_INVALID,
@@ -894,7 +926,8 @@ int32_t launch_small(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double
     // forms when K <= 32 and D <= 128; VMP_PCA_FAST_SMALL=0 disables them), anything else
     // falls back to one launch per operation
     static const int fast_enabled = getenv("VMP_PCA_FAST_SMALL") ? atoi(getenv("VMP_PCA_FAST_SMALL")) : 1;
-    const bool fast = fast_enabled && a.L.KP <= 32 && D <= FAST_D;
+    // (the LDS-resident forms are built for the zero prior mean of the demo model)
+    const bool fast = fast_enabled && a.L.KP <= 32 && D <= FAST_D && !a.has_mean;
     int i = 0;
     while (i < nops) {
         const int o0 = ops[i], o1 = i + 1 < nops ? ops[i + 1] : 0, o2 = i + 2 < nops ? ops[i + 2] : 0;
@@ -943,6 +976,14 @@ int32_t vmp_pca_small_ops(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, d
 {
     return launch_small(ctx, D, K, n_total, x_prec, a0_tau, b0_tau, a0_alpha, b0_alpha, nops, ops,
                         state);
+}
+
+int32_t vmp_pca_small_ops_mean(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
+                               double a0_tau, double b0_tau, double a0_alpha, double b0_alpha,
+                               int32_t nops, const int32_t *ops, int32_t has_mean, double *state)
+{
+    return launch_small(ctx, D, K, n_total, x_prec, a0_tau, b0_tau, a0_alpha, b0_alpha, nops, ops,
+                        state, has_mean);
 }
 
 int32_t vmp_pca_update_w(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double *state)

@@ -85,10 +85,16 @@ class HIPKernels:
         self.rt.check(self.lib.vmp_pca_stats_from_x(self.ctx, ptr(Y), ldy, N, D, K, ptr(X), ldx,
                                                     ptr(state), ptr(ws)))
 
-    def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state):
+    def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state, has_mean=False):
         """Replicated-node operations (OP_* codes) in order, fused into as few
-        single-workgroup launches as the library knows sequences for."""
+        single-workgroup launches as the library knows sequences for.  ``has_mean``: W has a
+        constant non-zero prior mean, kept in state[off_mu] (vmp_pca_small_ops_mean)."""
         arr = (ctypes.c_int32 * len(ops))(*ops)
+        if has_mean:
+            self.rt.check(self.lib.vmp_pca_small_ops_mean(self.ctx, D, K, n_total, x_prec, a0t,
+                                                          b0t, a0a, b0a, len(ops), arr, 1,
+                                                          ptr(state)))
+            return
         self.rt.check(self.lib.vmp_pca_small_ops(self.ctx, D, K, n_total, x_prec, a0t, b0t, a0a,
                                                  b0a, len(ops), arr, ptr(state)))
 
@@ -171,6 +177,16 @@ def _const_zero(node):
     return isinstance(node, Constant) and not np.any(node.value)
 
 
+def _const_mean(node, shape):
+    """A constant that broadcasts to ``shape`` (the prior mean of W: plates (D, 1) + (K,))."""
+    if not isinstance(node, Constant):
+        return False
+    try:
+        return np.broadcast_shapes(node.value.shape, shape) == tuple(shape)
+    except ValueError:
+        return False
+
+
 def _gamma_with_const_parents(node):
     return (isinstance(node, Gamma) and _const_scalar(node.parents[0])
             and _const_scalar(node.parents[1]))
@@ -185,7 +201,7 @@ class PCAPlan:
 
     @staticmethod
     def describe():
-        return ("GaussianARD(SumMultiply('i,i', W, X), Gamma) with W=GaussianARD(0, Gamma, "
+        return ("GaussianARD(SumMultiply('i,i', W, X), Gamma) with W=GaussianARD(const, Gamma, "
                 "shape=(K,), plates=(D,1)), X=GaussianARD(0, const, shape=(K,), plates=(1,N)), "
                 "fully observed")
 
@@ -214,7 +230,7 @@ class PCAPlan:
 
     @staticmethod
     def match(nodes, why=None):
-        roles = PCAPlan.match_graph(nodes, why)
+        roles = PCAPlan.match_graph(nodes, why, allow_mean=True)
         if roles is None:
             return None
         bad = PCAPlan.unsupported_state(roles)
@@ -225,8 +241,10 @@ class PCAPlan:
         return roles
 
     @staticmethod
-    def match_graph(nodes, why=None):
+    def match_graph(nodes, why=None, allow_mean=False):
         """The graph pattern alone (shared with the missing-data block, plans/masked_pca.py).
+        ``allow_mean``: a constant NON-ZERO prior mean of W is part of the pattern (this block:
+        yes, the missing-data block: no).
         ``why``: a list that receives, for every node that looks like the observed node of this
         block, the first condition it fails (compile_model reports them when a model that
         resembles a fused block ends up on the generic engine)."""
@@ -272,7 +290,12 @@ class PCAPlan:
                 continue
             K = W.shape[0]
             alpha = W.parents[1]
-            if not _const_zero(W.parents[0]):
+            if allow_mean:
+                if not _const_mean(W.parents[0], (D, 1, K)):
+                    no(Y, 'the prior mean of %s is not a constant of shape (D, 1, K)'
+                          % (W.name or 'W'))
+                    continue
+            elif not _const_zero(W.parents[0]):
                 no(Y, 'the prior mean of %s is not the constant 0' % (W.name or 'W'))
                 continue
             if not _gamma_with_const_parents(alpha) or _lead(alpha.plates, 1) != (K,):
@@ -314,6 +337,10 @@ class PCAPlan:
         self.a0a = self.alpha.parents[0].scalar()
         self.b0a = self.alpha.parents[1].scalar()
         self.x_prec = self.X.parents[1].scalar()
+        # constant prior mean of W (gaussian.py:805-830: phi0 = alpha * mu): None when it is 0
+        mu = self.W.parents[0].value
+        self.mu0 = (np.array(np.broadcast_to(mu, (self.D, 1, self.K)), dtype=np.float64)
+                    .reshape(self.D, self.K) if np.any(mu) else None)
         self._rt = runtime
         self._kernels = kernels
         self._ready = False
@@ -448,14 +475,17 @@ class PCAPlan:
             self.Xd[:K, :N].copy_(torch.from_numpy(np.array(x0.T, dtype=np.float64, order='C')))
         self._x_rows_modified()
 
-    def _load_w_value(self, w0):
-        """<w_d> <- the rows of a (D, K) host array, Sww = W^T W (delta moments: no covariance)."""
+    def _load_w_value(self, w0, cov=None):
+        """<w_d> <- the rows of a (D, K) host array, Sww = W^T W (+ D cov; delta moments without
+        one); with a prior mean mu also sum_d mu_dk <w_dk> and sum_d mu_dk^2 (state[off_mstat]:
+        the sums the alpha update and the bound centre sum_d <w_dk^2> with)."""
         L = self.layout
         D, K, KP = self.D, self.K, int(L.KP)
-        wp = np.zeros((D, KP))
-        wp[:, :K] = w0
-        self.state[L.off_W:L.off_W + D * KP].copy_(self.rt.torch.from_numpy(wp.reshape(-1)))
-        self._set_block(L.off_Sww, w0.T @ w0)
+        self._put_block(L.off_W, np.asarray(w0, dtype=np.float64), KP)
+        self._set_block(L.off_Sww, w0.T @ w0 + (0.0 if cov is None else D * cov))
+        if self.mu0 is not None:
+            self._put_block(L.off_mstat, np.stack([np.sum(self.mu0 * w0, axis=0),
+                                                   np.sum(self.mu0 ** 2, axis=0)]), KP)
 
     def _reinitialise(self, node):
         """initialize_from_value on X or W AFTER updates: that node becomes the point mass of the
@@ -554,13 +584,19 @@ class PCAPlan:
                     self.Xd.mul_(self.x_prec ** -0.5)
             k.stats_from_x(self.Yd, self.ldy, N, D, K, self.Xd, self.ldx, self.state, self.ws)
             self._reduce(self.state[L.off_S:L.off_S + L.len_S])
-        # ---- W: prior (mean 0, Cov diag(1/<alpha>)) or a given value ---------------------
+        # ---- W: prior (mean mu, Cov diag(1/<alpha>)) or a given value --------------------
         KP = int(L.KP)
         init = self.W._init
+        mu0 = self.mu0
+        if mu0 is not None:
+            self._put_block(L.off_mu, mu0, KP)
         if init is None:
             cw = np.eye(K) * (self.b0a / self.a0a)
             self._set_block(L.off_CW, cw)
-            self._set_block(L.off_Sww, D * cw)
+            if mu0 is None:
+                self._set_block(L.off_Sww, D * cw)
+            else:
+                self._load_w_value(mu0, cov=cw)
         else:
             if init[0] == 'value':
                 w0 = init[1]
@@ -570,6 +606,8 @@ class PCAPlan:
                                      self.W.plates + (K,)).reshape(D, K)
             else:
                 w0 = np.random.normal(size=(D, K)) * np.sqrt(self.b0a / self.a0a)
+                if mu0 is not None:
+                    w0 = w0 + mu0
             self._load_w_value(w0)
         self._ready = True
         self._version += 1
@@ -773,8 +811,13 @@ class PCAPlan:
         ops, self._pending = self._pending, []
         self.rt.sync_stream()
         for i in range(0, len(ops), 8):
-            self.kernels.small_ops(self.D, self.K, self.n_total, self.x_prec, self.a0t, self.b0t,
-                                   self.a0a, self.b0a, ops[i:i + 8], self.state)
+            if self.mu0 is None:
+                self.kernels.small_ops(self.D, self.K, self.n_total, self.x_prec, self.a0t,
+                                       self.b0t, self.a0a, self.b0a, ops[i:i + 8], self.state)
+            else:
+                self.kernels.small_ops(self.D, self.K, self.n_total, self.x_prec, self.a0t,
+                                       self.b0t, self.a0a, self.b0a, ops[i:i + 8], self.state,
+                                       has_mean=True)
 
     def finish(self):
         """Order the caller's stream after the outstanding latent pass (Gram form runs it on the
@@ -965,12 +1008,20 @@ class PCAPlan:
         L = self.layout
         K, KP, DP = self.K, int(L.KP), int(L.DP)
         if node is self.W:
+            self._no_rotation_with_mean()
             return dict(XX=self._block(L.off_Sww, K, K, KP), nplates=self.D)
         if node is self.X:
             sxx = self._block(L.off_S + DP * KP, K, K, KP)
             cx = self._block(L.off_CX, K, K, KP)
             return dict(XX=self.n_total * cx + 0.5 * (sxx + sxx.T), nplates=self.n_total)
         raise NotImplementedError('rotation of %s' % node.name)
+
+    def _no_rotation_with_mean(self):
+        """The rotation cost of transformations.py is built for a zero prior mean (its mu terms,
+        transformations.py:476-640, are not): decline instead of optimising the wrong bound."""
+        if self.mu0 is not None:
+            raise NotImplementedError('rotation of %s: the fused PCA block rotates a node with '
+                                      'prior mean 0 only' % (self.W.name or 'W'))
 
     def _put_block(self, off, mat, ld):
         """Upload a small host matrix into a row-major state block of leading dimension ld."""
@@ -990,6 +1041,7 @@ class PCAPlan:
         D, K, KP, DP = self.D, self.K, int(L.KP), int(L.DP)
         sc = self.state[L.off_scal:L.off_scal + 2].cpu().numpy()
         if node is self.W:
+            self._no_rotation_with_mean()
             w = self._block(L.off_W, D, K, KP)
             cw = self._block(L.off_CW, K, K, KP)
             sww = self._block(L.off_Sww, K, K, KP)

@@ -103,6 +103,9 @@ typedef struct vmp_pca_layout {
     int64_t off_scal;   /* 8 : [0] log|Lambda_W|  [1] log|Lambda_X|  [2] residual  [3] status  */
     int64_t off_L;      /* 8 : L_Y, L_X, L_W, L_tau, L_alpha, L_total                          */
     int64_t total;      /* doubles in the state block                                          */
+    int64_t off_mu;     /* D x KP   constant prior mean of W (zero unless the caller writes it;  */
+                        /*          read by vmp_pca_small_ops_mean with has_mean = 1)           */
+    int64_t off_mstat;  /* 2*KP : sum_d mu_dk <w_dk> | sum_d mu_dk^2 (written by the W update)   */
 } vmp_pca_layout;
 
 int32_t vmp_pca_get_layout(int32_t D, int32_t K, vmp_pca_layout *out);
@@ -143,6 +146,15 @@ enum vmp_pca_op {
 int32_t vmp_pca_small_ops(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
                           double a0_tau, double b0_tau, double a0_alpha, double b0_alpha,
                           int32_t nops, const int32_t *ops, double *state);
+
+/* The same with a constant NON-ZERO prior mean of W (GaussianARD(mu, alpha, ...): gaussian.py:649-670
+ * phi0_d = <alpha> * mu_d + message; the Gamma message to alpha and the bound term of W see
+ * <(w - mu)^2>, gaussian.py:2344-2369).  mu lies in state[off_mu] (D x KP, written by the caller
+ * after vmp_pca_init_state); has_mean = 0 is vmp_pca_small_ops.  The operations then run as the
+ * general single-workgroup kernel (the LDS-resident fused forms are built for mu = 0). */
+int32_t vmp_pca_small_ops_mean(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double x_prec,
+                               double a0_tau, double b0_tau, double a0_alpha, double b0_alpha,
+                               int32_t nops, const int32_t *ops, int32_t has_mean, double *state);
 
 /* W.update(): GaussianARDDistribution.compute_phi_from_parents + messages E3/E4
  * + compute_moments_and_cgf (gaussian.py:649-706, dot.py:581).  Uses S (already

@@ -85,6 +85,55 @@ def pca_case(name, N, D, K, n_iter, seed):
     print(name, 'L =', Ls)
 
 
+def pca_mean_case(name):
+    """demos/pca.py's model with a constant NON-ZERO prior mean of W (GaussianARD(mu, alpha):
+    gaussian.py:805-880): mu an array of shape (D, 1, K) (m3), of shape (K,) with W initialised from
+    a value (mk), a scalar with the default prior initialisation of W (ms); mk and ms in the update
+    order X, W, tau, alpha, so that the initial state of W enters the trace."""
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply
+    from bayespy.inference import VB
+    out = {}
+    for tag, N, D, K, seed in (('m3', 300, 7, 3, 31), ('mk', 257, 12, 4, 32), ('ms', 130, 5, 2, 33)):
+        rs = np.random.RandomState(seed)
+        if tag == 'm3':
+            mu = rs.normal(0, 1, (D, 1, K))
+        elif tag == 'mk':
+            mu = rs.normal(0, 2, (K,))
+        else:
+            mu = np.array(0.75)
+        w = np.broadcast_to(mu, (D, 1, K)).reshape(D, K) + 0.5 * rs.normal(0, 1, (D, K))
+        x = rs.normal(0, 1, (N, K))
+        y = w @ x.T + 0.1 * rs.normal(size=(D, N))
+        x0 = rs.normal(0, 1, (N, K))
+        w0 = rs.normal(0, 1, (D, K))
+        alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+        W = GaussianARD(mu, alpha, shape=(K,), plates=(D, 1), name='W')
+        X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+        F = SumMultiply('i,i', W, X, name='F')
+        tau = Gamma(1e-2, 1e-2, name='tau')
+        Y = GaussianARD(F, tau, name='Y')
+        X.initialize_from_value(x0[None, :, :])
+        if tag == 'mk':
+            W.initialize_from_value(w0[:, None, :])
+        Y.observe(y)
+        order = (W, X, tau, alpha) if tag == 'm3' else (X, W, tau, alpha)
+        Q = VB(Y, F, W, X, tau, alpha)
+        Q.ignore_bound_checks = True
+        Ls, terms = [], {k: [] for k in ('Y', 'X', 'W', 'tau', 'alpha')}
+        for _ in range(5):
+            Q.update(*order, repeat=1, verbose=False)
+            Ls.append(Q.L[Q.iter - 1])
+            for k in terms:
+                terms[k].append(Q.l[Q[k]][Q.iter - 1])
+        out.update({tag + '_y': y, tag + '_x0': x0, tag + '_w0': w0, tag + '_mu': mu,
+                    tag + '_L': np.array(Ls), tag + '_W_u0': W.u[0], tag + '_W_u1': W.u[1],
+                    tag + '_X_u0': X.u[0], tag + '_tau_u0': tau.u[0], tag + '_alpha_u0': alpha.u[0],
+                    tag + '_alpha_phi0': alpha.phi[0]})
+        out.update({tag + '_L_' + k: np.array(v) for k, v in terms.items()})
+        print(name, tag, 'L =', Ls)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+
+
 def pca_seeded_case(name, N=100000, D=128, K=32, n_iter=3, seed=2718):
     """The headline (D, K) at the largest N the reference runs comfortably here (35 s per
     iteration).  Stores the SEED and the reference's outputs only; the
@@ -1359,6 +1408,7 @@ def main():
     pca_case('pca_n2048_d128_k32', N=2048, D=128, K=32, n_iter=4, seed=9)
     pca_case('pca_n4000_d64_k16', N=4000, D=64, K=16, n_iter=4, seed=10)
     pca_seeded_case('pca_seeded_n100000_d128_k32')
+    pca_mean_case('pca_prior_mean')
     gmm_case('gmm_n400_d3_k4', N=400, D=3, K=4, n_iter=5, seed=11)
     gmm_case('gmm_n3000_d8_k16', N=3000, D=8, K=16, n_iter=4, seed=12)
     utils_cases('utils_known_answers')

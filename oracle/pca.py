@@ -90,10 +90,14 @@ def init_stats(y, x0, chunk=1 << 16):
 class PCAOracle:
     """Chunked float64 VB for fully observed PCA.  See module docstring."""
 
-    def __init__(self, y, x0, a0=1e-2, b0=1e-2, chunk=1 << 16, keep_x=True):
+    def __init__(self, y, x0, a0=1e-2, b0=1e-2, chunk=1 << 16, keep_x=True, mu=None):
+        """``mu``: a constant prior mean of W, broadcastable to (D, K) (GaussianARD(mu, alpha):
+        phi0 = <alpha> mu, gaussian.py:805-830); None = 0."""
         self.y = np.ascontiguousarray(y, dtype=np.float64)
         self.D, self.N = self.y.shape
         self.K = x0.shape[1]
+        self.mu = (None if mu is None else
+                   np.array(np.broadcast_to(mu, (self.D, self.K)), dtype=np.float64))
         self.a0 = float(a0)
         self.b0 = float(b0)
         self.chunk = int(chunk)
@@ -119,8 +123,18 @@ class PCAOracle:
         alpha, _ = gamma_moments(self.alpha_a, self.alpha_b)
         Lam = np.diag(alpha) + tau * self.Sxx
         self.CW, self.logdet_LamW = spd_inv_logdet(Lam)
-        self.W = tau * self.Syx @ self.CW                      # (D,K)
+        rhs = tau * self.Syx
+        if self.mu is not None:
+            rhs = rhs + alpha * self.mu                        # prior term <alpha_k> mu_dk
+        self.W = rhs @ self.CW                                 # (D,K)
         self.Sww = self.D * self.CW + self.W.T @ self.W
+
+    def _ww(self):
+        """sum_d <(w_dk - mu_dk)^2> (the message to alpha, gaussian.py:862-880)."""
+        ww = np.diag(self.Sww).copy()
+        if self.mu is not None:
+            ww += np.sum(self.mu * self.mu - 2.0 * self.mu * self.W, axis=0)
+        return ww
 
     def update_X(self):
         """gaussian.py:649-706 with the messages of dot.py:581 (E5/E6): the
@@ -156,7 +170,7 @@ class PCAOracle:
 
     def update_alpha(self):
         self.alpha_a = np.full(self.K, self.a0 + 0.5 * self.D)
-        self.alpha_b = self.b0 + 0.5 * np.diag(self.Sww)
+        self.alpha_b = self.b0 + 0.5 * self._ww()
 
     # -- lower bound ---------------------------------------------------------
 
@@ -169,7 +183,7 @@ class PCAOracle:
                - 0.5 * tau * self._residual())
         L_X = -0.5 * np.trace(self.Sxx) + N * (-0.5 * self.logdet_LamX + 0.5 * K)
         L_W = (0.5 * D * np.sum(logalpha)
-               - 0.5 * np.sum(alpha * np.diag(self.Sww))
+               - 0.5 * np.sum(alpha * self._ww())
                + D * (-0.5 * self.logdet_LamW + 0.5 * K))
         L_tau = gamma_elbo(self.a0, self.b0, self.tau_a, self.tau_b)
         L_alpha = gamma_elbo(self.a0, self.b0, self.alpha_a, self.alpha_b)

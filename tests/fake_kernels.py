@@ -52,8 +52,19 @@ class CPURuntimeKernels:
             G=s[L.off_G:L.off_G + DP * DP].reshape(DP, DP),
             scal=s[L.off_scal:L.off_scal + 8],
             Lt=s[L.off_L:L.off_L + 8],
+            mu=s[L.off_mu:L.off_mu + D * KP].reshape(D, KP),
+            mstat=s[L.off_mstat:L.off_mstat + 2 * KP].reshape(2, KP),
         )
         return v
+
+    has_mean = False    # set by small_ops: W has a constant non-zero prior mean (state[off_mu])
+
+    def _ww(self, v, K):
+        """sum_d <(w_dk - mu_dk)^2>: the diagonal of Sww, centred with the sums update_w keeps."""
+        ww = np.diag(v['Sww'][:K, :K]).copy()
+        if self.has_mean:
+            ww += v['mstat'][1, :K] - 2.0 * v['mstat'][0, :K]
+        return ww
 
     # -- kernels --------------------------------------------------------------------
     def init_state(self, D, K, a0t, b0t, a0a, b0a, state):
@@ -86,11 +97,17 @@ class CPURuntimeKernels:
         tau = v['tau'][2]
         Lam = np.diag(v['alpha'][2, :K]) + tau * self._sxx(v, K, n_total)
         C, logdet = spd_inv_logdet(Lam)
-        W = tau * v['S'][:D, :K] @ C
+        rhs = tau * v['S'][:D, :K]
+        if self.has_mean:
+            rhs = rhs + v['alpha'][2, :K] * v['mu'][:, :K]
+        W = rhs @ C
         v['CW'][:K, :K] = C
         v['W'][:, :K] = W
         v['Sww'][:K, :K] = D * C + W.T @ W
         v['scal'][0] = logdet
+        if self.has_mean:
+            v['mstat'][0, :K] = np.sum(v['mu'][:, :K] * W, axis=0)
+            v['mstat'][1, :K] = np.sum(v['mu'][:, :K] ** 2, axis=0)
 
     def prepare_x(self, D, K, x_prec, state):
         self.calls.append('prepare_x')
@@ -176,8 +193,9 @@ class CPURuntimeKernels:
             self.xpass(torch.from_numpy(np.ascontiguousarray(y)), N, N, D, K, X, ldx, state, ws)
         self.calls.pop()
 
-    def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state):
-        """vmp_pca_small_ops: the operations in order (launch fusion is not modelled)."""
+    def small_ops(self, D, K, n_total, x_prec, a0t, b0t, a0a, b0a, ops, state, has_mean=False):
+        """vmp_pca_small_ops[_mean]: the operations in order (launch fusion is not modelled)."""
+        self.has_mean = bool(has_mean)
         for op in ops:
             if op == 1:
                 self.update_w(D, K, n_total, state)
@@ -207,7 +225,7 @@ class CPURuntimeKernels:
         self.calls.append('update_alpha')
         v = self._v(state, D, K)
         a = a0 + 0.5 * D
-        b = b0 + 0.5 * np.diag(v['Sww'][:K, :K])
+        b = b0 + 0.5 * self._ww(v, K)
         v['alpha'][0, :K] = a
         v['alpha'][1, :K] = b
         v['alpha'][2, :K] = a / b
@@ -222,7 +240,7 @@ class CPURuntimeKernels:
         LX = (-0.5 * x_prec * np.trace(Sxx)
               + n_total * (0.5 * K * np.log(x_prec) - 0.5 * v['scal'][1] + 0.5 * K))
         LW = (0.5 * D * np.sum(v['alpha'][3, :K])
-              - 0.5 * np.sum(v['alpha'][2, :K] * np.diag(v['Sww'][:K, :K]))
+              - 0.5 * np.sum(v['alpha'][2, :K] * self._ww(v, K))
               + D * (-0.5 * v['scal'][0] + 0.5 * K))
         Lt = gamma_elbo(a0t, b0t, v['tau'][0], v['tau'][1])
         La = gamma_elbo(a0a, b0a, v['alpha'][0, :K], v['alpha'][1, :K])

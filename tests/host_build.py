@@ -32,10 +32,12 @@ def lssmm_host():
     so = os.path.join(d, 'liblssmm_host.so')
     if not os.path.exists(so):
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, 'sf.h'), 'w') as f:
+        # per-process names + atomic renames: several pytest workers may build at once
+        sfh = os.path.join(d, 'sf.%d.h' % os.getpid())
+        with open(sfh, 'w') as f:
             f.write(sf)
         tmp = so + '.%d.tmp' % os.getpid()
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off', '-pthread',
-                               '-include', os.path.join(d, 'sf.h'), srcs[0], '-o', tmp])
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off',
+                               '-pthread', '-include', sfh, srcs[0], '-o', tmp])
         os.replace(tmp, so)
     return ctypes.CDLL(so)

@@ -10,6 +10,21 @@ from oracle.pca import PCAOracle, make_pca_data
 PCA_CASES = ['pca_n500_d6_k3', 'pca_n777_d20_k5', 'pca_n2048_d128_k32', 'pca_n4000_d64_k16']
 
 
+def test_pca_oracle_with_prior_mean_matches_reference(golden_dir):
+    """A constant non-zero prior mean of W (oracle/make_golden.py:pca_mean_case, case m3)."""
+    g = np.load(os.path.join(golden_dir, 'pca_prior_mean.npz'))
+    D = g['m3_y'].shape[0]
+    o = PCAOracle(g['m3_y'], g['m3_x0'], mu=g['m3_mu'].reshape(D, -1), chunk=97)
+    o.iterate(len(g['m3_L']))
+    np.testing.assert_allclose(np.array(o.L), g['m3_L'], rtol=1e-11)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose(np.array([t[k] for t in o.L_terms]), g['m3_L_' + k], rtol=1e-9,
+                                   atol=1e-7)
+    m = o.moments()
+    np.testing.assert_allclose(m['W'], g['m3_W_u0'][:, 0, :], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m['alpha'][0], g['m3_alpha_u0'], rtol=1e-10)
+
+
 @pytest.mark.parametrize('name', PCA_CASES)
 @pytest.mark.parametrize('chunk', [257, 1 << 16])
 def test_pca_oracle_matches_reference(golden_dir, name, chunk):

@@ -59,6 +59,47 @@ def test_gpu_matches_reference_golden(golden_dir, name, stats):
     np.testing.assert_allclose(Q['alpha'].u[1], g['alpha_u1'], rtol=MOM_RTOL)
 
 
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+@pytest.mark.parametrize('tag', ['m3', 'mk', 'ms'])
+def test_constant_prior_mean_of_w_matches_reference(golden_dir, tag, stats):
+    """W = GaussianARD(mu, alpha) with a constant mu != 0 on the fused block
+    (vmp_pca_small_ops_mean): live-reference traces of oracle/make_golden.py:pca_mean_case."""
+    from test_pca_plan_host import build_pca_with_mean, check_pca_with_mean
+    from bayespy_amd.inference.plans.pca import PCAPlan
+    g = np.load(os.path.join(golden_dir, 'pca_prior_mean.npz'))
+    Q, order = build_pca_with_mean(g, tag)
+    assert isinstance(Q.plans[0], PCAPlan)
+    Q.plans[0].stats = stats
+    check_pca_with_mean(Q, order, g, tag)
+
+
+@pytest.mark.parametrize('N,D,K', [(1, 1, 1), (33, 17, 3), (5000, 128, 32), (3001, 129, 33),
+                                   (2000, 256, 64)])
+def test_constant_prior_mean_vs_oracle(N, D, K):
+    """The same at the sizes of the block's kernels (the LDS-resident forms decline a mean, the
+    general single-workgroup kernel carries it), against oracle/pca.py."""
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.inference import VB
+    from oracle.pca import PCAOracle, make_pca_data
+    y, x0 = make_pca_data(N, D, K, seed=N + D + K)
+    mu = np.random.RandomState(N).normal(size=(D, 1, K))
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = nodes.GaussianARD(mu, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+    F = nodes.SumMultiply('i,i', W, X, name='F')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None])
+    Y.observe(y)
+    Q = VB(Y, F, W, X, tau, alpha)
+    Q.update(repeat=3, verbose=False)
+    o = PCAOracle(y, x0, mu=mu.reshape(D, K))
+    o.iterate(3)
+    np.testing.assert_allclose(Q.L[:3], o.L, rtol=ELBO_RTOL)
+    np.testing.assert_allclose(Q['W'].u[0][:, 0], o.W, rtol=MOM_RTOL, atol=1e-10)
+    np.testing.assert_allclose(Q['alpha'].u[0], o.moments()['alpha'][0], rtol=MOM_RTOL)
+
+
 @pytest.mark.parametrize('N,D,K', [
     (1, 1, 1), (2, 3, 1), (31, 5, 2), (32, 16, 16), (33, 17, 3), (63, 33, 17),
     (1000, 64, 16), (4097, 100, 10), (5000, 128, 32), (3001, 129, 33), (2000, 256, 64),

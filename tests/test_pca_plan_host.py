@@ -450,17 +450,23 @@ def test_near_misses_of_the_fused_blocks_are_reported():
             ns.append(Z)
         return ns
 
-    with pytest.warns(UserWarning, match='prior mean of W is not the constant 0'):
-        Q = VB(*build(mu_w=1.0))
+    def hyper_mean():
+        ns = build(mu_w=nodes.GaussianARD(0, 1, shape=(K,), name='m'))
+        return ns + [ns[1].parents[0]]
+
+    with pytest.warns(UserWarning, match='prior mean of W is not a constant'):
+        Q = VB(*hyper_mean())
     assert isinstance(Q.plans[0], GenericPlan)
     with pytest.warns(UserWarning, match='has other children as well'):
         Q = VB(*build(extra_child=True))
     assert isinstance(Q.plans[0], GenericPlan)
     with warnings.catch_warnings():
         warnings.simplefilter('error')
-        Q = VB(*build(mu_w=1.0), engine='generic')          # asked for: no warning
+        Q = VB(*hyper_mean(), engine='generic')              # asked for: no warning
         assert isinstance(Q.plans[0], GenericPlan)
         Q = VB(*build())                                     # the fused block: no warning
+        assert not isinstance(Q.plans[0], GenericPlan)
+        Q = VB(*build(mu_w=1.0))                             # a constant prior mean as well
         assert not isinstance(Q.plans[0], GenericPlan)
 
 
@@ -491,3 +497,72 @@ def test_tile_major_x_is_invisible_behind_the_row_major_view(golden_dir):
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
 
+
+
+def build_pca_with_mean(g, tag):
+    """The models of oracle/make_golden.py:pca_mean_case."""
+    y, x0, mu = g[tag + '_y'], g[tag + '_x0'], g[tag + '_mu']
+    D, N = y.shape
+    K = x0.shape[1]
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = nodes.GaussianARD(mu, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X')
+    F = nodes.SumMultiply('i,i', W, X, name='F')
+    tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None, :, :])
+    if tag == 'mk':
+        W.initialize_from_value(g[tag + '_w0'][:, None, :])
+    Y.observe(y)
+    Q = VB(Y, F, W, X, tau, alpha)
+    Q.ignore_bound_checks = True
+    order = ('W', 'X', 'tau', 'alpha') if tag == 'm3' else ('X', 'W', 'tau', 'alpha')
+    return Q, [Q[k] for k in order]
+
+
+def check_pca_with_mean(Q, order, g, tag):
+    n = len(g[tag + '_L'])
+    Q.update(*order, repeat=n, verbose=False)
+    np.testing.assert_allclose(Q.L[:n], g[tag + '_L'], rtol=1e-10)
+    for k in ('Y', 'X', 'W', 'tau', 'alpha'):
+        np.testing.assert_allclose(Q.l[Q[k]][:n], g[tag + '_L_' + k], rtol=1e-8, atol=1e-7,
+                                   err_msg=k)
+    np.testing.assert_allclose(Q['W'].u[0], g[tag + '_W_u0'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Q['W'].u[1], g[tag + '_W_u1'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Q['X'].u[0], g[tag + '_X_u0'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Q['tau'].u[0], g[tag + '_tau_u0'], rtol=1e-10)
+    np.testing.assert_allclose(Q['alpha'].u[0], g[tag + '_alpha_u0'], rtol=1e-9)
+    np.testing.assert_allclose(Q['alpha'].phi[0], g[tag + '_alpha_phi0'], rtol=1e-9)
+
+
+@pytest.mark.parametrize('stats', ['gram', 'stream'])
+@pytest.mark.parametrize('tag', ['m3', 'mk', 'ms'])
+def test_constant_prior_mean_of_w_matches_reference(golden_dir, tag, stats):
+    """GaussianARD(mu, alpha) for W with a constant mu != 0 stays on the fused block: an array of
+    shape (D, 1, K), of shape (K,) with W started from a value, a scalar with W started from its
+    prior (live-reference traces, oracle/make_golden.py:pca_mean_case)."""
+    g = np.load(os.path.join(golden_dir, 'pca_prior_mean.npz'))
+    Q, order = build_pca_with_mean(g, tag)
+    assert isinstance(Q.plans[0], PCAPlan) and Q.plans[0].mu0 is not None
+    _attach_cpu(Q, stats)
+    check_pca_with_mean(Q, order, g, tag)
+    from bayespy_amd.inference import transformations
+    with pytest.raises(NotImplementedError):
+        transformations.RotateGaussianARD(Q['W'], Q['alpha']).setup()
+
+
+def test_prior_mean_with_missing_values_goes_to_the_generic_engine(golden_dir):
+    """The missing-data block keeps requiring a zero prior mean."""
+    from bayespy_amd.inference.plans.masked_pca import MaskedPCAPlan
+    g = np.load(os.path.join(golden_dir, 'pca_prior_mean.npz'))
+    y, mu = g['ms_y'], g['ms_mu']
+    D, N = y.shape
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(2,), name='alpha')
+    W = nodes.GaussianARD(mu, alpha, shape=(2,), plates=(D, 1), name='W')
+    X = nodes.GaussianARD(0, 1, shape=(2,), plates=(1, N), name='X')
+    F = nodes.SumMultiply('i,i', W, X, name='F')
+    tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    Y.observe(y, mask=np.random.RandomState(0).rand(D, N) < 0.8)
+    assert MaskedPCAPlan.match([Y, F, W, X, tau, alpha]) is None
+    assert PCAPlan.match([Y, F, W, X, tau, alpha]) is None
