@@ -132,6 +132,7 @@ SIGNATURES = {
     'vmp_queue_begin': (c_i32, [c_vp]),
     'vmp_queue_flush': (c_i32, [c_vp]),
     'vmp_queue_end': (c_i32, [c_vp]),
+    'vmp_queue_commit': (c_i32, [c_vp]),
     'vmp_queue_stats': (c_i32, [c_vp, P(c_i64), P(c_i64)]),
     'vmp_pca_gram': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'vmp_pca_update_tau': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_vp]),

@@ -48,10 +48,13 @@ struct vmp_ctx {
 // every entry point that puts work on ctx->stream behind the caller's back of the queue calls this
 // first: queued small operations run before anything that may read what they write
 int32_t vmp_queue_flush(vmp_ctx *ctx);
+int32_t vmp_queue_commit(vmp_ctx *ctx);
 int32_t destroy_small_queue(vmp_ctx *ctx);       // internal: frees the queue with the context
+extern const char *vmp_flush_cause;               // diagnostic: who asked for the flush (VMP_QUEUE_TRACE=1)
 #define VMP_FLUSH_SMALL(ctx)                                   \
     do {                                                       \
         if ((ctx) && (ctx)->queue) {                           \
+            vmp_flush_cause = __func__;                        \
             const int32_t rc__ = vmp_queue_flush(ctx);         \
             if (rc__ != VMP_OK) return rc__;                   \
         }                                                      \

@@ -166,6 +166,12 @@ int32_t vmp_graph_end(vmp_ctx *ctx, void **graph)
         (void)hipGraphDestroy(g);
         VMP_HIP_CHECK(ctx, e);
     }
+    const int32_t rcc = vmp_queue_commit(ctx);    // device copies of the recorded small operations
+    if (rcc != VMP_OK) {
+        (void)hipGraphExecDestroy(x);
+        (void)hipGraphDestroy(g);
+        return rcc;
+    }
     vmp_graph *h = new (std::nothrow) vmp_graph{g, x};
     if (!h) {
         (void)hipGraphExecDestroy(x);

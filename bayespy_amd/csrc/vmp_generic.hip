@@ -32,7 +32,9 @@ struct Iter {
     int i32;                         // every flat index fits 32 bits: cheaper divisions
 };
 
-__device__ inline void decode_keep(const Iter &it, int64_t o, int64_t *off, int64_t &ooff)
+// (IT: Iter as a kernel argument, or the record of a queued operation in constant memory)
+template <class IT>
+__device__ inline void decode_keep(const IT &it, int64_t o, int64_t *off, int64_t &ooff)
 {
     for (int i = 0; i < it.nin; ++i) off[i] = 0;
     ooff = 0;
@@ -56,7 +58,8 @@ __device__ inline void decode_keep(const Iter &it, int64_t o, int64_t *off, int6
     }
 }
 
-__device__ inline double product_at(const Iter &it, const int64_t *base, int64_t r)
+template <class IT>
+__device__ inline double product_at(const IT &it, const int64_t *base, int64_t r)
 {
     int64_t off[MAXIN];
     for (int i = 0; i < it.nin; ++i) off[i] = base[i];
@@ -534,18 +537,10 @@ struct EwiseArgs {
     int pairmask;       // VEC instance: operands read as aligned pairs (the others broadcast)
 };
 
-// one output element of a fused formula: flat index -> operand offsets, then the postfix program
-__device__ inline double ewise_element(const EwiseArgs &a, int64_t e)
+// the postfix program of a fused formula at the operand offsets of one element
+template <class EA>
+__device__ inline double ewise_program(const EA &a, const int64_t *off)
 {
-    int64_t off[MAXIN];
-    for (int i = 0; i < a.nin; ++i) off[i] = 0;
-    int64_t t = e;
-    for (int d = a.ndim - 1; d >= 0; --d) {
-        const int64_t q = t / a.shape[d];
-        const int64_t c = t - q * a.shape[d];
-        t = q;
-        for (int i = 0; i < a.nin; ++i) off[i] += c * a.stride[i][d];
-    }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
 #define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
@@ -578,6 +573,21 @@ __device__ inline double ewise_element(const EwiseArgs &a, int64_t e)
 #undef PUSH
 #undef BIN
     return s0;
+}
+
+// one output element of a fused formula: flat index -> operand offsets, then the postfix program
+__device__ inline double ewise_element(const EwiseArgs &a, int64_t e)
+{
+    int64_t off[MAXIN];
+    for (int i = 0; i < a.nin; ++i) off[i] = 0;
+    int64_t t = e;
+    for (int d = a.ndim - 1; d >= 0; --d) {
+        const int64_t q = t / a.shape[d];
+        const int64_t c = t - q * a.shape[d];
+        t = q;
+        for (int i = 0; i < a.nin; ++i) off[i] += c * a.stride[i][d];
+    }
+    return ewise_program(a, off);
 }
 
 __global__ void __launch_bounds__(NT)
@@ -746,31 +756,28 @@ ewise_small_kernel(EwiseArgs a, double *__restrict__ out)
 constexpr int SPD_MAXN = 64;
 constexpr int SPD_LD = SPD_MAXN + 1;
 
-// one workgroup per matrix (n <= 64)
-__global__ void __launch_bounds__(NT)
-spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
-                         double *__restrict__ Ainv, double *__restrict__ logdet,
-                         int32_t *__restrict__ info)
+// one workgroup of NTH threads per matrix (n <= 64): Gauss-Jordan sweeps in LDS.  The arithmetic of
+// an element does not depend on NTH (the stand-alone kernel runs it with 256 threads, the
+// interpreter of queued small operations with its 1024).
+template <int NTH>
+__device__ inline void spd_block_body(double *M, int *bad, int tid, int n,
+                                      const double *__restrict__ a, double *__restrict__ ainv,
+                                      double *__restrict__ logdet, int32_t *__restrict__ info)
 {
-    __shared__ double M[SPD_MAXN * SPD_LD];
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    const double *a = A + b * n * n;
-    if (tid == 0) bad = 0;
-    for (int e = tid; e < n * n; e += NT) {
+    if (tid == 0) *bad = 0;
+    for (int e = tid; e < n * n; e += NTH) {
         const int i = e / n, j = e - i * n;
         M[i * SPD_LD + j] = 0.5 * (a[i * n + j] + a[j * n + i]);
     }
     double ld = 0.0, prod = 1.0;
-    constexpr int EPT = SPD_MAXN * SPD_MAXN / NT;
+    constexpr int EPT = SPD_MAXN * SPD_MAXN / NTH;
     for (int p = 0; p < n; ++p) {
         __syncthreads();
         const double piv = M[p * SPD_LD + p];
         double ci[EPT], rj[EPT], me[EPT];
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
-            const int e = tid + m * NT;
+            const int e = tid + m * NTH;
             if (e < n * n) {
                 const int i = e / n, j = e - i * n;
                 ci[m] = M[i * SPD_LD + p];
@@ -779,14 +786,14 @@ spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
             }
         }
         if (tid == 0) {
-            if (!(piv > 0.0)) bad = 1;
+            if (!(piv > 0.0)) *bad = 1;
             logdet_accumulate(piv, prod, ld);
         }
         const double d = fast_recip(piv);
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
-            const int e = tid + m * NT;
+            const int e = tid + m * NTH;
             if (e < n * n) {
                 const int i = e / n, j = e - i * n;
                 double v;
@@ -798,15 +805,27 @@ spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
         }
     }
     __syncthreads();
-    if (Ainv)
-        for (int e = tid; e < n * n; e += NT) {
+    if (ainv)
+        for (int e = tid; e < n * n; e += NTH) {
             const int i = e / n, j = e - i * n;
-            Ainv[b * n * n + e] = M[i * SPD_LD + j];
+            ainv[e] = M[i * SPD_LD + j];
         }
     if (tid == 0) {
-        if (logdet) logdet[b] = logdet_finish(prod, ld);
-        if (info) info[b] = bad;
+        if (logdet) *logdet = logdet_finish(prod, ld);
+        if (info) *info = *bad;
     }
+}
+
+__global__ void __launch_bounds__(NT)
+spd_batched_block_kernel(int n, int64_t batch, const double *__restrict__ A,
+                         double *__restrict__ Ainv, double *__restrict__ logdet,
+                         int32_t *__restrict__ info)
+{
+    __shared__ double M[SPD_MAXN * SPD_LD];
+    __shared__ int bad;
+    const int64_t b = blockIdx.x;
+    spd_block_body<NT>(M, &bad, threadIdx.x, n, A + b * n * n, Ainv ? Ainv + b * n * n : nullptr,
+                       logdet ? logdet + b : nullptr, info ? info + b : nullptr);
 }
 
 // one wavefront per matrix (n <= 8): n*n <= 64 elements, one per lane
@@ -1145,19 +1164,30 @@ void launch_finish(vmp_ctx *ctx, const Iter &it, int nsplit, double scale, const
 // default; queued plate sums use another summation order than the stand-alone kernels and stay
 // an opt-in (small_queue_sm = 1).
 // ---------------------------------------------------------------------------
-enum { SMALL_EWISE = 0, SMALL_SUM = 1 };
-struct SmallOp {
+enum { SMALL_EWISE = 0, SMALL_SUM = 1, SMALL_SPD = 2 };
+struct SmallSpd {
+    int n;
+    int64_t batch;
+    const double *A;
+    double *Ainv, *logdet;
+    int32_t *info;
+};
+struct alignas(16) SmallOp {
     int32_t kind, pad;
     double scale;
     double *out;
     union {
         EwiseArgs ew;
         Iter it;
+        SmallSpd spd;
     };
 };
-constexpr int QUEUE_CAP = 64;                    // records per launch
+constexpr int QNT = 512;                         // threads of the interpreter (256 VGPRs each: no spills)
+constexpr int QUEUE_CAP = 128;                   // records per launch
 constexpr int64_t SMALL_EW_MAX = 2048;           // elements of a queued formula
 constexpr int64_t SMALL_SM_KEEP = 2048, SMALL_SM_WORK = 32768;   // outputs, products of a queued sum
+constexpr int SMALL_SPD_MAXN = 32;               // a queued inverse / log-determinant: n x n, n <= 32
+constexpr int64_t SMALL_SPD_BATCH = 4;
 
 constexpr int QUEUE_SLOTS = 16;                  // staging buffers in rotation (eager flushes)
 constexpr int ARENA_RECORDS = 16384;             // records of flushes recorded into HIP graphs
@@ -1172,54 +1202,193 @@ struct small_queue {
     int pending[QUEUE_SLOTS];
     // a flush inside a stream capture is replayed with the graph: its records must stay where they
     // are for as long as the graph lives, so they are moved into an arena that is never reused
-    // (allocated with the queue: nothing can be allocated while a stream records)
+    // (allocated with the queue: nothing can be allocated while a stream records).  Their device
+    // copy is made ONCE, by vmp_queue_commit after the recording -- not by a copy node that every
+    // replay would pay for
     SmallOp *arena_host, *arena_dev;
-    int arena_used;
+    int arena_used, arena_committed;
     int64_t launches, ops;
 };
 
-__global__ void __launch_bounds__(NT)
+// The records of a launch are CONSTANT memory for the interpreter (written before the launch,
+// never during it): read through the constant address space they arrive by scalar loads through
+// the scalar cache, like kernel arguments -- the program of a formula is walked without a vector
+// memory round trip per step.
+#define VMP_CONST_AS __attribute__((address_space(4)))
+typedef const VMP_CONST_AS SmallOp CSmallOp;
+
+// (a pointer handed to a function arrives in vector registers: back into scalar ones, or the loads
+// through it are vector loads again)
+__device__ inline CSmallOp *uniform_record(CSmallOp *op)
+{
+    const uint64_t p = (uint64_t)op;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return (CSmallOp *)(((uint64_t)hi << 32) | lo);
+}
+
+// one element of a queued formula: everything fits 32 bits here (total <= SMALL_EW_MAX), the
+// arithmetic is ewise_element's
+template <class EA>
+__device__ inline double ewise_element32(const EA &a, uint32_t e)
+{
+    int64_t off[MAXIN];
+    const int nin = a.nin, ndim = a.ndim;
+    for (int i = 0; i < nin; ++i) off[i] = 0;
+    uint32_t t = e;
+    for (int d = ndim - 1; d >= 1; --d) {
+        const uint32_t sz = (uint32_t)a.shape[d];
+        const uint32_t q = t / sz, c = t - q * sz;
+        t = q;
+        for (int i = 0; i < nin; ++i) off[i] += (int64_t)c * a.stride[i][d];
+    }
+    if (ndim >= 1)
+        for (int i = 0; i < nin; ++i) off[i] += (int64_t)t * a.stride[i][0];
+    return ewise_program(a, off);
+}
+
+__device__ inline double wave_sum(double v)
+{
+    for (int st = 32; st > 0; st >>= 1) v += __shfl_down(v, st, 64);
+    return v;
+}
+
+// the three kinds of records, each a function of its own (their register needs differ widely; as
+// one body the interpreter spilled)
+__device__ __noinline__ void small_ewise(CSmallOp *op, int tid)
+{
+    op = uniform_record(op);
+    const uint32_t total = (uint32_t)op->ew.total;
+    double *out = op->out;
+    for (uint32_t e = tid; e < total; e += QNT) out[e] = ewise_element32(op->ew, e);
+}
+
+__device__ __noinline__ void small_spd(CSmallOp *op, double *M, int *bad, int tid)
+{
+    op = uniform_record(op);
+    const int n = op->spd.n, nn = n * n;
+    const int64_t batch = op->spd.batch;
+    const double *A = op->spd.A;
+    double *Ainv = op->spd.Ainv, *logdet = op->spd.logdet;
+    int32_t *info = op->spd.info;
+    for (int64_t b = 0; b < batch; ++b) {
+        spd_block_body<QNT>(M, bad, tid, n, A + b * nn, Ainv ? Ainv + b * nn : nullptr,
+                            logdet ? logdet + b : nullptr, info ? info + b : nullptr);
+        __syncthreads();
+    }
+}
+
+// A queued sum of products.  The latency of one dependent load (~1 us from L2 / HBM) is what a
+// small operation costs, so the products of a lane are formed EIGHT at a time (their loads in
+// flight together), G lanes share an output (G a power of two <= 64 chosen so that the workgroup
+// is filled), and the partial sums of a group meet by xor-shuffles.  The order of the additions
+// is fixed by the shape of the operation alone.
+template <int NIN>
+__device__ inline double small_sum_lane(const VMP_CONST_AS Iter &it, const double *const *in,
+                                        const int64_t *base, int64_t first, int64_t step,
+                                        int64_t nred)
+{
+    const int nin = it.nin, nr = it.nr;
+    double acc = 0.0;
+    for (int64_t r0 = first; r0 < nred; r0 += 8 * step) {
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = r0 + u * step;
+            const bool ok = r < nred;
+            int64_t off[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) off[i] = base[i];
+            uint32_t t = ok ? (uint32_t)r : 0u;        // (nred <= 32768: 32 bits)
+            for (int d = nr - 1; d >= 1; --d) {
+                const uint32_t sz = (uint32_t)it.rsize[d];
+                const uint32_t q = t / sz, c = t - q * sz;
+                t = q;
+#pragma unroll
+                for (int i = 0; i < NIN; ++i)
+                    if (i < nin) off[i] += (int64_t)c * it.rstride[i][d];
+            }
+            if (nr >= 1) {
+#pragma unroll
+                for (int i = 0; i < NIN; ++i)
+                    if (i < nin) off[i] += (int64_t)t * it.rstride[i][0];
+            }
+            double v = in[0][off[0]];
+#pragma unroll
+            for (int i = 1; i < NIN; ++i)
+                if (i < nin) v *= in[i][off[i]];
+            p[u] = ok ? v : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += p[u];
+    }
+    return acc;
+}
+
+template <int NIN>
+__device__ inline void small_sum_body(CSmallOp *op, double *red, int tid)
+{
+    const VMP_CONST_AS Iter &it = op->it;
+    double *out = op->out;
+    const double scale = op->scale;
+    const int64_t nkeep = it.nkeep, nred = it.nred;
+    const double *in[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) in[i] = it.in[i < it.nin ? i : 0];
+    if (nkeep * 64 < QNT && nred > 1024) {
+        // a few long sums: the workgroup per output, wavefront sums combined in a fixed order
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int64_t o = 0; o < nkeep; ++o) {
+            int64_t base[MAXIN], ooff;
+            decode_keep(it, o, base, ooff);
+            double acc = small_sum_lane<NIN>(it, in, base, tid, QNT, nred);
+            acc = wave_sum(acc);
+            if (lane == 0) red[wave] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int w = 0; w < QNT / 64; ++w) t += red[w];
+                out[ooff] = scale * t;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    int G = 1;
+    while (G < 64 && (int64_t)(2 * G) * nkeep <= QNT && 2 * G <= nred) G <<= 1;
+    const int per = QNT / G, gl = tid & (G - 1), slot = tid / G;
+    for (int64_t o0 = 0; o0 < nkeep; o0 += per) {
+        const int64_t o = o0 + slot;
+        const bool act = o < nkeep;
+        int64_t base[MAXIN], ooff;
+        decode_keep(it, act ? o : 0, base, ooff);
+        double acc = small_sum_lane<NIN>(it, in, base, gl, G, nred);
+        for (int st = G >> 1; st > 0; st >>= 1) acc += __shfl_xor(acc, st, 64);
+        if (act && gl == 0) out[ooff] = scale * acc;
+    }
+}
+
+__device__ __noinline__ void small_sum(CSmallOp *op, double *red, int tid)
+{
+    op = uniform_record(op);
+    if (op->it.nin <= 2) small_sum_body<2>(op, red, tid);
+    else small_sum_body<MAXIN>(op, red, tid);
+}
+
+__global__ void __launch_bounds__(QNT)
 small_ops_kernel(const SmallOp *__restrict__ ops, int n)
 {
-    __shared__ SmallOp op;
-    __shared__ double red[NT];
+    __shared__ double red[QNT / 64];
+    __shared__ double M[SMALL_SPD_MAXN * SPD_LD];
+    __shared__ int bad;
+    CSmallOp *rec = (CSmallOp *)ops;
+    const int tid = threadIdx.x;
     for (int i = 0; i < n; ++i) {
-        // the record into LDS (uniform reads from there; 1 KB)
-        {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(ops + i);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(&op);
-            for (int e = threadIdx.x; e < (int)(sizeof(SmallOp) / 4); e += NT) dst[e] = src[e];
-        }
-        __syncthreads();
-        if (op.kind == SMALL_EWISE) {
-            for (int64_t e = threadIdx.x; e < op.ew.total; e += NT) op.out[e] = ewise_element(op.ew, e);
-        } else if (op.it.nkeep >= NT / 4 || op.it.nred < 64) {
-            // a thread per output, sequential sum (the order of sum_multiply_thread_kernel)
-            for (int64_t o = threadIdx.x; o < op.it.nkeep; o += NT) {
-                int64_t base[MAXIN], ooff;
-                decode_keep(op.it, o, base, ooff);
-                double acc = 0.0;
-                for (int64_t r = 0; r < op.it.nred; ++r) acc += product_at(op.it, base, r);
-                op.out[ooff] = op.scale * acc;
-            }
-        } else {
-            // few outputs, longer sums: the workgroup per output, lanes along the sum, partial
-            // sums combined in a fixed tree
-            for (int64_t o = 0; o < op.it.nkeep; ++o) {
-                int64_t base[MAXIN], ooff;
-                decode_keep(op.it, o, base, ooff);
-                double acc = 0.0;
-                for (int64_t r = threadIdx.x; r < op.it.nred; r += NT) acc += product_at(op.it, base, r);
-                red[threadIdx.x] = acc;
-                __syncthreads();
-                for (int st = NT / 2; st > 0; st >>= 1) {
-                    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-                    __syncthreads();
-                }
-                if (threadIdx.x == 0) op.out[ooff] = op.scale * red[0];
-                __syncthreads();
-            }
-        }
+        CSmallOp *op = rec + i;
+        const int kind = op->kind;
+        if (kind == SMALL_EWISE) small_ewise(op, tid);
+        else if (kind == SMALL_SPD) small_spd(op, M, &bad, tid);
+        else small_sum(op, red, tid);
         // what this record wrote is visible to the next one (one workgroup, one CU)
         __threadfence_block();
         __syncthreads();
@@ -1256,6 +1425,8 @@ inline int32_t queue_slot(vmp_ctx *ctx, SmallOp **slot)
 }
 
 }  // namespace
+
+const char *vmp_flush_cause = nullptr;
 
 int32_t destroy_small_queue(vmp_ctx *ctx)
 {
@@ -1294,6 +1465,7 @@ int32_t vmp_queue_begin(vmp_ctx *ctx)
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&q->arena_dev), arena);
         for (int i = 0; i < QUEUE_SLOTS && e == hipSuccess; ++i)
             e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
+
         ctx->queue = q;
         if (e != hipSuccess) {
             (void)destroy_small_queue(ctx);
@@ -1317,23 +1489,41 @@ int32_t vmp_queue_flush(vmp_ctx *ctx)
 {
     VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
     small_queue *q = queue_of(ctx);
+    const char *cause = vmp_flush_cause ? vmp_flush_cause : "caller";
+    vmp_flush_cause = nullptr;
     if (!q || q->n == 0) return VMP_OK;
     const int n = q->n;
+    static const bool trace = getenv("VMP_QUEUE_TRACE") != nullptr;
+    if (trace) {
+        fprintf(stderr, "[vmp queue] flush of %d records for %s\n", n, cause);
+        const SmallOp *h = q->host + (size_t)q->cur * QUEUE_CAP;
+        for (int i = 0; i < n; ++i)
+            if (h[i].kind == SMALL_EWISE)
+                fprintf(stderr, "    ew  total=%lld nin=%d nops=%d ndim=%d\n", (long long)h[i].ew.total,
+                        h[i].ew.nin, h[i].ew.nops, h[i].ew.ndim);
+            else if (h[i].kind == SMALL_SUM)
+                fprintf(stderr, "    sum nkeep=%lld nred=%lld nin=%d nk=%d nr=%d\n",
+                        (long long)h[i].it.nkeep, (long long)h[i].it.nred, h[i].it.nin, h[i].it.nk,
+                        h[i].it.nr);
+            else
+                fprintf(stderr, "    spd n=%d batch=%lld\n", h[i].spd.n, (long long)h[i].spd.batch);
+    }
     q->n = 0;
     SmallOp *host = q->host + (size_t)q->cur * QUEUE_CAP, *dev = q->dev + (size_t)q->cur * QUEUE_CAP;
     const bool rec = stream_records(ctx);
     if (rec) {
-        // replayed with the graph: the records move into the arena (queue_slot made sure they fit)
+        // replayed with the graph: the records move into the arena (queue_slot made sure they
+        // fit); vmp_queue_commit copies them to the device once, after the recording
         VMP_REQUIRE(ctx, q->arena_used + n <= ARENA_RECORDS, VMP_ERR_UNSUPPORTED,
                     "arena of recorded small operations exhausted");
         memcpy(q->arena_host + q->arena_used, host, (size_t)n * sizeof(SmallOp));
-        host = q->arena_host + q->arena_used;
         dev = q->arena_dev + q->arena_used;
         q->arena_used += n;
+    } else {
+        VMP_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, (size_t)n * sizeof(SmallOp),
+                                          hipMemcpyHostToDevice, ctx->stream));
     }
-    VMP_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, (size_t)n * sizeof(SmallOp), hipMemcpyHostToDevice,
-                                      ctx->stream));
-    hipLaunchKernelGGL(small_ops_kernel, dim3(1), dim3(NT), 0, ctx->stream, dev, n);
+    hipLaunchKernelGGL(small_ops_kernel, dim3(1), dim3(QNT), 0, ctx->stream, dev, n);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     q->launches += 1;
     q->ops += n;
@@ -1348,6 +1538,21 @@ int32_t vmp_queue_flush(vmp_ctx *ctx)
             q->pending[q->cur] = 0;
         }
     }
+    return VMP_OK;
+}
+
+int32_t vmp_queue_commit(vmp_ctx *ctx)
+{
+    VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
+    small_queue *q = queue_of(ctx);
+    if (!q || q->arena_committed == q->arena_used) return VMP_OK;
+    VMP_REQUIRE(ctx, !stream_records(ctx), VMP_ERR_INVALID,
+                "vmp_queue_commit belongs after the recording, not into it");
+    VMP_HIP_CHECK(ctx, hipMemcpy(q->arena_dev + q->arena_committed,
+                                 q->arena_host + q->arena_committed,
+                                 (size_t)(q->arena_used - q->arena_committed) * sizeof(SmallOp),
+                                 hipMemcpyHostToDevice));
+    q->arena_committed = q->arena_used;
     return VMP_OK;
 }
 
@@ -1426,8 +1631,9 @@ int32_t vmp_sum_multiply(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32
         --it.nr;
     }
     it.i32 = (it.nkeep < ((int64_t)1 << 31) && it.nred < ((int64_t)1 << 31)) ? 1 : 0;
-    if (it.nkeep <= SMALL_SM_KEEP && it.nkeep * (it.nred > 0 ? it.nred : 1) <= SMALL_SM_WORK
-        && vmp_tune_get("small_queue_sm", 0)) {
+    if (it.nkeep <= SMALL_SM_KEEP
+        && it.nkeep * (it.nred > 0 ? it.nred : 1) <= vmp_tune_get("small_queue_sm_work", SMALL_SM_WORK)
+        && vmp_tune_get("small_queue_sm", 1)) {
         SmallOp *slot = nullptr;
         const int32_t rc = queue_slot(ctx, &slot);
         if (rc != VMP_OK) return rc;
@@ -1642,7 +1848,7 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
     }
     for (int c = 0; c < nconsts; ++c) a.consts[c] = consts[c];
     if (a.total == 0) return VMP_OK;
-    if (a.total <= SMALL_EW_MAX && vmp_tune_get("small_queue_ew", 1)) {
+    if (a.total <= vmp_tune_get("small_queue_ew_max", SMALL_EW_MAX) && vmp_tune_get("small_queue_ew", 1)) {
         SmallOp *slot = nullptr;
         const int32_t rc = queue_slot(ctx, &slot);
         if (rc != VMP_OK) return rc;
@@ -1718,12 +1924,32 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
 int32_t vmp_spd_batched(vmp_ctx *ctx, int32_t n, int64_t batch, const double *A, double *Ainv,
                         double *logdet, int32_t *info)
 {
-    VMP_FLUSH_SMALL(ctx);
     VMP_REQUIRE(ctx, ctx && A, VMP_ERR_INVALID, "null argument");
     VMP_REQUIRE(ctx, n >= 1 && batch >= 0, VMP_ERR_INVALID, "bad dims");
     VMP_REQUIRE(ctx, n <= SPD_MAXN, VMP_ERR_UNSUPPORTED, "batched SPD kernels support n <= %d",
                 SPD_MAXN);
     if (batch == 0) return VMP_OK;
+    if (n > 8 && n <= SMALL_SPD_MAXN && batch <= SMALL_SPD_BATCH && vmp_tune_get("small_queue_sm", 1)
+        && vmp_tune_get("small_queue_spd", 1)) {
+        // (n <= 8 has its own wavefront-per-matrix arithmetic; the queued form is the block kernel's)
+        SmallOp *slot = nullptr;
+        const int32_t rc = queue_slot(ctx, &slot);
+        if (rc != VMP_OK) return rc;
+        if (slot) {
+            slot->kind = SMALL_SPD;
+            slot->scale = 1.0;
+            slot->out = nullptr;
+            slot->spd.n = n;
+            slot->spd.batch = batch;
+            slot->spd.A = A;
+            slot->spd.Ainv = Ainv;
+            slot->spd.logdet = logdet;
+            slot->spd.info = info;
+            queue_of(ctx)->n += 1;
+            return VMP_OK;
+        }
+    }
+    VMP_FLUSH_SMALL(ctx);
     const int64_t big = 4 * (int64_t)ctx->num_cu;      // enough matrices to fill the chip row-wise
     if (n > 8 && n <= 16 && batch >= big)
         hipLaunchKernelGGL((spd_batched_rows_kernel<16, 256, false>),

@@ -243,6 +243,18 @@ class Runtime:
             self.check(self.lib.vmp_queue_flush(self.ctx))
         self._queue_alive = []
 
+    def queue_commit(self):
+        """After a stream capture that recorded flushes: the device copies of their records
+        (vmp_queue_commit) -- before the first replay."""
+        if self.ctx is not None and self.lib is not None:
+            self.check(self.lib.vmp_queue_commit(self.ctx))
+
+    def queue_collects_sums(self):
+        """Small contractions go to the queue of small operations right now (it is open and
+        "small_queue_sm" is on): the caller then prefers vmp_sum_multiply over a GEMM launch."""
+        return self._op_depth > 0 and self._queue_env and self.lib is not None \
+            and self._tune_sm
+
     def keep_until_flush(self, arrays, out):
         """A queued operation runs LATER: its operands and its result must not go back to the
         allocator before (a block handed out again would be written by something else first).
@@ -250,9 +262,13 @@ class Runtime:
         if self._op_depth > 0 and self.lib is not None:
             self._queue_alive.append((arrays, out))
 
+    _tune_sm = True
+
     def set_tune(self, key, value):
         if self.lib is not None:
             self.check(self.lib.vmp_tune_set(key.encode(), int(value)))
+            if key == 'small_queue_sm':
+                self._tune_sm = bool(value)
 
     def queue_stats(self):
         if self.ctx is None or self.lib is None:

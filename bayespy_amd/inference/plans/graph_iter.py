@@ -260,14 +260,18 @@ class GraphIteration:
             import gc
             gc_was_on = gc.isenabled()
             gc.disable()
+            sm_was = rt._tune_sm
             try:
                 from ...utils import misc
                 memo_was = misc._CUR_MEMO[0]
                 misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
-                # the queue of small formulas (vmp_queue_*) pays in eager sweeps only: a graph node
-                # costs what a queued record costs its interpreter.  Same arithmetic either way.
+                # the queue of small operations (vmp_queue_*) stays open: a run of formulas, small
+                # sums and K x K inverses is ONE node of the graph; the records of its flushes are
+                # kept by the library and copied to the device once (queue_commit below)
                 rt.flush_small()
-                rt.set_tune('small_queue_ew', 0)
+                if os.environ.get('BAYESPY_AMD_GRAPH_QUEUE', '1') == '0':
+                    rt.set_tune('small_queue_ew', 0)
+                    rt.set_tune('small_queue_sm', 0)
                 with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):
                     with rt.operation():
                         for n in upd:
@@ -280,6 +284,8 @@ class GraphIteration:
                         rec.outvec = torch.cat(dev + flags) if dev or flags else None
             finally:
                 rt.set_tune('small_queue_ew', 1)
+                rt.set_tune('small_queue_sm', int(sm_was))
+                rt.queue_commit()
                 rt._capturing = False
                 rt._deferred = []
                 misc._CUR_MEMO[0] = memo_was

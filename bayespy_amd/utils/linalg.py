@@ -37,12 +37,15 @@ class CholFactor:
         batch = C.size // (n * n) if n else 0
         inv = DArray.empty(C.shape)
         logdet = DArray.empty(C.shape[:-2])
-        info = rt.torch.zeros(max(batch, 1), dtype=rt.torch.int32, device=rt.device)
+        # (every flag is written by the kernel; an empty batch never reads it)
+        info = (rt.torch.empty(batch, dtype=rt.torch.int32, device=rt.device) if batch else
+                rt.torch.zeros(1, dtype=rt.torch.int32, device=rt.device))
         rt.sync_stream()
         rt.check(rt.lib.vmp_spd_batched(rt.ctx, n, batch, ctypes.c_void_p(C.t.data_ptr()),
                                         ctypes.c_void_p(inv.t.data_ptr()),
                                         ctypes.c_void_p(logdet.t.data_ptr()),
                                         ctypes.c_void_p(info.data_ptr())))
+        rt.keep_until_flush([C], (inv, logdet, info))       # a few small matrices are queued
         # same failure the reference reports (utils/linalg.py:58-59); inside a plan
         # operation the flag is read together with the operation's other checks
         rt.defer_check(info, _lib.NotPositiveDefiniteError, "Matrix not positive definite")

@@ -188,8 +188,12 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
         if hoisted is not None:
             return hoisted
     out = DArray.empty(out_shape_keep)
-    if len(arrays) >= 2 and len(reduce_axes) > 0 and _try_gemm(rt, arrays, shape, reduce_axes,
-                                                                 out, scale):
+    # a small contraction inside an operation joins the queue of small operations (one interpreter
+    # launch for a run of them) instead of being a GEMM launch of its own
+    small = rt.queue_collects_sums() and int(np.prod(out_shape_keep)) <= 2048 \
+        and int(np.prod(shape)) <= 32768
+    if not small and len(arrays) >= 2 and len(reduce_axes) > 0 \
+            and _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
         return out
     # coalesce neighbouring axes of the same role (both kept or both reduced) that every
     # operand and the output walk densely: the kernels decode a flat index into axes with

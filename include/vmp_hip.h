@@ -589,19 +589,24 @@ int32_t vmp_graph_launch(vmp_ctx *ctx, void *graph);
 int32_t vmp_graph_destroy(vmp_ctx *ctx, void *graph);
 
 /* Queue of SMALL operations.  Between vmp_queue_begin and vmp_queue_end, vmp_ewise and
- * vmp_sum_multiply calls on small arrays (<= 2048 outputs, <= 32768 products) are recorded on the
- * host and run, in order, by ONE launch of an interpreter kernel -- when any other entry point of
- * the generic part of this library needs the stream (it flushes first), when 64 of them are
- * collected, at vmp_queue_flush or at the outermost vmp_queue_end.  A VB sweep of the generic engine
+ * vmp_sum_multiply calls on small arrays (<= 2048 outputs, <= 32768 products) and vmp_spd_batched
+ * calls on a few small matrices (8 < n <= 32, batch <= 4) are recorded on the host and run, in
+ * order, by ONE launch of an interpreter kernel -- when any other entry point of the generic part
+ * of this library needs the stream (it flushes first), when 128 of them are collected, at
+ * vmp_queue_flush or at the outermost vmp_queue_end.  A VB sweep of the generic engine
  * is ~90 such operations on scalars and K x K arrays (the Gamma / ARD formulas of gamma.py:142-148,
  * gaussian.py:2344-2369, the bound terms of expfamily.py:449-468) between a dozen plate-sized
  * kernels.  Results do not depend on the grouping.  The caller must flush before it reads an
  * output on the host or hands it to work outside this library.  begin / end nest; a context whose
- * stream records a HIP graph keeps the records of its flushes for the life of the context.
- * vmp_tune_set("small_queue", 0) makes begin / end no-ops. */
+ * stream records a HIP graph keeps the records of its flushes for the life of the context; their
+ * device copies are made by vmp_queue_commit, which belongs between the end of the recording and
+ * the first launch of the graph (vmp_graph_end calls it; a binding that records through another
+ * API calls it itself).  vmp_tune_set("small_queue", 0) makes begin / end no-ops;
+ * "small_queue_ew" / "small_queue_sm" = 0 keep formulas / sums and inverses out of the queue. */
 int32_t vmp_queue_begin(vmp_ctx *ctx);
 int32_t vmp_queue_flush(vmp_ctx *ctx);
 int32_t vmp_queue_end(vmp_ctx *ctx);
+int32_t vmp_queue_commit(vmp_ctx *ctx);
 int32_t vmp_queue_stats(vmp_ctx *ctx, int64_t *launches, int64_t *ops);
 
 /* Batched SPD inverse and log-determinant of `batch` contiguous n x n matrices

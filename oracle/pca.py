@@ -90,6 +90,8 @@ def init_stats(y, x0, chunk=1 << 16):
 class PCAOracle:
     """Chunked float64 VB for fully observed PCA.  See module docstring."""
 
+    mu = None          # constant prior mean of W (None = 0); set by __init__
+
     def __init__(self, y, x0, a0=1e-2, b0=1e-2, chunk=1 << 16, keep_x=True, mu=None):
         """``mu``: a constant prior mean of W, broadcastable to (D, K) (GaussianARD(mu, alpha):
         phi0 = <alpha> mu, gaussian.py:805-830); None = 0."""

@@ -615,6 +615,10 @@ def test_cabi_queue_and_graph_of_small_operations():
         t1 = torch.empty(K, K, dtype=torch.float64, device=dev)      # a * b + 2
         t2 = torch.empty(K, dtype=torch.float64, device=dev)         # sum_j t1[i, j] * b[j]
         t3 = torch.empty((), dtype=torch.float64, device=dev)        # sum_i t2[i]
+        spd = torch.empty(K, K, dtype=torch.float64, device=dev)     # a a^T + K I
+        sinv = torch.empty(K, K, dtype=torch.float64, device=dev)
+        sld = torch.empty(1, dtype=torch.float64, device=dev)
+        sinfo = torch.empty(1, dtype=torch.int32, device=dev)
         ws = torch.empty(1 << 20, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -636,28 +640,69 @@ def test_cabi_queue_and_graph_of_small_operations():
             o3 = (ctypes.c_int64 * 1)(0)
             assert lib.vmp_sum_multiply(ctx, 1, shape1, 1, ins3, s3, o3, ctypes.c_uint32(1), 1.0,
                                         vp(t3), vp(ws), ws.numel() * 8) == 0
+            # spd = a a^T + K I (a contraction over the second axis of both), then its inverse
+            shape3 = (ctypes.c_int64 * 3)(K, K, K)
+            ins4 = (ctypes.c_void_p * 2)(a.data_ptr(), a.data_ptr())
+            str4 = (ctypes.c_int64 * 6)(K, 0, 1, 0, K, 1)
+            ostr4 = (ctypes.c_int64 * 3)(K, 1, 0)
+            assert lib.vmp_sum_multiply(ctx, 3, shape3, 2, ins4, str4, ostr4, ctypes.c_uint32(4), 1.0,
+                                        vp(spd), vp(ws), ws.numel() * 8) == 0
+            ins5 = (ctypes.c_void_p * 1)(spd.data_ptr())
+            str5 = (ctypes.c_int64 * 2)(K, 1)
+            ops5 = (ctypes.c_int32 * 1)(OP_IN | (0 << 8))
+            del ins5, str5, ops5
+            assert lib.vmp_spd_batched(ctx, K, 1, vp(spd), vp(sinv), vp(sld), vp(sinfo)) == 0
 
         def expect():
             A, Bv = a.cpu().numpy(), b.cpu().numpy()
             T1 = A * Bv + 2.0
             return T1, T1 @ Bv, (T1 @ Bv).sum()
 
-        # unqueued, then queued (both kinds: the plate sums are an opt-in of the queue)
+        def check_spd():
+            S = a.cpu().numpy() @ a.cpu().numpy().T
+            np.testing.assert_allclose(spd.cpu().numpy(), S, rtol=1e-12, atol=1e-12)
+            S = spd.cpu().numpy()
+            if np.linalg.eigvalsh(S).min() > 1e-6:
+                np.testing.assert_allclose(sinv.cpu().numpy() @ S, np.eye(K), atol=1e-6)
+                np.testing.assert_allclose(float(sld.cpu()), np.linalg.slogdet(S)[1], rtol=1e-9)
+                assert int(sinfo.cpu()) == 0
+
+        # unqueued, then queued: the five operations are ONE launch of the interpreter
         sweep()
         assert lib.vmp_ctx_sync(ctx) == 0
-        ref = (t1.cpu().numpy().copy(), t2.cpu().numpy().copy(), float(t3.cpu()))
+        ref = (t1.cpu().numpy().copy(), t2.cpu().numpy().copy(), float(t3.cpu()),
+               sinv.cpu().numpy().copy(), float(sld.cpu()))
         np.testing.assert_allclose(ref[0], expect()[0], rtol=1e-14)
         np.testing.assert_allclose(ref[1], expect()[1], rtol=1e-12)
+        check_spd()
         l0, n0 = ctypes.c_int64(), ctypes.c_int64()
         assert lib.vmp_queue_begin(ctx) == 0
-        for t in (t1, t2, t3):
+        for t in (t1, t2, t3, spd, sinv, sld):
             t.zero_()
         torch.cuda.synchronize()
         sweep()
         assert lib.vmp_queue_end(ctx) == 0 and lib.vmp_ctx_sync(ctx) == 0
         assert lib.vmp_queue_stats(ctx, ctypes.byref(l0), ctypes.byref(n0)) == 0
-        assert l0.value == 1 and n0.value == 1        # the formula waited for the first plate sum
-        assert np.array_equal(t1.cpu().numpy(), ref[0]) and np.array_equal(t2.cpu().numpy(), ref[1])
+        assert l0.value == 1 and n0.value == 5
+        # formulas and inverses: the arithmetic of the stand-alone kernels, bit for bit; sums: another
+        # order of the additions
+        assert np.array_equal(t1.cpu().numpy(), ref[0])
+        np.testing.assert_allclose(t2.cpu().numpy(), ref[1], rtol=1e-14)
+        np.testing.assert_allclose(float(t3.cpu()), ref[2], rtol=1e-14)
+        np.testing.assert_allclose(sinv.cpu().numpy(), ref[3], rtol=1e-10, atol=1e-13)
+        check_spd()
+        # "small_queue_sm" = 0: sums and inverses launch on their own, the formula waits for them
+        assert lib.vmp_tune_set(b'small_queue_sm', 0) == 0
+        try:
+            assert lib.vmp_queue_begin(ctx) == 0
+            sweep()
+            assert lib.vmp_queue_end(ctx) == 0 and lib.vmp_ctx_sync(ctx) == 0
+            l1, n1 = ctypes.c_int64(), ctypes.c_int64()
+            assert lib.vmp_queue_stats(ctx, ctypes.byref(l1), ctypes.byref(n1)) == 0
+            assert l1.value - l0.value == 1 and n1.value - n0.value == 1
+            assert np.array_equal(t2.cpu().numpy(), ref[1]) and np.array_equal(sinv.cpu().numpy(), ref[3])
+        finally:
+            assert lib.vmp_tune_set(b'small_queue_sm', 1) == 0
         # the sweep as a graph (the queue open inside: its flush is recorded too), replayed on new data
         g = ctypes.c_void_p()
         assert lib.vmp_queue_begin(ctx) == 0
@@ -674,6 +719,7 @@ def test_cabi_queue_and_graph_of_small_operations():
             np.testing.assert_allclose(t1.cpu().numpy(), e1, rtol=1e-14)
             np.testing.assert_allclose(t2.cpu().numpy(), e2, rtol=1e-12)
             np.testing.assert_allclose(float(t3.cpu()), e3, rtol=1e-12)
+            check_spd()
         assert lib.vmp_graph_destroy(ctx, g) == 0
     finally:
         lib.vmp_ctx_destroy(ctx)
