@@ -5,7 +5,7 @@
 # of VB iterations the profiled command ran.  Every step runs under its own `timeout`.
 O=${1:-gpurun_out/prof_r05}
 shift
-WHICH=${@:-pca_gram lssm_masked lssm_masked_1e5 masked generic_pca}
+WHICH=${@:-pca_gram gmm masked lssm lssm_masked lssm_masked_1e5 generic_pca}
 mkdir -p $O
 R=$PWD
 export TMPDIR=/tmp
