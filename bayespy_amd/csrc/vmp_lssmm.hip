@@ -23,7 +23,8 @@ namespace {
 
 constexpr int WNT = 64;       // one wavefront per workgroup: few sequences must spread over many CUs
 constexpr int RNT = 256;
-constexpr int MG1 = 4;        // rows of C per thread of the statistics pass, one thread per sequence
+constexpr int MG1 = 8;        // rows of C per thread of the statistics pass, one thread per sequence (B = 1e5,
+                              // M = 8: ONE pass over P, Z, Y at 468 registers, 3.6 ms, instead of two at 232, 5.15 ms)
 constexpr int MG4 = 8;        // rows of C per lane group of the statistics pass, D <= 4
 constexpr int MG8 = 4;        // ... D > 4 (two rows of the matrices per lane)
 
@@ -294,7 +295,7 @@ inline int64_t nwg(int64_t B, int G) { return (B * G + WNT - 1) / WNT; }
 // lanes per sequence: 4 (rows dealt over a DPP quad) while the sequences alone do not fill the
 // chip -- below 32768 of them four-lane groups are fewer than eight wavefronts per SIMD and the
 // shorter serial chain of a step wins (B = 1e4: 2.5 against 4.0 ms per iteration) --, one thread per
-// sequence beyond (a third of the instructions per sequence; B = 1e5: 14.5 against 17 ms).  D > 4
+// sequence beyond (a third of the instructions per sequence; B = 1e5: 12.2 against 17 ms).  D > 4
 // exists with four lanes only.  vmp_tune_set("lssmm_lanes", 1 | 4) fixes the form.
 inline int lanes_for(int D, int64_t B)
 {
@@ -305,7 +306,9 @@ inline int lanes_for(int D, int64_t B)
     return B >= 32768 ? 1 : GMAX;
 }
 
-// the backward sweep carries the statistics of all rows of C (G = 4 only: 40 accumulators a lane)
+// the backward sweep carries the statistics of all rows of C (G = 4 only: 40 accumulators a lane; one
+// thread per sequence would need 112 of them on top of its matrices: 512 registers and 2.3 KB of
+// scratch, measured 13.0 against 12.2 ms at B = 1e5)
 inline bool fused_stats(int D, int M, int G)
 {
     return G == GMAX && D <= 4 && M <= LSSMM_MFUSE && vmp_tune_get("lssmm_fuse", 1) != 0;

@@ -231,6 +231,12 @@ class Runtime:
                 self._queue_env = os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') != '0'
                 if not self._queue_env:
                     self.check(self.lib.vmp_tune_set(b'small_queue', 0))
+                # formulas only by default: their queued arithmetic is that of the stand-alone
+                # kernel bit for bit, so eager sweeps, recorded sweeps and single launches agree
+                # exactly.  BAYESPY_AMD_SMALL_QUEUE=all adds small plate sums and K x K inverses
+                # (another order of the additions; measured no faster: DESIGN.md section 4.18)
+                self.set_tune('small_queue_sm',
+                              1 if os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') == 'all' else 0)
             self.check(self.lib.vmp_queue_begin(self.ctx))
 
     def queue_end(self):
@@ -262,7 +268,7 @@ class Runtime:
         if self._op_depth > 0 and self.lib is not None:
             self._queue_alive.append((arrays, out))
 
-    _tune_sm = True
+    _tune_sm = False
 
     def set_tune(self, key, value):
         if self.lib is not None:

@@ -265,11 +265,14 @@ class GraphIteration:
                 from ...utils import misc
                 memo_was = misc._CUR_MEMO[0]
                 misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
-                # the queue of small operations (vmp_queue_*) stays open: a run of formulas, small
-                # sums and K x K inverses is ONE node of the graph; the records of its flushes are
-                # kept by the library and copied to the device once (queue_commit below)
+                # the queue of small operations (vmp_queue_*) pays in eager sweeps only: a node of the
+                # graph and a record of the interpreter both cost one dependent round trip through
+                # memory, and replays measure 1.96 ms without against 2.00 ms with it at config 2
+                # (DESIGN.md section 4.18).  BAYESPY_AMD_GRAPH_QUEUE=1 keeps it open inside the
+                # recording (a run of small operations is then ONE node; the records of its flushes
+                # are kept by the library and copied to the device once, queue_commit)
                 rt.flush_small()
-                if os.environ.get('BAYESPY_AMD_GRAPH_QUEUE', '1') == '0':
+                if os.environ.get('BAYESPY_AMD_GRAPH_QUEUE', '0') != '1':
                     rt.set_tune('small_queue_ew', 0)
                     rt.set_tune('small_queue_sm', 0)
                 with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):

@@ -132,3 +132,37 @@ def test_other_model_families_agree_with_eager(case, golden_dir, monkeypatch):
         return np.array_equal(np.asarray(a), np.asarray(b))
     for k in eager:
         assert same(eager[k], graph[k]), k
+
+
+@pytest.mark.parametrize('mode', ['eager_all', 'graph_all'])
+def test_queue_of_sums_and_recorded_queue_agree_with_the_default(mode, monkeypatch):
+    """Opt-ins of the queue of small operations: small plate sums and
+    K x K inverses queued as well (BAYESPY_AMD_SMALL_QUEUE=all -- another order of the additions),
+    and the queue kept open inside the recorded sweep (BAYESPY_AMD_GRAPH_QUEUE=1: its flushes become
+    nodes of the graph, their records are committed to the device after the recording)."""
+    from bayespy_amd.device import get_runtime
+
+    def run():
+        Q = _pca(N=5000, D=40, K=12)             # K > 8: the inverses are queueable
+        Q.update(repeat=8, verbose=False)
+        return Q.L[:8].copy(), Q['W'].get_moments()[0], Q['W']._plan.graph_info()
+
+    rt = get_runtime()
+    L0, W0, info0 = run()
+    assert info0['recorded']
+    rt.set_tune('small_queue_sm', 1)
+    if mode == 'eager_all':
+        monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
+    else:
+        monkeypatch.setenv('BAYESPY_AMD_GRAPH_QUEUE', '1')
+    try:
+        s0 = rt.queue_stats()
+        L1, W1, info1 = run()
+        s1 = rt.queue_stats()
+    finally:
+        rt.set_tune('small_queue_sm', 0)
+    assert info1['recorded'] == (mode == 'graph_all')
+    # operations were in fact queued: far fewer interpreter launches than records
+    assert s1['operations'] - s0['operations'] > 3 * (s1['launches'] - s0['launches']) > 0
+    np.testing.assert_allclose(L1, L0, rtol=1e-12)
+    np.testing.assert_allclose(W1, W0, rtol=1e-9, atol=1e-12)

@@ -28,6 +28,7 @@ Y = GaussianARD(F, tau, name='Y')
 X.initialize_from_value(x0[None]); Y.observe(y)
 Q = VB(Y, F, W, X, tau, alpha, engine='generic'); Q.ignore_bound_checks = True
 rt = get_runtime()
+rt.queue_begin(); rt.queue_end()      # (the runtime sets its default of small_queue_sm on first use)
 rt.set_tune('small_queue_sm', int(os.environ.get('QUEUE_LAB_SM', '1')))
 for key in ('small_queue_ew_max', 'small_queue_sm_work', 'small_queue_spd'):
     if os.environ.get(key.upper()):
