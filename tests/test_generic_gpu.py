@@ -608,6 +608,9 @@ def test_cabi_queue_and_graph_of_small_operations():
     stream = torch.cuda.Stream(dev)
     ctx = ctypes.c_void_p()
     assert lib.vmp_ctx_create(0, ctypes.c_void_p(stream.cuda_stream), ctypes.byref(ctx)) == 0
+    # tune keys are per process: the Python runtime keeps sums and inverses out of the queue unless
+    # asked (BAYESPY_AMD_SMALL_QUEUE=all); this test is about the library's own default
+    assert lib.vmp_tune_set(b'small_queue_sm', 1) == 0
     try:
         K = 16
         a = torch.randn(K, K, dtype=torch.float64, device=dev)
@@ -702,7 +705,7 @@ def test_cabi_queue_and_graph_of_small_operations():
             assert l1.value - l0.value == 1 and n1.value - n0.value == 1
             assert np.array_equal(t2.cpu().numpy(), ref[1]) and np.array_equal(sinv.cpu().numpy(), ref[3])
         finally:
-            assert lib.vmp_tune_set(b'small_queue_sm', 1) == 0
+            assert lib.vmp_tune_set(b'small_queue_sm', 1) == 0     # (for the graph part below)
         # the sweep as a graph (the queue open inside: its flush is recorded too), replayed on new data
         g = ctypes.c_void_p()
         assert lib.vmp_queue_begin(ctx) == 0
@@ -722,4 +725,6 @@ def test_cabi_queue_and_graph_of_small_operations():
             check_spd()
         assert lib.vmp_graph_destroy(ctx, g) == 0
     finally:
+        from bayespy_amd.device import get_runtime
+        lib.vmp_tune_set(b'small_queue_sm', int(get_runtime()._tune_sm))
         lib.vmp_ctx_destroy(ctx)
