@@ -101,7 +101,7 @@ inline void fill_layout(int D, int K, vmp_gmm_layout *L)
 // of tiles; the surplus ones are empty).  Sums are combined as (half 0) + (half 1) in both
 // wavefronts, so the two halves of a row of r carry the same normaliser bit for bit.
 // ---------------------------------------------------------------------------
-template <int DPT, int KT, int FT2, bool FROM_LABELS, int NW, bool REGEN, int KS>
+template <int DPT, int KT, int FT2, bool FROM_LABELS, int NW, bool REGEN, int KS, bool M4 = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
 gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
                 const double *__restrict__ Cmat, const int64_t *__restrict__ labels,
@@ -348,6 +348,28 @@ gmm_pass_kernel(const double *__restrict__ Y, int64_t N, int D, int K,
 #pragma unroll
                     for (int it = 0; it < KTL; ++it)
                         acc2[it][ft] = mfma_f64(a[it], b, acc2[it][ft]);
+                }
+            } else if constexpr (M4) {
+                // the SHORT matrix instruction (v_mfma_f64_4x4x4, four blocks; section 4.7 of
+                // 62-71 flop/ns against 44-46 of the 16x16x4 form).  The B operand of
+                // the long form IS the B operand of the short one -- lane (l15, g) holds feature
+                // 16 ft + l15 of point 4q + g, i.e. B[b][k][j] with 4b + j = l15, k = g --, the
+                // A operand is r[4Q + i][4q + k] for ALL four blocks (lane i + 4b + 16k: a read
+                // that does not depend on b), and D[b][i][j] lands in lane (l15 = 4b + j, g = i)
+                // = T[4Q + g][16 ft + l15]: component (Q & 3) of the long form's accumulator
+                // tile Q >> 2.  Four times the matrix instructions, each less than a quarter of
+                // the time; the feature operands stay in registers over the 4 KTL row blocks
+                double bf[FT2];
+#pragma unroll
+                for (int ft = 0; ft < FT2; ++ft) bf[ft] = ftile[nn * FS + ft * 16 + l15];
+#pragma unroll
+                for (int Q = 0; Q < 4 * KTL; ++Q) {
+                    if ((Q & 3) == 0) asm volatile("" ::: "memory");
+                    const double a = rtile[(4 * Q + (l & 3)) * RS + nn];
+#pragma unroll
+                    for (int ft = 0; ft < FT2; ++ft)
+                        acc2[Q >> 2][ft][Q & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                            a, bf[ft], acc2[Q >> 2][ft][Q & 3], 0, 0, 0);
                 }
             } else {
                 double bf[FT2];
@@ -841,12 +863,19 @@ int32_t launch_gmm_pass_as(vmp_ctx *ctx, const double *Y, int64_t N, int D, int 
     if (g > gmm_max_grid(ctx)) g = gmm_max_grid(ctx);
     if (g < 1) g = 1;
     auto kern = gmm_pass_kernel<DPT, KT, FT2, FROM_LABELS, NW, REGEN, KS>;
-    static bool attr = false;
-    if (!attr) {
+    if constexpr (!REGEN) {
+        // phase 2 on the short matrix instruction (the staged-feature instances: D <= 8): an
+        // experiment kept behind the tune key -- measured 2.84-2.86 against 2.81 ms at config 3
+        // (tools/gmm_lab.py, profiles/r05/pmc_gmm_mfma4.txt)
+        if (vmp_tune_get("gmm_mfma4", 0) != 0)
+            kern = gmm_pass_kernel<DPT, KT, FT2, FROM_LABELS, NW, REGEN, KS, true>;
+    }
+    static const void *attr_done[2] = {nullptr, nullptr};
+    if (attr_done[0] != (const void *)kern && attr_done[1] != (const void *)kern) {
         VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern,
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024));
-        attr = true;
+        attr_done[attr_done[0] ? 1 : 0] = (const void *)kern;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(64 * NW), lds, ctx->stream, Y, N, D, K, C,
                        labels, R, P, ntiles);

@@ -1,6 +1,9 @@
 """Op-level trace of one generic-engine PCA iteration (BASELINE config 2): every fused elementwise
 launch and every sum_multiply / GEMM launch with shapes and its synchronous duration."""
 import os, sys, time, traceback
+# launch by launch: no replay from the sweep graph, no queue of small operations
+os.environ.setdefault('BAYESPY_AMD_GRAPH', '0')
+os.environ.setdefault('BAYESPY_AMD_SMALL_QUEUE', '0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bayespy_amd import darray
