@@ -165,3 +165,54 @@ def test_sharded_checkpoint_is_written_per_rank(tmp_path):
         r = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % k))
         np.testing.assert_array_equal(r['L'], r['L2'])
         np.testing.assert_array_equal(r['x'], r['x2'])
+
+
+def _mean_worker(rank, world, port, out_dir):
+    """The prior-mean model of tests/golden/pca_prior_mean.npz (case m3) with the observation plate
+    split over two ranks: mu is replicated state, the collectives are those of the zero-mean block."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bayespy_amd.nodes as nodes
+    from bayespy_amd.device import Runtime
+    from bayespy_amd.inference import VB
+    from bayespy_amd.inference.plans.pca import PCAPlan
+    from fake_kernels import CPURuntimeKernels
+    g = np.load(os.path.join(GOLDEN, 'pca_prior_mean.npz'))
+    y, x0, mu = g['m3_y'], g['m3_x0'], g['m3_mu']
+    D, N = y.shape
+    K = x0.shape[1]
+    lo, hi = N * rank // world, N * (rank + 1) // world
+    alpha = nodes.Gamma(1e-2, 1e-2, plates=(K,), name='alpha')
+    W = nodes.GaussianARD(mu, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = nodes.GaussianARD(0, 1, shape=(K,), plates=(1, hi - lo), name='X').shard(-1)
+    F = nodes.SumMultiply('i,i', W, X, name='F')
+    tau = nodes.Gamma(1e-2, 1e-2, name='tau')
+    Y = nodes.GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None, lo:hi, :])
+    Y.observe(np.ascontiguousarray(y[:, lo:hi]))
+    Q = VB(Y, F, W, X, tau, alpha)
+    Q.ignore_bound_checks = True
+    rt = Runtime(device='cpu')
+    plan = Q.plans[0]
+    assert isinstance(plan, PCAPlan) and plan.mu0 is not None
+    plan._rt, plan._kernels = rt, CPURuntimeKernels(rt)
+    n = len(g['m3_L'])
+    Q.update(repeat=n, verbose=False)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), L=Q.L[:n], W=Q['W'].u[0],
+             alpha=Q['alpha'].u[0])
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_with_a_prior_mean_of_w(tmp_path):
+    world = 2
+    mp.spawn(_mean_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(GOLDEN, 'pca_prior_mean.npz'))
+    for r in range(world):
+        out = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        np.testing.assert_allclose(out['L'], g['m3_L'], rtol=1e-10)
+        np.testing.assert_allclose(out['W'], g['m3_W_u0'], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(out['alpha'], g['m3_alpha_u0'], rtol=1e-9)
