@@ -333,11 +333,17 @@ def test_bench_extra_records_are_compact():
     c = workloads.compact(full, 'gmm')
     assert c['leg'] == 'gmm' and c['ms_per_step'] == 2.92 and c['ms_max'] == 3.16
     assert c['frac'] == 0.851 and c['kernel_ms'] == 2.795 and c['parity_on'] == 'sample'
-    assert abs(c['traffic_over_alg'] - 1.0) < 2e-3 and c['cpu_cores'] == 128
+    assert abs(c['traffic_over_alg'] - 1.0) < 2e-3
+    # the usual values are left out (all 128 cores; no single slow step): nine legs, one 5 KB line
+    assert 'cpu_cores' not in c and 'argmax_step' not in c and 'wall_s' not in c
+    slow = dict(full, step_ms=dict(full['step_ms'], ms_max=49.0, argmax_step=7),
+                cpu_baseline=dict(full['cpu_baseline'], cores=1))
+    cs = workloads.compact(slow, 'gmm')
+    assert cs['argmax_step'] == 7 and cs['cpu_cores'] == 1
     assert len(json.dumps(c)) < 420
     err = workloads.compact({'error': 'RuntimeError: ' + 'q' * 500, 'wall_s': 1.0}, 'lssm')
     assert err['leg'] == 'lssm' and len(json.dumps(err)) < 260
-    assert len(json.dumps([c] * 8)) < 3400
+    assert len(json.dumps([c] * 9)) < 3400
 
 
 def test_contraction_plans_avoid_plates_sized_intermediates():

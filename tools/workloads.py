@@ -128,9 +128,11 @@ def compact(rec, leg):
         return None if v is None else float('%.*g' % (n, v))
     out = {'leg': leg, 'steps': rec.get('steps'), 'ms_per_step': r(rec.get('ms_per_step')),
            'ms_median': r(sp.get('ms_median')), 'ms_max': r(sp.get('ms_max')),
-           'argmax_step': sp.get('argmax_step'), 'it_s': r(rec.get('value')),
+           'it_s': r(rec.get('value')),
            'bound': roof.get('bound'), 'frac': r(roof.get('frac'), 3),
            'kernel_ms': r(roof.get('avg_launch_ms'))}
+    if sp.get('ms_max') and sp.get('ms_median') and sp['ms_max'] > 1.25 * sp['ms_median']:
+        out['argmax_step'] = sp.get('argmax_step')      # where the one slow step fell
     if roof.get('frac_alg') is not None:
         out['frac_alg'] = r(roof['frac_alg'], 3)
     if roof.get('kernel_ms'):
@@ -149,13 +151,14 @@ def compact(rec, leg):
         out['parity_on'] = 'whole' if 'elbo_rel_err_full' in cpu else 'sample'
     if cpu.get('value') is not None:
         out['cpu_it_s'] = r(cpu['value'], 3)
-        out['cpu_cores'] = cpu.get('cores')
+        if cpu.get('cores') not in (None, 128):       # (128 = all cores of the box: the default)
+            out['cpu_cores'] = cpu.get('cores')
     if rec.get('peak_mem_GB') is not None:
         out['peak_GB'] = r(rec['peak_mem_GB'], 3)
     sg = rec.get('config', {}).get('sweep_graph')
     if sg is not None:
         out['sweep'] = 'graph' if sg.get('recorded') else 'eager'
-    out['wall_s'] = round(rec.get('wall_s', 0), 1)
+    # (the wall time of a leg is in the verbose record, --full-out: nine legs must fit a 5 KB line)
     return out
 
 
