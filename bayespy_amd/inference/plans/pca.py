@@ -991,6 +991,15 @@ class PCAPlan:
                              % (dims, (self.D, self.N, self.K)))
         torch = self.rt.torch
         st = np.array(reader.get(base + 'state'), dtype=np.float64)
+        if st.size != int(self.layout.total):
+            # the packed state grew in round 5 (the prior mean of W and its sums at the end): a
+            # file of the older layout is its prefix, the new blocks are those of mu = 0
+            if st.size < int(self.layout.total) and self.mu0 is None \
+                    and st.size == int(self.layout.off_mu):
+                st = np.concatenate([st, np.zeros(int(self.layout.total) - st.size)])
+            else:
+                raise ValueError('checkpoint holds %d state values, this build of the fused PCA block '
+                                 'keeps %d' % (st.size, int(self.layout.total)))
         self.state.copy_(torch.from_numpy(st))
         self.Xd[:self.K, :self.N].copy_(torch.from_numpy(np.array(reader.get(base + 'X'),
                                                                  dtype=np.float64)))

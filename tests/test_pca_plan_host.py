@@ -566,3 +566,38 @@ def test_prior_mean_with_missing_values_goes_to_the_generic_engine(golden_dir):
     Y.observe(y, mask=np.random.RandomState(0).rand(D, N) < 0.8)
     assert MaskedPCAPlan.match([Y, F, W, X, tau, alpha]) is None
     assert PCAPlan.match([Y, F, W, X, tau, alpha]) is None
+
+
+def test_checkpoint_of_the_older_state_layout_loads(golden_dir):
+    """The packed state grew at its END in round 5 (prior mean of W and its sums): the state of a
+    file written before that is the prefix of today's and loads into a zero-mean model; a state of
+    any other length is refused with a message instead of a shape error from the copy."""
+    g = np.load(os.path.join(golden_dir, 'pca_n500_d6_k3.npz'))
+
+    class Reader:
+        def __init__(self, items):
+            self.items = items
+
+        def has(self, k):
+            return k in self.items
+
+        def get(self, k):
+            return self.items[k]
+
+    Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q.update(repeat=2, verbose=False)
+    items = {}
+    Q.plans[0].save_state(lambda k, v: items.__setitem__(k, np.asarray(v)), [], 0)
+    old_len = int(Q.plans[0].layout.off_mu)              # where the state ended before round 5
+    assert old_len < items['plans/0/state'].size
+    items['plans/0/state'] = items['plans/0/state'][:old_len]
+    Q.update(repeat=2, verbose=False)
+    Q2 = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
+    Q2.update(repeat=1, verbose=False)                    # (device state exists; the load overwrites it)
+    Q2.plans[0].load_state(Reader(items), [], 0)
+    Q2.iter = 2
+    Q2.update(repeat=2, verbose=False)
+    np.testing.assert_array_equal(np.array(Q2.L[2:4]), np.array(Q.L[2:4]))
+    items['plans/0/state'] = items['plans/0/state'][:-3]
+    with pytest.raises(ValueError, match='state values'):
+        Q2.plans[0].load_state(Reader(items), [], 0)
