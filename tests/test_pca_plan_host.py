@@ -587,7 +587,8 @@ def test_checkpoint_of_the_older_state_layout_loads(golden_dir):
     Q = _attach_cpu(build_pca(nodes, VB, g['y'], g['x0'], 3))
     Q.update(repeat=2, verbose=False)
     items = {}
-    Q.plans[0].save_state(lambda k, v: items.__setitem__(k, np.asarray(v)), [], 0)
+    # (copies: on the CPU double the saved views alias the live arrays)
+    Q.plans[0].save_state(lambda k, v: items.__setitem__(k, np.array(v)), [], 0)
     old_len = int(Q.plans[0].layout.off_mu)              # where the state ended before round 5
     assert old_len < items['plans/0/state'].size
     items['plans/0/state'] = items['plans/0/state'][:old_len]
