@@ -448,8 +448,12 @@ int32_t vmp_lssmm_x_update(vmp_ctx *ctx, int32_t given, const double *Yt, const 
             const size_t ldsf = lds + (size_t)A.nib_len * sizeof(double);
             // M <= 8 with the nibble tables: the straight-line step (observation terms a step ahead)
             if (M <= 8 && D <= 4 && A.nib_len > 0) {
-#define LSSMM_FWD(d, gg) hipLaunchKernelGGL((lssmm_forward_kernel<d, gg, 8>), dim3((unsigned)g), dim3(WNT), ldsf, s, Af);
-                LSSMM_FOR_DG(LSSMM_FWD)
+                // (D <= 4 only: no instance of this form is compiled for the wider blocks)
+#define LSSMM_FWD(d)                                                                                 \
+    if (G == 1) hipLaunchKernelGGL((lssmm_forward_kernel<d, 1, 8>), dim3((unsigned)g), dim3(WNT), ldsf, s, Af);  \
+    else hipLaunchKernelGGL((lssmm_forward_kernel<d, GMAX, 8>), dim3((unsigned)g), dim3(WNT), ldsf, s, Af);
+                switch (D) { case 1: LSSMM_FWD(1) break; case 2: LSSMM_FWD(2) break;
+                             case 3: LSSMM_FWD(3) break; default: LSSMM_FWD(4) break; }
 #undef LSSMM_FWD
             } else {
 #define LSSMM_FWD(d, gg) hipLaunchKernelGGL((lssmm_forward_kernel<d, gg, 64>), dim3((unsigned)g), dim3(WNT), ldsf, s, Af);
