@@ -166,6 +166,17 @@ class GraphIteration:
         return leaves, sig
 
     @staticmethod
+    def _dead_inputs(sig, leaves, upd):
+        """Per leaf of a state snapshot: is it the natural parameters or the log-normaliser of a
+        node the sweep updates (``upd``)?  Those are written before anything in the sweep reads
+        them, so the recorded graph never reads the copy it was given."""
+        tags = [e[0] for e in sig if len(e) >= 2 and e[1] == 'tensor']
+        if len(tags) != len(leaves) or os.environ.get('BAYESPY_AMD_GRAPH_COPY_ALL') == '1':
+            return [False] * len(leaves)
+        upd_ids = set(id(n) for n in upd)
+        return [len(t) >= 2 and t[0] in upd_ids and t[1] in ('phi', 'g') for t in tags]
+
+    @staticmethod
     def _rewrap(obj, memo):
         """Fresh wrapper objects around the same device tensors: identity-keyed caches and lazily
         evaluated dense forms made from the previous contents cannot be reached through them."""
@@ -307,11 +318,7 @@ class GraphIteration:
             # node's bound term, after its update): as inputs of the graph they are dead, and the
             # copy-back of a replay leaves them out -- at config 2 of the PCA model 136 of 264 MB.
             # (An array that is also reachable through a live field keeps its copy.)
-            tags = [e[0] for e in sig_old if len(e) >= 2 and e[1] == 'tensor']
-            upd_ids = set(id(n) for n in upd)
-            dead_tag = [len(t) >= 2 and t[0] in upd_ids and t[1] in ('phi', 'g') for t in tags]
-            if len(tags) != len(old) or os.environ.get('BAYESPY_AMD_GRAPH_COPY_ALL') == '1':
-                dead_tag = [False] * len(old)
+            dead_tag = self._dead_inputs(sig_old, old, upd)
             live_ptrs = set(o.data_ptr() for o, d in zip(old, dead_tag) if not d)
             seen, pairs = set(), []
             for o, n_, d in zip(old, new, dead_tag):

@@ -254,3 +254,30 @@ def test_vb_offers_a_sweep_to_one_generic_plan_only():
     assert VB._graph_sweep(Q, ['a']) is False
     Q.model = [node('b', None)]
     assert VB._graph_sweep(Q, ['b']) is False
+
+
+def test_dead_inputs_of_a_recorded_sweep(monkeypatch):
+    """Which leaves of the state snapshot the replay's copy-back may leave out: the natural
+    parameters and the log-normaliser of the nodes the sweep updates -- not their moments, and
+    nothing of a node the sweep only reads (graph_iter.py:_dead_inputs)."""
+    from bayespy_amd.inference.plans.graph_iter import GraphIteration
+
+    class N:
+        pass
+    a, b = N(), N()
+    sig = [((id(a), 'u'), 'list', 2), ((id(a), 'u', 0), 'tensor', (4,)), ((id(a), 'u', 1), 'factored', 1),
+           ((id(a), 'u', 1, 'cov'), 'tensor', (2, 2)), ((id(a), 'u', 1, 'mean'), 'tensor', (4,)),
+           ((id(a), 'phi'), 'list', 2), ((id(a), 'phi', 0), 'tensor', (4,)), ((id(a), 'phi', 1), 'tensor', (2, 2)),
+           ((id(a), 'g'), 'tensor', (4,)), ((id(a), 'f'), 'host', None),
+           (id(a), 'flags', False, False, True, False),
+           ((id(b), 'u', 0), 'tensor', (3,)), ((id(b), 'phi', 0), 'tensor', (3,)), ((id(b), 'g'), 'tensor', ()),
+           (id(b), 'flags', False, False, True, False)]
+    leaves = list(range(9))
+    dead = GraphIteration._dead_inputs(sig, leaves, [a])
+    assert dead == [False, False, False, True, True, True, False, False, False]
+    assert GraphIteration._dead_inputs(sig, leaves, [a, b]) == [False, False, False, True, True, True,
+                                                               False, True, True]
+    # a snapshot whose tags do not line up with its leaves, or the opt-out: everything is copied
+    assert GraphIteration._dead_inputs(sig, leaves[:-1], [a]) == [False] * 8
+    monkeypatch.setenv('BAYESPY_AMD_GRAPH_COPY_ALL', '1')
+    assert GraphIteration._dead_inputs(sig, leaves, [a, b]) == [False] * 9
