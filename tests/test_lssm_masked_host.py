@@ -179,22 +179,24 @@ def _worker(rank, world, port, tag, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    g = np.load(os.path.join(GOLDEN, 'lssm_masked.npz'))
+    g = golden_of(tag)
     y, mask, x0, c0 = g[tag + '_y'], g[tag + '_mask'], g[tag + '_x0'], g[tag + '_c0']
     B = y.shape[1]
     lo, hi = (0, 2) if rank == 0 else (2, B)               # ragged shards of the sequence plate
     mk = mask if mask.shape[1] == 1 else mask[:, lo:hi]
-    Q, track = build(y[:, lo:hi], mk, x0[lo:hi], c0, hi - lo, tag in ('mb', 'me'), shard=True)
+    nu = dict((t, n_) for t, _, n_ in CASES + WIDE_CASES)[tag]
+    Q, track = build(y[:, lo:hi], mk, x0[lo:hi], c0, hi - lo, nu, shard=True)
     n = len(g[tag + '_L'])
     Q.update(repeat=n, verbose=False)
     q.put((rank, np.array(Q.L[:n]), track['C'].u[0], track['X'].u[0]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('tag', ['mb', 'me', 'ms'])
+@pytest.mark.parametrize('tag', ['mb', 'me', 'ms', 'w6', 'w7'])
 def test_sharded_sequence_plate_world2_gloo(tag):
     """Two ranks, the sequence plate split 2 + (B - 2): the unsharded live-reference trace on both
-    ranks (set-up counts and every plate sum all-reduced), each rank's own <x>."""
+    ranks (set-up counts and every plate sum all-reduced), each rank's own <x>; w6 / w7: six and
+    seven states (two rows of the blocks per lane)."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -207,7 +209,7 @@ def test_sharded_sequence_plate_world2_gloo(tag):
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
-    g = np.load(os.path.join(GOLDEN, 'lssm_masked.npz'))
+    g = golden_of(tag)
     for rank, L, cu0, xu0 in res:
         np.testing.assert_allclose(L, g[tag + '_L'], rtol=1e-9)
         np.testing.assert_allclose(cu0, g[tag + '_C_u0'], rtol=1e-7, atol=1e-9)
