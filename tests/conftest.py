@@ -24,6 +24,13 @@ def pytest_collection_modifyitems(config, items):
         has_gpu = False
     if has_gpu:
         return
+    if os.environ.get('BAYESPY_AMD_HOST_DOUBLE') == '1':
+        # development aid: the generic-engine GPU tests run here against the NumPy double of
+        # the generic entry points (tests/host_generic.py) -- host logic only, no kernel is
+        # exercised; tests that need a fused block or the device itself fail / are skipped
+        from host_generic import install
+        install()
+        return
     skip = pytest.mark.skip(reason='no GPU visible')
     for item in items:
         if 'gpu' in item.keywords:

@@ -1,4 +1,5 @@
-"""Op-level trace of one generic-engine PCA iteration (BASELINE config 2): every fused elementwise
+"""Op-level trace of one generic-engine iteration (argument: pca = BASELINE config 2, gmm = the
+mixture of bench.py --config generic_gmm): every fused elementwise
 launch and every sum_multiply / GEMM launch with shapes and its synchronous duration."""
 import os, sys, time, traceback
 # launch by launch: no replay from the sweep graph, no queue of small operations
@@ -47,20 +48,36 @@ def fuse_t(fn, *ops):
 darray.fuse = fuse_t; G.fuse = fuse_t; misc.fuse = fuse_t
 import bayespy_amd.utils.linalg as LA
 if hasattr(LA, 'fuse'): LA.fuse = fuse_t
-from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+MODEL = sys.argv[1] if len(sys.argv) > 1 else 'pca'
 from bayespy_amd.inference import VB
-N, D, K = 1_000_000, 64, 16
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev); g.manual_seed(42)
-w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)
-x = torch.randn(K, N, generator=g, device=dev, dtype=torch.float64)
-y = w @ x + 0.1 * torch.randn(D, N, generator=g, device=dev, dtype=torch.float64)
-x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
-alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha'); W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
-X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X'); F = SumMultiply('i,i', W, X, name='F')
-tau = Gamma(1e-2, 1e-2, name='tau'); Y = GaussianARD(F, tau, name='Y')
-X.initialize_from_value(x0[None]); Y.observe(y)
-Q = VB(Y, F, W, X, tau, alpha, engine='generic'); Q.ignore_bound_checks = True
+if MODEL == 'pca':
+    from bayespy_amd.nodes import GaussianARD, Gamma, SumMultiply
+    N, D, K = 1_000_000, 64, 16
+    w = torch.randn(D, K, generator=g, device=dev, dtype=torch.float64)
+    x = torch.randn(K, N, generator=g, device=dev, dtype=torch.float64)
+    y = w @ x + 0.1 * torch.randn(D, N, generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
+    alpha = Gamma(1e-2, 1e-2, plates=(K,), name='alpha'); W = GaussianARD(0, alpha, shape=(K,), plates=(D, 1), name='W')
+    X = GaussianARD(0, 1, shape=(K,), plates=(1, N), name='X'); F = SumMultiply('i,i', W, X, name='F')
+    tau = Gamma(1e-2, 1e-2, name='tau'); Y = GaussianARD(F, tau, name='Y')
+    X.initialize_from_value(x0[None]); Y.observe(y)
+    Q = VB(Y, F, W, X, tau, alpha, engine='generic'); Q.ignore_bound_checks = True
+else:
+    # the mixture of bench.py --config generic_gmm
+    from bayespy_amd.nodes import GaussianARD, Gaussian, Wishart, Dirichlet, Categorical, Mixture
+    N, D, K = 100_000, 16, 32
+    centers = 3 * torch.randn(K, D, generator=g, device=dev, dtype=torch.float64)
+    lab = torch.randint(0, K, (N,), generator=g, device=dev)
+    y = centers[lab] + 0.5 * torch.randn(N, D, generator=g, device=dev, dtype=torch.float64)
+    lab0 = torch.randint(0, K, (N,), generator=g, device=dev)
+    alpha = Dirichlet(1e-3 * np.ones(K), name='alpha'); z = Categorical(alpha, plates=(N,), name='z')
+    mu = GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
+    Lam = Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
+    Y = Mixture(z, Gaussian, mu, Lam, plates=(N,), name='Y')
+    z.initialize_from_value(lab0.cpu().numpy()); Y.observe(y)
+    Q = VB(Y, mu, Lam, z, alpha, engine='generic'); Q.ignore_bound_checks = True
 Q.update(repeat=2, verbose=False)
 torch.cuda.synchronize()
 t = time.perf_counter(); Q.update(repeat=3, verbose=False); torch.cuda.synchronize()
@@ -73,7 +90,7 @@ print('traced launches', len(LOG), 'sum ms', round(tot, 2))
 for l in sorted(LOG, key=lambda l: -l[0])[:40]:
     print('%7.3f %-3s %-110s %s' % l)
 os.makedirs('gpurun_out', exist_ok=True)
-with open('gpurun_out/gen_trace_seq.txt', 'w') as f:
+with open('gpurun_out/gen_trace_seq_%s.txt' % MODEL, 'w') as f:
     for l in LOG:
         f.write('%7.3f %-3s %-110s %s\n' % l)
 print('peak GB', torch.cuda.max_memory_allocated() / 1e9)
