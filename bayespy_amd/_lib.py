@@ -194,6 +194,10 @@ SIGNATURES = {
                           c_i32, P(c_f64), c_vp]),
     'vmp_spd_batched': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'vmp_gaussian_moments': (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'vmp_gaussian_shared_update_workspace_bytes': (c_sz, [c_i32, c_i32]),
+    'vmp_gaussian_shared_update': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp,
+                                           c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp,
+                                           c_i64, c_i64, c_vp, c_vp, c_sz]),
     'vmp_softmax_moments': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_onehot_i64': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'vmp_alpha_beta_recursion': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64,

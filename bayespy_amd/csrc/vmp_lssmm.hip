@@ -547,12 +547,13 @@ int32_t vmp_lssmm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, const
     const size_t lds = (size_t)A.L.total * sizeof(double);
     if (lds + sizeof(double) * lssmm_small_scratch(64) > 64 * 1024) {
         // beyond the default 64 KB of a workgroup (D = 8 with many rows of C): gfx950 has 160 KB
-        static bool raised = false;
-        if (!raised) {
+        static bool raised[64] = {false};          // per device of the process
+        const int dev = ctx->device & 63;
+        if (!raised[dev]) {
             VMP_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(lssmm_small_kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    120 * 1024));
-            raised = true;
+            raised[dev] = true;
         }
     }
     hipLaunchKernelGGL(lssmm_small_kernel, dim3(1), dim3(64), lds, ctx->stream, A, state);

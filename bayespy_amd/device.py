@@ -261,20 +261,35 @@ class Runtime:
         return self._op_depth > 0 and self._queue_env and self.lib is not None \
             and self._tune_sm
 
-    def keep_until_flush(self, arrays, out):
+    def keep_until_flush(self, arrays, out, kind='ew'):
         """A queued operation runs LATER: its operands and its result must not go back to the
         allocator before (a block handed out again would be written by something else first).
-        Only small arrays are ever queued; the list is dropped at every flush this side knows of."""
-        if self._op_depth > 0 and self.lib is not None:
-            self._queue_alive.append((arrays, out))
+        References are kept only when the library can have queued the call -- the queue is open,
+        the tune of this kind of operation (``'ew'`` formulas, ``'sm'`` sums and inverses) is on,
+        and the result is small (the library queues <= 2048 outputs) -- so plate-sized temporaries
+        go back to the allocator at once, also inside a sweep recording (where both tunes are off);
+        the list is dropped at every flush this side knows of."""
+        if self._op_depth == 0 or self.lib is None or not self._queue_env:
+            return
+        if not (self._tune_sm if kind == 'sm' else self._tune_ew):
+            return
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        for o in outs:
+            t = getattr(o, 't', o)
+            if hasattr(t, 'numel') and t.numel() > 2048:
+                return
+        self._queue_alive.append((arrays, out))
 
     _tune_sm = False
+    _tune_ew = True
 
     def set_tune(self, key, value):
         if self.lib is not None:
             self.check(self.lib.vmp_tune_set(key.encode(), int(value)))
             if key == 'small_queue_sm':
                 self._tune_sm = bool(value)
+            elif key == 'small_queue_ew':
+                self._tune_ew = bool(value)
 
     def queue_stats(self):
         if self.ctx is None or self.lib is None:

@@ -21,12 +21,13 @@ Differences from the reference's design (not its results):
 * plate sums, masks and the integer plate multiplier (utils/misc.py:761-844)
   are a single ``sum_multiply_to_plates`` launch per message.
 """
+import ctypes
 import os
 
 import numpy as np
 
 from ... import darray as da
-from ...darray import DArray, fuse
+from ...darray import DArray, fuse, contiguous
 from ...nodes.node import Constant, Stochastic
 from ...nodes.gamma import Gamma
 from ...nodes.gaussian import (GaussianARD, Gaussian, GaussianGamma, GaussianToGaussianGamma,
@@ -82,14 +83,16 @@ class FactoredMoment(DArray):
     the product of (Cov + x x^T) terms, the Gamma message takes diag(Cov) + x^2, the bound takes
     phi : Cov + x^T phi x -- and anything else sees an ordinary device array: ``.t`` forms the
     dense array on first use (same values as the reference's)."""
-    __slots__ = ('cov', 'mean', 'nd', '_dense', 'logdet_prec')
+    __slots__ = ('cov', 'mean', 'nd', '_dense', 'logdet_prec', 'sums')
 
-    def __init__(self, cov, mean, nd, logdet_prec=None):
+    def __init__(self, cov, mean, nd, logdet_prec=None, sums=None):
         self.cov, self.mean, self.nd = cov, mean, int(nd)
         self._dense = None
         # log|Cov^-1| with the plates of ``cov`` (no variable axes), or None when the maker does
         # not have it (point masses, rotated moments): the bound term then takes the general route
         self.logdet_prec = logdet_prec
+        # plate sums of the means made by the pass that wrote them (PlateSums), or None
+        self.sums = sums
 
     @property
     def t(self):
@@ -112,6 +115,60 @@ class FactoredMoment(DArray):
     @property
     def size(self):
         return int(np.prod(self.shape))
+
+
+class PlateSums:
+    """Sums over the plates of the posterior means <x_n> of a shared-covariance Gaussian node, made
+    by the pass that wrote the means (vmp_gaussian_shared_update): ``x`` = sum_n <x_n> (K),
+    ``xx`` = sum_n <x_n><x_n>^T (K, K) and, when the pass streamed the data array Y of the Dot
+    message, ``yx`` = sum_n y_n <x_n>^T (D, K) with ``ydesc`` = (address, stride along the rows,
+    stride along the plates, D) of that array and ``ykeep`` the tensor itself.  They are part of
+    the node's state (the next sweep's first message reads them) and are offered to whoever asks
+    for the same reductions through the plan's memo (GenericPlan._seed_sums)."""
+    __slots__ = ('x', 'xx', 'yx', 'ydesc', 'ykeep', 'n')
+
+    def __init__(self, x, xx, yx=None, ydesc=None, ykeep=None, n=0):
+        self.x, self.xx, self.yx, self.ydesc, self.ykeep, self.n = x, xx, yx, ydesc, ykeep, int(n)
+
+
+class DerivedArray(DArray):
+    """A state array that is a function of other state arrays and is formed only if somebody
+    reads it: the natural parameter phi0 = Lambda <x> and the log-normaliser
+    g = -<x>^T Lambda <x> / 2 + log|Lambda| / 2 of a shared-covariance Gaussian node after the fused
+    update (the reference stores both, gaussian.py:649-706; here nothing in a sweep reads them)."""
+    __slots__ = ('kind', 'deps', '_shape', '_dense')
+
+    def __init__(self, kind, deps, shape):
+        self.kind, self.deps, self._shape = kind, tuple(deps), tuple(shape)
+        self._dense = None
+
+    @property
+    def t(self):
+        if self._dense is None:
+            if self.kind == 'gauss_phi0':
+                phi1, x = self.deps
+                lam = fuse(lambda p: -2.0 * p, phi1)
+                self._dense = linalg.mvdot(lam, x).t
+            elif self.kind == 'gauss_g':
+                phi1, x, ld = self.deps
+                lam = fuse(lambda p: -2.0 * p, phi1)
+                q = misc.sum_multiply(linalg.mvdot(lam, x), x, axis=-1)
+                self._dense = fuse(lambda q_, l: -0.5 * q_ + 0.5 * l, q, ld).t
+            else:
+                raise ValueError(self.kind)
+        return self._dense
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return len(self._shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self._shape))
 
 
 class LazySum(DArray):
@@ -154,11 +211,12 @@ class LazyContract(DArray):
     (``misc.contract_path``: sum_dn y_dn w_dk x_nk = sum_dk w_dk (Y X^T)_dk, a K-sliced GEMM, and
     sum <f>^2 = (W^T W) : (X^T X)) without the (D, N) array; anything else sees an ordinary device
     array: ``.t`` evaluates the contraction on first use."""
-    __slots__ = ('ops', 'labs', 'out', 'sizes', 'compress', '_shape', '_dense')
+    __slots__ = ('ops', 'labs', 'out', 'sizes', 'compress', '_shape', '_dense', '_make')
 
-    def __init__(self, ops, labs, out, sizes, compress):
+    def __init__(self, ops, labs, out, sizes, compress, make=None):
         self.ops, self.labs, self.out = list(ops), [list(l) for l in labs], list(out)
         self.sizes, self.compress = dict(sizes), tuple(compress)
+        self._make = make          # how to form the dense array, if not as ONE contraction launch
         var = set()
         for a, ls in zip(self.ops, self.labs):
             for ax, lab in enumerate(ls):
@@ -171,8 +229,12 @@ class LazyContract(DArray):
     @property
     def t(self):
         if self._dense is None:
-            self._dense = misc.contract(self.ops, self.labs, self.out, self.sizes,
-                                        compress=self.compress).t
+            if self._make is not None:
+                self._dense = self._make().t
+                self._make = None
+            else:
+                self._dense = misc.contract(self.ops, self.labs, self.out, self.sizes,
+                                            compress=self.compress).t
         return self._dense
 
     @property
@@ -220,6 +282,20 @@ def _inner_second(phi, xx, nd):
         b = misc.sum_multiply(linalg.mvdot(pf, xf), xf, axis=-1)
         return fuse(lambda p, q: p + q, a, b)
     return misc.sum_multiply(_arr(phi), _arr(xx), axis=axes)
+
+
+def _lazy_mvdot(A, b):
+    """linalg.mvdot(A, b) -- (..., D, E) . (..., E) -> (..., D) with broadcast plates -- as a
+    LazyContract: whoever plate-sums a product that contains it plans the contraction pair by
+    pair; anything else sees the array (``.t`` evaluates it)."""
+    npl = max(A.ndim - 2, b.ndim - 1)
+    q = ['q%d' % i for i in range(npl)]
+    la = q[npl - (A.ndim - 2):] + ['d', 'e']
+    lb = q[npl - (b.ndim - 1):] + ['e']
+    plates = broadcasted_shape(A.shape[:-2], b.shape[:-1])
+    sizes = {lab: s for lab, s in zip(q, plates)}
+    sizes['d'], sizes['e'] = A.shape[-2], A.shape[-1]
+    return LazyContract([A, b], [la, lb], q + ['d'], sizes, q)
 
 
 _CONSTS = {}
@@ -632,6 +708,13 @@ class GaussianFamily(Family):
         m, mm = up[0]
         L = up[1][0]
         if index == 0:
+            if getattr(self, '_terms_ok', False) and isinstance(L, DArray) and isinstance(x, DArray) \
+                    and not isinstance(x, (LazySum, LazyContract)):
+                # Lambda x stays a contraction: under a mixture it is weighted by the
+                # responsibilities and summed over the plates, sum_n r_nk Lambda_k x_n =
+                # Lambda_k (sum_n r_nk x_n) -- the (N, K, D) array of the reference
+                # (gaussian.py:2451-2454 under mixture.py:126-158) is never formed
+                return [_lazy_mvdot(L, x), fuse(lambda l: -0.5 * l, L)]
             return [linalg.mvdot(L, x), fuse(lambda l: -0.5 * l, L)]
         if getattr(self, '_terms_ok', False) and all(isinstance(a, DArray) for a in (x, xx, m, mm)):
             # -(<xx^T> - <x><m>^T - <m><x>^T + <mm^T>) / 2 as four products: whoever sums it over
@@ -1074,25 +1157,59 @@ class MixtureFamily(Family):
     def gradient(self, rg, u, phi):
         return self.base.gradient(rg, u, phi)          # mixture.py:352-356
 
+    def _loglik(self, u, up, uk=None):
+        """E[log p(y | cluster k)] - f(y) for every plate and cluster (mixture.py:67-104,
+        expfamily.py:45-61); ``up`` with the cluster axis last.  f(y) is left out like in the
+        reference (it passes f = 0, mixture.py:92-98): it is the same for every cluster and cancels
+        in the normalisation of q(z).  The last answer stands while the arrays it was made from are
+        the same objects: the message to the assignments and, one node later, the bound term of
+        the observed mixture ask for the same array."""
+        deps = [a for a in u] + [a for j in up[1:] for a in j]
+        key = tuple(id(a) for a in deps)
+        hit = getattr(self, '_ll_cache', None)
+        if hit is not None and hit[0] == key and all(isinstance(a, DArray) for a in deps):
+            return hit[2]
+        if uk is None:
+            uk = self._with_cluster_axis(u)
+        phik = self.base.phi_from_parents(up[1:])
+        L = _arr(self.base.cgf_from_parents(up[1:]))
+        for ph, ui, nd in zip(phik, uk, self.ndims):
+            if nd > 0 and getattr(self.base, 'finite_phi', False):
+                # phi_k . u_n as a contraction (plates x clusters, over the variable axes: a
+                # matrix-core GEMM) -- not a plates x clusters x D x D product and its sum
+                t = misc.sum_multiply(_arr(ph), ui, axis=tuple(range(-nd, 0)))
+                L = fuse(lambda a, b: a + b, L, t)
+                continue
+            t = fuse(lambda a, b: da.where_nonzero(b, a) * b, _arr(ph), ui)
+            L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
+        self._ll_cache = (key, deps, L)          # `deps` keeps the keyed arrays alive
+        return L
+
+    def observed_bound_terms(self, u, up):
+        """cgf_from_parents + f + phi_p . u of a fully observed mixture over its plates
+        (expfamily.py:400-480 with mixture.py:53-65): sum_k r_nk (g_k + phi_k . u_n) + f_n -- the
+        responsibilities times the array the message to the assignments is made of, instead of
+        forming phi_n = sum_k r_nk phi_k (plates x D x D) and contracting it with u_n.  None when
+        the mixed family's natural parameters may be infinite (0 * inf needs the guarded form)."""
+        if not getattr(self.base, 'finite_phi', False) or isinstance(self.base, MixtureFamily):
+            return None
+        if os.environ.get('BAYESPY_AMD_MIXTURE_BOUND', '1') == '0':
+            return None
+        up = self._cluster_last(up)
+        p = up[0][0]
+        if not isinstance(p, DArray) or not all(isinstance(a, DArray) for a in u):
+            return None
+        L = self._loglik(u, up)
+        if tuple(broadcasted_shape(p.shape, L.shape)[:-1]) != \
+                tuple(broadcasted_shape(self.node.plates, p.shape[:-1], L.shape[:-1])):
+            return None
+        return [(1.0, [misc.sum_multiply(p, L, axis=-1)])]
+
     def message_to_parent(self, index, u, up):
         up = self._cluster_last(up)
         uk = self._with_cluster_axis(u)
         if index == 0:
-            # E[log p(y | cluster k)] for every cluster (mixture.py:67-104, expfamily.py:45-61)
-            phik = self.base.phi_from_parents(up[1:])
-            # f(y) is left out like in the reference (it passes f = 0, mixture.py:92-98): it
-            # is the same for every cluster and cancels in the normalisation of q(z)
-            L = _arr(self.base.cgf_from_parents(up[1:]))
-            for ph, ui, nd in zip(phik, uk, self.ndims):
-                if nd > 0 and getattr(self.base, 'finite_phi', False):
-                    # phi_k . u_n as a contraction (plates x clusters, over the variable axes: a
-                    # matrix-core GEMM) -- not a plates x clusters x D x D product and its sum
-                    t = misc.sum_multiply(_arr(ph), ui, axis=tuple(range(-nd, 0)))
-                    L = fuse(lambda a, b: a + b, L, t)
-                    continue
-                t = fuse(lambda a, b: da.where_nonzero(b, a) * b, _arr(ph), ui)
-                L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
-            return [L]
+            return [self._loglik(u, up, uk)]
         p = up[0][0]
         self.base._terms_ok = getattr(self, '_terms_ok', False) and not isinstance(self.base, MixtureFamily)
         try:
@@ -1443,9 +1560,20 @@ class SumMultiplyFamily:
             # (a key of the second copy that is an OUTPUT key stays; one that is contracted goes)
             t_out = [l for l in pl if l in used] + [l for l in out1 if l not in pl and l in used]
             t_out += [l for l in keys_k if l in used and l not in t_out]
-            T = misc.contract([o[0] for o in rest] + [xK], [o[1] for o in rest] + [lK], t_out, sizes,
-                              compress=pl)
-            terms.append(('t', misc.contract([T, xk], [t_out, lk], out1, sizes, compress=pl)))
+            def two_steps(rest=rest, xK=xK, lK=lK, xk=xk, lk=lk, t_out=t_out):
+                T = misc.contract([o[0] for o in rest] + [xK], [o[1] for o in rest] + [lK], t_out,
+                                  sizes, compress=pl)
+                return misc.contract([T, xk], [t_out, lk], out1, sizes, compress=pl)
+            if nk == 0 and os.environ.get('BAYESPY_AMD_LAZY_SUMS', '1') != '0' \
+                    and os.environ.get('BAYESPY_AMD_LAZY_QUAD', '1') != '0':
+                # x^T C x per plate stays a contraction (dense form: the two steps above): whoever
+                # sums it over the plates contracts <x><x>^T first -- sum_n x_n^T C x_n = C : sum_n
+                # x_n x_n^T, a sum the sweep has anyway -- and never forms the per-plate rows
+                terms.append(('t', LazyContract([o[0] for o in rest] + [xK, xk],
+                                                [o[1] for o in rest] + [lK, lk], out1, sizes, pl,
+                                                make=two_steps)))
+            else:
+                terms.append(('t', two_steps()))
         arrs = [t[1] for t in terms if t[0] == 't']
         if any(t[0] == 'sq' for t in terms):
             if nk == 0 and os.environ.get('BAYESPY_AMD_LAZY_SUMS', '1') != '0':
@@ -1484,7 +1612,7 @@ class SumMultiplyFamily:
         par = n.parents[index]
         npl, nparpl = len(pl), len(par.plates)
 
-        def one_term(ops, labs, second):
+        def one_term(ops, labs, second, lazy=False):
             present = set()
             for a, ls in zip(ops, labs):
                 for ax, lab in enumerate(ls):
@@ -1528,6 +1656,25 @@ class SumMultiplyFamily:
                         a0 = fuse(lambda a_, b_: a_ * b_, a0, s_.reshape(()))
                     rest[small] = (a0, rest[small][1])
                     ones = []
+                if lazy and not ones and mult == 1 and len(rest) == 2 \
+                        and max(a.size for a, _ in rest) >= int(
+                            os.environ.get('BAYESPY_AMD_LAZY_DOT_MIN', 1 << 14)):
+                    # the message stays a contraction of its two operands (the data and the other
+                    # parent's means): the receiving node's update may stream the data itself
+                    # (GenericPlan._shared_cov_update); anything else evaluates it on first use
+                    outl, sz, nu = [], dict(sizes), 0
+                    for ax, lab in enumerate(pl):
+                        pax = ax - (npl - nparpl)
+                        if pax < 0:
+                            continue
+                        if par.plates[pax] != 1 and lab in present:
+                            outl.append(lab)
+                        else:
+                            sz['u%d' % nu] = 1
+                            outl.append('u%d' % nu)
+                            nu += 1
+                    return LazyContract([a for a, _ in rest], [ls for _, ls in rest],
+                                        outl + keys, sz, ())
                 res = misc.contract([a for a, _ in rest], [ls for _, ls in rest], lout + keys,
                                     sizes, scale=float(mult)).reshape(final)
                 for s_ in ones:
@@ -1565,7 +1712,7 @@ class SumMultiplyFamily:
                     lj = self._parent_labels(j, False)
                     ops.append(a)
                     labs.append(lj[len(lj) - a.ndim:])
-                out.append(one_term(ops, labs, False))
+                out.append(one_term(ops, labs, False, lazy=getattr(self, '_lazy_first', False)))
                 continue
             # second moments of the other parents: dense, or factored (Cov + <x><x>^T) and then
             # expanded term by term -- e.g. the message to W of a PCA model,
@@ -1666,6 +1813,8 @@ def _operation(method):
         misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
         try:
             with rt.operation():
+                if rt._op_depth == 1:
+                    self._seed_sums()
                 return method(self, *args, **kwargs)
         finally:
             misc._CUR_MEMO[0] = prev
@@ -2050,10 +2199,7 @@ class GenericPlan(GraphIteration):
                 from_shape = plates_self + dims
                 if mask is not None:
                     factors.append(_trail(mask, nd))
-                t = self._plate_sum(factors, to_shape, from_shape) \
-                    if isinstance(m, Terms) or _is_lazy(m) else \
-                    misc.sum_multiply_to_plates(*factors, to_plates=to_shape,
-                                                from_plates=from_shape, ndim=0)
+                t = self._plate_sum(factors, to_shape, from_shape)
                 c = float(coef) * r
                 if msg is None:
                     msg = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
@@ -2109,14 +2255,29 @@ class GenericPlan(GraphIteration):
         return total
 
     # -- node operations -------------------------------------------------------------------------
-    def _optimal_phi(self, node):
-        """Natural parameters of the VB-optimal factor: prior from the parents plus the
-        messages of the children (expfamily.py:215-257)."""
+    def _phi_parts(self, node, lazy=False):
+        """(prior natural parameters from the parents, summed messages of the children);
+        ``lazy``: a Dot child may hand its first-moment message over as a contraction."""
         fam = self.family[id(node)]
         up = self._parent_moments(node)
         phi = fam.phi_from_parents(up)
-        msgs = self._messages_from_children(node)
+        flagged = []
+        if lazy:
+            for c, _ in node.children:
+                cf = self.family.get(id(c))
+                if isinstance(cf, SumMultiplyFamily):
+                    cf._lazy_first = True
+                    flagged.append(cf)
+        try:
+            msgs = self._messages_from_children(node)
+        finally:
+            for cf in flagged:
+                cf._lazy_first = False
+        return phi, msgs
+
+    def _combine_phi(self, node, phi, msgs):
         a = float(getattr(node, 'annealing', 1.0))
+        phi = list(phi)
         for i in range(len(phi)):
             if msgs[i] is not None:
                 phi[i] = fuse(lambda p, m: p + m, _arr(phi[i]), msgs[i])
@@ -2124,6 +2285,164 @@ class GenericPlan(GraphIteration):
                 # deterministic annealing (expfamily.py:343-350)
                 phi[i] = fuse(lambda p, a_=a: a_ * p, _arr(phi[i]))
         return phi
+
+    def _optimal_phi(self, node):
+        """Natural parameters of the VB-optimal factor: prior from the parents plus the
+        messages of the children (expfamily.py:215-257)."""
+        phi, msgs = self._phi_parts(node)
+        return self._combine_phi(node, phi, msgs)
+
+    # -- the fused update of a shared-covariance Gaussian node (vmp_gaussian_shared_update) ------
+    def _shared_cov_candidate(self, node, fam):
+        if os.environ.get('BAYESPY_AMD_SHARED_UPDATE', '1') == '0':
+            return False
+        if type(fam) not in (GaussianARDFamily, GaussianFamily) or fam.ndim != 1 \
+                or getattr(fam, 'mu_gg', False):
+            return False
+        if float(getattr(node, 'annealing', 1.0)) != 1.0:
+            return False
+        K = int(fam.shape[0])
+        nplates = int(np.prod(node.plates)) if node.plates else 1
+        return 1 <= K <= 64 and nplates >= max(_factored_min_plates(), 2) \
+            and hasattr(self.rt.lib, 'vmp_gaussian_shared_update')
+
+    @staticmethod
+    def _dot_operands(msg, K):
+        """(Y tensor, stride along its rows d, stride along the plates n, D, N, B array, its strides)
+        of a first-moment Dot message m_nk = sum_d Y[d, n] B[d, k] kept as a contraction, or None."""
+        if not isinstance(msg, LazyContract) or len(msg.ops) != 2 or msg._dense is not None:
+            return None
+        big = [lab for lab in msg.out if msg.sizes[lab] != 1]
+        if len(big) != 2 or msg.sizes[big[-1]] != K:
+            return None
+        nlab, klab = big
+
+        def varying(a, ls):
+            return {lab: a.t.stride(ax) for ax, lab in enumerate(ls) if a.shape[ax] != 1}
+        v = [varying(a, ls) for a, ls in zip(msg.ops, msg.labs)]
+        for iy, ib in ((0, 1), (1, 0)):
+            vy, vb = v[iy], v[ib]
+            if nlab in vy and klab not in vy and klab in vb and nlab not in vb:
+                dl = [lab for lab in vy if lab != nlab]
+                if len(dl) != 1 or set(vb) != {dl[0], klab}:
+                    continue
+                d = dl[0]
+                D, N = int(msg.sizes[d]), int(msg.sizes[nlab])
+                if D > 256 or (vy[nlab] != 1 and vy[d] != 1):
+                    return None
+                return (msg.ops[iy], vy[d], vy[nlab], D, N, msg.ops[ib], vb[d], vb[klab])
+        return None
+
+    def _shared_cov_update(self, node, st, fam, phi_p, msgs):
+        """node.update() of a Gaussian node whose precision carries no plate axis (every plate
+        shares Cov = (-2 phi1)^-1) as ONE pass: <x_n> = Cov (phi0_prior + m_n) written once, with
+        the plate sums sum <x>, sum <x><x>^T (and sum y <x>^T when the message is the Dot message
+        of a data array, which the pass then streams itself instead of reading a formed message)
+        made on the fly -- gaussian.py:649-706 behind dot.py:581.  False: not this case."""
+        rt = self.rt
+        K = int(fam.shape[0])
+        p1 = _arr(phi_p[1])
+        if msgs[1] is not None:
+            if not isinstance(msgs[1], DArray) or isinstance(msgs[1], (LazySum, LazyContract)):
+                return False
+            p1 = fuse(lambda p, m: p + m, p1, msgs[1])
+        if p1.size != K * K or msgs[0] is None:
+            return False
+        m0, p0 = msgs[0], _arr(phi_p[0])
+        if not isinstance(m0, DArray):
+            return False
+        xshape = tuple(broadcasted_shape(p0.shape, m0.shape))
+        if len(xshape) < 1 or xshape[-1] != K:
+            return False
+        N = int(np.prod(xshape[:-1])) if len(xshape) > 1 else 1
+        if N < 2 or int(np.prod(node.plates)) != N:
+            return False          # (the means must span the node's plates: no plate multiplier)
+        dot = self._dot_operands(m0, K)
+        if dot is not None and dot[4] != N:
+            dot = None
+        if p0.size == K:
+            p0v = contiguous(p0.reshape((K,)))
+        else:
+            # a prior that varies over the plates joins the message rows
+            m0 = fuse(lambda p, m: p + m, p0, m0)
+            p0v, dot = None, None
+        U = linalg.chol(fuse(lambda p: -2.0 * p, p1.reshape((K, K))))
+        cov = linalg.chol_inv(U)
+        ld = linalg.chol_logdet(U)
+        x = DArray.empty(xshape)
+        torch = rt.torch
+        D = dot[3] if dot is not None else 0
+        stats = DArray.empty((K + K * K + D * K,))
+        nbytes = int(rt.lib.vmp_gaussian_shared_update_workspace_bytes(D, K))
+        ws = self.__dict__.setdefault('_gs_ws', {})
+        if ws.get('n', -1) < nbytes:
+            ws['t'] = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=rt.device)
+            ws['n'] = nbytes
+        vp = ctypes.c_void_p
+        if dot is not None:
+            Yop, y_sd, y_sn, D, _, Bop, b_sd, b_sk = dot
+            rc = rt.lib.vmp_gaussian_shared_update(
+                rt.ctx, N, K, D, vp(Yop.t.data_ptr()), y_sd, y_sn, vp(Bop.t.data_ptr()), b_sd, b_sk,
+                None, 0, 0, vp(p0v.t.data_ptr()), vp(cov.t.data_ptr()), vp(x.t.data_ptr()), K, 1,
+                vp(stats.t.data_ptr()), vp(ws['t'].data_ptr()), nbytes)
+            keep = [Yop, Bop, p0v, cov]
+        else:
+            m2 = contiguous(_arr(m0).broadcast_to(xshape)).reshape((N, K))
+            rc = rt.lib.vmp_gaussian_shared_update(
+                rt.ctx, N, K, 0, None, 0, 0, None, 0, 0, vp(m2.t.data_ptr()), K, 1,
+                None if p0v is None else vp(p0v.t.data_ptr()), vp(cov.t.data_ptr()),
+                vp(x.t.data_ptr()), K, 1, vp(stats.t.data_ptr()), vp(ws['t'].data_ptr()), nbytes)
+            keep = [m2, p0v, cov]
+        rt.check(rc)
+        del keep          # (launched at once, never queued: stream order keeps the operands valid)
+        npl = len(xshape) - 1
+        sums = PlateSums(DArray(stats.t[:K]), DArray(stats.t[K:K + K * K].view(K, K)), n=N)
+        if dot is not None:
+            sums.yx = DArray(stats.t[K + K * K:].view(D, K))
+            sums.ydesc = (int(Yop.t.data_ptr()), int(y_sd), int(y_sn), int(D))
+            sums.ykeep = Yop
+        covs = cov.reshape((1,) * npl + (K, K))
+        ldp = ld.reshape((1,) * npl)
+        phi1 = p1 if p1.ndim >= 2 and p1.shape[-2:] == (K, K) else p1.reshape((K, K))
+        st.phi = [DerivedArray('gauss_phi0', (phi1, x), xshape), phi1]
+        st.g = DerivedArray('gauss_g', (phi1, x, ldp), xshape[:-1])
+        st.u = [x, FactoredMoment(covs, x, 1, logdet_prec=ldp, sums=sums)]
+        self._seed_sums()
+        return True
+
+    def _seed_sums(self):
+        """Offer the plate sums the fused updates made (PlateSums) to whoever asks for the same
+        reductions: entries of the plan's memo under the signature misc._launch_sum_multiply forms
+        for them -- sum_n y_n <x_n>^T for the Dot message to the other parent and for sum y <f> of the
+        message to the noise precision, sum_n <x_n><x_n>^T for the second-moment message, for
+        sum <f>^2 and for the node's own bound term.  (The memo is emptied when a sweep ends; the sums
+        are state and are offered again.)"""
+        memo = self.__dict__.get('_contract_memo')
+        if memo is None:
+            return
+        for st in self.state.values():
+            u = st.u
+            if not st.ready or st.observed or not isinstance(u, list) or len(u) != 2:
+                continue
+            fm = u[1]
+            if not isinstance(fm, FactoredMoment) or fm.sums is None:
+                continue
+            sm, x = fm.sums, fm.mean
+            if x.ndim < 2 or not x.t.is_contiguous():
+                continue
+            K, N = int(x.shape[-1]), sm.n
+            if N < misc._MEMO_MIN // max(K, 1) or N * K < misc._MEMO_MIN:
+                continue
+            xp = int(x.t.data_ptr())
+            a, b = (xp, (1, 0, K)), (xp, (0, 1, K))
+            memo[((a, b) if a < b else (b, a), ((K, False), (K, False), (N, True)), 1.0)] = \
+                (sm.xx, [x])
+            memo[(((xp, (1, K)),), ((K, False), (N, True)), 1.0)] = (sm.x, [x])
+            if sm.yx is not None:
+                yp, y_sd, y_sn, D = sm.ydesc
+                a, b = (yp, (y_sd, 0, y_sn)), (xp, (0, 1, K))
+                memo[((a, b) if a < b else (b, a), ((D, False), (K, False), (N, True)), 1.0)] = \
+                    (sm.yx, [x, sm.ykeep])
 
     @_operation
     def update(self, node):
@@ -2136,9 +2455,14 @@ class GenericPlan(GraphIteration):
                 # (VB.update visits an observed leaf first: its q is one iteration behind W, X)
                 self._refresh_partial(node, st)
             return
-        phi = self._optimal_phi(node)
+        fam = self.family[id(node)]
+        cand = self._shared_cov_candidate(node, fam)
+        phi_p, msgs = self._phi_parts(node, lazy=cand)
+        if cand and self._shared_cov_update(node, st, fam, phi_p, msgs):
+            return
+        phi = self._combine_phi(node, phi_p, msgs)
         st.phi = phi
-        st.u, st.g = self.family[id(node)].moments_and_cgf(phi)
+        st.u, st.g = fam.moments_and_cgf(phi)
 
     @_operation
     def gradient_step(self, nodes, scale=1.0):
@@ -2178,6 +2502,10 @@ class GenericPlan(GraphIteration):
             # plate-summed product by product, no plates-sized temporaries
             terms = fam.observed_bound_terms(st.u, up)
             if terms is not None:
+                if isinstance(fam, MixtureFamily):
+                    # (its terms leave f(y) out, like the message they share an array with)
+                    terms = list(terms) + [(1.0, [st.f]) if isinstance(st.f, DArray)
+                                           else (float(st.f), [])]
                 return self._finish_bound(node, terms, ignore_masked)
         phi_p = fam.phi_from_parents(up)
         L = _arr(fam.cgf_from_parents(up))
@@ -2263,6 +2591,8 @@ class GenericPlan(GraphIteration):
         if any(c != 1 for c in cpl):
             return None
         k = float(np.prod(node.dims[0]))
+        if p0.size != int(k) or p1.size != int(k) * int(k):
+            return None           # a prior that varies over the plates: the general route
         # plate-constant parts: the plate sum multiplies them with the number of plates
         qc = fuse(lambda ld, k_=k: 0.5 * k_ - 0.5 * ld, _arr(xx.logdet_prec))
         tr = misc.sum_multiply(p1, cov, axis=tuple(range(-2 * nd, 0)))
@@ -2271,13 +2601,14 @@ class GenericPlan(GraphIteration):
         # lacks included), contracted with the prior's parameters
         D = int(np.prod(node.dims[0]))
         xf = x.reshape(x.shape[:x.ndim - nd] + (D,))
-        s1 = misc.sum_multiply_to_plates(xf, to_plates=(), from_plates=node.plates, ndim=1)
-        s2 = misc.sum_multiply_to_plates(_trail(xf, 1), xf.reshape(xf.shape[:-1] + (1, D)),
-                                         to_plates=(), from_plates=node.plates, ndim=2)
-        p0f = p0.reshape((-1, D)) if p0.size == D else None
-        p1f = p1.reshape((-1, D, D)) if p1.size == D * D else None
-        if p0f is None or p1f is None:
-            return None
+        if xx.sums is not None and nd == 1 and xx.sums.n == int(np.prod(node.plates)):
+            # the pass that wrote <x> summed it (and <x><x>^T) over these very plates
+            s1, s2 = xx.sums.x, xx.sums.xx
+        else:
+            s1 = misc.sum_multiply_to_plates(xf, to_plates=(), from_plates=node.plates, ndim=1)
+            s2 = misc.sum_multiply_to_plates(_trail(xf, 1), xf.reshape(xf.shape[:-1] + (1, D)),
+                                             to_plates=(), from_plates=node.plates, ndim=2)
+        p0f, p1f = p0.reshape((-1, D)), p1.reshape((-1, D, D))
         pre = fuse(lambda a, b: a + b, misc.sum_multiply(p0f, s1.reshape((1, D))),
                    misc.sum_multiply(p1f, s2.reshape((1, D, D))))
         return self._finish_bound(node, terms, ignore_masked, presummed=pre)
@@ -2308,24 +2639,85 @@ class GenericPlan(GraphIteration):
         small = [f for f in factors if f.size <= 1]
         if not big:
             big, small = list(factors), []
-        # two factors commute exactly, so either order may answer for both; three or more are
-        # multiplied left to right and only the same order is the same number
-        ids = tuple(id(f) for f in big)
-        key = (tuple(sorted(ids)) if len(big) <= 2 else ids, tuple(to_plates), tuple(from_plates))
-        cache = self.__dict__.setdefault('_sum_cache', {})
-        hit = cache.get(key)
-        if hit is not None and sorted(id(r()) for r in hit[0]) == sorted(ids):
-            # (a dead reference gives id(None): never among the ids of live factors)
-            t = hit[1]
+        # factors that do not vary along any summed axis leave the (long) reduction and multiply
+        # its (small) result: sum_n r_nk M_k = M_k sum_n r_nk, and the sum is remembered under the
+        # varying factors alone (sum_n r_nk serves the messages to the precision, to its degrees of
+        # freedom and to the mixing weights of a mixture)
+        full = tuple(broadcasted_shape(*[f.shape for f in big]))
+        nf, nt = len(full), len(tuple(to_plates))
+        to = ((1,) * (nf - nt) + tuple(to_plates)) if nf >= nt else tuple(to_plates)[nt - nf:]
+        red = [i for i in range(nf) if full[i] != 1 and to[i] == 1]
+        inv = []
+        if red and len(big) >= 2:
+            def varies(f):
+                off = nf - f.ndim
+                return any(ax - off >= 0 and f.shape[ax - off] != 1 for ax in red)
+            var = [f for f in big if varies(f)]
+            if var and len(var) < len(big) \
+                    and int(np.prod([full[i] for i in red])) >= int(
+                        os.environ.get('BAYESPY_AMD_HOIST_MIN', 1024)):
+                inv = [f for f in big if not any(f is v for v in var)]
+                big = var
+        if len(big) >= 3 and self._pairwise_pays(big, to_plates):
+            # three or more arrays under a plate sum: pair by pair when a pair's result is much
+            # smaller than its operands (sum_n r_nk y_nd mu_ke = (sum_n r_nk y_nd) mu_ke)
+            t = self._plate_sum_contract(big, to_plates, from_plates)
         else:
-            t = misc.sum_multiply_to_plates(*big, to_plates=tuple(to_plates),
-                                            from_plates=tuple(from_plates), ndim=0)
-            for k in [k for k, v in cache.items() if any(r() is None for r in v[0])]:
-                del cache[k]
-            cache[key] = ([weakref.ref(f) for f in big], t)
+            # two factors commute exactly, so either order may answer for both; three or more are
+            # multiplied left to right and only the same order is the same number
+            ids = tuple(id(f) for f in big)
+            key = (tuple(sorted(ids)) if len(big) <= 2 else ids, tuple(to_plates),
+                   tuple(from_plates))
+            cache = self.__dict__.setdefault('_sum_cache', {})
+            hit = cache.get(key)
+            if hit is not None and sorted(id(r()) for r in hit[0]) == sorted(ids):
+                # (a dead reference gives id(None): never among the ids of live factors)
+                t = hit[1]
+            else:
+                t = misc.sum_multiply_to_plates(*big, to_plates=tuple(to_plates),
+                                                from_plates=tuple(from_plates), ndim=0)
+                for k in [k for k, v in cache.items() if any(r() is None for r in v[0])]:
+                    del cache[k]
+                cache[key] = ([weakref.ref(f) for f in big], t)
+        for f in inv:
+            t = fuse(lambda t_, s_: t_ * s_, t, f)
+        if inv:
+            s_ = t.shape
+            while len(s_) > nt and s_[0] == 1:
+                s_ = s_[1:]
+            t = t.reshape(s_)
         for f in small:
             t = fuse(lambda t_, s_: t_ * s_, t, f.reshape(()))
         return t
+
+    @staticmethod
+    def _pairwise_pays(factors, to_plates):
+        """Would contracting ``factors`` pair by pair (misc.plan_contraction) keep every
+        intermediate result much smaller than the largest factor?  (An elementwise-like product
+        -- three (N, K) arrays -- is one fused launch; a pair whose result is (N, K) again is not
+        worth a temporary.)"""
+        if os.environ.get('BAYESPY_AMD_PAIRWISE_SUMS', '1') == '0' or len(factors) > 6:
+            return False
+        full = tuple(broadcasted_shape(*[f.shape for f in factors]))
+        n, nt = len(full), len(tuple(to_plates))
+        to = ((1,) * (n - nt) + tuple(to_plates)) if n >= nt else tuple(to_plates)[nt - n:]
+        sizes = {'p%d' % i: full[i] for i in range(n)}
+        out_labels = ['p%d' % i for i in range(n) if full[i] != 1 and to[i] != 1]
+        varying = [['p%d' % (n - f.ndim + ax) for ax in range(f.ndim) if f.shape[ax] != 1]
+                   for f in factors]
+        biggest = max(f.size for f in factors)
+        if biggest < int(os.environ.get('BAYESPY_AMD_PAIRWISE_MIN', 1 << 16)):
+            return False
+        steps = misc.plan_contraction(varying, out_labels, sizes)
+        if not steps:
+            return False
+        for _, _, res in steps:
+            ext = 1
+            for lab in res:
+                ext *= sizes[lab]
+            if ext * 8 > biggest:
+                return False
+        return True
 
     def _plate_sum_contract(self, factors, to_plates, from_plates):
         """_plate_sum of a product that contains contractions (LazyContract): one labelled
@@ -2572,6 +2964,26 @@ class GenericPlan(GraphIteration):
 
         def rot2(L_, a, R_):
             return linalg.mmdot(linalg.mmdot(L_, _arr(a)), R_)
+        fm = None if chain else st.u[1]
+        if Q is None and isinstance(fm, FactoredMoment) and fm.sums is not None \
+                and fm.logdet_prec is not None and st.phi is not None \
+                and isinstance(st.phi[0], DerivedArray) and isinstance(st.g, DerivedArray):
+            # the state of the fused update keeps its form: means and covariance rotate, the plate
+            # sums with them (sum <x> -> R sum <x>, sum <x><x>^T -> R . R^T, sum y <x>^T -> . R^T),
+            # log|Lambda| -> log|Lambda| - 2 log|det R|; phi0 and g stay functions of those
+            u0 = linalg.mvdot(Rd, _arr(st.u[0]))
+            phi1 = rot2(Rit, st.phi[1], Ri)
+            sm = fm.sums
+            sums = PlateSums(linalg.mvdot(Rd, sm.x), rot2(Rd, sm.xx, Rt),
+                             None if sm.yx is None else linalg.mmdot(sm.yx, Rt), sm.ydesc, sm.ykeep,
+                             sm.n)
+            ld = fuse(lambda l: l - 2.0 * float(logdetR), _arr(fm.logdet_prec))
+            st.u = [u0, FactoredMoment(rot2(Rd, fm.cov, Rt), u0, node.ndim, logdet_prec=ld,
+                                       sums=sums)]
+            st.phi = [DerivedArray('gauss_phi0', (phi1, u0), st.phi[0].shape), phi1]
+            st.g = DerivedArray('gauss_g', (phi1, u0, ld), st.g.shape)
+            self._seed_sums()
+            return
         if st.phi is not None:
             phi = [linalg.mvdot(Rit, _arr(st.phi[0]))] + [rot2(Rit, p, Ri) for p in st.phi[1:]]
         else:

@@ -143,6 +143,18 @@ class GraphIteration:
             sig.append((path, 'factored', obj.nd))
             GraphIteration._leaves(obj.cov, out, sig, path + ('cov',))
             GraphIteration._leaves(obj.mean, out, sig, path + ('mean',))
+            if obj.sums is not None:
+                # plate sums made by the pass that wrote the means: the next sweep's first
+                # message reads them, so they travel like the means
+                sm = obj.sums
+                sig.append((path, 'sums', sm.n, sm.ydesc))
+                GraphIteration._leaves(sm.x, out, sig, path + ('sum_x',))
+                GraphIteration._leaves(sm.xx, out, sig, path + ('sum_xx',))
+                if sm.yx is not None:
+                    GraphIteration._leaves(sm.yx, out, sig, path + ('sum_yx',))
+        elif isinstance(obj, G.DerivedArray):
+            # a function of other state arrays, formed on demand: nothing of its own to carry
+            sig.append((path, 'derived', obj.kind, tuple(obj.shape)))
         elif isinstance(obj, G.LazySum):
             t = obj.t                       # a state array is read as a whole: evaluate it
             out.append(t)
@@ -184,10 +196,19 @@ class GraphIteration:
         if id(obj) in memo:
             return memo[id(obj)]
         if isinstance(obj, G.FactoredMoment):
+            sums = obj.sums
+            if sums is not None:
+                sums = G.PlateSums(GraphIteration._rewrap(sums.x, memo),
+                                   GraphIteration._rewrap(sums.xx, memo),
+                                   None if sums.yx is None else GraphIteration._rewrap(sums.yx, memo),
+                                   sums.ydesc, sums.ykeep, sums.n)
             new = G.FactoredMoment(GraphIteration._rewrap(obj.cov, memo),
                                    GraphIteration._rewrap(obj.mean, memo), obj.nd,
                                    None if obj.logdet_prec is None
-                                   else GraphIteration._rewrap(obj.logdet_prec, memo))
+                                   else GraphIteration._rewrap(obj.logdet_prec, memo), sums)
+        elif isinstance(obj, G.DerivedArray):
+            new = G.DerivedArray(obj.kind, [GraphIteration._rewrap(d, memo) for d in obj.deps],
+                                 obj.shape)
         elif isinstance(obj, G.LazySum):
             new = DArray(obj.t)
         elif isinstance(obj, DArray):
@@ -271,11 +292,12 @@ class GraphIteration:
             import gc
             gc_was_on = gc.isenabled()
             gc.disable()
-            sm_was = rt._tune_sm
+            sm_was, ew_was = rt._tune_sm, rt._tune_ew
             try:
                 from ...utils import misc
                 memo_was = misc._CUR_MEMO[0]
                 misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
+                self._seed_sums()
                 # the queue of small operations (vmp_queue_*) pays in eager sweeps only: a node of the
                 # graph and a record of the interpreter both cost one dependent round trip through
                 # memory, and replays measure 1.96 ms without against 2.00 ms with it at config 2
@@ -297,9 +319,12 @@ class GraphIteration:
                         flags = [f.reshape(-1).any().reshape(1).to(torch.float64) for f, _, _ in items]
                         rec.outvec = torch.cat(dev + flags) if dev or flags else None
             finally:
-                rt.set_tune('small_queue_ew', 1)
+                rt.set_tune('small_queue_ew', int(ew_was))
                 rt.set_tune('small_queue_sm', int(sm_was))
-                rt.queue_commit()
+                try:
+                    rt.queue_commit()
+                except Exception:         # noqa: BLE001 -- the error of the recording itself matters more
+                    pass
                 rt._capturing = False
                 rt._deferred = []
                 misc._CUR_MEMO[0] = memo_was

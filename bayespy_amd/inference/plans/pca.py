@@ -1000,6 +1000,12 @@ class PCAPlan:
             else:
                 raise ValueError('checkpoint holds %d state values, this build of the fused PCA block '
                                  'keeps %d' % (st.size, int(self.layout.total)))
+        L = self.layout
+        KP = int(L.KP)
+        mu_file = st[int(L.off_mu):int(L.off_mu) + self.D * KP].reshape(self.D, KP)[:, :self.K]
+        mu_model = np.zeros((self.D, self.K)) if self.mu0 is None else self.mu0     # (D, K)
+        if not np.allclose(mu_file, mu_model, rtol=1e-12, atol=0.0):
+            raise ValueError('checkpoint was saved with another prior mean of W than the model has')
         self.state.copy_(torch.from_numpy(st))
         self.Xd[:self.K, :self.N].copy_(torch.from_numpy(np.array(reader.get(base + 'X'),
                                                                  dtype=np.float64)))

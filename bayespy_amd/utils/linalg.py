@@ -45,7 +45,7 @@ class CholFactor:
                                         ctypes.c_void_p(inv.t.data_ptr()),
                                         ctypes.c_void_p(logdet.t.data_ptr()),
                                         ctypes.c_void_p(info.data_ptr())))
-        rt.keep_until_flush([C], (inv, logdet, info))       # a few small matrices are queued
+        rt.keep_until_flush([C], (inv, logdet, info), kind='sm')   # a few small matrices are queued
         # same failure the reference reports (utils/linalg.py:58-59); inside a plan
         # operation the flag is read together with the operation's other checks
         rt.defer_check(info, _lib.NotPositiveDefiniteError, "Matrix not positive definite")

@@ -11,6 +11,7 @@ and error behaviour; every reduction is the ``vmp_sum_multiply`` HIP kernel.
 import ctypes
 import functools
 import operator
+import os
 
 import numpy as np
 
@@ -183,10 +184,21 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
         # modified in place; a plate "sum" of a message that already has the parent's plates was
         # a 0.3 ms copy of a (D, N) array at N = 1e6)
         return arrays[0]
+    memo, sig = _CUR_MEMO[0], None
+    if memo is not None and len(reduce_axes) > 0 and any(a.size >= _MEMO_MIN for a in arrays):
+        # the same reduction of the same (immutable) arrays, asked for again within one sweep --
+        # sum_n y_dn x_nk for the Dot message to W and for sum y <f> of the message to tau;
+        # sum_n r_nk y_nd for the messages of a mixture to its means and to its precisions.  The key
+        # is the memory the operands occupy and how the index space walks it (unit axes dropped:
+        # (N, 1, D, 1) and (N, 1, 1, D) views of one array under the same sum are the same numbers)
+        sig = _canonical_signature(arrays, shape, reduce_axes, scale)
+        hit = memo.get(sig)
+        if hit is not None:
+            return hit[0].reshape(tuple(out_shape_keep))
     if len(arrays) >= 2 and len(reduce_axes) > 0:
         hoisted = _hoist_invariant(arrays, shape, reduce_axes, out_shape_keep, scale)
         if hoisted is not None:
-            return hoisted
+            return _remember(memo, sig, hoisted, arrays)
     out = DArray.empty(out_shape_keep)
     # a small contraction inside an operation joins the queue of small operations (one interpreter
     # launch for a run of them) instead of being a GEMM launch of its own
@@ -194,7 +206,7 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
         and int(np.prod(shape)) <= 32768
     if not small and len(arrays) >= 2 and len(reduce_axes) > 0 \
             and _try_gemm(rt, arrays, shape, reduce_axes, out, scale):
-        return out
+        return _remember(memo, sig, out, arrays)
     # coalesce neighbouring axes of the same role (both kept or both reduced) that every
     # operand and the output walk densely: the kernels decode a flat index into axes with
     # 64-bit divisions, so fewer axes is directly fewer instructions per element
@@ -239,7 +251,36 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
         rt.ctx, nd, c_shape, len(arrays), c_in, c_str, c_ostr, ctypes.c_uint32(mask),
         float(scale), ctypes.c_void_p(out.t.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
         ws.numel() * 8))
-    rt.keep_until_flush(arrays, out)
+    rt.keep_until_flush(arrays, out, kind='sm')
+    return _remember(memo, sig, out, arrays)
+
+
+def _canonical_signature(arrays, shape, reduce_axes, scale):
+    nd = len(shape)
+    red = set(reduce_axes)
+    strides = [_strides(a.t, shape) for a in arrays]
+    # kept axes in their order (it is the layout of the result), then the summed ones in an order
+    # of their own (extent, strides): sum over (k, e, n) of one pair of arrays = sum over (n, k, d)
+    axes = [ax for ax in range(nd) if shape[ax] != 1 and ax not in red] + \
+        sorted((ax for ax in range(nd) if shape[ax] != 1 and ax in red),
+               key=lambda ax: (int(shape[ax]), tuple(st[ax] for st in strides)))
+    ops = tuple((a.t.data_ptr(), tuple(st[ax] for ax in axes)) for a, st in zip(arrays, strides))
+    if len(ops) == 2 and ops[1] < ops[0]:
+        ops = (ops[1], ops[0])             # two factors commute exactly
+    return (ops, tuple((int(shape[ax]), ax in red) for ax in axes), float(scale))
+
+
+def _remember(memo, sig, out, arrays):
+    if sig is None:
+        return out
+
+    def held(entry):
+        return sum(int(t.size) * 8 for t in [entry[0]] + list(entry[1]))
+    # bounded by entries AND by the bytes the entries keep alive (operands + results): a loop of
+    # single node.update() calls never reaches the end-of-sweep clear of the plan
+    while len(memo) >= 32 or (memo and sum(held(e) for e in memo.values()) > _MEMO_BYTES):
+        memo.pop(next(iter(memo)))
+    memo[sig] = (out, list(arrays))        # the operands stay alive: their addresses stay theirs
     return out
 
 
@@ -450,20 +491,6 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     broadcast-compressed moments, node.py:311-345).
     """
     ops = [asdarray(a) for a in operands]
-    memo, sig = _CUR_MEMO[0], None
-    if memo is not None and any(a.size >= (1 << 16) for a in ops):
-        # the same contraction of the same (immutable) arrays, asked for by two consumers of one
-        # sweep -- sum_n y_dn x_nk for the Dot message to W and for sum y <f> of the message to tau
-        ren = {}
-        sig = (tuple((a.t.data_ptr(), tuple(a.t.shape), tuple(a.t.stride()),
-                      tuple(ren.setdefault(lab, len(ren)) for lab in ls))
-                     for a, ls in zip(ops, labels)),
-               tuple(ren.setdefault(lab, len(ren)) for lab in out_labels),
-               tuple(sorted((ren[lab], int(sizes[lab])) for lab in ren)), float(scale),
-               tuple(ren[lab] for lab in compress if lab in ren))
-        hit = memo.get(sig)
-        if hit is not None:
-            return hit[0]
     all_labels = list(out_labels)
     for ls in labels:
         for lab in ls:
@@ -506,20 +533,13 @@ def contract(operands, labels, out_labels, sizes, scale=1.0, compress=()):
     keep_shape = tuple(1 if i in red else shape[i] for i in range(nd))
     out = _launch_sum_multiply(views, shape, red, keep_shape, scale)
     out = out.reshape(tuple(shape[i] for i in range(len(out_labels))))
-    if sig is not None:
-        # bounded by entries AND by the bytes the entries keep alive (operands + results): a loop of
-        # single node.update() calls never reaches the end-of-sweep clear of the plan
-        def held(entry):
-            return sum(int(t.size) * 8 for t in [entry[0]] + list(entry[1]))
-        while len(memo) >= 16 or (memo and sum(held(e) for e in memo.values()) > _MEMO_BYTES):
-            memo.pop(next(iter(memo)))
-        memo[sig] = (out, ops)            # the operands stay alive: their addresses stay theirs
     return out
 
 
 # the memo of the plan whose operation is running (plans/generic.py sets and clears it); None: off
 _CUR_MEMO = [None]
 _MEMO_BYTES = 512 << 20          # operands and results a memo may keep alive
+_MEMO_MIN = int(os.environ.get('BAYESPY_AMD_MEMO_MIN', 1 << 16))    # reductions with an operand of at least this many elements are remembered
 
 
 def plan_contraction(varying, out_labels, sizes):

@@ -629,6 +629,30 @@ int32_t vmp_gaussian_moments(vmp_ctx *ctx, int32_t n, int64_t batch, const doubl
                              const double *phi1, double *u0, double *u1, double *g,
                              int32_t *info);
 
+/* ONE pass for the update of a Gaussian node whose posterior covariance is SHARED by its N plates
+ * (a plate-free precision: GaussianARD / Gaussian under a scalar mask) -- the natural parameters
+ * from the prior and the message (GaussianARDDistribution.compute_phi_from_parents,
+ * gaussian.py:649-670), the posterior means (compute_moments_and_cgf, gaussian.py:672-706:
+ * <x> = Cov phi0), the Dot / SumMultiply message the node receives when it is given as its
+ * operands (dot.py:581: m_n = B^T y_n), and the plate sums its neighbours ask for next (dot.py:581
+ * for the other parent, expfamily.py:449-468):
+ *     m_n = B^T y_n                 Y form: Y (D x N, element strides y_sd, y_sn, one of them 1),
+ *                                   B (D x K, strides b_sd, b_sk); m0 = NULL
+ *         | m0[n, :]                message form: rows of a given array (strides m0_sn, m0_sk); Y = NULL
+ *     x_n = Cov (p0 + m_n)          p0: K doubles or NULL (= 0); Cov: K x K contiguous
+ *     stats = [ sum_n x_n (K) ; sum_n x_n x_n^T (K x K) ; sum_n y_n x_n^T (D x K; Y form only) ]
+ * x: N x K with element strides (x_sn, x_sk).  Y form: fp64 MFMA tile kernel (8 N (D + K) bytes of
+ * algorithmic traffic, 4 N D K + 2 N K^2 flops), D <= 256; message form: 16 N K bytes.  K <= 64.
+ * Partial sums are combined in fixed order.  `workspace`: at least
+ * vmp_gaussian_shared_update_workspace_bytes(D, K) bytes (D = 0 for the message form). */
+size_t vmp_gaussian_shared_update_workspace_bytes(int32_t D, int32_t K);
+int32_t vmp_gaussian_shared_update(vmp_ctx *ctx, int64_t N, int32_t K, int32_t D,
+                                   const double *Y, int64_t y_sd, int64_t y_sn, const double *B,
+                                   int64_t b_sd, int64_t b_sk, const double *m0, int64_t m0_sn,
+                                   int64_t m0_sk, const double *p0, const double *cov, double *x,
+                                   int64_t x_sn, int64_t x_sk, double *stats, void *workspace,
+                                   size_t workspace_bytes);
+
 /* Row softmax moments of Multinomial/Categorical: p = normalized_exp(phi),
  * lse = logsumexp(phi) (multinomial.py:114-120, utils/misc.py:1366-1401). */
 int32_t vmp_softmax_moments(vmp_ctx *ctx, int64_t rows, int32_t K, const double *phi, double *p,

@@ -258,6 +258,9 @@ class HostGenericLib:
                 xo[r] = (inv @ yy[r].reshape(-1)).reshape(T, K)
         return 0
 
+    def vmp_gaussian_shared_update_workspace_bytes(self, D, K):
+        return 64
+
     def vmp_gaussian_shared_update(self, ctx, N, K, D, Y, y_sd, y_sn, B, b_sd, b_sk, m0, m0_sn,
                                    m0_sk, p0, cov, x, x_sn, x_sk, stats, ws, ws_bytes):
         """include/vmp_hip.h: x_n = Cov (p0 + m_n), m_n = B^T y_n (or the given rows), and the plate
@@ -276,7 +279,7 @@ class HostGenericLib:
             m = m + _dense(p0, (K,))[None, :]
         xs = m @ c.T
         _view(x, (N, K), (x_sn, x_sk))[...] = xs
-        st = _dense(stats, (K + K * K + D * K,))
+        st = _dense(stats, (K + K * K + (D * K if yv is not None else 0),))
         st[:K] = xs.sum(axis=0)
         st[K:K + K * K] = (xs.T @ xs).reshape(-1)
         if yv is not None:

@@ -728,3 +728,70 @@ def test_cabi_queue_and_graph_of_small_operations():
         from bayespy_amd.device import get_runtime
         lib.vmp_tune_set(b'small_queue_sm', int(get_runtime()._tune_sm))
         lib.vmp_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize('N,D,K,ylay', [
+    (4099, 64, 16, 'n'), (4099, 64, 16, 'd'), (777, 20, 5, 'n'), (777, 20, 5, 'd'),
+    (33, 7, 3, 'n'), (5000, 128, 32, 'n'), (2500, 130, 40, 'd'), (1500, 256, 64, 'n'),
+    (9001, 33, 17, 'n'), (64, 0, 16, 'rows'), (3001, 0, 5, 'rows'), (2000, 0, 33, 'rows'),
+    (700, 0, 64, 'rows')])
+def test_gaussian_shared_update_through_the_c_abi(N, D, K, ylay):
+    """vmp_gaussian_shared_update (include/vmp_hip.h) through raw ctypes against NumPy: <x_n> =
+    Cov (p0 + B^T y_n) -- or the given message rows -- and the plate sums sum <x>, sum <x><x>^T,
+    sum y <x>^T; both memory orders of Y, ragged D / K / N, every tile instance up to D = 256,
+    K = 64; run twice: identical bits (fixed-order combination of the partial sums)."""
+    import ctypes
+    import torch
+    from bayespy_amd.device import get_runtime
+    rt = get_runtime()
+    rs = np.random.RandomState(N + 3 * D + K)
+    dev = rt.device
+    A = rs.normal(size=(K, K))
+    cov = np.linalg.inv(A @ A.T + K * np.eye(K))
+    p0 = rs.normal(size=K)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    nbytes = int(rt.lib.vmp_gaussian_shared_update_workspace_bytes(D, K))
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    x = torch.full((N, K), np.nan, dtype=torch.float64, device=dev)
+    nst = K + K * K + D * K
+    outs = []
+    p0t, covt = up(p0), up(cov)          # (device arrays stay referenced while the call runs)
+    for rep in range(2):
+        stats = torch.full((nst,), np.nan, dtype=torch.float64, device=dev)
+        rt.sync_stream()
+        if ylay == 'rows':
+            m = rs.normal(size=(N, K)) if rep == 0 else m
+            mt = up(m)
+            rc = rt.lib.vmp_gaussian_shared_update(
+                rt.ctx, N, K, 0, None, 0, 0, None, 0, 0, vp(mt), K, 1, vp(p0t), vp(covt),
+                vp(x), K, 1, vp(stats), vp(ws), nbytes)
+            ref = (m + p0) @ cov.T
+        else:
+            if rep == 0:
+                y = rs.normal(size=(D, N))
+                B = rs.normal(size=(D, K))
+            Bt = up(B)
+            if ylay == 'n':
+                yt = up(y)
+                y_sd, y_sn = N, 1
+            else:
+                yt = up(y.T)
+                y_sd, y_sn = 1, D
+            rc = rt.lib.vmp_gaussian_shared_update(
+                rt.ctx, N, K, D, vp(yt), y_sd, y_sn, vp(Bt), K, 1, None, 0, 0, vp(p0t),
+                vp(covt), vp(x), K, 1, vp(stats), vp(ws), nbytes)
+            ref = (y.T @ B + p0) @ cov.T
+        rt.check(rc)
+        torch.cuda.synchronize()
+        outs.append((x.cpu().numpy().copy(), stats.cpu().numpy().copy()))
+    xs, st = outs[0]
+    tol = dict(rtol=1e-11, atol=1e-11 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(xs, ref, **tol)
+    big = dict(rtol=1e-10, atol=1e-10 * N)
+    np.testing.assert_allclose(st[:K], ref.sum(axis=0), **big)
+    np.testing.assert_allclose(st[K:K + K * K].reshape(K, K), ref.T @ ref, **big)
+    if ylay != 'rows':
+        np.testing.assert_allclose(st[K + K * K:].reshape(D, K), y @ ref, **big)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
