@@ -129,6 +129,8 @@ SIGNATURES = {
     'vmp_graph_end': (c_i32, [c_vp, P(c_vp)]),
     'vmp_graph_launch': (c_i32, [c_vp, c_vp]),
     'vmp_graph_destroy': (c_i32, [c_vp, c_vp]),
+    'vmp_copy_many': (c_i32, [c_vp, c_i32, P(c_vp), P(c_vp), P(c_i64)]),
+    'vmp_pack_outputs': (c_i32, [c_vp, c_i32, P(c_vp), P(c_i64), P(c_i32), c_vp]),
     'vmp_queue_begin': (c_i32, [c_vp]),
     'vmp_queue_flush': (c_i32, [c_vp]),
     'vmp_queue_end': (c_i32, [c_vp]),

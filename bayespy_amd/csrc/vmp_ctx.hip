@@ -278,4 +278,107 @@ int32_t vmp_memset_zero(vmp_ctx *ctx, void *dst, size_t bytes)
     return VMP_OK;
 }
 
+// Several small device-to-device copies as ONE launch (the copy-back of a recorded sweep: a dozen
+// state arrays of a few hundred bytes each were a dozen dependent copy nodes of 4 us).
+struct CopyMany {
+    const double *src[24];
+    double *dst[24];
+    int64_t count[24];
+};
+
+__global__ void __launch_bounds__(256) copy_many_kernel(CopyMany a)
+{
+    const int c = blockIdx.y;
+    const double *s = a.src[c];
+    double *d = a.dst[c];
+    const int64_t n = a.count[c];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        d[i] = s[i];
+}
+
+int32_t vmp_copy_many(vmp_ctx *ctx, int32_t n, const double *const *src, double *const *dst,
+                      const int64_t *count)
+{
+    VMP_REQUIRE(ctx, ctx != nullptr, VMP_ERR_INVALID, "null context");
+    VMP_REQUIRE(ctx, n >= 0 && (n == 0 || (src && dst && count)), VMP_ERR_INVALID, "null argument");
+    VMP_FLUSH_SMALL(ctx);
+    for (int32_t b = 0; b < n; b += 24) {
+        CopyMany a;
+        memset(&a, 0, sizeof(a));
+        const int m = (n - b) < 24 ? (n - b) : 24;
+        int64_t most = 0;
+        for (int i = 0; i < m; ++i) {
+            a.src[i] = src[b + i];
+            a.dst[i] = dst[b + i];
+            a.count[i] = count[b + i];
+            VMP_REQUIRE(ctx, a.count[i] >= 0 && (a.count[i] == 0 || (a.src[i] && a.dst[i])),
+                        VMP_ERR_INVALID, "vmp_copy_many: bad entry %d", b + i);
+            if (a.count[i] > most) most = a.count[i];
+        }
+        int64_t gx = (most + 1023) / 1024;
+        if (gx < 1) gx = 1;
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)gx, (unsigned)m), dim3(256), 0,
+                           ctx->stream, a);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return VMP_OK;
+}
+
+// The outputs of a recorded sweep in one vector: lower-bound terms (device scalars) and validity
+// flags (any element non-zero) -- one launch instead of a reduction, a conversion and a copy node
+// per entry (graph_iter.py: eight dependent nodes of 4-5 us at the end of a PCA sweep).
+struct PackArgs {
+    const void *src[48];
+    int64_t count[48];
+    int32_t kind[48];          // 0: copy one double; 1: any(int32 != 0); 2: any(double != 0)
+};
+
+__global__ void __launch_bounds__(64) pack_outputs_kernel(PackArgs a, double *__restrict__ out,
+                                                           int base)
+{
+    const int e = blockIdx.x;
+    const int kind = a.kind[e];
+    if (kind == 0) {
+        if (threadIdx.x == 0) out[base + e] = *reinterpret_cast<const double *>(a.src[e]);
+        return;
+    }
+    int bad = 0;
+    const int64_t n = a.count[e];
+    if (kind == 1) {
+        const int32_t *f = reinterpret_cast<const int32_t *>(a.src[e]);
+        for (int64_t i = threadIdx.x; i < n; i += 64) bad |= (f[i] != 0);
+    } else {
+        const double *f = reinterpret_cast<const double *>(a.src[e]);
+        for (int64_t i = threadIdx.x; i < n; i += 64) bad |= (f[i] != 0.0);   // (NaN counts too)
+    }
+    const unsigned long long m = __ballot(bad);
+    if (threadIdx.x == 0) out[base + e] = m ? 1.0 : 0.0;
+}
+
+int32_t vmp_pack_outputs(vmp_ctx *ctx, int32_t n, const void *const *src, const int64_t *count,
+                         const int32_t *kind, double *out)
+{
+    VMP_REQUIRE(ctx, ctx != nullptr, VMP_ERR_INVALID, "null context");
+    VMP_REQUIRE(ctx, n >= 0 && (n == 0 || (src && count && kind && out)), VMP_ERR_INVALID,
+                "null argument");
+    VMP_FLUSH_SMALL(ctx);
+    for (int32_t b = 0; b < n; b += 48) {
+        PackArgs a;
+        memset(&a, 0, sizeof(a));
+        const int m = (n - b) < 48 ? (n - b) : 48;
+        for (int i = 0; i < m; ++i) {
+            a.src[i] = src[b + i];
+            a.count[i] = count[b + i];
+            a.kind[i] = kind[b + i];
+            VMP_REQUIRE(ctx, a.src[i] && a.kind[i] >= 0 && a.kind[i] <= 2 && a.count[i] >= 0,
+                        VMP_ERR_INVALID, "vmp_pack_outputs: bad entry %d", b + i);
+        }
+        hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)m), dim3(64), 0, ctx->stream, a, out,
+                           (int)b);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return VMP_OK;
+}
+
 }  // extern "C"

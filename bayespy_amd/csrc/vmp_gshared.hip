@@ -42,24 +42,38 @@ __device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// Apad (KP x DP, zero padded) = Cov B^T; cpad (KP) = Cov p0
+// Apad (KP x DP, zero padded) = Cov B^T; cpad (KP) = Cov p0.  Cov and B are staged in LDS first
+// (the products then run without a dependent trip to memory per term).
 __global__ void __launch_bounds__(NT)
 gshared_prepare_kernel(int K, int D, int KP, int DP, const double *__restrict__ cov,
                        const double *__restrict__ B, int64_t b_sd, int64_t b_sk,
                        const double *__restrict__ p0, double *__restrict__ Apad,
                        double *__restrict__ cpad)
 {
-    for (int e = threadIdx.x; e < KP * DP; e += NT) {
-        const int k = e / DP, d = e - k * DP;
-        double s = 0.0;
-        if (k < K && d < D)
-            for (int j = 0; j < K; ++j) s += cov[k * K + j] * B[d * b_sd + j * b_sk];
-        Apad[e] = s;
+    extern __shared__ double lds[];
+    double *cs = lds, *bs = cs + K * K;          // cs[k][j]; bs[d - d0][j], row stride K + 1
+    constexpr int DC = 64;                       // rows of B per round
+    for (int e = threadIdx.x; e < K * K; e += NT) cs[e] = cov[e];
+    for (int d0 = 0; d0 < DP; d0 += DC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < DC * K; e += NT) {
+            const int dd = e / K, j = e - dd * K;
+            bs[dd * (K + 1) + j] = (d0 + dd < D) ? B[(int64_t)(d0 + dd) * b_sd + j * b_sk] : 0.0;
+        }
+        __syncthreads();
+        const int dn = (DP - d0) < DC ? (DP - d0) : DC;
+        for (int e = threadIdx.x; e < KP * dn; e += NT) {
+            const int k = e / dn, dd = e - k * dn;
+            double s = 0.0;
+            if (k < K)
+                for (int j = 0; j < K; ++j) s += cs[k * K + j] * bs[dd * (K + 1) + j];
+            Apad[k * DP + d0 + dd] = s;
+        }
     }
     for (int k = threadIdx.x; k < KP; k += NT) {
         double s = 0.0;
         if (k < K && p0)
-            for (int j = 0; j < K; ++j) s += cov[k * K + j] * p0[j];
+            for (int j = 0; j < K; ++j) s += cs[k * K + j] * p0[j];
         cpad[k] = s;
     }
 }
@@ -87,7 +101,11 @@ gshared_pass_kernel(const double *__restrict__ Y, int64_t y_sd, int64_t y_sn, in
     const int w = tid >> 6, l = tid & 63;
     const int l15 = l & 15, l4 = l >> 4;
     const int it1 = w % KT;
-    const int jt2 = w % KT;
+    // role-2 tiles are dealt starting behind the wavefronts that carry the role-1 tiles, so that
+    // the matrix work of a tile is spread over the four SIMDs (D = 64, K = 16: 24 / 24 / 16 / 8
+    // instructions per wavefront instead of 32 / 24 / 8 / 8)
+    const int w2 = (w + 4 - (T1 % 4)) % 4;
+    const int jt2 = w2 % KT;
     const bool nmajor = (y_sn == 1);     // plates contiguous (the reference's (D, N) data)
 
     double afrag[KS1];
@@ -236,7 +254,7 @@ gshared_pass_kernel(const double *__restrict__ Y, int64_t y_sd, int64_t y_sn, in
                 const double b = zbB[4 * q];
 #pragma unroll
                 for (int m = 0; m < R2; ++m) {
-                    const int t2 = w + 4 * m;
+                    const int t2 = w2 + 4 * m;
                     if (t2 < T2) {
                         const int it2 = t2 / KT;
                         const double a = zbA[it2 * 16 * SZ + 4 * q];
@@ -251,7 +269,7 @@ gshared_pass_kernel(const double *__restrict__ Y, int64_t y_sd, int64_t y_sn, in
     double *Pb = P + (int64_t)blockIdx.x * (ZR * KP + KP);
 #pragma unroll
     for (int m = 0; m < R2; ++m) {
-        const int t2 = w + 4 * m;
+        const int t2 = w2 + 4 * m;
         if (t2 < T2) {
             const int it2 = t2 / KT;
 #pragma unroll
@@ -281,38 +299,50 @@ gshared_pass_kernel(const double *__restrict__ Y, int64_t y_sd, int64_t y_sn, in
     }
 }
 
-// stats (unpadded) = sum over the workgroups' partial blocks, in fixed order
+// stats (unpadded) = sum over the workgroups' partial blocks, in fixed order: 16 lanes per output
+// element, lane j adds the blocks j, j + 16, ... (four running sums), the lanes are combined by
+// xor-shuffles -- the result depends on the number of blocks only.
 __global__ void __launch_bounds__(NT)
 gshared_reduce_kernel(const double *__restrict__ P, int nb, int64_t blk, int K, int D, int KP,
                       int DP, int with_y, double *__restrict__ stats)
 {
     const int total = K + K * K + (with_y ? D * K : 0);
-    const int e = blockIdx.x * NT + threadIdx.x;
-    if (e >= total) return;
-    int64_t src;
-    if (e < K) src = (int64_t)(DP + KP) * KP + e;
-    else if (e < K + K * K) {
-        const int i = (e - K) / K, j = (e - K) - i * K;
-        src = (int64_t)(DP + i) * KP + j;
-    } else {
-        const int d = (e - K - K * K) / K, k = (e - K - K * K) - d * K;
-        src = (int64_t)d * KP + k;
+    const int e = blockIdx.x * (NT / 16) + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15;
+    const bool ok = e < total;
+    int64_t src = 0;
+    if (ok) {
+        if (e < K) src = (int64_t)(DP + KP) * KP + e;
+        else if (e < K + K * K) {
+            const int i = (e - K) / K, c = (e - K) - i * K;
+            src = (int64_t)(DP + i) * KP + c;
+        } else {
+            const int d = (e - K - K * K) / K, k = (e - K - K * K) - d * K;
+            src = (int64_t)d * KP + k;
+        }
     }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = 0;
-    for (; b + 3 < nb; b += 4) {
-        s0 += P[(int64_t)b * blk + src];
-        s1 += P[(int64_t)(b + 1) * blk + src];
-        s2 += P[(int64_t)(b + 2) * blk + src];
-        s3 += P[(int64_t)(b + 3) * blk + src];
+    if (ok) {
+        int b = j;
+        for (; b + 48 < nb; b += 64) {
+            s0 += P[(int64_t)b * blk + src];
+            s1 += P[(int64_t)(b + 16) * blk + src];
+            s2 += P[(int64_t)(b + 32) * blk + src];
+            s3 += P[(int64_t)(b + 48) * blk + src];
+        }
+        for (; b < nb; b += 16) s0 += P[(int64_t)b * blk + src];
     }
-    for (; b < nb; ++b) s0 += P[(int64_t)b * blk + src];
-    stats[e] = (s0 + s1) + (s2 + s3);
+    double v = (s0 + s1) + (s2 + s3);
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (ok && j == 0) stats[e] = v;
 }
 
 // Message form: x_n = Cov (p0 + m_n) for given rows m_n, one thread per plate, rows staged in LDS.
 // Partial block of one workgroup: [K sums of x ; K x K sums of x x^T] (unpadded).
-// Dynamic LDS: cov (K*K) | p0 (K) | min (TR x (K+1)) | xout (TR x (K+1)).
+// Dynamic LDS: cov (K x (K+1)) | p0 (K) | min (TR x (K+1)) | xout (TR x (K+1)).
 __global__ void __launch_bounds__(NT)
 gshared_rows_kernel(int64_t N, int K, int TR, const double *__restrict__ M, int64_t m_sn,
                     int64_t m_sk, const double *__restrict__ p0, const double *__restrict__ cov,
@@ -320,10 +350,12 @@ gshared_rows_kernel(int64_t N, int K, int TR, const double *__restrict__ M, int6
                     int64_t ntiles)
 {
     extern __shared__ double lds[];
-    double *covs = lds, *p0s = covs + K * K, *mt = p0s + K, *xt = mt + TR * (K + 1);
+    // (rows of Cov with stride K + 1: the 16 lanes that form <x>_k for k = 0..15 of one plate
+    // read 16 different banks)
+    double *covs = lds, *p0s = covs + K * (K + 1), *mt = p0s + K, *xt = mt + TR * (K + 1);
     const int tid = threadIdx.x;
     const int KK = K * K;
-    for (int e = tid; e < KK; e += NT) covs[e] = cov[e];
+    for (int e = tid; e < KK; e += NT) covs[(e / K) * (K + 1) + (e % K)] = cov[e];
     for (int e = tid; e < K; e += NT) p0s[e] = p0 ? p0[e] : 0.0;
     double axx[16];
 #pragma unroll
@@ -338,14 +370,18 @@ gshared_rows_kernel(int64_t N, int K, int TR, const double *__restrict__ M, int6
             mt[r * (K + 1) + k] = (n < N) ? M[n * m_sn + (int64_t)k * m_sk] + p0s[k] : 0.0;
         }
         __syncthreads();
-        if (tid < TR) {
-            const bool ok = (n0 + tid) < N;
-            const double *row = mt + tid * (K + 1);
-            for (int k = 0; k < K; ++k) {
-                double s = 0.0;
-                for (int j = 0; j < K; ++j) s += covs[k * K + j] * row[j];
-                xt[tid * (K + 1) + k] = ok ? s : 0.0;
+        const int rows = (int)((N - n0) < TR ? (N - n0) : TR);
+        // one thread per (plate, component): all lanes busy also when a tile holds few plates
+        for (int e = tid; e < TR * K; e += NT) {
+            const int r = e / K, k = e - r * K;
+            double s0 = 0.0, s1 = 0.0;
+            if (r < rows) {
+                const double *row = mt + r * (K + 1), *cr = covs + k * (K + 1);
+                int j = 0;
+                for (; j + 1 < K; j += 2) { s0 += cr[j] * row[j]; s1 += cr[j + 1] * row[j + 1]; }
+                if (j < K) s0 += cr[j] * row[j];
             }
+            xt[r * (K + 1) + k] = s0 + s1;
         }
         __syncthreads();
         for (int e = tid; e < TR * K; e += NT) {
@@ -355,7 +391,7 @@ gshared_rows_kernel(int64_t N, int K, int TR, const double *__restrict__ M, int6
         }
         if (tid < K) {
             double s = 0.0;
-            for (int r = 0; r < TR; ++r) s += xt[r * (K + 1) + tid];
+            for (int r = 0; r < rows; ++r) s += xt[r * (K + 1) + tid];
             ax += s;
         }
 #pragma unroll
@@ -363,9 +399,14 @@ gshared_rows_kernel(int64_t N, int K, int TR, const double *__restrict__ M, int6
             const int e = q * NT + tid;
             if (e < KK) {
                 const int i = e / K, j = e - i * K;
-                double s = 0.0;
-                for (int r = 0; r < TR; ++r) s += xt[r * (K + 1) + i] * xt[r * (K + 1) + j];
-                axx[q] += s;
+                double s0 = 0.0, s1 = 0.0;
+                int r = 0;
+                for (; r + 1 < rows; r += 2) {
+                    s0 += xt[r * (K + 1) + i] * xt[r * (K + 1) + j];
+                    s1 += xt[(r + 1) * (K + 1) + i] * xt[(r + 1) * (K + 1) + j];
+                }
+                if (r < rows) s0 += xt[r * (K + 1) + i] * xt[r * (K + 1) + j];
+                axx[q] += s0 + s1;
             }
         }
         __syncthreads();
@@ -400,11 +441,11 @@ extern "C" {
 
 size_t vmp_gaussian_shared_update_workspace_bytes(int32_t D, int32_t K)
 {
-    // partial blocks of <= 512 workgroups + A, c (Y form: D >= 1; message form: D = 0)
+    // partial blocks of <= 768 workgroups + A, c (Y form: D >= 1; message form: D = 0)
     if (K < 1 || K > 64 || D < 0 || D > 256) return 0;
     if (D == 0) return (size_t)(512 * (K + K * K)) * sizeof(double);
     const size_t DP = 32 * pow2_blocks(D, 32), KP = 16 * pow2_blocks(K, 16);
-    return (512 * ((DP + KP) * KP + KP) + KP * DP + KP) * sizeof(double);
+    return (768 * ((DP + KP) * KP + KP) + KP * DP + KP) * sizeof(double);
 }
 
 int32_t vmp_gaussian_shared_update(vmp_ctx *ctx, int64_t N, int32_t K, int32_t D,
@@ -433,15 +474,24 @@ int32_t vmp_gaussian_shared_update(vmp_ctx *ctx, int64_t N, int32_t K, int32_t D
         const int DP = 32 * pow2_blocks(D, 32), KP = 16 * pow2_blocks(K, 16);
         const int DB = DP / 32, KT = KP / 16;
         double *Apad = ws, *cpad = Apad + (int64_t)KP * DP, *P = cpad + KP;
-        hipLaunchKernelGGL(gshared_prepare_kernel, dim3(1), dim3(NT), 0, s, K, D, KP, DP, cov, B,
+        const size_t plds = (size_t)(K * K + 64 * (K + 1)) * sizeof(double);
+        static bool praised[64] = {false};
+        if (plds > 48 * 1024 && !praised[ctx->device & 63]) {
+            VMP_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)gshared_prepare_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   160 * 1024));
+            praised[ctx->device & 63] = true;
+        }
+        hipLaunchKernelGGL(gshared_prepare_kernel, dim3(1), dim3(NT), plds, s, K, D, KP, DP, cov, B,
                            b_sd, b_sk, p0, Apad, cpad);
         VMP_HIP_CHECK(ctx, hipGetLastError());
         const int64_t ntiles = (N + TN - 1) / TN;
         const int64_t blk = (int64_t)(DP + KP) * KP + KP;
         int64_t g = ntiles;
-        const int64_t gmax = (int64_t)ctx->num_cu * 2;
+        const int per_cu = vmp_tune_get("gshared_wgs_per_cu", DB * KT <= 2 ? 3 : 2);
+        const int64_t gmax = (int64_t)ctx->num_cu * per_cu;
         if (g > gmax) g = gmax;
-        if (g > 512) g = 512;
+        if (g > 768) g = 768;
         if (g < 1) g = 1;
         // 16-byte accesses where every address they touch is 16-byte aligned
         const int yvec = ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
@@ -461,8 +511,8 @@ int32_t vmp_gaussian_shared_update(vmp_ctx *ctx, int64_t N, int32_t K, int32_t D
 #undef VMP_GS
         VMP_HIP_CHECK(ctx, hipGetLastError());
         const int total = K + K * K + D * K;
-        hipLaunchKernelGGL(gshared_reduce_kernel, dim3((total + NT - 1) / NT), dim3(NT), 0, s, P,
-                           (int)g, blk, K, D, KP, DP, 1, stats);
+        hipLaunchKernelGGL(gshared_reduce_kernel, dim3((total + NT / 16 - 1) / (NT / 16)), dim3(NT),
+                           0, s, P, (int)g, blk, K, D, KP, DP, 1, stats);
         VMP_HIP_CHECK(ctx, hipGetLastError());
         return VMP_OK;
     }
@@ -474,7 +524,7 @@ int32_t vmp_gaussian_shared_update(vmp_ctx *ctx, int64_t N, int32_t K, int32_t D
     if (g > gmax) g = gmax;
     if (g > 512) g = 512;
     if (g < 1) g = 1;
-    const size_t lds = (size_t)(K * K + K + 2 * TR * (K + 1)) * sizeof(double);
+    const size_t lds = (size_t)(K * (K + 1) + K + 2 * TR * (K + 1)) * sizeof(double);
     static bool raised[64] = {false};
     const int dev = ctx->device & 63;
     if (!raised[dev] && lds > 48 * 1024) {

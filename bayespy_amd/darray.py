@@ -232,7 +232,9 @@ def _program_key(fn, kinds):
         cells = tuple(c.cell_contents for c in (fn.__closure__ or ()))
         if not all(isinstance(v, numbers.Number) for v in cells):
             return None
-        key = (fn.__code__, fn.__defaults__, cells, kinds)
+        kw = getattr(fn, '__kwdefaults__', None)
+        key = (fn.__code__, fn.__defaults__, None if not kw else tuple(sorted(kw.items())), cells,
+               kinds)
         hash(key)
         return key
     except (AttributeError, TypeError, ValueError):
@@ -291,6 +293,7 @@ def fuse(fn, *operands):
         flat += _strides(a.t, shape)
     c_str = (ctypes.c_int64 * max(len(flat), 1))(*flat)
     rt.sync_stream()
+    rt.note_reads(arrays)
     rt.check(rt.lib.vmp_ewise(rt.ctx, nd, c_shape, nin, c_in, c_str, nops, c_ops,
                               nconsts, c_consts, ctypes.c_void_p(out.t.data_ptr())))
     rt.keep_until_flush(arrays, out)

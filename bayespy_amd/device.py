@@ -132,7 +132,12 @@ class Runtime:
         collective: it stands where the reference sums a message over a plate the parent
         lacks (node.py:650, dot.py:581) and where it sums the per-node lower bound
         (expfamily.py:470-480)."""
-        self.host_access('all_reduce_sum_')
+        if self._capturing and self._comm_state is True:
+            # the library's collective is a launch on the context's stream like its kernels: a
+            # sweep recording holds it (graph_iter.py establishes the communicator beforehand)
+            self.flush_small()
+        else:
+            self.host_access('all_reduce_sum_')
         self._refresh_dist()
         if self._ensure_comm():
             if tensor.numel() == 0:
@@ -282,6 +287,19 @@ class Runtime:
 
     _tune_sm = False
     _tune_ew = True
+
+    # which device arrays the kernels of a sweep recording READ (graph_iter.py: an input of the
+    # recorded graph that no launch reads needs no copy-back before a replay); None = not logging
+    _read_log = None
+
+    def note_reads(self, arrays):
+        log = self._read_log
+        if log is None:
+            return
+        for a in arrays:
+            t = getattr(a, 't', a) if a is not None else None
+            if t is not None and hasattr(t, 'untyped_storage'):
+                log.add(t.untyped_storage().data_ptr())
 
     def set_tune(self, key, value):
         if self.lib is not None:

@@ -337,6 +337,30 @@ def _check_device(x, bad, exc_type, message):
     get_runtime().defer_check(misc.sum_multiply(ind).t, exc_type, message)
 
 
+def _wsum(pairs):
+    """sum_i coef_i * array_i as ONE fused launch per six operands (a chain of two-operand
+    additions is a chain of dependent launches: 3-5 us each on scalars)."""
+    pairs = [(float(c), _arr(a)) for c, a in pairs]
+    if not pairs:
+        return None
+    while True:
+        chunk, pairs = pairs[:6], pairs[6:]
+        cs = tuple(c for c, _ in chunk)
+        if len(chunk) == 1 and cs[0] == 1.0:
+            acc = chunk[0][1]
+        else:
+            def f(*xs, cs=cs):
+                tot = None
+                for c, x in zip(cs, xs):
+                    t = x if c == 1.0 else c * x
+                    tot = t if tot is None else tot + t
+                return tot
+            acc = fuse(f, *[a for _, a in chunk])
+        if not pairs:
+            return acc
+        pairs = [(1.0, acc)] + pairs
+
+
 def _sum_last(x, n):
     return x if n == 0 else misc.sum_multiply(x, axis=tuple(range(-n, 0)))
 
@@ -1172,16 +1196,16 @@ class MixtureFamily(Family):
         if uk is None:
             uk = self._with_cluster_axis(u)
         phik = self.base.phi_from_parents(up[1:])
-        L = _arr(self.base.cgf_from_parents(up[1:]))
+        parts = [(1.0, _arr(self.base.cgf_from_parents(up[1:])))]
         for ph, ui, nd in zip(phik, uk, self.ndims):
             if nd > 0 and getattr(self.base, 'finite_phi', False):
                 # phi_k . u_n as a contraction (plates x clusters, over the variable axes: a
                 # matrix-core GEMM) -- not a plates x clusters x D x D product and its sum
-                t = misc.sum_multiply(_arr(ph), ui, axis=tuple(range(-nd, 0)))
-                L = fuse(lambda a, b: a + b, L, t)
+                parts.append((1.0, misc.sum_multiply(_arr(ph), ui, axis=tuple(range(-nd, 0)))))
                 continue
             t = fuse(lambda a, b: da.where_nonzero(b, a) * b, _arr(ph), ui)
-            L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
+            parts.append((1.0, _sum_last(t, nd)))
+        L = _wsum(parts)                         # (one pass over plates x clusters)
         self._ll_cache = (key, deps, L)          # `deps` keeps the keyed arrays alive
         return L
 
@@ -2191,7 +2215,7 @@ class GenericPlan(GraphIteration):
                 continue
             terms = m.terms if isinstance(m, Terms) or _is_lazy(m) else \
                 [(1.0, list(m) if isinstance(m, tuple) else [_arr(m)])]
-            msg = None
+            parts = []
             for coef, factors in terms:
                 factors = list(factors)
                 mshape = broadcasted_shape(*[f.shape for f in factors])
@@ -2199,13 +2223,8 @@ class GenericPlan(GraphIteration):
                 from_shape = plates_self + dims
                 if mask is not None:
                     factors.append(_trail(mask, nd))
-                t = self._plate_sum(factors, to_shape, from_shape)
-                c = float(coef) * r
-                if msg is None:
-                    msg = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
-                else:
-                    msg = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, msg, t)
-            out.append(msg)
+                parts.append((float(coef) * r, self._plate_sum(factors, to_shape, from_shape)))
+            out.append(_wsum(parts))
         if ckey is not None:
             self._msg_cache[(id(child), index)] = (ckey, (u, up), list(out))    # keeps the keyed arrays alive
         return out
@@ -2229,7 +2248,9 @@ class GenericPlan(GraphIteration):
             return False
         rt = self.rt
         rt._refresh_dist()
-        return rt.world > 1
+        # (BAYESPY_AMD_SHARD_WORLD1=1: a world of ONE rank runs the sharded code path too, every
+        # collective included -- how the RCCL path is exercised on a one-GPU box)
+        return rt.world > 1 or os.environ.get('BAYESPY_AMD_SHARD_WORLD1') == '1'
 
     def _messages_from_children(self, node):
         total = [None] * len(node.dims)
@@ -2381,6 +2402,7 @@ class GenericPlan(GraphIteration):
         vp = ctypes.c_void_p
         if dot is not None:
             Yop, y_sd, y_sn, D, _, Bop, b_sd, b_sk = dot
+            rt.note_reads([Yop, Bop, p0v, cov])
             rc = rt.lib.vmp_gaussian_shared_update(
                 rt.ctx, N, K, D, vp(Yop.t.data_ptr()), y_sd, y_sn, vp(Bop.t.data_ptr()), b_sd, b_sk,
                 None, 0, 0, vp(p0v.t.data_ptr()), vp(cov.t.data_ptr()), vp(x.t.data_ptr()), K, 1,
@@ -2388,6 +2410,7 @@ class GenericPlan(GraphIteration):
             keep = [Yop, Bop, p0v, cov]
         else:
             m2 = contiguous(_arr(m0).broadcast_to(xshape)).reshape((N, K))
+            rt.note_reads([m2, p0v, cov])
             rc = rt.lib.vmp_gaussian_shared_update(
                 rt.ctx, N, K, 0, None, 0, 0, None, 0, 0, vp(m2.t.data_ptr()), K, 1,
                 None if p0v is None else vp(p0v.t.data_ptr()), vp(cov.t.data_ptr()),
@@ -2624,15 +2647,8 @@ class GenericPlan(GraphIteration):
             if _is_lazy(f):
                 # a sum of products among the factors: one plate sum per product
                 rest = factors[:i] + factors[i + 1:]
-                tot = None
-                for coef, fs in f.terms:
-                    t = self._plate_sum(rest + list(fs), to_plates, from_plates)
-                    c = float(coef)
-                    if tot is None:
-                        tot = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
-                    else:
-                        tot = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, tot, t)
-                return tot
+                return _wsum([(coef, self._plate_sum(rest + list(fs), to_plates, from_plates))
+                              for coef, fs in f.terms])
         if any(isinstance(f, LazyContract) for f in factors):
             return self._plate_sum_contract(factors, to_plates, from_plates)
         big = [f for f in factors if f.size > 1]
@@ -2785,20 +2801,16 @@ class GenericPlan(GraphIteration):
         sharded = self._is_sharded(node)
         if not any_active and not sharded:
             return None, 0.0
-        tot = None
+        parts = []
         for coef, factors in terms:
             factors = list(factors) if factors else [_ones(())]
             if mask is not None:
                 factors.append(mask)
-            t = self._plate_sum(factors, (), node.plates)
-            c = float(coef)
-            if tot is None:
-                tot = t if c == 1.0 else fuse(lambda t_, c_=c: c_ * t_, t)
-            else:
-                tot = fuse(lambda a_, t_, c_=c: a_ + c_ * t_, tot, t)
+            parts.append((float(coef), self._plate_sum(factors, (), node.plates).reshape(())))
         if presummed is not None:
             # a part of the term that is a sum over this rank's plates already
-            tot = presummed if tot is None else fuse(lambda a_, b_: a_ + b_, tot, presummed)
+            parts.append((1.0, _arr(presummed).reshape(())))
+        tot = _wsum(parts)
         if sharded:
             tot = fuse(lambda x: x + 0.0, tot) if any_active else DArray.zeros(())
             self.rt.all_reduce_sum_(tot.t)

@@ -57,7 +57,7 @@ def _enabled():
 
 class _Recording:
     __slots__ = ('key', 'graph', 'copy_graph', 'pairs', 'outvec', 'n_bound', 'bound_index', 'factors',
-                 'checks', 'template', 'fresh', 'replays', 'copy_bytes', 'old', 'new', 'sig')
+                 'checks', 'template', 'fresh', 'replays', 'copy_bytes', 'old', 'new', 'sig', 'skip')
 
 
 class GraphIteration:
@@ -178,15 +178,31 @@ class GraphIteration:
         return leaves, sig
 
     @staticmethod
-    def _dead_inputs(sig, leaves, upd):
-        """Per leaf of a state snapshot: is it the natural parameters or the log-normaliser of a
-        node the sweep updates (``upd``)?  Those are written before anything in the sweep reads
-        them, so the recorded graph never reads the copy it was given."""
+    def _dead_inputs(sig, leaves, upd, reads=None):
+        """Per leaf of a state snapshot: is it dead as an INPUT of the recorded sweep?  (a) The
+        natural parameters and the log-normaliser of a node the sweep updates (``upd``): written
+        before anything in the sweep reads them.  (b) With ``reads`` -- the storages the launches
+        of the recording read (Runtime.note_reads) --: any array of an updated node that no launch
+        read, e.g. the means of a node whose plate sums serve every message that leaves it before
+        its own update writes new means.  The recorded graph never reads the copy it was given."""
         tags = [e[0] for e in sig if len(e) >= 2 and e[1] == 'tensor']
         if len(tags) != len(leaves) or os.environ.get('BAYESPY_AMD_GRAPH_COPY_ALL') == '1':
             return [False] * len(leaves)
         upd_ids = set(id(n) for n in upd)
-        return [len(t) >= 2 and t[0] in upd_ids and t[1] in ('phi', 'g') for t in tags]
+        dead = [len(t) >= 2 and t[0] in upd_ids and t[1] in ('phi', 'g') for t in tags]
+        if reads is not None and os.environ.get('BAYESPY_AMD_GRAPH_READ_LOG', '1') != '0':
+            for i, (t, leaf) in enumerate(zip(tags, leaves)):
+                if not dead[i] and len(t) >= 2 and t[0] in upd_ids \
+                        and leaf.untyped_storage().data_ptr() not in reads:
+                    dead[i] = True
+        return dead
+
+    @staticmethod
+    def _constant_state(st):
+        """A fully observed node: its arrays never change -- they keep their wrapper objects, so that
+        sums over them remembered by identity (sum y^2 of the data: a pass over (D, N)) stay
+        remembered through recordings and replays."""
+        return bool(st.observed and not st.partial)
 
     @staticmethod
     def _rewrap(obj, memo):
@@ -265,6 +281,8 @@ class GraphIteration:
         # fresh wrappers: nothing lazily evaluated from the present contents stays reachable
         memo = {}
         for _, st in states:
+            if self._constant_state(st):
+                continue
             for f in _STATE_FIELDS:
                 setattr(st, f, self._rewrap(getattr(st, f), memo))
         try:
@@ -308,6 +326,7 @@ class GraphIteration:
                 if os.environ.get('BAYESPY_AMD_GRAPH_QUEUE', '0') != '1':
                     rt.set_tune('small_queue_ew', 0)
                     rt.set_tune('small_queue_sm', 0)
+                rt._read_log = set()
                 with torch.cuda.graph(rec.graph, capture_error_mode='thread_local'):
                     with rt.operation():
                         for n in upd:
@@ -315,9 +334,8 @@ class GraphIteration:
                         parts = [self._lower_bound_device(n) for n in bound]
                         items, rt._deferred = rt._deferred, []
                         dev = [t.t.reshape(1) for t, _ in parts if t is not None]
-                        rt.flush_small()        # the bound terms are about to be read by torch
-                        flags = [f.reshape(-1).any().reshape(1).to(torch.float64) for f, _, _ in items]
-                        rec.outvec = torch.cat(dev + flags) if dev or flags else None
+                        rt.flush_small()        # the bound terms are about to be read
+                        rec.outvec = self._pack_outputs(dev, [f for f, _, _ in items])
             finally:
                 rt.set_tune('small_queue_ew', int(ew_was))
                 rt.set_tune('small_queue_sm', int(sm_was))
@@ -326,6 +344,7 @@ class GraphIteration:
                 except Exception:         # noqa: BLE001 -- the error of the recording itself matters more
                     pass
                 rt._capturing = False
+                reads, rt._read_log = rt._read_log, None
                 rt._deferred = []
                 misc._CUR_MEMO[0] = memo_was
                 self.__dict__.get('_contract_memo', {}).clear()
@@ -343,7 +362,7 @@ class GraphIteration:
             # node's bound term, after its update): as inputs of the graph they are dead, and the
             # copy-back of a replay leaves them out -- at config 2 of the PCA model 136 of 264 MB.
             # (An array that is also reachable through a live field keeps its copy.)
-            dead_tag = self._dead_inputs(sig_old, old, upd)
+            dead_tag = self._dead_inputs(sig_old, old, upd, reads)
             live_ptrs = set(o.data_ptr() for o, d in zip(old, dead_tag) if not d)
             seen, pairs = set(), []
             for o, n_, d in zip(old, new, dead_tag):
@@ -356,6 +375,7 @@ class GraphIteration:
                 seen.add(ko)
                 pairs.append((o, n_))
             rec.pairs = pairs
+            rec.skip = [bool(d and o.data_ptr() not in live_ptrs) for o, d in zip(old, dead_tag)]
             rec.old, rec.new, rec.sig = old, new, sig_old
             rec.copy_graph = None
             if pairs:
@@ -363,8 +383,7 @@ class GraphIteration:
                 gc.disable()
                 try:
                     with torch.cuda.graph(rec.copy_graph, capture_error_mode='thread_local'):
-                        for o, n_ in pairs:
-                            o.copy_(n_)
+                        self._copy_pairs(pairs)
                 finally:
                     if gc_was_on:
                         gc.enable()
@@ -395,6 +414,53 @@ class GraphIteration:
                 traceback.print_exc()
             return None
 
+    def _pack_outputs(self, vals, flags):
+        """One vector [bound terms ..., any(flag) ...] for the single read of a replay: ONE launch of
+        the library (vmp_pack_outputs) where it takes the arrays as they are, torch otherwise."""
+        import ctypes
+        rt = self.rt
+        torch = rt.torch
+        if not vals and not flags:
+            return None
+        ok = hasattr(rt.lib, 'vmp_pack_outputs') and all(
+            f.is_contiguous() and f.dtype in (torch.int32, torch.float64) for f in flags) and all(
+            v.is_contiguous() and v.dtype == torch.float64 for v in vals)
+        if not ok:
+            fl = [f.reshape(-1).any().reshape(1).to(torch.float64) for f in flags]
+            return torch.cat(list(vals) + fl)
+        ents = [(v, 1, 0) for v in vals] + \
+            [(f, f.numel(), 1 if f.dtype == torch.int32 else 2) for f in flags]
+        n = len(ents)
+        out = torch.empty(n, dtype=torch.float64, device=rt.device)
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _, _ in ents])
+        cnt = (ctypes.c_int64 * n)(*[int(c) for _, c, _ in ents])
+        kind = (ctypes.c_int32 * n)(*[k for _, _, k in ents])
+        rt.check(rt.lib.vmp_pack_outputs(rt.ctx, n, src, cnt, kind, ctypes.c_void_p(out.data_ptr())))
+        self._pack_keep = ents          # (operands stay referenced while the recording lives)
+        return out
+
+    def _copy_pairs(self, pairs):
+        """dst <- src for (dst, src) tensor pairs: the dense ones by ONE launch of the library
+        (vmp_copy_many: a dozen small state arrays were a dozen dependent copy nodes), the rest
+        one by one."""
+        import ctypes
+        rt = self.rt
+        dense = [(o, n_) for o, n_ in pairs if o.is_contiguous() and n_.is_contiguous()
+                 and o.numel() == n_.numel() and o.dtype == n_.dtype == rt.torch.float64]
+        for o, n_ in pairs:
+            if not any(o is d for d, _ in dense):
+                o.copy_(n_)
+        if dense and hasattr(rt.lib, 'vmp_copy_many'):
+            m = len(dense)
+            src = (ctypes.c_void_p * m)(*[n_.data_ptr() for _, n_ in dense])
+            dst = (ctypes.c_void_p * m)(*[o.data_ptr() for o, _ in dense])
+            cnt = (ctypes.c_int64 * m)(*[o.numel() for o, _ in dense])
+            rt.sync_stream()
+            rt.check(rt.lib.vmp_copy_many(rt.ctx, m, src, dst, cnt))
+        else:
+            for o, n_ in dense:
+                o.copy_(n_)
+
     def _graph_replay(self, rec):
         rt = self.rt
         torch = rt.torch
@@ -415,12 +481,12 @@ class GraphIteration:
                 return a.data_ptr() == b.data_ptr() and a.shape == b.shape \
                     and a.stride() == b.stride()
             extra, from_new = [], False
-            for c, o, n_ in zip(cur, rec.old, rec.new):
+            for c, o, n_, skip in zip(cur, rec.old, rec.new, rec.skip):
                 if same(c, o):
                     continue
                 if same(c, n_):
                     from_new = True
-                else:
+                elif not skip:            # (a dead input needs no copy wherever it lives now)
                     extra.append((o, c))
             if from_new and rec.copy_graph is not None:
                 rec.copy_graph.replay()
@@ -434,8 +500,9 @@ class GraphIteration:
         # the state objects of the recording, as fresh wrappers (same device arrays)
         memo = {}
         for st, fields in rec.template:
+            const = self._constant_state(st)
             for f, v in fields.items():
-                setattr(st, f, self._rewrap(v, memo) if f != 'stale' else v)
+                setattr(st, f, v if (f == 'stale' or const) else self._rewrap(v, memo))
         self._graph_reset_caches()
         for bad, (exc_type, message) in zip(vals[rec.n_bound:], rec.checks):
             if bad:
@@ -455,8 +522,13 @@ class GraphIteration:
         if rt.device.type != 'cuda':
             return False
         rt._refresh_dist()
-        if rt.world > 1:
-            return False
+        if rt.world > 1 or os.environ.get('BAYESPY_AMD_SHARD_WORLD1') == '1':
+            # a sharded model: its plate sums are completed over the ranks inside the sweep.  The
+            # library's RCCL collective (vmp_allreduce_sum_f64) is enqueued on the context's stream
+            # and is recorded like a kernel; torch.distributed's (gloo: CPU tests, several ranks on
+            # one GPU) is not -- those worlds keep the eager sweeps
+            if os.environ.get('BAYESPY_AMD_GRAPH_SHARDED', '1') == '0' or not rt._ensure_comm():
+                return False
         key = self._graph_key(upd, bound)
         log, self._g_log = self._g_log, []
         rec = self._g_rec

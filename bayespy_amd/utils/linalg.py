@@ -41,6 +41,7 @@ class CholFactor:
         info = (rt.torch.empty(batch, dtype=rt.torch.int32, device=rt.device) if batch else
                 rt.torch.zeros(1, dtype=rt.torch.int32, device=rt.device))
         rt.sync_stream()
+        rt.note_reads([C])
         rt.check(rt.lib.vmp_spd_batched(rt.ctx, n, batch, ctypes.c_void_p(C.t.data_ptr()),
                                         ctypes.c_void_p(inv.t.data_ptr()),
                                         ctypes.c_void_p(logdet.t.data_ptr()),
@@ -73,6 +74,7 @@ def gaussian_moments(phi0, phi1):
     u0, u1, g = DArray.empty(p0.shape), DArray.empty(p1.shape), DArray.empty(plates)
     info = rt.torch.zeros(batch, dtype=rt.torch.int32, device=rt.device)
     rt.sync_stream()
+    rt.note_reads([p0, p1])
     rt.check(rt.lib.vmp_gaussian_moments(rt.ctx, n, batch, ctypes.c_void_p(p0.t.data_ptr()),
                                          ctypes.c_void_p(p1.t.data_ptr()),
                                          ctypes.c_void_p(u0.t.data_ptr()),
@@ -212,6 +214,7 @@ def block_banded_solve(A, B, y):
     ldet = DArray.empty(pm)
     info = rt.torch.zeros(max(nm, 1), dtype=rt.torch.int32, device=rt.device)
     rt.sync_stream()
+    rt.note_reads([Ac, Bc, yc])
     rt.check(rt.lib.vmp_block_banded_solve(
         rt.ctx, N, D, nm, ny, ctypes.c_void_p(Ac.t.data_ptr()), ctypes.c_void_p(Bc.t.data_ptr()),
         ctypes.c_void_p(yc.t.data_ptr()), ctypes.c_void_p(V.t.data_ptr()),

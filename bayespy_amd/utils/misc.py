@@ -195,6 +195,7 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
         hit = memo.get(sig)
         if hit is not None:
             return hit[0].reshape(tuple(out_shape_keep))
+    rt.note_reads(arrays)
     if len(arrays) >= 2 and len(reduce_axes) > 0:
         hoisted = _hoist_invariant(arrays, shape, reduce_axes, out_shape_keep, scale)
         if hoisted is not None:
@@ -401,6 +402,7 @@ def normalized_exp(phi):
     p = DArray.empty(phi.shape)
     lse = DArray.empty(phi.shape[:-1] + (1,))
     rt.sync_stream()
+    rt.note_reads([phi])
     rt.check(rt.lib.vmp_softmax_moments(rt.ctx, rows, K, ctypes.c_void_p(phi.t.data_ptr()),
                                         ctypes.c_void_p(p.t.data_ptr()),
                                         ctypes.c_void_p(lse.t.data_ptr())))
@@ -646,6 +648,7 @@ def take(x, imap, axis=-1):
     out = DArray.empty(x.shape[:a] + imap.shape + x.shape[a + 1:])
     rt = get_runtime()
     rt.sync_stream()
+    rt.note_reads([x])
     rt.check(rt.lib.vmp_take_axis(rt.ctx, outer, imap.length, inner,
                                   ctypes.c_void_p(x.t.data_ptr()), imap.n,
                                   ctypes.c_void_p(imap.idx.data_ptr()),
@@ -674,6 +677,7 @@ def put_simple(y, imap, axis=-1):
     out = DArray.empty(y.shape[:a] + (imap.length,) + y.shape[a + nax:])
     rt = get_runtime()
     rt.sync_stream()
+    rt.note_reads([y])
     rt.check(rt.lib.vmp_segment_sum_axis(rt.ctx, outer, imap.n, inner,
                                          ctypes.c_void_p(y.t.data_ptr()), imap.length,
                                          ctypes.c_void_p(imap.ptr.data_ptr()),
@@ -702,6 +706,7 @@ def concatenate(arrays, axis=-1):
     off = 0
     for a, n in zip(arrays, lengths):
         src = contiguous(a.broadcast_to(common[:ax] + (n,) + common[ax + 1:]))
+        rt.note_reads([src])
         rt.check(rt.lib.vmp_take_axis(rt.ctx, outer, n, inner, ctypes.c_void_p(src.t.data_ptr()),
                                       n, None, ctypes.c_void_p(out.t.data_ptr()), total, off))
         off += n

@@ -62,6 +62,7 @@ def alpha_beta_recursion(logp0, logP):
     g = DArray.empty(plates)
     ws = rt.torch.empty(max(B * N * K, 1), dtype=rt.torch.float64, device=rt.device)
     rt.sync_stream()
+    rt.note_reads([p0, Pd])
     rt.check(rt.lib.vmp_alpha_beta_recursion(
         rt.ctx, N, K, B, ctypes.c_void_p(p0.t.data_ptr()), p0_bs,
         ctypes.c_void_p(Pd.t.data_ptr()), P_bs, P_ts, ctypes.c_void_p(z0.t.data_ptr()),

@@ -588,6 +588,19 @@ int32_t vmp_graph_end(vmp_ctx *ctx, void **graph);
 int32_t vmp_graph_launch(vmp_ctx *ctx, void *graph);
 int32_t vmp_graph_destroy(vmp_ctx *ctx, void *graph);
 
+/* n device-to-device copies of `count[i]` doubles each (contiguous, non-overlapping) as ONE launch
+ * per 24 of them on the context's stream -- the copy-back of the state arrays of a recorded sweep
+ * (graph_iter.py; the reference has no analogue: it rebinds NumPy arrays, stochastic.py:223-273). */
+int32_t vmp_copy_many(vmp_ctx *ctx, int32_t n, const double *const *src, double *const *dst,
+                      const int64_t *count);
+
+/* out[i] for i < n: kind[i] = 0: the double at src[i]; 1 / 2: 1.0 if any of the count[i] int32 /
+ * double values at src[i] is non-zero (NaN included), else 0.0 -- the lower-bound terms and the
+ * validity flags of a recorded sweep (expfamily.py:400-480; "Matrix not positive definite",
+ * utils/linalg.py:58-59) gathered by ONE launch for the single device-to-host read of a replay. */
+int32_t vmp_pack_outputs(vmp_ctx *ctx, int32_t n, const void *const *src, const int64_t *count,
+                         const int32_t *kind, double *out);
+
 /* Queue of SMALL operations.  Between vmp_queue_begin and vmp_queue_end, vmp_ewise and
  * vmp_sum_multiply calls on small arrays (<= 2048 outputs, <= 32768 products) and vmp_spd_batched
  * calls on a few small matrices (8 < n <= 32, batch <= 4) are recorded on the host and run, in

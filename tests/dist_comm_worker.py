@@ -53,6 +53,25 @@ def main():
         Q.update(repeat=int(g['n_iter']), verbose=False)
         res['L_' + stats] = np.array(Q.L[:Q.iter])
         res['W_' + stats] = np.asarray(Q['W'].u[0])
+    # ---- the generic engine on the same split: its sweep is recorded into a HIP graph WITH the
+    # library's all-reduces inside (on a one-GPU box the world has one rank: the sharded code
+    # path, every collective included, is switched on for it) ------------------------------------
+    if world == 1:
+        os.environ['BAYESPY_AMD_SHARD_WORLD1'] = '1'
+    n_it = max(int(g['n_iter']), 8)
+    for mode in ('graph', 'eager'):
+        os.environ['BAYESPY_AMD_GRAPH'] = '1' if mode == 'graph' else '0'
+        before = rt.collective_calls['library']
+        Q = build_pca(nodes, VB, y[:, lo:hi], x0[lo:hi], x0.shape[1], shard=True, engine='generic')
+        Q.ignore_bound_checks = True
+        Q.update(repeat=n_it, verbose=False)
+        res['Lg_' + mode] = np.array(Q.L[:Q.iter])
+        res['Wg_' + mode] = np.asarray(Q['W'].u[0])
+        info = Q.plans[0].graph_info()
+        res['recorded_' + mode] = np.array([int(info['recorded']), int(info['replays'])])
+        res['calls_' + mode] = np.array([rt.collective_calls['library'] - before])
+    os.environ.pop('BAYESPY_AMD_SHARD_WORLD1', None)
+    os.environ['BAYESPY_AMD_GRAPH'] = '1'
     res['lo'], res['hi'] = lo, hi
     np.savez(os.path.join(out, 'rank%d.npz' % rank), **res)
     rt.check(rt.lib.vmp_comm_destroy(rt.ctx))

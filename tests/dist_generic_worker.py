@@ -166,6 +166,64 @@ def main():
         for nm, nd in dict(A=A, C=C, tau=tau, alpha=alpha, gamma=gamma, nu=nu).items():
             res['L_' + nm] = np.array(Q.l[nd][:n])
         res['A_u0'] = np.asarray(A.u[0])
+        res['engine'] = type(Q.plans[0]).__name__
+    elif case in ('pca_fused_gram', 'pca_fused_stream', 'pca_generic'):
+        # the headline block (both statistics forms) and the same model on the generic engine, the
+        # plate split RAGGED over the two ranks (a third / two thirds)
+        from models import build_pca
+        from bayespy_amd.device import get_runtime
+        g = np.load(os.path.join(golden, 'pca_n777_d20_k5.npz'))
+        y, x0 = g['y'], g['x0']
+        N = y.shape[1]
+        cut = [0, N // 3, N]
+        lo, hi = cut[rank], cut[rank + 1]
+        kw = {'engine': 'generic'} if case == 'pca_generic' else {}
+        Q = build_pca(nodes, VB, y[:, lo:hi], x0[lo:hi], x0.shape[1], shard=True, **kw)
+        if case != 'pca_generic':
+            Q.plans[0].stats = case.split('_')[-1]
+        Q.ignore_bound_checks = True
+        Q.update(repeat=int(g['n_iter']), verbose=False)
+        res['engine'] = type(Q.plans[0]).__name__
+        res['L'] = np.array(Q.L[:Q.iter])
+        for nm in ('Y', 'X', 'W', 'tau', 'alpha'):
+            res['L_' + nm] = np.array(Q.l[Q[nm]][:Q.iter])
+        res['W_u0'], res['W_u1'] = np.asarray(Q['W'].u[0]), np.asarray(Q['W'].u[1])
+        res['X_u0'] = np.asarray(Q['X'].u[0])
+        res['tau_u0'], res['alpha_u1'] = np.asarray(Q['tau'].u[0]), np.asarray(Q['alpha'].u[1])
+        rt = get_runtime()
+        res['calls'] = np.array([rt.collective_calls['library'] + rt.collective_calls['torch']])
+        res['lo'], res['hi'] = lo, hi
+    elif case in ('gmm_fused', 'gmm_generic'):
+        # the mixture block / the mixture on the generic engine, plate split ragged over the ranks
+        from bayespy_amd.nodes import (GaussianARD, Gaussian, Wishart, Dirichlet, Categorical,
+                                       Mixture)
+        from bayespy_amd.device import get_runtime
+        g = np.load(os.path.join(golden, 'gmm_n3000_d8_k16.npz'))
+        y, lab0 = g['y'], g['lab0']
+        N, D = y.shape
+        K = g['alpha_u0'].shape[-1]
+        cut = [0, N // 3 + 1, N]
+        lo, hi = cut[rank], cut[rank + 1]
+        alpha = Dirichlet(1e-3 * np.ones(K), name='alpha')
+        z = Categorical(alpha, plates=(hi - lo,), name='z').shard(-1)
+        mu = GaussianARD(0, 1e-3, shape=(D,), plates=(K,), name='mu')
+        Lam = Wishart(D, 0.01 * np.identity(D), plates=(K,), name='Lambda')
+        Y = Mixture(z, Gaussian, mu, Lam, plates=(hi - lo,), name='Y')
+        z.initialize_from_value(lab0[lo:hi])
+        Y.observe(y[lo:hi])
+        Q = VB(Y, mu, Lam, z, alpha, engine='generic' if case == 'gmm_generic' else None)
+        Q.ignore_bound_checks = True
+        n = int(g['n_iter'])
+        Q.update(repeat=n, verbose=False)
+        res['engine'] = type(Q.plans[0]).__name__
+        res['L'] = np.array(Q.L[:n])
+        for nm in ('Y', 'mu', 'Lambda', 'z', 'alpha'):
+            res['L_' + nm] = np.array(Q.l[Q[nm]][:n])
+        res['mu_u0'], res['Lambda_u0'] = np.asarray(mu.u[0]), np.asarray(Lam.u[0])
+        res['alpha_u0'], res['z_u0'] = np.asarray(alpha.u[0]), np.asarray(z.u[0])
+        rt = get_runtime()
+        res['calls'] = np.array([rt.collective_calls['library'] + rt.collective_calls['torch']])
+        res['lo'], res['hi'] = lo, hi
     elif case == 'lssm_rotation':
         # the batch case of tests/golden/lssm_rotations.npz with the sequences split over the ranks:
         # the rotation statistics are global plate sums, every rank finds the same R and rotates

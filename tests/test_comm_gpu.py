@@ -41,3 +41,13 @@ def test_rccl_communicator_in_context(golden_dir, tmp_path):
             np.testing.assert_allclose(o['W_' + stats], g['W_u0'], rtol=1e-7, atol=1e-10)
             # replicated nodes are bitwise identical on all ranks
             np.testing.assert_array_equal(o['W_' + stats], outs[0]['W_' + stats])
+        # the generic engine's sharded sweep: recorded with the RCCL all-reduces inside, replayed,
+        # same bounds as the eager sweeps and as the unsharded live reference
+        n = len(g['L'])
+        assert o['recorded_graph'][0] == 1 and o['recorded_graph'][1] >= 3, o['recorded_graph']
+        assert o['recorded_eager'][0] == 0
+        assert o['calls_graph'][0] > 0 and o['calls_eager'][0] > o['calls_graph'][0]
+        np.testing.assert_allclose(o['Lg_graph'][:n], g['L'], rtol=1e-9)
+        np.testing.assert_allclose(o['Lg_graph'], o['Lg_eager'], rtol=1e-12)
+        np.testing.assert_allclose(o['Wg_graph'], o['Wg_eager'], rtol=1e-10, atol=1e-12)
+        np.testing.assert_array_equal(o['Wg_graph'], outs[0]['Wg_graph'])

@@ -24,14 +24,15 @@ class _Node:
 class _Plan(GraphIteration):
     """The decisions of GraphIteration over stubbed device work."""
 
-    def __init__(self, nodes, world=1, device='cuda'):
+    def __init__(self, nodes, world=1, device='cuda', library_comm=False):
         self.all = list(nodes)
         self.state = {id(n): object() for n in nodes}
         self._graph_init()
         self.recorded, self.replayed = 0, 0
         self.fail_recording = False
         self.rt = types.SimpleNamespace(device=types.SimpleNamespace(type=device), world=world,
-                                        _refresh_dist=lambda: None)
+                                        _refresh_dist=lambda: None,
+                                        _ensure_comm=lambda: library_comm)
 
     def _update_masks(self):
         pass
@@ -135,7 +136,10 @@ def test_graphs_are_declined_where_they_cannot_work(monkeypatch):
     p = _Plan([a])
     assert _sweeps(p, [a], [a], 5) == [False] * 5 and p.recorded == 0
     monkeypatch.delenv('BAYESPY_AMD_GRAPH')
-    assert _sweeps(_Plan([a], world=2), [a], [a], 5) == [False] * 5      # sharded: all-reduces
+    # sharded: the sweep holds all-reduces -- recorded only when they are the library's own RCCL
+    # launches (torch.distributed's gloo collectives cannot be recorded)
+    assert _sweeps(_Plan([a], world=2), [a], [a], 5) == [False] * 5
+    assert _sweeps(_Plan([a], world=2, library_comm=True), [a], [a], 5) == [False] * 2 + [True] * 3
     assert _sweeps(_Plan([a], device='cpu'), [a], [a], 5) == [False] * 5
     p = _Plan([a])
     p.fail_recording = True

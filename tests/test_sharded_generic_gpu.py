@@ -117,11 +117,56 @@ def test_sharded_lssm_matches_reference(golden_dir, tmp_path):
     r0, r1 = _launch('lssm', golden_dir, tmp_path, 29543)
     g = np.load(os.path.join(golden_dir, 'lssm.npz'))
     for r in (r0, r1):
+        assert str(r['engine']) == 'LSSMPlan'          # the fused state-space block's real kernels
         np.testing.assert_allclose(r['L'], g['lssmB_L'], rtol=1e-9)
         for nm in ('A', 'C', 'tau', 'alpha', 'gamma', 'nu'):
             np.testing.assert_allclose(r['L_' + nm], g['lssmB_%s_L' % nm], rtol=1e-8, atol=1e-7,
                                        err_msg=nm)
     assert np.array_equal(r0['A_u0'], r1['A_u0'])
+
+
+@pytest.mark.parametrize('case,port', [('pca_fused_gram', 29553), ('pca_fused_stream', 29554),
+                                       ('pca_generic', 29555)])
+def test_two_ranks_through_the_pca_block(golden_dir, tmp_path, case, port):
+    """Two real ranks through the headline block's REAL kernels (both statistics forms) and
+    through the generic engine's fused node update, the plate split a third / two thirds: bounds
+    and moments of the unsharded live-reference trace, replicated nodes bitwise equal."""
+    r0, r1 = _launch(case, golden_dir, tmp_path, port)
+    g = np.load(os.path.join(golden_dir, 'pca_n777_d20_k5.npz'))
+    for r in (r0, r1):
+        assert str(r['engine']) == ('GenericPlan' if case == 'pca_generic' else 'PCAPlan')
+        assert int(r['calls'][0]) > 0
+        np.testing.assert_allclose(r['L'], g['L'], rtol=1e-9)
+        for nm in ('Y', 'X', 'W', 'tau', 'alpha'):
+            np.testing.assert_allclose(r['L_' + nm], g['L_' + nm], rtol=1e-8, atol=1e-7, err_msg=nm)
+        np.testing.assert_allclose(r['W_u0'], g['W_u0'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r['W_u1'], g['W_u1'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r['tau_u0'], g['tau_u0'], rtol=1e-9)
+        np.testing.assert_allclose(r['alpha_u1'], g['alpha_u1'], rtol=1e-8)
+        np.testing.assert_allclose(r['X_u0'], g['X_u0'][:, int(r['lo']):int(r['hi'])],
+                                   rtol=1e-7, atol=1e-10)
+    assert int(r0['hi']) - int(r0['lo']) != int(r1['hi']) - int(r1['lo'])
+    for k in ('L', 'W_u0', 'W_u1', 'tau_u0', 'alpha_u1'):
+        assert np.array_equal(r0[k], r1[k]), k
+
+
+@pytest.mark.parametrize('case,port', [('gmm_fused', 29556), ('gmm_generic', 29557)])
+def test_two_ranks_through_the_mixture_block(golden_dir, tmp_path, case, port):
+    r0, r1 = _launch(case, golden_dir, tmp_path, port)
+    g = np.load(os.path.join(golden_dir, 'gmm_n3000_d8_k16.npz'))
+    for r in (r0, r1):
+        assert str(r['engine']) == ('GenericPlan' if case == 'gmm_generic' else 'GMMPlan')
+        assert int(r['calls'][0]) > 0
+        np.testing.assert_allclose(r['L'], g['L'], rtol=1e-9)
+        for nm in ('Y', 'mu', 'Lambda', 'z', 'alpha'):
+            np.testing.assert_allclose(r['L_' + nm], g['L_' + nm], rtol=1e-8, atol=1e-6, err_msg=nm)
+        np.testing.assert_allclose(r['mu_u0'], g['mu_u0'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r['Lambda_u0'], g['Lambda_u0'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r['alpha_u0'], g['alpha_u0'], rtol=1e-7)
+        np.testing.assert_allclose(r['z_u0'], g['z_u0'][int(r['lo']):int(r['hi'])], rtol=1e-6,
+                                   atol=1e-12)
+    for k in ('L', 'mu_u0', 'Lambda_u0', 'alpha_u0'):
+        assert np.array_equal(r0[k], r1[k]), k
 
 
 def test_sharded_lssm_rotation_matches_reference(golden_dir, tmp_path):
