@@ -1769,7 +1769,14 @@ class SumMultiplyFamily:
 
 
 def make_family(node):
+    from .extension import registered_family
     from .families_extra import make_extra_family
+    # node types registered from outside the package (plans/extension.py: the reference's
+    # Distribution contract, writingnodes.rst) come first: a registration may also replace a
+    # built-in family
+    fam = registered_family(node)
+    if fam is not None:
+        return fam
     fam = make_extra_family(node)
     if fam is not None:
         return fam
@@ -1801,7 +1808,10 @@ def make_family(node):
         return GaussianMarkovChainFamily(node)
     if isinstance(node, MarkovChainToGaussian):
         return ChainToGaussianFamily(node)
-    raise NotImplementedError('no device family for node type %s' % type(node).__name__)
+    raise NotImplementedError('no device family for node type %s (a node type defined outside the '
+                              'package registers its formulas with '
+                              'bayespy_amd.inference.register_family, plans/extension.py)'
+                              % type(node).__name__)
 
 
 # ---------------------------------------------------------------------------
