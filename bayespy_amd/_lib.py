@@ -213,6 +213,7 @@ SIGNATURES = {
                                        c_vp, c_vp, c_vp, c_vp]),
     'vmp_ctx_set_timing': (c_i32, [c_vp, c_i32]),
     'vmp_pca_xjoin': (c_i32, [c_vp]),
+    'vmp_pca_ensure_gram': (c_i32, [c_vp]),
     'vmp_pca_small_ops': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                   c_i32, P(c_i32), c_vp]),
     'vmp_pca_small_ops_mean': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64,

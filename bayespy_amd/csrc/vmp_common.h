@@ -35,6 +35,13 @@ struct vmp_ctx {
     // streams / events of the pipelined plate pass of the missing-data PCA block (vmp_mpca.hip)
     hipStream_t ms[3];
     hipEvent_t me[VMP_NME];
+    // Gram-form PCA block: the messages to W, S = [G A^T; A G A^T], of the latest latent pass are
+    // still to be formed from (G, A) -- by the fused tail kernel (vmp_pca_small.hip) when the next
+    // small operation is tau / alpha / bound, by vmp_pca_ensure_gram before anything else reads S
+    int gram_pending;
+    int gram_D, gram_K;
+    double *gram_state;
+    double *gram_P;
     // RCCL communicator (vmp_comm.hip); null = a world of one rank
     void *comm;
     int comm_rank, comm_world;
@@ -44,6 +51,9 @@ struct vmp_ctx {
     void *queue;
     char err[512];
 };
+
+// forms the pending S = [G A^T; A G A^T] of the Gram-form PCA block, if any (vmp_pca.hip)
+int32_t vmp_pca_ensure_gram(vmp_ctx *ctx);
 
 // every entry point that puts work on ctx->stream behind the caller's back of the queue calls this
 // first: queued small operations run before anything that may read what they write

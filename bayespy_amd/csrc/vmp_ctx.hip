@@ -122,6 +122,10 @@ int32_t vmp_ctx_sync(vmp_ctx *ctx)
 {
     if (!ctx) return VMP_ERR_INVALID;
     VMP_FLUSH_SMALL(ctx);
+    {
+        const int32_t rcg = vmp_pca_ensure_gram(ctx);
+        if (rcg != VMP_OK) return rcg;
+    }
     VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->xs) VMP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->xs));
     for (int i = 0; i < 3; ++i)

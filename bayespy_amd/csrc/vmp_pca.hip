@@ -925,11 +925,36 @@ int32_t run_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int D, 
         VMP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_xbuf[b], s));
         ctx->x_buf_pending[b] = 1;
     }
-    // messages to W from (G, A): main stream, concurrent with the pass
+    // messages to W from (G, A): main stream, concurrent with the pass.  Where the LDS-resident
+    // tail kernel applies they are left to it (pca_tail_fast_kernel<KP, true> forms S itself: one
+    // launch instead of three beside the pass); anything else that reads S first
+    // calls vmp_pca_ensure_gram
+    // (measured, same process, tools/c2_fuse_ab.py, profiles/r06/c2_fuse_ab.txt: the ONE workgroup that
+    // then does the work of pca_gram_stats' DP / 8 workgroups beside the pass is slower -- config 2
+    // 0.120 -> 0.138 ms per iteration, the 8-rank shard 0.320 -> 0.337 -- so the default stays 0)
+    if (vmp_tune_get("pca_fuse_gram", env_int("VMP_PCA_FUSE_GRAM", 0, 0, 1)) && L.KP <= 32 &&
+        D <= 128) {
+        ctx->gram_pending = 1;
+        ctx->gram_D = D;
+        ctx->gram_K = K;
+        ctx->gram_state = state;
+        ctx->gram_P = reinterpret_cast<double *>(workspace);
+        return VMP_OK;
+    }
     return run_gram_stats(ctx, L, D, K, state, reinterpret_cast<double *>(workspace), m);
 }
 
 }  // namespace
+
+int32_t vmp_pca_ensure_gram(vmp_ctx *ctx)
+{
+    if (!ctx || !ctx->gram_pending) return VMP_OK;
+    ctx->gram_pending = 0;
+    vmp_pca_layout L;
+    fill_layout(ctx->gram_D, ctx->gram_K, &L);
+    return run_gram_stats(ctx, L, ctx->gram_D, ctx->gram_K, ctx->gram_state, ctx->gram_P,
+                          ctx->stream);
+}
 
 extern "C" {
 
@@ -996,6 +1021,7 @@ int32_t vmp_pca_syy(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32
 int32_t vmp_pca_gram(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
                      double *state, void *workspace)
 {
+    if (ctx) ctx->gram_pending = 0;          // (S is written anew / G changes)
     int32_t rc = check_pass_args(ctx, Y, Y, state, workspace, ldy, ldy, N, D, K);
     if (rc != VMP_OK) return rc;
     vmp_pca_layout L;
@@ -1021,6 +1047,7 @@ int32_t vmp_pca_stats_from_x(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t
                              int32_t K, const double *X, int64_t ldx, double *state,
                              void *workspace)
 {
+    if (ctx) ctx->gram_pending = 0;          // (S is written anew / G changes)
     int32_t rc = check_pass_args(ctx, Y, X, state, workspace, ldy, ldx, N, D, K);
     if (rc != VMP_OK) return rc;
     vmp_pca_layout L;
@@ -1034,6 +1061,7 @@ int32_t vmp_pca_stats_from_x(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t
 int32_t vmp_pca_pass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N, int32_t D, int32_t K,
                      double *X, int64_t ldx, double *state, void *workspace)
 {
+    if (ctx) ctx->gram_pending = 0;          // (S is written anew / G changes)
     int32_t rc = check_pass_args(ctx, Y, X, state, workspace, ldy, ldx, N, D, K);
     if (rc != VMP_OK) return rc;
     vmp_pca_layout L;
@@ -1137,6 +1165,10 @@ int32_t vmp_pca_xpass_tiled(vmp_ctx *ctx, const double *Yt, int64_t N, int32_t D
 
 int32_t vmp_pca_xjoin(vmp_ctx *ctx)
 {
+    {
+        const int32_t rcg = vmp_pca_ensure_gram(ctx);
+        if (rcg != VMP_OK) return rcg;
+    }
     VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null argument");
     if (ctx->x_pending) {
         VMP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_xdone, 0));

@@ -737,11 +737,18 @@ pca_head_fast_kernel(small_args a, double *st)
 }
 
 // (tau.update(), alpha.update(), lower bound)
-template <int KP>
+// GRAM: the messages to W of the Gram form, S = [G A^T ; A G A^T] (sum y <x>^T and
+// sum <x><x>^T collapsed onto the constant Gram matrix), are formed HERE first -- G streamed through
+// LDS in batches of GB rows, A resident -- instead of by pca_gram_stats_kernel + reduce_partials_kernel
+// in front of this kernel: one launch of the replicated-node chain instead of three beside the plate
+// pass (BASELINE config 2: the chain, not the pass, set the iteration time).
+constexpr int GB = 32;            // rows of G per batch
+template <int KP, bool GRAM>
 __global__ void __launch_bounds__(NTF)
 pca_tail_fast_kernel(small_args a, double *st)
 {
     constexpr int LDM = KP + 1, E = KP * KP / NTF;
+    extern __shared__ double gl[];          // GRAM: A (KP x (DP+1)) | G batch (GB x (DP+1)) | S batch (GB x LDM)
     __shared__ double Sw[KP * LDM];         // Sww
     __shared__ double Cx[KP * LDM];         // Cov_X
     __shared__ double Sx[KP * LDM];         // sum <x><x>^T (shard sum)
@@ -751,6 +758,61 @@ pca_tail_fast_kernel(small_args a, double *st)
     const lay32 L(a.L);
     const int tid = threadIdx.x, D = a.D, K = a.K;
     __builtin_amdgcn_s_setprio(3);   // latency-critical: win issue arbitration on a shared CU
+    double t1 = 0.0;
+    double sxx[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) sxx[m] = 0.0;
+    if constexpr (GRAM) {
+        const int DP = L.DP, LA = DP + 1;
+        double *As = gl, *Gs = As + KP * LA, *Ss = Gs + GB * LA;
+        for (int e = tid; e < KP * DP; e += NTF) {
+            const int k = e / DP, d = e - k * DP;
+            As[k * LA + d] = (k < K && d < D) ? st[L.off_A + k * DP + d] : 0.0;
+        }
+        for (int r0 = 0; r0 < D; r0 += GB) {
+            for (int e = tid; e < GB * DP; e += NTF) {
+                const int r = e / DP, d = e - r * DP;
+                Gs[r * LA + d] = (r0 + r < D && d < D) ? st[(int)a.L.off_G + (r0 + r) * DP + d] : 0.0;
+            }
+            __syncthreads();
+            // Syx[r][k] = sum_d G[r][d] A[k][d]  (and sum W o Syx on the way)
+#pragma unroll
+            for (int m = 0; m < GB * KP / NTF; ++m) {
+                const int e = tid + m * NTF;
+                const int r = e / KP, k = e % KP;
+                const double *gr = Gs + r * LA, *ar = As + k * LA;
+                double s0 = 0.0, s1 = 0.0;
+                for (int d = 0; d < D; d += 2) {
+                    s0 += gr[d] * ar[d];
+                    s1 += gr[d + 1] * ar[d + 1];        // (d + 1 <= DP - 1: zero padded)
+                }
+                const double sv = s0 + s1;
+                Ss[r * LDM + k] = sv;
+                if (r0 + r < D) {
+                    st[L.off_S + (r0 + r) * KP + k] = sv;
+                    if (k < K) t1 += st[L.off_W + (r0 + r) * KP + k] * sv;
+                }
+            }
+            __syncthreads();
+            // Sxx[k][k'] += sum_{r in batch} A[k][r] Syx[r][k']
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int e = tid + m * NTF;
+                const int i = e / KP, j = e % KP;
+                double s0 = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < GB; ++r) s0 += As[i * LA + r0 + r] * Ss[r * LDM + j];
+                sxx[m] += s0;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int e = tid + m * NTF;
+            const int i = e / KP, j = e % KP;
+            st[L.off_S + (L.DP + i) * KP + j] = (i < K && j < K) ? sxx[m] : 0.0;
+        }
+    }
     // ---- one batch of loads ------------------------------------------------------------
     {
         double v0[E], v1[E], v2[E];
@@ -761,7 +823,8 @@ pca_tail_fast_kernel(small_args a, double *st)
             const bool in = (i < K && j < K);
             v0[m] = in ? st[L.off_Sww + i * KP + j] : 0.0;
             v1[m] = in ? st[L.off_CX + i * KP + j] : 0.0;
-            v2[m] = in ? st[L.off_S + (L.DP + i) * KP + j] : 0.0;
+            if constexpr (GRAM) v2[m] = in ? sxx[m] : 0.0;
+            else v2[m] = in ? st[L.off_S + (L.DP + i) * KP + j] : 0.0;
         }
         if (tid == 0) {
             sc[4] = st[L.off_Syy];
@@ -778,8 +841,7 @@ pca_tail_fast_kernel(small_args a, double *st)
         }
     }
     // sum(W o Syx): padded entries of W are zero, so the D x KP blocks are walked linearly
-    double t1 = 0.0;
-    {
+    if constexpr (!GRAM) {
         const int n = D * KP;
 #pragma unroll 1
         for (int e0 = 0; e0 < n; e0 += 8 * NTF) {
@@ -928,6 +990,21 @@ int32_t launch_small(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double
     static const int fast_enabled = getenv("VMP_PCA_FAST_SMALL") ? atoi(getenv("VMP_PCA_FAST_SMALL")) : 1;
     // (the LDS-resident forms are built for the zero prior mean of the demo model)
     const bool fast = fast_enabled && a.L.KP <= 32 && D <= FAST_D && !a.has_mean;
+    // the Gram-form messages to W of the latest latent pass may still be pending (vmp_pca.hip
+    // run_xpass): the LDS-resident tail kernel forms them itself when it comes first, anything
+    // else has them formed now
+    bool gram_here = false;
+    if (ctx->gram_pending) {
+        const bool tail_first = nops >= 3 && ops[0] == VMP_PCA_OP_TAU && ops[1] == VMP_PCA_OP_ALPHA
+                                && ops[2] == VMP_PCA_OP_ELBO;
+        if (fast && tail_first && ctx->gram_state == state && ctx->gram_D == D && ctx->gram_K == K) {
+            gram_here = true;
+            ctx->gram_pending = 0;
+        } else {
+            rc = vmp_pca_ensure_gram(ctx);
+            if (rc != VMP_OK) return rc;
+        }
+    }
     int i = 0;
     while (i < nops) {
         const int o0 = ops[i], o1 = i + 1 < nops ? ops[i + 1] : 0, o2 = i + 2 < nops ? ops[i + 2] : 0;
@@ -942,12 +1019,34 @@ int32_t launch_small(vmp_ctx *ctx, int32_t D, int32_t K, int64_t n_total, double
                 launch_sequence<VMP_PCA_OP_W, VMP_PCA_OP_XPREP, 0>(ctx, a, state);
             i += 2;
         } else if (o0 == VMP_PCA_OP_TAU && o1 == VMP_PCA_OP_ALPHA && o2 == VMP_PCA_OP_ELBO) {
-            if (fast && a.L.KP == 16)
-                hipLaunchKernelGGL(pca_tail_fast_kernel<16>, dim3(1), dim3(NTF), 0, ctx->stream, a,
-                                   state);
+            if (fast && gram_here) {
+                // S = [G A^T; A G A^T] of the latest pass is formed by the tail kernel itself
+                const size_t lds = ((size_t)(a.L.KP + GB) * (a.L.DP + 1) + (size_t)GB * (a.L.KP + 1))
+                                   * sizeof(double);
+                static bool raised[64] = {false};
+                const int dev = ctx->device & 63;
+                if (!raised[dev]) {
+                    VMP_HIP_CHECK(ctx, hipFuncSetAttribute(
+                        (const void *)pca_tail_fast_kernel<16, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    VMP_HIP_CHECK(ctx, hipFuncSetAttribute(
+                        (const void *)pca_tail_fast_kernel<32, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    raised[dev] = true;
+                }
+                if (a.L.KP == 16)
+                    hipLaunchKernelGGL((pca_tail_fast_kernel<16, true>), dim3(1), dim3(NTF), lds,
+                                       ctx->stream, a, state);
+                else
+                    hipLaunchKernelGGL((pca_tail_fast_kernel<32, true>), dim3(1), dim3(NTF), lds,
+                                       ctx->stream, a, state);
+                gram_here = false;
+            } else if (fast && a.L.KP == 16)
+                hipLaunchKernelGGL((pca_tail_fast_kernel<16, false>), dim3(1), dim3(NTF), 0,
+                                   ctx->stream, a, state);
             else if (fast)
-                hipLaunchKernelGGL(pca_tail_fast_kernel<32>, dim3(1), dim3(NTF), 0, ctx->stream, a,
-                                   state);
+                hipLaunchKernelGGL((pca_tail_fast_kernel<32, false>), dim3(1), dim3(NTF), 0,
+                                   ctx->stream, a, state);
             else
                 launch_sequence<VMP_PCA_OP_TAU, VMP_PCA_OP_ALPHA, VMP_PCA_OP_ELBO>(ctx, a, state);
             i += 3;

@@ -112,6 +112,11 @@ class HIPKernels:
     def xjoin(self):
         self.rt.check(self.lib.vmp_pca_xjoin(self.ctx))
 
+    def ensure_gram(self):
+        """The Gram-form messages to W are formed lazily by the library (vmp_pca_ensure_gram):
+        before the state block is read directly."""
+        self.rt.check(self.lib.vmp_pca_ensure_gram(self.ctx))
+
     def tile_y(self, Y, ldy, N, D, K):
         """Tile-major copy of the constant data (vmp_pca_tile_y): [tile][DP][32]."""
         n = ctypes.c_int64()
@@ -878,6 +883,9 @@ class PCAPlan:
 
     # -- host views (reference shapes) ---------------------------------------------------------
     def _block(self, off, rows, cols, ld):
+        if hasattr(self.kernels, 'ensure_gram'):
+            self.rt.sync_stream()
+            self.kernels.ensure_gram()
         a = self.state[off:off + rows * ld].cpu().numpy().reshape(rows, ld)
         return a[:, :cols].copy()
 
@@ -970,6 +978,9 @@ class PCAPlan:
         _delta.save(put, base, self._delta)
         put(base + 'kind', np.array([ord(c) for c in 'pca'], dtype=np.uint8))
         put(base + 'dims', np.array([self.D, self.N, self.K], dtype=np.int64))
+        if hasattr(self.kernels, 'ensure_gram'):
+            self.rt.sync_stream()
+            self.kernels.ensure_gram()
         put(base + 'state', self.state.cpu().numpy())
         put(base + 'X', self.Xd[:self.K, :self.N].cpu().numpy())
         for node in nodes:

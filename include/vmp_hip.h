@@ -196,6 +196,12 @@ int32_t vmp_pca_xpass(vmp_ctx *ctx, const double *Y, int64_t ldy, int64_t N,
 
 /* Make the context's stream wait for the outstanding vmp_pca_xpass (no host block). */
 int32_t vmp_pca_xjoin(vmp_ctx *ctx);
+/* Gram form: the messages to W of the latest latent pass, S = [G A^T ; A G A^T] in the state block
+ * (dot.py:581 collapsed onto the Gram matrix), are formed lazily -- by the fused tau / alpha / bound
+ * kernel when it comes next, else by this call, which every other entry point that reads S makes
+ * itself (vmp_pca_small_ops*, vmp_pca_xjoin, vmp_ctx_sync).  A binding that reads the state block
+ * directly (vmp_memcpy_d2h) calls it first.  No-op when nothing is pending. */
+int32_t vmp_pca_ensure_gram(vmp_ctx *ctx);
 
 /* Tile-major layout of the plate arrays.  Y is constant after Y.observe()
  * (stochastic.py:223-250), so it is re-laid-out ONCE into blocks of 32 plate elements,
