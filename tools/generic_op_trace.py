@@ -14,7 +14,7 @@ LOG = []
 ON = [False]
 def caller():
     for fs in reversed(traceback.extract_stack()[:-3]):
-        if 'plans/generic.py' in fs.filename or 'utils/linalg.py' in fs.filename or 'utils/misc.py' in fs.filename:
+        if '/plans/' in fs.filename or 'utils/linalg.py' in fs.filename or 'utils/misc.py' in fs.filename:
             return '%s:%d %s' % (os.path.basename(fs.filename), fs.lineno, fs.name)
     return '?'
 def wrap(mod, name, kind):
@@ -45,9 +45,11 @@ def fuse_t(fn, *ops):
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     LOG.append((dt * 1e3, 'ew', str([tuple(x.shape) for x in ops if hasattr(x, 'shape')])[:110], caller()))
     return r
-darray.fuse = fuse_t; G.fuse = fuse_t; misc.fuse = fuse_t
 import bayespy_amd.utils.linalg as LA
-if hasattr(LA, 'fuse'): LA.fuse = fuse_t
+for _m in list(sys.modules.values()):
+    # (every module of the package that imported `fuse` by name: plans/lazy.py, plans/families/*, ...)
+    if getattr(_m, '__name__', '').startswith('bayespy_amd') and getattr(_m, 'fuse', None) is orig_fuse:
+        _m.fuse = fuse_t
 MODEL = sys.argv[1] if len(sys.argv) > 1 else 'pca'
 from bayespy_amd.inference import VB
 dev = torch.device('cuda', 0)
