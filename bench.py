@@ -405,6 +405,16 @@ def main():
             setup['placement'] = {'candidates': [len(pl['yt_ms']) - 1, len(pl['grid_ms'][-1])],
                                   'kept_ms': round(min(flat), 4), 'first_ms': round(flat[0], 4),
                                   'worst_ms': round(max(flat), 4)}
+            # what a user gets who cannot afford the trial (BAYESPY_AMD_PLACEMENT_TRIES=1: the
+            # first allocation is kept): this run's iteration with its pass replaced by the pass
+            # time measured on the first allocation pair -- the iteration is pass-bound, the
+            # replicated-node chain runs beside the pass
+            first_step = ms_step - avg_pass + flat[0]
+            out['value_first_allocation'] = {
+                'value': 1e3 / first_step, 'ms_per_step': first_step,
+                'roofline_frac': alg_bytes / (flat[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'note': 'estimate: ms_per_step - kept pass + first-allocation pass (both measured '
+                        'in this run); `value` above is with the placement trial'}
         else:
             setup['placement'] = None
         out['config']['setup'] = {k: (round(v, 3) if isinstance(v, float) else v)

@@ -586,9 +586,14 @@ int32_t vmp_ewise(vmp_ctx *ctx, int32_t ndim, const int64_t *shape, int32_t nin,
  * binding records one sweep (every call of this library between begin and end is recorded on the
  * context's stream instead of run; the arrays must be allocated before, nothing may be read on
  * the host inside) and launches the graph once per iteration afterwards.  The context needs a
- * stream of its own (vmp_ctx_create / vmp_ctx_set_stream: not the legacy default stream).  The
- * Python front end records through torch.cuda.graph (it also allocates inside a sweep and needs
- * torch's graph memory pool); a binding that manages its own arrays uses these four. */
+ * stream of its own (vmp_ctx_create / vmp_ctx_set_stream: not the legacy default stream).  A binding
+ * that manages its own arrays uses these four.  The Python front end (plans/graph_iter.py) cannot:
+ * its sweeps ALLOCATE -- every array operation of the engine returns a fresh device array -- and an
+ * allocation inside a stream capture must come from a pool that lives as long as the graph, which
+ * is what torch.cuda.graph provides (torch's caching allocator is the allocator of this package:
+ * DESIGN.md section 1).  It therefore opens the capture through torch and issues the SAME library
+ * calls on the capturing stream; vmp_copy_many / vmp_pack_outputs / vmp_queue_commit are the pieces
+ * of such a recording that live behind this boundary. */
 int32_t vmp_graph_begin(vmp_ctx *ctx);
 int32_t vmp_graph_end(vmp_ctx *ctx, void **graph);
 int32_t vmp_graph_launch(vmp_ctx *ctx, void *graph);
