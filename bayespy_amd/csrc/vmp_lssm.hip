@@ -26,7 +26,8 @@ constexpr int NT = 256;
 // only 1563 wavefronts for 1024 SIMDs; single-wavefront workgroups spread them more evenly over the
 // CUs but measured no better (forward 1.83 vs 1.72 ms, backward equal): kept at 256.
 constexpr int SNT = 256;
-constexpr int DMAX = 8;
+constexpr int DMAX = 16;         // states of the fused block (D <= 8: everything in registers; 9..16: the big-state path)
+constexpr int DREG = 8;          // largest D of the register-resident kernels
 
 // ---------------------------------------------------------------------------------------------
 // set-up: Y (M, B, T) sequence-major -> Yt (T, M, BL) time-major, BL >= B (pad columns zero)
@@ -440,7 +441,9 @@ lssm_cov_kernel(cov_args a, int phase, int t0, int t1)
 // CK = 0: every z_t is written to Z (T, D, BL).  CK = S > 0 (checkpoint form): only z_{kS-1},
 // k = 1, 2, ..., is written, to Zc (T/S, D, BL); the backward kernel forms the S steps of a block
 // again from the checkpoint in front of it (lssm_backward_ck_kernel).  t0 is a multiple of S.
-template <int D, int MM, int CK>
+// IDENT: the "observations" are the projected data H = tau C^T Y already (M = D, C = I, tau = 1):
+// h_t = y_t, no D x D table of tau c_m (the big-state path: 256 uniform values at D = 16).
+template <int D, int MM, int CK, bool IDENT = false>
 __global__ void __launch_bounds__(SNT)
 lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
                     const double *__restrict__ Cm /* M x D */, const double *__restrict__ tau_ptr,
@@ -449,12 +452,14 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
 {
     const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
     if (b >= B) return;
-    const double tau = tau_ptr[0];
-    double tc[MM][D];                       // tau * c_m (uniform: scalar registers)
+    const double tau = IDENT ? 1.0 : tau_ptr[0];
+    double tc[IDENT ? 1 : MM][IDENT ? 1 : D];      // tau * c_m (uniform: scalar registers)
+    if constexpr (!IDENT) {
 #pragma unroll
-    for (int m = 0; m < MM; ++m)
+        for (int m = 0; m < MM; ++m)
 #pragma unroll
-        for (int i = 0; i < D; ++i) tc[m][i] = (m < M) ? tau * Cm[m * D + i] : 0.0;
+            for (int i = 0; i < D; ++i) tc[m][i] = (m < M) ? tau * Cm[m * D + i] : 0.0;
+    }
     double z[D];
     // steps [t0, t1): a later segment picks z_{t0-1} up where the previous launch left it
 #pragma unroll
@@ -477,8 +482,12 @@ lssm_forward_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int6
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             double s = (t == 0) ? h0[i] : 0.0;
+            if constexpr (IDENT) {
+                s += ycur[i];
+            } else {
 #pragma unroll
-            for (int m = 0; m < MM; ++m) s += ycur[m] * tc[m][i];
+                for (int m = 0; m < MM; ++m) s += ycur[m] * tc[m][i];
+            }
             h[i] = s;
         }
         if (t > 0) {
@@ -844,6 +853,231 @@ int plen_of(int D, int M) { return 4 * D * D + D + M * D; }
 
 // workspace: [partial sums of the sweeps | relayout partials] then the checkpoints of the forward
 // sweep, (T / CKS, D, BL) with BL <= the sequences rounded up to 256
+// ---------------------------------------------------------------------------------------------
+// big-state path (8 < D <= 16; round 6).  The register-resident sweeps hold the state AND the
+// D x D plate sums of a sequence in one thread (D = 8 spills); here the sweeps carry the state
+// only, and the plate sums are formed behind them:
+//   lssm_forward_kernel<D, D, 0, true>   on the projected data H = tau C^T Y
+//   lssm_backward_plain_kernel<D>        x_t = S_t^-1 z_t - J_t x_t+1 in place over Z
+//   lssm_pairsum_kernel<D>               sum_{b, t in [T0, T1)} A[t + dt][r][b] Z[t][i][b] for eight rows
+//                                        r of an array A (T, R, BL) per workgroup row: sum x x^T
+//                                        (A = Z), sum x_t+1 x_t^T (A = Z, dt = 1), the first / last
+//                                        step's terms (one-step ranges), sum y x^T (A = Yt)
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(SNT)
+lssm_backward_plain_kernel(int64_t B, int T, int64_t BL, const double *__restrict__ Sinv,
+                           const double *__restrict__ J, double *__restrict__ Z)
+{
+    const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
+    if (b >= B) return;
+    double *zp = Z + b;
+    double xn[D], zc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        xn[i] = 0.0;
+        zc[i] = __builtin_nontemporal_load(&zp[((int64_t)(T - 1) * D + i) * BL]);
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        double zq[D];
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) zq[i] = __builtin_nontemporal_load(&zp[((int64_t)(t - 1) * D + i) * BL]);
+        }
+        const double *St = Sinv + (int64_t)t * D * D;
+        double x[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += St[i * D + k] * zc[k];
+            x[i] = s;
+        }
+        if (t < T - 1) {
+            const double *Jt = J + (int64_t)t * D * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = x[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s -= Jt[i * D + k] * xn[k];
+                x[i] = s;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            __builtin_nontemporal_store(x[i], &zp[((int64_t)t * D + i) * BL]);
+            xn[i] = x[i];
+            zc[i] = zq[i];
+        }
+    }
+}
+
+constexpr int PSR = 8;            // rows of A per workgroup row of the pair-sum pass
+
+template <int D>
+__global__ void __launch_bounds__(SNT)
+lssm_pairsum_kernel(const double *__restrict__ A, int R, int dt, int64_t B, int T0, int T1,
+                    int64_t BL, const double *__restrict__ Z, double *__restrict__ partial, int RP)
+{
+    __shared__ double red[SNT / 64];
+    const int64_t b = (int64_t)blockIdx.x * SNT + threadIdx.x;
+    const bool live = b < B;
+    const int64_t bb = live ? b : 0;
+    const int r0 = blockIdx.y * PSR;
+    double acc[PSR][D];
+#pragma unroll
+    for (int j = 0; j < PSR; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) acc[j][i] = 0.0;
+    for (int t = T1 - 1; t >= T0; --t) {              // time descending, like the sweeps' sums
+        double x[D], a[PSR];
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = Z[((int64_t)t * D + i) * BL + bb];
+#pragma unroll
+        for (int j = 0; j < PSR; ++j)
+            a[j] = (r0 + j < R) ? (A ? A[((int64_t)(t + dt) * R + r0 + j) * BL + bb] : 1.0) : 0.0;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < PSR; ++j)
+#pragma unroll
+                for (int i = 0; i < D; ++i) acc[j][i] += a[j] * x[i];
+        }
+    }
+    double *pb = partial + (int64_t)blockIdx.x * RP * D;
+#pragma unroll
+    for (int j = 0; j < PSR; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double v = block_sum<SNT>(acc[j][i], red);
+            if (threadIdx.x == 0) pb[(r0 + j) * D + i] = v;
+        }
+}
+
+// <x_bt> <- R <x_bt> with R in LDS (D > 8: D^2 uniform registers do not exist)
+template <int D>
+__global__ void __launch_bounds__(NT)
+lssm_rotate_big_kernel(const double *__restrict__ R, int T, int64_t B, int64_t BL, double *__restrict__ Z)
+{
+    __shared__ double rs[D * D];
+    for (int e = threadIdx.x; e < D * D; e += NT) rs[e] = R[e];
+    __syncthreads();
+    const int64_t total = (int64_t)T * B;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t t = e / B, b = e - t * B;
+        double *zp = Z + t * D * BL + b;
+        double x[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = zp[(int64_t)i * BL];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) s += rs[i * D + j] * x[j];
+            zp[(int64_t)i * BL] = s;
+        }
+    }
+}
+
+// The shared covariance recursion for 8 < D <= 16: one workgroup of 256 threads, thread (i, j) owns
+// element (i, j) of the 16 x 16 padded matrices (identity in the padding, so the pivots there are 1),
+// operands through LDS -- the lane-crossing moves of lssm_cov_kernel do not reach across the four
+// wavefronts.  Same recursion, same outputs (S^-1, J, the sums of V_t and Cov(x_t, x_t+1), log|Phi|);
+// no stationarity shortcut; phase bit 0 = forward half, bit 1 = backward half (each whole in one
+// launch).  ~3 us per step.
+__global__ void __launch_bounds__(256)
+lssm_cov_big_kernel(cov_args a, int phase)
+{
+    constexpr int P = 16, LP = 17;
+    __shared__ double U[2][P * LP];
+    __shared__ double Es[P * LP], Js[P * LP], Vs[P * LP];
+    const int tid = threadIdx.x, i = tid >> 4, j = tid & 15, D = a.D, T = a.T;
+    const bool act = i < D && j < D;
+    const int l = i * D + j, q = i * LP + j;
+    const double pad = (i == j) ? 1.0 : 0.0;
+    const double e = act ? a.E[l] : 0.0;
+    const double dgm = act ? a.Dgm[l] : pad, dgT = act ? a.DgT[l] : pad;
+    const int DD = D * D;
+    Es[q] = e;
+    __syncthreads();
+    if (phase & 1) {
+        double prod = 1.0, ex = 0.0;
+        int bad = 0;
+        double s = act ? a.Dg0[l] : pad;
+        for (int t = 0; t < T; ++t) {
+            int cur = 0;
+            U[0][q] = s;
+            __syncthreads();
+            double v = s;
+            for (int p = 0; p < D; ++p) {
+                const double *M = U[cur];
+                const double piv = M[p * LP + p], ci = M[i * LP + p], rj = M[p * LP + j];
+                if (!(piv > 0.0)) bad = 1;
+                const double pq = prod * piv;
+                ex += (double)__builtin_amdgcn_frexp_exp(pq);
+                prod = __builtin_amdgcn_frexp_mant(pq);
+                const double d = 1.0 / piv;
+                if (i == p) v = (j == p) ? d : rj * d;
+                else if (j == p) v = -ci * d;
+                else v = v - ci * rj * d;
+                U[cur ^ 1][q] = v;
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (act) a.Sinv[(int64_t)t * DD + l] = v;
+            if (t < T - 1) {
+                const double *Si = U[cur];
+                double jt = 0.0;
+                for (int k = 0; k < D; ++k) jt += Si[i * LP + k] * Es[k * LP + j];        // S^-1 E
+                if (act) a.J[(int64_t)t * DD + l] = jt;
+                Js[q] = jt;
+                __syncthreads();
+                double ej = 0.0;
+                for (int k = 0; k < D; ++k) ej += Es[k * LP + i] * Js[k * LP + j];         // E^T J
+                s = ((t + 1 < T - 1) ? dgm : dgT) - ej;
+            }
+        }
+        if (tid == 0) {
+            a.sums[5 * DD + 0] = log(prod) + ex * 0.69314718055994530942;
+            a.sums[5 * DD + 1] = (double)bad;
+            a.sums[5 * DD + 2] = -1.0;
+            a.sums[5 * DD + 4] = prod;
+            a.sums[5 * DD + 5] = ex;
+            a.sums[5 * DD + 6] = 1.0;
+        }
+        if (!(phase & 2)) return;
+        __threadfence();
+        __syncthreads();
+    }
+    // ---- backward: V_T-1 = S_T-1^-1;  C_t = -J_t V_t+1;  V_t = S_t^-1 - C_t J_t^T -----------------
+    double v = act ? a.Sinv[(int64_t)(T - 1) * DD + l] : 0.0;
+    double sv = v, sc = 0.0;
+    const double vlast = v;
+    for (int t = T - 2; t >= 0; --t) {
+        const double jt = act ? a.J[(int64_t)t * DD + l] : 0.0;
+        const double si = act ? a.Sinv[(int64_t)t * DD + l] : 0.0;
+        Js[q] = jt;
+        Vs[q] = v;
+        __syncthreads();
+        double c = 0.0;
+        for (int k = 0; k < D; ++k) c -= Js[i * LP + k] * Vs[k * LP + j];                  // -J V
+        U[0][q] = c;
+        __syncthreads();
+        double cj = 0.0;
+        for (int k = 0; k < D; ++k) cj += U[0][i * LP + k] * Js[j * LP + k];               // C J^T
+        v = si - cj;
+        sv += v;
+        sc += c;
+        __syncthreads();
+    }
+    if (act) {
+        a.sums[0 * DD + l] = sv;
+        a.sums[1 * DD + l] = v;         // V_0
+        a.sums[2 * DD + l] = vlast;
+        a.sums[3 * DD + l] = sc;
+    }
+    if (tid == 0) a.sums[5 * DD + 3] = -1.0;
+}
+
 constexpr int CKS = 4;
 inline int64_t ck_bl_max(int64_t B) { return (B + 255) / 256 * 256; }
 inline int64_t ws_base_doubles(int D, int M, int64_t B)
@@ -1207,6 +1441,18 @@ inline int64_t ck_doubles(int D, int64_t B, int T)
 {
     return D <= 4 ? (int64_t)((T + CKS - 1) / CKS) * D * ck_bl_max(B) : 0;
 }
+// big-state path (D > DREG): rows of the widest pair-sum job, padded to whole workgroup rows;
+// workspace = [base | pair-sum partials g x RP x D | H (T, D, BL)]
+inline int big_rows(int D, int M)
+{
+    const int r = D > M ? D : M;
+    return (r + PSR - 1) / PSR * PSR;
+}
+inline int64_t big_extra_doubles(int D, int M, int64_t B, int T)
+{
+    const int64_t g = (B + SNT - 1) / SNT;
+    return g * big_rows(D, M) * D + 64 + (int64_t)T * D * ck_bl_max(B) + 64;
+}
 
 }  // namespace
 
@@ -1271,6 +1517,13 @@ static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int
     a.Sinv = Sinv;
     a.J = J;
     a.sums = sums;
+    if (D > DREG) {
+        // one launch per half (no segments: a later forward segment has nothing left to do)
+        if ((phase & 1) && t0 > 0) return VMP_OK;
+        hipLaunchKernelGGL(lssm_cov_big_kernel, dim3(1), dim3(256), 0, s, a, phase);
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        return VMP_OK;
+    }
     switch (D) {
 #define LSSM_COV(d) case d: hipLaunchKernelGGL(lssm_cov_kernel<d>, dim3(1), dim3(64), 0, s, a, phase, t0, t1); break;
         LSSM_COV(1) LSSM_COV(2) LSSM_COV(3) LSSM_COV(4) LSSM_COV(5) LSSM_COV(6) LSSM_COV(7) LSSM_COV(8)
@@ -1303,6 +1556,61 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
     VMP_REQUIRE(ctx, D <= DMAX && M <= LSSM_MAXM, VMP_ERR_UNSUPPORTED,
                 "the fused LSSM block supports D <= %d states, M <= %d observed dimensions", DMAX,
                 LSSM_MAXM);
+    if (D > DREG) {
+        // big-state path: sweeps on the projected data carrying the state only, plate sums behind
+        VMP_REQUIRE(ctx, BL <= ck_bl_max(B), VMP_ERR_INVALID,
+                    "leading dimension beyond the workspace contract (B rounded up to 256)");
+        double *wsd = reinterpret_cast<double *>(workspace);
+        double *part = wsd;                                   // pair-sum partials: g x RP x D
+        const int64_t g = (B + SNT - 1) / SNT;
+        const int RP = big_rows(D, M);
+        double *H = wsd + ws_base_doubles(D, M, B) + g * RP * D + 64;
+        hipStream_t sw = ctx->stream;
+        if (!given && g > 0) {
+            int64_t gp = ((int64_t)T * B + SNT - 1) / SNT;
+            if (gp > (int64_t)ctx->num_cu * 16) gp = (int64_t)ctx->num_cu * 16;
+#define LSSM_BIG(d)                                                                              \
+    if (D == d) {                                                                                \
+        hipLaunchKernelGGL(lssm_project_kernel<d>, dim3((unsigned)gp), dim3(SNT), 0, sw, Yt, M,  \
+                           B, T, BL, Cm, tau, H);                                                \
+        for (int k = 0; k < nseg; ++k) {                                                         \
+            if (seg_ready) (void)hipStreamWaitEvent(sw, seg_ready[k], 0);                        \
+            hipLaunchKernelGGL((lssm_forward_kernel<d, d, 0, true>), dim3((unsigned)g),          \
+                               dim3(SNT), 0, sw, H, d, B, T, BL, nullptr, nullptr, h0, J, Z,     \
+                               (int)((int64_t)T * k / nseg), (int)((int64_t)T * (k + 1) / nseg)); \
+        }                                                                                        \
+        hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0, sw,   \
+                           B, T, BL, Sinv, J, Z);                                                \
+    }
+            LSSM_BIG(9) LSSM_BIG(10) LSSM_BIG(11) LSSM_BIG(12) LSSM_BIG(13) LSSM_BIG(14)
+            LSSM_BIG(15) LSSM_BIG(16)
+#undef LSSM_BIG
+            VMP_HIP_CHECK(ctx, hipGetLastError());
+        }
+        // plate sums: [0, DD) x x^T | x_t+1 x_t^T | x_0 x_0^T | x_T-1 x_T-1^T | x_0 (D) | y x^T (M x D)
+        const int DD = D * D;
+        struct { const double *A; int R, dt, t0, t1, off, len; } jobs[6] = {
+            {Z, D, 0, 0, T, 0, DD},          {Z, D, 1, 0, T - 1, DD, DD},
+            {Z, D, 0, 0, 1, 2 * DD, DD},     {Z, D, 0, T - 1, T, 3 * DD, DD},
+            {nullptr, 1, 0, 0, 1, 4 * DD, D}, {Yt, M, 0, 0, T, 4 * DD + D, M * D}};
+        for (int q = 0; q < 6; ++q) {
+            const int yb = (jobs[q].R + PSR - 1) / PSR;
+            if (g > 0) {
+#define LSSM_PS(d)                                                                               \
+    if (D == d)                                                                                  \
+        hipLaunchKernelGGL(lssm_pairsum_kernel<d>, dim3((unsigned)g, (unsigned)yb), dim3(SNT), 0, \
+                           sw, jobs[q].A, jobs[q].R, jobs[q].dt, B, jobs[q].t0, jobs[q].t1, BL,  \
+                           Z, part, RP);
+                LSSM_PS(9) LSSM_PS(10) LSSM_PS(11) LSSM_PS(12) LSSM_PS(13) LSSM_PS(14) LSSM_PS(15)
+                LSSM_PS(16)
+#undef LSSM_PS
+            }
+            hipLaunchKernelGGL(lssm_sum_kernel, dim3((unsigned)((jobs[q].len + 15) / 16)), dim3(NT), 0,
+                               sw, part, (int)g, RP * D, jobs[q].len, stats + jobs[q].off);
+        }
+        VMP_HIP_CHECK(ctx, hipGetLastError());
+        return VMP_OK;
+    }
     if (lssm_wide(D, M)) {
         // projected data in front of the unchanged sweeps, the y <x>^T sums behind them
         VMP_REQUIRE(ctx, BL <= ck_bl_max(B), VMP_ERR_INVALID,
@@ -1486,6 +1794,10 @@ int32_t vmp_lssm_rotate_x(vmp_ctx *ctx, int32_t D, int32_t T, int64_t B, int64_t
 #define LSSM_ROT(d) case d: hipLaunchKernelGGL(lssm_rotate_kernel<d>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, R, T, B, BL, Z); break;
         LSSM_ROT(1) LSSM_ROT(2) LSSM_ROT(3) LSSM_ROT(4) LSSM_ROT(5) LSSM_ROT(6) LSSM_ROT(7) LSSM_ROT(8)
 #undef LSSM_ROT
+#define LSSM_ROTB(d) case d: hipLaunchKernelGGL(lssm_rotate_big_kernel<d>, dim3((unsigned)g), dim3(NT), 0, ctx->stream, R, T, B, BL, Z); break;
+        LSSM_ROTB(9) LSSM_ROTB(10) LSSM_ROTB(11) LSSM_ROTB(12) LSSM_ROTB(13) LSSM_ROTB(14)
+        LSSM_ROTB(15) LSSM_ROTB(16)
+#undef LSSM_ROTB
     }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
@@ -1512,8 +1824,19 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
     A.B = B_total;
     for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
     A.nu_latent = nu_latent;
-    hipLaunchKernelGGL(lssm_small_kernel, dim3(1), dim3(64), (size_t)A.L.total * sizeof(double),
-                       ctx->stream, A, state);
+    const size_t small_lds = (size_t)A.L.total * sizeof(double);
+    if (small_lds > 48 * 1024) {
+        // (the state vector of D = 16, M = 64 is 105 KB: gfx950 has 160 KB of LDS per workgroup)
+        static bool raised[64] = {false};
+        const int dev = ctx->device & 63;
+        if (!raised[dev]) {
+            VMP_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(lssm_small_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   150 * 1024));
+            raised[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(lssm_small_kernel, dim3(1), dim3(64), small_lds, ctx->stream, A, state);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     return VMP_OK;
 }
@@ -1522,7 +1845,8 @@ int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, i
 {
     if (!n || D < 1 || M < 1 || B < 0) return VMP_ERR_INVALID;
     *n = ws_base_doubles(D, M, B) + ck_doubles(D, B, T);
-    if (lssm_wide(D, M)) *n += wide_extra_doubles(D, M, B, T);
+    if (D > DREG) *n += big_extra_doubles(D, M, B, T);
+    else if (lssm_wide(D, M)) *n += wide_extra_doubles(D, M, B, T);
     return VMP_OK;
 }
 
