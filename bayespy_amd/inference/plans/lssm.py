@@ -54,7 +54,7 @@ class LSSMKernels:
         L = _lib.LSSMLayout()
         rc = self.lib.vmp_lssm_get_layout(D, M, ctypes.byref(L))
         if rc != _lib.VMP_OK:
-            _lib.raise_for_status(rc, 'the fused LSSM block supports D <= 8 states and M <= 64 '
+            _lib.raise_for_status(rc, 'the fused LSSM block supports D <= 16 states and M <= 64 '
                                       'observed dimensions')
         return L
 
@@ -122,7 +122,7 @@ class LSSMPlan:
     @staticmethod
     def describe():
         return ("GaussianARD(SumMultiply('i,i', C, GaussianMarkovChain(mu0, Lam0, A, nu)), tau) fully "
-                "observed, shared dynamics, D <= 8 states")
+                "observed, shared dynamics, D <= 16 states")
 
     # -- pattern matching ---------------------------------------------------------------------------
     @staticmethod

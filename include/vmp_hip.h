@@ -345,7 +345,9 @@ int32_t vmp_mpca_unpack_xx(vmp_ctx *ctx, int32_t D, int32_t K, int64_t nplates,
  * linalg.block_banded_solve (utils/linalg.py:468-575, gaussian_markov_chain.py:89-123) runs ONCE
  * (vmp_lssm_cov) and only the means are per-sequence (vmp_lssm_smooth: one thread per
  * sequence, time-major arrays Yt[t][m][b], Z[t][i][b], b contiguous); the other nodes and the
- * bound read plate sums only.  D <= 8 states, M <= 64 observations per step (beyond M = 8, or 16
+ * bound read plate sums only.  D <= 16 states (round 6: for 8 < D <= 16 the sweeps carry the state
+ * only -- on the projected data tau C^T Y -- and the plate sums are formed behind them, the shared
+ * covariance recursion runs on one workgroup with its blocks in LDS), M <= 64 observations per step (beyond M = 8, or 16
  * at D <= 4, the sweeps run on the projected data tau C^T y with a separate y <x>^T pass).  Details: bayespy_amd/csrc/vmp_lssm.hip, formulas: oracle/lssm.py. */
 typedef struct vmp_lssm_layout {
     int64_t off_tau;      /* 4: a, b, <tau>, <log tau>                                             */

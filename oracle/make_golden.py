@@ -370,6 +370,62 @@ def small_model_cases(name):
     print(name, {k: v for k, v in out.items() if k.endswith('_L') and k.count('_') == 1})
 
 
+def _lssm_build(rs, out, tag, M, T, D, B, gamma_nu, n_iter=4):
+    from bayespy.nodes import GaussianARD, Gamma, SumMultiply, GaussianMarkovChain
+    from bayespy.inference import VB
+    plates_x = () if B is None else (B,)
+    a_true = 0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]
+    nseq = 1 if B is None else B
+    x = np.zeros((nseq, T, D))
+    x[:, 0] = rs.normal(size=(nseq, D))
+    for t in range(1, T):
+        x[:, t] = x[:, t - 1] @ a_true.T + rs.normal(size=(nseq, D))
+    c_true = rs.normal(size=(M, D))
+    f = np.einsum('md,btd->mbt', c_true, x)
+    y = f + 0.3 * rs.normal(size=f.shape)
+    if B is None:
+        y = y[:, 0]
+    alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
+    A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
+    A.initialize_from_value(np.identity(D))
+    nu = Gamma(1e-3, 1e-3, plates=(D,), name='nu') if gamma_nu else np.ones(D)
+    X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, nu, n=T,
+                            plates=plates_x, name='X')
+    x0 = rs.normal(size=plates_x + (T, D))
+    X.initialize_from_value(x0)
+    gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
+    gamma.initialize_from_value(1e-2 * np.ones(D))
+    cplates = (M, 1) if B is None else (M, 1, 1)
+    C = GaussianARD(0, gamma, shape=(D,), plates=cplates, name='C')
+    c0 = rs.normal(size=cplates + (D,))
+    C.initialize_from_value(c0)
+    tau = Gamma(1e-5, 1e-5, name='tau')
+    tau.initialize_from_value(1e2)
+    F = SumMultiply('i,i', C, X, name='F')
+    Y = GaussianARD(F, tau, name='Y')
+    Y.observe(y)
+    nodes = [Y, F, C, gamma, X, A, alpha, tau]
+    if gamma_nu:
+        nodes.append(nu)
+    Q = VB(*nodes)
+    Q.ignore_bound_checks = True
+    Ls = []
+    n_iter = 4
+    for _ in range(n_iter):
+        Q.update(repeat=1, verbose=False)
+        Ls.append(Q.L[Q.iter - 1])
+    out[tag + '_y'], out[tag + '_x0'], out[tag + '_c0'] = y, x0, c0
+    out[tag + '_L'] = np.array(Ls)
+    track = dict(X=X, A=A, C=C, tau=tau, alpha=alpha, gamma=gamma)
+    if gamma_nu:
+        track['nu'] = nu
+    for nm, nd in track.items():
+        for i, ui in enumerate(nd.u):
+            out['%s_%s_u%d' % (tag, nm, i)] = np.asarray(ui)
+        out['%s_%s_L' % (tag, nm)] = np.array(Q.l[nd][:Q.iter])
+    print(tag, Ls)
+
+
 def lssm_cases(name):
     """Linear state-space models (bayespy/demos/lssm.py:33-103): a single chain with fixed
     innovation precision, and a batch of sequences with a Gamma innovation precision;
@@ -381,57 +437,7 @@ def lssm_cases(name):
     out = {}
 
     def build(tag, M, T, D, B, gamma_nu):
-        plates_x = () if B is None else (B,)
-        a_true = 0.9 * np.linalg.qr(rs.normal(size=(D, D)))[0]
-        nseq = 1 if B is None else B
-        x = np.zeros((nseq, T, D))
-        x[:, 0] = rs.normal(size=(nseq, D))
-        for t in range(1, T):
-            x[:, t] = x[:, t - 1] @ a_true.T + rs.normal(size=(nseq, D))
-        c_true = rs.normal(size=(M, D))
-        f = np.einsum('md,btd->mbt', c_true, x)
-        y = f + 0.3 * rs.normal(size=f.shape)
-        if B is None:
-            y = y[:, 0]
-        alpha = Gamma(1e-5, 1e-5, plates=(D,), name='alpha')
-        A = GaussianARD(0, alpha, shape=(D,), plates=(D,), name='A')
-        A.initialize_from_value(np.identity(D))
-        nu = Gamma(1e-3, 1e-3, plates=(D,), name='nu') if gamma_nu else np.ones(D)
-        X = GaussianMarkovChain(np.zeros(D), 1e-3 * np.identity(D), A, nu, n=T,
-                                plates=plates_x, name='X')
-        x0 = rs.normal(size=plates_x + (T, D))
-        X.initialize_from_value(x0)
-        gamma = Gamma(1e-5, 1e-5, plates=(D,), name='gamma')
-        gamma.initialize_from_value(1e-2 * np.ones(D))
-        cplates = (M, 1) if B is None else (M, 1, 1)
-        C = GaussianARD(0, gamma, shape=(D,), plates=cplates, name='C')
-        c0 = rs.normal(size=cplates + (D,))
-        C.initialize_from_value(c0)
-        tau = Gamma(1e-5, 1e-5, name='tau')
-        tau.initialize_from_value(1e2)
-        F = SumMultiply('i,i', C, X, name='F')
-        Y = GaussianARD(F, tau, name='Y')
-        Y.observe(y)
-        nodes = [Y, F, C, gamma, X, A, alpha, tau]
-        if gamma_nu:
-            nodes.append(nu)
-        Q = VB(*nodes)
-        Q.ignore_bound_checks = True
-        Ls = []
-        n_iter = 4
-        for _ in range(n_iter):
-            Q.update(repeat=1, verbose=False)
-            Ls.append(Q.L[Q.iter - 1])
-        out[tag + '_y'], out[tag + '_x0'], out[tag + '_c0'] = y, x0, c0
-        out[tag + '_L'] = np.array(Ls)
-        track = dict(X=X, A=A, C=C, tau=tau, alpha=alpha, gamma=gamma)
-        if gamma_nu:
-            track['nu'] = nu
-        for nm, nd in track.items():
-            for i, ui in enumerate(nd.u):
-                out['%s_%s_u%d' % (tag, nm, i)] = np.asarray(ui)
-            out['%s_%s_L' % (tag, nm)] = np.array(Q.l[nd][:Q.iter])
-        print(tag, Ls)
+        _lssm_build(rs, out, tag, M, T, D, B, gamma_nu)
 
     build('lssm1', M=5, T=30, D=3, B=None, gamma_nu=False)
     build('lssmB', M=4, T=25, D=2, B=6, gamma_nu=True)
@@ -452,6 +458,19 @@ def lssm_cases(name):
         out[tag + '_V'], out[tag + '_C'], out[tag + '_x'], out[tag + '_ld'] = V, Cc, xx, ld
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
 
+
+
+def lssm_wide_state_cases(name):
+    """The batched state-space model of lssm_cases with 8, 12 and 16 latent states (the demo itself,
+    bayespy/demos/lssm.py:193-247, runs D = 10): the fused block's big-state path (8 < D <= 16) and
+    its largest register-resident instance, against the live reference."""
+    rs = np.random.RandomState(4242)
+    out = {}
+    _lssm_build(rs, out, 'w8', M=6, T=20, D=8, B=5, gamma_nu=True)
+    _lssm_build(rs, out, 'w12', M=7, T=18, D=12, B=6, gamma_nu=True)
+    _lssm_build(rs, out, 'w16', M=20, T=15, D=16, B=4, gamma_nu=False)
+    _lssm_build(rs, out, 'w10single', M=12, T=25, D=10, B=None, gamma_nu=True)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
 
 
 def lssm_masked_cases(name, wide=False):
@@ -1414,6 +1433,7 @@ def main():
     utils_cases('utils_known_answers')
     small_model_cases('small_models')
     lssm_cases('lssm')
+    lssm_wide_state_cases('lssm_wide_states')
     lssm_masked_cases('lssm_masked')
     lssm_masked_cases('lssm_masked_wide', wide=True)
     lssm_prior_init_case('lssm_prior_init')

@@ -169,6 +169,29 @@ def test_lssm_matches_reference(golden_dir, tag, B, gamma_nu, engine):
                                        err_msg='%s u[%d]' % (nm, i))
 
 
+@pytest.mark.parametrize('tag,B,gamma_nu', [('w8', 5, True), ('w12', 6, True), ('w16', 4, False),
+                                             ('w10single', None, True)])
+def test_lssm_with_up_to_16_states_matches_reference(golden_dir, tag, B, gamma_nu):
+    """8, 10, 12 and 16 latent states on the FUSED block against live-reference traces
+    (tests/golden/lssm_wide_states.npz, oracle/make_golden.py:lssm_wide_state_cases): D = 8 is the
+    largest register-resident instance, 8 < D <= 16 the big-state path (sweeps on the projected
+    data carrying the state only, plate sums behind them, the shared covariance recursion on one
+    workgroup through LDS).  The demo itself (demos/lssm.py:193-247) runs D = 10."""
+    g = np.load(os.path.join(golden_dir, 'lssm_wide_states.npz'))
+    Q, track = _build_lssm(g, tag, B, gamma_nu, engine=None)
+    assert type(Q.plans[0]).__name__ == 'LSSMPlan'
+    n = len(g[tag + '_L'])
+    Q.update(repeat=n, verbose=False)
+    np.testing.assert_allclose(Q.L[:n], g[tag + '_L'], rtol=1e-9)
+    for nm, nd in track.items():
+        np.testing.assert_allclose(Q.l[nd][:n], g['%s_%s_L' % (tag, nm)], rtol=1e-8, atol=1e-7,
+                                   err_msg=nm)
+        for i, ui in enumerate(nd.u):
+            ref = g['%s_%s_u%d' % (tag, nm, i)]
+            np.testing.assert_allclose(np.broadcast_to(ui, ref.shape), ref, rtol=1e-7, atol=1e-9,
+                                       err_msg='%s u[%d]' % (nm, i))
+
+
 @pytest.mark.parametrize('engine', ['fused', 'generic'])
 def test_lssm_from_prior_initialisation_matches_reference(golden_dir, engine):
     """Every node at its default (prior) initialisation except C: the chain starts from

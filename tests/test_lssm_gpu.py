@@ -56,7 +56,10 @@ def _build(y, x0, c0, gamma_nu, shard=False):
                                      # wide observations: the sweeps on the projected data
                                      # tau C^T y, a separate y <x>^T pass (M > 8, > 16 at D <= 4)
                                      (30, 300, 40, 3), (9, 70, 33, 8), (17, 513, 9, 4),
-                                     (64, 40, 100, 8), (33, 1, 20, 1), (20, 260, 1000, 4)])
+                                     (64, 40, 100, 8), (33, 1, 20, 1), (20, 260, 1000, 4),
+                                     # 8 < D <= 16: the big-state path (round 6)
+                                     (5, 300, 40, 9), (12, 70, 33, 12), (8, 513, 120, 16),
+                                     (40, 257, 9, 13), (3, 1, 1, 16), (16, 1000, 50, 16)])
 @pytest.mark.parametrize('gamma_nu', [False, True])
 def test_fused_lssm_vs_oracle(M, B, T, D, gamma_nu):
     from oracle.lssm import LSSMOracle

@@ -125,12 +125,14 @@ def test_masked_pca_oracle_matches_reference(golden_dir, tag, chunk):
         np.testing.assert_allclose(f_prev[miss], g[tag + '_Y_u0'][miss], rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize('tag,nu_prior', [('lssmBc', None), ('lssmB', (1e-3, 1e-3))])
+@pytest.mark.parametrize('tag,nu_prior', [('lssmBc', None), ('lssmB', (1e-3, 1e-3)),
+                                          # 8, 12, 16 states (lssm_wide_states.npz; round 6)
+                                          ('w8', (1e-3, 1e-3)), ('w12', (1e-3, 1e-3)), ('w16', None)])
 def test_lssm_oracle_matches_reference(golden_dir, tag, nu_prior):
     """oracle/lssm.py (plate sums + ONE shared covariance recursion) against the live-reference
     traces of the batched linear state-space model (fixed and Gamma innovation precision)."""
     from oracle.lssm import LSSMOracle
-    g = np.load(os.path.join(golden_dir, 'lssm.npz'))
+    g = np.load(os.path.join(golden_dir, 'lssm_wide_states.npz' if tag.startswith('w') else 'lssm.npz'))
     o = LSSMOracle(g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0'], nu_prior=nu_prior)
     n = len(g[tag + '_L'])
     o.iterate(n)
@@ -138,14 +140,18 @@ def test_lssm_oracle_matches_reference(golden_dir, tag, nu_prior):
     for nm in ('X', 'A', 'C', 'tau', 'alpha', 'gamma') + (('nu',) if nu_prior else ()):
         np.testing.assert_allclose([t[nm] for t in o.L_terms], g['%s_%s_L' % (tag, nm)],
                                    rtol=1e-9, atol=1e-8, err_msg=nm)
-    np.testing.assert_allclose(o.X, g[tag + '_X_u0'], rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(o.Am, g[tag + '_A_u0'], rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(o.AA, g[tag + '_A_u1'], rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(o.Cm, g[tag + '_C_u0'].reshape(o.Cm.shape), rtol=1e-9, atol=1e-12)
+    # (12 / 16 states: the smoother's conditioning costs two more digits on the entries near zero)
+    wide = tag.startswith('w')
+    np.testing.assert_allclose(o.X, g[tag + '_X_u0'], rtol=1e-8 if wide else 1e-9,
+                               atol=1e-9 if wide else 1e-11)
+    at = 1e-10 if wide else 1e-12
+    np.testing.assert_allclose(o.Am, g[tag + '_A_u0'], rtol=1e-9, atol=at)
+    np.testing.assert_allclose(o.AA, g[tag + '_A_u1'], rtol=1e-9, atol=at)
+    np.testing.assert_allclose(o.Cm, g[tag + '_C_u0'].reshape(o.Cm.shape), rtol=1e-9, atol=at)
     xx = o.V[None] + o.X[:, :, :, None] * o.X[:, :, None, :]
-    np.testing.assert_allclose(xx, g[tag + '_X_u1'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(xx, g[tag + '_X_u1'], rtol=1e-8, atol=1e-9 if wide else 1e-11)
     xpxn = o.Cn[None] + o.X[:, :-1, :, None] * o.X[:, 1:, None, :]
-    np.testing.assert_allclose(xpxn, g[tag + '_X_u2'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(xpxn, g[tag + '_X_u2'], rtol=1e-8, atol=1e-9 if wide else 1e-11)
 
 
 @pytest.mark.parametrize('name', ['gmm_n400_d3_k4', 'gmm_n3000_d8_k16'])
