@@ -912,6 +912,151 @@ lssm_backward_plain_kernel(int64_t B, int T, int64_t BL, const double *__restric
     }
 }
 
+// The same two sweeps ON THE MATRIX CORES (default for 8 < D <= 16; tune key lssm_big_mfma).  A
+// wavefront owns 32 consecutive sequences as two 16-column tiles (even / odd columns, so that a
+// lane's 16-byte access serves both); the state of a tile is ONE accumulator of
+// v_mfma_f64_16x16x4_f64 -- lane l holds rows (l >> 4) + 4 r of column l & 15 -- and that is also the
+// instruction's B-operand layout for k-step r: z_t = h_t - J_t-1^T z_t-1 and x_t = S_t^-1 z_t - J_t x_t+1
+// chain through the accumulators without moving a value between lanes.  The A operands are the
+// (uniform, cache-resident) D x D blocks of the covariance recursion; operands of step t +- 1 are
+// requested before the matrix instructions of step t.  4 (forward) / 8 (backward) instructions per
+// tile and step instead of 2 D^2 / 4 D^2 scalar-operand multiply-adds per thread.  Rows >= D of the
+// padded 16 x 16 blocks are zero; columns >= B (padding of the plate to BL) are computed like the
+// others and ignored by every reader.  BL % 32 == 0, 16-byte aligned arrays.
+template <int D>
+__global__ void __launch_bounds__(256)
+lssm_forward_mfma_kernel(const double *__restrict__ H, int64_t B, int T, int64_t BL,
+                         const double *__restrict__ h0, const double *__restrict__ J,
+                         double *__restrict__ Z, int t0, int t1)
+{
+    const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (b0 >= B) return;
+    const int64_t col = b0 + 2 * l15;
+    const v2f64 zero2 = v2f64{0.0, 0.0};
+    auto load_rows = [&](const double *base, int t, v2f64 (&out)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            out[r] = row < D ? *reinterpret_cast<const v2f64 *>(&base[((int64_t)t * D + row) * BL + col])
+                             : zero2;
+        }
+    };
+    // A[i = l15][k = 4 q + l4] = -J_t[k][i]
+    auto load_jt = [&](int t, double (&a)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + l4;
+            a[q] = (l15 < D && k < D) ? -J[(int64_t)t * D * D + k * D + l15] : 0.0;
+        }
+    };
+    v4f64 z0 = {0.0, 0.0, 0.0, 0.0}, z1 = {0.0, 0.0, 0.0, 0.0};
+    if (t0 > 0) {
+        v2f64 zp[4];
+        load_rows(Z, t0 - 1, zp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z0[r] = zp[r].x; z1[r] = zp[r].y; }
+    }
+    v2f64 h[4], hn[4];
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, an[4];
+    load_rows(H, t0, h);
+    if (t0 > 0) load_jt(t0 - 1, a);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) {
+            load_rows(H, t + 1, hn);
+            load_jt(t, an);
+        }
+        v4f64 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            const double add = (t == 0 && row < D) ? h0[row] : 0.0;
+            c0[r] = h[r].x + add;
+            c1[r] = h[r].y + add;
+        }
+        if (t > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], z0[q], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], z1[q], c1, 0, 0, 0);
+            }
+        }
+        z0 = c0;
+        z1 = c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            if (row < D)
+                *reinterpret_cast<v2f64 *>(&Z[((int64_t)t * D + row) * BL + col]) = v2f64{z0[r], z1[r]};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = hn[r]; a[r] = an[r]; }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+lssm_backward_mfma_kernel(int64_t B, int T, int64_t BL, const double *__restrict__ Sinv,
+                          const double *__restrict__ J, double *__restrict__ Z)
+{
+    const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (b0 >= B) return;
+    const int64_t col = b0 + 2 * l15;
+    const v2f64 zero2 = v2f64{0.0, 0.0};
+    auto load_rows = [&](int t, v2f64 (&out)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            out[r] = row < D ? *reinterpret_cast<const v2f64 *>(&Z[((int64_t)t * D + row) * BL + col])
+                             : zero2;
+        }
+    };
+    // A[i = l15][k = 4 q + l4] = sign * M_t[i][k]
+    auto load_a = [&](const double *M, int t, double sign, double (&a)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + l4;
+            a[q] = (l15 < D && k < D) ? sign * M[(int64_t)t * D * D + l15 * D + k] : 0.0;
+        }
+    };
+    v4f64 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+    v2f64 z[4], zn[4];
+    double as[4], aj[4] = {0.0, 0.0, 0.0, 0.0}, asn[4], ajn[4];
+    load_rows(T - 1, z);
+    load_a(Sinv, T - 1, 1.0, as);
+    for (int t = T - 1; t >= 0; --t) {
+        if (t > 0) {
+            load_rows(t - 1, zn);
+            load_a(Sinv, t - 1, 1.0, asn);
+            load_a(J, t - 1, -1.0, ajn);
+        }
+        v4f64 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(as[q], z[q].x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(as[q], z[q].y, c1, 0, 0, 0);
+        }
+        if (t < T - 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], x0[q], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], x1[q], c1, 0, 0, 0);
+            }
+        }
+        x0 = c0;
+        x1 = c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            if (row < D)
+                *reinterpret_cast<v2f64 *>(&Z[((int64_t)t * D + row) * BL + col]) = v2f64{x0[r], x1[r]};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z[r] = zn[r]; as[r] = asn[r]; aj[r] = ajn[r]; }
+    }
+}
+
 constexpr int PSR = 8;            // rows of A per workgroup row of the pair-sum pass
 
 template <int D>
@@ -1300,6 +1445,36 @@ __device__ __noinline__ void lssm_small_body(const lssm_small_args &A, double *s
     if (bad) sc[2] = (double)VMP_ERR_NOT_POSDEF;
 }
 
+// A.update() with one thread per row of A (D > 8: the D inversions of D x D matrices, 16^4 dependent
+// steps of one thread, were 2.4 ms of the replicated-node chain at D = 16): thread i inverts
+// nu_i Spp + diag<alpha> in its own D x D scratch and forms <a_i>, <a_i a_i^T>, log|Cov_i|.  Same
+// arithmetic per row as the serial form (lssm_small_body, VMP_LSSM_OP_A).
+__device__ void lssm_op_a_rows(const lssm_small_args &A, double *st, double *scratch, int tid)
+{
+    const vmp_lssm_layout &L = A.L;
+    const int D = A.D, DD = D * D;
+    if (tid >= D) return;
+    const int i = tid;
+    double *alp = st + L.off_alpha, *nu = st + L.off_nu;
+    double *Am = st + L.off_Am, *AA = st + L.off_AA, *ldA = st + L.off_ldA;
+    const double *S = st + L.off_S, *Spp = S + DD, *Snp = S + 3 * DD;
+    double *tmp = scratch + (int64_t)i * DD;
+    int bad = 0;
+    for (int e = 0; e < DD; ++e) tmp[e] = nu[2 * D + i] * Spp[e];
+    for (int j = 0; j < D; ++j) tmp[j * D + j] += alp[2 * D + j];
+    const double ld = serial_spd_inverse(tmp, D, &bad);
+    ldA[i] = -ld;
+    for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += tmp[j * D + k] * nu[2 * D + i] * Snp[i * D + k];
+        Am[i * D + j] = s;
+    }
+    for (int j = 0; j < D; ++j)
+        for (int k = 0; k < D; ++k)
+            AA[(i * D + j) * D + k] = tmp[j * D + k] + Am[i * D + j] * Am[i * D + k];
+    if (bad) st[L.off_scal + 2] = (double)VMP_ERR_NOT_POSDEF;
+}
+
 __global__ void __launch_bounds__(64)
 lssm_small_kernel(lssm_small_args A, double *__restrict__ gst)
 {
@@ -1308,7 +1483,23 @@ lssm_small_kernel(lssm_small_args A, double *__restrict__ gst)
     const int total = (int)A.L.total;
     for (int e = threadIdx.x; e < total; e += 64) st_lds[e] = gst[e];
     __syncthreads();
-    if (threadIdx.x == 0) lssm_small_body(A, st_lds, tmp);
+    if (A.D <= DREG) {
+        if (threadIdx.x == 0) lssm_small_body(A, st_lds, tmp);
+    } else {
+        // big-state path: operation by operation, A.update() dealt over the rows (its scratch,
+        // D matrices of D x D, lies behind the state copy in the dynamic LDS)
+        for (int oi = 0; oi < A.nops; ++oi) {
+            if (A.ops[oi] == VMP_LSSM_OP_A) {
+                lssm_op_a_rows(A, st_lds, st_lds + (total + 7) / 8 * 8, threadIdx.x);
+            } else if (threadIdx.x == 0) {
+                lssm_small_args one = A;
+                one.nops = 1;
+                one.ops[0] = A.ops[oi];
+                lssm_small_body(one, st_lds, tmp);
+            }
+            __syncthreads();
+        }
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < total; e += 64) gst[e] = st_lds[e];
 }
@@ -1451,7 +1642,7 @@ inline int big_rows(int D, int M)
 inline int64_t big_extra_doubles(int D, int M, int64_t B, int T)
 {
     const int64_t g = (B + SNT - 1) / SNT;
-    return g * big_rows(D, M) * D + 64 + (int64_t)T * D * ck_bl_max(B) + 64;
+    return g * big_rows(D, M) * D + 64 + 8 + (int64_t)T * D * ck_bl_max(B) + 64;
 }
 
 }  // namespace
@@ -1564,23 +1755,37 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
         double *part = wsd;                                   // pair-sum partials: g x RP x D
         const int64_t g = (B + SNT - 1) / SNT;
         const int RP = big_rows(D, M);
-        double *H = wsd + ws_base_doubles(D, M, B) + g * RP * D + 64;
+        double *H = wsd + (ws_base_doubles(D, M, B) + g * RP * D + 64 + 7) / 8 * 8;
         hipStream_t sw = ctx->stream;
         if (!given && g > 0) {
             int64_t gp = ((int64_t)T * B + SNT - 1) / SNT;
             if (gp > (int64_t)ctx->num_cu * 16) gp = (int64_t)ctx->num_cu * 16;
+            // on the matrix cores (default) when the arrays allow 16-byte accesses per column pair
+            const bool mf = vmp_tune_get("lssm_big_mfma", 1) != 0 && BL % 32 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(H)) & 15) == 0;
+            const int64_t gm = (B + 127) / 128;                 // four wavefronts of 32 sequences
 #define LSSM_BIG(d)                                                                              \
     if (D == d) {                                                                                \
         hipLaunchKernelGGL(lssm_project_kernel<d>, dim3((unsigned)gp), dim3(SNT), 0, sw, Yt, M,  \
                            B, T, BL, Cm, tau, H);                                                \
         for (int k = 0; k < nseg; ++k) {                                                         \
             if (seg_ready) (void)hipStreamWaitEvent(sw, seg_ready[k], 0);                        \
-            hipLaunchKernelGGL((lssm_forward_kernel<d, d, 0, true>), dim3((unsigned)g),          \
-                               dim3(SNT), 0, sw, H, d, B, T, BL, nullptr, nullptr, h0, J, Z,     \
-                               (int)((int64_t)T * k / nseg), (int)((int64_t)T * (k + 1) / nseg)); \
+            const int ta = (int)((int64_t)T * k / nseg), tb = (int)((int64_t)T * (k + 1) / nseg); \
+            if (tb <= ta) continue;                                                              \
+            if (mf)                                                                              \
+                hipLaunchKernelGGL(lssm_forward_mfma_kernel<d>, dim3((unsigned)gm), dim3(256), 0, \
+                                   sw, H, B, T, BL, h0, J, Z, ta, tb);                           \
+            else                                                                                 \
+                hipLaunchKernelGGL((lssm_forward_kernel<d, d, 0, true>), dim3((unsigned)g),      \
+                                   dim3(SNT), 0, sw, H, d, B, T, BL, nullptr, nullptr, h0, J, Z, \
+                                   ta, tb);                                                      \
         }                                                                                        \
-        hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0, sw,   \
-                           B, T, BL, Sinv, J, Z);                                                \
+        if (mf)                                                                                  \
+            hipLaunchKernelGGL(lssm_backward_mfma_kernel<d>, dim3((unsigned)gm), dim3(256), 0,   \
+                               sw, B, T, BL, Sinv, J, Z);                                        \
+        else                                                                                     \
+            hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0,   \
+                               sw, B, T, BL, Sinv, J, Z);                                        \
     }
             LSSM_BIG(9) LSSM_BIG(10) LSSM_BIG(11) LSSM_BIG(12) LSSM_BIG(13) LSSM_BIG(14)
             LSSM_BIG(15) LSSM_BIG(16)
@@ -1824,7 +2029,8 @@ int32_t vmp_lssm_small_ops(vmp_ctx *ctx, int32_t D, int32_t M, int32_t T, double
     A.B = B_total;
     for (int i = 0; i < 8; ++i) A.pri[i] = priors[i];
     A.nu_latent = nu_latent;
-    const size_t small_lds = (size_t)A.L.total * sizeof(double);
+    const size_t small_lds = ((size_t)(A.L.total + 7) / 8 * 8 + (D > DREG ? (size_t)D * D * D : 0))
+                             * sizeof(double);
     if (small_lds > 48 * 1024) {
         // (the state vector of D = 16, M = 64 is 105 KB: gfx950 has 160 KB of LDS per workgroup)
         static bool raised[64] = {false};

@@ -263,3 +263,48 @@ def test_checkpoint_form_of_the_sweeps_agrees_with_the_two_array_form():
         # 1000-step recursions)
         for a, b in zip(res[0][2:], res[1][2:]):
             np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8 * np.abs(b).max())
+
+
+@pytest.mark.parametrize('D', [4, 8, 12, 16])
+def test_state_rotation_of_the_means_through_the_c_abi(D):
+    """vmp_lssm_rotate_x: <x_bt> <- R <x_bt> on the time-major array (transformations.py:1167-1176);
+    D <= 8 with R in scalar registers, 8 < D <= 16 with R in LDS (round 6)."""
+    import ctypes
+    import torch
+    from bayespy_amd.device import get_runtime
+    rt = get_runtime()
+    rs = np.random.RandomState(D)
+    T, B, BL = 7, 300, 320
+    z = rs.normal(size=(T, D, BL))
+    R = rs.normal(size=(D, D))
+    zt = torch.from_numpy(z.copy()).to(rt.device)
+    Rt = torch.from_numpy(R).to(rt.device)
+    rt.sync_stream()
+    rt.check(rt.lib.vmp_lssm_rotate_x(rt.ctx, D, T, B, BL, ctypes.c_void_p(Rt.data_ptr()),
+                                      ctypes.c_void_p(zt.data_ptr())))
+    got = zt.cpu().numpy()
+    ref = z.copy()
+    ref[:, :, :B] = np.einsum('ij,tjb->tib', R, z[:, :, :B])
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize('M,B,T,D', [(6, 301, 45, 12), (8, 96, 130, 16), (3, 33, 17, 9)])
+def test_matrix_core_sweeps_agree_with_the_thread_per_sequence_form(M, B, T, D):
+    """8 < D <= 16: the sweeps on v_mfma_f64_16x16x4_f64 (state of 16 sequences = one accumulator,
+    default) against the same sweeps as one thread per sequence (tune key lssm_big_mfma = 0): same
+    bound trace and means to rounding; both against the oracle in test_fused_lssm_vs_oracle."""
+    from bayespy_amd.device import get_runtime
+    y, x0, c0 = _data(M, B, T, D, seed=5 * D + M)
+    out = []
+    rt = get_runtime()
+    try:
+        for mf in (1, 0):
+            rt.lib.vmp_tune_set(b'lssm_big_mfma', mf)
+            Q = _build(y, x0, c0, True)
+            assert type(Q.plans[0]).__name__ == 'LSSMPlan'
+            Q.update(repeat=3, verbose=False)
+            out.append((np.array(Q.L[:3]), np.asarray(Q['X'].u[0])))
+    finally:
+        rt.lib.vmp_tune_set(b'lssm_big_mfma', 1)
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-12)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9, atol=1e-11)
