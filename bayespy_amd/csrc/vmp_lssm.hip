@@ -1057,6 +1057,103 @@ lssm_backward_mfma_kernel(int64_t B, int T, int64_t BL, const double *__restrict
     }
 }
 
+// The plate sums of the big-state path ON THE MATRIX CORES (default; tune key lssm_big_mfma).  Per
+// (time step, 32 sequences) a tile [x_t (16 rows) ; x_t+1 (16) ; y_t and a row of ones (MP)] x 32
+// columns is staged in LDS (row stride 34: both operand patterns below are bank-conflict free) and
+//     S += tile * x_t^T        (contraction over the 32 sequences, eight k-steps)
+// accumulates sum x x^T (row tile 0), sum x_t+1 x_t^T (1), sum y x^T and sum x (2 ...) in the
+// accumulators of the four wavefronts, which stay resident over all tiles of the workgroup.  Columns
+// >= B contribute zeros.  Three launches per update: all steps; t = 0 (x_0 x_0^T, sum x_0); t = T - 1.
+// Partial block of a workgroup: (32 + MP) x 16 doubles, combined in fixed order by lssm_stats_reduce_kernel.
+constexpr int STN = 32, STZ = STN + 2;
+template <int D>
+__global__ void __launch_bounds__(256)
+lssm_stats_mfma_kernel(const double *__restrict__ Z, const double *__restrict__ Yt, int M, int MP,
+                       int64_t B, int T, int T0, int T1, int64_t BL, double *__restrict__ P)
+{
+    extern __shared__ double Zs[];                 // (32 + MP) x STZ
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, l15 = l & 15, l4 = l >> 4;
+    const int RZ = 32 + MP, NT2 = RZ / 16;         // row tiles
+    const int64_t nbt = (B + STN - 1) / STN;
+    const int64_t ntile = (int64_t)(T1 - T0) * nbt;
+    constexpr int MAXR = 2;                        // row tiles per wavefront: NT2 <= 8
+    v4f64 acc[MAXR];
+#pragma unroll
+    for (int m = 0; m < MAXR; ++m) acc[m] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int lrow = tid >> 4, lcol = (tid & 15) * 2;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int t = T0 + (int)(tile / nbt);
+        const int64_t b0 = (tile % nbt) * STN;
+        const int64_t c = b0 + lcol;
+        __syncthreads();                           // (the previous tile's operands have been read)
+        for (int r = lrow; r < RZ; r += 16) {
+            v2f64 v = v2f64{0.0, 0.0};
+            const double *src = nullptr;
+            if (r < 16) {
+                if (r < D) src = Z + ((int64_t)t * D + r) * BL + c;
+            } else if (r < 32) {
+                if (r - 16 < D && t + 1 < T) src = Z + ((int64_t)(t + 1) * D + (r - 16)) * BL + c;
+            } else if (r - 32 < M) {
+                src = Yt + ((int64_t)t * M + (r - 32)) * BL + c;
+            }
+            if (src) v = *reinterpret_cast<const v2f64 *>(src);
+            else if (r - 32 == M) v = v2f64{1.0, 1.0};
+            if (c >= B) v.x = 0.0;
+            if (c + 1 >= B) v.y = 0.0;
+            *reinterpret_cast<v2f64 *>(&Zs[r * STZ + lcol]) = v;
+        }
+        __syncthreads();
+        const double *zb = Zs + l15 * STZ + l4;            // x_t rows: the B operand
+#pragma unroll
+        for (int q = 0; q < STN / 4; ++q) {
+            const double b = zb[4 * q];
+#pragma unroll
+            for (int m = 0; m < MAXR; ++m) {
+                const int rt = w + 4 * m;
+                if (rt < NT2) {
+                    const double a = Zs[(rt * 16 + l15) * STZ + 4 * q + l4];
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    double *Pb = P + (int64_t)blockIdx.x * RZ * 16;
+#pragma unroll
+    for (int m = 0; m < MAXR; ++m) {
+        const int rt = w + 4 * m;
+        if (rt < NT2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pb[(rt * 16 + l4 + 4 * r) * 16 + l15] = acc[m][r];
+        }
+    }
+}
+
+// out[r * D + c] = sum over the workgroups' partial blocks of P[g][(row0 + r) * 16 + c], r < R, c < D
+__global__ void __launch_bounds__(NT)
+lssm_stats_reduce_kernel(const double *__restrict__ P, int ng, int pstride, int row0, int R, int D,
+                         double *__restrict__ out)
+{
+    const int e = blockIdx.x * (NT / 16) + (threadIdx.x >> 4), j = threadIdx.x & 15;
+    const bool ok = e < R * D;
+    const int r = ok ? e / D : 0, c = ok ? e - r * D : 0;
+    const int64_t src = (int64_t)(row0 + r) * 16 + c;
+    double s0 = 0.0, s1 = 0.0;
+    if (ok) {
+        int g = j;
+        for (; g + 16 < ng; g += 32) {
+            s0 += P[(int64_t)g * pstride + src];
+            s1 += P[(int64_t)(g + 16) * pstride + src];
+        }
+        if (g < ng) s0 += P[(int64_t)g * pstride + src];
+    }
+    double v = s0 + s1;
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (ok && j == 0) out[e] = v;
+}
+
 constexpr int PSR = 8;            // rows of A per workgroup row of the pair-sum pass
 
 template <int D>
@@ -1639,10 +1736,16 @@ inline int big_rows(int D, int M)
     const int r = D > M ? D : M;
     return (r + PSR - 1) / PSR * PSR;
 }
+inline int64_t big_partial_doubles(int D, int M, int64_t B)
+{
+    // the larger of: pair-sum partials (g x RP x D), matrix-core partials (2048 x (32 + MP) x 16)
+    const int64_t g = (B + SNT - 1) / SNT;
+    const int64_t a = g * big_rows(D, M) * D, m = (int64_t)2048 * (32 + 96) * 16;
+    return a > m ? a : m;
+}
 inline int64_t big_extra_doubles(int D, int M, int64_t B, int T)
 {
-    const int64_t g = (B + SNT - 1) / SNT;
-    return g * big_rows(D, M) * D + 64 + 8 + (int64_t)T * D * ck_bl_max(B) + 64;
+    return big_partial_doubles(D, M, B) + 64 + 8 + (int64_t)T * D * ck_bl_max(B) + 64;
 }
 
 }  // namespace
@@ -1755,7 +1858,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
         double *part = wsd;                                   // pair-sum partials: g x RP x D
         const int64_t g = (B + SNT - 1) / SNT;
         const int RP = big_rows(D, M);
-        double *H = wsd + (ws_base_doubles(D, M, B) + g * RP * D + 64 + 7) / 8 * 8;
+        double *H = wsd + (ws_base_doubles(D, M, B) + big_partial_doubles(D, M, B) + 64 + 7) / 8 * 8;
         hipStream_t sw = ctx->stream;
         if (!given && g > 0) {
             int64_t gp = ((int64_t)T * B + SNT - 1) / SNT;
@@ -1794,6 +1897,45 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
         }
         // plate sums: [0, DD) x x^T | x_t+1 x_t^T | x_0 x_0^T | x_T-1 x_T-1^T | x_0 (D) | y x^T (M x D)
         const int DD = D * D;
+        const int MPs = (M + 1 + 15) / 16 * 16;             // y rows + the row of ones, whole tiles
+        if (vmp_tune_get("lssm_big_mfma", 1) != 0 && BL % 32 == 0 && MPs <= 96 &&
+            ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(Yt)) & 15) == 0) {
+            const int RZ = 32 + MPs;
+            const size_t lds = (size_t)RZ * STZ * sizeof(double);
+            const int64_t nbt = (B + STN - 1) / STN;
+            double *Pm = part;                              // <= 2048 blocks x RZ x 16 (sized below)
+            struct { int t0, t1; } rng[3] = {{0, T}, {0, 1}, {T - 1, T}};
+            for (int q = 0; q < 3; ++q) {
+                int64_t gs = (int64_t)(rng[q].t1 - rng[q].t0) * nbt;
+                if (gs > (int64_t)ctx->num_cu * 8) gs = (int64_t)ctx->num_cu * 8;   // (latency: 8 per CU)
+                if (gs > 2048) gs = 2048;
+                if (gs < 1) gs = 1;
+#define LSSM_ST(d)                                                                                \
+    if (D == d)                                                                                   \
+        hipLaunchKernelGGL(lssm_stats_mfma_kernel<d>, dim3((unsigned)gs), dim3(256), lds, sw, Z,  \
+                           Yt, M, MPs, B, T, rng[q].t0, rng[q].t1, BL, Pm);
+                LSSM_ST(9) LSSM_ST(10) LSSM_ST(11) LSSM_ST(12) LSSM_ST(13) LSSM_ST(14) LSSM_ST(15)
+                LSSM_ST(16)
+#undef LSSM_ST
+                auto red = [&](int row0, int R, double *out) {
+                    hipLaunchKernelGGL(lssm_stats_reduce_kernel,
+                                       dim3((unsigned)((R * D + NT / 16 - 1) / (NT / 16))), dim3(NT), 0,
+                                       sw, Pm, (int)gs, RZ * 16, row0, R, D, out);
+                };
+                if (q == 0) {
+                    red(0, D, stats);                        // sum x x^T
+                    red(16, D, stats + DD);                  // sum x_t+1 x_t^T
+                    red(32, M, stats + 4 * DD + D);          // sum y x^T
+                } else if (q == 1) {
+                    red(0, D, stats + 2 * DD);               // x_0 x_0^T
+                    red(32 + M, 1, stats + 4 * DD);          // sum x_0
+                } else {
+                    red(0, D, stats + 3 * DD);               // x_T-1 x_T-1^T
+                }
+            }
+            VMP_HIP_CHECK(ctx, hipGetLastError());
+            return VMP_OK;
+        }
         struct { const double *A; int R, dt, t0, t1, off, len; } jobs[6] = {
             {Z, D, 0, 0, T, 0, DD},          {Z, D, 1, 0, T - 1, DD, DD},
             {Z, D, 0, 0, 1, 2 * DD, DD},     {Z, D, 0, T - 1, T, 3 * DD, DD},
