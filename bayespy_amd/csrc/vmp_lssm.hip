@@ -28,6 +28,10 @@ constexpr int NT = 256;
 constexpr int SNT = 256;
 constexpr int DMAX = 16;         // states of the fused block (D <= 8: everything in registers; 9..16: the big-state path)
 constexpr int DREG = 8;          // largest D of the register-resident kernels
+// smallest D whose sweeps / plate sums take the matrix-core path (instances exist from 7; the tune
+// key lssm_mfma_from moves it for A/B runs)
+inline int lssm_mfma_from() { return vmp_tune_get("lssm_mfma_from", 9); }
+inline bool lssm_big(int D) { return D > DREG || (D >= 7 && D >= lssm_mfma_from()); }
 
 // ---------------------------------------------------------------------------------------------
 // set-up: Y (M, B, T) sequence-major -> Yt (T, M, BL) time-major, BL >= B (pad columns zero)
@@ -1850,7 +1854,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
     VMP_REQUIRE(ctx, D <= DMAX && M <= LSSM_MAXM, VMP_ERR_UNSUPPORTED,
                 "the fused LSSM block supports D <= %d states, M <= %d observed dimensions", DMAX,
                 LSSM_MAXM);
-    if (D > DREG) {
+    if (lssm_big(D)) {
         // big-state path: sweeps on the projected data carrying the state only, plate sums behind
         VMP_REQUIRE(ctx, BL <= ck_bl_max(B), VMP_ERR_INVALID,
                     "leading dimension beyond the workspace contract (B rounded up to 256)");
@@ -1890,7 +1894,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0,   \
                                sw, B, T, BL, Sinv, J, Z);                                        \
     }
-            LSSM_BIG(9) LSSM_BIG(10) LSSM_BIG(11) LSSM_BIG(12) LSSM_BIG(13) LSSM_BIG(14)
+            LSSM_BIG(7) LSSM_BIG(8) LSSM_BIG(9) LSSM_BIG(10) LSSM_BIG(11) LSSM_BIG(12) LSSM_BIG(13) LSSM_BIG(14)
             LSSM_BIG(15) LSSM_BIG(16)
 #undef LSSM_BIG
             VMP_HIP_CHECK(ctx, hipGetLastError());
@@ -1914,7 +1918,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
     if (D == d)                                                                                   \
         hipLaunchKernelGGL(lssm_stats_mfma_kernel<d>, dim3((unsigned)gs), dim3(256), lds, sw, Z,  \
                            Yt, M, MPs, B, T, rng[q].t0, rng[q].t1, BL, Pm);
-                LSSM_ST(9) LSSM_ST(10) LSSM_ST(11) LSSM_ST(12) LSSM_ST(13) LSSM_ST(14) LSSM_ST(15)
+                LSSM_ST(7) LSSM_ST(8) LSSM_ST(9) LSSM_ST(10) LSSM_ST(11) LSSM_ST(12) LSSM_ST(13) LSSM_ST(14) LSSM_ST(15)
                 LSSM_ST(16)
 #undef LSSM_ST
                 auto red = [&](int row0, int R, double *out) {
@@ -1948,7 +1952,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
         hipLaunchKernelGGL(lssm_pairsum_kernel<d>, dim3((unsigned)g, (unsigned)yb), dim3(SNT), 0, \
                            sw, jobs[q].A, jobs[q].R, jobs[q].dt, B, jobs[q].t0, jobs[q].t1, BL,  \
                            Z, part, RP);
-                LSSM_PS(9) LSSM_PS(10) LSSM_PS(11) LSSM_PS(12) LSSM_PS(13) LSSM_PS(14) LSSM_PS(15)
+                LSSM_PS(7) LSSM_PS(8) LSSM_PS(9) LSSM_PS(10) LSSM_PS(11) LSSM_PS(12) LSSM_PS(13) LSSM_PS(14) LSSM_PS(15)
                 LSSM_PS(16)
 #undef LSSM_PS
             }
@@ -2193,8 +2197,8 @@ int32_t vmp_lssm_workspace_doubles(int32_t D, int32_t M, int64_t B, int32_t T, i
 {
     if (!n || D < 1 || M < 1 || B < 0) return VMP_ERR_INVALID;
     *n = ws_base_doubles(D, M, B) + ck_doubles(D, B, T);
-    if (D > DREG) *n += big_extra_doubles(D, M, B, T);
-    else if (lssm_wide(D, M)) *n += wide_extra_doubles(D, M, B, T);
+    if (D >= 7) *n += big_extra_doubles(D, M, B, T);          // (7, 8: either path, by tune key)
+    if (D <= DREG && lssm_wide(D, M)) *n += wide_extra_doubles(D, M, B, T);
     return VMP_OK;
 }
 
