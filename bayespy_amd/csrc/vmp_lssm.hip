@@ -28,10 +28,13 @@ constexpr int NT = 256;
 constexpr int SNT = 256;
 constexpr int DMAX = 16;         // states of the fused block (D <= 8: everything in registers; 9..16: the big-state path)
 constexpr int DREG = 8;          // largest D of the register-resident kernels
-// smallest D whose sweeps / plate sums take the matrix-core path (instances exist from 7; the tune
-// key lssm_mfma_from moves it for A/B runs)
-inline int lssm_mfma_from() { return vmp_tune_get("lssm_mfma_from", 9); }
-inline bool lssm_big(int D) { return D > DREG || (D >= 7 && D >= lssm_mfma_from()); }
+// smallest D of the SPLIT form: sweeps that carry the state only + the plate sums as a separate pass
+// on the matrix cores (instances exist from 7; tune key lssm_split_from).  Below it the backward
+// sweep carries the sums in its registers (the D = 7 / 8 instances of that kernel spill).  Within the
+// split form the sweeps themselves are the register kernels up to DREG unless lssm_split_sweeps = 1
+// asks for the matrix-core sweeps there too (measured slower at D <= 8: half of every tile is padding).
+inline int lssm_split_from() { return vmp_tune_get("lssm_split_from", 7); }
+inline bool lssm_big(int D) { return D > DREG || (D >= 7 && D >= lssm_split_from()); }
 
 // ---------------------------------------------------------------------------------------------
 // set-up: Y (M, B, T) sequence-major -> Yt (T, M, BL) time-major, BL >= B (pad columns zero)
@@ -1132,6 +1135,116 @@ lssm_stats_mfma_kernel(const double *__restrict__ Z, const double *__restrict__ 
     }
 }
 
+// The same sums, one WAVEFRONT per (32 sequences, chunk of TC time steps): no workgroup barrier, the
+// x_t+1 rows of a step stay in LDS as the x_t rows of the next (the smoothed states are read ONCE, not
+// twice), the rows of step t + 1 are in flight in registers while step t is on the matrix cores.  A
+// workgroup IS one wavefront (its barriers are waits on the LDS counter); the accumulators stay
+// resident over the jobs of a wavefront; same partial layout as above.
+constexpr int STY = 16;           // y rows prefetched in registers (more rows: loaded at the step)
+template <int D>
+__global__ void __launch_bounds__(64)
+lssm_stats_wave_kernel(const double *__restrict__ Z, const double *__restrict__ Yt, int M, int MP,
+                       int64_t B, int T, int T0, int T1, int TC, int64_t BL, double *__restrict__ P)
+{
+    extern __shared__ double Zs[];                 // x ping [16] | x pong [16] | y and ones [MP], stride STZ
+    const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4, lcol = l15 * 2;
+    const int NY = MP / 16;                        // row tiles of [y ; 1]
+    const int64_t nbt = (B + STN - 1) / STN;
+    const int nch = (T1 - T0 + TC - 1) / TC;
+    const int64_t njob = (int64_t)nch * nbt;
+    constexpr int XR = (D + 3) / 4;                // row groups (4 rows per load) of a state tile
+    constexpr int MAXY = 5;                        // M + 1 <= 80
+    v4f64 axx = v4f64{0.0, 0.0, 0.0, 0.0}, axn = axx, ay[MAXY];
+#pragma unroll
+    for (int m = 0; m < MAXY; ++m) ay[m] = axx;
+    double *Yl = Zs + 32 * STZ;              // state tile k at Zs + k * 16 * STZ
+    // rows that are never loaded: zero once (D .. 15 of both state tiles; M .. MP - 1 of the y tile)
+    for (int r = l4; r < 32 + MP; r += 4) {
+        const bool dead = r < 32 ? (r & 15) >= D : r - 32 >= M;
+        if (dead) *reinterpret_cast<v2f64 *>(&Zs[r * STZ + lcol]) = v2f64{0.0, 0.0};
+    }
+    const v2f64 zero2 = v2f64{0.0, 0.0};
+    for (int64_t job = blockIdx.x; job < njob; job += gridDim.x) {
+        const int ch = (int)(job / nbt);
+        const int64_t c = (job - (int64_t)ch * nbt) * STN + lcol;
+        const int ta = T0 + ch * TC, tb = ta + TC < T1 ? ta + TC : T1;
+        const bool ok0 = c < B, ok1 = c + 1 < B;
+        auto mask = [&](v2f64 v) { if (!ok0) v.x = 0.0; if (!ok1) v.y = 0.0; return v; };
+        auto load_x = [&](int t, v2f64 (&out)[XR]) {
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int row = 4 * i + l4;
+                out[i] = (row < D && t < T && ok0)
+                             ? *reinterpret_cast<const v2f64 *>(&Z[((int64_t)t * D + row) * BL + c]) : zero2;
+            }
+        };
+        auto load_y = [&](int t, v2f64 (&out)[STY / 4]) {
+#pragma unroll
+            for (int i = 0; i < STY / 4; ++i) {
+                const int row = 4 * i + l4;
+                out[i] = (row < M && ok0)
+                             ? *reinterpret_cast<const v2f64 *>(&Yt[((int64_t)t * M + row) * BL + c]) : zero2;
+            }
+        };
+        auto store_x = [&](double *dst, const v2f64 (&v)[XR]) {
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int row = 4 * i + l4;
+                if (row < D) *reinterpret_cast<v2f64 *>(&dst[row * STZ + lcol]) = mask(v[i]);
+            }
+        };
+        v2f64 xr[XR], yr[STY / 4];
+        __syncthreads();                           // (the previous job's operands have been read)
+        load_x(ta, xr);
+        store_x(Zs, xr);
+        if (l4 == 0) *reinterpret_cast<v2f64 *>(&Yl[M * STZ + lcol]) = mask(v2f64{1.0, 1.0});
+        load_x(ta + 1, xr);
+        load_y(ta, yr);
+        for (int t = ta; t < tb; ++t) {
+            const int cur = (t - ta) & 1;
+            store_x(Zs + (cur ^ 1) * 16 * STZ, xr);
+#pragma unroll
+            for (int i = 0; i < STY / 4; ++i) {
+                const int row = 4 * i + l4;
+                if (row < M) *reinterpret_cast<v2f64 *>(&Yl[row * STZ + lcol]) = mask(yr[i]);
+            }
+            for (int row = STY + l4; row < M; row += 4)
+                *reinterpret_cast<v2f64 *>(&Yl[row * STZ + lcol]) =
+                    mask(ok0 ? *reinterpret_cast<const v2f64 *>(&Yt[((int64_t)t * M + row) * BL + c]) : zero2);
+            if (t + 1 < tb) {                      // in flight while this step multiplies
+                load_x(t + 2, xr);
+                load_y(t + 1, yr);
+            }
+            __syncthreads();
+            const double *xc = Zs + (cur * 16 + l15) * STZ + l4, *xn = Zs + ((cur ^ 1) * 16 + l15) * STZ + l4;
+            const double *yl = Yl + l15 * STZ + l4;
+#pragma unroll
+            for (int q = 0; q < STN / 4; ++q) {
+                const double b = xc[4 * q];
+                axx = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, axx, 0, 0, 0);
+                axn = __builtin_amdgcn_mfma_f64_16x16x4f64(xn[4 * q], b, axn, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MAXY; ++m)
+                    if (m < NY)
+                        ay[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(yl[m * 16 * STZ + 4 * q], b, ay[m], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    double *Pb = P + (int64_t)blockIdx.x * (32 + MP) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Pb[(l4 + 4 * r) * 16 + l15] = axx[r];
+        Pb[(16 + l4 + 4 * r) * 16 + l15] = axn[r];
+    }
+#pragma unroll
+    for (int m = 0; m < MAXY; ++m)
+        if (m < NY) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pb[(32 + m * 16 + l4 + 4 * r) * 16 + l15] = ay[m][r];
+        }
+}
+
 // out[r * D + c] = sum over the workgroups' partial blocks of P[g][(row0 + r) * 16 + c], r < R, c < D
 __global__ void __launch_bounds__(NT)
 lssm_stats_reduce_kernel(const double *__restrict__ P, int ng, int pstride, int row0, int R, int D,
@@ -1894,8 +2007,36 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0,   \
                                sw, B, T, BL, Sinv, J, Z);                                        \
     }
+            const bool regsw = D <= DREG && vmp_tune_get("lssm_split_sweeps", 0) == 0;
+            // register sweeps (D <= DREG): straight from the observations when M <= 8 (no projection pass)
+#define LSSM_BIGR(d)                                                                             \
+    if (D == d) {                                                                                \
+        const bool direct = M <= 8;                                                              \
+        if (!direct)                                                                             \
+            hipLaunchKernelGGL(lssm_project_kernel<d>, dim3((unsigned)gp), dim3(SNT), 0, sw, Yt, \
+                               M, B, T, BL, Cm, tau, H);                                         \
+        for (int k = 0; k < nseg; ++k) {                                                         \
+            if (seg_ready) (void)hipStreamWaitEvent(sw, seg_ready[k], 0);                        \
+            const int ta = (int)((int64_t)T * k / nseg), tb = (int)((int64_t)T * (k + 1) / nseg); \
+            if (tb <= ta) continue;                                                              \
+            if (direct)                                                                          \
+                hipLaunchKernelGGL((lssm_forward_kernel<d, 8, 0>), dim3((unsigned)g), dim3(SNT), \
+                                   0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb);           \
+            else                                                                                 \
+                hipLaunchKernelGGL((lssm_forward_kernel<d, d, 0, true>), dim3((unsigned)g),      \
+                                   dim3(SNT), 0, sw, H, d, B, T, BL, nullptr, nullptr, h0, J, Z, \
+                                   ta, tb);                                                      \
+        }                                                                                        \
+        hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0, sw,   \
+                           B, T, BL, Sinv, J, Z);                                                \
+    }
+            if (regsw) {
+                LSSM_BIGR(7) LSSM_BIGR(8)
+            } else {
             LSSM_BIG(7) LSSM_BIG(8) LSSM_BIG(9) LSSM_BIG(10) LSSM_BIG(11) LSSM_BIG(12) LSSM_BIG(13) LSSM_BIG(14)
             LSSM_BIG(15) LSSM_BIG(16)
+            }
+#undef LSSM_BIGR
 #undef LSSM_BIG
             VMP_HIP_CHECK(ctx, hipGetLastError());
         }
@@ -1909,8 +2050,31 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             const int64_t nbt = (B + STN - 1) / STN;
             double *Pm = part;                              // <= 2048 blocks x RZ x 16 (sized below)
             struct { int t0, t1; } rng[3] = {{0, T}, {0, 1}, {T - 1, T}};
+            const bool wavef = vmp_tune_get("lssm_stats_form", 1) != 0;
             for (int q = 0; q < 3; ++q) {
-                int64_t gs = (int64_t)(rng[q].t1 - rng[q].t0) * nbt;
+                int64_t gs;
+                if (wavef) {
+                    // one wavefront per job of (32 sequences, TC steps); as many resident as LDS holds
+                    const int steps = rng[q].t1 - rng[q].t0;
+                    int TC = 32;
+                    while (TC > 4 && (int64_t)((steps + TC - 1) / TC) * nbt < (int64_t)ctx->num_cu * 8) TC /= 2;
+                    const int64_t njob = (int64_t)((steps + TC - 1) / TC) * nbt;
+                    int per_cu = (int)((size_t)150 * 1024 / lds);
+                    if (per_cu > 16) per_cu = 16;
+                    gs = (int64_t)ctx->num_cu * per_cu;
+                    const int64_t cap = big_partial_doubles(D, M, B) / ((int64_t)RZ * 16);
+                    if (gs > cap) gs = cap;
+                    if (gs > njob) gs = njob;
+                    if (gs < 1) gs = 1;
+#define LSSM_STW(d)                                                                               \
+    if (D == d)                                                                                   \
+        hipLaunchKernelGGL(lssm_stats_wave_kernel<d>, dim3((unsigned)gs), dim3(64), lds, sw, Z,   \
+                           Yt, M, MPs, B, T, rng[q].t0, rng[q].t1, TC, BL, Pm);
+                    LSSM_STW(7) LSSM_STW(8) LSSM_STW(9) LSSM_STW(10) LSSM_STW(11) LSSM_STW(12) LSSM_STW(13)
+                    LSSM_STW(14) LSSM_STW(15) LSSM_STW(16)
+#undef LSSM_STW
+                } else {
+                gs = (int64_t)(rng[q].t1 - rng[q].t0) * nbt;
                 if (gs > (int64_t)ctx->num_cu * 8) gs = (int64_t)ctx->num_cu * 8;   // (latency: 8 per CU)
                 if (gs > 2048) gs = 2048;
                 if (gs < 1) gs = 1;
@@ -1921,6 +2085,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
                 LSSM_ST(7) LSSM_ST(8) LSSM_ST(9) LSSM_ST(10) LSSM_ST(11) LSSM_ST(12) LSSM_ST(13) LSSM_ST(14) LSSM_ST(15)
                 LSSM_ST(16)
 #undef LSSM_ST
+                }
                 auto red = [&](int row0, int R, double *out) {
                     hipLaunchKernelGGL(lssm_stats_reduce_kernel,
                                        dim3((unsigned)((R * D + NT / 16 - 1) / (NT / 16))), dim3(NT), 0,
