@@ -157,6 +157,7 @@ lssm_sum_kernel(const double *__restrict__ partial, int n, int stride, int len, 
 // ---------------------------------------------------------------------------------------------
 struct cov_args {
     int T, D;
+    int shortcut;                    // big kernel: ulp of the stationarity rule (tune key lssm_cov_shortcut; 0 = off)
     // inputs (device, D x D row-major unless noted)
     const double *Dg0, *Dgm, *DgT;   // diagonal blocks of Phi: t = 0, 0 < t < T-1, t = T-1
     const double *E;                 // super-diagonal block Phi[t, t+1] (same for all t)
@@ -1337,18 +1338,39 @@ lssm_rotate_big_kernel(const double *__restrict__ R, int T, int64_t B, int64_t B
     }
 }
 
+// the 256-thread form of stationary(): all elements of the two iterates agree within 8 ulp of the
+// largest magnitude.  red: 8 doubles of LDS; every thread of the workgroup calls it.
+__device__ inline bool stationary_block(double a, double b, bool act, double *red, double ulps)
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    double m = act ? fabs(a) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (l == 0) red[w] = m;
+    __syncthreads();
+    m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    const bool ok = __all(!act || fabs(a - b) <= ulps * 2.220446049250313e-16 * m);
+    if (l == 0) red[4 + w] = ok ? 1.0 : 0.0;
+    __syncthreads();
+    const bool all = red[4] != 0.0 && red[5] != 0.0 && red[6] != 0.0 && red[7] != 0.0;
+    __syncthreads();
+    return all;
+}
+
 // The shared covariance recursion for 8 < D <= 16: one workgroup of 256 threads, thread (i, j) owns
 // element (i, j) of the 16 x 16 padded matrices (identity in the padding, so the pivots there are 1),
 // operands through LDS -- the lane-crossing moves of lssm_cov_kernel do not reach across the four
-// wavefronts.  Same recursion, same outputs (S^-1, J, the sums of V_t and Cov(x_t, x_t+1), log|Phi|);
-// no stationarity shortcut; phase bit 0 = forward half, bit 1 = backward half (each whole in one
-// launch).  ~3 us per step.
+// wavefronts.  Same recursion, same outputs (S^-1, J, the sums of V_t and Cov(x_t, x_t+1), log|Phi|),
+// the same stationarity rule as lssm_cov_kernel (tested every eighth step; the interior steps behind
+// a converged iterate are filled in, not recomputed); phase bit 0 = forward half, bit 1 = backward
+// half (each whole in one launch).  ~4 us per computed forward step, ~1 us per backward step.
 __global__ void __launch_bounds__(256)
 lssm_cov_big_kernel(cov_args a, int phase)
 {
     constexpr int P = 16, LP = 17;
     __shared__ double U[2][P * LP];
     __shared__ double Es[P * LP], Js[P * LP], Vs[P * LP];
+    __shared__ double red[8];
     const int tid = threadIdx.x, i = tid >> 4, j = tid & 15, D = a.D, T = a.T;
     const bool act = i < D && j < D;
     const int l = i * D + j, q = i * LP + j;
@@ -1356,6 +1378,9 @@ lssm_cov_big_kernel(cov_args a, int phase)
     const double e = act ? a.E[l] : 0.0;
     const double dgm = act ? a.Dgm[l] : pad, dgT = act ? a.DgT[l] : pad;
     const int DD = D * D;
+    const bool shortcut = a.shortcut != 0;
+    const double ulps = (double)a.shortcut;
+    int fix_from = -1;                     // steps fix_from .. T-2 share one (S^-1, J)
     Es[q] = e;
     __syncthreads();
     if (phase & 1) {
@@ -1364,6 +1389,7 @@ lssm_cov_big_kernel(cov_args a, int phase)
         double s = act ? a.Dg0[l] : pad;
         for (int t = 0; t < T; ++t) {
             int cur = 0;
+            const double prod0 = prod, ex0 = ex;
             U[0][q] = s;
             __syncthreads();
             double v = s;
@@ -1392,13 +1418,29 @@ lssm_cov_big_kernel(cov_args a, int phase)
                 __syncthreads();
                 double ej = 0.0;
                 for (int k = 0; k < D; ++k) ej += Es[k * LP + i] * Js[k * LP + j];         // E^T J
-                s = ((t + 1 < T - 1) ? dgm : dgT) - ej;
+                const double snew = ((t + 1 < T - 1) ? dgm : dgT) - ej;
+                if (shortcut && t >= 1 && (t & 7) == 0 && t + 1 < T - 1 && stationary_block(snew, s, act, red, ulps)) {
+                    const int tl = T - 2;                               // last interior step
+                    for (int tt = t + 1; tt <= tl; ++tt) {
+                        if (act) {
+                            a.Sinv[(int64_t)tt * DD + l] = v;
+                            a.J[(int64_t)tt * DD + l] = jt;
+                        }
+                    }
+                    // (tl - t) more copies of this step's pivots
+                    ex += (double)(tl - t) * ((ex - ex0) + (log2(prod) - log2(prod0)));
+                    fix_from = t;
+                    s = act ? dgT - ej : pad;                           // S_T-1
+                    t = tl;
+                    continue;
+                }
+                s = snew;
             }
         }
         if (tid == 0) {
             a.sums[5 * DD + 0] = log(prod) + ex * 0.69314718055994530942;
             a.sums[5 * DD + 1] = (double)bad;
-            a.sums[5 * DD + 2] = -1.0;
+            a.sums[5 * DD + 2] = (double)fix_from;
             a.sums[5 * DD + 4] = prod;
             a.sums[5 * DD + 5] = ex;
             a.sums[5 * DD + 6] = 1.0;
@@ -1406,14 +1448,38 @@ lssm_cov_big_kernel(cov_args a, int phase)
         if (!(phase & 2)) return;
         __threadfence();
         __syncthreads();
+    } else {
+        fix_from = (int)a.sums[5 * DD + 2];                 // left by the forward launch
     }
     // ---- backward: V_T-1 = S_T-1^-1;  C_t = -J_t V_t+1;  V_t = S_t^-1 - C_t J_t^T -----------------
     double v = act ? a.Sinv[(int64_t)(T - 1) * DD + l] : 0.0;
     double sv = v, sc = 0.0;
     const double vlast = v;
+    double vprev = 0.0, cprev = 0.0;
+    int bfix = -1, have_prev = 0;
+    double jn = (T >= 2 && act) ? a.J[(int64_t)(T - 2) * DD + l] : 0.0;
+    double sn = (T >= 2 && act) ? a.Sinv[(int64_t)(T - 2) * DD + l] : 0.0;
     for (int t = T - 2; t >= 0; --t) {
-        const double jt = act ? a.J[(int64_t)t * DD + l] : 0.0;
-        const double si = act ? a.Sinv[(int64_t)t * DD + l] : 0.0;
+        const double jt = jn, si = sn;
+        if (t > 0) {                                   // next step's operands: off the serial path
+            jn = act ? a.J[(int64_t)(t - 1) * DD + l] : 0.0;
+            sn = act ? a.Sinv[(int64_t)(t - 1) * DD + l] : 0.0;
+        }
+        // same (S^-1, J) as the step before and a V_t+1 that has stopped moving: the same V, C again,
+        // down to the first step of the stationary stretch (tested every fourth step)
+        if (shortcut && have_prev && fix_from >= 0 && t >= fix_from && t + 1 <= T - 2 && (t & 3) == 0
+            && stationary_block(v, vprev, act, red, ulps)) {
+            const double cnt = (double)(t - fix_from + 1);
+            sv += cnt * v;
+            sc += cnt * cprev;
+            bfix = t;
+            t = fix_from;
+            if (t > 0) {
+                jn = act ? a.J[(int64_t)(t - 1) * DD + l] : 0.0;
+                sn = act ? a.Sinv[(int64_t)(t - 1) * DD + l] : 0.0;
+            }
+            continue;
+        }
         Js[q] = jt;
         Vs[q] = v;
         __syncthreads();
@@ -1423,7 +1489,10 @@ lssm_cov_big_kernel(cov_args a, int phase)
         __syncthreads();
         double cj = 0.0;
         for (int k = 0; k < D; ++k) cj += U[0][i * LP + k] * Js[j * LP + k];               // C J^T
+        vprev = v;
         v = si - cj;
+        have_prev = 1;
+        cprev = c;
         sv += v;
         sc += c;
         __syncthreads();
@@ -1434,7 +1503,7 @@ lssm_cov_big_kernel(cov_args a, int phase)
         a.sums[2 * DD + l] = vlast;
         a.sums[3 * DD + l] = sc;
     }
-    if (tid == 0) a.sums[5 * DD + 3] = -1.0;
+    if (tid == 0) a.sums[5 * DD + 3] = (double)bfix;       // diagnostics, backward map
 }
 
 constexpr int CKS = 4;
@@ -1928,6 +1997,7 @@ static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int
     a.Sinv = Sinv;
     a.J = J;
     a.sums = sums;
+    a.shortcut = vmp_tune_get("lssm_cov_shortcut", 8);     // in ulp; 0: every step computed
     if (D > DREG) {
         // one launch per half (no segments: a later forward segment has nothing left to do)
         if ((phase & 1) && t0 > 0) return VMP_OK;

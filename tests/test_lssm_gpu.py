@@ -5,6 +5,8 @@ seeded inputs incl. tiny / ragged sizes; the live-reference traces themselves ar
 tests/test_chain_gpu.py::test_lssm_matches_reference[fused].
 Bars: bound rtol 1e-9 per iteration and per node term; moments rtol 1e-7.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -309,3 +311,104 @@ def test_matrix_core_sweeps_agree_with_the_thread_per_sequence_form(M, B, T, D):
     # (the two forms also sum the plates in different orders: matrix-core tiles / thread blocks)
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-10)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-8, atol=1e-8 * np.abs(out[1][1]).max())
+
+
+def _cov_recursion_numpy(Dg0, Dgm, DgT, E, T):
+    """The block recursion of vmp_lssm_cov, every step computed (oracle/lssm.py: block LDL^T of the
+    block-tridiagonal precision; utils/linalg.py:468-575 in the reference)."""
+    D = E.shape[0]
+    Sinv = np.zeros((T, D, D))
+    J = np.zeros((T - 1, D, D))
+    S = Dg0.copy()
+    ld = 0.0
+    for t in range(T):
+        ld += np.linalg.slogdet(S)[1]
+        Sinv[t] = np.linalg.inv(S)
+        if t < T - 1:
+            J[t] = Sinv[t] @ E
+            S = (Dgm if t + 1 < T - 1 else DgT) - E.T @ J[t]
+    V = Sinv[T - 1].copy()
+    sv, sc = V.copy(), np.zeros((D, D))
+    for t in range(T - 2, -1, -1):
+        C = -J[t] @ V
+        V = Sinv[t] - C @ J[t].T
+        sv += V
+        sc += C
+    return Sinv, J, sv, V, sc, ld
+
+
+@pytest.mark.parametrize('D,T', [(12, 700), (16, 500), (9, 400)])
+def test_big_state_covariance_recursion_fills_in_its_stationary_stretch(D, T):
+    """8 < D <= 16, through the C ABI: the 256-thread covariance recursion applies the rule of the
+    one-wavefront kernel (iterates within 8 ulp: the interior steps behind are filled in).  On a
+    strongly contracting map the shortcut is taken (diagnostics); S^-1, J, the sums of V and C and
+    log|Phi| agree with the recursion that computes every step (tune key lssm_cov_shortcut = 0) and
+    with a NumPy restatement."""
+    import torch
+    from bayespy_amd.device import get_runtime
+    rt = get_runtime()
+    rng = np.random.RandomState(D)
+    G = rng.randn(D, D)
+    E = -0.35 * np.linalg.qr(G)[0] + 0.02 * rng.randn(D, D)
+    W = rng.randn(D, D) * 0.1
+    Dgm = 3.0 * np.eye(D) + W @ W.T
+    Dg0 = Dgm + np.eye(D)
+    DgT = Dgm - 0.5 * np.eye(D)
+    dev = rt.device
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    ins = [up(Dg0), up(Dgm), up(DgT), up(E)]
+    ref = _cov_recursion_numpy(Dg0, Dgm, DgT, E, T)
+    out = []
+    try:
+        for sc in (8, 0):
+            rt.lib.vmp_tune_set(b'lssm_cov_shortcut', sc)
+            Sinv = torch.zeros(T, D, D, dtype=torch.float64, device=dev)
+            J = torch.zeros(T, D, D, dtype=torch.float64, device=dev)
+            sums = torch.zeros(5 * D * D + 16, dtype=torch.float64, device=dev)
+            rt.check(rt.lib.vmp_lssm_cov(rt.ctx, T, D, vp(ins[0]), vp(ins[1]), vp(ins[2]), vp(ins[3]),
+                                         vp(Sinv), vp(J), vp(sums)))
+            rt.sync_stream()
+            sm = sums.cpu().numpy()
+            fwd, bwd = int(sm[5 * D * D + 2]), int(sm[5 * D * D + 3])
+            if sc:
+                assert 0 < fwd < T - 2 and 0 < bwd < T - 2
+            else:
+                assert fwd < 0 and bwd < 0
+            assert sm[5 * D * D + 1] == 0.0
+            out.append((Sinv.cpu().numpy(), J.cpu().numpy()[:T - 1], sm[:D * D].reshape(D, D),
+                        sm[D * D:2 * D * D].reshape(D, D), sm[3 * D * D:4 * D * D].reshape(D, D),
+                        sm[5 * D * D]))
+    finally:
+        rt.lib.vmp_tune_set(b'lssm_cov_shortcut', 8)
+    for o in out:
+        for got, want in zip(o, ref):
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('M,B,T,D', [(8, 301, 45, 8), (5, 96, 130, 7), (20, 70, 33, 8), (8, 1000, 20, 12)])
+def test_split_form_of_the_plate_sums_agrees_with_the_other_forms(M, B, T, D):
+    """D >= 7 (default): sweeps that carry the state only + the plate sums as a matrix-core pass, one
+    wavefront per (32 sequences, time chunk).  Against (a) the workgroup form of that pass
+    (lssm_stats_form = 0) and, for D <= 8, (b) the sums carried in the backward sweep's registers
+    (lssm_split_from = 9): same bound trace and moments to rounding."""
+    from bayespy_amd.device import get_runtime
+    y, x0, c0 = _data(M, B, T, D, seed=7 * D + M)
+    rt = get_runtime()
+    variants = [(7, 1), (7, 0)] + ([(9, 1)] if D <= 8 else [])
+    out = []
+    try:
+        for frm, form in variants:
+            rt.lib.vmp_tune_set(b'lssm_split_from', frm)
+            rt.lib.vmp_tune_set(b'lssm_stats_form', form)
+            Q = _build(y, x0, c0, True)
+            assert type(Q.plans[0]).__name__ == 'LSSMPlan'
+            Q.update(repeat=3, verbose=False)
+            out.append((np.array(Q.L[:3]), np.asarray(Q['X'].u[0]), np.asarray(Q['C'].u[0])))
+    finally:
+        rt.lib.vmp_tune_set(b'lssm_split_from', 7)
+        rt.lib.vmp_tune_set(b'lssm_stats_form', 1)
+    for o in out[1:]:
+        np.testing.assert_allclose(out[0][0], o[0], rtol=1e-10)
+        np.testing.assert_allclose(out[0][1], o[1], rtol=1e-8, atol=1e-8 * np.abs(o[1]).max())
+        np.testing.assert_allclose(out[0][2], o[2], rtol=1e-8, atol=1e-8 * np.abs(o[2]).max())

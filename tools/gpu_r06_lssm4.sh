@@ -1,3 +1,2 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -4
-timeout 900 python tools/lssm_d8_ab.py 2>&1 | grep -v amdgpu.ids
+timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -12
