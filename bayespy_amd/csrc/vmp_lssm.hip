@@ -1002,6 +1002,99 @@ lssm_forward_mfma_kernel(const double *__restrict__ H, int64_t B, int T, int64_t
     }
 }
 
+// The same forward sweep WITH the projection h_t = tau C^T y_t inside (M <= 16): the observations of
+// a step are loaded in the B-operand layout (row m = 4 q + (l >> 4), sequences along l & 15) and
+// h_t is MQ more products into the accumulator the recursion continues in -- the (T, D, BL) array of
+// projected data is neither written nor read (lssm_project_kernel: 4.1 of 24.9 ms at D = 16, B = 1e5).
+template <int D, int MQ>
+__global__ void __launch_bounds__(256)
+lssm_forward_mfma_y_kernel(const double *__restrict__ Yt, int M, int64_t B, int T, int64_t BL,
+                           const double *__restrict__ Cm, const double *__restrict__ tau_ptr,
+                           const double *__restrict__ h0, const double *__restrict__ J,
+                           double *__restrict__ Z, int t0, int t1)
+{
+    const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (b0 >= B) return;
+    const int64_t col = b0 + 2 * l15;
+    const v2f64 zero2 = v2f64{0.0, 0.0};
+    auto load_y = [&](int t, v2f64 (&out)[MQ]) {
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const int m = 4 * q + l4;
+            out[q] = m < M ? *reinterpret_cast<const v2f64 *>(&Yt[((int64_t)t * M + m) * BL + col]) : zero2;
+        }
+    };
+    auto load_jt = [&](int t, double (&a)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + l4;
+            a[q] = (l15 < D && k < D) ? -J[(int64_t)t * D * D + k * D + l15] : 0.0;
+        }
+    };
+    // A[i = l15][k = m = 4 q + l4] = tau C[m][i]
+    const double tau = tau_ptr[0];
+    double ac[MQ];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const int m = 4 * q + l4;
+        ac[q] = (l15 < D && m < M) ? tau * Cm[m * D + l15] : 0.0;
+    }
+    v4f64 z0 = {0.0, 0.0, 0.0, 0.0}, z1 = {0.0, 0.0, 0.0, 0.0};
+    if (t0 > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            const v2f64 zp = row < D ? *reinterpret_cast<const v2f64 *>(&Z[((int64_t)(t0 - 1) * D + row) * BL + col])
+                                     : zero2;
+            z0[r] = zp.x;
+            z1[r] = zp.y;
+        }
+    }
+    v2f64 y[MQ], yn[MQ];
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, an[4];
+    load_y(t0, y);
+    if (t0 > 0) load_jt(t0 - 1, a);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) {
+            load_y(t + 1, yn);
+            load_jt(t, an);
+        }
+        v4f64 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            const double add = (t == 0 && row < D) ? h0[row] : 0.0;
+            c0[r] = add;
+            c1[r] = add;
+        }
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], y[q].x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], y[q].y, c1, 0, 0, 0);
+        }
+        if (t > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], z0[q], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], z1[q], c1, 0, 0, 0);
+            }
+        }
+        z0 = c0;
+        z1 = c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            if (row < D)
+                *reinterpret_cast<v2f64 *>(&Z[((int64_t)t * D + row) * BL + col]) = v2f64{z0[r], z1[r]};
+        }
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) y[q] = yn[q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = an[r];
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256)
 lssm_backward_mfma_kernel(int64_t B, int T, int64_t BL, const double *__restrict__ Sinv,
@@ -2054,15 +2147,28 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             const bool mf = vmp_tune_get("lssm_big_mfma", 1) != 0 && BL % 32 == 0 &&
                             ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(H)) & 15) == 0;
             const int64_t gm = (B + 127) / 128;                 // four wavefronts of 32 sequences
+            // the projection inside the sweep when the observations fit four k-steps
+            const bool fy = mf && M <= 16 && vmp_tune_get("lssm_fuse_project", 1) != 0 &&
+                            (reinterpret_cast<uintptr_t>(Yt) & 15) == 0;
 #define LSSM_BIG(d)                                                                              \
     if (D == d) {                                                                                \
-        hipLaunchKernelGGL(lssm_project_kernel<d>, dim3((unsigned)gp), dim3(SNT), 0, sw, Yt, M,  \
-                           B, T, BL, Cm, tau, H);                                                \
+        if (!fy)                                                                                 \
+            hipLaunchKernelGGL(lssm_project_kernel<d>, dim3((unsigned)gp), dim3(SNT), 0, sw, Yt, \
+                               M, B, T, BL, Cm, tau, H);                                         \
         for (int k = 0; k < nseg; ++k) {                                                         \
             if (seg_ready) (void)hipStreamWaitEvent(sw, seg_ready[k], 0);                        \
             const int ta = (int)((int64_t)T * k / nseg), tb = (int)((int64_t)T * (k + 1) / nseg); \
             if (tb <= ta) continue;                                                              \
-            if (mf)                                                                              \
+            if (fy && M <= 4)                                                                    \
+                hipLaunchKernelGGL((lssm_forward_mfma_y_kernel<d, 1>), dim3((unsigned)gm),       \
+                                   dim3(256), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
+            else if (fy && M <= 8)                                                               \
+                hipLaunchKernelGGL((lssm_forward_mfma_y_kernel<d, 2>), dim3((unsigned)gm),       \
+                                   dim3(256), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
+            else if (fy)                                                                         \
+                hipLaunchKernelGGL((lssm_forward_mfma_y_kernel<d, 4>), dim3((unsigned)gm),       \
+                                   dim3(256), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
+            else if (mf)                                                                         \
                 hipLaunchKernelGGL(lssm_forward_mfma_kernel<d>, dim3((unsigned)gm), dim3(256), 0, \
                                    sw, H, B, T, BL, h0, J, Z, ta, tb);                           \
             else                                                                                 \

@@ -1,2 +1,14 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -3
+python - <<'PY'
+import sys
+sys.path.insert(0,'.')
+from tools import workloads
+from bayespy_amd.device import get_runtime
+rt = get_runtime()
+for (B,D,M) in ((20000,16,8),(100000,16,8),(100000,12,8),(50000,16,16),(100000,9,4)):
+    for fp in (0, 1):
+        rt.lib.vmp_tune_set(b'lssm_fuse_project', fp)
+        r = workloads.run_lssm(B=B, T=1000, M=M, D=D, steps=8, warmup=2, cpu_baseline=False)
+        print('B=%d D=%d M=%d  fuse_project=%d: %.3f ms per iteration' % (B, D, M, fp, r['ms_per_step']), flush=True)
+PY
