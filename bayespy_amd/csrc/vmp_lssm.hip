@@ -1458,7 +1458,7 @@ __device__ inline bool stationary_block(double a, double b, bool act, double *re
 // a converged iterate are filled in, not recomputed); phase bit 0 = forward half, bit 1 = backward
 // half (each whole in one launch).  ~4 us per computed forward step, ~1 us per backward step.
 __global__ void __launch_bounds__(256)
-lssm_cov_big_kernel(cov_args a, int phase)
+lssm_cov_big_kernel(cov_args a, int phase, int t0, int t1)
 {
     constexpr int P = 16, LP = 17;
     __shared__ double U[2][P * LP];
@@ -1480,7 +1480,18 @@ lssm_cov_big_kernel(cov_args a, int phase)
         double prod = 1.0, ex = 0.0;
         int bad = 0;
         double s = act ? a.Dg0[l] : pad;
-        for (int t = 0; t < T; ++t) {
+        if (t0 > 0) {
+            // a later segment (see lssm_cov_kernel): state left by the one before; nothing to do
+            // when an earlier segment found the stationary stretch and finished the recursion
+            if (a.sums[5 * DD + 6] != 0.0) return;
+            s = act ? a.sums[4 * DD + l] : pad;
+            prod = a.sums[5 * DD + 4];
+            ex = a.sums[5 * DD + 5];
+            bad = (int)a.sums[5 * DD + 1];
+            fix_from = (int)a.sums[5 * DD + 2];
+        }
+        int tend = t1 < T ? t1 : T;
+        for (int t = t0; t < tend; ++t) {
             int cur = 0;
             const double prod0 = prod, ex0 = ex;
             U[0][q] = s;
@@ -1525,18 +1536,20 @@ lssm_cov_big_kernel(cov_args a, int phase)
                     fix_from = t;
                     s = act ? dgT - ej : pad;                           // S_T-1
                     t = tl;
+                    tend = T;                       // this launch finishes the recursion
                     continue;
                 }
                 s = snew;
             }
         }
+        if (act) a.sums[4 * DD + l] = s;                    // state for the next segment
         if (tid == 0) {
             a.sums[5 * DD + 0] = log(prod) + ex * 0.69314718055994530942;
             a.sums[5 * DD + 1] = (double)bad;
             a.sums[5 * DD + 2] = (double)fix_from;
             a.sums[5 * DD + 4] = prod;
             a.sums[5 * DD + 5] = ex;
-            a.sums[5 * DD + 6] = 1.0;
+            a.sums[5 * DD + 6] = (tend >= T) ? 1.0 : 0.0;
         }
         if (!(phase & 2)) return;
         __threadfence();
@@ -2092,9 +2105,7 @@ static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int
     a.sums = sums;
     a.shortcut = vmp_tune_get("lssm_cov_shortcut", 8);     // in ulp; 0: every step computed
     if (D > DREG) {
-        // one launch per half (no segments: a later forward segment has nothing left to do)
-        if ((phase & 1) && t0 > 0) return VMP_OK;
-        hipLaunchKernelGGL(lssm_cov_big_kernel, dim3(1), dim3(256), 0, s, a, phase);
+        hipLaunchKernelGGL(lssm_cov_big_kernel, dim3(1), dim3(256), 0, s, a, phase, t0, t1);
         VMP_HIP_CHECK(ctx, hipGetLastError());
         return VMP_OK;
     }

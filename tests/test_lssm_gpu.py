@@ -218,7 +218,8 @@ def test_segmented_covariance_recursion_is_bit_identical():
     also when the stationary stretch is found inside a segment."""
     from bayespy_amd.device import get_runtime
     lib = get_runtime().lib
-    for (M, B, T, D, seed) in [(8, 300, 1000, 4, 1), (2, 70, 600, 2, 5), (5, 200, 640, 8, 3)]:
+    for (M, B, T, D, seed) in [(8, 300, 1000, 4, 1), (2, 70, 600, 2, 5), (5, 200, 640, 8, 3),
+                               (6, 120, 640, 12, 7), (3, 64, 520, 16, 9)]:
         y, x0, c0 = _data(M, B, T, D, seed=seed)
         res = []
         try:

@@ -6,9 +6,9 @@ sys.path.insert(0,'.')
 from tools import workloads
 from bayespy_amd.device import get_runtime
 rt = get_runtime()
-for (B,D,M) in ((20000,16,8),(100000,16,8),(100000,12,8),(50000,16,16),(100000,9,4)):
-    for fp in (0, 1):
-        rt.lib.vmp_tune_set(b'lssm_fuse_project', fp)
+for (B,D,M) in ((20000,16,8),(100000,16,8),(100000,12,8)):
+    for sg in (0, 1):
+        rt.lib.vmp_tune_set(b'lssm_segments', sg)
         r = workloads.run_lssm(B=B, T=1000, M=M, D=D, steps=8, warmup=2, cpu_baseline=False)
-        print('B=%d D=%d M=%d  fuse_project=%d: %.3f ms per iteration' % (B, D, M, fp, r['ms_per_step']), flush=True)
+        print('B=%d D=%d M=%d  segments=%d: %.3f ms per iteration' % (B, D, M, sg, r['ms_per_step']), flush=True)
 PY
