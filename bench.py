@@ -55,7 +55,8 @@ def parse():
                    help='columns of the CPU-baseline sample; 0 = the whole workload when the '
                         'host has the memory for it (direct parity at the metric size)')
     p.add_argument('--config', choices=['pca', 'pca_c2', 'gmm', 'gmm_d16', 'masked', 'lssm',
-                                        'lssm_masked', 'lssm_masked_1e5', 'generic_pca', 'generic_gmm'],
+                                        'lssm_d8', 'lssm_d16', 'lssm_masked', 'lssm_masked_1e5', 'generic_pca',
+                                        'generic_gmm'],
                    default='pca',
                    help="pca = the BASELINE.json metric (default); the others print the "
                         "secondary configurations of tools/workloads.py as the JSON line")
@@ -245,6 +246,8 @@ def main():
             'gmm_d16': ('run_gmm', dict(N=4_000_000, D=16, K=32, cpu_sample_n=50_000), 100),
             'masked': ('run_masked', dict(), 50),
             'lssm': ('run_lssm', dict(), 100),
+            'lssm_d8': ('run_lssm', dict(D=8, cpu_sample_b=4000), 50),
+            'lssm_d16': ('run_lssm', dict(D=16, cpu_sample_b=2000), 50),
             'lssm_masked': ('run_lssm_masked', dict(), 50),
             'lssm_masked_1e5': ('run_lssm_masked', dict(B=100_000), 20),
             'generic_pca': ('run_generic_pca', dict(), 50),
@@ -447,6 +450,8 @@ def main():
                                             cpu_sample_n=50_000)),
                 ('masked', 'run_masked', dict(steps=50, warmup=1)),
                 ('lssm', 'run_lssm', dict(steps=150, warmup=3)),
+                ('lssm_d8', 'run_lssm', dict(D=8, steps=50, warmup=2, cpu_sample_b=4000)),
+                ('lssm_d16', 'run_lssm', dict(D=16, steps=50, warmup=2, cpu_sample_b=2000)),
                 ('lssm_masked', 'run_lssm_masked', dict(steps=50, warmup=2)),
                 ('lssm_masked_1e5', 'run_lssm_masked', dict(B=100_000, steps=20, warmup=2)),
                 ('generic_pca', 'run_generic_pca', dict(steps=50, warmup=4)),

@@ -5,7 +5,7 @@
 # of VB iterations the profiled command ran.  Every step runs under its own `timeout`.
 O=${1:-gpurun_out/prof_r06}
 shift
-WHICH=${@:-pca_gram gmm masked lssm lssm_masked lssm_masked_1e5 generic_pca generic_gmm}
+WHICH=${@:-pca_gram gmm masked lssm lssm_d8 lssm_d16 lssm_masked lssm_masked_1e5 generic_pca generic_gmm}
 mkdir -p $O
 R=$PWD
 export TMPDIR=/tmp
@@ -41,6 +41,16 @@ for w in $WHICH; do
       Ll="python $R/bench.py --config lssm --exact-steps --steps 50 --warmup 1 --no-cpu-baseline"
       prof lssm lssm_backward_ck 50 $Ll
       pmcs lssm lssm_ "LSSM B=100000 T=1000 M=8 D=4" 6 $Ls ;;
+    lssm_d8)
+      L8="python $R/bench.py --config lssm_d8 --exact-steps --steps 5 --warmup 1 --no-cpu-baseline"
+      L8l="python $R/bench.py --config lssm_d8 --exact-steps --steps 30 --warmup 1 --no-cpu-baseline"
+      prof lssm_d8 lssm_stats_wave 90 $L8l
+      pmcs lssm_d8 lssm_ "LSSM B=100000 T=1000 M=8 D=8" 6 $L8 ;;
+    lssm_d16)
+      L16="python $R/bench.py --config lssm_d16 --exact-steps --steps 5 --warmup 1 --no-cpu-baseline"
+      L16l="python $R/bench.py --config lssm_d16 --exact-steps --steps 30 --warmup 1 --no-cpu-baseline"
+      prof lssm_d16 lssm_backward_mfma 30 $L16l
+      pmcs lssm_d16 lssm_ "LSSM B=100000 T=1000 M=8 D=16" 6 $L16 ;;
     lssm_masked)
       Lm="python $R/bench.py --config lssm_masked --exact-steps --steps 5 --warmup 1 --no-cpu-baseline"
       Lml="python $R/bench.py --config lssm_masked --exact-steps --steps 50 --warmup 1 --no-cpu-baseline"

@@ -7,7 +7,8 @@ export TMPDIR=/tmp
 timeout 2400 bash tools/collect_profiles_r06.sh $O > $O/collect.log 2>&1
 mkdir -p profiles/r06
 cp $O/kernel_stats_*.txt $O/pmc_*.txt profiles/r06/ 2>/dev/null
-timeout 1500 python bench.py --full-out $O/bench_full.json > $O/bench_default.json 2> $O/bench_default.err
+timeout 900 python tools/lssm_wide_ab.py > profiles/r06/lssm_wide_ab.txt 2> $O/lssm_wide_ab.err
+timeout 1800 python bench.py --full-out $O/bench_full.json > $O/bench_default.json 2> $O/bench_default.err
 tail -c 3000 $O/bench_default.json
 timeout 2700 python -m pytest tests/ -q -m gpu > $O/pytest_gpu.log 2>&1
 tail -5 $O/pytest_gpu.log
