@@ -1612,6 +1612,249 @@ lssm_cov_big_kernel(cov_args a, int phase, int t0, int t1)
     if (tid == 0) a.sums[5 * DD + 3] = (double)bfix;       // diagnostics, backward map
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same recursion for 8 < D <= 16 by ONE wavefront on the matrix cores (default; tune key
+// lssm_cov_mfma).  A 16 x 16 (padded) matrix lives in one accumulator of v_mfma_f64_16x16x4_f64:
+// register r of lane l holds element (4 r + (l >> 4), l & 15).  Register p of a SYMMETRIC matrix is
+// then at once the B operand "rows 4p .. 4p+3" and the A operand "columns 4p .. 4p+3", so the
+// symmetric sweep operator with 4 x 4 block pivots needs no lane moves:
+//     W = M_PP^-1;  T = W M_P.;  M <- M - M_.P T;  M_.P <- M_.P W;  M_P. <- T;  M_PP <- -W
+// is three matrix instructions per pivot block (after the four, M = -S^-1), and J = S^-1 E,
+// E^T J, G = V J^T, J G are four each with E (accumulator layout) and J ("transposed" layout, read
+// back from the output array) as ready operands.  The 4 x 4 pivot block is read into scalars
+// (v_readlane) and inverted by every lane (2 x 2 block elimination, two reciprocals).
+// ~1.2 us per forward step against ~5 of the 256-thread form, ~0.2 against ~1 per backward step.
+__device__ __forceinline__ double rdlane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int P>
+__device__ __forceinline__ void sweep_block16(v4f64 &m, int l4, int l15, double &prod, double &ex, int &bad)
+{
+    const double R = m[P];
+    constexpr int c0 = 4 * P;
+    const double k00 = rdlane(R, c0), k10 = rdlane(R, 16 + c0), k11 = rdlane(R, 16 + c0 + 1);
+    const double k20 = rdlane(R, 32 + c0), k21 = rdlane(R, 32 + c0 + 1), k22 = rdlane(R, 32 + c0 + 2);
+    const double k30 = rdlane(R, 48 + c0), k31 = rdlane(R, 48 + c0 + 1), k32 = rdlane(R, 48 + c0 + 2);
+    const double k33 = rdlane(R, 48 + c0 + 3);
+    // [[A, Bt^T], [Bt, C]] with 2 x 2 blocks
+    const double detA = k00 * k11 - k10 * k10;
+    const double rA = fast_recip(detA);
+    const double a00 = k11 * rA, a10 = -k10 * rA, a11 = k00 * rA;          // A^-1
+    const double x00 = k20 * a00 + k21 * a10, x01 = k20 * a10 + k21 * a11;  // X = Bt A^-1
+    const double x10 = k30 * a00 + k31 * a10, x11 = k30 * a10 + k31 * a11;
+    const double s00 = k22 - (x00 * k20 + x01 * k21);                       // S = C - X Bt^T
+    const double s10 = k32 - (x10 * k20 + x11 * k21);
+    const double s11 = k33 - (x10 * k30 + x11 * k31);
+    const double detS = s00 * s11 - s10 * s10;
+    const double rS = fast_recip(detS);
+    const double w22 = s11 * rS, w32 = -s10 * rS, w33 = s00 * rS;          // S^-1
+    const double w20 = -(w22 * x00 + w32 * x10), w21 = -(w22 * x01 + w32 * x11);   // -S^-1 X
+    const double w30 = -(w32 * x00 + w33 * x10), w31 = -(w32 * x01 + w33 * x11);
+    const double w00 = a00 - (x00 * w20 + x10 * w30);                       // A^-1 - X^T W21
+    const double w10 = a10 - (x01 * w20 + x11 * w30);
+    const double w11 = a11 - (x01 * w21 + x11 * w31);
+    if (!(k00 > 0.0) || !(detA > 0.0) || !(s00 > 0.0) || !(detS > 0.0)) bad = 1;
+    {
+        const double pq = prod * (detA * detS);
+        ex += (double)__builtin_amdgcn_frexp_exp(pq);
+        prod = __builtin_amdgcn_frexp_mant(pq);
+    }
+    // W[a = l4][b = l15 & 3]
+    const int b = l15 & 3;
+    const double r0 = l4 == 0 ? w00 : (l4 == 1 ? w10 : (l4 == 2 ? w20 : w30));
+    const double r1 = l4 == 0 ? w10 : (l4 == 1 ? w11 : (l4 == 2 ? w21 : w31));
+    const double r2 = l4 == 0 ? w20 : (l4 == 1 ? w21 : (l4 == 2 ? w22 : w32));
+    const double r3 = l4 == 0 ? w30 : (l4 == 1 ? w31 : (l4 == 2 ? w32 : w33));
+    const double wsel = b == 0 ? r0 : (b == 1 ? r1 : (b == 2 ? r2 : r3));
+    const bool inP = (l15 >> 2) == P;
+    const double Wpad = inP ? wsel : 0.0, Wa = l15 < 4 ? wsel : 0.0;
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    const v4f64 Tt = __builtin_amdgcn_mfma_f64_16x16x4f64(Wa, R, zero, 0, 0, 0);
+    const double Tp = Tt[0];                                                // (W M_P.)[l4][l15]
+    m = __builtin_amdgcn_mfma_f64_16x16x4f64(-R, Tp, m, 0, 0, 0);           // trailing update
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = inP ? 0.0 : m[r];                    // (cancelled to rounding)
+    m = __builtin_amdgcn_mfma_f64_16x16x4f64(R, Wpad, m, 0, 0, 0);          // M_.P W
+    m[P] = inP ? -wsel : Tp;
+}
+
+__device__ __forceinline__ bool stationary16(const v4f64 &a, const v4f64 &b, double ulps)
+{
+    double mx = 0.0, df = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        mx = fmax(mx, fabs(a[r]));
+        df = fmax(df, fabs(a[r] - b[r]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    return __all(df <= ulps * 2.220446049250313e-16 * mx);
+}
+
+__global__ void __launch_bounds__(64)
+lssm_cov_mfma_kernel(cov_args a, int phase, int t0, int t1)
+{
+    const int l = threadIdx.x, l4 = l >> 4, l15 = l & 15, D = a.D, T = a.T, DD = D * D;
+    const bool colok = l15 < D;
+    auto ld_acc = [&](const double *src, double pad) {
+        v4f64 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + l4;
+            v[r] = (row < D && colok) ? src[row * D + l15] : (row == l15 ? pad : 0.0);
+        }
+        return v;
+    };
+    auto st_acc = [&](double *dst, const v4f64 &v, double sign) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + l4;
+            if (row < D && colok) dst[row * D + l15] = sign * v[r];
+        }
+    };
+    // J_t in the "transposed" layout: register q = J[l15][4 q + l4]
+    auto ld_jt = [&](const double *src) {
+        v4f64 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + l4;
+            v[q] = (colok && k < D) ? src[l15 * D + k] : 0.0;
+        }
+        return v;
+    };
+    const bool shortcut = a.shortcut != 0;
+    const double ulps = (double)a.shortcut;
+    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+    int fix_from = -1;
+    if (phase & 1) {
+        const v4f64 e = ld_acc(a.E, 0.0), dgm = ld_acc(a.Dgm, 1.0), dgT = ld_acc(a.DgT, 1.0);
+        double prod = 1.0, ex = 0.0;
+        int bad = 0;
+        v4f64 s = ld_acc(a.Dg0, 1.0);
+        if (t0 > 0) {
+            if (a.sums[5 * DD + 6] != 0.0) return;
+            s = ld_acc(a.sums + 4 * DD, 1.0);
+            prod = a.sums[5 * DD + 4];
+            ex = a.sums[5 * DD + 5];
+            bad = (int)a.sums[5 * DD + 1];
+            fix_from = (int)a.sums[5 * DD + 2];
+        }
+        int tend = t1 < T ? t1 : T;
+        for (int t = t0; t < tend; ++t) {
+            const double prod0 = prod, ex0 = ex;
+            v4f64 m = s;
+            sweep_block16<0>(m, l4, l15, prod, ex, bad);
+            if (D > 4) sweep_block16<1>(m, l4, l15, prod, ex, bad);
+            if (D > 8) sweep_block16<2>(m, l4, l15, prod, ex, bad);
+            if (D > 12) sweep_block16<3>(m, l4, l15, prod, ex, bad);
+            v4f64 sinv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sinv[r] = -m[r];
+            st_acc(a.Sinv + (int64_t)t * DD, sinv, 1.0);
+            if (t < T - 1) {
+                v4f64 j = zero, ej = zero;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) j = __builtin_amdgcn_mfma_f64_16x16x4f64(sinv[q], e[q], j, 0, 0, 0);
+                st_acc(a.J + (int64_t)t * DD, j, 1.0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ej = __builtin_amdgcn_mfma_f64_16x16x4f64(e[q], j[q], ej, 0, 0, 0);
+                v4f64 snew;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) snew[r] = ((t + 1 < T - 1) ? dgm[r] : dgT[r]) - ej[r];
+                if (shortcut && t >= 1 && (t & 7) == 0 && t + 1 < T - 1 && stationary16(snew, s, ulps)) {
+                    const int tl = T - 2;
+                    for (int tt = t + 1; tt <= tl; ++tt) {
+                        st_acc(a.Sinv + (int64_t)tt * DD, sinv, 1.0);
+                        st_acc(a.J + (int64_t)tt * DD, j, 1.0);
+                    }
+                    ex += (double)(tl - t) * ((ex - ex0) + (log2(prod) - log2(prod0)));
+                    fix_from = t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] = dgT[r] - ej[r];
+                    t = tl;
+                    tend = T;
+                    continue;
+                }
+                s = snew;
+            }
+        }
+        st_acc(a.sums + 4 * DD, s, 1.0);
+        if (l == 0) {
+            a.sums[5 * DD + 0] = log(prod) + ex * 0.69314718055994530942;
+            a.sums[5 * DD + 1] = (double)bad;
+            a.sums[5 * DD + 2] = (double)fix_from;
+            a.sums[5 * DD + 4] = prod;
+            a.sums[5 * DD + 5] = ex;
+            a.sums[5 * DD + 6] = (tend >= T) ? 1.0 : 0.0;
+        }
+        if (!(phase & 2)) return;
+        __threadfence();
+    } else {
+        fix_from = (int)a.sums[5 * DD + 2];
+    }
+    // ---- backward: V_T-1 = S_T-1^-1;  G_t = V_t+1 J_t^T (= -C_t^T);  V_t = S_t^-1 + J_t G_t ---------
+    v4f64 v = ld_acc(a.Sinv + (int64_t)(T - 1) * DD, 0.0);
+    v4f64 sv = v, sg = zero, vprev = zero, gprev = zero;
+    const v4f64 vlast = v;
+    int bfix = -1, have_prev = 0;
+    v4f64 jn = zero, sn = zero;
+    if (T >= 2) {
+        jn = ld_jt(a.J + (int64_t)(T - 2) * DD);
+        sn = ld_acc(a.Sinv + (int64_t)(T - 2) * DD, 0.0);
+    }
+    for (int t = T - 2; t >= 0; --t) {
+        const v4f64 ja = jn, si = sn;
+        if (t > 0) {
+            jn = ld_jt(a.J + (int64_t)(t - 1) * DD);
+            sn = ld_acc(a.Sinv + (int64_t)(t - 1) * DD, 0.0);
+        }
+        if (shortcut && have_prev && fix_from >= 0 && t >= fix_from && t + 1 <= T - 2 && (t & 3) == 0
+            && stationary16(v, vprev, ulps)) {
+            const double cnt = (double)(t - fix_from + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sv[r] += cnt * v[r];
+                sg[r] += cnt * gprev[r];
+            }
+            bfix = t;
+            t = fix_from;
+            if (t > 0) {
+                jn = ld_jt(a.J + (int64_t)(t - 1) * DD);
+                sn = ld_acc(a.Sinv + (int64_t)(t - 1) * DD, 0.0);
+            }
+            continue;
+        }
+        v4f64 g = zero, vn = si;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q], ja[q], g, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vn = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[q], g[q], vn, 0, 0, 0);
+        vprev = v;
+        v = vn;
+        have_prev = 1;
+        gprev = g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sv[r] += v[r];
+            sg[r] += g[r];
+        }
+    }
+    st_acc(a.sums + 0 * DD, sv, 1.0);
+    st_acc(a.sums + 1 * DD, v, 1.0);          // V_0
+    st_acc(a.sums + 2 * DD, vlast, 1.0);
+    // sum_t Cov(x_t, x_t+1) = -(sum_t G_t)^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * r + l4;
+        if (row < D && colok) a.sums[3 * DD + l15 * D + row] = -sg[r];
+    }
+    if (l == 0) a.sums[5 * DD + 3] = (double)bfix;
+}
+
 constexpr int CKS = 4;
 inline int64_t ck_bl_max(int64_t B) { return (B + 255) / 256 * 256; }
 inline int64_t ws_base_doubles(int D, int M, int64_t B)
@@ -1677,7 +1920,8 @@ __device__ inline double gamma_term(double a0, double b0, const double *g, int n
 // a copy of the state vector in LDS (<= 18 KB, loaded and stored back by the whole wavefront):
 // on the state in global memory every one of its ~50 dependent reads was an HBM round trip
 // (58 us per launch, three launches per iteration).
-__device__ __noinline__ void lssm_small_body(const lssm_small_args &A, double *st, double *tmp)
+__device__ __noinline__ void lssm_small_body(const lssm_small_args &A, double *st, double *tmp,
+                                             const double *innov_pre = nullptr)
 {
     const vmp_lssm_layout &L = A.L;
     const int D = A.D, M = A.M, T = A.T, DD = D * D;
@@ -1780,6 +2024,10 @@ __device__ __noinline__ void lssm_small_body(const lssm_small_args &A, double *s
             const double resid = sc[0] - 2.0 * syf + sff;
             double innov[DMAX];
             for (int i = 0; i < D; ++i) {
+                if (innov_pre) {
+                    innov[i] = innov_pre[i];
+                    continue;
+                }
                 double s = Snn[i * D + i];
                 for (int j = 0; j < D; ++j) s -= 2.0 * Am[i * D + j] * Snp[i * D + j];
                 for (int j = 0; j < D; ++j)
@@ -1864,11 +2112,115 @@ __device__ void lssm_op_a_rows(const lssm_small_args &A, double *st, double *scr
     if (bad) st[L.off_scal + 2] = (double)VMP_ERR_NOT_POSDEF;
 }
 
+// The other heavy operations of the replicated nodes dealt over the wavefront (D > 8), element by
+// element the arithmetic of lssm_small_body in the same order (bit-identical to the one-thread form):
+// C.update() -- Gauss-Jordan with one row per lane --, the blocks of the chain precision, and the
+// innovation sums of tau / nu / the bound (D^3 products each, three times per iteration).
+__device__ void lssm_op_c_par(const lssm_small_args &A, double *st, double *tmp, int tid)
+{
+    const vmp_lssm_layout &L = A.L;
+    const int D = A.D, M = A.M, DD = D * D;
+    double *tau = st + L.off_tau, *gam = st + L.off_gamma;
+    double *Cm = st + L.off_Cm, *CovC = st + L.off_CovC, *SCC = st + L.off_SCC;
+    const double *S = st + L.off_S, *Sxx = S, *Syx = S + 5 * DD + D;
+    double *sc = st + L.off_scal;
+    for (int e = tid; e < DD; e += 64) tmp[e] = tau[2] * Sxx[e];
+    __syncthreads();
+    if (tid < D) tmp[tid * D + tid] += gam[2 * D + tid];
+    __syncthreads();
+    // serial_spd_inverse, row i on lane i
+    double ld = 0.0;
+    int bad = 0;
+    for (int p = 0; p < D; ++p) {
+        const double piv = tmp[p * D + p];
+        if (!(piv > 0.0)) bad = 1;
+        ld += log(piv);
+        const double d = 1.0 / piv;
+        __syncthreads();
+        if (tid == p) {
+            for (int j = 0; j < D; ++j) tmp[p * D + j] *= d;
+            tmp[p * D + p] = d;
+        }
+        __syncthreads();
+        if (tid < D && tid != p) {
+            const int i = tid;
+            const double c = tmp[i * D + p];
+            for (int j = 0; j < D; ++j) tmp[i * D + j] -= c * tmp[p * D + j];
+            tmp[i * D + p] = -c * d;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < DD; e += 64) CovC[e] = tmp[e];
+    if (tid == 0) {
+        sc[4] = -ld;
+        if (bad) sc[2] = (double)VMP_ERR_NOT_POSDEF;
+    }
+    __syncthreads();
+    for (int e = tid; e < M * D; e += 64) {
+        const int m = e / D, i = e % D;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += CovC[i * D + k] * tau[2] * Syx[m * D + k];
+        Cm[m * D + i] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < DD; e += 64) {
+        const int i = e / D, j = e % D;
+        double s = M * CovC[e];
+        for (int m = 0; m < M; ++m) s += Cm[m * D + i] * Cm[m * D + j];
+        SCC[e] = s;
+    }
+}
+
+__device__ void lssm_op_xprep_par(const lssm_small_args &A, double *st, int tid)
+{
+    const vmp_lssm_layout &L = A.L;
+    const int D = A.D, T = A.T, DD = D * D;
+    double *tau = st + L.off_tau, *nu = st + L.off_nu;
+    const double *SCC = st + L.off_SCC, *Am = st + L.off_Am, *AA = st + L.off_AA;
+    double *Dg0 = st + L.off_Dg, *Dgm = Dg0 + DD, *DgT = Dg0 + 2 * DD, *E = Dg0 + 3 * DD;
+    double *h0 = st + L.off_h0;
+    const double *Lam0 = st + L.off_Lam0, *mu0 = st + L.off_mu0;
+    for (int e = tid; e < DD; e += 64) {
+        const int j = e / D, k = e % D;
+        double anua = 0.0;
+        for (int i = 0; i < D; ++i) anua += nu[2 * D + i] * AA[(i * D + j) * D + k];
+        const double obs = tau[2] * SCC[e];
+        const double dn = (j == k) ? nu[2 * D + j] : 0.0;
+        Dg0[e] = obs + Lam0[e] + (T > 1 ? anua : 0.0);
+        Dgm[e] = obs + dn + anua;
+        DgT[e] = obs + (T > 1 ? dn : Lam0[e]);
+        E[e] = -nu[2 * D + k] * Am[k * D + j];
+    }
+    if (tid < D) {
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += Lam0[tid * D + k] * mu0[k];
+        h0[tid] = s;
+    }
+    if (tid == 0) st[L.off_scal + 3] = tau[2];
+}
+
+__device__ void lssm_innov_par(const lssm_small_args &A, const double *st, double *innov, int tid)
+{
+    const vmp_lssm_layout &L = A.L;
+    const int D = A.D, DD = D * D;
+    const double *Am = st + L.off_Am, *AA = st + L.off_AA;
+    const double *S = st + L.off_S, *Spp = S + DD, *Snn = S + 2 * DD, *Snp = S + 3 * DD;
+    if (tid < D) {
+        const int i = tid;
+        double s = Snn[i * D + i];
+        for (int j = 0; j < D; ++j) s -= 2.0 * Am[i * D + j] * Snp[i * D + j];
+        for (int j = 0; j < D; ++j)
+            for (int k = 0; k < D; ++k) s += AA[(i * D + j) * D + k] * Spp[j * D + k];
+        innov[i] = s;
+    }
+}
+
 __global__ void __launch_bounds__(64)
 lssm_small_kernel(lssm_small_args A, double *__restrict__ gst)
 {
     extern __shared__ double st_lds[];
     __shared__ double tmp[DMAX * DMAX];
+    __shared__ double innov_s[DMAX];
     const int total = (int)A.L.total;
     for (int e = threadIdx.x; e < total; e += 64) st_lds[e] = gst[e];
     __syncthreads();
@@ -1878,13 +2230,25 @@ lssm_small_kernel(lssm_small_args A, double *__restrict__ gst)
         // big-state path: operation by operation, A.update() dealt over the rows (its scratch,
         // D matrices of D x D, lies behind the state copy in the dynamic LDS)
         for (int oi = 0; oi < A.nops; ++oi) {
-            if (A.ops[oi] == VMP_LSSM_OP_A) {
+            const int op = A.ops[oi];
+            if (op == VMP_LSSM_OP_A) {
                 lssm_op_a_rows(A, st_lds, st_lds + (total + 7) / 8 * 8, threadIdx.x);
-            } else if (threadIdx.x == 0) {
-                lssm_small_args one = A;
-                one.nops = 1;
-                one.ops[0] = A.ops[oi];
-                lssm_small_body(one, st_lds, tmp);
+            } else if (op == VMP_LSSM_OP_C) {
+                lssm_op_c_par(A, st_lds, tmp, threadIdx.x);
+            } else if (op == VMP_LSSM_OP_XPREP) {
+                lssm_op_xprep_par(A, st_lds, threadIdx.x);
+            } else {
+                const bool inn = op == VMP_LSSM_OP_TAU || op == VMP_LSSM_OP_NU || op == VMP_LSSM_OP_ELBO;
+                if (inn) {
+                    lssm_innov_par(A, st_lds, innov_s, threadIdx.x);
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) {
+                    lssm_small_args one = A;
+                    one.nops = 1;
+                    one.ops[0] = op;
+                    lssm_small_body(one, st_lds, tmp, inn ? innov_s : nullptr);
+                }
             }
             __syncthreads();
         }
@@ -2105,7 +2469,10 @@ static int32_t launch_cov(vmp_ctx *ctx, hipStream_t s, int phase, int32_t T, int
     a.sums = sums;
     a.shortcut = vmp_tune_get("lssm_cov_shortcut", 8);     // in ulp; 0: every step computed
     if (D > DREG) {
-        hipLaunchKernelGGL(lssm_cov_big_kernel, dim3(1), dim3(256), 0, s, a, phase, t0, t1);
+        if (vmp_tune_get("lssm_cov_mfma", 1) != 0)
+            hipLaunchKernelGGL(lssm_cov_mfma_kernel, dim3(1), dim3(64), 0, s, a, phase, t0, t1);
+        else
+            hipLaunchKernelGGL(lssm_cov_big_kernel, dim3(1), dim3(256), 0, s, a, phase, t0, t1);
         VMP_HIP_CHECK(ctx, hipGetLastError());
         return VMP_OK;
     }

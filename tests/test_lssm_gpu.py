@@ -338,10 +338,13 @@ def _cov_recursion_numpy(Dg0, Dgm, DgT, E, T):
     return Sinv, J, sv, V, sc, ld
 
 
-@pytest.mark.parametrize('D,T', [(12, 700), (16, 500), (9, 400)])
-def test_big_state_covariance_recursion_fills_in_its_stationary_stretch(D, T):
-    """8 < D <= 16, through the C ABI: the 256-thread covariance recursion applies the rule of the
-    one-wavefront kernel (iterates within 8 ulp: the interior steps behind are filled in).  On a
+@pytest.mark.parametrize('form', [1, 0])
+@pytest.mark.parametrize('D,T', [(12, 700), (16, 500), (9, 400), (13, 90)])
+def test_big_state_covariance_recursion_fills_in_its_stationary_stretch(D, T, form):
+    """8 < D <= 16, through the C ABI, both forms of the covariance recursion (tune key lssm_cov_mfma:
+    1 = one wavefront on the matrix cores, block sweeps with 4 x 4 pivots; 0 = 256 threads, scalar
+    Gauss-Jordan through LDS): each applies the rule of the D <= 8 kernel (iterates within 8 ulp: the
+    interior steps behind are filled in).  On a
     strongly contracting map the shortcut is taken (diagnostics); S^-1, J, the sums of V and C and
     log|Phi| agree with the recursion that computes every step (tune key lssm_cov_shortcut = 0) and
     with a NumPy restatement."""
@@ -362,6 +365,7 @@ def test_big_state_covariance_recursion_fills_in_its_stationary_stretch(D, T):
     ref = _cov_recursion_numpy(Dg0, Dgm, DgT, E, T)
     out = []
     try:
+        rt.lib.vmp_tune_set(b'lssm_cov_mfma', form)
         for sc in (8, 0):
             rt.lib.vmp_tune_set(b'lssm_cov_shortcut', sc)
             Sinv = torch.zeros(T, D, D, dtype=torch.float64, device=dev)
@@ -382,6 +386,7 @@ def test_big_state_covariance_recursion_fills_in_its_stationary_stretch(D, T):
                         sm[5 * D * D]))
     finally:
         rt.lib.vmp_tune_set(b'lssm_cov_shortcut', 8)
+        rt.lib.vmp_tune_set(b'lssm_cov_mfma', 1)
     for o in out:
         for got, want in zip(o, ref):
             np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
