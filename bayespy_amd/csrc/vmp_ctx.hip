@@ -8,12 +8,34 @@ static char g_err[512] = "no context";
 // ---- measurement knobs ---------------------------------------------------------------------
 namespace {
 struct tune_entry { char key[32]; int value; };
-tune_entry g_tune[32];
+tune_entry g_tune[128];
 int g_ntune = 0;
+bool g_tune_env = false;
 }  // namespace
+
+extern "C" char **environ;
+
+// VMP_TUNE_<key>=<int> in the environment presets a key (read once, before the first lookup)
+static void tune_from_env()
+{
+    g_tune_env = true;
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "VMP_TUNE_", 9) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        const size_t len = (size_t)(eq - (*e + 9));
+        if (len == 0 || len >= sizeof(g_tune[0].key) || g_ntune >= (int)(sizeof(g_tune) / sizeof(g_tune[0])))
+            continue;
+        memcpy(g_tune[g_ntune].key, *e + 9, len);
+        g_tune[g_ntune].key[len] = 0;
+        g_tune[g_ntune].value = atoi(eq + 1);
+        g_ntune += 1;
+    }
+}
 
 int vmp_tune_get(const char *key, int dflt)
 {
+    if (!g_tune_env) tune_from_env();
     for (int i = 0; i < g_ntune; ++i)
         if (strcmp(g_tune[i].key, key) == 0) return g_tune[i].value;
     return dflt;
@@ -24,6 +46,7 @@ extern "C" {
 int32_t vmp_tune_set(const char *key, int32_t value)
 {
     if (!key || strlen(key) >= sizeof(g_tune[0].key)) return VMP_ERR_INVALID;
+    if (!g_tune_env) tune_from_env();
     for (int i = 0; i < g_ntune; ++i)
         if (strcmp(g_tune[i].key, key) == 0) {
             g_tune[i].value = value;

@@ -538,16 +538,20 @@ struct EwiseArgs {
 };
 
 // the postfix program of a fused formula at the operand offsets of one element
-template <class EA>
-__device__ inline double ewise_program(const EA &a, const int64_t *off)
+// (UNI: the program comes from LDS -- vector registers -- although it is the same for all lanes: the
+// dispatch is kept on the scalar unit by reading the words back through the first lane)
+template <bool UNI, class EA, class LD>
+__device__ inline double ewise_program_impl(const EA &a, const int64_t *off, LD ld)
 {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #define PUSH(v) do { s3 = s2; s2 = s1; s1 = s0; s0 = (v); } while (0)
 #define BIN(expr) do { const double y = s0, x = s1; s0 = (expr); s1 = s2; s2 = s3; } while (0)
-    for (int p = 0; p < a.nops; ++p) {
-        const int op = a.ops[p] & 0xff, arg = a.ops[p] >> 8;
+    const int nops = UNI ? __builtin_amdgcn_readfirstlane(a.nops) : a.nops;
+    for (int p = 0; p < nops; ++p) {
+        const int word = UNI ? __builtin_amdgcn_readfirstlane(a.ops[p]) : a.ops[p];
+        const int op = word & 0xff, arg = word >> 8;
         switch (op) {
-        case VMP_OP_IN:      PUSH(a.in[arg][off[arg]]); break;
+        case VMP_OP_IN:      PUSH(ld(arg, off[arg])); break;
         case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
         case VMP_OP_ADD:     BIN(x + y); break;
         case VMP_OP_SUB:     BIN(x - y); break;
@@ -573,6 +577,12 @@ __device__ inline double ewise_program(const EA &a, const int64_t *off)
 #undef PUSH
 #undef BIN
     return s0;
+}
+
+template <class EA>
+__device__ inline double ewise_program(const EA &a, const int64_t *off)
+{
+    return ewise_program_impl<false>(a, off, [&](int arg, int64_t o) { return a.in[arg][o]; });
 }
 
 // one output element of a fused formula: flat index -> operand offsets, then the postfix program
@@ -1181,6 +1191,15 @@ struct alignas(16) SmallOp {
         Iter it;
         SmallSpd spd;
     };
+    // filled in by the flush (queue_place): where in the interpreter's LDS arena operand i / the
+    // result live (element offsets; -1: in global memory only)
+    int32_t lin[MAXIN];
+    int32_t lout, pad2;
+};
+// an array from OUTSIDE the launch that its records read: copied into the arena before the first record
+struct SmallPre {
+    const double *src;
+    int32_t off, n;
 };
 constexpr int QNT = 512;                         // threads of the interpreter (256 VGPRs each: no spills)
 constexpr int QUEUE_CAP = 128;                   // records per launch
@@ -1191,6 +1210,9 @@ constexpr int64_t SMALL_SPD_BATCH = 4;
 
 constexpr int QUEUE_SLOTS = 16;                  // staging buffers in rotation (eager flushes)
 constexpr int ARENA_RECORDS = 16384;             // records of flushes recorded into HIP graphs
+constexpr int QLDS = 14336;                      // doubles of the interpreter's LDS arena (112 KB)
+constexpr int PRE_CAP = 256;                     // arrays copied in per launch
+constexpr int ARENA_PRE = 2 * ARENA_RECORDS;
 
 struct small_queue {
     int open;
@@ -1208,24 +1230,22 @@ struct small_queue {
     SmallOp *arena_host, *arena_dev;
     int arena_used, arena_committed;
     int64_t launches, ops;
+    // the tables of arrays copied into the LDS arena, one per flush, kept like the records
+    SmallPre *pre_host, *pre_dev, *pre_arena_host, *pre_arena_dev;
+    int pre_arena_used, pre_arena_committed;
+    int64_t cached_in, global_in;      // operands of the records read from the arena / from memory
 };
 
-// The records of a launch are CONSTANT memory for the interpreter (written before the launch,
-// never during it): read through the constant address space they arrive by scalar loads through
-// the scalar cache, like kernel arguments -- the program of a formula is walked without a vector
-// memory round trip per step.
-#define VMP_CONST_AS __attribute__((address_space(4)))
+// The records of a launch are staged through LDS, RC at a time, by the whole workgroup (one memory
+// latency per RC records).  Read one field at a time where the program flow needs it -- as scalar
+// loads from the constant address space, the form of round 5 -- every record cost ~18 dependent cache
+// misses, 3.8 us per record in a recorded sweep (profiles/r06/queue_lds_ab.txt), more than the graph
+// node it replaced.  Values that steer the control flow come back through the first lane.
+#define VMP_CONST_AS __attribute__((address_space(3)))
 typedef const VMP_CONST_AS SmallOp CSmallOp;
 
-// (a pointer handed to a function arrives in vector registers: back into scalar ones, or the loads
-// through it are vector loads again)
-__device__ inline CSmallOp *uniform_record(CSmallOp *op)
-{
-    const uint64_t p = (uint64_t)op;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-    return (CSmallOp *)(((uint64_t)hi << 32) | lo);
-}
+__device__ inline CSmallOp *uniform_record(CSmallOp *op) { return op; }
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // one element of a queued formula: everything fits 32 bits here (total <= SMALL_EW_MAX), the
 // arithmetic is ewise_element's
@@ -1255,12 +1275,45 @@ __device__ inline double wave_sum(double v)
 
 // the three kinds of records, each a function of its own (their register needs differ widely; as
 // one body the interpreter spilled)
-__device__ __noinline__ void small_ewise(CSmallOp *op, int tid)
+// Operand i of a record: in the LDS arena when the flush placed it there (lin >= 0), else where the
+// record says.  Both are reached through one generic pointer (a flat access resolves the aperture).
+__device__ inline const double *small_operand(CSmallOp *op, const double *glob, int i, const double *lds)
+{
+    const int32_t li = op->lin[i];
+    return li >= 0 ? lds + li : glob;
+}
+
+__device__ __noinline__ void small_ewise(CSmallOp *op, int tid, double *lds)
 {
     op = uniform_record(op);
-    const uint32_t total = (uint32_t)op->ew.total;
+    const uint32_t total = (uint32_t)uni((int)op->ew.total);
     double *out = op->out;
-    for (uint32_t e = tid; e < total; e += QNT) out[e] = ewise_element32(op->ew, e);
+    const int nin = uni(op->ew.nin), ndim = uni(op->ew.ndim);
+    const double *in0 = small_operand(op, op->ew.in[0], 0, lds), *in1 = small_operand(op, op->ew.in[1], 1, lds);
+    const double *in2 = small_operand(op, op->ew.in[2], 2, lds), *in3 = small_operand(op, op->ew.in[3], 3, lds);
+    const double *in4 = small_operand(op, op->ew.in[4], 4, lds), *in5 = small_operand(op, op->ew.in[5], 5, lds);
+    static_assert(MAXIN == 6, "operand selection below is written for six operands");
+    const int32_t lout = op->lout;
+    auto ld = [&](int arg, int64_t o) {
+        const double *p = arg == 0 ? in0 : (arg == 1 ? in1 : (arg == 2 ? in2 : (arg == 3 ? in3 : (arg == 4 ? in4 : in5))));
+        return p[o];
+    };
+    for (uint32_t e = tid; e < total; e += QNT) {
+        int64_t off[MAXIN];
+        for (int i = 0; i < nin; ++i) off[i] = 0;
+        uint32_t t = e;
+        for (int d = ndim - 1; d >= 1; --d) {
+            const uint32_t sz = (uint32_t)op->ew.shape[d];
+            const uint32_t q = t / sz, c = t - q * sz;
+            t = q;
+            for (int i = 0; i < nin; ++i) off[i] += (int64_t)c * op->ew.stride[i][d];
+        }
+        if (ndim >= 1)
+            for (int i = 0; i < nin; ++i) off[i] += (int64_t)t * op->ew.stride[i][0];
+        const double v = ewise_program_impl<true>(op->ew, off, ld);
+        out[e] = v;
+        if (lout >= 0) lds[lout + e] = v;
+    }
 }
 
 __device__ __noinline__ void small_spd(CSmallOp *op, double *M, int *bad, int tid)
@@ -1326,15 +1379,19 @@ __device__ inline double small_sum_lane(const VMP_CONST_AS Iter &it, const doubl
 }
 
 template <int NIN>
-__device__ inline void small_sum_body(CSmallOp *op, double *red, int tid)
+__device__ inline void small_sum_body(CSmallOp *op, double *red, int tid, double *lds)
 {
     const VMP_CONST_AS Iter &it = op->it;
     double *out = op->out;
     const double scale = op->scale;
     const int64_t nkeep = it.nkeep, nred = it.nred;
+    const int32_t lout = op->lout;
     const double *in[NIN];
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) in[i] = it.in[i < it.nin ? i : 0];
+    for (int i = 0; i < NIN; ++i) {
+        const int k = i < it.nin ? i : 0;
+        in[i] = small_operand(op, it.in[k], k, lds);
+    }
     if (nkeep * 64 < QNT && nred > 1024) {
         // a few long sums: the workgroup per output, wavefront sums combined in a fixed order
         const int lane = tid & 63, wave = tid >> 6;
@@ -1349,6 +1406,7 @@ __device__ inline void small_sum_body(CSmallOp *op, double *red, int tid)
                 double t = 0.0;
                 for (int w = 0; w < QNT / 64; ++w) t += red[w];
                 out[ooff] = scale * t;
+                if (lout >= 0) lds[lout + ooff] = scale * t;
             }
             __syncthreads();
         }
@@ -1364,35 +1422,176 @@ __device__ inline void small_sum_body(CSmallOp *op, double *red, int tid)
         decode_keep(it, act ? o : 0, base, ooff);
         double acc = small_sum_lane<NIN>(it, in, base, gl, G, nred);
         for (int st = G >> 1; st > 0; st >>= 1) acc += __shfl_xor(acc, st, 64);
-        if (act && gl == 0) out[ooff] = scale * acc;
+        if (act && gl == 0) {
+            out[ooff] = scale * acc;
+            if (lout >= 0) lds[lout + ooff] = scale * acc;
+        }
     }
 }
 
-__device__ __noinline__ void small_sum(CSmallOp *op, double *red, int tid)
+__device__ __noinline__ void small_sum(CSmallOp *op, double *red, int tid, double *lds)
 {
     op = uniform_record(op);
-    if (op->it.nin <= 2) small_sum_body<2>(op, red, tid);
-    else small_sum_body<MAXIN>(op, red, tid);
+    if (op->it.nin <= 2) small_sum_body<2>(op, red, tid, lds);
+    else small_sum_body<MAXIN>(op, red, tid, lds);
 }
 
+// The interpreter keeps the small arrays of its launch in LDS: arrays from outside that its records
+// read are copied in first (all of them in flight together: one memory latency for the launch), a
+// record's result is written to memory AND to the arena, and a record reads whatever an earlier
+// record of the launch produced -- or what was copied in -- from the arena.  A record then costs a
+// barrier and LDS latency instead of a dependent round trip through memory (2-3 us, which was also
+// what a node of a HIP graph costs: the reason the queue did not pay inside recorded sweeps).
 __global__ void __launch_bounds__(QNT)
-small_ops_kernel(const SmallOp *__restrict__ ops, int n)
+small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restrict__ pre, int npre)
 {
+    extern __shared__ double qlds[];
     __shared__ double red[QNT / 64];
     __shared__ double M[SMALL_SPD_MAXN * SPD_LD];
     __shared__ int bad;
-    CSmallOp *rec = (CSmallOp *)ops;
+    constexpr int RC = 8, RW = (int)(sizeof(SmallOp) / sizeof(double));
+    __shared__ double recbuf[RC * RW];
     const int tid = threadIdx.x;
+    {
+        // a wavefront per array, eight arrays in flight per round
+        const int w = tid >> 6, l = tid & 63;
+        for (int p0 = 0; p0 < npre; p0 += QNT / 64) {
+            const int p = p0 + w;
+            if (p < npre) {
+                const double *src = pre[p].src;
+                const int off = pre[p].off, cnt = pre[p].n;
+                for (int e = l; e < cnt; e += 64) qlds[off + e] = src[e];
+            }
+        }
+        __syncthreads();
+    }
+    const double *words = reinterpret_cast<const double *>(ops);
     for (int i = 0; i < n; ++i) {
-        CSmallOp *op = rec + i;
-        const int kind = op->kind;
-        if (kind == SMALL_EWISE) small_ewise(op, tid);
+        if (i % RC == 0) {
+            const int cnt = (n - i < RC ? n - i : RC) * RW;
+            for (int e = tid; e < cnt; e += QNT) recbuf[e] = words[(int64_t)i * RW + e];
+            __syncthreads();
+        }
+        CSmallOp *op = (CSmallOp *)(recbuf + (i % RC) * RW);          // (C cast: generic -> LDS address space)
+        const int kind = uni(op->kind);
+        if (kind == SMALL_EWISE) small_ewise(op, tid, qlds);
         else if (kind == SMALL_SPD) small_spd(op, M, &bad, tid);
-        else small_sum(op, red, tid);
+        else small_sum(op, red, tid, qlds);
         // what this record wrote is visible to the next one (one workgroup, one CU)
         __threadfence_block();
         __syncthreads();
     }
+}
+
+// ---- placement of a launch's small arrays in the interpreter's LDS arena (host, at the flush) ----
+struct ByteRange {
+    const char *lo, *hi;           // [lo, hi)
+    int32_t off;                   // arena offset of lo (elements), or -1: not in the arena
+};
+
+// elements an operand touches: [lo, hi] relative to its base pointer
+inline void span_of(int nd, const int64_t *size, const int64_t *stride, int64_t &lo, int64_t &hi)
+{
+    for (int d = 0; d < nd; ++d) {
+        const int64_t ext = (size[d] - 1) * stride[d];
+        if (ext < 0) lo += ext; else hi += ext;
+    }
+}
+
+// Fills lin / lout of the n records and the table of arrays to copy in.  Rules: an operand that lies
+// inside the result of an earlier record of the launch is read from that result's place in the arena
+// (from memory if the result has no place there: the barrier + fence between records makes the write
+// visible); an operand that overlaps no earlier result is an array from outside -- copied in when it
+// is small and there is room; results of inverses (SMALL_SPD) are never placed.
+inline void queue_place(SmallOp *h, int n, SmallPre *pre, int *npre_out, int64_t *cached, int64_t *uncached)
+{
+    ByteRange outs[2 * QUEUE_CAP + 8];      // results of the records so far (inverses: two each)
+    ByteRange ext[PRE_CAP];
+    int nout = 0, next = 0, used = 0;
+    const int64_t PRE_MAX = 2048;
+    auto alloc = [&](int64_t cnt) -> int32_t {
+        const int64_t c = (cnt + 1) & ~(int64_t)1;       // 16-byte granules
+        if (used + c > QLDS) return -1;
+        const int32_t o = used;
+        used += (int)c;
+        return o;
+    };
+    for (int i = 0; i < n; ++i) {
+        SmallOp &op = h[i];
+        for (int k = 0; k < MAXIN; ++k) op.lin[k] = -1;
+        op.lout = -1;
+        op.pad2 = 0;
+        if (op.kind != SMALL_SPD) {
+            const int nin = op.kind == SMALL_EWISE ? op.ew.nin : op.it.nin;
+            for (int k = 0; k < nin; ++k) {
+                const double *base = op.kind == SMALL_EWISE ? op.ew.in[k] : op.it.in[k];
+                int64_t lo = 0, hi = 0;
+                if (op.kind == SMALL_EWISE) {
+                    span_of(op.ew.ndim, op.ew.shape, op.ew.stride[k], lo, hi);
+                } else {
+                    span_of(op.it.nk, op.it.ksize, op.it.kstride[k], lo, hi);
+                    span_of(op.it.nr, op.it.rsize, op.it.rstride[k], lo, hi);
+                }
+                const char *blo = reinterpret_cast<const char *>(base + lo);
+                const char *bhi = reinterpret_cast<const char *>(base + hi + 1);
+                bool overlaps = false;
+                int32_t place = -1;
+                for (int j = nout - 1; j >= 0; --j) {
+                    if (blo < outs[j].hi && outs[j].lo < bhi) {
+                        overlaps = true;
+                        if (outs[j].off >= 0 && outs[j].lo <= blo && bhi <= outs[j].hi)
+                            place = outs[j].off + (int32_t)((reinterpret_cast<const char *>(base) - outs[j].lo) / 8);
+                        break;                        // the latest writer decides
+                    }
+                }
+                if (!overlaps) {
+                    for (int j = 0; j < next; ++j)
+                        if (ext[j].lo <= blo && bhi <= ext[j].hi) {
+                            place = ext[j].off + (int32_t)((reinterpret_cast<const char *>(base) - ext[j].lo) / 8);
+                            break;
+                        }
+                    const int64_t cnt = hi - lo + 1;
+                    if (place < 0 && cnt <= PRE_MAX && next < PRE_CAP) {
+                        const int32_t o = alloc(cnt);
+                        if (o >= 0) {
+                            ext[next] = ByteRange{blo, bhi, o};
+                            pre[next] = SmallPre{base + lo, o, (int32_t)cnt};
+                            ++next;
+                            place = o + (int32_t)(-lo);
+                        }
+                    }
+                }
+                op.lin[k] = place;
+                if (place >= 0) *cached += 1; else *uncached += 1;
+            }
+        }
+        // the record's result(s)
+        if (op.kind == SMALL_SPD) {
+            const int64_t nn = (int64_t)op.spd.n * op.spd.n * op.spd.batch;
+            if (op.spd.Ainv)
+                outs[nout++] = ByteRange{reinterpret_cast<const char *>(op.spd.Ainv),
+                                         reinterpret_cast<const char *>(op.spd.Ainv + nn), -1};
+            if (op.spd.logdet)
+                outs[nout++] = ByteRange{reinterpret_cast<const char *>(op.spd.logdet),
+                                         reinterpret_cast<const char *>(op.spd.logdet + op.spd.batch), -1};
+        } else {
+            int64_t cnt;
+            if (op.kind == SMALL_EWISE) {
+                cnt = op.ew.total;
+            } else {
+                int64_t lo = 0, hi = 0;
+                span_of(op.it.nk, op.it.ksize, op.it.okstride, lo, hi);
+                cnt = lo < 0 ? -1 : hi + 1;
+            }
+            int32_t o = -1;
+            if (cnt > 0 && cnt <= PRE_MAX) o = alloc(cnt);
+            op.lout = o;
+            const int64_t bytes = (cnt > 0 ? cnt : 0) * 8;
+            outs[nout++] = ByteRange{reinterpret_cast<const char *>(op.out),
+                                     reinterpret_cast<const char *>(op.out) + bytes, o};
+        }
+    }
+    *npre_out = next;
 }
 
 inline small_queue *queue_of(vmp_ctx *ctx) { return reinterpret_cast<small_queue *>(ctx->queue); }
@@ -1438,6 +1637,10 @@ int32_t destroy_small_queue(vmp_ctx *ctx)
     if (q->dev) (void)hipFree(q->dev);
     if (q->arena_host) (void)hipHostFree(q->arena_host);
     if (q->arena_dev) (void)hipFree(q->arena_dev);
+    if (q->pre_host) (void)hipHostFree(q->pre_host);
+    if (q->pre_dev) (void)hipFree(q->pre_dev);
+    if (q->pre_arena_host) (void)hipHostFree(q->pre_arena_host);
+    if (q->pre_arena_dev) (void)hipFree(q->pre_arena_dev);
     delete q;
     ctx->queue = nullptr;
     return VMP_OK;
@@ -1463,8 +1666,19 @@ int32_t vmp_queue_begin(vmp_ctx *ctx)
         if (e == hipSuccess)
             e = hipHostMalloc(reinterpret_cast<void **>(&q->arena_host), arena, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&q->arena_dev), arena);
+        const size_t pring = (size_t)QUEUE_SLOTS * PRE_CAP * sizeof(SmallPre);
+        const size_t parena = (size_t)ARENA_PRE * sizeof(SmallPre);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&q->pre_host), pring, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&q->pre_dev), pring);
+        if (e == hipSuccess)
+            e = hipHostMalloc(reinterpret_cast<void **>(&q->pre_arena_host), parena, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&q->pre_arena_dev), parena);
         for (int i = 0; i < QUEUE_SLOTS && e == hipSuccess; ++i)
             e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
+        // (the interpreter's LDS arena is beyond the 64 KB a kernel gets without asking; per device)
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(small_ops_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, QLDS * (int)sizeof(double));
 
         ctx->queue = q;
         if (e != hipSuccess) {
@@ -1510,20 +1724,37 @@ int32_t vmp_queue_flush(vmp_ctx *ctx)
     }
     q->n = 0;
     SmallOp *host = q->host + (size_t)q->cur * QUEUE_CAP, *dev = q->dev + (size_t)q->cur * QUEUE_CAP;
+    SmallPre *phost = q->pre_host + (size_t)q->cur * PRE_CAP, *pdev = q->pre_dev + (size_t)q->cur * PRE_CAP;
+    int npre = 0;
+    if (vmp_tune_get("small_queue_lds", 1) != 0) {
+        queue_place(host, n, phost, &npre, &q->cached_in, &q->global_in);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < MAXIN; ++k) host[i].lin[k] = -1;
+            host[i].lout = -1;
+        }
+    }
     const bool rec = stream_records(ctx);
     if (rec) {
         // replayed with the graph: the records move into the arena (queue_slot made sure they
         // fit); vmp_queue_commit copies them to the device once, after the recording
-        VMP_REQUIRE(ctx, q->arena_used + n <= ARENA_RECORDS, VMP_ERR_UNSUPPORTED,
-                    "arena of recorded small operations exhausted");
+        VMP_REQUIRE(ctx, q->arena_used + n <= ARENA_RECORDS && q->pre_arena_used + npre <= ARENA_PRE,
+                    VMP_ERR_UNSUPPORTED, "arena of recorded small operations exhausted");
         memcpy(q->arena_host + q->arena_used, host, (size_t)n * sizeof(SmallOp));
         dev = q->arena_dev + q->arena_used;
         q->arena_used += n;
+        memcpy(q->pre_arena_host + q->pre_arena_used, phost, (size_t)npre * sizeof(SmallPre));
+        pdev = q->pre_arena_dev + q->pre_arena_used;
+        q->pre_arena_used += npre;
     } else {
         VMP_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, (size_t)n * sizeof(SmallOp),
                                           hipMemcpyHostToDevice, ctx->stream));
+        if (npre > 0)
+            VMP_HIP_CHECK(ctx, hipMemcpyAsync(pdev, phost, (size_t)npre * sizeof(SmallPre),
+                                              hipMemcpyHostToDevice, ctx->stream));
     }
-    hipLaunchKernelGGL(small_ops_kernel, dim3(1), dim3(QNT), 0, ctx->stream, dev, n);
+    hipLaunchKernelGGL(small_ops_kernel, dim3(1), dim3(QNT), QLDS * sizeof(double), ctx->stream, dev, n,
+                       pdev, npre);
     VMP_HIP_CHECK(ctx, hipGetLastError());
     q->launches += 1;
     q->ops += n;
@@ -1545,7 +1776,7 @@ int32_t vmp_queue_commit(vmp_ctx *ctx)
 {
     VMP_REQUIRE(ctx, ctx, VMP_ERR_INVALID, "null context");
     small_queue *q = queue_of(ctx);
-    if (!q || q->arena_committed == q->arena_used) return VMP_OK;
+    if (!q || (q->arena_committed == q->arena_used && q->pre_arena_committed == q->pre_arena_used)) return VMP_OK;
     VMP_REQUIRE(ctx, !stream_records(ctx), VMP_ERR_INVALID,
                 "vmp_queue_commit belongs after the recording, not into it");
     VMP_HIP_CHECK(ctx, hipMemcpy(q->arena_dev + q->arena_committed,
@@ -1553,6 +1784,13 @@ int32_t vmp_queue_commit(vmp_ctx *ctx)
                                  (size_t)(q->arena_used - q->arena_committed) * sizeof(SmallOp),
                                  hipMemcpyHostToDevice));
     q->arena_committed = q->arena_used;
+    if (q->pre_arena_committed != q->pre_arena_used) {
+        VMP_HIP_CHECK(ctx, hipMemcpy(q->pre_arena_dev + q->pre_arena_committed,
+                                     q->pre_arena_host + q->pre_arena_committed,
+                                     (size_t)(q->pre_arena_used - q->pre_arena_committed) * sizeof(SmallPre),
+                                     hipMemcpyHostToDevice));
+        q->pre_arena_committed = q->pre_arena_used;
+    }
     return VMP_OK;
 }
 

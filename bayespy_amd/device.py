@@ -236,12 +236,13 @@ class Runtime:
                 self._queue_env = os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') != '0'
                 if not self._queue_env:
                     self.check(self.lib.vmp_tune_set(b'small_queue', 0))
-                # formulas only by default: their queued arithmetic is that of the stand-alone
-                # kernel bit for bit, so eager sweeps, recorded sweeps and single launches agree
-                # exactly.  BAYESPY_AMD_SMALL_QUEUE=all adds small plate sums and K x K inverses
-                # (another order of the additions; measured no faster: DESIGN.md section 4.18)
+                # formulas, small plate sums and K x K inverses (round 6: the interpreter keeps the
+                # small arrays of a launch in LDS, which made queueing pay inside recorded sweeps).
+                # The order of the additions of a queued sum depends on its shape alone, so eager
+                # and recorded sweeps agree bit for bit; a single launch outside an operation (the
+                # stand-alone kernels) agrees to rounding.  BAYESPY_AMD_SMALL_QUEUE=ew: formulas only
                 self.set_tune('small_queue_sm',
-                              1 if os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') == 'all' else 0)
+                              0 if os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') == 'ew' else 1)
             self.check(self.lib.vmp_queue_begin(self.ctx))
 
     def queue_end(self):

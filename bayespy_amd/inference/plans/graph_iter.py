@@ -115,12 +115,41 @@ class GraphIteration:
 
     def _graph_key(self, upd, bound):
         self._update_masks()
-        host = []
-        for n in self.all:
-            host.append((float(getattr(n, 'annealing', 1.0)),
-                         tuple(np.ravel(getattr(n, 'plates_multiplier', ()))),
-                         bool(getattr(n, 'observed', False))))
-        return (tuple(id(n) for n in upd), tuple(id(n) for n in bound), tuple(host),
+        # what the user can change between two sweeps without going through the plan: annealing,
+        # plate multipliers (stochastic VI), observed flags.  The multipliers a node SEES are derived
+        # from the ones set along its ancestors (node.py:294-301: a walk over the graph per node,
+        # 70 us of the host time between two replays at config 2); they are recomputed only when one
+        # of the values they derive from -- read here directly -- has changed
+        nodes = self.__dict__.get('_g_key_nodes')
+        if nodes is None:
+            seen, nodes = set(), []
+            stack = list(self.all)
+            while stack:
+                n = stack.pop()
+                if id(n) in seen:
+                    continue
+                seen.add(id(n))
+                nodes.append(n)
+                stack.extend(getattr(n, 'parents', ()))
+            self._g_key_nodes = nodes
+        def own_multiplier(n):
+            d = getattr(n, '__dict__', {})
+            if '_plates_multiplier_arg' in d:         # a Node: the value set on it (None: inherited)
+                return d['_plates_multiplier_arg']
+            m = getattr(n, 'plates_multiplier', None)  # anything else: whatever it shows
+            return None if m is None else tuple(np.ravel(m))
+        raw = tuple((getattr(n, 'annealing', 1.0), own_multiplier(n), getattr(n, 'observed', False))
+                    for n in nodes)
+        cached = self.__dict__.get('_g_key_host')
+        if cached is None or cached[0] != raw:
+            host = []
+            for n in self.all:
+                host.append((float(getattr(n, 'annealing', 1.0)),
+                             tuple(np.ravel(getattr(n, 'plates_multiplier', ()))),
+                             bool(getattr(n, 'observed', False))))
+            cached = (raw, tuple(host))
+            self._g_key_host = cached
+        return (tuple(id(n) for n in upd), tuple(id(n) for n in bound), cached[1],
                 self._mask_epoch)
 
     # -- state leaves ------------------------------------------------------------------------------
@@ -316,14 +345,15 @@ class GraphIteration:
                 memo_was = misc._CUR_MEMO[0]
                 misc._CUR_MEMO[0] = self.__dict__.setdefault('_contract_memo', {})
                 self._seed_sums()
-                # the queue of small operations (vmp_queue_*) pays in eager sweeps only: a node of the
-                # graph and a record of the interpreter both cost one dependent round trip through
-                # memory, and replays measure 1.96 ms without against 2.00 ms with it at config 2
-                # (DESIGN.md section 4.18).  BAYESPY_AMD_GRAPH_QUEUE=1 keeps it open inside the
-                # recording (a run of small operations is then ONE node; the records of its flushes
-                # are kept by the library and copied to the device once, queue_commit)
+                # the queue of small operations (vmp_queue_*) stays open inside the recording: a run
+                # of small operations is ONE node, its records are kept by the library and copied to
+                # the device once (queue_commit).  Until round 6 a record cost the interpreter what a
+                # node costs the graph -- a dependent round trip through memory -- and the queue was
+                # switched off here; with the launch's small arrays and its records in LDS it pays
+                # (config 2: 0.86 -> 0.71 ms).  BAYESPY_AMD_GRAPH_QUEUE=0 records every operation as
+                # a node of its own
                 rt.flush_small()
-                if os.environ.get('BAYESPY_AMD_GRAPH_QUEUE', '0') != '1':
+                if os.environ.get('BAYESPY_AMD_GRAPH_QUEUE', '1') == '0':
                     rt.set_tune('small_queue_ew', 0)
                     rt.set_tune('small_queue_sm', 0)
                 rt._read_log = set()
@@ -496,14 +526,15 @@ class GraphIteration:
         rec.fresh = False
         self._g_touched = False
         rec.replays += 1
-        vals = rec.outvec.cpu().numpy() if rec.outvec is not None else np.zeros(0)
-        # the state objects of the recording, as fresh wrappers (same device arrays)
+        # the state objects of the recording, as fresh wrappers (same device arrays) -- host work that
+        # needs no value of the replay: done while the device runs it, BEFORE the read that waits
         memo = {}
         for st, fields in rec.template:
             const = self._constant_state(st)
             for f, v in fields.items():
                 setattr(st, f, v if (f == 'stale' or const) else self._rewrap(v, memo))
         self._graph_reset_caches()
+        vals = rec.outvec.cpu().numpy() if rec.outvec is not None else np.zeros(0)
         for bad, (exc_type, message) in zip(vals[rec.n_bound:], rec.checks):
             if bad:
                 self._graph_drop('a validity check failed')

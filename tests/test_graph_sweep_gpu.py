@@ -134,12 +134,14 @@ def test_other_model_families_agree_with_eager(case, golden_dir, monkeypatch):
         assert same(eager[k], graph[k]), k
 
 
-@pytest.mark.parametrize('mode', ['eager_all', 'graph_all'])
-def test_queue_of_sums_and_recorded_queue_agree_with_the_default(mode, monkeypatch):
-    """Opt-ins of the queue of small operations: small plate sums and
-    K x K inverses queued as well (BAYESPY_AMD_SMALL_QUEUE=all -- another order of the additions),
-    and the queue kept open inside the recorded sweep (BAYESPY_AMD_GRAPH_QUEUE=1: its flushes become
-    nodes of the graph, their records are committed to the device after the recording)."""
+@pytest.mark.parametrize('mode', ['formulas_only', 'graph_without_queue', 'eager'])
+def test_queue_of_small_operations_agrees_with_its_opt_outs(mode, monkeypatch):
+    """The queue of small operations: by default formulas, small plate sums and
+    K x K inverses of a sweep are records of a few interpreter launches, in eager sweeps and -- as
+    nodes of the graph -- in recorded ones.  Against the opt-outs: formulas only (tune small_queue_sm
+    = 0: sums by the stand-alone kernels, another order of the additions), recorded sweeps with one
+    node per operation (BAYESPY_AMD_GRAPH_QUEUE=0), eager sweeps (BAYESPY_AMD_GRAPH=0: the same
+    queued arithmetic, so bit for bit)."""
     from bayespy_amd.device import get_runtime
 
     def run():
@@ -148,21 +150,24 @@ def test_queue_of_sums_and_recorded_queue_agree_with_the_default(mode, monkeypat
         return Q.L[:8].copy(), Q['W'].get_moments()[0], Q['W']._plan.graph_info()
 
     rt = get_runtime()
+    s0 = rt.queue_stats()
     L0, W0, info0 = run()
+    s1 = rt.queue_stats()
     assert info0['recorded']
-    rt.set_tune('small_queue_sm', 1)
-    if mode == 'eager_all':
-        monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
-    else:
-        monkeypatch.setenv('BAYESPY_AMD_GRAPH_QUEUE', '1')
-    try:
-        s0 = rt.queue_stats()
-        L1, W1, info1 = run()
-        s1 = rt.queue_stats()
-    finally:
-        rt.set_tune('small_queue_sm', 0)
-    assert info1['recorded'] == (mode == 'graph_all')
     # operations were in fact queued: far fewer interpreter launches than records
     assert s1['operations'] - s0['operations'] > 3 * (s1['launches'] - s0['launches']) > 0
+    if mode == 'formulas_only':
+        rt.set_tune('small_queue_sm', 0)
+    elif mode == 'eager':
+        monkeypatch.setenv('BAYESPY_AMD_GRAPH', '0')
+    else:
+        monkeypatch.setenv('BAYESPY_AMD_GRAPH_QUEUE', '0')
+    try:
+        L1, W1, info1 = run()
+    finally:
+        rt.set_tune('small_queue_sm', 1)
+    assert info1['recorded'] == (mode != 'eager')
+    if mode == 'eager':
+        assert np.array_equal(L1, L0) and np.array_equal(np.asarray(W1), np.asarray(W0))
     np.testing.assert_allclose(L1, L0, rtol=1e-12)
     np.testing.assert_allclose(W1, W0, rtol=1e-9, atol=1e-12)

@@ -4,7 +4,7 @@ launch and every sum_multiply / GEMM launch with shapes and its synchronous dura
 import os, sys, time, traceback
 # launch by launch: no replay from the sweep graph, no queue of small operations
 os.environ.setdefault('BAYESPY_AMD_GRAPH', '0')
-os.environ.setdefault('BAYESPY_AMD_SMALL_QUEUE', '0')
+os.environ.setdefault('BAYESPY_AMD_SMALL_QUEUE', '0')   # (the trace wants every operation as a launch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bayespy_amd import darray
