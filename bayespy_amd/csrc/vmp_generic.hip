@@ -551,7 +551,7 @@ __device__ inline double ewise_program_impl(const EA &a, const int64_t *off, LD 
         const int word = UNI ? __builtin_amdgcn_readfirstlane(a.ops[p]) : a.ops[p];
         const int op = word & 0xff, arg = word >> 8;
         switch (op) {
-        case VMP_OP_IN:      PUSH(ld(arg, off[arg])); break;
+        case VMP_OP_IN:      PUSH(ld(arg, UNI ? (int64_t)0 : off[arg])); break;
         case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
         case VMP_OP_ADD:     BIN(x + y); break;
         case VMP_OP_SUB:     BIN(x - y); break;
@@ -1194,7 +1194,8 @@ struct alignas(16) SmallOp {
     // filled in by the flush (queue_place): where in the interpreter's LDS arena operand i / the
     // result live (element offsets; -1: in global memory only)
     int32_t lin[MAXIN];
-    int32_t lout, pad2;
+    int32_t lout;
+    int32_t fence;       // the record reads MEMORY that an earlier record of the launch wrote
 };
 // an array from OUTSIDE the launch that its records read: copied into the arena before the first record
 struct SmallPre {
@@ -1283,40 +1284,80 @@ __device__ inline const double *small_operand(CSmallOp *op, const double *glob, 
     return li >= 0 ? lds + li : glob;
 }
 
-__device__ __noinline__ void small_ewise(CSmallOp *op, int tid, double *lds)
+// The program of a queued formula held ACROSS THE LANES of a wavefront -- lane p has word p, lane c
+// constant c -- and read back with v_readlane: a word costs a few cycles instead of a dependent LDS
+// round trip (0.17 us per word before: a 33-word formula on a scalar was 6.8 us).
+struct ProgWords {
+    int w;
+    __device__ int operator[](int p) const { return __builtin_amdgcn_readlane(w, p); }
+};
+struct ProgConsts {
+    double c;
+    __device__ double operator[](int a) const
+    {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(c), a);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(c), a);
+        return __hiloint2double(hi, lo);
+    }
+};
+struct ProgRegs {
+    int nops;
+    ProgWords ops;
+    ProgConsts consts;
+};
+static_assert(VMP_EWISE_MAX_OPS <= 64 && VMP_EWISE_MAX_CONSTS <= 64, "one lane per program word");
+
+// (no private array is indexed with a run-time value here: `off[arg]` with arg from the program put the
+// offsets into scratch MEMORY -- a vector-memory round trip per operand read, and with it a wait for
+// every store in flight: 2.5 us for a scalar formula)
+__device__ __forceinline__ void small_ewise(CSmallOp *op, int tid, double *lds)
 {
-    op = uniform_record(op);
     const uint32_t total = (uint32_t)uni((int)op->ew.total);
     double *out = op->out;
     const int nin = uni(op->ew.nin), ndim = uni(op->ew.ndim);
-    const double *in0 = small_operand(op, op->ew.in[0], 0, lds), *in1 = small_operand(op, op->ew.in[1], 1, lds);
-    const double *in2 = small_operand(op, op->ew.in[2], 2, lds), *in3 = small_operand(op, op->ew.in[3], 3, lds);
-    const double *in4 = small_operand(op, op->ew.in[4], 4, lds), *in5 = small_operand(op, op->ew.in[5], 5, lds);
     static_assert(MAXIN == 6, "operand selection below is written for six operands");
+    const double *base[MAXIN];
+#pragma unroll
+    for (int i = 0; i < MAXIN; ++i) base[i] = small_operand(op, op->ew.in[i], i, lds);
     const int32_t lout = op->lout;
-    auto ld = [&](int arg, int64_t o) {
-        const double *p = arg == 0 ? in0 : (arg == 1 ? in1 : (arg == 2 ? in2 : (arg == 3 ? in3 : (arg == 4 ? in4 : in5))));
-        return p[o];
-    };
+    ProgRegs prog;
+    {
+        const int lane = tid & 63;
+        prog.nops = uni(op->ew.nops);
+        prog.ops.w = lane < VMP_EWISE_MAX_OPS ? op->ew.ops[lane] : 0;
+        prog.consts.c = lane < VMP_EWISE_MAX_CONSTS ? op->ew.consts[lane] : 0.0;
+    }
     for (uint32_t e = tid; e < total; e += QNT) {
         int64_t off[MAXIN];
-        for (int i = 0; i < nin; ++i) off[i] = 0;
+#pragma unroll
+        for (int i = 0; i < MAXIN; ++i) off[i] = 0;
         uint32_t t = e;
         for (int d = ndim - 1; d >= 1; --d) {
             const uint32_t sz = (uint32_t)op->ew.shape[d];
             const uint32_t q = t / sz, c = t - q * sz;
             t = q;
-            for (int i = 0; i < nin; ++i) off[i] += (int64_t)c * op->ew.stride[i][d];
+#pragma unroll
+            for (int i = 0; i < MAXIN; ++i)
+                if (i < nin) off[i] += (int64_t)c * op->ew.stride[i][d];
         }
-        if (ndim >= 1)
-            for (int i = 0; i < nin; ++i) off[i] += (int64_t)t * op->ew.stride[i][0];
-        const double v = ewise_program_impl<true>(op->ew, off, ld);
+        if (ndim >= 1) {
+#pragma unroll
+            for (int i = 0; i < MAXIN; ++i)
+                if (i < nin) off[i] += (int64_t)t * op->ew.stride[i][0];
+        }
+        const double *p0 = base[0] + off[0], *p1 = base[1] + off[1], *p2 = base[2] + off[2];
+        const double *p3 = base[3] + off[3], *p4 = base[4] + off[4], *p5 = base[5] + off[5];
+        auto ld = [&](int arg, int64_t) {
+            const double *p = arg == 0 ? p0 : (arg == 1 ? p1 : (arg == 2 ? p2 : (arg == 3 ? p3 : (arg == 4 ? p4 : p5))));
+            return *p;
+        };
+        const double v = ewise_program_impl<true>(prog, nullptr, ld);
         out[e] = v;
         if (lout >= 0) lds[lout + e] = v;
     }
 }
 
-__device__ __noinline__ void small_spd(CSmallOp *op, double *M, int *bad, int tid)
+__device__ __forceinline__ void small_spd(CSmallOp *op, double *M, int *bad, int tid)
 {
     op = uniform_record(op);
     const int n = op->spd.n, nn = n * n;
@@ -1429,7 +1470,7 @@ __device__ inline void small_sum_body(CSmallOp *op, double *red, int tid, double
     }
 }
 
-__device__ __noinline__ void small_sum(CSmallOp *op, double *red, int tid, double *lds)
+__device__ __forceinline__ void small_sum(CSmallOp *op, double *red, int tid, double *lds)
 {
     op = uniform_record(op);
     if (op->it.nin <= 2) small_sum_body<2>(op, red, tid, lds);
@@ -1449,7 +1490,7 @@ small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restr
     __shared__ double red[QNT / 64];
     __shared__ double M[SMALL_SPD_MAXN * SPD_LD];
     __shared__ int bad;
-    constexpr int RC = 8, RW = (int)(sizeof(SmallOp) / sizeof(double));
+    constexpr int RC = 16, RW = (int)(sizeof(SmallOp) / sizeof(double));
     __shared__ double recbuf[RC * RW];
     const int tid = threadIdx.x;
     {
@@ -1470,16 +1511,22 @@ small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restr
         if (i % RC == 0) {
             const int cnt = (n - i < RC ? n - i : RC) * RW;
             for (int e = tid; e < cnt; e += QNT) recbuf[e] = words[(int64_t)i * RW + e];
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         CSmallOp *op = (CSmallOp *)(recbuf + (i % RC) * RW);          // (C cast: generic -> LDS address space)
         const int kind = uni(op->kind);
+        if (uni(op->fence)) {
+            // it reads memory an earlier record wrote: those stores have to have arrived (a round
+            // trip of ~2 us -- which EVERY record paid while this was unconditional)
+            __threadfence_block();
+            __syncthreads();
+        }
         if (kind == SMALL_EWISE) small_ewise(op, tid, qlds);
         else if (kind == SMALL_SPD) small_spd(op, M, &bad, tid);
         else small_sum(op, red, tid, qlds);
-        // what this record wrote is visible to the next one (one workgroup, one CU)
-        __threadfence_block();
-        __syncthreads();
+        // what this record wrote INTO THE ARENA is visible to the next one: LDS operations done,
+        // then the barrier -- without waiting for the stores to memory (see above)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -1520,7 +1567,7 @@ inline void queue_place(SmallOp *h, int n, SmallPre *pre, int *npre_out, int64_t
         SmallOp &op = h[i];
         for (int k = 0; k < MAXIN; ++k) op.lin[k] = -1;
         op.lout = -1;
-        op.pad2 = 0;
+        op.fence = 0;
         if (op.kind != SMALL_SPD) {
             const int nin = op.kind == SMALL_EWISE ? op.ew.nin : op.it.nin;
             for (int k = 0; k < nin; ++k) {
@@ -1562,12 +1609,19 @@ inline void queue_place(SmallOp *h, int n, SmallPre *pre, int *npre_out, int64_t
                     }
                 }
                 op.lin[k] = place;
+                if (overlaps && place < 0) op.fence = 1;
                 if (place >= 0) *cached += 1; else *uncached += 1;
             }
         }
         // the record's result(s)
         if (op.kind == SMALL_SPD) {
             const int64_t nn = (int64_t)op.spd.n * op.spd.n * op.spd.batch;
+            {
+                const char *blo = reinterpret_cast<const char *>(op.spd.A);
+                const char *bhi = reinterpret_cast<const char *>(op.spd.A + nn);
+                for (int j = 0; j < nout; ++j)
+                    if (blo < outs[j].hi && outs[j].lo < bhi) op.fence = 1;
+            }
             if (op.spd.Ainv)
                 outs[nout++] = ByteRange{reinterpret_cast<const char *>(op.spd.Ainv),
                                          reinterpret_cast<const char *>(op.spd.Ainv + nn), -1};
@@ -1732,6 +1786,7 @@ int32_t vmp_queue_flush(vmp_ctx *ctx)
         for (int i = 0; i < n; ++i) {
             for (int k = 0; k < MAXIN; ++k) host[i].lin[k] = -1;
             host[i].lout = -1;
+            host[i].fence = 1;
         }
     }
     const bool rec = stream_records(ctx);
