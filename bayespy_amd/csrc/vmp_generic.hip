@@ -1240,7 +1240,7 @@ struct small_queue {
 // The records of a launch are staged through LDS, RC at a time, by the whole workgroup (one memory
 // latency per RC records).  Read one field at a time where the program flow needs it -- as scalar
 // loads from the constant address space, the form of round 5 -- every record cost ~18 dependent cache
-// misses, 3.8 us per record in a recorded sweep (profiles/r06/queue_lds_ab.txt), more than the graph
+// misses, 3.8 us per record in a recorded sweep (profiles/r06/queue_record_cost.txt), more than the graph
 // node it replaced.  Values that steer the control flow come back through the first lane.
 #define VMP_CONST_AS __attribute__((address_space(3)))
 typedef const VMP_CONST_AS SmallOp CSmallOp;

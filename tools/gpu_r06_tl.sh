@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r06_tl
+O=${O:-gpurun_out/r06_tl}
 mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
