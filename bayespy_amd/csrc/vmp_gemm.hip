@@ -38,14 +38,19 @@ __device__ inline v4f64 mfma_f64(double a, double b, v4f64 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// TM x TN output tile: 64 x 64 (wavefronts 2 x 2) or 128 x 32 (4 x 1: outputs of at most 32 columns --
+// the K = 32 components of a mixture -- ran the 64-wide tile half empty); every wavefront a 32 x 32 block
+template <int TM, int TN>
 __global__ void __launch_bounds__(NT, 2)
 gemm_kernel(GemmArgs g)
 {
+    constexpr int BM = TM, BN = TN, LDB_S = TN + 16;
+    constexpr int EA = TM * BK / NT, EB = BK * TN / NT;      // elements per thread of the tile loads
     __shared__ double As[BM * LDA_S];
     __shared__ double Bs[BK * LDB_S];
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, l15 = l & 15, l4 = l >> 4;
-    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    const int wm = (TN == 64 ? (w >> 1) : w) * 32, wn = (TN == 64 ? (w & 1) : 0) * 32;
     const int64_t tiles_n = (g.N + BN - 1) / BN;
     const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int64_t m0 = tm * BM, n0 = tn * BN;
@@ -76,10 +81,10 @@ gemm_kernel(GemmArgs g)
 
     // Tile loads go global -> registers -> LDS; the registers of tile k0+BK are filled while the
     // MFMAs of tile k0 run (the loads' latency hides behind the matrix pipe).
-    double ra[4], rb[4];
+    double ra[EA], rb[EB];
     auto fetch = [&](int64_t k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EA; ++e) {
             const int idx = tid + e * NT;
             const int mi = a_kfast ? idx / BK : idx % BM;
             const int ki = a_kfast ? idx % BK : idx / BM;
@@ -87,7 +92,7 @@ gemm_kernel(GemmArgs g)
             ra[e] = (m < g.M && k < k_end) ? A[m * g.a_ms + k * g.a_ks] : 0.0;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EB; ++e) {
             const int idx = tid + e * NT;
             const int ki = b_nfast ? idx / BN : idx % BK;
             const int ni = b_nfast ? idx % BN : idx / BK;
@@ -97,14 +102,14 @@ gemm_kernel(GemmArgs g)
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EA; ++e) {
             const int idx = tid + e * NT;
             const int mi = a_kfast ? idx / BK : idx % BM;
             const int ki = a_kfast ? idx % BK : idx / BM;
             As[mi * LDA_S + ki] = ra[e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EB; ++e) {
             const int idx = tid + e * NT;
             const int ki = b_nfast ? idx / BN : idx % BK;
             const int ni = b_nfast ? idx % BN : idx / BK;
@@ -469,7 +474,10 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
             return VMP_OK;
         }
     }
-    const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // outputs of at most 32 columns: the 128 x 32 tile (tune key gemm_narrow_tile)
+    const bool narrow = N <= 32 && M > 64 && vmp_tune_get("gemm_narrow_tile", 1) != 0;
+    const int64_t TMh = narrow ? 128 : BM, TNh = narrow ? 32 : BN;
+    const int64_t tiles = ((M + TMh - 1) / TMh) * ((N + TNh - 1) / TNh);
     VMP_REQUIRE(ctx, nbatch <= 65535, VMP_ERR_UNSUPPORTED, "too many batch elements (%lld)",
                 (long long)nbatch);
     // split K when the output alone cannot fill the chip
@@ -492,7 +500,10 @@ int32_t vmp_gemm_strided(vmp_ctx *ctx, int32_t nbatch_dims, const int64_t *bshap
     if (g.kchunk < BK) g.kchunk = BK;
     g.C = nsplit > 1 ? reinterpret_cast<double *>(workspace) : C;
     const dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)nbatch);
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(NT), 0, s, g);
+    if (narrow)
+        hipLaunchKernelGGL((gemm_kernel<128, 32>), grid, dim3(NT), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_kernel<64, 64>), grid, dim3(NT), 0, s, g);
     if (nsplit > 1) {
         const int64_t total = nbatch * M * N;
         int64_t gb = (total + 15) / 16;

@@ -178,11 +178,12 @@ def _launch_sum_multiply(arrays, shape, reduce_axes, out_shape_keep, scale=1.0):
     nd = len(shape)
     if nd > 8 or len(arrays) > 6:
         raise NotImplementedError('sum_multiply supports <= 8 axes and <= 6 operands')
-    if len(arrays) == 1 and len(reduce_axes) == 0 and scale == 1.0 \
+    if len(arrays) == 1 and scale == 1.0 and all(shape[ax] == 1 for ax in reduce_axes) \
             and tuple(arrays[0].shape) == tuple(out_shape_keep):
         # nothing to multiply, nothing to sum: the operand IS the result (device arrays are never
         # modified in place; a plate "sum" of a message that already has the parent's plates was
-        # a 0.3 ms copy of a (D, N) array at N = 1e6)
+        # a 0.3 ms copy of a (D, N) array at N = 1e6; "sums" over axes of extent one -- scalar terms
+        # of the bound on their way through the plate sums -- were a record each)
         return arrays[0]
     memo, sig = _CUR_MEMO[0], None
     if memo is not None and len(reduce_axes) > 0 and any(a.size >= _MEMO_MIN for a in arrays):

@@ -795,3 +795,40 @@ def test_gaussian_shared_update_through_the_c_abi(N, D, K, ylay):
     if ylay != 'rows':
         np.testing.assert_allclose(st[K + K * K:].reshape(D, K), y @ ref, **big)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (5000, 32, 256, False, True),      # mixture log-likelihood: y y^T (N, D^2) against Lambda_k (K, D^2)
+    (256, 32, 30000, True, False),     # weighted statistics: sum_n r_nk y y^T, split over the plates
+    (130, 17, 300, False, False),      # ragged in every direction
+    (4097, 24, 100, True, True),
+    (65, 32, 64 + 16, False, False)])
+def test_narrow_output_gemm_matches_numpy(M, N, K, ta, tb):
+    """gemm_kernel<128, 32> (csrc/vmp_gemm.hip): outputs of at most 32 columns on a 128 x 32 tile
+    (the 64 x 64 tile ran half empty for the 32 components of a mixture), every stride pattern,
+    split-K included; identical to the 64 x 64 tile's result up to the order of the K slices
+    (tune key gemm_narrow_tile = 0) and run-to-run identical."""
+    from bayespy_amd.utils import misc
+    from bayespy_amd.darray import DArray
+    from bayespy_amd.device import get_runtime
+    rt = get_runtime()
+    rs = np.random.RandomState(M + N * 11 + K)
+    a = rs.normal(size=(K, M) if ta else (M, K))
+    b = rs.normal(size=(N, K) if tb else (K, N))
+    A = DArray.from_host(a)
+    B = DArray.from_host(b)
+    A = A.swapaxes(0, 1) if ta else A
+    B = B.swapaxes(0, 1) if tb else B
+    A3 = DArray(A.t.unsqueeze(1))
+    B3 = DArray(B.t.transpose(0, 1).unsqueeze(0))
+    ref = (a.T if ta else a) @ (b.T if tb else b)
+    r1 = misc.sum_multiply(A3, B3, axis=(2,)).numpy()
+    r2 = misc.sum_multiply(A3, B3, axis=(2,)).numpy()
+    assert r1.shape == (M, N) and np.array_equal(r1, r2)
+    np.testing.assert_allclose(r1, ref, rtol=1e-12, atol=1e-12 * np.sqrt(K))
+    try:
+        rt.lib.vmp_tune_set(b'gemm_narrow_tile', 0)
+        r0 = misc.sum_multiply(A3, B3, axis=(2,)).numpy()
+    finally:
+        rt.lib.vmp_tune_set(b'gemm_narrow_tile', 1)
+    np.testing.assert_allclose(r1, r0, rtol=1e-13, atol=1e-13 * np.sqrt(K))
