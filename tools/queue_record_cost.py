@@ -99,7 +99,11 @@ def spd_inv(i):
 
 
 print('library', lib.vmp_version().decode())
-for lds in (0, 1):
+BUSY = '--busy' in sys.argv      # the same launches beside a stream of large matrix products: is a lone
+                                 # workgroup on an otherwise idle chip clocked down?
+side = torch.cuda.Stream(dev)
+big = torch.randn(6144, 6144, dtype=torch.float64, device=dev)
+for lds in ((1,) if BUSY else (0, 1)):
     lib.vmp_tune_set(b'small_queue_lds', lds)
     for name, fn in (('formula: copy of a scalar', ew_copy), ('formula: 33 words on a scalar', ew_long), ('formula 16 x 16', ew_kk), ('formula scalar log', ew_scalar), ('formula digamma(16)', ew_digamma),
                      ('sum 16 x 16 . 16', sum_mv), ('sum of 256 products of three', sum_all), ('inverse 16 x 16', spd_inv)):
@@ -108,6 +112,10 @@ for lds in (0, 1):
             assert lib.vmp_queue_begin(ctx) == 0
             for i in range(NREC):
                 fn(i)
+            if BUSY:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        big @ big
             with torch.cuda.stream(stream):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -115,5 +123,5 @@ for lds in (0, 1):
                 e1.record(stream)
             assert lib.vmp_ctx_sync(ctx) == 0
             ts.append(e0.elapsed_time(e1) * 1e3 / NREC)
-        print('arrays in LDS = %d  %-32s %6.2f us per record' % (lds, name, min(ts)))
+        print('arrays in LDS = %d%s  %-32s %6.2f us per record' % (lds, ' beside GEMMs' if BUSY else '', name, min(ts)))
 lib.vmp_ctx_destroy(ctx)
