@@ -1158,6 +1158,133 @@ lssm_backward_mfma_kernel(int64_t B, int T, int64_t BL, const double *__restrict
     }
 }
 
+// The backward sweep WITH the plate sums (M <= 15; default, tune key lssm_fuse_stats): the smoothed
+// states of a step go through a wavefront-private 16 x 16 LDS transpose per tile into the operand
+// layout (state along l & 15, sequence along l >> 4), and  sum x x^T,  sum x_t+1 x_t^T,  sum [y ; 1] x^T
+// accumulate in three matrix-core tiles per wavefront -- the pass of lssm_stats_wave_kernel over the
+// states and the data (24 of 80 doubles per sequence and step, 4.1 of 16 ms at D = 16, B = 1e5) is
+// replaced by a read of y here (8).  One partial block (48 x 16) per wavefront, the layout of the
+// statistics kernels: combined by lssm_stats_reduce_kernel.  Columns >= B contribute zeros.
+template <int D>
+__global__ void __launch_bounds__(256)
+lssm_backward_mfma_stats_kernel(int64_t B, int T, int64_t BL, const double *__restrict__ Sinv,
+                                const double *__restrict__ J, double *__restrict__ Z,
+                                const double *__restrict__ Yt, int M, double *__restrict__ P)
+{
+    constexpr int LT = 17;
+    __shared__ double Ts[4][2][16 * LT];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + w;
+    const int64_t b0 = wv * 32;
+    if (b0 >= B) return;
+    const int64_t col = b0 + 2 * l15;
+    const v2f64 zero2 = v2f64{0.0, 0.0};
+    auto load_rows = [&](int t, v2f64 (&out)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            out[r] = row < D ? *reinterpret_cast<const v2f64 *>(&Z[((int64_t)t * D + row) * BL + col])
+                             : zero2;
+        }
+    };
+    auto load_a = [&](const double *Mx, int t, double sign, double (&a)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + l4;
+            a[q] = (l15 < D && k < D) ? sign * Mx[(int64_t)t * D * D + l15 * D + k] : 0.0;
+        }
+    };
+    // [y ; 1] of step t in the A-operand layout: row m = l15, sequences b0 + 2 (4 q + l4) (+ 1)
+    auto load_y = [&](int t, v2f64 (&out)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t c = b0 + 2 * (4 * q + l4);
+            out[q] = l15 < M ? *reinterpret_cast<const v2f64 *>(&Yt[((int64_t)t * M + l15) * BL + c])
+                             : (l15 == M ? v2f64{1.0, 1.0} : zero2);
+        }
+    };
+    bool live0[4], live1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t c = b0 + 2 * (4 * q + l4);
+        live0[q] = c < B;
+        live1[q] = c + 1 < B;
+    }
+    v4f64 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+    v4f64 sxx = x0, snp = x0, syx = x0;
+    double xn0[4] = {0.0, 0.0, 0.0, 0.0}, xn1[4] = {0.0, 0.0, 0.0, 0.0};     // x_t+1, operand layout
+    v2f64 z[4], zn[4], ya[4], yan[4];
+    double as[4], aj[4] = {0.0, 0.0, 0.0, 0.0}, asn[4], ajn[4];
+    load_rows(T - 1, z);
+    load_a(Sinv, T - 1, 1.0, as);
+    load_y(T - 1, ya);
+    double *t0s = &Ts[w][0][0], *t1s = &Ts[w][1][0];
+    for (int t = T - 1; t >= 0; --t) {
+        if (t > 0) {
+            load_rows(t - 1, zn);
+            load_a(Sinv, t - 1, 1.0, asn);
+            load_a(J, t - 1, -1.0, ajn);
+            load_y(t - 1, yan);
+        }
+        v4f64 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(as[q], z[q].x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(as[q], z[q].y, c1, 0, 0, 0);
+        }
+        if (t < T - 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], x0[q], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aj[q], x1[q], c1, 0, 0, 0);
+            }
+        }
+        x0 = c0;
+        x1 = c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r;
+            if (row < D)
+                *reinterpret_cast<v2f64 *>(&Z[((int64_t)t * D + row) * BL + col]) = v2f64{x0[r], x1[r]};
+            // (rows >= D of the accumulators are zero: zero A rows)
+            t0s[row * LT + l15] = x0[r];
+            t1s[row * LT + l15] = x1[r];
+        }
+        double xt0[4], xt1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v0 = t0s[l15 * LT + 4 * q + l4], v1 = t1s[l15 * LT + 4 * q + l4];
+            xt0[q] = live0[q] ? v0 : 0.0;
+            xt1[q] = live1[q] ? v1 : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sxx = __builtin_amdgcn_mfma_f64_16x16x4f64(xt0[q], xt0[q], sxx, 0, 0, 0);
+            sxx = __builtin_amdgcn_mfma_f64_16x16x4f64(xt1[q], xt1[q], sxx, 0, 0, 0);
+            snp = __builtin_amdgcn_mfma_f64_16x16x4f64(xn0[q], xt0[q], snp, 0, 0, 0);
+            snp = __builtin_amdgcn_mfma_f64_16x16x4f64(xn1[q], xt1[q], snp, 0, 0, 0);
+            syx = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q].x, xt0[q], syx, 0, 0, 0);
+            syx = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q].y, xt1[q], syx, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xn0[q] = xt0[q];
+            xn1[q] = xt1[q];
+            z[q] = zn[q];
+            as[q] = asn[q];
+            aj[q] = ajn[q];
+            ya[q] = yan[q];
+        }
+    }
+    double *Pb = P + wv * (48 * 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Pb[(l4 + 4 * r) * 16 + l15] = sxx[r];
+        Pb[(16 + l4 + 4 * r) * 16 + l15] = snp[r];
+        Pb[(32 + l4 + 4 * r) * 16 + l15] = syx[r];
+    }
+}
+
 // The plate sums of the big-state path ON THE MATRIX CORES (default; tune key lssm_big_mfma).  Per
 // (time step, 32 sequences) a tile [x_t (16 rows) ; x_t+1 (16) ; y_t and a row of ones (MP)] x 32
 // columns is staged in LDS (row stride 34: both operand patterns below are bank-conflict free) and
@@ -2518,6 +2645,7 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
         const int RP = big_rows(D, M);
         double *H = wsd + (ws_base_doubles(D, M, B) + big_partial_doubles(D, M, B) + 64 + 7) / 8 * 8;
         hipStream_t sw = ctx->stream;
+        bool fs = false;                                      // the backward sweep made the main sums
         if (!given && g > 0) {
             int64_t gp = ((int64_t)T * B + SNT - 1) / SNT;
             if (gp > (int64_t)ctx->num_cu * 16) gp = (int64_t)ctx->num_cu * 16;
@@ -2528,6 +2656,16 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             // the projection inside the sweep when the observations fit four k-steps
             const bool fy = mf && M <= 16 && vmp_tune_get("lssm_fuse_project", 1) != 0 &&
                             (reinterpret_cast<uintptr_t>(Yt) & 15) == 0;
+            // the plate sums inside the backward sweep: one partial block per wavefront must fit.
+            // Tune key lssm_fuse_stats: 1 always, 0 never, default (2) where it was measured to pay --
+            // D >= 15 and enough sequences that the sweeps, not the covariance recursion, are the
+            // critical path (D = 16: -10 % at B = 1e5, +6 % at B = 2e4; D = 12: +8 % at B = 1e5: the
+            // kernel holds 198 registers, two wavefronts per SIMD, and its arithmetic is that of 16
+            // padded states whatever D)
+            const int fsk = vmp_tune_get("lssm_fuse_stats", 2);
+            fs = mf && D > DREG && M <= 15 && (fsk == 1 || (fsk == 2 && D >= 15 && B >= 40000)) &&
+                 (reinterpret_cast<uintptr_t>(Yt) & 15) == 0 &&
+                 ((B + 31) / 32) * (48 * 16) <= big_partial_doubles(D, M, B);
 #define LSSM_BIG(d)                                                                              \
     if (D == d) {                                                                                \
         if (!fy)                                                                                 \
@@ -2554,7 +2692,10 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
                                    dim3(SNT), 0, sw, H, d, B, T, BL, nullptr, nullptr, h0, J, Z, \
                                    ta, tb);                                                      \
         }                                                                                        \
-        if (mf)                                                                                  \
+        if (fs)                                                                                  \
+            hipLaunchKernelGGL(lssm_backward_mfma_stats_kernel<d>, dim3((unsigned)gm), dim3(256), \
+                               0, sw, B, T, BL, Sinv, J, Z, Yt, M, part);                        \
+        else if (mf)                                                                             \
             hipLaunchKernelGGL(lssm_backward_mfma_kernel<d>, dim3((unsigned)gm), dim3(256), 0,   \
                                sw, B, T, BL, Sinv, J, Z);                                        \
         else                                                                                     \
@@ -2607,7 +2748,9 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             const bool wavef = vmp_tune_get("lssm_stats_form", 1) != 0;
             for (int q = 0; q < 3; ++q) {
                 int64_t gs;
-                if (wavef) {
+                if (q == 0 && fs) {
+                    gs = (B + 31) / 32;                     // the partial blocks of the backward sweep
+                } else if (wavef) {
                     // one wavefront per job of (32 sequences, TC steps); as many resident as LDS holds
                     const int steps = rng[q].t1 - rng[q].t0;
                     int TC = 32;

@@ -392,7 +392,8 @@ def test_big_state_covariance_recursion_fills_in_its_stationary_stretch(D, T, fo
             np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
 
 
-@pytest.mark.parametrize('M,B,T,D', [(8, 301, 45, 8), (5, 96, 130, 7), (20, 70, 33, 8), (8, 1000, 20, 12)])
+@pytest.mark.parametrize('M,B,T,D', [(8, 301, 45, 8), (5, 96, 130, 7), (20, 70, 33, 8), (8, 1000, 20, 12),
+                                     (15, 333, 40, 16), (3, 97, 25, 9)])
 def test_split_form_of_the_plate_sums_agrees_with_the_other_forms(M, B, T, D):
     """D >= 7 (default): sweeps that carry the state only + the plate sums as a matrix-core pass, one
     wavefront per (32 sequences, time chunk).  Against (a) the workgroup form of that pass
@@ -401,12 +402,13 @@ def test_split_form_of_the_plate_sums_agrees_with_the_other_forms(M, B, T, D):
     from bayespy_amd.device import get_runtime
     y, x0, c0 = _data(M, B, T, D, seed=7 * D + M)
     rt = get_runtime()
-    variants = [(7, 1), (7, 0)] + ([(9, 1)] if D <= 8 else [])
+    variants = [(7, 1), (7, 0)] + ([(9, 1)] if D <= 8 else [(7, 2)])      # (2: sums outside the backward sweep)
     out = []
     try:
         for frm, form in variants:
             rt.lib.vmp_tune_set(b'lssm_split_from', frm)
-            rt.lib.vmp_tune_set(b'lssm_stats_form', form)
+            rt.lib.vmp_tune_set(b'lssm_stats_form', 1 if form == 2 else form)
+            rt.lib.vmp_tune_set(b'lssm_fuse_stats', 0 if form != 1 else 1)    # (1: fused whatever the size)
             Q = _build(y, x0, c0, True)
             assert type(Q.plans[0]).__name__ == 'LSSMPlan'
             Q.update(repeat=3, verbose=False)
@@ -414,6 +416,7 @@ def test_split_form_of_the_plate_sums_agrees_with_the_other_forms(M, B, T, D):
     finally:
         rt.lib.vmp_tune_set(b'lssm_split_from', 7)
         rt.lib.vmp_tune_set(b'lssm_stats_form', 1)
+        rt.lib.vmp_tune_set(b'lssm_fuse_stats', 2)
     for o in out[1:]:
         np.testing.assert_allclose(out[0][0], o[0], rtol=1e-10)
         np.testing.assert_allclose(out[0][1], o[1], rtol=1e-8, atol=1e-8 * np.abs(o[1]).max())

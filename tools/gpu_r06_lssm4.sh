@@ -1,5 +1,5 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -3
 python - <<'PY'
 import sys, gc
 sys.path.insert(0,'.')
@@ -7,10 +7,10 @@ import torch
 from tools import workloads
 from bayespy_amd.device import get_runtime
 rt = get_runtime()
-for (B,D,M) in ((20000,16,8),(100000,16,8),(20000,12,8),(20000,9,8)):
-    for cm in (0, 1):
-        rt.lib.vmp_tune_set(b'lssm_cov_mfma', cm)
+for (B,D,M) in ((20000,16,8),(100000,16,8),(100000,12,8),(50000,16,15)):
+    for fsn in (0, 1):
+        rt.lib.vmp_tune_set(b'lssm_fuse_stats', fsn)
         r = workloads.run_lssm(B=B, T=1000, M=M, D=D, steps=8, warmup=2, cpu_baseline=False)
-        print('B=%d D=%d M=%d  cov_mfma=%d: %.3f ms per iteration' % (B, D, M, cm, r['ms_per_step']), flush=True)
+        print('B=%d D=%d M=%d fuse_stats=%d: %.3f ms per iteration' % (B, D, M, fsn, r['ms_per_step']), flush=True)
         del r; gc.collect(); torch.cuda.empty_cache()
 PY
