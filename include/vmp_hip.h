@@ -622,7 +622,12 @@ int32_t vmp_pack_outputs(vmp_ctx *ctx, int32_t n, const void *const *src, const 
  * vmp_queue_flush or at the outermost vmp_queue_end.  A VB sweep of the generic engine
  * is ~90 such operations on scalars and K x K arrays (the Gamma / ARD formulas of gamma.py:142-148,
  * gaussian.py:2344-2369, the bound terms of expfamily.py:449-468) between a dozen plate-sized
- * kernels.  Results do not depend on the grouping.  The caller must flush before it reads an
+ * kernels.  The interpreter keeps the small arrays of a launch in LDS: results are written to
+ * memory AND to a 112 KB arena, a record reads what an earlier record of the launch produced --
+ * or a small array from outside, copied in when the launch starts -- from there, and only a record
+ * that reads MEMORY written earlier in the launch waits for those stores; the records themselves are
+ * staged through LDS.  ("small_queue_lds" = 0: every operand from memory, a fence per record.)
+ * Results do not depend on the grouping.  The caller must flush before it reads an
  * output on the host or hands it to work outside this library.  begin / end nest; a context whose
  * stream records a HIP graph keeps the records of its flushes for the life of the context; their
  * device copies are made by vmp_queue_commit, which belongs between the end of the recording and

@@ -1,16 +1,11 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_lssm_gpu.py tests/test_chain_gpu.py -x -q -m gpu 2>&1 | tail -3
 python - <<'PY'
 import sys, gc
 sys.path.insert(0,'.')
 import torch
 from tools import workloads
-from bayespy_amd.device import get_runtime
-rt = get_runtime()
-for (B,D,M) in ((20000,16,8),(100000,16,8),(100000,12,8),(50000,16,15)):
-    for fsn in (0, 1):
-        rt.lib.vmp_tune_set(b'lssm_fuse_stats', fsn)
-        r = workloads.run_lssm(B=B, T=1000, M=M, D=D, steps=8, warmup=2, cpu_baseline=False)
-        print('B=%d D=%d M=%d fuse_stats=%d: %.3f ms per iteration' % (B, D, M, fsn, r['ms_per_step']), flush=True)
-        del r; gc.collect(); torch.cuda.empty_cache()
+for (B,D,M) in ((98304,16,8),(100000,16,8),(65536,16,8),(66000,16,8),(131072,16,8)):
+    r = workloads.run_lssm(B=B, T=1000, M=M, D=D, steps=8, warmup=2, cpu_baseline=False)
+    print('B=%d D=%d M=%d: %.3f ms per iteration = %.2f ns per sequence-step' % (B, D, M, r['ms_per_step'], r['ms_per_step']*1e6/(B*1000)), flush=True)
+    del r; gc.collect(); torch.cuda.empty_cache()
 PY
