@@ -832,3 +832,71 @@ def test_narrow_output_gemm_matches_numpy(M, N, K, ta, tb):
     finally:
         rt.lib.vmp_tune_set(b'gemm_narrow_tile', 1)
     np.testing.assert_allclose(r1, r0, rtol=1e-13, atol=1e-13 * np.sqrt(K))
+
+
+def test_queue_places_small_arrays_in_lds_without_changing_results():
+    """The interpreter of small operations keeps the small arrays of a launch in LDS (DESIGN.md
+    section 5.7).  A chain that exercises the placement rules -- strided VIEWS into an earlier record's
+    result (diagonal, transposed, a row), results too large or too many for the arena (read back from
+    memory behind a fence), an inverse between formulas, an operand from outside used twice, more
+    records than one staging chunk -- gives, formula by formula, the bits of the same chain with every
+    operation launched on its own, and sums / inverses to rounding."""
+    import torch
+    from bayespy_amd.utils import misc, linalg
+    from bayespy_amd.darray import DArray, fuse
+    from bayespy_amd.device import get_runtime
+    rt = get_runtime()
+    rs = np.random.RandomState(11)
+    K = 16
+    A = DArray.from_host(rs.normal(size=(K, K)))
+    v = DArray.from_host(rs.normal(size=(K,)))
+    BIG = [DArray.from_host(rs.normal(size=(2048,))) for _ in range(9)]      # 9 x 2048 > the arena
+    G = rs.normal(size=(K, K))
+    S = DArray.from_host(G @ G.T + K * np.eye(K))
+
+    def chain():
+        out = []
+        a = fuse(lambda x, y: x * y + 2.0, A, v)                  # (K, K), broadcast operand
+        d = misc.get_diag(a)                                      # strided view of a record's result
+        b = fuse(lambda x, y: x + 3.0 * y, d, v)
+        at = a.swapaxes(0, 1)                                     # transposed view
+        c = fuse(lambda x, y: x - y, a, at)
+        row = a[3]                                                # a row
+        e = fuse(lambda x, y: x * y, row, b)
+        bigs = [fuse(lambda x: x * 1.5 + 1.0, g) for g in BIG]    # the later ones find no room
+        f = fuse(lambda x, y: x + y, bigs[0], bigs[8])            # one from the arena, one from memory
+        s1 = misc.sum_multiply(a, c, axis=(-1, -2))               # scalar
+        s2 = misc.sum_multiply(a, v, axis=(-1,))                  # (K,)
+        inv = linalg.chol_inv(linalg.chol(S))                     # a queued 16 x 16 inverse
+        h = fuse(lambda x, y: x * y, inv, a)                      # reads an inverse's result
+        s3 = misc.sum_multiply(h, axis=(-1, -2))
+        t = e
+        for _ in range(24):                                       # beyond one staging chunk
+            t = fuse(lambda x, y: 0.5 * x + y, t, v)
+        out = [a, b, c, e, f, s1, s2, inv, h, s3, t]
+        return out
+
+    def run(queue):
+        rt.lib.vmp_tune_set(b'small_queue', queue)
+        try:
+            if queue:
+                with rt.operation():
+                    res = chain()
+            else:
+                res = chain()
+            rt.flush_small()
+            return [np.asarray(r.numpy()) for r in res]
+        finally:
+            rt.lib.vmp_tune_set(b'small_queue', 1)
+
+    s0 = rt.queue_stats()
+    q = run(1)
+    s1 = rt.queue_stats()
+    assert s1['operations'] - s0['operations'] >= 40 and s1['launches'] - s0['launches'] <= 6
+    u = run(0)
+    names = ['a', 'b', 'c', 'e', 'f', 's1', 's2', 'inv', 'h', 's3', 't']
+    for n_, x, y in zip(names, q, u):
+        if n_ in ('s1', 's2', 's3', 'inv', 'h'):
+            np.testing.assert_allclose(x, y, rtol=1e-12, atol=1e-12, err_msg=n_)
+        else:
+            assert np.array_equal(x, y), n_
