@@ -351,6 +351,23 @@ class GenericPlan(GraphIteration):
                 out.append(one(i, p))
         return out
 
+    def _prior_terms(self, node, fam, up, cgf=False):
+        """phi_from_parents (and, ``cgf``, cgf_from_parents) of ``node``.  When every parent is a
+        constant these never change: formed once and kept with the constants (a Gamma or Gaussian
+        node with fixed hyperparameters paid 3-5 small launches for them in its update and again
+        in its lower-bound term, every sweep)."""
+        if os.environ.get('BAYESPY_AMD_PRIOR_CACHE', '1') == '0' or not node.parents \
+                or not all(isinstance(p, Constant) for p in node.parents):
+            return fam.phi_from_parents(up), (fam.cgf_from_parents(up) if cgf else None)
+        key = (id(node), 'prior')
+        hit = self._const_cache.get(key)
+        if hit is None:
+            hit = [fam.phi_from_parents(up), None]
+            self._const_cache[key] = hit
+        if cgf and hit[1] is None:
+            hit[1] = _arr(fam.cgf_from_parents(up))
+        return hit[0], hit[1]
+
     # -- masks (node.py:457-526) -----------------------------------------------------------
     def _update_masks(self):
         if self._masks_ready:
@@ -557,7 +574,7 @@ class GenericPlan(GraphIteration):
         ``lazy``: a Dot child may hand its first-moment message over as a contraction."""
         fam = self.family[id(node)]
         up = self._parent_moments(node)
-        phi = fam.phi_from_parents(up)
+        phi, _ = self._prior_terms(node, fam, up)
         flagged = []
         if lazy:
             for c, _ in node.children:
@@ -806,8 +823,9 @@ class GenericPlan(GraphIteration):
                     terms = list(terms) + [(1.0, [st.f]) if isinstance(st.f, DArray)
                                            else (float(st.f), [])]
                 return self._finish_bound(node, terms, ignore_masked)
-        phi_p = fam.phi_from_parents(up)
-        L = _arr(fam.cgf_from_parents(up))
+        phi_p, L = self._prior_terms(node, fam, up, cgf=True)
+        L = _arr(L)
+        pend = None
         fast = self._shared_cov_bound(node, st, fam, phi_p, L, T, ignore_masked) \
             if not st.observed else None
         if fast is not None:
@@ -830,9 +848,20 @@ class GenericPlan(GraphIteration):
                 # Gaussian factors: -(g_q + phi_q . u_q) in closed form, no K x K contraction
                 L = fuse(lambda a, q: a + q, L, closed(st.phi, st.u, st.g))
             else:
-                L = fuse(lambda a, g, T_=T: a - T_ * g, L, st.g)
+                # (cgf_p - T g_q joins the formula of the first moment when that is a scalar per plate:
+                # same operations in the same order, one launch less)
+                pend = (L, st.g)
+                L = None
+        fold = os.environ.get('BAYESPY_AMD_BOUND_FOLD', '1') != '0'
+
+        def settle():
+            nonlocal L, pend
+            if pend is not None:
+                L = fuse(lambda a, g, T_=T: a - T_ * g, pend[0], pend[1])
+                pend = None
         for i, nd in enumerate(len(d) for d in node.dims):
             if closed is not None and nd > 0:
+                settle()
                 # finite Gaussian prior parameters: phi_p . u as one contraction, no temporary
                 if i == 1 and isinstance(st.u[i], FactoredMoment):
                     L = fuse(lambda a, b: a + b, L, _inner_second(phi_p[i], st.u[i], nd // 2))
@@ -842,15 +871,34 @@ class GenericPlan(GraphIteration):
                                            axis=tuple(range(-nd, 0))))
                 continue
             if partial:
+                settle()
                 t = fuse(lambda pp, pq, m, u, T_=T:
                          da.where_nonzero(u, pp - T_ * (1.0 - m) * pq) * u,
                          _arr(phi_p[i]), _arr(st.phi[i]), _trail(st.obs_mask, nd), _arr(st.u[i]))
             elif st.observed or closed is not None:
+                settle()
+                if nd == 0 and fold:
+                    L = fuse(lambda a, pp, u: a + da.where_nonzero(u, pp) * u,
+                             L, _arr(phi_p[i]), _arr(st.u[i]))
+                    continue
                 t = fuse(lambda pp, u: da.where_nonzero(u, pp) * u, _arr(phi_p[i]), _arr(st.u[i]))
             else:
+                if nd == 0 and fold:
+                    # a scalar moment per plate: its term and the running sum in ONE formula
+                    if pend is not None:
+                        L = fuse(lambda a, g, pp, pq, u, T_=T:
+                                 (a - T_ * g) + da.where_nonzero(u, pp - T_ * pq) * u,
+                                 pend[0], pend[1], _arr(phi_p[i]), _arr(st.phi[i]), _arr(st.u[i]))
+                        pend = None
+                    else:
+                        L = fuse(lambda a, pp, pq, u, T_=T: a + da.where_nonzero(u, pp - T_ * pq) * u,
+                                 L, _arr(phi_p[i]), _arr(st.phi[i]), _arr(st.u[i]))
+                    continue
+                settle()
                 t = fuse(lambda pp, pq, u, T_=T: da.where_nonzero(u, pp - T_ * pq) * u,
                          _arr(phi_p[i]), _arr(st.phi[i]), _arr(st.u[i]))
             L = fuse(lambda a, b: a + b, L, _sum_last(t, nd))
+        settle()
         return self._finish_bound(node, [(1.0, [L])], ignore_masked)
 
     def _shared_cov_bound(self, node, st, fam, phi_p, cgf, T, ignore_masked):
