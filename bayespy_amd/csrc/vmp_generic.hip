@@ -550,6 +550,15 @@ __device__ inline double ewise_program_impl(const EA &a, const int64_t *off, LD 
     for (int p = 0; p < nops; ++p) {
         const int word = UNI ? __builtin_amdgcn_readfirstlane(a.ops[p]) : a.ops[p];
         const int op = word & 0xff, arg = word >> 8;
+        if (UNI) {
+            // the interpreter of the queue: a word is dispatched by taken scalar branches; the frequent
+            // cheap words first (the compiler's balanced tree over 20 cases costs every word ~5 of them)
+            if (op == VMP_OP_IN) { PUSH(ld(arg, (int64_t)0)); continue; }
+            if (op == VMP_OP_CONST) { PUSH(a.consts[arg]); continue; }
+            if (op == VMP_OP_MUL) { BIN(x * y); continue; }
+            if (op == VMP_OP_ADD) { BIN(x + y); continue; }
+            if (op == VMP_OP_SUB) { BIN(x - y); continue; }
+        }
         switch (op) {
         case VMP_OP_IN:      PUSH(ld(arg, UNI ? (int64_t)0 : off[arg])); break;
         case VMP_OP_CONST:   PUSH(a.consts[arg]); break;
@@ -1484,7 +1493,8 @@ __device__ __forceinline__ void small_sum(CSmallOp *op, double *red, int tid, do
 // barrier and LDS latency instead of a dependent round trip through memory (2-3 us, which was also
 // what a node of a HIP graph costs: the reason the queue did not pay inside recorded sweeps).
 __global__ void __launch_bounds__(QNT)
-small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restrict__ pre, int npre)
+small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restrict__ pre, int npre,
+                 long long *__restrict__ prof)
 {
     extern __shared__ double qlds[];
     __shared__ double red[QNT / 64];
@@ -1507,7 +1517,10 @@ small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restr
         __syncthreads();
     }
     const double *words = reinterpret_cast<const double *>(ops);
+    // (measurement only, tune key small_queue_prof: cycles of lane 0 per stage of a record)
+    long long pc[4] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
+        const long long c0 = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (i % RC == 0) {
             const int cnt = (n - i < RC ? n - i : RC) * RW;
             for (int e = tid; e < cnt; e += QNT) recbuf[e] = words[(int64_t)i * RW + e];
@@ -1521,12 +1534,27 @@ small_ops_kernel(const SmallOp *__restrict__ ops, int n, const SmallPre *__restr
             __threadfence_block();
             __syncthreads();
         }
+        const long long c1 = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (kind == SMALL_EWISE) small_ewise(op, tid, qlds);
         else if (kind == SMALL_SPD) small_spd(op, M, &bad, tid);
         else small_sum(op, red, tid, qlds);
         // what this record wrote INTO THE ARENA is visible to the next one: LDS operations done,
         // then the barrier -- without waiting for the stores to memory (see above)
+        const long long c2 = prof ? (long long)__builtin_readcyclecounter() : 0;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (prof) {
+            const long long c3 = (long long)__builtin_readcyclecounter();
+            pc[0] += c1 - c0;
+            pc[1] += c2 - c1;
+            pc[2] += c3 - c2;
+            pc[3] += 1;
+        }
+    }
+    if (prof && tid == 0) {
+        prof[0] = pc[0];
+        prof[1] = pc[1];
+        prof[2] = pc[2];
+        prof[3] = pc[3];
     }
 }
 
@@ -1790,6 +1818,16 @@ int32_t vmp_queue_flush(vmp_ctx *ctx)
         }
     }
     const bool rec = stream_records(ctx);
+    if (rec && q->pre_arena_used + npre > ARENA_PRE) {
+        // no room left to keep this launch's table of copied-in arrays for the life of the graph:
+        // the launch reads everything from memory (correct, slower)
+        npre = 0;
+        for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < MAXIN; ++k) host[i].lin[k] = -1;
+            host[i].lout = -1;
+            host[i].fence = 1;
+        }
+    }
     if (rec) {
         // replayed with the graph: the records move into the arena (queue_slot made sure they
         // fit); vmp_queue_commit copies them to the device once, after the recording
@@ -1808,8 +1846,22 @@ int32_t vmp_queue_flush(vmp_ctx *ctx)
             VMP_HIP_CHECK(ctx, hipMemcpyAsync(pdev, phost, (size_t)npre * sizeof(SmallPre),
                                               hipMemcpyHostToDevice, ctx->stream));
     }
+    long long *prof = nullptr;
+    if (vmp_tune_get("small_queue_prof", 0) != 0 && !rec) {
+        static long long *prof_dev = nullptr;
+        if (!prof_dev) (void)hipMalloc(reinterpret_cast<void **>(&prof_dev), 8 * sizeof(long long));
+        prof = prof_dev;
+    }
     hipLaunchKernelGGL(small_ops_kernel, dim3(1), dim3(QNT), QLDS * sizeof(double), ctx->stream, dev, n,
-                       pdev, npre);
+                       pdev, npre, prof);
+    if (prof) {
+        long long h[4] = {0, 0, 0, 0};
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[vmp queue] %lld records: staging + dispatch %.0f, body %.0f, barrier %.0f cycles per record\n",
+                h[3], (double)h[0] / (double)(h[3] ? h[3] : 1), (double)h[1] / (double)(h[3] ? h[3] : 1),
+                (double)h[2] / (double)(h[3] ? h[3] : 1));
+    }
     VMP_HIP_CHECK(ctx, hipGetLastError());
     q->launches += 1;
     q->ops += n;
