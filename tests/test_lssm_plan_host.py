@@ -217,3 +217,57 @@ def test_reobserving_data_keeps_the_posteriors():
     np.testing.assert_allclose(res['lssm_L_c'], g['lssm_L_c'], rtol=1e-9)
     for key in ('lssm_X_u0', 'lssm_C_u0', 'lssm_A_u0'):
         np.testing.assert_allclose(res[key], g[key], rtol=1e-7, atol=1e-9, err_msg=key)
+
+
+WIDE = os.path.join(GOLDEN, 'lssm_wide_states.npz')
+
+
+@pytest.mark.parametrize('tag,B,gamma_nu', [('w8', 5, True), ('w12', 6, True), ('w16', 4, False)])
+def test_plan_reproduces_reference_trace_at_8_to_16_states(tag, B, gamma_nu):
+    """The host logic of the block does not depend on the number of states (round 6: D <= 16); the
+    live-reference traces of tests/golden/lssm_wide_states.npz through the plan and the kernel double."""
+    g = np.load(WIDE)
+    Q, track = _build(g[tag + '_y'], g[tag + '_x0'], g[tag + '_c0'], B, gamma_nu)
+    n = len(g[tag + '_L'])
+    Q.update(repeat=n, verbose=False)
+    np.testing.assert_allclose(Q.L[:n], g[tag + '_L'], rtol=1e-8)
+    for nm, nd in track.items():
+        for i, ui in enumerate(nd.u):
+            ref = g['%s_%s_u%d' % (tag, nm, i)]
+            np.testing.assert_allclose(np.broadcast_to(ui, ref.shape), ref, rtol=1e-6,
+                                       atol=1e-8 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg='%s u[%d]' % (nm, i))
+
+
+def _wide_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = np.load(WIDE)
+    tag, B = 'w12', 6
+    lo, hi = (0, 4) if rank == 0 else (4, 6)            # ragged shards of the sequence plate
+    y, x0 = g[tag + '_y'][:, lo:hi], g[tag + '_x0'][lo:hi]
+    Q, track = _build(np.ascontiguousarray(y), np.ascontiguousarray(x0), g[tag + '_c0'], hi - lo,
+                      True, shard=True)
+    n = len(g[tag + '_L'])
+    Q.update(repeat=n, verbose=False)
+    assert Q.plans[0].B_total == B
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), L=Q.L[:n], x=track['X'].u[0], lo=lo, hi=hi,
+             A=track['A'].u[0])
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_at_12_states_matches_unsharded_reference(tmp_path):
+    world = 2
+    mp.spawn(_wide_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = np.load(WIDE)
+    r = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % i)) for i in range(world)]
+    for ri in r:
+        np.testing.assert_allclose(ri['L'], g['w12_L'], rtol=1e-8)
+        np.testing.assert_allclose(ri['A'], g['w12_A_u0'], rtol=1e-6, atol=1e-8)
+        ref = g['w12_X_u0'][int(ri['lo']):int(ri['hi'])]
+        np.testing.assert_allclose(ri['x'], ref, rtol=1e-6, atol=1e-8 * float(np.abs(ref).max()))
+    assert np.array_equal(r[0]['L'], r[1]['L'])
