@@ -711,14 +711,17 @@ class PCAPlan:
         a few allocations of the tile-major Y and of X at set-up -- every pair, with the pass it
         is about to run anyway (same A, same Y: every trial writes the <x> of this update, bit
         for bit) -- and keeps the fastest pair; the others go back to the allocator.  Arrays
-        below 1 GB per pass, the CPU test double and BAYESPY_AMD_PLACEMENT_TRIES=1 skip it; with
+        below 0.2 GB per pass (BAYESPY_AMD_PLACEMENT_MIN_BYTES; 1 GB until round 6: BASELINE config 2,
+        0.64 GB, ran 0.148 ms per step as a leg of bench.py behind the headline's 40 GB and 0.126 with
+        the trial), the CPU test double and BAYESPY_AMD_PLACEMENT_TRIES=1 skip it; with
         little free memory fewer candidates are tried, an allocation that fails ends the list."""
         rt, k = self.rt, self.kernels
         torch = rt.torch
         N, D, K = self.N, self.D, self.K
         tries = int(os.environ.get('BAYESPY_AMD_PLACEMENT_TRIES', '4'))
         self.placement = None
-        if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < 1e9:
+        min_bytes = float(os.environ.get('BAYESPY_AMD_PLACEMENT_MIN_BYTES', 2e8))
+        if rt.device.type != 'cuda' or tries <= 1 or 8.0 * N * (D + K) < min_bytes:
             return
         set_bytes = 8 * (self.Yt.numel() + 2 * (self._Xt if self._Xt is not None else self.Xd).numel())
         free = torch.cuda.mem_get_info(rt.device)[0]
