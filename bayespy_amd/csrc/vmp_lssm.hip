@@ -938,7 +938,7 @@ lssm_forward_mfma_kernel(const double *__restrict__ H, int64_t B, int T, int64_t
                          double *__restrict__ Z, int t0, int t1)
 {
     const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    const int64_t b0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
     if (b0 >= B) return;
     const int64_t col = b0 + 2 * l15;
     const v2f64 zero2 = v2f64{0.0, 0.0};
@@ -1014,7 +1014,7 @@ lssm_forward_mfma_y_kernel(const double *__restrict__ Yt, int M, int64_t B, int 
                            double *__restrict__ Z, int t0, int t1)
 {
     const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    const int64_t b0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
     if (b0 >= B) return;
     const int64_t col = b0 + 2 * l15;
     const v2f64 zero2 = v2f64{0.0, 0.0};
@@ -1101,7 +1101,7 @@ lssm_backward_mfma_kernel(int64_t B, int T, int64_t BL, const double *__restrict
                           const double *__restrict__ J, double *__restrict__ Z)
 {
     const int l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    const int64_t b0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
     if (b0 >= B) return;
     const int64_t col = b0 + 2 * l15;
     const v2f64 zero2 = v2f64{0.0, 0.0};
@@ -1174,7 +1174,7 @@ lssm_backward_mfma_stats_kernel(int64_t B, int T, int64_t BL, const double *__re
     constexpr int LT = 17;
     __shared__ double Ts[4][2][16 * LT];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, l15 = l & 15, l4 = l >> 4;
-    const int64_t wv = (int64_t)blockIdx.x * 4 + w;
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
     const int64_t b0 = wv * 32;
     if (b0 >= B) return;
     const int64_t col = b0 + 2 * l15;
@@ -2652,7 +2652,13 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             // on the matrix cores (default) when the arrays allow 16-byte accesses per column pair
             const bool mf = vmp_tune_get("lssm_big_mfma", 1) != 0 && BL % 32 == 0 &&
                             ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(H)) & 15) == 0;
-            const int64_t gm = (B + 127) / 128;                 // four wavefronts of 32 sequences
+            // one wavefront of 32 sequences per workgroup (tune key lssm_sweep_waves: wavefronts per
+            // workgroup; four until round 6): a sweep's time is that of the busiest CU, and B = 1e5 as 782
+            // workgroups over 256 CUs is three on most and FOUR on some (+31 %), as 3125 it is 12 or 13
+            int swv = vmp_tune_get("lssm_sweep_waves", 1);
+            if (swv < 1 || swv > 4) swv = 1;
+            const unsigned sth = 64u * (unsigned)swv;
+            const int64_t gm = (B + 32 * swv - 1) / (32 * swv);
             // the projection inside the sweep when the observations fit four k-steps
             const bool fy = mf && M <= 16 && vmp_tune_get("lssm_fuse_project", 1) != 0 &&
                             (reinterpret_cast<uintptr_t>(Yt) & 15) == 0;
@@ -2677,15 +2683,15 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
             if (tb <= ta) continue;                                                              \
             if (fy && M <= 4)                                                                    \
                 hipLaunchKernelGGL((lssm_forward_mfma_y_kernel<d, 1>), dim3((unsigned)gm),       \
-                                   dim3(256), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
+                                   dim3(sth), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
             else if (fy && M <= 8)                                                               \
                 hipLaunchKernelGGL((lssm_forward_mfma_y_kernel<d, 2>), dim3((unsigned)gm),       \
-                                   dim3(256), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
+                                   dim3(sth), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
             else if (fy)                                                                         \
                 hipLaunchKernelGGL((lssm_forward_mfma_y_kernel<d, 4>), dim3((unsigned)gm),       \
-                                   dim3(256), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
+                                   dim3(sth), 0, sw, Yt, M, B, T, BL, Cm, tau, h0, J, Z, ta, tb); \
             else if (mf)                                                                         \
-                hipLaunchKernelGGL(lssm_forward_mfma_kernel<d>, dim3((unsigned)gm), dim3(256), 0, \
+                hipLaunchKernelGGL(lssm_forward_mfma_kernel<d>, dim3((unsigned)gm), dim3(sth), 0, \
                                    sw, H, B, T, BL, h0, J, Z, ta, tb);                           \
             else                                                                                 \
                 hipLaunchKernelGGL((lssm_forward_kernel<d, d, 0, true>), dim3((unsigned)g),      \
@@ -2693,10 +2699,10 @@ static int32_t smooth_impl(vmp_ctx *ctx, int32_t given, const double *Yt, int32_
                                    ta, tb);                                                      \
         }                                                                                        \
         if (fs)                                                                                  \
-            hipLaunchKernelGGL(lssm_backward_mfma_stats_kernel<d>, dim3((unsigned)gm), dim3(256), \
+            hipLaunchKernelGGL(lssm_backward_mfma_stats_kernel<d>, dim3((unsigned)gm), dim3(sth), \
                                0, sw, B, T, BL, Sinv, J, Z, Yt, M, part);                        \
         else if (mf)                                                                             \
-            hipLaunchKernelGGL(lssm_backward_mfma_kernel<d>, dim3((unsigned)gm), dim3(256), 0,   \
+            hipLaunchKernelGGL(lssm_backward_mfma_kernel<d>, dim3((unsigned)gm), dim3(sth), 0,   \
                                sw, B, T, BL, Sinv, J, Z);                                        \
         else                                                                                     \
             hipLaunchKernelGGL(lssm_backward_plain_kernel<d>, dim3((unsigned)g), dim3(SNT), 0,   \
