@@ -171,3 +171,20 @@ def test_queue_of_small_operations_agrees_with_its_opt_outs(mode, monkeypatch):
         assert np.array_equal(L1, L0) and np.array_equal(np.asarray(W1), np.asarray(W0))
     np.testing.assert_allclose(L1, L0, rtol=1e-12)
     np.testing.assert_allclose(W1, W0, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('knob', ['BAYESPY_AMD_PRIOR_CACHE', 'BAYESPY_AMD_BOUND_FOLD'])
+def test_record_reductions_do_not_change_a_bit(knob, monkeypatch):
+    """Round 6 removed records from a sweep without touching its arithmetic: the prior terms of a
+    node whose parents are constants are formed once instead of twice per sweep, and a scalar moment's
+    bound term joins the running sum in one formula (the interpreter executes the same operations in
+    the same order).  With either switched off the traces and moments are the same bits."""
+    def run():
+        Q = _pca(N=6000, D=20, K=5, seed=9)
+        Q.update(repeat=7, verbose=False)
+        return [Q.L[:7].copy()] + [np.asarray(m) for n in ('W', 'tau', 'alpha') for m in Q[n].get_moments()]
+    on = run()
+    monkeypatch.setenv(knob, '0')
+    off = run()
+    for a, b in zip(on, off):
+        assert np.array_equal(a, b)
