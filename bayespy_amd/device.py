@@ -243,6 +243,8 @@ class Runtime:
                 # stand-alone kernels) agrees to rounding.  BAYESPY_AMD_SMALL_QUEUE=ew: formulas only
                 self.set_tune('small_queue_sm',
                               0 if os.environ.get('BAYESPY_AMD_SMALL_QUEUE', '1') == 'ew' else 1)
+                # formulas of up to this many elements are records (the library's own default is 2048)
+                self.set_tune('small_queue_ew_max', int(os.environ.get('BAYESPY_AMD_QUEUE_EW_MAX', 2048)))
             self.check(self.lib.vmp_queue_begin(self.ctx))
 
     def queue_end(self):
@@ -282,12 +284,13 @@ class Runtime:
         outs = out if isinstance(out, (tuple, list)) else (out,)
         for o in outs:
             t = getattr(o, 't', o)
-            if hasattr(t, 'numel') and t.numel() > 2048:
+            if hasattr(t, 'numel') and t.numel() > self._queue_max_out:
                 return
         self._queue_alive.append((arrays, out))
 
     _tune_sm = False
     _tune_ew = True
+    _queue_max_out = 2048        # elements of a result the library may have queued (its tune small_queue_ew_max)
 
     # which device arrays the kernels of a sweep recording READ (graph_iter.py: an input of the
     # recorded graph that no launch reads needs no copy-back before a replay); None = not logging
@@ -309,6 +312,8 @@ class Runtime:
                 self._tune_sm = bool(value)
             elif key == 'small_queue_ew':
                 self._tune_ew = bool(value)
+            elif key == 'small_queue_ew_max':
+                self._queue_max_out = max(2048, int(value))
 
     def queue_stats(self):
         if self.ctx is None or self.lib is None:
